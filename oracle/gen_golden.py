@@ -1,0 +1,225 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by running the REAL reference.
+
+Runs only in the build container (needs /root/reference; CPU).  The reference never travels:
+what is committed is data only -- inputs (X, y, per-call x and adjacency exactly as the
+reference's own utils/graph.py produced them, parameters) and outputs (scores, logits, h_out,
+attention at the incident positions, parameter / input gradients, BatchNorm buffers).
+
+    PYTHONDONTWRITEBYTECODE=1 python oracle/gen_golden.py [--reference-path /root/reference]
+
+Each fixture is one rolling sequence that reproduces the reference call pattern
+(train.py:65-68,92-107,132-135): initialize_graph -> forward(h_in=None, dense adjacency),
+then per timestep update_graph(mode='train') -> forward(sparse adjacency), then one extra
+forward with an empty x, then ONE backward of a seeded linear functional of all outputs.
+"""
+import argparse
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+from oracle.trackmpnn_oracle import graph_from_adjacency  # noqa: E402
+
+
+def synth_sequence(seed, T, dmean, ncat, feats, fp_rate=0.15, miss=0.2):
+    """Seeded synthetic detections: X [1, ND, F], y [1, ND, 2] = [ts, track_id] (-1 = false positive)."""
+    rng = np.random.RandomState(seed)
+    ntracks = max(2, int(dmean) + 1)
+    rows = []
+    for t in range(T):
+        ids = [i for i in range(ntracks) if rng.rand() > miss]
+        if len(ids) == 0:
+            ids = [int(rng.randint(ntracks))]
+        nfp = int(rng.rand() < fp_rate * 2) + int(rng.rand() < fp_rate)
+        ids = ids + [-1] * nfp
+        rng.shuffle(ids)
+        rows += [(t, i) for i in ids]
+    y = torch.tensor(rows, dtype=torch.int64)[None]
+    F = 0
+    if '2d' in feats:
+        F += ncat + 5
+    if 'temp' in feats:
+        F += 2
+    if 'vis' in feats:
+        F += 128
+    g = torch.Generator().manual_seed(seed + 1000)
+    X = torch.randn(1, y.shape[1], F, generator=g)
+    return X, y
+
+
+def adj_arrays(adj):
+    if adj.is_sparse:
+        return adj._indices().numpy().copy(), adj._values().numpy().copy(), 0
+    nz = torch.nonzero(adj)
+    return nz.t().numpy().copy(), adj[nz[:, 0], nz[:, 1]].numpy().copy(), 1
+
+
+def run_fixture(name, out_dir, features, ncat, H, K, msg, mode, seed, T=4, dmean=3, static_iters=0):
+    from models.track_mpnn import TrackMPNN
+    from utils.graph import initialize_graph, update_graph
+
+    torch.manual_seed(5)
+    model = TrackMPNN(features, ncat, H, K, msg)
+    gp = torch.Generator().manual_seed(seed + 77)
+    with torch.no_grad():
+        for _, prm in model.named_parameters():
+            prm.add_(0.3 * torch.randn(prm.shape, generator=gp))
+        for k, b in model.named_buffers():
+            if k.endswith('running_mean'):
+                b.copy_(0.2 * torch.randn(b.shape, generator=gp))
+            elif k.endswith('running_var'):
+                b.copy_(0.5 + torch.rand(b.shape, generator=gp))
+    model.train() if mode == 'train' else model.eval()
+    out = {}
+    for k, v in model.state_dict().items():
+        out['param/' + k] = v.detach().numpy().copy()
+
+    X, y = synth_sequence(seed, T, dmean, ncat, features)
+    X.requires_grad_(True)
+    out['X'] = X.detach().numpy().copy()
+    out['y'] = y.numpy().copy()
+
+    y_pred, feats, node_adj, edge_adj, labels, t_st, t_end = initialize_graph(X, y, 0, 'train', cuda=False)
+    calls = [(feats, node_adj, edge_adj)]
+    # graphs depend only on GT in train mode, so they can be built before any forward
+    scores_dummy = torch.zeros(node_adj.shape[0], 1)
+    for t in range(t_st, t_end):
+        y_pred, feats, node_adj, edge_adj, labels = update_graph(
+            node_adj, labels, scores_dummy, y_pred, X, y, t, mode='train', cuda=False)
+        scores_dummy = torch.zeros(node_adj.shape[0], 1)
+        calls.append((feats, node_adj, edge_adj))
+    if static_iters > 0:
+        # static mode: only the final graph; x = every row, then empty-x iterations
+        allx = torch.cat([c[0] for c in calls], 0)
+        calls = [(allx, node_adj, edge_adj)] + [(allx[:0], node_adj, edge_adj)] * (static_iters - 1)
+    else:
+        calls.append((feats[:0], node_adj, edge_adj))   # extra MP iteration with empty x
+
+    gw = torch.Generator().manual_seed(seed + 99)
+    loss = 0.0
+    h = None
+    G = len(model.feature_idx)
+    for c, (x, na, ea) in enumerate(calls):
+        scores, logits, h, att = model(x, h, na, ea)
+        N = logits.shape[0]
+        graph = graph_from_adjacency(na, ea)
+        wl = torch.randn(N, 1, generator=gw)
+        ws = torch.randn(N, 1, generator=gw)
+        loss = loss + (wl * logits).sum() + (ws * scores).sum()
+        pre = f'c{c}/'
+        out[pre + 'x'] = x.detach().numpy().copy()
+        for nm, a in (('node_adj', na), ('edge_adj', ea)):
+            idx, val, dense = adj_arrays(a.detach())
+            out[pre + nm + '_idx'] = idx.astype(np.int64)
+            out[pre + nm + '_val'] = val.astype(np.float32)
+            out[pre + nm + '_dense'] = np.int64(dense)
+        out[pre + 'N'] = np.int64(N)
+        out[pre + 'wl'] = wl.numpy().copy()
+        out[pre + 'ws'] = ws.numpy().copy()
+        if static_iters == 0 or c == len(calls) - 1:
+            out[pre + 'h_out'] = h.detach().numpy().copy()
+        out[pre + 'scores'] = scores.detach().numpy().copy()
+        out[pre + 'logits'] = logits.detach().numpy().copy()
+        if K > 0:
+            er = torch.from_numpy(graph.edge_row)
+            s_, d_ = torch.from_numpy(graph.src), torch.from_numpy(graph.dst)
+            for g in range(G):
+                keeps = []
+                for k in range(K):
+                    a = att[g][k].detach()
+                    vals = torch.stack([a[s_, er], a[d_, er]], 1)
+                    out[pre + f'att_g{g}_k{k}'] = vals.numpy().copy()
+                    keeps.append((vals != 0).to(torch.uint8))
+                    if mode != 'train':
+                        # edge rows are the uniform 1/N of an all-masked softmax (layers.py:35-36)
+                        assert torch.allclose(a[er], torch.full_like(a[er], 1.0 / N))
+                        # nothing outside the incident positions on det rows
+                        dense = torch.zeros_like(a)
+                        dense[s_, er] = vals[:, 0]
+                        dense[d_, er] = vals[:, 1]
+                        dr = torch.from_numpy(graph.det_row)
+                        has_inc = torch.zeros(N, dtype=torch.bool)
+                        has_inc[s_] = True
+                        has_inc[d_] = True
+                        rows = dr[has_inc[dr]]
+                        assert torch.allclose(a[rows], dense[rows], atol=1e-7)
+                if mode == 'train':
+                    out[pre + f'keep_g{g}'] = torch.stack(keeps, 0).numpy().copy()
+    V = torch.randn(h.shape, generator=gw)
+    loss = loss + (V * h).sum()
+    out['V'] = V.numpy().copy()
+    loss.backward()
+    for k, prm in model.named_parameters():
+        out['grad/' + k] = prm.grad.detach().numpy().copy()
+    out['grad/X'] = X.grad.detach().numpy().copy()
+    out['loss'] = np.float64(loss.item())
+    for k, b in model.named_buffers():
+        out['final/' + k] = b.detach().numpy().copy()
+    meta = dict(name=name, features=features, ncategories=ncat, nhidden=H, nattheads=K, msg_type=msg,
+                mode=mode, ncalls=len(calls), seed=seed, T=T, static_iters=static_iters,
+                torch=torch.__version__, reference='arangesh/TrackMPNN @ /root/reference')
+    out['meta'] = np.array(json.dumps(meta))
+    path = os.path.join(out_dir, name + '.npz')
+    np.savez_compressed(path, **out)
+    print(f'{name}: calls={len(calls)} N_final={h.shape[0]} loss={loss.item():.6f} '
+          f'-> {os.path.getsize(path) / 1024:.0f} KiB')
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--reference-path', default='/root/reference')
+    ap.add_argument('--out', default=os.path.join(os.path.dirname(HERE), 'tests', 'golden'))
+    args = ap.parse_args()
+    sys.dont_write_bytecode = True
+    sys.path.insert(0, args.reference_path)
+    os.makedirs(args.out, exist_ok=True)
+    torch.set_num_threads(1)
+    seed = 0
+    for feats, ncat in (('2d', 3), ('2d+temp+vis', 3)):
+        for msg in ('diff', 'concat'):
+            for K in (0, 2):
+                for mode in ('train', 'eval'):
+                    # H=64 (the headline width) where it is cheap to store, H=32 elsewhere
+                    H = 64 if (feats == '2d' and K == 0 and mode == 'train') else 32
+                    if feats != '2d' and (msg, K, mode) not in (('diff', 0, 'train'), ('diff', 2, 'eval'),
+                                                                ('concat', 2, 'train'), ('concat', 0, 'eval')):
+                        seed += 1
+                        continue    # three-group fixtures are bulky; keep one per factor level
+                    fname = f"roll_{feats.replace('+', '-')}_{msg}_k{K}_{mode}"
+                    run_fixture(fname, args.out, feats, ncat, H, K, msg, mode, seed)
+                    seed += 1
+    # BDD-shaped input width (ncat=8 -> F=13), one rolling train fixture
+    run_fixture('roll_bdd_diff_k0_train', args.out, '2d', 8, 64, 0, 'diff', 'train', 100, T=5, dmean=4)
+    # C1 of BASELINE.json: static 5-frame window, 20 dets/frame, 64-d, 2 MP iterations
+    run_c1(args.out)
+
+
+def run_c1(out_dir):
+    """C1: every frame a random permutation of ids 0..D-1 (all TPs), X ~ N(0,1) seed 0."""
+    T, D = 5, 20
+
+    def c1_seq(seed, T_, dmean, ncat, feats, **kw):
+        g = torch.Generator().manual_seed(0)
+        X = torch.randn(1, T * D, ncat + 5, generator=g)
+        y = torch.zeros(1, T * D, 2, dtype=torch.int64)
+        for t in range(T):
+            y[0, t * D:(t + 1) * D, 0] = t
+            y[0, t * D:(t + 1) * D, 1] = torch.randperm(D, generator=g)
+        return X, y
+
+    global synth_sequence
+    keep = synth_sequence
+    synth_sequence = c1_seq
+    try:
+        run_fixture('c1_static_diff_k0_train', out_dir, '2d', 3, 64, 0, 'diff', 'train', 200, T=T, static_iters=2)
+    finally:
+        synth_sequence = keep
+
+
+if __name__ == '__main__':
+    main()
