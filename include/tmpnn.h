@@ -1,0 +1,200 @@
+/*
+ * tmpnn.h -- C ABI of libtmpnn.so: the MI355X (gfx950) implementation of the TrackMPNN
+ * message-passing hot path.
+ *
+ * Every entry point replaces one stage of the reference's per-timestep forward/backward
+ * (reference = arangesh/TrackMPNN; file:line cited at each declaration).  The reference has no
+ * FFI of its own (it is pure Python on torch ops); the stages below are exactly the ATen calls
+ * `TrackMPNN.forward` (models/track_mpnn.py:54-75) and `FactorGraphGRU.forward`
+ * (models/layers.py:84-116) dispatch, regrouped by what they compute.
+ *
+ * Conventions
+ *   - all feature tensors are fp32, row-major, with an explicit leading dimension (`ld*`, in
+ *     floats) so one [N, G*H] state tensor can be addressed per feature group without repacking;
+ *   - all index arrays are int32 and live in device memory;
+ *   - the caller owns every buffer (including workspaces); the library never allocates, frees,
+ *     or keeps a device pointer past the call;
+ *   - work is only ENQUEUED on `stream`; nothing synchronises the device;
+ *   - return value: TMPNN_OK (0) or a negative TMPNN_E* code; `tmpnn_last_error()` gives the
+ *     thread-local message of the last failure.  Nothing is ever thrown across the boundary.
+ *   - supported hidden widths: H in {32, 64, 128, 256}.
+ */
+#ifndef TMPNN_H
+#define TMPNN_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TMPNN_ABI_VERSION 1
+
+#define TMPNN_OK 0
+#define TMPNN_EINVAL (-1)   /* bad shape / null pointer / unsupported width */
+#define TMPNN_ELAUNCH (-2)  /* hipGetLastError() after a launch */
+#define TMPNN_EWORKSPACE (-3) /* workspace too small */
+
+typedef void* tmpnn_stream; /* hipStream_t */
+
+/*
+ * Index form of the reference's adjacency pair (utils/graph.py:151-163, 294-308): every edge
+ * row e of node_adj holds +1 at its earlier det (`src`) and -1 at its later det (`dst`);
+ * edge_adj is its transpose, i.e. the det -> incident-edge lists, stored here as a CSR whose
+ * entries are edge ROW indices with the sign of edge_adj[d, e] in bit 31 (set = -1 = d is the
+ * later det of e).  Built once per call by the host from the adjacency the reference passes.
+ */
+typedef struct tmpnn_graph {
+    int32_t N;               /* rows of the state tensor (dets + edges) */
+    int32_t E;               /* edge rows */
+    int32_t Dn;              /* det rows */
+    const int32_t* src;      /* [E]  row of the +1 det of edge e */
+    const int32_t* dst;      /* [E]  row of the -1 det of edge e */
+    const int32_t* edge_row; /* [E]  row of edge e (ascending) */
+    const int32_t* det_row;  /* [Dn] row of det d (ascending) */
+    const int32_t* rowptr;   /* [Dn+1] CSR offsets into inc */
+    const int32_t* inc;      /* [2E] (edge row) | (sign bit: 0x80000000 when d == dst) */
+} tmpnn_graph;
+
+int tmpnn_abi_version(void);
+const char* tmpnn_last_error(void);
+
+/* ---- row E: node -> edge message (models/layers.py:90-95) -------------------------------
+ * diff  : out[edge_row[e], 0:H]  (=|+=)  in[src[e], 0:H] - in[dst[e], 0:H]
+ * concat: out[edge_row[e], 0:2H] (=|+=) [in[src[e], 0:H] | in[dst[e], 0:H]]
+ * `accumulate` != 0 adds into out.  The backward of either is tmpnn_segsum_fwd on the gradient
+ * (diff: signs +1/-1, concat: column offsets 0/H), exposed as tmpnn_gather_*_bwd. */
+int tmpnn_gather_diff_fwd(const tmpnn_graph* g, const float* in, int ld_in, float* out, int ld_out,
+                          int H, int accumulate, tmpnn_stream stream);
+int tmpnn_gather_concat_fwd(const tmpnn_graph* g, const float* in, int ld_in, float* out, int ld_out,
+                            int H, int accumulate, tmpnn_stream stream);
+/* d_in[det_row[d], 0:H] (=|+=) sum_{e: src=d} d_out[row e, 0:H] - sum_{e: dst=d} d_out[row e, 0:H] */
+int tmpnn_gather_diff_bwd(const tmpnn_graph* g, const float* d_out, int ld_dout, float* d_in, int ld_din,
+                          int H, int accumulate, tmpnn_stream stream);
+/* d_in[det_row[d], 0:H] (=|+=) sum_{e: src=d} d_out[row e, 0:H] + sum_{e: dst=d} d_out[row e, H:2H] */
+int tmpnn_gather_concat_bwd(const tmpnn_graph* g, const float* d_out, int ld_dout, float* d_in, int ld_din,
+                            int H, int accumulate, tmpnn_stream stream);
+
+/* ---- row F: edge -> node signed aggregation, no attention (models/layers.py:103) --------
+ * out[det_row[d], 0:H] (=|+=) sum_{e: src=d} in[row e] - sum_{e: dst=d} in[row e]
+ * backward: d_in[edge_row[e]] (=|+=) d_out[src[e]] - d_out[dst[e]]  (= tmpnn_gather_diff_fwd). */
+int tmpnn_segsum_fwd(const tmpnn_graph* g, const float* in, int ld_in, float* out, int ld_out,
+                     int H, int accumulate, int compact_out /* out row = d instead of det_row[d] */,
+                     tmpnn_stream stream);
+int tmpnn_segsum_bwd(const tmpnn_graph* g, const float* d_out, int ld_dout, float* d_in, int ld_din,
+                     int H, int accumulate, tmpnn_stream stream);
+
+/* ---- row G: attention-weighted aggregation (models/layers.py:26-43, 105-112) -------------
+ * K heads (1..8); W_att [K][H][H] (in x out, as stored by the reference), a [K][H].
+ *   ha    = h[det rows] @ W_k                       (ws_ha [K][Dn][H])
+ *   s_e   = LeakyReLU_0.2(|ha[src]-ha[dst]| . a_k)  (score [K][N], written at edge rows)
+ *   alpha = softmax over each det's incident edges  (alpha [K][2E], CSR order, AFTER dropout)
+ *   out[d, 0:H] = 1/K sum_k sum_p sign_p * alpha_kp * h[inc row p]     (COMPACT rows: d, not det_row[d])
+ * keep: NULL (eval / no dropout) or uint8 [K][2E] in CSR order (kept entries scaled 1/(1-p_drop)).
+ * pos [N]: row -> index of the row within its type (det index for det rows, edge index e for
+ * edge rows). */
+int tmpnn_att_fwd(const tmpnn_graph* g, const int32_t* pos, const float* h, int ld_h, int H, int K,
+                  const float* W_att, const float* a, const uint8_t* keep, float p_drop,
+                  float* ws_ha, float* score, float* alpha, float* out, int ld_out, tmpnn_stream stream);
+/* Backward of tmpnn_att_fwd.  d_out [N rows, ld_dout] is read at det rows (row-indexed).
+ * Accumulates: d_h (+=, edge rows through the values, det rows through ha), dW_att [K][H][H] (+=),
+ * da [K][H] (+=).  Workspaces (fp32): ws [tmpnn_att_bwd_ws(E, Dn, H, K) floats],
+ * ws_dha [K][Dn][H], ws_edge [K][N]. */
+size_t tmpnn_att_bwd_ws(int E, int Dn, int H, int K);
+int tmpnn_att_bwd(const tmpnn_graph* g, const int32_t* pos, const float* h, int ld_h, int H, int K,
+                  const float* W_att, const float* a, const uint8_t* keep, float p_drop,
+                  const float* ws_ha, const float* score, const float* alpha,
+                  const float* d_out, int ld_dout,
+                  float* ws, size_t ws_floats, float* ws_dha, float* ws_edge,
+                  float* d_h, int ld_dh, float* dW_att, float* da, tmpnn_stream stream);
+
+/* ---- rows H', I: GRU cells with row indirection + type-masked merge ----------------------
+ * (torch.nn.GRUCell as used at models/layers.py:97,114; merge layers.py:116).
+ * For every r < R with row = rows[r]:
+ *     x      = xmode 0: msg[msg_compact ? r : row, 0:IN]
+ *              xmode 1: h[src[r]] - h[dst[r]]          (fused row E, diff;   IN = H)
+ *              xmode 2: [h[src[r]] | h[dst[r]]]        (fused row E, concat; IN = 2H)
+ *     h_out[row] = GRUCell(x, h[row])
+ * so running it once with rows = edge_row and once with rows = det_row performs the merge in
+ * place.  Weights are passed TRANSPOSED (wih_t [IN][3H], whh_t [H][3H], see tmpnn_transpose);
+ * gate order r,z,n.  gates: NULL or 4 planes [4][gate_plane] of row-indexed [N][H] floats
+ * (r, z, n, W_hn h + b_hn) saved for the backward. */
+int tmpnn_gru_fwd(const int32_t* rows, int R, int xmode, const int32_t* src, const int32_t* dst,
+                  const float* msg, int ld_msg, int msg_compact, int IN, const float* h, int ld_h, int H,
+                  const float* wih_t, const float* whh_t, const float* b_ih, const float* b_hh,
+                  float* h_out, int ld_out, float* gates, size_t gate_plane, tmpnn_stream stream);
+/* Data gradient: d_msg[row, 0:IN] = d_gi @ W_ih ; d_h[row] = d_hout[row]*z + d_gh @ W_hh
+ * (both written, not accumulated).  W_ih [3H][IN], W_hh [3H][H] in the reference layout. */
+int tmpnn_gru_bwd_data(const int32_t* rows, int R, int IN, const float* h, int ld_h, int H,
+                       const float* w_ih, const float* w_hh,
+                       const float* gates, size_t gate_plane, const float* d_hout, int ld_dhout,
+                       float* d_msg, int ld_dmsg, float* d_h, int ld_dh, tmpnn_stream stream);
+/* Weight gradient: dW_ih [3H][IN], dW_hh [3H][H], db_ih [3H], db_hh [3H] are ACCUMULATED (+=).
+ * x is re-formed as in tmpnn_gru_fwd (xmode).  ws: tmpnn_gru_bwd_weights_ws(R, IN, H) bytes. */
+size_t tmpnn_gru_bwd_weights_ws(int R, int IN, int H);
+int tmpnn_gru_bwd_weights(const int32_t* rows, int R, int xmode, const int32_t* src, const int32_t* dst,
+                          const float* msg, int ld_msg, int msg_compact, int IN,
+                          const float* h, int ld_h, int H,
+                          const float* gates, size_t gate_plane, const float* d_hout, int ld_dhout,
+                          float* dW_ih, float* dW_hh, float* db_ih, float* db_hh,
+                          void* ws, size_t ws_bytes, tmpnn_stream stream);
+
+/* out [cols][rows] = in[rows][cols]^T (weight re-layout for tmpnn_gru_fwd) */
+int tmpnn_transpose(const float* in, int rows, int cols, float* out, tmpnn_stream stream);
+
+/* ---- rows C, D: input transform on the NEW rows (models/track_mpnn.py:45-52, 59-61) -------
+ * Lin1 -> BatchNorm1d -> ReLU -> Lin2, evaluated only on the nd new det rows (the new edge
+ * rows are all-zero inputs: they enter the BatchNorm statistics as `b1` and are masked to zero
+ * afterwards, track_mpnn.py:61).  Statistics are per segment (= per window of a block-diagonal
+ * batch; one segment reproduces the reference):
+ *   xdet [nd][ld_x] gathered det-row features (group columns start at xdet), F inputs
+ *   seg_ptr [S+1] det rows of segment s are [seg_ptr[s], seg_ptr[s+1]); seg_cnt [S] = ALL new
+ *   rows of the segment (dets + zero rows)
+ *   training: batch stats (biased var, eps 1e-5) written to mean/rstd [S][H] and running stats
+ *   updated sequentially over segments with momentum 0.1 (unbiased var); else running stats.
+ *   y_save [nd][H] = Lin1 output (saved for backward); out rows written to
+ *   h_new[out_row[i], 0:H] (ld_h). */
+int tmpnn_input_bn_fwd(const float* xdet, int ld_x, int F, int nd, const int32_t* seg_ptr,
+                       const int32_t* seg_cnt, int S, int H, int training,
+                       const float* w1, const float* b1, const float* gamma, const float* beta,
+                       float* running_mean, float* running_var,
+                       const float* w2, const float* b2,
+                       float* y_save, float* mean, float* rstd, float* ws_a /* [nd][H] scratch */,
+                       const int32_t* out_row, float* h_new, int ld_h, tmpnn_stream stream);
+/* Backward.  d_h rows are read at out_row; mean/rstd/y_save are the forward's outputs (eval
+ * mode: one row holding the running statistics).  Accumulates (+=) dw1 [H][F], db1, dgamma,
+ * dbeta, dw2 [H][H], db2; writes d_xdet [nd][ld_dx] (may be NULL) and d_xzero [S][F] (may be
+ * NULL): the gradient every all-zero row of segment s receives through the batch statistics
+ * (0 in eval mode).  ws: tmpnn_input_bn_bwd_ws(nd, S, H, F) floats. */
+size_t tmpnn_input_bn_bwd_ws(int nd, int S, int H, int F);
+int tmpnn_input_bn_bwd(const float* xdet, int ld_x, int F, int nd, const int32_t* seg_ptr,
+                       const int32_t* seg_cnt, int S, int H, int training,
+                       const float* w1, const float* b1, const float* gamma, const float* beta,
+                       const float* w2,
+                       const float* y_save, const float* mean, const float* rstd,
+                       const int32_t* out_row, const float* d_h, int ld_dh,
+                       float* d_xdet, int ld_dx, float* d_xzero,
+                       float* dw1, float* db1, float* dgamma, float* dbeta, float* dw2, float* db2,
+                       float* ws, size_t ws_floats, tmpnn_stream stream);
+
+/* ---- row J: masked output heads + sigmoid (models/track_mpnn.py:72-75) -------------------
+ * logits[i] = is_edge[i] ? w_e . h[i] + b_e : w_n . h[i] + b_n ; scores = sigmoid(logits).
+ * h [N][ld_h], C = G*H columns. */
+int tmpnn_heads_fwd(const float* h, int ld_h, int C, int N, const uint8_t* is_edge,
+                    const float* w_node, const float* b_node, const float* w_edge, const float* b_edge,
+                    float* logits, float* scores, tmpnn_stream stream);
+/* d_y = d_logits + d_scores * s(1-s) (either may be NULL); d_h[i] (=|+=) d_y[i] * w_type(i);
+ * dw_node/dw_edge [C], db_node/db_edge [1] accumulated (+=).  ws: tmpnn_heads_bwd_ws(N, C). */
+size_t tmpnn_heads_bwd_ws(int N, int C);
+int tmpnn_heads_bwd(const float* h, int ld_h, int C, int N, const uint8_t* is_edge,
+                    const float* w_node, const float* w_edge, const float* scores,
+                    const float* d_logits, const float* d_scores,
+                    float* d_h, int ld_dh, int accumulate,
+                    float* dw_node, float* db_node, float* dw_edge, float* db_edge,
+                    void* ws, size_t ws_bytes, tmpnn_stream stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TMPNN_H */

@@ -1,0 +1,395 @@
+"""Per-stage checks of the C ABI against torch-CPU / oracle formulas (used by test_parity_gpu.py and
+runnable as a script on the GPU box: prints one line per stage instead of stopping at the first error)."""
+import ctypes
+import sys
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from oracle import trackmpnn_oracle as orc
+from trackmpnn_amd import WindowBuilder, _lib, batch_windows, synth_window
+
+DEV = 'cuda:0'
+
+
+def make_graph(B=6, frames=5, mean=4, seed=0):
+    wins = [WindowBuilder(synth_window(seed + s, frames, mean, 10)).calls() for s in range(B)]
+    plans, _ = batch_windows(wins, static=True)
+    return plans[-1].graph
+
+
+def st():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def idx(t):
+    return t.long().cpu()
+
+
+def check_gather(H, concat, acc, g, gd):
+    IN = 2 * H if concat else H
+    h = torch.randn(g.N, H + 32)      # ld > H on purpose
+    out0 = torch.randn(g.N, IN + 4)
+    exp = out0.clone()
+    hs, hd = h[idx(g.src), :H], h[idx(g.dst), :H]
+    val = torch.cat([hs, hd], 1) if concat else hs - hd
+    er = idx(g.edge_row)
+    exp[er, :IN] = (exp[er, :IN] + val) if acc else val
+    hd_, od = h.to(DEV), out0.to(DEV)
+    _lib.call('tmpnn_gather_concat_fwd' if concat else 'tmpnn_gather_diff_fwd', gd.cref(), hd_.data_ptr(), h.shape[1],
+              od.data_ptr(), out0.shape[1], H, int(acc), st())
+    return (od.cpu() - exp).abs().max().item()
+
+
+def check_segsum(H, mode, acc, compact, g, gd):
+    # mode: 'fwd' (row F), 'gdiff_bwd', 'gconcat_bwd'
+    W = 2 * H if mode == 'gconcat_bwd' else H
+    x = torch.randn(g.N, W + 4)
+    rows_out = g.Dn if compact else g.N
+    out0 = torch.randn(rows_out, H + 8)
+    exp = out0.clone()
+    er, s, d, dr = idx(g.edge_row), idx(g.src), idx(g.dst), idx(g.det_row)
+    full = torch.zeros(g.N, H)
+    if mode == 'gconcat_bwd':
+        full.index_add_(0, s, x[er, :H])
+        full.index_add_(0, d, x[er, H:2 * H])
+    else:
+        full.index_add_(0, s, x[er, :H])
+        full.index_add_(0, d, -x[er, :H])
+    tgt = torch.arange(g.Dn) if compact else dr
+    exp[tgt, :H] = (exp[tgt, :H] + full[dr]) if acc else full[dr]
+    xd, od = x.to(DEV), out0.to(DEV)
+    if mode == 'fwd':
+        _lib.call('tmpnn_segsum_fwd', gd.cref(), xd.data_ptr(), x.shape[1], od.data_ptr(), out0.shape[1], H, int(acc),
+                  int(compact), st())
+    else:
+        name = 'tmpnn_gather_concat_bwd' if mode == 'gconcat_bwd' else 'tmpnn_gather_diff_bwd'
+        _lib.call(name, gd.cref(), xd.data_ptr(), x.shape[1], od.data_ptr(), out0.shape[1], H, int(acc), st())
+    return (od.cpu() - exp).abs().max().item()
+
+
+def gru_ref(x, h, wih, whh, bih, bhh):
+    gi = F.linear(x, wih, bih)
+    gh = F.linear(h, whh, bhh)
+    i_r, i_z, i_n = gi.chunk(3, 1)
+    h_r, h_z, h_n = gh.chunk(3, 1)
+    r = torch.sigmoid(i_r + h_r)
+    z = torch.sigmoid(i_z + h_z)
+    n = torch.tanh(i_n + r * h_n)
+    return (1 - z) * n + z * h, (r, z, n, h_n + 0)
+
+
+def check_gru(H, xmode, g, gd, rows_kind='edge'):
+    """fwd + bwd_data + bwd_weights of one cell; returns dict of max errors."""
+    torch.manual_seed(H + xmode)
+    G = 2                                  # exercise the group stride
+    ld = G * H
+    hfull = torch.randn(g.N, ld)
+    h = hfull[:, H:2 * H]
+    if rows_kind == 'edge':
+        rows = idx(g.edge_row)
+        src, dst = idx(g.src), idx(g.dst)
+    else:
+        rows = idx(g.det_row)
+        src = dst = None
+    R = rows.numel()
+    IN = 2 * H if xmode == 2 else H
+    msg = torch.randn(R, IN)               # compact messages (xmode 0)
+    if xmode == 1:
+        x = h[src] - h[dst]
+    elif xmode == 2:
+        x = torch.cat([h[src], h[dst]], 1)
+    else:
+        x = msg
+    x = x.clone().requires_grad_(True)
+    hrow = h[rows].clone().requires_grad_(True)
+    wih = (0.3 * torch.randn(3 * H, IN)).requires_grad_(True)
+    whh = (0.3 * torch.randn(3 * H, H)).requires_grad_(True)
+    bih = (0.3 * torch.randn(3 * H)).requires_grad_(True)
+    bhh = (0.3 * torch.randn(3 * H)).requires_grad_(True)
+    out, (r, z, n, hn) = gru_ref(x, hrow, wih, whh, bih, bhh)
+    dout = torch.randn(R, H)
+    out.backward(dout)
+
+    d = lambda t: t.detach().to(DEV).contiguous()
+    hD = d(hfull)
+    outD = torch.zeros(g.N, ld, device=DEV)
+    gates = torch.zeros(4, g.N, H, device=DEV)
+    rowsD = rows.to(torch.int32).to(DEV)
+    wih_t, whh_t = d(wih.t()), d(whh.t())
+    msgD = d(msg)
+    bihD, bhhD = d(bih), d(bhh)
+    _lib.call('tmpnn_gru_fwd', rowsD.data_ptr(), R, xmode, gd.src.data_ptr() if xmode else None,
+              gd.dst.data_ptr() if xmode else None, msgD.data_ptr() if xmode == 0 else None, IN, 1, IN,
+              hD.data_ptr() + 4 * H, ld, H, wih_t.data_ptr(), whh_t.data_ptr(), bihD.data_ptr(), bhhD.data_ptr(),
+              outD.data_ptr() + 4 * H, ld, gates.data_ptr(), g.N * H, st())
+    res = {}
+    res['fwd'] = (outD.cpu()[rows, H:2 * H] - out.detach()).abs().max().item()
+    gc = gates.cpu()
+    res['gates'] = max((gc[i][rows] - t.detach()).abs().max().item() for i, t in enumerate((r, z, n, hn)))
+    other = torch.ones(g.N, dtype=torch.bool)
+    other[rows] = False
+    res['untouched'] = outD.cpu()[other].abs().max().item() if other.any() else 0.0
+    res['untouched'] = max(res['untouched'], outD.cpu()[:, :H].abs().max().item())
+
+    # backward, data
+    doutfull = torch.zeros(g.N, ld)
+    doutfull[rows, H:2 * H] = dout
+    doutD = d(doutfull)
+    dmsg = torch.zeros(g.N, IN + 4, device=DEV)
+    dh = torch.zeros(g.N, ld, device=DEV)
+    wihD, whhD = d(wih), d(whh)
+    _lib.call('tmpnn_gru_bwd_data', rowsD.data_ptr(), R, IN, hD.data_ptr() + 4 * H, ld, H, wihD.data_ptr(),
+              whhD.data_ptr(), gates.data_ptr(), g.N * H, doutD.data_ptr() + 4 * H, ld, dmsg.data_ptr(), IN + 4,
+              dh.data_ptr() + 4 * H, ld, st())
+    res['dx'] = (dmsg.cpu()[rows, :IN] - x.grad).abs().max().item()
+    res['dh'] = (dh.cpu()[rows, H:2 * H] - hrow.grad).abs().max().item()
+    # backward, weights (accumulate into non-zero buffers)
+    base = 0.5
+    dW_ih = torch.full((3 * H, IN), base, device=DEV)
+    dW_hh = torch.full((3 * H, H), base, device=DEV)
+    db_ih = torch.full((3 * H,), base, device=DEV)
+    db_hh = torch.full((3 * H,), base, device=DEV)
+    wsb = _lib.load().tmpnn_gru_bwd_weights_ws(R, IN, H)
+    ws = torch.empty(wsb // 4 + 1, device=DEV)
+    _lib.call('tmpnn_gru_bwd_weights', rowsD.data_ptr(), R, xmode, gd.src.data_ptr() if xmode else None,
+              gd.dst.data_ptr() if xmode else None, msgD.data_ptr() if xmode == 0 else None, IN, 1, IN,
+              hD.data_ptr() + 4 * H, ld, H, gates.data_ptr(), g.N * H, doutD.data_ptr() + 4 * H, ld,
+              dW_ih.data_ptr(), dW_hh.data_ptr(), db_ih.data_ptr(), db_hh.data_ptr(), ws.data_ptr(), wsb, st())
+    sc = max(1.0, wih.grad.abs().max().item())
+    res['dW_ih'] = (dW_ih.cpu() - base - wih.grad).abs().max().item() / sc
+    res['dW_hh'] = (dW_hh.cpu() - base - whh.grad).abs().max().item() / sc
+    res['db_ih'] = (db_ih.cpu() - base - bih.grad).abs().max().item() / sc
+    res['db_hh'] = (db_hh.cpu() - base - bhh.grad).abs().max().item() / sc
+    return res
+
+
+def check_heads(C, g, gd):
+    torch.manual_seed(C)
+    N = g.N
+    h = torch.randn(N, C + 4)
+    hh = h[:, :C].clone().requires_grad_(True)
+    wn = torch.randn(1, C, requires_grad=True)
+    we = torch.randn(1, C, requires_grad=True)
+    bn = torch.randn(1, requires_grad=True)
+    be = torch.randn(1, requires_grad=True)
+    ie = g.is_edge.cpu().bool()
+    y = torch.where(ie[:, None], F.linear(hh, we, be), F.linear(hh, wn, bn))
+    s = torch.sigmoid(y)
+    dl, ds = torch.randn(N, 1), torch.randn(N, 1)
+    (y * dl + s * ds).sum().backward()
+    d = lambda t: t.detach().to(DEV).contiguous()
+    hD = d(h)
+    logits = torch.empty(N, 1, device=DEV)
+    scores = torch.empty(N, 1, device=DEV)
+    _lib.call('tmpnn_heads_fwd', hD.data_ptr(), C + 4, C, N, gd.is_edge.data_ptr(), d(wn).data_ptr(), d(bn).data_ptr(),
+              d(we).data_ptr(), d(be).data_ptr(), logits.data_ptr(), scores.data_ptr(), st())
+    res = {'logits': (logits.cpu() - y.detach()).abs().max().item(),
+           'scores': (scores.cpu() - s.detach()).abs().max().item()}
+    pre = torch.randn(N, C)
+    dh = d(pre)
+    g_wn, g_we = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+    g_bn, g_be = torch.zeros(1, device=DEV), torch.zeros(1, device=DEV)
+    wsb = _lib.load().tmpnn_heads_bwd_ws(N, C)
+    ws = torch.empty(wsb // 4 + 1, device=DEV)
+    wnD, weD = d(wn), d(we)
+    _lib.call('tmpnn_heads_bwd', hD.data_ptr(), C + 4, C, N, gd.is_edge.data_ptr(), wnD.data_ptr(), weD.data_ptr(),
+              scores.data_ptr(), d(dl).data_ptr(), d(ds).data_ptr(), dh.data_ptr(), C, 1,
+              g_wn.data_ptr(), g_bn.data_ptr(), g_we.data_ptr(), g_be.data_ptr(), ws.data_ptr(), wsb, st())
+    sc = max(1.0, wn.grad.abs().max().item(), we.grad.abs().max().item())
+    res['dh'] = (dh.cpu() - pre - hh.grad).abs().max().item()
+    res['dw'] = max((g_wn.cpu() - wn.grad[0]).abs().max().item(), (g_we.cpu() - we.grad[0]).abs().max().item()) / sc
+    res['db'] = max((g_bn.cpu() - bn.grad).abs().max().item(), (g_be.cpu() - be.grad).abs().max().item()) / sc
+    return res
+
+
+def check_input_bn(H, F_, training, S=4):
+    torch.manual_seed(H + F_)
+    # S segments, each with nd_s det rows and some zero rows
+    nds = [3, 1, 5, 2][:S]
+    cnts = [n + z for n, z in zip(nds, [6, 4, 0, 9][:S])]
+    nd = sum(nds)
+    Ft = F_ + 3                                   # group columns embedded in a wider feature row
+    xdet = torch.randn(nd, Ft)
+    cfg = orc.OracleConfig('2d', F_ - 5, H, 0, 'diff')
+    p = orc.random_params(cfg, seed=H)
+    p = {k: v for k, v in p.items() if k.startswith('input_transforms.0.')}
+    pg = {k: (v.clone().requires_grad_(True) if v.dtype.is_floating_point and 'running' not in k else v.clone())
+          for k, v in p.items()}
+    # oracle on the full row set: per segment [zeros ..., dets ...]
+    xs, seg, is_det = [], [], []
+    o = 0
+    for s in range(S):
+        nz = cnts[s] - nds[s]
+        xs.append(torch.zeros(nz, F_))
+        xs.append(xdet[o:o + nds[s], 1:1 + F_])
+        seg += [s] * cnts[s]
+        is_det += [False] * nz + [True] * nds[s]
+        o += nds[s]
+    xfull = torch.cat(xs).requires_grad_(True)
+    seg = torch.tensor(seg)
+    is_det = torch.tensor(is_det)
+    out = orc._input_transform(pg, 0, xfull, seg, S, training, True)
+    dsel = torch.randn(nd, H)
+    (out[is_det] * dsel).sum().backward()
+
+    d = lambda t: t.detach().to(DEV).contiguous()
+    P = {k: d(v) for k, v in p.items()}
+    t = 'input_transforms.0.'
+    seg_ptr = torch.tensor(np.concatenate([[0], np.cumsum(nds)]), dtype=torch.int32, device=DEV)
+    seg_cnt = torch.tensor(cnts, dtype=torch.int32, device=DEV)
+    xD = d(xdet)
+    y_save = torch.empty(nd, H, device=DEV)
+    SS = S if training else 1
+    mean, rstd = torch.empty(SS, H, device=DEV), torch.empty(SS, H, device=DEV)
+    ws_a = torch.empty(nd, H, device=DEV)
+    Nrows, ld = nd + 5, 2 * H
+    out_row = torch.tensor(np.random.RandomState(0).permutation(Nrows)[:nd], dtype=torch.int32, device=DEV)
+    h_new = torch.zeros(Nrows, ld, device=DEV)
+    _lib.call('tmpnn_input_bn_fwd', xD.data_ptr() + 4, Ft, F_, nd, seg_ptr.data_ptr(), seg_cnt.data_ptr(), S, H,
+              int(training), P[t + '0.weight'].data_ptr(), P[t + '0.bias'].data_ptr(), P[t + '1.weight'].data_ptr(),
+              P[t + '1.bias'].data_ptr(), P[t + '1.running_mean'].data_ptr(), P[t + '1.running_var'].data_ptr(),
+              P[t + '3.weight'].data_ptr(), P[t + '3.bias'].data_ptr(), y_save.data_ptr(), mean.data_ptr(),
+              rstd.data_ptr(), ws_a.data_ptr(), out_row.data_ptr(), h_new.data_ptr() + 4 * H, ld, st())
+    res = {}
+    got = h_new.cpu()[out_row.long().cpu(), H:2 * H]
+    res['fwd'] = (got - out[is_det].detach()).abs().max().item()
+    res['running_mean'] = (P[t + '1.running_mean'].cpu() - pg[t + '1.running_mean']).abs().max().item()
+    res['running_var'] = (P[t + '1.running_var'].cpu() - pg[t + '1.running_var']).abs().max().item()
+    # backward
+    d_h = torch.zeros(Nrows, ld)
+    d_h[out_row.long().cpu(), H:2 * H] = dsel
+    d_hD = d(d_h)
+    grads = {k: torch.zeros_like(P[t + k]) for k in ('0.weight', '0.bias', '1.weight', '1.bias', '3.weight', '3.bias')}
+    d_xdet = torch.zeros(nd, Ft, device=DEV)
+    d_xzero = torch.zeros(S, F_, device=DEV)
+    wsn = _lib.load().tmpnn_input_bn_bwd_ws(nd, S, H, F_)
+    ws = torch.empty(wsn + 1, device=DEV)
+    _lib.call('tmpnn_input_bn_bwd', xD.data_ptr() + 4, Ft, F_, nd, seg_ptr.data_ptr(), seg_cnt.data_ptr(), S, H,
+              int(training), P[t + '0.weight'].data_ptr(), P[t + '0.bias'].data_ptr(), P[t + '1.weight'].data_ptr(),
+              P[t + '1.bias'].data_ptr(), P[t + '3.weight'].data_ptr(), y_save.data_ptr(), mean.data_ptr(),
+              rstd.data_ptr(), out_row.data_ptr(), d_hD.data_ptr() + 4 * H, ld, d_xdet.data_ptr() + 4, Ft,
+              d_xzero.data_ptr(), grads['0.weight'].data_ptr(), grads['0.bias'].data_ptr(),
+              grads['1.weight'].data_ptr(), grads['1.bias'].data_ptr(), grads['3.weight'].data_ptr(),
+              grads['3.bias'].data_ptr(), ws.data_ptr(), wsn + 1, st())
+    gs = max(1.0, max(pg[t + k].grad.abs().max().item() for k in grads))
+    for k in grads:
+        res['d' + k] = (grads[k].cpu() - pg[t + k].grad).abs().max().item() / gs
+    res['d_xdet'] = (d_xdet.cpu()[:, 1:1 + F_] - xfull.grad[is_det]).abs().max().item() / gs
+    gz = xfull.grad[~is_det]
+    segz = seg[~is_det]
+    res['d_xzero'] = (d_xzero.cpu()[segz] - gz).abs().max().item() / gs if gz.numel() else 0.0
+    return res
+
+
+def check_attention(H, K, training, g, gd):
+    torch.manual_seed(H * 10 + K)
+    G = 2
+    ld = G * H
+    hfull = torch.randn(g.N, ld)
+    h = hfull[:, H:2 * H].clone().requires_grad_(True)
+    og = orc.OracleGraph(g.N, g.is_edge.cpu().numpy().astype(bool), idx(g.src).numpy(), idx(g.dst).numpy(),
+                         idx(g.edge_row).numpy(), idx(g.det_row).numpy())
+    p = {}
+    for k in range(K):
+        p[f'gat.{k}.W_att'] = (0.4 * torch.randn(H, H)).requires_grad_(True)
+        p[f'gat.{k}.a'] = (0.4 * torch.randn(H, 1)).requires_grad_(True)
+    keep = (torch.rand(K, g.E, 2) > 0.5).to(torch.uint8) if training else None
+    es = 0
+    alphas = []
+    for k in range(K):
+        e_k, a_k = orc._attention(p, '', k, h, og, None if keep is None else keep[k])
+        es = es + e_k
+        alphas.append(a_k)
+    es = es / K
+    dr = idx(g.det_row)
+    d_es = torch.randn(g.Dn, H)
+    (es[dr] * d_es).sum().backward()
+
+    d = lambda t: t.detach().to(DEV).contiguous()
+    e_of_p, ep = gd.inc_edge_endpoint()
+    keepD = None
+    if keep is not None:
+        keepD = d(keep)[:, e_of_p, ep].contiguous()
+    W = d(torch.stack([p[f'gat.{k}.W_att'] for k in range(K)]))
+    a = d(torch.stack([p[f'gat.{k}.a'].reshape(-1) for k in range(K)]))
+    hD = d(hfull)
+    ws_ha = torch.empty(K, g.Dn, H, device=DEV)
+    score = torch.zeros(K, g.N, device=DEV)
+    alpha = torch.empty(K, 2 * g.E, device=DEV)
+    out = torch.empty(g.Dn, H, device=DEV)
+    _lib.call('tmpnn_att_fwd', gd.cref(), gd.pos.data_ptr(), hD.data_ptr() + 4 * H, ld, H, K, W.data_ptr(),
+              a.data_ptr(), _lib.ptr(keepD), 0.5, ws_ha.data_ptr(), score.data_ptr(), alpha.data_ptr(),
+              out.data_ptr(), H, st())
+    res = {'es': (out.cpu() - es[dr].detach()).abs().max().item()}
+    al = torch.zeros(K, g.E, 2)
+    al[:, e_of_p.cpu(), ep.cpu()] = alpha.cpu()
+    res['alpha'] = max((al[k] - alphas[k].detach()).abs().max().item() for k in range(K))
+    # backward
+    dmsg = torch.zeros(g.N, H + 4)
+    dmsg[dr, :H] = d_es
+    dmsgD = d(dmsg)
+    pre = torch.randn(g.N, ld)
+    d_h = d(pre)
+    dW, da = torch.zeros_like(W), torch.zeros_like(a)
+    wsn = _lib.load().tmpnn_att_bwd_ws(g.E, g.Dn, H, K)
+    ws = torch.empty(wsn + 1, device=DEV)
+    ws_dha = torch.empty(K, g.Dn, H, device=DEV)
+    ws_edge = torch.zeros(K, g.N, device=DEV)
+    _lib.call('tmpnn_att_bwd', gd.cref(), gd.pos.data_ptr(), hD.data_ptr() + 4 * H, ld, H, K, W.data_ptr(),
+              a.data_ptr(), _lib.ptr(keepD), 0.5, ws_ha.data_ptr(), score.data_ptr(), alpha.data_ptr(),
+              dmsgD.data_ptr(), H + 4, ws.data_ptr(), wsn + 1, ws_dha.data_ptr(), ws_edge.data_ptr(),
+              d_h.data_ptr() + 4 * H, ld, dW.data_ptr(), da.data_ptr(), st())
+    gs = max(1.0, h.grad.abs().max().item())
+    res['d_h'] = ((d_h.cpu() - pre)[:, H:2 * H] - h.grad).abs().max().item() / gs
+    res['d_h_other_group'] = (d_h.cpu() - pre)[:, :H].abs().max().item()
+    res['dW'] = max((dW.cpu()[k] - p[f'gat.{k}.W_att'].grad).abs().max().item() for k in range(K)) / max(
+        1.0, max(p[f'gat.{k}.W_att'].grad.abs().max().item() for k in range(K)))
+    res['da'] = max((da.cpu()[k] - p[f'gat.{k}.a'].grad[:, 0]).abs().max().item() for k in range(K)) / max(
+        1.0, max(p[f'gat.{k}.a'].grad.abs().max().item() for k in range(K)))
+    return res
+
+
+def run_all(report=print):
+    """Yield (name, worst error, tolerance) for every stage/width combination."""
+    g = make_graph()
+    gd = g.to(DEV)
+    results = []
+
+    def rec(name, err, tol):
+        results.append((name, err, tol))
+        report(f'{"OK  " if err <= tol else "FAIL"} {name:48s} err={err:.3e} tol={tol:.0e}')
+
+    for H in (32, 64, 128, 256):
+        for concat in (False, True):
+            for acc in (False, True):
+                rec(f'gather H={H} concat={concat} acc={acc}', check_gather(H, concat, acc, g, gd), 1e-6)
+        for mode in ('fwd', 'gdiff_bwd', 'gconcat_bwd'):
+            for acc in (False, True):
+                rec(f'segsum {mode} H={H} acc={acc}', check_segsum(H, mode, acc, False, g, gd), 2e-5)
+        rec(f'segsum fwd compact H={H}', check_segsum(H, 'fwd', False, True, g, gd), 2e-5)
+        for xmode, kind in ((1, 'edge'), (2, 'edge'), (0, 'det'), (0, 'edge')):
+            r = check_gru(H, xmode, g, gd, kind)
+            for k, v in r.items():
+                rec(f'gru H={H} xmode={xmode} rows={kind} {k}', v, 0.0 if k == 'untouched' else 2e-4)
+    for C in (32, 64, 96, 192, 256, 768):
+        for k, v in check_heads(C, g, gd).items():
+            rec(f'heads C={C} {k}', v, 2e-4)
+    for H, F_ in ((64, 8), (32, 13), (128, 2), (64, 128)):
+        for training in (True, False):
+            for k, v in check_input_bn(H, F_, training).items():
+                rec(f'input_bn H={H} F={F_} train={training} {k}', v, 2e-4)
+    for H, K in ((64, 2), (32, 1), (128, 3)):
+        for training in (False, True):
+            for k, v in check_attention(H, K, training, g, gd).items():
+                rec(f'attention H={H} K={K} train={training} {k}', v, 2e-4)
+    torch.cuda.synchronize()
+    return results
+
+
+if __name__ == '__main__':
+    res = run_all()
+    bad = [r for r in res if not (r[1] <= r[2])]
+    print(f'{len(res) - len(bad)}/{len(res)} stage checks passed')
+    sys.exit(1 if bad else 0)

@@ -1,0 +1,152 @@
+"""Host-side graph logic: adjacency ingestion, the index-form window builder, block-diagonal batching."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import trackmpnn_oracle as orc
+from tests.conftest import golden_names
+from tests.golden_util import Golden
+from trackmpnn_amd import (TrackMPNN, WindowBuilder, batch_windows, graph_from_adjacency, graph_from_edges,
+                           plan_single, synth_window)
+
+
+def as_oracle_graph(g):
+    return orc.OracleGraph(g.N, g.is_edge.cpu().numpy().astype(bool), g.src.cpu().numpy().astype(np.int64),
+                           g.dst.cpu().numpy().astype(np.int64), g.edge_row.cpu().numpy().astype(np.int64),
+                           g.det_row.cpu().numpy().astype(np.int64))
+
+
+@pytest.mark.parametrize('name', golden_names())
+def test_adjacency_ingestion_matches_oracle(name):
+    gold = Golden(name)
+    for c in range(gold.ncalls):
+        na, ea = gold.adjacency(c, 'node_adj'), gold.adjacency(c, 'edge_adj')
+        g = graph_from_adjacency(na, ea)
+        o = orc.graph_from_adjacency(na, ea)
+        assert (g.N, g.E, g.Dn) == (o.N, o.E, o.Dn)
+        assert np.array_equal(g.src.numpy(), o.src) and np.array_equal(g.dst.numpy(), o.dst)
+        assert np.array_equal(g.edge_row.numpy(), o.edge_row) and np.array_equal(g.det_row.numpy(), o.det_row)
+        # CSR: per det, incident edge rows ascending, sign bit = det is the later endpoint
+        rowptr, inc = g.rowptr.numpy(), g.inc.numpy()
+        assert rowptr[0] == 0 and rowptr[-1] == 2 * g.E
+        for d, drow in enumerate(o.det_row):
+            rows = inc[rowptr[d]:rowptr[d + 1]] & 0x7FFFFFFF
+            neg = inc[rowptr[d]:rowptr[d + 1]] < 0
+            exp_pos = o.edge_row[o.src == drow]
+            exp_neg = o.edge_row[o.dst == drow]
+            assert np.array_equal(np.sort(rows[~neg]), exp_pos) and np.array_equal(np.sort(rows[neg]), exp_neg)
+            assert np.all(np.diff(rows) > 0)
+        assert np.array_equal(g.pos.numpy()[o.det_row], np.arange(o.Dn))
+        assert np.array_equal(g.pos.numpy()[o.edge_row], np.arange(o.E))
+
+
+def test_adjacency_invariants_rejected():
+    a = torch.zeros(3, 3)
+    a[0, 0] = a[2, 2] = 1
+    a[1, 0] = 1                         # edge row with only a +1
+    with pytest.raises(ValueError):
+        graph_from_adjacency(a)
+    b = torch.zeros(3, 3)
+    b[0, 0] = b[2, 2] = 1
+    b[1, 0], b[1, 2] = 1, -1
+    e = b.t().clone()
+    e[0, 0] = e[2, 2] = 0
+    e[1, 1] = 1
+    graph_from_adjacency(b, e)          # valid
+    e[0, 1] = -1                        # sign flipped
+    with pytest.raises(ValueError):
+        graph_from_adjacency(b, e)
+
+
+def test_empty_and_edgeless_graphs():
+    g = graph_from_edges(0, torch.zeros(0, dtype=torch.bool), torch.zeros(0), torch.zeros(0))
+    assert (g.N, g.E, g.Dn) == (0, 0, 0)
+    g = graph_from_adjacency(torch.eye(4))
+    assert (g.N, g.E, g.Dn) == (4, 0, 4) and g.rowptr.tolist() == [0] * 5
+
+
+@pytest.mark.parametrize('name', [n for n in golden_names() if n.startswith('roll_')])
+def test_window_builder_matches_reference_graphs(name):
+    """The index-form replay of initialize_graph/update_graph(train) builds the reference's graphs."""
+    gold = Golden(name)
+    y = gold.d['y'][0]
+    calls = WindowBuilder(y).calls()
+    assert len(calls) == gold.ncalls - 1          # the fixture's last call is an empty-x iteration
+    plans, refs = batch_windows([calls])
+    for c, plan in enumerate(plans):
+        g = graph_from_adjacency(gold.adjacency(c, 'node_adj'), gold.adjacency(c, 'edge_adj'))
+        for f in ('src', 'dst', 'edge_row', 'det_row', 'rowptr', 'inc'):
+            assert torch.equal(getattr(plan.graph, f), getattr(g, f)), (c, f)
+        x = gold.t(f'c{c}/x')
+        assert plan.n_new == x.shape[0]
+        X = torch.from_numpy(gold.d['X'][0])
+        assert torch.equal(x[plan.new_det_local], X[refs[c][:, 1]])
+        ps = plan_single(g, x.shape[0])
+        assert torch.equal(ps.new_det_local, plan.new_det_local) and torch.equal(ps.new_det_row, plan.new_det_row)
+
+
+def _run_oracle(cfg, p, plans, xs, training):
+    h = None
+    outs = []
+    for plan, x in zip(plans, xs):
+        s, l, h, _ = orc.forward(p, cfg, x, h, as_oracle_graph(plan.graph), training=training,
+                                 seg_ids=plan.seg_of_new)
+        outs.append((s, l, h))
+    return outs
+
+
+@pytest.mark.parametrize('static', [False, True])
+def test_block_diagonal_batch_equals_per_window(static):
+    """Batching B windows call-major with per-window BatchNorm segments changes no per-window result."""
+    cfg = orc.OracleConfig('2d', 3, 32, 0, 'diff')
+    B = 5
+    ys = [synth_window(seed=s, frames=5, mean_dets=3, max_dets=6) for s in range(B)]
+    wins = [WindowBuilder(y).calls() for y in ys]
+    Xs = [torch.randn(y.shape[0], 8, generator=torch.Generator().manual_seed(100 + i)) for i, y in enumerate(ys)]
+    plans, refs = batch_windows(wins, static=static)
+    xs = []
+    for plan, ref in zip(plans, refs):
+        x = torch.zeros(plan.n_new, 8)
+        x[plan.new_det_local] = torch.stack([Xs[b][i] for b, i in ref]) if len(ref) else x[:0]
+        xs.append(x)
+    p = orc.random_params(cfg, seed=3)
+    batched = _run_oracle(cfg, {k: v.clone() for k, v in p.items()}, plans, xs, True)
+    # per window, rows of window b inside the batch: recover through a marker pass
+    for b in range(B):
+        plans_b, refs_b = batch_windows([wins[b]], static=static)
+        xs_b = []
+        for plan, ref in zip(plans_b, refs_b):
+            x = torch.zeros(plan.n_new, 8)
+            x[plan.new_det_local] = Xs[b][ref[:, 1]]
+            xs_b.append(x)
+        single = _run_oracle(cfg, {k: v.clone() for k, v in p.items()}, plans_b, xs_b, True)
+        # rows of window b in the batched layout, call by call
+        rows = []
+        for c, plan in enumerate(plans):
+            seg = plan.seg_of_new
+            # segments are numbered by order of appearance among windows that have rows in this call
+            present = [w for w in range(B) if (static or c < len(wins[w]))]
+            if b in present:
+                s_id = present.index(b)
+                new_rows = (plan.graph.N - plan.n_new) + torch.nonzero(seg == s_id).flatten()
+                rows.append(new_rows)
+            if static or c < len(plans_b):
+                allrows = torch.cat(rows)
+                cb = 0 if static else c
+                assert torch.allclose(batched[c][1][allrows], single[cb][1], atol=2e-5, rtol=1e-5)
+                assert torch.allclose(batched[c][2][allrows], single[cb][2], atol=2e-5, rtol=1e-5)
+
+
+def test_state_dict_keys_match_oracle_shapes():
+    for feats, K, msg in (('2d', 0, 'diff'), ('2d+temp+vis', 2, 'concat')):
+        m = TrackMPNN(feats, 3, 32, K, msg)
+        sd = m.state_dict()
+        shapes = orc.param_shapes(orc.OracleConfig(feats, 3, 32, K, msg))
+        assert list(sd.keys()) == list(shapes.keys())
+        for k, v in sd.items():
+            assert tuple(v.shape) == shapes[k], k
+        assert sorted(m.spec.param_names()) == sorted(k for k, _ in m.named_parameters())
+    with pytest.raises(ValueError):
+        TrackMPNN('2d', 3, 48, 0, 'diff')
+    with pytest.raises(AssertionError):
+        TrackMPNN('2d', 3, 32, 0, 'sum')

@@ -1,0 +1,252 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP path, called through the C ABI, against
+(1) the reference-generated golden fixtures, (2) the CPU oracle on seeded inputs, (3) size-independent
+properties at the bench sizes."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import trackmpnn_oracle as orc
+from tests.conftest import golden_names
+from tests.golden_util import Golden
+
+pytestmark = pytest.mark.gpu
+
+DEV = 'cuda:0'
+SCORE_TOL = 1e-4     # BASELINE.json: edge/node scores within 1e-4 fp32 of the reference
+LOGIT_ATOL, LOGIT_RTOL = 2e-4, 2e-5   # fixtures have |y|,|h| up to ~50 (weights perturbed by 0.3*N(0,1))
+GRAD_RTOL = 2e-4     # relative to the largest gradient entry of the fixture
+
+
+@pytest.fixture(scope='module', autouse=True)
+def _need_gpu():
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU')
+    import __graft_entry__
+    __graft_entry__.build()
+
+
+def test_stage_checks():
+    """Every C-ABI stage against its torch-CPU formula, H in {32, 64, 128, 256}."""
+    from tests import gpu_stage_checks
+    lines = []
+    res = gpu_stage_checks.run_all(report=lines.append)
+    bad = [ln for ln in lines if ln.startswith('FAIL')]
+    assert not bad, '\n'.join(bad)
+    assert len(res) > 200
+
+
+def build_model(meta, params):
+    from trackmpnn_amd import TrackMPNN
+    m = TrackMPNN(meta['features'], meta['ncategories'], meta['nhidden'], meta['nattheads'], meta['msg_type'])
+    missing = m.load_state_dict(params, strict=True)
+    assert not missing.missing_keys and not missing.unexpected_keys
+    m = m.to(DEV)
+    return m.train() if meta['mode'] == 'train' else m.eval()
+
+
+@pytest.mark.parametrize('name', golden_names())
+def test_golden_reference_parity(name):
+    """Drop-in forward(x, h_in, node_adj, edge_adj) on the reference's own adjacency tensors, fwd + bwd."""
+    from trackmpnn_amd import graph_from_adjacency, plan_single
+    gold = Golden(name)
+    meta = gold.meta
+    model = build_model(meta, gold.params())
+    K, G = meta['nattheads'], len(model.feature_idx)
+    train = meta['mode'] == 'train'
+    h = None
+    loss = 0.0
+    xs = []
+    for c in range(gold.ncalls):
+        na = gold.adjacency(c, 'node_adj', DEV)
+        ea = gold.adjacency(c, 'edge_adj', DEV)
+        x = gold.t(f'c{c}/x').to(DEV).requires_grad_(True)
+        xs.append(x)
+        if train and K > 0:
+            # the reference's dense dropout stream cannot be replayed: inject the mask it actually drew
+            graph = graph_from_adjacency(na, ea)
+            e, ep = graph.inc_edge_endpoint()
+            keep = [gold.t(f'c{c}/keep_g{g}').to(DEV)[:, e, ep].contiguous() for g in range(G)]
+            scores, logits, h, att = model.forward_graph(x, h, plan_single(graph, x.shape[0]), dropout_keep=keep)
+        else:
+            scores, logits, h, att = model(x, h, na, ea)
+        assert (scores.detach().cpu() - gold.t(f'c{c}/scores')).abs().max().item() <= SCORE_TOL, f'scores call {c}'
+        assert torch.allclose(logits.detach().cpu(), gold.t(f'c{c}/logits'), atol=LOGIT_ATOL, rtol=LOGIT_RTOL), c
+        if gold.has(f'c{c}/h_out'):
+            assert torch.allclose(h.detach().cpu(), gold.t(f'c{c}/h_out'), atol=LOGIT_ATOL, rtol=LOGIT_RTOL), c
+        for g in range(G):
+            for k in range(K):
+                got = att[g][k].per_edge().cpu()
+                assert torch.allclose(got, gold.t(f'c{c}/att_g{g}_k{k}'), atol=1e-5, rtol=1e-4), (c, g, k)
+        if K > 0 and not train and c == 0:
+            # dense reference layout incl. the uniform rows of all-masked softmaxes
+            dense = att[0][0].to_reference_dense()
+            assert dense.shape == (logits.shape[0], logits.shape[0])
+            assert torch.allclose(dense.sum(1), torch.ones_like(dense[:, 0]), atol=1e-5)
+        loss = loss + (gold.t(f'c{c}/wl').to(DEV) * logits).sum() + (gold.t(f'c{c}/ws').to(DEV) * scores).sum()
+    loss = loss + (gold.t('V').to(DEV) * h).sum()
+    ref_loss = float(gold.d['loss'])
+    assert abs(loss.item() - ref_loss) <= 2e-4 * max(1.0, abs(ref_loss))
+    loss.backward()
+    grads = gold.grads()
+    gscale = max(1.0, max(v.abs().max().item() for k, v in grads.items() if k != 'X'))
+    for k, prm in model.named_parameters():
+        tol = GRAD_RTOL * gscale
+        if train and k.startswith('input_transforms.') and k.endswith('.0.bias'):
+            tol = 2e-3 * gscale      # exactly-zero true gradient (BatchNorm removes the mean): cancellation noise
+        err = (prm.grad.cpu() - grads[k]).abs().max().item()
+        assert err <= tol, f'grad {k}: {err} > {tol}'
+    if meta['static_iters'] == 0:
+        gx = torch.cat([x.grad.cpu() if x.grad is not None else torch.zeros(x.shape) for x in xs], 0)
+        is_det_new = []
+        for c in range(gold.ncalls):
+            g = graph_from_adjacency(gold.adjacency(c, 'node_adj'), gold.adjacency(c, 'edge_adj'))
+            n = xs[c].shape[0]
+            is_det_new.append(g.is_edge[g.N - n:] == 0)
+        is_det_new = torch.cat(is_det_new)
+        gX = grads['X'][0]
+        assert torch.allclose(gx[is_det_new], gX, atol=GRAD_RTOL * max(1.0, gX.abs().max().item()), rtol=0)
+    for k, ref in gold.final_buffers().items():
+        got = dict(model.named_buffers())[k].cpu()
+        if ref.dtype.is_floating_point:
+            assert torch.allclose(got, ref, atol=1e-5, rtol=1e-5), k
+        else:
+            assert int(got) == int(ref), k
+
+
+def _oracle_graph(g):
+    return orc.OracleGraph(g.N, g.is_edge.cpu().numpy().astype(bool), g.src.cpu().numpy().astype(np.int64),
+                           g.dst.cpu().numpy().astype(np.int64), g.edge_row.cpu().numpy().astype(np.int64),
+                           g.det_row.cpu().numpy().astype(np.int64))
+
+
+def _batched_case(B, frames, mean, max_dets, F, seed0=0, static=False):
+    from trackmpnn_amd import WindowBuilder, batch_windows, synth_window
+    ys = [synth_window(seed0 + s, frames, mean, max_dets) for s in range(B)]
+    wins = [WindowBuilder(y).calls() for y in ys]
+    plans, refs = batch_windows(wins, static=static)
+    gen = torch.Generator().manual_seed(seed0 + 999)
+    Xs = [torch.randn(y.shape[0], F, generator=gen) for y in ys]
+    xs = []
+    for plan, ref in zip(plans, refs):
+        x = torch.zeros(plan.n_new, F)
+        if len(ref):
+            x[plan.new_det_local] = torch.stack([Xs[b][i] for b, i in ref])
+        xs.append(x)
+    return plans, xs
+
+
+@pytest.mark.parametrize('features,ncat,H,K,msg,train', [
+    ('2d', 3, 64, 0, 'diff', True),           # C2 shape (KITTI 2d feats)
+    ('2d', 8, 64, 0, 'diff', True),           # C4 shape (BDD, F=13)
+    ('2d', 3, 64, 2, 'diff', False),
+    ('2d', 3, 128, 0, 'concat', True),
+    ('2d+temp+vis', 3, 64, 0, 'diff', True),
+    ('2d', 3, 256, 0, 'diff', True),          # C5 width
+])
+def test_batched_windows_vs_oracle(features, ncat, H, K, msg, train):
+    """Block-diagonal batches of KITTI-shaped rolling windows (per-window BatchNorm segments), fwd + bwd."""
+    from trackmpnn_amd import TrackMPNN
+    cfg = orc.OracleConfig(features, ncat, H, K, msg)
+    F = sum(f for _, f in cfg.groups)
+    plans, xs = _batched_case(B=16, frames=7, mean=6, max_dets=20, F=F, seed0=H + K)
+    p = orc.random_params(cfg, seed=H, scale=0.15)
+    model = TrackMPNN(features, ncat, H, K, msg)
+    model.load_state_dict({k: v.clone() for k, v in p.items()}, strict=True)
+    model = model.to(DEV)
+    model.train() if train else model.eval()
+    pr = {k: (v.clone().requires_grad_(True) if v.dtype.is_floating_point and 'running' not in k else v.clone())
+          for k, v in p.items()}
+    h = h_ref = None
+    loss = loss_ref = 0.0
+    gen = torch.Generator().manual_seed(1)
+    for plan, x in zip(plans, xs):
+        s_ref, l_ref, h_ref, _ = orc.forward(pr, cfg, x, h_ref, _oracle_graph(plan.graph), training=train,
+                                             seg_ids=plan.seg_of_new)
+        s, l, h, _ = model.forward_graph(x.to(DEV), h, plan.to(DEV))
+        assert (s.detach().cpu() - s_ref.detach()).abs().max().item() <= SCORE_TOL
+        assert torch.allclose(l.detach().cpu(), l_ref.detach(), atol=LOGIT_ATOL, rtol=LOGIT_RTOL)
+        assert torch.allclose(h.detach().cpu(), h_ref.detach(), atol=LOGIT_ATOL, rtol=LOGIT_RTOL)
+        w = torch.randn(l.shape, generator=gen)
+        loss = loss + (w.to(DEV) * l).sum() + s.sum()
+        loss_ref = loss_ref + (w * l_ref).sum() + s_ref.sum()
+    loss.backward()
+    loss_ref.backward()
+    gscale = max(1.0, max(v.grad.abs().max().item() for v in pr.values() if v.grad is not None))
+    for k, prm in model.named_parameters():
+        tol = GRAD_RTOL * gscale * (10 if (train and k.endswith('.0.bias') and k.startswith('input_')) else 1)
+        err = (prm.grad.cpu() - pr[k].grad).abs().max().item()
+        assert err <= tol, f'grad {k}: {err} > {tol}'
+    for k, b in model.named_buffers():
+        if b.dtype.is_floating_point:
+            assert torch.allclose(b.cpu(), pr[k], atol=1e-5, rtol=1e-4), k
+
+
+def test_eval_no_grad_and_empty_calls():
+    """Inference pattern (infer.py:48-51,60-87): eval mode, no autograd, an empty-x extra iteration."""
+    from trackmpnn_amd import TrackMPNN
+    cfg = orc.OracleConfig('2d', 3, 64, 0, 'diff')
+    plans, xs = _batched_case(B=3, frames=4, mean=4, max_dets=8, F=8, seed0=7)
+    p = orc.random_params(cfg, seed=2, scale=0.2)
+    model = TrackMPNN('2d', 3, 64, 0, 'diff')
+    model.load_state_dict({k: v.clone() for k, v in p.items()})
+    model = model.to(DEV).eval()
+    h = h_ref = None
+    with torch.no_grad():
+        for plan, x in zip(plans, xs):
+            s_ref, l_ref, h_ref, _ = orc.forward(p, cfg, x, h_ref, _oracle_graph(plan.graph), training=False)
+            s, l, h, _ = model.forward_graph(x.to(DEV), h, plan.to(DEV))
+            assert (s.cpu() - s_ref).abs().max().item() <= SCORE_TOL
+        # extra message-passing iteration with no new rows (track_mpnn.py:67-68)
+        from trackmpnn_amd import plan_single
+        plan0 = plan_single(plans[-1].graph.to(DEV), 0)
+        s_ref, l_ref, h_ref, _ = orc.forward(p, cfg, xs[0][:0], h_ref, _oracle_graph(plans[-1].graph), training=False)
+        s, l, h, _ = model.forward_graph(xs[0][:0].to(DEV), h, plan0)
+        assert (s.cpu() - s_ref).abs().max().item() <= SCORE_TOL
+        assert torch.allclose(h.cpu(), h_ref, atol=LOGIT_ATOL, rtol=LOGIT_RTOL)
+
+
+def test_single_row_batchnorm_raises():
+    from trackmpnn_amd import TrackMPNN, graph_from_edges, plan_single
+    model = TrackMPNN('2d', 3, 64, 0, 'diff').to(DEV).train()
+    g = graph_from_edges(1, torch.zeros(1, dtype=torch.bool), torch.zeros(0), torch.zeros(0), device=DEV)
+    with pytest.raises(ValueError, match='more than 1 value per channel'):
+        model.forward_graph(torch.randn(1, 8, device=DEV), None, plan_single(g, 1))
+
+
+def test_aggregation_properties_at_scale():
+    """Size-independent properties of rows E/F on a graph far larger than the oracle can chew:
+    <gather(h), m> == <h, gather^T(m)>  (the two kernels are exact adjoints), linearity, and
+    bitwise run-to-run reproducibility (no float atomics)."""
+    from trackmpnn_amd import _lib
+    from trackmpnn_amd import WindowBuilder, batch_windows, synth_window
+    wins = [WindowBuilder(synth_window(s, 7, 6, 20)).calls() for s in range(64)]
+    plans, _ = batch_windows(wins * 32, static=True)           # 2048 windows, ~0.5 M rows
+    g = plans[-1].graph.to(DEV)
+    H = 64
+    st = torch.cuda.current_stream().cuda_stream
+    gen = torch.Generator(device=DEV).manual_seed(0)
+    h = torch.randn(g.N, H, device=DEV, generator=gen)
+    m = torch.randn(g.N, H, device=DEV, generator=gen)
+    h[g.edge_row.long()] = 0            # gather reads det rows only
+    m[g.det_row.long()] = 0             # its adjoint reads edge rows only
+    out = torch.zeros(g.N, H, device=DEV)
+    _lib.call('tmpnn_gather_diff_fwd', g.cref(), h.data_ptr(), H, out.data_ptr(), H, H, 0, st)
+    adj = torch.zeros(g.N, H, device=DEV)
+    _lib.call('tmpnn_gather_diff_bwd', g.cref(), m.data_ptr(), H, adj.data_ptr(), H, H, 0, st)
+    lhs = (out.double() * m.double()).sum().item()
+    rhs = (h.double() * adj.double()).sum().item()
+    assert abs(lhs - rhs) <= 1e-6 * max(1.0, abs(lhs))
+    # segsum (row F) is the adjoint of "gather on gradients" as well
+    es = torch.zeros(g.N, H, device=DEV)
+    h2 = torch.randn(g.N, H, device=DEV, generator=gen)
+    _lib.call('tmpnn_segsum_fwd', g.cref(), h2.data_ptr(), H, es.data_ptr(), H, H, 0, 0, st)
+    es2 = torch.zeros(g.N, H, device=DEV)
+    _lib.call('tmpnn_segsum_fwd', g.cref(), h2.data_ptr(), H, es2.data_ptr(), H, H, 0, 0, st)
+    assert torch.equal(es, es2)                                   # bitwise reproducible
+    es3 = torch.zeros(g.N, H, device=DEV)
+    h3 = (2.0 * h2).contiguous()
+    _lib.call('tmpnn_segsum_fwd', g.cref(), h3.data_ptr(), H, es3.data_ptr(), H, H, 0, 0, st)
+    assert torch.equal(es3, 2.0 * es)                             # exact linearity under power-of-two scaling
+    # sum over dets of es == sum over edges of (h[e] - h[e]) == 0 column-wise: every edge enters once with + and once with -
+    col = es.double().sum(0)
+    assert col.abs().max().item() <= 1e-6 * h2.double().abs().sum(0).max().item()

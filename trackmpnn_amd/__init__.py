@@ -1,0 +1,10 @@
+"""trackmpnn_amd: MI355X-native (gfx950) implementation of the TrackMPNN message-passing hot path.
+
+    from trackmpnn_amd import TrackMPNN          # drop-in for reference models/track_mpnn.py
+"""
+from .graph import (CallPlan, FrameGraph, WindowBuilder, batch_windows, graph_from_adjacency, graph_from_edges,
+                    plan_single, synth_window)
+from .track_mpnn import SparseAttention, TrackMPNN
+
+__all__ = ['TrackMPNN', 'SparseAttention', 'FrameGraph', 'CallPlan', 'graph_from_adjacency', 'graph_from_edges',
+           'plan_single', 'WindowBuilder', 'batch_windows', 'synth_window']

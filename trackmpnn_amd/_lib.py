@@ -1,0 +1,129 @@
+"""ctypes binding of libtmpnn.so (the C ABI declared in include/tmpnn.h).
+
+The library is the product: there is NO fallback.  If the shared object is missing or a call
+fails, a RuntimeError is raised -- nothing silently reroutes through torch ops or the oracle.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import re
+from typing import Dict, List, Optional
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'lib', 'libtmpnn.so')
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), 'include', 'tmpnn.h')
+
+ABI_VERSION = 1
+
+c_int = C.c_int
+c_void_p = C.c_void_p
+c_size_t = C.c_size_t
+c_float = C.c_float
+
+
+class CGraph(C.Structure):
+    """struct tmpnn_graph (include/tmpnn.h)."""
+    _fields_ = [('N', C.c_int32), ('E', C.c_int32), ('Dn', C.c_int32),
+                ('src', c_void_p), ('dst', c_void_p), ('edge_row', c_void_p), ('det_row', c_void_p),
+                ('rowptr', c_void_p), ('inc', c_void_p)]
+
+
+_GP = C.POINTER(CGraph)
+
+# name -> (restype, argtypes); must mirror include/tmpnn.h (tests/test_abi.py cross-checks the names)
+_SIGNATURES = {
+    'tmpnn_abi_version': (c_int, []),
+    'tmpnn_last_error': (C.c_char_p, []),
+    'tmpnn_gather_diff_fwd': (c_int, [_GP, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p]),
+    'tmpnn_gather_concat_fwd': (c_int, [_GP, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p]),
+    'tmpnn_gather_diff_bwd': (c_int, [_GP, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p]),
+    'tmpnn_gather_concat_bwd': (c_int, [_GP, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p]),
+    'tmpnn_segsum_fwd': (c_int, [_GP, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    'tmpnn_segsum_bwd': (c_int, [_GP, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p]),
+    'tmpnn_att_fwd': (c_int, [_GP, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_float,
+                              c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    'tmpnn_att_bwd_ws': (c_size_t, [c_int, c_int, c_int, c_int]),
+    'tmpnn_att_bwd': (c_int, [_GP, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_float,
+                              c_void_p, c_void_p, c_void_p, c_void_p, c_int,
+                              c_void_p, c_size_t, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
+    'tmpnn_gru_fwd': (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
+                              c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                              c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
+    'tmpnn_gru_bwd_data': (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p,
+                                   c_void_p, c_size_t, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p]),
+    'tmpnn_gru_bwd_weights_ws': (c_size_t, [c_int, c_int, c_int]),
+    'tmpnn_gru_bwd_weights': (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
+                                      c_void_p, c_int, c_int, c_void_p, c_size_t, c_void_p, c_int,
+                                      c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    'tmpnn_transpose': (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    'tmpnn_input_bn_fwd': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_int,
+                                   c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                   c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    'tmpnn_input_bn_bwd_ws': (c_size_t, [c_int, c_int, c_int, c_int]),
+    'tmpnn_input_bn_bwd': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_int,
+                                   c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                   c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
+                                   c_void_p, c_int, c_void_p,
+                                   c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                   c_void_p, c_size_t, c_void_p]),
+    'tmpnn_heads_fwd': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                c_void_p, c_void_p, c_void_p]),
+    'tmpnn_heads_bwd_ws': (c_size_t, [c_int, c_int]),
+    'tmpnn_heads_bwd': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                                c_void_p, c_size_t, c_void_p]),
+}
+
+_lib: Optional[C.CDLL] = None
+
+
+def header_symbols() -> List[str]:
+    """Every function name include/tmpnn.h declares."""
+    with open(HEADER_PATH) as f:
+        txt = f.read()
+    txt = re.sub(r'/\*.*?\*/', '', txt, flags=re.S)
+    return sorted(set(re.findall(r'\b(tmpnn_[a-z0-9_]+)\s*\(', txt)))
+
+
+def load() -> C.CDLL:
+    """Load libtmpnn.so (once).  Fails loudly when the HIP extension has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f'{LIB_PATH} is missing: build it with `python -c "import __graft_entry__ as g; g.build()"` '
+            '(hipcc --offload-arch=gfx950).  trackmpnn_amd has no CPU or torch fallback.')
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise RuntimeError(f'libtmpnn.so does not export {name}; rebuild it') from e
+        fn.restype = res
+        fn.argtypes = args
+    v = lib.tmpnn_abi_version()
+    if v != ABI_VERSION:
+        raise RuntimeError(f'libtmpnn.so ABI version {v} != expected {ABI_VERSION}; rebuild it')
+    _lib = lib
+    return lib
+
+
+def last_error() -> str:
+    return load().tmpnn_last_error().decode('utf-8', 'replace')
+
+
+def call(name: str, *args) -> None:
+    """Invoke an int-returning entry point; raise RuntimeError(tmpnn_last_error()) on failure."""
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    if rc != 0:
+        raise RuntimeError(f'{name} failed (code {rc}): {last_error()}')
+
+
+def ptr(t) -> Optional[int]:
+    """Device pointer of a torch tensor (None -> NULL)."""
+    if t is None:
+        return None
+    return t.data_ptr()

@@ -1,0 +1,245 @@
+// Aggregation kernels of the TrackMPNN hot path (SURVEY 8(a) rows E, F and their adjoints).
+//
+// Both are HBM-bound row movers over the bipartite det/edge graph:
+//   gather : one output row per EDGE  = f(two det rows)          (models/layers.py:90-95)
+//   segsum : one output row per DET   = signed sum of its edges   (models/layers.py:103)
+// and each is the other's adjoint, so the same two kernels serve forward and backward.
+//
+// Layout choices for gfx950: a state row is H fp32 = 128 B .. 1 KiB; a row is always moved by
+// H/4 adjacent lanes with one 16-byte access each (full 64/128-byte segments, dwordx4), several
+// rows per 64-lane wave.  Index loads are wave-uniform per row group.  The per-det sum walks the
+// CSR run in a fixed order and combines the row groups with xor-shuffles, so results are bitwise
+// reproducible (no float atomics anywhere).
+#include "common.h"
+
+namespace tmpnn {
+
+static thread_local char g_err[512] = "";
+
+int set_error(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+// ------------------------------------------------------------------------------------------
+// gather: out[edge_row[e]] = in[src[e]] - in[dst[e]]        (CONCAT: [in[src] | in[dst]])
+// ------------------------------------------------------------------------------------------
+template <bool CONCAT, bool ACC>
+__global__ __launch_bounds__(256) void k_gather(int E, const int32_t* __restrict__ src,
+                                                const int32_t* __restrict__ dst,
+                                                const int32_t* __restrict__ edge_row,
+                                                const float* __restrict__ in, int ld_in,
+                                                float* __restrict__ out, int ld_out, int H) {
+    const int lpr = H >> 2;                       // lanes per row (one float4 each)
+    const int rpb = 256 / lpr;                    // rows per block pass
+    const int c4 = (threadIdx.x % lpr) * 4;
+    const int slot = threadIdx.x / lpr;
+    for (long e = (long)blockIdx.x * rpb + slot; e < E; e += (long)gridDim.x * rpb) {
+        const int s = src[e], d = dst[e], r = edge_row[e];
+        const float4 a = *reinterpret_cast<const float4*>(in + (size_t)s * ld_in + c4);
+        const float4 b = *reinterpret_cast<const float4*>(in + (size_t)d * ld_in + c4);
+        float* o = out + (size_t)r * ld_out + c4;
+        if (!CONCAT) {
+            float4 v = make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w);
+            if (ACC) {
+                const float4 p = *reinterpret_cast<const float4*>(o);
+                v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w;
+            }
+            *reinterpret_cast<float4*>(o) = v;
+        } else {
+            float4 va = a, vb = b;
+            if (ACC) {
+                const float4 p = *reinterpret_cast<const float4*>(o);
+                const float4 q = *reinterpret_cast<const float4*>(o + H);
+                va.x += p.x; va.y += p.y; va.z += p.z; va.w += p.w;
+                vb.x += q.x; vb.y += q.y; vb.z += q.z; vb.w += q.w;
+            }
+            *reinterpret_cast<float4*>(o) = va;
+            *reinterpret_cast<float4*>(o + H) = vb;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// segsum: out[det_row[d]] = sum_p  (neg_p ? wneg * in[row_p, cneg:cneg+H] : in[row_p, 0:H])
+//   diff adjoint / row F : wneg = -1, cneg = 0        concat adjoint : wneg = +1, cneg = H
+// One wave per det; the wave's 64/lpr row groups take CSR entries round-robin.
+// ------------------------------------------------------------------------------------------
+template <bool ACC>
+__global__ __launch_bounds__(256) void k_segsum(int Dn, const int32_t* __restrict__ det_row,
+                                                const int32_t* __restrict__ rowptr,
+                                                const int32_t* __restrict__ inc,
+                                                const float* __restrict__ in, int ld_in,
+                                                float* __restrict__ out, int ld_out, int H,
+                                                float wneg, int cneg, int compact_out) {
+    const int lane = threadIdx.x & 63;
+    const int lpr = H >> 2;
+    const int ngrp = 64 / lpr;
+    const int grp = lane / lpr;
+    const int c4 = (lane % lpr) * 4;
+    const long nwaves = (long)gridDim.x * 4;
+    for (long d = (long)blockIdx.x * 4 + (threadIdx.x >> 6); d < Dn; d += nwaves) {
+        const int p0 = rowptr[d], p1 = rowptr[d + 1];
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int p = p0 + grp; p < p1; p += ngrp) {
+            const int v = inc[p];
+            const int row = v & 0x7fffffff;
+            const bool neg = v < 0;
+            const float4 x = *reinterpret_cast<const float4*>(in + (size_t)row * ld_in + (neg ? cneg : 0) + c4);
+            const float w = neg ? wneg : 1.0f;
+            acc.x += w * x.x; acc.y += w * x.y; acc.z += w * x.z; acc.w += w * x.w;
+        }
+        for (int off = lpr; off < 64; off <<= 1) {
+            acc.x += __shfl_xor(acc.x, off);
+            acc.y += __shfl_xor(acc.y, off);
+            acc.z += __shfl_xor(acc.z, off);
+            acc.w += __shfl_xor(acc.w, off);
+        }
+        if (grp == 0) {
+            float* o = out + (size_t)(compact_out ? (int)d : det_row[d]) * ld_out + c4;
+            if (ACC) {
+                const float4 p = *reinterpret_cast<const float4*>(o);
+                acc.x += p.x; acc.y += p.y; acc.z += p.z; acc.w += p.w;
+            }
+            *reinterpret_cast<float4*>(o) = acc;
+        }
+    }
+}
+
+__global__ void k_transpose(const float* __restrict__ in, int rows, int cols, float* __restrict__ out) {
+    __shared__ float tile[32][33];
+    const int bx = blockIdx.x * 32, by = blockIdx.y * 32;
+    for (int j = threadIdx.y; j < 32; j += blockDim.y) {
+        const int r = by + j, c = bx + threadIdx.x;
+        if (r < rows && c < cols) tile[j][threadIdx.x] = in[(size_t)r * cols + c];
+    }
+    __syncthreads();
+    for (int j = threadIdx.y; j < 32; j += blockDim.y) {
+        const int c = bx + j, r = by + threadIdx.x;
+        if (r < rows && c < cols) out[(size_t)c * rows + r] = tile[threadIdx.x][j];
+    }
+}
+
+__global__ void k_reduce_slabs(const float* __restrict__ slabs, size_t stride, int nslab,
+                               float* __restrict__ dst, size_t n, int accumulate) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float s = 0.f;
+    for (int k = 0; k < nslab; ++k) s += slabs[(size_t)k * stride + i];
+    dst[i] = accumulate ? dst[i] + s : s;
+}
+
+int launch_reduce_slabs(const float* slabs, size_t stride, int nslab, float* dst, size_t n, int accumulate,
+                        hipStream_t st) {
+    if (n == 0) return TMPNN_OK;
+    hipLaunchKernelGGL(k_reduce_slabs, dim3(ceil_div((long)n, 256)), dim3(256), 0, st, slabs, stride, nslab, dst,
+                       n, accumulate);
+    return check_launch("reduce_slabs");
+}
+
+static int check_graph(const tmpnn_graph* g) {
+    TM_REQUIRE(g != nullptr, "graph is null");
+    TM_REQUIRE(g->N >= 0 && g->E >= 0 && g->Dn >= 0 && (long)g->E + g->Dn == g->N,
+               "graph sizes inconsistent: N=%d E=%d Dn=%d", g->N, g->E, g->Dn);
+    if (g->E > 0)
+        TM_REQUIRE(g->src && g->dst && g->edge_row && g->inc, "graph edge arrays are null (E=%d)", g->E);
+    if (g->Dn > 0) TM_REQUIRE(g->det_row && g->rowptr, "graph det arrays are null (Dn=%d)", g->Dn);
+    return TMPNN_OK;
+}
+
+static int check_rows(const float* in, int ld_in, const float* out, int ld_out, int H, int w_in, int w_out) {
+    TM_REQUIRE(supported_H(H), "unsupported hidden width H=%d (need 32/64/128/256)", H);
+    TM_REQUIRE(in && out, "null feature pointer");
+    TM_REQUIRE(ld_in >= w_in && ld_out >= w_out, "leading dimension too small (ld_in=%d ld_out=%d)", ld_in, ld_out);
+    TM_REQUIRE((ld_in & 3) == 0 && (ld_out & 3) == 0 && aligned16(in) && aligned16(out),
+               "feature rows must be 16-byte aligned (ld multiple of 4 floats)");
+    return TMPNN_OK;
+}
+
+static int grid_for(long items, int per_block) {
+    long b = (items + per_block - 1) / per_block;
+    if (b > 256L * 16) b = 256L * 16;   // grid-stride beyond 16 blocks per CU
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+static int gather(const tmpnn_graph* g, const float* in, int ld_in, float* out, int ld_out, int H, int accumulate,
+                  bool concat, tmpnn_stream stream) {
+    int rc = check_graph(g);
+    if (rc) return rc;
+    rc = check_rows(in, ld_in, out, ld_out, H, H, concat ? 2 * H : H);
+    if (rc) return rc;
+    if (g->E == 0) return TMPNN_OK;
+    const int rpb = 256 / (H >> 2);
+    dim3 grid(grid_for(g->E, rpb)), block(256);
+    hipStream_t st = as_stream(stream);
+#define L(C, A) hipLaunchKernelGGL((k_gather<C, A>), grid, block, 0, st, g->E, g->src, g->dst, g->edge_row, in, ld_in, out, ld_out, H)
+    if (concat) { if (accumulate) L(true, true); else L(true, false); }
+    else        { if (accumulate) L(false, true); else L(false, false); }
+#undef L
+    return check_launch("gather");
+}
+
+static int segsum(const tmpnn_graph* g, const float* in, int ld_in, float* out, int ld_out, int H, int accumulate,
+                  float wneg, int cneg, int compact_out, tmpnn_stream stream) {
+    int rc = check_graph(g);
+    if (rc) return rc;
+    rc = check_rows(in, ld_in, out, ld_out, H, H + cneg, H);
+    if (rc) return rc;
+    if (g->Dn == 0) return TMPNN_OK;
+    dim3 grid(grid_for(g->Dn, 4)), block(256);
+    hipStream_t st = as_stream(stream);
+    if (accumulate)
+        hipLaunchKernelGGL((k_segsum<true>), grid, block, 0, st, g->Dn, g->det_row, g->rowptr, g->inc, in, ld_in, out,
+                           ld_out, H, wneg, cneg, compact_out);
+    else
+        hipLaunchKernelGGL((k_segsum<false>), grid, block, 0, st, g->Dn, g->det_row, g->rowptr, g->inc, in, ld_in, out,
+                           ld_out, H, wneg, cneg, compact_out);
+    return check_launch("segsum");
+}
+
+}  // namespace tmpnn
+
+using namespace tmpnn;
+
+extern "C" {
+
+int tmpnn_abi_version(void) { return TMPNN_ABI_VERSION; }
+const char* tmpnn_last_error(void) { return tmpnn::g_err; }
+
+int tmpnn_gather_diff_fwd(const tmpnn_graph* g, const float* in, int ld_in, float* out, int ld_out, int H,
+                          int accumulate, tmpnn_stream stream) {
+    return gather(g, in, ld_in, out, ld_out, H, accumulate, false, stream);
+}
+int tmpnn_gather_concat_fwd(const tmpnn_graph* g, const float* in, int ld_in, float* out, int ld_out, int H,
+                            int accumulate, tmpnn_stream stream) {
+    return gather(g, in, ld_in, out, ld_out, H, accumulate, true, stream);
+}
+int tmpnn_gather_diff_bwd(const tmpnn_graph* g, const float* d_out, int ld_dout, float* d_in, int ld_din, int H,
+                          int accumulate, tmpnn_stream stream) {
+    return segsum(g, d_out, ld_dout, d_in, ld_din, H, accumulate, -1.0f, 0, 0, stream);
+}
+int tmpnn_gather_concat_bwd(const tmpnn_graph* g, const float* d_out, int ld_dout, float* d_in, int ld_din, int H,
+                            int accumulate, tmpnn_stream stream) {
+    return segsum(g, d_out, ld_dout, d_in, ld_din, H, accumulate, 1.0f, H, 0, stream);
+}
+int tmpnn_segsum_fwd(const tmpnn_graph* g, const float* in, int ld_in, float* out, int ld_out, int H, int accumulate,
+                     int compact_out, tmpnn_stream stream) {
+    return segsum(g, in, ld_in, out, ld_out, H, accumulate, -1.0f, 0, compact_out, stream);
+}
+int tmpnn_segsum_bwd(const tmpnn_graph* g, const float* d_out, int ld_dout, float* d_in, int ld_din, int H,
+                     int accumulate, tmpnn_stream stream) {
+    return gather(g, d_out, ld_dout, d_in, ld_din, H, accumulate, false, stream);
+}
+
+int tmpnn_transpose(const float* in, int rows, int cols, float* out, tmpnn_stream stream) {
+    TM_REQUIRE(in && out && rows > 0 && cols > 0, "transpose: bad arguments");
+    dim3 grid(ceil_div(cols, 32), ceil_div(rows, 32)), block(32, 8);
+    hipLaunchKernelGGL(k_transpose, grid, block, 0, as_stream(stream), in, rows, cols, out);
+    return check_launch("transpose");
+}
+
+}  // extern "C"

@@ -1,0 +1,55 @@
+// Shared helpers for the libtmpnn kernels (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "tmpnn.h"
+
+namespace tmpnn {
+
+int set_error(int code, const char* fmt, ...);
+
+#define TM_REQUIRE(cond, ...)                                            \
+    do {                                                                 \
+        if (!(cond)) return ::tmpnn::set_error(TMPNN_EINVAL, __VA_ARGS__); \
+    } while (0)
+
+inline int check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return set_error(TMPNN_ELAUNCH, "%s: %s", what, hipGetErrorString(e));
+    return TMPNN_OK;
+}
+
+inline bool supported_H(int H) { return H == 32 || H == 64 || H == 128 || H == 256; }
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+inline hipStream_t as_stream(tmpnn_stream s) { return reinterpret_cast<hipStream_t>(s); }
+inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// sum over `nslab` slabs of `n` floats each: dst[i] (+)= sum_s slabs[s*stride + i]   (deterministic)
+int launch_reduce_slabs(const float* slabs, size_t stride, int nslab, float* dst, size_t n, int accumulate,
+                        hipStream_t st);
+
+// Generic small dense product on the vector ALU (tiny operands only: input transform, attention
+// projections).  C[crow(m)*ldc + n] (+)= sum_k A[arow(m)*sam + k*sak] * B[k*sbk + n*sbn] (+ bias[n])
+struct GemmArgs {
+    const float* A; long sam, sak; const int32_t* a_rows; const int32_t* a_krows;   // optional row gathers on m / k
+    const float* B; long sbk, sbn;
+    const float* bias;
+    float* C; long ldc; const int32_t* c_rows;
+    int M, N, K;
+    int accumulate;
+};
+int launch_gemm(const GemmArgs& g, hipStream_t st);
+// split-K variant for K >> M,N (weight gradients): partial products go to `ws`, then reduced into C (+=).
+size_t gemm_splitk_ws_floats(int M, int N, int K);
+int launch_gemm_splitk(const GemmArgs& g, float* ws, size_t ws_floats, hipStream_t st);
+// dst[j] (+)= sum_i src[i*ld + j] * (mul ? mul[i*ldm + j] : 1)     (two level, deterministic)
+size_t colsum_ws_floats(int rows, int cols);
+int launch_colsum(const float* src, long ld, const float* mul, long ldm, int rows, int cols, float* dst,
+                  int accumulate, float* ws, size_t ws_floats, hipStream_t st);
+
+}  // namespace tmpnn

@@ -1,0 +1,626 @@
+// Small dense stages of the hot path: the input transform with (segmented) BatchNorm
+// (models/track_mpnn.py:45-52,59-61) and the masked output heads
+// (row J; models/track_mpnn.py:72-75), forward + backward.
+//
+// These touch only the NEW det rows of a call (tens of rows per tracking window) and one scalar
+// per state row, i.e. < 1 % of the bytes and flops of the GRU/aggregation kernels, so they are
+// plain vector-ALU kernels: an LDS-tiled strided GEMM, deterministic two-level column sums and
+// a handful of elementwise passes.  No float atomics: every reduction has a fixed order.
+#include "common.h"
+
+namespace tmpnn {
+
+static constexpr float BN_EPS = 1e-5f;
+static constexpr float BN_MOMENTUM = 0.1f;
+
+// ------------------------------------------------------------------------------------------
+// generic strided GEMM, 64x64 tile, BK=16, 4x4 per thread
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_gemm(GemmArgs g, int kper, float* slab) {
+    __shared__ float As[16][68];
+    __shared__ float Bs[16][68];
+    const int tid = threadIdx.x;
+    const int tx = tid & 15, ty = tid >> 4;
+    const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+    const int kbeg = blockIdx.z * kper;
+    const int kend = min(g.K, kbeg + kper);
+    float acc[4][4] = {};
+    for (int k0 = kbeg; k0 < kend; k0 += 16) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int idx = tid + i * 256;
+            int m, k;
+            if (g.sak == 1) { k = idx & 15; m = idx >> 4; } else { m = idx & 63; k = idx >> 6; }
+            float v = 0.f;
+            if (m0 + m < g.M && k0 + k < kend) {
+                const long ar = g.a_rows ? g.a_rows[m0 + m] : (m0 + m);
+                const long ak = g.a_krows ? g.a_krows[k0 + k] : (k0 + k);
+                v = g.A[ar * g.sam + ak * g.sak];
+            }
+            As[k][m] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int idx = tid + i * 256;
+            int n, k;
+            if (g.sbn == 1) { n = idx & 63; k = idx >> 6; } else { k = idx & 15; n = idx >> 4; }
+            float v = 0.f;
+            if (n0 + n < g.N && k0 + k < kend) v = g.B[(long)(k0 + k) * g.sbk + (long)(n0 + n) * g.sbn];
+            Bs[k][n] = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            float a[4], b[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { a[i] = As[k][ty * 4 + i]; b[i] = Bs[k][tx * 4 + i]; }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] += a[i] * b[j];
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = m0 + ty * 4 + i;
+        if (m >= g.M) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = n0 + tx * 4 + j;
+            if (n >= g.N) continue;
+            if (slab) {
+                slab[(size_t)blockIdx.z * g.M * g.N + (size_t)m * g.N + n] = acc[i][j];
+            } else {
+                const long cr = g.c_rows ? g.c_rows[m] : m;
+                float v = acc[i][j] + (g.bias ? g.bias[n] : 0.f);
+                float* p = g.C + cr * g.ldc + n;
+                *p = g.accumulate ? *p + v : v;
+            }
+        }
+    }
+}
+
+int launch_gemm(const GemmArgs& g, hipStream_t st) {
+    if (g.M <= 0 || g.N <= 0) return TMPNN_OK;
+    dim3 grid(ceil_div(g.N, 64), ceil_div(g.M, 64), 1), block(256);
+    hipLaunchKernelGGL(k_gemm, grid, block, 0, st, g, g.K > 0 ? g.K : 1, (float*)nullptr);
+    return check_launch("gemm");
+}
+
+static int splitk_plan(int K, int* kper) {
+    int nsplit = (K + 511) / 512;
+    if (nsplit > 512) nsplit = 512;
+    if (nsplit < 1) nsplit = 1;
+    int kp = (K + nsplit - 1) / nsplit;
+    kp = (kp + 15) & ~15;
+    if (kp < 16) kp = 16;
+    nsplit = (K + kp - 1) / kp;
+    if (nsplit < 1) nsplit = 1;
+    *kper = kp;
+    return nsplit;
+}
+
+size_t gemm_splitk_ws_floats(int M, int N, int K) {
+    int kper;
+    const int ns = splitk_plan(K, &kper);
+    return (size_t)ns * M * N;
+}
+
+int launch_gemm_splitk(const GemmArgs& g, float* ws, size_t ws_floats, hipStream_t st) {
+    if (g.M <= 0 || g.N <= 0) return TMPNN_OK;
+    if (g.K <= 0) return TMPNN_OK;
+    int kper;
+    const int ns = splitk_plan(g.K, &kper);
+    if (ws_floats < (size_t)ns * g.M * g.N) return set_error(TMPNN_EWORKSPACE, "gemm_splitk: workspace too small");
+    dim3 grid(ceil_div(g.N, 64), ceil_div(g.M, 64), ns), block(256);
+    hipLaunchKernelGGL(k_gemm, grid, block, 0, st, g, kper, ws);
+    int rc = check_launch("gemm_splitk");
+    if (rc) return rc;
+    // C is dense [M][ldc] here (weight gradients); reduce row by row when ldc != N
+    if (g.ldc == g.N) return launch_reduce_slabs(ws, (size_t)g.M * g.N, ns, g.C, (size_t)g.M * g.N, g.accumulate, st);
+    for (int m = 0; m < g.M; ++m) {
+        rc = launch_reduce_slabs(ws + (size_t)m * g.N, (size_t)g.M * g.N, ns, g.C + (size_t)m * g.ldc, g.N,
+                                 g.accumulate, st);
+        if (rc) return rc;
+    }
+    return TMPNN_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// column sums
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_colsum_partial(const float* __restrict__ src, long ld,
+                                                        const float* __restrict__ mul, long ldm, int rows, int cols,
+                                                        float* __restrict__ part) {
+    __shared__ float red[4][64];
+    const int c = blockIdx.y * 64 + (threadIdx.x & 63);
+    const int slot = threadIdx.x >> 6;
+    const int r0 = blockIdx.x * 1024;
+    const int r1 = min(rows, r0 + 1024);
+    float s = 0.f;
+    if (c < cols)
+        for (int r = r0 + slot; r < r1; r += 4) {
+            float v = src[(size_t)r * ld + c];
+            if (mul) v *= mul[(size_t)r * ldm + c];
+            s += v;
+        }
+    red[slot][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (slot == 0 && c < cols)
+        part[(size_t)blockIdx.x * cols + c] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+
+size_t colsum_ws_floats(int rows, int cols) { return (size_t)ceil_div(rows > 0 ? rows : 1, 1024) * cols; }
+
+int launch_colsum(const float* src, long ld, const float* mul, long ldm, int rows, int cols, float* dst,
+                  int accumulate, float* ws, size_t ws_floats, hipStream_t st) {
+    if (cols <= 0) return TMPNN_OK;
+    if (rows <= 0) {
+        if (!accumulate) (void)hipMemsetAsync(dst, 0, sizeof(float) * cols, st);
+        return TMPNN_OK;
+    }
+    const int nch = ceil_div(rows, 1024);
+    if (ws_floats < (size_t)nch * cols) return set_error(TMPNN_EWORKSPACE, "colsum: workspace too small");
+    hipLaunchKernelGGL(k_colsum_partial, dim3(nch, ceil_div(cols, 64)), dim3(256), 0, st, src, ld, mul, ldm, rows,
+                       cols, ws);
+    int rc = check_launch("colsum_partial");
+    if (rc) return rc;
+    return launch_reduce_slabs(ws, cols, nch, dst, cols, accumulate, st);
+}
+
+// ------------------------------------------------------------------------------------------
+// BatchNorm pieces (segmented).  y [nd][H] = Lin1 output on det rows; all-zero rows give b1.
+// ------------------------------------------------------------------------------------------
+// one block per segment, H threads
+__global__ void k_bn_stats(const float* __restrict__ y, const int32_t* __restrict__ seg_ptr,
+                           const int32_t* __restrict__ seg_cnt, int H, const float* __restrict__ b1,
+                           float* __restrict__ mean, float* __restrict__ rstd) {
+    const int s = blockIdx.x, j = threadIdx.x;
+    const int p0 = seg_ptr[s], p1 = seg_ptr[s + 1];
+    const float cnt = (float)seg_cnt[s];
+    const float nz = cnt - (float)(p1 - p0);      // all-zero rows of the segment
+    const float b = b1[j];
+    float sum = nz * b;
+    for (int i = p0; i < p1; ++i) sum += y[(size_t)i * H + j];
+    const float m = sum / cnt;
+    float sq = nz * (b - m) * (b - m);
+    for (int i = p0; i < p1; ++i) {
+        const float d = y[(size_t)i * H + j] - m;
+        sq += d * d;
+    }
+    const float var = sq / cnt;
+    mean[(size_t)s * H + j] = m;
+    rstd[(size_t)s * H + j] = rsqrtf(var + BN_EPS);
+}
+
+// running statistics: windows are seen one after another in the reference, so the momentum
+// update is applied segment by segment (unbiased variance), one thread per feature.
+__global__ void k_bn_running(const float* __restrict__ mean, const float* __restrict__ rstd,
+                             const int32_t* __restrict__ seg_cnt, int S, int H, float* __restrict__ rm,
+                             float* __restrict__ rv) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= H) return;
+    float m = rm[j], v = rv[j];
+    for (int s = 0; s < S; ++s) {
+        const float cnt = (float)seg_cnt[s];
+        const float r = rstd[(size_t)s * H + j];
+        const float var = 1.0f / (r * r) - BN_EPS;
+        m = (1.0f - BN_MOMENTUM) * m + BN_MOMENTUM * mean[(size_t)s * H + j];
+        v = (1.0f - BN_MOMENTUM) * v + BN_MOMENTUM * var * (cnt / (cnt - 1.0f));
+    }
+    rm[j] = m;
+    rv[j] = v;
+}
+
+__device__ __forceinline__ int seg_of(const int32_t* __restrict__ seg_ptr, int S, int i) {
+    int lo = 0, hi = S - 1;            // last s with seg_ptr[s] <= i
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (seg_ptr[mid] <= i) lo = mid; else hi = mid - 1;
+    }
+    return lo;
+}
+
+// yhat = (y - mean) * rstd ; a = relu(yhat * gamma + beta).  mean/rstd per segment (training) or
+// running (eval: seg_ptr == nullptr, mean/rstd hold one row).
+__global__ void k_bn_apply(const float* __restrict__ y, int nd, int H, const int32_t* __restrict__ seg_ptr, int S,
+                           const float* __restrict__ mean, const float* __restrict__ rstd,
+                           const float* __restrict__ gamma, const float* __restrict__ beta,
+                           float* __restrict__ yhat_out, float* __restrict__ a_out) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)nd * H) return;
+    const int i = (int)(idx / H), j = (int)(idx % H);
+    const int s = seg_ptr ? seg_of(seg_ptr, S, i) : 0;
+    const float yh = (y[idx] - mean[(size_t)s * H + j]) * rstd[(size_t)s * H + j];
+    if (yhat_out) yhat_out[idx] = yh;
+    if (a_out) a_out[idx] = fmaxf(yh * gamma[j] + beta[j], 0.f);
+}
+
+__global__ void k_running_to_stats(const float* __restrict__ rm, const float* __restrict__ rv, int H,
+                                   float* __restrict__ mean, float* __restrict__ rstd) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= H) return;
+    mean[j] = rm[j];
+    rstd[j] = rsqrtf(rv[j] + BN_EPS);
+}
+
+// dyhat = da * (yhat*gamma+beta > 0) * gamma   (in place over da); dz (= da*mask) is written to dz_out
+__global__ void k_bn_bwd_act(float* __restrict__ da, const float* __restrict__ yhat, int nd, int H,
+                             const float* __restrict__ gamma, const float* __restrict__ beta,
+                             float* __restrict__ dz_out) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)nd * H) return;
+    const int j = (int)(idx % H);
+    const float pre = yhat[idx] * gamma[j] + beta[j];
+    const float dz = pre > 0.f ? da[idx] : 0.f;
+    dz_out[idx] = dz;
+    da[idx] = dz * gamma[j];
+}
+
+// per segment: s1 = sum dyhat, s2 = sum dyhat*yhat (zero rows contribute nothing: their output is
+// masked, track_mpnn.py:61).  Then s1 <- dy0, the gradient wrt the Lin1 output of a zero row.
+__global__ void k_bn_bwd_seg(const float* __restrict__ dyhat, const float* __restrict__ yhat,
+                             const int32_t* __restrict__ seg_ptr, const int32_t* __restrict__ seg_cnt, int H,
+                             const float* __restrict__ b1, const float* __restrict__ mean,
+                             const float* __restrict__ rstd, float* __restrict__ s1, float* __restrict__ s2) {
+    const int s = blockIdx.x, j = threadIdx.x;
+    const int p0 = seg_ptr[s], p1 = seg_ptr[s + 1];
+    float a = 0.f, b = 0.f;
+    for (int i = p0; i < p1; ++i) {
+        const float d = dyhat[(size_t)i * H + j];
+        a += d;
+        b += d * yhat[(size_t)i * H + j];
+    }
+    s1[(size_t)s * H + j] = a;
+    s2[(size_t)s * H + j] = b;
+}
+
+// dy_i = rstd/cnt * (cnt*dyhat_i - s1 - yhat_i*s2)  (in place over dyhat)
+__global__ void k_bn_bwd_dy(float* __restrict__ dyhat, const float* __restrict__ yhat, int nd, int H,
+                            const int32_t* __restrict__ seg_ptr, const int32_t* __restrict__ seg_cnt, int S,
+                            const float* __restrict__ rstd, const float* __restrict__ s1,
+                            const float* __restrict__ s2, int training) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)nd * H) return;
+    const int i = (int)(idx / H), j = (int)(idx % H);
+    if (!training) {
+        dyhat[idx] *= rstd[j];
+        return;
+    }
+    const int s = seg_of(seg_ptr, S, i);
+    const float cnt = (float)seg_cnt[s];
+    const size_t sj = (size_t)s * H + j;
+    dyhat[idx] = rstd[sj] / cnt * (cnt * dyhat[idx] - s1[sj] - yhat[idx] * s2[sj]);
+}
+
+// dy0[s][j] = rstd/cnt * (-s1 - yhat0*s2), yhat0 = (b1 - mean)*rstd ; written over s1.
+// zsum[j] = sum_s (cnt_s - nd_s) * dy0[s][j]  is added to db1 by the caller via colsum of `s2` <- nz*dy0.
+__global__ void k_bn_bwd_dy0(float* __restrict__ s1, float* __restrict__ s2, const int32_t* __restrict__ seg_ptr,
+                             const int32_t* __restrict__ seg_cnt, int S, int H, const float* __restrict__ b1,
+                             const float* __restrict__ mean, const float* __restrict__ rstd) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)S * H) return;
+    const int s = (int)(idx / H), j = (int)(idx % H);
+    const float cnt = (float)seg_cnt[s];
+    const float nz = cnt - (float)(seg_ptr[s + 1] - seg_ptr[s]);
+    const float yh0 = (b1[j] - mean[idx]) * rstd[idx];
+    const float dy0 = rstd[idx] / cnt * (-s1[idx] - yh0 * s2[idx]);
+    s1[idx] = dy0;
+    s2[idx] = nz * dy0;
+}
+
+__global__ void k_gather_rows(const float* __restrict__ src, long ld, const int32_t* __restrict__ rows, int n, int H,
+                              float* __restrict__ dst) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)n * H) return;
+    const int i = (int)(idx / H), j = (int)(idx % H);
+    dst[idx] = src[(size_t)rows[i] * ld + j];
+}
+
+// ------------------------------------------------------------------------------------------
+// heads
+// ------------------------------------------------------------------------------------------
+// 16 lanes per row, float4 chunks
+__global__ __launch_bounds__(256) void k_heads_fwd(const float* __restrict__ h, int ld_h, int C, int N,
+                                                   const uint8_t* __restrict__ is_edge,
+                                                   const float* __restrict__ w_node, const float* __restrict__ b_node,
+                                                   const float* __restrict__ w_edge, const float* __restrict__ b_edge,
+                                                   float* __restrict__ logits, float* __restrict__ scores) {
+    const int sub = threadIdx.x & 15;
+    const long rows_per_pass = (long)gridDim.x * 16;
+    for (long i = (long)blockIdx.x * 16 + (threadIdx.x >> 4); i < N; i += rows_per_pass) {
+        const bool e = is_edge[i] != 0;
+        const float* w = e ? w_edge : w_node;
+        const float* hr = h + (size_t)i * ld_h;
+        float s = 0.f;
+        for (int c4 = sub * 4; c4 < C; c4 += 64) {
+            const float4 x = *reinterpret_cast<const float4*>(hr + c4);
+            const float4 ww = *reinterpret_cast<const float4*>(w + c4);
+            s += x.x * ww.x + x.y * ww.y + x.z * ww.z + x.w * ww.w;
+        }
+        s += __shfl_xor(s, 8);
+        s += __shfl_xor(s, 4);
+        s += __shfl_xor(s, 2);
+        s += __shfl_xor(s, 1);
+        if (sub == 0) {
+            const float y = s + (e ? b_edge[0] : b_node[0]);
+            logits[i] = y;
+            scores[i] = 1.0f / (1.0f + expf(-y));
+        }
+    }
+}
+
+// d_h[i] (+)= dy_i * w_type ; per-block partial dw_node/dw_edge [C], db_node, db_edge
+// block = 256 threads: cpt = C/4 threads per row (float4), slots = 256/cpt rows per pass.
+// partial layout per block: [2][C] then [2]
+__global__ __launch_bounds__(256) void k_heads_bwd(const float* __restrict__ h, int ld_h, int C, int N,
+                                                   const uint8_t* __restrict__ is_edge,
+                                                   const float* __restrict__ w_node, const float* __restrict__ w_edge,
+                                                   const float* __restrict__ scores, const float* __restrict__ d_logits,
+                                                   const float* __restrict__ d_scores, float* __restrict__ d_h,
+                                                   int ld_dh, int accumulate, int rows_per_block,
+                                                   float* __restrict__ part) {
+    extern __shared__ float sm[];          // [slots][2][C] + [slots][2]
+    const int cpt = C >> 2;
+    const int slots = 256 / cpt;
+    const int slot = threadIdx.x / cpt;
+    const int c4 = (threadIdx.x % cpt) * 4;
+    const bool active = slot < slots;
+    float4 an = make_float4(0.f, 0.f, 0.f, 0.f), ae = an;
+    float bn = 0.f, be = 0.f;
+    const long r0 = (long)blockIdx.x * rows_per_block;
+    const long r1 = min((long)N, r0 + rows_per_block);
+    if (active) {
+        for (long i = r0 + slot; i < r1; i += slots) {
+            float dy = d_logits ? d_logits[i] : 0.f;
+            if (d_scores) {
+                const float s = scores[i];
+                dy += d_scores[i] * s * (1.0f - s);
+            }
+            const bool e = is_edge[i] != 0;
+            const float4 w = *reinterpret_cast<const float4*>((e ? w_edge : w_node) + c4);
+            const float4 x = *reinterpret_cast<const float4*>(h + (size_t)i * ld_h + c4);
+            float* dp = d_h + (size_t)i * ld_dh + c4;
+            float4 o = make_float4(dy * w.x, dy * w.y, dy * w.z, dy * w.w);
+            if (accumulate) {
+                const float4 p = *reinterpret_cast<const float4*>(dp);
+                o.x += p.x; o.y += p.y; o.z += p.z; o.w += p.w;
+            }
+            *reinterpret_cast<float4*>(dp) = o;
+            if (e) { ae.x += dy * x.x; ae.y += dy * x.y; ae.z += dy * x.z; ae.w += dy * x.w; if (c4 == 0) be += dy; }
+            else   { an.x += dy * x.x; an.y += dy * x.y; an.z += dy * x.z; an.w += dy * x.w; if (c4 == 0) bn += dy; }
+        }
+        float* my = sm + (size_t)slot * 2 * C;
+        *reinterpret_cast<float4*>(my + c4) = an;
+        *reinterpret_cast<float4*>(my + C + c4) = ae;
+        if (c4 == 0) {
+            sm[(size_t)slots * 2 * C + slot * 2 + 0] = bn;
+            sm[(size_t)slots * 2 * C + slot * 2 + 1] = be;
+        }
+    }
+    __syncthreads();
+    float* out = part + (size_t)blockIdx.x * (2 * C + 2);
+    for (int j = threadIdx.x; j < 2 * C + 2; j += 256) {
+        float s = 0.f;
+        if (j < 2 * C) for (int k = 0; k < slots; ++k) s += sm[(size_t)k * 2 * C + j];
+        else for (int k = 0; k < slots; ++k) s += sm[(size_t)slots * 2 * C + k * 2 + (j - 2 * C)];
+        out[j] = s;
+    }
+}
+
+__global__ void k_heads_bwd_final(const float* __restrict__ part, int nblk, int C, float* __restrict__ dw_node,
+                                  float* __restrict__ db_node, float* __restrict__ dw_edge,
+                                  float* __restrict__ db_edge) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= 2 * C + 2) return;
+    float s = 0.f;
+    for (int k = 0; k < nblk; ++k) s += part[(size_t)k * (2 * C + 2) + j];
+    if (j < C) dw_node[j] += s;
+    else if (j < 2 * C) dw_edge[j - C] += s;
+    else if (j == 2 * C) db_node[0] += s;
+    else db_edge[0] += s;
+}
+
+static int heads_rows_per_block(int N) {
+    long rpb = ((long)N + 1023) / 1024;     // at most 1024 partial blocks
+    if (rpb < 64) rpb = 64;
+    return (int)rpb;
+}
+
+}  // namespace tmpnn
+
+using namespace tmpnn;
+
+extern "C" {
+
+int tmpnn_input_bn_fwd(const float* xdet, int ld_x, int F, int nd, const int32_t* seg_ptr, const int32_t* seg_cnt,
+                       int S, int H, int training, const float* w1, const float* b1, const float* gamma,
+                       const float* beta, float* running_mean, float* running_var, const float* w2, const float* b2,
+                       float* y_save, float* mean, float* rstd, float* ws_a, const int32_t* out_row, float* h_new,
+                       int ld_h, tmpnn_stream stream) {
+    TM_REQUIRE(supported_H(H), "input_bn_fwd: unsupported H=%d", H);
+    TM_REQUIRE(F > 0 && nd >= 0 && S >= 0, "input_bn_fwd: F=%d nd=%d S=%d", F, nd, S);
+    TM_REQUIRE(w1 && b1 && gamma && beta && running_mean && running_var && w2 && b2 && mean && rstd,
+               "input_bn_fwd: null parameter pointer");
+    TM_REQUIRE(!training || (seg_ptr && seg_cnt && S > 0), "input_bn_fwd: training needs segments");
+    hipStream_t st = as_stream(stream);
+    int rc;
+    if (nd > 0) {
+        TM_REQUIRE(xdet && y_save && ws_a && out_row && h_new && ld_x >= F && ld_h >= H, "input_bn_fwd: null/short buffers");
+        GemmArgs g{xdet, ld_x, 1, nullptr, nullptr, w1, 1, F, b1, y_save, H, nullptr, nd, H, F, 0};   // y = x W1^T + b1
+        if ((rc = launch_gemm(g, st))) return rc;
+    }
+    if (training) {
+        hipLaunchKernelGGL(k_bn_stats, dim3(S), dim3(H), 0, st, y_save, seg_ptr, seg_cnt, H, b1, mean, rstd);
+        if ((rc = check_launch("bn_stats"))) return rc;
+        hipLaunchKernelGGL(k_bn_running, dim3(ceil_div(H, 64)), dim3(64), 0, st, mean, rstd, seg_cnt, S, H,
+                           running_mean, running_var);
+        if ((rc = check_launch("bn_running"))) return rc;
+    } else {
+        hipLaunchKernelGGL(k_running_to_stats, dim3(ceil_div(H, 64)), dim3(64), 0, st, running_mean, running_var, H,
+                           mean, rstd);
+        if ((rc = check_launch("running_to_stats"))) return rc;
+    }
+    if (nd == 0) return TMPNN_OK;
+    hipLaunchKernelGGL(k_bn_apply, dim3(ceil_div((long)nd * H, 256)), dim3(256), 0, st, y_save, nd, H,
+                       training ? seg_ptr : nullptr, S, mean, rstd, gamma, beta, (float*)nullptr, ws_a);
+    if ((rc = check_launch("bn_apply"))) return rc;
+    GemmArgs g2{ws_a, H, 1, nullptr, nullptr, w2, 1, H, b2, h_new, ld_h, out_row, nd, H, H, 0};        // out = a W2^T + b2
+    return launch_gemm(g2, st);
+}
+
+int tmpnn_input_bn_bwd(const float* xdet, int ld_x, int F, int nd, const int32_t* seg_ptr, const int32_t* seg_cnt,
+                       int S, int H, int training, const float* w1, const float* b1, const float* gamma,
+                       const float* beta, const float* w2, const float* y_save, const float* mean, const float* rstd,
+                       const int32_t* out_row, const float* d_h, int ld_dh, float* d_xdet, int ld_dx, float* d_xzero,
+                       float* dw1, float* db1, float* dgamma, float* dbeta, float* dw2, float* db2, float* ws,
+                       size_t ws_floats, tmpnn_stream stream) {
+    TM_REQUIRE(supported_H(H), "input_bn_bwd: unsupported H=%d", H);
+    TM_REQUIRE(F > 0 && nd >= 0 && S >= 0, "input_bn_bwd: F=%d nd=%d S=%d", F, nd, S);
+    TM_REQUIRE(w1 && b1 && gamma && beta && w2 && mean && rstd && dw1 && db1 && dgamma && dbeta && dw2 && db2,
+               "input_bn_bwd: null parameter pointer");
+    hipStream_t st = as_stream(stream);
+    if (nd == 0) {
+        if (d_xzero && S > 0) (void)hipMemsetAsync(d_xzero, 0, sizeof(float) * (size_t)S * F, st);
+        return TMPNN_OK;   // no det rows: nothing reaches the loss through this transform
+    }
+    TM_REQUIRE(xdet && y_save && out_row && d_h && ws, "input_bn_bwd: null buffers");
+    const size_t ndH = (size_t)nd * H, SH = (size_t)(S > 0 ? S : 1) * H;
+    const size_t cs_ws = colsum_ws_floats(nd, H);
+    size_t gk = gemm_splitk_ws_floats(H, H, nd);
+    const size_t gk1 = gemm_splitk_ws_floats(H, F, nd);
+    if (gk1 > gk) gk = gk1;
+    const size_t need = 3 * ndH + 2 * SH + (cs_ws > gk ? cs_ws : gk);
+    if (ws_floats < need) return set_error(TMPNN_EWORKSPACE, "input_bn_bwd: workspace %zu < %zu floats", ws_floats, need);
+    float* B0 = ws;              // d_out -> dy
+    float* B1 = B0 + ndH;        // yhat
+    float* B2 = B1 + ndH;        // a -> da -> dyhat
+    float* s1 = B2 + ndH;        // [S][H]
+    float* s2 = s1 + SH;
+    float* scratch = s2 + SH;
+    const size_t scratch_n = ws_floats - (3 * ndH + 2 * SH);
+    const int gridE = ceil_div((long)ndH, 256);
+    int rc;
+    hipLaunchKernelGGL(k_gather_rows, dim3(gridE), dim3(256), 0, st, d_h, (long)ld_dh, out_row, nd, H, B0);
+    if ((rc = check_launch("gather_rows"))) return rc;
+    hipLaunchKernelGGL(k_bn_apply, dim3(gridE), dim3(256), 0, st, y_save, nd, H, training ? seg_ptr : nullptr, S, mean,
+                       rstd, gamma, beta, B1, B2);
+    if ((rc = check_launch("bn_apply"))) return rc;
+    // dW2 += d_out^T a ; db2 += colsum(d_out)
+    {
+        GemmArgs g{B0, 1, H, nullptr, nullptr, B2, H, 1, nullptr, dw2, H, nullptr, H, H, nd, 1};
+        if ((rc = launch_gemm_splitk(g, scratch, scratch_n, st))) return rc;
+        if ((rc = launch_colsum(B0, H, nullptr, 0, nd, H, db2, 1, scratch, scratch_n, st))) return rc;
+    }
+    // da = d_out W2  -> B2
+    {
+        GemmArgs g{B0, H, 1, nullptr, nullptr, w2, H, 1, nullptr, B2, H, nullptr, nd, H, H, 0};
+        if ((rc = launch_gemm(g, st))) return rc;
+    }
+    // dz = da*mask -> B0 ; dyhat = dz*gamma -> B2 ; dgamma += sum dz*yhat ; dbeta += sum dz
+    hipLaunchKernelGGL(k_bn_bwd_act, dim3(gridE), dim3(256), 0, st, B2, B1, nd, H, gamma, beta, B0);
+    if ((rc = check_launch("bn_bwd_act"))) return rc;
+    if ((rc = launch_colsum(B0, H, B1, H, nd, H, dgamma, 1, scratch, scratch_n, st))) return rc;
+    if ((rc = launch_colsum(B0, H, nullptr, 0, nd, H, dbeta, 1, scratch, scratch_n, st))) return rc;
+    if (training) {
+        hipLaunchKernelGGL(k_bn_bwd_seg, dim3(S), dim3(H), 0, st, B2, B1, seg_ptr, seg_cnt, H, b1, mean, rstd, s1, s2);
+        if ((rc = check_launch("bn_bwd_seg"))) return rc;
+    }
+    hipLaunchKernelGGL(k_bn_bwd_dy, dim3(gridE), dim3(256), 0, st, B2, B1, nd, H, seg_ptr, seg_cnt, S, rstd, s1, s2,
+                       training);
+    if ((rc = check_launch("bn_bwd_dy"))) return rc;
+    // now B2 = dy (det rows)
+    // dW1 += dy^T x ; db1 += colsum(dy) (+ zero-row part below) ; d_xdet = dy W1
+    {
+        GemmArgs g{B2, 1, H, nullptr, nullptr, xdet, ld_x, 1, nullptr, dw1, F, nullptr, H, F, nd, 1};
+        if ((rc = launch_gemm_splitk(g, scratch, scratch_n, st))) return rc;
+        if ((rc = launch_colsum(B2, H, nullptr, 0, nd, H, db1, 1, scratch, scratch_n, st))) return rc;
+        if (d_xdet) {
+            GemmArgs gx{B2, H, 1, nullptr, nullptr, w1, F, 1, nullptr, d_xdet, ld_dx, nullptr, nd, F, H, 0};
+            if ((rc = launch_gemm(gx, st))) return rc;
+        }
+    }
+    if (training) {
+        hipLaunchKernelGGL(k_bn_bwd_dy0, dim3(ceil_div((long)S * H, 256)), dim3(256), 0, st, s1, s2, seg_ptr, seg_cnt,
+                           S, H, b1, mean, rstd);
+        if ((rc = check_launch("bn_bwd_dy0"))) return rc;
+        // db1 += sum_s nz_s * dy0_s ; d_xzero = dy0 W1
+        const size_t cs2 = colsum_ws_floats(S, H);
+        if (scratch_n < cs2) return set_error(TMPNN_EWORKSPACE, "input_bn_bwd: workspace too small for segments");
+        if ((rc = launch_colsum(s2, H, nullptr, 0, S, H, db1, 1, scratch, scratch_n, st))) return rc;
+        if (d_xzero) {
+            GemmArgs gz{s1, H, 1, nullptr, nullptr, w1, F, 1, nullptr, d_xzero, F, nullptr, S, F, H, 0};
+            if ((rc = launch_gemm(gz, st))) return rc;
+        }
+    } else if (d_xzero && S > 0) {
+        (void)hipMemsetAsync(d_xzero, 0, sizeof(float) * (size_t)S * F, st);
+    }
+    return TMPNN_OK;
+}
+
+size_t tmpnn_input_bn_bwd_ws(int nd, int S, int H, int F) {
+    if (nd <= 0) return 0;
+    const size_t ndH = (size_t)nd * H, SH = (size_t)(S > 0 ? S : 1) * H;
+    size_t x = colsum_ws_floats(nd, H);
+    const size_t a = gemm_splitk_ws_floats(H, H, nd), b = gemm_splitk_ws_floats(H, F, nd),
+                 c = colsum_ws_floats(S > 0 ? S : 1, H);
+    if (a > x) x = a;
+    if (b > x) x = b;
+    if (c > x) x = c;
+    return 3 * ndH + 2 * SH + x;
+}
+
+int tmpnn_heads_fwd(const float* h, int ld_h, int C, int N, const uint8_t* is_edge, const float* w_node,
+                    const float* b_node, const float* w_edge, const float* b_edge, float* logits, float* scores,
+                    tmpnn_stream stream) {
+    TM_REQUIRE(C > 0 && (C & 3) == 0 && N >= 0, "heads_fwd: C=%d N=%d", C, N);
+    if (N == 0) return TMPNN_OK;
+    TM_REQUIRE(h && is_edge && w_node && b_node && w_edge && b_edge && logits && scores, "heads_fwd: null pointer");
+    TM_REQUIRE(ld_h >= C && (ld_h & 3) == 0 && aligned16(h) && aligned16(w_node) && aligned16(w_edge),
+               "heads_fwd: rows must be 16-byte aligned");
+    long b = ((long)N + 15) / 16;
+    if (b > 4096) b = 4096;
+    hipLaunchKernelGGL(k_heads_fwd, dim3((int)b), dim3(256), 0, as_stream(stream), h, ld_h, C, N, is_edge, w_node,
+                       b_node, w_edge, b_edge, logits, scores);
+    return check_launch("heads_fwd");
+}
+
+size_t tmpnn_heads_bwd_ws(int N, int C) {
+    if (N <= 0) return 0;
+    const int rpb = heads_rows_per_block(N);
+    const int nblk = ceil_div(N, rpb);
+    return (size_t)nblk * (2 * C + 2) * sizeof(float);
+}
+
+int tmpnn_heads_bwd(const float* h, int ld_h, int C, int N, const uint8_t* is_edge, const float* w_node,
+                    const float* w_edge, const float* scores, const float* d_logits, const float* d_scores,
+                    float* d_h, int ld_dh, int accumulate, float* dw_node, float* db_node, float* dw_edge,
+                    float* db_edge, void* ws, size_t ws_bytes, tmpnn_stream stream) {
+    TM_REQUIRE(C > 0 && (C & 3) == 0 && C <= 1024 && N >= 0, "heads_bwd: C=%d N=%d", C, N);
+    if (N == 0) return TMPNN_OK;
+    TM_REQUIRE(h && is_edge && w_node && w_edge && d_h && dw_node && db_node && dw_edge && db_edge,
+               "heads_bwd: null pointer");
+    TM_REQUIRE(d_scores == nullptr || scores != nullptr, "heads_bwd: d_scores needs scores");
+    TM_REQUIRE((ld_h & 3) == 0 && (ld_dh & 3) == 0 && aligned16(h) && aligned16(d_h) && aligned16(w_node) &&
+                   aligned16(w_edge),
+               "heads_bwd: rows must be 16-byte aligned");
+    const size_t need = tmpnn_heads_bwd_ws(N, C);
+    if (!ws || ws_bytes < need) return set_error(TMPNN_EWORKSPACE, "heads_bwd: workspace %zu < %zu", ws_bytes, need);
+    const int rpb = heads_rows_per_block(N);
+    const int nblk = ceil_div(N, rpb);
+    const int cpt = C >> 2;
+    TM_REQUIRE(cpt <= 256, "heads_bwd: C too wide");
+    const int slots = 256 / cpt;
+    const size_t shm = ((size_t)slots * 2 * C + (size_t)slots * 2) * sizeof(float);
+    hipStream_t st = as_stream(stream);
+    hipLaunchKernelGGL(k_heads_bwd, dim3(nblk), dim3(256), shm, st, h, ld_h, C, N, is_edge, w_node, w_edge, scores,
+                       d_logits, d_scores, d_h, ld_dh, accumulate, rpb, reinterpret_cast<float*>(ws));
+    int rc = check_launch("heads_bwd");
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_heads_bwd_final, dim3(ceil_div(2 * C + 2, 256)), dim3(256), 0, st,
+                       reinterpret_cast<const float*>(ws), nblk, C, dw_node, db_node, dw_edge, db_edge);
+    return check_launch("heads_bwd_final");
+}
+
+}  // extern "C"

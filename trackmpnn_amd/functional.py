@@ -1,0 +1,368 @@
+"""One TrackMPNN message-passing call (reference/models/track_mpnn.py:54-75) on the HIP kernels.
+
+`mp_forward` / `mp_backward` sequence the C-ABI stages of include/tmpnn.h on the current HIP
+stream; `MPIteration` wraps them in a torch.autograd.Function so that the carried hidden state
+`h_in` (BPTT over a chunk, reference/train.py:104-107,132-135), the new-row features `x` and every
+parameter receive gradients exactly as in the reference.  torch is used for memory, streams and
+index plumbing only -- every flop of the path runs in libtmpnn.so, and there is no fallback.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib
+from .graph import CallPlan
+
+ATT_DROPOUT_P = 0.5
+
+
+@dataclass(frozen=True)
+class ModelSpec:
+    groups: Tuple[Tuple[str, int], ...]   # (name, F_g)
+    H: int
+    K: int
+    msg_type: str
+
+    @property
+    def G(self) -> int:
+        return len(self.groups)
+
+    @property
+    def IN_e(self) -> int:
+        return 2 * self.H if self.msg_type == 'concat' else self.H
+
+    @property
+    def F_total(self) -> int:
+        return sum(f for _, f in self.groups)
+
+    def param_names(self) -> List[str]:
+        """state_dict names of every nn.Parameter, in the order MPIteration takes them."""
+        names = []
+        for g in range(self.G):
+            t = f'input_transforms.{g}.'
+            names += [t + '0.weight', t + '0.bias', t + '1.weight', t + '1.bias', t + '3.weight', t + '3.bias']
+        for g in range(self.G):
+            f = f'factor_grus.{g}.'
+            names += [f + 'edge_gru.weight_ih', f + 'edge_gru.weight_hh', f + 'edge_gru.bias_ih', f + 'edge_gru.bias_hh']
+            for k in range(self.K):
+                names += [f + f'gat.{k}.W_att', f + f'gat.{k}.a']
+            names += [f + 'node_gru.weight_ih', f + 'node_gru.weight_hh', f + 'node_gru.bias_ih', f + 'node_gru.bias_hh']
+        names += ['output_transform_node.weight', 'output_transform_node.bias',
+                  'output_transform_edge.weight', 'output_transform_edge.bias']
+        return names
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _require_device(t: torch.Tensor, what: str):
+    if not t.is_cuda:
+        raise RuntimeError(f'{what} is on {t.device}: trackmpnn_amd runs on the MI355X HIP kernels only '
+                           '(no CPU or torch fallback exists)')
+
+
+def _f32c(t: torch.Tensor) -> torch.Tensor:
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _transpose(w: torch.Tensor) -> torch.Tensor:
+    out = torch.empty((w.shape[1], w.shape[0]), dtype=torch.float32, device=w.device)
+    _lib.call('tmpnn_transpose', w.data_ptr(), w.shape[0], w.shape[1], out.data_ptr(), _stream())
+    return out
+
+
+def mp_forward(spec: ModelSpec, plan: CallPlan, x: torch.Tensor, h_in: Optional[torch.Tensor],
+               P: Dict[str, torch.Tensor], buffers: Dict[str, torch.Tensor], training: bool, save: bool,
+               keep: Optional[Sequence[torch.Tensor]] = None):
+    """Returns (scores [N,1], logits [N,1], h_out [N,G*H], alphas, saved)."""
+    g = plan.graph
+    H, G, K = spec.H, spec.G, spec.K
+    GH = G * H
+    N, E, Dn = g.N, g.E, g.Dn
+    n = plan.n_new
+    N_old = N - n
+    dev = x.device
+    st = _stream()
+    if h_in is None:
+        if N_old != 0:
+            raise ValueError(f'h_in is None but the graph has {N_old} rows that are not new')
+    else:
+        if h_in.shape[0] != N_old or h_in.shape[1] != GH:
+            raise ValueError(f'h_in must be [{N_old}, {GH}] (N - n, G*H), got {tuple(h_in.shape)}')
+    if x.shape[0] != n or (n > 0 and x.shape[1] != spec.F_total):
+        raise ValueError(f'x must be [{n}, {spec.F_total}], got {tuple(x.shape)}')
+
+    opts = dict(dtype=torch.float32, device=dev)
+    h_cat = torch.empty((N, GH), **opts)
+    if N_old > 0:
+        h_cat[:N_old].copy_(h_in)
+    saved = dict(n=n)
+    if n > 0:
+        h_cat[N_old:].zero_()                       # new edge rows start at 0 (track_mpnn.py:61)
+        nd = int(plan.new_det_row.numel())
+        S = plan.S
+        if training and plan.min_seg_cnt <= 1:
+            # torch.nn.functional.batch_norm refuses a single row in training mode; so does the reference
+            raise ValueError('Expected more than 1 value per channel when training, got input size '
+                             f'[1, {H}]')
+        xdet = _f32c(x.detach().index_select(0, plan.new_det_local)) if nd > 0 else torch.empty((0, spec.F_total), **opts)
+        ws_a = torch.empty((max(nd, 1), H), **opts)
+        y_saves, means, rstds = [], [], []
+        f0 = 0
+        for gi, (_, F) in enumerate(spec.groups):
+            t = f'input_transforms.{gi}.'
+            y_save = torch.empty((max(nd, 1), H), **opts)
+            SS = S if training else 1
+            mean = torch.empty((SS, H), **opts)
+            rstd = torch.empty((SS, H), **opts)
+            _lib.call('tmpnn_input_bn_fwd', xdet.data_ptr() + 4 * f0, spec.F_total, F, nd,
+                      plan.seg_ptr.data_ptr(), plan.seg_cnt.data_ptr(), S, H, int(training),
+                      P[t + '0.weight'].data_ptr(), P[t + '0.bias'].data_ptr(),
+                      P[t + '1.weight'].data_ptr(), P[t + '1.bias'].data_ptr(),
+                      buffers[t + '1.running_mean'].data_ptr(), buffers[t + '1.running_var'].data_ptr(),
+                      P[t + '3.weight'].data_ptr(), P[t + '3.bias'].data_ptr(),
+                      y_save.data_ptr(), mean.data_ptr(), rstd.data_ptr(), ws_a.data_ptr(),
+                      plan.new_det_row.data_ptr(), h_cat.data_ptr() + 4 * gi * H, GH, st)
+            if training:
+                buffers[t + '1.num_batches_tracked'] += S
+            y_saves.append(y_save)
+            means.append(mean)
+            rstds.append(rstd)
+            f0 += F
+        if save:
+            saved.update(xdet=xdet, y_save=y_saves, mean=means, rstd=rstds)
+
+    h_out = torch.empty((N, GH), **opts)
+    gates = torch.empty((G, 4, N, H), **opts) if save else None
+    es_all = torch.empty((G, max(Dn, 1), H), **opts)
+    alphas: List[Optional[List[torch.Tensor]]] = []
+    att_saved = []
+    xmode = 2 if spec.msg_type == 'concat' else 1
+    plane = N * H
+    for gi in range(G):
+        f = f'factor_grus.{gi}.'
+        hg = h_cat.data_ptr() + 4 * gi * H
+        og = h_out.data_ptr() + 4 * gi * H
+        gp = gates[gi].data_ptr() if save else None
+        # edge update: GRU(h[src]-h[dst] | concat, h[e])      (layers.py:90-97)
+        # (temporaries stay referenced until their consumer is enqueued: the caching allocator may
+        #  hand a freed block to the very next allocation)
+        e_wih_t, e_whh_t = _transpose(P[f + 'edge_gru.weight_ih']), _transpose(P[f + 'edge_gru.weight_hh'])
+        n_wih_t, n_whh_t = _transpose(P[f + 'node_gru.weight_ih']), _transpose(P[f + 'node_gru.weight_hh'])
+        _lib.call('tmpnn_gru_fwd', g.edge_row.data_ptr(), E, xmode, g.src.data_ptr(), g.dst.data_ptr(),
+                  None, 0, 0, spec.IN_e, hg, GH, H,
+                  e_wih_t.data_ptr(), e_whh_t.data_ptr(),
+                  P[f + 'edge_gru.bias_ih'].data_ptr(), P[f + 'edge_gru.bias_hh'].data_ptr(),
+                  og, GH, gp, plane, st)
+        # edge -> node aggregation                              (layers.py:99-112)
+        es = es_all[gi]
+        if K == 0:
+            _lib.call('tmpnn_segsum_fwd', g.cref(), hg, GH, es.data_ptr(), H, H, 0, 1, st)
+            alphas.append(None)
+        else:
+            W = torch.stack([P[f + f'gat.{k}.W_att'] for k in range(K)]).contiguous()
+            a = torch.stack([P[f + f'gat.{k}.a'].reshape(-1) for k in range(K)]).contiguous()
+            ws_ha = torch.empty((K, max(Dn, 1), H), **opts)
+            score = torch.zeros((K, max(N, 1)), **opts)
+            alpha = torch.empty((K, max(2 * E, 1)), **opts)
+            kp = None
+            if training:
+                if keep is None or keep[gi] is None:
+                    kp = (torch.rand((K, max(2 * E, 1)), device=dev) >= ATT_DROPOUT_P).to(torch.uint8)
+                else:
+                    kp = keep[gi].to(torch.uint8).contiguous()
+            _lib.call('tmpnn_att_fwd', g.cref(), g.pos.data_ptr(), hg, GH, H, K, W.data_ptr(), a.data_ptr(),
+                      _lib.ptr(kp), ATT_DROPOUT_P, ws_ha.data_ptr(), score.data_ptr(), alpha.data_ptr(),
+                      es.data_ptr(), H, st)
+            alphas.append([alpha[k, :2 * E] for k in range(K)])
+            att_saved.append((W, a, kp, ws_ha, score, alpha))
+        # node update: GRU(es, h[d])                            (layers.py:114)
+        _lib.call('tmpnn_gru_fwd', g.det_row.data_ptr(), Dn, 0, None, None,
+                  es.data_ptr(), H, 1, H, hg, GH, H,
+                  n_wih_t.data_ptr(), n_whh_t.data_ptr(),
+                  P[f + 'node_gru.bias_ih'].data_ptr(), P[f + 'node_gru.bias_hh'].data_ptr(),
+                  og, GH, gp, plane, st)
+    logits = torch.empty((N, 1), **opts)
+    scores = torch.empty((N, 1), **opts)
+    _lib.call('tmpnn_heads_fwd', h_out.data_ptr(), GH, GH, N, g.is_edge.data_ptr(),
+              P['output_transform_node.weight'].data_ptr(), P['output_transform_node.bias'].data_ptr(),
+              P['output_transform_edge.weight'].data_ptr(), P['output_transform_edge.bias'].data_ptr(),
+              logits.data_ptr(), scores.data_ptr(), st)
+    if save:
+        saved.update(h_cat=h_cat, gates=gates, es=es_all, att=att_saved, h_out=h_out, scores=scores)
+    return scores, logits, h_out, alphas, saved
+
+
+def mp_backward(spec: ModelSpec, plan: CallPlan, saved: dict, P: Dict[str, torch.Tensor], training: bool,
+                d_scores: Optional[torch.Tensor], d_logits: Optional[torch.Tensor], d_hout: Optional[torch.Tensor],
+                need_x: bool, need_h: bool):
+    """Returns (d_x | None, d_h_in | None, {param name: grad})."""
+    g = plan.graph
+    H, G, K = spec.H, spec.G, spec.K
+    GH = G * H
+    N, E, Dn = g.N, g.E, g.Dn
+    n = saved['n']
+    N_old = N - n
+    h_cat, gates, es_all, h_out = saved['h_cat'], saved['gates'], saved['es'], saved['h_out']
+    dev = h_cat.device
+    st = _stream()
+    opts = dict(dtype=torch.float32, device=dev)
+    grads = {name: torch.zeros_like(P[name], dtype=torch.float32) for name in spec.param_names()}
+
+    # heads (track_mpnn.py:72-75): d_hout_total = d_hout + dy * w_type
+    if d_hout is not None:
+        dh_tot = _f32c(d_hout).clone()
+        acc = 1
+    else:
+        dh_tot = torch.empty((N, GH), **opts)
+        acc = 0
+    if d_scores is None and d_logits is None:
+        if acc == 0:
+            dh_tot.zero_()
+    else:
+        ws_b = _lib.load().tmpnn_heads_bwd_ws(N, GH)
+        ws = torch.empty((max(ws_b // 4, 1),), **opts)
+        dl = _f32c(d_logits) if d_logits is not None else None
+        ds = _f32c(d_scores) if d_scores is not None else None
+        _lib.call('tmpnn_heads_bwd', h_out.data_ptr(), GH, GH, N, g.is_edge.data_ptr(),
+                  P['output_transform_node.weight'].data_ptr(), P['output_transform_edge.weight'].data_ptr(),
+                  saved['scores'].data_ptr(), _lib.ptr(dl), _lib.ptr(ds), dh_tot.data_ptr(), GH, acc,
+                  grads['output_transform_node.weight'].data_ptr(), grads['output_transform_node.bias'].data_ptr(),
+                  grads['output_transform_edge.weight'].data_ptr(), grads['output_transform_edge.bias'].data_ptr(),
+                  ws.data_ptr(), ws_b, st)
+
+    d_hcat = torch.empty((N, GH), **opts)
+    IN_e = spec.IN_e
+    dmsg = torch.empty((N, IN_e), **opts)
+    xmode = 2 if spec.msg_type == 'concat' else 1
+    plane = N * H
+    lib = _lib.load()
+    ws_e = lib.tmpnn_gru_bwd_weights_ws(E, IN_e, H)
+    ws_n = lib.tmpnn_gru_bwd_weights_ws(Dn, H, H)
+    ws_w = torch.empty((max(ws_e, ws_n) // 4 + 1,), **opts)
+    for gi in range(G):
+        f = f'factor_grus.{gi}.'
+        hg = h_cat.data_ptr() + 4 * gi * H
+        dog = dh_tot.data_ptr() + 4 * gi * H
+        dhg = d_hcat.data_ptr() + 4 * gi * H
+        gp = gates[gi].data_ptr()
+        es = es_all[gi]
+        # node GRU backward: d_es -> dmsg[det rows, 0:H], d_hcat[det rows]
+        _lib.call('tmpnn_gru_bwd_data', g.det_row.data_ptr(), Dn, H, hg, GH, H,
+                  P[f + 'node_gru.weight_ih'].data_ptr(), P[f + 'node_gru.weight_hh'].data_ptr(),
+                  gp, plane, dog, GH, dmsg.data_ptr(), IN_e, dhg, GH, st)
+        _lib.call('tmpnn_gru_bwd_weights', g.det_row.data_ptr(), Dn, 0, None, None, es.data_ptr(), H, 1, H,
+                  hg, GH, H, gp, plane, dog, GH,
+                  grads[f + 'node_gru.weight_ih'].data_ptr(), grads[f + 'node_gru.weight_hh'].data_ptr(),
+                  grads[f + 'node_gru.bias_ih'].data_ptr(), grads[f + 'node_gru.bias_hh'].data_ptr(),
+                  ws_w.data_ptr(), ws_w.numel() * 4, st)
+        # edge GRU backward: d_ns -> dmsg[edge rows, 0:IN_e], d_hcat[edge rows]
+        _lib.call('tmpnn_gru_bwd_data', g.edge_row.data_ptr(), E, IN_e, hg, GH, H,
+                  P[f + 'edge_gru.weight_ih'].data_ptr(), P[f + 'edge_gru.weight_hh'].data_ptr(),
+                  gp, plane, dog, GH, dmsg.data_ptr(), IN_e, dhg, GH, st)
+        _lib.call('tmpnn_gru_bwd_weights', g.edge_row.data_ptr(), E, xmode, g.src.data_ptr(), g.dst.data_ptr(),
+                  None, 0, 0, IN_e, hg, GH, H, gp, plane, dog, GH,
+                  grads[f + 'edge_gru.weight_ih'].data_ptr(), grads[f + 'edge_gru.weight_hh'].data_ptr(),
+                  grads[f + 'edge_gru.bias_ih'].data_ptr(), grads[f + 'edge_gru.bias_hh'].data_ptr(),
+                  ws_w.data_ptr(), ws_w.numel() * 4, st)
+        # adjoint of the edge -> node aggregation: into d_hcat[edge rows] (and dets via attention)
+        if K == 0:
+            _lib.call('tmpnn_segsum_bwd', g.cref(), dmsg.data_ptr(), IN_e, dhg, GH, H, 1, st)
+        else:
+            W, a, kp, ws_ha, score, alpha = saved['att'][gi]
+            dW = torch.zeros_like(W)
+            da = torch.zeros_like(a)
+            ws_n_att = lib.tmpnn_att_bwd_ws(E, Dn, H, K)
+            ws_att = torch.empty((max(ws_n_att, 1),), **opts)
+            ws_dha = torch.empty((K, max(Dn, 1), H), **opts)
+            ws_edge = torch.zeros((K, max(N, 1)), **opts)
+            _lib.call('tmpnn_att_bwd', g.cref(), g.pos.data_ptr(), hg, GH, H, K, W.data_ptr(), a.data_ptr(),
+                      _lib.ptr(kp), ATT_DROPOUT_P, ws_ha.data_ptr(), score.data_ptr(), alpha.data_ptr(),
+                      dmsg.data_ptr(), IN_e, ws_att.data_ptr(), ws_att.numel(), ws_dha.data_ptr(), ws_edge.data_ptr(),
+                      dhg, GH, dW.data_ptr(), da.data_ptr(), st)
+            for k in range(K):
+                grads[f + f'gat.{k}.W_att'] = dW[k]
+                grads[f + f'gat.{k}.a'] = da[k].reshape(-1, 1)
+        # adjoint of the node -> edge message: into d_hcat[det rows]
+        name = 'tmpnn_gather_concat_bwd' if spec.msg_type == 'concat' else 'tmpnn_gather_diff_bwd'
+        _lib.call(name, g.cref(), dmsg.data_ptr(), IN_e, dhg, GH, H, 1, st)
+
+    d_x = None
+    if n > 0:
+        nd = int(plan.new_det_row.numel())
+        S = plan.S
+        xdet = saved['xdet']
+        Ft = spec.F_total
+        d_xdet = torch.empty((max(nd, 1), Ft), **opts) if need_x else None
+        d_xzero = torch.empty((max(S, 1), Ft), **opts) if need_x else None
+        f0 = 0
+        for gi, (_, F) in enumerate(spec.groups):
+            t = f'input_transforms.{gi}.'
+            wsn = lib.tmpnn_input_bn_bwd_ws(nd, S, H, F)
+            ws = torch.empty((max(wsn, 1),), **opts)
+            # d_xzero is [S][F] per group: write into a per-group buffer, then place it
+            dz_g = torch.empty((max(S, 1), F), **opts) if need_x else None
+            _lib.call('tmpnn_input_bn_bwd', xdet.data_ptr() + 4 * f0, Ft, F, nd,
+                      plan.seg_ptr.data_ptr(), plan.seg_cnt.data_ptr(), S, H, int(training),
+                      P[t + '0.weight'].data_ptr(), P[t + '0.bias'].data_ptr(),
+                      P[t + '1.weight'].data_ptr(), P[t + '1.bias'].data_ptr(), P[t + '3.weight'].data_ptr(),
+                      saved['y_save'][gi].data_ptr(), saved['mean'][gi].data_ptr(), saved['rstd'][gi].data_ptr(),
+                      plan.new_det_row.data_ptr(), d_hcat.data_ptr() + 4 * gi * H, GH,
+                      (d_xdet.data_ptr() + 4 * f0) if need_x else None, Ft, _lib.ptr(dz_g),
+                      grads[t + '0.weight'].data_ptr(), grads[t + '0.bias'].data_ptr(),
+                      grads[t + '1.weight'].data_ptr(), grads[t + '1.bias'].data_ptr(),
+                      grads[t + '3.weight'].data_ptr(), grads[t + '3.bias'].data_ptr(),
+                      ws.data_ptr(), ws.numel(), st)
+            if need_x:
+                d_xzero[:, f0:f0 + F] = dz_g
+            f0 += F
+        if need_x:
+            # all-zero (edge) rows get the gradient that flows through their segment's batch statistics
+            d_x = d_xzero[:S].index_select(0, plan.seg_of_new) if S > 0 else torch.zeros((n, Ft), **opts)
+            if nd > 0:
+                d_x.index_copy_(0, plan.new_det_local, d_xdet[:nd])
+    elif need_x:
+        d_x = torch.zeros((0, spec.F_total), **opts)
+    d_h_in = d_hcat[:N_old] if (need_h and N_old > 0) else None
+    return d_x, d_h_in, grads
+
+
+class MPIteration(torch.autograd.Function):
+    """autograd node of one forward call.  Inputs: (ctx_obj, x, h_in_or_None, *params)."""
+
+    @staticmethod
+    def forward(ctx, call, x, h_in, *params):
+        spec: ModelSpec = call['spec']
+        names = spec.param_names()
+        P = {nm: _f32c(p.detach()) for nm, p in zip(names, params)}
+        for nm, p in P.items():
+            _require_device(p, nm)
+        need_grad = call['need_grad']
+        scores, logits, h_out, alphas, saved = mp_forward(
+            spec, call['plan'], x.detach(), None if h_in is None else _f32c(h_in.detach()), P, call['buffers'],
+            call['training'], need_grad, call.get('keep'))
+        call['alphas'] = alphas
+        ctx.call = call
+        ctx.saved = saved
+        ctx.P = P
+        ctx.has_h = h_in is not None
+        ctx.set_materialize_grads(False)
+        return scores, logits, h_out
+
+    @staticmethod
+    def backward(ctx, d_scores, d_logits, d_hout):
+        call = ctx.call
+        spec: ModelSpec = call['spec']
+        need = ctx.needs_input_grad
+        d_x, d_h_in, grads = mp_backward(spec, call['plan'], ctx.saved, ctx.P, call['training'],
+                                         d_scores, d_logits, d_hout, need_x=need[1],
+                                         need_h=ctx.has_h and need[2])
+        ctx.saved = None
+        names = spec.param_names()
+        return (None, d_x, d_h_in) + tuple(grads[nm] for nm in names)

@@ -1,0 +1,378 @@
+"""Device graph format of the hot path and the host code that produces it.
+
+The reference hands `TrackMPNN.forward` a pair of N x N adjacency tensors
+(reference/utils/graph.py:151-163, 294-308).  The HIP kernels want index arrays instead
+(`FrameGraph`, = `struct tmpnn_graph` of include/tmpnn.h):
+
+    src[e], dst[e]   det rows holding +1 / -1 in node_adj[edge e, :]
+    edge_row, det_row
+    rowptr/inc       det -> incident edge rows (CSR), sign of edge_adj[d, e] in bit 31
+
+`graph_from_adjacency` converts (and validates) whatever the reference passes -- dense, coalesced
+with explicit zeros, or uncoalesced COO.  `graph_from_edges` builds the same thing straight from
+edge lists; `WindowBuilder` re-creates the reference's train-mode rolling construction
+(utils/graph.py:96-186, 189-334) in index form, and `batch_windows` lays many windows out
+block-diagonally in call-major row order so one launch serves thousands of tracking windows.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass, field
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib
+
+
+@dataclass
+class FrameGraph:
+    N: int
+    E: int
+    Dn: int
+    src: torch.Tensor        # int32 [E]
+    dst: torch.Tensor        # int32 [E]
+    edge_row: torch.Tensor   # int32 [E]
+    det_row: torch.Tensor    # int32 [Dn]
+    rowptr: torch.Tensor     # int32 [Dn+1]
+    inc: torch.Tensor        # int32 [2E]   edge row | sign bit
+    is_edge: torch.Tensor    # uint8 [N]
+    pos: torch.Tensor        # int32 [N]    row -> index within its type (det index | edge index)
+    _c: Optional[_lib.CGraph] = field(default=None, repr=False, compare=False)
+
+    @property
+    def device(self):
+        return self.src.device
+
+    def to(self, device) -> 'FrameGraph':
+        if torch.device(device) == self.device:
+            return self
+        mv = lambda t: t.to(device)
+        return FrameGraph(self.N, self.E, self.Dn, mv(self.src), mv(self.dst), mv(self.edge_row), mv(self.det_row),
+                          mv(self.rowptr), mv(self.inc), mv(self.is_edge), mv(self.pos))
+
+    def cstruct(self) -> _lib.CGraph:
+        if self._c is None:
+            self._c = _lib.CGraph(self.N, self.E, self.Dn, self.src.data_ptr(), self.dst.data_ptr(),
+                                  self.edge_row.data_ptr(), self.det_row.data_ptr(), self.rowptr.data_ptr(),
+                                  self.inc.data_ptr())
+        return self._c
+
+    def cref(self):
+        return C.byref(self.cstruct())
+
+    def inc_edge_endpoint(self) -> Tuple[torch.Tensor, torch.Tensor]:
+        """For every CSR position: (edge index e, endpoint 0 = src side / 1 = dst side)."""
+        row = (self.inc & 0x7FFFFFFF).long()
+        endpoint = (self.inc < 0).long()
+        epos = torch.full((self.N,), -1, dtype=torch.long, device=self.device)
+        epos[self.edge_row.long()] = torch.arange(self.E, device=self.device)
+        return epos[row], endpoint
+
+
+def graph_from_edges(N: int, is_edge: torch.Tensor, src: torch.Tensor, dst: torch.Tensor,
+                     device=None) -> FrameGraph:
+    """Build the FrameGraph from the type mask and the per-edge (src, dst) det rows.
+
+    `src`/`dst` are given per edge in ascending edge-row order.  Pure index plumbing (torch ops,
+    any device); the CSR keeps, for each det, its incidences in ascending edge-row order.
+    """
+    is_edge = torch.as_tensor(is_edge).to(torch.bool)
+    dev = device if device is not None else is_edge.device
+    is_edge = is_edge.to(dev)
+    src = torch.as_tensor(src).to(dev).long()
+    dst = torch.as_tensor(dst).to(dev).long()
+    edge_row = torch.nonzero(is_edge).flatten()
+    det_row = torch.nonzero(~is_edge).flatten()
+    E, Dn = int(edge_row.numel()), int(det_row.numel())
+    if src.numel() != E or dst.numel() != E:
+        raise ValueError(f'need one (src, dst) per edge row: E={E}, got {src.numel()}/{dst.numel()}')
+    det_pos = torch.full((N,), -1, dtype=torch.long, device=dev)
+    det_pos[det_row] = torch.arange(Dn, device=dev)
+    pos = det_pos.clone()
+    pos[edge_row] = torch.arange(E, device=dev)
+    if E > 0:
+        if bool(is_edge[src].any()) or bool(is_edge[dst].any()):
+            raise ValueError('edge endpoint is not a det row')
+        if not bool(((src < edge_row) & (edge_row < dst)).all()):
+            raise ValueError('expected src row < edge row < dst row (utils/graph.py:153-156,298-301)')
+    # incidences: (det index, edge row, sign) ; sorted by det, then by edge row
+    d_all = torch.cat([det_pos[src], det_pos[dst]])
+    r_all = torch.cat([edge_row, edge_row])
+    neg = torch.cat([torch.zeros(E, dtype=torch.bool, device=dev), torch.ones(E, dtype=torch.bool, device=dev)])
+    key = d_all * (N + 1) + r_all
+    order = torch.argsort(key)
+    inc = r_all[order].to(torch.int32)
+    inc = torch.where(neg[order], inc | torch.tensor(-2 ** 31, dtype=torch.int32, device=dev), inc)
+    counts = torch.bincount(d_all, minlength=Dn) if E > 0 else torch.zeros(Dn, dtype=torch.long, device=dev)
+    rowptr = torch.zeros(Dn + 1, dtype=torch.long, device=dev)
+    rowptr[1:] = torch.cumsum(counts, 0)
+    i32 = lambda t: t.to(torch.int32).contiguous()
+    return FrameGraph(N=N, E=E, Dn=Dn, src=i32(src), dst=i32(dst), edge_row=i32(edge_row), det_row=i32(det_row),
+                      rowptr=i32(rowptr), inc=inc.contiguous(), is_edge=is_edge.to(torch.uint8).contiguous(),
+                      pos=i32(pos))
+
+
+def _coo(adj: torch.Tensor):
+    if adj.is_sparse:
+        adj = adj.coalesce()
+        idx, val = adj.indices(), adj.values()
+        keep = val != 0
+        return idx[0][keep], idx[1][keep], val[keep]
+    nz = torch.nonzero(adj)
+    return nz[:, 0], nz[:, 1], adj[nz[:, 0], nz[:, 1]]
+
+
+def graph_from_adjacency(node_adj: torch.Tensor, edge_adj: Optional[torch.Tensor] = None,
+                         validate: bool = True) -> FrameGraph:
+    """Convert the reference's adjacency pair into a FrameGraph on the same device.
+
+    Accepts dense tensors (first CPU-path call, utils/graph.py:180-184 only sparsifies under
+    cuda=True), coalesced COO with explicit zeros (node_adj) and uncoalesced COO (edge_adj).
+    Raises ValueError when the factor-graph invariants (one +1 and one -1 per edge row,
+    no off-diagonals on det rows, edge_adj = node_adj^T off the diagonal) do not hold.
+    """
+    N = int(node_adj.shape[0])
+    dev = node_adj.device
+    r, c, v = _coo(node_adj.detach())
+    diag = r == c
+    is_det = torch.zeros(N, dtype=torch.bool, device=dev)
+    is_det[r[diag]] = True
+    is_edge = ~is_det
+    ro, co, vo = r[~diag], c[~diag], v[~diag]
+    pos, neg = vo > 0, vo < 0
+    src = torch.full((N,), -1, dtype=torch.long, device=dev)
+    dst = torch.full((N,), -1, dtype=torch.long, device=dev)
+    src[ro[pos]] = co[pos]
+    dst[ro[neg]] = co[neg]
+    edge_row = torch.nonzero(is_edge).flatten()
+    if validate:
+        E = int(edge_row.numel())
+        ok = (int(pos.sum()) == E and int(neg.sum()) == E and bool((vo.abs() == 1).all())
+              and not bool(is_det[ro].any())
+              and bool((src[edge_row] >= 0).all()) and bool((dst[edge_row] >= 0).all()))
+        if not ok:
+            raise ValueError('node_adj is not a TrackMPNN factor graph: every edge row needs exactly one +1 and '
+                             'one -1 off-diagonal entry and det rows none')
+        if edge_adj is not None:
+            r2, c2, v2 = _coo(edge_adj.detach())
+            d2 = r2 == c2
+            ie = torch.zeros(N, dtype=torch.bool, device=dev)
+            ie[r2[d2]] = True
+            if not bool((ie == is_edge).all()):
+                raise ValueError('diag(edge_adj) does not complement diag(node_adj)')
+            ka = torch.argsort(c2[~d2] * N + r2[~d2])
+            kb = torch.argsort(ro * N + co)
+            if not (ka.numel() == kb.numel() and bool((c2[~d2][ka] == ro[kb]).all())
+                    and bool((r2[~d2][ka] == co[kb]).all()) and bool((v2[~d2][ka] == vo[kb]).all())):
+                raise ValueError('edge_adj is not node_adj^T off the diagonal')
+    return graph_from_edges(N, is_edge, src[edge_row], dst[edge_row], device=dev)
+
+
+# ----------------------------------------------------------------------------------------------
+# train-mode rolling window construction in index form (reference/utils/graph.py:96-186,189-334)
+# ----------------------------------------------------------------------------------------------
+@dataclass
+class WindowCall:
+    """What one forward call of one window appends: rows [n_edges new edge rows][n_dets new det rows]."""
+    n_new: int
+    new_is_edge: np.ndarray     # bool [n_new]
+    new_src: np.ndarray         # int64 [n_new_edges] window-local det row
+    new_dst: np.ndarray         # int64 [n_new_edges]
+    det_ids: np.ndarray         # int64 [n_new_dets] index into the window's detection list (rows of X)
+
+
+class WindowBuilder:
+    """Index-form replay of initialize_graph / update_graph(mode='train') for one chunk.
+
+    y [ND, 2] = [timestep, track id (-1 = false positive)].  Row layout per call, as in the
+    reference: `[edges active x new dets, src-major][new dets]` appended after the old rows
+    (utils/graph.py:141-156, 285-301); first call: `[dets t0][edges t0 x t1][dets t1]`.
+    Active set at time t = dets of the previous non-empty timestep + earlier true-positive dets
+    whose track has no later detection yet (utils/graph.py:229-245, 271-274).
+    """
+
+    def __init__(self, y: np.ndarray):
+        self.y = np.asarray(y, dtype=np.int64)
+
+    def calls(self) -> List[WindowCall]:
+        y = self.y
+        times = np.unique(y[:, 0])
+        if times.size < 2:
+            return []
+        out: List[WindowCall] = []
+        t0, t1 = int(times[0]), int(times[1])
+        ids0 = np.nonzero(y[:, 0] == t0)[0]
+        ids1 = np.nonzero(y[:, 0] == t1)[0]
+        n0, n1 = ids0.size, ids1.size
+        is_edge = np.concatenate([np.zeros(n0, bool), np.ones(n0 * n1, bool), np.zeros(n1, bool)])
+        src = np.repeat(np.arange(n0), n1)
+        dst = n0 + n0 * n1 + np.tile(np.arange(n1), n0)
+        out.append(WindowCall(n0 + n0 * n1 + n1, is_edge, src, dst, np.concatenate([ids0, ids1])))
+        # bookkeeping per det row: (row, timestep, det id, track id, associated?)
+        det_rows = np.concatenate([np.arange(n0), n0 + n0 * n1 + np.arange(n1)])
+        det_ts = np.concatenate([np.full(n0, t0), np.full(n1, t1)])
+        det_ids = np.concatenate([ids0, ids1])
+        N = n0 + n0 * n1 + n1
+        # which det pairs have an edge (for the association rule): set of (src det id, dst det id)
+        has_edge = set((int(a), int(b)) for a in ids0 for b in ids1)
+        t_prev = t1
+        for t in times[2:]:
+            t = int(t)
+            trk = y[det_ids, 1]
+            # y_pred[:, 2] update (utils/graph.py:229-245): a TP det is associated iff one of its
+            # FUTURE edges leads to a det of the same track; FPs self-associate (stay inactive)
+            assoc = np.zeros(det_ids.size, bool)
+            for i in range(det_ids.size):
+                if trk[i] < 0:
+                    assoc[i] = True
+                    continue
+                later = np.nonzero((trk == trk[i]) & (det_ts > det_ts[i]))[0]
+                assoc[i] = any((int(det_ids[i]), int(det_ids[j])) in has_edge for j in later)
+            active = np.nonzero((~assoc) | (det_ts == t_prev))[0]      # utils/graph.py:273-274
+            ids_t = np.nonzero(y[:, 0] == t)[0]
+            nt, na = ids_t.size, active.size
+            n_new = na * nt + nt
+            is_edge = np.concatenate([np.ones(na * nt, bool), np.zeros(nt, bool)])
+            src = np.repeat(det_rows[active], nt)
+            dst = N + na * nt + np.tile(np.arange(nt), na)
+            out.append(WindowCall(n_new, is_edge, src, dst, ids_t))
+            for a in active:
+                for b in ids_t:
+                    has_edge.add((int(det_ids[a]), int(b)))
+            det_rows = np.concatenate([det_rows, N + na * nt + np.arange(nt)])
+            det_ts = np.concatenate([det_ts, np.full(nt, t)])
+            det_ids = np.concatenate([det_ids, ids_t])
+            N += n_new
+            t_prev = t
+        return out
+
+
+def synth_window(seed: int, frames: int, mean_dets: float, max_dets: int, survival: float = 0.9,
+                 fp_rate: float = 0.1, dropout: float = 0.2) -> np.ndarray:
+    """KITTI/BDD-shaped synthetic chunk: y [ND, 2] = [timestep, track id].
+
+    Tracks are born to keep ~Poisson(mean_dets) alive, survive a frame with prob `survival`, are
+    missed by the detector with prob `dropout` (reference/dataset/kitti_mot.py:102,530-532) and
+    ~`fp_rate` of the detections are false positives (track id -1).
+    """
+    rng = np.random.RandomState(seed)
+    alive: List[int] = []
+    next_id = 0
+    rows = []
+    for t in range(frames):
+        alive = [i for i in alive if rng.rand() < survival]
+        target = int(np.clip(rng.poisson(mean_dets), 1, max_dets))
+        while len(alive) < target:
+            alive.append(next_id)
+            next_id += 1
+        seen = [i for i in alive if rng.rand() >= dropout]
+        if not seen:
+            seen = [alive[0]]
+        nfp = int(rng.binomial(len(seen), fp_rate))
+        ids = (seen + [-1] * nfp)[:max_dets]
+        rng.shuffle(ids)
+        rows += [(t, i) for i in ids]
+    return np.asarray(rows, dtype=np.int64)
+
+
+@dataclass
+class CallPlan:
+    """One forward call over a (possibly batched) graph: everything the device needs, resident."""
+    graph: FrameGraph
+    n_new: int
+    new_det_local: torch.Tensor   # int64 [nd]  index into x (the call's new rows) of the new det rows
+    new_det_row: torch.Tensor     # int32 [nd]  global row of each new det
+    seg_ptr: torch.Tensor         # int32 [S+1] new det rows of window s
+    seg_cnt: torch.Tensor         # int32 [S]   ALL new rows of window s
+    seg_of_new: torch.Tensor      # int64 [n_new] window of each new row
+    min_seg_cnt: int
+
+    @property
+    def S(self) -> int:
+        return int(self.seg_cnt.numel())
+
+    def to(self, device) -> 'CallPlan':
+        return CallPlan(self.graph.to(device), self.n_new, self.new_det_local.to(device),
+                        self.new_det_row.to(device), self.seg_ptr.to(device), self.seg_cnt.to(device),
+                        self.seg_of_new.to(device), self.min_seg_cnt)
+
+
+def plan_single(graph: FrameGraph, n_new: int) -> CallPlan:
+    """CallPlan of an unbatched reference-style call: the last n_new rows are new, one segment."""
+    dev = graph.device
+    N = graph.N
+    new_is_det = graph.is_edge[N - n_new:] == 0 if n_new > 0 else torch.zeros(0, dtype=torch.bool, device=dev)
+    loc = torch.nonzero(new_is_det).flatten()
+    nd = int(loc.numel())
+    return CallPlan(graph=graph, n_new=n_new, new_det_local=loc, new_det_row=(loc + (N - n_new)).to(torch.int32),
+                    seg_ptr=torch.tensor([0, nd], dtype=torch.int32, device=dev),
+                    seg_cnt=torch.tensor([n_new], dtype=torch.int32, device=dev),
+                    seg_of_new=torch.zeros(n_new, dtype=torch.long, device=dev), min_seg_cnt=n_new)
+
+
+def batch_windows(windows: Sequence[Sequence[WindowCall]], static: bool = False,
+                  device='cpu') -> Tuple[List[CallPlan], List[np.ndarray]]:
+    """Block-diagonal batch of many windows, rows in CALL-MAJOR order.
+
+    Call c of the batch appends, for every window b in turn, the rows window b would append at its
+    call c -- so the append-only contract of `forward(x, h_in, ...)` (N' = N + n) holds for the
+    batch and no row of an earlier call ever moves.  Returns one CallPlan per call plus, per call,
+    the (window, det id) of every new det row (to fetch features).  `static=True` collapses each
+    window to its final graph presented in ONE call (SURVEY 8(d) static mode).
+    """
+    B = len(windows)
+    ncalls = max(len(w) for w in windows)
+    base = [dict() for _ in range(B)]           # window-local row -> global row, per window as arrays
+    local2global = [np.zeros(0, np.int64) for _ in range(B)]
+    plans: List[CallPlan] = []
+    det_refs: List[np.ndarray] = []
+    N = 0
+    g_is_edge: List[np.ndarray] = []
+    g_src: List[np.ndarray] = []
+    g_dst: List[np.ndarray] = []
+    call_range = [range(ncalls)] if static else [[c] for c in range(ncalls)]
+    for group in call_range:
+        seg_cnt, seg_nd, refs, new_is_edge_all, seg_ids = [], [], [], [], []
+        n_before = N
+        for b, w in enumerate(windows):
+            cnt = nd = 0
+            for c in group:
+                if c >= len(w):
+                    continue
+                wc = w[c]
+                l2g = np.concatenate([local2global[b], N + np.arange(wc.n_new)])
+                local2global[b] = l2g
+                g_is_edge.append(wc.new_is_edge)
+                g_src.append(l2g[wc.new_src])
+                g_dst.append(l2g[wc.new_dst])
+                new_is_edge_all.append(wc.new_is_edge)
+                refs.append(np.stack([np.full(wc.det_ids.size, b), wc.det_ids], 1))
+                N += wc.n_new
+                cnt += wc.n_new
+                nd += int((~wc.new_is_edge).sum())
+            if cnt > 0:
+                seg_cnt.append(cnt)
+                seg_nd.append(nd)
+                seg_ids.append(np.full(cnt, len(seg_cnt) - 1))
+        is_edge = np.concatenate(g_is_edge) if g_is_edge else np.zeros(0, bool)
+        src = np.concatenate(g_src) if g_src else np.zeros(0, np.int64)
+        dst = np.concatenate(g_dst) if g_dst else np.zeros(0, np.int64)
+        # edges must be listed in ascending edge-row order: they are, rows are appended in order
+        graph = graph_from_edges(N, torch.from_numpy(is_edge), torch.from_numpy(src), torch.from_numpy(dst),
+                                 device=device)
+        n_new = N - n_before
+        nie = np.concatenate(new_is_edge_all) if new_is_edge_all else np.zeros(0, bool)
+        loc = np.nonzero(~nie)[0]
+        seg_ptr = np.concatenate([[0], np.cumsum(seg_nd)]).astype(np.int32)
+        plans.append(CallPlan(
+            graph=graph, n_new=n_new,
+            new_det_local=torch.from_numpy(loc).to(device),
+            new_det_row=torch.from_numpy((loc + n_before).astype(np.int32)).to(device),
+            seg_ptr=torch.from_numpy(seg_ptr).to(device),
+            seg_cnt=torch.from_numpy(np.asarray(seg_cnt, dtype=np.int32)).to(device),
+            seg_of_new=torch.from_numpy(np.concatenate(seg_ids) if seg_ids else np.zeros(0, np.int64)).to(device),
+            min_seg_cnt=int(min(seg_cnt)) if seg_cnt else 0))
+        det_refs.append(np.concatenate(refs) if refs else np.zeros((0, 2), np.int64))
+    return plans, det_refs
