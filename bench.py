@@ -1,0 +1,308 @@
+#!/usr/bin/env python3
+"""graph-edges/sec (fwd+bwd) of the TrackMPNN message-passing hot path on MI355X (BASELINE.json metric).
+
+One step = one pass of the hot path over one batch of synthetic input: B KITTI-Car/RRC-shaped
+rolling tracking windows (BASELINE.json configs[1] = SURVEY 8(d) C2: 7 frames, D_t ~ clip(Poisson(6),1,20),
+F = 8 '2d' features, H = 64, no attention, diff messages), batched block-diagonally.  Per window the
+reference call pattern is reproduced exactly (train.py:65-68,92-107,132-135): one forward per frame on the
+growing graph with the hidden state carried (BPTT), one backward of a BCE loss over all logits; then (N > 1)
+ONE flat-bucket RCCL all-reduce of the gradients and an Adam step.  Graphs are prebuilt and resident in HBM.
+A "graph-edge" = one edge node processed by one forward call.
+
+    python bench.py --gpus 1 --steps 10 --warmup 2
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s measured stream copy
+MFMA_F32_PEAK_TF = 157.3     # dense fp32-input MFMA peak (same guide)
+
+
+def build_batch(B, frames, mean_dets, max_dets, F, seed, device):
+    """B windows = 64 distinct seeded windows tiled; returns (plans on device, per-call x on device, stats)."""
+    from trackmpnn_amd import WindowBuilder, batch_windows, synth_window
+    distinct = min(B, 64)
+    wins = [WindowBuilder(synth_window(seed * 1000 + s, frames, mean_dets, max_dets)).calls() for s in range(distinct)]
+    reps = (B + distinct - 1) // distinct
+    wins = (wins * reps)[:B]
+    plans, refs = batch_windows(wins, device='cpu')
+    gen = torch.Generator().manual_seed(seed)
+    xs = []
+    for plan, ref in zip(plans, refs):
+        x = torch.zeros(plan.n_new, F)
+        x[plan.new_det_local] = torch.randn(len(ref), F, generator=gen)     # standardised features (kitti_mot.py:545-566)
+        xs.append(x.to(device))
+    plans = [p.to(device) for p in plans]
+    edge_iters = sum(p.graph.E for p in plans)
+    return plans, xs, edge_iters
+
+
+def step(model, plans, xs, targets, opt, bucket, world):
+    """fwd over every call of the window batch, one backward, (all-reduce), Adam."""
+    import torch.nn.functional as Fnn
+    h = None
+    loss = 0.0
+    for plan, x, t in zip(plans, xs, targets):
+        scores, logits, h, _ = model.forward_graph(x, h, plan)
+        loss = loss + Fnn.binary_cross_entropy_with_logits(logits, t, reduction='sum')
+    opt.zero_grad(set_to_none=False)
+    loss.backward()
+    if world > 1:
+        import torch.distributed as dist
+        from trackmpnn_amd.dist import allreduce_grads
+        allreduce_grads(model, bucket, world)
+    opt.step()
+    return loss
+
+
+def time_stage(fn, iters=5):
+    """Average duration (ms) of one enqueue of `fn` on the current stream, measured with HIP events."""
+    fn()
+    torch.cuda.synchronize()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    ev[0].record()
+    for _ in range(iters):
+        fn()
+    ev[1].record()
+    torch.cuda.synchronize()
+    return ev[0].elapsed_time(ev[1]) / iters
+
+
+def stage_profile(model, plan, H):
+    """Per-kernel timing on the LAST call's graph (the largest): the fused edge GRU kernels (MFMA-bound) and
+    the stand-alone aggregation kernels (HBM-bound, SURVEY 8(d) byte model)."""
+    from trackmpnn_amd import _lib
+    g = plan.graph
+    dev = g.device
+    N, E, Dn = g.N, g.E, g.Dn
+    st = torch.cuda.current_stream().cuda_stream
+    f = 'factor_grus.0.'
+    P = dict(model.named_parameters())
+    h = torch.randn(N, H, device=dev)
+    out = torch.empty(N, H, device=dev)
+    gates = torch.empty(4, N, H, device=dev)
+    wih_t = P[f + 'edge_gru.weight_ih'].detach().t().contiguous()
+    whh_t = P[f + 'edge_gru.weight_hh'].detach().t().contiguous()
+    wih, whh = P[f + 'edge_gru.weight_ih'].detach(), P[f + 'edge_gru.weight_hh'].detach()
+    bih, bhh = P[f + 'edge_gru.bias_ih'].detach(), P[f + 'edge_gru.bias_hh'].detach()
+    dout = torch.randn(N, H, device=dev)
+    dmsg = torch.empty(N, H, device=dev)
+    dh = torch.empty(N, H, device=dev)
+    gW = [torch.zeros_like(wih), torch.zeros_like(whh), torch.zeros_like(bih), torch.zeros_like(bhh)]
+    wsb = _lib.load().tmpnn_gru_bwd_weights_ws(E, H, H)
+    ws = torch.empty(wsb // 4 + 1, device=dev)
+    es = torch.empty(Dn, H, device=dev)
+
+    def gru_fwd():
+        _lib.call('tmpnn_gru_fwd', g.edge_row.data_ptr(), E, 1, g.src.data_ptr(), g.dst.data_ptr(), None, 0, 0, H,
+                  h.data_ptr(), H, H, wih_t.data_ptr(), whh_t.data_ptr(), bih.data_ptr(), bhh.data_ptr(),
+                  out.data_ptr(), H, gates.data_ptr(), N * H, st)
+
+    def gru_bwd_data():
+        _lib.call('tmpnn_gru_bwd_data', g.edge_row.data_ptr(), E, H, h.data_ptr(), H, H, wih.data_ptr(), whh.data_ptr(),
+                  gates.data_ptr(), N * H, dout.data_ptr(), H, dmsg.data_ptr(), H, dh.data_ptr(), H, st)
+
+    def gru_bwd_w():
+        _lib.call('tmpnn_gru_bwd_weights', g.edge_row.data_ptr(), E, 1, g.src.data_ptr(), g.dst.data_ptr(), None, 0, 0,
+                  H, h.data_ptr(), H, H, gates.data_ptr(), N * H, dout.data_ptr(), H, gW[0].data_ptr(),
+                  gW[1].data_ptr(), gW[2].data_ptr(), gW[3].data_ptr(), ws.data_ptr(), wsb, st)
+
+    def gather():
+        _lib.call('tmpnn_gather_diff_fwd', g.cref(), h.data_ptr(), H, out.data_ptr(), H, H, 0, st)
+
+    def segsum():
+        _lib.call('tmpnn_segsum_fwd', g.cref(), h.data_ptr(), H, es.data_ptr(), H, H, 0, 1, st)
+
+    gru_fwd()          # gates must hold sane values before the backward kernels read them
+    t = {name: time_stage(fn) for name, fn in (('gru_fwd_edge', gru_fwd), ('gru_bwd_data_edge', gru_bwd_data),
+                                               ('gru_bwd_weights_edge', gru_bwd_w), ('gather_diff', gather),
+                                               ('segsum', segsum))}
+    flops = {'gru_fwd_edge': 12.0 * H * H * E, 'gru_bwd_data_edge': 12.0 * H * H * E,
+             'gru_bwd_weights_edge': 12.0 * H * H * E}
+    # SURVEY 8(d) algorithmic bytes per launch
+    b_gather = 4.0 * H * E + 4.0 * H * Dn + 8.0 * E
+    b_segsum = 4.0 * H * E + 4.0 * H * Dn + 4.0 * (2 * E + Dn + 1) + 2.0 * E
+    return t, flops, {'gather_diff': b_gather, 'segsum': b_segsum}
+
+
+def cpu_baseline(frames, mean_dets, max_dets, F, H, seed, budget_s=15.0):
+    """The oracle (CPU restatement, kind 'port') on the host cores, one window at a time as the reference
+    runs them (batch size 1, utils/graph.py:117), same call pattern, bounded sample."""
+    from oracle import trackmpnn_oracle as orc
+    from trackmpnn_amd import WindowBuilder, batch_windows, synth_window
+    import torch.nn.functional as Fnn
+    cfg = orc.OracleConfig('2d', F - 5, H, 0, 'diff')
+    p = orc.random_params(cfg, seed=0, scale=0.05)
+    for k, v in p.items():
+        if v.dtype.is_floating_point and not k.endswith(orc.BUFFER_SUFFIXES):
+            v.requires_grad_(True)
+    cases = []
+    for s in range(64):
+        calls = WindowBuilder(synth_window(seed * 1000 + s, frames, mean_dets, max_dets)).calls()
+        plans, refs = batch_windows([calls])
+        gen = torch.Generator().manual_seed(s)
+        graphs, xs = [], []
+        for plan, ref in zip(plans, refs):
+            g = plan.graph
+            graphs.append(orc.OracleGraph(g.N, g.is_edge.numpy().astype(bool), g.src.numpy().astype(np.int64),
+                                          g.dst.numpy().astype(np.int64), g.edge_row.numpy().astype(np.int64),
+                                          g.det_row.numpy().astype(np.int64)))
+            x = torch.zeros(plan.n_new, F)
+            x[plan.new_det_local] = torch.randn(len(ref), F, generator=gen)
+            xs.append(x)
+        cases.append((graphs, xs))
+
+    def run(case):
+        graphs, xs = case
+        h = None
+        loss = 0.0
+        for g, x in zip(graphs, xs):
+            s, l, h, _ = orc.forward(p, cfg, x, h, g, training=True)
+            loss = loss + Fnn.binary_cross_entropy_with_logits(l, torch.zeros_like(l), reduction='sum')
+        for v in p.values():
+            v.grad = None
+        loss.backward()
+        return sum(g.E for g in graphs)
+
+    run(cases[0])
+    results = {}
+    ncpu = os.cpu_count() or 1
+    for nthreads in sorted({1, min(8, ncpu), min(16, ncpu)}):   # more threads only slow these tiny per-window ops down
+        torch.set_num_threads(nthreads)
+        run(cases[0])
+        t0 = time.perf_counter()
+        edges = nwin = 0
+        done = False
+        while not done:
+            for case in cases:
+                edges += run(case)
+                nwin += 1
+                if time.perf_counter() - t0 > budget_s / 3:
+                    done = True
+                    break
+        dt = time.perf_counter() - t0
+        results[nthreads] = (edges / dt, nwin, edges, dt)
+    best = max(results, key=lambda k: results[k][0])
+    v, nwin, edges, dt = results[best]
+    others = ', '.join(f'{k} threads: {r[0]:.0f}/s' for k, r in results.items())
+    return dict(value=v, unit='graph-edges/s', cores=best, kind='port',
+                sample=f'{nwin} windows of the same C2 generator run one at a time (batch 1 as the reference), '
+                       f'{edges} edge-iterations in {dt:.1f} s, torch-CPU fp32 oracle fwd+bwd; best of [{others}] '
+                       f'on a {ncpu}-core host')
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--windows', type=int, default=16384, help='tracking windows per GPU per step')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-stage-profile', action='store_true')
+    args = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit('launch with python -m torch.distributed.run --nproc-per-node N for --gpus N > 1')
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', device_id=dev)
+
+    import __graft_entry__
+    if rank == 0:
+        __graft_entry__.build()
+    if world > 1:
+        dist.barrier()
+    from trackmpnn_amd import TrackMPNN
+    from trackmpnn_amd.dist import GradBucket
+
+    frames, mean_dets, max_dets, F, H = 7, 6.0, 20, 8, 64
+    torch.manual_seed(5)
+    model = TrackMPNN('2d', 3, H, 0, 'diff').to(dev).train()
+    opt = torch.optim.Adam(model.parameters(), lr=1e-4, weight_decay=5e-4)       # train.py:329
+    bucket = GradBucket(model) if world > 1 else None
+    plans, xs, edge_iters = build_batch(args.windows, frames, mean_dets, max_dets, F, seed=rank + 1, device=dev)
+    gen = torch.Generator().manual_seed(rank)
+    targets = [(torch.rand(p.graph.N, 1, generator=gen) < 0.3).float().to(dev) for p in plans]
+
+    for _ in range(args.warmup):
+        step(model, plans, xs, targets, opt, bucket, world)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(model, plans, xs, targets, opt, bucket, world)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = tmax.item()
+        tot = torch.tensor([float(edge_iters)], device=dev, dtype=torch.float64)
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        total_edges = tot.item()
+    else:
+        total_edges = float(edge_iters)
+    value = total_edges * args.steps / dt
+
+    roofline = None
+    extra = {}
+    if rank == 0 and not args.no_stage_profile:
+        t, flops, nbytes = stage_profile(model, plans[-1], H)
+        dom = max(flops, key=lambda k: t[k])
+        ach = flops[dom] / (t[dom] * 1e-3) / 1e12
+        roofline = dict(bound='mfma', kernel=dom, achieved=ach, peak=MFMA_F32_PEAK_TF, unit='TFLOP/s',
+                        frac=ach / MFMA_F32_PEAK_TF, traffic=None, ms=t[dom])
+        agg_b = nbytes['gather_diff'] + nbytes['segsum']
+        agg_t = (t['gather_diff'] + t['segsum']) * 1e-3
+        extra['roofline_aggregation'] = dict(
+            bound='hbm', kernel='gather_diff+segsum', achieved=agg_b / agg_t / 1e9, peak=HBM_PEAK_GBS, unit='GB/s',
+            frac=agg_b / agg_t / 1e9 / HBM_PEAK_GBS, traffic=None,
+            gather_GBs=nbytes['gather_diff'] / (t['gather_diff'] * 1e-3) / 1e9,
+            segsum_GBs=nbytes['segsum'] / (t['segsum'] * 1e-3) / 1e9)
+        extra['stage_ms'] = {k: round(v, 4) for k, v in t.items()}
+        extra['stage_graph'] = dict(N=plans[-1].graph.N, E=plans[-1].graph.E, Dn=plans[-1].graph.Dn)
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(frames, mean_dets, max_dets, F, H, seed=1)
+
+    if rank == 0:
+        out = dict(metric='graph_edges_per_sec_fwd_bwd', value=value, unit='graph-edges/s', n_gpus=world,
+                   steps=args.steps, warmup=args.warmup, ms_per_step=dt / args.steps * 1e3, higher_is_better=True,
+                   scaling='weak', vs_baseline=None, dtype='f32', data='synthetic',
+                   config=dict(workload='C2 KITTI Car/RRC-shaped rolling windows: 7 frames, D_t~clip(Poisson(6),1,20), '
+                                        'F=8 (2d), H=64, K=0, diff; 1 fwd per frame + 1 bwd per window; '
+                                        f'{args.windows} windows/GPU batched block-diagonally (64 distinct seeds tiled)',
+                               windows_per_gpu=args.windows, edge_iterations_per_gpu_step=edge_iters,
+                               rows_final=plans[-1].graph.N, parallelism=f'sequence-dp{world}'),
+                   roofline=roofline, cpu_baseline=cpu)
+        out.update(extra)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

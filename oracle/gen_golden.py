@@ -59,7 +59,7 @@ def adj_arrays(adj):
     return nz.t().numpy().copy(), adj[nz[:, 0], nz[:, 1]].numpy().copy(), 1
 
 
-def run_fixture(name, out_dir, features, ncat, H, K, msg, mode, seed, T=4, dmean=3, static_iters=0):
+def run_fixture(name, out_dir, features, ncat, H, K, msg, mode, seed, T=4, dmean=3, static_iters=0, pscale=0.3):
     from models.track_mpnn import TrackMPNN
     from utils.graph import initialize_graph, update_graph
 
@@ -68,7 +68,7 @@ def run_fixture(name, out_dir, features, ncat, H, K, msg, mode, seed, T=4, dmean
     gp = torch.Generator().manual_seed(seed + 77)
     with torch.no_grad():
         for _, prm in model.named_parameters():
-            prm.add_(0.3 * torch.randn(prm.shape, generator=gp))
+            prm.add_(pscale * torch.randn(prm.shape, generator=gp))
         for k, b in model.named_buffers():
             if k.endswith('running_mean'):
                 b.copy_(0.2 * torch.randn(b.shape, generator=gp))
@@ -161,7 +161,7 @@ def run_fixture(name, out_dir, features, ncat, H, K, msg, mode, seed, T=4, dmean
     for k, b in model.named_buffers():
         out['final/' + k] = b.detach().numpy().copy()
     meta = dict(name=name, features=features, ncategories=ncat, nhidden=H, nattheads=K, msg_type=msg,
-                mode=mode, ncalls=len(calls), seed=seed, T=T, static_iters=static_iters,
+                mode=mode, ncalls=len(calls), seed=seed, T=T, static_iters=static_iters, pscale=pscale,
                 torch=torch.__version__, reference='arangesh/TrackMPNN @ /root/reference')
     out['meta'] = np.array(json.dumps(meta))
     path = os.path.join(out_dir, name + '.npz')
@@ -216,7 +216,11 @@ def run_c1(out_dir):
     keep = synth_sequence
     synth_sequence = c1_seq
     try:
-        run_fixture('c1_static_diff_k0_train', out_dir, '2d', 3, 64, 0, 'diff', 'train', 200, T=T, static_iters=2)
+        # weights perturbed by 0.1 (not 0.3): at N=1700 with 40 incident edges per det the 0.3 problem is
+        # ill-conditioned -- an fp64 evaluation differs from the reference's own fp32 result by 1.4e-3 in
+        # the logits, so no implementation could be pinned to 1e-4 on it
+        run_fixture('c1_static_diff_k0_train', out_dir, '2d', 3, 64, 0, 'diff', 'train', 200, T=T, static_iters=2,
+                    pscale=0.1)
     finally:
         synth_sequence = keep
 

@@ -183,8 +183,9 @@ def check_heads(C, g, gd):
     hD = d(h)
     logits = torch.empty(N, 1, device=DEV)
     scores = torch.empty(N, 1, device=DEV)
-    _lib.call('tmpnn_heads_fwd', hD.data_ptr(), C + 4, C, N, gd.is_edge.data_ptr(), d(wn).data_ptr(), d(bn).data_ptr(),
-              d(we).data_ptr(), d(be).data_ptr(), logits.data_ptr(), scores.data_ptr(), st())
+    wnD, weD, bnD, beD = d(wn), d(we), d(bn), d(be)     # keep alive: freed blocks are reused at once
+    _lib.call('tmpnn_heads_fwd', hD.data_ptr(), C + 4, C, N, gd.is_edge.data_ptr(), wnD.data_ptr(), bnD.data_ptr(),
+              weD.data_ptr(), beD.data_ptr(), logits.data_ptr(), scores.data_ptr(), st())
     res = {'logits': (logits.cpu() - y.detach()).abs().max().item(),
            'scores': (scores.cpu() - s.detach()).abs().max().item()}
     pre = torch.randn(N, C)
@@ -193,9 +194,9 @@ def check_heads(C, g, gd):
     g_bn, g_be = torch.zeros(1, device=DEV), torch.zeros(1, device=DEV)
     wsb = _lib.load().tmpnn_heads_bwd_ws(N, C)
     ws = torch.empty(wsb // 4 + 1, device=DEV)
-    wnD, weD = d(wn), d(we)
+    dlD, dsD = d(dl), d(ds)
     _lib.call('tmpnn_heads_bwd', hD.data_ptr(), C + 4, C, N, gd.is_edge.data_ptr(), wnD.data_ptr(), weD.data_ptr(),
-              scores.data_ptr(), d(dl).data_ptr(), d(ds).data_ptr(), dh.data_ptr(), C, 1,
+              scores.data_ptr(), dlD.data_ptr(), dsD.data_ptr(), dh.data_ptr(), C, 1,
               g_wn.data_ptr(), g_bn.data_ptr(), g_we.data_ptr(), g_be.data_ptr(), ws.data_ptr(), wsb, st())
     sc = max(1.0, wn.grad.abs().max().item(), we.grad.abs().max().item())
     res['dh'] = (dh.cpu() - pre - hh.grad).abs().max().item()

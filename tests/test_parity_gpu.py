@@ -149,7 +149,8 @@ def test_batched_windows_vs_oracle(features, ncat, H, K, msg, train):
     cfg = orc.OracleConfig(features, ncat, H, K, msg)
     F = sum(f for _, f in cfg.groups)
     plans, xs = _batched_case(B=16, frames=7, mean=6, max_dets=20, F=F, seed0=H + K)
-    p = orc.random_params(cfg, seed=H, scale=0.15)
+    # keep the per-layer gain (scale * sqrt(H)) fixed so wider models stay as well conditioned as H = 64
+    p = orc.random_params(cfg, seed=H, scale=1.2 / (H ** 0.5))
     model = TrackMPNN(features, ncat, H, K, msg)
     model.load_state_dict({k: v.clone() for k, v in p.items()}, strict=True)
     model = model.to(DEV)

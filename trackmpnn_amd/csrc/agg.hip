@@ -128,13 +128,37 @@ __global__ void k_reduce_slabs(const float* __restrict__ slabs, size_t stride, i
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     float s = 0.f;
+#pragma unroll 8
     for (int k = 0; k < nslab; ++k) s += slabs[(size_t)k * stride + i];
     dst[i] = accumulate ? dst[i] + s : s;
 }
 
+// fold groups of 32 slabs: out[g][i] = sum_{k in group g} slabs[k][i]
+__global__ void k_fold_slabs(const float* __restrict__ slabs, size_t stride, int nslab, float* __restrict__ out,
+                             size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int k0 = blockIdx.y * 32, k1 = min(nslab, k0 + 32);
+    float s = 0.f;
+#pragma unroll 8
+    for (int k = k0; k < k1; ++k) s += slabs[(size_t)k * stride + i];
+    out[(size_t)blockIdx.y * n + i] = s;
+}
+
+size_t reduce_slabs_ws_floats(int nslab, size_t n) { return nslab > 64 ? (size_t)ceil_div(nslab, 32) * n : 0; }
+
 int launch_reduce_slabs(const float* slabs, size_t stride, int nslab, float* dst, size_t n, int accumulate,
-                        hipStream_t st) {
+                        hipStream_t st, float* ws2) {
     if (n == 0) return TMPNN_OK;
+    if (nslab > 64 && ws2 != nullptr) {
+        const int ng = ceil_div(nslab, 32);
+        hipLaunchKernelGGL(k_fold_slabs, dim3(ceil_div((long)n, 256), ng), dim3(256), 0, st, slabs, stride, nslab, ws2, n);
+        int rc = check_launch("fold_slabs");
+        if (rc) return rc;
+        slabs = ws2;
+        stride = n;
+        nslab = ng;
+    }
     hipLaunchKernelGGL(k_reduce_slabs, dim3(ceil_div((long)n, 256)), dim3(256), 0, st, slabs, stride, nslab, dst,
                        n, accumulate);
     return check_launch("reduce_slabs");

@@ -30,8 +30,10 @@ inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // sum over `nslab` slabs of `n` floats each: dst[i] (+)= sum_s slabs[s*stride + i]   (deterministic)
+// More than 64 slabs are first folded 32:1 into `ws2` (reduce_slabs_ws_floats(nslab, n) floats).
+size_t reduce_slabs_ws_floats(int nslab, size_t n);
 int launch_reduce_slabs(const float* slabs, size_t stride, int nslab, float* dst, size_t n, int accumulate,
-                        hipStream_t st);
+                        hipStream_t st, float* ws2 = nullptr);
 
 // Generic small dense product on the vector ALU (tiny operands only: input transform, attention
 // projections).  C[crow(m)*ldc + n] (+)= sum_k A[arow(m)*sam + k*sak] * B[k*sbk + n*sbn] (+ bias[n])

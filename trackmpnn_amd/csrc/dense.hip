@@ -89,8 +89,8 @@ int launch_gemm(const GemmArgs& g, hipStream_t st) {
 }
 
 static int splitk_plan(int K, int* kper) {
-    int nsplit = (K + 511) / 512;
-    if (nsplit > 512) nsplit = 512;
+    int nsplit = (K + 127) / 128;
+    if (nsplit > 1024) nsplit = 1024;
     if (nsplit < 1) nsplit = 1;
     int kp = (K + nsplit - 1) / nsplit;
     kp = (kp + 15) & ~15;
@@ -104,7 +104,7 @@ static int splitk_plan(int K, int* kper) {
 size_t gemm_splitk_ws_floats(int M, int N, int K) {
     int kper;
     const int ns = splitk_plan(K, &kper);
-    return (size_t)ns * M * N;
+    return (size_t)ns * M * N + reduce_slabs_ws_floats(ns, (size_t)M * N);
 }
 
 int launch_gemm_splitk(const GemmArgs& g, float* ws, size_t ws_floats, hipStream_t st) {
@@ -112,16 +112,19 @@ int launch_gemm_splitk(const GemmArgs& g, float* ws, size_t ws_floats, hipStream
     if (g.K <= 0) return TMPNN_OK;
     int kper;
     const int ns = splitk_plan(g.K, &kper);
-    if (ws_floats < (size_t)ns * g.M * g.N) return set_error(TMPNN_EWORKSPACE, "gemm_splitk: workspace too small");
+    if (ws_floats < gemm_splitk_ws_floats(g.M, g.N, g.K))
+        return set_error(TMPNN_EWORKSPACE, "gemm_splitk: workspace too small");
+    float* ws2 = ws + (size_t)ns * g.M * g.N;
     dim3 grid(ceil_div(g.N, 64), ceil_div(g.M, 64), ns), block(256);
     hipLaunchKernelGGL(k_gemm, grid, block, 0, st, g, kper, ws);
     int rc = check_launch("gemm_splitk");
     if (rc) return rc;
     // C is dense [M][ldc] here (weight gradients); reduce row by row when ldc != N
-    if (g.ldc == g.N) return launch_reduce_slabs(ws, (size_t)g.M * g.N, ns, g.C, (size_t)g.M * g.N, g.accumulate, st);
+    if (g.ldc == g.N)
+        return launch_reduce_slabs(ws, (size_t)g.M * g.N, ns, g.C, (size_t)g.M * g.N, g.accumulate, st, ws2);
     for (int m = 0; m < g.M; ++m) {
         rc = launch_reduce_slabs(ws + (size_t)m * g.N, (size_t)g.M * g.N, ns, g.C + (size_t)m * g.ldc, g.N,
-                                 g.accumulate, st);
+                                 g.accumulate, st, ws2);
         if (rc) return rc;
     }
     return TMPNN_OK;
@@ -136,8 +139,8 @@ __global__ __launch_bounds__(256) void k_colsum_partial(const float* __restrict_
     __shared__ float red[4][64];
     const int c = blockIdx.y * 64 + (threadIdx.x & 63);
     const int slot = threadIdx.x >> 6;
-    const int r0 = blockIdx.x * 1024;
-    const int r1 = min(rows, r0 + 1024);
+    const int r0 = blockIdx.x * 128;
+    const int r1 = min(rows, r0 + 128);
     float s = 0.f;
     if (c < cols)
         for (int r = r0 + slot; r < r1; r += 4) {
@@ -151,7 +154,10 @@ __global__ __launch_bounds__(256) void k_colsum_partial(const float* __restrict_
         part[(size_t)blockIdx.x * cols + c] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
 }
 
-size_t colsum_ws_floats(int rows, int cols) { return (size_t)ceil_div(rows > 0 ? rows : 1, 1024) * cols; }
+size_t colsum_ws_floats(int rows, int cols) {
+    const size_t nch = ceil_div(rows > 0 ? rows : 1, 128);
+    return nch * cols + reduce_slabs_ws_floats((int)nch, cols);
+}
 
 int launch_colsum(const float* src, long ld, const float* mul, long ldm, int rows, int cols, float* dst,
                   int accumulate, float* ws, size_t ws_floats, hipStream_t st) {
@@ -160,13 +166,13 @@ int launch_colsum(const float* src, long ld, const float* mul, long ldm, int row
         if (!accumulate) (void)hipMemsetAsync(dst, 0, sizeof(float) * cols, st);
         return TMPNN_OK;
     }
-    const int nch = ceil_div(rows, 1024);
-    if (ws_floats < (size_t)nch * cols) return set_error(TMPNN_EWORKSPACE, "colsum: workspace too small");
+    const int nch = ceil_div(rows, 128);
+    if (ws_floats < colsum_ws_floats(rows, cols)) return set_error(TMPNN_EWORKSPACE, "colsum: workspace too small");
     hipLaunchKernelGGL(k_colsum_partial, dim3(nch, ceil_div(cols, 64)), dim3(256), 0, st, src, ld, mul, ldm, rows,
                        cols, ws);
     int rc = check_launch("colsum_partial");
     if (rc) return rc;
-    return launch_reduce_slabs(ws, cols, nch, dst, cols, accumulate, st);
+    return launch_reduce_slabs(ws, cols, nch, dst, cols, accumulate, st, ws + (size_t)nch * cols);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -194,15 +200,19 @@ __global__ void k_bn_stats(const float* __restrict__ y, const int32_t* __restric
     rstd[(size_t)s * H + j] = rsqrtf(var + BN_EPS);
 }
 
-// running statistics: windows are seen one after another in the reference, so the momentum
-// update is applied segment by segment (unbiased variance), one thread per feature.
+// running statistics: windows are seen one after another in the reference, so the momentum update
+// is applied segment by segment (unbiased variance), one thread per feature.  A segment that is L
+// places from the end carries the weight 0.1 * 0.9^L, so only the last 320 can reach an fp32 result
+// (0.9^320 = 2e-15): older ones, and the incoming running value, are dropped when S > 320.
 __global__ void k_bn_running(const float* __restrict__ mean, const float* __restrict__ rstd,
                              const int32_t* __restrict__ seg_cnt, int S, int H, float* __restrict__ rm,
                              float* __restrict__ rv) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= H) return;
-    float m = rm[j], v = rv[j];
-    for (int s = 0; s < S; ++s) {
+    const int s0 = S > 320 ? S - 320 : 0;
+    float m = s0 > 0 ? 0.f : rm[j], v = s0 > 0 ? 0.f : rv[j];
+#pragma unroll 8
+    for (int s = s0; s < S; ++s) {
         const float cnt = (float)seg_cnt[s];
         const float r = rstd[(size_t)s * H + j];
         const float var = 1.0f / (r * r) - BN_EPS;
@@ -409,13 +419,13 @@ __global__ __launch_bounds__(256) void k_heads_bwd(const float* __restrict__ h, 
     }
 }
 
-__global__ void k_heads_bwd_final(const float* __restrict__ part, int nblk, int C, float* __restrict__ dw_node,
+// scatter the reduced [2C+2] vector into the four gradient buffers (+=)
+__global__ void k_heads_bwd_final(const float* __restrict__ red, int C, float* __restrict__ dw_node,
                                   float* __restrict__ db_node, float* __restrict__ dw_edge,
                                   float* __restrict__ db_edge) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= 2 * C + 2) return;
-    float s = 0.f;
-    for (int k = 0; k < nblk; ++k) s += part[(size_t)k * (2 * C + 2) + j];
+    const float s = red[j];
     if (j < C) dw_node[j] += s;
     else if (j < 2 * C) dw_edge[j - C] += s;
     else if (j == 2 * C) db_node[0] += s;
@@ -423,7 +433,7 @@ __global__ void k_heads_bwd_final(const float* __restrict__ part, int nblk, int 
 }
 
 static int heads_rows_per_block(int N) {
-    long rpb = ((long)N + 1023) / 1024;     // at most 1024 partial blocks
+    long rpb = ((long)N + 2047) / 2048;     // at most 2048 partial blocks
     if (rpb < 64) rpb = 64;
     return (int)rpb;
 }
@@ -487,11 +497,7 @@ int tmpnn_input_bn_bwd(const float* xdet, int ld_x, int F, int nd, const int32_t
     }
     TM_REQUIRE(xdet && y_save && out_row && d_h && ws, "input_bn_bwd: null buffers");
     const size_t ndH = (size_t)nd * H, SH = (size_t)(S > 0 ? S : 1) * H;
-    const size_t cs_ws = colsum_ws_floats(nd, H);
-    size_t gk = gemm_splitk_ws_floats(H, H, nd);
-    const size_t gk1 = gemm_splitk_ws_floats(H, F, nd);
-    if (gk1 > gk) gk = gk1;
-    const size_t need = 3 * ndH + 2 * SH + (cs_ws > gk ? cs_ws : gk);
+    const size_t need = tmpnn_input_bn_bwd_ws(nd, S, H, F);
     if (ws_floats < need) return set_error(TMPNN_EWORKSPACE, "input_bn_bwd: workspace %zu < %zu floats", ws_floats, need);
     float* B0 = ws;              // d_out -> dy
     float* B1 = B0 + ndH;        // yhat
@@ -590,7 +596,8 @@ size_t tmpnn_heads_bwd_ws(int N, int C) {
     if (N <= 0) return 0;
     const int rpb = heads_rows_per_block(N);
     const int nblk = ceil_div(N, rpb);
-    return (size_t)nblk * (2 * C + 2) * sizeof(float);
+    const size_t n = 2 * (size_t)C + 2;
+    return ((size_t)nblk * n + n + reduce_slabs_ws_floats(nblk, n)) * sizeof(float);
 }
 
 int tmpnn_heads_bwd(const float* h, int ld_h, int C, int N, const uint8_t* is_edge, const float* w_node,
@@ -618,8 +625,12 @@ int tmpnn_heads_bwd(const float* h, int ld_h, int C, int N, const uint8_t* is_ed
                        d_logits, d_scores, d_h, ld_dh, accumulate, rpb, reinterpret_cast<float*>(ws));
     int rc = check_launch("heads_bwd");
     if (rc) return rc;
-    hipLaunchKernelGGL(k_heads_bwd_final, dim3(ceil_div(2 * C + 2, 256)), dim3(256), 0, st,
-                       reinterpret_cast<const float*>(ws), nblk, C, dw_node, db_node, dw_edge, db_edge);
+    const size_t nred = 2 * (size_t)C + 2;
+    float* part = reinterpret_cast<float*>(ws);
+    float* red = part + (size_t)nblk * nred;
+    if ((rc = launch_reduce_slabs(part, nred, nblk, red, nred, 0, st, red + nred))) return rc;
+    hipLaunchKernelGGL(k_heads_bwd_final, dim3(ceil_div(2 * C + 2, 256)), dim3(256), 0, st, red, C, dw_node, db_node,
+                       dw_edge, db_edge);
     return check_launch("heads_bwd_final");
 }
 

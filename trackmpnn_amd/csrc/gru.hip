@@ -332,6 +332,344 @@ __global__ __launch_bounds__(256) void k_gru_bwd_weights(GruBwdWArgs a) {
     }
 }
 
+
+// ==========================================================================================
+// LDS-resident-weight variants for the headline width (H <= 64).
+//
+// At H = 64 both weight matrices of a cell (2 x 48 KiB fp32) fit the 160 KiB LDS of a CU, so a
+// block of 8 waves (2 per SIMD) loads them once and then streams row tiles through the fp32
+// MFMAs: the B operand becomes a conflict-free ds_read_b32 (a half-wave reads 32 consecutive
+// floats), nothing but state rows and gates crosses L2/HBM, and the grid is persistent
+// (<= 1 block per CU) so the weight load is amortised over the whole launch.
+// ==========================================================================================
+template <int H, int IN, int XMODE>
+__global__ __launch_bounds__(512) void k_gru_fwd_lds(GruFwdArgs a, int ntiles) {
+    extern __shared__ float lds[];
+    constexpr int H3 = 3 * H;
+    constexpr int CT = H / 32;
+    float* sWih = lds;               // [IN][3H]
+    float* sWhh = lds + IN * H3;     // [H][3H]
+    for (int i = threadIdx.x * 4; i < IN * H3; i += 512 * 4)
+        *reinterpret_cast<float4*>(sWih + i) = *reinterpret_cast<const float4*>(a.wih_t + i);
+    for (int i = threadIdx.x * 4; i < H * H3; i += 512 * 4)
+        *reinterpret_cast<float4*>(sWhh + i) = *reinterpret_cast<const float4*>(a.whh_t + i);
+    __syncthreads();
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int c = lane & 31, half = lane >> 5;
+
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int r0 = (tile * 8 + wave) * 32;
+        if (r0 >= a.R) continue;
+        const int li = min(r0 + c, a.R - 1);
+        const int row = a.rows[li];
+        f32x16 acc_r[CT], acc_z[CT], acc_in[CT], acc_hn[CT];
+#pragma unroll
+        for (int t = 0; t < CT; ++t)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { acc_r[t][i] = 0.f; acc_z[t][i] = 0.f; acc_in[t][i] = 0.f; acc_hn[t][i] = 0.f; }
+#pragma unroll
+        for (int kt = 0; kt < IN / 32; ++kt) {
+            const int f0 = kt * 32 + half * 16;
+            float av[16];
+            load_x16<XMODE>(a, li, row, f0, av);
+            const float* b0 = sWih + f0 * H3 + c;
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+#pragma unroll
+                for (int t = 0; t < CT; ++t) {
+                    acc_r[t] = mfma32(av[s], b0[s * H3 + t * 32], acc_r[t]);
+                    acc_z[t] = mfma32(av[s], b0[s * H3 + H + t * 32], acc_z[t]);
+                    acc_in[t] = mfma32(av[s], b0[s * H3 + 2 * H + t * 32], acc_in[t]);
+                }
+            }
+        }
+#pragma unroll
+        for (int kt = 0; kt < H / 32; ++kt) {
+            const int f0 = kt * 32 + half * 16;
+            float av[16];
+            load16(a.h + (size_t)row * a.ld_h + f0, av);
+            const float* b0 = sWhh + f0 * H3 + c;
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+#pragma unroll
+                for (int t = 0; t < CT; ++t) {
+                    acc_r[t] = mfma32(av[s], b0[s * H3 + t * 32], acc_r[t]);
+                    acc_z[t] = mfma32(av[s], b0[s * H3 + H + t * 32], acc_z[t]);
+                    acc_hn[t] = mfma32(av[s], b0[s * H3 + 2 * H + t * 32], acc_hn[t]);
+                }
+            }
+        }
+        int orow[16];
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const int lpos = r0 + acc_row(reg, half);
+            orow[reg] = lpos < a.R ? a.rows[lpos] : -1;
+        }
+#pragma unroll
+        for (int t = 0; t < CT; ++t) {
+            const int col = t * 32 + c;
+            const float br = a.b_ih[col] + a.b_hh[col];
+            const float bz = a.b_ih[H + col] + a.b_hh[H + col];
+            const float bin = a.b_ih[2 * H + col];
+            const float bhn = a.b_hh[2 * H + col];
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                if (orow[reg] >= 0) {
+                    const float r = sigmoidf_(acc_r[t][reg] + br);
+                    const float z = sigmoidf_(acc_z[t][reg] + bz);
+                    const float hn = acc_hn[t][reg] + bhn;
+                    const float n = tanhf(acc_in[t][reg] + bin + r * hn);
+                    const float hp = a.h[(size_t)orow[reg] * a.ld_h + col];
+                    a.h_out[(size_t)orow[reg] * a.ld_out + col] = (1.0f - z) * n + z * hp;
+                    if (a.gates) {
+                        float* gp = a.gates + (size_t)orow[reg] * H + col;
+                        gp[0] = r;
+                        gp[a.gate_plane] = z;
+                        gp[2 * a.gate_plane] = n;
+                        gp[3 * a.gate_plane] = hn;
+                    }
+                }
+            }
+        }
+    }
+}
+
+// d_msg = d_gi @ W_ih and d_h = d_hout*z + d_gh @ W_hh in ONE pass over the gates
+template <int H, int IN>
+__global__ __launch_bounds__(512) void k_gru_bwd_data_lds(GruBwdDataArgs a, int ntiles) {
+    extern __shared__ float lds[];
+    constexpr int NTX = IN / 32, NTH = H / 32;
+    float* sWih = lds;                 // [3H][IN]
+    float* sWhh = lds + 3 * H * IN;    // [3H][H]
+    for (int i = threadIdx.x * 4; i < 3 * H * IN; i += 512 * 4)
+        *reinterpret_cast<float4*>(sWih + i) = *reinterpret_cast<const float4*>(a.w_ih + i);
+    for (int i = threadIdx.x * 4; i < 3 * H * H; i += 512 * 4)
+        *reinterpret_cast<float4*>(sWhh + i) = *reinterpret_cast<const float4*>(a.w_hh + i);
+    __syncthreads();
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int c = lane & 31, half = lane >> 5;
+    const size_t gp = a.gate_plane;
+
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int r0 = (tile * 8 + wave) * 32;
+        if (r0 >= a.R) continue;
+        const int li = min(r0 + c, a.R - 1);
+        const int row = a.rows[li];
+        f32x16 accx[NTX], acch[NTH];
+#pragma unroll
+        for (int t = 0; t < NTX; ++t)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) accx[t][i] = 0.f;
+#pragma unroll
+        for (int t = 0; t < NTH; ++t)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acch[t][i] = 0.f;
+#pragma unroll
+        for (int fb = 0; fb < H / 32; ++fb) {
+            const int f0 = fb * 32 + half * 16;
+            float dh[16], r[16], z[16], n[16], hn[16], hp[16];
+            load16(a.d_hout + (size_t)row * a.ld_dhout + f0, dh);
+            const float* g0 = a.gates + (size_t)row * H + f0;
+            load16(g0, r);
+            load16(g0 + gp, z);
+            load16(g0 + 2 * gp, n);
+            load16(g0 + 3 * gp, hn);
+            load16(a.h + (size_t)row * a.ld_h + f0, hp);
+            float ar[16], az[16], an[16], anr[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const float dn = dh[i] * (1.0f - z[i]) * (1.0f - n[i] * n[i]);
+                ar[i] = dn * hn[i] * r[i] * (1.0f - r[i]);
+                az[i] = dh[i] * (hp[i] - n[i]) * z[i] * (1.0f - z[i]);
+                an[i] = dn;
+                anr[i] = dn * r[i];
+            }
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+                const float* wx = sWih + (f0 + s) * IN + c;
+                const float* wh = sWhh + (f0 + s) * H + c;
+#pragma unroll
+                for (int t = 0; t < NTX; ++t) {
+                    accx[t] = mfma32(ar[s], wx[t * 32], accx[t]);
+                    accx[t] = mfma32(az[s], wx[H * IN + t * 32], accx[t]);
+                    accx[t] = mfma32(an[s], wx[2 * H * IN + t * 32], accx[t]);
+                }
+#pragma unroll
+                for (int t = 0; t < NTH; ++t) {
+                    acch[t] = mfma32(ar[s], wh[t * 32], acch[t]);
+                    acch[t] = mfma32(az[s], wh[H * H + t * 32], acch[t]);
+                    acch[t] = mfma32(anr[s], wh[2 * H * H + t * 32], acch[t]);
+                }
+            }
+        }
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const int lpos = r0 + acc_row(reg, half);
+            if (lpos < a.R) {
+                const int orow = a.rows[lpos];
+#pragma unroll
+                for (int t = 0; t < NTX; ++t) a.d_msg[(size_t)orow * a.ld_dmsg + t * 32 + c] = accx[t][reg];
+#pragma unroll
+                for (int t = 0; t < NTH; ++t) {
+                    const int col = t * 32 + c;
+                    const float zz = a.gates[gp + (size_t)orow * H + col];
+                    a.d_h[(size_t)orow * a.ld_dh + col] = acch[t][reg] + a.d_hout[(size_t)orow * a.ld_dhout + col] * zz;
+                }
+            }
+        }
+    }
+}
+
+// Weight gradient, block-staged (IN == H): 32-row tiles of d_g = [dr|dz|dn|dn*r] and [x|h] are formed
+// once in LDS and consumed by all four waves as MFMA operands (A = d_g^T, B = [x|h]); each wave owns
+// 3 x (H/32) output tiles of dW_ih (waves 0,1) or dW_hh (waves 2,3).  Persistent blocks keep their
+// partial dW in registers over all their tiles and write ONE slab each.
+template <int H, int XMODE>
+__global__ __launch_bounds__(256, 2) void k_gru_bwd_weights_lds(GruBwdWArgs a, int ntiles) {
+    constexpr int NC = H / 32;           // column tiles per matrix
+    constexpr int DG = 4 * H;            // dr | dz | dn | dnr
+    constexpr int XHW = 2 * H;           // x | h
+    constexpr int F8 = H / 8;            // threads per row in the staging phase
+    constexpr int RT = 256 / F8;         // rows per tile (32 at H = 64)
+    static_assert(RT == 32, "staging layout assumes 32-row tiles");
+    __shared__ float s_dg[RT * DG];
+    __shared__ float s_xh[RT * XHW];
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63;
+    const int c = lane & 31, half = lane >> 5;
+    const int which = wave >> 1;                 // 0: dW_ih (x columns), 1: dW_hh (h columns)
+    const int jt0 = (wave & 1) * 3 * (H / 64) ;  // first of this wave's j tiles (3H/32 tiles split in two)
+    constexpr int NJ = 3 * H / 64;               // j tiles per wave
+    const size_t gp = a.gate_plane;
+    const int srow = tid / F8, f8 = (tid % F8) * 8;
+
+    f32x16 acc[NJ][NC];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int t = 0; t < NC; ++t)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[j][t][i] = 0.f;
+    float csum = 0.f;                            // column sum of d_g column `tid` (bias gradients)
+
+    // LDS column of A for (j tile, lane): the n gate of dW_hh reads the dn*r block
+    int colA[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int jj = (jt0 + j) * 32 + c;
+        colA[j] = (which == 1 && jj >= 2 * H) ? jj + H : jj;
+    }
+    const int colB0 = which * H + c;
+
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        // ---- stage: 8 features of one row per thread
+        const int lpos_raw = tile * RT + srow;
+        const bool valid = lpos_raw < a.R;
+        const int lpos = valid ? lpos_raw : a.R - 1;
+        const int orow = a.rows[lpos];
+        float dh[8], r[8], z[8], n[8], hn[8], hp[8], x[8];
+        {
+            const float4* p;
+            p = reinterpret_cast<const float4*>(a.d_hout + (size_t)orow * a.ld_dhout + f8);
+            float4 u = p[0], v = p[1];
+            dh[0] = u.x; dh[1] = u.y; dh[2] = u.z; dh[3] = u.w; dh[4] = v.x; dh[5] = v.y; dh[6] = v.z; dh[7] = v.w;
+            p = reinterpret_cast<const float4*>(a.gates + (size_t)orow * H + f8);
+            u = p[0]; v = p[1];
+            r[0] = u.x; r[1] = u.y; r[2] = u.z; r[3] = u.w; r[4] = v.x; r[5] = v.y; r[6] = v.z; r[7] = v.w;
+            p = reinterpret_cast<const float4*>(a.gates + gp + (size_t)orow * H + f8);
+            u = p[0]; v = p[1];
+            z[0] = u.x; z[1] = u.y; z[2] = u.z; z[3] = u.w; z[4] = v.x; z[5] = v.y; z[6] = v.z; z[7] = v.w;
+            p = reinterpret_cast<const float4*>(a.gates + 2 * gp + (size_t)orow * H + f8);
+            u = p[0]; v = p[1];
+            n[0] = u.x; n[1] = u.y; n[2] = u.z; n[3] = u.w; n[4] = v.x; n[5] = v.y; n[6] = v.z; n[7] = v.w;
+            p = reinterpret_cast<const float4*>(a.gates + 3 * gp + (size_t)orow * H + f8);
+            u = p[0]; v = p[1];
+            hn[0] = u.x; hn[1] = u.y; hn[2] = u.z; hn[3] = u.w; hn[4] = v.x; hn[5] = v.y; hn[6] = v.z; hn[7] = v.w;
+            p = reinterpret_cast<const float4*>(a.h + (size_t)orow * a.ld_h + f8);
+            u = p[0]; v = p[1];
+            hp[0] = u.x; hp[1] = u.y; hp[2] = u.z; hp[3] = u.w; hp[4] = v.x; hp[5] = v.y; hp[6] = v.z; hp[7] = v.w;
+            if (XMODE == 0) {
+                p = reinterpret_cast<const float4*>(a.msg + (size_t)(a.msg_compact ? lpos : orow) * a.ld_msg + f8);
+                u = p[0]; v = p[1];
+                x[0] = u.x; x[1] = u.y; x[2] = u.z; x[3] = u.w; x[4] = v.x; x[5] = v.y; x[6] = v.z; x[7] = v.w;
+            } else {
+                p = reinterpret_cast<const float4*>(a.h + (size_t)a.src[lpos] * a.ld_h + f8);
+                u = p[0]; v = p[1];
+                const float4* q = reinterpret_cast<const float4*>(a.h + (size_t)a.dst[lpos] * a.ld_h + f8);
+                const float4 u2 = q[0], v2 = q[1];
+                x[0] = u.x - u2.x; x[1] = u.y - u2.y; x[2] = u.z - u2.z; x[3] = u.w - u2.w;
+                x[4] = v.x - v2.x; x[5] = v.y - v2.y; x[6] = v.z - v2.z; x[7] = v.w - v2.w;
+            }
+        }
+        float dr[8], dz[8], dn[8], dnr[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float d0 = valid ? dh[i] : 0.f;
+            const float t = d0 * (1.0f - z[i]) * (1.0f - n[i] * n[i]);
+            dn[i] = t;
+            dnr[i] = t * r[i];
+            dr[i] = t * hn[i] * r[i] * (1.0f - r[i]);
+            dz[i] = d0 * (hp[i] - n[i]) * z[i] * (1.0f - z[i]);
+        }
+        __syncthreads();                         // the previous tile's MFMA phase has drained the LDS
+        {
+            float* d = s_dg + srow * DG + f8;
+            *reinterpret_cast<float4*>(d) = make_float4(dr[0], dr[1], dr[2], dr[3]);
+            *reinterpret_cast<float4*>(d + 4) = make_float4(dr[4], dr[5], dr[6], dr[7]);
+            *reinterpret_cast<float4*>(d + H) = make_float4(dz[0], dz[1], dz[2], dz[3]);
+            *reinterpret_cast<float4*>(d + H + 4) = make_float4(dz[4], dz[5], dz[6], dz[7]);
+            *reinterpret_cast<float4*>(d + 2 * H) = make_float4(dn[0], dn[1], dn[2], dn[3]);
+            *reinterpret_cast<float4*>(d + 2 * H + 4) = make_float4(dn[4], dn[5], dn[6], dn[7]);
+            *reinterpret_cast<float4*>(d + 3 * H) = make_float4(dnr[0], dnr[1], dnr[2], dnr[3]);
+            *reinterpret_cast<float4*>(d + 3 * H + 4) = make_float4(dnr[4], dnr[5], dnr[6], dnr[7]);
+            float* e = s_xh + srow * XHW + f8;
+            *reinterpret_cast<float4*>(e) = make_float4(x[0], x[1], x[2], x[3]);
+            *reinterpret_cast<float4*>(e + 4) = make_float4(x[4], x[5], x[6], x[7]);
+            *reinterpret_cast<float4*>(e + H) = make_float4(hp[0], hp[1], hp[2], hp[3]);
+            *reinterpret_cast<float4*>(e + H + 4) = make_float4(hp[4], hp[5], hp[6], hp[7]);
+        }
+        __syncthreads();
+        if (tid < DG) {
+#pragma unroll 8
+            for (int rr = 0; rr < RT; ++rr) csum += s_dg[rr * DG + tid];
+        }
+        // ---- MFMA: one step eats two rows (lane half picks the row)
+#pragma unroll 4
+        for (int s = 0; s < RT / 2; ++s) {
+            const float* ar = s_dg + (2 * s + half) * DG;
+            const float* br = s_xh + (2 * s + half) * XHW + colB0;
+            float av[NJ], bv[NC];
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) av[j] = ar[colA[j]];
+#pragma unroll
+            for (int t = 0; t < NC; ++t) bv[t] = br[t * 32];
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                for (int t = 0; t < NC; ++t) acc[j][t] = mfma32(av[j], bv[t], acc[j][t]);
+        }
+    }
+    // ---- one slab per block: [3H][IN+H] weights, then [2][3H] biases
+    float* sw = a.slab_w + (size_t)blockIdx.x * (3 * H) * XHW;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int t = 0; t < NC; ++t)
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int jj = (jt0 + j) * 32 + acc_row(reg, half);
+                sw[(size_t)jj * XHW + which * H + t * 32 + c] = acc[j][t][reg];
+            }
+    if (tid < DG) {
+        const float sum = csum;
+        float* sb = a.slab_b + (size_t)blockIdx.x * 6 * H;
+        const int g = tid / H, f = tid % H;
+        if (g < 3) sb[g * H + f] = sum;                   // d_gi sums: dr | dz | dn
+        if (g < 2) sb[3 * H + g * H + f] = sum;           // d_gh sums: dr | dz | dn*r
+        if (g == 3) sb[3 * H + 2 * H + f] = sum;
+    }
+}
+
 // dW_ih[j][k] += sum_rs slab[rs][j][k], k < IN ; dW_hh[j][k-IN] += ... ; biases likewise
 __global__ void k_gru_reduce_w(const float* __restrict__ slab_w, const float* __restrict__ slab_b, int n_rs,
                                int IN, int H, float* __restrict__ dW_ih, float* __restrict__ dW_hh,
@@ -352,6 +690,17 @@ __global__ void k_gru_reduce_w(const float* __restrict__ slab_w, const float* __
         if (b < 3 * H) db_ih[b] += s;
         else db_hh[b - 3 * H] += s;
     }
+}
+
+__global__ void k_fold_slabs_gru(const float* __restrict__ slabs, size_t stride, int nslab, float* __restrict__ out,
+                                 size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int k0 = blockIdx.y * 32, k1 = min(nslab, k0 + 32);
+    float s = 0.f;
+#pragma unroll 8
+    for (int k = k0; k < k1; ++k) s += slabs[(size_t)k * stride + i];
+    out[(size_t)blockIdx.y * n + i] = s;
 }
 
 static void plan_weights(int R, int IN, int H, int* n_rs, int* RS, int* NQ, int* NCH) {
@@ -396,9 +745,26 @@ int tmpnn_gru_fwd(const int32_t* rows, int R, int xmode, const int32_t* src, con
     TM_REQUIRE(gates == nullptr || gate_plane >= (size_t)H, "gru_fwd: gate_plane too small");
     GruFwdArgs a{rows, R, src, dst, msg, ld_msg, IN, msg_compact, h, ld_h, H, wih_t, whh_t, b_ih, b_hh, h_out, ld_out, gates,
                  gate_plane};
+    hipStream_t st = as_stream(stream);
+    if (H <= 64 && aligned16(wih_t) && aligned16(whh_t)) {
+        // weights resident in LDS, persistent 8-wave blocks (see k_gru_fwd_lds)
+        const int ntiles = ceil_div(R, 256);
+        dim3 pgrid(ntiles < 256 ? ntiles : 256), pblock(512);
+        const size_t shm = sizeof(float) * (size_t)(IN + H) * 3 * H;
+#define LL(HH, II, X)                                                                                        \
+    do {                                                                                                     \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gru_fwd_lds<HH, II, X>),                  \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);                     \
+        hipLaunchKernelGGL((k_gru_fwd_lds<HH, II, X>), pgrid, pblock, shm, st, a, ntiles);                   \
+    } while (0)
+        if (H == 64) { if (xmode == 0 && IN == 64) LL(64, 64, 0); else if (xmode == 1) LL(64, 64, 1); else if (xmode == 2) LL(64, 128, 2); else goto generic; }
+        else         { if (xmode == 0 && IN == 32) LL(32, 32, 0); else if (xmode == 1) LL(32, 32, 1); else if (xmode == 2) LL(32, 64, 2); else goto generic; }
+#undef LL
+        return check_launch("gru_fwd_lds");
+    }
+generic:
     const int CT = (H % 64 == 0) ? 2 : 1;
     dim3 grid(ceil_div(R, 128), H / (32 * CT)), block(256);
-    hipStream_t st = as_stream(stream);
 #define L(C, X) hipLaunchKernelGGL((k_gru_fwd<C, X>), grid, block, 0, st, a)
     if (CT == 2) { if (xmode == 0) L(2, 0); else if (xmode == 1) L(2, 1); else L(2, 2); }
     else         { if (xmode == 0) L(1, 0); else if (xmode == 1) L(1, 1); else L(1, 2); }
@@ -419,19 +785,42 @@ int tmpnn_gru_bwd_data(const int32_t* rows, int R, int IN, const float* h, int l
     TM_REQUIRE(ld_dmsg >= IN && ld_dh >= H && ld_h >= H && ld_dhout >= H, "gru_bwd_data: leading dimension too small");
     GruBwdDataArgs a{rows, R, IN, h, ld_h, H, w_ih, w_hh, gates, gate_plane, d_hout, ld_dhout, d_msg, ld_dmsg, d_h,
                      ld_dh};
+    hipStream_t st = as_stream(stream);
+    if (H <= 64 && (IN == H || IN == 2 * H) && aligned16(w_ih) && aligned16(w_hh)) {
+        const int ntiles = ceil_div(R, 256);
+        dim3 pgrid(ntiles < 256 ? ntiles : 256), pblock(512);
+        const size_t shm = sizeof(float) * (size_t)(IN + H) * 3 * H;
+#define LL(HH, II)                                                                                           \
+    do {                                                                                                     \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gru_bwd_data_lds<HH, II>),                \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);                     \
+        hipLaunchKernelGGL((k_gru_bwd_data_lds<HH, II>), pgrid, pblock, shm, st, a, ntiles);                 \
+    } while (0)
+        if (H == 64) { if (IN == 64) LL(64, 64); else LL(64, 128); }
+        else         { if (IN == 32) LL(32, 32); else LL(32, 64); }
+#undef LL
+        return check_launch("gru_bwd_data_lds");
+    }
     const int NT = (H % 64 == 0) ? 2 : 1;
     dim3 grid(ceil_div(R, 128), (IN + H) / (32 * NT)), block(256);
-    hipStream_t st = as_stream(stream);
     if (NT == 2) hipLaunchKernelGGL((k_gru_bwd_data<2>), grid, block, 0, st, a);
     else hipLaunchKernelGGL((k_gru_bwd_data<1>), grid, block, 0, st, a);
     return check_launch("gru_bwd_data");
+}
+
+static bool weights_use_lds(int IN, int H) { return H == 64 && IN == H; }
+static int weights_lds_blocks(int R) {
+    const int ntiles = ceil_div(R, 32);
+    return ntiles < 512 ? ntiles : 512;          // persistent: <= 2 blocks per CU
 }
 
 size_t tmpnn_gru_bwd_weights_ws(int R, int IN, int H) {
     if (R <= 0) return 0;
     int n_rs, RS, NQ, NCH;
     plan_weights(R, IN, H, &n_rs, &RS, &NQ, &NCH);
-    return ((size_t)n_rs * 3 * H * (IN + H) + (size_t)n_rs * 6 * H) * sizeof(float);
+    if (weights_use_lds(IN, H)) n_rs = weights_lds_blocks(R);
+    const size_t per = (size_t)3 * H * (IN + H) + (size_t)6 * H;
+    return ((size_t)n_rs * per + reduce_slabs_ws_floats(n_rs, per)) * sizeof(float);
 }
 
 int tmpnn_gru_bwd_weights(const int32_t* rows, int R, int xmode, const int32_t* src, const int32_t* dst,
@@ -451,20 +840,47 @@ int tmpnn_gru_bwd_weights(const int32_t* rows, int R, int xmode, const int32_t* 
         return set_error(TMPNN_EWORKSPACE, "gru_bwd_weights: workspace %zu < %zu bytes", ws_bytes, need);
     int n_rs, RS, NQ, NCH;
     plan_weights(R, IN, H, &n_rs, &RS, &NQ, &NCH);
+    const bool use_lds = weights_use_lds(IN, H) && xmode != 2 && (ld_h & 3) == 0 && (ld_dhout & 3) == 0 &&
+                         aligned16(h) && aligned16(d_hout) && aligned16(gates) && (gate_plane & 3) == 0 &&
+                         (xmode != 0 || ((ld_msg & 3) == 0 && aligned16(msg)));
+    if (use_lds) n_rs = weights_lds_blocks(R);
+    const size_t nW = (size_t)3 * H * (IN + H), nB = (size_t)6 * H;
     float* slab_w = reinterpret_cast<float*>(ws);
-    float* slab_b = slab_w + (size_t)n_rs * 3 * H * (IN + H);
+    float* slab_b = slab_w + (size_t)n_rs * nW;
+    float* fold = slab_b + (size_t)n_rs * nB;
     GruBwdWArgs a{rows, R, src, dst, msg, ld_msg, IN, msg_compact, h, ld_h, H, gates, gate_plane, d_hout, ld_dhout, slab_w, slab_b,
                   n_rs, RS, NQ, NCH};
-    const long nworkers = (long)n_rs * NQ * NCH;
-    dim3 grid(ceil_div(nworkers, 4)), block(256);
     hipStream_t st = as_stream(stream);
-    if (xmode == 0) hipLaunchKernelGGL((k_gru_bwd_weights<0>), grid, block, 0, st, a);
-    else if (xmode == 1) hipLaunchKernelGGL((k_gru_bwd_weights<1>), grid, block, 0, st, a);
-    else hipLaunchKernelGGL((k_gru_bwd_weights<2>), grid, block, 0, st, a);
-    int rc = check_launch("gru_bwd_weights");
+    int rc;
+    if (use_lds) {
+        const int ntiles = ceil_div(R, 32);
+        dim3 grid(n_rs), block(256);
+        if (xmode == 0) hipLaunchKernelGGL((k_gru_bwd_weights_lds<64, 0>), grid, block, 0, st, a, ntiles);
+        else hipLaunchKernelGGL((k_gru_bwd_weights_lds<64, 1>), grid, block, 0, st, a, ntiles);
+        rc = check_launch("gru_bwd_weights_lds");
+    } else {
+        const long nworkers = (long)n_rs * NQ * NCH;
+        dim3 grid(ceil_div(nworkers, 4)), block(256);
+        if (xmode == 0) hipLaunchKernelGGL((k_gru_bwd_weights<0>), grid, block, 0, st, a);
+        else if (xmode == 1) hipLaunchKernelGGL((k_gru_bwd_weights<1>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((k_gru_bwd_weights<2>), grid, block, 0, st, a);
+        rc = check_launch("gru_bwd_weights");
+    }
     if (rc) return rc;
-    const size_t n = (size_t)3 * H * (IN + H) + (size_t)6 * H;
-    hipLaunchKernelGGL(k_gru_reduce_w, dim3(ceil_div((long)n, 256)), dim3(256), 0, st, slab_w, slab_b, n_rs, IN, H,
+    // fold the slabs 32:1 when there are many, then add into the gradient buffers
+    const float* rw = slab_w;
+    const float* rb = slab_b;
+    int nred = n_rs;
+    if (n_rs > 64) {
+        const int ng = ceil_div(n_rs, 32);
+        float* fw = fold;
+        float* fb = fold + (size_t)ng * nW;
+        hipLaunchKernelGGL(k_fold_slabs_gru, dim3(ceil_div((long)nW, 256), ng), dim3(256), 0, st, slab_w, nW, n_rs, fw, nW);
+        hipLaunchKernelGGL(k_fold_slabs_gru, dim3(ceil_div((long)nB, 256), ng), dim3(256), 0, st, slab_b, nB, n_rs, fb, nB);
+        if ((rc = check_launch("gru_fold"))) return rc;
+        rw = fw; rb = fb; nred = ng;
+    }
+    hipLaunchKernelGGL(k_gru_reduce_w, dim3(ceil_div((long)(nW + nB), 256)), dim3(256), 0, st, rw, rb, nred, IN, H,
                        dW_ih, dW_hh, db_ih, db_hh);
     return check_launch("gru_reduce_w");
 }

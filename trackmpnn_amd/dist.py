@@ -1,0 +1,55 @@
+"""Sequence-level data parallelism: one process per GPU, each owning different tracking windows.
+
+Windows are independent graphs (batch size 1 per forward in the reference, utils/graph.py:117), so
+the data path has NO collective; the only exchange is the gradient sum before the optimizer step.
+The parameter set is tiny (55 k .. 860 k fp32), i.e. the all-reduce is latency bound: all gradients
+live in ONE contiguous fp32 bucket (each `p.grad` is a view into it, so autograd accumulates in
+place and nothing is packed or unpacked) and ONE `all_reduce(SUM)` (RCCL over xGMI with the `nccl`
+backend; `gloo` in the CPU tests) is issued per step.  BatchNorm running statistics stay per rank,
+as in the reference (it has no SyncBN).
+"""
+from __future__ import annotations
+
+from typing import List
+
+import torch
+import torch.distributed as dist
+
+
+class GradBucket:
+    """Flat gradient storage for a module; `p.grad` of every parameter aliases a slice of `flat`."""
+
+    def __init__(self, module: torch.nn.Module):
+        params = [p for p in module.parameters() if p.requires_grad]
+        if not params:
+            raise ValueError('module has no trainable parameters')
+        dev, dt = params[0].device, torch.float32
+        n = sum(p.numel() for p in params)
+        self.flat = torch.zeros(n, dtype=dt, device=dev)
+        self.params: List[torch.nn.Parameter] = params
+        o = 0
+        for p in params:
+            p.grad = self.flat[o:o + p.numel()].view_as(p)
+            o += p.numel()
+
+    def check_alias(self) -> bool:
+        """True while every p.grad still aliases the bucket (zero_grad(set_to_none=True) breaks it)."""
+        o = 0
+        for p in self.params:
+            if p.grad is None or p.grad.data_ptr() != self.flat.data_ptr() + 4 * o:
+                return False
+            o += p.numel()
+        return True
+
+
+def allreduce_grads(module: torch.nn.Module, bucket: GradBucket, world: int) -> None:
+    """Sum the gradient bucket over ranks and average it (one collective)."""
+    if not bucket.check_alias():
+        raise RuntimeError('parameter gradients no longer alias the bucket; use zero_grad(set_to_none=False)')
+    dist.all_reduce(bucket.flat, op=dist.ReduceOp.SUM)
+    bucket.flat.mul_(1.0 / world)
+
+
+def shard_windows(n_windows: int, rank: int, world: int) -> List[int]:
+    """Rank r takes windows {i : i mod world == r} (reference shuffles chunks, train.py:22)."""
+    return list(range(rank, n_windows, world))
