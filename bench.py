@@ -52,8 +52,9 @@ def step(model, plans, xs, targets, opt, bucket, world):
     import torch.nn.functional as Fnn
     h = None
     loss = 0.0
-    for plan, x, t in zip(plans, xs, targets):
-        scores, logits, h, _ = model.forward_graph(x, h, plan)
+    for c, (plan, x, t) in enumerate(zip(plans, xs, targets)):
+        nxt = plans[c + 1].n_new if c + 1 < len(plans) else 0
+        scores, logits, h, _ = model.forward_graph(x, h, plan, reserve_rows=nxt)
         loss = loss + Fnn.binary_cross_entropy_with_logits(logits, t, reduction='sum')
     opt.zero_grad(set_to_none=False)
     loss.backward()
@@ -110,11 +111,20 @@ def stage_profile(model, plan, H):
 
     def gru_bwd_data():
         _lib.call('tmpnn_gru_bwd_data', g.edge_row.data_ptr(), E, H, h.data_ptr(), H, H, wih.data_ptr(), whh.data_ptr(),
-                  gates.data_ptr(), N * H, dout.data_ptr(), H, dmsg.data_ptr(), H, dh.data_ptr(), H, st)
+                  gates.data_ptr(), N * H, dout.data_ptr(), H, None, None, dmsg.data_ptr(), H, dh.data_ptr(), H,
+                  None, None, None, 0, st)
+
+    dyv = torch.randn(N, device=dev)
+    w_head = torch.randn(H, device=dev)
+
+    def gru_bwd_data_folded():      # as the training step runs it: head term folded in, row-F adjoint fused
+        _lib.call('tmpnn_gru_bwd_data', g.edge_row.data_ptr(), E, H, h.data_ptr(), H, H, wih.data_ptr(), whh.data_ptr(),
+                  gates.data_ptr(), N * H, dout.data_ptr(), H, dyv.data_ptr(), w_head.data_ptr(), dmsg.data_ptr(), H,
+                  dh.data_ptr(), H, g.src.data_ptr(), g.dst.data_ptr(), dmsg.data_ptr(), H, st)
 
     def gru_bwd_w():
         _lib.call('tmpnn_gru_bwd_weights', g.edge_row.data_ptr(), E, 1, g.src.data_ptr(), g.dst.data_ptr(), None, 0, 0,
-                  H, h.data_ptr(), H, H, gates.data_ptr(), N * H, dout.data_ptr(), H, gW[0].data_ptr(),
+                  H, h.data_ptr(), H, H, gates.data_ptr(), N * H, dout.data_ptr(), H, None, None, gW[0].data_ptr(),
                   gW[1].data_ptr(), gW[2].data_ptr(), gW[3].data_ptr(), ws.data_ptr(), wsb, st)
 
     def gather():
@@ -125,9 +135,11 @@ def stage_profile(model, plan, H):
 
     gru_fwd()          # gates must hold sane values before the backward kernels read them
     t = {name: time_stage(fn) for name, fn in (('gru_fwd_edge', gru_fwd), ('gru_bwd_data_edge', gru_bwd_data),
+                                               ('gru_bwd_data_edge_folded', gru_bwd_data_folded),
                                                ('gru_bwd_weights_edge', gru_bwd_w), ('gather_diff', gather),
                                                ('segsum', segsum))}
     flops = {'gru_fwd_edge': 12.0 * H * H * E, 'gru_bwd_data_edge': 12.0 * H * H * E,
+             'gru_bwd_data_edge_folded': 12.0 * H * H * E,
              'gru_bwd_weights_edge': 12.0 * H * H * E}
     # SURVEY 8(d) algorithmic bytes per launch
     b_gather = 4.0 * H * E + 4.0 * H * Dn + 8.0 * E

@@ -124,12 +124,22 @@ int tmpnn_gru_fwd(const int32_t* rows, int R, int xmode, const int32_t* src, con
                   const float* msg, int ld_msg, int msg_compact, int IN, const float* h, int ld_h, int H,
                   const float* wih_t, const float* whh_t, const float* b_ih, const float* b_hh,
                   float* h_out, int ld_out, float* gates, size_t gate_plane, tmpnn_stream stream);
-/* Data gradient: d_msg[row, 0:IN] = d_gi @ W_ih ; d_h[row] = d_hout[row]*z + d_gh @ W_hh
- * (both written, not accumulated).  W_ih [3H][IN], W_hh [3H][H] in the reference layout. */
+/* Upstream gradient of both backward entry points: dh[row] = d_hout[row] (NULL = 0) + dy[row] * w_head
+ * (dy NULL = no head term).  dy [N] is the gradient of the logits (tmpnn_heads_bwd's dy_out) and
+ * w_head [H] the slice of the output head (w_node for det rows, w_edge for edge rows) of this group.
+ *
+ * Data gradient: d_msg[row, 0:IN] = d_gi @ W_ih ; d_h[row] = dh[row]*z + d_gh @ W_hh (both written,
+ * not accumulated).  W_ih [3H][IN], W_hh [3H][H] in the reference layout.  If add_msg != NULL the
+ * adjoint of row F is fused into the store: d_h[row] += add_msg[add_src[r]] - add_msg[add_dst[r]]
+ * (rows = edge_row, add_src/dst = src/dst, add_msg = the d_msg buffer whose DET rows the node cell's
+ * call has already written). */
 int tmpnn_gru_bwd_data(const int32_t* rows, int R, int IN, const float* h, int ld_h, int H,
                        const float* w_ih, const float* w_hh,
                        const float* gates, size_t gate_plane, const float* d_hout, int ld_dhout,
-                       float* d_msg, int ld_dmsg, float* d_h, int ld_dh, tmpnn_stream stream);
+                       const float* dy, const float* w_head,
+                       float* d_msg, int ld_dmsg, float* d_h, int ld_dh,
+                       const int32_t* add_src, const int32_t* add_dst, const float* add_msg, int ld_add,
+                       tmpnn_stream stream);
 /* Weight gradient: dW_ih [3H][IN], dW_hh [3H][H], db_ih [3H], db_hh [3H] are ACCUMULATED (+=).
  * x is re-formed as in tmpnn_gru_fwd (xmode).  ws: tmpnn_gru_bwd_weights_ws(R, IN, H) bytes. */
 size_t tmpnn_gru_bwd_weights_ws(int R, int IN, int H);
@@ -137,6 +147,7 @@ int tmpnn_gru_bwd_weights(const int32_t* rows, int R, int xmode, const int32_t* 
                           const float* msg, int ld_msg, int msg_compact, int IN,
                           const float* h, int ld_h, int H,
                           const float* gates, size_t gate_plane, const float* d_hout, int ld_dhout,
+                          const float* dy, const float* w_head,
                           float* dW_ih, float* dW_hh, float* db_ih, float* db_hh,
                           void* ws, size_t ws_bytes, tmpnn_stream stream);
 
@@ -184,12 +195,13 @@ int tmpnn_input_bn_bwd(const float* xdet, int ld_x, int F, int nd, const int32_t
 int tmpnn_heads_fwd(const float* h, int ld_h, int C, int N, const uint8_t* is_edge,
                     const float* w_node, const float* b_node, const float* w_edge, const float* b_edge,
                     float* logits, float* scores, tmpnn_stream stream);
-/* d_y = d_logits + d_scores * s(1-s) (either may be NULL); d_h[i] (=|+=) d_y[i] * w_type(i);
- * dw_node/dw_edge [C], db_node/db_edge [1] accumulated (+=).  ws: tmpnn_heads_bwd_ws(N, C). */
+/* dy = d_logits + d_scores * s(1-s) (either may be NULL).  dy_out [N] (may be NULL) receives dy;
+ * d_h (may be NULL): d_h[i] (=|+=) dy[i] * w_type(i); dw_node/dw_edge [C], db_node/db_edge [1]
+ * accumulated (+=).  ws: tmpnn_heads_bwd_ws(N, C) bytes. */
 size_t tmpnn_heads_bwd_ws(int N, int C);
 int tmpnn_heads_bwd(const float* h, int ld_h, int C, int N, const uint8_t* is_edge,
                     const float* w_node, const float* w_edge, const float* scores,
-                    const float* d_logits, const float* d_scores,
+                    const float* d_logits, const float* d_scores, float* dy_out,
                     float* d_h, int ld_dh, int accumulate,
                     float* dw_node, float* db_node, float* dw_edge, float* db_edge,
                     void* ws, size_t ws_bytes, tmpnn_stream stream);

@@ -141,10 +141,45 @@ def check_gru(H, xmode, g, gd, rows_kind='edge'):
     dh = torch.zeros(g.N, ld, device=DEV)
     wihD, whhD = d(wih), d(whh)
     _lib.call('tmpnn_gru_bwd_data', rowsD.data_ptr(), R, IN, hD.data_ptr() + 4 * H, ld, H, wihD.data_ptr(),
-              whhD.data_ptr(), gates.data_ptr(), g.N * H, doutD.data_ptr() + 4 * H, ld, dmsg.data_ptr(), IN + 4,
-              dh.data_ptr() + 4 * H, ld, st())
+              whhD.data_ptr(), gates.data_ptr(), g.N * H, doutD.data_ptr() + 4 * H, ld, None, None,
+              dmsg.data_ptr(), IN + 4, dh.data_ptr() + 4 * H, ld, None, None, None, 0, st())
     res['dx'] = (dmsg.cpu()[rows, :IN] - x.grad).abs().max().item()
     res['dh'] = (dh.cpu()[rows, H:2 * H] - hrow.grad).abs().max().item()
+    # same gradient split as d_hout' + dy * w_head (the folded output-head term), plus the fused
+    # aggregation adjoint on edge rows
+    dyv = torch.randn(g.N)
+    wv = torch.randn(H)
+    split = doutfull.clone()
+    split[:, H:2 * H] -= dyv[:, None] * wv[None, :]
+    splitD, dyD, wD = d(split), d(dyv), d(wv)
+    addm = torch.randn(g.N, H + 8)
+    addD = d(addm)
+    dmsg2 = torch.zeros(g.N, IN + 4, device=DEV)
+    dh2 = torch.zeros(g.N, ld, device=DEV)
+    fuse = rows_kind == 'edge'
+    _lib.call('tmpnn_gru_bwd_data', rowsD.data_ptr(), R, IN, hD.data_ptr() + 4 * H, ld, H, wihD.data_ptr(),
+              whhD.data_ptr(), gates.data_ptr(), g.N * H, splitD.data_ptr() + 4 * H, ld, dyD.data_ptr(), wD.data_ptr(),
+              dmsg2.data_ptr(), IN + 4, dh2.data_ptr() + 4 * H, ld,
+              gd.src.data_ptr() if fuse else None, gd.dst.data_ptr() if fuse else None,
+              addD.data_ptr() if fuse else None, H + 8, st())
+    exp_dh = hrow.grad.clone()
+    if fuse:
+        exp_dh = exp_dh + addm[idx(g.src), :H] - addm[idx(g.dst), :H]
+    res['dx_split'] = (dmsg2.cpu()[rows, :IN] - x.grad).abs().max().item()
+    res['dh_split_fused'] = (dh2.cpu()[rows, H:2 * H] - exp_dh).abs().max().item()
+    # head term only (d_hout = NULL)
+    only = torch.zeros(g.N, ld)
+    only[:, H:2 * H] = dyv[:, None] * wv[None, :]
+    onlyD = d(only)
+    dm_a, dh_a = torch.zeros(g.N, IN + 4, device=DEV), torch.zeros(g.N, ld, device=DEV)
+    dm_b, dh_b = torch.zeros(g.N, IN + 4, device=DEV), torch.zeros(g.N, ld, device=DEV)
+    _lib.call('tmpnn_gru_bwd_data', rowsD.data_ptr(), R, IN, hD.data_ptr() + 4 * H, ld, H, wihD.data_ptr(),
+              whhD.data_ptr(), gates.data_ptr(), g.N * H, onlyD.data_ptr() + 4 * H, ld, None, None,
+              dm_a.data_ptr(), IN + 4, dh_a.data_ptr() + 4 * H, ld, None, None, None, 0, st())
+    _lib.call('tmpnn_gru_bwd_data', rowsD.data_ptr(), R, IN, hD.data_ptr() + 4 * H, ld, H, wihD.data_ptr(),
+              whhD.data_ptr(), gates.data_ptr(), g.N * H, None, 0, dyD.data_ptr(), wD.data_ptr(),
+              dm_b.data_ptr(), IN + 4, dh_b.data_ptr() + 4 * H, ld, None, None, None, 0, st())
+    res['dy_only'] = max((dm_a - dm_b).abs().max().item(), (dh_a - dh_b).abs().max().item())
     # backward, weights (accumulate into non-zero buffers)
     base = 0.5
     dW_ih = torch.full((3 * H, IN), base, device=DEV)
@@ -155,7 +190,8 @@ def check_gru(H, xmode, g, gd, rows_kind='edge'):
     ws = torch.empty(wsb // 4 + 1, device=DEV)
     _lib.call('tmpnn_gru_bwd_weights', rowsD.data_ptr(), R, xmode, gd.src.data_ptr() if xmode else None,
               gd.dst.data_ptr() if xmode else None, msgD.data_ptr() if xmode == 0 else None, IN, 1, IN,
-              hD.data_ptr() + 4 * H, ld, H, gates.data_ptr(), g.N * H, doutD.data_ptr() + 4 * H, ld,
+              hD.data_ptr() + 4 * H, ld, H, gates.data_ptr(), g.N * H, splitD.data_ptr() + 4 * H, ld,
+              dyD.data_ptr(), wD.data_ptr(),
               dW_ih.data_ptr(), dW_hh.data_ptr(), db_ih.data_ptr(), db_hh.data_ptr(), ws.data_ptr(), wsb, st())
     sc = max(1.0, wih.grad.abs().max().item())
     res['dW_ih'] = (dW_ih.cpu() - base - wih.grad).abs().max().item() / sc
@@ -195,11 +231,13 @@ def check_heads(C, g, gd):
     wsb = _lib.load().tmpnn_heads_bwd_ws(N, C)
     ws = torch.empty(wsb // 4 + 1, device=DEV)
     dlD, dsD = d(dl), d(ds)
+    dyo = torch.zeros(N, device=DEV)
     _lib.call('tmpnn_heads_bwd', hD.data_ptr(), C + 4, C, N, gd.is_edge.data_ptr(), wnD.data_ptr(), weD.data_ptr(),
-              scores.data_ptr(), dlD.data_ptr(), dsD.data_ptr(), dh.data_ptr(), C, 1,
+              scores.data_ptr(), dlD.data_ptr(), dsD.data_ptr(), dyo.data_ptr(), dh.data_ptr(), C, 1,
               g_wn.data_ptr(), g_bn.data_ptr(), g_we.data_ptr(), g_be.data_ptr(), ws.data_ptr(), wsb, st())
     sc = max(1.0, wn.grad.abs().max().item(), we.grad.abs().max().item())
     res['dh'] = (dh.cpu() - pre - hh.grad).abs().max().item()
+    res['dy'] = (dyo.cpu()[:, None] - (dl + ds * s.detach() * (1 - s.detach()))).abs().max().item()
     res['dw'] = max((g_wn.cpu() - wn.grad[0]).abs().max().item(), (g_we.cpu() - we.grad[0]).abs().max().item()) / sc
     res['db'] = max((g_bn.cpu() - bn.grad).abs().max().item(), (g_be.cpu() - be.grad).abs().max().item()) / sc
     return res

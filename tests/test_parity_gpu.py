@@ -251,3 +251,27 @@ def test_aggregation_properties_at_scale():
     # sum over dets of es == sum over edges of (h[e] - h[e]) == 0 column-wise: every edge enters once with + and once with -
     col = es.double().sum(0)
     assert col.abs().max().item() <= 1e-6 * h2.double().abs().sum(0).max().item()
+
+
+def test_inplace_append_is_bitwise_identical():
+    """reserve_rows (carried state extended in place, no copy) must not change a single bit, fwd or bwd."""
+    from trackmpnn_amd import TrackMPNN
+    plans, xs = _batched_case(B=8, frames=6, mean=5, max_dets=12, F=8, seed0=3)
+    outs = []
+    for reserve in (False, True):
+        torch.manual_seed(5)
+        model = TrackMPNN('2d', 3, 64, 0, 'diff').to(DEV).train()
+        with torch.no_grad():
+            for p in model.parameters():
+                p.add_(0.1 * torch.randn(p.shape, generator=torch.Generator().manual_seed(p.numel())).to(DEV))
+        h = None
+        loss = 0.0
+        for c, (plan, x) in enumerate(zip(plans, xs)):
+            nxt = plans[c + 1].n_new if (reserve and c + 1 < len(plans)) else 0
+            s, l, h, _ = model.forward_graph(x.to(DEV), h, plan.to(DEV), reserve_rows=nxt)
+            loss = loss + (l * l).sum() + s.sum()
+        loss.backward()
+        outs.append((h.detach().clone(), [p.grad.clone() for p in model.parameters()]))
+    assert torch.equal(outs[0][0], outs[1][0])
+    for a, b in zip(outs[0][1], outs[1][1]):
+        assert torch.equal(a, b)

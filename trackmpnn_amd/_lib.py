@@ -51,10 +51,12 @@ _SIGNATURES = {
                               c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                               c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
     'tmpnn_gru_bwd_data': (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p,
-                                   c_void_p, c_size_t, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p]),
+                                   c_void_p, c_size_t, c_void_p, c_int, c_void_p, c_void_p,
+                                   c_void_p, c_int, c_void_p, c_int,
+                                   c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     'tmpnn_gru_bwd_weights_ws': (c_size_t, [c_int, c_int, c_int]),
     'tmpnn_gru_bwd_weights': (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
-                                      c_void_p, c_int, c_int, c_void_p, c_size_t, c_void_p, c_int,
+                                      c_void_p, c_int, c_int, c_void_p, c_size_t, c_void_p, c_int, c_void_p, c_void_p,
                                       c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     'tmpnn_transpose': (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
     'tmpnn_input_bn_fwd': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_int,
@@ -71,7 +73,7 @@ _SIGNATURES = {
                                 c_void_p, c_void_p, c_void_p]),
     'tmpnn_heads_bwd_ws': (c_size_t, [c_int, c_int]),
     'tmpnn_heads_bwd': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-                                c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                                c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                 c_void_p, c_size_t, c_void_p]),
 }
 

@@ -368,7 +368,8 @@ __global__ __launch_bounds__(256) void k_heads_bwd(const float* __restrict__ h, 
                                                    const uint8_t* __restrict__ is_edge,
                                                    const float* __restrict__ w_node, const float* __restrict__ w_edge,
                                                    const float* __restrict__ scores, const float* __restrict__ d_logits,
-                                                   const float* __restrict__ d_scores, float* __restrict__ d_h,
+                                                   const float* __restrict__ d_scores, float* __restrict__ dy_out,
+                                                   float* __restrict__ d_h,
                                                    int ld_dh, int accumulate, int rows_per_block,
                                                    float* __restrict__ part) {
     extern __shared__ float sm[];          // [slots][2][C] + [slots][2]
@@ -391,13 +392,16 @@ __global__ __launch_bounds__(256) void k_heads_bwd(const float* __restrict__ h, 
             const bool e = is_edge[i] != 0;
             const float4 w = *reinterpret_cast<const float4*>((e ? w_edge : w_node) + c4);
             const float4 x = *reinterpret_cast<const float4*>(h + (size_t)i * ld_h + c4);
-            float* dp = d_h + (size_t)i * ld_dh + c4;
-            float4 o = make_float4(dy * w.x, dy * w.y, dy * w.z, dy * w.w);
-            if (accumulate) {
-                const float4 p = *reinterpret_cast<const float4*>(dp);
-                o.x += p.x; o.y += p.y; o.z += p.z; o.w += p.w;
+            if (dy_out && c4 == 0) dy_out[i] = dy;
+            if (d_h) {
+                float* dp = d_h + (size_t)i * ld_dh + c4;
+                float4 o = make_float4(dy * w.x, dy * w.y, dy * w.z, dy * w.w);
+                if (accumulate) {
+                    const float4 p = *reinterpret_cast<const float4*>(dp);
+                    o.x += p.x; o.y += p.y; o.z += p.z; o.w += p.w;
+                }
+                *reinterpret_cast<float4*>(dp) = o;
             }
-            *reinterpret_cast<float4*>(dp) = o;
             if (e) { ae.x += dy * x.x; ae.y += dy * x.y; ae.z += dy * x.z; ae.w += dy * x.w; if (c4 == 0) be += dy; }
             else   { an.x += dy * x.x; an.y += dy * x.y; an.z += dy * x.z; an.w += dy * x.w; if (c4 == 0) bn += dy; }
         }
@@ -602,15 +606,14 @@ size_t tmpnn_heads_bwd_ws(int N, int C) {
 
 int tmpnn_heads_bwd(const float* h, int ld_h, int C, int N, const uint8_t* is_edge, const float* w_node,
                     const float* w_edge, const float* scores, const float* d_logits, const float* d_scores,
-                    float* d_h, int ld_dh, int accumulate, float* dw_node, float* db_node, float* dw_edge,
-                    float* db_edge, void* ws, size_t ws_bytes, tmpnn_stream stream) {
+                    float* dy_out, float* d_h, int ld_dh, int accumulate, float* dw_node, float* db_node,
+                    float* dw_edge, float* db_edge, void* ws, size_t ws_bytes, tmpnn_stream stream) {
     TM_REQUIRE(C > 0 && (C & 3) == 0 && C <= 1024 && N >= 0, "heads_bwd: C=%d N=%d", C, N);
     if (N == 0) return TMPNN_OK;
-    TM_REQUIRE(h && is_edge && w_node && w_edge && d_h && dw_node && db_node && dw_edge && db_edge,
-               "heads_bwd: null pointer");
+    TM_REQUIRE(h && is_edge && w_node && w_edge && dw_node && db_node && dw_edge && db_edge, "heads_bwd: null pointer");
     TM_REQUIRE(d_scores == nullptr || scores != nullptr, "heads_bwd: d_scores needs scores");
-    TM_REQUIRE((ld_h & 3) == 0 && (ld_dh & 3) == 0 && aligned16(h) && aligned16(d_h) && aligned16(w_node) &&
-                   aligned16(w_edge),
+    TM_REQUIRE((ld_h & 3) == 0 && aligned16(h) && aligned16(w_node) && aligned16(w_edge) &&
+                   (d_h == nullptr || ((ld_dh & 3) == 0 && aligned16(d_h))),
                "heads_bwd: rows must be 16-byte aligned");
     const size_t need = tmpnn_heads_bwd_ws(N, C);
     if (!ws || ws_bytes < need) return set_error(TMPNN_EWORKSPACE, "heads_bwd: workspace %zu < %zu", ws_bytes, need);
@@ -622,7 +625,7 @@ int tmpnn_heads_bwd(const float* h, int ld_h, int C, int N, const uint8_t* is_ed
     const size_t shm = ((size_t)slots * 2 * C + (size_t)slots * 2) * sizeof(float);
     hipStream_t st = as_stream(stream);
     hipLaunchKernelGGL(k_heads_bwd, dim3(nblk), dim3(256), shm, st, h, ld_h, C, N, is_edge, w_node, w_edge, scores,
-                       d_logits, d_scores, d_h, ld_dh, accumulate, rpb, reinterpret_cast<float*>(ws));
+                       d_logits, d_scores, dy_out, d_h, ld_dh, accumulate, rpb, reinterpret_cast<float*>(ws));
     int rc = check_launch("heads_bwd");
     if (rc) return rc;
     const size_t nred = 2 * (size_t)C + 2;

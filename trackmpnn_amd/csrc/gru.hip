@@ -16,7 +16,14 @@
 
 namespace tmpnn {
 
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+// sigmoid / tanh on the hardware transcendentals (v_exp_f32, v_rcp_f32: 1 ulp each).  Both stay within
+// ~3e-7 of the libm results, far inside the 1e-4 parity budget, at a fraction of the VALU cost
+// (the gate epilogue competes with the MFMAs for issue slots).
+__device__ __forceinline__ float sigmoidf_(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+__device__ __forceinline__ float tanhf_(float x) {
+    // 1 - 2/(1+e^{2x}); saturates cleanly: e^{2x} -> inf gives 1, -> 0 gives -1
+    return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(2.0f * x));
+}
 
 __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
@@ -31,6 +38,56 @@ __device__ __forceinline__ void load16(const float* __restrict__ p, float* v) {
     for (int i = 0; i < 4; ++i) {
         const float4 t = q[i];
         v[4 * i + 0] = t.x; v[4 * i + 1] = t.y; v[4 * i + 2] = t.z; v[4 * i + 3] = t.w;
+    }
+}
+
+// upstream gradient of a cell's output: dh[row][f] = d_hout[row][f] (if given) + dy[row] * w_head[f] (if given).
+// The second term is the output head's contribution (track_mpnn.py:73), folded in here so that the
+// summed gradient never has to be materialised in HBM.
+struct DhSrc {
+    const float* d_hout; int ld_dhout;
+    const float* dy; const float* w_head;
+};
+__device__ __forceinline__ float dh_at(const DhSrc& s, int row, int f) {
+    float v = s.d_hout ? s.d_hout[(size_t)row * s.ld_dhout + f] : 0.f;
+    if (s.dy) v += s.dy[row] * s.w_head[f];
+    return v;
+}
+__device__ __forceinline__ void dh_load16(const DhSrc& s, int row, int f0, float* v) {
+    if (s.d_hout) load16(s.d_hout + (size_t)row * s.ld_dhout + f0, v);
+    else {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) v[i] = 0.f;
+    }
+    if (s.dy) {
+        const float d = s.dy[row];
+        float w[16];
+        load16(s.w_head + f0, w);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) v[i] += d * w[i];
+    }
+}
+
+// compile-time variants (UP bit 0: d_hout present, bit 1: head term present) for the hot LDS kernels
+template <int UP>
+__device__ __forceinline__ float dh_at_t(const DhSrc& s, int row, int f) {
+    float v = (UP & 1) ? s.d_hout[(size_t)row * s.ld_dhout + f] : 0.f;
+    if (UP & 2) v += s.dy[row] * s.w_head[f];
+    return v;
+}
+template <int UP>
+__device__ __forceinline__ void dh_load16_t(const DhSrc& s, int row, int f0, float* v) {
+    if (UP & 1) load16(s.d_hout + (size_t)row * s.ld_dhout + f0, v);
+    else {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) v[i] = 0.f;
+    }
+    if (UP & 2) {
+        const float d = s.dy[row];
+        float w[16];
+        load16(s.w_head + f0, w);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) v[i] += d * w[i];
     }
 }
 
@@ -130,7 +187,7 @@ __global__ __launch_bounds__(256, 2) void k_gru_fwd(GruFwdArgs a) {
                 const float r = sigmoidf_(acc_r[t][reg] + br);
                 const float z = sigmoidf_(acc_z[t][reg] + bz);
                 const float hn = acc_hn[t][reg] + bhn;
-                const float n = tanhf(acc_in[t][reg] + bin + r * hn);
+                const float n = tanhf_(acc_in[t][reg] + bin + r * hn);
                 const float hp = a.h[(size_t)orow * a.ld_h + col];
                 a.h_out[(size_t)orow * a.ld_out + col] = (1.0f - z) * n + z * hp;
                 if (a.gates) {
@@ -153,9 +210,11 @@ struct GruBwdDataArgs {
     const float* h; int ld_h; int H;
     const float* w_ih; const float* w_hh;
     const float* gates; size_t gate_plane;
-    const float* d_hout; int ld_dhout;
+    DhSrc up;
     float* d_msg; int ld_dmsg;
     float* d_h; int ld_dh;
+    // optional fused adjoint of the edge -> node sum (row F): d_h[row] += add_msg[add_src[r]] - add_msg[add_dst[r]]
+    const int32_t* add_src; const int32_t* add_dst; const float* add_msg; int ld_add;
 };
 
 // grid: (ceil(R/128), (IN+H)/(32*NT)); a block's NT*32 output columns lie entirely in d_msg
@@ -185,7 +244,7 @@ __global__ __launch_bounds__(256) void k_gru_bwd_data(GruBwdDataArgs a) {
     for (int fb = 0; fb < H / 32; ++fb) {
         const int f0 = fb * 32 + half * 16;
         float dh[16], r[16], z[16], n[16], hn[16], hp[16];
-        load16(a.d_hout + (size_t)row * a.ld_dhout + f0, dh);
+        dh_load16(a.up, row, f0, dh);
         const float* g0 = a.gates + (size_t)row * H + f0;
         load16(g0, r);
         load16(g0 + gp, z);
@@ -225,8 +284,11 @@ __global__ __launch_bounds__(256) void k_gru_bwd_data(GruBwdDataArgs a) {
                     a.d_msg[(size_t)orow * a.ld_dmsg + col] = acc[t][reg];
                 } else {
                     const float zz = a.gates[gp + (size_t)orow * H + col];
-                    a.d_h[(size_t)orow * a.ld_dh + col] =
-                        acc[t][reg] + a.d_hout[(size_t)orow * a.ld_dhout + col] * zz;
+                    float v = acc[t][reg] + dh_at(a.up, orow, col) * zz;
+                    if (a.add_msg)
+                        v += a.add_msg[(size_t)a.add_src[lpos] * a.ld_add + col] -
+                             a.add_msg[(size_t)a.add_dst[lpos] * a.ld_add + col];
+                    a.d_h[(size_t)orow * a.ld_dh + col] = v;
                 }
             }
         }
@@ -243,7 +305,7 @@ struct GruBwdWArgs {
     const float* msg; int ld_msg; int IN; int msg_compact;
     const float* h; int ld_h; int H;
     const float* gates; size_t gate_plane;
-    const float* d_hout; int ld_dhout;
+    DhSrc up;
     float* slab_w;      // [n_rs][3H][IN+H]
     float* slab_b;      // [n_rs][2][3H]
     int n_rs, RS, NQ, NCH;
@@ -285,7 +347,7 @@ __global__ __launch_bounds__(256) void k_gru_bwd_weights(GruBwdWArgs a) {
         const bool valid = lpos_raw < hi;
         const int lpos = valid ? lpos_raw : hi - 1;
         const int orow = a.rows[lpos];
-        const float dh = a.d_hout[(size_t)orow * a.ld_dhout + f];
+        const float dh = dh_at(a.up, orow, f);
         const float* gq = a.gates + (size_t)orow * H + f;
         const float r = gq[0], z = gq[gp], n = gq[2 * gp], hn = gq[3 * gp];
         const float hp = a.h[(size_t)orow * a.ld_h + f];
@@ -342,11 +404,33 @@ __global__ __launch_bounds__(256) void k_gru_bwd_weights(GruBwdWArgs a) {
 // floats), nothing but state rows and gates crosses L2/HBM, and the grid is persistent
 // (<= 1 block per CU) so the weight load is amortised over the whole launch.
 // ==========================================================================================
+// raw A-operand slice of one 32-wide k tile (16 floats per lane; the diff message needs two rows)
+struct ATile { float u[16]; float w[16]; };
+
+template <int H, int IN, int XMODE>
+__device__ __forceinline__ void a_issue(const GruFwdArgs& a, int kt, int li, int row, int half, ATile& t) {
+    constexpr int NKX = IN / 32;
+    if (kt < NKX) {
+        const int f0 = kt * 32 + half * 16;
+        if (XMODE == 0) load16(a.msg + (size_t)(a.msg_compact ? li : row) * a.ld_msg + f0, t.u);
+        else if (XMODE == 1) {
+            load16(a.h + (size_t)a.src[li] * a.ld_h + f0, t.u);
+            load16(a.h + (size_t)a.dst[li] * a.ld_h + f0, t.w);
+        } else {
+            if (f0 < H) load16(a.h + (size_t)a.src[li] * a.ld_h + f0, t.u);
+            else        load16(a.h + (size_t)a.dst[li] * a.ld_h + (f0 - H), t.u);
+        }
+    } else {
+        load16(a.h + (size_t)row * a.ld_h + (kt - NKX) * 32 + half * 16, t.u);
+    }
+}
+
 template <int H, int IN, int XMODE>
 __global__ __launch_bounds__(512) void k_gru_fwd_lds(GruFwdArgs a, int ntiles) {
     extern __shared__ float lds[];
     constexpr int H3 = 3 * H;
     constexpr int CT = H / 32;
+    constexpr int NKX = IN / 32, NK = NKX + H / 32;
     float* sWih = lds;               // [IN][3H]
     float* sWhh = lds + IN * H3;     // [H][3H]
     for (int i = threadIdx.x * 4; i < IN * H3; i += 512 * 4)
@@ -367,44 +451,42 @@ __global__ __launch_bounds__(512) void k_gru_fwd_lds(GruFwdArgs a, int ntiles) {
         for (int t = 0; t < CT; ++t)
 #pragma unroll
             for (int i = 0; i < 16; ++i) { acc_r[t][i] = 0.f; acc_z[t][i] = 0.f; acc_in[t][i] = 0.f; acc_hn[t][i] = 0.f; }
+        // k tiles are software pipelined: the rows of tile kt+1 are requested before the MFMAs of tile kt
+        ATile cur, nxt;
+        a_issue<H, IN, XMODE>(a, 0, li, row, half, cur);
 #pragma unroll
-        for (int kt = 0; kt < IN / 32; ++kt) {
-            const int f0 = kt * 32 + half * 16;
+        for (int kt = 0; kt < NK; ++kt) {
             float av[16];
-            load_x16<XMODE>(a, li, row, f0, av);
-            const float* b0 = sWih + f0 * H3 + c;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) av[i] = (XMODE == 1 && kt < NKX) ? cur.u[i] - cur.w[i] : cur.u[i];
+            if (kt + 1 < NK) a_issue<H, IN, XMODE>(a, kt + 1, li, row, half, nxt);
+            __builtin_amdgcn_sched_barrier(0);
+            const bool xpart = kt < NKX;
+            const float* b0 = (xpart ? sWih + (kt * 32 + half * 16) * H3 : sWhh + ((kt - NKX) * 32 + half * 16) * H3) + c;
 #pragma unroll
             for (int s = 0; s < 16; ++s) {
 #pragma unroll
                 for (int t = 0; t < CT; ++t) {
                     acc_r[t] = mfma32(av[s], b0[s * H3 + t * 32], acc_r[t]);
                     acc_z[t] = mfma32(av[s], b0[s * H3 + H + t * 32], acc_z[t]);
-                    acc_in[t] = mfma32(av[s], b0[s * H3 + 2 * H + t * 32], acc_in[t]);
+                    if (xpart) acc_in[t] = mfma32(av[s], b0[s * H3 + 2 * H + t * 32], acc_in[t]);
+                    else       acc_hn[t] = mfma32(av[s], b0[s * H3 + 2 * H + t * 32], acc_hn[t]);
                 }
             }
+            cur = nxt;
         }
-#pragma unroll
-        for (int kt = 0; kt < H / 32; ++kt) {
-            const int f0 = kt * 32 + half * 16;
-            float av[16];
-            load16(a.h + (size_t)row * a.ld_h + f0, av);
-            const float* b0 = sWhh + f0 * H3 + c;
-#pragma unroll
-            for (int s = 0; s < 16; ++s) {
-#pragma unroll
-                for (int t = 0; t < CT; ++t) {
-                    acc_r[t] = mfma32(av[s], b0[s * H3 + t * 32], acc_r[t]);
-                    acc_z[t] = mfma32(av[s], b0[s * H3 + H + t * 32], acc_z[t]);
-                    acc_hn[t] = mfma32(av[s], b0[s * H3 + 2 * H + t * 32], acc_hn[t]);
-                }
-            }
-        }
+        // epilogue: every load is issued before the first store (a store in between would make the
+        // next load wait for the store's completion)
+        const bool full = r0 + 32 <= a.R;
         int orow[16];
 #pragma unroll
-        for (int reg = 0; reg < 16; ++reg) {
-            const int lpos = r0 + acc_row(reg, half);
-            orow[reg] = lpos < a.R ? a.rows[lpos] : -1;
-        }
+        for (int reg = 0; reg < 16; ++reg) orow[reg] = a.rows[min(r0 + acc_row(reg, half), a.R - 1)];
+        float hp[CT][16];
+#pragma unroll
+        for (int t = 0; t < CT; ++t)
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) hp[t][reg] = a.h[(size_t)orow[reg] * a.ld_h + t * 32 + c];
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int t = 0; t < CT; ++t) {
             const int col = t * 32 + c;
@@ -414,13 +496,12 @@ __global__ __launch_bounds__(512) void k_gru_fwd_lds(GruFwdArgs a, int ntiles) {
             const float bhn = a.b_hh[2 * H + col];
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) {
-                if (orow[reg] >= 0) {
-                    const float r = sigmoidf_(acc_r[t][reg] + br);
-                    const float z = sigmoidf_(acc_z[t][reg] + bz);
-                    const float hn = acc_hn[t][reg] + bhn;
-                    const float n = tanhf(acc_in[t][reg] + bin + r * hn);
-                    const float hp = a.h[(size_t)orow[reg] * a.ld_h + col];
-                    a.h_out[(size_t)orow[reg] * a.ld_out + col] = (1.0f - z) * n + z * hp;
+                const float r = sigmoidf_(acc_r[t][reg] + br);
+                const float z = sigmoidf_(acc_z[t][reg] + bz);
+                const float hn = acc_hn[t][reg] + bhn;
+                const float n = tanhf_(acc_in[t][reg] + bin + r * hn);
+                if (full || r0 + acc_row(reg, half) < a.R) {
+                    a.h_out[(size_t)orow[reg] * a.ld_out + col] = (1.0f - z) * n + z * hp[t][reg];
                     if (a.gates) {
                         float* gp = a.gates + (size_t)orow[reg] * H + col;
                         gp[0] = r;
@@ -434,11 +515,26 @@ __global__ __launch_bounds__(512) void k_gru_fwd_lds(GruFwdArgs a, int ntiles) {
     }
 }
 
+struct GRaw { float dh[16], r[16], z[16], n[16], hn[16], hp[16]; };
+
+template <int UP>
+__device__ __forceinline__ void g_issue(const GruBwdDataArgs& a, int H, int fb, int row, int half, GRaw& g) {
+    const int f0 = fb * 32 + half * 16;
+    const size_t gp = a.gate_plane;
+    dh_load16_t<UP>(a.up, row, f0, g.dh);
+    const float* g0 = a.gates + (size_t)row * H + f0;
+    load16(g0, g.r);
+    load16(g0 + gp, g.z);
+    load16(g0 + 2 * gp, g.n);
+    load16(g0 + 3 * gp, g.hn);
+    load16(a.h + (size_t)row * a.ld_h + f0, g.hp);
+}
+
 // d_msg = d_gi @ W_ih and d_h = d_hout*z + d_gh @ W_hh in ONE pass over the gates
-template <int H, int IN>
+template <int H, int IN, int UP, bool FUSE>
 __global__ __launch_bounds__(512) void k_gru_bwd_data_lds(GruBwdDataArgs a, int ntiles) {
     extern __shared__ float lds[];
-    constexpr int NTX = IN / 32, NTH = H / 32;
+    constexpr int NTX = IN / 32, NTH = H / 32, NF = H / 32;
     float* sWih = lds;                 // [3H][IN]
     float* sWhh = lds + 3 * H * IN;    // [3H][H]
     for (int i = threadIdx.x * 4; i < 3 * H * IN; i += 512 * 4)
@@ -464,28 +560,28 @@ __global__ __launch_bounds__(512) void k_gru_bwd_data_lds(GruBwdDataArgs a, int 
         for (int t = 0; t < NTH; ++t)
 #pragma unroll
             for (int i = 0; i < 16; ++i) acch[t][i] = 0.f;
+        GRaw cur, nxt;
+        g_issue<UP>(a, H, 0, row, half, cur);
 #pragma unroll
-        for (int fb = 0; fb < H / 32; ++fb) {
+        for (int fb = 0; fb < NF; ++fb) {
             const int f0 = fb * 32 + half * 16;
-            float dh[16], r[16], z[16], n[16], hn[16], hp[16];
-            load16(a.d_hout + (size_t)row * a.ld_dhout + f0, dh);
-            const float* g0 = a.gates + (size_t)row * H + f0;
-            load16(g0, r);
-            load16(g0 + gp, z);
-            load16(g0 + 2 * gp, n);
-            load16(g0 + 3 * gp, hn);
-            load16(a.h + (size_t)row * a.ld_h + f0, hp);
             float ar[16], az[16], an[16], anr[16];
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
-                const float dn = dh[i] * (1.0f - z[i]) * (1.0f - n[i] * n[i]);
-                ar[i] = dn * hn[i] * r[i] * (1.0f - r[i]);
-                az[i] = dh[i] * (hp[i] - n[i]) * z[i] * (1.0f - z[i]);
+                const float dn = cur.dh[i] * (1.0f - cur.z[i]) * (1.0f - cur.n[i] * cur.n[i]);
+                ar[i] = dn * cur.hn[i] * cur.r[i] * (1.0f - cur.r[i]);
+                az[i] = cur.dh[i] * (cur.hp[i] - cur.n[i]) * cur.z[i] * (1.0f - cur.z[i]);
                 an[i] = dn;
-                anr[i] = dn * r[i];
+                anr[i] = dn * cur.r[i];
             }
+            // the next feature block's rows are requested half way through this block's MFMAs: early
+            // enough to hide their latency, late enough that half of this block's operands are dead
 #pragma unroll
             for (int s = 0; s < 16; ++s) {
+                if (s == 8) {
+                    if (fb + 1 < NF) g_issue<UP>(a, H, fb + 1, row, half, nxt);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
                 const float* wx = sWih + (f0 + s) * IN + c;
                 const float* wh = sWhh + (f0 + s) * H + c;
 #pragma unroll
@@ -501,19 +597,47 @@ __global__ __launch_bounds__(512) void k_gru_bwd_data_lds(GruBwdDataArgs a, int 
                     acch[t] = mfma32(anr[s], wh[2 * H * H + t * 32], acch[t]);
                 }
             }
+            cur = nxt;
         }
+        const bool full = r0 + 32 <= a.R;
+        int orow[16];
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) orow[reg] = a.rows[min(r0 + acc_row(reg, half), a.R - 1)];
+        // d_msg first (pure stores), then d_h one column tile at a time: all loads of a tile are issued
+        // before its stores
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg) {
-            const int lpos = r0 + acc_row(reg, half);
-            if (lpos < a.R) {
-                const int orow = a.rows[lpos];
+            if (full || r0 + acc_row(reg, half) < a.R) {
 #pragma unroll
-                for (int t = 0; t < NTX; ++t) a.d_msg[(size_t)orow * a.ld_dmsg + t * 32 + c] = accx[t][reg];
+                for (int t = 0; t < NTX; ++t) a.d_msg[(size_t)orow[reg] * a.ld_dmsg + t * 32 + c] = accx[t][reg];
+            }
+        }
+        // d_h: RCH accumulator rows x one column tile per phase (loads, then stores) -- small phases keep
+        // the register footprint of the fused variants inside the 256-VGPR budget of 2 waves per SIMD
+        constexpr int RCH = (FUSE && UP == 3) ? 4 : 8;
 #pragma unroll
-                for (int t = 0; t < NTH; ++t) {
-                    const int col = t * 32 + c;
-                    const float zz = a.gates[gp + (size_t)orow * H + col];
-                    a.d_h[(size_t)orow * a.ld_dh + col] = acch[t][reg] + a.d_hout[(size_t)orow * a.ld_dhout + col] * zz;
+        for (int rb = 0; rb < 16; rb += RCH) {
+#pragma unroll
+            for (int t = 0; t < NTH; ++t) {
+                const int col = t * 32 + c;
+                float ex[RCH];
+#pragma unroll
+                for (int q = 0; q < RCH; ++q) {
+                    const int reg = rb + q;
+                    const float zz = a.gates[gp + (size_t)orow[reg] * H + col];
+                    ex[q] = dh_at_t<UP>(a.up, orow[reg], col) * zz;
+                    if (FUSE) {
+                        const int lp = min(r0 + acc_row(reg, half), a.R - 1);
+                        ex[q] += a.add_msg[(size_t)a.add_src[lp] * a.ld_add + col] -
+                                 a.add_msg[(size_t)a.add_dst[lp] * a.ld_add + col];
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int q = 0; q < RCH; ++q) {
+                    const int reg = rb + q;
+                    if (full || r0 + acc_row(reg, half) < a.R)
+                        a.d_h[(size_t)orow[reg] * a.ld_dh + col] = acch[t][reg] + ex[q];
                 }
             }
         }
@@ -524,7 +648,7 @@ __global__ __launch_bounds__(512) void k_gru_bwd_data_lds(GruBwdDataArgs a, int 
 // once in LDS and consumed by all four waves as MFMA operands (A = d_g^T, B = [x|h]); each wave owns
 // 3 x (H/32) output tiles of dW_ih (waves 0,1) or dW_hh (waves 2,3).  Persistent blocks keep their
 // partial dW in registers over all their tiles and write ONE slab each.
-template <int H, int XMODE>
+template <int H, int XMODE, int UP>
 __global__ __launch_bounds__(256, 2) void k_gru_bwd_weights_lds(GruBwdWArgs a, int ntiles) {
     constexpr int NC = H / 32;           // column tiles per matrix
     constexpr int DG = 4 * H;            // dr | dz | dn | dnr
@@ -570,8 +694,20 @@ __global__ __launch_bounds__(256, 2) void k_gru_bwd_weights_lds(GruBwdWArgs a, i
         float dh[8], r[8], z[8], n[8], hn[8], hp[8], x[8];
         {
             const float4* p;
-            p = reinterpret_cast<const float4*>(a.d_hout + (size_t)orow * a.ld_dhout + f8);
-            float4 u = p[0], v = p[1];
+            float4 u, v;
+            if (UP & 1) {
+                p = reinterpret_cast<const float4*>(a.up.d_hout + (size_t)orow * a.up.ld_dhout + f8);
+                u = p[0]; v = p[1];
+            } else {
+                u = make_float4(0.f, 0.f, 0.f, 0.f); v = u;
+            }
+            if (UP & 2) {
+                const float d = a.up.dy[orow];
+                const float4* q = reinterpret_cast<const float4*>(a.up.w_head + f8);
+                const float4 w0 = q[0], w1 = q[1];
+                u.x += d * w0.x; u.y += d * w0.y; u.z += d * w0.z; u.w += d * w0.w;
+                v.x += d * w1.x; v.y += d * w1.y; v.z += d * w1.z; v.w += d * w1.w;
+            }
             dh[0] = u.x; dh[1] = u.y; dh[2] = u.z; dh[3] = u.w; dh[4] = v.x; dh[5] = v.y; dh[6] = v.z; dh[7] = v.w;
             p = reinterpret_cast<const float4*>(a.gates + (size_t)orow * H + f8);
             u = p[0]; v = p[1];
@@ -774,31 +910,44 @@ generic:
 
 int tmpnn_gru_bwd_data(const int32_t* rows, int R, int IN, const float* h, int ld_h, int H, const float* w_ih,
                        const float* w_hh, const float* gates, size_t gate_plane, const float* d_hout, int ld_dhout,
-                       float* d_msg, int ld_dmsg, float* d_h, int ld_dh, tmpnn_stream stream) {
+                       const float* dy, const float* w_head, float* d_msg, int ld_dmsg, float* d_h, int ld_dh,
+                       const int32_t* add_src, const int32_t* add_dst, const float* add_msg, int ld_add,
+                       tmpnn_stream stream) {
     TM_REQUIRE(supported_H(H), "gru_bwd_data: unsupported H=%d", H);
     if (R == 0) return TMPNN_OK;
     TM_REQUIRE(R > 0 && IN > 0 && IN % 32 == 0 && (H % 64 != 0 || IN % 64 == 0), "gru_bwd_data: R=%d IN=%d", R, IN);
-    TM_REQUIRE(rows && h && w_ih && w_hh && gates && d_hout && d_msg && d_h, "gru_bwd_data: null pointer");
-    TM_REQUIRE((ld_h & 3) == 0 && (ld_dhout & 3) == 0 && aligned16(h) && aligned16(d_hout) && aligned16(gates) &&
-                   (gate_plane & 3) == 0,
+    TM_REQUIRE(rows && h && w_ih && w_hh && gates && d_msg && d_h, "gru_bwd_data: null pointer");
+    TM_REQUIRE(d_hout != nullptr || dy != nullptr, "gru_bwd_data: no upstream gradient (d_hout and dy both null)");
+    TM_REQUIRE(dy == nullptr || (w_head != nullptr && aligned16(w_head)), "gru_bwd_data: dy needs a 16-byte aligned w_head");
+    TM_REQUIRE((ld_h & 3) == 0 && aligned16(h) && aligned16(gates) && (gate_plane & 3) == 0 &&
+                   (d_hout == nullptr || ((ld_dhout & 3) == 0 && aligned16(d_hout) && ld_dhout >= H)),
                "gru_bwd_data: rows must be 16-byte aligned");
-    TM_REQUIRE(ld_dmsg >= IN && ld_dh >= H && ld_h >= H && ld_dhout >= H, "gru_bwd_data: leading dimension too small");
-    GruBwdDataArgs a{rows, R, IN, h, ld_h, H, w_ih, w_hh, gates, gate_plane, d_hout, ld_dhout, d_msg, ld_dmsg, d_h,
-                     ld_dh};
+    TM_REQUIRE(ld_dmsg >= IN && ld_dh >= H && ld_h >= H, "gru_bwd_data: leading dimension too small");
+    TM_REQUIRE(add_msg == nullptr || (add_src && add_dst && ld_add >= H), "gru_bwd_data: fused aggregation adjoint args");
+    GruBwdDataArgs a{rows, R, IN, h, ld_h, H, w_ih, w_hh, gates, gate_plane, DhSrc{d_hout, ld_dhout, dy, w_head},
+                     d_msg, ld_dmsg, d_h, ld_dh, add_src, add_dst, add_msg, ld_add};
     hipStream_t st = as_stream(stream);
     if (H <= 64 && (IN == H || IN == 2 * H) && aligned16(w_ih) && aligned16(w_hh)) {
         const int ntiles = ceil_div(R, 256);
         dim3 pgrid(ntiles < 256 ? ntiles : 256), pblock(512);
         const size_t shm = sizeof(float) * (size_t)(IN + H) * 3 * H;
+        const int up = (d_hout ? 1 : 0) | (dy ? 2 : 0);
+        const bool fuse = add_msg != nullptr;
+#define L3(HH, II, UU, FF)                                                                                   \
+    do {                                                                                                     \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gru_bwd_data_lds<HH, II, UU, FF>),        \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);                     \
+        hipLaunchKernelGGL((k_gru_bwd_data_lds<HH, II, UU, FF>), pgrid, pblock, shm, st, a, ntiles);         \
+    } while (0)
 #define LL(HH, II)                                                                                           \
     do {                                                                                                     \
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gru_bwd_data_lds<HH, II>),                \
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);                     \
-        hipLaunchKernelGGL((k_gru_bwd_data_lds<HH, II>), pgrid, pblock, shm, st, a, ntiles);                 \
+        if (fuse) { if (up == 1) L3(HH, II, 1, true); else if (up == 2) L3(HH, II, 2, true); else L3(HH, II, 3, true); }      \
+        else      { if (up == 1) L3(HH, II, 1, false); else if (up == 2) L3(HH, II, 2, false); else L3(HH, II, 3, false); }   \
     } while (0)
         if (H == 64) { if (IN == 64) LL(64, 64); else LL(64, 128); }
         else         { if (IN == 32) LL(32, 32); else LL(32, 64); }
 #undef LL
+#undef L3
         return check_launch("gru_bwd_data_lds");
     }
     const int NT = (H % 64 == 0) ? 2 : 1;
@@ -826,37 +975,45 @@ size_t tmpnn_gru_bwd_weights_ws(int R, int IN, int H) {
 int tmpnn_gru_bwd_weights(const int32_t* rows, int R, int xmode, const int32_t* src, const int32_t* dst,
                           const float* msg, int ld_msg, int msg_compact, int IN, const float* h, int ld_h, int H,
                           const float* gates,
-                          size_t gate_plane, const float* d_hout, int ld_dhout, float* dW_ih, float* dW_hh,
+                          size_t gate_plane, const float* d_hout, int ld_dhout, const float* dy, const float* w_head,
+                          float* dW_ih, float* dW_hh,
                           float* db_ih, float* db_hh, void* ws, size_t ws_bytes, tmpnn_stream stream) {
     TM_REQUIRE(supported_H(H), "gru_bwd_weights: unsupported H=%d", H);
     if (R == 0) return TMPNN_OK;
     TM_REQUIRE(R > 0 && xmode >= 0 && xmode <= 2 && IN % 32 == 0 && IN > 0, "gru_bwd_weights: R=%d xmode=%d IN=%d", R,
                xmode, IN);
     TM_REQUIRE(IN == (xmode == 2 ? 2 * H : (xmode == 1 ? H : IN)), "gru_bwd_weights: IN=%d vs xmode=%d", IN, xmode);
-    TM_REQUIRE(rows && h && gates && d_hout && dW_ih && dW_hh && db_ih && db_hh, "gru_bwd_weights: null pointer");
+    TM_REQUIRE(rows && h && gates && dW_ih && dW_hh && db_ih && db_hh, "gru_bwd_weights: null pointer");
+    TM_REQUIRE(d_hout != nullptr || dy != nullptr, "gru_bwd_weights: no upstream gradient");
+    TM_REQUIRE(dy == nullptr || (w_head != nullptr && aligned16(w_head)), "gru_bwd_weights: dy needs a 16-byte aligned w_head");
     TM_REQUIRE(xmode == 0 ? msg != nullptr : (src != nullptr && dst != nullptr), "gru_bwd_weights: message source");
     const size_t need = tmpnn_gru_bwd_weights_ws(R, IN, H);
     if (ws == nullptr || ws_bytes < need)
         return set_error(TMPNN_EWORKSPACE, "gru_bwd_weights: workspace %zu < %zu bytes", ws_bytes, need);
     int n_rs, RS, NQ, NCH;
     plan_weights(R, IN, H, &n_rs, &RS, &NQ, &NCH);
-    const bool use_lds = weights_use_lds(IN, H) && xmode != 2 && (ld_h & 3) == 0 && (ld_dhout & 3) == 0 &&
-                         aligned16(h) && aligned16(d_hout) && aligned16(gates) && (gate_plane & 3) == 0 &&
+    const bool use_lds = weights_use_lds(IN, H) && xmode != 2 && (ld_h & 3) == 0 &&
+                         (d_hout == nullptr || ((ld_dhout & 3) == 0 && aligned16(d_hout))) &&
+                         aligned16(h) && aligned16(gates) && (gate_plane & 3) == 0 &&
                          (xmode != 0 || ((ld_msg & 3) == 0 && aligned16(msg)));
     if (use_lds) n_rs = weights_lds_blocks(R);
     const size_t nW = (size_t)3 * H * (IN + H), nB = (size_t)6 * H;
     float* slab_w = reinterpret_cast<float*>(ws);
     float* slab_b = slab_w + (size_t)n_rs * nW;
     float* fold = slab_b + (size_t)n_rs * nB;
-    GruBwdWArgs a{rows, R, src, dst, msg, ld_msg, IN, msg_compact, h, ld_h, H, gates, gate_plane, d_hout, ld_dhout, slab_w, slab_b,
+    GruBwdWArgs a{rows, R, src, dst, msg, ld_msg, IN, msg_compact, h, ld_h, H, gates, gate_plane,
+                  DhSrc{d_hout, ld_dhout, dy, w_head}, slab_w, slab_b,
                   n_rs, RS, NQ, NCH};
     hipStream_t st = as_stream(stream);
     int rc;
     if (use_lds) {
         const int ntiles = ceil_div(R, 32);
         dim3 grid(n_rs), block(256);
-        if (xmode == 0) hipLaunchKernelGGL((k_gru_bwd_weights_lds<64, 0>), grid, block, 0, st, a, ntiles);
-        else hipLaunchKernelGGL((k_gru_bwd_weights_lds<64, 1>), grid, block, 0, st, a, ntiles);
+        const int up = (d_hout ? 1 : 0) | (dy ? 2 : 0);
+#define LW(X, U) hipLaunchKernelGGL((k_gru_bwd_weights_lds<64, X, U>), grid, block, 0, st, a, ntiles)
+        if (xmode == 0) { if (up == 1) LW(0, 1); else if (up == 2) LW(0, 2); else LW(0, 3); }
+        else            { if (up == 1) LW(1, 1); else if (up == 2) LW(1, 2); else LW(1, 3); }
+#undef LW
         rc = check_launch("gru_bwd_weights_lds");
     } else {
         const long nworkers = (long)n_rs * NQ * NCH;

@@ -79,8 +79,13 @@ def _transpose(w: torch.Tensor) -> torch.Tensor:
 
 def mp_forward(spec: ModelSpec, plan: CallPlan, x: torch.Tensor, h_in: Optional[torch.Tensor],
                P: Dict[str, torch.Tensor], buffers: Dict[str, torch.Tensor], training: bool, save: bool,
-               keep: Optional[Sequence[torch.Tensor]] = None):
-    """Returns (scores [N,1], logits [N,1], h_out [N,G*H], alphas, saved)."""
+               keep: Optional[Sequence[torch.Tensor]] = None, reserve_rows: int = 0, h_spare: int = 0):
+    """Returns (scores [N,1], logits [N,1], h_out [N,G*H], alphas, saved).
+
+    reserve_rows > 0 allocates h_out with that many spare rows behind it; the NEXT call, when handed
+    that h_out as h_in with n <= spare new rows, appends its new rows in place instead of copying
+    the carried state (the caller promises to continue from a given h_out at most once).
+    """
     g = plan.graph
     H, G, K = spec.H, spec.G, spec.K
     GH = G * H
@@ -99,9 +104,18 @@ def mp_forward(spec: ModelSpec, plan: CallPlan, x: torch.Tensor, h_in: Optional[
         raise ValueError(f'x must be [{n}, {spec.F_total}], got {tuple(x.shape)}')
 
     opts = dict(dtype=torch.float32, device=dev)
-    h_cat = torch.empty((N, GH), **opts)
-    if N_old > 0:
-        h_cat[:N_old].copy_(h_in)
+    h_cat = None
+    if h_in is not None and N_old > 0 and n > 0 and h_in.is_contiguous():
+        st_ = h_in.untyped_storage()
+        if h_spare >= n and st_.nbytes() >= 4 * (h_in.storage_offset() + N * GH):
+            h_cat = torch.empty(0, **opts).set_(st_, h_in.storage_offset(), (N, GH), (GH, 1))   # append in place
+    if h_cat is None:
+        if h_in is not None and n == 0:
+            h_cat = h_in                               # pure extra iteration: nothing to append
+        else:
+            h_cat = torch.empty((N, GH), **opts)
+            if N_old > 0:
+                h_cat[:N_old].copy_(h_in)
     saved = dict(n=n)
     if n > 0:
         h_cat[N_old:].zero_()                       # new edge rows start at 0 (track_mpnn.py:61)
@@ -138,7 +152,12 @@ def mp_forward(spec: ModelSpec, plan: CallPlan, x: torch.Tensor, h_in: Optional[
         if save:
             saved.update(xdet=xdet, y_save=y_saves, mean=means, rstd=rstds)
 
-    h_out = torch.empty((N, GH), **opts)
+    spare = max(int(reserve_rows), 0)
+    if spare > 0:      # plain (non-view) tensor over a larger storage: the next call may extend it in place
+        buf = torch.empty(((N + spare) * GH,), **opts)
+        h_out = torch.empty(0, **opts).set_(buf.untyped_storage(), 0, (N, GH), (GH, 1))
+    else:
+        h_out = torch.empty((N, GH), **opts)
     gates = torch.empty((G, 4, N, H), **opts) if save else None
     es_all = torch.empty((G, max(Dn, 1), H), **opts)
     alphas: List[Optional[List[torch.Tensor]]] = []
@@ -215,66 +234,68 @@ def mp_backward(spec: ModelSpec, plan: CallPlan, saved: dict, P: Dict[str, torch
     opts = dict(dtype=torch.float32, device=dev)
     grads = {name: torch.zeros_like(P[name], dtype=torch.float32) for name in spec.param_names()}
 
-    # heads (track_mpnn.py:72-75): d_hout_total = d_hout + dy * w_type
-    if d_hout is not None:
-        dh_tot = _f32c(d_hout).clone()
-        acc = 1
-    else:
-        dh_tot = torch.empty((N, GH), **opts)
-        acc = 0
-    if d_scores is None and d_logits is None:
-        if acc == 0:
-            dh_tot.zero_()
-    else:
-        ws_b = _lib.load().tmpnn_heads_bwd_ws(N, GH)
+    # heads (track_mpnn.py:72-75): dy = d_logits + d_scores * s(1-s); its contribution dy * w_type to the
+    # gradient of h_out is folded into the GRU backward kernels (never materialised)
+    lib = _lib.load()
+    dh_up = _f32c(d_hout) if d_hout is not None else None
+    dy = None
+    if d_scores is not None or d_logits is not None:
+        dy = torch.empty((N,), **opts)
+        ws_b = lib.tmpnn_heads_bwd_ws(N, GH)
         ws = torch.empty((max(ws_b // 4, 1),), **opts)
         dl = _f32c(d_logits) if d_logits is not None else None
         ds = _f32c(d_scores) if d_scores is not None else None
         _lib.call('tmpnn_heads_bwd', h_out.data_ptr(), GH, GH, N, g.is_edge.data_ptr(),
                   P['output_transform_node.weight'].data_ptr(), P['output_transform_edge.weight'].data_ptr(),
-                  saved['scores'].data_ptr(), _lib.ptr(dl), _lib.ptr(ds), dh_tot.data_ptr(), GH, acc,
+                  saved['scores'].data_ptr(), _lib.ptr(dl), _lib.ptr(ds), dy.data_ptr(), None, 0, 0,
                   grads['output_transform_node.weight'].data_ptr(), grads['output_transform_node.bias'].data_ptr(),
                   grads['output_transform_edge.weight'].data_ptr(), grads['output_transform_edge.bias'].data_ptr(),
                   ws.data_ptr(), ws_b, st)
+    elif dh_up is None:
+        dh_up = torch.zeros((N, GH), **opts)
 
     d_hcat = torch.empty((N, GH), **opts)
     IN_e = spec.IN_e
     dmsg = torch.empty((N, IN_e), **opts)
     xmode = 2 if spec.msg_type == 'concat' else 1
     plane = N * H
-    lib = _lib.load()
     ws_e = lib.tmpnn_gru_bwd_weights_ws(E, IN_e, H)
     ws_n = lib.tmpnn_gru_bwd_weights_ws(Dn, H, H)
     ws_w = torch.empty((max(ws_e, ws_n) // 4 + 1,), **opts)
+    w_node, w_edge = P['output_transform_node.weight'], P['output_transform_edge.weight']
     for gi in range(G):
         f = f'factor_grus.{gi}.'
         hg = h_cat.data_ptr() + 4 * gi * H
-        dog = dh_tot.data_ptr() + 4 * gi * H
+        dog = (dh_up.data_ptr() + 4 * gi * H) if dh_up is not None else None
         dhg = d_hcat.data_ptr() + 4 * gi * H
         gp = gates[gi].data_ptr()
         es = es_all[gi]
+        dyp = _lib.ptr(dy)
+        wn = (w_node.data_ptr() + 4 * gi * H) if dy is not None else None
+        we = (w_edge.data_ptr() + 4 * gi * H) if dy is not None else None
         # node GRU backward: d_es -> dmsg[det rows, 0:H], d_hcat[det rows]
         _lib.call('tmpnn_gru_bwd_data', g.det_row.data_ptr(), Dn, H, hg, GH, H,
                   P[f + 'node_gru.weight_ih'].data_ptr(), P[f + 'node_gru.weight_hh'].data_ptr(),
-                  gp, plane, dog, GH, dmsg.data_ptr(), IN_e, dhg, GH, st)
+                  gp, plane, dog, GH, dyp, wn, dmsg.data_ptr(), IN_e, dhg, GH, None, None, None, 0, st)
         _lib.call('tmpnn_gru_bwd_weights', g.det_row.data_ptr(), Dn, 0, None, None, es.data_ptr(), H, 1, H,
-                  hg, GH, H, gp, plane, dog, GH,
+                  hg, GH, H, gp, plane, dog, GH, dyp, wn,
                   grads[f + 'node_gru.weight_ih'].data_ptr(), grads[f + 'node_gru.weight_hh'].data_ptr(),
                   grads[f + 'node_gru.bias_ih'].data_ptr(), grads[f + 'node_gru.bias_hh'].data_ptr(),
                   ws_w.data_ptr(), ws_w.numel() * 4, st)
-        # edge GRU backward: d_ns -> dmsg[edge rows, 0:IN_e], d_hcat[edge rows]
+        # edge GRU backward: d_ns -> dmsg[edge rows, 0:IN_e], d_hcat[edge rows]; without attention the
+        # adjoint of the edge -> node sum (d_es[src] - d_es[dst], read from dmsg's det rows) rides along
+        fuse = K == 0
         _lib.call('tmpnn_gru_bwd_data', g.edge_row.data_ptr(), E, IN_e, hg, GH, H,
                   P[f + 'edge_gru.weight_ih'].data_ptr(), P[f + 'edge_gru.weight_hh'].data_ptr(),
-                  gp, plane, dog, GH, dmsg.data_ptr(), IN_e, dhg, GH, st)
+                  gp, plane, dog, GH, dyp, we, dmsg.data_ptr(), IN_e, dhg, GH,
+                  g.src.data_ptr() if fuse else None, g.dst.data_ptr() if fuse else None,
+                  dmsg.data_ptr() if fuse else None, IN_e, st)
         _lib.call('tmpnn_gru_bwd_weights', g.edge_row.data_ptr(), E, xmode, g.src.data_ptr(), g.dst.data_ptr(),
-                  None, 0, 0, IN_e, hg, GH, H, gp, plane, dog, GH,
+                  None, 0, 0, IN_e, hg, GH, H, gp, plane, dog, GH, dyp, we,
                   grads[f + 'edge_gru.weight_ih'].data_ptr(), grads[f + 'edge_gru.weight_hh'].data_ptr(),
                   grads[f + 'edge_gru.bias_ih'].data_ptr(), grads[f + 'edge_gru.bias_hh'].data_ptr(),
                   ws_w.data_ptr(), ws_w.numel() * 4, st)
-        # adjoint of the edge -> node aggregation: into d_hcat[edge rows] (and dets via attention)
-        if K == 0:
-            _lib.call('tmpnn_segsum_bwd', g.cref(), dmsg.data_ptr(), IN_e, dhg, GH, H, 1, st)
-        else:
+        if K > 0:
             W, a, kp, ws_ha, score, alpha = saved['att'][gi]
             dW = torch.zeros_like(W)
             da = torch.zeros_like(a)
@@ -346,7 +367,7 @@ class MPIteration(torch.autograd.Function):
         need_grad = call['need_grad']
         scores, logits, h_out, alphas, saved = mp_forward(
             spec, call['plan'], x.detach(), None if h_in is None else _f32c(h_in.detach()), P, call['buffers'],
-            call['training'], need_grad, call.get('keep'))
+            call['training'], need_grad, call.get('keep'), call.get('reserve', 0), call.get('h_spare', 0))
         call['alphas'] = alphas
         ctx.call = call
         ctx.saved = saved

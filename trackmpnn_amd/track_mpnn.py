@@ -100,11 +100,14 @@ class TrackMPNN(nn.Module):
         return params, buffers
 
     def forward_graph(self, x: torch.Tensor, h_in: Optional[torch.Tensor], plan: CallPlan,
-                      dropout_keep: Optional[Sequence[torch.Tensor]] = None):
+                      dropout_keep: Optional[Sequence[torch.Tensor]] = None, reserve_rows: int = 0):
         """One message-passing call on a prebuilt CallPlan (see trackmpnn_amd.graph).
 
         dropout_keep: optional per-group uint8 [K, 2E] keep masks (CSR order) replacing the
         internally drawn attention dropout (train mode, nattheads > 0).
+        reserve_rows: rows the NEXT call will append; h_out is then allocated with that much spare room
+        and the next call extends it in place instead of copying the carried state (only valid when
+        each h_out is continued from at most once, as in the reference's train / infer loops).
         """
         if not x.is_cuda:
             raise RuntimeError(f'x is on {x.device}: trackmpnn_amd runs on the MI355X HIP kernels only '
@@ -113,8 +116,10 @@ class TrackMPNN(nn.Module):
         need_grad = torch.is_grad_enabled() and (
             x.requires_grad or (h_in is not None and h_in.requires_grad) or any(p.requires_grad for p in params))
         call = dict(spec=self.spec, plan=plan, buffers=buffers, training=self.training, need_grad=need_grad,
-                    keep=dropout_keep)
+                    keep=dropout_keep, reserve=reserve_rows,
+                    h_spare=getattr(h_in, '_tmpnn_spare_rows', 0) if h_in is not None else 0)
         scores, logits, h_out = MPIteration.apply(call, x, h_in, *params)
+        h_out._tmpnn_spare_rows = max(int(reserve_rows), 0)
         attention = tuple(None if a is None else [SparseAttention(plan.graph, ak) for ak in a]
                           for a in call['alphas'])
         return scores, logits, h_out, attention
