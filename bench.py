@@ -147,6 +147,28 @@ def stage_profile(model, plan, H):
     return t, flops, {'gather_diff': b_gather, 'segsum': b_segsum}
 
 
+_PMC_KERNEL = {'gru_fwd_edge': 'k_gru_fwd_lds<64, 64, 1>', 'gru_bwd_data_edge': 'k_gru_bwd_data_lds<64, 64, 1, false>',
+               'gru_bwd_data_edge_folded': 'k_gru_bwd_data_lds<64, 64, 3, true>',
+               'gru_bwd_weights_edge': 'k_gru_bwd_weights_lds<64, 1, 1>'}
+
+
+def pmc_traffic(stage, E):
+    """HBM bytes per launch of the stage's kernel from the committed rocprofv3 PMC passes (FETCH_SIZE and
+    WRITE_SIZE, separate runs of tools/stage_bench.py; raw counters, see the note in the file).  None unless the
+    profile was taken on a graph of exactly this size."""
+    path = os.path.join(ROOT, 'profiles', 'r01_pmc_traffic_stage_kernels.json')
+    try:
+        prof = json.load(open(path))
+    except OSError:
+        return None
+    if prof.get('graph', {}).get('E') != E:
+        return None
+    for name, v in prof['kernels'].items():
+        if _PMC_KERNEL.get(stage, '?') in name and v.get('WRITE_SIZE_KB') is not None:
+            return (v['FETCH_SIZE_KB'] + v['WRITE_SIZE_KB']) * 1024.0
+    return None
+
+
 def cpu_baseline(frames, mean_dets, max_dets, F, H, seed, budget_s=15.0):
     """The oracle (CPU restatement, kind 'port') on the host cores, one window at a time as the reference
     runs them (batch size 1, utils/graph.py:117), same call pattern, bounded sample."""
@@ -286,7 +308,7 @@ def main():
         dom = max(flops, key=lambda k: t[k])
         ach = flops[dom] / (t[dom] * 1e-3) / 1e12
         roofline = dict(bound='mfma', kernel=dom, achieved=ach, peak=MFMA_F32_PEAK_TF, unit='TFLOP/s',
-                        frac=ach / MFMA_F32_PEAK_TF, traffic=None, ms=t[dom])
+                        frac=ach / MFMA_F32_PEAK_TF, traffic=pmc_traffic(dom, plans[-1].graph.E), ms=t[dom])
         agg_b = nbytes['gather_diff'] + nbytes['segsum']
         agg_t = (t['gather_diff'] + t['segsum']) * 1e-3
         extra['roofline_aggregation'] = dict(

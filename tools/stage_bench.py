@@ -6,7 +6,7 @@ import bench
 from trackmpnn_amd import TrackMPNN
 
 ap = argparse.ArgumentParser()
-ap.add_argument('--windows', type=int, default=4096)
+ap.add_argument("--windows", type=int, default=16384)
 args = ap.parse_args()
 dev = torch.device('cuda:0')
 torch.manual_seed(5)
