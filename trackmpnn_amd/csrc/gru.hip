@@ -404,6 +404,27 @@ __global__ __launch_bounds__(256) void k_gru_bwd_weights(GruBwdWArgs a) {
 // floats), nothing but state rows and gates crosses L2/HBM, and the grid is persistent
 // (<= 1 block per CU) so the weight load is amortised over the whole launch.
 // ==========================================================================================
+// Transposing store of one 32 x 32 fp32 tile held one ROW per lane pair (lane (c, half) owns columns
+// 8q + 4*half .. +3, q = 0..3, of row c) through a private LDS tile: written as ds_write_b128, read back
+// so that lane l of pass k holds 16 bytes of row (64k + l)/8 -- eight lanes cover one 128-byte row segment.
+// The staging row stride of 36 floats keeps both the writes and the reads bank-conflict free.
+constexpr int STG_LD = 36;
+__device__ __forceinline__ void stage_store32(float* stg, int c, int half, int lane, const float4* v,
+                                              float* dst, int ld, int col0, int row, int r0, int R) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) *reinterpret_cast<float4*>(stg + c * STG_LD + 8 * q + 4 * half) = v[q];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // same-wave LDS ops are ordered; keep the compiler honest
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int idx = k * 64 + lane;
+        const int rr = idx >> 3, ch = idx & 7;
+        const float4 x = *reinterpret_cast<const float4*>(stg + rr * STG_LD + ch * 4);
+        const int orow = __shfl(row, rr, 64);               // lane rr (< 32) owns row r0 + rr
+        if (r0 + rr < R) *reinterpret_cast<float4*>(dst + (size_t)orow * ld + col0 + ch * 4) = x;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+}
+
 // raw A-operand slice of one 32-wide k tile (16 floats per lane; the diff message needs two rows)
 struct ATile { float u[16]; float w[16]; };
 
@@ -425,24 +446,51 @@ __device__ __forceinline__ void a_issue(const GruFwdArgs& a, int kt, int li, int
     }
 }
 
-template <int H, int IN, int XMODE>
-__global__ __launch_bounds__(512) void k_gru_fwd_lds(GruFwdArgs a, int ntiles) {
+// CT = 32-column tiles per wave; (H/32)/CT waves share a 32-row tile (each owning CT column tiles),
+// WPB waves per block.  CT = 1 halves the accumulator file of a wave (64 registers), which buys a third
+// wave per SIMD and room for the operand prefetch without spilling.
+template <int H, int IN, int XMODE, int CT, int WPB>
+__global__ __launch_bounds__(WPB * 64) void k_gru_fwd_lds(GruFwdArgs a, int ntiles) {
     extern __shared__ float lds[];
     constexpr int H3 = 3 * H;
-    constexpr int CT = H / 32;
+    constexpr int CW = (H / 32) / CT;          // column waves per row tile
+    constexpr int RTB = WPB / CW;              // row tiles per block iteration
     constexpr int NKX = IN / 32, NK = NKX + H / 32;
     float* sWih = lds;               // [IN][3H]
     float* sWhh = lds + IN * H3;     // [H][3H]
-    for (int i = threadIdx.x * 4; i < IN * H3; i += 512 * 4)
+    for (int i = threadIdx.x * 4; i < IN * H3; i += WPB * 64 * 4)
         *reinterpret_cast<float4*>(sWih + i) = *reinterpret_cast<const float4*>(a.wih_t + i);
-    for (int i = threadIdx.x * 4; i < H * H3; i += 512 * 4)
+    for (int i = threadIdx.x * 4; i < H * H3; i += WPB * 64 * 4)
         *reinterpret_cast<float4*>(sWhh + i) = *reinterpret_cast<const float4*>(a.whh_t + i);
+    // work distribution: the block owns a contiguous range of (32-row tile, column wave) items and its
+    // waves pull them from an LDS counter.  Waves on one SIMD get DIFFERENT static priorities
+    // (waves w, w+4, w+8 share a SIMD): identical waves otherwise run in lockstep -- all in their
+    // MFMA phase together, then all in their store phase together -- and the matrix pipe idles while
+    // the epilogues drain.  With a strict order the top wave runs at full rate and the others fill
+    // every gap its loads and stores leave.
+    int* next_item = reinterpret_cast<int*>(lds + (IN + H) * H3 + WPB * (32 * STG_LD));
+    if (threadIdx.x == 0) *next_item = 0;
     __syncthreads();
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int c = lane & 31, half = lane >> 5;
+    {
+        const int grp = __builtin_amdgcn_readfirstlane(wave) >> 2;
+        if (grp == 0) __builtin_amdgcn_s_setprio(3);
+        else if (grp == 1) __builtin_amdgcn_s_setprio(2);
+        else if (grp == 2) __builtin_amdgcn_s_setprio(1);
+    }
+    const int items_total = ntiles * RTB * CW;                 // ntiles = passes of RTB row tiles
+    const int per_block = (items_total + gridDim.x - 1) / gridDim.x;
+    const int item_lo = blockIdx.x * per_block;
+    const int item_hi = min(items_total, item_lo + per_block);
 
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const int r0 = (tile * 8 + wave) * 32;
+    for (;;) {
+        int item = 0;
+        if (lane == 0) item = atomicAdd(next_item, 1);
+        item = __builtin_amdgcn_readfirstlane(item) + item_lo;
+        if (item >= item_hi) break;
+        const int cw0 = (item % CW) * CT * 32;                 // first output column of this item
+        const int r0 = (item / CW) * 32;
         if (r0 >= a.R) continue;
         const int li = min(r0 + c, a.R - 1);
         const int row = a.rows[li];
@@ -462,54 +510,88 @@ __global__ __launch_bounds__(512) void k_gru_fwd_lds(GruFwdArgs a, int ntiles) {
             if (kt + 1 < NK) a_issue<H, IN, XMODE>(a, kt + 1, li, row, half, nxt);
             __builtin_amdgcn_sched_barrier(0);
             const bool xpart = kt < NKX;
-            const float* b0 = (xpart ? sWih + (kt * 32 + half * 16) * H3 : sWhh + ((kt - NKX) * 32 + half * 16) * H3) + c;
+            const float* b0 = (xpart ? sWih + (kt * 32 + half * 16) * H3 : sWhh + ((kt - NKX) * 32 + half * 16) * H3) + cw0 + c;
+            // B operands are read from LDS one k step AHEAD of the MFMAs that consume them, so a step's
+            // six matrix instructions never wait on their own ds_read
+            float bq[2][3 * CT];
+#pragma unroll
+            for (int t = 0; t < CT; ++t) { bq[0][3 * t] = b0[t * 32]; bq[0][3 * t + 1] = b0[H + t * 32]; bq[0][3 * t + 2] = b0[2 * H + t * 32]; }
 #pragma unroll
             for (int s = 0; s < 16; ++s) {
+                if (s + 1 < 16) {
+#pragma unroll
+                    for (int t = 0; t < CT; ++t) {
+                        bq[(s + 1) & 1][3 * t] = b0[(s + 1) * H3 + t * 32];
+                        bq[(s + 1) & 1][3 * t + 1] = b0[(s + 1) * H3 + H + t * 32];
+                        bq[(s + 1) & 1][3 * t + 2] = b0[(s + 1) * H3 + 2 * H + t * 32];
+                    }
+                }
 #pragma unroll
                 for (int t = 0; t < CT; ++t) {
-                    acc_r[t] = mfma32(av[s], b0[s * H3 + t * 32], acc_r[t]);
-                    acc_z[t] = mfma32(av[s], b0[s * H3 + H + t * 32], acc_z[t]);
-                    if (xpart) acc_in[t] = mfma32(av[s], b0[s * H3 + 2 * H + t * 32], acc_in[t]);
-                    else       acc_hn[t] = mfma32(av[s], b0[s * H3 + 2 * H + t * 32], acc_hn[t]);
+                    // weights as the FIRST operand: the accumulator then holds the transposed tile
+                    // (lane = state row, registers = 4-wide runs of output features), which makes the
+                    // epilogue one row per lane with 16-byte loads and stores
+                    acc_r[t] = mfma32(bq[s & 1][3 * t], av[s], acc_r[t]);
+                    acc_z[t] = mfma32(bq[s & 1][3 * t + 1], av[s], acc_z[t]);
+                    if (xpart) acc_in[t] = mfma32(bq[s & 1][3 * t + 2], av[s], acc_in[t]);
+                    else       acc_hn[t] = mfma32(bq[s & 1][3 * t + 2], av[s], acc_hn[t]);
                 }
+                __builtin_amdgcn_sched_group_barrier(0x100, 3 * CT, 0);
+                __builtin_amdgcn_sched_group_barrier(0x8, 3 * CT, 0);
             }
             cur = nxt;
         }
-        // epilogue: every load is issued before the first store (a store in between would make the
-        // next load wait for the store's completion)
-        const bool full = r0 + 32 <= a.R;
-        int orow[16];
-#pragma unroll
-        for (int reg = 0; reg < 16; ++reg) orow[reg] = a.rows[min(r0 + acc_row(reg, half), a.R - 1)];
-        float hp[CT][16];
+        // epilogue: lane = its own row (li), accumulator register 4q+i <-> feature 8q + 4*half + i of the tile.
+        // Outputs leave through a per-wave LDS staging tile so that every global store instruction writes
+        // full 128-byte row segments with 16 bytes per lane (8 lanes per row): dword stores are issue-bound
+        // and 32-byte runs (what the accumulator layout would give directly) waste the write path.
+        float* stg = lds + (IN + H) * H3 + wave * (32 * STG_LD);   // (the item counter sits behind the tiles)
+        float4 hp4[CT][4];
 #pragma unroll
         for (int t = 0; t < CT; ++t)
 #pragma unroll
-            for (int reg = 0; reg < 16; ++reg) hp[t][reg] = a.h[(size_t)orow[reg] * a.ld_h + t * 32 + c];
-        __builtin_amdgcn_sched_barrier(0);
+            for (int q = 0; q < 4; ++q)
+                hp4[t][q] = *reinterpret_cast<const float4*>(a.h + (size_t)row * a.ld_h + cw0 + t * 32 + 8 * q + 4 * half);
 #pragma unroll
         for (int t = 0; t < CT; ++t) {
-            const int col = t * 32 + c;
-            const float br = a.b_ih[col] + a.b_hh[col];
-            const float bz = a.b_ih[H + col] + a.b_hh[H + col];
-            const float bin = a.b_ih[2 * H + col];
-            const float bhn = a.b_hh[2 * H + col];
+            float4 vo[4], vr[4], vz[4], vn[4], vh[4];
 #pragma unroll
-            for (int reg = 0; reg < 16; ++reg) {
-                const float r = sigmoidf_(acc_r[t][reg] + br);
-                const float z = sigmoidf_(acc_z[t][reg] + bz);
-                const float hn = acc_hn[t][reg] + bhn;
-                const float n = tanhf_(acc_in[t][reg] + bin + r * hn);
-                if (full || r0 + acc_row(reg, half) < a.R) {
-                    a.h_out[(size_t)orow[reg] * a.ld_out + col] = (1.0f - z) * n + z * hp[t][reg];
-                    if (a.gates) {
-                        float* gp = a.gates + (size_t)orow[reg] * H + col;
-                        gp[0] = r;
-                        gp[a.gate_plane] = z;
-                        gp[2 * a.gate_plane] = n;
-                        gp[3 * a.gate_plane] = hn;
-                    }
+            for (int q = 0; q < 4; ++q) {
+                const int col = cw0 + t * 32 + 8 * q + 4 * half;
+                const float4 bir = *reinterpret_cast<const float4*>(a.b_ih + col);
+                const float4 bhr = *reinterpret_cast<const float4*>(a.b_hh + col);
+                const float4 biz = *reinterpret_cast<const float4*>(a.b_ih + H + col);
+                const float4 bhz = *reinterpret_cast<const float4*>(a.b_hh + H + col);
+                const float4 bin = *reinterpret_cast<const float4*>(a.b_ih + 2 * H + col);
+                const float4 bhn = *reinterpret_cast<const float4*>(a.b_hh + 2 * H + col);
+                const float br[4] = {bir.x + bhr.x, bir.y + bhr.y, bir.z + bhr.z, bir.w + bhr.w};
+                const float bz[4] = {biz.x + bhz.x, biz.y + bhz.y, biz.z + bhz.z, biz.w + bhz.w};
+                const float bi[4] = {bin.x, bin.y, bin.z, bin.w};
+                const float bh[4] = {bhn.x, bhn.y, bhn.z, bhn.w};
+                const float hp[4] = {hp4[t][q].x, hp4[t][q].y, hp4[t][q].z, hp4[t][q].w};
+                float ro[4], zo[4], no[4], ho[4], out[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int reg = 4 * q + i;
+                    ro[i] = sigmoidf_(acc_r[t][reg] + br[i]);
+                    zo[i] = sigmoidf_(acc_z[t][reg] + bz[i]);
+                    ho[i] = acc_hn[t][reg] + bh[i];
+                    no[i] = tanhf_(acc_in[t][reg] + bi[i] + ro[i] * ho[i]);
+                    out[i] = (1.0f - zo[i]) * no[i] + zo[i] * hp[i];
                 }
+                vo[q] = make_float4(out[0], out[1], out[2], out[3]);
+                vr[q] = make_float4(ro[0], ro[1], ro[2], ro[3]);
+                vz[q] = make_float4(zo[0], zo[1], zo[2], zo[3]);
+                vn[q] = make_float4(no[0], no[1], no[2], no[3]);
+                vh[q] = make_float4(ho[0], ho[1], ho[2], ho[3]);
+            }
+            const int colt = cw0 + t * 32;
+            stage_store32(stg, c, half, lane, vo, a.h_out, a.ld_out, colt, row, r0, a.R);
+            if (a.gates) {
+                stage_store32(stg, c, half, lane, vr, a.gates, H, colt, row, r0, a.R);
+                stage_store32(stg, c, half, lane, vz, a.gates + a.gate_plane, H, colt, row, r0, a.R);
+                stage_store32(stg, c, half, lane, vn, a.gates + 2 * a.gate_plane, H, colt, row, r0, a.R);
+                stage_store32(stg, c, half, lane, vh, a.gates + 3 * a.gate_plane, H, colt, row, r0, a.R);
             }
         }
     }
@@ -585,60 +667,60 @@ __global__ __launch_bounds__(512) void k_gru_bwd_data_lds(GruBwdDataArgs a, int 
                 const float* wx = sWih + (f0 + s) * IN + c;
                 const float* wh = sWhh + (f0 + s) * H + c;
 #pragma unroll
-                for (int t = 0; t < NTX; ++t) {
-                    accx[t] = mfma32(ar[s], wx[t * 32], accx[t]);
-                    accx[t] = mfma32(az[s], wx[H * IN + t * 32], accx[t]);
-                    accx[t] = mfma32(an[s], wx[2 * H * IN + t * 32], accx[t]);
+                for (int t = 0; t < NTX; ++t) {       // weights first: transposed accumulator (lane = row)
+                    accx[t] = mfma32(wx[t * 32], ar[s], accx[t]);
+                    accx[t] = mfma32(wx[H * IN + t * 32], az[s], accx[t]);
+                    accx[t] = mfma32(wx[2 * H * IN + t * 32], an[s], accx[t]);
                 }
 #pragma unroll
                 for (int t = 0; t < NTH; ++t) {
-                    acch[t] = mfma32(ar[s], wh[t * 32], acch[t]);
-                    acch[t] = mfma32(az[s], wh[H * H + t * 32], acch[t]);
-                    acch[t] = mfma32(anr[s], wh[2 * H * H + t * 32], acch[t]);
+                    acch[t] = mfma32(wh[t * 32], ar[s], acch[t]);
+                    acch[t] = mfma32(wh[H * H + t * 32], az[s], acch[t]);
+                    acch[t] = mfma32(wh[2 * H * H + t * 32], anr[s], acch[t]);
                 }
             }
             cur = nxt;
         }
-        const bool full = r0 + 32 <= a.R;
-        int orow[16];
+        // epilogue: lane = its own row; register 4q+i <-> column 8q + 4*half + i of the tile
+        const bool live = r0 + c < a.R;
+        if (live) {
 #pragma unroll
-        for (int reg = 0; reg < 16; ++reg) orow[reg] = a.rows[min(r0 + acc_row(reg, half), a.R - 1)];
-        // d_msg first (pure stores), then d_h one column tile at a time: all loads of a tile are issued
-        // before its stores
+            for (int t = 0; t < NTX; ++t)
 #pragma unroll
-        for (int reg = 0; reg < 16; ++reg) {
-            if (full || r0 + acc_row(reg, half) < a.R) {
-#pragma unroll
-                for (int t = 0; t < NTX; ++t) a.d_msg[(size_t)orow[reg] * a.ld_dmsg + t * 32 + c] = accx[t][reg];
-            }
+                for (int q = 0; q < 4; ++q)
+                    *reinterpret_cast<float4*>(a.d_msg + (size_t)row * a.ld_dmsg + t * 32 + 8 * q + 4 * half) =
+                        make_float4(accx[t][4 * q], accx[t][4 * q + 1], accx[t][4 * q + 2], accx[t][4 * q + 3]);
         }
-        // d_h: RCH accumulator rows x one column tile per phase (loads, then stores) -- small phases keep
-        // the register footprint of the fused variants inside the 256-VGPR budget of 2 waves per SIMD
-        constexpr int RCH = (FUSE && UP == 3) ? 4 : 8;
+        int srow = 0, drow = 0;
+        if (FUSE) { srow = a.add_src[li]; drow = a.add_dst[li]; }
+        const float dyr = (UP & 2) ? a.up.dy[row] : 0.f;
 #pragma unroll
-        for (int rb = 0; rb < 16; rb += RCH) {
+        for (int t = 0; t < NTH; ++t) {
+            float4 ex[4];
 #pragma unroll
-            for (int t = 0; t < NTH; ++t) {
-                const int col = t * 32 + c;
-                float ex[RCH];
-#pragma unroll
-                for (int q = 0; q < RCH; ++q) {
-                    const int reg = rb + q;
-                    const float zz = a.gates[gp + (size_t)orow[reg] * H + col];
-                    ex[q] = dh_at_t<UP>(a.up, orow[reg], col) * zz;
-                    if (FUSE) {
-                        const int lp = min(r0 + acc_row(reg, half), a.R - 1);
-                        ex[q] += a.add_msg[(size_t)a.add_src[lp] * a.ld_add + col] -
-                                 a.add_msg[(size_t)a.add_dst[lp] * a.ld_add + col];
-                    }
+            for (int q = 0; q < 4; ++q) {
+                const int col = t * 32 + 8 * q + 4 * half;
+                const float4 zz = *reinterpret_cast<const float4*>(a.gates + gp + (size_t)row * H + col);
+                float4 d = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (UP & 1) d = *reinterpret_cast<const float4*>(a.up.d_hout + (size_t)row * a.up.ld_dhout + col);
+                if (UP & 2) {
+                    const float4 w = *reinterpret_cast<const float4*>(a.up.w_head + col);
+                    d.x += dyr * w.x; d.y += dyr * w.y; d.z += dyr * w.z; d.w += dyr * w.w;
                 }
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int q = 0; q < RCH; ++q) {
-                    const int reg = rb + q;
-                    if (full || r0 + acc_row(reg, half) < a.R)
-                        a.d_h[(size_t)orow[reg] * a.ld_dh + col] = acch[t][reg] + ex[q];
+                ex[q] = make_float4(d.x * zz.x, d.y * zz.y, d.z * zz.z, d.w * zz.w);
+                if (FUSE) {
+                    const float4 u = *reinterpret_cast<const float4*>(a.add_msg + (size_t)srow * a.ld_add + col);
+                    const float4 v = *reinterpret_cast<const float4*>(a.add_msg + (size_t)drow * a.ld_add + col);
+                    ex[q].x += u.x - v.x; ex[q].y += u.y - v.y; ex[q].z += u.z - v.z; ex[q].w += u.w - v.w;
                 }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (live) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    *reinterpret_cast<float4*>(a.d_h + (size_t)row * a.ld_dh + t * 32 + 8 * q + 4 * half) =
+                        make_float4(acch[t][4 * q] + ex[q].x, acch[t][4 * q + 1] + ex[q].y, acch[t][4 * q + 2] + ex[q].z,
+                                    acch[t][4 * q + 3] + ex[q].w);
             }
         }
     }
@@ -882,19 +964,25 @@ int tmpnn_gru_fwd(const int32_t* rows, int R, int xmode, const int32_t* src, con
     GruFwdArgs a{rows, R, src, dst, msg, ld_msg, IN, msg_compact, h, ld_h, H, wih_t, whh_t, b_ih, b_hh, h_out, ld_out, gates,
                  gate_plane};
     hipStream_t st = as_stream(stream);
-    if (H <= 64 && aligned16(wih_t) && aligned16(whh_t)) {
+    if (H <= 64 && aligned16(wih_t) && aligned16(whh_t) && aligned16(h_out) && (ld_out & 3) == 0 && aligned16(b_ih) &&
+        aligned16(b_hh) && (gates == nullptr || (aligned16(gates) && (gate_plane & 3) == 0))) {
         // weights resident in LDS, persistent 8-wave blocks (see k_gru_fwd_lds)
-        const int ntiles = ceil_div(R, 256);
-        dim3 pgrid(ntiles < 256 ? ntiles : 256), pblock(512);
-        const size_t shm = sizeof(float) * (size_t)(IN + H) * 3 * H;
-#define LL(HH, II, X)                                                                                        \
+        // H = 64: 12 waves per block (3 per SIMD), two per 32-row tile (one per 32-column half) -> 192 rows per pass;
+        // H = 32: 8 waves, one per row tile
+        const int rows_per_pass = (H == 64) ? 192 : 256;
+        const int ntiles = ceil_div(R, rows_per_pass);
+        dim3 pgrid(ntiles < 256 ? ntiles : 256), pblock(H == 64 ? 768 : 512);
+        const int wpb = (H == 64) ? 12 : 8;
+        const size_t shm = sizeof(float) * ((size_t)(IN + H) * 3 * H + (size_t)wpb * 32 * STG_LD + 4);
+        if (shm > 160 * 1024) goto generic;      // e.g. concat at H = 64: the weights alone take 144 KiB
+#define LL(HH, II, X, CC, WW)                                                                                \
     do {                                                                                                     \
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gru_fwd_lds<HH, II, X>),                  \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gru_fwd_lds<HH, II, X, CC, WW>),          \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);                     \
-        hipLaunchKernelGGL((k_gru_fwd_lds<HH, II, X>), pgrid, pblock, shm, st, a, ntiles);                   \
+        hipLaunchKernelGGL((k_gru_fwd_lds<HH, II, X, CC, WW>), pgrid, pblock, shm, st, a, ntiles);           \
     } while (0)
-        if (H == 64) { if (xmode == 0 && IN == 64) LL(64, 64, 0); else if (xmode == 1) LL(64, 64, 1); else if (xmode == 2) LL(64, 128, 2); else goto generic; }
-        else         { if (xmode == 0 && IN == 32) LL(32, 32, 0); else if (xmode == 1) LL(32, 32, 1); else if (xmode == 2) LL(32, 64, 2); else goto generic; }
+        if (H == 64) { if (xmode == 0 && IN == 64) LL(64, 64, 0, 1, 12); else if (xmode == 1) LL(64, 64, 1, 1, 12); else if (xmode == 2) LL(64, 128, 2, 1, 12); else goto generic; }
+        else         { if (xmode == 0 && IN == 32) LL(32, 32, 0, 1, 8); else if (xmode == 1) LL(32, 32, 1, 1, 8); else if (xmode == 2) LL(32, 64, 2, 1, 8); else goto generic; }
 #undef LL
         return check_launch("gru_fwd_lds");
     }
@@ -927,7 +1015,9 @@ int tmpnn_gru_bwd_data(const int32_t* rows, int R, int IN, const float* h, int l
     GruBwdDataArgs a{rows, R, IN, h, ld_h, H, w_ih, w_hh, gates, gate_plane, DhSrc{d_hout, ld_dhout, dy, w_head},
                      d_msg, ld_dmsg, d_h, ld_dh, add_src, add_dst, add_msg, ld_add};
     hipStream_t st = as_stream(stream);
-    if (H <= 64 && (IN == H || IN == 2 * H) && aligned16(w_ih) && aligned16(w_hh)) {
+    if (H <= 64 && (IN == H || IN == 2 * H) && aligned16(w_ih) && aligned16(w_hh) && aligned16(d_msg) &&
+        (ld_dmsg & 3) == 0 && aligned16(d_h) && (ld_dh & 3) == 0 &&
+        (add_msg == nullptr || (aligned16(add_msg) && (ld_add & 3) == 0))) {
         const int ntiles = ceil_div(R, 256);
         dim3 pgrid(ntiles < 256 ? ntiles : 256), pblock(512);
         const size_t shm = sizeof(float) * (size_t)(IN + H) * 3 * H;
