@@ -37,28 +37,46 @@ __global__ __launch_bounds__(256) void k_gather(int E, const int32_t* __restrict
     const int rpb = 256 / lpr;                    // rows per block pass
     const int c4 = (threadIdx.x % lpr) * 4;
     const int slot = threadIdx.x / lpr;
-    for (long e = (long)blockIdx.x * rpb + slot; e < E; e += (long)gridDim.x * rpb) {
-        const int s = src[e], d = dst[e], r = edge_row[e];
-        const float4 a = *reinterpret_cast<const float4*>(in + (size_t)s * ld_in + c4);
-        const float4 b = *reinterpret_cast<const float4*>(in + (size_t)d * ld_in + c4);
-        float* o = out + (size_t)r * ld_out + c4;
-        if (!CONCAT) {
-            float4 v = make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w);
-            if (ACC) {
-                const float4 p = *reinterpret_cast<const float4*>(o);
-                v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w;
+    constexpr int U = 4;                          // edges in flight per lane group (memory-level parallelism)
+    const long stride = (long)gridDim.x * rpb;
+    for (long e0 = (long)blockIdx.x * rpb + slot; e0 < E; e0 += stride * U) {
+        int s[U], d[U], r[U];
+        bool ok[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const long e = e0 + u * stride;
+            ok[u] = e < E;
+            const long ec = ok[u] ? e : e0;
+            s[u] = src[ec]; d[u] = dst[ec]; r[u] = edge_row[ec];
+        }
+        float4 a[U], b[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            a[u] = *reinterpret_cast<const float4*>(in + (size_t)s[u] * ld_in + c4);
+            b[u] = *reinterpret_cast<const float4*>(in + (size_t)d[u] * ld_in + c4);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (!ok[u]) continue;
+            float* o = out + (size_t)r[u] * ld_out + c4;
+            if (!CONCAT) {
+                float4 v = make_float4(a[u].x - b[u].x, a[u].y - b[u].y, a[u].z - b[u].z, a[u].w - b[u].w);
+                if (ACC) {
+                    const float4 p = *reinterpret_cast<const float4*>(o);
+                    v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w;
+                }
+                *reinterpret_cast<float4*>(o) = v;
+            } else {
+                float4 va = a[u], vb = b[u];
+                if (ACC) {
+                    const float4 p = *reinterpret_cast<const float4*>(o);
+                    const float4 q = *reinterpret_cast<const float4*>(o + H);
+                    va.x += p.x; va.y += p.y; va.z += p.z; va.w += p.w;
+                    vb.x += q.x; vb.y += q.y; vb.z += q.z; vb.w += q.w;
+                }
+                *reinterpret_cast<float4*>(o) = va;
+                *reinterpret_cast<float4*>(o + H) = vb;
             }
-            *reinterpret_cast<float4*>(o) = v;
-        } else {
-            float4 va = a, vb = b;
-            if (ACC) {
-                const float4 p = *reinterpret_cast<const float4*>(o);
-                const float4 q = *reinterpret_cast<const float4*>(o + H);
-                va.x += p.x; va.y += p.y; va.z += p.z; va.w += p.w;
-                vb.x += q.x; vb.y += q.y; vb.z += q.z; vb.w += q.w;
-            }
-            *reinterpret_cast<float4*>(o) = va;
-            *reinterpret_cast<float4*>(o + H) = vb;
         }
     }
 }
@@ -66,7 +84,9 @@ __global__ __launch_bounds__(256) void k_gather(int E, const int32_t* __restrict
 // ------------------------------------------------------------------------------------------
 // segsum: out[det_row[d]] = sum_p  (neg_p ? wneg * in[row_p, cneg:cneg+H] : in[row_p, 0:H])
 //   diff adjoint / row F : wneg = -1, cneg = 0        concat adjoint : wneg = +1, cneg = H
-// One wave per det; the wave's 64/lpr row groups take CSR entries round-robin.
+// One wave per det; the wave's 64/lpr row groups take CSR entries round-robin, four entries of a
+// group in flight at a time (the CSR run of a det is short -- ~16 at KITTI sizes -- so the kernel is
+// latency bound unless every lane group keeps several row loads outstanding).
 // ------------------------------------------------------------------------------------------
 template <bool ACC>
 __global__ __launch_bounds__(256) void k_segsum(int Dn, const int32_t* __restrict__ det_row,
@@ -81,16 +101,29 @@ __global__ __launch_bounds__(256) void k_segsum(int Dn, const int32_t* __restric
     const int grp = lane / lpr;
     const int c4 = (lane % lpr) * 4;
     const long nwaves = (long)gridDim.x * 4;
+    constexpr int U = 4;
     for (long d = (long)blockIdx.x * 4 + (threadIdx.x >> 6); d < Dn; d += nwaves) {
         const int p0 = rowptr[d], p1 = rowptr[d + 1];
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int p = p0 + grp; p < p1; p += ngrp) {
-            const int v = inc[p];
-            const int row = v & 0x7fffffff;
-            const bool neg = v < 0;
-            const float4 x = *reinterpret_cast<const float4*>(in + (size_t)row * ld_in + (neg ? cneg : 0) + c4);
-            const float w = neg ? wneg : 1.0f;
-            acc.x += w * x.x; acc.y += w * x.y; acc.z += w * x.z; acc.w += w * x.w;
+        for (int pb = p0 + grp; pb < p1; pb += ngrp * U) {
+            int v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int p = pb + u * ngrp;
+                v[u] = p < p1 ? inc[p] : 0x7fffffff;       // sentinel: nothing to add
+            }
+            float4 x[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const bool live = v[u] != 0x7fffffff;
+                const int row = live ? (v[u] & 0x7fffffff) : 0;
+                x[u] = *reinterpret_cast<const float4*>(in + (size_t)row * ld_in + (v[u] < 0 ? cneg : 0) + c4);
+                const float w = v[u] < 0 ? wneg : 1.0f;
+                if (live) { x[u].x *= w; x[u].y *= w; x[u].z *= w; x[u].w *= w; }
+                else x[u] = make_float4(0.f, 0.f, 0.f, 0.f);     // (never multiply: row 0 may hold inf/nan)
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) { acc.x += x[u].x; acc.y += x[u].y; acc.z += x[u].z; acc.w += x[u].w; }
         }
         for (int off = lpr; off < 64; off <<= 1) {
             acc.x += __shfl_xor(acc.x, off);

@@ -623,13 +623,26 @@ __global__ __launch_bounds__(512) void k_gru_bwd_data_lds(GruBwdDataArgs a, int 
         *reinterpret_cast<float4*>(sWih + i) = *reinterpret_cast<const float4*>(a.w_ih + i);
     for (int i = threadIdx.x * 4; i < 3 * H * H; i += 512 * 4)
         *reinterpret_cast<float4*>(sWhh + i) = *reinterpret_cast<const float4*>(a.w_hh + i);
+    // 32-row tiles are pulled from an LDS counter; the two waves of a SIMD (w, w+4) get different static
+    // priorities so they do not run their MFMA and their store phases in lockstep (see k_gru_fwd_lds)
+    int* next_item = reinterpret_cast<int*>(lds + 3 * H * (IN + H));
+    if (threadIdx.x == 0) *next_item = 0;
     __syncthreads();
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int c = lane & 31, half = lane >> 5;
     const size_t gp = a.gate_plane;
+    if ((__builtin_amdgcn_readfirstlane(wave) >> 2) == 0) __builtin_amdgcn_s_setprio(2);
+    const int items_total = ntiles * 8;
+    const int per_block = (items_total + gridDim.x - 1) / gridDim.x;
+    const int item_lo = blockIdx.x * per_block;
+    const int item_hi = min(items_total, item_lo + per_block);
 
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const int r0 = (tile * 8 + wave) * 32;
+    for (;;) {
+        int item = 0;
+        if (lane == 0) item = atomicAdd(next_item, 1);
+        item = __builtin_amdgcn_readfirstlane(item) + item_lo;
+        if (item >= item_hi) break;
+        const int r0 = item * 32;
         if (r0 >= a.R) continue;
         const int li = min(r0 + c, a.R - 1);
         const int row = a.rows[li];
@@ -1020,7 +1033,7 @@ int tmpnn_gru_bwd_data(const int32_t* rows, int R, int IN, const float* h, int l
         (add_msg == nullptr || (aligned16(add_msg) && (ld_add & 3) == 0))) {
         const int ntiles = ceil_div(R, 256);
         dim3 pgrid(ntiles < 256 ? ntiles : 256), pblock(512);
-        const size_t shm = sizeof(float) * (size_t)(IN + H) * 3 * H;
+        const size_t shm = sizeof(float) * ((size_t)(IN + H) * 3 * H + 4);
         const int up = (d_hout ? 1 : 0) | (dy ? 2 : 0);
         const bool fuse = add_msg != nullptr;
 #define L3(HH, II, UU, FF)                                                                                   \
