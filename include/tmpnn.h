@@ -115,6 +115,9 @@ int tmpnn_att_bwd(const tmpnn_graph* g, const int32_t* pos, const float* h, int 
  *     x      = xmode 0: msg[msg_compact ? r : row, 0:IN]
  *              xmode 1: h[src[r]] - h[dst[r]]          (fused row E, diff;   IN = H)
  *              xmode 2: [h[src[r]] | h[dst[r]]]        (fused row E, concat; IN = 2H)
+ *              xmode 3: as xmode 1, but the x-part of the gates is read PRE-PROJECTED: msg = P [Dn][ld_msg >= 3H]
+ *                       with P = h[det rows] @ W_ih^T (tmpnn_rows_linear), src/dst = DET INDICES of the two
+ *                       endpoints; gi[r] = P[src[r]] - P[dst[r]] (linearity of row E).  H <= 64 only; wih_t unused.
  *     h_out[row] = GRUCell(x, h[row])
  * so running it once with rows = edge_row and once with rows = det_row performs the merge in
  * place.  Weights are passed TRANSPOSED (wih_t [IN][3H], whh_t [H][3H], see tmpnn_transpose);
@@ -150,6 +153,11 @@ int tmpnn_gru_bwd_weights(const int32_t* rows, int R, int xmode, const int32_t* 
                           const float* dy, const float* w_head,
                           float* dW_ih, float* dW_hh, float* db_ih, float* db_hh,
                           void* ws, size_t ws_bytes, tmpnn_stream stream);
+
+/* out[r, 0:NOUT] = in[rows[r], 0:H] @ wt[H][NOUT]  (compact output rows; H in {32, 64}, NOUT = 3H):
+ * the det-row projection P of tmpnn_gru_fwd's xmode 3. */
+int tmpnn_rows_linear(const int32_t* rows, int R, const float* in, int ld_in, int H, const float* wt, int NOUT,
+                      float* out, int ld_out, tmpnn_stream stream);
 
 /* out [cols][rows] = in[rows][cols]^T (weight re-layout for tmpnn_gru_fwd) */
 int tmpnn_transpose(const float* in, int rows, int cols, float* out, tmpnn_stream stream);

@@ -132,6 +132,21 @@ def check_gru(H, xmode, g, gd, rows_kind='edge'):
     other[rows] = False
     res['untouched'] = outD.cpu()[other].abs().max().item() if other.any() else 0.0
     res['untouched'] = max(res['untouched'], outD.cpu()[:, :H].abs().max().item())
+    if xmode == 1 and H <= 64:
+        # pre-projected variant (xmode 3): P = h[dets] @ W_ih^T, then gi = P[src] - P[dst]
+        dr = idx(g.det_row)
+        proj = torch.zeros(g.Dn, 3 * H + 4, device=DEV)
+        _lib.call('tmpnn_rows_linear', gd.det_row.data_ptr(), g.Dn, hD.data_ptr() + 4 * H, ld, H, wih_t.data_ptr(), 3 * H,
+                  proj.data_ptr(), 3 * H + 4, st())
+        res['proj'] = (proj.cpu()[:, :3 * H] - h[dr] @ wih.detach().t()).abs().max().item()
+        out3 = torch.zeros(g.N, ld, device=DEV)
+        gates3 = torch.zeros(4, g.N, H, device=DEV)
+        _lib.call('tmpnn_gru_fwd', rowsD.data_ptr(), R, 3, gd.src_pos.data_ptr(), gd.dst_pos.data_ptr(), proj.data_ptr(),
+                  3 * H + 4, 0, IN, hD.data_ptr() + 4 * H, ld, H, None, whh_t.data_ptr(), bihD.data_ptr(), bhhD.data_ptr(),
+                  out3.data_ptr() + 4 * H, ld, gates3.data_ptr(), g.N * H, st())
+        res['fwd_proj'] = (out3.cpu()[rows, H:2 * H] - out.detach()).abs().max().item()
+        g3 = gates3.cpu()
+        res['gates_proj'] = max((g3[i][rows] - t.detach()).abs().max().item() for i, t in enumerate((r, z, n, hn)))
 
     # backward, data
     doutfull = torch.zeros(g.N, ld)

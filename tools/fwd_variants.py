@@ -22,6 +22,18 @@ def mk(save, xmode):
     return fn
 for name, a in (('diff+gates', (1, 1)), ('diff nogates', (0, 1)), ('buf+gates', (1, 0)), ('buf nogates', (0, 0))):
     t = bench.time_stage(mk(*a)); print(name, round(t, 3), 'ms', round(12*H*H*E/t/1e9, 1), 'TF', flush=True)
+proj = torch.empty(g.Dn, 3*H, device=dev)
+def projk():
+    _lib.call('tmpnn_rows_linear', g.det_row.data_ptr(), g.Dn, h.data_ptr(), H, H, wih_t.data_ptr(), 3*H, proj.data_ptr(), 3*H, st)
+def mk3(save):
+    def fn():
+        _lib.call('tmpnn_gru_fwd', g.edge_row.data_ptr(), E, 3, g.src_pos.data_ptr(), g.dst_pos.data_ptr(), proj.data_ptr(), 3*H, 0, H,
+                  h.data_ptr(), H, H, None, whh_t.data_ptr(), bih.data_ptr(), bhh.data_ptr(), out.data_ptr(), H,
+                  gates.data_ptr() if save else None, N*H, st)
+    return fn
+print('rows_linear (P)', round(bench.time_stage(projk), 3), 'ms', flush=True)
+for name, a in (('proj+gates', 1), ('proj nogates', 0)):
+    t = bench.time_stage(mk3(a)); print(name, round(t, 3), 'ms', flush=True)
 # cache-resident experiment: all rows folded into 4096 distinct rows -> gate stores stay in L2
 rows_small = (g.edge_row % 4096).to(torch.int32).contiguous()
 def mk2(save):

@@ -409,10 +409,13 @@ __global__ __launch_bounds__(256) void k_gru_bwd_weights(GruBwdWArgs a) {
 // so that lane l of pass k holds 16 bytes of row (64k + l)/8 -- eight lanes cover one 128-byte row segment.
 // The staging row stride of 36 floats keeps both the writes and the reads bank-conflict free.
 constexpr int STG_LD = 36;
-__device__ __forceinline__ void stage_store32(float* stg, int c, int half, int lane, const float4* v,
+template <bool NT = false>
+__device__ __forceinline__ void stage_store32(float* stg, int c, int half, int lane, const f32x16& v,
                                               float* dst, int ld, int col0, int row, int r0, int R) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) *reinterpret_cast<float4*>(stg + c * STG_LD + 8 * q + 4 * half) = v[q];
+    for (int q = 0; q < 4; ++q)
+        *reinterpret_cast<float4*>(stg + c * STG_LD + 8 * q + 4 * half) =
+            make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // same-wave LDS ops are ordered; keep the compiler honest
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -420,9 +423,23 @@ __device__ __forceinline__ void stage_store32(float* stg, int c, int half, int l
         const int rr = idx >> 3, ch = idx & 7;
         const float4 x = *reinterpret_cast<const float4*>(stg + rr * STG_LD + ch * 4);
         const int orow = __shfl(row, rr, 64);               // lane rr (< 32) owns row r0 + rr
-        if (r0 + rr < R) *reinterpret_cast<float4*>(dst + (size_t)orow * ld + col0 + ch * 4) = x;
+        if (r0 + rr < R) {
+            float* p = dst + (size_t)orow * ld + col0 + ch * 4;
+            if (NT) {      // streamed once, read back only by the backward pass: keep it out of the way of L2
+                __builtin_nontemporal_store(x.x, p); __builtin_nontemporal_store(x.y, p + 1);
+                __builtin_nontemporal_store(x.z, p + 2); __builtin_nontemporal_store(x.w, p + 3);
+            } else {
+                *reinterpret_cast<float4*>(p) = x;
+            }
+        }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+}
+
+// output row of staging pass k for this lane = row owned by lane (64k + lane)/8 (lanes 0..31 own the tile's rows)
+__device__ __forceinline__ void stage_rows(int row, int lane, int* orow4) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) orow4[k] = __shfl(row, (k * 64 + lane) >> 3, 64);
 }
 
 // raw A-operand slice of one 32-wide k tile (16 floats per lane; the diff message needs two rows)
@@ -430,7 +447,7 @@ struct ATile { float u[16]; float w[16]; };
 
 template <int H, int IN, int XMODE>
 __device__ __forceinline__ void a_issue(const GruFwdArgs& a, int kt, int li, int row, int half, ATile& t) {
-    constexpr int NKX = IN / 32;
+    constexpr int NKX = (XMODE == 3) ? 0 : IN / 32;
     if (kt < NKX) {
         const int f0 = kt * 32 + half * 16;
         if (XMODE == 0) load16(a.msg + (size_t)(a.msg_compact ? li : row) * a.ld_msg + f0, t.u);
@@ -455,10 +472,14 @@ __global__ __launch_bounds__(WPB * 64) void k_gru_fwd_lds(GruFwdArgs a, int ntil
     constexpr int H3 = 3 * H;
     constexpr int CW = (H / 32) / CT;          // column waves per row tile
     constexpr int RTB = WPB / CW;              // row tiles per block iteration
-    constexpr int NKX = IN / 32, NK = NKX + H / 32;
-    float* sWih = lds;               // [IN][3H]
-    float* sWhh = lds + IN * H3;     // [H][3H]
-    for (int i = threadIdx.x * 4; i < IN * H3; i += WPB * 64 * 4)
+    // XMODE 3: the x-part of the gates arrives pre-projected (msg = h[dets] @ W_ih^T, [Dn][3H]) and is
+    // gathered in the epilogue -- by linearity (h[src]-h[dst]) W = h[src] W - h[dst] W, so the per-EDGE
+    // half of the forward GEMM collapses into one small GEMM over the det rows.
+    constexpr int INL = (XMODE == 3) ? 0 : IN;      // x columns that go through the MFMAs
+    constexpr int NKX = INL / 32, NK = NKX + H / 32;
+    float* sWih = lds;               // [INL][3H]
+    float* sWhh = lds + INL * H3;    // [H][3H]
+    for (int i = threadIdx.x * 4; i < INL * H3; i += WPB * 64 * 4)
         *reinterpret_cast<float4*>(sWih + i) = *reinterpret_cast<const float4*>(a.wih_t + i);
     for (int i = threadIdx.x * 4; i < H * H3; i += WPB * 64 * 4)
         *reinterpret_cast<float4*>(sWhh + i) = *reinterpret_cast<const float4*>(a.whh_t + i);
@@ -468,7 +489,7 @@ __global__ __launch_bounds__(WPB * 64) void k_gru_fwd_lds(GruFwdArgs a, int ntil
     // MFMA phase together, then all in their store phase together -- and the matrix pipe idles while
     // the epilogues drain.  With a strict order the top wave runs at full rate and the others fill
     // every gap its loads and stores leave.
-    int* next_item = reinterpret_cast<int*>(lds + (IN + H) * H3 + WPB * (32 * STG_LD));
+    int* next_item = reinterpret_cast<int*>(lds + (INL + H) * H3 + WPB * (32 * STG_LD));
     if (threadIdx.x == 0) *next_item = 0;
     __syncthreads();
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -478,6 +499,7 @@ __global__ __launch_bounds__(WPB * 64) void k_gru_fwd_lds(GruFwdArgs a, int ntil
         if (grp == 0) __builtin_amdgcn_s_setprio(3);
         else if (grp == 1) __builtin_amdgcn_s_setprio(2);
         else if (grp == 2) __builtin_amdgcn_s_setprio(1);
+        // (a fourth group, if any, stays at priority 0)
     }
     const int items_total = ntiles * RTB * CW;                 // ntiles = passes of RTB row tiles
     const int per_block = (items_total + gridDim.x - 1) / gridDim.x;
@@ -545,7 +567,7 @@ __global__ __launch_bounds__(WPB * 64) void k_gru_fwd_lds(GruFwdArgs a, int ntil
         // Outputs leave through a per-wave LDS staging tile so that every global store instruction writes
         // full 128-byte row segments with 16 bytes per lane (8 lanes per row): dword stores are issue-bound
         // and 32-byte runs (what the accumulator layout would give directly) waste the write path.
-        float* stg = lds + (IN + H) * H3 + wave * (32 * STG_LD);   // (the item counter sits behind the tiles)
+        float* stg = lds + (INL + H) * H3 + wave * (32 * STG_LD);   // (the item counter sits behind the tiles)
         float4 hp4[CT][4];
 #pragma unroll
         for (int t = 0; t < CT; ++t)
@@ -554,7 +576,9 @@ __global__ __launch_bounds__(WPB * 64) void k_gru_fwd_lds(GruFwdArgs a, int ntil
                 hp4[t][q] = *reinterpret_cast<const float4*>(a.h + (size_t)row * a.ld_h + cw0 + t * 32 + 8 * q + 4 * half);
 #pragma unroll
         for (int t = 0; t < CT; ++t) {
-            float4 vo[4], vr[4], vz[4], vn[4], vh[4];
+            // results overwrite the accumulators they were computed from (r -> acc_r, z -> acc_z, n -> acc_in,
+            // W_hn h + b -> acc_hn), so the five output tiles cost 16 extra registers, not 80
+            f32x16 outv;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int col = cw0 + t * 32 + 8 * q + 4 * half;
@@ -569,30 +593,81 @@ __global__ __launch_bounds__(WPB * 64) void k_gru_fwd_lds(GruFwdArgs a, int ntil
                 const float bi[4] = {bin.x, bin.y, bin.z, bin.w};
                 const float bh[4] = {bhn.x, bhn.y, bhn.z, bhn.w};
                 const float hp[4] = {hp4[t][q].x, hp4[t][q].y, hp4[t][q].z, hp4[t][q].w};
-                float ro[4], zo[4], no[4], ho[4], out[4];
+                float xr[4] = {0.f, 0.f, 0.f, 0.f}, xz[4] = {0.f, 0.f, 0.f, 0.f}, xn[4] = {0.f, 0.f, 0.f, 0.f};
+                if (XMODE == 3) {
+                    const float* ps = a.msg + (size_t)a.src[li] * a.ld_msg + col;
+                    const float* pd = a.msg + (size_t)a.dst[li] * a.ld_msg + col;
+                    const float4 sr = *reinterpret_cast<const float4*>(ps), dr = *reinterpret_cast<const float4*>(pd);
+                    const float4 sz = *reinterpret_cast<const float4*>(ps + H), dz = *reinterpret_cast<const float4*>(pd + H);
+                    const float4 sn = *reinterpret_cast<const float4*>(ps + 2 * H), dn = *reinterpret_cast<const float4*>(pd + 2 * H);
+                    xr[0] = sr.x - dr.x; xr[1] = sr.y - dr.y; xr[2] = sr.z - dr.z; xr[3] = sr.w - dr.w;
+                    xz[0] = sz.x - dz.x; xz[1] = sz.y - dz.y; xz[2] = sz.z - dz.z; xz[3] = sz.w - dz.w;
+                    xn[0] = sn.x - dn.x; xn[1] = sn.y - dn.y; xn[2] = sn.z - dn.z; xn[3] = sn.w - dn.w;
+                }
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const int reg = 4 * q + i;
-                    ro[i] = sigmoidf_(acc_r[t][reg] + br[i]);
-                    zo[i] = sigmoidf_(acc_z[t][reg] + bz[i]);
-                    ho[i] = acc_hn[t][reg] + bh[i];
-                    no[i] = tanhf_(acc_in[t][reg] + bi[i] + ro[i] * ho[i]);
-                    out[i] = (1.0f - zo[i]) * no[i] + zo[i] * hp[i];
+                    const float ro = sigmoidf_(acc_r[t][reg] + xr[i] + br[i]);
+                    const float zo = sigmoidf_(acc_z[t][reg] + xz[i] + bz[i]);
+                    const float ho = acc_hn[t][reg] + bh[i];
+                    const float no = tanhf_((XMODE == 3 ? xn[i] : acc_in[t][reg]) + bi[i] + ro * ho);
+                    outv[reg] = (1.0f - zo) * no + zo * hp[i];
+                    acc_r[t][reg] = ro; acc_z[t][reg] = zo; acc_hn[t][reg] = ho; acc_in[t][reg] = no;
                 }
-                vo[q] = make_float4(out[0], out[1], out[2], out[3]);
-                vr[q] = make_float4(ro[0], ro[1], ro[2], ro[3]);
-                vz[q] = make_float4(zo[0], zo[1], zo[2], zo[3]);
-                vn[q] = make_float4(no[0], no[1], no[2], no[3]);
-                vh[q] = make_float4(ho[0], ho[1], ho[2], ho[3]);
             }
             const int colt = cw0 + t * 32;
-            stage_store32(stg, c, half, lane, vo, a.h_out, a.ld_out, colt, row, r0, a.R);
+            stage_store32(stg, c, half, lane, outv, a.h_out, a.ld_out, colt, row, r0, a.R);
             if (a.gates) {
-                stage_store32(stg, c, half, lane, vr, a.gates, H, colt, row, r0, a.R);
-                stage_store32(stg, c, half, lane, vz, a.gates + a.gate_plane, H, colt, row, r0, a.R);
-                stage_store32(stg, c, half, lane, vn, a.gates + 2 * a.gate_plane, H, colt, row, r0, a.R);
-                stage_store32(stg, c, half, lane, vh, a.gates + 3 * a.gate_plane, H, colt, row, r0, a.R);
+                stage_store32<true>(stg, c, half, lane, acc_r[t], a.gates, H, colt, row, r0, a.R);
+                stage_store32<true>(stg, c, half, lane, acc_z[t], a.gates + a.gate_plane, H, colt, row, r0, a.R);
+                stage_store32<true>(stg, c, half, lane, acc_in[t], a.gates + 2 * a.gate_plane, H, colt, row, r0, a.R);
+                stage_store32<true>(stg, c, half, lane, acc_hn[t], a.gates + 3 * a.gate_plane, H, colt, row, r0, a.R);
             }
+        }
+    }
+}
+
+// out[r][0:NOUT] = in[rows[r]][0:H] @ Wt[H][NOUT]   (no bias; H <= 64; NOUT multiple of 32).  Used to
+// project the det rows once per call (P = h[dets] W_ih^T) for the XMODE 3 forward.
+template <int H, int NT>     // NT = NOUT / 32 column tiles, all owned by one wave
+__global__ __launch_bounds__(512) void k_rows_gemm_lds(const int32_t* __restrict__ rows, int R,
+                                                       const float* __restrict__ in, int ld_in,
+                                                       const float* __restrict__ wt, float* __restrict__ out,
+                                                       int ld_out, int ntiles) {
+    extern __shared__ float lds[];
+    constexpr int NOUT = NT * 32;
+    float* sW = lds;                                   // [H][NOUT]
+    for (int i = threadIdx.x * 4; i < H * NOUT; i += 512 * 4)
+        *reinterpret_cast<float4*>(sW + i) = *reinterpret_cast<const float4*>(wt + i);
+    __syncthreads();
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int c = lane & 31, half = lane >> 5;
+    float* stg = lds + H * NOUT + wave * (32 * STG_LD);
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int r0 = (tile * 8 + wave) * 32;
+        if (r0 >= R) continue;
+        const int li = min(r0 + c, R - 1);
+        const int row = rows[li];
+        f32x16 acc[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < H / 32; ++kt) {
+            const int f0 = kt * 32 + half * 16;
+            float av[16];
+            load16(in + (size_t)row * ld_in + f0, av);
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+                const float* b = sW + (f0 + s) * NOUT + c;
+#pragma unroll
+                for (int t = 0; t < NT; ++t) acc[t] = mfma32(b[t * 32], av[s], acc[t]);
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            stage_store32(stg, c, half, lane, acc[t], out, ld_out, t * 32, li, r0, R);   // compact rows: list position
         }
     }
 }
@@ -965,28 +1040,30 @@ int tmpnn_gru_fwd(const int32_t* rows, int R, int xmode, const int32_t* src, con
     TM_REQUIRE(supported_H(H), "gru_fwd: unsupported H=%d", H);
     TM_REQUIRE(R >= 0, "gru_fwd: R=%d", R);
     if (R == 0) return TMPNN_OK;
-    TM_REQUIRE(xmode >= 0 && xmode <= 2, "gru_fwd: xmode=%d", xmode);
-    TM_REQUIRE(IN == (xmode == 2 ? 2 * H : (xmode == 1 ? H : IN)) && IN % 32 == 0 && IN > 0,
+    TM_REQUIRE(xmode >= 0 && xmode <= 3, "gru_fwd: xmode=%d", xmode);
+    TM_REQUIRE(IN == (xmode == 2 ? 2 * H : (xmode == 1 || xmode == 3 ? H : IN)) && IN % 32 == 0 && IN > 0,
                "gru_fwd: IN=%d does not match xmode=%d H=%d", IN, xmode, H);
-    TM_REQUIRE(rows && h && wih_t && whh_t && b_ih && b_hh && h_out, "gru_fwd: null pointer");
+    TM_REQUIRE(rows && h && whh_t && b_ih && b_hh && h_out && (wih_t || xmode == 3), "gru_fwd: null pointer");
     TM_REQUIRE(xmode == 0 ? (msg != nullptr && ld_msg >= IN && (ld_msg & 3) == 0 && aligned16(msg))
                           : (src != nullptr && dst != nullptr),
                "gru_fwd: message source missing/misaligned for xmode=%d", xmode);
+    TM_REQUIRE(xmode != 3 || (H <= 64 && msg != nullptr && ld_msg >= 3 * H && (ld_msg & 3) == 0 && aligned16(msg)),
+               "gru_fwd: xmode 3 needs H <= 64 and the projected det rows msg [Dn][3H]");
     TM_REQUIRE(ld_h >= H && ld_out >= H && (ld_h & 3) == 0 && aligned16(h), "gru_fwd: bad state layout");
     TM_REQUIRE(gates == nullptr || gate_plane >= (size_t)H, "gru_fwd: gate_plane too small");
     GruFwdArgs a{rows, R, src, dst, msg, ld_msg, IN, msg_compact, h, ld_h, H, wih_t, whh_t, b_ih, b_hh, h_out, ld_out, gates,
                  gate_plane};
     hipStream_t st = as_stream(stream);
-    if (H <= 64 && aligned16(wih_t) && aligned16(whh_t) && aligned16(h_out) && (ld_out & 3) == 0 && aligned16(b_ih) &&
+    if (H <= 64 && (xmode == 3 || aligned16(wih_t)) && aligned16(whh_t) && aligned16(h_out) && (ld_out & 3) == 0 && aligned16(b_ih) &&
         aligned16(b_hh) && (gates == nullptr || (aligned16(gates) && (gate_plane & 3) == 0))) {
         // weights resident in LDS, persistent 8-wave blocks (see k_gru_fwd_lds)
         // H = 64: 12 waves per block (3 per SIMD), two per 32-row tile (one per 32-column half) -> 192 rows per pass;
         // H = 32: 8 waves, one per row tile
-        const int rows_per_pass = (H == 64) ? 192 : 256;
+        const int rows_per_pass = (H == 64 && xmode != 3) ? 192 : 256;
         const int ntiles = ceil_div(R, rows_per_pass);
-        dim3 pgrid(ntiles < 256 ? ntiles : 256), pblock(H == 64 ? 768 : 512);
-        const int wpb = (H == 64) ? 12 : 8;
-        const size_t shm = sizeof(float) * ((size_t)(IN + H) * 3 * H + (size_t)wpb * 32 * STG_LD + 4);
+        dim3 pgrid(ntiles < 256 ? ntiles : 256), pblock(H == 64 ? (xmode == 3 ? 1024 : 768) : 512);
+        const int wpb = (H == 64) ? (xmode == 3 ? 16 : 12) : 8;
+        const size_t shm = sizeof(float) * ((size_t)((xmode == 3 ? 0 : IN) + H) * 3 * H + (size_t)wpb * 32 * STG_LD + 4);
         if (shm > 160 * 1024) goto generic;      // e.g. concat at H = 64: the weights alone take 144 KiB
 #define LL(HH, II, X, CC, WW)                                                                                \
     do {                                                                                                     \
@@ -994,12 +1071,13 @@ int tmpnn_gru_fwd(const int32_t* rows, int R, int xmode, const int32_t* src, con
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);                     \
         hipLaunchKernelGGL((k_gru_fwd_lds<HH, II, X, CC, WW>), pgrid, pblock, shm, st, a, ntiles);           \
     } while (0)
-        if (H == 64) { if (xmode == 0 && IN == 64) LL(64, 64, 0, 1, 12); else if (xmode == 1) LL(64, 64, 1, 1, 12); else if (xmode == 2) LL(64, 128, 2, 1, 12); else goto generic; }
-        else         { if (xmode == 0 && IN == 32) LL(32, 32, 0, 1, 8); else if (xmode == 1) LL(32, 32, 1, 1, 8); else if (xmode == 2) LL(32, 64, 2, 1, 8); else goto generic; }
+        if (H == 64) { if (xmode == 0 && IN == 64) LL(64, 64, 0, 1, 12); else if (xmode == 1) LL(64, 64, 1, 1, 12); else if (xmode == 2) LL(64, 128, 2, 1, 12); else if (xmode == 3) LL(64, 64, 3, 1, 16); else goto generic; }
+        else         { if (xmode == 0 && IN == 32) LL(32, 32, 0, 1, 8); else if (xmode == 1) LL(32, 32, 1, 1, 8); else if (xmode == 2) LL(32, 64, 2, 1, 8); else if (xmode == 3) LL(32, 32, 3, 1, 8); else goto generic; }
 #undef LL
         return check_launch("gru_fwd_lds");
     }
 generic:
+    TM_REQUIRE(xmode != 3, "gru_fwd: xmode 3 is only available on the LDS path (H <= 64, 16-byte aligned buffers)");
     const int CT = (H % 64 == 0) ? 2 : 1;
     dim3 grid(ceil_div(R, 128), H / (32 * CT)), block(256);
 #define L(C, X) hipLaunchKernelGGL((k_gru_fwd<C, X>), grid, block, 0, st, a)
@@ -1007,6 +1085,30 @@ generic:
     else         { if (xmode == 0) L(1, 0); else if (xmode == 1) L(1, 1); else L(1, 2); }
 #undef L
     return check_launch("gru_fwd");
+}
+
+int tmpnn_rows_linear(const int32_t* rows, int R, const float* in, int ld_in, int H, const float* wt, int NOUT,
+                      float* out, int ld_out, tmpnn_stream stream) {
+    TM_REQUIRE((H == 32 || H == 64) && (NOUT == 3 * H), "rows_linear: only [H<=64] x [3H] projections (H=%d NOUT=%d)", H, NOUT);
+    if (R == 0) return TMPNN_OK;
+    TM_REQUIRE(R > 0 && rows && in && wt && out, "rows_linear: null pointer");
+    TM_REQUIRE(ld_in >= H && (ld_in & 3) == 0 && aligned16(in) && aligned16(wt) && ld_out >= NOUT && (ld_out & 3) == 0 &&
+                   aligned16(out),
+               "rows_linear: rows must be 16-byte aligned");
+    const int ntiles = ceil_div(R, 256);
+    dim3 grid(ntiles < 256 ? ntiles : 256), block(512);
+    const size_t shm = sizeof(float) * ((size_t)H * NOUT + 8 * 32 * STG_LD);
+    hipStream_t st = as_stream(stream);
+    if (H == 64) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rows_gemm_lds<64, 6>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+        hipLaunchKernelGGL((k_rows_gemm_lds<64, 6>), grid, block, shm, st, rows, R, in, ld_in, wt, out, ld_out, ntiles);
+    } else {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rows_gemm_lds<32, 3>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+        hipLaunchKernelGGL((k_rows_gemm_lds<32, 3>), grid, block, shm, st, rows, R, in, ld_in, wt, out, ld_out, ntiles);
+    }
+    return check_launch("rows_linear");
 }
 
 int tmpnn_gru_bwd_data(const int32_t* rows, int R, int IN, const float* h, int ld_h, int H, const float* w_ih,

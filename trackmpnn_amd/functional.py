@@ -174,11 +174,22 @@ def mp_forward(spec: ModelSpec, plan: CallPlan, x: torch.Tensor, h_in: Optional[
         #  hand a freed block to the very next allocation)
         e_wih_t, e_whh_t = _transpose(P[f + 'edge_gru.weight_ih']), _transpose(P[f + 'edge_gru.weight_hh'])
         n_wih_t, n_whh_t = _transpose(P[f + 'node_gru.weight_ih']), _transpose(P[f + 'node_gru.weight_hh'])
-        _lib.call('tmpnn_gru_fwd', g.edge_row.data_ptr(), E, xmode, g.src.data_ptr(), g.dst.data_ptr(),
-                  None, 0, 0, spec.IN_e, hg, GH, H,
-                  e_wih_t.data_ptr(), e_whh_t.data_ptr(),
-                  P[f + 'edge_gru.bias_ih'].data_ptr(), P[f + 'edge_gru.bias_hh'].data_ptr(),
-                  og, GH, gp, plane, st)
+        if spec.msg_type == 'diff' and H <= 64 and g.src_pos is not None and Dn > 0:
+            # (h[src]-h[dst]) W_ih^T = P[src] - P[dst] with P = h[dets] W_ih^T: the x-half of the edge cell's
+            # forward GEMM runs over the Dn det rows instead of the E edge rows
+            proj = torch.empty((Dn, 3 * H), **opts)
+            _lib.call('tmpnn_rows_linear', g.det_row.data_ptr(), Dn, hg, GH, H, e_wih_t.data_ptr(), 3 * H,
+                      proj.data_ptr(), 3 * H, st)
+            _lib.call('tmpnn_gru_fwd', g.edge_row.data_ptr(), E, 3, g.src_pos.data_ptr(), g.dst_pos.data_ptr(),
+                      proj.data_ptr(), 3 * H, 0, H, hg, GH, H, None, e_whh_t.data_ptr(),
+                      P[f + 'edge_gru.bias_ih'].data_ptr(), P[f + 'edge_gru.bias_hh'].data_ptr(),
+                      og, GH, gp, plane, st)
+        else:
+            _lib.call('tmpnn_gru_fwd', g.edge_row.data_ptr(), E, xmode, g.src.data_ptr(), g.dst.data_ptr(),
+                      None, 0, 0, spec.IN_e, hg, GH, H,
+                      e_wih_t.data_ptr(), e_whh_t.data_ptr(),
+                      P[f + 'edge_gru.bias_ih'].data_ptr(), P[f + 'edge_gru.bias_hh'].data_ptr(),
+                      og, GH, gp, plane, st)
         # edge -> node aggregation                              (layers.py:99-112)
         es = es_all[gi]
         if K == 0:

@@ -39,6 +39,8 @@ class FrameGraph:
     inc: torch.Tensor        # int32 [2E]   edge row | sign bit
     is_edge: torch.Tensor    # uint8 [N]
     pos: torch.Tensor        # int32 [N]    row -> index within its type (det index | edge index)
+    src_pos: Optional[torch.Tensor] = None   # int32 [E]  det INDEX of src[e] (= pos[src])
+    dst_pos: Optional[torch.Tensor] = None   # int32 [E]  det INDEX of dst[e]
     _c: Optional[_lib.CGraph] = field(default=None, repr=False, compare=False)
 
     @property
@@ -50,7 +52,9 @@ class FrameGraph:
             return self
         mv = lambda t: t.to(device)
         return FrameGraph(self.N, self.E, self.Dn, mv(self.src), mv(self.dst), mv(self.edge_row), mv(self.det_row),
-                          mv(self.rowptr), mv(self.inc), mv(self.is_edge), mv(self.pos))
+                          mv(self.rowptr), mv(self.inc), mv(self.is_edge), mv(self.pos),
+                          None if self.src_pos is None else mv(self.src_pos),
+                          None if self.dst_pos is None else mv(self.dst_pos))
 
     def cstruct(self) -> _lib.CGraph:
         if self._c is None:
@@ -111,7 +115,7 @@ def graph_from_edges(N: int, is_edge: torch.Tensor, src: torch.Tensor, dst: torc
     i32 = lambda t: t.to(torch.int32).contiguous()
     return FrameGraph(N=N, E=E, Dn=Dn, src=i32(src), dst=i32(dst), edge_row=i32(edge_row), det_row=i32(det_row),
                       rowptr=i32(rowptr), inc=inc.contiguous(), is_edge=is_edge.to(torch.uint8).contiguous(),
-                      pos=i32(pos))
+                      pos=i32(pos), src_pos=i32(det_pos[src]), dst_pos=i32(det_pos[dst]))
 
 
 def _coo(adj: torch.Tensor):
