@@ -104,10 +104,14 @@ def stage_profile(model, plan, H):
     ws = torch.empty(wsb // 4 + 1, device=dev)
     es = torch.empty(Dn, H, device=dev)
 
-    def gru_fwd():
-        _lib.call('tmpnn_gru_fwd', g.edge_row.data_ptr(), E, 1, g.src.data_ptr(), g.dst.data_ptr(), None, 0, 0, H,
-                  h.data_ptr(), H, H, wih_t.data_ptr(), whh_t.data_ptr(), bih.data_ptr(), bhh.data_ptr(),
-                  out.data_ptr(), H, gates.data_ptr(), N * H, st)
+    proj = torch.empty(Dn, 3 * H, device=dev)
+
+    def gru_fwd():      # as the training step runs it: det rows projected once, edge cell gathers P[src] - P[dst]
+        _lib.call('tmpnn_rows_linear', g.det_row.data_ptr(), Dn, h.data_ptr(), H, H, wih_t.data_ptr(), 3 * H,
+                  proj.data_ptr(), 3 * H, st)
+        _lib.call('tmpnn_gru_fwd', g.edge_row.data_ptr(), E, 3, g.src_pos.data_ptr(), g.dst_pos.data_ptr(),
+                  proj.data_ptr(), 3 * H, 0, H, h.data_ptr(), H, H, None, whh_t.data_ptr(), bih.data_ptr(),
+                  bhh.data_ptr(), out.data_ptr(), H, gates.data_ptr(), N * H, st)
 
     def gru_bwd_data():
         _lib.call('tmpnn_gru_bwd_data', g.edge_row.data_ptr(), E, H, h.data_ptr(), H, H, wih.data_ptr(), whh.data_ptr(),
@@ -147,7 +151,7 @@ def stage_profile(model, plan, H):
     return t, flops, {'gather_diff': b_gather, 'segsum': b_segsum}
 
 
-_PMC_KERNEL = {'gru_fwd_edge': 'k_gru_fwd_lds<64, 64, 1>', 'gru_bwd_data_edge': 'k_gru_bwd_data_lds<64, 64, 1, false>',
+_PMC_KERNEL = {'gru_fwd_edge': 'k_gru_fwd_lds<64, 64, 3,', 'gru_bwd_data_edge': 'k_gru_bwd_data_lds<64, 64, 1, false>',
                'gru_bwd_data_edge_folded': 'k_gru_bwd_data_lds<64, 64, 3, true>',
                'gru_bwd_weights_edge': 'k_gru_bwd_weights_lds<64, 1, 1>'}
 

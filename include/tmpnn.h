@@ -175,7 +175,8 @@ int tmpnn_transpose(const float* in, int rows, int cols, float* out, tmpnn_strea
  *   y_save [nd][H] = Lin1 output (saved for backward); out rows written to
  *   h_new[out_row[i], 0:H] (ld_h). */
 int tmpnn_input_bn_fwd(const float* xdet, int ld_x, int F, int nd, const int32_t* seg_ptr,
-                       const int32_t* seg_cnt, int S, int H, int training,
+                       const int32_t* seg_cnt, const int32_t* seg_of_det /* [nd] segment of each det row, or NULL */,
+                       int S, int H, int training,
                        const float* w1, const float* b1, const float* gamma, const float* beta,
                        float* running_mean, float* running_var,
                        const float* w2, const float* b2,
@@ -188,7 +189,7 @@ int tmpnn_input_bn_fwd(const float* xdet, int ld_x, int F, int nd, const int32_t
  * (0 in eval mode).  ws: tmpnn_input_bn_bwd_ws(nd, S, H, F) floats. */
 size_t tmpnn_input_bn_bwd_ws(int nd, int S, int H, int F);
 int tmpnn_input_bn_bwd(const float* xdet, int ld_x, int F, int nd, const int32_t* seg_ptr,
-                       const int32_t* seg_cnt, int S, int H, int training,
+                       const int32_t* seg_cnt, const int32_t* seg_of_det, int S, int H, int training,
                        const float* w1, const float* b1, const float* gamma, const float* beta,
                        const float* w2,
                        const float* y_save, const float* mean, const float* rstd,

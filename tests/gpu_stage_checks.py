@@ -301,7 +301,8 @@ def check_input_bn(H, F_, training, S=4):
     Nrows, ld = nd + 5, 2 * H
     out_row = torch.tensor(np.random.RandomState(0).permutation(Nrows)[:nd], dtype=torch.int32, device=DEV)
     h_new = torch.zeros(Nrows, ld, device=DEV)
-    _lib.call('tmpnn_input_bn_fwd', xD.data_ptr() + 4, Ft, F_, nd, seg_ptr.data_ptr(), seg_cnt.data_ptr(), S, H,
+    seg_of_det = torch.repeat_interleave(torch.arange(S, dtype=torch.int32), torch.tensor(nds)).to(DEV) if H != 32 else None
+    _lib.call('tmpnn_input_bn_fwd', xD.data_ptr() + 4, Ft, F_, nd, seg_ptr.data_ptr(), seg_cnt.data_ptr(), _lib.ptr(seg_of_det), S, H,
               int(training), P[t + '0.weight'].data_ptr(), P[t + '0.bias'].data_ptr(), P[t + '1.weight'].data_ptr(),
               P[t + '1.bias'].data_ptr(), P[t + '1.running_mean'].data_ptr(), P[t + '1.running_var'].data_ptr(),
               P[t + '3.weight'].data_ptr(), P[t + '3.bias'].data_ptr(), y_save.data_ptr(), mean.data_ptr(),
@@ -320,7 +321,7 @@ def check_input_bn(H, F_, training, S=4):
     d_xzero = torch.zeros(S, F_, device=DEV)
     wsn = _lib.load().tmpnn_input_bn_bwd_ws(nd, S, H, F_)
     ws = torch.empty(wsn + 1, device=DEV)
-    _lib.call('tmpnn_input_bn_bwd', xD.data_ptr() + 4, Ft, F_, nd, seg_ptr.data_ptr(), seg_cnt.data_ptr(), S, H,
+    _lib.call('tmpnn_input_bn_bwd', xD.data_ptr() + 4, Ft, F_, nd, seg_ptr.data_ptr(), seg_cnt.data_ptr(), _lib.ptr(seg_of_det), S, H,
               int(training), P[t + '0.weight'].data_ptr(), P[t + '0.bias'].data_ptr(), P[t + '1.weight'].data_ptr(),
               P[t + '1.bias'].data_ptr(), P[t + '3.weight'].data_ptr(), y_save.data_ptr(), mean.data_ptr(),
               rstd.data_ptr(), out_row.data_ptr(), d_hD.data_ptr() + 4 * H, ld, d_xdet.data_ptr() + 4, Ft,

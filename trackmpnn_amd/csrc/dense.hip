@@ -200,27 +200,31 @@ __global__ void k_bn_stats(const float* __restrict__ y, const int32_t* __restric
     rstd[(size_t)s * H + j] = rsqrtf(var + BN_EPS);
 }
 
-// running statistics: windows are seen one after another in the reference, so the momentum update
-// is applied segment by segment (unbiased variance), one thread per feature.  A segment that is L
-// places from the end carries the weight 0.1 * 0.9^L, so only the last 320 can reach an fp32 result
-// (0.9^320 = 2e-15): older ones, and the incoming running value, are dropped when S > 320.
-__global__ void k_bn_running(const float* __restrict__ mean, const float* __restrict__ rstd,
-                             const int32_t* __restrict__ seg_cnt, int S, int H, float* __restrict__ rm,
-                             float* __restrict__ rv) {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= H) return;
+// running statistics: windows are seen one after another in the reference, so the momentum update is
+// the EMA over segments in order: rm <- 0.9^S rm + sum_s 0.1 * 0.9^(S-1-s) mean_s (unbiased variance
+// likewise).  A segment L places from the end carries 0.1 * 0.9^L, so only the last 320 can reach an fp32
+// result (0.9^320 = 2e-15).  One 64-lane block per feature, lanes striding over those segments.
+__global__ __launch_bounds__(64) void k_bn_running(const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                   const int32_t* __restrict__ seg_cnt, int S, int H,
+                                                   float* __restrict__ rm, float* __restrict__ rv) {
+    const int j = blockIdx.x;
+    const int lane = threadIdx.x;
     const int s0 = S > 320 ? S - 320 : 0;
-    float m = s0 > 0 ? 0.f : rm[j], v = s0 > 0 ? 0.f : rv[j];
-#pragma unroll 8
-    for (int s = s0; s < S; ++s) {
+    float m = 0.f, v = 0.f;
+    for (int s = s0 + lane; s < S; s += 64) {
+        const float w = BN_MOMENTUM * powf(1.0f - BN_MOMENTUM, (float)(S - 1 - s));
         const float cnt = (float)seg_cnt[s];
         const float r = rstd[(size_t)s * H + j];
         const float var = 1.0f / (r * r) - BN_EPS;
-        m = (1.0f - BN_MOMENTUM) * m + BN_MOMENTUM * mean[(size_t)s * H + j];
-        v = (1.0f - BN_MOMENTUM) * v + BN_MOMENTUM * var * (cnt / (cnt - 1.0f));
+        m += w * mean[(size_t)s * H + j];
+        v += w * var * (cnt / (cnt - 1.0f));
     }
-    rm[j] = m;
-    rv[j] = v;
+    for (int off = 32; off >= 1; off >>= 1) { m += __shfl_xor(m, off); v += __shfl_xor(v, off); }
+    if (lane == 0) {
+        const float keep = s0 > 0 ? 0.f : powf(1.0f - BN_MOMENTUM, (float)S);
+        rm[j] = keep * rm[j] + m;
+        rv[j] = keep * rv[j] + v;
+    }
 }
 
 __device__ __forceinline__ int seg_of(const int32_t* __restrict__ seg_ptr, int S, int i) {
@@ -235,13 +239,14 @@ __device__ __forceinline__ int seg_of(const int32_t* __restrict__ seg_ptr, int S
 // yhat = (y - mean) * rstd ; a = relu(yhat * gamma + beta).  mean/rstd per segment (training) or
 // running (eval: seg_ptr == nullptr, mean/rstd hold one row).
 __global__ void k_bn_apply(const float* __restrict__ y, int nd, int H, const int32_t* __restrict__ seg_ptr, int S,
+                           const int32_t* __restrict__ seg_of_det,
                            const float* __restrict__ mean, const float* __restrict__ rstd,
                            const float* __restrict__ gamma, const float* __restrict__ beta,
                            float* __restrict__ yhat_out, float* __restrict__ a_out) {
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (size_t)nd * H) return;
     const int i = (int)(idx / H), j = (int)(idx % H);
-    const int s = seg_ptr ? seg_of(seg_ptr, S, i) : 0;
+    const int s = seg_ptr ? (seg_of_det ? seg_of_det[i] : seg_of(seg_ptr, S, i)) : 0;
     const float yh = (y[idx] - mean[(size_t)s * H + j]) * rstd[(size_t)s * H + j];
     if (yhat_out) yhat_out[idx] = yh;
     if (a_out) a_out[idx] = fmaxf(yh * gamma[j] + beta[j], 0.f);
@@ -289,6 +294,7 @@ __global__ void k_bn_bwd_seg(const float* __restrict__ dyhat, const float* __res
 // dy_i = rstd/cnt * (cnt*dyhat_i - s1 - yhat_i*s2)  (in place over dyhat)
 __global__ void k_bn_bwd_dy(float* __restrict__ dyhat, const float* __restrict__ yhat, int nd, int H,
                             const int32_t* __restrict__ seg_ptr, const int32_t* __restrict__ seg_cnt, int S,
+                            const int32_t* __restrict__ seg_of_det,
                             const float* __restrict__ rstd, const float* __restrict__ s1,
                             const float* __restrict__ s2, int training) {
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -298,7 +304,7 @@ __global__ void k_bn_bwd_dy(float* __restrict__ dyhat, const float* __restrict__
         dyhat[idx] *= rstd[j];
         return;
     }
-    const int s = seg_of(seg_ptr, S, i);
+    const int s = seg_of_det ? seg_of_det[i] : seg_of(seg_ptr, S, i);
     const float cnt = (float)seg_cnt[s];
     const size_t sj = (size_t)s * H + j;
     dyhat[idx] = rstd[sj] / cnt * (cnt * dyhat[idx] - s1[sj] - yhat[idx] * s2[sj]);
@@ -449,7 +455,7 @@ using namespace tmpnn;
 extern "C" {
 
 int tmpnn_input_bn_fwd(const float* xdet, int ld_x, int F, int nd, const int32_t* seg_ptr, const int32_t* seg_cnt,
-                       int S, int H, int training, const float* w1, const float* b1, const float* gamma,
+                       const int32_t* seg_of_det, int S, int H, int training, const float* w1, const float* b1, const float* gamma,
                        const float* beta, float* running_mean, float* running_var, const float* w2, const float* b2,
                        float* y_save, float* mean, float* rstd, float* ws_a, const int32_t* out_row, float* h_new,
                        int ld_h, tmpnn_stream stream) {
@@ -468,8 +474,8 @@ int tmpnn_input_bn_fwd(const float* xdet, int ld_x, int F, int nd, const int32_t
     if (training) {
         hipLaunchKernelGGL(k_bn_stats, dim3(S), dim3(H), 0, st, y_save, seg_ptr, seg_cnt, H, b1, mean, rstd);
         if ((rc = check_launch("bn_stats"))) return rc;
-        hipLaunchKernelGGL(k_bn_running, dim3(ceil_div(H, 64)), dim3(64), 0, st, mean, rstd, seg_cnt, S, H,
-                           running_mean, running_var);
+        hipLaunchKernelGGL(k_bn_running, dim3(H), dim3(64), 0, st, mean, rstd, seg_cnt, S, H, running_mean,
+                           running_var);
         if ((rc = check_launch("bn_running"))) return rc;
     } else {
         hipLaunchKernelGGL(k_running_to_stats, dim3(ceil_div(H, 64)), dim3(64), 0, st, running_mean, running_var, H,
@@ -478,14 +484,14 @@ int tmpnn_input_bn_fwd(const float* xdet, int ld_x, int F, int nd, const int32_t
     }
     if (nd == 0) return TMPNN_OK;
     hipLaunchKernelGGL(k_bn_apply, dim3(ceil_div((long)nd * H, 256)), dim3(256), 0, st, y_save, nd, H,
-                       training ? seg_ptr : nullptr, S, mean, rstd, gamma, beta, (float*)nullptr, ws_a);
+                       training ? seg_ptr : nullptr, S, seg_of_det, mean, rstd, gamma, beta, (float*)nullptr, ws_a);
     if ((rc = check_launch("bn_apply"))) return rc;
     GemmArgs g2{ws_a, H, 1, nullptr, nullptr, w2, 1, H, b2, h_new, ld_h, out_row, nd, H, H, 0};        // out = a W2^T + b2
     return launch_gemm(g2, st);
 }
 
 int tmpnn_input_bn_bwd(const float* xdet, int ld_x, int F, int nd, const int32_t* seg_ptr, const int32_t* seg_cnt,
-                       int S, int H, int training, const float* w1, const float* b1, const float* gamma,
+                       const int32_t* seg_of_det, int S, int H, int training, const float* w1, const float* b1, const float* gamma,
                        const float* beta, const float* w2, const float* y_save, const float* mean, const float* rstd,
                        const int32_t* out_row, const float* d_h, int ld_dh, float* d_xdet, int ld_dx, float* d_xzero,
                        float* dw1, float* db1, float* dgamma, float* dbeta, float* dw2, float* db2, float* ws,
@@ -514,8 +520,8 @@ int tmpnn_input_bn_bwd(const float* xdet, int ld_x, int F, int nd, const int32_t
     int rc;
     hipLaunchKernelGGL(k_gather_rows, dim3(gridE), dim3(256), 0, st, d_h, (long)ld_dh, out_row, nd, H, B0);
     if ((rc = check_launch("gather_rows"))) return rc;
-    hipLaunchKernelGGL(k_bn_apply, dim3(gridE), dim3(256), 0, st, y_save, nd, H, training ? seg_ptr : nullptr, S, mean,
-                       rstd, gamma, beta, B1, B2);
+    hipLaunchKernelGGL(k_bn_apply, dim3(gridE), dim3(256), 0, st, y_save, nd, H, training ? seg_ptr : nullptr, S,
+                       seg_of_det, mean, rstd, gamma, beta, B1, B2);
     if ((rc = check_launch("bn_apply"))) return rc;
     // dW2 += d_out^T a ; db2 += colsum(d_out)
     {
@@ -537,8 +543,8 @@ int tmpnn_input_bn_bwd(const float* xdet, int ld_x, int F, int nd, const int32_t
         hipLaunchKernelGGL(k_bn_bwd_seg, dim3(S), dim3(H), 0, st, B2, B1, seg_ptr, seg_cnt, H, b1, mean, rstd, s1, s2);
         if ((rc = check_launch("bn_bwd_seg"))) return rc;
     }
-    hipLaunchKernelGGL(k_bn_bwd_dy, dim3(gridE), dim3(256), 0, st, B2, B1, nd, H, seg_ptr, seg_cnt, S, rstd, s1, s2,
-                       training);
+    hipLaunchKernelGGL(k_bn_bwd_dy, dim3(gridE), dim3(256), 0, st, B2, B1, nd, H, seg_ptr, seg_cnt, S, seg_of_det, rstd,
+                       s1, s2, training);
     if ((rc = check_launch("bn_bwd_dy"))) return rc;
     // now B2 = dy (det rows)
     // dW1 += dy^T x ; db1 += colsum(dy) (+ zero-row part below) ; d_xdet = dy W1

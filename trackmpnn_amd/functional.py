@@ -136,7 +136,7 @@ def mp_forward(spec: ModelSpec, plan: CallPlan, x: torch.Tensor, h_in: Optional[
             mean = torch.empty((SS, H), **opts)
             rstd = torch.empty((SS, H), **opts)
             _lib.call('tmpnn_input_bn_fwd', xdet.data_ptr() + 4 * f0, spec.F_total, F, nd,
-                      plan.seg_ptr.data_ptr(), plan.seg_cnt.data_ptr(), S, H, int(training),
+                      plan.seg_ptr.data_ptr(), plan.seg_cnt.data_ptr(), _lib.ptr(plan.seg_of_det), S, H, int(training),
                       P[t + '0.weight'].data_ptr(), P[t + '0.bias'].data_ptr(),
                       P[t + '1.weight'].data_ptr(), P[t + '1.bias'].data_ptr(),
                       buffers[t + '1.running_mean'].data_ptr(), buffers[t + '1.running_var'].data_ptr(),
@@ -243,7 +243,14 @@ def mp_backward(spec: ModelSpec, plan: CallPlan, saved: dict, P: Dict[str, torch
     dev = h_cat.device
     st = _stream()
     opts = dict(dtype=torch.float32, device=dev)
-    grads = {name: torch.zeros_like(P[name], dtype=torch.float32) for name in spec.param_names()}
+    # one zero-filled buffer for every parameter gradient of this call (the kernels accumulate with +=)
+    names = spec.param_names()
+    sizes = [P[nm].numel() for nm in names]
+    offs = [0]
+    for sz in sizes:
+        offs.append(offs[-1] + ((sz + 63) // 64) * 64)          # 256-byte aligned slices
+    flat = torch.zeros((offs[-1],), **opts)
+    grads = {nm: flat[o:o + sz].view(P[nm].shape) for nm, o, sz in zip(names, offs, sizes)}
 
     # heads (track_mpnn.py:72-75): dy = d_logits + d_scores * s(1-s); its contribution dy * w_type to the
     # gradient of h_out is folded into the GRU backward kernels (never materialised)
@@ -341,7 +348,7 @@ def mp_backward(spec: ModelSpec, plan: CallPlan, saved: dict, P: Dict[str, torch
             # d_xzero is [S][F] per group: write into a per-group buffer, then place it
             dz_g = torch.empty((max(S, 1), F), **opts) if need_x else None
             _lib.call('tmpnn_input_bn_bwd', xdet.data_ptr() + 4 * f0, Ft, F, nd,
-                      plan.seg_ptr.data_ptr(), plan.seg_cnt.data_ptr(), S, H, int(training),
+                      plan.seg_ptr.data_ptr(), plan.seg_cnt.data_ptr(), _lib.ptr(plan.seg_of_det), S, H, int(training),
                       P[t + '0.weight'].data_ptr(), P[t + '0.bias'].data_ptr(),
                       P[t + '1.weight'].data_ptr(), P[t + '1.bias'].data_ptr(), P[t + '3.weight'].data_ptr(),
                       saved['y_save'][gi].data_ptr(), saved['mean'][gi].data_ptr(), saved['rstd'][gi].data_ptr(),

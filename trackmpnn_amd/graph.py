@@ -292,6 +292,7 @@ class CallPlan:
     seg_cnt: torch.Tensor         # int32 [S]   ALL new rows of window s
     seg_of_new: torch.Tensor      # int64 [n_new] window of each new row
     min_seg_cnt: int
+    seg_of_det: Optional[torch.Tensor] = None   # int32 [nd] window of each new det row
 
     @property
     def S(self) -> int:
@@ -300,7 +301,8 @@ class CallPlan:
     def to(self, device) -> 'CallPlan':
         return CallPlan(self.graph.to(device), self.n_new, self.new_det_local.to(device),
                         self.new_det_row.to(device), self.seg_ptr.to(device), self.seg_cnt.to(device),
-                        self.seg_of_new.to(device), self.min_seg_cnt)
+                        self.seg_of_new.to(device), self.min_seg_cnt,
+                        None if self.seg_of_det is None else self.seg_of_det.to(device))
 
 
 def plan_single(graph: FrameGraph, n_new: int) -> CallPlan:
@@ -313,7 +315,8 @@ def plan_single(graph: FrameGraph, n_new: int) -> CallPlan:
     return CallPlan(graph=graph, n_new=n_new, new_det_local=loc, new_det_row=(loc + (N - n_new)).to(torch.int32),
                     seg_ptr=torch.tensor([0, nd], dtype=torch.int32, device=dev),
                     seg_cnt=torch.tensor([n_new], dtype=torch.int32, device=dev),
-                    seg_of_new=torch.zeros(n_new, dtype=torch.long, device=dev), min_seg_cnt=n_new)
+                    seg_of_new=torch.zeros(n_new, dtype=torch.long, device=dev), min_seg_cnt=n_new,
+                    seg_of_det=torch.zeros(nd, dtype=torch.int32, device=dev))
 
 
 def batch_windows(windows: Sequence[Sequence[WindowCall]], static: bool = False,
@@ -377,6 +380,7 @@ def batch_windows(windows: Sequence[Sequence[WindowCall]], static: bool = False,
             seg_ptr=torch.from_numpy(seg_ptr).to(device),
             seg_cnt=torch.from_numpy(np.asarray(seg_cnt, dtype=np.int32)).to(device),
             seg_of_new=torch.from_numpy(np.concatenate(seg_ids) if seg_ids else np.zeros(0, np.int64)).to(device),
-            min_seg_cnt=int(min(seg_cnt)) if seg_cnt else 0))
+            min_seg_cnt=int(min(seg_cnt)) if seg_cnt else 0,
+            seg_of_det=torch.from_numpy((np.concatenate(seg_ids)[loc] if seg_ids else np.zeros(0)).astype(np.int32)).to(device)))
         det_refs.append(np.concatenate(refs) if refs else np.zeros((0, 2), np.int64))
     return plans, det_refs
