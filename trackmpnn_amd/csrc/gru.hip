@@ -445,21 +445,35 @@ __device__ __forceinline__ void stage_rows(int row, int lane, int* orow4) {
 // raw A-operand slice of one 32-wide k tile (16 floats per lane; the diff message needs two rows)
 struct ATile { float u[16]; float w[16]; };
 
+// row ids of one work item for this lane: list position, state row, and the two endpoint ids
+// (XMODE 1/2: state rows of src/dst; XMODE 3: det indices into the projected buffer)
+struct TileIdx { int li, row, s, d; };
+
+template <int XMODE>
+__device__ __forceinline__ TileIdx tile_idx(const GruFwdArgs& a, int r0, int c) {
+    TileIdx t;
+    t.li = min(r0 + c, a.R - 1);
+    t.row = a.rows[t.li];
+    t.s = (XMODE != 0) ? a.src[t.li] : 0;
+    t.d = (XMODE != 0) ? a.dst[t.li] : 0;
+    return t;
+}
+
 template <int H, int IN, int XMODE>
-__device__ __forceinline__ void a_issue(const GruFwdArgs& a, int kt, int li, int row, int half, ATile& t) {
+__device__ __forceinline__ void a_issue(const GruFwdArgs& a, int kt, const TileIdx& ix, int half, ATile& t) {
     constexpr int NKX = (XMODE == 3) ? 0 : IN / 32;
     if (kt < NKX) {
         const int f0 = kt * 32 + half * 16;
-        if (XMODE == 0) load16(a.msg + (size_t)(a.msg_compact ? li : row) * a.ld_msg + f0, t.u);
+        if (XMODE == 0) load16(a.msg + (size_t)(a.msg_compact ? ix.li : ix.row) * a.ld_msg + f0, t.u);
         else if (XMODE == 1) {
-            load16(a.h + (size_t)a.src[li] * a.ld_h + f0, t.u);
-            load16(a.h + (size_t)a.dst[li] * a.ld_h + f0, t.w);
+            load16(a.h + (size_t)ix.s * a.ld_h + f0, t.u);
+            load16(a.h + (size_t)ix.d * a.ld_h + f0, t.w);
         } else {
-            if (f0 < H) load16(a.h + (size_t)a.src[li] * a.ld_h + f0, t.u);
-            else        load16(a.h + (size_t)a.dst[li] * a.ld_h + (f0 - H), t.u);
+            if (f0 < H) load16(a.h + (size_t)ix.s * a.ld_h + f0, t.u);
+            else        load16(a.h + (size_t)ix.d * a.ld_h + (f0 - H), t.u);
         }
     } else {
-        load16(a.h + (size_t)row * a.ld_h + (kt - NKX) * 32 + half * 16, t.u);
+        load16(a.h + (size_t)ix.row * a.ld_h + (kt - NKX) * 32 + half * 16, t.u);
     }
 }
 
@@ -501,35 +515,46 @@ __global__ __launch_bounds__(WPB * 64) void k_gru_fwd_lds(GruFwdArgs a, int ntil
         else if (grp == 2) __builtin_amdgcn_s_setprio(1);
         // (a fourth group, if any, stays at priority 0)
     }
-    const int items_total = ntiles * RTB * CW;                 // ntiles = passes of RTB row tiles
+    const int items_total = ((a.R + 31) / 32) * CW;            // (32-row tile, column wave) pairs
     const int per_block = (items_total + gridDim.x - 1) / gridDim.x;
     const int item_lo = blockIdx.x * per_block;
     const int item_hi = min(items_total, item_lo + per_block);
+    (void)ntiles;
+
+    // Items are software pipelined ACROSS tiles: while a tile's MFMAs run, the next item's row ids are
+    // already loaded, and its first operand slice is requested before this tile's epilogue -- a global load
+    // takes microseconds under load, longer than a tile's matrix work.
+    int item = 0;
+    if (lane == 0) item = atomicAdd(next_item, 1);
+    item = __builtin_amdgcn_readfirstlane(item) + item_lo;
+    if (item >= item_hi) return;
+    int cw0 = (item % CW) * CT * 32;                           // first output column of this item
+    int r0 = (item / CW) * 32;
+    TileIdx ix = tile_idx<XMODE>(a, r0, c);
+    ATile cur, nxt;
+    a_issue<H, IN, XMODE>(a, 0, ix, half, cur);
 
     for (;;) {
-        int item = 0;
-        if (lane == 0) item = atomicAdd(next_item, 1);
-        item = __builtin_amdgcn_readfirstlane(item) + item_lo;
-        if (item >= item_hi) break;
-        const int cw0 = (item % CW) * CT * 32;                 // first output column of this item
-        const int r0 = (item / CW) * 32;
-        if (r0 >= a.R) continue;
-        const int li = min(r0 + c, a.R - 1);
-        const int row = a.rows[li];
+        int nitem = 0;
+        if (lane == 0) nitem = atomicAdd(next_item, 1);
+        nitem = __builtin_amdgcn_readfirstlane(nitem) + item_lo;
+        const bool nvalid = nitem < item_hi;
+        const int ncw0 = (nitem % CW) * CT * 32;
+        const int nr0 = nvalid ? (nitem / CW) * 32 : r0;
+        const TileIdx nix = tile_idx<XMODE>(a, nr0, c);
+        const int li = ix.li, row = ix.row;
         f32x16 acc_r[CT], acc_z[CT], acc_in[CT], acc_hn[CT];
 #pragma unroll
         for (int t = 0; t < CT; ++t)
 #pragma unroll
             for (int i = 0; i < 16; ++i) { acc_r[t][i] = 0.f; acc_z[t][i] = 0.f; acc_in[t][i] = 0.f; acc_hn[t][i] = 0.f; }
-        // k tiles are software pipelined: the rows of tile kt+1 are requested before the MFMAs of tile kt
-        ATile cur, nxt;
-        a_issue<H, IN, XMODE>(a, 0, li, row, half, cur);
 #pragma unroll
         for (int kt = 0; kt < NK; ++kt) {
             float av[16];
 #pragma unroll
             for (int i = 0; i < 16; ++i) av[i] = (XMODE == 1 && kt < NKX) ? cur.u[i] - cur.w[i] : cur.u[i];
-            if (kt + 1 < NK) a_issue<H, IN, XMODE>(a, kt + 1, li, row, half, nxt);
+            if (kt + 1 < NK) a_issue<H, IN, XMODE>(a, kt + 1, ix, half, nxt);
+            else if (nvalid) a_issue<H, IN, XMODE>(a, 0, nix, half, nxt);      // next item's first slice
             __builtin_amdgcn_sched_barrier(0);
             const bool xpart = kt < NKX;
             const float* b0 = (xpart ? sWih + (kt * 32 + half * 16) * H3 : sWhh + ((kt - NKX) * 32 + half * 16) * H3) + cw0 + c;
@@ -595,8 +620,8 @@ __global__ __launch_bounds__(WPB * 64) void k_gru_fwd_lds(GruFwdArgs a, int ntil
                 const float hp[4] = {hp4[t][q].x, hp4[t][q].y, hp4[t][q].z, hp4[t][q].w};
                 float xr[4] = {0.f, 0.f, 0.f, 0.f}, xz[4] = {0.f, 0.f, 0.f, 0.f}, xn[4] = {0.f, 0.f, 0.f, 0.f};
                 if (XMODE == 3) {
-                    const float* ps = a.msg + (size_t)a.src[li] * a.ld_msg + col;
-                    const float* pd = a.msg + (size_t)a.dst[li] * a.ld_msg + col;
+                    const float* ps = a.msg + (size_t)ix.s * a.ld_msg + col;
+                    const float* pd = a.msg + (size_t)ix.d * a.ld_msg + col;
                     const float4 sr = *reinterpret_cast<const float4*>(ps), dr = *reinterpret_cast<const float4*>(pd);
                     const float4 sz = *reinterpret_cast<const float4*>(ps + H), dz = *reinterpret_cast<const float4*>(pd + H);
                     const float4 sn = *reinterpret_cast<const float4*>(ps + 2 * H), dn = *reinterpret_cast<const float4*>(pd + 2 * H);
@@ -624,6 +649,8 @@ __global__ __launch_bounds__(WPB * 64) void k_gru_fwd_lds(GruFwdArgs a, int ntil
                 stage_store32<true>(stg, c, half, lane, acc_hn[t], a.gates + 3 * a.gate_plane, H, colt, row, r0, a.R);
             }
         }
+        if (!nvalid) break;
+        cw0 = ncw0; r0 = nr0; ix = nix;
     }
 }
 
@@ -1059,10 +1086,10 @@ int tmpnn_gru_fwd(const int32_t* rows, int R, int xmode, const int32_t* src, con
         // weights resident in LDS, persistent 8-wave blocks (see k_gru_fwd_lds)
         // H = 64: 12 waves per block (3 per SIMD), two per 32-row tile (one per 32-column half) -> 192 rows per pass;
         // H = 32: 8 waves, one per row tile
-        const int rows_per_pass = (H == 64 && xmode != 3) ? 192 : 256;
+        const int rows_per_pass = (H == 64) ? 192 : 256;
         const int ntiles = ceil_div(R, rows_per_pass);
-        dim3 pgrid(ntiles < 256 ? ntiles : 256), pblock(H == 64 ? (xmode == 3 ? 1024 : 768) : 512);
-        const int wpb = (H == 64) ? (xmode == 3 ? 16 : 12) : 8;
+        dim3 pgrid(ntiles < 256 ? ntiles : 256), pblock(H == 64 ? 768 : 512);
+        const int wpb = (H == 64) ? 12 : 8;
         const size_t shm = sizeof(float) * ((size_t)((xmode == 3 ? 0 : IN) + H) * 3 * H + (size_t)wpb * 32 * STG_LD + 4);
         if (shm > 160 * 1024) goto generic;      // e.g. concat at H = 64: the weights alone take 144 KiB
 #define LL(HH, II, X, CC, WW)                                                                                \
@@ -1071,7 +1098,7 @@ int tmpnn_gru_fwd(const int32_t* rows, int R, int xmode, const int32_t* src, con
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);                     \
         hipLaunchKernelGGL((k_gru_fwd_lds<HH, II, X, CC, WW>), pgrid, pblock, shm, st, a, ntiles);           \
     } while (0)
-        if (H == 64) { if (xmode == 0 && IN == 64) LL(64, 64, 0, 1, 12); else if (xmode == 1) LL(64, 64, 1, 1, 12); else if (xmode == 2) LL(64, 128, 2, 1, 12); else if (xmode == 3) LL(64, 64, 3, 1, 16); else goto generic; }
+        if (H == 64) { if (xmode == 0 && IN == 64) LL(64, 64, 0, 1, 12); else if (xmode == 1) LL(64, 64, 1, 1, 12); else if (xmode == 2) LL(64, 128, 2, 1, 12); else if (xmode == 3) LL(64, 64, 3, 1, 12); else goto generic; }
         else         { if (xmode == 0 && IN == 32) LL(32, 32, 0, 1, 8); else if (xmode == 1) LL(32, 32, 1, 1, 8); else if (xmode == 2) LL(32, 64, 2, 1, 8); else if (xmode == 3) LL(32, 32, 3, 1, 8); else goto generic; }
 #undef LL
         return check_launch("gru_fwd_lds");
