@@ -1,9 +1,14 @@
 """Copy the rocprofv3 summaries of the last GPU run (gpurun_out/r01_*) into profiles/ (tracked)."""
 import csv, glob, json, collections, shutil, os, sys
+
+
+def newest(pattern):
+    return max(glob.glob(pattern), key=os.path.getmtime)
+
 tag = sys.argv[1] if len(sys.argv) > 1 else 'r01'
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 os.chdir(root)
-src = glob.glob(f'gpurun_out/{tag}_stats/runc/*_kernel_stats.csv')[0]
+src = newest(f'gpurun_out/{tag}_stats/runc/*_kernel_stats.csv')
 shutil.copy(src, f'profiles/{tag}_bench_kernel_stats.csv')
 rows = list(csv.DictReader(open(src)))
 tot = sum(float(r['TotalDurationNs']) for r in rows)
@@ -17,7 +22,7 @@ with open(f'profiles/{tag}_bench_kernel_stats.md', 'w') as f:
 line = [l for l in open(f'gpurun_out/{tag}_bench.log', errors='ignore') if l.startswith('{"metric"')][0]
 open(f'profiles/{tag}_bench_line.json', 'w').write(line)
 def pmc(path, name):
-    rows = list(csv.DictReader(open(glob.glob(path)[0])))
+    rows = list(csv.DictReader(open(newest(path))))
     agg = collections.defaultdict(list)
     for r in rows:
         if r['Counter_Name'] == name:
