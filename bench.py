@@ -111,7 +111,7 @@ def stage_profile(model, plan, H):
                   proj.data_ptr(), 3 * H, st)
         _lib.call('tmpnn_gru_fwd', g.edge_row.data_ptr(), E, 3, g.src_pos.data_ptr(), g.dst_pos.data_ptr(),
                   proj.data_ptr(), 3 * H, 0, H, h.data_ptr(), H, H, None, whh_t.data_ptr(), bih.data_ptr(),
-                  bhh.data_ptr(), out.data_ptr(), H, gates.data_ptr(), N * H, st)
+                  bhh.data_ptr(), out.data_ptr(), H, gates.data_ptr(), N * H, None, None, 0, st)
 
     def gru_bwd_data():
         _lib.call('tmpnn_gru_bwd_data', g.edge_row.data_ptr(), E, H, h.data_ptr(), H, H, wih.data_ptr(), whh.data_ptr(),

@@ -122,11 +122,18 @@ int tmpnn_att_bwd(const tmpnn_graph* g, const int32_t* pos, const float* h, int 
  * so running it once with rows = edge_row and once with rows = det_row performs the merge in
  * place.  Weights are passed TRANSPOSED (wih_t [IN][3H], whh_t [H][3H], see tmpnn_transpose);
  * gate order r,z,n.  gates: NULL or 4 planes [4][gate_plane] of row-indexed [N][H] floats
- * (r, z, n, W_hn h + b_hn) saved for the backward. */
+ * (r, z, n, W_hn h + b_hn) saved for the backward.
+ * Fused output head (row J): if logit_part != NULL, plane p of logit_part (p < tmpnn_gru_fwd_head_parts(),
+ * plane stride part_stride >= N floats) receives at `row` the partial dot product of h_out[row] with
+ * w_head[0:H] over the p-th 32-column slice; tmpnn_heads_finish sums the planes of all groups, adds the bias
+ * and applies the sigmoid.  tmpnn_gru_fwd_head_parts() == 0 means the fused head is unavailable for that
+ * shape (use tmpnn_heads_fwd). */
+int tmpnn_gru_fwd_head_parts(int H, int IN, int xmode);
 int tmpnn_gru_fwd(const int32_t* rows, int R, int xmode, const int32_t* src, const int32_t* dst,
                   const float* msg, int ld_msg, int msg_compact, int IN, const float* h, int ld_h, int H,
                   const float* wih_t, const float* whh_t, const float* b_ih, const float* b_hh,
-                  float* h_out, int ld_out, float* gates, size_t gate_plane, tmpnn_stream stream);
+                  float* h_out, int ld_out, float* gates, size_t gate_plane,
+                  const float* w_head, float* logit_part, size_t part_stride, tmpnn_stream stream);
 /* Upstream gradient of both backward entry points: dh[row] = d_hout[row] (NULL = 0) + dy[row] * w_head
  * (dy NULL = no head term).  dy [N] is the gradient of the logits (tmpnn_heads_bwd's dy_out) and
  * w_head [H] the slice of the output head (w_node for det rows, w_edge for edge rows) of this group.
@@ -204,6 +211,9 @@ int tmpnn_input_bn_bwd(const float* xdet, int ld_x, int F, int nd, const int32_t
 int tmpnn_heads_fwd(const float* h, int ld_h, int C, int N, const uint8_t* is_edge,
                     const float* w_node, const float* b_node, const float* w_edge, const float* b_edge,
                     float* logits, float* scores, tmpnn_stream stream);
+/* logits[i] = sum_p parts[p*part_stride + i] + (is_edge[i] ? b_edge : b_node) ; scores = sigmoid(logits). */
+int tmpnn_heads_finish(const float* parts, size_t part_stride, int nparts, int N, const uint8_t* is_edge,
+                       const float* b_node, const float* b_edge, float* logits, float* scores, tmpnn_stream stream);
 /* dy = d_logits + d_scores * s(1-s) (either may be NULL).  dy_out [N] (may be NULL) receives dy;
  * d_h (may be NULL): d_h[i] (=|+=) dy[i] * w_type(i); dw_node/dw_edge [C], db_node/db_edge [1]
  * accumulated (+=).  ws: tmpnn_heads_bwd_ws(N, C) bytes. */

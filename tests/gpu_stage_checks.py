@@ -123,7 +123,7 @@ def check_gru(H, xmode, g, gd, rows_kind='edge'):
     _lib.call('tmpnn_gru_fwd', rowsD.data_ptr(), R, xmode, gd.src.data_ptr() if xmode else None,
               gd.dst.data_ptr() if xmode else None, msgD.data_ptr() if xmode == 0 else None, IN, 1, IN,
               hD.data_ptr() + 4 * H, ld, H, wih_t.data_ptr(), whh_t.data_ptr(), bihD.data_ptr(), bhhD.data_ptr(),
-              outD.data_ptr() + 4 * H, ld, gates.data_ptr(), g.N * H, st())
+              outD.data_ptr() + 4 * H, ld, gates.data_ptr(), g.N * H, None, None, 0, st())
     res = {}
     res['fwd'] = (outD.cpu()[rows, H:2 * H] - out.detach()).abs().max().item()
     gc = gates.cpu()
@@ -132,6 +132,17 @@ def check_gru(H, xmode, g, gd, rows_kind='edge'):
     other[rows] = False
     res['untouched'] = outD.cpu()[other].abs().max().item() if other.any() else 0.0
     res['untouched'] = max(res['untouched'], outD.cpu()[:, :H].abs().max().item())
+    nparts = _lib.load().tmpnn_gru_fwd_head_parts(H, IN, xmode)
+    if nparts > 0:
+        wv_h = torch.randn(H)
+        wv_hD = d(wv_h)
+        parts = torch.zeros(nparts, g.N, device=DEV)
+        outH = torch.zeros(g.N, ld, device=DEV)
+        _lib.call('tmpnn_gru_fwd', rowsD.data_ptr(), R, xmode, gd.src.data_ptr() if xmode else None,
+                  gd.dst.data_ptr() if xmode else None, msgD.data_ptr() if xmode == 0 else None, IN, 1, IN,
+                  hD.data_ptr() + 4 * H, ld, H, wih_t.data_ptr(), whh_t.data_ptr(), bihD.data_ptr(), bhhD.data_ptr(),
+                  outH.data_ptr() + 4 * H, ld, None, 0, wv_hD.data_ptr(), parts.data_ptr(), g.N, st())
+        res['fused_head'] = (parts.cpu().sum(0)[rows] - out.detach() @ wv_h).abs().max().item()
     if xmode == 1 and H <= 64:
         # pre-projected variant (xmode 3): P = h[dets] @ W_ih^T, then gi = P[src] - P[dst]
         dr = idx(g.det_row)
@@ -143,7 +154,7 @@ def check_gru(H, xmode, g, gd, rows_kind='edge'):
         gates3 = torch.zeros(4, g.N, H, device=DEV)
         _lib.call('tmpnn_gru_fwd', rowsD.data_ptr(), R, 3, gd.src_pos.data_ptr(), gd.dst_pos.data_ptr(), proj.data_ptr(),
                   3 * H + 4, 0, IN, hD.data_ptr() + 4 * H, ld, H, None, whh_t.data_ptr(), bihD.data_ptr(), bhhD.data_ptr(),
-                  out3.data_ptr() + 4 * H, ld, gates3.data_ptr(), g.N * H, st())
+                  out3.data_ptr() + 4 * H, ld, gates3.data_ptr(), g.N * H, None, None, 0, st())
         res['fwd_proj'] = (out3.cpu()[rows, H:2 * H] - out.detach()).abs().max().item()
         g3 = gates3.cpu()
         res['gates_proj'] = max((g3[i][rows] - t.detach()).abs().max().item() for i, t in enumerate((r, z, n, hn)))

@@ -39,10 +39,11 @@ def test_argument_validation_needs_no_gpu(lib):
     rc = lib.tmpnn_segsum_fwd(ctypes.byref(g), None, 64, None, 64, 48, 0, 0, None)
     assert rc == -1
     rc = lib.tmpnn_gru_fwd(None, 4, 1, None, None, None, 0, 0, 64, None, 64, 48, None, None, None, None, None, 64,
-                           None, 0, None)
+                           None, 0, None, None, 0, None)
     assert rc == -1 and b'unsupported H' in lib.tmpnn_last_error()
     assert lib.tmpnn_gru_bwd_weights_ws(1000, 64, 64) > 0
     assert lib.tmpnn_heads_bwd_ws(1000, 64) > 0
+    assert lib.tmpnn_gru_fwd_head_parts(64, 64, 3) == 2 and lib.tmpnn_gru_fwd_head_parts(256, 256, 1) == 0
 
 
 def test_cpu_tensors_fail_loudly():

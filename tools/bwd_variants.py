@@ -15,7 +15,7 @@ wih_t, whh_t = wih.t().contiguous(), whh.t().contiguous()
 bih, bhh = P[f+'edge_gru.bias_ih'].detach(), P[f+'edge_gru.bias_hh'].detach()
 dout = torch.randn(N, H, device=dev); dmsg = torch.empty(N, H, device=dev); dh = torch.empty(N, H, device=dev)
 dyv = torch.randn(N, device=dev); w_head = torch.randn(H, device=dev)
-_lib.call('tmpnn_gru_fwd', g.edge_row.data_ptr(), E, 1, g.src.data_ptr(), g.dst.data_ptr(), None, 0, 0, H, h.data_ptr(), H, H, wih_t.data_ptr(), whh_t.data_ptr(), bih.data_ptr(), bhh.data_ptr(), out.data_ptr(), H, gates.data_ptr(), N*H, st)
+_lib.call('tmpnn_gru_fwd', g.edge_row.data_ptr(), E, 1, g.src.data_ptr(), g.dst.data_ptr(), None, 0, 0, H, h.data_ptr(), H, H, wih_t.data_ptr(), whh_t.data_ptr(), bih.data_ptr(), bhh.data_ptr(), out.data_ptr(), H, gates.data_ptr(), N*H, None, None, 0, st)
 def mk(dho, dy, fuse):
     def fn():
         _lib.call('tmpnn_gru_bwd_data', g.edge_row.data_ptr(), E, H, h.data_ptr(), H, H, wih.data_ptr(), whh.data_ptr(),

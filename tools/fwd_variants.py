@@ -18,7 +18,7 @@ def mk(save, xmode):
     def fn():
         _lib.call('tmpnn_gru_fwd', g.edge_row.data_ptr(), E, xmode, g.src.data_ptr(), g.dst.data_ptr(), msg.data_ptr() if xmode == 0 else None, H, 1, H,
                   h.data_ptr(), H, H, wih_t.data_ptr(), whh_t.data_ptr(), bih.data_ptr(), bhh.data_ptr(), out.data_ptr(), H,
-                  gates.data_ptr() if save else None, N*H, st)
+                  gates.data_ptr() if save else None, N*H, None, None, 0, st)
     return fn
 for name, a in (('diff+gates', (1, 1)), ('diff nogates', (0, 1)), ('buf+gates', (1, 0)), ('buf nogates', (0, 0))):
     t = bench.time_stage(mk(*a)); print(name, round(t, 3), 'ms', round(12*H*H*E/t/1e9, 1), 'TF', flush=True)
@@ -29,7 +29,7 @@ def mk3(save):
     def fn():
         _lib.call('tmpnn_gru_fwd', g.edge_row.data_ptr(), E, 3, g.src_pos.data_ptr(), g.dst_pos.data_ptr(), proj.data_ptr(), 3*H, 0, H,
                   h.data_ptr(), H, H, None, whh_t.data_ptr(), bih.data_ptr(), bhh.data_ptr(), out.data_ptr(), H,
-                  gates.data_ptr() if save else None, N*H, st)
+                  gates.data_ptr() if save else None, N*H, None, None, 0, st)
     return fn
 print('rows_linear (P)', round(bench.time_stage(projk), 3), 'ms', flush=True)
 for name, a in (('proj+gates', 1), ('proj nogates', 0)):
@@ -40,7 +40,7 @@ def mk2(save):
     def fn():
         _lib.call('tmpnn_gru_fwd', rows_small.data_ptr(), E, 0, None, None, msg.data_ptr(), H, 1, H,
                   h.data_ptr(), H, H, wih_t.data_ptr(), whh_t.data_ptr(), bih.data_ptr(), bhh.data_ptr(), out.data_ptr(), H,
-                  gates.data_ptr() if save else None, N*H, st)
+                  gates.data_ptr() if save else None, N*H, None, None, 0, st)
     return fn
 for name, a in (('L2-resident buf+gates', 1), ('L2-resident buf nogates', 0)):
     t = bench.time_stage(mk2(a)); print(name, round(t, 3), 'ms', round(12*H*H*E/t/1e9, 1), 'TF', flush=True)

@@ -367,6 +367,19 @@ __global__ __launch_bounds__(256) void k_heads_fwd(const float* __restrict__ h, 
     }
 }
 
+// logits[i] = sum_p parts[p][i] + b_type(i) ; scores = sigmoid   (finishes the head fused into tmpnn_gru_fwd)
+__global__ void k_heads_finish(const float* __restrict__ parts, size_t stride, int nparts, int N,
+                               const uint8_t* __restrict__ is_edge, const float* __restrict__ b_node,
+                               const float* __restrict__ b_edge, float* __restrict__ logits,
+                               float* __restrict__ scores) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    float y = is_edge[i] ? b_edge[0] : b_node[0];
+    for (int p = 0; p < nparts; ++p) y += parts[(size_t)p * stride + i];
+    logits[i] = y;
+    scores[i] = 1.0f / (1.0f + expf(-y));
+}
+
 // d_h[i] (+)= dy_i * w_type ; per-block partial dw_node/dw_edge [C], db_node, db_edge
 // block = 256 threads: cpt = C/4 threads per row (float4), slots = 256/cpt rows per pass.
 // partial layout per block: [2][C] then [2]
@@ -600,6 +613,16 @@ int tmpnn_heads_fwd(const float* h, int ld_h, int C, int N, const uint8_t* is_ed
     hipLaunchKernelGGL(k_heads_fwd, dim3((int)b), dim3(256), 0, as_stream(stream), h, ld_h, C, N, is_edge, w_node,
                        b_node, w_edge, b_edge, logits, scores);
     return check_launch("heads_fwd");
+}
+
+int tmpnn_heads_finish(const float* parts, size_t part_stride, int nparts, int N, const uint8_t* is_edge,
+                       const float* b_node, const float* b_edge, float* logits, float* scores, tmpnn_stream stream) {
+    TM_REQUIRE(nparts > 0 && N >= 0, "heads_finish: nparts=%d N=%d", nparts, N);
+    if (N == 0) return TMPNN_OK;
+    TM_REQUIRE(parts && is_edge && b_node && b_edge && logits && scores && part_stride >= (size_t)N, "heads_finish: null pointer");
+    hipLaunchKernelGGL(k_heads_finish, dim3(ceil_div(N, 256)), dim3(256), 0, as_stream(stream), parts, part_stride, nparts, N,
+                       is_edge, b_node, b_edge, logits, scores);
+    return check_launch("heads_finish");
 }
 
 size_t tmpnn_heads_bwd_ws(int N, int C) {

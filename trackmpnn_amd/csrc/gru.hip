@@ -99,6 +99,8 @@ struct GruFwdArgs {
     const float* wih_t; const float* whh_t; const float* b_ih; const float* b_hh;
     float* h_out; int ld_out;
     float* gates; size_t gate_plane;
+    // optional fused output head (track_mpnn.py:73): logit_part[cw][row] = w_head[cols of column wave cw] . h_out[row]
+    const float* w_head; float* logit_part; size_t part_stride;
 };
 
 // 16 floats of x for list position li at feature offset f0 (multiple of 16)
@@ -641,6 +643,16 @@ __global__ __launch_bounds__(WPB * 64) void k_gru_fwd_lds(GruFwdArgs a, int ntil
                 }
             }
             const int colt = cw0 + t * 32;
+            if (a.logit_part) {
+                float p = 0.f;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4 w = *reinterpret_cast<const float4*>(a.w_head + colt + 8 * q + 4 * half);
+                    p += outv[4 * q] * w.x + outv[4 * q + 1] * w.y + outv[4 * q + 2] * w.z + outv[4 * q + 3] * w.w;
+                }
+                p += __shfl_xor(p, 32);
+                if (half == 0 && r0 + c < a.R) a.logit_part[(size_t)(colt / 32) * a.part_stride + row] = p;
+            }
             stage_store32(stg, c, half, lane, outv, a.h_out, a.ld_out, colt, row, r0, a.R);
             if (a.gates) {
                 stage_store32<true>(stg, c, half, lane, acc_r[t], a.gates, H, colt, row, r0, a.R);
@@ -1060,10 +1072,18 @@ using namespace tmpnn;
 
 extern "C" {
 
+int tmpnn_gru_fwd_head_parts(int H, int IN, int xmode) {
+    // column waves per row tile of the LDS-resident kernel; 0 where that kernel cannot run
+    if (H != 32 && H != 64) return 0;
+    const size_t wpb = (H == 64) ? 12 : 8;
+    const size_t shm = sizeof(float) * ((size_t)((xmode == 3 ? 0 : IN) + H) * 3 * H + wpb * 32 * STG_LD + 4);
+    return shm > 160 * 1024 ? 0 : H / 32;
+}
+
 int tmpnn_gru_fwd(const int32_t* rows, int R, int xmode, const int32_t* src, const int32_t* dst, const float* msg,
                   int ld_msg, int msg_compact, int IN, const float* h, int ld_h, int H, const float* wih_t, const float* whh_t,
                   const float* b_ih, const float* b_hh, float* h_out, int ld_out, float* gates, size_t gate_plane,
-                  tmpnn_stream stream) {
+                  const float* w_head, float* logit_part, size_t part_stride, tmpnn_stream stream) {
     TM_REQUIRE(supported_H(H), "gru_fwd: unsupported H=%d", H);
     TM_REQUIRE(R >= 0, "gru_fwd: R=%d", R);
     if (R == 0) return TMPNN_OK;
@@ -1078,8 +1098,10 @@ int tmpnn_gru_fwd(const int32_t* rows, int R, int xmode, const int32_t* src, con
                "gru_fwd: xmode 3 needs H <= 64 and the projected det rows msg [Dn][3H]");
     TM_REQUIRE(ld_h >= H && ld_out >= H && (ld_h & 3) == 0 && aligned16(h), "gru_fwd: bad state layout");
     TM_REQUIRE(gates == nullptr || gate_plane >= (size_t)H, "gru_fwd: gate_plane too small");
+    TM_REQUIRE(logit_part == nullptr || (w_head != nullptr && aligned16(w_head) && tmpnn_gru_fwd_head_parts(H, IN, xmode) > 0),
+               "gru_fwd: fused head not available for H=%d IN=%d xmode=%d (see tmpnn_gru_fwd_head_parts)", H, IN, xmode);
     GruFwdArgs a{rows, R, src, dst, msg, ld_msg, IN, msg_compact, h, ld_h, H, wih_t, whh_t, b_ih, b_hh, h_out, ld_out, gates,
-                 gate_plane};
+                 gate_plane, w_head, logit_part, part_stride};
     hipStream_t st = as_stream(stream);
     if (H <= 64 && (xmode == 3 || aligned16(wih_t)) && aligned16(whh_t) && aligned16(h_out) && (ld_out & 3) == 0 && aligned16(b_ih) &&
         aligned16(b_hh) && (gates == nullptr || (aligned16(gates) && (gate_plane & 3) == 0))) {
@@ -1104,6 +1126,7 @@ int tmpnn_gru_fwd(const int32_t* rows, int R, int xmode, const int32_t* src, con
         return check_launch("gru_fwd_lds");
     }
 generic:
+    TM_REQUIRE(logit_part == nullptr, "gru_fwd: fused head requested but the LDS path is unavailable (alignment)");
     TM_REQUIRE(xmode != 3, "gru_fwd: xmode 3 is only available on the LDS path (H <= 64, 16-byte aligned buffers)");
     const int CT = (H % 64 == 0) ? 2 : 1;
     dim3 grid(ceil_div(R, 128), H / (32 * CT)), block(256);

@@ -164,17 +164,26 @@ def mp_forward(spec: ModelSpec, plan: CallPlan, x: torch.Tensor, h_in: Optional[
     att_saved = []
     xmode = 2 if spec.msg_type == 'concat' else 1
     plane = N * H
+    lib = _lib.load()
+    use_proj = spec.msg_type == 'diff' and H <= 64 and g.src_pos is not None and Dn > 0
+    # output head fused into the cells' epilogues where the LDS-resident kernel runs (else tmpnn_heads_fwd)
+    cw = min(lib.tmpnn_gru_fwd_head_parts(H, spec.IN_e, 3 if use_proj else xmode), lib.tmpnn_gru_fwd_head_parts(H, H, 0))
+    parts = torch.empty((G * cw, N), **opts) if cw > 0 else None
+    w_node, w_edge = P['output_transform_node.weight'], P['output_transform_edge.weight']
     for gi in range(G):
         f = f'factor_grus.{gi}.'
         hg = h_cat.data_ptr() + 4 * gi * H
         og = h_out.data_ptr() + 4 * gi * H
         gp = gates[gi].data_ptr() if save else None
+        part_g = (parts.data_ptr() + 4 * gi * cw * N) if cw > 0 else None
+        we_g = (w_edge.data_ptr() + 4 * gi * H) if cw > 0 else None
+        wn_g = (w_node.data_ptr() + 4 * gi * H) if cw > 0 else None
         # edge update: GRU(h[src]-h[dst] | concat, h[e])      (layers.py:90-97)
         # (temporaries stay referenced until their consumer is enqueued: the caching allocator may
         #  hand a freed block to the very next allocation)
         e_wih_t, e_whh_t = _transpose(P[f + 'edge_gru.weight_ih']), _transpose(P[f + 'edge_gru.weight_hh'])
         n_wih_t, n_whh_t = _transpose(P[f + 'node_gru.weight_ih']), _transpose(P[f + 'node_gru.weight_hh'])
-        if spec.msg_type == 'diff' and H <= 64 and g.src_pos is not None and Dn > 0:
+        if use_proj:
             # (h[src]-h[dst]) W_ih^T = P[src] - P[dst] with P = h[dets] W_ih^T: the x-half of the edge cell's
             # forward GEMM runs over the Dn det rows instead of the E edge rows
             proj = torch.empty((Dn, 3 * H), **opts)
@@ -183,13 +192,13 @@ def mp_forward(spec: ModelSpec, plan: CallPlan, x: torch.Tensor, h_in: Optional[
             _lib.call('tmpnn_gru_fwd', g.edge_row.data_ptr(), E, 3, g.src_pos.data_ptr(), g.dst_pos.data_ptr(),
                       proj.data_ptr(), 3 * H, 0, H, hg, GH, H, None, e_whh_t.data_ptr(),
                       P[f + 'edge_gru.bias_ih'].data_ptr(), P[f + 'edge_gru.bias_hh'].data_ptr(),
-                      og, GH, gp, plane, st)
+                      og, GH, gp, plane, we_g, part_g, N, st)
         else:
             _lib.call('tmpnn_gru_fwd', g.edge_row.data_ptr(), E, xmode, g.src.data_ptr(), g.dst.data_ptr(),
                       None, 0, 0, spec.IN_e, hg, GH, H,
                       e_wih_t.data_ptr(), e_whh_t.data_ptr(),
                       P[f + 'edge_gru.bias_ih'].data_ptr(), P[f + 'edge_gru.bias_hh'].data_ptr(),
-                      og, GH, gp, plane, st)
+                      og, GH, gp, plane, we_g, part_g, N, st)
         # edge -> node aggregation                              (layers.py:99-112)
         es = es_all[gi]
         if K == 0:
@@ -217,13 +226,18 @@ def mp_forward(spec: ModelSpec, plan: CallPlan, x: torch.Tensor, h_in: Optional[
                   es.data_ptr(), H, 1, H, hg, GH, H,
                   n_wih_t.data_ptr(), n_whh_t.data_ptr(),
                   P[f + 'node_gru.bias_ih'].data_ptr(), P[f + 'node_gru.bias_hh'].data_ptr(),
-                  og, GH, gp, plane, st)
+                  og, GH, gp, plane, wn_g, part_g, N, st)
     logits = torch.empty((N, 1), **opts)
     scores = torch.empty((N, 1), **opts)
-    _lib.call('tmpnn_heads_fwd', h_out.data_ptr(), GH, GH, N, g.is_edge.data_ptr(),
-              P['output_transform_node.weight'].data_ptr(), P['output_transform_node.bias'].data_ptr(),
-              P['output_transform_edge.weight'].data_ptr(), P['output_transform_edge.bias'].data_ptr(),
-              logits.data_ptr(), scores.data_ptr(), st)
+    if cw > 0:
+        _lib.call('tmpnn_heads_finish', parts.data_ptr(), N, G * cw, N, g.is_edge.data_ptr(),
+                  P['output_transform_node.bias'].data_ptr(), P['output_transform_edge.bias'].data_ptr(),
+                  logits.data_ptr(), scores.data_ptr(), st)
+    else:
+        _lib.call('tmpnn_heads_fwd', h_out.data_ptr(), GH, GH, N, g.is_edge.data_ptr(),
+                  P['output_transform_node.weight'].data_ptr(), P['output_transform_node.bias'].data_ptr(),
+                  P['output_transform_edge.weight'].data_ptr(), P['output_transform_edge.bias'].data_ptr(),
+                  logits.data_ptr(), scores.data_ptr(), st)
     if save:
         saved.update(h_cat=h_cat, gates=gates, es=es_all, att=att_saved, h_out=h_out, scores=scores)
     return scores, logits, h_out, alphas, saved
