@@ -161,6 +161,21 @@ int tmpnn_gru_bwd_weights(const int32_t* rows, int R, int xmode, const int32_t* 
                           float* dW_ih, float* dW_hh, float* db_ih, float* db_hh,
                           void* ws, size_t ws_bytes, tmpnn_stream stream);
 
+/* Fused backward of one cell: tmpnn_gru_bwd_data + tmpnn_gru_bwd_weights in ONE pass over the gates
+ * (arguments as in those two; available when tmpnn_gru_bwd_fused_available(H, IN, xmode) != 0, i.e. H = 64,
+ * IN = H, xmode 0 or 1).  ws: tmpnn_gru_bwd_fused_ws(R, IN, H) bytes. */
+int tmpnn_gru_bwd_fused_available(int H, int IN, int xmode);
+size_t tmpnn_gru_bwd_fused_ws(int R, int IN, int H);
+int tmpnn_gru_bwd_fused(const int32_t* rows, int R, int xmode, const int32_t* src, const int32_t* dst,
+                        const float* msg, int ld_msg, int msg_compact, int IN,
+                        const float* h, int ld_h, int H, const float* w_ih, const float* w_hh,
+                        const float* gates, size_t gate_plane, const float* d_hout, int ld_dhout,
+                        const float* dy, const float* w_head,
+                        float* d_msg, int ld_dmsg, float* d_h, int ld_dh,
+                        const int32_t* add_src, const int32_t* add_dst, const float* add_msg, int ld_add,
+                        float* dW_ih, float* dW_hh, float* db_ih, float* db_hh,
+                        void* ws, size_t ws_bytes, tmpnn_stream stream);
+
 /* out[r, 0:NOUT] = in[rows[r], 0:H] @ wt[H][NOUT]  (compact output rows; H in {32, 64}, NOUT = 3H):
  * the det-row projection P of tmpnn_gru_fwd's xmode 3. */
 int tmpnn_rows_linear(const int32_t* rows, int R, const float* in, int ld_in, int H, const float* wt, int NOUT,

@@ -275,3 +275,28 @@ def test_inplace_append_is_bitwise_identical():
     assert torch.equal(outs[0][0], outs[1][0])
     for a, b in zip(outs[0][1], outs[1][1]):
         assert torch.equal(a, b)
+
+
+def test_fused_backward_matches_two_kernel_backward(monkeypatch):
+    """tmpnn_gru_bwd_fused (opt-in) gives the gradients of the default two-kernel backward."""
+    import trackmpnn_amd.functional as F
+    from trackmpnn_amd import TrackMPNN
+    plans, xs = _batched_case(B=8, frames=6, mean=5, max_dets=12, F=8, seed0=11)
+    outs = []
+    for fused in (False, True):
+        monkeypatch.setattr(F, 'FUSED_BWD', fused)
+        torch.manual_seed(5)
+        model = TrackMPNN('2d', 3, 64, 0, 'diff').to(DEV).train()
+        with torch.no_grad():
+            for p in model.parameters():
+                p.add_(0.1 * torch.randn(p.shape, generator=torch.Generator().manual_seed(p.numel())).to(DEV))
+        h = None
+        loss = 0.0
+        for plan, x in zip(plans, xs):
+            s, l, h, _ = model.forward_graph(x.to(DEV), h, plan.to(DEV))
+            loss = loss + (l * l).sum() + s.sum()
+        loss.backward()
+        outs.append([p.grad.clone() for p in model.parameters()])
+    gmax = max(g.abs().max().item() for g in outs[0])
+    for a, b in zip(outs[0], outs[1]):
+        assert (a - b).abs().max().item() <= 1e-5 * max(1.0, gmax)

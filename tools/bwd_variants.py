@@ -24,3 +24,17 @@ def mk(dho, dy, fuse):
     return fn
 for name, args in (('up1', (1,0,0)), ('up2', (0,1,0)), ('up3', (1,1,0)), ('up1_fuse', (1,0,1)), ('up2_fuse', (0,1,1)), ('up3_fuse', (1,1,1))):
     print(name, round(bench.time_stage(mk(*args)), 3), 'ms', flush=True)
+
+gW = [torch.zeros_like(wih), torch.zeros_like(whh), torch.zeros_like(bih), torch.zeros_like(bhh)]
+wsb = _lib.load().tmpnn_gru_bwd_weights_ws(E, H, H); ws = torch.empty(wsb // 4 + 1, device=dev)
+def wfn():
+    _lib.call('tmpnn_gru_bwd_weights', g.edge_row.data_ptr(), E, 1, g.src.data_ptr(), g.dst.data_ptr(), None, 0, 0, H, h.data_ptr(), H, H,
+              gates.data_ptr(), N*H, dout.data_ptr(), H, dyv.data_ptr(), w_head.data_ptr(), gW[0].data_ptr(), gW[1].data_ptr(), gW[2].data_ptr(), gW[3].data_ptr(), ws.data_ptr(), wsb, st)
+print('weights up3', round(bench.time_stage(wfn), 3), 'ms', flush=True)
+fwsb = _lib.load().tmpnn_gru_bwd_fused_ws(E, H, H); fws = torch.empty(fwsb // 4 + 1, device=dev)
+def ffn():
+    _lib.call('tmpnn_gru_bwd_fused', g.edge_row.data_ptr(), E, 1, g.src.data_ptr(), g.dst.data_ptr(), None, 0, 0, H, h.data_ptr(), H, H,
+              wih.data_ptr(), whh.data_ptr(), gates.data_ptr(), N*H, dout.data_ptr(), H, dyv.data_ptr(), w_head.data_ptr(),
+              dmsg.data_ptr(), H, dh.data_ptr(), H, g.src.data_ptr(), g.dst.data_ptr(), dmsg.data_ptr(), H,
+              gW[0].data_ptr(), gW[1].data_ptr(), gW[2].data_ptr(), gW[3].data_ptr(), fws.data_ptr(), fwsb, st)
+print('FUSED data+weights up3_fuse', round(bench.time_stage(ffn), 3), 'ms', flush=True)

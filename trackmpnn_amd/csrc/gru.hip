@@ -1015,6 +1015,247 @@ __global__ __launch_bounds__(256, 2) void k_gru_bwd_weights_lds(GruBwdWArgs a, i
     }
 }
 
+
+// ==========================================================================================
+// Fused backward of one cell (H = 64, IN = H): data gradient AND weight gradient from ONE pass over
+// the gates.  The two stand-alone kernels each stream dh, the four gate planes and h (1.5 KB per row);
+// here a 32-row tile of d_g = [dr|dz|dn|dn*r], [x|h] and dh*z is formed once in LDS and consumed by
+//   waves 0-3: dW_ih / dW_hh tiles (A = d_g^T, B = [x|h]; 6 accumulator tiles each, kept over all tiles
+//              of the persistent block, one slab per block at the end);
+//   waves 4-7: the four 32x32 output tiles of d_msg = d_gi W_ih and d_h = d_gh W_hh (+ dh*z + fused
+//              row-F adjoint), weights (96 KiB) resident in LDS, transposed accumulator (lane = row).
+// Both groups issue 96 MFMAs per tile and wave w shares its SIMD with wave w+4, so every SIMD runs one
+// wave of each kind.  The next tile's global loads are in flight during the MFMA phase.
+// ==========================================================================================
+struct GruBwdFusedArgs {
+    const int32_t* rows; int R; const int32_t* src; const int32_t* dst;
+    const float* msg; int ld_msg; int msg_compact;
+    const float* h; int ld_h;
+    const float* w_ih; const float* w_hh;
+    const float* gates; size_t gate_plane;
+    DhSrc up;
+    float* d_msg; int ld_dmsg; float* d_h; int ld_dh;
+    const int32_t* add_src; const int32_t* add_dst; const float* add_msg; int ld_add;
+    float* slab_w; float* slab_b;
+};
+
+struct FRaw { float4 dh, r, z, n, hn, hp, x; int orow; bool valid; };
+
+template <int H, int XMODE, int UP>
+__device__ __forceinline__ void fused_issue(const GruBwdFusedArgs& a, int tile, int srow, int f4, FRaw& q) {
+    const int lpos_raw = tile * 32 + srow;
+    q.valid = lpos_raw < a.R;
+    const int lpos = q.valid ? lpos_raw : a.R - 1;
+    const int orow = a.rows[lpos];
+    q.orow = orow;
+    const size_t gp = a.gate_plane;
+    float4 u = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (UP & 1) u = *reinterpret_cast<const float4*>(a.up.d_hout + (size_t)orow * a.up.ld_dhout + f4);
+    if (UP & 2) {
+        const float d = a.up.dy[orow];
+        const float4 w = *reinterpret_cast<const float4*>(a.up.w_head + f4);
+        u.x += d * w.x; u.y += d * w.y; u.z += d * w.z; u.w += d * w.w;
+    }
+    q.dh = u;
+    const float* g0 = a.gates + (size_t)orow * H + f4;
+    q.r = *reinterpret_cast<const float4*>(g0);
+    q.z = *reinterpret_cast<const float4*>(g0 + gp);
+    q.n = *reinterpret_cast<const float4*>(g0 + 2 * gp);
+    q.hn = *reinterpret_cast<const float4*>(g0 + 3 * gp);
+    q.hp = *reinterpret_cast<const float4*>(a.h + (size_t)orow * a.ld_h + f4);
+    if (XMODE == 0) {
+        q.x = *reinterpret_cast<const float4*>(a.msg + (size_t)(a.msg_compact ? lpos : orow) * a.ld_msg + f4);
+    } else {
+        const float4 s = *reinterpret_cast<const float4*>(a.h + (size_t)a.src[lpos] * a.ld_h + f4);
+        const float4 d = *reinterpret_cast<const float4*>(a.h + (size_t)a.dst[lpos] * a.ld_h + f4);
+        q.x = make_float4(s.x - d.x, s.y - d.y, s.z - d.z, s.w - d.w);
+    }
+}
+
+template <int H, int XMODE, int UP, bool FUSE>
+__global__ __launch_bounds__(512) void k_gru_bwd_fused(GruBwdFusedArgs a, int ntiles) {
+    static_assert(H == 64, "fused backward is written for H = 64");
+    extern __shared__ float lds[];
+    constexpr int DGS = 4 * H + 4;       // d_g row stride: 260 floats = 4 mod 64 -> conflict-free ds_read_b128 per row
+    constexpr int XHS = 2 * H + 4;
+    constexpr int DZS = H + 4;
+    float* sWih = lds;                   // [3H][H]
+    float* sWhh = sWih + 3 * H * H;      // [3H][H]
+    float* s_dg = sWhh + 3 * H * H;      // [32][DGS]  dr | dz | dn | dn*r
+    float* s_xh = s_dg + 32 * DGS;       // [32][XHS]  x | h
+    float* s_dz = s_xh + 32 * XHS;       // [32][DZS]  dh * z
+    const int tid = threadIdx.x;
+    for (int i = tid * 4; i < 3 * H * H; i += 512 * 4) {
+        *reinterpret_cast<float4*>(sWih + i) = *reinterpret_cast<const float4*>(a.w_ih + i);
+        *reinterpret_cast<float4*>(sWhh + i) = *reinterpret_cast<const float4*>(a.w_hh + i);
+    }
+    const int wave = tid >> 6, lane = tid & 63;
+    const int c = lane & 31, half = lane >> 5;
+    const int srow = tid >> 4, f4 = (tid & 15) * 4;         // staging: 16 threads x float4 per row
+    const bool wgrad = wave < 4;
+    // weight-gradient waves: as in k_gru_bwd_weights_lds
+    const int which = (wave >> 1) & 1;
+    const int jt0 = (wave & 1) * 3;
+    f32x16 acc[3][2];
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[j][t][i] = 0.f;
+    float csum = 0.f;
+    int colA[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const int jj = (jt0 + j) * 32 + c;
+        colA[j] = (which == 1 && jj >= 2 * H) ? jj + H : jj;
+    }
+    const int colB0 = which * H + c;
+    // data-gradient waves: output tile ot = wave - 4 : 0,1 -> d_msg columns [0,32),[32,64) ; 2,3 -> d_h
+    const int ot = wave & 3;
+    const bool is_dx = ot < 2;
+    const int n0 = (ot & 1) * 32;
+    const float* sW = is_dx ? sWih : sWhh;
+
+    FRaw q;
+    int tile = blockIdx.x;
+    if (tile < ntiles) fused_issue<H, XMODE, UP>(a, tile, srow, f4, q);
+    __syncthreads();                                         // weights are in LDS
+    for (; tile < ntiles; tile += gridDim.x) {
+        // ---- elementwise: 4 features of one row per thread
+        float4 dr, dz, dn, dnr, dhz;
+        {
+            const float dh[4] = {q.dh.x, q.dh.y, q.dh.z, q.dh.w}, r[4] = {q.r.x, q.r.y, q.r.z, q.r.w};
+            const float z[4] = {q.z.x, q.z.y, q.z.z, q.z.w}, n[4] = {q.n.x, q.n.y, q.n.z, q.n.w};
+            const float hn[4] = {q.hn.x, q.hn.y, q.hn.z, q.hn.w}, hp[4] = {q.hp.x, q.hp.y, q.hp.z, q.hp.w};
+            float o_r[4], o_z[4], o_n[4], o_nr[4], o_dz[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float d0 = q.valid ? dh[i] : 0.f;
+                const float t = d0 * (1.0f - z[i]) * (1.0f - n[i] * n[i]);
+                o_n[i] = t;
+                o_nr[i] = t * r[i];
+                o_r[i] = t * hn[i] * r[i] * (1.0f - r[i]);
+                o_z[i] = d0 * (hp[i] - n[i]) * z[i] * (1.0f - z[i]);
+                o_dz[i] = d0 * z[i];
+            }
+            dr = make_float4(o_r[0], o_r[1], o_r[2], o_r[3]);
+            dz = make_float4(o_z[0], o_z[1], o_z[2], o_z[3]);
+            dn = make_float4(o_n[0], o_n[1], o_n[2], o_n[3]);
+            dnr = make_float4(o_nr[0], o_nr[1], o_nr[2], o_nr[3]);
+            dhz = make_float4(o_dz[0], o_dz[1], o_dz[2], o_dz[3]);
+        }
+        const float4 xq = q.x, hq = q.hp;
+        __syncthreads();                                     // previous tile's readers are done with the LDS tiles
+        {
+            float* d = s_dg + srow * DGS + f4;
+            *reinterpret_cast<float4*>(d) = dr;
+            *reinterpret_cast<float4*>(d + H) = dz;
+            *reinterpret_cast<float4*>(d + 2 * H) = dn;
+            *reinterpret_cast<float4*>(d + 3 * H) = dnr;
+            float* e = s_xh + srow * XHS + f4;
+            *reinterpret_cast<float4*>(e) = xq;
+            *reinterpret_cast<float4*>(e + H) = hq;
+            *reinterpret_cast<float4*>(s_dz + srow * DZS + f4) = dhz;
+        }
+        __syncthreads();
+        // ---- next tile's rows are requested now and land during the MFMA phase
+        if (tile + (int)gridDim.x < ntiles) fused_issue<H, XMODE, UP>(a, tile + gridDim.x, srow, f4, q);
+        __builtin_amdgcn_sched_barrier(0);
+        if (wgrad) {
+            if (tid < 4 * H) {
+#pragma unroll 8
+                for (int rr = 0; rr < 32; ++rr) csum += s_dg[rr * DGS + tid];
+            }
+#pragma unroll 4
+            for (int s = 0; s < 16; ++s) {
+                const float* ar = s_dg + (2 * s + half) * DGS;
+                const float* br = s_xh + (2 * s + half) * XHS + colB0;
+                float av[3], bv[2];
+#pragma unroll
+                for (int j = 0; j < 3; ++j) av[j] = ar[colA[j]];
+#pragma unroll
+                for (int t = 0; t < 2; ++t) bv[t] = br[t * 32];
+#pragma unroll
+                for (int j = 0; j < 3; ++j)
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) acc[j][t] = mfma32(av[j], bv[t], acc[j][t]);
+            }
+        } else {
+            // out^T[col][row] = sum_j W[j][n0 + col] * d_g[row][j] ; lane (c, half) owns row c of the tile.
+            // k enumeration: block m (8 consecutive j), lane half takes j = 8m + 4*half + t, t = 0..3
+            f32x16 o;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) o[i] = 0.f;
+            const float* drow = s_dg + c * DGS;
+#pragma unroll 2
+            for (int m = 0; m < 3 * H / 8; ++m) {
+                const int j0 = 8 * m + 4 * half;                       // gate g = j0 / H
+                const int col = (!is_dx && j0 >= 2 * H) ? j0 + H : j0;  // d_h uses the dn*r block for the n gate
+                const float4 dv = *reinterpret_cast<const float4*>(drow + col);
+                const float* wr = sW + j0 * H + n0 + c;
+                o = mfma32(wr[0], dv.x, o);
+                o = mfma32(wr[H], dv.y, o);
+                o = mfma32(wr[2 * H], dv.z, o);
+                o = mfma32(wr[3 * H], dv.w, o);
+            }
+            const int tr0 = tile * 32;
+            const bool live = tr0 + c < a.R;
+            const int lp = min(tr0 + c, a.R - 1);
+            const int orow = a.rows[lp];
+            if (is_dx) {
+                if (live) {
+#pragma unroll
+                    for (int qq = 0; qq < 4; ++qq)
+                        *reinterpret_cast<float4*>(a.d_msg + (size_t)orow * a.ld_dmsg + n0 + 8 * qq + 4 * half) =
+                            make_float4(o[4 * qq], o[4 * qq + 1], o[4 * qq + 2], o[4 * qq + 3]);
+                }
+            } else {
+                int sr = 0, dr2 = 0;
+                if (FUSE) { sr = a.add_src[lp]; dr2 = a.add_dst[lp]; }
+                float4 ex[4];
+#pragma unroll
+                for (int qq = 0; qq < 4; ++qq) {
+                    const int col = n0 + 8 * qq + 4 * half;
+                    ex[qq] = *reinterpret_cast<const float4*>(s_dz + c * DZS + col);
+                    if (FUSE) {
+                        const float4 u = *reinterpret_cast<const float4*>(a.add_msg + (size_t)sr * a.ld_add + col);
+                        const float4 v = *reinterpret_cast<const float4*>(a.add_msg + (size_t)dr2 * a.ld_add + col);
+                        ex[qq].x += u.x - v.x; ex[qq].y += u.y - v.y; ex[qq].z += u.z - v.z; ex[qq].w += u.w - v.w;
+                    }
+                }
+                if (live) {
+#pragma unroll
+                    for (int qq = 0; qq < 4; ++qq)
+                        *reinterpret_cast<float4*>(a.d_h + (size_t)orow * a.ld_dh + n0 + 8 * qq + 4 * half) =
+                            make_float4(o[4 * qq] + ex[qq].x, o[4 * qq + 1] + ex[qq].y, o[4 * qq + 2] + ex[qq].z,
+                                        o[4 * qq + 3] + ex[qq].w);
+                }
+            }
+        }
+    }
+    // ---- one slab per block (weight-gradient waves)
+    if (wgrad) {
+        float* sw = a.slab_w + (size_t)blockIdx.x * (3 * H) * (2 * H);
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    const int jj = (jt0 + j) * 32 + acc_row(reg, half);
+                    sw[(size_t)jj * (2 * H) + which * H + t * 32 + c] = acc[j][t][reg];
+                }
+        if (tid < 4 * H) {
+            float* sb = a.slab_b + (size_t)blockIdx.x * 6 * H;
+            const int g = tid / H, f = tid % H;
+            if (g < 3) sb[g * H + f] = csum;
+            if (g < 2) sb[3 * H + g * H + f] = csum;
+            if (g == 3) sb[3 * H + 2 * H + f] = csum;
+        }
+    }
+}
+
 // dW_ih[j][k] += sum_rs slab[rs][j][k], k < IN ; dW_hh[j][k-IN] += ... ; biases likewise
 __global__ void k_gru_reduce_w(const float* __restrict__ slab_w, const float* __restrict__ slab_b, int n_rs,
                                int IN, int H, float* __restrict__ dW_ih, float* __restrict__ dW_hh,
@@ -1216,6 +1457,86 @@ static bool weights_use_lds(int IN, int H) { return H == 64 && IN == H; }
 static int weights_lds_blocks(int R) {
     const int ntiles = ceil_div(R, 32);
     return ntiles < 512 ? ntiles : 512;          // persistent: <= 2 blocks per CU
+}
+
+
+static int fused_blocks(int R) {
+    const int ntiles = ceil_div(R, 32);
+    return ntiles < 256 ? ntiles : 256;
+}
+
+int tmpnn_gru_bwd_fused_available(int H, int IN, int xmode) { return (H == 64 && IN == 64 && (xmode == 0 || xmode == 1)) ? 1 : 0; }
+
+size_t tmpnn_gru_bwd_fused_ws(int R, int IN, int H) {
+    if (R <= 0) return 0;
+    const int n = fused_blocks(R);
+    const size_t per = (size_t)3 * H * (IN + H) + (size_t)6 * H;
+    return ((size_t)n * per + reduce_slabs_ws_floats(n, per)) * sizeof(float);
+}
+
+int tmpnn_gru_bwd_fused(const int32_t* rows, int R, int xmode, const int32_t* src, const int32_t* dst, const float* msg,
+                        int ld_msg, int msg_compact, int IN, const float* h, int ld_h, int H, const float* w_ih,
+                        const float* w_hh, const float* gates, size_t gate_plane, const float* d_hout, int ld_dhout,
+                        const float* dy, const float* w_head, float* d_msg, int ld_dmsg, float* d_h, int ld_dh,
+                        const int32_t* add_src, const int32_t* add_dst, const float* add_msg, int ld_add, float* dW_ih,
+                        float* dW_hh, float* db_ih, float* db_hh, void* ws, size_t ws_bytes, tmpnn_stream stream) {
+    TM_REQUIRE(tmpnn_gru_bwd_fused_available(H, IN, xmode), "gru_bwd_fused: H=%d IN=%d xmode=%d not supported", H, IN, xmode);
+    if (R == 0) return TMPNN_OK;
+    TM_REQUIRE(R > 0 && rows && h && w_ih && w_hh && gates && d_msg && d_h && dW_ih && dW_hh && db_ih && db_hh,
+               "gru_bwd_fused: null pointer");
+    TM_REQUIRE(d_hout != nullptr || dy != nullptr, "gru_bwd_fused: no upstream gradient");
+    TM_REQUIRE(dy == nullptr || (w_head != nullptr && aligned16(w_head)), "gru_bwd_fused: dy needs a 16-byte aligned w_head");
+    TM_REQUIRE(xmode == 0 ? (msg != nullptr && (ld_msg & 3) == 0 && aligned16(msg) && ld_msg >= IN) : (src && dst),
+               "gru_bwd_fused: message source");
+    TM_REQUIRE((ld_h & 3) == 0 && aligned16(h) && aligned16(gates) && (gate_plane & 3) == 0 && aligned16(w_ih) &&
+                   aligned16(w_hh) && (d_hout == nullptr || ((ld_dhout & 3) == 0 && aligned16(d_hout))) &&
+                   (ld_dmsg & 3) == 0 && aligned16(d_msg) && (ld_dh & 3) == 0 && aligned16(d_h) &&
+                   (add_msg == nullptr || ((ld_add & 3) == 0 && aligned16(add_msg) && add_src && add_dst)),
+               "gru_bwd_fused: rows must be 16-byte aligned");
+    const size_t need = tmpnn_gru_bwd_fused_ws(R, IN, H);
+    if (ws == nullptr || ws_bytes < need)
+        return set_error(TMPNN_EWORKSPACE, "gru_bwd_fused: workspace %zu < %zu bytes", ws_bytes, need);
+    const int n_rs = fused_blocks(R);
+    const size_t nW = (size_t)3 * H * (IN + H), nB = (size_t)6 * H;
+    float* slab_w = reinterpret_cast<float*>(ws);
+    float* slab_b = slab_w + (size_t)n_rs * nW;
+    float* fold = slab_b + (size_t)n_rs * nB;
+    GruBwdFusedArgs a{rows, R, src, dst, msg, ld_msg, msg_compact, h, ld_h, w_ih, w_hh, gates, gate_plane,
+                      DhSrc{d_hout, ld_dhout, dy, w_head}, d_msg, ld_dmsg, d_h, ld_dh, add_src, add_dst, add_msg, ld_add,
+                      slab_w, slab_b};
+    const int ntiles = ceil_div(R, 32);
+    const size_t shm = sizeof(float) * ((size_t)6 * H * H + 32 * (4 * H + 4) + 32 * (2 * H + 4) + 32 * (H + 4));
+    hipStream_t st = as_stream(stream);
+    const int up = (d_hout ? 1 : 0) | (dy ? 2 : 0);
+    const bool fuse = add_msg != nullptr;
+#define LF(X, U, F)                                                                                          \
+    do {                                                                                                     \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gru_bwd_fused<64, X, U, F>),              \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);                     \
+        hipLaunchKernelGGL((k_gru_bwd_fused<64, X, U, F>), dim3(n_rs), dim3(512), shm, st, a, ntiles);       \
+    } while (0)
+#define LU(X, F) do { if (up == 1) LF(X, 1, F); else if (up == 2) LF(X, 2, F); else LF(X, 3, F); } while (0)
+    if (xmode == 0) { if (fuse) LU(0, true); else LU(0, false); }
+    else            { if (fuse) LU(1, true); else LU(1, false); }
+#undef LU
+#undef LF
+    int rc = check_launch("gru_bwd_fused");
+    if (rc) return rc;
+    const float* rw = slab_w;
+    const float* rb = slab_b;
+    int nred = n_rs;
+    if (n_rs > 64) {
+        const int ng = ceil_div(n_rs, 32);
+        float* fw = fold;
+        float* fb = fold + (size_t)ng * nW;
+        hipLaunchKernelGGL(k_fold_slabs_gru, dim3(ceil_div((long)nW, 256), ng), dim3(256), 0, st, slab_w, nW, n_rs, fw, nW);
+        hipLaunchKernelGGL(k_fold_slabs_gru, dim3(ceil_div((long)nB, 256), ng), dim3(256), 0, st, slab_b, nB, n_rs, fb, nB);
+        if ((rc = check_launch("gru_fold"))) return rc;
+        rw = fw; rb = fb; nred = ng;
+    }
+    hipLaunchKernelGGL(k_gru_reduce_w, dim3(ceil_div((long)(nW + nB), 256)), dim3(256), 0, st, rw, rb, nred, IN, H,
+                       dW_ih, dW_hh, db_ih, db_hh);
+    return check_launch("gru_reduce_w");
 }
 
 size_t tmpnn_gru_bwd_weights_ws(int R, int IN, int H) {

@@ -8,6 +8,7 @@ index plumbing only -- every flop of the path runs in libtmpnn.so, and there is 
 """
 from __future__ import annotations
 
+import os
 from dataclasses import dataclass
 from typing import Dict, List, Optional, Sequence, Tuple
 
@@ -17,6 +18,7 @@ from . import _lib
 from .graph import CallPlan
 
 ATT_DROPOUT_P = 0.5
+FUSED_BWD = os.environ.get('TMPNN_FUSED_BWD', '0') == '1'     # see mp_backward
 
 
 @dataclass(frozen=True)
@@ -293,7 +295,13 @@ def mp_backward(spec: ModelSpec, plan: CallPlan, saved: dict, P: Dict[str, torch
     plane = N * H
     ws_e = lib.tmpnn_gru_bwd_weights_ws(E, IN_e, H)
     ws_n = lib.tmpnn_gru_bwd_weights_ws(Dn, H, H)
-    ws_w = torch.empty((max(ws_e, ws_n) // 4 + 1,), **opts)
+    # The single-pass backward (tmpnn_gru_bwd_fused) reads the gates once instead of twice but, with one
+    # barrier-synchronised block per CU, measured 7 % SLOWER than the two stand-alone kernels on MI355X
+    # (3.60 vs 3.36 ms per 3 M rows, round 1) -- opt-in until its staging is double-buffered.
+    use_fused_bwd = (FUSED_BWD and lib.tmpnn_gru_bwd_fused_available(H, H, 0)
+                     and lib.tmpnn_gru_bwd_fused_available(H, IN_e, xmode))
+    ws_f = max(lib.tmpnn_gru_bwd_fused_ws(E, IN_e, H), lib.tmpnn_gru_bwd_fused_ws(Dn, H, H)) if use_fused_bwd else 0
+    ws_w = torch.empty((max(ws_e, ws_n, ws_f) // 4 + 1,), **opts)
     w_node, w_edge = P['output_transform_node.weight'], P['output_transform_edge.weight']
     for gi in range(G):
         f = f'factor_grus.{gi}.'
@@ -305,28 +313,46 @@ def mp_backward(spec: ModelSpec, plan: CallPlan, saved: dict, P: Dict[str, torch
         dyp = _lib.ptr(dy)
         wn = (w_node.data_ptr() + 4 * gi * H) if dy is not None else None
         we = (w_edge.data_ptr() + 4 * gi * H) if dy is not None else None
-        # node GRU backward: d_es -> dmsg[det rows, 0:H], d_hcat[det rows]
-        _lib.call('tmpnn_gru_bwd_data', g.det_row.data_ptr(), Dn, H, hg, GH, H,
-                  P[f + 'node_gru.weight_ih'].data_ptr(), P[f + 'node_gru.weight_hh'].data_ptr(),
-                  gp, plane, dog, GH, dyp, wn, dmsg.data_ptr(), IN_e, dhg, GH, None, None, None, 0, st)
-        _lib.call('tmpnn_gru_bwd_weights', g.det_row.data_ptr(), Dn, 0, None, None, es.data_ptr(), H, 1, H,
-                  hg, GH, H, gp, plane, dog, GH, dyp, wn,
-                  grads[f + 'node_gru.weight_ih'].data_ptr(), grads[f + 'node_gru.weight_hh'].data_ptr(),
-                  grads[f + 'node_gru.bias_ih'].data_ptr(), grads[f + 'node_gru.bias_hh'].data_ptr(),
-                  ws_w.data_ptr(), ws_w.numel() * 4, st)
-        # edge GRU backward: d_ns -> dmsg[edge rows, 0:IN_e], d_hcat[edge rows]; without attention the
-        # adjoint of the edge -> node sum (d_es[src] - d_es[dst], read from dmsg's det rows) rides along
         fuse = K == 0
-        _lib.call('tmpnn_gru_bwd_data', g.edge_row.data_ptr(), E, IN_e, hg, GH, H,
-                  P[f + 'edge_gru.weight_ih'].data_ptr(), P[f + 'edge_gru.weight_hh'].data_ptr(),
-                  gp, plane, dog, GH, dyp, we, dmsg.data_ptr(), IN_e, dhg, GH,
-                  g.src.data_ptr() if fuse else None, g.dst.data_ptr() if fuse else None,
-                  dmsg.data_ptr() if fuse else None, IN_e, st)
-        _lib.call('tmpnn_gru_bwd_weights', g.edge_row.data_ptr(), E, xmode, g.src.data_ptr(), g.dst.data_ptr(),
-                  None, 0, 0, IN_e, hg, GH, H, gp, plane, dog, GH, dyp, we,
-                  grads[f + 'edge_gru.weight_ih'].data_ptr(), grads[f + 'edge_gru.weight_hh'].data_ptr(),
-                  grads[f + 'edge_gru.bias_ih'].data_ptr(), grads[f + 'edge_gru.bias_hh'].data_ptr(),
-                  ws_w.data_ptr(), ws_w.numel() * 4, st)
+        if use_fused_bwd:
+            # one pass over the gates per cell: data and weight gradients together
+            _lib.call('tmpnn_gru_bwd_fused', g.det_row.data_ptr(), Dn, 0, None, None, es.data_ptr(), H, 1, H,
+                      hg, GH, H, P[f + 'node_gru.weight_ih'].data_ptr(), P[f + 'node_gru.weight_hh'].data_ptr(),
+                      gp, plane, dog, GH, dyp, wn, dmsg.data_ptr(), IN_e, dhg, GH, None, None, None, 0,
+                      grads[f + 'node_gru.weight_ih'].data_ptr(), grads[f + 'node_gru.weight_hh'].data_ptr(),
+                      grads[f + 'node_gru.bias_ih'].data_ptr(), grads[f + 'node_gru.bias_hh'].data_ptr(),
+                      ws_w.data_ptr(), ws_w.numel() * 4, st)
+            _lib.call('tmpnn_gru_bwd_fused', g.edge_row.data_ptr(), E, xmode, g.src.data_ptr(), g.dst.data_ptr(),
+                      None, 0, 0, IN_e, hg, GH, H,
+                      P[f + 'edge_gru.weight_ih'].data_ptr(), P[f + 'edge_gru.weight_hh'].data_ptr(),
+                      gp, plane, dog, GH, dyp, we, dmsg.data_ptr(), IN_e, dhg, GH,
+                      g.src.data_ptr() if fuse else None, g.dst.data_ptr() if fuse else None,
+                      dmsg.data_ptr() if fuse else None, IN_e,
+                      grads[f + 'edge_gru.weight_ih'].data_ptr(), grads[f + 'edge_gru.weight_hh'].data_ptr(),
+                      grads[f + 'edge_gru.bias_ih'].data_ptr(), grads[f + 'edge_gru.bias_hh'].data_ptr(),
+                      ws_w.data_ptr(), ws_w.numel() * 4, st)
+        else:
+            # node GRU backward: d_es -> dmsg[det rows, 0:H], d_hcat[det rows]
+            _lib.call('tmpnn_gru_bwd_data', g.det_row.data_ptr(), Dn, H, hg, GH, H,
+                      P[f + 'node_gru.weight_ih'].data_ptr(), P[f + 'node_gru.weight_hh'].data_ptr(),
+                      gp, plane, dog, GH, dyp, wn, dmsg.data_ptr(), IN_e, dhg, GH, None, None, None, 0, st)
+            _lib.call('tmpnn_gru_bwd_weights', g.det_row.data_ptr(), Dn, 0, None, None, es.data_ptr(), H, 1, H,
+                      hg, GH, H, gp, plane, dog, GH, dyp, wn,
+                      grads[f + 'node_gru.weight_ih'].data_ptr(), grads[f + 'node_gru.weight_hh'].data_ptr(),
+                      grads[f + 'node_gru.bias_ih'].data_ptr(), grads[f + 'node_gru.bias_hh'].data_ptr(),
+                      ws_w.data_ptr(), ws_w.numel() * 4, st)
+            # edge GRU backward: d_ns -> dmsg[edge rows, 0:IN_e], d_hcat[edge rows]; without attention the
+            # adjoint of the edge -> node sum (d_es[src] - d_es[dst], read from dmsg's det rows) rides along
+            _lib.call('tmpnn_gru_bwd_data', g.edge_row.data_ptr(), E, IN_e, hg, GH, H,
+                      P[f + 'edge_gru.weight_ih'].data_ptr(), P[f + 'edge_gru.weight_hh'].data_ptr(),
+                      gp, plane, dog, GH, dyp, we, dmsg.data_ptr(), IN_e, dhg, GH,
+                      g.src.data_ptr() if fuse else None, g.dst.data_ptr() if fuse else None,
+                      dmsg.data_ptr() if fuse else None, IN_e, st)
+            _lib.call('tmpnn_gru_bwd_weights', g.edge_row.data_ptr(), E, xmode, g.src.data_ptr(), g.dst.data_ptr(),
+                      None, 0, 0, IN_e, hg, GH, H, gp, plane, dog, GH, dyp, we,
+                      grads[f + 'edge_gru.weight_ih'].data_ptr(), grads[f + 'edge_gru.weight_hh'].data_ptr(),
+                      grads[f + 'edge_gru.bias_ih'].data_ptr(), grads[f + 'edge_gru.bias_hh'].data_ptr(),
+                      ws_w.data_ptr(), ws_w.numel() * 4, st)
         if K > 0:
             W, a, kp, ws_ha, score, alpha = saved['att'][gi]
             dW = torch.zeros_like(W)
