@@ -300,3 +300,44 @@ def test_fused_backward_matches_two_kernel_backward(monkeypatch):
     gmax = max(g.abs().max().item() for g in outs[0])
     for a, b in zip(outs[0], outs[1]):
         assert (a - b).abs().max().item() <= 1e-5 * max(1.0, gmax)
+
+
+def test_ragged_graph_after_row_deletion_vs_oracle():
+    """Inference pattern (infer.py:82-87, utils/graph.py:492-520): decode_tracks deletes the oldest frames'
+    rows from states / node_adj, leaving a ragged graph (dets that lost all their past edges, uneven runs).
+    Emulated by deleting whole det rows + their incident edge rows from a batched graph; HIP vs oracle, eval."""
+    from trackmpnn_amd import TrackMPNN, graph_from_edges, plan_single
+    plans, xs = _batched_case(B=4, frames=6, mean=5, max_dets=10, F=8, seed0=21)
+    g = plans[-1].graph
+    N = g.N
+    rng = np.random.RandomState(0)
+    is_edge = g.is_edge.numpy().astype(bool)
+    det_rows = g.det_row.numpy()
+    drop_det = set(det_rows[rng.rand(det_rows.size) < 0.3].tolist())
+    src, dst, er = g.src.numpy(), g.dst.numpy(), g.edge_row.numpy()
+    drop = np.zeros(N, bool)
+    drop[list(drop_det)] = True
+    drop[er[np.isin(src, list(drop_det)) | np.isin(dst, list(drop_det))]] = True
+    drop[er[rng.rand(er.size) < 0.2]] = True                      # plus some pruned low-probability edges
+    lone = [d for d in det_rows.tolist() if d not in drop_det][3]   # and one det that keeps no edge at all
+    drop[er[(src == lone) | (dst == lone)]] = True
+    keep = np.nonzero(~drop)[0]
+    remap = -np.ones(N, np.int64)
+    remap[keep] = np.arange(keep.size)
+    ek = ~drop[er]
+    g2 = graph_from_edges(keep.size, torch.from_numpy(is_edge[keep]), torch.from_numpy(remap[src[ek]]),
+                          torch.from_numpy(remap[dst[ek]]))
+    assert (g2.rowptr[1:] - g2.rowptr[:-1]).min().item() == 0       # some dets are isolated now
+    cfg = orc.OracleConfig('2d', 3, 64, 2, 'diff')                 # attention too: isolated dets have an empty softmax
+    p = orc.random_params(cfg, seed=4, scale=0.15)
+    model = TrackMPNN('2d', 3, 64, 2, 'diff')
+    model.load_state_dict({k: v.clone() for k, v in p.items()})
+    model = model.to(DEV).eval()
+    h0 = torch.randn(keep.size, 64, generator=torch.Generator().manual_seed(3))
+    with torch.no_grad():
+        s_ref, l_ref, h_ref, a_ref = orc.forward(p, cfg, torch.zeros(0, 8), h0, _oracle_graph(g2), training=False)
+        s, l, h, att = model.forward_graph(torch.zeros(0, 8, device=DEV), h0.to(DEV), plan_single(g2.to(DEV), 0))
+    assert (s.cpu() - s_ref).abs().max().item() <= SCORE_TOL
+    assert torch.allclose(h.cpu(), h_ref, atol=LOGIT_ATOL, rtol=LOGIT_RTOL)
+    for k in range(2):
+        assert torch.allclose(att[0][k].per_edge().cpu(), a_ref[0][k], atol=1e-5, rtol=1e-4)
