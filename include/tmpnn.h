@@ -240,6 +240,34 @@ int tmpnn_heads_bwd(const float* h, int ld_h, int C, int N, const uint8_t* is_ed
                     float* dw_node, float* db_node, float* dw_edge, float* db_edge,
                     void* ws, size_t ws_bytes, tmpnn_stream stream);
 
+/* ---- training targets and losses on the same CSR (models/loss.py) ---------------
+ * labels / targets: uint8 [N] (1 = positive).  A det's PAST edges are its CSR entries with the sign bit set,
+ * its FUTURE edges the others, both in ascending edge-row order.
+ *
+ * tmpnn_targets (create_targets, loss.py:8-44): targets[det] = labels[det]; per det the LAST label-positive
+ * past edge and the FIRST label-positive future edge get target 1, every other edge 0. */
+int tmpnn_targets(const tmpnn_graph* g, const uint8_t* labels, uint8_t* targets, tmpnn_stream stream);
+/* CELoss (loss.py:77-115): loss[0] = sum over dets and over their two sets (past, future) that contain a
+ * positive target of cross_entropy(logits[set], target) / |set|  (target = last positive of the past set,
+ * first positive of the future set).  stats [Dn][2][4] (max, sum exp, target row, set size) is saved for the
+ * backward; ws: tmpnn_ce_loss_ws(Dn) floats.  Backward: d_logits[edge rows] += d_loss[0] * d loss / d logit;
+ * src_pos/dst_pos [E] = det INDEX of each edge's endpoints. */
+size_t tmpnn_ce_loss_ws(int Dn);
+int tmpnn_ce_loss_fwd(const tmpnn_graph* g, const float* logits, const uint8_t* targets, float* stats, float* loss,
+                      float* ws, size_t ws_floats, tmpnn_stream stream);
+int tmpnn_ce_loss_bwd(const tmpnn_graph* g, const int32_t* src_pos, const int32_t* dst_pos, const float* logits,
+                      const float* stats, const float* d_loss, float* d_logits, tmpnn_stream stream);
+/* FocalLoss (loss.py:47-74) over the R rows listed in `rows`: loss_sum[0] = sum_i -(1-pt_i)^gamma log(pt_i) alpha_t,
+ * pt = (t ? s : 1-s) + 1e-10 (the caller divides by R for size_average).  Backward: d_scores[row] += d_loss[0] *
+ * scale * d loss_i / d s.  ws: tmpnn_focal_loss_ws(R) floats. */
+size_t tmpnn_focal_loss_ws(int R);
+int tmpnn_focal_loss_fwd(const int32_t* rows, int R, const float* scores, const uint8_t* targets, float gamma,
+                         int use_alpha, float alpha0, float alpha1, float* loss_sum, float* ws, size_t ws_floats,
+                         tmpnn_stream stream);
+int tmpnn_focal_loss_bwd(const int32_t* rows, int R, const float* scores, const uint8_t* targets, float gamma,
+                         int use_alpha, float alpha0, float alpha1, const float* d_loss, float scale, float* d_scores,
+                         tmpnn_stream stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -170,6 +170,50 @@ def run_fixture(name, out_dir, features, ncat, H, K, msg, mode, seed, T=4, dmean
           f'-> {os.path.getsize(path) / 1024:.0f} KiB')
 
 
+def run_loss_fixture(name, out_dir, seed, T=5, dmean=4):
+    """Targets and losses of the reference (models/loss.py) on reference-built train-mode graphs."""
+    from models.loss import CELoss, FocalLoss, create_targets
+    from utils.graph import initialize_graph, update_graph
+    X, y = synth_sequence(seed, T, dmean, 3, '2d', fp_rate=0.25)
+    y_pred, feats, node_adj, edge_adj, labels, t_st, t_end = initialize_graph(X, y, 0, 'train', cuda=False)
+    graphs = [(node_adj, labels, y_pred)]
+    for t in range(t_st, t_end):
+        y_pred, feats, node_adj, edge_adj, labels = update_graph(
+            node_adj, labels, torch.zeros(node_adj.shape[0], 1), y_pred, X, y, t, mode='train', cuda=False)
+        graphs.append((node_adj, labels, y_pred))
+    gen = torch.Generator().manual_seed(seed + 5)
+    out = {}
+    for c, (na, lab, yp) in enumerate(graphs):
+        N = na.shape[0]
+        logits = (2.0 * torch.randn(N, 1, generator=gen)).requires_grad_(True)
+        scores = torch.sigmoid(logits)
+        idx_edge = torch.nonzero((yp[:, 0] == -1))[:, 0]
+        idx_node = torch.nonzero((yp[:, 0] != -1))[:, 0]
+        targets = create_targets(lab, na, idx_node)
+        loss_c = CELoss()(logits, targets, na, idx_node)
+        loss_f = FocalLoss(gamma=0)(scores[idx_node, 0], targets[idx_node]) + FocalLoss(gamma=0)(scores[idx_edge, 0], targets[idx_edge])
+        loss_g = FocalLoss(gamma=2, alpha=0.25, size_average=False)(scores[idx_edge, 0], targets[idx_edge])
+        (loss_c + loss_f + 0.5 * loss_g).backward()
+        pre = f'c{c}/'
+        idx, val, dense = adj_arrays(na.detach())
+        out[pre + 'node_adj_idx'] = idx.astype(np.int64)
+        out[pre + 'node_adj_val'] = val.astype(np.float32)
+        out[pre + 'node_adj_dense'] = np.int64(dense)
+        out[pre + 'N'] = np.int64(N)
+        out[pre + 'labels'] = lab.numpy().copy()
+        out[pre + 'logits'] = logits.detach().numpy().copy()
+        out[pre + 'targets'] = targets.numpy().copy()
+        out[pre + 'loss_c'] = np.float64(loss_c.item())
+        out[pre + 'loss_f'] = np.float64(loss_f.item())
+        out[pre + 'loss_g'] = np.float64(loss_g.item())
+        out[pre + 'grad_logits'] = logits.grad.numpy().copy()
+    out['meta'] = np.array(json.dumps(dict(name=name, ncalls=len(graphs), seed=seed, kind='loss',
+                                           reference='arangesh/TrackMPNN models/loss.py')))
+    path = os.path.join(out_dir, name + '.npz')
+    np.savez_compressed(path, **out)
+    print(f'{name}: calls={len(graphs)} -> {os.path.getsize(path) / 1024:.0f} KiB')
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--reference-path', default='/root/reference')
@@ -195,6 +239,8 @@ def main():
                     seed += 1
     # BDD-shaped input width (ncat=8 -> F=13), one rolling train fixture
     run_fixture('roll_bdd_diff_k0_train', args.out, '2d', 8, 64, 0, 'diff', 'train', 100, T=5, dmean=4)
+    for i in range(3):
+        run_loss_fixture(f'loss_{i}', args.out, 300 + i)
     # C1 of BASELINE.json: static 5-frame window, 20 dets/frame, 64-d, 2 MP iterations
     run_c1(args.out)
 

@@ -366,3 +366,67 @@ def random_params(cfg: OracleConfig, seed: int = 0, scale: float = 0.3) -> Dict[
         else:
             p[k] = scale * torch.randn(s, generator=g)
     return p
+
+
+# ----------------------------------------------------------------------------------------
+# training targets and losses (reference models/loss.py) -- SURVEY 8(f) row 1
+# ----------------------------------------------------------------------------------------
+def _det_sets(graph: OracleGraph):
+    """per det row: (past edge rows ascending, future edge rows ascending)"""
+    past = {int(d): [] for d in graph.det_row}
+    fut = {int(d): [] for d in graph.det_row}
+    for e, s, d in zip(graph.edge_row, graph.src, graph.dst):
+        fut[int(s)].append(int(e))
+        past[int(d)].append(int(e))
+    return past, fut
+
+
+def create_targets(labels: torch.Tensor, graph: OracleGraph) -> torch.Tensor:
+    """models/loss.py:8-44: dets keep their label; per det the LAST positive past edge and the FIRST positive
+    future edge get target 1."""
+    lab = labels.reshape(-1)
+    targets = torch.zeros_like(lab)
+    dr = torch.from_numpy(graph.det_row)
+    targets[dr] = lab[dr]
+    past, fut = _det_sets(graph)
+    for d in graph.det_row:
+        p = [e for e in past[int(d)] if lab[e] != 0]
+        f = [e for e in fut[int(d)] if lab[e] != 0]
+        if p:
+            targets[p[-1]] = 1
+        if f:
+            targets[f[0]] = 1
+    return targets
+
+
+def ce_loss(logits: torch.Tensor, targets: torch.Tensor, graph: OracleGraph) -> torch.Tensor:
+    """models/loss.py:77-115."""
+    out = logits.reshape(-1)
+    tg = targets.reshape(-1)
+    past, fut = _det_sets(graph)
+    loss = torch.zeros((), dtype=out.dtype)
+    for d in graph.det_row:
+        for rows, pick_last in ((past[int(d)], True), (fut[int(d)], False)):
+            if not rows:
+                continue
+            pos = [i for i, e in enumerate(rows) if tg[e] != 0]
+            if not pos:
+                continue
+            t = pos[-1] if pick_last else pos[0]
+            sel = out[torch.tensor(rows)]
+            loss = loss + (torch.logsumexp(sel, 0) - sel[t]) / len(rows)
+    return loss
+
+
+def focal_loss(outputs: torch.Tensor, targets: torch.Tensor, gamma=0.0, alpha=None, size_average=True) -> torch.Tensor:
+    """models/loss.py:47-74 (eps 1e-10 inside the log)."""
+    s = outputs.reshape(-1)
+    t = targets.reshape(-1) != 0
+    pt_in = torch.where(t, s, 1 - s)
+    logpt = torch.log(pt_in + 1e-10)
+    pt = torch.exp(logpt)
+    if alpha is not None:
+        a = torch.where(t, torch.tensor(float(alpha[1])), torch.tensor(float(alpha[0])))
+        logpt = logpt * a
+    loss = -1 * (1 - pt) ** gamma * logpt
+    return loss.mean() if size_average else loss.sum()

@@ -15,7 +15,13 @@ def pytest_configure(config):
 
 
 def golden_names():
-    return sorted(f[:-4] for f in os.listdir(GOLDEN_DIR) if f.endswith('.npz'))
+    """model fixtures (one rolling / static sequence each)"""
+    return sorted(f[:-4] for f in os.listdir(GOLDEN_DIR) if f.endswith('.npz') and not f.startswith('loss_'))
+
+
+def loss_golden_names():
+    """targets / loss fixtures (reference models/loss.py)"""
+    return sorted(f[:-4] for f in os.listdir(GOLDEN_DIR) if f.endswith('.npz') and f.startswith('loss_'))
 
 
 @pytest.fixture(scope='session')

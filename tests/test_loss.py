@@ -1,0 +1,105 @@
+"""Targets and losses: oracle vs the reference-generated fixtures on CPU, HIP vs fixtures on GPU."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import trackmpnn_oracle as orc
+from tests.conftest import loss_golden_names
+from tests.golden_util import Golden
+
+
+def _call(gold, c):
+    na = gold.adjacency(c, 'node_adj')
+    return (na, gold.t(f'c{c}/labels'), gold.t(f'c{c}/logits'), gold.t(f'c{c}/targets'), gold.t(f'c{c}/grad_logits'),
+            float(gold.d[f'c{c}/loss_c']), float(gold.d[f'c{c}/loss_f']), float(gold.d[f'c{c}/loss_g']))
+
+
+@pytest.mark.parametrize('name', loss_golden_names())
+def test_oracle_losses_match_reference(name):
+    gold = Golden(name)
+    for c in range(gold.ncalls):
+        na, labels, logits, targets, grad, lc, lf, lg = _call(gold, c)
+        g = orc.graph_from_adjacency(na)
+        t = orc.create_targets(labels, g)
+        assert torch.equal(t, targets), c
+        lo = logits.clone().requires_grad_(True)
+        sc = torch.sigmoid(lo)
+        dr, er = torch.from_numpy(g.det_row), torch.from_numpy(g.edge_row)
+        loss_c = orc.ce_loss(lo, t, g)
+        loss_f = orc.focal_loss(sc[dr, 0], t[dr]) + orc.focal_loss(sc[er, 0], t[er])
+        loss_g = orc.focal_loss(sc[er, 0], t[er], gamma=2, alpha=[0.75, 0.25], size_average=False)
+        assert abs(loss_c.item() - lc) <= 1e-5 * max(1.0, abs(lc))
+        assert abs(loss_f.item() - lf) <= 1e-5 * max(1.0, abs(lf))
+        assert abs(loss_g.item() - lg) <= 1e-5 * max(1.0, abs(lg))
+        (loss_c + loss_f + 0.5 * loss_g).backward()
+        assert torch.allclose(lo.grad, grad, atol=1e-5, rtol=1e-4)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('name', loss_golden_names())
+def test_hip_losses_match_reference(name):
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU')
+    from trackmpnn_amd.loss import CELoss, FocalLoss, create_targets
+    from trackmpnn_amd import graph_from_adjacency
+    dev = 'cuda:0'
+    gold = Golden(name)
+    for c in range(gold.ncalls):
+        na, labels, logits, targets, grad, lc, lf, lg = _call(gold, c)
+        na_d = na.to(dev)
+        t = create_targets(labels.to(dev), na_d, None)                      # reference signature: adjacency tensor
+        assert t.dtype == labels.dtype and torch.equal(t.cpu(), targets), c
+        g = graph_from_adjacency(na_d)
+        lo = logits.to(dev).requires_grad_(True)
+        sc = torch.sigmoid(lo)
+        dr, er = g.det_row.long(), g.edge_row.long()
+        loss_c = CELoss()(lo, t, g, None)                                   # ... or a prebuilt FrameGraph
+        loss_f = FocalLoss(gamma=0)(sc[dr, 0], t[dr]) + FocalLoss(gamma=0)(sc[er, 0], t[er])
+        loss_g = FocalLoss(gamma=2, alpha=0.25, size_average=False)(sc[er, 0], t[er])
+        assert abs(loss_c.item() - lc) <= 2e-5 * max(1.0, abs(lc))
+        assert abs(loss_f.item() - lf) <= 2e-5 * max(1.0, abs(lf))
+        assert abs(loss_g.item() - lg) <= 2e-5 * max(1.0, abs(lg))
+        (loss_c + loss_f + 0.5 * loss_g).backward()
+        assert torch.allclose(lo.grad.cpu(), grad, atol=2e-5, rtol=2e-4)
+
+
+@pytest.mark.gpu
+def test_hip_losses_at_scale_vs_torch():
+    """A 2048-window batch: CE loss against an independent torch formulation (scatter logsumexp per set)."""
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU')
+    from trackmpnn_amd import WindowBuilder, batch_windows, synth_window
+    from trackmpnn_amd.loss import CELoss, create_targets
+    dev = 'cuda:0'
+    wins = [WindowBuilder(synth_window(s, 7, 6, 20)).calls() for s in range(64)]
+    plans, _ = batch_windows(wins * 32, static=True)
+    g = plans[-1].graph.to(dev)
+    gen = torch.Generator(device=dev).manual_seed(0)
+    labels = (torch.rand(g.N, device=dev, generator=gen) < 0.15).long()
+    logits = torch.randn(g.N, 1, device=dev, generator=gen, requires_grad=True)
+    t = create_targets(labels, g)
+    loss = CELoss()(logits, t, g)
+    loss.backward()
+    # independent formulation: set id = 2*det + (0 past | 1 future) per CSR entry
+    counts = (g.rowptr[1:] - g.rowptr[:-1]).long()
+    det_of = torch.repeat_interleave(torch.arange(g.Dn, device=dev), counts)
+    row = (g.inc & 0x7FFFFFFF).long()
+    sid = 2 * det_of + (g.inc >= 0).long()
+    lo = logits.detach()[row, 0].double().requires_grad_(True)
+    S = 2 * g.Dn
+    mx = torch.full((S,), -1e30, device=dev, dtype=torch.float64).scatter_reduce(0, sid, lo.detach(), 'amax')
+    z = torch.zeros(S, device=dev, dtype=torch.float64).index_add(0, sid, torch.exp(lo - mx[sid]))
+    n = torch.zeros(S, device=dev, dtype=torch.float64).index_add(0, sid, torch.ones_like(lo))
+    tpos = t[row] != 0
+    # target entry per set: last positive (past, sid even) / first positive (future, sid odd)
+    pos_idx = torch.arange(row.numel(), device=dev)
+    last = torch.full((S,), -1, device=dev, dtype=torch.long).scatter_reduce(0, sid[tpos], pos_idx[tpos], 'amax')
+    first = torch.full((S,), 2 ** 62, device=dev, dtype=torch.long).scatter_reduce(0, sid[tpos], pos_idx[tpos], 'amin')
+    is_past = (torch.arange(S, device=dev) % 2) == 0
+    tgt = torch.where(is_past, last, torch.where(first == 2 ** 62, torch.full_like(first, -1), first))
+    has = tgt >= 0
+    ref = ((torch.log(z[has]) + mx[has] - lo[tgt[has]]) / n[has]).sum()
+    assert abs(loss.item() - ref.item()) <= 1e-5 * abs(ref.item())
+    ref.backward()
+    gref = torch.zeros(g.N, device=dev, dtype=torch.float64).index_add(0, row, lo.grad)
+    assert torch.allclose(logits.grad[:, 0].double(), gref, atol=1e-6, rtol=1e-4)

@@ -4,7 +4,8 @@
 """
 from .graph import (CallPlan, FrameGraph, WindowBuilder, batch_windows, graph_from_adjacency, graph_from_edges,
                     plan_single, synth_window)
+from .loss import CELoss, FocalLoss, create_targets
 from .track_mpnn import SparseAttention, TrackMPNN
 
-__all__ = ['TrackMPNN', 'SparseAttention', 'FrameGraph', 'CallPlan', 'graph_from_adjacency', 'graph_from_edges',
+__all__ = ['TrackMPNN', 'SparseAttention', 'create_targets', 'CELoss', 'FocalLoss', 'FrameGraph', 'CallPlan', 'graph_from_adjacency', 'graph_from_edges',
            'plan_single', 'WindowBuilder', 'batch_windows', 'synth_window']

@@ -85,6 +85,15 @@ _SIGNATURES = {
     'tmpnn_heads_bwd': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                 c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                 c_void_p, c_size_t, c_void_p]),
+    'tmpnn_targets': (c_int, [_GP, c_void_p, c_void_p, c_void_p]),
+    'tmpnn_ce_loss_ws': (c_size_t, [c_int]),
+    'tmpnn_ce_loss_fwd': (c_int, [_GP, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    'tmpnn_ce_loss_bwd': (c_int, [_GP, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    'tmpnn_focal_loss_ws': (c_size_t, [c_int]),
+    'tmpnn_focal_loss_fwd': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_float, c_int, c_float, c_float, c_void_p,
+                                     c_void_p, c_size_t, c_void_p]),
+    'tmpnn_focal_loss_bwd': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_float, c_int, c_float, c_float, c_void_p,
+                                     c_float, c_void_p, c_void_p]),
 }
 
 _lib: Optional[C.CDLL] = None

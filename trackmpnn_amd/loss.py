@@ -1,0 +1,137 @@
+"""Training targets and losses of the reference (models/loss.py) on the HIP kernels -- SURVEY 8(f) row 1.
+
+Same call surface as the reference (`train.py:73-81,112-120`):
+
+    targets = create_targets(labels, node_adj, idx_node)
+    loss_c  = CELoss()(logits, targets, node_adj, idx_node)
+    loss_f  = FocalLoss(gamma=0)(scores[idx_node, 0], targets[idx_node]) + ...
+
+`node_adj` may also be a `FrameGraph` (or `CallPlan`), which skips the adjacency conversion; `idx_node`
+is accepted for signature compatibility and ignored (the graph knows its det rows).
+"""
+from __future__ import annotations
+
+from typing import Optional, Union
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+from .graph import CallPlan, FrameGraph, graph_from_adjacency
+
+_cache = {}
+
+
+def _as_graph(adj: Union[torch.Tensor, FrameGraph, CallPlan]) -> FrameGraph:
+    if isinstance(adj, CallPlan):
+        return adj.graph
+    if isinstance(adj, FrameGraph):
+        return adj
+    key = id(adj)
+    hit = _cache.get('k')
+    if hit is not None and hit[0] == key and hit[2] is adj:
+        return hit[1]
+    g = graph_from_adjacency(adj if adj.is_cuda else adj.cuda(), None)
+    _cache['k'] = (key, g, adj)
+    return g
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _need_cuda(t: torch.Tensor, what: str):
+    if not t.is_cuda:
+        raise RuntimeError(f'{what} is on {t.device}: trackmpnn_amd runs on the MI355X HIP kernels only '
+                           '(no CPU or torch fallback exists)')
+
+
+def create_targets(labels: torch.Tensor, node_adj, idx_node=None) -> torch.Tensor:
+    """reference models/loss.py:8-44.  labels int64 [N] -> targets int64 [N]."""
+    _need_cuda(labels, 'labels')
+    g = _as_graph(node_adj)
+    lab = (labels != 0).to(torch.uint8).contiguous()
+    out = torch.empty_like(lab)
+    _lib.call('tmpnn_targets', g.cref(), lab.data_ptr(), out.data_ptr(), _stream())
+    return out.to(labels.dtype)
+
+
+class _CE(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, targets_u8, graph):
+        g: FrameGraph = graph
+        lg = logits.detach().reshape(-1).float().contiguous()
+        stats = torch.empty((max(g.Dn, 1), 2, 4), dtype=torch.float32, device=lg.device)
+        loss = torch.empty((1,), dtype=torch.float32, device=lg.device)
+        wsn = _lib.load().tmpnn_ce_loss_ws(g.Dn)
+        ws = torch.empty((wsn,), dtype=torch.float32, device=lg.device)
+        _lib.call('tmpnn_ce_loss_fwd', g.cref(), lg.data_ptr(), targets_u8.data_ptr(), stats.data_ptr(), loss.data_ptr(),
+                  ws.data_ptr(), wsn, _stream())
+        ctx.g, ctx.lg, ctx.stats, ctx.shape = g, lg, stats, logits.shape
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, d_loss):
+        g: FrameGraph = ctx.g
+        d = torch.zeros_like(ctx.lg)
+        dl = d_loss.reshape(1).float().contiguous()
+        _lib.call('tmpnn_ce_loss_bwd', g.cref(), _lib.ptr(g.src_pos), _lib.ptr(g.dst_pos), ctx.lg.data_ptr(),
+                  ctx.stats.data_ptr(), dl.data_ptr(), d.data_ptr(), _stream())
+        return d.reshape(ctx.shape), None, None
+
+
+class CELoss(nn.Module):
+    """reference models/loss.py:77-115: per det, softmax cross-entropy over its past / future incident edge
+    logits against the (last / first) positive target of the set, divided by the set size; summed."""
+
+    def forward(self, outputs, targets, node_adj, idx_node=None):
+        _need_cuda(outputs, 'outputs')
+        g = _as_graph(node_adj)
+        t8 = (targets.reshape(-1) != 0).to(torch.uint8).contiguous()
+        return _CE.apply(outputs, t8, g)
+
+
+class _Focal(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, outputs, targets_u8, gamma, use_alpha, a0, a1, mean):
+        s = outputs.detach().reshape(-1).float().contiguous()
+        R = s.numel()
+        loss = torch.empty((1,), dtype=torch.float32, device=s.device)
+        wsn = _lib.load().tmpnn_focal_loss_ws(R)
+        ws = torch.empty((wsn,), dtype=torch.float32, device=s.device)
+        rows = torch.arange(R, dtype=torch.int32, device=s.device)
+        _lib.call('tmpnn_focal_loss_fwd', rows.data_ptr(), R, s.data_ptr(), targets_u8.data_ptr(), float(gamma),
+                  int(use_alpha), float(a0), float(a1), loss.data_ptr(), ws.data_ptr(), wsn, _stream())
+        ctx.s, ctx.t, ctx.rows, ctx.args = s, targets_u8, rows, (float(gamma), int(use_alpha), float(a0), float(a1))
+        ctx.scale = (1.0 / R) if (mean and R > 0) else 1.0
+        ctx.shape = outputs.shape
+        return (loss * ctx.scale).reshape(()) if R > 0 else loss.reshape(()) * float('nan') if mean else loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, d_loss):
+        d = torch.zeros_like(ctx.s)
+        dl = d_loss.reshape(1).float().contiguous()
+        gamma, ua, a0, a1 = ctx.args
+        _lib.call('tmpnn_focal_loss_bwd', ctx.rows.data_ptr(), ctx.s.numel(), ctx.s.data_ptr(), ctx.t.data_ptr(), gamma,
+                  ua, a0, a1, dl.data_ptr(), float(ctx.scale), d.data_ptr(), _stream())
+        return d.reshape(ctx.shape), None, None, None, None, None, None
+
+
+class FocalLoss(nn.Module):
+    """reference models/loss.py:47-74 (gamma = 0 is the BCE with eps 1e-10 the reference trains with)."""
+
+    def __init__(self, gamma=0, alpha=None, size_average=True):
+        super().__init__()
+        self.gamma = gamma
+        self.alpha = alpha
+        if isinstance(alpha, (float, int)):
+            self.alpha = [1 - alpha, alpha]
+        self.size_average = size_average
+        self.eps = 1e-10
+
+    def forward(self, outputs, targets):
+        _need_cuda(outputs, 'outputs')
+        t8 = (targets.reshape(-1) != 0).to(torch.uint8).contiguous()
+        ua = self.alpha is not None
+        a0, a1 = (float(self.alpha[0]), float(self.alpha[1])) if ua else (1.0, 1.0)
+        return _Focal.apply(outputs, t8, self.gamma, ua, a0, a1, self.size_average)
