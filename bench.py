@@ -247,6 +247,9 @@ def main():
     ap.add_argument('--windows', type=int, default=16384, help='tracking windows per GPU per step')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-stage-profile', action='store_true')
+    ap.add_argument('--backend', default='nccl', help='torch.distributed backend (nccl = RCCL; gloo only to rehearse '
+                    'the N > 1 code path with several ranks sharing one GPU)')
+    ap.add_argument('--single-device', action='store_true', help='rehearsal: every rank uses cuda:0')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', '0'))
@@ -256,12 +259,17 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit('launch with python -m torch.distributed.run --nproc-per-node N for --gpus N > 1')
     os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    if args.single_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', device_id=dev)
+        if args.backend == 'nccl':
+            dist.init_process_group('nccl', device_id=dev)
+        else:
+            dist.init_process_group(args.backend)
 
     import __graft_entry__
     if rank == 0:
