@@ -13,6 +13,7 @@
 //     touches HBM; the type-masked merge (row I) is the row indirection of the store.
 // Exact fp32 (MFMA f32 == fmaf chain), within 1e-6 of torch.nn.GRUCell.
 #include "common.h"
+#include <algorithm>
 
 namespace tmpnn {
 
@@ -1016,6 +1017,183 @@ __global__ __launch_bounds__(256, 2) void k_gru_bwd_weights_lds(GruBwdWArgs a, i
 }
 
 
+// Weight gradient for the wide cells (H or IN a multiple of 64 beyond the 64/64 case): the same block-staged
+// scheme, tiled over the OUTPUT.  blockIdx.y = (fc, cc) picks 64 hidden features (-> 192 rows of dW: the
+// r, z and n gate of those features) and 128 columns of [x | h]; blockIdx.x is the row slab.  Per 32-row
+// tile the block forms d_g = [dr|dz|dn|dn*r] for its 64 features and the 128-column operand slice in LDS
+// (48 KiB, two blocks per CU) and each wave accumulates 3 x 2 output tiles, as above.  A 64-column half of
+// a chunk never straddles the x / h boundary (IN, H multiples of 64), so a wave is wholly dW_ih or dW_hh.
+template <int XMODE, int UP>
+__global__ __launch_bounds__(256, 2) void k_gru_bwd_weights_chunk(GruBwdWArgs a, int ntiles, int n_cc) {
+    constexpr int FC = 64, CC = 128, DG = 4 * FC, RT = 32;
+    __shared__ float s_dg[RT * DG];
+    __shared__ float s_xh[RT * CC];
+    const int H = a.H, IN = a.IN, XH = IN + H;
+    const int fc = blockIdx.y / n_cc, cc = blockIdx.y % n_cc;
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63;
+    const int c = lane & 31, half = lane >> 5;
+    const int col0 = cc * CC + (wave >> 1) * 64;     // first [x|h] column of this wave's two column tiles
+    const bool col_live = col0 < XH;
+    const bool is_h = col0 >= IN;
+    const int jt0 = (wave & 1) * 3;                  // chunk-local j tiles: gate = jt >> 1, 32-half = jt & 1
+    const size_t gp = a.gate_plane;
+    const int srow = tid >> 3, q8 = tid & 7;
+    const int f8 = fc * FC + q8 * 8;                 // this thread's 8 hidden features
+    const int vc0 = cc * CC + q8 * 16;               // ... and its 16 operand columns
+
+    f32x16 acc[3][2];
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[j][t][i] = 0.f;
+    float csum = 0.f;
+    int colA[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const int jj = (jt0 + j) * 32 + c;
+        colA[j] = (is_h && jj >= 2 * FC) ? jj + FC : jj;
+    }
+    const int colB0 = (wave >> 1) * 64 + c;
+
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int lpos_raw = tile * RT + srow;
+        const bool valid = lpos_raw < a.R;
+        const int lpos = valid ? lpos_raw : a.R - 1;
+        const int orow = a.rows[lpos];
+        float4 xv[4];
+        if (vc0 >= XH) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) xv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        } else if (vc0 >= IN) {
+            const float4* p = reinterpret_cast<const float4*>(a.h + (size_t)orow * a.ld_h + (vc0 - IN));
+#pragma unroll
+            for (int i = 0; i < 4; ++i) xv[i] = p[i];
+        } else if (XMODE == 0) {
+            const float4* p = reinterpret_cast<const float4*>(a.msg + (size_t)(a.msg_compact ? lpos : orow) * a.ld_msg + vc0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) xv[i] = p[i];
+        } else if (XMODE == 1) {
+            const float4* p = reinterpret_cast<const float4*>(a.h + (size_t)a.src[lpos] * a.ld_h + vc0);
+            const float4* q = reinterpret_cast<const float4*>(a.h + (size_t)a.dst[lpos] * a.ld_h + vc0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float4 u = p[i], v = q[i];
+                xv[i] = make_float4(u.x - v.x, u.y - v.y, u.z - v.z, u.w - v.w);
+            }
+        } else {
+            const float4* p = vc0 < H ? reinterpret_cast<const float4*>(a.h + (size_t)a.src[lpos] * a.ld_h + vc0)
+                                      : reinterpret_cast<const float4*>(a.h + (size_t)a.dst[lpos] * a.ld_h + (vc0 - H));
+#pragma unroll
+            for (int i = 0; i < 4; ++i) xv[i] = p[i];
+        }
+        float dh[8], r[8], z[8], n[8], hn[8], hp[8];
+        {
+            const float4* p;
+            float4 u, v;
+            if (UP & 1) {
+                p = reinterpret_cast<const float4*>(a.up.d_hout + (size_t)orow * a.up.ld_dhout + f8);
+                u = p[0]; v = p[1];
+            } else {
+                u = make_float4(0.f, 0.f, 0.f, 0.f); v = u;
+            }
+            if (UP & 2) {
+                const float d = a.up.dy[orow];
+                const float4* q = reinterpret_cast<const float4*>(a.up.w_head + f8);
+                const float4 w0 = q[0], w1 = q[1];
+                u.x += d * w0.x; u.y += d * w0.y; u.z += d * w0.z; u.w += d * w0.w;
+                v.x += d * w1.x; v.y += d * w1.y; v.z += d * w1.z; v.w += d * w1.w;
+            }
+            dh[0] = u.x; dh[1] = u.y; dh[2] = u.z; dh[3] = u.w; dh[4] = v.x; dh[5] = v.y; dh[6] = v.z; dh[7] = v.w;
+            p = reinterpret_cast<const float4*>(a.gates + (size_t)orow * H + f8);
+            u = p[0]; v = p[1];
+            r[0] = u.x; r[1] = u.y; r[2] = u.z; r[3] = u.w; r[4] = v.x; r[5] = v.y; r[6] = v.z; r[7] = v.w;
+            p = reinterpret_cast<const float4*>(a.gates + gp + (size_t)orow * H + f8);
+            u = p[0]; v = p[1];
+            z[0] = u.x; z[1] = u.y; z[2] = u.z; z[3] = u.w; z[4] = v.x; z[5] = v.y; z[6] = v.z; z[7] = v.w;
+            p = reinterpret_cast<const float4*>(a.gates + 2 * gp + (size_t)orow * H + f8);
+            u = p[0]; v = p[1];
+            n[0] = u.x; n[1] = u.y; n[2] = u.z; n[3] = u.w; n[4] = v.x; n[5] = v.y; n[6] = v.z; n[7] = v.w;
+            p = reinterpret_cast<const float4*>(a.gates + 3 * gp + (size_t)orow * H + f8);
+            u = p[0]; v = p[1];
+            hn[0] = u.x; hn[1] = u.y; hn[2] = u.z; hn[3] = u.w; hn[4] = v.x; hn[5] = v.y; hn[6] = v.z; hn[7] = v.w;
+            p = reinterpret_cast<const float4*>(a.h + (size_t)orow * a.ld_h + f8);
+            u = p[0]; v = p[1];
+            hp[0] = u.x; hp[1] = u.y; hp[2] = u.z; hp[3] = u.w; hp[4] = v.x; hp[5] = v.y; hp[6] = v.z; hp[7] = v.w;
+        }
+        float dr[8], dz[8], dn[8], dnr[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float d0 = valid ? dh[i] : 0.f;
+            const float t = d0 * (1.0f - z[i]) * (1.0f - n[i] * n[i]);
+            dn[i] = t;
+            dnr[i] = t * r[i];
+            dr[i] = t * hn[i] * r[i] * (1.0f - r[i]);
+            dz[i] = d0 * (hp[i] - n[i]) * z[i] * (1.0f - z[i]);
+        }
+        __syncthreads();                         // the previous tile's MFMA phase has drained the LDS
+        {
+            float* d = s_dg + srow * DG + q8 * 8;
+            *reinterpret_cast<float4*>(d) = make_float4(dr[0], dr[1], dr[2], dr[3]);
+            *reinterpret_cast<float4*>(d + 4) = make_float4(dr[4], dr[5], dr[6], dr[7]);
+            *reinterpret_cast<float4*>(d + FC) = make_float4(dz[0], dz[1], dz[2], dz[3]);
+            *reinterpret_cast<float4*>(d + FC + 4) = make_float4(dz[4], dz[5], dz[6], dz[7]);
+            *reinterpret_cast<float4*>(d + 2 * FC) = make_float4(dn[0], dn[1], dn[2], dn[3]);
+            *reinterpret_cast<float4*>(d + 2 * FC + 4) = make_float4(dn[4], dn[5], dn[6], dn[7]);
+            *reinterpret_cast<float4*>(d + 3 * FC) = make_float4(dnr[0], dnr[1], dnr[2], dnr[3]);
+            *reinterpret_cast<float4*>(d + 3 * FC + 4) = make_float4(dnr[4], dnr[5], dnr[6], dnr[7]);
+            float* e = s_xh + srow * CC + q8 * 16;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) *reinterpret_cast<float4*>(e + 4 * i) = xv[i];
+        }
+        __syncthreads();
+        if (cc == 0) {
+#pragma unroll 8
+            for (int rr = 0; rr < RT; ++rr) csum += s_dg[rr * DG + tid];
+        }
+        if (col_live) {
+#pragma unroll 4
+            for (int s = 0; s < RT / 2; ++s) {
+                const float* ar = s_dg + (2 * s + half) * DG;
+                const float* br = s_xh + (2 * s + half) * CC + colB0;
+                float av[3], bv[2];
+#pragma unroll
+                for (int j = 0; j < 3; ++j) av[j] = ar[colA[j]];
+#pragma unroll
+                for (int t = 0; t < 2; ++t) bv[t] = br[t * 32];
+#pragma unroll
+                for (int j = 0; j < 3; ++j)
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) acc[j][t] = mfma32(av[j], bv[t], acc[j][t]);
+            }
+        }
+    }
+    if (col_live) {
+        float* sw = a.slab_w + (size_t)blockIdx.x * (3 * H) * XH;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int jt = jt0 + j;
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    const int jj = (jt >> 1) * H + fc * FC + (jt & 1) * 32 + acc_row(reg, half);
+                    sw[(size_t)jj * XH + col0 + t * 32 + c] = acc[j][t][reg];
+                }
+        }
+    }
+    if (cc == 0) {
+        float* sb = a.slab_b + (size_t)blockIdx.x * 6 * H;
+        const int g = tid / FC, f = fc * FC + tid % FC;
+        if (g < 3) sb[g * H + f] = csum;                  // d_gi sums: dr | dz | dn
+        if (g < 2) sb[3 * H + g * H + f] = csum;          // d_gh sums: dr | dz | dn*r
+        if (g == 3) sb[3 * H + 2 * H + f] = csum;
+    }
+}
+
+
 // ==========================================================================================
 // Fused backward of one cell (H = 64, IN = H): data gradient AND weight gradient from ONE pass over
 // the gates.  The two stand-alone kernels each stream dh, the four gate planes and h (1.5 KB per row);
@@ -1458,6 +1636,15 @@ static int weights_lds_blocks(int R) {
     const int ntiles = ceil_div(R, 32);
     return ntiles < 512 ? ntiles : 512;          // persistent: <= 2 blocks per CU
 }
+// output-tiled kernel for the wide cells: (H/64) x ceil((IN+H)/128) output chunks per row slab
+static bool weights_use_chunk(int IN, int H) { return H % 64 == 0 && IN % 64 == 0 && !weights_use_lds(IN, H); }
+static int weights_chunk_slabs(int R, int IN, int H) {
+    const int ntiles = ceil_div(R, 32);
+    const int per = (H / 64) * ceil_div(IN + H, 128);
+    int want = 1024 / per;
+    if (want < 1) want = 1;
+    return ntiles < want ? ntiles : want;
+}
 
 
 static int fused_blocks(int R) {
@@ -1543,7 +1730,9 @@ size_t tmpnn_gru_bwd_weights_ws(int R, int IN, int H) {
     if (R <= 0) return 0;
     int n_rs, RS, NQ, NCH;
     plan_weights(R, IN, H, &n_rs, &RS, &NQ, &NCH);
-    if (weights_use_lds(IN, H)) n_rs = weights_lds_blocks(R);
+    // the staged kernels need aligned operands; size for whichever path the call ends up on
+    if (weights_use_lds(IN, H)) n_rs = std::max(n_rs, weights_lds_blocks(R));
+    if (weights_use_chunk(IN, H)) n_rs = std::max(n_rs, weights_chunk_slabs(R, IN, H));
     const size_t per = (size_t)3 * H * (IN + H) + (size_t)6 * H;
     return ((size_t)n_rs * per + reduce_slabs_ws_floats(n_rs, per)) * sizeof(float);
 }
@@ -1568,11 +1757,13 @@ int tmpnn_gru_bwd_weights(const int32_t* rows, int R, int xmode, const int32_t* 
         return set_error(TMPNN_EWORKSPACE, "gru_bwd_weights: workspace %zu < %zu bytes", ws_bytes, need);
     int n_rs, RS, NQ, NCH;
     plan_weights(R, IN, H, &n_rs, &RS, &NQ, &NCH);
-    const bool use_lds = weights_use_lds(IN, H) && xmode != 2 && (ld_h & 3) == 0 &&
-                         (d_hout == nullptr || ((ld_dhout & 3) == 0 && aligned16(d_hout))) &&
-                         aligned16(h) && aligned16(gates) && (gate_plane & 3) == 0 &&
-                         (xmode != 0 || ((ld_msg & 3) == 0 && aligned16(msg)));
+    const bool vec_ok = (ld_h & 3) == 0 && (d_hout == nullptr || ((ld_dhout & 3) == 0 && aligned16(d_hout))) &&
+                        aligned16(h) && aligned16(gates) && (gate_plane & 3) == 0 &&
+                        (xmode != 0 || ((ld_msg & 3) == 0 && aligned16(msg)));
+    const bool use_lds = weights_use_lds(IN, H) && xmode != 2 && vec_ok;
+    const bool use_chunk = weights_use_chunk(IN, H) && vec_ok;
     if (use_lds) n_rs = weights_lds_blocks(R);
+    if (use_chunk) n_rs = weights_chunk_slabs(R, IN, H);
     const size_t nW = (size_t)3 * H * (IN + H), nB = (size_t)6 * H;
     float* slab_w = reinterpret_cast<float*>(ws);
     float* slab_b = slab_w + (size_t)n_rs * nW;
@@ -1591,6 +1782,17 @@ int tmpnn_gru_bwd_weights(const int32_t* rows, int R, int xmode, const int32_t* 
         else            { if (up == 1) LW(1, 1); else if (up == 2) LW(1, 2); else LW(1, 3); }
 #undef LW
         rc = check_launch("gru_bwd_weights_lds");
+    } else if (use_chunk) {
+        const int ntiles = ceil_div(R, 32);
+        const int n_cc = ceil_div(IN + H, 128);
+        dim3 grid(n_rs, (H / 64) * n_cc), block(256);
+        const int up = (d_hout ? 1 : 0) | (dy ? 2 : 0);
+#define LW(X, U) hipLaunchKernelGGL((k_gru_bwd_weights_chunk<X, U>), grid, block, 0, st, a, ntiles, n_cc)
+#define LWU(X) do { if (up == 1) LW(X, 1); else if (up == 2) LW(X, 2); else LW(X, 3); } while (0)
+        if (xmode == 0) LWU(0); else if (xmode == 1) LWU(1); else LWU(2);
+#undef LWU
+#undef LW
+        rc = check_launch("gru_bwd_weights_chunk");
     } else {
         const long nworkers = (long)n_rs * NQ * NCH;
         dim3 grid(ceil_div(nworkers, 4)), block(256);
