@@ -1624,9 +1624,11 @@ int tmpnn_gru_bwd_data(const int32_t* rows, int R, int IN, const float* h, int l
 #undef L3
         return check_launch("gru_bwd_data_lds");
     }
-    const int NT = (H % 64 == 0) ? 2 : 1;
+    // wider column blocks re-read (and re-derive) the gate planes fewer times
+    const int NT = (H % 128 == 0 && IN % 128 == 0) ? 4 : (H % 64 == 0) ? 2 : 1;
     dim3 grid(ceil_div(R, 128), (IN + H) / (32 * NT)), block(256);
-    if (NT == 2) hipLaunchKernelGGL((k_gru_bwd_data<2>), grid, block, 0, st, a);
+    if (NT == 4) hipLaunchKernelGGL((k_gru_bwd_data<4>), grid, block, 0, st, a);
+    else if (NT == 2) hipLaunchKernelGGL((k_gru_bwd_data<2>), grid, block, 0, st, a);
     else hipLaunchKernelGGL((k_gru_bwd_data<1>), grid, block, 0, st, a);
     return check_launch("gru_bwd_data");
 }
