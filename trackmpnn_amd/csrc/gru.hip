@@ -14,6 +14,7 @@
 // Exact fp32 (MFMA f32 == fmaf chain), within 1e-6 of torch.nn.GRUCell.
 #include "common.h"
 #include <algorithm>
+#include <stdlib.h>
 
 namespace tmpnn {
 
@@ -28,6 +29,60 @@ __device__ __forceinline__ float tanhf_(float x) {
 
 __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+
+// ------------------------------------------------------------------------------------------
+// fp32 products on the bf16 matrix pipe ("bf16x6").  The f32-input MFMA runs at 1/16 of the bf16 rate, so a
+// GEMM whose operands are split into three bf16 pieces each, a = a1 + a2 + a3 (round-to-nearest residuals,
+// |a - a1 - a2 - a3| <= 2^-27 |a|), and evaluated as
+//     a.b ~= a3 b1 + a1 b3 + a2 b2 + a2 b1 + a1 b2 + a1 b1        (six v_mfma_f32_32x32x16_bf16)
+// costs 6/16 of the f32 instruction time.  Every partial product of two 8-bit significands is exact in the
+// f32 accumulator; the dropped terms (a2 b3, a3 b2, a3 b3) are below 2^-25 |a.b|, i.e. under the rounding of
+// one f32 fma, so the result is as accurate as the f32 MFMA chain (checked per stage against fp64).
+// ------------------------------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ uint32_t pk_bf16(float lo, float hi) {       // v_cvt_pk_bf16_f32: lo -> bits 0..15
+    bf16x2 v;
+    v[0] = (__bf16)lo; v[1] = (__bf16)hi;
+    return __builtin_bit_cast(uint32_t, v);
+}
+__device__ __forceinline__ void split_pair(float x0, float x1, uint32_t& p1, uint32_t& p2, uint32_t& p3) {
+    p1 = pk_bf16(x0, x1);
+    float r0 = x0 - __uint_as_float(p1 << 16), r1 = x1 - __uint_as_float(p1 & 0xFFFF0000u);
+    p2 = pk_bf16(r0, r1);
+    r0 -= __uint_as_float(p2 << 16);
+    r1 -= __uint_as_float(p2 & 0xFFFF0000u);
+    p3 = pk_bf16(r0, r1);
+}
+struct Split8 { uint4 p1, p2, p3; };            // eight consecutive k values as three packed-bf16 pieces
+__device__ __forceinline__ Split8 split8(const float4& u, const float4& v) {
+    Split8 s;
+    split_pair(u.x, u.y, s.p1.x, s.p2.x, s.p3.x);
+    split_pair(u.z, u.w, s.p1.y, s.p2.y, s.p3.y);
+    split_pair(v.x, v.y, s.p1.z, s.p2.z, s.p3.z);
+    split_pair(v.z, v.w, s.p1.w, s.p2.w, s.p3.w);
+    return s;
+}
+__device__ __forceinline__ f32x16 mfma_bf16(const uint4& a, const uint4& b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+// acc += A B over 16 k values, smallest terms first
+__device__ __forceinline__ f32x16 mfma_x6(const uint4& a1, const uint4& a2, const uint4& a3, const Split8& b, f32x16 c) {
+    c = mfma_bf16(a3, b.p1, c);
+    c = mfma_bf16(a1, b.p3, c);
+    c = mfma_bf16(a2, b.p2, c);
+    c = mfma_bf16(a2, b.p1, c);
+    c = mfma_bf16(a1, b.p2, c);
+    c = mfma_bf16(a1, b.p1, c);
+    return c;
+}
+// one fp32 value -> its three bf16 pieces (bit patterns)
+__device__ __forceinline__ void split1(float x, uint16_t& q1, uint16_t& q2, uint16_t& q3) {
+    uint32_t p1, p2, p3;
+    split_pair(x, 0.f, p1, p2, p3);
+    q1 = (uint16_t)p1; q2 = (uint16_t)p2; q3 = (uint16_t)p3;
 }
 
 // row (within the wave's 32) held by accumulator register `reg` of lane-half `half`
@@ -667,6 +722,160 @@ __global__ __launch_bounds__(WPB * 64) void k_gru_fwd_lds(GruFwdArgs a, int ntil
     }
 }
 
+// XMODE 3 forward on the bf16 pipe (bf16x6, see mfma_x6).  Same persistent structure and the same epilogue as
+// k_gru_fwd_lds<H, H, 3, 1, WPB>; what changes is the operand path:
+//   * W_hh sits in LDS as three bf16 pieces [piece][3H][H + 8] (k contiguous, rows padded by 16 bytes),
+//     read as one ds_read_b128 per piece and 16-deep k block;
+//   * a lane's operand is H/2 CONTIGUOUS floats of its state row (k = (H/2)*half + 8*kb + j), split into
+//     pieces in registers; the whole next-item operand is requested before this item's matrix phase, so no
+//     operand load is ever queued behind this item's gate stores.
+template <int H, int WPB>
+__global__ __launch_bounds__(WPB * 64) void k_gru_fwd_split(GruFwdArgs a) {
+    extern __shared__ float lds[];
+    constexpr int H3 = 3 * H, KP = H + 8, NKB = H / 16, CW = H / 32, NQ4 = H / 8;   // NQ4 float4 per lane operand
+    uint16_t* sW = reinterpret_cast<uint16_t*>(lds);                  // [3][3H][KP]
+    for (int i = threadIdx.x; i < H * H3 / 4; i += WPB * 64) {
+        const int k = i / (H3 / 4), j0 = (i % (H3 / 4)) * 4;
+        const float4 w = *reinterpret_cast<const float4*>(a.whh_t + (size_t)k * H3 + j0);
+        const float wv[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            uint16_t q1, q2, q3;
+            split1(wv[e], q1, q2, q3);
+            sW[(0 * H3 + j0 + e) * KP + k] = q1;
+            sW[(1 * H3 + j0 + e) * KP + k] = q2;
+            sW[(2 * H3 + j0 + e) * KP + k] = q3;
+        }
+    }
+    float* stg_base = reinterpret_cast<float*>(sW + 3 * H3 * KP);
+    int* next_item = reinterpret_cast<int*>(stg_base + WPB * (32 * STG_LD));
+    if (threadIdx.x == 0) *next_item = 0;
+    __syncthreads();
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int c = lane & 31, half = lane >> 5;
+    {
+        const int grp = __builtin_amdgcn_readfirstlane(wave) >> 2;
+        if (grp == 0) __builtin_amdgcn_s_setprio(3);
+        else if (grp == 1) __builtin_amdgcn_s_setprio(2);
+        else if (grp == 2) __builtin_amdgcn_s_setprio(1);
+    }
+    const int items_total = ((a.R + 31) / 32) * CW;
+    const int per_block = (items_total + gridDim.x - 1) / gridDim.x;
+    const int item_lo = blockIdx.x * per_block;
+    const int item_hi = min(items_total, item_lo + per_block);
+
+    int item = 0;
+    if (lane == 0) item = atomicAdd(next_item, 1);
+    item = __builtin_amdgcn_readfirstlane(item) + item_lo;
+    if (item >= item_hi) return;
+    int cw0 = (item % CW) * 32;
+    int r0 = (item / CW) * 32;
+    TileIdx ix = tile_idx<3>(a, r0, c);
+    float4 raw[NQ4];
+    {
+        const float4* xr = reinterpret_cast<const float4*>(a.h + (size_t)ix.row * a.ld_h + (H / 2) * half);
+#pragma unroll
+        for (int i = 0; i < NQ4; ++i) raw[i] = xr[i];
+    }
+    float* stg = stg_base + wave * (32 * STG_LD);
+
+    for (;;) {
+        int nitem = 0;
+        if (lane == 0) nitem = atomicAdd(next_item, 1);
+        nitem = __builtin_amdgcn_readfirstlane(nitem) + item_lo;
+        const bool nvalid = nitem < item_hi;
+        const int ncw0 = (nitem % CW) * 32;
+        const int nr0 = nvalid ? (nitem / CW) * 32 : r0;
+        const TileIdx nix = tile_idx<3>(a, nr0, c);
+        const int row = ix.row;
+        Split8 b[NKB];
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb) b[kb] = split8(raw[2 * kb], raw[2 * kb + 1]);
+        if (nvalid) {
+            const float4* xr = reinterpret_cast<const float4*>(a.h + (size_t)nix.row * a.ld_h + (H / 2) * half);
+#pragma unroll
+            for (int i = 0; i < NQ4; ++i) raw[i] = xr[i];
+        }
+        f32x16 acc_r, acc_z, acc_hn, acc_in;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { acc_r[i] = 0.f; acc_z[i] = 0.f; acc_hn[i] = 0.f; }
+        {
+            const uint16_t* wp0 = sW + (cw0 + c) * KP + (H / 2) * half;
+#pragma unroll
+            for (int kb = 0; kb < NKB; ++kb) {
+                const uint16_t* wp = wp0 + 8 * kb;
+#pragma unroll
+                for (int g = 0; g < 3; ++g) {
+                    const uint4 w1 = *reinterpret_cast<const uint4*>(wp + (g * H) * KP);
+                    const uint4 w2 = *reinterpret_cast<const uint4*>(wp + (H3 + g * H) * KP);
+                    const uint4 w3 = *reinterpret_cast<const uint4*>(wp + (2 * H3 + g * H) * KP);
+                    if (g == 0) acc_r = mfma_x6(w1, w2, w3, b[kb], acc_r);
+                    else if (g == 1) acc_z = mfma_x6(w1, w2, w3, b[kb], acc_z);
+                    else acc_hn = mfma_x6(w1, w2, w3, b[kb], acc_hn);
+                }
+            }
+        }
+        // epilogue: as in k_gru_fwd_lds (lane = its own row, accumulator register 4q+i <-> feature 8q + 4*half + i)
+        float4 hp4[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            hp4[q] = *reinterpret_cast<const float4*>(a.h + (size_t)row * a.ld_h + cw0 + 8 * q + 4 * half);
+        f32x16 outv;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int col = cw0 + 8 * q + 4 * half;
+            const float4 bir = *reinterpret_cast<const float4*>(a.b_ih + col);
+            const float4 bhr = *reinterpret_cast<const float4*>(a.b_hh + col);
+            const float4 biz = *reinterpret_cast<const float4*>(a.b_ih + H + col);
+            const float4 bhz = *reinterpret_cast<const float4*>(a.b_hh + H + col);
+            const float4 bin = *reinterpret_cast<const float4*>(a.b_ih + 2 * H + col);
+            const float4 bhn = *reinterpret_cast<const float4*>(a.b_hh + 2 * H + col);
+            const float br[4] = {bir.x + bhr.x, bir.y + bhr.y, bir.z + bhr.z, bir.w + bhr.w};
+            const float bz[4] = {biz.x + bhz.x, biz.y + bhz.y, biz.z + bhz.z, biz.w + bhz.w};
+            const float bi[4] = {bin.x, bin.y, bin.z, bin.w};
+            const float bh[4] = {bhn.x, bhn.y, bhn.z, bhn.w};
+            const float hp[4] = {hp4[q].x, hp4[q].y, hp4[q].z, hp4[q].w};
+            const float* ps = a.msg + (size_t)ix.s * a.ld_msg + col;
+            const float* pd = a.msg + (size_t)ix.d * a.ld_msg + col;
+            const float4 sr = *reinterpret_cast<const float4*>(ps), dr = *reinterpret_cast<const float4*>(pd);
+            const float4 sz = *reinterpret_cast<const float4*>(ps + H), dz = *reinterpret_cast<const float4*>(pd + H);
+            const float4 sn = *reinterpret_cast<const float4*>(ps + 2 * H), dn = *reinterpret_cast<const float4*>(pd + 2 * H);
+            const float xr[4] = {sr.x - dr.x, sr.y - dr.y, sr.z - dr.z, sr.w - dr.w};
+            const float xz[4] = {sz.x - dz.x, sz.y - dz.y, sz.z - dz.z, sz.w - dz.w};
+            const float xn[4] = {sn.x - dn.x, sn.y - dn.y, sn.z - dn.z, sn.w - dn.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int reg = 4 * q + i;
+                const float ro = sigmoidf_(acc_r[reg] + xr[i] + br[i]);
+                const float zo = sigmoidf_(acc_z[reg] + xz[i] + bz[i]);
+                const float ho = acc_hn[reg] + bh[i];
+                const float no = tanhf_(xn[i] + bi[i] + ro * ho);
+                outv[reg] = (1.0f - zo) * no + zo * hp[i];
+                acc_r[reg] = ro; acc_z[reg] = zo; acc_hn[reg] = ho; acc_in[reg] = no;
+            }
+        }
+        if (a.logit_part) {
+            float p = 0.f;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 w = *reinterpret_cast<const float4*>(a.w_head + cw0 + 8 * q + 4 * half);
+                p += outv[4 * q] * w.x + outv[4 * q + 1] * w.y + outv[4 * q + 2] * w.z + outv[4 * q + 3] * w.w;
+            }
+            p += __shfl_xor(p, 32);
+            if (half == 0 && r0 + c < a.R) a.logit_part[(size_t)(cw0 / 32) * a.part_stride + row] = p;
+        }
+        stage_store32(stg, c, half, lane, outv, a.h_out, a.ld_out, cw0, row, r0, a.R);
+        if (a.gates) {
+            stage_store32<true>(stg, c, half, lane, acc_r, a.gates, H, cw0, row, r0, a.R);
+            stage_store32<true>(stg, c, half, lane, acc_z, a.gates + a.gate_plane, H, cw0, row, r0, a.R);
+            stage_store32<true>(stg, c, half, lane, acc_in, a.gates + 2 * a.gate_plane, H, cw0, row, r0, a.R);
+            stage_store32<true>(stg, c, half, lane, acc_hn, a.gates + 3 * a.gate_plane, H, cw0, row, r0, a.R);
+        }
+        if (!nvalid) break;
+        cw0 = ncw0; r0 = nr0; ix = nix;
+    }
+}
+
 // out[r][0:NOUT] = in[rows[r]][0:H] @ Wt[H][NOUT]   (no bias; H <= 64; NOUT multiple of 32).  Used to
 // project the det rows once per call (P = h[dets] W_ih^T) for the XMODE 3 forward.
 template <int H, int NT>     // NT = NOUT / 32 column tiles, all owned by one wave
@@ -708,6 +917,67 @@ __global__ __launch_bounds__(512) void k_rows_gemm_lds(const int32_t* __restrict
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             stage_store32(stg, c, half, lane, acc[t], out, ld_out, t * 32, li, r0, R);   // compact rows: list position
+        }
+    }
+}
+
+// The same projection on the bf16 pipe (bf16x6, see mfma_x6): the weight pieces sit in LDS as [piece][out col][k]
+// bf16 with k contiguous (rows padded by 16 bytes: conflict-free ds_read_b128), a lane's 8 operand values per
+// MFMA are 8 consecutive k of its row.  k is enumerated as k = (H/2)*(lane>>5) + 8*kb + j, so a lane reads H/2
+// CONTIGUOUS floats of its row.
+template <int H, int NT>
+__global__ __launch_bounds__(512) void k_rows_gemm_split(const int32_t* __restrict__ rows, int R,
+                                                         const float* __restrict__ in, int ld_in,
+                                                         const float* __restrict__ wt, float* __restrict__ out,
+                                                         int ld_out, int ntiles) {
+    extern __shared__ float lds[];
+    constexpr int NOUT = NT * 32, KP = H + 8, NKB = H / 16;
+    uint16_t* sW = reinterpret_cast<uint16_t*>(lds);          // [3][NOUT][KP]
+    for (int i = threadIdx.x; i < H * NOUT / 4; i += 512) {
+        const int k = i / (NOUT / 4), j0 = (i % (NOUT / 4)) * 4;
+        const float4 w = *reinterpret_cast<const float4*>(wt + (size_t)k * NOUT + j0);
+        const float wv[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            uint16_t q1, q2, q3;
+            split1(wv[e], q1, q2, q3);
+            sW[(0 * NOUT + j0 + e) * KP + k] = q1;
+            sW[(1 * NOUT + j0 + e) * KP + k] = q2;
+            sW[(2 * NOUT + j0 + e) * KP + k] = q3;
+        }
+    }
+    __syncthreads();
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int c = lane & 31, half = lane >> 5;
+    float* stg = reinterpret_cast<float*>(sW + 3 * NOUT * KP) + wave * (32 * STG_LD);
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int r0 = (tile * 8 + wave) * 32;
+        if (r0 >= R) continue;
+        const int li = min(r0 + c, R - 1);
+        const int row = rows[li];
+        const float4* xr = reinterpret_cast<const float4*>(in + (size_t)row * ld_in + (H / 2) * half);
+        Split8 b[NKB];
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb) b[kb] = split8(xr[2 * kb], xr[2 * kb + 1]);
+        f32x16 acc[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+#pragma unroll
+            for (int kb = 0; kb < NKB; ++kb) {
+                const uint16_t* wp = sW + (t * 32 + c) * KP + (H / 2) * half + 8 * kb;
+                const uint4 w1 = *reinterpret_cast<const uint4*>(wp);
+                const uint4 w2 = *reinterpret_cast<const uint4*>(wp + NOUT * KP);
+                const uint4 w3 = *reinterpret_cast<const uint4*>(wp + 2 * NOUT * KP);
+                acc[t] = mfma_x6(w1, w2, w3, b[kb], acc[t]);
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            stage_store32(stg, c, half, lane, acc[t], out, ld_out, t * 32, li, r0, R);
         }
     }
 }
@@ -1467,6 +1737,12 @@ __global__ void k_fold_slabs_gru(const float* __restrict__ slabs, size_t stride,
     out[(size_t)blockIdx.y * n + i] = s;
 }
 
+// TMPNN_SPLIT=0 keeps every GEMM on the f32-input MFMA (v_mfma_f32_32x32x2_f32)
+static bool split_enabled() {
+    static const int on = [] { const char* e = getenv("TMPNN_SPLIT"); return (e && e[0] == '0') ? 0 : 1; }();
+    return on != 0;
+}
+
 static void plan_weights(int R, int IN, int H, int* n_rs, int* RS, int* NQ, int* NCH) {
     *NQ = 3 * H / 32;
     *NCH = (IN + H + 127) / 128;
@@ -1531,6 +1807,20 @@ int tmpnn_gru_fwd(const int32_t* rows, int R, int xmode, const int32_t* src, con
         const int ntiles = ceil_div(R, rows_per_pass);
         dim3 pgrid(ntiles < 256 ? ntiles : 256), pblock(H == 64 ? 768 : 512);
         const int wpb = (H == 64) ? 12 : 8;
+        if (xmode == 3 && split_enabled()) {
+            // bf16x6 operand path, 8 waves (two per SIMD: the prefetched next operand needs the registers)
+            const size_t shm2 = (size_t)3 * 3 * H * (H + 8) * 2 + sizeof(float) * ((size_t)8 * 32 * STG_LD + 4);
+            if (H == 64) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gru_fwd_split<64, 8>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm2);
+                hipLaunchKernelGGL((k_gru_fwd_split<64, 8>), pgrid, dim3(512), shm2, st, a);
+            } else {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gru_fwd_split<32, 8>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm2);
+                hipLaunchKernelGGL((k_gru_fwd_split<32, 8>), pgrid, dim3(512), shm2, st, a);
+            }
+            return check_launch("gru_fwd_split");
+        }
         const size_t shm = sizeof(float) * ((size_t)((xmode == 3 ? 0 : IN) + H) * 3 * H + (size_t)wpb * 32 * STG_LD + 4);
         if (shm > 160 * 1024) goto generic;      // e.g. concat at H = 64: the weights alone take 144 KiB
 #define LL(HH, II, X, CC, WW)                                                                                \
@@ -1566,8 +1856,21 @@ int tmpnn_rows_linear(const int32_t* rows, int R, const float* in, int ld_in, in
                "rows_linear: rows must be 16-byte aligned");
     const int ntiles = ceil_div(R, 256);
     dim3 grid(ntiles < 256 ? ntiles : 256), block(512);
-    const size_t shm = sizeof(float) * ((size_t)H * NOUT + 8 * 32 * STG_LD);
     hipStream_t st = as_stream(stream);
+    if (split_enabled()) {
+        const size_t shm2 = (size_t)3 * NOUT * (H + 8) * 2 + sizeof(float) * 8 * 32 * STG_LD;
+        if (H == 64) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rows_gemm_split<64, 6>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm2);
+            hipLaunchKernelGGL((k_rows_gemm_split<64, 6>), grid, block, shm2, st, rows, R, in, ld_in, wt, out, ld_out, ntiles);
+        } else {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rows_gemm_split<32, 3>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm2);
+            hipLaunchKernelGGL((k_rows_gemm_split<32, 3>), grid, block, shm2, st, rows, R, in, ld_in, wt, out, ld_out, ntiles);
+        }
+        return check_launch("rows_linear_split");
+    }
+    const size_t shm = sizeof(float) * ((size_t)H * NOUT + 8 * 32 * STG_LD);
     if (H == 64) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rows_gemm_lds<64, 6>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
