@@ -1124,6 +1124,175 @@ __global__ __launch_bounds__(512) void k_gru_bwd_data_lds(GruBwdDataArgs a, int 
     }
 }
 
+// The same pass on the bf16 pipe (bf16x6, see mfma_x6), IN == H.  Both transposed weight matrices sit in LDS as
+// three bf16 pieces [piece][column of x|h][3H + 8] (k = gate feature j contiguous; 150 KiB at H = 64), a lane's
+// operand is 8 consecutive hidden features of its row per k block: k = g*H + 16*fblk + 8*(lane>>5) + j, so
+// the two lane halves read adjacent 32-byte runs of the same 128-byte line of every gate plane.
+struct GRaw8 { float4 dh[2], r[2], z[2], n[2], hn[2], hp[2]; };
+
+template <int UP>
+__device__ __forceinline__ void g_issue8(const GruBwdDataArgs& a, int H, int f0, int row, GRaw8& g) {
+    const size_t gp = a.gate_plane;
+    if (UP & 1) {
+        const float4* p = reinterpret_cast<const float4*>(a.up.d_hout + (size_t)row * a.up.ld_dhout + f0);
+        g.dh[0] = p[0]; g.dh[1] = p[1];
+    } else {
+        g.dh[0] = make_float4(0.f, 0.f, 0.f, 0.f); g.dh[1] = g.dh[0];
+    }
+    const float4* g0 = reinterpret_cast<const float4*>(a.gates + (size_t)row * H + f0);
+    g.r[0] = g0[0]; g.r[1] = g0[1];
+    const float4* g1 = reinterpret_cast<const float4*>(a.gates + gp + (size_t)row * H + f0);
+    g.z[0] = g1[0]; g.z[1] = g1[1];
+    const float4* g2 = reinterpret_cast<const float4*>(a.gates + 2 * gp + (size_t)row * H + f0);
+    g.n[0] = g2[0]; g.n[1] = g2[1];
+    const float4* g3 = reinterpret_cast<const float4*>(a.gates + 3 * gp + (size_t)row * H + f0);
+    g.hn[0] = g3[0]; g.hn[1] = g3[1];
+    const float4* hp = reinterpret_cast<const float4*>(a.h + (size_t)row * a.ld_h + f0);
+    g.hp[0] = hp[0]; g.hp[1] = hp[1];
+}
+
+__device__ __forceinline__ void f4_to_arr(const float4& u, const float4& v, float* o) {
+    o[0] = u.x; o[1] = u.y; o[2] = u.z; o[3] = u.w; o[4] = v.x; o[5] = v.y; o[6] = v.z; o[7] = v.w;
+}
+__device__ __forceinline__ Split8 split8_arr(const float* x) {
+    return split8(make_float4(x[0], x[1], x[2], x[3]), make_float4(x[4], x[5], x[6], x[7]));
+}
+
+template <int H, int UP, bool FUSE>
+__global__ __launch_bounds__(512) void k_gru_bwd_data_split(GruBwdDataArgs a, int ntiles) {
+    extern __shared__ float lds[];
+    constexpr int IN = H, XH = IN + H, J = 3 * H, JP = J + 8, NT = H / 32, NFB = H / 16;
+    uint16_t* sWT = reinterpret_cast<uint16_t*>(lds);         // [3][XH][JP]
+    for (int i = threadIdx.x; i < J * IN / 4; i += 512) {
+        const int j = i / (IN / 4), c0 = (i % (IN / 4)) * 4;
+        const float4 wi = *reinterpret_cast<const float4*>(a.w_ih + (size_t)j * IN + c0);
+        const float4 wh = *reinterpret_cast<const float4*>(a.w_hh + (size_t)j * H + c0);
+        const float wiv[4] = {wi.x, wi.y, wi.z, wi.w}, whv[4] = {wh.x, wh.y, wh.z, wh.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            uint16_t q1, q2, q3;
+            split1(wiv[e], q1, q2, q3);
+            sWT[(0 * XH + c0 + e) * JP + j] = q1; sWT[(1 * XH + c0 + e) * JP + j] = q2; sWT[(2 * XH + c0 + e) * JP + j] = q3;
+            split1(whv[e], q1, q2, q3);
+            sWT[(0 * XH + IN + c0 + e) * JP + j] = q1; sWT[(1 * XH + IN + c0 + e) * JP + j] = q2; sWT[(2 * XH + IN + c0 + e) * JP + j] = q3;
+        }
+    }
+    int* next_item = reinterpret_cast<int*>(sWT + 3 * XH * JP);
+    if (threadIdx.x == 0) *next_item = 0;
+    __syncthreads();
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int c = lane & 31, half = lane >> 5;
+    const size_t gp = a.gate_plane;
+    if ((__builtin_amdgcn_readfirstlane(wave) >> 2) == 0) __builtin_amdgcn_s_setprio(2);
+    const int items_total = ntiles * 8;
+    const int per_block = (items_total + gridDim.x - 1) / gridDim.x;
+    const int item_lo = blockIdx.x * per_block;
+    const int item_hi = min(items_total, item_lo + per_block);
+
+    for (;;) {
+        int item = 0;
+        if (lane == 0) item = atomicAdd(next_item, 1);
+        item = __builtin_amdgcn_readfirstlane(item) + item_lo;
+        if (item >= item_hi) break;
+        const int r0 = item * 32;
+        if (r0 >= a.R) continue;
+        const int li = min(r0 + c, a.R - 1);
+        const int row = a.rows[li];
+        const float dyr = (UP & 2) ? a.up.dy[row] : 0.f;
+        f32x16 accx[NT], acch[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { accx[t][i] = 0.f; acch[t][i] = 0.f; }
+        GRaw8 cur, nxt;
+        g_issue8<UP>(a, H, 8 * half, row, cur);
+#pragma unroll
+        for (int fb = 0; fb < NFB; ++fb) {
+            const int f0 = 16 * fb + 8 * half;
+            float dh[8], r[8], z[8], n[8], hn[8], hp[8];
+            f4_to_arr(cur.dh[0], cur.dh[1], dh); f4_to_arr(cur.r[0], cur.r[1], r); f4_to_arr(cur.z[0], cur.z[1], z);
+            f4_to_arr(cur.n[0], cur.n[1], n); f4_to_arr(cur.hn[0], cur.hn[1], hn); f4_to_arr(cur.hp[0], cur.hp[1], hp);
+            if (UP & 2) {
+                const float4 w0 = *reinterpret_cast<const float4*>(a.up.w_head + f0);
+                const float4 w1 = *reinterpret_cast<const float4*>(a.up.w_head + f0 + 4);
+                dh[0] += dyr * w0.x; dh[1] += dyr * w0.y; dh[2] += dyr * w0.z; dh[3] += dyr * w0.w;
+                dh[4] += dyr * w1.x; dh[5] += dyr * w1.y; dh[6] += dyr * w1.z; dh[7] += dyr * w1.w;
+            }
+            float ar[8], az[8], an[8], anr[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float dn = dh[i] * (1.0f - z[i]) * (1.0f - n[i] * n[i]);
+                ar[i] = dn * hn[i] * r[i] * (1.0f - r[i]);
+                az[i] = dh[i] * (hp[i] - n[i]) * z[i] * (1.0f - z[i]);
+                an[i] = dn;
+                anr[i] = dn * r[i];
+            }
+            const Split8 sr = split8_arr(ar), sz = split8_arr(az), sn = split8_arr(an), snr = split8_arr(anr);
+            if (fb + 1 < NFB) g_issue8<UP>(a, H, 16 * (fb + 1) + 8 * half, row, nxt);
+            __builtin_amdgcn_sched_barrier(0);
+            const uint16_t* wp0 = sWT + c * JP + f0;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+#pragma unroll
+                for (int g = 0; g < 3; ++g) {
+                    const uint16_t* wx = wp0 + (t * 32) * JP + g * H;
+                    const uint4 x1 = *reinterpret_cast<const uint4*>(wx);
+                    const uint4 x2 = *reinterpret_cast<const uint4*>(wx + XH * JP);
+                    const uint4 x3 = *reinterpret_cast<const uint4*>(wx + 2 * XH * JP);
+                    accx[t] = mfma_x6(x1, x2, x3, g == 0 ? sr : (g == 1 ? sz : sn), accx[t]);
+                    const uint16_t* wh = wp0 + (IN + t * 32) * JP + g * H;
+                    const uint4 h1 = *reinterpret_cast<const uint4*>(wh);
+                    const uint4 h2 = *reinterpret_cast<const uint4*>(wh + XH * JP);
+                    const uint4 h3 = *reinterpret_cast<const uint4*>(wh + 2 * XH * JP);
+                    acch[t] = mfma_x6(h1, h2, h3, g == 0 ? sr : (g == 1 ? sz : snr), acch[t]);
+                }
+            }
+            cur = nxt;
+        }
+        // epilogue: lane = its own row; register 4q+i <-> column 8q + 4*half + i of the tile
+        const bool live = r0 + c < a.R;
+        if (live) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    *reinterpret_cast<float4*>(a.d_msg + (size_t)row * a.ld_dmsg + t * 32 + 8 * q + 4 * half) =
+                        make_float4(accx[t][4 * q], accx[t][4 * q + 1], accx[t][4 * q + 2], accx[t][4 * q + 3]);
+        }
+        int srow = 0, drow = 0;
+        if (FUSE) { srow = a.add_src[li]; drow = a.add_dst[li]; }
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            float4 ex[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int col = t * 32 + 8 * q + 4 * half;
+                const float4 zz = *reinterpret_cast<const float4*>(a.gates + gp + (size_t)row * H + col);
+                float4 d = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (UP & 1) d = *reinterpret_cast<const float4*>(a.up.d_hout + (size_t)row * a.up.ld_dhout + col);
+                if (UP & 2) {
+                    const float4 w = *reinterpret_cast<const float4*>(a.up.w_head + col);
+                    d.x += dyr * w.x; d.y += dyr * w.y; d.z += dyr * w.z; d.w += dyr * w.w;
+                }
+                ex[q] = make_float4(d.x * zz.x, d.y * zz.y, d.z * zz.z, d.w * zz.w);
+                if (FUSE) {
+                    const float4 u = *reinterpret_cast<const float4*>(a.add_msg + (size_t)srow * a.ld_add + col);
+                    const float4 v = *reinterpret_cast<const float4*>(a.add_msg + (size_t)drow * a.ld_add + col);
+                    ex[q].x += u.x - v.x; ex[q].y += u.y - v.y; ex[q].z += u.z - v.z; ex[q].w += u.w - v.w;
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (live) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    *reinterpret_cast<float4*>(a.d_h + (size_t)row * a.ld_dh + t * 32 + 8 * q + 4 * half) =
+                        make_float4(acch[t][4 * q] + ex[q].x, acch[t][4 * q + 1] + ex[q].y, acch[t][4 * q + 2] + ex[q].z,
+                                    acch[t][4 * q + 3] + ex[q].w);
+            }
+        }
+    }
+}
+
 // Weight gradient, block-staged (IN == H): 32-row tiles of d_g = [dr|dz|dn|dn*r] and [x|h] are formed
 // once in LDS and consumed by all four waves as MFMA operands (A = d_g^T, B = [x|h]); each wave owns
 // 3 x (H/32) output tiles of dW_ih (waves 0,1) or dW_hh (waves 2,3).  Persistent blocks keep their
@@ -1286,6 +1455,219 @@ __global__ __launch_bounds__(256, 2) void k_gru_bwd_weights_lds(GruBwdWArgs a, i
     }
 }
 
+
+// ------------------------------------------------------------------------------------------
+// Weight gradient on the bf16 pipe (bf16x6), H = IN = 64.  dW = d_g^T [x|h] contracts over ROWS, so both MFMA
+// operands need 8 consecutive rows of one column per lane -- the transpose of how the data lies in HBM.
+// Staging is the same as in k_gru_bwd_weights_lds (a thread owns 8 features of one row, 16-byte coalesced
+// loads), but the 32-row tiles of d_g = [dr|dz|dn|dn*r] and [x|h] are written ROW-major as three bf16 pieces
+// and the operands are fetched with the transposing LDS read ds_read_b64_tr_b16 (a 16-lane group reads
+// 4 rows x 16 columns and receives them column-major): two reads give a lane its 8 rows.
+// The 64-byte chunks of a row are XOR-swizzled with (row & 3), so the four rows of one transposing read fall
+// into different bank windows without padding: 72 KiB per block, two 4-wave blocks per CU as before.
+// ------------------------------------------------------------------------------------------
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint2 lds_read_tr(const uint16_t* p) {
+    const s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+        (__attribute__((address_space(3))) s16x4*)(p));
+    return __builtin_bit_cast(uint2, v);
+}
+// element offset of (row, col) in a swizzled row-major bf16 image with `cols` columns (cols*2 bytes a multiple of 256)
+template <int COLS>
+__device__ __forceinline__ int swz_off(int row, int col) {
+    return row * COLS + ((((col >> 5) ^ (row & 3)) << 5) | (col & 31));
+}
+
+struct WRaw { float4 dh[2], r[2], z[2], n[2], hn[2], hp[2], x[2], x2[2]; bool valid; };
+
+template <int XMODE, int UP>
+__device__ __forceinline__ void w_issue(const GruBwdWArgs& a, int tile, int srow, int f8, WRaw& q) {
+    constexpr int H = 64;
+    const int lpos_raw = tile * 32 + srow;
+    q.valid = lpos_raw < a.R;
+    const int lpos = q.valid ? lpos_raw : a.R - 1;
+    const int orow = a.rows[lpos];
+    const size_t gp = a.gate_plane;
+    const float4* p;
+    if (UP & 1) {
+        p = reinterpret_cast<const float4*>(a.up.d_hout + (size_t)orow * a.up.ld_dhout + f8);
+        q.dh[0] = p[0]; q.dh[1] = p[1];
+    } else {
+        q.dh[0] = make_float4(0.f, 0.f, 0.f, 0.f); q.dh[1] = q.dh[0];
+    }
+    if (UP & 2) {
+        const float d = a.up.dy[orow];
+        const float4* w = reinterpret_cast<const float4*>(a.up.w_head + f8);
+        const float4 w0 = w[0], w1 = w[1];
+        q.dh[0].x += d * w0.x; q.dh[0].y += d * w0.y; q.dh[0].z += d * w0.z; q.dh[0].w += d * w0.w;
+        q.dh[1].x += d * w1.x; q.dh[1].y += d * w1.y; q.dh[1].z += d * w1.z; q.dh[1].w += d * w1.w;
+    }
+    p = reinterpret_cast<const float4*>(a.gates + (size_t)orow * H + f8);
+    q.r[0] = p[0]; q.r[1] = p[1];
+    p = reinterpret_cast<const float4*>(a.gates + gp + (size_t)orow * H + f8);
+    q.z[0] = p[0]; q.z[1] = p[1];
+    p = reinterpret_cast<const float4*>(a.gates + 2 * gp + (size_t)orow * H + f8);
+    q.n[0] = p[0]; q.n[1] = p[1];
+    p = reinterpret_cast<const float4*>(a.gates + 3 * gp + (size_t)orow * H + f8);
+    q.hn[0] = p[0]; q.hn[1] = p[1];
+    p = reinterpret_cast<const float4*>(a.h + (size_t)orow * a.ld_h + f8);
+    q.hp[0] = p[0]; q.hp[1] = p[1];
+    if (XMODE == 0) {
+        p = reinterpret_cast<const float4*>(a.msg + (size_t)(a.msg_compact ? lpos : orow) * a.ld_msg + f8);
+        q.x[0] = p[0]; q.x[1] = p[1];
+    } else {
+        p = reinterpret_cast<const float4*>(a.h + (size_t)a.src[lpos] * a.ld_h + f8);
+        q.x[0] = p[0]; q.x[1] = p[1];
+        p = reinterpret_cast<const float4*>(a.h + (size_t)a.dst[lpos] * a.ld_h + f8);
+        q.x2[0] = p[0]; q.x2[1] = p[1];
+    }
+}
+
+template <int XMODE, int UP>
+__global__ __launch_bounds__(256, 2) void k_gru_bwd_weights_split(GruBwdWArgs a, int ntiles) {
+    constexpr int H = 64, DG = 4 * H, XHW = 2 * H, RT = 32, NJ = 3, NC = 2;
+    extern __shared__ float lds[];
+    uint16_t* sA = reinterpret_cast<uint16_t*>(lds);           // [3][RT][DG]   swizzled
+    uint16_t* sB = sA + 3 * RT * DG;                           // [3][RT][XHW]  swizzled
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63;
+    const int c = lane & 31, half = lane >> 5;
+    const int which = wave >> 1;                 // 0: dW_ih (x columns), 1: dW_hh (h columns)
+    const int jt0 = (wave & 1) * NJ;
+    const int srow = tid >> 3, f8 = (tid & 7) * 8;
+    // transposing-read coordinates of this lane: row q (+ 8*half, + 4 for the second read), columns 16*(g&1) + 4p
+    const int i16 = lane & 15, tq = i16 >> 2, tp = i16 & 3, tg = (lane >> 4) & 1;
+
+    f32x16 acc[NJ][NC];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int t = 0; t < NC; ++t)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[j][t][i] = 0.f;
+    float cs[4][8];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) cs[k][i] = 0.f;
+
+    int colA0[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int jj0 = (jt0 + j) * 32;
+        colA0[j] = (which == 1 && jj0 >= 2 * H) ? jj0 + H : jj0;
+    }
+
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        // (no cross-tile prefetch: the six accumulator tiles leave no room for it; the CU's second block covers the latency)
+        WRaw raw;
+        w_issue<XMODE, UP>(a, tile, srow, f8, raw);
+        float dh[8], r[8], z[8], n[8], hn[8], hp[8], x[8];
+        f4_to_arr(raw.dh[0], raw.dh[1], dh); f4_to_arr(raw.r[0], raw.r[1], r); f4_to_arr(raw.z[0], raw.z[1], z);
+        f4_to_arr(raw.n[0], raw.n[1], n); f4_to_arr(raw.hn[0], raw.hn[1], hn); f4_to_arr(raw.hp[0], raw.hp[1], hp);
+        f4_to_arr(raw.x[0], raw.x[1], x);
+        if (XMODE != 0) {
+            float x2[8];
+            f4_to_arr(raw.x2[0], raw.x2[1], x2);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) x[i] -= x2[i];
+        }
+        float dr[8], dz[8], dn[8], dnr[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float d0 = raw.valid ? dh[i] : 0.f;
+            const float t = d0 * (1.0f - z[i]) * (1.0f - n[i] * n[i]);
+            dn[i] = t;
+            dnr[i] = t * r[i];
+            dr[i] = t * hn[i] * r[i] * (1.0f - r[i]);
+            dz[i] = d0 * (hp[i] - n[i]) * z[i] * (1.0f - z[i]);
+            cs[0][i] += dr[i]; cs[1][i] += dz[i]; cs[2][i] += dn[i]; cs[3][i] += dnr[i];
+        }
+        const Split8 s0 = split8_arr(dr), s1 = split8_arr(dz), s2 = split8_arr(dn), s3 = split8_arr(dnr);
+        const Split8 sx = split8_arr(x), sh = split8_arr(hp);
+        __syncthreads();                         // the previous tile's matrix phase has drained the LDS
+        {
+            uint16_t* d = sA + swz_off<DG>(srow, f8);          // + arr*64 stays inside the row: chunk index += 2*arr
+            // (col >> 5) ^ (row & 3): adding 64 columns adds 2 to the chunk index before the XOR
+            const int o1 = swz_off<DG>(srow, H + f8) - swz_off<DG>(srow, f8);
+            const int o2 = swz_off<DG>(srow, 2 * H + f8) - swz_off<DG>(srow, f8);
+            const int o3 = swz_off<DG>(srow, 3 * H + f8) - swz_off<DG>(srow, f8);
+            constexpr int PA = RT * DG;
+            *reinterpret_cast<uint4*>(d) = s0.p1; *reinterpret_cast<uint4*>(d + PA) = s0.p2; *reinterpret_cast<uint4*>(d + 2 * PA) = s0.p3;
+            *reinterpret_cast<uint4*>(d + o1) = s1.p1; *reinterpret_cast<uint4*>(d + o1 + PA) = s1.p2; *reinterpret_cast<uint4*>(d + o1 + 2 * PA) = s1.p3;
+            *reinterpret_cast<uint4*>(d + o2) = s2.p1; *reinterpret_cast<uint4*>(d + o2 + PA) = s2.p2; *reinterpret_cast<uint4*>(d + o2 + 2 * PA) = s2.p3;
+            *reinterpret_cast<uint4*>(d + o3) = s3.p1; *reinterpret_cast<uint4*>(d + o3 + PA) = s3.p2; *reinterpret_cast<uint4*>(d + o3 + 2 * PA) = s3.p3;
+            constexpr int PB = RT * XHW;
+            uint16_t* e = sB + swz_off<XHW>(srow, f8);
+            uint16_t* e2 = sB + swz_off<XHW>(srow, H + f8);
+            *reinterpret_cast<uint4*>(e) = sx.p1; *reinterpret_cast<uint4*>(e + PB) = sx.p2; *reinterpret_cast<uint4*>(e + 2 * PB) = sx.p3;
+            *reinterpret_cast<uint4*>(e2) = sh.p1; *reinterpret_cast<uint4*>(e2 + PB) = sh.p2; *reinterpret_cast<uint4*>(e2 + 2 * PB) = sh.p3;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kb = 0; kb < RT / 16; ++kb) {
+            const int row0 = kb * 16 + 8 * half + tq;          // first read; the second is 4 rows further ((row & 3) == tq for both)
+            Split8 b[NC];
+#pragma unroll
+            for (int t = 0; t < NC; ++t) {
+                const int col = which * H + t * 32 + 16 * tg + 4 * tp;
+                const uint16_t* p0 = sB + swz_off<XHW>(row0, col);
+                const uint16_t* p1 = sB + swz_off<XHW>(row0 + 4, col);
+                constexpr int PB = RT * XHW;
+                const uint2 u0 = lds_read_tr(p0), u1 = lds_read_tr(p1);
+                const uint2 v0 = lds_read_tr(p0 + PB), v1 = lds_read_tr(p1 + PB);
+                const uint2 w0 = lds_read_tr(p0 + 2 * PB), w1 = lds_read_tr(p1 + 2 * PB);
+                b[t].p1 = make_uint4(u0.x, u0.y, u1.x, u1.y);
+                b[t].p2 = make_uint4(v0.x, v0.y, v1.x, v1.y);
+                b[t].p3 = make_uint4(w0.x, w0.y, w1.x, w1.y);
+            }
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int col = colA0[j] + 16 * tg + 4 * tp;
+                const uint16_t* p0 = sA + swz_off<DG>(row0, col);
+                const uint16_t* p1 = sA + swz_off<DG>(row0 + 4, col);
+                constexpr int PA = RT * DG;
+                const uint2 u0 = lds_read_tr(p0), u1 = lds_read_tr(p1);
+                const uint2 v0 = lds_read_tr(p0 + PA), v1 = lds_read_tr(p1 + PA);
+                const uint2 w0 = lds_read_tr(p0 + 2 * PA), w1 = lds_read_tr(p1 + 2 * PA);
+                const uint4 a1 = make_uint4(u0.x, u0.y, u1.x, u1.y);
+                const uint4 a2 = make_uint4(v0.x, v0.y, v1.x, v1.y);
+                const uint4 a3 = make_uint4(w0.x, w0.y, w1.x, w1.y);
+#pragma unroll
+                for (int t = 0; t < NC; ++t) acc[j][t] = mfma_x6(a1, a2, a3, b[t], acc[j][t]);
+            }
+        }
+    }
+    // ---- one slab per block: [3H][IN+H] weights, then [2][3H] biases
+    float* sw = a.slab_w + (size_t)blockIdx.x * (3 * H) * XHW;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int t = 0; t < NC; ++t)
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int jj = (jt0 + j) * 32 + acc_row(reg, half);
+                sw[(size_t)jj * XHW + which * H + t * 32 + c] = acc[j][t][reg];
+            }
+    // bias gradients: column sums of d_g; 32 threads (one per tile row) hold partial sums of the same 8 features
+    __syncthreads();
+    float* red = lds;                                          // [32 rows][256] floats = 32 KiB (the images are dead)
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) red[srow * DG + k * H + f8 + i] = cs[k][i];
+    __syncthreads();
+    {
+        float sum = 0.f;
+#pragma unroll 8
+        for (int rr = 0; rr < RT; ++rr) sum += red[rr * DG + tid];
+        float* sb = a.slab_b + (size_t)blockIdx.x * 6 * H;
+        const int g = tid / H, ff = tid % H;
+        if (g < 3) sb[g * H + ff] = sum;                   // d_gi sums: dr | dz | dn
+        if (g < 2) sb[3 * H + g * H + ff] = sum;           // d_gh sums: dr | dz | dn*r
+        if (g == 3) sb[3 * H + 2 * H + ff] = sum;
+    }
+}
 
 // Weight gradient for the wide cells (H or IN a multiple of 64 beyond the 64/64 case): the same block-staged
 // scheme, tiled over the OUTPUT.  blockIdx.y = (fc, cc) picks 64 hidden features (-> 192 rows of dW: the
@@ -1910,6 +2292,24 @@ int tmpnn_gru_bwd_data(const int32_t* rows, int R, int IN, const float* h, int l
         const size_t shm = sizeof(float) * ((size_t)(IN + H) * 3 * H + 4);
         const int up = (d_hout ? 1 : 0) | (dy ? 2 : 0);
         const bool fuse = add_msg != nullptr;
+        if (split_enabled() && IN == H) {
+            const size_t shm2 = (size_t)3 * (IN + H) * (3 * H + 8) * 2 + 16;
+#define S3(HH, UU, FF)                                                                                       \
+    do {                                                                                                     \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gru_bwd_data_split<HH, UU, FF>),          \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm2);                    \
+        hipLaunchKernelGGL((k_gru_bwd_data_split<HH, UU, FF>), pgrid, pblock, shm2, st, a, ntiles);          \
+    } while (0)
+#define SL(HH)                                                                                               \
+    do {                                                                                                     \
+        if (fuse) { if (up == 1) S3(HH, 1, true); else if (up == 2) S3(HH, 2, true); else S3(HH, 3, true); }      \
+        else      { if (up == 1) S3(HH, 1, false); else if (up == 2) S3(HH, 2, false); else S3(HH, 3, false); }   \
+    } while (0)
+            if (H == 64) SL(64); else SL(32);
+#undef SL
+#undef S3
+            return check_launch("gru_bwd_data_split");
+        }
 #define L3(HH, II, UU, FF)                                                                                   \
     do {                                                                                                     \
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gru_bwd_data_lds<HH, II, UU, FF>),        \
@@ -1941,6 +2341,7 @@ static int weights_lds_blocks(int R) {
     const int ntiles = ceil_div(R, 32);
     return ntiles < 512 ? ntiles : 512;          // persistent: <= 2 blocks per CU
 }
+
 // output-tiled kernel for the wide cells: (H/64) x ceil((IN+H)/128) output chunks per row slab
 static bool weights_use_chunk(int IN, int H) { return H % 64 == 0 && IN % 64 == 0 && !weights_use_lds(IN, H); }
 static int weights_chunk_slabs(int R, int IN, int H) {
@@ -2078,7 +2479,22 @@ int tmpnn_gru_bwd_weights(const int32_t* rows, int R, int xmode, const int32_t* 
                   n_rs, RS, NQ, NCH};
     hipStream_t st = as_stream(stream);
     int rc;
-    if (use_lds) {
+    if (use_lds && H == 64 && split_enabled()) {
+        const int ntiles = ceil_div(R, 32);
+        dim3 grid(n_rs), block(256);
+        const size_t shm = (size_t)3 * 32 * (256 + 128) * 2;
+        const int up = (d_hout ? 1 : 0) | (dy ? 2 : 0);
+#define SW(X, U)                                                                                             \
+    do {                                                                                                     \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gru_bwd_weights_split<X, U>),             \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);                     \
+        hipLaunchKernelGGL((k_gru_bwd_weights_split<X, U>), grid, block, shm, st, a, ntiles);                \
+    } while (0)
+        if (xmode == 0) { if (up == 1) SW(0, 1); else if (up == 2) SW(0, 2); else SW(0, 3); }
+        else            { if (up == 1) SW(1, 1); else if (up == 2) SW(1, 2); else SW(1, 3); }
+#undef SW
+        rc = check_launch("gru_bwd_weights_split");
+    } else if (use_lds) {
         const int ntiles = ceil_div(R, 32);
         dim3 grid(n_rs), block(256);
         const int up = (d_hout ? 1 : 0) | (dy ? 2 : 0);
