@@ -1218,7 +1218,7 @@ __global__ __launch_bounds__(512) void k_gru_bwd_data_split(GruBwdDataArgs a, in
                 dh[0] += dyr * w0.x; dh[1] += dyr * w0.y; dh[2] += dyr * w0.z; dh[3] += dyr * w0.w;
                 dh[4] += dyr * w1.x; dh[5] += dyr * w1.y; dh[6] += dyr * w1.z; dh[7] += dyr * w1.w;
             }
-            float ar[8], az[8], an[8], anr[8];
+            float ar[8], az[8], an[8], anr[8], ex[8];
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 const float dn = dh[i] * (1.0f - z[i]) * (1.0f - n[i] * n[i]);
@@ -1226,8 +1226,27 @@ __global__ __launch_bounds__(512) void k_gru_bwd_data_split(GruBwdDataArgs a, in
                 az[i] = dh[i] * (hp[i] - n[i]) * z[i] * (1.0f - z[i]);
                 an[i] = dn;
                 anr[i] = dn * r[i];
+                ex[i] = dh[i] * z[i];
             }
             const Split8 sr = split8_arr(ar), sz = split8_arr(az), sn = split8_arr(an), snr = split8_arr(anr);
+            // the pass-through term d_h += dh (.) z rides the matrix pipe as well: the three pieces of dh*z times an
+            // identity fragment built in registers land in the accumulator layout exactly (1.0 is a bf16), so the
+            // epilogue does not have to read z and dh a second time
+            {
+                const Split8 se = split8_arr(ex);
+                const int te = (16 * fb) / 32;                           // the h tile that holds this block's 16 columns
+                const int d = c - (16 * fb - 32 * te + 8 * half);         // this lane's output column relative to its k run
+                const bool in = d >= 0 && d < 8;
+                const uint32_t one = (d & 1) ? 0x3F800000u : 0x00003F80u;
+                uint4 idf;
+                idf.x = (in && (d >> 1) == 0) ? one : 0u;
+                idf.y = (in && (d >> 1) == 1) ? one : 0u;
+                idf.z = (in && (d >> 1) == 2) ? one : 0u;
+                idf.w = (in && (d >> 1) == 3) ? one : 0u;
+                acch[te] = mfma_bf16(idf, se.p3, acch[te]);
+                acch[te] = mfma_bf16(idf, se.p2, acch[te]);
+                acch[te] = mfma_bf16(idf, se.p1, acch[te]);
+            }
             if (fb + 1 < NFB) g_issue8<UP>(a, H, 16 * (fb + 1) + 8 * half, row, nxt);
             __builtin_amdgcn_sched_barrier(0);
             const uint16_t* wp0 = sWT + c * JP + f0;
@@ -1263,22 +1282,15 @@ __global__ __launch_bounds__(512) void k_gru_bwd_data_split(GruBwdDataArgs a, in
         if (FUSE) { srow = a.add_src[li]; drow = a.add_dst[li]; }
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-            float4 ex[4];
+            float4 ex4[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const int col = t * 32 + 8 * q + 4 * half;
-                const float4 zz = *reinterpret_cast<const float4*>(a.gates + gp + (size_t)row * H + col);
-                float4 d = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (UP & 1) d = *reinterpret_cast<const float4*>(a.up.d_hout + (size_t)row * a.up.ld_dhout + col);
-                if (UP & 2) {
-                    const float4 w = *reinterpret_cast<const float4*>(a.up.w_head + col);
-                    d.x += dyr * w.x; d.y += dyr * w.y; d.z += dyr * w.z; d.w += dyr * w.w;
-                }
-                ex[q] = make_float4(d.x * zz.x, d.y * zz.y, d.z * zz.z, d.w * zz.w);
+                ex4[q] = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (FUSE) {
+                    const int col = t * 32 + 8 * q + 4 * half;
                     const float4 u = *reinterpret_cast<const float4*>(a.add_msg + (size_t)srow * a.ld_add + col);
                     const float4 v = *reinterpret_cast<const float4*>(a.add_msg + (size_t)drow * a.ld_add + col);
-                    ex[q].x += u.x - v.x; ex[q].y += u.y - v.y; ex[q].z += u.z - v.z; ex[q].w += u.w - v.w;
+                    ex4[q] = make_float4(u.x - v.x, u.y - v.y, u.z - v.z, u.w - v.w);
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -1286,8 +1298,8 @@ __global__ __launch_bounds__(512) void k_gru_bwd_data_split(GruBwdDataArgs a, in
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
                     *reinterpret_cast<float4*>(a.d_h + (size_t)row * a.ld_dh + t * 32 + 8 * q + 4 * half) =
-                        make_float4(acch[t][4 * q] + ex[q].x, acch[t][4 * q + 1] + ex[q].y, acch[t][4 * q + 2] + ex[q].z,
-                                    acch[t][4 * q + 3] + ex[q].w);
+                        make_float4(acch[t][4 * q] + ex4[q].x, acch[t][4 * q + 1] + ex4[q].y, acch[t][4 * q + 2] + ex4[q].z,
+                                    acch[t][4 * q + 3] + ex4[q].w);
             }
         }
     }
