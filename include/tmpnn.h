@@ -55,6 +55,10 @@ typedef struct tmpnn_graph {
     const int32_t* det_row;  /* [Dn] row of det d (ascending) */
     const int32_t* rowptr;   /* [Dn+1] CSR offsets into inc */
     const int32_t* inc;      /* [2E] (edge row) | (sign bit: 0x80000000 when d == dst) */
+    const int32_t* det_order; /* [Dn] or NULL: order in which the det -> edge reductions visit the dets (a permutation of
+                                0..Dn-1).  Results do not depend on it; a host that batches independent windows lists
+                                each window's dets together, so that the two reads of an edge row (one from either
+                                endpoint) are issued from the same CU close in time */
 } tmpnn_graph;
 
 int tmpnn_abi_version(void);

@@ -137,6 +137,27 @@ def test_block_diagonal_batch_equals_per_window(static):
                 assert torch.allclose(batched[c][2][allrows], single[cb][2], atol=2e-5, rtol=1e-5)
 
 
+def test_batch_sets_window_major_det_order():
+    """batch_windows lists each window's dets together (struct tmpnn_graph, det_order): a permutation of the dets
+    whose window labels are non-decreasing; single graphs carry no order."""
+    from trackmpnn_amd import WindowBuilder, batch_windows, synth_window
+    from trackmpnn_amd.graph import set_det_groups
+    wins = [WindowBuilder(synth_window(s, 5, 4, 8)).calls() for s in range(3)]
+    plans, det_refs = batch_windows(wins)
+    for plan in plans:
+        g = plan.graph
+        assert g.det_order is not None and g.det_order.dtype == torch.int32
+        assert torch.equal(torch.sort(g.det_order.long()).values, torch.arange(g.Dn))
+    g = plans[-1].graph
+    win_of_det = torch.from_numpy(np.concatenate([r[:, 0] for r in det_refs]))
+    lab = win_of_det[g.det_order.long()]
+    assert bool((lab[1:] >= lab[:-1]).all())
+    single, _ = batch_windows(wins[:1])
+    assert single[-1].graph.det_order is None
+    with pytest.raises(ValueError):
+        set_det_groups(g, np.zeros(g.Dn + 1))
+
+
 def test_state_dict_keys_match_oracle_shapes():
     for feats, K, msg in (('2d', 0, 'diff'), ('2d+temp+vis', 2, 'concat')):
         m = TrackMPNN(feats, 3, 32, K, msg)

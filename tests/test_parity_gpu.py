@@ -251,6 +251,17 @@ def test_aggregation_properties_at_scale():
     # sum over dets of es == sum over edges of (h[e] - h[e]) == 0 column-wise: every edge enters once with + and once with -
     col = es.double().sum(0)
     assert col.abs().max().item() <= 1e-6 * h2.double().abs().sum(0).max().item()
+    # the visiting order (tmpnn_graph.det_order, set by batch_windows) only changes the access pattern, never a bit
+    assert g.det_order is not None and torch.equal(torch.sort(g.det_order.long()).values, torch.arange(g.Dn, device=DEV))
+    saved = g.det_order
+    g.det_order, g._c = None, None
+    es4 = torch.zeros(g.N, H, device=DEV)
+    _lib.call('tmpnn_segsum_fwd', g.cref(), h2.data_ptr(), H, es4.data_ptr(), H, H, 0, 0, st)
+    g.det_order, g._c = torch.flip(saved, [0]).contiguous(), None
+    es5 = torch.zeros(g.N, H, device=DEV)
+    _lib.call('tmpnn_segsum_fwd', g.cref(), h2.data_ptr(), H, es5.data_ptr(), H, H, 0, 0, st)
+    g.det_order, g._c = saved, None
+    assert torch.equal(es, es4) and torch.equal(es, es5)
 
 
 def test_inplace_append_is_bitwise_identical():

@@ -26,7 +26,7 @@ class CGraph(C.Structure):
     """struct tmpnn_graph (include/tmpnn.h)."""
     _fields_ = [('N', C.c_int32), ('E', C.c_int32), ('Dn', C.c_int32),
                 ('src', c_void_p), ('dst', c_void_p), ('edge_row', c_void_p), ('det_row', c_void_p),
-                ('rowptr', c_void_p), ('inc', c_void_p)]
+                ('rowptr', c_void_p), ('inc', c_void_p), ('det_order', c_void_p)]
 
 
 _GP = C.POINTER(CGraph)

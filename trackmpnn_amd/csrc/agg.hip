@@ -92,6 +92,7 @@ template <bool ACC>
 __global__ __launch_bounds__(256) void k_segsum(int Dn, const int32_t* __restrict__ det_row,
                                                 const int32_t* __restrict__ rowptr,
                                                 const int32_t* __restrict__ inc,
+                                                const int32_t* __restrict__ det_order,
                                                 const float* __restrict__ in, int ld_in,
                                                 float* __restrict__ out, int ld_out, int H,
                                                 float wneg, int cneg, int compact_out) {
@@ -100,44 +101,51 @@ __global__ __launch_bounds__(256) void k_segsum(int Dn, const int32_t* __restric
     const int ngrp = 64 / lpr;
     const int grp = lane / lpr;
     const int c4 = (lane % lpr) * 4;
-    const long nwaves = (long)gridDim.x * 4;
     constexpr int U = 4;
-    for (long d = (long)blockIdx.x * 4 + (threadIdx.x >> 6); d < Dn; d += nwaves) {
-        const int p0 = rowptr[d], p1 = rowptr[d + 1];
-        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int pb = p0 + grp; pb < p1; pb += ngrp * U) {
-            int v[U];
+    // a block walks SEG_CHUNK consecutive entries of the visiting order at a time (its four waves interleaved), so
+    // dets that share edges -- neighbours in that order -- are reduced on the same CU at about the same time
+    constexpr int SEG_CHUNK = 64;
+    const int wv = threadIdx.x >> 6;
+    for (long base = (long)blockIdx.x * SEG_CHUNK; base < Dn; base += (long)gridDim.x * SEG_CHUNK) {
+        const long hi = base + SEG_CHUNK < Dn ? base + SEG_CHUNK : Dn;
+        for (long i = base + wv; i < hi; i += 4) {
+            const int d = det_order ? det_order[i] : (int)i;
+            const int p0 = rowptr[d], p1 = rowptr[d + 1];
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int pb = p0 + grp; pb < p1; pb += ngrp * U) {
+                int v[U];
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int p = pb + u * ngrp;
-                v[u] = p < p1 ? inc[p] : 0x7fffffff;       // sentinel: nothing to add
-            }
-            float4 x[U];
+                for (int u = 0; u < U; ++u) {
+                    const int p = pb + u * ngrp;
+                    v[u] = p < p1 ? inc[p] : 0x7fffffff;       // sentinel: nothing to add
+                }
+                float4 x[U];
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const bool live = v[u] != 0x7fffffff;
-                const int row = live ? (v[u] & 0x7fffffff) : 0;
-                x[u] = *reinterpret_cast<const float4*>(in + (size_t)row * ld_in + (v[u] < 0 ? cneg : 0) + c4);
-                const float w = v[u] < 0 ? wneg : 1.0f;
-                if (live) { x[u].x *= w; x[u].y *= w; x[u].z *= w; x[u].w *= w; }
-                else x[u] = make_float4(0.f, 0.f, 0.f, 0.f);     // (never multiply: row 0 may hold inf/nan)
-            }
+                for (int u = 0; u < U; ++u) {
+                    const bool live = v[u] != 0x7fffffff;
+                    const int row = live ? (v[u] & 0x7fffffff) : 0;
+                    x[u] = *reinterpret_cast<const float4*>(in + (size_t)row * ld_in + (v[u] < 0 ? cneg : 0) + c4);
+                    const float w = v[u] < 0 ? wneg : 1.0f;
+                    if (live) { x[u].x *= w; x[u].y *= w; x[u].z *= w; x[u].w *= w; }
+                    else x[u] = make_float4(0.f, 0.f, 0.f, 0.f);     // (never multiply: row 0 may hold inf/nan)
+                }
 #pragma unroll
-            for (int u = 0; u < U; ++u) { acc.x += x[u].x; acc.y += x[u].y; acc.z += x[u].z; acc.w += x[u].w; }
-        }
-        for (int off = lpr; off < 64; off <<= 1) {
-            acc.x += __shfl_xor(acc.x, off);
-            acc.y += __shfl_xor(acc.y, off);
-            acc.z += __shfl_xor(acc.z, off);
-            acc.w += __shfl_xor(acc.w, off);
-        }
-        if (grp == 0) {
-            float* o = out + (size_t)(compact_out ? (int)d : det_row[d]) * ld_out + c4;
-            if (ACC) {
-                const float4 p = *reinterpret_cast<const float4*>(o);
-                acc.x += p.x; acc.y += p.y; acc.z += p.z; acc.w += p.w;
+                for (int u = 0; u < U; ++u) { acc.x += x[u].x; acc.y += x[u].y; acc.z += x[u].z; acc.w += x[u].w; }
             }
-            *reinterpret_cast<float4*>(o) = acc;
+            for (int off = lpr; off < 64; off <<= 1) {
+                acc.x += __shfl_xor(acc.x, off);
+                acc.y += __shfl_xor(acc.y, off);
+                acc.z += __shfl_xor(acc.z, off);
+                acc.w += __shfl_xor(acc.w, off);
+            }
+            if (grp == 0) {
+                float* o = out + (size_t)(compact_out ? d : det_row[d]) * ld_out + c4;
+                if (ACC) {
+                    const float4 p = *reinterpret_cast<const float4*>(o);
+                    acc.x += p.x; acc.y += p.y; acc.z += p.z; acc.w += p.w;
+                }
+                *reinterpret_cast<float4*>(o) = acc;
+            }
         }
     }
 }
@@ -247,14 +255,14 @@ static int segsum(const tmpnn_graph* g, const float* in, int ld_in, float* out, 
     rc = check_rows(in, ld_in, out, ld_out, H, H + cneg, H);
     if (rc) return rc;
     if (g->Dn == 0) return TMPNN_OK;
-    dim3 grid(grid_for(g->Dn, 4)), block(256);
     hipStream_t st = as_stream(stream);
+    dim3 grid(grid_for(g->Dn, 64)), block(256);
     if (accumulate)
-        hipLaunchKernelGGL((k_segsum<true>), grid, block, 0, st, g->Dn, g->det_row, g->rowptr, g->inc, in, ld_in, out,
-                           ld_out, H, wneg, cneg, compact_out);
+        hipLaunchKernelGGL((k_segsum<true>), grid, block, 0, st, g->Dn, g->det_row, g->rowptr, g->inc, g->det_order, in,
+                           ld_in, out, ld_out, H, wneg, cneg, compact_out);
     else
-        hipLaunchKernelGGL((k_segsum<false>), grid, block, 0, st, g->Dn, g->det_row, g->rowptr, g->inc, in, ld_in, out,
-                           ld_out, H, wneg, cneg, compact_out);
+        hipLaunchKernelGGL((k_segsum<false>), grid, block, 0, st, g->Dn, g->det_row, g->rowptr, g->inc, g->det_order, in,
+                           ld_in, out, ld_out, H, wneg, cneg, compact_out);
     return check_launch("segsum");
 }
 

@@ -41,6 +41,7 @@ class FrameGraph:
     pos: torch.Tensor        # int32 [N]    row -> index within its type (det index | edge index)
     src_pos: Optional[torch.Tensor] = None   # int32 [E]  det INDEX of src[e] (= pos[src])
     dst_pos: Optional[torch.Tensor] = None   # int32 [E]  det INDEX of dst[e]
+    det_order: Optional[torch.Tensor] = None  # int32 [Dn] visiting order of the det -> edge reductions (tmpnn.h)
     _c: Optional[_lib.CGraph] = field(default=None, repr=False, compare=False)
 
     @property
@@ -54,13 +55,14 @@ class FrameGraph:
         return FrameGraph(self.N, self.E, self.Dn, mv(self.src), mv(self.dst), mv(self.edge_row), mv(self.det_row),
                           mv(self.rowptr), mv(self.inc), mv(self.is_edge), mv(self.pos),
                           None if self.src_pos is None else mv(self.src_pos),
-                          None if self.dst_pos is None else mv(self.dst_pos))
+                          None if self.dst_pos is None else mv(self.dst_pos),
+                          None if self.det_order is None else mv(self.det_order))
 
     def cstruct(self) -> _lib.CGraph:
         if self._c is None:
             self._c = _lib.CGraph(self.N, self.E, self.Dn, self.src.data_ptr(), self.dst.data_ptr(),
                                   self.edge_row.data_ptr(), self.det_row.data_ptr(), self.rowptr.data_ptr(),
-                                  self.inc.data_ptr())
+                                  self.inc.data_ptr(), _lib.ptr(self.det_order))
         return self._c
 
     def cref(self):
@@ -73,6 +75,19 @@ class FrameGraph:
         epos = torch.full((self.N,), -1, dtype=torch.long, device=self.device)
         epos[self.edge_row.long()] = torch.arange(self.E, device=self.device)
         return epos[row], endpoint
+
+
+def set_det_groups(graph: FrameGraph, det_group) -> FrameGraph:
+    """Visit the dets group by group in the det -> edge reductions (struct tmpnn_graph, det_order).
+
+    det_group [Dn]: any integer label per det, in det order; dets that share edges should share a label (the window
+    id in a block-diagonal batch).  Only the memory access order changes, never a result."""
+    dg = torch.as_tensor(det_group, dtype=torch.long, device=graph.device)
+    if dg.numel() != graph.Dn:
+        raise ValueError('set_det_groups: one label per det expected')
+    graph.det_order = torch.argsort(dg, stable=True).to(torch.int32).contiguous()
+    graph._c = None
+    return graph
 
 
 def graph_from_edges(N: int, is_edge: torch.Tensor, src: torch.Tensor, dst: torch.Tensor,
@@ -339,6 +354,7 @@ def batch_windows(windows: Sequence[Sequence[WindowCall]], static: bool = False,
     g_is_edge: List[np.ndarray] = []
     g_src: List[np.ndarray] = []
     g_dst: List[np.ndarray] = []
+    g_det_window: List[np.ndarray] = []         # window of every det row, in det order
     call_range = [range(ncalls)] if static else [[c] for c in range(ncalls)]
     for group in call_range:
         seg_cnt, seg_nd, refs, new_is_edge_all, seg_ids = [], [], [], [], []
@@ -356,6 +372,7 @@ def batch_windows(windows: Sequence[Sequence[WindowCall]], static: bool = False,
                 g_dst.append(l2g[wc.new_dst])
                 new_is_edge_all.append(wc.new_is_edge)
                 refs.append(np.stack([np.full(wc.det_ids.size, b), wc.det_ids], 1))
+                g_det_window.append(np.full(int((~wc.new_is_edge).sum()), b, np.int64))
                 N += wc.n_new
                 cnt += wc.n_new
                 nd += int((~wc.new_is_edge).sum())
@@ -369,6 +386,10 @@ def batch_windows(windows: Sequence[Sequence[WindowCall]], static: bool = False,
         # edges must be listed in ascending edge-row order: they are, rows are appended in order
         graph = graph_from_edges(N, torch.from_numpy(is_edge), torch.from_numpy(src), torch.from_numpy(dst),
                                  device=device)
+        if B > 1:
+            # visit each window's dets together: both endpoint reads of an edge row then come from one CU within a
+            # window's ~100 KB working set instead of from two CUs a whole call block apart
+            set_det_groups(graph, np.concatenate(g_det_window) if g_det_window else np.zeros(0, np.int64))
         n_new = N - n_before
         nie = np.concatenate(new_is_edge_all) if new_is_edge_all else np.zeros(0, bool)
         loc = np.nonzero(~nie)[0]
