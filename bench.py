@@ -145,15 +145,35 @@ def stage_profile(model, plan, H):
     flops = {'gru_fwd_edge': 12.0 * H * H * E, 'gru_bwd_data_edge': 12.0 * H * H * E,
              'gru_bwd_data_edge_folded': 12.0 * H * H * E,
              'gru_bwd_weights_edge': 12.0 * H * H * E}
-    # SURVEY 8(d) algorithmic bytes per launch
+    # SURVEY 8(d) algorithmic bytes per launch (every array counted once; det-row gathers count the det table once)
     b_gather = 4.0 * H * E + 4.0 * H * Dn + 8.0 * E
     b_segsum = 4.0 * H * E + 4.0 * H * Dn + 4.0 * (2 * E + Dn + 1) + 2.0 * E
-    return t, flops, {'gather_diff': b_gather, 'segsum': b_segsum}
+    nbytes = {'gather_diff': b_gather, 'segsum': b_segsum,
+              # det rows -> P (4H in, 12H out per det), then per edge: h 4H in, h_out 4H + gates 16H out, 3 ids; P read once
+              'gru_fwd_edge': (24.0 * H + 12.0) * E + 28.0 * H * Dn,
+              # per edge: dh 4H + gates 16H + h 4H in, d_msg 4H + d_h 4H out, row id
+              'gru_bwd_data_edge': (32.0 * H + 4.0) * E,
+              # ... + dy, two ids and the fused row-F adjoint (its det table once)
+              'gru_bwd_data_edge_folded': (32.0 * H + 16.0) * E + 4.0 * H * Dn,
+              # per edge: dh 4H + gates 16H + h 4H in, 3 ids; h[src], h[dst] from the det table (once)
+              'gru_bwd_weights_edge': (24.0 * H + 12.0) * E + 4.0 * H * Dn}
+    return t, flops, nbytes
 
 
-_PMC_KERNEL = {'gru_fwd_edge': 'k_gru_fwd_lds<64, 64, 3,', 'gru_bwd_data_edge': 'k_gru_bwd_data_lds<64, 64, 1, false>',
-               'gru_bwd_data_edge_folded': 'k_gru_bwd_data_lds<64, 64, 3, true>',
-               'gru_bwd_weights_edge': 'k_gru_bwd_weights_lds<64, 1, 1>'}
+def split_enabled():
+    """The library default: GRU GEMMs on the bf16 matrix pipe as fp32-accurate 3 x 3 split products (bf16x6,
+    csrc/gru.hip); TMPNN_SPLIT=0 keeps them on the f32-input MFMA."""
+    return os.environ.get('TMPNN_SPLIT', '1')[:1] != '0'
+
+
+def _pmc_kernel(stage):
+    if split_enabled():
+        return {'gru_fwd_edge': 'k_gru_fwd_split<64, 8>', 'gru_bwd_data_edge': 'k_gru_bwd_data_split<64, 1, false>',
+                'gru_bwd_data_edge_folded': 'k_gru_bwd_data_split<64, 3, true>',
+                'gru_bwd_weights_edge': 'k_gru_bwd_weights_split<1, 1>'}.get(stage, '?')
+    return {'gru_fwd_edge': 'k_gru_fwd_lds<64, 64, 3,', 'gru_bwd_data_edge': 'k_gru_bwd_data_lds<64, 64, 1, false>',
+            'gru_bwd_data_edge_folded': 'k_gru_bwd_data_lds<64, 64, 3, true>',
+            'gru_bwd_weights_edge': 'k_gru_bwd_weights_lds<64, 1, 1>'}.get(stage, '?')
 
 
 def pmc_traffic(stage, E):
@@ -168,7 +188,7 @@ def pmc_traffic(stage, E):
     if prof.get('graph', {}).get('E') != E:
         return None
     for name, v in prof['kernels'].items():
-        if _PMC_KERNEL.get(stage, '?') in name and v.get('WRITE_SIZE_KB') is not None:
+        if _pmc_kernel(stage) in name and v.get('WRITE_SIZE_KB') is not None:
             return (v['FETCH_SIZE_KB'] + v['WRITE_SIZE_KB']) * 1024.0
     return None
 
@@ -318,9 +338,24 @@ def main():
     if rank == 0 and not args.no_stage_profile:
         t, flops, nbytes = stage_profile(model, plans[-1], H)
         dom = max(flops, key=lambda k: t[k])
-        ach = flops[dom] / (t[dom] * 1e-3) / 1e12
-        roofline = dict(bound='mfma', kernel=dom, achieved=ach, peak=MFMA_F32_PEAK_TF, unit='TFLOP/s',
-                        frac=ach / MFMA_F32_PEAK_TF, traffic=pmc_traffic(dom, plans[-1].graph.E), ms=t[dom])
+        # the dominant kernel against BOTH roofs; the one it sits closer to is reported as its bound.  Matrix-pipe
+        # time: f32-equivalent flops at the f32-input MFMA rate, or 6 bf16 MFMAs (1/16 of the f32 cost each) per
+        # f32 MFMA of work on the split path.
+        tf = flops[dom] / (t[dom] * 1e-3) / 1e12
+        gbs = nbytes[dom] / (t[dom] * 1e-3) / 1e9
+        pipe_frac = tf / MFMA_F32_PEAK_TF * (6.0 / 16.0 if split_enabled() else 1.0)
+        hbm_frac = gbs / HBM_PEAK_GBS
+        if hbm_frac >= pipe_frac:
+            roofline = dict(bound='hbm', kernel=dom, achieved=gbs, peak=HBM_PEAK_GBS, unit='GB/s', frac=hbm_frac,
+                            traffic=pmc_traffic(dom, plans[-1].graph.E), ms=t[dom], algorithmic_bytes=nbytes[dom],
+                            matrix_pipe_frac=pipe_frac, f32_equiv_tflops=tf)
+        else:
+            roofline = dict(bound='mfma', kernel=dom, achieved=tf, peak=MFMA_F32_PEAK_TF, unit='TFLOP/s', frac=pipe_frac,
+                            traffic=pmc_traffic(dom, plans[-1].graph.E), ms=t[dom], hbm_frac=hbm_frac)
+        extra['stage_roofs'] = {k: dict(ms=round(t[k], 4), GBs=round(nbytes[k] / (t[k] * 1e-3) / 1e9, 1),
+                                        hbm_frac=round(nbytes[k] / (t[k] * 1e-3) / 1e9 / HBM_PEAK_GBS, 3),
+                                        f32_equiv_tflops=round(flops[k] / (t[k] * 1e-3) / 1e12, 1) if k in flops else None)
+                                for k in t}
         agg_b = nbytes['gather_diff'] + nbytes['segsum']
         agg_t = (t['gather_diff'] + t['segsum']) * 1e-3
         extra['roofline_aggregation'] = dict(
@@ -338,6 +373,8 @@ def main():
         out = dict(metric='graph_edges_per_sec_fwd_bwd', value=value, unit='graph-edges/s', n_gpus=world,
                    steps=args.steps, warmup=args.warmup, ms_per_step=dt / args.steps * 1e3, higher_is_better=True,
                    scaling='weak', vs_baseline=None, dtype='f32', data='synthetic',
+                   arithmetic=('fp32 in/out; GRU GEMMs as bf16x6 split products on the bf16 matrix pipe, fp32 accumulate, '
+                               'error <= the f32 MFMA chain (tools/pilot_split.py)') if split_enabled() else 'fp32 MFMA',
                    config=dict(workload='C2 KITTI Car/RRC-shaped rolling windows: 7 frames, D_t~clip(Poisson(6),1,20), '
                                         'F=8 (2d), H=64, K=0, diff; 1 fwd per frame + 1 bwd per window; '
                                         f'{args.windows} windows/GPU batched block-diagonally (64 distinct seeds tiled)',
