@@ -35,6 +35,20 @@ def test_stage_checks():
     assert len(res) > 200
 
 
+def test_stage_checks_f32_mfma_path():
+    """The same stage checks with TMPNN_SPLIT=0: the GRU GEMMs on the f32-input MFMA kernels instead of the bf16x6
+    split products.  The switch is read once per process, hence the child process (one, sequential)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, TMPNN_SPLIT='0', PYTHONPATH=root + os.pathsep + os.environ.get('PYTHONPATH', ''))
+    r = subprocess.run([sys.executable, os.path.join(root, 'tests', 'gpu_stage_checks.py')], env=env, cwd=root,
+                       capture_output=True, text=True, timeout=600)
+    tail = '\n'.join([ln for ln in r.stdout.splitlines() if ln.startswith('FAIL')] + r.stdout.splitlines()[-2:])
+    assert r.returncode == 0, tail + r.stderr[-2000:]
+
+
 def build_model(meta, params):
     from trackmpnn_amd import TrackMPNN
     m = TrackMPNN(meta['features'], meta['ncategories'], meta['nhidden'], meta['nattheads'], meta['msg_type'])
