@@ -278,6 +278,59 @@ def test_aggregation_properties_at_scale():
     assert torch.equal(es, es4) and torch.equal(es, es5)
 
 
+def test_full_bench_size_tiling_invariance():
+    """BASELINE C2 at the full bench size (16 384 windows, 6.8 M rows, 18.7 M edge-iterations): the batch is 64
+    distinct windows tiled 256 times with identical features, and windows are independent (block-diagonal graph,
+    per-window BatchNorm), so every copy must reproduce its original bit for bit -- scores of all six rolling calls --
+    and the parameter gradients must be 256 x those of the 64-window batch.  Size-independent, no oracle needed."""
+    import torch.nn.functional as Fnn
+    from trackmpnn_amd import TrackMPNN, WindowBuilder, batch_windows, synth_window
+    distinct, reps, F, H = 64, 256, 8, 64
+    wins = [WindowBuilder(synth_window(1000 + s, 7, 6.0, 20)).calls() for s in range(distinct)]
+    table = torch.randn(distinct, 512, F, generator=torch.Generator().manual_seed(3))      # features by (seed, det id)
+
+    def run(B):
+        plans, refs = batch_windows((wins * (B // distinct))[:B], device='cpu')
+        torch.manual_seed(11)
+        model = TrackMPNN('2d', F - 5, H, 0, 'diff').to(DEV).train()
+        h, loss, outs = None, 0.0, []
+        row_window = torch.empty(plans[-1].graph.N, dtype=torch.long)
+        for c, (plan, ref) in enumerate(zip(plans, refs)):
+            ref = torch.from_numpy(ref)
+            assert int(ref[:, 1].max()) < table.shape[1]
+            x = torch.zeros(plan.n_new, F)
+            x[plan.new_det_local] = table[ref[:, 0] % distinct, ref[:, 1]]
+            row_window[plan.new_det_row.long()] = ref[:, 0]
+            pd = plan.to(DEV)
+            nxt = plans[c + 1].n_new if c + 1 < len(plans) else 0
+            scores, logits, h, _ = model.forward_graph(x.to(DEV), h, pd, reserve_rows=nxt)
+            loss = loss + (Fnn.softplus(logits) * 0.5).sum()        # a loss that does not depend on the row position
+            outs.append(scores.detach())
+        g = plans[-1].graph
+        row_window[g.edge_row.long()] = row_window[g.src.long()]
+        loss.backward()
+        grads = torch.cat([p.grad.reshape(-1) for p in model.parameters()]).double().cpu()
+        return plans, outs, row_window, grads
+
+    plans, outs, row_window, grads_full = run(distinct * reps)
+    assert plans[-1].graph.N > 6_000_000
+    rw = row_window.to(DEV)
+    for c, sc in enumerate(outs):
+        n = sc.numel()
+        w = rw[:n]
+        order = torch.argsort(w, stable=True)
+        ws, vs = w[order], sc[order]
+        cnt = torch.bincount(ws, minlength=distinct * reps)
+        start = torch.cumsum(cnt, 0) - cnt
+        posw = torch.arange(n, device=DEV) - start[ws]
+        assert torch.equal(cnt, cnt[:distinct].repeat(reps)), f'call {c}: copies differ in size'
+        ref_idx = start[ws % distinct] + posw
+        assert torch.equal(vs, vs[ref_idx]), f'call {c}: a tiled copy differs from its original'
+    _, _, _, grads_small = run(distinct)
+    err = (grads_full - reps * grads_small).abs().max().item()
+    assert err <= 2e-4 * (reps * grads_small).abs().max().item(), err
+
+
 def test_inplace_append_is_bitwise_identical():
     """reserve_rows (carried state extended in place, no copy) must not change a single bit, fwd or bwd."""
     from trackmpnn_amd import TrackMPNN
