@@ -156,6 +156,11 @@ int tmpnn_gru_bwd_data(const int32_t* rows, int R, int IN, const float* h, int l
                        tmpnn_stream stream);
 /* Weight gradient: dW_ih [3H][IN], dW_hh [3H][H], db_ih [3H], db_hh [3H] are ACCUMULATED (+=).
  * x is re-formed as in tmpnn_gru_fwd (xmode).  ws: tmpnn_gru_bwd_weights_ws(R, IN, H) bytes. */
+/* Which H = 64 weight-gradient kernel this process uses: 1 = bf16x6 split products, 0 = f32-input MFMA, -1 = not
+ * decided yet.  Unless TMPNN_SPLIT_WEIGHTS=0/1 (or TMPNN_SPLIT=0) fixes it, the first call with >= 2^20 rows times
+ * both forms once on the caller's stream (the ONLY place the library synchronises) and keeps the faster one: the
+ * ranking of the two differs between MI355X machines. */
+int tmpnn_gru_bwd_weights_choice(void);
 size_t tmpnn_gru_bwd_weights_ws(int R, int IN, int H);
 int tmpnn_gru_bwd_weights(const int32_t* rows, int R, int xmode, const int32_t* src, const int32_t* dst,
                           const float* msg, int ld_msg, int msg_compact, int IN,

@@ -67,6 +67,7 @@ _SIGNATURES = {
                                     c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int,
                                     c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                     c_void_p, c_size_t, c_void_p]),
+    'tmpnn_gru_bwd_weights_choice': (c_int, []),
     'tmpnn_rows_linear': (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p]),
     'tmpnn_transpose': (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
     'tmpnn_input_bn_fwd': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,

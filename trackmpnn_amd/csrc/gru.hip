@@ -14,6 +14,7 @@
 // Exact fp32 (MFMA f32 == fmaf chain), within 1e-6 of torch.nn.GRUCell.
 #include "common.h"
 #include <algorithm>
+#include <atomic>
 #include <stdlib.h>
 
 namespace tmpnn {
@@ -1491,14 +1492,28 @@ __device__ __forceinline__ int swz_off(int row, int col) {
 }
 
 struct WRaw { float4 dh[2], r[2], z[2], n[2], hn[2], hp[2], x[2], x2[2]; bool valid; };
+// row ids of one staged row: fetched one tile AHEAD of the rows themselves, so the row loads of a tile do not
+// start with a dependent index round trip (the kernel has no room to prefetch the rows; see the register note)
+struct WIds { int lpos, orow, s, d; bool valid; };
+
+template <int XMODE>
+__device__ __forceinline__ WIds w_ids(const GruBwdWArgs& a, int tile, int srow) {
+    WIds w;
+    const int lpos_raw = tile * 32 + srow;
+    w.valid = lpos_raw < a.R;
+    w.lpos = w.valid ? lpos_raw : a.R - 1;
+    w.orow = a.rows[w.lpos];
+    w.s = XMODE != 0 ? a.src[w.lpos] : 0;
+    w.d = XMODE != 0 ? a.dst[w.lpos] : 0;
+    return w;
+}
 
 template <int XMODE, int UP>
-__device__ __forceinline__ void w_issue(const GruBwdWArgs& a, int tile, int srow, int f8, WRaw& q) {
+__device__ __forceinline__ void w_issue(const GruBwdWArgs& a, const WIds& w, int f8, WRaw& q) {
     constexpr int H = 64;
-    const int lpos_raw = tile * 32 + srow;
-    q.valid = lpos_raw < a.R;
-    const int lpos = q.valid ? lpos_raw : a.R - 1;
-    const int orow = a.rows[lpos];
+    q.valid = w.valid;
+    const int lpos = w.lpos;
+    const int orow = w.orow;
     const size_t gp = a.gate_plane;
     const float4* p;
     if (UP & 1) {
@@ -1528,9 +1543,9 @@ __device__ __forceinline__ void w_issue(const GruBwdWArgs& a, int tile, int srow
         p = reinterpret_cast<const float4*>(a.msg + (size_t)(a.msg_compact ? lpos : orow) * a.ld_msg + f8);
         q.x[0] = p[0]; q.x[1] = p[1];
     } else {
-        p = reinterpret_cast<const float4*>(a.h + (size_t)a.src[lpos] * a.ld_h + f8);
+        p = reinterpret_cast<const float4*>(a.h + (size_t)w.s * a.ld_h + f8);
         q.x[0] = p[0]; q.x[1] = p[1];
-        p = reinterpret_cast<const float4*>(a.h + (size_t)a.dst[lpos] * a.ld_h + f8);
+        p = reinterpret_cast<const float4*>(a.h + (size_t)w.d * a.ld_h + f8);
         q.x2[0] = p[0]; q.x2[1] = p[1];
     }
 }
@@ -1570,10 +1585,13 @@ __global__ __launch_bounds__(256, 2) void k_gru_bwd_weights_split(GruBwdWArgs a,
         colA0[j] = (which == 1 && jj0 >= 2 * H) ? jj0 + H : jj0;
     }
 
+    WIds ids = w_ids<XMODE>(a, min((int)blockIdx.x, ntiles - 1), srow);
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        // (no cross-tile prefetch: the six accumulator tiles leave no room for it; the CU's second block covers the latency)
+        // (no cross-tile prefetch of the rows: the six accumulator tiles leave no room for it; the CU's second block
+        //  covers that latency.  The row IDS of the next tile are fetched during this tile.)
         WRaw raw;
-        w_issue<XMODE, UP>(a, tile, srow, f8, raw);
+        w_issue<XMODE, UP>(a, ids, f8, raw);
+        ids = w_ids<XMODE>(a, min(tile + (int)gridDim.x, ntiles - 1), srow);
         float dh[8], r[8], z[8], n[8], hn[8], hp[8], x[8];
         f4_to_arr(raw.dh[0], raw.dh[1], dh); f4_to_arr(raw.r[0], raw.r[1], r); f4_to_arr(raw.z[0], raw.z[1], z);
         f4_to_arr(raw.n[0], raw.n[1], n); f4_to_arr(raw.hn[0], raw.hn[1], hn); f4_to_arr(raw.hp[0], raw.hp[1], hp);
@@ -1595,25 +1613,26 @@ __global__ __launch_bounds__(256, 2) void k_gru_bwd_weights_split(GruBwdWArgs a,
             dz[i] = d0 * (hp[i] - n[i]) * z[i] * (1.0f - z[i]);
             cs[0][i] += dr[i]; cs[1][i] += dz[i]; cs[2][i] += dn[i]; cs[3][i] += dnr[i];
         }
-        const Split8 s0 = split8_arr(dr), s1 = split8_arr(dz), s2 = split8_arr(dn), s3 = split8_arr(dnr);
-        const Split8 sx = split8_arr(x), sh = split8_arr(hp);
         __syncthreads();                         // the previous tile's matrix phase has drained the LDS
         {
-            uint16_t* d = sA + swz_off<DG>(srow, f8);          // + arr*64 stays inside the row: chunk index += 2*arr
-            // (col >> 5) ^ (row & 3): adding 64 columns adds 2 to the chunk index before the XOR
-            const int o1 = swz_off<DG>(srow, H + f8) - swz_off<DG>(srow, f8);
-            const int o2 = swz_off<DG>(srow, 2 * H + f8) - swz_off<DG>(srow, f8);
-            const int o3 = swz_off<DG>(srow, 3 * H + f8) - swz_off<DG>(srow, f8);
-            constexpr int PA = RT * DG;
-            *reinterpret_cast<uint4*>(d) = s0.p1; *reinterpret_cast<uint4*>(d + PA) = s0.p2; *reinterpret_cast<uint4*>(d + 2 * PA) = s0.p3;
-            *reinterpret_cast<uint4*>(d + o1) = s1.p1; *reinterpret_cast<uint4*>(d + o1 + PA) = s1.p2; *reinterpret_cast<uint4*>(d + o1 + 2 * PA) = s1.p3;
-            *reinterpret_cast<uint4*>(d + o2) = s2.p1; *reinterpret_cast<uint4*>(d + o2 + PA) = s2.p2; *reinterpret_cast<uint4*>(d + o2 + 2 * PA) = s2.p3;
-            *reinterpret_cast<uint4*>(d + o3) = s3.p1; *reinterpret_cast<uint4*>(d + o3 + PA) = s3.p2; *reinterpret_cast<uint4*>(d + o3 + 2 * PA) = s3.p3;
-            constexpr int PB = RT * XHW;
-            uint16_t* e = sB + swz_off<XHW>(srow, f8);
-            uint16_t* e2 = sB + swz_off<XHW>(srow, H + f8);
-            *reinterpret_cast<uint4*>(e) = sx.p1; *reinterpret_cast<uint4*>(e + PB) = sx.p2; *reinterpret_cast<uint4*>(e + 2 * PB) = sx.p3;
-            *reinterpret_cast<uint4*>(e2) = sh.p1; *reinterpret_cast<uint4*>(e2 + PB) = sh.p2; *reinterpret_cast<uint4*>(e2 + 2 * PB) = sh.p3;
+            // split each array right before its store (one array's pieces live at a time: the kernel sits at the
+            // 256-register limit of two blocks per CU)
+            constexpr int PA = RT * DG, PB = RT * XHW;
+#define W_PUT(img, off, plane, arr)                                                                         \
+    do {                                                                                                     \
+        const Split8 sp_ = split8_arr(arr);                                                                  \
+        uint16_t* d_ = (img) + (off);                                                                        \
+        *reinterpret_cast<uint4*>(d_) = sp_.p1;                                                              \
+        *reinterpret_cast<uint4*>(d_ + (plane)) = sp_.p2;                                                    \
+        *reinterpret_cast<uint4*>(d_ + 2 * (plane)) = sp_.p3;                                                \
+    } while (0)
+            W_PUT(sA, swz_off<DG>(srow, f8), PA, dr);
+            W_PUT(sA, swz_off<DG>(srow, H + f8), PA, dz);
+            W_PUT(sA, swz_off<DG>(srow, 2 * H + f8), PA, dn);
+            W_PUT(sA, swz_off<DG>(srow, 3 * H + f8), PA, dnr);
+            W_PUT(sB, swz_off<XHW>(srow, f8), PB, x);
+            W_PUT(sB, swz_off<XHW>(srow, H + f8), PB, hp);
+#undef W_PUT
         }
         __syncthreads();
 #pragma unroll
@@ -2131,6 +2150,16 @@ __global__ void k_fold_slabs_gru(const float* __restrict__ slabs, size_t stride,
     out[(size_t)blockIdx.y * n + i] = s;
 }
 
+// weight-gradient kernel choice at H = 64 (see tmpnn_gru_bwd_weights): -1 = measure on first large call
+static std::atomic<int> g_weights_split_choice{[] {
+    const char* e = getenv("TMPNN_SPLIT_WEIGHTS");
+    return (e && (e[0] == '0' || e[0] == '1')) ? e[0] - '0' : -1;
+}()};
+static bool stream_is_capturing(hipStream_t st) {
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    return hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone;
+}
+
 // TMPNN_SPLIT=0 keeps every GEMM on the f32-input MFMA (v_mfma_f32_32x32x2_f32)
 static bool split_enabled() {
     static const int on = [] { const char* e = getenv("TMPNN_SPLIT"); return (e && e[0] == '0') ? 0 : 1; }();
@@ -2444,6 +2473,8 @@ int tmpnn_gru_bwd_fused(const int32_t* rows, int R, int xmode, const int32_t* sr
     return check_launch("gru_reduce_w");
 }
 
+int tmpnn_gru_bwd_weights_choice(void) { return g_weights_split_choice.load(); }
+
 size_t tmpnn_gru_bwd_weights_ws(int R, int IN, int H) {
     if (R <= 0) return 0;
     int n_rs, RS, NQ, NCH;
@@ -2491,30 +2522,62 @@ int tmpnn_gru_bwd_weights(const int32_t* rows, int R, int xmode, const int32_t* 
                   n_rs, RS, NQ, NCH};
     hipStream_t st = as_stream(stream);
     int rc;
-    if (use_lds && H == 64 && split_enabled()) {
+    if (use_lds) {
         const int ntiles = ceil_div(R, 32);
         dim3 grid(n_rs), block(256);
         const size_t shm = (size_t)3 * 32 * (256 + 128) * 2;
         const int up = (d_hout ? 1 : 0) | (dy ? 2 : 0);
+        auto launch_split = [&]() {
 #define SW(X, U)                                                                                             \
     do {                                                                                                     \
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gru_bwd_weights_split<X, U>),             \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);                     \
         hipLaunchKernelGGL((k_gru_bwd_weights_split<X, U>), grid, block, shm, st, a, ntiles);                \
     } while (0)
-        if (xmode == 0) { if (up == 1) SW(0, 1); else if (up == 2) SW(0, 2); else SW(0, 3); }
-        else            { if (up == 1) SW(1, 1); else if (up == 2) SW(1, 2); else SW(1, 3); }
+            if (xmode == 0) { if (up == 1) SW(0, 1); else if (up == 2) SW(0, 2); else SW(0, 3); }
+            else            { if (up == 1) SW(1, 1); else if (up == 2) SW(1, 2); else SW(1, 3); }
 #undef SW
-        rc = check_launch("gru_bwd_weights_split");
-    } else if (use_lds) {
-        const int ntiles = ceil_div(R, 32);
-        dim3 grid(n_rs), block(256);
-        const int up = (d_hout ? 1 : 0) | (dy ? 2 : 0);
+        };
+        auto launch_f32 = [&]() {
 #define LW(X, U) hipLaunchKernelGGL((k_gru_bwd_weights_lds<64, X, U>), grid, block, 0, st, a, ntiles)
-        if (xmode == 0) { if (up == 1) LW(0, 1); else if (up == 2) LW(0, 2); else LW(0, 3); }
-        else            { if (up == 1) LW(1, 1); else if (up == 2) LW(1, 2); else LW(1, 3); }
+            if (xmode == 0) { if (up == 1) LW(0, 1); else if (up == 2) LW(0, 2); else LW(0, 3); }
+            else            { if (up == 1) LW(1, 1); else if (up == 2) LW(1, 2); else LW(1, 3); }
 #undef LW
-        rc = check_launch("gru_bwd_weights_lds");
+        };
+        // Which form is faster depends on the machine: the bf16x6 kernel moves 25 % fewer cycles through the
+        // matrix pipe but, with no room to prefetch rows, it is latency-bound; on some MI355X boxes it measured
+        // 1.3x FASTER than the f32-MFMA kernel and on others 1.25x SLOWER (same binary, same inputs).  So the first
+        // large call of a process times both once (two events, one synchronisation, ~10 ms) and the winner is kept.
+        // TMPNN_SPLIT_WEIGHTS=0/1 (or TMPNN_SPLIT=0) fixes the choice and skips the measurement.
+        int choice = split_enabled() && H == 64 ? g_weights_split_choice.load() : 0;
+        if (choice < 0 && R >= (1 << 20) && !stream_is_capturing(st)) {
+            hipEvent_t e0, e1, e2;
+            if (hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess && hipEventCreate(&e2) == hipSuccess) {
+                launch_f32();
+                launch_split();                      // warm both
+                (void)hipEventRecord(e0, st);
+                launch_split();
+                (void)hipEventRecord(e1, st);
+                launch_f32();
+                (void)hipEventRecord(e2, st);
+                float t_split = 0.f, t_f32 = 0.f;
+                if (hipEventSynchronize(e2) == hipSuccess && hipEventElapsedTime(&t_split, e0, e1) == hipSuccess &&
+                    hipEventElapsedTime(&t_f32, e1, e2) == hipSuccess && t_split > 0.f && t_f32 > 0.f) {
+                    choice = t_split <= t_f32 ? 1 : 0;
+                    g_weights_split_choice.store(choice);
+                }
+                (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipEventDestroy(e2);
+            }
+            (void)hipGetLastError();
+            // (the slabs now hold the f32 kernel's partial sums of THIS call: valid input for the reduction below)
+            rc = check_launch("gru_bwd_weights_calibrate");
+        } else if (choice != 0) {
+            launch_split();
+            rc = check_launch("gru_bwd_weights_split");
+        } else {
+            launch_f32();
+            rc = check_launch("gru_bwd_weights_lds");
+        }
     } else if (use_chunk) {
         const int ntiles = ceil_div(R, 32);
         const int n_cc = ceil_div(IN + H, 128);
