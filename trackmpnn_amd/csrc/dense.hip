@@ -402,27 +402,48 @@ __global__ __launch_bounds__(256) void k_heads_bwd(const float* __restrict__ h, 
     const long r0 = (long)blockIdx.x * rows_per_block;
     const long r1 = min((long)N, r0 + rows_per_block);
     if (active) {
-        for (long i = r0 + slot; i < r1; i += slots) {
-            float dy = d_logits ? d_logits[i] : 0.f;
-            if (d_scores) {
-                const float s = scores[i];
-                dy += d_scores[i] * s * (1.0f - s);
-            }
-            const bool e = is_edge[i] != 0;
-            const float4 w = *reinterpret_cast<const float4*>((e ? w_edge : w_node) + c4);
-            const float4 x = *reinterpret_cast<const float4*>(h + (size_t)i * ld_h + c4);
-            if (dy_out && c4 == 0) dy_out[i] = dy;
-            if (d_h) {
-                float* dp = d_h + (size_t)i * ld_dh + c4;
-                float4 o = make_float4(dy * w.x, dy * w.y, dy * w.z, dy * w.w);
-                if (accumulate) {
-                    const float4 p = *reinterpret_cast<const float4*>(dp);
-                    o.x += p.x; o.y += p.y; o.z += p.z; o.w += p.w;
+        // four rows per trip with every load issued up front: one row per trip leaves the loop latency-bound
+        // (a dependent scalar + 16-byte load chain per row and ~200 trips per thread)
+        constexpr int UR = 4;
+        for (long i0 = r0 + slot; i0 < r1; i0 += (long)slots * UR) {
+            float dyv[UR];
+            bool ev[UR], live[UR];
+            float4 xv[UR];
+#pragma unroll
+            for (int u = 0; u < UR; ++u) {
+                const long i = i0 + (long)u * slots;
+                live[u] = i < r1;
+                const long ic = live[u] ? i : r1 - 1;
+                float dy = d_logits ? d_logits[ic] : 0.f;
+                if (d_scores) {
+                    const float sc = scores[ic];
+                    dy += d_scores[ic] * sc * (1.0f - sc);
                 }
-                *reinterpret_cast<float4*>(dp) = o;
+                dyv[u] = live[u] ? dy : 0.f;
+                ev[u] = is_edge[ic] != 0;
+                xv[u] = *reinterpret_cast<const float4*>(h + (size_t)ic * ld_h + c4);
             }
-            if (e) { ae.x += dy * x.x; ae.y += dy * x.y; ae.z += dy * x.z; ae.w += dy * x.w; if (c4 == 0) be += dy; }
-            else   { an.x += dy * x.x; an.y += dy * x.y; an.z += dy * x.z; an.w += dy * x.w; if (c4 == 0) bn += dy; }
+#pragma unroll
+            for (int u = 0; u < UR; ++u) {
+                if (!live[u]) continue;
+                const long i = i0 + (long)u * slots;
+                const float dy = dyv[u];
+                const bool e = ev[u];
+                const float4 x = xv[u];
+                if (dy_out && c4 == 0) dy_out[i] = dy;
+                if (d_h) {
+                    const float4 w = *reinterpret_cast<const float4*>((e ? w_edge : w_node) + c4);
+                    float* dp = d_h + (size_t)i * ld_dh + c4;
+                    float4 o = make_float4(dy * w.x, dy * w.y, dy * w.z, dy * w.w);
+                    if (accumulate) {
+                        const float4 p = *reinterpret_cast<const float4*>(dp);
+                        o.x += p.x; o.y += p.y; o.z += p.z; o.w += p.w;
+                    }
+                    *reinterpret_cast<float4*>(dp) = o;
+                }
+                if (e) { ae.x += dy * x.x; ae.y += dy * x.y; ae.z += dy * x.z; ae.w += dy * x.w; if (c4 == 0) be += dy; }
+                else   { an.x += dy * x.x; an.y += dy * x.y; an.z += dy * x.z; an.w += dy * x.w; if (c4 == 0) bn += dy; }
+            }
         }
         float* my = sm + (size_t)slot * 2 * C;
         *reinterpret_cast<float4*>(my + c4) = an;
