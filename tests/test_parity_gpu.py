@@ -355,6 +355,43 @@ def test_inplace_append_is_bitwise_identical():
         assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize('heads', [0, 2])
+def test_inplace_param_grad_accumulation_matches_returned_grads(heads):
+    """With p.grad buffers in place (zero_grad(set_to_none=False), GradBucket) the kernels add each call's parameter
+    gradients straight into them and autograd gets None; without, the per-call tensors are returned and autograd adds
+    them.  Same kernels; only the association of the per-call sums changes (a parameter that receives two partial sums
+    per call sees (prev + a) + b instead of prev + (a + b)), so the results agree to fp32 rounding, and a second
+    backward accumulates on top (2 x)."""
+    from trackmpnn_amd import TrackMPNN
+    plans, xs = _batched_case(B=6, frames=5, mean=4, max_dets=10, F=8, seed0=11)
+    results = []
+    for preallocate in (False, True):
+        torch.manual_seed(5)
+        model = TrackMPNN('2d', 3, 64, heads, 'diff').to(DEV).train()
+        if preallocate:
+            for p in model.parameters():
+                p.grad = torch.zeros_like(p)
+        reps = 2 if preallocate else 1
+        for _ in range(reps):
+            torch.manual_seed(77)                     # same attention dropout draw in every run
+            h, loss = None, 0.0
+            for plan, x in zip(plans, xs):
+                s, l, h, _ = model.forward_graph(x.to(DEV), h, plan.to(DEV))
+                loss = loss + (l * l).sum() + s.sum()
+            loss.backward()
+            if len(results) < 2:
+                results.append([p.grad.clone() for p in model.parameters()])
+        if preallocate:
+            final = [p.grad.clone() for p in model.parameters()]
+    scale = max(float(a.abs().max()) for a in results[0])
+    for a, b in zip(results[0], results[1]):
+        assert float((a - b).abs().max()) <= 2e-6 * max(float(a.abs().max()), 1e-3 * scale)
+    for a, b in zip(results[1], final):
+        # (the pre-BatchNorm bias has a zero true gradient: what it holds is cancellation noise, so compare at the
+        #  scale of the largest gradient)
+        assert float((2 * a - b).abs().max()) <= 4e-6 * max(float(a.abs().max()), 1e-3 * scale)
+
+
 def test_fused_backward_matches_two_kernel_backward(monkeypatch):
     """tmpnn_gru_bwd_fused (opt-in) gives the gradients of the default two-kernel backward."""
     import trackmpnn_amd.functional as F

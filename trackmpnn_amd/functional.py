@@ -18,6 +18,9 @@ from . import _lib
 from .graph import CallPlan
 
 ATT_DROPOUT_P = 0.5
+# accumulate parameter gradients straight into existing p.grad buffers (the kernels add into their outputs) instead
+# of returning per-call tensors for autograd to add: saves a zero-fill and ~20 small add kernels per call
+INPLACE_GRADS = os.environ.get('TMPNN_INPLACE_GRADS', '1') != '0'
 FUSED_BWD = os.environ.get('TMPNN_FUSED_BWD', '0') == '1'     # see mp_backward
 
 
@@ -247,7 +250,7 @@ def mp_forward(spec: ModelSpec, plan: CallPlan, x: torch.Tensor, h_in: Optional[
 
 def mp_backward(spec: ModelSpec, plan: CallPlan, saved: dict, P: Dict[str, torch.Tensor], training: bool,
                 d_scores: Optional[torch.Tensor], d_logits: Optional[torch.Tensor], d_hout: Optional[torch.Tensor],
-                need_x: bool, need_h: bool):
+                need_x: bool, need_h: bool, grad_out=None):
     """Returns (d_x | None, d_h_in | None, {param name: grad})."""
     g = plan.graph
     H, G, K = spec.H, spec.G, spec.K
@@ -265,8 +268,11 @@ def mp_backward(spec: ModelSpec, plan: CallPlan, saved: dict, P: Dict[str, torch
     offs = [0]
     for sz in sizes:
         offs.append(offs[-1] + ((sz + 63) // 64) * 64)          # 256-byte aligned slices
-    flat = torch.zeros((offs[-1],), **opts)
-    grads = {nm: flat[o:o + sz].view(P[nm].shape) for nm, o, sz in zip(names, offs, sizes)}
+    if grad_out is not None:
+        grads = dict(grad_out)                 # caller-owned accumulators (p.grad): every kernel below adds into them
+    else:
+        flat = torch.zeros((offs[-1],), **opts)
+        grads = {nm: flat[o:o + sz].view(P[nm].shape) for nm, o, sz in zip(names, offs, sizes)}
 
     # heads (track_mpnn.py:72-75): dy = d_logits + d_scores * s(1-s); its contribution dy * w_type to the
     # gradient of h_out is folded into the GRU backward kernels (never materialised)
@@ -366,8 +372,12 @@ def mp_backward(spec: ModelSpec, plan: CallPlan, saved: dict, P: Dict[str, torch
                       dmsg.data_ptr(), IN_e, ws_att.data_ptr(), ws_att.numel(), ws_dha.data_ptr(), ws_edge.data_ptr(),
                       dhg, GH, dW.data_ptr(), da.data_ptr(), st)
             for k in range(K):
-                grads[f + f'gat.{k}.W_att'] = dW[k]
-                grads[f + f'gat.{k}.a'] = da[k].reshape(-1, 1)
+                if grad_out is not None:
+                    grads[f + f'gat.{k}.W_att'].add_(dW[k])
+                    grads[f + f'gat.{k}.a'].add_(da[k].reshape(-1, 1))
+                else:
+                    grads[f + f'gat.{k}.W_att'] = dW[k]
+                    grads[f + f'gat.{k}.a'] = da[k].reshape(-1, 1)
         # adjoint of the node -> edge message: into d_hcat[det rows]
         name = 'tmpnn_gather_concat_bwd' if spec.msg_type == 'concat' else 'tmpnn_gather_diff_bwd'
         _lib.call(name, g.cref(), dmsg.data_ptr(), IN_e, dhg, GH, H, 1, st)
@@ -439,9 +449,18 @@ class MPIteration(torch.autograd.Function):
         call = ctx.call
         spec: ModelSpec = call['spec']
         need = ctx.needs_input_grad
+        names = spec.param_names()
+        objs = call.get('param_objs')
+        grad_out = None
+        if INPLACE_GRADS and objs is not None and all(need[3:]):
+            gs = [p.grad for p in objs]
+            if all(g is not None and g.dtype == torch.float32 and g.is_contiguous() and g.device == ctx.P[nm].device
+                   and g.shape == ctx.P[nm].shape for g, nm in zip(gs, names)):
+                grad_out = dict(zip(names, gs))
         d_x, d_h_in, grads = mp_backward(spec, call['plan'], ctx.saved, ctx.P, call['training'],
                                          d_scores, d_logits, d_hout, need_x=need[1],
-                                         need_h=ctx.has_h and need[2])
+                                         need_h=ctx.has_h and need[2], grad_out=grad_out)
         ctx.saved = None
-        names = spec.param_names()
+        if grad_out is not None:
+            return (None, d_x, d_h_in) + (None,) * len(names)      # already added into p.grad
         return (None, d_x, d_h_in) + tuple(grads[nm] for nm in names)

@@ -117,7 +117,8 @@ class TrackMPNN(nn.Module):
             x.requires_grad or (h_in is not None and h_in.requires_grad) or any(p.requires_grad for p in params))
         call = dict(spec=self.spec, plan=plan, buffers=buffers, training=self.training, need_grad=need_grad,
                     keep=dropout_keep, reserve=reserve_rows,
-                    h_spare=getattr(h_in, '_tmpnn_spare_rows', 0) if h_in is not None else 0)
+                    h_spare=getattr(h_in, '_tmpnn_spare_rows', 0) if h_in is not None else 0,
+                    param_objs=params)
         scores, logits, h_out = MPIteration.apply(call, x, h_in, *params)
         h_out._tmpnn_spare_rows = max(int(reserve_rows), 0)
         attention = tuple(None if a is None else [SparseAttention(plan.graph, ak) for ak in a]
