@@ -750,6 +750,16 @@ __global__ __launch_bounds__(WPB * 64) void k_gru_fwd_split(GruFwdArgs a) {
     }
     float* stg_base = reinterpret_cast<float*>(sW + 3 * H3 * KP);
     int* next_item = reinterpret_cast<int*>(stg_base + WPB * (32 * STG_LD));
+    // gate biases, pre-added where the cell adds them: [b_ir+b_hr | b_iz+b_hz | b_in | b_hn | w_head], read back with
+    // ds_read_b128 in the epilogue (24 fewer vector-memory instructions per item than fetching them from L1)
+    float* sBias = reinterpret_cast<float*>(next_item + 4);
+    for (int i = threadIdx.x; i < H; i += WPB * 64) {
+        sBias[i] = a.b_ih[i] + a.b_hh[i];
+        sBias[H + i] = a.b_ih[H + i] + a.b_hh[H + i];
+        sBias[2 * H + i] = a.b_ih[2 * H + i];
+        sBias[3 * H + i] = a.b_hh[2 * H + i];
+        sBias[4 * H + i] = a.logit_part ? a.w_head[i] : 0.f;      // output head slice for the fused partial dot product
+    }
     if (threadIdx.x == 0) *next_item = 0;
     __syncthreads();
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -825,16 +835,14 @@ __global__ __launch_bounds__(WPB * 64) void k_gru_fwd_split(GruFwdArgs a) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int col = cw0 + 8 * q + 4 * half;
-            const float4 bir = *reinterpret_cast<const float4*>(a.b_ih + col);
-            const float4 bhr = *reinterpret_cast<const float4*>(a.b_hh + col);
-            const float4 biz = *reinterpret_cast<const float4*>(a.b_ih + H + col);
-            const float4 bhz = *reinterpret_cast<const float4*>(a.b_hh + H + col);
-            const float4 bin = *reinterpret_cast<const float4*>(a.b_ih + 2 * H + col);
-            const float4 bhn = *reinterpret_cast<const float4*>(a.b_hh + 2 * H + col);
-            const float br[4] = {bir.x + bhr.x, bir.y + bhr.y, bir.z + bhr.z, bir.w + bhr.w};
-            const float bz[4] = {biz.x + bhz.x, biz.y + bhz.y, biz.z + bhz.z, biz.w + bhz.w};
-            const float bi[4] = {bin.x, bin.y, bin.z, bin.w};
-            const float bh[4] = {bhn.x, bhn.y, bhn.z, bhn.w};
+            const float4 b4r = *reinterpret_cast<const float4*>(sBias + col);
+            const float4 b4z = *reinterpret_cast<const float4*>(sBias + H + col);
+            const float4 b4i = *reinterpret_cast<const float4*>(sBias + 2 * H + col);
+            const float4 b4h = *reinterpret_cast<const float4*>(sBias + 3 * H + col);
+            const float br[4] = {b4r.x, b4r.y, b4r.z, b4r.w};
+            const float bz[4] = {b4z.x, b4z.y, b4z.z, b4z.w};
+            const float bi[4] = {b4i.x, b4i.y, b4i.z, b4i.w};
+            const float bh[4] = {b4h.x, b4h.y, b4h.z, b4h.w};
             const float hp[4] = {hp4[q].x, hp4[q].y, hp4[q].z, hp4[q].w};
             const float* ps = a.msg + (size_t)ix.s * a.ld_msg + col;
             const float* pd = a.msg + (size_t)ix.d * a.ld_msg + col;
@@ -859,7 +867,7 @@ __global__ __launch_bounds__(WPB * 64) void k_gru_fwd_split(GruFwdArgs a) {
             float p = 0.f;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const float4 w = *reinterpret_cast<const float4*>(a.w_head + cw0 + 8 * q + 4 * half);
+                const float4 w = *reinterpret_cast<const float4*>(sBias + 4 * H + cw0 + 8 * q + 4 * half);
                 p += outv[4 * q] * w.x + outv[4 * q + 1] * w.y + outv[4 * q + 2] * w.z + outv[4 * q + 3] * w.w;
             }
             p += __shfl_xor(p, 32);
@@ -1179,6 +1187,8 @@ __global__ __launch_bounds__(512) void k_gru_bwd_data_split(GruBwdDataArgs a, in
         }
     }
     int* next_item = reinterpret_cast<int*>(sWT + 3 * XH * JP);
+    float* sHead = reinterpret_cast<float*>(next_item + 4);          // output head slice (UP & 2), read with ds_read_b128
+    if ((UP & 2) && threadIdx.x < H) sHead[threadIdx.x] = a.up.w_head[threadIdx.x];
     if (threadIdx.x == 0) *next_item = 0;
     __syncthreads();
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -1214,8 +1224,8 @@ __global__ __launch_bounds__(512) void k_gru_bwd_data_split(GruBwdDataArgs a, in
             f4_to_arr(cur.dh[0], cur.dh[1], dh); f4_to_arr(cur.r[0], cur.r[1], r); f4_to_arr(cur.z[0], cur.z[1], z);
             f4_to_arr(cur.n[0], cur.n[1], n); f4_to_arr(cur.hn[0], cur.hn[1], hn); f4_to_arr(cur.hp[0], cur.hp[1], hp);
             if (UP & 2) {
-                const float4 w0 = *reinterpret_cast<const float4*>(a.up.w_head + f0);
-                const float4 w1 = *reinterpret_cast<const float4*>(a.up.w_head + f0 + 4);
+                const float4 w0 = *reinterpret_cast<const float4*>(sHead + f0);
+                const float4 w1 = *reinterpret_cast<const float4*>(sHead + f0 + 4);
                 dh[0] += dyr * w0.x; dh[1] += dyr * w0.y; dh[2] += dyr * w0.z; dh[3] += dyr * w0.w;
                 dh[4] += dyr * w1.x; dh[5] += dyr * w1.y; dh[6] += dyr * w1.z; dh[7] += dyr * w1.w;
             }
@@ -2232,7 +2242,7 @@ int tmpnn_gru_fwd(const int32_t* rows, int R, int xmode, const int32_t* src, con
         const int wpb = (H == 64) ? 12 : 8;
         if (xmode == 3 && split_enabled()) {
             // bf16x6 operand path, 8 waves (two per SIMD: the prefetched next operand needs the registers)
-            const size_t shm2 = (size_t)3 * 3 * H * (H + 8) * 2 + sizeof(float) * ((size_t)8 * 32 * STG_LD + 4);
+            const size_t shm2 = (size_t)3 * 3 * H * (H + 8) * 2 + sizeof(float) * ((size_t)8 * 32 * STG_LD + 4 + 5 * H);
             if (H == 64) {
                 (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gru_fwd_split<64, 8>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm2);
@@ -2334,7 +2344,7 @@ int tmpnn_gru_bwd_data(const int32_t* rows, int R, int IN, const float* h, int l
         const int up = (d_hout ? 1 : 0) | (dy ? 2 : 0);
         const bool fuse = add_msg != nullptr;
         if (split_enabled() && IN == H) {
-            const size_t shm2 = (size_t)3 * (IN + H) * (3 * H + 8) * 2 + 16;
+            const size_t shm2 = (size_t)3 * (IN + H) * (3 * H + 8) * 2 + 16 + sizeof(float) * H;
 #define S3(HH, UU, FF)                                                                                       \
     do {                                                                                                     \
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gru_bwd_data_split<HH, UU, FF>),          \
