@@ -1519,7 +1519,7 @@ __device__ __forceinline__ WIds w_ids(const GruBwdWArgs& a, int tile, int srow) 
 }
 
 template <int XMODE, int UP>
-__device__ __forceinline__ void w_issue(const GruBwdWArgs& a, const WIds& w, int f8, WRaw& q) {
+__device__ __forceinline__ void w_issue(const GruBwdWArgs& a, const WIds& w, int f8, const float* s_head, WRaw& q) {
     constexpr int H = 64;
     q.valid = w.valid;
     const int lpos = w.lpos;
@@ -1534,8 +1534,8 @@ __device__ __forceinline__ void w_issue(const GruBwdWArgs& a, const WIds& w, int
     }
     if (UP & 2) {
         const float d = a.up.dy[orow];
-        const float4* w = reinterpret_cast<const float4*>(a.up.w_head + f8);
-        const float4 w0 = w[0], w1 = w[1];
+        const float4* wh = reinterpret_cast<const float4*>(s_head + f8);       // head slice, staged in LDS once per block
+        const float4 w0 = wh[0], w1 = wh[1];
         q.dh[0].x += d * w0.x; q.dh[0].y += d * w0.y; q.dh[0].z += d * w0.z; q.dh[0].w += d * w0.w;
         q.dh[1].x += d * w1.x; q.dh[1].y += d * w1.y; q.dh[1].z += d * w1.z; q.dh[1].w += d * w1.w;
     }
@@ -1566,6 +1566,9 @@ __global__ __launch_bounds__(256, 2) void k_gru_bwd_weights_split(GruBwdWArgs a,
     extern __shared__ float lds[];
     uint16_t* sA = reinterpret_cast<uint16_t*>(lds);           // [3][RT][DG]   swizzled
     uint16_t* sB = sA + 3 * RT * DG;                           // [3][RT][XHW]  swizzled
+    float* s_head = reinterpret_cast<float*>(sB + 3 * RT * XHW);   // [H] output head slice (UP & 2)
+    if ((UP & 2) && threadIdx.x < H) s_head[threadIdx.x] = a.up.w_head[threadIdx.x];
+    if (UP & 2) __syncthreads();
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
     const int c = lane & 31, half = lane >> 5;
@@ -1600,7 +1603,7 @@ __global__ __launch_bounds__(256, 2) void k_gru_bwd_weights_split(GruBwdWArgs a,
         // (no cross-tile prefetch of the rows: the six accumulator tiles leave no room for it; the CU's second block
         //  covers that latency.  The row IDS of the next tile are fetched during this tile.)
         WRaw raw;
-        w_issue<XMODE, UP>(a, ids, f8, raw);
+        w_issue<XMODE, UP>(a, ids, f8, s_head, raw);
         ids = w_ids<XMODE>(a, min(tile + (int)gridDim.x, ntiles - 1), srow);
         float dh[8], r[8], z[8], n[8], hn[8], hp[8], x[8];
         f4_to_arr(raw.dh[0], raw.dh[1], dh); f4_to_arr(raw.r[0], raw.r[1], r); f4_to_arr(raw.z[0], raw.z[1], z);
@@ -2535,7 +2538,7 @@ int tmpnn_gru_bwd_weights(const int32_t* rows, int R, int xmode, const int32_t* 
     if (use_lds) {
         const int ntiles = ceil_div(R, 32);
         dim3 grid(n_rs), block(256);
-        const size_t shm = (size_t)3 * 32 * (256 + 128) * 2;
+        const size_t shm = (size_t)3 * 32 * (256 + 128) * 2 + sizeof(float) * 64;
         const int up = (d_hout ? 1 : 0) | (dy ? 2 : 0);
         auto launch_split = [&]() {
 #define SW(X, U)                                                                                             \
