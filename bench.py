@@ -365,7 +365,8 @@ def main():
             segsum_GBs=nbytes['segsum'] / (t['segsum'] * 1e-3) / 1e9)
         extra['stage_ms'] = {k: round(v, 4) for k, v in t.items()}
         from trackmpnn_amd import _lib as _l
-        extra['weights_kernel'] = {1: 'bf16x6', 0: 'f32-mfma', -1: 'undecided'}[_l.load().tmpnn_gru_bwd_weights_choice()]
+        extra['weights_kernel'] = ({1: 'bf16x6', 0: 'f32-mfma', -1: 'undecided'}[_l.load().tmpnn_gru_bwd_weights_choice()]
+                                   if split_enabled() else 'f32-mfma')
         extra['stage_graph'] = dict(N=plans[-1].graph.N, E=plans[-1].graph.E, Dn=plans[-1].graph.Dn)
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
