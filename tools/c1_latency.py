@@ -35,3 +35,23 @@ torch.cuda.synchronize()
 ms = (time.perf_counter() - t0) / n * 1e3
 print(f'C1 ({gold.ncalls} calls, N={N} rows, {E} edge-iterations): {ms:.2f} ms per fwd+bwd step through model(x, h, node_adj, edge_adj) '
       f'= {E / ms * 1e3:.3g} graph-edges/s (launch-latency bound: one window)')
+
+# where the time goes: adjacency -> index conversion alone, and the same step on prebuilt plans
+from trackmpnn_amd import plan_single
+torch.cuda.synchronize(); t0 = time.perf_counter()
+for _ in range(n):
+    graphs = [graph_from_adjacency(na, ea) for _, na, ea in calls]
+torch.cuda.synchronize(); conv = (time.perf_counter() - t0) / n * 1e3
+plans = [plan_single(g, x.shape[0]) for g, (x, _, _) in zip(graphs, calls)]
+def step2():
+    h, loss = None, 0.0
+    for (x, _, _), p in zip(calls, plans):
+        s, l, h, _ = model.forward_graph(x, h, p)
+        loss = loss + l.sum() + s.sum()
+    model.zero_grad(set_to_none=False)
+    loss.backward()
+for _ in range(5): step2()
+torch.cuda.synchronize(); t0 = time.perf_counter()
+for _ in range(n): step2()
+torch.cuda.synchronize(); pre = (time.perf_counter() - t0) / n * 1e3
+print(f'   adjacency -> index form: {conv:.2f} ms per step; forward_graph on prebuilt plans: {pre:.2f} ms per step')

@@ -112,9 +112,12 @@ def graph_from_edges(N: int, is_edge: torch.Tensor, src: torch.Tensor, dst: torc
     pos = det_pos.clone()
     pos[edge_row] = torch.arange(E, device=dev)
     if E > 0:
-        if bool(is_edge[src].any()) or bool(is_edge[dst].any()):
+        # both invariants in ONE host round trip (this runs once per forward call of the drop-in API)
+        bad = torch.stack([is_edge[src].any() | is_edge[dst].any(),
+                           ~((src < edge_row) & (edge_row < dst)).all()]).tolist()
+        if bad[0]:
             raise ValueError('edge endpoint is not a det row')
-        if not bool(((src < edge_row) & (edge_row < dst)).all()):
+        if bad[1]:
             raise ValueError('expected src row < edge row < dst row (utils/graph.py:153-156,298-301)')
     # incidences: (det index, edge row, sign) ; sorted by det, then by edge row
     d_all = torch.cat([det_pos[src], det_pos[dst]])
@@ -168,23 +171,27 @@ def graph_from_adjacency(node_adj: torch.Tensor, edge_adj: Optional[torch.Tensor
     edge_row = torch.nonzero(is_edge).flatten()
     if validate:
         E = int(edge_row.numel())
-        ok = (int(pos.sum()) == E and int(neg.sum()) == E and bool((vo.abs() == 1).all())
-              and not bool(is_det[ro].any())
-              and bool((src[edge_row] >= 0).all()) and bool((dst[edge_row] >= 0).all()))
-        if not ok:
-            raise ValueError('node_adj is not a TrackMPNN factor graph: every edge row needs exactly one +1 and '
-                             'one -1 off-diagonal entry and det rows none')
+        # every condition as a 0-dim tensor, fetched with one host round trip
+        conds = [pos.sum() == E, neg.sum() == E, (vo.abs() == 1).all(), ~is_det[ro].any(),
+                 (src[edge_row] >= 0).all(), (dst[edge_row] >= 0).all()]
         if edge_adj is not None:
+            # edge_adj must be node_adj^T off the diagonal: entry (det d, edge e, v) <=> d is the +1 (v > 0) or the
+            # -1 (v < 0) det of e, and there are exactly 2E of them -- elementwise, no sorting
             r2, c2, v2 = _coo(edge_adj.detach())
             d2 = r2 == c2
             ie = torch.zeros(N, dtype=torch.bool, device=dev)
             ie[r2[d2]] = True
-            if not bool((ie == is_edge).all()):
+            ro2, co2, vo2 = r2[~d2], c2[~d2], v2[~d2]
+            match = torch.where(vo2 > 0, src[co2] == ro2, dst[co2] == ro2) & (vo2.abs() == 1)
+            conds += [(ie == is_edge).all(), match.all(), torch.as_tensor(ro2.numel() == 2 * E, device=dev)]
+        ok = torch.stack([c.reshape(()) for c in conds]).tolist()
+        if not all(ok[:6]):
+            raise ValueError('node_adj is not a TrackMPNN factor graph: every edge row needs exactly one +1 and '
+                             'one -1 off-diagonal entry and det rows none')
+        if edge_adj is not None:
+            if not ok[6]:
                 raise ValueError('diag(edge_adj) does not complement diag(node_adj)')
-            ka = torch.argsort(c2[~d2] * N + r2[~d2])
-            kb = torch.argsort(ro * N + co)
-            if not (ka.numel() == kb.numel() and bool((c2[~d2][ka] == ro[kb]).all())
-                    and bool((r2[~d2][ka] == co[kb]).all()) and bool((v2[~d2][ka] == vo[kb]).all())):
+            if not (ok[7] and ok[8]):
                 raise ValueError('edge_adj is not node_adj^T off the diagonal')
     return graph_from_edges(N, is_edge, src[edge_row], dst[edge_row], device=dev)
 
