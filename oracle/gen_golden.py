@@ -59,7 +59,8 @@ def adj_arrays(adj):
     return nz.t().numpy().copy(), adj[nz[:, 0], nz[:, 1]].numpy().copy(), 1
 
 
-def run_fixture(name, out_dir, features, ncat, H, K, msg, mode, seed, T=4, dmean=3, static_iters=0, pscale=0.3):
+def run_fixture(name, out_dir, features, ncat, H, K, msg, mode, seed, T=4, dmean=3, static_iters=0, pscale=0.3,
+                sequence=None, extra_iter=True, h_every=1):
     from models.track_mpnn import TrackMPNN
     from utils.graph import initialize_graph, update_graph
 
@@ -79,7 +80,7 @@ def run_fixture(name, out_dir, features, ncat, H, K, msg, mode, seed, T=4, dmean
     for k, v in model.state_dict().items():
         out['param/' + k] = v.detach().numpy().copy()
 
-    X, y = synth_sequence(seed, T, dmean, ncat, features)
+    X, y = sequence if sequence is not None else synth_sequence(seed, T, dmean, ncat, features)
     X.requires_grad_(True)
     out['X'] = X.detach().numpy().copy()
     out['y'] = y.numpy().copy()
@@ -97,7 +98,7 @@ def run_fixture(name, out_dir, features, ncat, H, K, msg, mode, seed, T=4, dmean
         # static mode: only the final graph; x = every row, then empty-x iterations
         allx = torch.cat([c[0] for c in calls], 0)
         calls = [(allx, node_adj, edge_adj)] + [(allx[:0], node_adj, edge_adj)] * (static_iters - 1)
-    else:
+    elif extra_iter:
         calls.append((feats[:0], node_adj, edge_adj))   # extra MP iteration with empty x
 
     gw = torch.Generator().manual_seed(seed + 99)
@@ -121,7 +122,7 @@ def run_fixture(name, out_dir, features, ncat, H, K, msg, mode, seed, T=4, dmean
         out[pre + 'N'] = np.int64(N)
         out[pre + 'wl'] = wl.numpy().copy()
         out[pre + 'ws'] = ws.numpy().copy()
-        if static_iters == 0 or c == len(calls) - 1:
+        if (static_iters == 0 and c % h_every == 0) or c == len(calls) - 1:
             out[pre + 'h_out'] = h.detach().numpy().copy()
         out[pre + 'scores'] = scores.detach().numpy().copy()
         out[pre + 'logits'] = logits.detach().numpy().copy()
@@ -214,10 +215,148 @@ def run_loss_fixture(name, out_dir, seed, T=5, dmean=4):
     print(f'{name}: calls={len(graphs)} -> {os.path.getsize(path) / 1024:.0f} KiB')
 
 
+
+def window_sequence(seed, frames, mean_dets, max_dets, ncat):
+    """One KITTI/BDD-shaped chunk of the bench generator: y from trackmpnn_amd.graph.synth_window
+    (a pure numpy function: track survival 0.9, 10 % false positives, 20 % missed detections), X ~ N(0, 1)."""
+    from trackmpnn_amd.graph import synth_window
+    yy = synth_window(seed, frames, mean_dets, max_dets)
+    y = torch.from_numpy(yy)[None]
+    X = torch.randn(1, yy.shape[0], ncat + 5, generator=torch.Generator().manual_seed(seed + 1000))
+    return X, y
+
+
+def run_infer_fixture(name, out_dir, seed, T, dmean, cur_win, ret_win, hungarian, H=32, K=0, msg='diff'):
+    """The inference loop of infer.py:48-87 on the real reference: eval-mode model, update_graph(mode='test'),
+    decode_tracks(cuda=False) with its row deletion between calls.  Every forward call is stored with ITS inputs
+    (x, the row-deleted carried state, the adjacency pair as produced) and outputs; every decode step with the rows
+    it kept (read off a marker array passed as `labels`), y_pred before / after and the finalised tracks y_out."""
+    from models.track_mpnn import TrackMPNN
+    from utils.graph import decode_tracks, initialize_graph, update_graph
+
+    torch.manual_seed(5)
+    model = TrackMPNN('2d', 3, H, K, msg)
+    gp = torch.Generator().manual_seed(seed + 77)
+    with torch.no_grad():
+        for k, prm in model.named_parameters():
+            prm.add_(0.3 * torch.randn(prm.shape, generator=gp))
+            if k.startswith('output_transform') and k.endswith('bias'):
+                prm.copy_(0.5 * torch.randn(prm.shape, generator=gp))    # scores on both sides of 0.5
+        for k, b in model.named_buffers():
+            if k.endswith('running_mean'):
+                b.copy_(0.2 * torch.randn(b.shape, generator=gp))
+            elif k.endswith('running_var'):
+                b.copy_(0.5 + torch.rand(b.shape, generator=gp))
+    model.eval()
+    out = {}
+    for k, v in model.state_dict().items():
+        out['param/' + k] = v.detach().numpy().copy()
+    X, y = synth_sequence(seed, T, dmean, 3, '2d', fp_rate=0.2)
+    out['X'] = X.numpy().copy()
+    out['y'] = y.numpy().copy()
+    y_out = y.squeeze(0).numpy().astype('int64').copy()
+    y_out[:, 1] = -1
+
+    def record_call(c, x, h_in, na, ea, scores, logits, h, y_pred):
+        pre = f'c{c}/'
+        out[pre + 'x'] = x.detach().numpy().copy()
+        out[pre + 'has_h_in'] = np.int64(h_in is not None)
+        if h_in is not None:
+            out[pre + 'h_in'] = h_in.detach().numpy().copy()
+        for nm, a in (('node_adj', na), ('edge_adj', ea)):
+            idx, val, dense = adj_arrays(a.detach())
+            out[pre + nm + '_idx'] = idx.astype(np.int64)
+            out[pre + nm + '_val'] = val.astype(np.float32)
+            out[pre + nm + '_dense'] = np.int64(dense)
+        out[pre + 'N'] = np.int64(logits.shape[0])
+        out[pre + 'scores'] = scores.detach().numpy().copy()
+        out[pre + 'logits'] = logits.detach().numpy().copy()
+        out[pre + 'h_out'] = h.detach().numpy().copy()
+        out[pre + 'y_pred'] = y_pred.numpy().copy()
+
+    with torch.no_grad():
+        y_pred, feats, node_adj, edge_adj, labels, t_st, t_end = initialize_graph(X, y, t_st=0, mode='test', cuda=False)
+        scores, logits, states, _ = model(feats, None, node_adj, edge_adj)
+        c = 0
+        record_call(c, feats, None, node_adj, edge_adj, scores, logits, states, y_pred)
+        scores = torch.cat((1 - scores, scores), dim=1)
+        nsteps = 0
+        t_skip = t_st
+        for t_cur in range(t_st, t_end):
+            if t_cur < t_skip:
+                continue
+            if feats.size()[0] == 0 and states.size()[0] == 0:
+                y_pred, feats, node_adj, edge_adj, labels, t_skip, _ = initialize_graph(X, y, t_st=t_cur, mode='test', cuda=False)
+                if y_pred is None:
+                    break
+                states = None
+            else:
+                y_pred, feats, node_adj, edge_adj, labels = update_graph(
+                    node_adj, labels, scores, y_pred, X, y, t_cur, use_hungraian=hungarian, mode='test', cuda=False)
+            h_in = states
+            scores, logits, states, _ = model(feats, states, node_adj, edge_adj)
+            c += 1
+            record_call(c, feats, h_in, node_adj, edge_adj, scores, logits, states, y_pred)
+            scores = torch.cat((1 - scores, scores), dim=1)
+            t_upto = t_end if t_cur == t_end - 1 else t_cur - cur_win + 2
+            N = states.shape[0]
+            marker = torch.arange(N, dtype=torch.int64)
+            y_pred_b = y_pred.clone()
+            y_pred, y_out, states, node_adj, kept, scores = decode_tracks(
+                states, node_adj, marker, scores, y_pred, y_out, t_upto, ret_win, use_hungraian=hungarian, cuda=False)
+            labels = labels[kept]
+            pre = f'd{c}/'
+            out[pre + 'keep'] = kept.numpy().copy()
+            out[pre + 't_upto'] = np.int64(t_upto)
+            out[pre + 'y_pred_before'] = y_pred_b.numpy().copy()
+            out[pre + 'y_pred_after'] = y_pred.numpy().copy()
+            out[pre + 'y_out'] = y_out.copy()
+            out[pre + 'h_kept'] = states.numpy().copy()
+            nsteps += 1
+    ncalls = c + 1
+    n_del = sum(int(out[f'd{i}/y_pred_before'].shape[0] - out[f'd{i}/keep'].shape[0]) for i in range(1, ncalls))
+    frac_pos = float(np.mean(np.concatenate([out[f'c{i}/scores'].ravel() for i in range(ncalls)]) >= 0.5))
+    meta = dict(name=name, kind='infer', features='2d', ncategories=3, nhidden=H, nattheads=K, msg_type=msg, mode='eval',
+                ncalls=ncalls, seed=seed, T=T, cur_win_size=cur_win, ret_win_size=ret_win, hungarian=bool(hungarian),
+                rows_deleted=n_del, torch=torch.__version__, reference='arangesh/TrackMPNN infer.py:48-87 loop')
+    out['meta'] = np.array(json.dumps(meta))
+    path = os.path.join(out_dir, name + '.npz')
+    np.savez_compressed(path, **out)
+    print(f'{name}: calls={ncalls} rows deleted={n_del} tracks={int(y_out[:, 1].max()) + 1} '
+          f'score>=0.5: {frac_pos:.2f} -> {os.path.getsize(path) / 1024:.0f} KiB')
+
+
+def run_init_fixture(out_dir):
+    """Un-perturbed initial weights of the reference under torch.manual_seed(5) (train.py:42-45,318): one small
+    state_dict in full and SHA-256 digests of every tensor for the larger configurations (bit-equality test)."""
+    import hashlib
+    from models.track_mpnn import TrackMPNN
+    out = {}
+    digests = {}
+    for tag, (feats, ncat, H, K, msg) in (('2d_h32_k0_diff', ('2d', 3, 32, 0, 'diff')),
+                                           ('2d_h64_k0_diff', ('2d', 3, 64, 0, 'diff')),
+                                           ('bdd_h64_k0_diff', ('2d', 8, 64, 0, 'diff')),
+                                           ('2d-temp-vis_h64_k2_concat', ('2d+temp+vis', 3, 64, 2, 'concat')),
+                                           ('2d_h256_k0_diff', ('2d', 3, 256, 0, 'diff'))):
+        torch.manual_seed(5)
+        sd = TrackMPNN(feats, ncat, H, K, msg).state_dict()
+        digests[tag] = dict(args=[feats, ncat, H, K, msg],
+                            sha256={k: hashlib.sha256(v.numpy().tobytes()).hexdigest() for k, v in sd.items()})
+        if tag == '2d_h32_k0_diff':
+            for k, v in sd.items():
+                out['full/' + k] = v.numpy().copy()
+    out['meta'] = np.array(json.dumps(dict(name='init_seed5', kind='init', seed=5, digests=digests,
+                                           torch=torch.__version__)))
+    path = os.path.join(out_dir, 'init_seed5.npz')
+    np.savez_compressed(path, **out)
+    print(f'init_seed5: {len(digests)} configurations -> {os.path.getsize(path) / 1024:.0f} KiB')
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--reference-path', default='/root/reference')
     ap.add_argument('--out', default=os.path.join(os.path.dirname(HERE), 'tests', 'golden'))
+    ap.add_argument('--only-new', action='store_true', help='skip the round-1 fixtures (debugging aid)')
     args = ap.parse_args()
     sys.dont_write_bytecode = True
     sys.path.insert(0, args.reference_path)
@@ -243,6 +382,19 @@ def main():
         run_loss_fixture(f'loss_{i}', args.out, 300 + i)
     # C1 of BASELINE.json: static 5-frame window, 20 dets/frame, 64-d, 2 MP iterations
     run_c1(args.out)
+    # round 2: one rolling train-mode window each at the real size of BASELINE.json configs[1..3] (bench generator),
+    # weights perturbed by 0.1 (see run_c1), h_out kept for every third call
+    run_fixture('roll_c2_kitti_car_w5', args.out, '2d', 3, 64, 0, 'diff', 'train', 400, pscale=0.1,
+                sequence=window_sequence(1001, 7, 6.0, 20, 3), h_every=3)
+    run_fixture('roll_c3_kitti_all_w10', args.out, '2d', 3, 64, 0, 'diff', 'train', 401, pscale=0.1,
+                sequence=window_sequence(1002, 12, 8.0, 25, 3), h_every=4)
+    run_fixture('roll_c4_bdd_w5', args.out, '2d', 8, 64, 0, 'diff', 'train', 402, pscale=0.1,
+                sequence=window_sequence(1003, 7, 12.0, 40, 8), h_every=3)
+    # the inference loop (update_graph(mode='test') + decode_tracks row deletion), greedy and Hungarian matching
+    run_infer_fixture('infer_greedy_w3_r0', args.out, 500, T=9, dmean=4, cur_win=3, ret_win=0, hungarian=False)
+    run_infer_fixture('infer_greedy_w4_r2', args.out, 501, T=10, dmean=5, cur_win=4, ret_win=2, hungarian=False, H=64)
+    run_infer_fixture('infer_hungarian_w3_r1', args.out, 502, T=9, dmean=4, cur_win=3, ret_win=1, hungarian=True)
+    run_init_fixture(args.out)
 
 
 def run_c1(out_dir):

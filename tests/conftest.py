@@ -14,9 +14,17 @@ def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
 
 
+_OTHER_KINDS = ('loss_', 'infer_', 'init_')
+
+
 def golden_names():
-    """model fixtures (one rolling / static sequence each)"""
-    return sorted(f[:-4] for f in os.listdir(GOLDEN_DIR) if f.endswith('.npz') and not f.startswith('loss_'))
+    """model fixtures (one rolling / static train-pattern sequence each)"""
+    return sorted(f[:-4] for f in os.listdir(GOLDEN_DIR) if f.endswith('.npz') and not f.startswith(_OTHER_KINDS))
+
+
+def infer_golden_names():
+    """inference-loop fixtures (reference infer.py:48-87: update_graph(mode='test') + decode_tracks)"""
+    return sorted(f[:-4] for f in os.listdir(GOLDEN_DIR) if f.endswith('.npz') and f.startswith('infer_'))
 
 
 def loss_golden_names():

@@ -171,3 +171,26 @@ def test_state_dict_keys_match_oracle_shapes():
         TrackMPNN('2d', 3, 48, 0, 'diff')
     with pytest.raises(AssertionError):
         TrackMPNN('2d', 3, 32, 0, 'sum')
+
+
+def test_initial_weights_bit_equal_to_reference():
+    """Same torch.nn containers created in the same order => the same RNG stream under torch.manual_seed(5)
+    (train.py:42-45,318): the initial state_dict equals the reference's bit for bit (fixture init_seed5, generated
+    by oracle/gen_golden.py from the real reference)."""
+    import hashlib
+    import json
+    import os
+    from tests.conftest import GOLDEN_DIR
+    d = np.load(os.path.join(GOLDEN_DIR, 'init_seed5.npz'))
+    meta = json.loads(str(d['meta']))
+    assert len(meta['digests']) >= 5
+    for tag, rec in meta['digests'].items():
+        torch.manual_seed(meta['seed'])
+        sd = TrackMPNN(*rec['args']).state_dict()
+        assert list(sd.keys()) == list(rec['sha256'].keys()), tag
+        for k, v in sd.items():
+            assert hashlib.sha256(v.numpy().tobytes()).hexdigest() == rec['sha256'][k], (tag, k)
+    torch.manual_seed(meta['seed'])
+    sd = TrackMPNN('2d', 3, 32, 0, 'diff').state_dict()
+    for k, v in sd.items():
+        assert np.array_equal(v.numpy(), d['full/' + k]), k

@@ -103,3 +103,26 @@ def test_graph_invariants_rejected():
     a[1, 0] = 1      # edge row with only a +1
     with pytest.raises(ValueError):
         orc.graph_from_adjacency(a)
+
+
+@pytest.mark.parametrize('name', __import__('tests.conftest', fromlist=['x']).infer_golden_names())
+def test_oracle_matches_reference_inference_loop(name):
+    """Every forward call of the reference's inference loop (infer.py:48-87: eval mode, update_graph(mode='test'),
+    decode_tracks row deletion between calls) with the call's own inputs: ragged graphs, carried state with rows
+    deleted, dets that lost all their edges."""
+    gold = Golden(name)
+    m = gold.meta
+    assert m['kind'] == 'infer' and m['rows_deleted'] > 0
+    cfg = orc.OracleConfig(m['features'], m['ncategories'], m['nhidden'], m['nattheads'], m['msg_type'])
+    p = gold.params()
+    with torch.no_grad():
+        for c in range(gold.ncalls):
+            na, ea = gold.adjacency(c, 'node_adj'), gold.adjacency(c, 'edge_adj')
+            graph = orc.graph_from_adjacency(na, ea)
+            h_in = gold.t(f'c{c}/h_in') if int(gold.d[f'c{c}/has_h_in']) else None
+            scores, logits, h, _ = orc.forward(p, cfg, gold.t(f'c{c}/x'), h_in, graph, training=False)
+            assert torch.allclose(scores, gold.t(f'c{c}/scores'), atol=SCORE_TOL, rtol=0), f'scores call {c}'
+            assert torch.allclose(logits, gold.t(f'c{c}/logits'), atol=TOL, rtol=RTOL), f'logits call {c}'
+            assert torch.allclose(h, gold.t(f'c{c}/h_out'), atol=TOL, rtol=RTOL), f'h_out call {c}'
+            # y_pred marks the type of every row (ts == -1 on edge rows, utils/graph.py:141-145,285-287)
+            assert np.array_equal(gold.d[f'c{c}/y_pred'][:, 0] == -1, graph.is_edge)

@@ -459,3 +459,147 @@ def test_ragged_graph_after_row_deletion_vs_oracle():
     assert torch.allclose(h.cpu(), h_ref, atol=LOGIT_ATOL, rtol=LOGIT_RTOL)
     for k in range(2):
         assert torch.allclose(att[0][k].per_edge().cpu(), a_ref[0][k], atol=1e-5, rtol=1e-4)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# round 2: the remaining BASELINE.json configs as workloads (C3, C4, C5) and the reference's inference loop
+# ------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('tag,frames,mean,max_dets,ncat', [
+    ('C3 KITTI All / CenterTrack, cur-win 10', 12, 8.0, 25, 3),
+    ('C4 BDD100K All / libra, cur-win 5', 7, 12.0, 40, 8),
+])
+def test_baseline_workloads_vs_oracle(tag, frames, mean, max_dets, ncat):
+    """BASELINE.json configs[2] / configs[3] as workloads (12-frame windows, D_t ~ clip(Poisson(8),
+    1, 25); C4: 7 frames, D_t ~ clip(Poisson(12), 1, 40), F = 13): B = 16 rolling windows batched block-diagonally,
+    forward of every call and one backward, HIP vs the oracle."""
+    from trackmpnn_amd import TrackMPNN
+    H = 64
+    cfg = orc.OracleConfig('2d', ncat, H, 0, 'diff')
+    F = ncat + 5
+    plans, xs = _batched_case(B=16, frames=frames, mean=mean, max_dets=max_dets, F=F, seed0=300 + frames)
+    assert len(plans) == frames - 1 and plans[-1].graph.E > 4000
+    p = orc.random_params(cfg, seed=frames, scale=0.1)
+    model = TrackMPNN('2d', ncat, H, 0, 'diff')
+    model.load_state_dict({k: v.clone() for k, v in p.items()}, strict=True)
+    model = model.to(DEV).train()
+    pr = {k: (v.clone().requires_grad_(True) if v.dtype.is_floating_point and 'running' not in k else v.clone())
+          for k, v in p.items()}
+    h = h_ref = None
+    loss = loss_ref = 0.0
+    gen = torch.Generator().manual_seed(1)
+    for c, (plan, x) in enumerate(zip(plans, xs)):
+        s_ref, l_ref, h_ref, _ = orc.forward(pr, cfg, x, h_ref, _oracle_graph(plan.graph), training=True,
+                                             seg_ids=plan.seg_of_new)
+        nxt = plans[c + 1].n_new if c + 1 < len(plans) else 0
+        s, l, h, _ = model.forward_graph(x.to(DEV), h, plan.to(DEV), reserve_rows=nxt)
+        assert (s.detach().cpu() - s_ref.detach()).abs().max().item() <= SCORE_TOL, (tag, c)
+        assert torch.allclose(l.detach().cpu(), l_ref.detach(), atol=LOGIT_ATOL, rtol=LOGIT_RTOL), (tag, c)
+        assert torch.allclose(h.detach().cpu(), h_ref.detach(), atol=LOGIT_ATOL, rtol=LOGIT_RTOL), (tag, c)
+        w = torch.randn(l.shape, generator=gen)
+        loss = loss + (w.to(DEV) * l).sum() + s.sum()
+        loss_ref = loss_ref + (w * l_ref).sum() + s_ref.sum()
+    loss.backward()
+    loss_ref.backward()
+    gscale = max(1.0, max(v.grad.abs().max().item() for v in pr.values() if v.grad is not None))
+    for k, prm in model.named_parameters():
+        tol = GRAD_RTOL * gscale * (10 if (k.endswith('.0.bias') and k.startswith('input_')) else 1)
+        err = (prm.grad.cpu() - pr[k].grad).abs().max().item()
+        assert err <= tol, f'{tag}: grad {k}: {err} > {tol}'
+
+
+def test_c5_dense_stress_full_size():
+    """BASELINE.json configs[4] (C5) at FULL size: one static window of 50 frames x 300 dets (Dn = 15 000,
+    E = 4 410 000, N = 4 425 000), H = 256, 4 message-passing iterations, forward + backward.  The reference cannot
+    hold this graph (dense N x N), so the checks are size-independent: (1) two tiny dense windows ride in the same
+    block-diagonal batch and must agree with the oracle run on them alone (scores of all 4 iterations, and their
+    d loss / d x); (2) the whole step re-run gives bit-identical scores and gradients; (3) the aggregation kernels
+    are exact adjoints at H = 256 on the 4.4 M-edge graph."""
+    from trackmpnn_amd import TrackMPNN, _lib, concat_static_graphs, dense_static_graph, plan_single
+    H, F, iters = 256, 8, 4
+    small = [dense_static_graph(4, 5), dense_static_graph(3, 7)]
+    big = dense_static_graph(50, 300)
+    assert (big.Dn, big.E, big.N) == (15000, 4410000, 4425000)
+    graph, plan0 = concat_static_graphs([big] + small)
+    graph = graph.to(DEV)
+    plan0 = plan0.to(DEV)
+    planr = plan_single(graph, 0)
+    cfg = orc.OracleConfig('2d', 3, H, 0, 'diff')
+    p = orc.random_params(cfg, seed=9, scale=1.2 / (H ** 0.5))
+    gen = torch.Generator().manual_seed(4)
+    x = torch.zeros(graph.N, F)
+    x[graph.det_row.cpu().long()] = torch.randn(graph.Dn, F, generator=gen)
+    w_small = torch.randn(graph.N - big.N, 1, generator=gen)
+
+    def run():
+        model = TrackMPNN('2d', 3, H, 0, 'diff')
+        model.load_state_dict({k: v.clone() for k, v in p.items()}, strict=True)
+        model = model.to(DEV).train()
+        xd = x.to(DEV).requires_grad_(True)
+        h, loss, outs = None, 0.0, []
+        for it in range(iters):
+            s, l, h, _ = model.forward_graph(xd if it == 0 else xd[:0], h, plan0 if it == 0 else planr)
+            # a loss that couples nothing across windows: mean over the big window, weighted sum over the small ones
+            loss = loss + l[:big.N].mean() + (w_small.to(DEV) * l[big.N:]).sum()
+            outs.append(s.detach())
+        loss.backward()
+        grads = torch.cat([q.grad.reshape(-1) for q in model.parameters()])
+        return outs, xd.grad.detach(), grads
+
+    outs, gx, grads = run()
+    assert all(bool(torch.isfinite(o).all()) for o in outs) and bool(torch.isfinite(grads).all())
+    # (1) the small windows against the oracle (their own BatchNorm segments => independent of the big window)
+    off = big.N
+    for i, g in enumerate(small):
+        pr = {k: v.clone() for k, v in p.items()}
+        xs = x[off:off + g.N].clone().requires_grad_(True)
+        h_ref, loss_ref = None, 0.0
+        for it in range(iters):
+            s_ref, l_ref, h_ref, _ = orc.forward(pr, cfg, xs if it == 0 else xs[:0], h_ref, _oracle_graph(g),
+                                                 training=True)
+            got = outs[it][off:off + g.N].cpu()
+            assert (got - s_ref.detach()).abs().max().item() <= SCORE_TOL, (i, it)
+            loss_ref = loss_ref + (w_small[off - big.N:off - big.N + g.N] * l_ref).sum()
+        loss_ref.backward()
+        det = ~torch.from_numpy(g.is_edge.cpu().numpy().astype(bool))
+        ref = xs.grad[det]
+        assert torch.allclose(gx[off:off + g.N].cpu()[det], ref, atol=GRAD_RTOL * max(1.0, ref.abs().max().item()), rtol=0)
+        off += g.N
+    # (2) bitwise reproducible at full size
+    outs2, gx2, grads2 = run()
+    for a, b in zip(outs, outs2):
+        assert torch.equal(a, b)
+    assert torch.equal(grads, grads2) and torch.equal(gx, gx2)
+    del outs, outs2, gx2, grads2
+    torch.cuda.empty_cache()
+    # (3) rows E / F are each other's adjoints at H = 256
+    st = torch.cuda.current_stream().cuda_stream
+    gd = torch.Generator(device=DEV).manual_seed(0)
+    hh = torch.randn(graph.N, H, device=DEV, generator=gd)
+    mm = torch.randn(graph.N, H, device=DEV, generator=gd)
+    hh[graph.edge_row.long()] = 0
+    mm[graph.det_row.long()] = 0
+    out = torch.zeros(graph.N, H, device=DEV)
+    adj = torch.zeros(graph.N, H, device=DEV)
+    _lib.call('tmpnn_gather_diff_fwd', graph.cref(), hh.data_ptr(), H, out.data_ptr(), H, H, 0, st)
+    _lib.call('tmpnn_gather_diff_bwd', graph.cref(), mm.data_ptr(), H, adj.data_ptr(), H, H, 0, st)
+    lhs = (out.double() * mm.double()).sum().item()
+    rhs = (hh.double() * adj.double()).sum().item()
+    assert abs(lhs - rhs) <= 1e-6 * max(1.0, abs(lhs))
+
+
+@pytest.mark.parametrize('name', __import__('tests.conftest', fromlist=['x']).infer_golden_names())
+def test_golden_inference_loop_parity(name):
+    """The reference's inference loop (infer.py:48-87) captured call by call from the real reference: eval mode,
+    graphs from update_graph(mode='test'), carried state with the rows decode_tracks deleted (utils/graph.py:492-520).
+    Each call goes through the drop-in forward(x, h_in, node_adj, edge_adj) with the reference's own tensors."""
+    gold = Golden(name)
+    model = build_model(gold.meta, gold.params())
+    with torch.no_grad():
+        for c in range(gold.ncalls):
+            na = gold.adjacency(c, 'node_adj', DEV)
+            ea = gold.adjacency(c, 'edge_adj', DEV)
+            h_in = gold.t(f'c{c}/h_in').to(DEV) if int(gold.d[f'c{c}/has_h_in']) else None
+            scores, logits, h, att = model(gold.t(f'c{c}/x').to(DEV), h_in, na, ea)
+            assert (scores.cpu() - gold.t(f'c{c}/scores')).abs().max().item() <= SCORE_TOL, f'scores call {c}'
+            assert torch.allclose(logits.cpu(), gold.t(f'c{c}/logits'), atol=LOGIT_ATOL, rtol=LOGIT_RTOL), c
+            assert torch.allclose(h.cpu(), gold.t(f'c{c}/h_out'), atol=LOGIT_ATOL, rtol=LOGIT_RTOL), c

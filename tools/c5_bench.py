@@ -5,21 +5,7 @@ import numpy as np, torch
 from trackmpnn_amd import TrackMPNN, graph_from_edges
 from trackmpnn_amd.graph import CallPlan, plan_single
 
-def dense_static_graph(T, D, device):
-    """Every frame holds D dets that are all true positives seen in every frame: the active set is the previous
-    frame (utils/graph.py:271-274), so consecutive frames are fully connected: [dets t0][D*D edges][dets t1]..."""
-    N = T * D + (T - 1) * D * D
-    is_edge = np.zeros(N, bool)
-    src = np.empty((T - 1) * D * D, np.int64); dst = np.empty_like(src)
-    row = 0; prev = None; e = 0
-    for t in range(T):
-        if t > 0:
-            is_edge[row:row + D * D] = True
-            src[e:e + D * D] = np.repeat(prev, D)
-            dst[e:e + D * D] = row + D * D + np.tile(np.arange(D), D)
-            row += D * D; e += D * D
-        prev = row + np.arange(D); row += D
-    return graph_from_edges(N, torch.from_numpy(is_edge), torch.from_numpy(src), torch.from_numpy(dst), device=device)
+from trackmpnn_amd.graph import dense_static_graph
 
 if __name__ == '__main__':
     ap = argparse.ArgumentParser()

@@ -341,6 +341,54 @@ def plan_single(graph: FrameGraph, n_new: int) -> CallPlan:
                     seg_of_det=torch.zeros(nd, dtype=torch.int32, device=dev))
 
 
+
+def dense_static_graph(T: int, D: int, device='cpu') -> FrameGraph:
+    """The final graph of a window in which every frame holds D true-positive dets seen in every frame: the active
+    set is always the previous frame (utils/graph.py:271-274), so consecutive frames are fully connected and the row
+    order is [dets t0][D*D edges, src-major][dets t1]...  (BASELINE.json C1: T=5, D=20; C5: T=50, D=300)."""
+    N = T * D + (T - 1) * D * D
+    is_edge = np.zeros(N, bool)
+    src = np.empty((T - 1) * D * D, np.int64)
+    dst = np.empty_like(src)
+    row = e = 0
+    prev = None
+    for t in range(T):
+        if t > 0:
+            is_edge[row:row + D * D] = True
+            src[e:e + D * D] = np.repeat(prev, D)
+            dst[e:e + D * D] = row + D * D + np.tile(np.arange(D), D)
+            row += D * D
+            e += D * D
+        prev = row + np.arange(D)
+        row += D
+    return graph_from_edges(N, torch.from_numpy(is_edge), torch.from_numpy(src), torch.from_numpy(dst), device=device)
+
+
+def concat_static_graphs(graphs: Sequence[FrameGraph], device='cpu') -> Tuple[FrameGraph, 'CallPlan']:
+    """Block-diagonal union of whole graphs presented in ONE call (all rows new, one BatchNorm segment per graph)."""
+    is_edge, src, dst, seg_cnt, seg_nd = [], [], [], [], []
+    off = 0
+    for g in graphs:
+        is_edge.append(g.is_edge.cpu().numpy().astype(bool))
+        src.append(g.src.cpu().numpy().astype(np.int64) + off)
+        dst.append(g.dst.cpu().numpy().astype(np.int64) + off)
+        seg_cnt.append(g.N)
+        seg_nd.append(g.Dn)
+        off += g.N
+    ie = np.concatenate(is_edge)
+    graph = graph_from_edges(off, torch.from_numpy(ie), torch.from_numpy(np.concatenate(src)),
+                             torch.from_numpy(np.concatenate(dst)), device=device)
+    seg_ids = np.repeat(np.arange(len(graphs)), seg_cnt)
+    loc = np.nonzero(~ie)[0]
+    plan = CallPlan(graph=graph, n_new=off, new_det_local=torch.from_numpy(loc).to(device),
+                    new_det_row=torch.from_numpy(loc.astype(np.int32)).to(device),
+                    seg_ptr=torch.from_numpy(np.concatenate([[0], np.cumsum(seg_nd)]).astype(np.int32)).to(device),
+                    seg_cnt=torch.from_numpy(np.asarray(seg_cnt, np.int32)).to(device),
+                    seg_of_new=torch.from_numpy(seg_ids).to(device), min_seg_cnt=int(min(seg_cnt)),
+                    seg_of_det=torch.from_numpy(seg_ids[loc].astype(np.int32)).to(device))
+    return graph, plan
+
+
 def batch_windows(windows: Sequence[Sequence[WindowCall]], static: bool = False,
                   device='cpu') -> Tuple[List[CallPlan], List[np.ndarray]]:
     """Block-diagonal batch of many windows, rows in CALL-MAJOR order.
