@@ -131,6 +131,13 @@ def stage_profile(model, plan, H):
                   H, h.data_ptr(), H, H, gates.data_ptr(), N * H, dout.data_ptr(), H, None, None, gW[0].data_ptr(),
                   gW[1].data_ptr(), gW[2].data_ptr(), gW[3].data_ptr(), ws.data_ptr(), wsb, st)
 
+    def gru_bwd_w_variant(v):
+        def run():
+            _lib.call('tmpnn_gru_bwd_weights_variant', g.edge_row.data_ptr(), E, 1, g.src.data_ptr(), g.dst.data_ptr(),
+                      None, 0, 0, H, h.data_ptr(), H, H, gates.data_ptr(), N * H, dout.data_ptr(), H, None, None,
+                      gW[0].data_ptr(), gW[1].data_ptr(), gW[2].data_ptr(), gW[3].data_ptr(), ws.data_ptr(), wsb, v, st)
+        return run
+
     def gather():
         _lib.call('tmpnn_gather_diff_fwd', g.cref(), h.data_ptr(), H, out.data_ptr(), H, H, 0, st)
 
@@ -140,11 +147,15 @@ def stage_profile(model, plan, H):
     gru_fwd()          # gates must hold sane values before the backward kernels read them
     t = {name: time_stage(fn) for name, fn in (('gru_fwd_edge', gru_fwd), ('gru_bwd_data_edge', gru_bwd_data),
                                                ('gru_bwd_data_edge_folded', gru_bwd_data_folded),
-                                               ('gru_bwd_weights_edge', gru_bwd_w), ('gather_diff', gather),
+                                               ('gru_bwd_weights_edge', gru_bwd_w),
+                                               ('gru_bwd_weights_edge_f32mfma', gru_bwd_w_variant(0)),
+                                               ('gru_bwd_weights_edge_bf16x6', gru_bwd_w_variant(1)),
+                                               ('gather_diff', gather),
                                                ('segsum', segsum))}
     flops = {'gru_fwd_edge': 12.0 * H * H * E, 'gru_bwd_data_edge': 12.0 * H * H * E,
              'gru_bwd_data_edge_folded': 12.0 * H * H * E,
-             'gru_bwd_weights_edge': 12.0 * H * H * E}
+             'gru_bwd_weights_edge': 12.0 * H * H * E, 'gru_bwd_weights_edge_f32mfma': 12.0 * H * H * E,
+             'gru_bwd_weights_edge_bf16x6': 12.0 * H * H * E}
     # SURVEY 8(d) algorithmic bytes per launch (every array counted once; det-row gathers count the det table once)
     b_gather = 4.0 * H * E + 4.0 * H * Dn + 8.0 * E
     b_segsum = 4.0 * H * E + 4.0 * H * Dn + 4.0 * (2 * E + Dn + 1) + 2.0 * E
@@ -157,6 +168,7 @@ def stage_profile(model, plan, H):
               'gru_bwd_data_edge_folded': (32.0 * H + 16.0) * E + 4.0 * H * Dn,
               # per edge: dh 4H + gates 16H + h 4H in, 3 ids; h[src], h[dst] from the det table (once)
               'gru_bwd_weights_edge': (24.0 * H + 12.0) * E + 4.0 * H * Dn}
+    nbytes['gru_bwd_weights_edge_f32mfma'] = nbytes['gru_bwd_weights_edge_bf16x6'] = nbytes['gru_bwd_weights_edge']
     return t, flops, nbytes
 
 
@@ -303,7 +315,7 @@ def main():
     torch.manual_seed(5)
     model = TrackMPNN('2d', 3, H, 0, 'diff').to(dev).train()
     opt = torch.optim.Adam(model.parameters(), lr=1e-4, weight_decay=5e-4)       # train.py:329
-    bucket = GradBucket(model) if world > 1 else None
+    bucket = GradBucket(model)      # flat gradient storage for every N: p.grad aliases it, one all-reduce when N > 1
     plans, xs, edge_iters = build_batch(args.windows, frames, mean_dets, max_dets, F, seed=rank + 1, device=dev)
     gen = torch.Generator().manual_seed(rank)
     targets = [(torch.rand(p.graph.N, 1, generator=gen) < 0.3).float().to(dev) for p in plans]
@@ -337,7 +349,7 @@ def main():
     extra = {}
     if rank == 0 and not args.no_stage_profile:
         t, flops, nbytes = stage_profile(model, plans[-1], H)
-        dom = max(flops, key=lambda k: t[k])
+        dom = max((k for k in flops if not k.endswith(('_f32mfma', '_bf16x6'))), key=lambda k: t[k])
         # the dominant kernel against BOTH roofs; the one it sits closer to is reported as its bound.  Matrix-pipe
         # time: f32-equivalent flops at the f32-input MFMA rate, or 6 bf16 MFMAs (1/16 of the f32 cost each) per
         # f32 MFMA of work on the split path.
@@ -365,8 +377,7 @@ def main():
             segsum_GBs=nbytes['segsum'] / (t['segsum'] * 1e-3) / 1e9)
         extra['stage_ms'] = {k: round(v, 4) for k, v in t.items()}
         from trackmpnn_amd import _lib as _l
-        extra['weights_kernel'] = ({1: 'bf16x6', 0: 'f32-mfma', -1: 'undecided'}[_l.load().tmpnn_gru_bwd_weights_choice()]
-                                   if split_enabled() else 'f32-mfma')
+        extra['weights_kernel'] = {1: 'bf16x6', 0: 'f32-mfma'}[_l.load().tmpnn_gru_bwd_weights_choice()]
         extra['stage_graph'] = dict(N=plans[-1].graph.N, E=plans[-1].graph.E, Dn=plans[-1].graph.Dn)
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -156,10 +156,11 @@ int tmpnn_gru_bwd_data(const int32_t* rows, int R, int IN, const float* h, int l
                        tmpnn_stream stream);
 /* Weight gradient: dW_ih [3H][IN], dW_hh [3H][H], db_ih [3H], db_hh [3H] are ACCUMULATED (+=).
  * x is re-formed as in tmpnn_gru_fwd (xmode).  ws: tmpnn_gru_bwd_weights_ws(R, IN, H) bytes. */
-/* Which H = 64 weight-gradient kernel this process uses: 1 = bf16x6 split products, 0 = f32-input MFMA, -1 = not
- * decided yet.  Unless TMPNN_SPLIT_WEIGHTS=0/1 (or TMPNN_SPLIT=0) fixes it, the first call with >= 2^20 rows times
- * both forms once on the caller's stream (the ONLY place the library synchronises) and keeps the faster one: the
- * ranking of the two differs between MI355X machines. */
+/* Which H = 64 weight-gradient kernel tmpnn_gru_bwd_weights uses: 1 = bf16x6 split products (default), 0 = f32-input
+ * MFMA.  A constant of the process (TMPNN_SPLIT_WEIGHTS=0/1 or TMPNN_SPLIT=0 in the environment when the library is
+ * loaded): nothing is measured or decided inside a call, so every run and every rank takes the same kernel and
+ * gradients are bitwise reproducible across processes.  tmpnn_gru_bwd_weights_variant takes the form explicitly
+ * (variant 0 / 1; -1 = the process default) -- used by bench.py to time both forms. */
 int tmpnn_gru_bwd_weights_choice(void);
 size_t tmpnn_gru_bwd_weights_ws(int R, int IN, int H);
 int tmpnn_gru_bwd_weights(const int32_t* rows, int R, int xmode, const int32_t* src, const int32_t* dst,
@@ -169,6 +170,13 @@ int tmpnn_gru_bwd_weights(const int32_t* rows, int R, int xmode, const int32_t* 
                           const float* dy, const float* w_head,
                           float* dW_ih, float* dW_hh, float* db_ih, float* db_hh,
                           void* ws, size_t ws_bytes, tmpnn_stream stream);
+int tmpnn_gru_bwd_weights_variant(const int32_t* rows, int R, int xmode, const int32_t* src, const int32_t* dst,
+                                  const float* msg, int ld_msg, int msg_compact, int IN,
+                                  const float* h, int ld_h, int H,
+                                  const float* gates, size_t gate_plane, const float* d_hout, int ld_dhout,
+                                  const float* dy, const float* w_head,
+                                  float* dW_ih, float* dW_hh, float* db_ih, float* db_hh,
+                                  void* ws, size_t ws_bytes, int variant, tmpnn_stream stream);
 
 /* Fused backward of one cell: tmpnn_gru_bwd_data + tmpnn_gru_bwd_weights in ONE pass over the gates
  * (arguments as in those two; available when tmpnn_gru_bwd_fused_available(H, IN, xmode) != 0, i.e. H = 64,

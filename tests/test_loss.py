@@ -103,3 +103,18 @@ def test_hip_losses_at_scale_vs_torch():
     ref.backward()
     gref = torch.zeros(g.N, device=dev, dtype=torch.float64).index_add(0, row, lo.grad)
     assert torch.allclose(logits.grad[:, 0].double(), gref, atol=1e-6, rtol=1e-4)
+
+
+@pytest.mark.gpu
+def test_focal_loss_empty_selection_matches_reference_semantics():
+    """models/loss.py:71-74 on an empty index set: mean() of nothing is nan, sum() of nothing is 0; zero gradient."""
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU')
+    from trackmpnn_amd.loss import FocalLoss
+    s = torch.zeros(0, device='cuda:0', requires_grad=True)
+    t = torch.zeros(0, device='cuda:0')
+    assert torch.isnan(FocalLoss(gamma=0)(s, t))
+    out = FocalLoss(gamma=2, alpha=0.25, size_average=False)(s, t)
+    assert out.item() == 0.0
+    out.backward()
+    assert s.grad.shape == (0,)

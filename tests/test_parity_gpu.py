@@ -360,8 +360,8 @@ def test_inplace_append_is_bitwise_identical():
 
 @pytest.mark.parametrize('heads', [0, 2])
 def test_inplace_param_grad_accumulation_matches_returned_grads(heads):
-    """With p.grad buffers in place (zero_grad(set_to_none=False), GradBucket) the kernels add each call's parameter
-    gradients straight into them and autograd gets None; without, the per-call tensors are returned and autograd adds
+    """With `inplace_param_grads` (opt-in; set by GradBucket) and p.grad buffers in place the kernels add each call's
+    parameter gradients straight into them and autograd gets None; without, the per-call tensors are returned and autograd adds
     them.  Same kernels; only the association of the per-call sums changes (a parameter that receives two partial sums
     per call sees (prev + a) + b instead of prev + (a + b)), so the results agree to fp32 rounding, and a second
     backward accumulates on top (2 x)."""
@@ -372,6 +372,7 @@ def test_inplace_param_grad_accumulation_matches_returned_grads(heads):
         torch.manual_seed(5)
         model = TrackMPNN('2d', 3, 64, heads, 'diff').to(DEV).train()
         if preallocate:
+            model.inplace_param_grads = True          # opt-in (what GradBucket sets); off by default
             for p in model.parameters():
                 p.grad = torch.zeros_like(p)
         reps = 2 if preallocate else 1
@@ -464,21 +465,23 @@ def test_ragged_graph_after_row_deletion_vs_oracle():
 # ------------------------------------------------------------------------------------------------------------------
 # round 2: the remaining BASELINE.json configs as workloads (C3, C4, C5) and the reference's inference loop
 # ------------------------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize('tag,frames,mean,max_dets,ncat', [
-    ('C3 KITTI All / CenterTrack, cur-win 10', 12, 8.0, 25, 3),
-    ('C4 BDD100K All / libra, cur-win 5', 7, 12.0, 40, 8),
+@pytest.mark.parametrize('tag,frames,mean,max_dets,ncat,pscale', [
+    ('C3 KITTI All / CenterTrack, cur-win 10', 12, 8.0, 25, 3, 0.05),
+    ('C4 BDD100K All / libra, cur-win 5', 7, 12.0, 40, 8, 0.07),
 ])
-def test_baseline_workloads_vs_oracle(tag, frames, mean, max_dets, ncat):
+def test_baseline_workloads_vs_oracle(tag, frames, mean, max_dets, ncat, pscale):
     """BASELINE.json configs[2] / configs[3] as workloads (12-frame windows, D_t ~ clip(Poisson(8),
     1, 25); C4: 7 frames, D_t ~ clip(Poisson(12), 1, 40), F = 13): B = 16 rolling windows batched block-diagonally,
-    forward of every call and one backward, HIP vs the oracle."""
+    forward of every call and one backward, HIP vs the oracle.  (pscale: the random model is a recurrence over up to
+    11 calls; at weight scale 0.1 the fp32 oracle itself drifts 1e-3 from its fp64 evaluation by call 10, so the
+    longer chain uses a better conditioned model -- measured drift <= 4e-5 at these scales.)"""
     from trackmpnn_amd import TrackMPNN
     H = 64
     cfg = orc.OracleConfig('2d', ncat, H, 0, 'diff')
     F = ncat + 5
     plans, xs = _batched_case(B=16, frames=frames, mean=mean, max_dets=max_dets, F=F, seed0=300 + frames)
     assert len(plans) == frames - 1 and plans[-1].graph.E > 4000
-    p = orc.random_params(cfg, seed=frames, scale=0.1)
+    p = orc.random_params(cfg, seed=frames, scale=pscale)
     model = TrackMPNN('2d', ncat, H, 0, 'diff')
     model.load_state_dict({k: v.clone() for k, v in p.items()}, strict=True)
     model = model.to(DEV).train()
@@ -603,3 +606,53 @@ def test_golden_inference_loop_parity(name):
             assert (scores.cpu() - gold.t(f'c{c}/scores')).abs().max().item() <= SCORE_TOL, f'scores call {c}'
             assert torch.allclose(logits.cpu(), gold.t(f'c{c}/logits'), atol=LOGIT_ATOL, rtol=LOGIT_RTOL), c
             assert torch.allclose(h.cpu(), gold.t(f'c{c}/h_out'), atol=LOGIT_ATOL, rtol=LOGIT_RTOL), c
+
+
+def test_default_backward_honours_the_autograd_contract():
+    """Default mode (no GradBucket, TMPNN_INPLACE_GRADS unset): parameter gradients are RETURNED to autograd even when
+    p.grad buffers exist, so torch.autograd.grad, tensor hooks and post-accumulate hooks behave as for any module."""
+    from trackmpnn_amd import TrackMPNN
+    plans, xs = _batched_case(B=3, frames=4, mean=4, max_dets=8, F=8, seed0=5)
+    torch.manual_seed(5)
+    model = TrackMPNN('2d', 3, 64, 0, 'diff').to(DEV).train()
+    assert model.inplace_param_grads is False
+    params = list(model.parameters())
+    for p in params:
+        p.grad = torch.full_like(p, 7.0)
+    fired = []
+    hook = params[0].register_hook(lambda g: fired.append(g.shape))
+
+    def loss_of():
+        h, loss = None, 0.0
+        for plan, x in zip(plans, xs):
+            s, l, h, _ = model.forward_graph(x.to(DEV), h, plan.to(DEV))
+            loss = loss + (l * l).sum() + s.sum()
+        return loss
+
+    grads = torch.autograd.grad(loss_of(), params)
+    assert all(g is not None and bool(torch.isfinite(g).all()) for g in grads)
+    assert all(bool((p.grad == 7.0).all()) for p in params)          # autograd.grad must not touch .grad
+    assert fired                                                     # tensor hooks fire
+    loss_of().backward()
+    for p, g in zip(params, grads):
+        assert torch.allclose(p.grad - 7.0, g, rtol=1e-5, atol=1e-5 * float(g.abs().max()) + 1e-7)
+    hook.remove()
+
+
+def test_gradients_bitwise_equal_across_processes():
+    """The C ABI is pure enqueue (tmpnn.h: nothing is measured or decided inside a call), so two FRESH processes
+    running the same step -- more than 2^20 edge rows, the size at which round 1's hidden autotune kicked in -- must
+    produce bit-identical scores and parameter gradients."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    digests = []
+    for _ in range(2):
+        r = subprocess.run([sys.executable, os.path.join(root, 'tests', 'gpu_grad_digest.py')], cwd=root,
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith('GRAD_DIGEST')]
+        assert line, r.stdout[-1500:]
+        digests.append(line[-1])
+    assert digests[0] == digests[1]

@@ -60,6 +60,9 @@ _SIGNATURES = {
     'tmpnn_gru_bwd_weights': (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                                       c_void_p, c_int, c_int, c_void_p, c_size_t, c_void_p, c_int, c_void_p, c_void_p,
                                       c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    'tmpnn_gru_bwd_weights_variant': (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
+                                              c_void_p, c_int, c_int, c_void_p, c_size_t, c_void_p, c_int, c_void_p, c_void_p,
+                                              c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
     'tmpnn_gru_bwd_fused_available': (c_int, [c_int, c_int, c_int]),
     'tmpnn_gru_bwd_fused_ws': (c_size_t, [c_int, c_int, c_int]),
     'tmpnn_gru_bwd_fused': (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,

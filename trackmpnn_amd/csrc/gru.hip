@@ -2163,22 +2163,38 @@ __global__ void k_fold_slabs_gru(const float* __restrict__ slabs, size_t stride,
     out[(size_t)blockIdx.y * n + i] = s;
 }
 
-// weight-gradient kernel choice at H = 64 (see tmpnn_gru_bwd_weights): -1 = measure on first large call
-static std::atomic<int> g_weights_split_choice{[] {
-    const char* e = getenv("TMPNN_SPLIT_WEIGHTS");
-    return (e && (e[0] == '0' || e[0] == '1')) ? e[0] - '0' : -1;
-}()};
-static bool stream_is_capturing(hipStream_t st) {
-    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-    return hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone;
-}
+
+// The LDS-resident kernels need more than the default 64 KiB of dynamic LDS: raise the limit ONCE per (kernel
+// instantiation, device) instead of before every launch (idempotent function-attribute setup, not data state).
+#define TM_SHM_ONCE(kernel, bytes)                                                                           \
+    do {                                                                                                     \
+        static std::atomic<int> done_[16];                                                                   \
+        int dev_ = 0;                                                                                        \
+        (void)hipGetDevice(&dev_);                                                                           \
+        const int b_ = (int)(bytes);                                                                         \
+        if (done_[dev_ & 15].load(std::memory_order_relaxed) < b_) {                                         \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&kernel),                                \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, b_);                       \
+            done_[dev_ & 15].store(b_, std::memory_order_relaxed);                                           \
+        }                                                                                                    \
+    } while (0)
 
 // TMPNN_SPLIT=0 keeps every GEMM on the f32-input MFMA (v_mfma_f32_32x32x2_f32)
 static bool split_enabled() {
     static const int on = [] { const char* e = getenv("TMPNN_SPLIT"); return (e && e[0] == '0') ? 0 : 1; }();
     return on != 0;
 }
-
+// H = 64 weight-gradient kernel: 1 = bf16x6 split products (default), 0 = f32-input MFMA.  A constant of the process,
+// read from the environment when the library is loaded (TMPNN_SPLIT_WEIGHTS=0/1; TMPNN_SPLIT=0 implies 0): every
+// rank and every run uses the same kernel, so gradients are bitwise reproducible across processes.
+static int weights_variant_default() {
+    static const int v = [] {
+        if (!split_enabled()) return 0;
+        const char* e = getenv("TMPNN_SPLIT_WEIGHTS");
+        return (e && e[0] == '0') ? 0 : 1;
+    }();
+    return v;
+}
 static void plan_weights(int R, int IN, int H, int* n_rs, int* RS, int* NQ, int* NCH) {
     *NQ = 3 * H / 32;
     *NCH = (IN + H + 127) / 128;
@@ -2247,12 +2263,10 @@ int tmpnn_gru_fwd(const int32_t* rows, int R, int xmode, const int32_t* src, con
             // bf16x6 operand path, 8 waves (two per SIMD: the prefetched next operand needs the registers)
             const size_t shm2 = (size_t)3 * 3 * H * (H + 8) * 2 + sizeof(float) * ((size_t)8 * 32 * STG_LD + 4 + 5 * H);
             if (H == 64) {
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gru_fwd_split<64, 8>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm2);
+                TM_SHM_ONCE((k_gru_fwd_split<64, 8>), shm2);
                 hipLaunchKernelGGL((k_gru_fwd_split<64, 8>), pgrid, dim3(512), shm2, st, a);
             } else {
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gru_fwd_split<32, 8>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm2);
+                TM_SHM_ONCE((k_gru_fwd_split<32, 8>), shm2);
                 hipLaunchKernelGGL((k_gru_fwd_split<32, 8>), pgrid, dim3(512), shm2, st, a);
             }
             return check_launch("gru_fwd_split");
@@ -2261,8 +2275,7 @@ int tmpnn_gru_fwd(const int32_t* rows, int R, int xmode, const int32_t* src, con
         if (shm > 160 * 1024) goto generic;      // e.g. concat at H = 64: the weights alone take 144 KiB
 #define LL(HH, II, X, CC, WW)                                                                                \
     do {                                                                                                     \
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gru_fwd_lds<HH, II, X, CC, WW>),          \
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);                     \
+        TM_SHM_ONCE((k_gru_fwd_lds<HH, II, X, CC, WW>), shm);                     \
         hipLaunchKernelGGL((k_gru_fwd_lds<HH, II, X, CC, WW>), pgrid, pblock, shm, st, a, ntiles);           \
     } while (0)
         if (H == 64) { if (xmode == 0 && IN == 64) LL(64, 64, 0, 1, 12); else if (xmode == 1) LL(64, 64, 1, 1, 12); else if (xmode == 2) LL(64, 128, 2, 1, 12); else if (xmode == 3) LL(64, 64, 3, 1, 12); else goto generic; }
@@ -2296,24 +2309,20 @@ int tmpnn_rows_linear(const int32_t* rows, int R, const float* in, int ld_in, in
     if (split_enabled()) {
         const size_t shm2 = (size_t)3 * NOUT * (H + 8) * 2 + sizeof(float) * 8 * 32 * STG_LD;
         if (H == 64) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rows_gemm_split<64, 6>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm2);
+            TM_SHM_ONCE((k_rows_gemm_split<64, 6>), shm2);
             hipLaunchKernelGGL((k_rows_gemm_split<64, 6>), grid, block, shm2, st, rows, R, in, ld_in, wt, out, ld_out, ntiles);
         } else {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rows_gemm_split<32, 3>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm2);
+            TM_SHM_ONCE((k_rows_gemm_split<32, 3>), shm2);
             hipLaunchKernelGGL((k_rows_gemm_split<32, 3>), grid, block, shm2, st, rows, R, in, ld_in, wt, out, ld_out, ntiles);
         }
         return check_launch("rows_linear_split");
     }
     const size_t shm = sizeof(float) * ((size_t)H * NOUT + 8 * 32 * STG_LD);
     if (H == 64) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rows_gemm_lds<64, 6>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+        TM_SHM_ONCE((k_rows_gemm_lds<64, 6>), shm);
         hipLaunchKernelGGL((k_rows_gemm_lds<64, 6>), grid, block, shm, st, rows, R, in, ld_in, wt, out, ld_out, ntiles);
     } else {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rows_gemm_lds<32, 3>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+        TM_SHM_ONCE((k_rows_gemm_lds<32, 3>), shm);
         hipLaunchKernelGGL((k_rows_gemm_lds<32, 3>), grid, block, shm, st, rows, R, in, ld_in, wt, out, ld_out, ntiles);
     }
     return check_launch("rows_linear");
@@ -2350,8 +2359,7 @@ int tmpnn_gru_bwd_data(const int32_t* rows, int R, int IN, const float* h, int l
             const size_t shm2 = (size_t)3 * (IN + H) * (3 * H + 8) * 2 + 16 + sizeof(float) * H;
 #define S3(HH, UU, FF)                                                                                       \
     do {                                                                                                     \
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gru_bwd_data_split<HH, UU, FF>),          \
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm2);                    \
+        TM_SHM_ONCE((k_gru_bwd_data_split<HH, UU, FF>), shm2);                    \
         hipLaunchKernelGGL((k_gru_bwd_data_split<HH, UU, FF>), pgrid, pblock, shm2, st, a, ntiles);          \
     } while (0)
 #define SL(HH)                                                                                               \
@@ -2366,8 +2374,7 @@ int tmpnn_gru_bwd_data(const int32_t* rows, int R, int IN, const float* h, int l
         }
 #define L3(HH, II, UU, FF)                                                                                   \
     do {                                                                                                     \
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gru_bwd_data_lds<HH, II, UU, FF>),        \
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);                     \
+        TM_SHM_ONCE((k_gru_bwd_data_lds<HH, II, UU, FF>), shm);                     \
         hipLaunchKernelGGL((k_gru_bwd_data_lds<HH, II, UU, FF>), pgrid, pblock, shm, st, a, ntiles);         \
     } while (0)
 #define LL(HH, II)                                                                                           \
@@ -2458,8 +2465,7 @@ int tmpnn_gru_bwd_fused(const int32_t* rows, int R, int xmode, const int32_t* sr
     const bool fuse = add_msg != nullptr;
 #define LF(X, U, F)                                                                                          \
     do {                                                                                                     \
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gru_bwd_fused<64, X, U, F>),              \
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);                     \
+        TM_SHM_ONCE((k_gru_bwd_fused<64, X, U, F>), shm);                     \
         hipLaunchKernelGGL((k_gru_bwd_fused<64, X, U, F>), dim3(n_rs), dim3(512), shm, st, a, ntiles);       \
     } while (0)
 #define LU(X, F) do { if (up == 1) LF(X, 1, F); else if (up == 2) LF(X, 2, F); else LF(X, 3, F); } while (0)
@@ -2486,7 +2492,7 @@ int tmpnn_gru_bwd_fused(const int32_t* rows, int R, int xmode, const int32_t* sr
     return check_launch("gru_reduce_w");
 }
 
-int tmpnn_gru_bwd_weights_choice(void) { return g_weights_split_choice.load(); }
+int tmpnn_gru_bwd_weights_choice(void) { return weights_variant_default(); }
 
 size_t tmpnn_gru_bwd_weights_ws(int R, int IN, int H) {
     if (R <= 0) return 0;
@@ -2505,6 +2511,19 @@ int tmpnn_gru_bwd_weights(const int32_t* rows, int R, int xmode, const int32_t* 
                           size_t gate_plane, const float* d_hout, int ld_dhout, const float* dy, const float* w_head,
                           float* dW_ih, float* dW_hh,
                           float* db_ih, float* db_hh, void* ws, size_t ws_bytes, tmpnn_stream stream) {
+    return tmpnn_gru_bwd_weights_variant(rows, R, xmode, src, dst, msg, ld_msg, msg_compact, IN, h, ld_h, H, gates,
+                                         gate_plane, d_hout, ld_dhout, dy, w_head, dW_ih, dW_hh, db_ih, db_hh, ws,
+                                         ws_bytes, -1, stream);
+}
+
+int tmpnn_gru_bwd_weights_variant(const int32_t* rows, int R, int xmode, const int32_t* src, const int32_t* dst,
+                                  const float* msg, int ld_msg, int msg_compact, int IN, const float* h, int ld_h, int H,
+                                  const float* gates,
+                                  size_t gate_plane, const float* d_hout, int ld_dhout, const float* dy,
+                                  const float* w_head, float* dW_ih, float* dW_hh,
+                                  float* db_ih, float* db_hh, void* ws, size_t ws_bytes, int variant,
+                                  tmpnn_stream stream) {
+    TM_REQUIRE(variant >= -1 && variant <= 1, "gru_bwd_weights: variant %d (need -1, 0 or 1)", variant);
     TM_REQUIRE(supported_H(H), "gru_bwd_weights: unsupported H=%d", H);
     if (R == 0) return TMPNN_OK;
     TM_REQUIRE(R > 0 && xmode >= 0 && xmode <= 2 && IN % 32 == 0 && IN > 0, "gru_bwd_weights: R=%d xmode=%d IN=%d", R,
@@ -2543,8 +2562,7 @@ int tmpnn_gru_bwd_weights(const int32_t* rows, int R, int xmode, const int32_t* 
         auto launch_split = [&]() {
 #define SW(X, U)                                                                                             \
     do {                                                                                                     \
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gru_bwd_weights_split<X, U>),             \
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);                     \
+        TM_SHM_ONCE((k_gru_bwd_weights_split<X, U>), shm);                     \
         hipLaunchKernelGGL((k_gru_bwd_weights_split<X, U>), grid, block, shm, st, a, ntiles);                \
     } while (0)
             if (xmode == 0) { if (up == 1) SW(0, 1); else if (up == 2) SW(0, 2); else SW(0, 3); }
@@ -2557,34 +2575,11 @@ int tmpnn_gru_bwd_weights(const int32_t* rows, int R, int xmode, const int32_t* 
             else            { if (up == 1) LW(1, 1); else if (up == 2) LW(1, 2); else LW(1, 3); }
 #undef LW
         };
-        // Which form is faster depends on the machine: the bf16x6 kernel moves 25 % fewer cycles through the
-        // matrix pipe but, with no room to prefetch rows, it is latency-bound; on some MI355X boxes it measured
-        // 1.3x FASTER than the f32-MFMA kernel and on others 1.25x SLOWER (same binary, same inputs).  So the first
-        // large call of a process times both once (two events, one synchronisation, ~10 ms) and the winner is kept.
-        // TMPNN_SPLIT_WEIGHTS=0/1 (or TMPNN_SPLIT=0) fixes the choice and skips the measurement.
-        int choice = split_enabled() && H == 64 ? g_weights_split_choice.load() : 0;
-        if (choice < 0 && R >= (1 << 20) && !stream_is_capturing(st)) {
-            hipEvent_t e0, e1, e2;
-            if (hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess && hipEventCreate(&e2) == hipSuccess) {
-                launch_f32();
-                launch_split();                      // warm both
-                (void)hipEventRecord(e0, st);
-                launch_split();
-                (void)hipEventRecord(e1, st);
-                launch_f32();
-                (void)hipEventRecord(e2, st);
-                float t_split = 0.f, t_f32 = 0.f;
-                if (hipEventSynchronize(e2) == hipSuccess && hipEventElapsedTime(&t_split, e0, e1) == hipSuccess &&
-                    hipEventElapsedTime(&t_f32, e1, e2) == hipSuccess && t_split > 0.f && t_f32 > 0.f) {
-                    choice = t_split <= t_f32 ? 1 : 0;
-                    g_weights_split_choice.store(choice);
-                }
-                (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipEventDestroy(e2);
-            }
-            (void)hipGetLastError();
-            // (the slabs now hold the f32 kernel's partial sums of THIS call: valid input for the reduction below)
-            rc = check_launch("gru_bwd_weights_calibrate");
-        } else if (choice != 0) {
+        // bf16x6 moves 25 % fewer cycles through the matrix pipe than the f32-input MFMA form; which one is faster
+        // differed between MI355X boxes in round 1, so the choice is a process constant (weights_variant_default)
+        // or the caller's explicit `variant` -- never a measurement inside the call.
+        const int choice = (H == 64 && split_enabled()) ? (variant < 0 ? weights_variant_default() : variant) : 0;
+        if (choice != 0) {
             launch_split();
             rc = check_launch("gru_bwd_weights_split");
         } else {

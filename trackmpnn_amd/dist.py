@@ -31,6 +31,10 @@ class GradBucket:
         for p in params:
             p.grad = self.flat[o:o + p.numel()].view_as(p)
             o += p.numel()
+        # the bucket owns every p.grad for the module's lifetime, so the HIP backward may add into it directly
+        # (functional.INPLACE_GRADS: plain loss.backward() only -- no hooks / DDP / torch.autograd.grad)
+        if hasattr(module, 'inplace_param_grads'):
+            module.inplace_param_grads = True
 
     def check_alias(self) -> bool:
         """True while every p.grad still aliases the bucket (zero_grad(set_to_none=True) breaks it)."""

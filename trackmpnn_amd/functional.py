@@ -18,9 +18,13 @@ from . import _lib
 from .graph import CallPlan
 
 ATT_DROPOUT_P = 0.5
-# accumulate parameter gradients straight into existing p.grad buffers (the kernels add into their outputs) instead
-# of returning per-call tensors for autograd to add: saves a zero-fill and ~20 small add kernels per call
-INPLACE_GRADS = os.environ.get('TMPNN_INPLACE_GRADS', '1') != '0'
+# OPT-IN fast path: accumulate parameter gradients straight into existing p.grad buffers (the kernels add into their
+# outputs) instead of returning per-call tensors for autograd to add: saves a zero-fill and ~20 small add kernels per
+# call.  It bypasses autograd's bookkeeping for the parameters (autograd receives None), so it is only valid for a
+# plain `loss.backward()` with no parameter hooks, no DistributedDataParallel wrapper and no torch.autograd.grad();
+# `GradBucket(model)` (trackmpnn_amd.dist) turns it on for its module (`module.inplace_param_grads = True`), the
+# environment variable TMPNN_INPLACE_GRADS=1 for every module.  Default: off -- real gradients are returned.
+INPLACE_GRADS = os.environ.get('TMPNN_INPLACE_GRADS', '0') == '1'
 FUSED_BWD = os.environ.get('TMPNN_FUSED_BWD', '0') == '1'     # see mp_backward
 
 
@@ -452,7 +456,7 @@ class MPIteration(torch.autograd.Function):
         names = spec.param_names()
         objs = call.get('param_objs')
         grad_out = None
-        if INPLACE_GRADS and objs is not None and all(need[3:]):
+        if (INPLACE_GRADS or call.get('inplace')) and objs is not None and all(need[3:]):
             gs = [p.grad for p in objs]
             if all(g is not None and g.dtype == torch.float32 and g.is_contiguous() and g.device == ctx.P[nm].device
                    and g.shape == ctx.P[nm].shape for g, nm in zip(gs, names)):

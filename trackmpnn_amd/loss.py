@@ -96,6 +96,11 @@ class _Focal(torch.autograd.Function):
     def forward(ctx, outputs, targets_u8, gamma, use_alpha, a0, a1, mean):
         s = outputs.detach().reshape(-1).float().contiguous()
         R = s.numel()
+        ctx.shape = outputs.shape
+        ctx.R = R
+        if R == 0:
+            # empty selection: the reference's loss.mean() is nan and loss.sum() is 0 (models/loss.py:71-74); no kernel
+            return s.new_full((), float('nan') if mean else 0.0)
         loss = torch.empty((1,), dtype=torch.float32, device=s.device)
         wsn = _lib.load().tmpnn_focal_loss_ws(R)
         ws = torch.empty((wsn,), dtype=torch.float32, device=s.device)
@@ -103,12 +108,13 @@ class _Focal(torch.autograd.Function):
         _lib.call('tmpnn_focal_loss_fwd', rows.data_ptr(), R, s.data_ptr(), targets_u8.data_ptr(), float(gamma),
                   int(use_alpha), float(a0), float(a1), loss.data_ptr(), ws.data_ptr(), wsn, _stream())
         ctx.s, ctx.t, ctx.rows, ctx.args = s, targets_u8, rows, (float(gamma), int(use_alpha), float(a0), float(a1))
-        ctx.scale = (1.0 / R) if (mean and R > 0) else 1.0
-        ctx.shape = outputs.shape
-        return (loss * ctx.scale).reshape(()) if R > 0 else loss.reshape(()) * float('nan') if mean else loss.reshape(())
+        ctx.scale = (1.0 / R) if mean else 1.0
+        return (loss * ctx.scale).reshape(())
 
     @staticmethod
     def backward(ctx, d_loss):
+        if ctx.R == 0:
+            return d_loss.new_zeros(ctx.shape), None, None, None, None, None, None
         d = torch.zeros_like(ctx.s)
         dl = d_loss.reshape(1).float().contiguous()
         gamma, ua, a0, a1 = ctx.args

@@ -82,6 +82,8 @@ class TrackMPNN(nn.Module):
         self.output_activation = nn.Sigmoid()
         self.spec = ModelSpec(tuple(groups), nhidden, max(int(nattheads), 0), msg_type)
         self._graph_cache = None
+        # set by trackmpnn_amd.dist.GradBucket: parameter gradients are added straight into p.grad (functional.py)
+        self.inplace_param_grads = False
 
     def get_input_transform(self, n_in, n_out):
         lin1 = nn.Linear(n_in, n_out, bias=True)
@@ -118,7 +120,7 @@ class TrackMPNN(nn.Module):
         call = dict(spec=self.spec, plan=plan, buffers=buffers, training=self.training, need_grad=need_grad,
                     keep=dropout_keep, reserve=reserve_rows,
                     h_spare=getattr(h_in, '_tmpnn_spare_rows', 0) if h_in is not None else 0,
-                    param_objs=params)
+                    param_objs=params, inplace=self.inplace_param_grads)
         scores, logits, h_out = MPIteration.apply(call, x, h_in, *params)
         h_out._tmpnn_spare_rows = max(int(reserve_rows), 0)
         attention = tuple(None if a is None else [SparseAttention(plan.graph, ak) for ak in a]
