@@ -18,6 +18,8 @@
  *   - return value: TMPNN_OK (0) or a negative TMPNN_E* code; `tmpnn_last_error()` gives the
  *     thread-local message of the last failure.  Nothing is ever thrown across the boundary.
  *   - supported hidden widths: H in {32, 64, 128, 256}.
+ *   - no entry point measures, tunes or keeps data between calls; the only process state is the thread-local
+ *     error string and idempotent per-kernel function attributes.
  */
 #ifndef TMPNN_H
 #define TMPNN_H
@@ -284,6 +286,98 @@ int tmpnn_focal_loss_fwd(const int32_t* rows, int R, const float* scores, const 
 int tmpnn_focal_loss_bwd(const int32_t* rows, int R, const float* scores, const uint8_t* targets, float gamma,
                          int use_alpha, float alpha0, float alpha1, const float* d_loss, float scale, float* d_scores,
                          tmpnn_stream stream);
+
+/* ======================================================================================================
+ * Batch-1 path (the reference's real call pattern, train.py:92-107 / infer.py:60-87: ONE small
+ * graph per call).  Two things make a call cheap when the graph has a few thousand rows:
+ *   (1) the graph's SIZES stay on the device (tmpnn_dgraph): the adjacency -> index conversion is one kernel and the
+ *       host never waits for E / Dn, so nothing synchronises between calls;
+ *   (2) the whole message-passing iteration is two launches forward (input transform; edge + node cells with the
+ *       aggregation, the merge and the output heads fused) and three backward: tmpnn_mp_iter_fwd / _bwd.
+ * Limits: N <= TMPNN_DG_MAX_ROWS rows, H in {32, 64}, no attention heads (the staged entry points above cover the
+ * rest).  Arithmetic: fp32 throughout (v_mfma_f32_16x16x4_f32 = an fmaf chain), reductions in a fixed order.
+ * ====================================================================================================== */
+#define TMPNN_DG_MAX_ROWS 4096
+#define TMPNN_DG_META 8      /* ints in tmpnn_dgraph.meta: [0] E, [1] Dn, [2] status, [3] N, rest reserved */
+/* status bits (0 = the adjacency is a TrackMPNN factor graph, SURVEY 8 "graph invariants") */
+#define TMPNN_DG_BAD_VALUE 1     /* an off-diagonal entry is not +-1, or an index is out of range */
+#define TMPNN_DG_BAD_ROW 2       /* an edge row without exactly one +1 and one -1, or a det row with off-diagonals */
+#define TMPNN_DG_BAD_ENDPOINT 4  /* an edge endpoint is not a det row */
+#define TMPNN_DG_BAD_ORDER 8     /* not src row < edge row < dst row (utils/graph.py:153-156,298-301) */
+#define TMPNN_DG_BAD_EDGE_DIAG 16 /* diag(edge_adj) does not complement diag(node_adj) */
+#define TMPNN_DG_BAD_EDGE_ADJ 32 /* edge_adj is not node_adj^T off the diagonal */
+
+/* Index form of one graph with device-side sizes.  All arrays are caller-owned device memory of capacity `cap`
+ * rows (one arena of tmpnn_dgraph_ints(cap) int32, carved by tmpnn_dgraph_bind).  When status != 0 the producer
+ * stores E = Dn = 0, so that consumers touch nothing; the host reads meta when it chooses to (deferred check). */
+typedef struct tmpnn_dgraph {
+    int32_t N;          /* rows of the state tensor: host-known (the adjacency's shape) */
+    int32_t cap;        /* capacity of the arrays, >= N */
+    int32_t* meta;      /* [TMPNN_DG_META] */
+    uint8_t* is_edge;   /* [cap]   1 on edge rows */
+    int32_t* pos;       /* [cap]   row -> index within its type */
+    int32_t* src;       /* [cap]   per edge index: ROW of the +1 det */
+    int32_t* dst;       /* [cap]   per edge index: ROW of the -1 det */
+    int32_t* src_pos;   /* [cap]   per edge index: det INDEX of src */
+    int32_t* dst_pos;   /* [cap]   per edge index: det INDEX of dst */
+    int32_t* edge_row;  /* [cap]   row of edge e (ascending) */
+    int32_t* det_row;   /* [cap]   row of det d (ascending) */
+    int32_t* rowptr;    /* [cap+1] det -> incident edges CSR */
+    int32_t* inc;       /* [2 cap] edge row | sign bit, ascending edge row per det (as tmpnn_graph.inc) */
+} tmpnn_dgraph;
+
+size_t tmpnn_dgraph_ints(int cap);
+/* pure host arithmetic: point `out`'s arrays into `arena` (tmpnn_dgraph_ints(cap) int32, 16-byte aligned) */
+int tmpnn_dgraph_bind(void* arena, int cap, int N, tmpnn_dgraph* out);
+
+/* Adjacency pair -> tmpnn_dgraph in ONE launch (replaces the dense round trips of models/track_mpnn.py:55-56 and
+ * models/layers.py:85-88, and validates what utils/graph.py:151-163,294-308 build).  COO entries as torch stores
+ * them: idx int64 [2][nnz] (rows then columns), val fp32 [nnz]; explicit zeros and UNcoalesced diagonals are fine
+ * (duplicate diagonal entries are summed; duplicate off-diagonal entries make the row invalid).  edge_idx may be
+ * NULL (no cross-check).  N <= TMPNN_DG_MAX_ROWS. */
+int tmpnn_graph_from_coo(int N, const int64_t* node_idx, const float* node_val, int64_t nnz_node,
+                         const int64_t* edge_idx, const float* edge_val, int64_t nnz_edge,
+                         const tmpnn_dgraph* g, tmpnn_stream stream);
+
+/* Parameters of the model as device pointers in the reference's layouts (state_dict keys of SURVEY 8(b)); the same
+ * struct with gradient buffers is what tmpnn_mp_iter_bwd accumulates into (+=).  G <= 3 feature groups. */
+typedef struct tmpnn_mp_params {
+    int32_t G, H, IN_e /* H (diff) or 2H (concat) */, F_total;
+    int32_t F[3];                 /* input width of each group's transform */
+    float* w1[3]; float* b1[3]; float* gamma[3]; float* beta[3]; float* w2[3]; float* b2[3];   /* input_transforms.g.{0,1,3} */
+    float* run_mean[3]; float* run_var[3];                                                      /* BatchNorm buffers (NULL in a gradient struct) */
+    float* e_wih[3]; float* e_whh[3]; float* e_bih[3]; float* e_bhh[3];                         /* factor_grus.g.edge_gru */
+    float* n_wih[3]; float* n_whh[3]; float* n_bih[3]; float* n_bhh[3];                         /* factor_grus.g.node_gru */
+    float* w_node; float* b_node; float* w_edge; float* b_edge;                                 /* output_transform_{node,edge} */
+} tmpnn_mp_params;
+
+/* MFMA-operand images of the four GRU weight matrices of every group (forward and backward-data forms): one
+ * launch, to be repeated whenever the weights change (once per optimizer step).  prep: tmpnn_mp_iter_prep_floats. */
+size_t tmpnn_mp_iter_prep_floats(int G, int H, int IN_e);
+int tmpnn_mp_iter_prepare(const tmpnn_mp_params* P, float* prep, tmpnn_stream stream);
+
+/* One TrackMPNN.forward call (models/track_mpnn.py:54-75 + models/layers.py:84-116).
+ *   h [N][G*H]: rows [0, N - n_new) hold the carried state on entry; the n_new new rows are written (input
+ *   transform on new det rows, zeros on new edge rows) -- this is the h the iteration reads.  x [n_new][ld_x]:
+ *   features of the new rows (only det rows are read: edge rows are all-zero by contract, utils/graph.py:148,291).
+ *   Outputs: h_out [N][G*H], logits [N], scores [N].  save: tmpnn_mp_iter_save_floats floats kept for
+ *   tmpnn_mp_iter_bwd (may be NULL only for an inference call without new rows).  training != 0: batch statistics (one segment) + running-stat update. */
+size_t tmpnn_mp_iter_save_floats(int N, int n_new, int G, int H);
+int tmpnn_mp_iter_fwd(const tmpnn_mp_params* P, const float* prep, const tmpnn_dgraph* g, int n_new,
+                      const float* x, int ld_x, float* h, int training,
+                      float* h_out, float* logits, float* scores, float* save, size_t save_floats,
+                      tmpnn_stream stream);
+/* Backward of tmpnn_mp_iter_fwd.  d_scores / d_logits [N] and d_hout [N][G*H] may each be NULL.  Writes d_h
+ * [N][G*H] (gradient of the h the iteration read: its first N - n_new rows are the gradient of the carried state)
+ * and d_x [n_new][F_total] (may be NULL); ACCUMULATES (+=) every parameter gradient into `grads`.
+ * ws: tmpnn_mp_iter_bwd_ws bytes. */
+size_t tmpnn_mp_iter_bwd_ws(int N, int n_new, int G, int H, int IN_e);
+int tmpnn_mp_iter_bwd(const tmpnn_mp_params* P, const float* prep, const tmpnn_dgraph* g, int n_new,
+                      const float* x, int ld_x, const float* h, const float* h_out, const float* scores,
+                      const float* save, int training,
+                      const float* d_scores, const float* d_logits, const float* d_hout,
+                      float* d_h, float* d_x, const tmpnn_mp_params* grads,
+                      void* ws, size_t ws_bytes, tmpnn_stream stream);
 
 #ifdef __cplusplus
 }

@@ -2,10 +2,10 @@
 
     from trackmpnn_amd import TrackMPNN          # drop-in for reference models/track_mpnn.py
 """
-from .graph import (CallPlan, FrameGraph, WindowBuilder, batch_windows, concat_static_graphs, dense_static_graph,
+from .graph import (CallPlan, DeviceGraph, FrameGraph, device_graph_from_adjacency, WindowBuilder, batch_windows, concat_static_graphs, dense_static_graph,
                     graph_from_adjacency, graph_from_edges, plan_single, synth_window)
 from .loss import CELoss, FocalLoss, create_targets
 from .track_mpnn import SparseAttention, TrackMPNN
 
 __all__ = ['TrackMPNN', 'SparseAttention', 'create_targets', 'CELoss', 'FocalLoss', 'FrameGraph', 'CallPlan', 'graph_from_adjacency', 'graph_from_edges',
-           'plan_single', 'WindowBuilder', 'batch_windows', 'synth_window', 'dense_static_graph', 'concat_static_graphs']
+           'plan_single', 'DeviceGraph', 'device_graph_from_adjacency', 'WindowBuilder', 'batch_windows', 'synth_window', 'dense_static_graph', 'concat_static_graphs']

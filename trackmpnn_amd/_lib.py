@@ -31,6 +31,30 @@ class CGraph(C.Structure):
 
 _GP = C.POINTER(CGraph)
 
+
+class CDGraph(C.Structure):
+    """struct tmpnn_dgraph (include/tmpnn.h): index-form graph whose sizes live on the device."""
+    _fields_ = [('N', C.c_int32), ('cap', C.c_int32), ('meta', c_void_p), ('is_edge', c_void_p), ('pos', c_void_p),
+                ('src', c_void_p), ('dst', c_void_p), ('src_pos', c_void_p), ('dst_pos', c_void_p),
+                ('edge_row', c_void_p), ('det_row', c_void_p), ('rowptr', c_void_p), ('inc', c_void_p)]
+
+
+_P3 = c_void_p * 3
+
+
+class CMpParams(C.Structure):
+    """struct tmpnn_mp_params (include/tmpnn.h): every parameter (or its gradient buffer) as a device pointer."""
+    _fields_ = [('G', C.c_int32), ('H', C.c_int32), ('IN_e', C.c_int32), ('F_total', C.c_int32), ('F', C.c_int32 * 3),
+                ('w1', _P3), ('b1', _P3), ('gamma', _P3), ('beta', _P3), ('w2', _P3), ('b2', _P3),
+                ('run_mean', _P3), ('run_var', _P3),
+                ('e_wih', _P3), ('e_whh', _P3), ('e_bih', _P3), ('e_bhh', _P3),
+                ('n_wih', _P3), ('n_whh', _P3), ('n_bih', _P3), ('n_bhh', _P3),
+                ('w_node', c_void_p), ('b_node', c_void_p), ('w_edge', c_void_p), ('b_edge', c_void_p)]
+
+
+_DGP = C.POINTER(CDGraph)
+_MPP = C.POINTER(CMpParams)
+
 # name -> (restype, argtypes); must mirror include/tmpnn.h (tests/test_abi.py cross-checks the names)
 _SIGNATURES = {
     'tmpnn_abi_version': (c_int, []),
@@ -98,6 +122,18 @@ _SIGNATURES = {
                                      c_void_p, c_size_t, c_void_p]),
     'tmpnn_focal_loss_bwd': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_float, c_int, c_float, c_float, c_void_p,
                                      c_float, c_void_p, c_void_p]),
+    'tmpnn_dgraph_ints': (c_size_t, [c_int]),
+    'tmpnn_dgraph_bind': (c_int, [c_void_p, c_int, c_int, _DGP]),
+    'tmpnn_graph_from_coo': (c_int, [c_int, c_void_p, c_void_p, C.c_int64, c_void_p, c_void_p, C.c_int64, _DGP, c_void_p]),
+    'tmpnn_mp_iter_prep_floats': (c_size_t, [c_int, c_int, c_int]),
+    'tmpnn_mp_iter_prepare': (c_int, [_MPP, c_void_p, c_void_p]),
+    'tmpnn_mp_iter_save_floats': (c_size_t, [c_int, c_int, c_int, c_int]),
+    'tmpnn_mp_iter_fwd': (c_int, [_MPP, c_void_p, _DGP, c_int, c_void_p, c_int, c_void_p, c_int,
+                                  c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    'tmpnn_mp_iter_bwd_ws': (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
+    'tmpnn_mp_iter_bwd': (c_int, [_MPP, c_void_p, _DGP, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                                  c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, _MPP, c_void_p, c_size_t,
+                                  c_void_p]),
 }
 
 _lib: Optional[C.CDLL] = None

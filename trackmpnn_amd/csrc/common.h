@@ -1,11 +1,28 @@
 // Shared helpers for the libtmpnn kernels (gfx950 only).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <stdarg.h>
 #include <stdint.h>
 #include <stdio.h>
 
 #include "tmpnn.h"
+
+// The LDS-resident kernels need more than the default 64 KiB of dynamic LDS: raise the limit ONCE per (kernel
+// instantiation, device) instead of before every launch (idempotent function-attribute setup, not data state).
+#define TM_SHM_ONCE(kernel, bytes)                                                                           \
+    do {                                                                                                     \
+        static std::atomic<int> done_[16];                                                                   \
+        int dev_ = 0;                                                                                        \
+        (void)hipGetDevice(&dev_);                                                                           \
+        const int b_ = (int)(bytes);                                                                         \
+        if (done_[dev_ & 15].load(std::memory_order_relaxed) < b_) {                                         \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&kernel),                                \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, b_);                       \
+            done_[dev_ & 15].store(b_, std::memory_order_relaxed);                                           \
+        }                                                                                                    \
+    } while (0)
+
 
 namespace tmpnn {
 

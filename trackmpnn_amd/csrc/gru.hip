@@ -2164,21 +2164,6 @@ __global__ void k_fold_slabs_gru(const float* __restrict__ slabs, size_t stride,
 }
 
 
-// The LDS-resident kernels need more than the default 64 KiB of dynamic LDS: raise the limit ONCE per (kernel
-// instantiation, device) instead of before every launch (idempotent function-attribute setup, not data state).
-#define TM_SHM_ONCE(kernel, bytes)                                                                           \
-    do {                                                                                                     \
-        static std::atomic<int> done_[16];                                                                   \
-        int dev_ = 0;                                                                                        \
-        (void)hipGetDevice(&dev_);                                                                           \
-        const int b_ = (int)(bytes);                                                                         \
-        if (done_[dev_ & 15].load(std::memory_order_relaxed) < b_) {                                         \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&kernel),                                \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, b_);                       \
-            done_[dev_ & 15].store(b_, std::memory_order_relaxed);                                           \
-        }                                                                                                    \
-    } while (0)
-
 // TMPNN_SPLIT=0 keeps every GEMM on the f32-input MFMA (v_mfma_f32_32x32x2_f32)
 static bool split_enabled() {
     static const int on = [] { const char* e = getenv("TMPNN_SPLIT"); return (e && e[0] == '0') ? 0 : 1; }();

@@ -1,0 +1,1067 @@
+// Fused message-passing iteration for ONE small graph (batch-1 path; include/tmpnn.h: tmpnn_mp_iter_*).
+//
+// The reference's real workload is one tracking window per call (train.py:92-107, infer.py:60-87; batch size 1,
+// utils/graph.py:117): a few hundred to a few thousand rows, H = 64.  At that size the staged entry points are
+// launch-bound (a dozen launches per group forward, two dozen backward) and their LDS-resident persistent kernels
+// pay a 100+ KB weight load per block for a handful of rows.  Here a forward call is TWO launches and a backward
+// THREE, each sized to the graph:
+//
+//   k_small_bn_fwd      rows C, D     input transform of the new det rows (Lin-BN-ReLU-Lin, batch statistics over ALL
+//                                     new rows with the analytic zero-row terms), zeros on new edge rows
+//   k_small_iter_fwd    rows E-J      16-row tiles: edge tiles form h[src]-h[dst] (or the concat) on the fly, det
+//                                     tiles reduce their incident edge rows (CSR, fixed order); both cells' GEMMs on
+//                                     v_mfma_f32_16x16x4_f32 with weight operands pre-arranged for coalesced 16-byte
+//                                     loads (tmpnn_mp_iter_prepare); GRU gates, merge (row indirection) and the
+//                                     output head in the epilogue
+//   k_small_iter_bwd    row K         per tile: gate gradients, d_x = d_gi W_ih, d_h = dh z + d_gh W_hh, and the
+//                                     weight / bias / head gradients accumulated in REGISTERS over a persistent
+//                                     block's tiles (one slab per block)
+//   k_small_bwd_finish  row K         adjoints of rows E and F (CSR segment sums / gathers of d_x) + slab reduction
+//   k_small_bn_bwd      row K         input-transform backward
+//
+// Sizes (E, Dn) are read from the graph's device-side meta (tmpnn_dgraph): grids are sized from N alone and
+// surplus blocks exit, so the host never synchronises.  fp32 throughout; every reduction has a fixed order.
+#include "common.h"
+
+namespace tmpnn {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+static constexpr float BN_EPS_S = 1e-5f;
+static constexpr float BN_MOM_S = 0.1f;
+static constexpr int TR = 16;            // rows per tile
+static constexpr int SMALL_BWD_BLOCKS = 96;
+
+__device__ __forceinline__ float sigm(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+__device__ __forceinline__ float tanh_(float x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(2.0f * x)); }
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+// LDS image of a [TR][W] operand tile whose k index is PERMUTED so that the four k values a lane needs for four
+// consecutive MFMA steps (k = 4*kq + (lane >> 4), kq = 4i .. 4i+3) are one aligned float4:
+//   element k of a row lives at position (k & 3) * (W / 4) + (k >> 2).
+__device__ __forceinline__ int perm_pos(int k, int W) { return (k & 3) * (W >> 2) + (k >> 2); }
+
+// ------------------------------------------------------------------------------------------------------------
+// weight operand images
+// ------------------------------------------------------------------------------------------------------------
+// W [3H][IN] row-major (reference layout).  Forward image (B operand of  g = x W^T : B[k][n] = W[n][k]):
+//   Wf[(((gate * (H/16) + cs) * (IN/16) + i) * 64 + lane) * 4 + jj] = W[gate*H + 16 cs + (lane & 15)][4 (4i + jj) + (lane >> 4)]
+// Backward-data image (B operand of  d_x = d_g W : B[k][n] = W[k][n]):
+//   Wb[((ct * (3H/16) + i) * 64 + lane) * 4 + jj] = W[4 (4i + jj) + (lane >> 4)][16 ct + (lane & 15)]
+struct PrepJob { const float* W; int IN; size_t off_f, off_b; };
+struct PrepArgs { PrepJob job[12]; int njobs; int H; };
+
+__global__ __launch_bounds__(256) void k_small_prepare(PrepArgs a, float* __restrict__ prep) {
+    const PrepJob jb = a.job[blockIdx.y];
+    const int H = a.H, IN = jb.IN;
+    const int total = 3 * H * IN;
+    for (int idx = blockIdx.x * 256 + threadIdx.x; idx < total; idx += gridDim.x * 256) {
+        {   // forward image
+            const int jj = idx & 3, lane = (idx >> 2) & 63;
+            int rest = idx >> 8;
+            const int i = rest % (IN / 16); rest /= (IN / 16);
+            const int cs = rest % (H / 16);
+            const int gate = rest / (H / 16);
+            prep[jb.off_f + idx] = jb.W[(size_t)(gate * H + 16 * cs + (lane & 15)) * IN + 4 * (4 * i + jj) + (lane >> 4)];
+        }
+        {   // backward-data image
+            const int jj = idx & 3, lane = (idx >> 2) & 63;
+            int rest = idx >> 8;
+            const int i = rest % (3 * H / 16);
+            const int ct = rest / (3 * H / 16);
+            prep[jb.off_b + idx] = jb.W[(size_t)(4 * (4 * i + jj) + (lane >> 4)) * IN + 16 * ct + (lane & 15)];
+        }
+    }
+}
+
+// offsets (floats) of the images inside `prep`: per group [edge ih f|b][edge hh f|b][node ih f|b][node hh f|b]
+struct PrepLayout {
+    size_t per_group, e_ih_f, e_ih_b, e_hh_f, e_hh_b, n_ih_f, n_ih_b, n_hh_f, n_hh_b;
+};
+__host__ __device__ inline PrepLayout prep_layout(int H, int IN_e) {
+    PrepLayout L;
+    const size_t a = (size_t)3 * H * IN_e, b = (size_t)3 * H * H;
+    L.e_ih_f = 0; L.e_ih_b = a; L.e_hh_f = 2 * a; L.e_hh_b = 2 * a + b;
+    L.n_ih_f = 2 * a + 2 * b; L.n_ih_b = L.n_ih_f + b; L.n_hh_f = L.n_ih_b + b; L.n_hh_b = L.n_hh_f + b;
+    L.per_group = 2 * a + 6 * b;
+    return L;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// saved-for-backward layout (floats)
+// ------------------------------------------------------------------------------------------------------------
+struct SaveLayout { size_t gates, es, ysave, mean, rstd, total; };
+__host__ __device__ inline SaveLayout save_layout(int N, int n, int G, int H) {
+    SaveLayout L;
+    L.gates = 0;                                   // [G][4][N][H]   r, z, n, W_hn h + b_hn   (row-indexed)
+    L.es = L.gates + (size_t)G * 4 * N * H;         // [G][N][H]      edge -> node sums, by det INDEX
+    L.ysave = L.es + (size_t)G * N * H;             // [G][n][H]      Lin1 output of the new det rows (by new-det index)
+    L.mean = L.ysave + (size_t)G * (n > 0 ? n : 1) * H;   // [G][H]
+    L.rstd = L.mean + (size_t)G * H;                // [G][H]
+    L.total = L.rstd + (size_t)G * H;
+    return L;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// input transform, forward: one block per feature group
+// ------------------------------------------------------------------------------------------------------------
+struct BnFwdArgs {
+    tmpnn_mp_params P;
+    tmpnn_dgraph g;
+    int n_new, training;
+    const float* x; int ld_x;
+    float* h;                  // [N][G*H]
+    float* ysave; float* mean; float* rstd;     // may be scratch when nothing is saved
+    int* newdet;               // [n_new + 1] scratch: local indices of the new det rows, count at [n_new]
+};
+
+template <int H>
+__global__ __launch_bounds__(256) void k_small_bn_fwd(BnFwdArgs a) {
+    const int gi = blockIdx.x;
+    const int G = a.P.G, GH = G * H;
+    const int N = a.g.N, n = a.n_new, N_old = N - n;
+    const int F = a.P.F[gi];
+    int f0 = 0;
+    for (int q = 0; q < gi; ++q) f0 += a.P.F[q];
+    const int tid = threadIdx.x;
+    __shared__ int s_wsum[5];
+    __shared__ float s_mean[H], s_rstd[H], s_w2t[H * (H + 1)];
+    extern __shared__ float s_a[];                 // [CH][H + 1] activation chunk
+    int* newdet = a.newdet + (size_t)gi * (n + 1);
+
+    // ---- compact list of the new det rows (ascending); every group's block builds its own copy
+    {
+        const int IT = (n + 255) / 256;
+        const int i0 = tid * IT, i1 = min(n, i0 + IT);
+        int cnt = 0;
+        for (int i = i0; i < i1; ++i) cnt += a.g.is_edge[N_old + i] ? 0 : 1;
+        const int lane = tid & 63, wave = tid >> 6;
+        int inc = cnt;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) { const int t = __shfl_up(inc, off); if (lane >= off) inc += t; }
+        if (lane == 63) s_wsum[wave] = inc;
+        __syncthreads();
+        if (tid == 0) { int run = 0; for (int w = 0; w < 4; ++w) { const int t = s_wsum[w]; s_wsum[w] = run; run += t; } s_wsum[4] = run; }
+        __syncthreads();
+        int p = s_wsum[wave] + inc - cnt;
+        for (int i = i0; i < i1; ++i)
+            if (!a.g.is_edge[N_old + i]) newdet[p++] = i;
+    }
+    const int nd = s_wsum[4];
+    if (tid == 0) newdet[n] = nd;
+    // new edge rows start at zero (track_mpnn.py:61); new det rows are written below
+    for (int idx = tid; idx < n * (H / 4); idx += 256) {
+        const int i = idx / (H / 4), c4 = idx % (H / 4);
+        if (a.g.is_edge[N_old + i])
+            *reinterpret_cast<float4*>(a.h + (size_t)(N_old + i) * GH + gi * H + 4 * c4) = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    __syncthreads();
+    const float* W1 = a.P.w1[gi];
+    const float* b1 = a.P.b1[gi];
+    float* ysave = a.ysave + (size_t)gi * (n > 0 ? n : 1) * H;
+    const int c = tid % H, sub = tid / H;
+    constexpr int NSUB = 256 / H;
+    // ---- Lin1 on the det rows: y1[i][c] = b1[c] + sum_f x[i][f] W1[c][f]
+    for (int i = sub; i < nd; i += NSUB) {
+        const float* xr = a.x + (size_t)newdet[i] * a.ld_x + f0;
+        float acc = b1[c];
+        for (int f = 0; f < F; ++f) acc = fmaf(xr[f], W1[c * F + f], acc);
+        ysave[(size_t)i * H + c] = acc;
+    }
+    __syncthreads();
+    // ---- statistics over ALL n new rows: the n - nd zero rows contribute Lin1(0) = b1 (models/track_mpnn.py:59)
+    if (a.training) {
+        const float cnt = (float)n, nz = (float)(n - nd);
+        if (tid < H) {
+            const float b = b1[tid];
+            float sum = nz * b;
+            for (int i = 0; i < nd; ++i) sum += ysave[(size_t)i * H + tid];
+            const float m = sum / cnt;
+            float sq = nz * (b - m) * (b - m);
+            for (int i = 0; i < nd; ++i) { const float d = ysave[(size_t)i * H + tid] - m; sq += d * d; }
+            const float var = sq / cnt;
+            s_mean[tid] = m;
+            s_rstd[tid] = rsqrtf(var + BN_EPS_S);
+            float* rm = a.P.run_mean[gi];
+            float* rv = a.P.run_var[gi];
+            rm[tid] = (1.0f - BN_MOM_S) * rm[tid] + BN_MOM_S * m;
+            rv[tid] = (1.0f - BN_MOM_S) * rv[tid] + BN_MOM_S * (var * (cnt / (cnt - 1.0f)));
+        }
+    } else if (tid < H) {
+        s_mean[tid] = a.P.run_mean[gi][tid];
+        s_rstd[tid] = rsqrtf(a.P.run_var[gi][tid] + BN_EPS_S);
+    }
+    // W2 transposed into LDS: s_w2t[k][c] = W2[c][k]
+    const float* W2 = a.P.w2[gi];
+    for (int idx = tid; idx < H * H; idx += 256) { const int cc = idx / H, k = idx % H; s_w2t[k * (H + 1) + cc] = W2[idx]; }
+    __syncthreads();
+    if (tid < H) {
+        a.mean[(size_t)gi * H + tid] = s_mean[tid];
+        a.rstd[(size_t)gi * H + tid] = s_rstd[tid];
+    }
+    // ---- a = relu(gamma yhat + beta) ; out = a W2^T + b2 -> h[new det rows], in chunks of CH rows
+    constexpr int CH = 64;
+    const float gam = a.P.gamma[gi][c], bet = a.P.beta[gi][c], b2 = a.P.b2[gi][c];
+    for (int i0 = 0; i0 < nd; i0 += CH) {
+        const int rows = min(CH, nd - i0);
+        for (int i = sub; i < rows; i += NSUB) {
+            const float yh = (ysave[(size_t)(i0 + i) * H + c] - s_mean[c]) * s_rstd[c];
+            s_a[i * (H + 1) + c] = fmaxf(yh * gam + bet, 0.f);
+        }
+        __syncthreads();
+        for (int i = sub; i < rows; i += NSUB) {
+            float acc = b2;
+#pragma unroll 8
+            for (int k = 0; k < H; ++k) acc = fmaf(s_a[i * (H + 1) + k], s_w2t[k * (H + 1) + c], acc);
+            a.h[(size_t)(N_old + newdet[i0 + i]) * GH + gi * H + c] = acc;
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// the iteration, forward
+// ------------------------------------------------------------------------------------------------------------
+struct IterFwdArgs {
+    tmpnn_mp_params P;
+    tmpnn_dgraph g;
+    const float* prep;
+    const float* h;            // [N][G*H]  (h_cat)
+    float* h_out;              // [N][G*H]
+    float* logits; float* scores;
+    float* gates;              // [G][4][N][H] or NULL
+    float* es;                 // [G][N][H]   or NULL (nothing saved)
+};
+
+// gi/gh MFMA loop of one column slice: acc[gate] += A(tile rows, K = W) x image
+template <int W, int H>
+__device__ __forceinline__ void cell_gemm(const float* __restrict__ sA, int ldA, const float* __restrict__ img, int cs,
+                                          int lane, f32x4 (&acc)[3]) {
+    const int row = lane & 15, kh = lane >> 4;
+    const float* ap = sA + row * ldA + kh * (W / 4);
+#pragma unroll 2
+    for (int i = 0; i < W / 16; ++i) {
+        const float4 av = *reinterpret_cast<const float4*>(ap + 4 * i);
+        float4 bv[3];
+#pragma unroll
+        for (int gate = 0; gate < 3; ++gate)
+            bv[gate] = *reinterpret_cast<const float4*>(img + ((size_t)((gate * (H / 16) + cs) * (W / 16) + i) * 64 + lane) * 4);
+#pragma unroll
+        for (int gate = 0; gate < 3; ++gate) {
+            acc[gate] = mfma16(av.x, bv[gate].x, acc[gate]);
+            acc[gate] = mfma16(av.y, bv[gate].y, acc[gate]);
+            acc[gate] = mfma16(av.z, bv[gate].z, acc[gate]);
+            acc[gate] = mfma16(av.w, bv[gate].w, acc[gate]);
+        }
+    }
+}
+
+template <int H, int IN_E>
+__global__ __launch_bounds__(256) void k_small_iter_fwd(IterFwdArgs a) {
+    const int E = a.g.meta[0], Dn = a.g.meta[1];
+    const int nEt = (E + TR - 1) / TR, nDt = (Dn + TR - 1) / TR;
+    const int b = blockIdx.x;
+    if (b >= nEt + nDt) return;
+    const bool is_e = b < nEt;
+    const int r0 = (is_e ? b : b - nEt) * TR;
+    const int R = is_e ? E : Dn;
+    const int G = a.P.G, GH = G * H, N = a.g.N;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int LDX = IN_E + 4, LDH = H + 4;
+    __shared__ __attribute__((aligned(16))) float sX[TR * LDX];
+    __shared__ __attribute__((aligned(16))) float sH[TR * LDH];
+    __shared__ float sHp[TR * (H + 1)];        // h_prev of the tile, natural order (merge term of the epilogue)
+    __shared__ float sLog[4][TR];
+    __shared__ int sRow[TR], sS[TR], sD[TR];
+    if (tid < TR) {
+        const int q = r0 + tid;
+        const bool ok = q < R;
+        const int qc = ok ? q : R - 1;
+        sRow[tid] = is_e ? a.g.edge_row[qc] : a.g.det_row[qc];
+        sS[tid] = is_e ? a.g.src[qc] : 0;
+        sD[tid] = is_e ? a.g.dst[qc] : 0;
+    }
+    float lsum[4] = {0.f, 0.f, 0.f, 0.f};
+    const PrepLayout PL = prep_layout(H, IN_E);
+    const int IN = is_e ? IN_E : H;
+    const float* w_head = is_e ? a.P.w_edge : a.P.w_node;
+    __syncthreads();
+    for (int gi = 0; gi < G; ++gi) {
+        const float* hg = a.h + gi * H;
+        // ---- stage the operand tiles
+        if (tid < TR * (H / 4)) {
+            const int row = tid / (H / 4), c4 = tid % (H / 4);
+            const bool ok = r0 + row < R;
+            const int grow = sRow[row];
+            float4 hp = make_float4(0.f, 0.f, 0.f, 0.f), x0 = hp, x1 = hp;
+            if (ok) {
+                hp = *reinterpret_cast<const float4*>(hg + (size_t)grow * GH + 4 * c4);
+                if (is_e) {
+                    x0 = *reinterpret_cast<const float4*>(hg + (size_t)sS[row] * GH + 4 * c4);
+                    x1 = *reinterpret_cast<const float4*>(hg + (size_t)sD[row] * GH + 4 * c4);
+                    if (IN_E == H) { x0.x -= x1.x; x0.y -= x1.y; x0.z -= x1.z; x0.w -= x1.w; }
+                } else {
+                    // edge -> node aggregation (models/layers.py:103): signed sum over the det's incident edge rows,
+                    // CSR order (ascending edge row), four rows in flight
+                    const int d = r0 + row;
+                    const int p0 = a.g.rowptr[d], p1 = a.g.rowptr[d + 1];
+                    for (int p = p0; p < p1; p += 4) {
+                        float4 v[4];
+                        float sg[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const bool live = p + u < p1;
+                            const int key = live ? a.g.inc[p + u] : 0;
+                            sg[u] = live ? (key < 0 ? -1.0f : 1.0f) : 0.f;
+                            v[u] = *reinterpret_cast<const float4*>(hg + (size_t)(key & 0x7fffffff) * GH + 4 * c4);
+                        }
+#pragma unroll
+                        for (int u = 0; u < 4; ++u)
+                            if (sg[u] != 0.f) { x0.x += sg[u] * v[u].x; x0.y += sg[u] * v[u].y; x0.z += sg[u] * v[u].z; x0.w += sg[u] * v[u].w; }
+                    }
+                    if (a.es) *reinterpret_cast<float4*>(a.es + ((size_t)gi * N + d) * H + 4 * c4) = x0;
+                }
+            }
+            const float xv[4] = {x0.x, x0.y, x0.z, x0.w}, yv[4] = {x1.x, x1.y, x1.z, x1.w}, hv[4] = {hp.x, hp.y, hp.z, hp.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int k = 4 * c4 + j;
+                sX[row * LDX + perm_pos(k, IN)] = xv[j];
+                if (is_e && IN_E == 2 * H) sX[row * LDX + perm_pos(H + k, IN)] = yv[j];
+                sH[row * LDH + perm_pos(k, H)] = hv[j];
+                sHp[row * (H + 1) + k] = hv[j];
+            }
+        }
+        __syncthreads();
+        const float* img = a.prep + (size_t)gi * PL.per_group;
+        const float* img_ih = img + (is_e ? PL.e_ih_f : PL.n_ih_f);
+        const float* img_hh = img + (is_e ? PL.e_hh_f : PL.n_hh_f);
+        const float* b_ih = is_e ? a.P.e_bih[gi] : a.P.n_bih[gi];
+        const float* b_hh = is_e ? a.P.e_bhh[gi] : a.P.n_bhh[gi];
+        for (int cs = wave; cs < H / 16; cs += 4) {
+            f32x4 gi_[3], gh_[3];
+#pragma unroll
+            for (int q = 0; q < 3; ++q) { gi_[q] = (f32x4){0.f, 0.f, 0.f, 0.f}; gh_[q] = gi_[q]; }
+            if (is_e) cell_gemm<IN_E, H>(sX, LDX, img_ih, cs, lane, gi_);
+            else cell_gemm<H, H>(sX, LDX, img_ih, cs, lane, gi_);
+            cell_gemm<H, H>(sH, LDH, img_hh, cs, lane, gh_);
+            const int col = 16 * cs + (lane & 15);
+            const float bir = b_ih[col], biz = b_ih[H + col], bin_ = b_ih[2 * H + col];
+            const float bhr = b_hh[col], bhz = b_hh[H + col], bhn = b_hh[2 * H + col];
+            const float wh = w_head[gi * H + col];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = 4 * (lane >> 4) + r;
+                if (r0 + row >= R) continue;
+                const float rr = sigm(gi_[0][r] + bir + gh_[0][r] + bhr);
+                const float zz = sigm(gi_[1][r] + biz + gh_[1][r] + bhz);
+                const float hn = gh_[2][r] + bhn;
+                const float nn = tanh_(gi_[2][r] + bin_ + rr * hn);
+                const float hp = sHp[row * (H + 1) + col];
+                const float hv = (1.0f - zz) * nn + zz * hp;
+                const int grow = sRow[row];
+                a.h_out[(size_t)grow * GH + gi * H + col] = hv;
+                if (a.gates) {
+                    float* gp = a.gates + (size_t)gi * 4 * N * H + (size_t)grow * H + col;
+                    const size_t plane = (size_t)N * H;
+                    gp[0] = rr; gp[plane] = zz; gp[2 * plane] = nn; gp[3 * plane] = hn;
+                }
+                lsum[r] += wh * hv;
+            }
+        }
+        __syncthreads();
+    }
+    // ---- output head (models/track_mpnn.py:72-75): sum over the 16 columns a lane group holds, then over the waves
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        float v = lsum[r];
+        v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8);
+        if ((lane & 15) == 0) sLog[wave][4 * (lane >> 4) + r] = v;
+    }
+    __syncthreads();
+    if (tid < TR && r0 + tid < R) {
+        const float bias = is_e ? a.P.b_edge[0] : a.P.b_node[0];
+        const float y = ((sLog[0][tid] + sLog[1][tid]) + (sLog[2][tid] + sLog[3][tid])) + bias;
+        const int grow = sRow[tid];
+        a.logits[grow] = y;
+        a.scores[grow] = sigm(y);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// the iteration, backward: row tiles
+// ------------------------------------------------------------------------------------------------------------
+// slab of one block and group (floats): [dW_ih 3H x IN][dW_hh 3H x H][db_ih 3H][db_hh 3H][dw_head H][db_head 1]
+__host__ __device__ inline size_t slab_floats(int H, int IN_e) { return (size_t)3 * H * (IN_e + H) + 6 * H + H + 4; }
+
+// how the persistent blocks of k_small_iter_bwd split between edge tiles and det tiles (also used by the finish kernel)
+__device__ __forceinline__ int bwd_edge_blocks(int nEt, int nDt, int nb) {
+    if (nEt == 0) return 0;
+    if (nDt == 0) return nb;
+    int d = (int)(((long)nb * nDt + (nEt + nDt) / 2) / (nEt + nDt));
+    if (d < 1) d = 1;
+    if (d > nb - 1) d = nb - 1;
+    return nb - d;
+}
+
+struct IterBwdArgs {
+    tmpnn_mp_params P;
+    tmpnn_dgraph g;
+    const float* prep;
+    const float* h;            // h_cat
+    const float* scores;
+    const float* gates; const float* es;
+    const float* d_scores; const float* d_logits; const float* d_hout;
+    float* d_h;                // [N][G*H] written (dh z + d_gh W_hh)
+    float* d_msg;              // [N][G*IN_e] written: d_x of every row (edge rows: IN_e columns, det rows: H)
+    float* slabs;              // [gridDim.x][G][slab_floats]
+};
+
+template <int H, int IN_E>
+__global__ __launch_bounds__(256) void k_small_iter_bwd(IterBwdArgs a) {
+    const int E = a.g.meta[0], Dn = a.g.meta[1];
+    const int nEt = (E + TR - 1) / TR, nDt = (Dn + TR - 1) / TR;
+    const int nb = gridDim.x;
+    const int nbE = bwd_edge_blocks(nEt, nDt, nb);
+    const bool is_e = (int)blockIdx.x < nbE;
+    const int my0 = is_e ? blockIdx.x : blockIdx.x - nbE;
+    const int mystride = is_e ? nbE : nb - nbE;
+    const int ntiles = is_e ? nEt : nDt;
+    const int R = is_e ? E : Dn;
+    const int G = a.P.G, GH = G * H, N = a.g.N;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int LDX = IN_E + 4, LDH = H + 4, LDG = 3 * H + 4;
+    constexpr int NJT = (3 * H / 16 + 3) / 4;          // j-tiles (16 rows of dW) per wave
+    constexpr int NCT_I = IN_E / 16, NCT_H = H / 16;   // column tiles of dW_ih (edge cell) / dW_hh
+    constexpr int O_X = 0, O_H = O_X + TR * LDX, O_GI = O_H + TR * LDH, O_GH = O_GI + TR * LDG, O_DHZ = O_GH + TR * LDG,
+                  O_END = O_DHZ + TR * (H + 1);
+    constexpr int RED = TR * (5 * H + 1);              // the end-of-group column sums reuse the tile images
+    __shared__ __attribute__((aligned(16))) float smem[O_END > RED ? O_END : RED];
+    float* sX = smem + O_X;
+    float* sH = smem + O_H;
+    float* sGi = smem + O_GI;        // [dr | dz | dn ]  permuted over 3H
+    float* sGh = smem + O_GH;        // [dr | dz | dnr]
+    float* sDhz = smem + O_DHZ;
+    __shared__ int sRow[TR], sS[TR], sD[TR];
+    __shared__ float sDy[TR];
+    const PrepLayout PL = prep_layout(H, IN_E);
+    const int IN = is_e ? IN_E : H;
+    const int nct_i = is_e ? NCT_I : NCT_H;
+    const float* w_head = is_e ? a.P.w_edge : a.P.w_node;
+    const size_t SLF = slab_floats(H, IN_E);
+    const size_t plane = (size_t)N * H;
+    for (int gi = 0; gi < G; ++gi) {
+        f32x4 wI[NJT][NCT_I], wH[NJT][NCT_H];
+#pragma unroll
+        for (int j = 0; j < NJT; ++j) {
+#pragma unroll
+            for (int t = 0; t < NCT_I; ++t) wI[j][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int t = 0; t < NCT_H; ++t) wH[j][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+        float4 cb[4], chw;                               // column sums of dr, dz, dn, dnr ; of dy * h'
+        float cdy = 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) cb[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+        chw = make_float4(0.f, 0.f, 0.f, 0.f);
+        const float* hg = a.h + gi * H;
+        const float* img = a.prep + (size_t)gi * PL.per_group;
+        const float* img_ih = img + (is_e ? PL.e_ih_b : PL.n_ih_b);
+        const float* img_hh = img + (is_e ? PL.e_hh_b : PL.n_hh_b);
+        for (int tile = my0; tile < ntiles; tile += mystride) {
+            const int r0 = tile * TR;
+            __syncthreads();                               // the previous tile's LDS reads are done
+            if (tid < TR) {
+                const int q = r0 + tid;
+                const bool ok = q < R;
+                const int qc = ok ? q : R - 1;
+                const int grow = is_e ? a.g.edge_row[qc] : a.g.det_row[qc];
+                sRow[tid] = grow;
+                sS[tid] = is_e ? a.g.src[qc] : 0;
+                sD[tid] = is_e ? a.g.dst[qc] : 0;
+                float dy = 0.f;
+                if (ok) {
+                    if (a.d_logits) dy += a.d_logits[grow];
+                    if (a.d_scores) { const float s = a.scores[grow]; dy += a.d_scores[grow] * s * (1.0f - s); }
+                }
+                sDy[tid] = dy;
+            }
+            __syncthreads();
+            if (tid < TR * (H / 4)) {
+                const int row = tid / (H / 4), c4 = tid % (H / 4);
+                const bool ok = r0 + row < R;
+                const int grow = sRow[row];
+                const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                float4 dh = z4, gr = z4, gz = z4, gn = z4, ghn = z4, hp = z4, x0 = z4, x1 = z4;
+                if (ok) {
+                    const float* gp = a.gates + (size_t)gi * 4 * plane + (size_t)grow * H + 4 * c4;
+                    gr = *reinterpret_cast<const float4*>(gp);
+                    gz = *reinterpret_cast<const float4*>(gp + plane);
+                    gn = *reinterpret_cast<const float4*>(gp + 2 * plane);
+                    ghn = *reinterpret_cast<const float4*>(gp + 3 * plane);
+                    hp = *reinterpret_cast<const float4*>(hg + (size_t)grow * GH + 4 * c4);
+                    if (a.d_hout) dh = *reinterpret_cast<const float4*>(a.d_hout + (size_t)grow * GH + gi * H + 4 * c4);
+                    const float dy = sDy[row];
+                    const float4 wh = *reinterpret_cast<const float4*>(w_head + gi * H + 4 * c4);
+                    dh.x += dy * wh.x; dh.y += dy * wh.y; dh.z += dy * wh.z; dh.w += dy * wh.w;
+                    if (is_e) {
+                        x0 = *reinterpret_cast<const float4*>(hg + (size_t)sS[row] * GH + 4 * c4);
+                        x1 = *reinterpret_cast<const float4*>(hg + (size_t)sD[row] * GH + 4 * c4);
+                        if (IN_E == H) { x0.x -= x1.x; x0.y -= x1.y; x0.z -= x1.z; x0.w -= x1.w; }
+                    } else {
+                        x0 = *reinterpret_cast<const float4*>(a.es + ((size_t)gi * N + (r0 + row)) * H + 4 * c4);
+                    }
+                    // head gradient needs h' = (1 - z) n + z h_prev (recomputed, not re-read)
+                    chw.x += dy * ((1.0f - gz.x) * gn.x + gz.x * hp.x);
+                    chw.y += dy * ((1.0f - gz.y) * gn.y + gz.y * hp.y);
+                    chw.z += dy * ((1.0f - gz.z) * gn.z + gz.z * hp.z);
+                    chw.w += dy * ((1.0f - gz.w) * gn.w + gz.w * hp.w);
+                    if (c4 == 0) cdy += dy;
+                }
+                const float dhv[4] = {dh.x, dh.y, dh.z, dh.w}, rv[4] = {gr.x, gr.y, gr.z, gr.w}, zv[4] = {gz.x, gz.y, gz.z, gz.w};
+                const float nv[4] = {gn.x, gn.y, gn.z, gn.w}, hnv[4] = {ghn.x, ghn.y, ghn.z, ghn.w}, hv[4] = {hp.x, hp.y, hp.z, hp.w};
+                const float xv[4] = {x0.x, x0.y, x0.z, x0.w}, yv[4] = {x1.x, x1.y, x1.z, x1.w};
+                float dr[4], dz[4], dn[4], dnr[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float t = dhv[j] * (1.0f - zv[j]) * (1.0f - nv[j] * nv[j]);
+                    dn[j] = t;
+                    dnr[j] = t * rv[j];
+                    dr[j] = t * hnv[j] * rv[j] * (1.0f - rv[j]);
+                    dz[j] = dhv[j] * (hv[j] - nv[j]) * zv[j] * (1.0f - zv[j]);
+                    const int k = 4 * c4 + j;
+                    sGi[row * LDG + perm_pos(k, 3 * H)] = dr[j];
+                    sGi[row * LDG + perm_pos(H + k, 3 * H)] = dz[j];
+                    sGi[row * LDG + perm_pos(2 * H + k, 3 * H)] = dn[j];
+                    sGh[row * LDG + perm_pos(k, 3 * H)] = dr[j];
+                    sGh[row * LDG + perm_pos(H + k, 3 * H)] = dz[j];
+                    sGh[row * LDG + perm_pos(2 * H + k, 3 * H)] = dnr[j];
+                    sX[row * LDX + perm_pos(k, IN)] = xv[j];
+                    if (is_e && IN_E == 2 * H) sX[row * LDX + perm_pos(H + k, IN)] = yv[j];
+                    sH[row * LDH + perm_pos(k, H)] = hv[j];
+                    sDhz[row * (H + 1) + k] = dhv[j] * zv[j];
+                }
+                cb[0].x += dr[0]; cb[0].y += dr[1]; cb[0].z += dr[2]; cb[0].w += dr[3];
+                cb[1].x += dz[0]; cb[1].y += dz[1]; cb[1].z += dz[2]; cb[1].w += dz[3];
+                cb[2].x += dn[0]; cb[2].y += dn[1]; cb[2].z += dn[2]; cb[2].w += dn[3];
+                cb[3].x += dnr[0]; cb[3].y += dnr[1]; cb[3].z += dnr[2]; cb[3].w += dnr[3];
+            }
+            __syncthreads();
+            // ---- data gradients: d_x = d_gi W_ih (IN columns), d_hprev = dh z + d_gh W_hh (H columns)
+            {
+                const int row = lane & 15, kh = lane >> 4;
+                for (int ct = wave; ct < nct_i + NCT_H; ct += 4) {
+                    const bool ih = ct < nct_i;
+                    const int c = ih ? ct : ct - nct_i;
+                    const float* sA = (ih ? sGi : sGh) + row * LDG + kh * (3 * H / 4);
+                    const float* im = (ih ? img_ih : img_hh) + (size_t)c * (3 * H / 16) * 256;
+                    f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+                    for (int i = 0; i < 3 * H / 16; ++i) {
+                        const float4 av = *reinterpret_cast<const float4*>(sA + 4 * i);
+                        const float4 bv = *reinterpret_cast<const float4*>(im + ((size_t)i * 64 + lane) * 4);
+                        acc = mfma16(av.x, bv.x, acc);
+                        acc = mfma16(av.y, bv.y, acc);
+                        acc = mfma16(av.z, bv.z, acc);
+                        acc = mfma16(av.w, bv.w, acc);
+                    }
+                    const int col = 16 * c + (lane & 15);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int rw = 4 * (lane >> 4) + r;
+                        if (r0 + rw >= R) continue;
+                        const int grow = sRow[rw];
+                        if (ih) a.d_msg[(size_t)grow * (G * IN_E) + gi * IN_E + col] = acc[r];
+                        else a.d_h[(size_t)grow * GH + gi * H + col] = acc[r] + sDhz[rw * (H + 1) + col];
+                    }
+                }
+            }
+            // ---- weight gradients: dW[j][c] += sum_rows d_g[row][j] * [x | h][row][c]   (K = the tile's 16 rows)
+#pragma unroll
+            for (int jq = 0; jq < NJT; ++jq) {
+                const int jt = wave + 4 * jq;
+                if (jt < 3 * H / 16) {
+                    const int j = 16 * jt + (lane & 15);
+                    float ai[4], ah[4];
+#pragma unroll
+                    for (int kq = 0; kq < 4; ++kq) {
+                        const int rw = 4 * kq + (lane >> 4);
+                        ai[kq] = sGi[rw * LDG + perm_pos(j, 3 * H)];
+                        ah[kq] = sGh[rw * LDG + perm_pos(j, 3 * H)];
+                    }
+#pragma unroll
+                    for (int t = 0; t < NCT_I; ++t) {
+                        if (t < nct_i) {
+                            const int c = 16 * t + (lane & 15);
+#pragma unroll
+                            for (int kq = 0; kq < 4; ++kq)
+                                wI[jq][t] = mfma16(ai[kq], sX[(4 * kq + (lane >> 4)) * LDX + perm_pos(c, IN)], wI[jq][t]);
+                        }
+                    }
+#pragma unroll
+                    for (int t = 0; t < NCT_H; ++t) {
+                        const int c = 16 * t + (lane & 15);
+#pragma unroll
+                        for (int kq = 0; kq < 4; ++kq)
+                            wH[jq][t] = mfma16(ah[kq], sH[(4 * kq + (lane >> 4)) * LDH + perm_pos(c, H)], wH[jq][t]);
+                    }
+                }
+            }
+        }
+        // ---- this block's slab for group gi
+        float* sl = a.slabs + ((size_t)blockIdx.x * G + gi) * SLF;
+        float* sl_hh = sl + (size_t)3 * H * IN;
+#pragma unroll
+        for (int jq = 0; jq < NJT; ++jq) {
+            const int jt = wave + 4 * jq;
+            if (jt < 3 * H / 16) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int j = 16 * jt + 4 * (lane >> 4) + r;
+#pragma unroll
+                    for (int t = 0; t < NCT_I; ++t)
+                        if (t < nct_i) sl[(size_t)j * IN + 16 * t + (lane & 15)] = wI[jq][t][r];
+#pragma unroll
+                    for (int t = 0; t < NCT_H; ++t) sl_hh[(size_t)j * H + 16 * t + (lane & 15)] = wH[jq][t][r];
+                }
+            }
+        }
+        // column sums: 16 threads (one per tile row) hold partial sums of the same 4 columns -> fixed-order sum in LDS
+        __syncthreads();
+        float* red = smem;                                 // [TR][5H + 1]
+        if (tid < TR * (H / 4)) {
+            const int row = tid / (H / 4), c4 = tid % (H / 4);
+            float* rr = red + row * (5 * H + 1);
+            rr[4 * c4 + 0] = cb[0].x; rr[4 * c4 + 1] = cb[0].y; rr[4 * c4 + 2] = cb[0].z; rr[4 * c4 + 3] = cb[0].w;
+            rr[H + 4 * c4 + 0] = cb[1].x; rr[H + 4 * c4 + 1] = cb[1].y; rr[H + 4 * c4 + 2] = cb[1].z; rr[H + 4 * c4 + 3] = cb[1].w;
+            rr[2 * H + 4 * c4 + 0] = cb[2].x; rr[2 * H + 4 * c4 + 1] = cb[2].y; rr[2 * H + 4 * c4 + 2] = cb[2].z; rr[2 * H + 4 * c4 + 3] = cb[2].w;
+            rr[3 * H + 4 * c4 + 0] = cb[3].x; rr[3 * H + 4 * c4 + 1] = cb[3].y; rr[3 * H + 4 * c4 + 2] = cb[3].z; rr[3 * H + 4 * c4 + 3] = cb[3].w;
+            rr[4 * H + 4 * c4 + 0] = chw.x; rr[4 * H + 4 * c4 + 1] = chw.y; rr[4 * H + 4 * c4 + 2] = chw.z; rr[4 * H + 4 * c4 + 3] = chw.w;
+            if (c4 == 0) rr[5 * H] = cdy;
+        }
+        __syncthreads();
+        float* sb = sl + (size_t)3 * H * (IN + H);
+        for (int q = tid; q < 5 * H + 1; q += 256) {
+            float s = 0.f;
+#pragma unroll
+            for (int row = 0; row < TR; ++row) s += red[row * (5 * H + 1) + q];
+            // q: [0,H) dr | [H,2H) dz | [2H,3H) dn | [3H,4H) dnr | [4H,5H) dy*h' | 5H: dy
+            if (q < 3 * H) sb[q] = s;                                   // db_ih = [dr | dz | dn]
+            if (q < 2 * H) sb[3 * H + q] = s;                           // db_hh = [dr | dz | dnr]
+            else if (q >= 3 * H && q < 4 * H) sb[3 * H + q - H] = s;
+            else if (q >= 4 * H) sb[6 * H + (q - 4 * H)] = s;           // dw_head [H], then db_head
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// backward, second launch: adjoints of the two aggregations + slab reduction into the gradient buffers
+// ------------------------------------------------------------------------------------------------------------
+struct FinishArgs {
+    tmpnn_mp_params P;         // only G, H, IN_e are read
+    tmpnn_mp_params grads;
+    tmpnn_dgraph g;
+    const float* d_msg;
+    float* d_h;
+    const float* slabs;
+    int nb_bwd;                // grid of k_small_iter_bwd
+    int row_blocks;            // blocks [0, row_blocks) do the row work, the rest reduce slabs
+};
+
+template <int H, int IN_E>
+__global__ __launch_bounds__(256) void k_small_bwd_finish(FinishArgs a) {
+    const int E = a.g.meta[0], Dn = a.g.meta[1];
+    const int G = a.P.G, GH = G * H, N = a.g.N;
+    const int tid = threadIdx.x;
+    constexpr int LPR = H / 4, RPB = 256 / LPR;
+    if ((int)blockIdx.x < a.row_blocks) {
+        if (E + Dn == 0) return;
+        const int c4 = tid % LPR, slot = tid / LPR;
+        for (int r = blockIdx.x * RPB + slot; r < N; r += a.row_blocks * RPB) {
+            const bool edge = a.g.is_edge[r] != 0;
+            const int p = a.g.pos[r];
+            for (int gi = 0; gi < G; ++gi) {
+                const float* dm = a.d_msg + gi * IN_E + 4 * c4;
+                const size_t ldm = (size_t)G * IN_E;
+                float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (edge) {
+                    // adjoint of row F: d h[e] += d_es[src(e)] - d_es[dst(e)]   (d_es = the node cell's d_x, at det rows)
+                    const float4 u = *reinterpret_cast<const float4*>(dm + (size_t)a.g.src[p] * ldm);
+                    const float4 v = *reinterpret_cast<const float4*>(dm + (size_t)a.g.dst[p] * ldm);
+                    acc = make_float4(u.x - v.x, u.y - v.y, u.z - v.z, u.w - v.w);
+                } else {
+                    // adjoint of row E: d h[d] += sum_{e: src=d} d_x[e][0:H] -/+ sum_{e: dst=d} d_x[e][0:H | H:2H]
+                    const int p0 = a.g.rowptr[p], p1 = a.g.rowptr[p + 1];
+                    for (int q = p0; q < p1; ++q) {
+                        const int key = a.g.inc[q];
+                        const bool neg = key < 0;
+                        const float4 v = *reinterpret_cast<const float4*>(dm + (size_t)(key & 0x7fffffff) * ldm +
+                                                                         ((neg && IN_E == 2 * H) ? H : 0));
+                        const float w = (neg && IN_E == H) ? -1.0f : 1.0f;
+                        acc.x += w * v.x; acc.y += w * v.y; acc.z += w * v.z; acc.w += w * v.w;
+                    }
+                }
+                float4* o = reinterpret_cast<float4*>(a.d_h + (size_t)r * GH + gi * H + 4 * c4);
+                float4 t = *o;
+                t.x += acc.x; t.y += acc.y; t.z += acc.z; t.w += acc.w;
+                *o = t;
+            }
+        }
+        return;
+    }
+    // ---- slab reduction (fixed order over the blocks of each cell)
+    const int nEt = (E + TR - 1) / TR, nDt = (Dn + TR - 1) / TR;
+    const int nbE = bwd_edge_blocks(nEt, nDt, a.nb_bwd);
+    const size_t SLF = slab_floats(H, IN_E);
+    const size_t n_e = (size_t)3 * H * (IN_E + H) + 7 * H + 1, n_n = (size_t)3 * H * (2 * H) + 7 * H + 1;
+    const size_t per_g = n_e + n_n;
+    const size_t total = per_g * G;
+    const int rb = gridDim.x - a.row_blocks;
+    for (size_t idx = (size_t)(blockIdx.x - a.row_blocks) * 256 + tid; idx < total; idx += (size_t)rb * 256) {
+        const int gi = (int)(idx / per_g);
+        size_t q = idx % per_g;
+        const bool edge = q < n_e;
+        if (!edge) q -= n_e;
+        const int IN = edge ? IN_E : H;
+        const int b0 = edge ? 0 : nbE, b1 = edge ? nbE : a.nb_bwd;
+        float s = 0.f;
+        for (int b = b0; b < b1; ++b) s += a.slabs[((size_t)b * G + gi) * SLF + q];
+        const size_t nih = (size_t)3 * H * IN, nhh = (size_t)3 * H * H;
+        float* dst;
+        if (q < nih) dst = (edge ? a.grads.e_wih[gi] : a.grads.n_wih[gi]) + q;
+        else if (q < nih + nhh) dst = (edge ? a.grads.e_whh[gi] : a.grads.n_whh[gi]) + (q - nih);
+        else {
+            const size_t k = q - nih - nhh;
+            if (k < (size_t)3 * H) dst = (edge ? a.grads.e_bih[gi] : a.grads.n_bih[gi]) + k;
+            else if (k < (size_t)6 * H) dst = (edge ? a.grads.e_bhh[gi] : a.grads.n_bhh[gi]) + (k - 3 * H);
+            else if (k < (size_t)7 * H) dst = (edge ? a.grads.w_edge : a.grads.w_node) + gi * H + (k - 6 * H);
+            else dst = nullptr;                        // head bias: summed over groups below
+        }
+        if (dst) *dst += s;
+    }
+    // head biases (one scalar per cell type): the same dy sums appear in every group's slab; take group 0
+    if ((int)blockIdx.x == a.row_blocks && tid < 2) {
+        const bool edge = tid == 0;
+        const int IN = edge ? IN_E : H;
+        const int b0 = edge ? 0 : nbE, b1 = edge ? nbE : a.nb_bwd;
+        const size_t q = (size_t)3 * H * (IN + H) + 7 * H;
+        float s = 0.f;
+        for (int b = b0; b < b1; ++b) s += a.slabs[((size_t)b * G + 0) * SLF + q];
+        float* dst = edge ? a.grads.b_edge : a.grads.b_node;
+        *dst += s;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// input transform, backward: one block per feature group
+// ------------------------------------------------------------------------------------------------------------
+struct BnBwdArgs {
+    tmpnn_mp_params P;
+    tmpnn_mp_params grads;
+    tmpnn_dgraph g;
+    int n_new, training;
+    const float* x; int ld_x;
+    const float* d_h;          // [N][G*H] complete gradient of the iteration's input state
+    const float* ysave; const float* mean; const float* rstd;
+    const int* newdet;         // [G][n_new + 1]
+    float* d_x;                // [n_new][F_total] or NULL
+    float* scratch;            // [G][2][n_new][H]  (d_out -> d_y1 ; a)
+};
+
+template <int H>
+__global__ __launch_bounds__(256) void k_small_bn_bwd(BnBwdArgs a) {
+    const int gi = blockIdx.x;
+    const int G = a.P.G, GH = G * H;
+    const int N = a.g.N, n = a.n_new, N_old = N - n;
+    const int F = a.P.F[gi], Ft = a.P.F_total;
+    int f0 = 0;
+    for (int q = 0; q < gi; ++q) f0 += a.P.F[q];
+    const int tid = threadIdx.x;
+    const int* newdet = a.newdet + (size_t)gi * (n + 1);
+    const int nd = newdet[n];
+    const float* ysave = a.ysave + (size_t)gi * (n > 0 ? n : 1) * H;
+    float* B0 = a.scratch + (size_t)gi * 2 * n * H;      // d_out, then d_y1
+    float* B1 = B0 + (size_t)n * H;                      // a (post-ReLU activations)
+    __shared__ float s_m1[H], s_m2[H], s_dyz[H];
+    const float cntf = (float)n, nz = (float)(n - nd);
+    const int c = tid % H, sub = tid / H;
+    constexpr int NSUB = 256 / H;
+    const float mean = a.mean[(size_t)gi * H + c], rstd = a.rstd[(size_t)gi * H + c];
+    const float gam = a.P.gamma[gi][c], bet = a.P.beta[gi][c];
+    if (nd == 0) {
+        if (a.d_x) for (int idx = tid; idx < n * F; idx += 256) a.d_x[(size_t)(idx / F) * Ft + f0 + idx % F] = 0.f;
+        return;
+    }
+    // 1. gather d_out and recompute a
+    for (int i = sub; i < nd; i += NSUB) {
+        B0[(size_t)i * H + c] = a.d_h[(size_t)(N_old + newdet[i]) * GH + gi * H + c];
+        const float yh = (ysave[(size_t)i * H + c] - mean) * rstd;
+        B1[(size_t)i * H + c] = fmaxf(yh * gam + bet, 0.f);
+    }
+    __syncthreads();
+    // 2. dW2[c][k] += sum_i d_out[i][c] a[i][k] ; db2[c] += sum_i d_out[i][c]
+    {
+        float* dW2 = a.grads.w2[gi];
+        for (int idx = tid; idx < H * H; idx += 256) {
+            const int cc = idx / H, k = idx % H;
+            float s = 0.f;
+            for (int i = 0; i < nd; ++i) s = fmaf(B0[(size_t)i * H + cc], B1[(size_t)i * H + k], s);
+            dW2[idx] += s;
+        }
+        if (tid < H) {
+            float s = 0.f;
+            for (int i = 0; i < nd; ++i) s += B0[(size_t)i * H + tid];
+            a.grads.b2[gi][tid] += s;
+        }
+    }
+    __syncthreads();
+    // 3. d_a = d_out W2 ; d_pre = d_a [a > 0] ; overwrite B0 with d_yhat = d_pre * gamma (column k = c), keep yhat implicit
+    {
+        const float* W2 = a.P.w2[gi];
+        // each thread produces column c of rows sub, sub + NSUB, ...; reads the whole d_out row first
+        for (int i = sub; i < nd; i += NSUB) {
+            float s = 0.f;
+            for (int cc = 0; cc < H; ++cc) s = fmaf(B0[(size_t)i * H + cc], W2[cc * H + c], s);
+            const float av = B1[(size_t)i * H + c];
+            B1[(size_t)i * H + c] = av > 0.f ? s : 0.f;          // d_pre (B1 no longer needed as a)
+        }
+    }
+    __syncthreads();
+    // 4. dgamma, dbeta, the two batch means of the BatchNorm backward
+    if (tid < H) {
+        float sg = 0.f, sb = 0.f;
+        for (int i = 0; i < nd; ++i) {
+            const float dp = B1[(size_t)i * H + tid];
+            const float yh = (ysave[(size_t)i * H + tid] - a.mean[(size_t)gi * H + tid]) * a.rstd[(size_t)gi * H + tid];
+            sg += dp * yh;
+            sb += dp;
+        }
+        a.grads.gamma[gi][tid] += sg;
+        a.grads.beta[gi][tid] += sb;
+        const float g_ = a.P.gamma[gi][tid];
+        s_m1[tid] = a.training ? g_ * sb / cntf : 0.f;       // mean over ALL n rows of d_yhat (zero rows contribute 0)
+        s_m2[tid] = a.training ? g_ * sg / cntf : 0.f;       // mean of d_yhat * yhat
+    }
+    __syncthreads();
+    // 5. d_y1 (det rows) into B0 ; the zero rows' d_y1 (one value per column)
+    for (int i = sub; i < nd; i += NSUB) {
+        const float yh = (ysave[(size_t)i * H + c] - mean) * rstd;
+        const float dyh = B1[(size_t)i * H + c] * gam;
+        B0[(size_t)i * H + c] = rstd * (dyh - s_m1[c] - yh * s_m2[c]);
+    }
+    if (tid < H) {
+        const float yz = (a.P.b1[gi][tid] - a.mean[(size_t)gi * H + tid]) * a.rstd[(size_t)gi * H + tid];
+        s_dyz[tid] = a.training ? a.rstd[(size_t)gi * H + tid] * (-s_m1[tid] - yz * s_m2[tid]) : 0.f;
+    }
+    __syncthreads();
+    // 6. dW1[k][f] += sum_i d_y1[i][k] x[i][f] ; db1[k] += sum_i d_y1[i][k] + nz * d_y1_zero[k]
+    {
+        float* dW1 = a.grads.w1[gi];
+        for (int idx = tid; idx < H * F; idx += 256) {
+            const int k = idx / F, f = idx % F;
+            float s = 0.f;
+            for (int i = 0; i < nd; ++i) s = fmaf(B0[(size_t)i * H + k], a.x[(size_t)newdet[i] * a.ld_x + f0 + f], s);
+            dW1[idx] += s;
+        }
+        if (tid < H) {
+            float s = nz * s_dyz[tid];
+            for (int i = 0; i < nd; ++i) s += B0[(size_t)i * H + tid];
+            a.grads.b1[gi][tid] += s;
+        }
+    }
+    // 7. d_x: det rows  d_y1 W1 ; zero rows  d_y1_zero W1 (the gradient that reaches them through the batch statistics)
+    if (a.d_x) {
+        const float* W1 = a.P.w1[gi];
+        for (int idx = tid; idx < n * F; idx += 256) {
+            const int i = idx / F, f = idx % F;
+            if (!a.g.is_edge[N_old + i]) continue;
+            float s = 0.f;
+            for (int k = 0; k < H; ++k) s = fmaf(s_dyz[k], W1[k * F + f], s);
+            a.d_x[(size_t)i * Ft + f0 + f] = s;
+        }
+        for (int idx = tid; idx < nd * F; idx += 256) {
+            const int i = idx / F, f = idx % F;
+            float s = 0.f;
+            for (int k = 0; k < H; ++k) s = fmaf(B0[(size_t)i * H + k], W1[k * F + f], s);
+            a.d_x[(size_t)newdet[i] * Ft + f0 + f] = s;
+        }
+    }
+}
+
+static int check_params(const tmpnn_mp_params* P, const char* what, bool grads) {
+    TM_REQUIRE(P != nullptr, "%s: null parameter struct", what);
+    TM_REQUIRE(P->G >= 1 && P->G <= 3 && (P->H == 32 || P->H == 64) && (P->IN_e == P->H || P->IN_e == 2 * P->H),
+               "%s: G=%d H=%d IN_e=%d (need G <= 3, H in {32, 64}, IN_e = H or 2H)", what, P->G, P->H, P->IN_e);
+    int ft = 0;
+    for (int g = 0; g < P->G; ++g) {
+        TM_REQUIRE(P->F[g] > 0, "%s: F[%d]=%d", what, g, P->F[g]);
+        ft += P->F[g];
+        TM_REQUIRE(P->w1[g] && P->b1[g] && P->gamma[g] && P->beta[g] && P->w2[g] && P->b2[g] && P->e_wih[g] &&
+                       P->e_whh[g] && P->e_bih[g] && P->e_bhh[g] && P->n_wih[g] && P->n_whh[g] && P->n_bih[g] &&
+                       P->n_bhh[g], "%s: null pointer in group %d", what, g);
+        if (!grads) TM_REQUIRE(P->run_mean[g] && P->run_var[g], "%s: null BatchNorm buffers in group %d", what, g);
+    }
+    TM_REQUIRE(ft == P->F_total, "%s: F_total=%d but the groups sum to %d", what, P->F_total, ft);
+    TM_REQUIRE(P->w_node && P->b_node && P->w_edge && P->b_edge, "%s: null output head", what);
+    return TMPNN_OK;
+}
+
+static int check_dgraph(const tmpnn_dgraph* g, const char* what) {
+    TM_REQUIRE(g != nullptr && g->meta && g->is_edge && g->pos && g->src && g->dst && g->edge_row && g->det_row &&
+                   g->rowptr && g->inc, "%s: unbound graph", what);
+    TM_REQUIRE(g->N >= 0 && g->N <= TMPNN_DG_MAX_ROWS && g->N <= g->cap, "%s: graph N=%d cap=%d (limit %d)", what,
+               g->N, g->cap, TMPNN_DG_MAX_ROWS);
+    return TMPNN_OK;
+}
+
+}  // namespace tmpnn
+
+using namespace tmpnn;
+
+extern "C" {
+
+size_t tmpnn_mp_iter_prep_floats(int G, int H, int IN_e) {
+    if (G <= 0 || H <= 0) return 0;
+    return (size_t)G * prep_layout(H, IN_e).per_group;
+}
+
+int tmpnn_mp_iter_prepare(const tmpnn_mp_params* P, float* prep, tmpnn_stream stream) {
+    int rc = check_params(P, "mp_iter_prepare", true);
+    if (rc) return rc;
+    TM_REQUIRE(prep != nullptr && aligned16(prep), "mp_iter_prepare: prep must be a 16-byte aligned buffer");
+    const int H = P->H, IN_e = P->IN_e;
+    const PrepLayout L = prep_layout(H, IN_e);
+    PrepArgs a;
+    a.H = H;
+    a.njobs = 0;
+    for (int g = 0; g < P->G; ++g) {
+        const size_t base = (size_t)g * L.per_group;
+        a.job[a.njobs++] = PrepJob{P->e_wih[g], IN_e, base + L.e_ih_f, base + L.e_ih_b};
+        a.job[a.njobs++] = PrepJob{P->e_whh[g], H, base + L.e_hh_f, base + L.e_hh_b};
+        a.job[a.njobs++] = PrepJob{P->n_wih[g], H, base + L.n_ih_f, base + L.n_ih_b};
+        a.job[a.njobs++] = PrepJob{P->n_whh[g], H, base + L.n_hh_f, base + L.n_hh_b};
+    }
+    hipLaunchKernelGGL(k_small_prepare, dim3(ceil_div(3L * H * IN_e, 256), a.njobs), dim3(256), 0, as_stream(stream), a, prep);
+    return check_launch("mp_iter_prepare");
+}
+
+size_t tmpnn_mp_iter_save_floats(int N, int n_new, int G, int H) {
+    if (N < 0 || n_new < 0 || G <= 0 || H <= 0) return 0;
+    // + the per-group lists of new det rows (ints, stored behind the floats)
+    return save_layout(N, n_new, G, H).total + (size_t)G * (n_new + 1) + 4;
+}
+
+int tmpnn_mp_iter_fwd(const tmpnn_mp_params* P, const float* prep, const tmpnn_dgraph* g, int n_new, const float* x,
+                      int ld_x, float* h, int training, float* h_out, float* logits, float* scores, float* save,
+                      size_t save_floats, tmpnn_stream stream) {
+    int rc = check_params(P, "mp_iter_fwd", false);
+    if (rc) return rc;
+    if ((rc = check_dgraph(g, "mp_iter_fwd"))) return rc;
+    const int N = g->N, G = P->G, H = P->H;
+    TM_REQUIRE(n_new >= 0 && n_new <= N, "mp_iter_fwd: n_new=%d N=%d", n_new, N);
+    if (N == 0) return TMPNN_OK;
+    TM_REQUIRE(prep && h && h_out && logits && scores, "mp_iter_fwd: null buffer");
+    TM_REQUIRE(aligned16(prep) && aligned16(h) && aligned16(h_out), "mp_iter_fwd: h / h_out / prep must be 16-byte aligned");
+    TM_REQUIRE(n_new == 0 || (x != nullptr && ld_x >= P->F_total), "mp_iter_fwd: x [%d][ld %d] for F_total=%d", n_new, ld_x, P->F_total);
+    TM_REQUIRE(!(training && n_new == 1), "Expected more than 1 value per channel when training, got input size [1, %d]", H);
+    const SaveLayout SL = save_layout(N, n_new, G, H);
+    float* sv = save;
+    if (save != nullptr) {
+        if (save_floats < tmpnn_mp_iter_save_floats(N, n_new, G, H))
+            return set_error(TMPNN_EWORKSPACE, "mp_iter_fwd: save buffer %zu < %zu floats", save_floats,
+                             tmpnn_mp_iter_save_floats(N, n_new, G, H));
+        TM_REQUIRE(aligned16(save), "mp_iter_fwd: save must be 16-byte aligned");
+    }
+    hipStream_t st = as_stream(stream);
+    if (n_new > 0) {
+        TM_REQUIRE(sv != nullptr, "mp_iter_fwd: a call with new rows needs the save buffer (the input transform keeps its "
+                                  "Lin1 outputs and statistics there), also in inference");
+        BnFwdArgs b{*P, *g, n_new, training, x, ld_x, h, sv + SL.ysave, sv + SL.mean, sv + SL.rstd,
+                    reinterpret_cast<int*>(sv + SL.total)};
+        const size_t shm = sizeof(float) * 64 * (H + 1);
+        if (H == 64) hipLaunchKernelGGL((k_small_bn_fwd<64>), dim3(G), dim3(256), shm, st, b);
+        else hipLaunchKernelGGL((k_small_bn_fwd<32>), dim3(G), dim3(256), shm, st, b);
+        if ((rc = check_launch("small_bn_fwd"))) return rc;
+    }
+    IterFwdArgs a{*P, *g, prep, h, h_out, logits, scores, sv ? sv + SL.gates : nullptr, sv ? sv + SL.es : nullptr};
+    const int grid = (N + TR - 1) / TR + 2;
+    if (H == 64 && P->IN_e == 64) hipLaunchKernelGGL((k_small_iter_fwd<64, 64>), dim3(grid), dim3(256), 0, st, a);
+    else if (H == 64) hipLaunchKernelGGL((k_small_iter_fwd<64, 128>), dim3(grid), dim3(256), 0, st, a);
+    else if (P->IN_e == 32) hipLaunchKernelGGL((k_small_iter_fwd<32, 32>), dim3(grid), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((k_small_iter_fwd<32, 64>), dim3(grid), dim3(256), 0, st, a);
+    return check_launch("small_iter_fwd");
+}
+
+static int bwd_blocks(int N) {
+    int nb = (N + TR - 1) / TR + 2;
+    if (nb > SMALL_BWD_BLOCKS) nb = SMALL_BWD_BLOCKS;
+    if (nb < 2) nb = 2;
+    return nb;
+}
+
+size_t tmpnn_mp_iter_bwd_ws(int N, int n_new, int G, int H, int IN_e) {
+    if (N < 0 || n_new < 0 || G <= 0 || H <= 0) return 0;
+    const size_t d_msg = (size_t)N * G * IN_e;
+    const size_t slabs = (size_t)bwd_blocks(N) * G * slab_floats(H, IN_e);
+    const size_t bn = (size_t)G * 2 * n_new * H;
+    return sizeof(float) * (d_msg + slabs + bn + 16);
+}
+
+int tmpnn_mp_iter_bwd(const tmpnn_mp_params* P, const float* prep, const tmpnn_dgraph* g, int n_new, const float* x,
+                      int ld_x, const float* h, const float* h_out, const float* scores, const float* save,
+                      int training, const float* d_scores, const float* d_logits, const float* d_hout, float* d_h,
+                      float* d_x, const tmpnn_mp_params* grads, void* ws, size_t ws_bytes, tmpnn_stream stream) {
+    int rc = check_params(P, "mp_iter_bwd", false);
+    if (rc) return rc;
+    if ((rc = check_params(grads, "mp_iter_bwd (grads)", true))) return rc;
+    if ((rc = check_dgraph(g, "mp_iter_bwd"))) return rc;
+    (void)h_out;
+    const int N = g->N, G = P->G, H = P->H, IN_e = P->IN_e;
+    TM_REQUIRE(grads->G == G && grads->H == H && grads->IN_e == IN_e, "mp_iter_bwd: grads struct does not match the parameters");
+    TM_REQUIRE(n_new >= 0 && n_new <= N, "mp_iter_bwd: n_new=%d N=%d", n_new, N);
+    if (N == 0) return TMPNN_OK;
+    TM_REQUIRE(prep && h && save && d_h && ws, "mp_iter_bwd: null buffer");
+    TM_REQUIRE(d_scores == nullptr || scores != nullptr, "mp_iter_bwd: d_scores needs the forward's scores");
+    TM_REQUIRE(aligned16(h) && aligned16(save) && aligned16(d_h) && aligned16(ws) && (d_hout == nullptr || aligned16(d_hout)) &&
+                   aligned16(P->w_node) && aligned16(P->w_edge), "mp_iter_bwd: 16-byte alignment");
+    const size_t need = tmpnn_mp_iter_bwd_ws(N, n_new, G, H, IN_e);
+    if (ws_bytes < need) return set_error(TMPNN_EWORKSPACE, "mp_iter_bwd: workspace %zu < %zu bytes", ws_bytes, need);
+    const SaveLayout SL = save_layout(N, n_new, G, H);
+    float* d_msg = reinterpret_cast<float*>(ws);
+    const int nb = bwd_blocks(N);
+    float* slabs = d_msg + (size_t)N * G * IN_e;
+    float* bn_scratch = slabs + (size_t)nb * G * slab_floats(H, IN_e);
+    hipStream_t st = as_stream(stream);
+    IterBwdArgs a{*P, *g, prep, h, scores, save + SL.gates, save + SL.es, d_scores, d_logits, d_hout, d_h, d_msg, slabs};
+    if (H == 64 && IN_e == 64) hipLaunchKernelGGL((k_small_iter_bwd<64, 64>), dim3(nb), dim3(256), 0, st, a);
+    else if (H == 64) hipLaunchKernelGGL((k_small_iter_bwd<64, 128>), dim3(nb), dim3(256), 0, st, a);
+    else if (IN_e == 32) hipLaunchKernelGGL((k_small_iter_bwd<32, 32>), dim3(nb), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((k_small_iter_bwd<32, 64>), dim3(nb), dim3(256), 0, st, a);
+    if ((rc = check_launch("small_iter_bwd"))) return rc;
+    const int rpb = 256 / (H / 4);
+    int row_blocks = (N + rpb - 1) / rpb;
+    if (row_blocks > 256) row_blocks = 256;
+    const size_t red_elems = (size_t)G * ((size_t)3 * H * (IN_e + 3 * H) + 14 * H + 2);
+    int red_blocks = (int)((red_elems + 255) / 256);
+    if (red_blocks > 128) red_blocks = 128;
+    FinishArgs f{*P, *grads, *g, d_msg, d_h, slabs, nb, row_blocks};
+    if (H == 64 && IN_e == 64) hipLaunchKernelGGL((k_small_bwd_finish<64, 64>), dim3(row_blocks + red_blocks), dim3(256), 0, st, f);
+    else if (H == 64) hipLaunchKernelGGL((k_small_bwd_finish<64, 128>), dim3(row_blocks + red_blocks), dim3(256), 0, st, f);
+    else if (IN_e == 32) hipLaunchKernelGGL((k_small_bwd_finish<32, 32>), dim3(row_blocks + red_blocks), dim3(256), 0, st, f);
+    else hipLaunchKernelGGL((k_small_bwd_finish<32, 64>), dim3(row_blocks + red_blocks), dim3(256), 0, st, f);
+    if ((rc = check_launch("small_bwd_finish"))) return rc;
+    if (n_new > 0) {
+        TM_REQUIRE(x != nullptr && ld_x >= P->F_total, "mp_iter_bwd: x");
+        BnBwdArgs b{*P, *grads, *g, n_new, training, x, ld_x, d_h, save + SL.ysave, save + SL.mean, save + SL.rstd,
+                    reinterpret_cast<const int*>(save + SL.total), d_x, bn_scratch};
+        if (H == 64) hipLaunchKernelGGL((k_small_bn_bwd<64>), dim3(G), dim3(256), 0, st, b);
+        else hipLaunchKernelGGL((k_small_bn_bwd<32>), dim3(G), dim3(256), 0, st, b);
+        if ((rc = check_launch("small_bn_bwd"))) return rc;
+    }
+    return TMPNN_OK;
+}
+
+}  // extern "C"

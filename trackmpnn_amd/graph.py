@@ -460,3 +460,119 @@ def batch_windows(windows: Sequence[Sequence[WindowCall]], static: bool = False,
             seg_of_det=torch.from_numpy((np.concatenate(seg_ids)[loc] if seg_ids else np.zeros(0)).astype(np.int32)).to(device)))
         det_refs.append(np.concatenate(refs) if refs else np.zeros((0, 2), np.int64))
     return plans, det_refs
+
+
+# ----------------------------------------------------------------------------------------------
+# batch-1 path: graphs whose sizes stay on the device (struct tmpnn_dgraph, include/tmpnn.h)
+# ----------------------------------------------------------------------------------------------
+DG_MAX_ROWS = 4096          # TMPNN_DG_MAX_ROWS
+_DG_STATUS = ((1, 'an off-diagonal adjacency entry is not +-1 (or an index is out of range)'),
+              (2, 'node_adj is not a TrackMPNN factor graph: every edge row needs exactly one +1 and one -1 '
+                  'off-diagonal entry and det rows none'),
+              (4, 'edge endpoint is not a det row'),
+              (8, 'expected src row < edge row < dst row (utils/graph.py:153-156,298-301)'),
+              (16, 'diag(edge_adj) does not complement diag(node_adj)'),
+              (32, 'edge_adj is not node_adj^T off the diagonal'))
+
+
+class DeviceGraph:
+    """Index-form graph of ONE call whose sizes (E, Dn) and validation status live in device memory.
+
+    Produced by `tmpnn_graph_from_coo` in one launch straight from the reference's adjacency tensors; consumed by
+    the fused iteration (`tmpnn_mp_iter_fwd/_bwd`) without the host ever reading E or Dn, so a forward call does not
+    synchronise.  The factor-graph validation therefore reports LATE: `status()` / `check()` read it back (one host
+    round trip) whenever the caller chooses -- `TrackMPNN` does so before the first backward of a chunk, every 64
+    calls, or immediately with TMPNN_STRICT_GRAPH=1.  An invalid graph is presented to the kernels as empty."""
+
+    def __init__(self, N: int, device, cap: Optional[int] = None):
+        lib = _lib.load()
+        self.N = int(N)
+        self.cap = int(cap if cap is not None else N)
+        self.arena = torch.empty((int(lib.tmpnn_dgraph_ints(self.cap)),), dtype=torch.int32, device=device)
+        self.c = _lib.CDGraph()
+        _lib.call('tmpnn_dgraph_bind', self.arena.data_ptr(), self.cap, self.N, C.byref(self.c))
+        self._meta = None
+        self._frame = None
+
+    @property
+    def device(self):
+        return self.arena.device
+
+    def cref(self):
+        return C.byref(self.c)
+
+    def _view(self, ptr, n, dtype=torch.int32):
+        off = (int(ptr) - self.arena.data_ptr()) // 4
+        t = self.arena[off:off + (n if dtype == torch.int32 else (n + 3) // 4)]
+        return t if dtype == torch.int32 else t.view(torch.uint8)[:n]
+
+    def meta(self):
+        """(E, Dn, status) -- synchronises with the stream that built the graph (cached afterwards)."""
+        if self._meta is None:
+            m = self.arena[:8].tolist()
+            self._meta = (m[4], m[5], m[2])
+        return self._meta
+
+    def status(self) -> int:
+        return self.meta()[2]
+
+    def check(self) -> 'DeviceGraph':
+        st = self.status()
+        if st:
+            raise ValueError('; '.join(msg for bit, msg in _DG_STATUS if st & bit))
+        return self
+
+    @property
+    def E(self) -> int:
+        return self.meta()[0]
+
+    @property
+    def Dn(self) -> int:
+        return self.meta()[1]
+
+    def frame_graph(self) -> FrameGraph:
+        """The classic FrameGraph (host-known sizes) as views into the arena; validates first."""
+        if self._frame is None:
+            self.check()
+            E, Dn, _ = self.meta()
+            c = self.c
+            self._frame = FrameGraph(N=self.N, E=E, Dn=Dn, src=self._view(c.src, E), dst=self._view(c.dst, E),
+                                     edge_row=self._view(c.edge_row, E), det_row=self._view(c.det_row, Dn),
+                                     rowptr=self._view(c.rowptr, Dn + 1), inc=self._view(c.inc, 2 * E),
+                                     is_edge=self._view(c.is_edge, self.N, torch.uint8), pos=self._view(c.pos, self.N),
+                                     src_pos=self._view(c.src_pos, E), dst_pos=self._view(c.dst_pos, E))
+        return self._frame
+
+
+def _coo_parts(adj: torch.Tensor, device):
+    """(indices int64 [2, nnz] contiguous, values fp32 [nnz]) of a dense or sparse-COO adjacency, on `device`;
+    sparse tensors are taken as stored (uncoalesced is fine: the converter sums duplicate diagonal entries)."""
+    adj = adj.detach()
+    if adj.is_sparse:
+        idx, val = adj._indices(), adj._values()
+    else:
+        idx = torch.nonzero(adj).t()
+        val = adj[idx[0], idx[1]]
+    idx = idx.to(device=device, dtype=torch.int64)
+    val = val.to(device=device, dtype=torch.float32)
+    return (idx if idx.is_contiguous() else idx.contiguous()), (val if val.is_contiguous() else val.contiguous())
+
+
+def device_graph_from_adjacency(node_adj: torch.Tensor, edge_adj: Optional[torch.Tensor], device) -> DeviceGraph:
+    """One-launch conversion of the reference's adjacency pair (N <= DG_MAX_ROWS) on `device`; no host round trip
+    for sparse inputs (a dense input costs the `nonzero` that sparsifies it)."""
+    N = int(node_adj.shape[0])
+    if N > DG_MAX_ROWS:
+        raise ValueError(f'device_graph_from_adjacency: N={N} > {DG_MAX_ROWS}; use graph_from_adjacency')
+    g = DeviceGraph(N, device)
+    nidx, nval = _coo_parts(node_adj, device)
+    if edge_adj is not None:
+        eidx, eval_ = _coo_parts(edge_adj, device)
+        ep, ev, en = eidx.data_ptr(), eval_.data_ptr(), int(eval_.numel())
+    else:
+        eidx = eval_ = None
+        ep, ev, en = None, None, 0
+    _lib.call('tmpnn_graph_from_coo', N, nidx.data_ptr(), nval.data_ptr(), int(nval.numel()), ep, ev, en, g.cref(),
+              torch.cuda.current_stream(device).cuda_stream)
+    g._keep = (nidx, nval, eidx, eval_)       # until the launch has consumed them (freed with the graph)
+    return g

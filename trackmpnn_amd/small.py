@@ -1,0 +1,236 @@
+"""Batch-1 path: one TrackMPNN.forward call on ONE small graph = one ctypes call (tmpnn_mp_iter_fwd / _bwd).
+
+The reference calls the model once per timestep on a single tracking window (train.py:92-107, infer.py:60-87).  At
+that size the cost of a call is launches and host bookkeeping, not flops, so this path keeps both minimal:
+the graph is a `DeviceGraph` (sizes stay on the device, no host round trip), the iteration is two launches forward and
+three backward (csrc/small.hip), parameters travel as one cached pointer struct, and everything saved for the backward
+lives in one buffer.  Eligible calls: K = 0 attention heads, H in {32, 64}, N <= 4096 rows, one BatchNorm segment;
+anything else takes the staged path of functional.py.  There is no fallback to torch ops or to the oracle.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional
+
+import numpy as np
+import torch
+
+from . import _lib
+from .graph import DG_MAX_ROWS, DeviceGraph
+
+_PTR_FIELDS = ('w1', 'b1', 'gamma', 'beta', 'w2', 'b2', 'run_mean', 'run_var', 'e_wih', 'e_whh', 'e_bih', 'e_bhh',
+               'n_wih', 'n_whh', 'n_bih', 'n_bhh')
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+class SmallPath:
+    """Per-model cache of what a fused call needs: the parameter pointer struct, the MFMA operand images of the GRU
+    weights (rebuilt when a weight's version counter changes, i.e. once per optimizer step) and the layout of the
+    flat per-call gradient buffer."""
+
+    def __init__(self, model):
+        self.model = model
+        spec = model.spec
+        self.spec = spec
+        self.names: List[str] = spec.param_names()
+        self.eligible = spec.K == 0 and spec.H in (32, 64)
+        self._ptr_key = None
+        self._ver_key = None
+        self.cparams = None
+        self.prep = None
+        self._grad_struct_cache = {}
+        # layout of the flat gradient buffer (256-byte aligned slices), in param_names() order
+        sizes, offs = [], [0]
+        named = dict(model.named_parameters())
+        for nm in self.names:
+            sizes.append(named[nm].numel())
+            offs.append(offs[-1] + ((sizes[-1] + 63) // 64) * 64)
+        self.grad_sizes, self.grad_offs, self.grad_total = sizes, offs[:-1], offs[-1]
+
+    # -- structs ---------------------------------------------------------------------------------------------
+    def _fill(self, st: _lib.CMpParams, ptr_of) -> None:
+        spec = self.spec
+        st.G, st.H, st.IN_e, st.F_total = spec.G, spec.H, spec.IN_e, spec.F_total
+        for g, (_, F) in enumerate(spec.groups):
+            st.F[g] = F
+            t, f = f'input_transforms.{g}.', f'factor_grus.{g}.'
+            st.w1[g], st.b1[g] = ptr_of(t + '0.weight'), ptr_of(t + '0.bias')
+            st.gamma[g], st.beta[g] = ptr_of(t + '1.weight'), ptr_of(t + '1.bias')
+            st.w2[g], st.b2[g] = ptr_of(t + '3.weight'), ptr_of(t + '3.bias')
+            st.e_wih[g], st.e_whh[g] = ptr_of(f + 'edge_gru.weight_ih'), ptr_of(f + 'edge_gru.weight_hh')
+            st.e_bih[g], st.e_bhh[g] = ptr_of(f + 'edge_gru.bias_ih'), ptr_of(f + 'edge_gru.bias_hh')
+            st.n_wih[g], st.n_whh[g] = ptr_of(f + 'node_gru.weight_ih'), ptr_of(f + 'node_gru.weight_hh')
+            st.n_bih[g], st.n_bhh[g] = ptr_of(f + 'node_gru.bias_ih'), ptr_of(f + 'node_gru.bias_hh')
+        st.w_node, st.b_node = ptr_of('output_transform_node.weight'), ptr_of('output_transform_node.bias')
+        st.w_edge, st.b_edge = ptr_of('output_transform_edge.weight'), ptr_of('output_transform_edge.bias')
+
+    def params(self, plist) -> _lib.CMpParams:
+        """Pointer struct of the parameters (+ BatchNorm buffers) and fresh operand images; cached by data pointers
+        and version counters."""
+        key = tuple(p.data_ptr() for p in plist)
+        if key != self._ptr_key:
+            for nm, p in zip(self.names, plist):
+                if not p.is_cuda or p.dtype != torch.float32 or not p.is_contiguous():
+                    raise RuntimeError(f'{nm}: the HIP path needs contiguous fp32 parameters on the GPU (no CPU or '
+                                       'torch fallback exists)')
+            ptrs = dict(zip(self.names, key))
+            st = _lib.CMpParams()
+            self._fill(st, ptrs.__getitem__)
+            bufs = dict(self.model.named_buffers())
+            for g in range(self.spec.G):
+                st.run_mean[g] = bufs[f'input_transforms.{g}.1.running_mean'].data_ptr()
+                st.run_var[g] = bufs[f'input_transforms.{g}.1.running_var'].data_ptr()
+            self.cparams, self._ptr_key, self._ver_key = st, key, None
+            self._w_idx = [i for i, nm in enumerate(self.names) if nm.endswith(('gru.weight_ih', 'gru.weight_hh'))]
+        vkey = tuple(plist[i]._version for i in self._w_idx)
+        if vkey != self._ver_key:
+            lib = _lib.load()
+            spec = self.spec
+            if self.prep is None or self.prep.device != plist[0].device:
+                self.prep = torch.empty((int(lib.tmpnn_mp_iter_prep_floats(spec.G, spec.H, spec.IN_e)),),
+                                        dtype=torch.float32, device=plist[0].device)
+            _lib.call('tmpnn_mp_iter_prepare', C.byref(self.cparams), self.prep.data_ptr(), _stream())
+            self._ver_key = vkey
+        return self.cparams
+
+    def grad_struct(self, tensors) -> _lib.CMpParams:
+        """Pointer struct over a list of gradient tensors (param_names() order); cached by their data pointers."""
+        key = tuple(t.data_ptr() for t in tensors)
+        st = self._grad_struct_cache.get(key)
+        if st is None:
+            if len(self._grad_struct_cache) > 8:
+                self._grad_struct_cache.clear()
+            st = _lib.CMpParams()
+            self._fill(st, dict(zip(self.names, key)).__getitem__)
+            self._grad_struct_cache[key] = st
+        return st
+
+
+class _SmallIter(torch.autograd.Function):
+    """autograd node of one fused forward call.  Inputs: (call dict, x, h_in | None, *params)."""
+
+    @staticmethod
+    def forward(ctx, call, x, h_in, *params):
+        sp: SmallPath = call['small']
+        spec = sp.spec
+        dg: DeviceGraph = call['graph']
+        lib = _lib.load()
+        H, G = spec.H, spec.G
+        GH = G * H
+        N, n = dg.N, int(x.shape[0])
+        N_old = N - n
+        dev = x.device
+        if h_in is None:
+            if N_old != 0:
+                raise ValueError(f'h_in is None but the graph has {N_old} rows that are not new')
+        elif h_in.shape[0] != N_old or h_in.shape[1] != GH:
+            raise ValueError(f'h_in must be [{N_old}, {GH}] (N - n, G*H), got {tuple(h_in.shape)}')
+        if n > 0 and x.shape[1] != spec.F_total:
+            raise ValueError(f'x must be [{n}, {spec.F_total}], got {tuple(x.shape)}')
+        training = call['training']
+        if training and n == 1:
+            raise ValueError(f'Expected more than 1 value per channel when training, got input size [1, {H}]')
+        cp = sp.params(params)
+        xd = x.detach()
+        if xd.dtype != torch.float32 or not xd.is_contiguous():
+            xd = xd.float().contiguous()
+        opts = dict(dtype=torch.float32, device=dev)
+        # ---- the state the iteration reads: carried rows + room for the new ones (appended in place when the carried
+        # tensor was produced by this path with spare rows and has not been continued from before)
+        h_cat = None
+        if call['append']:
+            hd = h_in.detach()
+            if hd.is_contiguous() and hd.dtype == torch.float32:
+                h_cat = torch.empty(0, **opts).set_(hd.untyped_storage(), hd.storage_offset(), (N, GH), (GH, 1))
+        if h_cat is None:
+            if h_in is not None and n == 0:
+                hd = h_in.detach()
+                h_cat = hd if (hd.is_contiguous() and hd.dtype == torch.float32) else hd.float().contiguous()
+            else:
+                h_cat = torch.empty((N, GH), **opts)
+                if N_old > 0:
+                    h_cat[:N_old].copy_(h_in.detach())
+        need_grad = call['need_grad']
+        spare_out = call['spare']
+        buf = torch.empty(((N + spare_out) * GH,), **opts)
+        h_out = torch.empty(0, **opts).set_(buf.untyped_storage(), 0, (N, GH), (GH, 1))
+        ls = torch.empty((2, max(N, 1)), **opts)
+        save = None
+        nsave = 0
+        if need_grad or n > 0:
+            nsave = int(lib.tmpnn_mp_iter_save_floats(N, n, G, H))
+            save = torch.empty((nsave,), **opts)
+        _lib.call('tmpnn_mp_iter_fwd', C.byref(cp), sp.prep.data_ptr(), dg.cref(), n, xd.data_ptr() if n > 0 else None,
+                  int(xd.shape[1]) if n > 0 else 0, h_cat.data_ptr(), int(training), h_out.data_ptr(), ls[0].data_ptr(),
+                  ls[1].data_ptr(), _lib.ptr(save), nsave, _stream())
+        if training and n > 0:
+            for g in range(G):
+                call['buffers'][f'input_transforms.{g}.1.num_batches_tracked'] += 1
+        ctx.call = call
+        ctx.saved = (xd, h_cat, h_out, ls, save, cp) if need_grad else None
+        ctx.has_h = h_in is not None
+        ctx.n = n
+        ctx.set_materialize_grads(False)
+        logits = ls[0, :N].unsqueeze(1)
+        scores = ls[1, :N].unsqueeze(1)
+        return scores, logits, h_out
+
+    @staticmethod
+    def backward(ctx, d_scores, d_logits, d_hout):
+        call = ctx.call
+        sp: SmallPath = call['small']
+        spec = sp.spec
+        dg: DeviceGraph = call['graph']
+        call['check_pending']()                      # deferred graph validation (one host read for the whole chunk)
+        lib = _lib.load()
+        xd, h_cat, h_out, ls, save, cp = ctx.saved
+        ctx.saved = None
+        H, G = spec.H, spec.G
+        GH = G * H
+        N, n = dg.N, ctx.n
+        dev = h_cat.device
+        opts = dict(dtype=torch.float32, device=dev)
+        need = ctx.needs_input_grad
+        names = sp.names
+        objs = call['param_objs']
+
+        def f32c(t):
+            return t if (t.dtype == torch.float32 and t.is_contiguous()) else t.float().contiguous()
+
+        ds = f32c(d_scores.reshape(-1)) if d_scores is not None else None
+        dl = f32c(d_logits.reshape(-1)) if d_logits is not None else None
+        dh = f32c(d_hout) if d_hout is not None else None
+        inplace = (call['inplace'] and all(need[3:])
+                   and all(p.grad is not None and p.grad.dtype == torch.float32 and p.grad.is_contiguous()
+                           and p.grad.device == dev for p in objs))
+        if inplace:
+            gts = [p.grad for p in objs]
+            flat = None
+        else:
+            flat = torch.zeros((sp.grad_total,), **opts)
+            gts = [flat[o:o + sz] for o, sz in zip(sp.grad_offs, sp.grad_sizes)]
+        gst = sp.grad_struct(gts)
+        d_h = torch.empty((N, GH), **opts)
+        need_x = need[1] and n > 0
+        d_x = torch.empty((n, spec.F_total), **opts) if need_x else None
+        wsb = int(lib.tmpnn_mp_iter_bwd_ws(N, n, G, H, spec.IN_e))
+        ws = torch.empty((wsb // 4 + 4,), **opts)
+        _lib.call('tmpnn_mp_iter_bwd', C.byref(cp), sp.prep.data_ptr(), dg.cref(), n, xd.data_ptr() if n > 0 else None,
+                  int(xd.shape[1]) if n > 0 else 0, h_cat.data_ptr(), h_out.data_ptr(), ls[1].data_ptr(), save.data_ptr(),
+                  int(call['training']), _lib.ptr(ds), _lib.ptr(dl), _lib.ptr(dh), d_h.data_ptr(), _lib.ptr(d_x),
+                  C.byref(gst), ws.data_ptr(), wsb, _stream())
+        if need[1] and d_x is None:
+            d_x = torch.zeros((n, spec.F_total), **opts)
+        d_h_in = d_h[:N - n] if (ctx.has_h and need[2] and N - n > 0) else None
+        if inplace:
+            return (None, d_x, d_h_in) + (None,) * len(names)
+        named = dict(zip(names, objs))
+        return (None, d_x, d_h_in) + tuple(g.view(named[nm].shape) for nm, g in zip(names, gts))
+
+
+def small_eligible(model, N: int) -> bool:
+    sp = model._small
+    return sp.eligible and 0 < N <= DG_MAX_ROWS

@@ -14,9 +14,17 @@ from typing import Dict, List, Optional, Sequence
 import torch
 import torch.nn as nn
 
+import os
+
+from . import functional as _functional
 from .functional import MPIteration, ModelSpec
-from .graph import CallPlan, FrameGraph, graph_from_adjacency, plan_single
+from .graph import (CallPlan, DeviceGraph, FrameGraph, device_graph_from_adjacency, graph_from_adjacency,
+                    plan_single)
 from .layers import FactorGraphGRU
+from .small import SmallPath, _SmallIter, small_eligible
+
+STRICT_GRAPH = os.environ.get('TMPNN_STRICT_GRAPH', '0') == '1'     # validate every adjacency at once (host sync)
+SMALL_PATH = os.environ.get('TMPNN_SMALL_PATH', '1') != '0'         # fused batch-1 iteration for eligible calls
 
 
 class SparseAttention:
@@ -84,6 +92,10 @@ class TrackMPNN(nn.Module):
         self._graph_cache = None
         # set by trackmpnn_amd.dist.GradBucket: parameter gradients are added straight into p.grad (functional.py)
         self.inplace_param_grads = False
+        self._small = SmallPath(self)          # batch-1 path state (pointer structs, operand images)
+        self._plist = None
+        self._bufs = None
+        self._pending_graphs = []              # DeviceGraphs whose validation status has not been read back yet
 
     def get_input_transform(self, n_in, n_out):
         lin1 = nn.Linear(n_in, n_out, bias=True)
@@ -127,16 +139,78 @@ class TrackMPNN(nn.Module):
                           for a in call['alphas'])
         return scores, logits, h_out, attention
 
-    def forward(self, x, h_in, node_adj, edge_adj):
-        """reference/models/track_mpnn.py:54-75.  node_adj / edge_adj: dense or sparse-COO [N, N]."""
+    # ------------------------------------------------------------------------------------------
+    # batch-1 path (csrc/small.hip): one ctypes call per forward / backward, no host synchronisation
+    # ------------------------------------------------------------------------------------------
+    def check_graphs(self) -> None:
+        """Read back the validation status of every adjacency converted since the last check (ONE host round trip)
+        and raise ValueError for the first invalid one.  Called automatically before a backward and every 64 calls."""
+        pending, self._pending_graphs = self._pending_graphs, []
+        if not pending:
+            return
+        metas = torch.stack([g.arena[:8] for g in pending]).tolist()
+        for g, m in zip(pending, metas):
+            g._meta = (m[4], m[5], m[2])
+        for g in pending:
+            g.check()
+
+    def forward_dgraph(self, x: torch.Tensor, h_in: Optional[torch.Tensor], graph: DeviceGraph):
+        """One message-passing call on a DeviceGraph through the fused iteration (K = 0, H in {32, 64})."""
         if not x.is_cuda:
             raise RuntimeError(f'x is on {x.device}: trackmpnn_amd runs on the MI355X HIP kernels only '
                                '(no CPU or torch fallback exists)')
-        key = (id(node_adj), id(edge_adj), int(node_adj.shape[0]))
+        if self._plist is None:
+            named = dict(self.named_parameters())
+            self._plist = [named[nm] for nm in self.spec.param_names()]
+            self._bufs = dict(self.named_buffers())
+        params = self._plist
+        need_grad = torch.is_grad_enabled() and (
+            x.requires_grad or (h_in is not None and h_in.requires_grad) or any(p.requires_grad for p in params))
+        spare = max(256, graph.N)
+        # the carried state is extended IN PLACE when it came out of this path (it has spare rows behind it) and has
+        # not been continued from before; a second continuation from the same tensor copies instead
+        n = int(x.shape[0])
+        append = (h_in is not None and n > 0 and getattr(h_in, '_tmpnn_spare_rows', 0) >= n
+                  and not getattr(h_in, '_tmpnn_consumed', False))
+        if append:
+            h_in._tmpnn_consumed = True
+        call = dict(small=self._small, graph=graph, training=self.training, need_grad=need_grad, spare=spare, append=append,
+                    buffers=self._bufs, param_objs=params,
+                    inplace=self.inplace_param_grads or _functional.INPLACE_GRADS, check_pending=self.check_graphs)
+        scores, logits, h_out = _SmallIter.apply(call, x, h_in, *params)
+        h_out._tmpnn_spare_rows = spare
+        return scores, logits, h_out, (None,) * self.spec.G
+
+    def forward(self, x, h_in, node_adj, edge_adj):
+        """reference/models/track_mpnn.py:54-75.  node_adj / edge_adj: dense or sparse-COO [N, N].
+
+        Contract on x (as produced by utils/graph.py:148-149,291-292): rows of new EDGE nodes are all-zero; only the
+        new det rows are read (a non-zero edge row would enter the reference's BatchNorm statistics; here it is
+        ignored).  Graphs of up to 4096 rows without attention heads take the fused batch-1 path: the adjacency is
+        converted on the device in one launch and validated LATE (check_graphs(); TMPNN_STRICT_GRAPH=1 validates
+        at once), everything else is converted with torch index ops and validated immediately."""
+        if not x.is_cuda:
+            raise RuntimeError(f'x is on {x.device}: trackmpnn_amd runs on the MI355X HIP kernels only '
+                               '(no CPU or torch fallback exists)')
+        N = int(node_adj.shape[0])
+        small = SMALL_PATH and small_eligible(self, N)
+        key = (id(node_adj), id(edge_adj), N, getattr(node_adj, '_version', 0), getattr(edge_adj, '_version', 0),
+               str(x.device), small)
         if self._graph_cache is not None and self._graph_cache[0] == key:
             graph = self._graph_cache[1]
         else:
-            graph = graph_from_adjacency(node_adj.to(x.device), edge_adj.to(x.device))
+            if small:
+                graph = device_graph_from_adjacency(node_adj, edge_adj, x.device)
+                if STRICT_GRAPH:
+                    graph.check()
+                else:
+                    self._pending_graphs.append(graph)
+                    if len(self._pending_graphs) >= 64:
+                        self.check_graphs()
+            else:
+                graph = graph_from_adjacency(node_adj.to(x.device), edge_adj.to(x.device))
             self._graph_cache = (key, graph, node_adj, edge_adj)   # keep the tensors alive: id() stays unique
+        if small:
+            return self.forward_dgraph(x, h_in, graph)
         plan = plan_single(graph, int(x.shape[0]))
         return self.forward_graph(x, h_in, plan)
