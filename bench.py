@@ -271,6 +271,94 @@ def cpu_baseline(frames, mean_dets, max_dets, F, H, seed, budget_s=15.0):
                        f'on a {ncpu}-core host')
 
 
+def latency_batch1():
+    """The reference's REAL call pattern (batch size 1, train.py:92-107): one window through the drop-in call
+    `model(x, h_in, node_adj, edge_adj)` with the reference's own adjacency tensors (fixtures generated by the real
+    reference): C1 of BASELINE.json (static 5 x 20 window, 2 MP iterations) and one C2 window (7 frames: 6 rolling calls
+    + 1 extra iteration).  A step = every forward call + loss + backward (no optimizer), (a) issued eagerly, adjacency ->
+    index conversion included, (b) replayed from a hipGraph captured once for the window (CapturedWindow; conversion
+    done at capture time), next to the CPU oracle on the same window on this host (1 thread: more threads are slower at
+    this size)."""
+    from oracle import trackmpnn_oracle as orc
+    from tests.golden_util import Golden
+    from trackmpnn_amd import CapturedWindow, TrackMPNN
+    from trackmpnn_amd.dist import GradBucket
+    dev = torch.device('cuda', torch.cuda.current_device())
+    out = {}
+    for tag, name in (('c1', 'c1_static_diff_k0_train'), ('c2_window', 'roll_c2_kitti_car_w5')):
+        gold = Golden(name)
+        m = gold.meta
+        model = TrackMPNN(m['features'], m['ncategories'], m['nhidden'], m['nattheads'], m['msg_type'])
+        model.load_state_dict(gold.params(), strict=True)
+        model = model.to(dev).train()
+        bucket = GradBucket(model)
+        calls, ograph, ox = [], [], []
+        for c in range(gold.ncalls):
+            na, ea = gold.adjacency(c, 'node_adj'), gold.adjacency(c, 'edge_adj')
+            ograph.append(orc.graph_from_adjacency(na, ea))
+            ox.append(gold.t(f'c{c}/x'))
+            na, ea = na.to(dev), ea.to(dev)
+            if not na.is_sparse:                   # initialize_graph(cuda=True) hands over sparse tensors
+                na, ea = na.to_sparse(), ea.to_sparse()
+            calls.append((ox[-1].to(dev), na, ea))
+        E = sum(g.E for g in ograph)
+        loss_fn = lambda outs, h: torch.cat([l for _, l in outs]).sum()      # noqa: E731
+
+        def step():
+            h, outs = None, []
+            for x, na, ea in calls:
+                s, l, h, _ = model(x, h, na, ea)
+                outs.append((s, l))
+            bucket.zero()
+            loss_fn(outs, h).backward()
+
+        def timed(fn, n):
+            for _ in range(10):
+                fn()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(n):
+                fn()
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t0) / n * 1e3
+
+        eager = timed(step, 200)
+        win = CapturedWindow(model, calls, loss_fn, optimizer=None, bucket=bucket)
+        captured = timed(win.replay, 200)
+        # CPU oracle, same window, same loss
+        cfg = orc.OracleConfig(m['features'], m['ncategories'], m['nhidden'], m['nattheads'], m['msg_type'])
+        p = gold.params()
+        for k, v in p.items():
+            if v.dtype.is_floating_point and not k.endswith(orc.BUFFER_SUFFIXES):
+                v.requires_grad_(True)
+
+        def cpu_step():
+            h, loss = None, 0.0
+            for g, x in zip(ograph, ox):
+                s, l, h, _ = orc.forward(p, cfg, x, h, g, training=True)
+                loss = loss + l.sum()
+            for v in p.values():
+                v.grad = None
+            loss.backward()
+
+        torch.set_num_threads(1)
+        cpu_step()
+        t0 = time.perf_counter()
+        reps = 0
+        while time.perf_counter() - t0 < 2.0:
+            cpu_step()
+            reps += 1
+        cpu_ms = (time.perf_counter() - t0) / reps * 1e3
+        out[tag] = dict(fixture=name, calls=gold.ncalls, rows=int(calls[-1][1].shape[0]), edge_iterations=E,
+                        eager_ms=round(eager, 4), captured_ms=round(captured, 4), cpu_oracle_ms=round(cpu_ms, 3),
+                        eager_edges_per_s=E / eager * 1e3, captured_edges_per_s=E / captured * 1e3,
+                        speedup_vs_cpu_oracle_eager=round(cpu_ms / eager, 2),
+                        speedup_vs_cpu_oracle_captured=round(cpu_ms / captured, 2))
+    out['note'] = ('fwd + loss + bwd of ONE window, fp32; eager = model(x, h, node_adj, edge_adj) per call incl. the '
+                   'adjacency conversion; captured = the same step replayed from one hipGraph; cpu oracle: 1 thread')
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -279,6 +367,7 @@ def main():
     ap.add_argument('--windows', type=int, default=16384, help='tracking windows per GPU per step')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-stage-profile', action='store_true')
+    ap.add_argument('--no-latency', action='store_true', help='skip the batch-1 latency block')
     ap.add_argument('--backend', default='nccl', help='torch.distributed backend (nccl = RCCL; gloo only to rehearse '
                     'the N > 1 code path with several ranks sharing one GPU)')
     ap.add_argument('--single-device', action='store_true', help='rehearsal: every rank uses cuda:0')
@@ -383,6 +472,10 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(frames, mean_dets, max_dets, F, H, seed=1)
 
+    lat = None
+    if rank == 0 and world == 1 and not args.no_latency:
+        lat = latency_batch1()
+
     if rank == 0:
         out = dict(metric='graph_edges_per_sec_fwd_bwd', value=value, unit='graph-edges/s', n_gpus=world,
                    steps=args.steps, warmup=args.warmup, ms_per_step=dt / args.steps * 1e3, higher_is_better=True,
@@ -396,6 +489,7 @@ def main():
                                rows_final=plans[-1].graph.N, parallelism=f'sequence-dp{world}'),
                    roofline=roofline, cpu_baseline=cpu)
         out.update(extra)
+        out['latency_batch1'] = lat
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -293,7 +293,7 @@ int tmpnn_focal_loss_bwd(const int32_t* rows, int R, const float* scores, const 
  *   (1) the graph's SIZES stay on the device (tmpnn_dgraph): the adjacency -> index conversion is one kernel and the
  *       host never waits for E / Dn, so nothing synchronises between calls;
  *   (2) the whole message-passing iteration is two launches forward (input transform; edge + node cells with the
- *       aggregation, the merge and the output heads fused) and three backward: tmpnn_mp_iter_fwd / _bwd.
+ *       aggregation, the merge and the output heads fused) and two backward: tmpnn_mp_iter_fwd / _bwd.
  * Limits: N <= TMPNN_DG_MAX_ROWS rows, H in {32, 64}, no attention heads (the staged entry points above cover the
  * rest).  Arithmetic: fp32 throughout (v_mfma_f32_16x16x4_f32 = an fmaf chain), reductions in a fixed order.
  * ====================================================================================================== */
@@ -346,6 +346,7 @@ typedef struct tmpnn_mp_params {
     int32_t F[3];                 /* input width of each group's transform */
     float* w1[3]; float* b1[3]; float* gamma[3]; float* beta[3]; float* w2[3]; float* b2[3];   /* input_transforms.g.{0,1,3} */
     float* run_mean[3]; float* run_var[3];                                                      /* BatchNorm buffers (NULL in a gradient struct) */
+    int64_t* num_batches_tracked[3];                                                            /* BatchNorm counters, +1 per training call with new rows (may be NULL) */
     float* e_wih[3]; float* e_whh[3]; float* e_bih[3]; float* e_bhh[3];                         /* factor_grus.g.edge_gru */
     float* n_wih[3]; float* n_whh[3]; float* n_bih[3]; float* n_bhh[3];                         /* factor_grus.g.node_gru */
     float* w_node; float* b_node; float* w_edge; float* b_edge;                                 /* output_transform_{node,edge} */
@@ -367,7 +368,8 @@ int tmpnn_mp_iter_fwd(const tmpnn_mp_params* P, const float* prep, const tmpnn_d
                       const float* x, int ld_x, float* h, int training,
                       float* h_out, float* logits, float* scores, float* save, size_t save_floats,
                       tmpnn_stream stream);
-/* Backward of tmpnn_mp_iter_fwd.  d_scores / d_logits [N] and d_hout [N][G*H] may each be NULL.  Writes d_h
+/* Backward of tmpnn_mp_iter_fwd.  d_scores / d_logits (N values each, element stride st_* >= 0; 0 = one broadcast
+ * value, the gradient of a plain sum) and d_hout [N][G*H] may each be NULL.  Writes d_h
  * [N][G*H] (gradient of the h the iteration read: its first N - n_new rows are the gradient of the carried state)
  * and d_x [n_new][F_total] (may be NULL); ACCUMULATES (+=) every parameter gradient into `grads`.
  * ws: tmpnn_mp_iter_bwd_ws bytes. */
@@ -375,8 +377,8 @@ size_t tmpnn_mp_iter_bwd_ws(int N, int n_new, int G, int H, int IN_e);
 int tmpnn_mp_iter_bwd(const tmpnn_mp_params* P, const float* prep, const tmpnn_dgraph* g, int n_new,
                       const float* x, int ld_x, const float* h, const float* h_out, const float* scores,
                       const float* save, int training,
-                      const float* d_scores, const float* d_logits, const float* d_hout,
-                      float* d_h, float* d_x, const tmpnn_mp_params* grads,
+                      const float* d_scores, int st_dscores, const float* d_logits, int st_dlogits,
+                      const float* d_hout, float* d_h, float* d_x, const tmpnn_mp_params* grads,
                       void* ws, size_t ws_bytes, tmpnn_stream stream);
 
 #ifdef __cplusplus

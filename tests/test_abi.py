@@ -60,3 +60,35 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     monkeypatch.setattr(_lib, 'LIB_PATH', str(tmp_path / 'nope.so'))
     with pytest.raises(RuntimeError, match='no CPU or torch fallback'):
         _lib.load()
+
+
+def test_device_graph_arena_layout_matches_the_library():
+    """trackmpnn_amd.graph.DeviceGraph restates tmpnn_dgraph_bind's pointer arithmetic in Python (one ctypes call
+    less per forward); it must agree with the library for every capacity."""
+    import ctypes as C
+    from trackmpnn_amd import _lib
+    lib = _lib.load()
+    for cap in (0, 1, 3, 4, 5, 17, 375, 1700, 4095, 4096):
+        ints = lib.tmpnn_dgraph_ints(cap)
+        c = (cap + 1 + 3) & ~3
+        nb = (((cap + 3) // 4) + 3) & ~3
+        assert ints == 8 + nb + 10 * c
+        st = _lib.CDGraph()
+        base = 1 << 20
+        assert lib.tmpnn_dgraph_bind(base, cap, cap, C.byref(st)) == 0
+        o = base + 32 + 4 * nb
+        assert (st.meta, st.is_edge, st.pos, st.src, st.dst, st.src_pos, st.dst_pos, st.edge_row, st.det_row, st.rowptr,
+                st.inc) == (base, base + 32, o, o + 4 * c, o + 8 * c, o + 12 * c, o + 16 * c, o + 20 * c, o + 24 * c,
+                            o + 28 * c, o + 32 * c)
+
+
+def test_fused_iteration_buffer_sizes_match_the_library():
+    """trackmpnn_amd.small restates the save / workspace size formulas of tmpnn_mp_iter_*; they must agree."""
+    from trackmpnn_amd import _lib
+    from trackmpnn_amd.small import bwd_ws_bytes, save_floats
+    lib = _lib.load()
+    for N, n in ((1, 0), (1, 1), (17, 5), (375, 60), (1700, 1700), (4096, 0), (4096, 4096)):
+        for G in (1, 3):
+            for H, IN_e in ((32, 32), (32, 64), (64, 64), (64, 128)):
+                assert save_floats(N, n, G, H) == lib.tmpnn_mp_iter_save_floats(N, n, G, H)
+                assert bwd_ws_bytes(N, n, G, H, IN_e) == lib.tmpnn_mp_iter_bwd_ws(N, n, G, H, IN_e)

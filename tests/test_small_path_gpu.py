@@ -138,7 +138,7 @@ def test_fused_iteration_matches_staged_kernels(name, monkeypatch):
         assert (g0[k] - g1[k]).abs().max().item() <= tol, f'grad {k}: {(g0[k] - g1[k]).abs().max().item()} > {tol}'
     for c, (a, b) in enumerate(zip(x0, x1)):
         if a.numel():
-            assert torch.allclose(a, b, atol=2e-5 * max(1.0, a.abs().max().item()), rtol=0), f'd_x call {c}'
+            assert torch.allclose(a, b, atol=1e-4 * max(1.0, a.abs().max().item()), rtol=0), f'd_x call {c}'
     for k in b0:
         if b0[k].dtype.is_floating_point:
             assert torch.allclose(b0[k], b1[k], atol=1e-6, rtol=1e-5), k
@@ -215,3 +215,55 @@ def test_fused_iteration_continuation_from_the_same_state_twice():
     (2 * l1.sum()).backward()
     for a, p in zip(g, model.parameters()):
         assert torch.allclose(a, p.grad, rtol=1e-5, atol=1e-6 * max(1.0, float(a.abs().max())))
+
+
+def test_captured_window_replay_equals_eager_steps():
+    """CapturedWindow (whole-window hipGraph: forward calls + loss + backward + Adam) replayed three times gives the
+    parameters of three eager steps bit for bit, and replays pick up refreshed features."""
+    from tests.test_parity_gpu import build_model
+    from trackmpnn_amd import CapturedWindow
+    from trackmpnn_amd.dist import GradBucket
+    gold = Golden('roll_c2_kitti_car_w5')
+    calls = []
+    for c in range(gold.ncalls):
+        na, ea = gold.adjacency(c, 'node_adj', DEV), gold.adjacency(c, 'edge_adj', DEV)
+        if not na.is_sparse:
+            na, ea = na.to_sparse(), ea.to_sparse()
+        calls.append((gold.t(f'c{c}/x').to(DEV), na, ea))
+    loss_fn = lambda outs, h: torch.cat([l for _, l in outs]).square().mean() + h.square().mean()      # noqa: E731
+    xs2 = [x * 0.5 for x, _, _ in calls]
+
+    def eager():
+        model = build_model(gold.meta, gold.params())
+        bucket = GradBucket(model)
+        opt = torch.optim.Adam(model.parameters(), lr=1e-3, capturable=True)
+        losses = []
+        for it in range(3):
+            h, outs = None, []
+            for i, (x, na, ea) in enumerate(calls):
+                s, l, h, _ = model(xs2[i] if it == 2 else x, h, na, ea)
+                outs.append((s, l))
+            loss = loss_fn(outs, h)
+            bucket.zero()
+            loss.backward()
+            opt.step()
+            losses.append(loss.item())
+        return model, losses
+
+    m_ref, l_ref = eager()
+    model = build_model(gold.meta, gold.params())
+    bucket = GradBucket(model)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3, capturable=True)
+    sd0 = {k: v.clone() for k, v in model.state_dict().items()}
+    st0 = None
+    win = CapturedWindow(model, calls, loss_fn, optimizer=opt, bucket=bucket, warmup=2)
+    # the warm-up and the capture itself stepped the optimizer: rewind model and optimizer, then replay 3 steps
+    model.load_state_dict(sd0)
+    for st in opt.state.values():
+        for k, v in st.items():
+            if torch.is_tensor(v):
+                v.zero_()
+    losses = [win.replay().item(), win.replay().item(), win.replay(xs2).item()]
+    assert losses == l_ref
+    for (k, a), (_, b) in zip(model.state_dict().items(), m_ref.state_dict().items()):
+        assert torch.equal(a, b), k

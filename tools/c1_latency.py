@@ -29,7 +29,7 @@ def measure(name, n=200):
             s, l, h, _ = model(x, h, na, ea)
             outs.append(l)
         loss = torch.cat(outs).sum()
-        opt.zero_grad(set_to_none=False)
+        bucket.zero()
         loss.backward()
         if with_opt:
             opt.step()
@@ -45,14 +45,37 @@ def measure(name, n=200):
     t0 = time.perf_counter()
     for _ in range(n):
         step(False)
+    enq = (time.perf_counter() - t0) / n * 1e3          # host time to ENQUEUE a step (no sync inside the loop)
     torch.cuda.synchronize()
     ms2 = (time.perf_counter() - t0) / n * 1e3
     # the same with the graphs cached (conversion excluded): re-use each call's adjacency objects
+    # the same step captured once into a hipGraph and replayed (CapturedWindow): forward calls + loss + backward + Adam
+    from trackmpnn_amd import CapturedWindow
+    opt2 = torch.optim.Adam(model.parameters(), lr=1e-5, capturable=True)
+    win = CapturedWindow(model, calls, lambda outs, h: torch.cat([l for _, l in outs]).sum(), optimizer=opt2, bucket=bucket)
+    for _ in range(5):
+        win.replay()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        win.replay()
+    torch.cuda.synchronize()
+    ms3 = (time.perf_counter() - t0) / n * 1e3
+    print(f'{name}: captured window replay (fwd + loss + bwd + Adam in one hipGraph launch): {ms3:.3f} ms per step '
+          f'= {E / ms3 * 1e3:.3g} graph-edges/s')
     print(f'{name}: {gold.ncalls} calls, N={calls[-1][1].shape[0]} rows, {E} edge-iterations: {ms:.3f} ms per fwd+bwd+Adam step, '
-          f'{ms2:.3f} ms without the optimizer = {E / ms2 * 1e3:.3g} graph-edges/s through model(x, h, node_adj, edge_adj)')
-    return ms, ms2
+          f'{ms2:.3f} ms without the optimizer (host enqueue {enq:.3f} ms) = {E / ms2 * 1e3:.3g} graph-edges/s through model(x, h, node_adj, edge_adj)')
+    return ms, ms2, ms3
 
 
 if __name__ == '__main__':
-    measure('c1_static_diff_k0_train')
-    measure('roll_c2_kitti_car_w5')
+    if '--profile' in sys.argv:
+        import cProfile, pstats
+        pr = cProfile.Profile()
+        pr.enable()
+        measure('roll_c2_kitti_car_w5', n=100)
+        pr.disable()
+        pstats.Stats(pr).sort_stats('tottime').print_stats(35)
+    else:
+        measure('c1_static_diff_k0_train')
+        measure('roll_c2_kitti_car_w5')

@@ -46,7 +46,7 @@ class CMpParams(C.Structure):
     """struct tmpnn_mp_params (include/tmpnn.h): every parameter (or its gradient buffer) as a device pointer."""
     _fields_ = [('G', C.c_int32), ('H', C.c_int32), ('IN_e', C.c_int32), ('F_total', C.c_int32), ('F', C.c_int32 * 3),
                 ('w1', _P3), ('b1', _P3), ('gamma', _P3), ('beta', _P3), ('w2', _P3), ('b2', _P3),
-                ('run_mean', _P3), ('run_var', _P3),
+                ('run_mean', _P3), ('run_var', _P3), ('num_batches_tracked', _P3),
                 ('e_wih', _P3), ('e_whh', _P3), ('e_bih', _P3), ('e_bhh', _P3),
                 ('n_wih', _P3), ('n_whh', _P3), ('n_bih', _P3), ('n_bhh', _P3),
                 ('w_node', c_void_p), ('b_node', c_void_p), ('w_edge', c_void_p), ('b_edge', c_void_p)]
@@ -132,8 +132,8 @@ _SIGNATURES = {
                                   c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     'tmpnn_mp_iter_bwd_ws': (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
     'tmpnn_mp_iter_bwd': (c_int, [_MPP, c_void_p, _DGP, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
-                                  c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, _MPP, c_void_p, c_size_t,
-                                  c_void_p]),
+                                  c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, _MPP, c_void_p,
+                                  c_size_t, c_void_p]),
 }
 
 _lib: Optional[C.CDLL] = None
@@ -181,6 +181,11 @@ def call(name: str, *args) -> None:
     rc = getattr(lib, name)(*args)
     if rc != 0:
         raise RuntimeError(f'{name} failed (code {rc}): {last_error()}')
+
+
+def fn(name: str):
+    """The bound ctypes function (for hot paths that call it many times; the caller checks the return code)."""
+    return getattr(load(), name)
 
 
 def ptr(t) -> Optional[int]:

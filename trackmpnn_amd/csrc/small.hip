@@ -4,7 +4,7 @@
 // utils/graph.py:117): a few hundred to a few thousand rows, H = 64.  At that size the staged entry points are
 // launch-bound (a dozen launches per group forward, two dozen backward) and their LDS-resident persistent kernels
 // pay a 100+ KB weight load per block for a handful of rows.  Here a forward call is TWO launches and a backward
-// THREE, each sized to the graph:
+// TWO, each sized to the graph:
 //
 //   k_small_bn_fwd      rows C, D     input transform of the new det rows (Lin-BN-ReLU-Lin, batch statistics over ALL
 //                                     new rows with the analytic zero-row terms), zeros on new edge rows
@@ -16,8 +16,8 @@
 //   k_small_iter_bwd    row K         per tile: gate gradients, d_x = d_gi W_ih, d_h = dh z + d_gh W_hh, and the
 //                                     weight / bias / head gradients accumulated in REGISTERS over a persistent
 //                                     block's tiles (one slab per block)
-//   k_small_bwd_finish  row K         adjoints of rows E and F (CSR segment sums / gathers of d_x) + slab reduction
-//   k_small_bn_bwd      row K         input-transform backward
+//   k_small_bwd_finish  row K         adjoints of rows E and F (CSR segment sums / gathers of d_x), slab reduction and --
+//                                     in G further blocks of the same launch -- the input-transform backward
 //
 // Sizes (E, Dn) are read from the graph's device-side meta (tmpnn_dgraph): grids are sized from N alone and
 // surplus blocks exit, so the host never synchronises.  fp32 throughout; every reduction has a fixed order.
@@ -188,6 +188,7 @@ __global__ __launch_bounds__(256) void k_small_bn_fwd(BnFwdArgs a) {
             float* rv = a.P.run_var[gi];
             rm[tid] = (1.0f - BN_MOM_S) * rm[tid] + BN_MOM_S * m;
             rv[tid] = (1.0f - BN_MOM_S) * rv[tid] + BN_MOM_S * (var * (cnt / (cnt - 1.0f)));
+            if (tid == 0 && a.P.num_batches_tracked[gi]) a.P.num_batches_tracked[gi][0] += 1;
         }
     } else if (tid < H) {
         s_mean[tid] = a.P.run_mean[gi][tid];
@@ -414,6 +415,7 @@ struct IterBwdArgs {
     const float* scores;
     const float* gates; const float* es;
     const float* d_scores; const float* d_logits; const float* d_hout;
+    int st_ds, st_dl;          // element strides of d_scores / d_logits (0 = one broadcast value, e.g. the gradient of a sum)
     float* d_h;                // [N][G*H] written (dh z + d_gh W_hh)
     float* d_msg;              // [N][G*IN_e] written: d_x of every row (edge rows: IN_e columns, det rows: H)
     float* slabs;              // [gridDim.x][G][slab_floats]
@@ -483,8 +485,8 @@ __global__ __launch_bounds__(256) void k_small_iter_bwd(IterBwdArgs a) {
                 sD[tid] = is_e ? a.g.dst[qc] : 0;
                 float dy = 0.f;
                 if (ok) {
-                    if (a.d_logits) dy += a.d_logits[grow];
-                    if (a.d_scores) { const float s = a.scores[grow]; dy += a.d_scores[grow] * s * (1.0f - s); }
+                    if (a.d_logits) dy += a.d_logits[(size_t)grow * a.st_dl];
+                    if (a.d_scores) { const float s = a.scores[grow]; dy += a.d_scores[(size_t)grow * a.st_ds] * s * (1.0f - s); }
                 }
                 sDy[tid] = dy;
             }
@@ -610,6 +612,7 @@ __global__ __launch_bounds__(256) void k_small_iter_bwd(IterBwdArgs a) {
                 }
             }
         }
+        if (my0 >= ntiles) continue;                       // no tile, no slab (the reducer skips this block too)
         // ---- this block's slab for group gi
         float* sl = a.slabs + ((size_t)blockIdx.x * G + gi) * SLF;
         float* sl_hh = sl + (size_t)3 * H * IN;
@@ -661,120 +664,65 @@ __global__ __launch_bounds__(256) void k_small_iter_bwd(IterBwdArgs a) {
 // backward, second launch: adjoints of the two aggregations + slab reduction into the gradient buffers
 // ------------------------------------------------------------------------------------------------------------
 struct FinishArgs {
-    tmpnn_mp_params P;         // only G, H, IN_e are read
+    tmpnn_mp_params P;
     tmpnn_mp_params grads;
     tmpnn_dgraph g;
     const float* d_msg;
     float* d_h;
     const float* slabs;
     int nb_bwd;                // grid of k_small_iter_bwd
-    int row_blocks;            // blocks [0, row_blocks) do the row work, the rest reduce slabs
-};
-
-template <int H, int IN_E>
-__global__ __launch_bounds__(256) void k_small_bwd_finish(FinishArgs a) {
-    const int E = a.g.meta[0], Dn = a.g.meta[1];
-    const int G = a.P.G, GH = G * H, N = a.g.N;
-    const int tid = threadIdx.x;
-    constexpr int LPR = H / 4, RPB = 256 / LPR;
-    if ((int)blockIdx.x < a.row_blocks) {
-        if (E + Dn == 0) return;
-        const int c4 = tid % LPR, slot = tid / LPR;
-        for (int r = blockIdx.x * RPB + slot; r < N; r += a.row_blocks * RPB) {
-            const bool edge = a.g.is_edge[r] != 0;
-            const int p = a.g.pos[r];
-            for (int gi = 0; gi < G; ++gi) {
-                const float* dm = a.d_msg + gi * IN_E + 4 * c4;
-                const size_t ldm = (size_t)G * IN_E;
-                float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (edge) {
-                    // adjoint of row F: d h[e] += d_es[src(e)] - d_es[dst(e)]   (d_es = the node cell's d_x, at det rows)
-                    const float4 u = *reinterpret_cast<const float4*>(dm + (size_t)a.g.src[p] * ldm);
-                    const float4 v = *reinterpret_cast<const float4*>(dm + (size_t)a.g.dst[p] * ldm);
-                    acc = make_float4(u.x - v.x, u.y - v.y, u.z - v.z, u.w - v.w);
-                } else {
-                    // adjoint of row E: d h[d] += sum_{e: src=d} d_x[e][0:H] -/+ sum_{e: dst=d} d_x[e][0:H | H:2H]
-                    const int p0 = a.g.rowptr[p], p1 = a.g.rowptr[p + 1];
-                    for (int q = p0; q < p1; ++q) {
-                        const int key = a.g.inc[q];
-                        const bool neg = key < 0;
-                        const float4 v = *reinterpret_cast<const float4*>(dm + (size_t)(key & 0x7fffffff) * ldm +
-                                                                         ((neg && IN_E == 2 * H) ? H : 0));
-                        const float w = (neg && IN_E == H) ? -1.0f : 1.0f;
-                        acc.x += w * v.x; acc.y += w * v.y; acc.z += w * v.z; acc.w += w * v.w;
-                    }
-                }
-                float4* o = reinterpret_cast<float4*>(a.d_h + (size_t)r * GH + gi * H + 4 * c4);
-                float4 t = *o;
-                t.x += acc.x; t.y += acc.y; t.z += acc.z; t.w += acc.w;
-                *o = t;
-            }
-        }
-        return;
-    }
-    // ---- slab reduction (fixed order over the blocks of each cell)
-    const int nEt = (E + TR - 1) / TR, nDt = (Dn + TR - 1) / TR;
-    const int nbE = bwd_edge_blocks(nEt, nDt, a.nb_bwd);
-    const size_t SLF = slab_floats(H, IN_E);
-    const size_t n_e = (size_t)3 * H * (IN_E + H) + 7 * H + 1, n_n = (size_t)3 * H * (2 * H) + 7 * H + 1;
-    const size_t per_g = n_e + n_n;
-    const size_t total = per_g * G;
-    const int rb = gridDim.x - a.row_blocks;
-    for (size_t idx = (size_t)(blockIdx.x - a.row_blocks) * 256 + tid; idx < total; idx += (size_t)rb * 256) {
-        const int gi = (int)(idx / per_g);
-        size_t q = idx % per_g;
-        const bool edge = q < n_e;
-        if (!edge) q -= n_e;
-        const int IN = edge ? IN_E : H;
-        const int b0 = edge ? 0 : nbE, b1 = edge ? nbE : a.nb_bwd;
-        float s = 0.f;
-        for (int b = b0; b < b1; ++b) s += a.slabs[((size_t)b * G + gi) * SLF + q];
-        const size_t nih = (size_t)3 * H * IN, nhh = (size_t)3 * H * H;
-        float* dst;
-        if (q < nih) dst = (edge ? a.grads.e_wih[gi] : a.grads.n_wih[gi]) + q;
-        else if (q < nih + nhh) dst = (edge ? a.grads.e_whh[gi] : a.grads.n_whh[gi]) + (q - nih);
-        else {
-            const size_t k = q - nih - nhh;
-            if (k < (size_t)3 * H) dst = (edge ? a.grads.e_bih[gi] : a.grads.n_bih[gi]) + k;
-            else if (k < (size_t)6 * H) dst = (edge ? a.grads.e_bhh[gi] : a.grads.n_bhh[gi]) + (k - 3 * H);
-            else if (k < (size_t)7 * H) dst = (edge ? a.grads.w_edge : a.grads.w_node) + gi * H + (k - 6 * H);
-            else dst = nullptr;                        // head bias: summed over groups below
-        }
-        if (dst) *dst += s;
-    }
-    // head biases (one scalar per cell type): the same dy sums appear in every group's slab; take group 0
-    if ((int)blockIdx.x == a.row_blocks && tid < 2) {
-        const bool edge = tid == 0;
-        const int IN = edge ? IN_E : H;
-        const int b0 = edge ? 0 : nbE, b1 = edge ? nbE : a.nb_bwd;
-        const size_t q = (size_t)3 * H * (IN + H) + 7 * H;
-        float s = 0.f;
-        for (int b = b0; b < b1; ++b) s += a.slabs[((size_t)b * G + 0) * SLF + q];
-        float* dst = edge ? a.grads.b_edge : a.grads.b_node;
-        *dst += s;
-    }
-}
-
-// ------------------------------------------------------------------------------------------------------------
-// input transform, backward: one block per feature group
-// ------------------------------------------------------------------------------------------------------------
-struct BnBwdArgs {
-    tmpnn_mp_params P;
-    tmpnn_mp_params grads;
-    tmpnn_dgraph g;
+    int row_blocks;            // blocks [0, row_blocks): adjoints on the carried rows
+    int red_blocks;            // then red_blocks blocks reduce the slabs; the remaining G blocks (if n_new > 0) run
+                               // the input-transform backward of one feature group each
     int n_new, training;
     const float* x; int ld_x;
-    const float* d_h;          // [N][G*H] complete gradient of the iteration's input state
     const float* ysave; const float* mean; const float* rstd;
     const int* newdet;         // [G][n_new + 1]
     float* d_x;                // [n_new][F_total] or NULL
-    float* scratch;            // [G][2][n_new][H]  (d_out -> d_y1 ; a)
+    float* scratch;            // [G][2][n_new][H]: used when the new det rows do not fit the LDS
 };
 
-template <int H>
-__global__ __launch_bounds__(256) void k_small_bn_bwd(BnBwdArgs a) {
-    const int gi = blockIdx.x;
-    const int G = a.P.G, GH = G * H;
+// gradient of the iteration's input state at row `row`, group gi, columns 4 c4 ..: what k_small_iter_bwd wrote
+// (dh z + d_gh W_hh) plus the adjoint of the aggregation the row took part in
+template <int H, int IN_E>
+__device__ __forceinline__ float4 adjoint_at(const FinishArgs& a, int row, int gi, int c4) {
+    const int G = a.P.G;
+    const float* dm = a.d_msg + gi * IN_E + 4 * c4;
+    const size_t ldm = (size_t)G * IN_E;
+    const int p = a.g.pos[row];
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (a.g.is_edge[row]) {
+        // adjoint of row F: d h[e] += d_es[src(e)] - d_es[dst(e)]   (d_es = the node cell's d_x, stored at det rows)
+        const float4 u = *reinterpret_cast<const float4*>(dm + (size_t)a.g.src[p] * ldm);
+        const float4 v = *reinterpret_cast<const float4*>(dm + (size_t)a.g.dst[p] * ldm);
+        acc = make_float4(u.x - v.x, u.y - v.y, u.z - v.z, u.w - v.w);
+    } else {
+        // adjoint of row E: d h[d] += sum_{e: src=d} d_x[e][0:H] -/+ sum_{e: dst=d} d_x[e][0:H | H:2H]; CSR order
+        const int p0 = a.g.rowptr[p], p1 = a.g.rowptr[p + 1];
+        for (int q = p0; q < p1; q += 4) {
+            float4 v[4];
+            float w[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const bool live = q + u < p1;
+                const int key = live ? a.g.inc[q + u] : 0;
+                const bool neg = key < 0;
+                w[u] = live ? ((neg && IN_E == H) ? -1.0f : 1.0f) : 0.f;
+                v[u] = *reinterpret_cast<const float4*>(dm + (size_t)(key & 0x7fffffff) * ldm + ((neg && IN_E == 2 * H) ? H : 0));
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (w[u] != 0.f) { acc.x += w[u] * v[u].x; acc.y += w[u] * v[u].y; acc.z += w[u] * v[u].z; acc.w += w[u] * v[u].w; }
+        }
+    }
+    const float4 t = *reinterpret_cast<const float4*>(a.d_h + (size_t)row * (G * H) + gi * H + 4 * c4);
+    return make_float4(t.x + acc.x, t.y + acc.y, t.z + acc.z, t.w + acc.w);
+}
+
+// input-transform backward of feature group gi by ONE block (models/track_mpnn.py:45-52,59-61 reversed).
+// B0 / B1: [nd][ldb] work arrays (LDS when the new det rows fit, else global scratch).
+template <int H, int IN_E>
+__device__ void bn_bwd_block(const FinishArgs& a, int gi, float* B0, float* B1, int ldb) {
     const int N = a.g.N, n = a.n_new, N_old = N - n;
     const int F = a.P.F[gi], Ft = a.P.F_total;
     int f0 = 0;
@@ -783,23 +731,34 @@ __global__ __launch_bounds__(256) void k_small_bn_bwd(BnBwdArgs a) {
     const int* newdet = a.newdet + (size_t)gi * (n + 1);
     const int nd = newdet[n];
     const float* ysave = a.ysave + (size_t)gi * (n > 0 ? n : 1) * H;
-    float* B0 = a.scratch + (size_t)gi * 2 * n * H;      // d_out, then d_y1
-    float* B1 = B0 + (size_t)n * H;                      // a (post-ReLU activations)
-    __shared__ float s_m1[H], s_m2[H], s_dyz[H];
+    __shared__ float s_m1[H], s_m2[H], s_dyz[H], s_mean[H], s_rstd[H], s_gam[H];
     const float cntf = (float)n, nz = (float)(n - nd);
     const int c = tid % H, sub = tid / H;
     constexpr int NSUB = 256 / H;
-    const float mean = a.mean[(size_t)gi * H + c], rstd = a.rstd[(size_t)gi * H + c];
-    const float gam = a.P.gamma[gi][c], bet = a.P.beta[gi][c];
     if (nd == 0) {
         if (a.d_x) for (int idx = tid; idx < n * F; idx += 256) a.d_x[(size_t)(idx / F) * Ft + f0 + idx % F] = 0.f;
         return;
     }
-    // 1. gather d_out and recompute a
-    for (int i = sub; i < nd; i += NSUB) {
-        B0[(size_t)i * H + c] = a.d_h[(size_t)(N_old + newdet[i]) * GH + gi * H + c];
-        const float yh = (ysave[(size_t)i * H + c] - mean) * rstd;
-        B1[(size_t)i * H + c] = fmaxf(yh * gam + bet, 0.f);
+    if (tid < H) {
+        s_mean[tid] = a.mean[(size_t)gi * H + tid];
+        s_rstd[tid] = a.rstd[(size_t)gi * H + tid];
+        s_gam[tid] = a.P.gamma[gi][tid];
+    }
+    __syncthreads();
+    // 1. d_out (complete gradient of the new det rows' state) and the recomputed activations a
+    {
+        constexpr int LPR = H / 4, RPP = 256 / LPR;
+        const int c4 = tid % LPR, slot = tid / LPR;
+        for (int i = slot; i < nd; i += RPP) {
+            const float4 v = adjoint_at<H, IN_E>(a, N_old + newdet[i], gi, c4);
+            float* o = B0 + (size_t)i * ldb + 4 * c4;
+            o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
+        }
+        const float bet = a.P.beta[gi][c];
+        for (int i = sub; i < nd; i += NSUB) {
+            const float yh = (ysave[(size_t)i * H + c] - s_mean[c]) * s_rstd[c];
+            B1[(size_t)i * ldb + c] = fmaxf(yh * s_gam[c] + bet, 0.f);
+        }
     }
     __syncthreads();
     // 2. dW2[c][k] += sum_i d_out[i][c] a[i][k] ; db2[c] += sum_i d_out[i][c]
@@ -808,25 +767,25 @@ __global__ __launch_bounds__(256) void k_small_bn_bwd(BnBwdArgs a) {
         for (int idx = tid; idx < H * H; idx += 256) {
             const int cc = idx / H, k = idx % H;
             float s = 0.f;
-            for (int i = 0; i < nd; ++i) s = fmaf(B0[(size_t)i * H + cc], B1[(size_t)i * H + k], s);
+            for (int i = 0; i < nd; ++i) s = fmaf(B0[(size_t)i * ldb + cc], B1[(size_t)i * ldb + k], s);
             dW2[idx] += s;
         }
         if (tid < H) {
             float s = 0.f;
-            for (int i = 0; i < nd; ++i) s += B0[(size_t)i * H + tid];
+            for (int i = 0; i < nd; ++i) s += B0[(size_t)i * ldb + tid];
             a.grads.b2[gi][tid] += s;
         }
     }
     __syncthreads();
-    // 3. d_a = d_out W2 ; d_pre = d_a [a > 0] ; overwrite B0 with d_yhat = d_pre * gamma (column k = c), keep yhat implicit
+    // 3. d_a = d_out W2 ; d_pre = d_a [a > 0]  (overwrites a in B1)
     {
         const float* W2 = a.P.w2[gi];
-        // each thread produces column c of rows sub, sub + NSUB, ...; reads the whole d_out row first
         for (int i = sub; i < nd; i += NSUB) {
             float s = 0.f;
-            for (int cc = 0; cc < H; ++cc) s = fmaf(B0[(size_t)i * H + cc], W2[cc * H + c], s);
-            const float av = B1[(size_t)i * H + c];
-            B1[(size_t)i * H + c] = av > 0.f ? s : 0.f;          // d_pre (B1 no longer needed as a)
+#pragma unroll 8
+            for (int cc = 0; cc < H; ++cc) s = fmaf(B0[(size_t)i * ldb + cc], W2[cc * H + c], s);
+            const float av = B1[(size_t)i * ldb + c];
+            B1[(size_t)i * ldb + c] = av > 0.f ? s : 0.f;
         }
     }
     __syncthreads();
@@ -834,27 +793,26 @@ __global__ __launch_bounds__(256) void k_small_bn_bwd(BnBwdArgs a) {
     if (tid < H) {
         float sg = 0.f, sb = 0.f;
         for (int i = 0; i < nd; ++i) {
-            const float dp = B1[(size_t)i * H + tid];
-            const float yh = (ysave[(size_t)i * H + tid] - a.mean[(size_t)gi * H + tid]) * a.rstd[(size_t)gi * H + tid];
+            const float dp = B1[(size_t)i * ldb + tid];
+            const float yh = (ysave[(size_t)i * H + tid] - s_mean[tid]) * s_rstd[tid];
             sg += dp * yh;
             sb += dp;
         }
         a.grads.gamma[gi][tid] += sg;
         a.grads.beta[gi][tid] += sb;
-        const float g_ = a.P.gamma[gi][tid];
-        s_m1[tid] = a.training ? g_ * sb / cntf : 0.f;       // mean over ALL n rows of d_yhat (zero rows contribute 0)
-        s_m2[tid] = a.training ? g_ * sg / cntf : 0.f;       // mean of d_yhat * yhat
+        s_m1[tid] = a.training ? s_gam[tid] * sb / cntf : 0.f;      // mean over ALL n rows of d_yhat (zero rows add 0)
+        s_m2[tid] = a.training ? s_gam[tid] * sg / cntf : 0.f;      // mean of d_yhat * yhat
     }
     __syncthreads();
-    // 5. d_y1 (det rows) into B0 ; the zero rows' d_y1 (one value per column)
+    // 5. d_y1 of the det rows into B0 ; the zero rows' d_y1 (one value per column)
     for (int i = sub; i < nd; i += NSUB) {
-        const float yh = (ysave[(size_t)i * H + c] - mean) * rstd;
-        const float dyh = B1[(size_t)i * H + c] * gam;
-        B0[(size_t)i * H + c] = rstd * (dyh - s_m1[c] - yh * s_m2[c]);
+        const float yh = (ysave[(size_t)i * H + c] - s_mean[c]) * s_rstd[c];
+        const float dyh = B1[(size_t)i * ldb + c] * s_gam[c];
+        B0[(size_t)i * ldb + c] = s_rstd[c] * (dyh - s_m1[c] - yh * s_m2[c]);
     }
     if (tid < H) {
-        const float yz = (a.P.b1[gi][tid] - a.mean[(size_t)gi * H + tid]) * a.rstd[(size_t)gi * H + tid];
-        s_dyz[tid] = a.training ? a.rstd[(size_t)gi * H + tid] * (-s_m1[tid] - yz * s_m2[tid]) : 0.f;
+        const float yz = (a.P.b1[gi][tid] - s_mean[tid]) * s_rstd[tid];
+        s_dyz[tid] = a.training ? s_rstd[tid] * (-s_m1[tid] - yz * s_m2[tid]) : 0.f;
     }
     __syncthreads();
     // 6. dW1[k][f] += sum_i d_y1[i][k] x[i][f] ; db1[k] += sum_i d_y1[i][k] + nz * d_y1_zero[k]
@@ -863,16 +821,16 @@ __global__ __launch_bounds__(256) void k_small_bn_bwd(BnBwdArgs a) {
         for (int idx = tid; idx < H * F; idx += 256) {
             const int k = idx / F, f = idx % F;
             float s = 0.f;
-            for (int i = 0; i < nd; ++i) s = fmaf(B0[(size_t)i * H + k], a.x[(size_t)newdet[i] * a.ld_x + f0 + f], s);
+            for (int i = 0; i < nd; ++i) s = fmaf(B0[(size_t)i * ldb + k], a.x[(size_t)newdet[i] * a.ld_x + f0 + f], s);
             dW1[idx] += s;
         }
         if (tid < H) {
             float s = nz * s_dyz[tid];
-            for (int i = 0; i < nd; ++i) s += B0[(size_t)i * H + tid];
+            for (int i = 0; i < nd; ++i) s += B0[(size_t)i * ldb + tid];
             a.grads.b1[gi][tid] += s;
         }
     }
-    // 7. d_x: det rows  d_y1 W1 ; zero rows  d_y1_zero W1 (the gradient that reaches them through the batch statistics)
+    // 7. d_x: det rows  d_y1 W1 ; zero rows  d_y1_zero W1 (what reaches them through the batch statistics)
     if (a.d_x) {
         const float* W1 = a.P.w1[gi];
         for (int idx = tid; idx < n * F; idx += 256) {
@@ -885,9 +843,87 @@ __global__ __launch_bounds__(256) void k_small_bn_bwd(BnBwdArgs a) {
         for (int idx = tid; idx < nd * F; idx += 256) {
             const int i = idx / F, f = idx % F;
             float s = 0.f;
-            for (int k = 0; k < H; ++k) s = fmaf(B0[(size_t)i * H + k], W1[k * F + f], s);
+            for (int k = 0; k < H; ++k) s = fmaf(B0[(size_t)i * ldb + k], W1[k * F + f], s);
             a.d_x[(size_t)newdet[i] * Ft + f0 + f] = s;
         }
+    }
+}
+
+static constexpr int BN_LDS_ROWS = 120;      // new det rows whose two work arrays fit the LDS (2 x 120 x 65 floats)
+
+template <int H, int IN_E>
+__global__ __launch_bounds__(256) void k_small_bwd_finish(FinishArgs a) {
+    const int E = a.g.meta[0], Dn = a.g.meta[1];
+    const int G = a.P.G, GH = G * H, N = a.g.N;
+    const int tid = threadIdx.x;
+    constexpr int LPR = H / 4, RPB = 256 / LPR;
+    if ((int)blockIdx.x < a.row_blocks) {
+        // ---- carried rows: d_h += adjoint (the new rows' gradient is only needed by the input transform below)
+        if (E + Dn == 0) return;
+        const int N_old = N - a.n_new;
+        const int c4 = tid % LPR, slot = tid / LPR;
+        for (int r = blockIdx.x * RPB + slot; r < N_old; r += a.row_blocks * RPB)
+            for (int gi = 0; gi < G; ++gi) {
+                const float4 v = adjoint_at<H, IN_E>(a, r, gi, c4);
+                *reinterpret_cast<float4*>(a.d_h + (size_t)r * GH + gi * H + 4 * c4) = v;
+            }
+        return;
+    }
+    if ((int)blockIdx.x >= a.row_blocks + a.red_blocks) {
+        // ---- input-transform backward, one block per feature group
+        if (E + Dn == 0) return;
+        const int gi = blockIdx.x - a.row_blocks - a.red_blocks;
+        extern __shared__ float dyn[];
+        const int nd = a.newdet[(size_t)gi * (a.n_new + 1) + a.n_new];
+        if (nd <= BN_LDS_ROWS) bn_bwd_block<H, IN_E>(a, gi, dyn, dyn + BN_LDS_ROWS * (H + 1), H + 1);
+        else {
+            float* B0 = a.scratch + (size_t)gi * 2 * a.n_new * H;
+            bn_bwd_block<H, IN_E>(a, gi, B0, B0 + (size_t)a.n_new * H, H);
+        }
+        return;
+    }
+    // ---- slab reduction (fixed order over the blocks of each cell that had tiles)
+    const int nEt = (E + TR - 1) / TR, nDt = (Dn + TR - 1) / TR;
+    const int nbE = bwd_edge_blocks(nEt, nDt, a.nb_bwd);
+    const int usedE = min(nbE, nEt), usedD = min(a.nb_bwd - nbE, nDt);
+    const size_t SLF = slab_floats(H, IN_E);
+    const size_t n_e = (size_t)3 * H * (IN_E + H) + 7 * H + 1, n_n = (size_t)3 * H * (2 * H) + 7 * H + 1;
+    const size_t per_g = n_e + n_n;
+    const size_t total = per_g * G;
+    const int rb = a.red_blocks;
+    const int bid = blockIdx.x - a.row_blocks;
+    for (size_t idx = (size_t)bid * 256 + tid; idx < total; idx += (size_t)rb * 256) {
+        const int gi = (int)(idx / per_g);
+        size_t q = idx % per_g;
+        const bool edge = q < n_e;
+        if (!edge) q -= n_e;
+        const int IN = edge ? IN_E : H;
+        const int b0 = edge ? 0 : nbE, b1 = edge ? usedE : nbE + usedD;
+        float s = 0.f;
+        for (int b = b0; b < b1; ++b) s += a.slabs[((size_t)b * G + gi) * SLF + q];
+        const size_t nih = (size_t)3 * H * IN, nhh = (size_t)3 * H * H;
+        float* dst;
+        if (q < nih) dst = (edge ? a.grads.e_wih[gi] : a.grads.n_wih[gi]) + q;
+        else if (q < nih + nhh) dst = (edge ? a.grads.e_whh[gi] : a.grads.n_whh[gi]) + (q - nih);
+        else {
+            const size_t k = q - nih - nhh;
+            if (k < (size_t)3 * H) dst = (edge ? a.grads.e_bih[gi] : a.grads.n_bih[gi]) + k;
+            else if (k < (size_t)6 * H) dst = (edge ? a.grads.e_bhh[gi] : a.grads.n_bhh[gi]) + (k - 3 * H);
+            else if (k < (size_t)7 * H) dst = (edge ? a.grads.w_edge : a.grads.w_node) + gi * H + (k - 6 * H);
+            else dst = nullptr;                        // head bias: one scalar per cell type, below
+        }
+        if (dst) *dst += s;
+    }
+    // head biases: the same dy sums appear in every group's slab; take group 0
+    if (bid == 0 && tid < 2) {
+        const bool edge = tid == 0;
+        const int IN = edge ? IN_E : H;
+        const int b0 = edge ? 0 : nbE, b1 = edge ? usedE : nbE + usedD;
+        const size_t q = (size_t)3 * H * (IN + H) + 7 * H;
+        float s = 0.f;
+        for (int b = b0; b < b1; ++b) s += a.slabs[((size_t)b * G + 0) * SLF + q];
+        float* dst = edge ? a.grads.b_edge : a.grads.b_node;
+        *dst += s;
     }
 }
 
@@ -1012,8 +1048,8 @@ size_t tmpnn_mp_iter_bwd_ws(int N, int n_new, int G, int H, int IN_e) {
 
 int tmpnn_mp_iter_bwd(const tmpnn_mp_params* P, const float* prep, const tmpnn_dgraph* g, int n_new, const float* x,
                       int ld_x, const float* h, const float* h_out, const float* scores, const float* save,
-                      int training, const float* d_scores, const float* d_logits, const float* d_hout, float* d_h,
-                      float* d_x, const tmpnn_mp_params* grads, void* ws, size_t ws_bytes, tmpnn_stream stream) {
+                      int training, const float* d_scores, int st_dscores, const float* d_logits, int st_dlogits,
+                      const float* d_hout, float* d_h, float* d_x, const tmpnn_mp_params* grads, void* ws, size_t ws_bytes, tmpnn_stream stream) {
     int rc = check_params(P, "mp_iter_bwd", false);
     if (rc) return rc;
     if ((rc = check_params(grads, "mp_iter_bwd (grads)", true))) return rc;
@@ -1035,32 +1071,39 @@ int tmpnn_mp_iter_bwd(const tmpnn_mp_params* P, const float* prep, const tmpnn_d
     float* slabs = d_msg + (size_t)N * G * IN_e;
     float* bn_scratch = slabs + (size_t)nb * G * slab_floats(H, IN_e);
     hipStream_t st = as_stream(stream);
-    IterBwdArgs a{*P, *g, prep, h, scores, save + SL.gates, save + SL.es, d_scores, d_logits, d_hout, d_h, d_msg, slabs};
+    TM_REQUIRE(st_dscores >= 0 && st_dlogits >= 0, "mp_iter_bwd: negative gradient stride");
+    IterBwdArgs a{*P, *g, prep, h, scores, save + SL.gates, save + SL.es, d_scores, d_logits, d_hout, st_dscores, st_dlogits,
+                  d_h, d_msg, slabs};
     if (H == 64 && IN_e == 64) hipLaunchKernelGGL((k_small_iter_bwd<64, 64>), dim3(nb), dim3(256), 0, st, a);
     else if (H == 64) hipLaunchKernelGGL((k_small_iter_bwd<64, 128>), dim3(nb), dim3(256), 0, st, a);
     else if (IN_e == 32) hipLaunchKernelGGL((k_small_iter_bwd<32, 32>), dim3(nb), dim3(256), 0, st, a);
     else hipLaunchKernelGGL((k_small_iter_bwd<32, 64>), dim3(nb), dim3(256), 0, st, a);
     if ((rc = check_launch("small_iter_bwd"))) return rc;
     const int rpb = 256 / (H / 4);
-    int row_blocks = (N + rpb - 1) / rpb;
+    int row_blocks = (N - n_new + rpb - 1) / rpb;
     if (row_blocks > 256) row_blocks = 256;
+    if (row_blocks < 1) row_blocks = 1;
     const size_t red_elems = (size_t)G * ((size_t)3 * H * (IN_e + 3 * H) + 14 * H + 2);
     int red_blocks = (int)((red_elems + 255) / 256);
-    if (red_blocks > 128) red_blocks = 128;
-    FinishArgs f{*P, *grads, *g, d_msg, d_h, slabs, nb, row_blocks};
-    if (H == 64 && IN_e == 64) hipLaunchKernelGGL((k_small_bwd_finish<64, 64>), dim3(row_blocks + red_blocks), dim3(256), 0, st, f);
-    else if (H == 64) hipLaunchKernelGGL((k_small_bwd_finish<64, 128>), dim3(row_blocks + red_blocks), dim3(256), 0, st, f);
-    else if (IN_e == 32) hipLaunchKernelGGL((k_small_bwd_finish<32, 32>), dim3(row_blocks + red_blocks), dim3(256), 0, st, f);
-    else hipLaunchKernelGGL((k_small_bwd_finish<32, 64>), dim3(row_blocks + red_blocks), dim3(256), 0, st, f);
+    if (red_blocks > 64) red_blocks = 64;
+    const int bn_blocks = n_new > 0 ? G : 0;
+    if (n_new > 0) TM_REQUIRE(x != nullptr && ld_x >= P->F_total, "mp_iter_bwd: x");
+    FinishArgs f{*P, *grads, *g, d_msg, d_h, slabs, nb, row_blocks, red_blocks, n_new, training, x, ld_x,
+                 save + SL.ysave, save + SL.mean, save + SL.rstd, reinterpret_cast<const int*>(save + SL.total), d_x,
+                 bn_scratch};
+    const size_t shm = sizeof(float) * 2 * BN_LDS_ROWS * (H + 1);
+    const dim3 fgrid(row_blocks + red_blocks + bn_blocks);
+#define LF(HH, II)                                                                                           \
+    do {                                                                                                     \
+        TM_SHM_ONCE((k_small_bwd_finish<HH, II>), shm);                                                      \
+        hipLaunchKernelGGL((k_small_bwd_finish<HH, II>), fgrid, dim3(256), shm, st, f);                      \
+    } while (0)
+    if (H == 64 && IN_e == 64) LF(64, 64);
+    else if (H == 64) LF(64, 128);
+    else if (IN_e == 32) LF(32, 32);
+    else LF(32, 64);
+#undef LF
     if ((rc = check_launch("small_bwd_finish"))) return rc;
-    if (n_new > 0) {
-        TM_REQUIRE(x != nullptr && ld_x >= P->F_total, "mp_iter_bwd: x");
-        BnBwdArgs b{*P, *grads, *g, n_new, training, x, ld_x, d_h, save + SL.ysave, save + SL.mean, save + SL.rstd,
-                    reinterpret_cast<const int*>(save + SL.total), d_x, bn_scratch};
-        if (H == 64) hipLaunchKernelGGL((k_small_bn_bwd<64>), dim3(G), dim3(256), 0, st, b);
-        else hipLaunchKernelGGL((k_small_bn_bwd<32>), dim3(G), dim3(256), 0, st, b);
-        if ((rc = check_launch("small_bn_bwd"))) return rc;
-    }
     return TMPNN_OK;
 }
 

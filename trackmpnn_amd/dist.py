@@ -36,6 +36,10 @@ class GradBucket:
         if hasattr(module, 'inplace_param_grads'):
             module.inplace_param_grads = True
 
+    def zero(self) -> None:
+        """zero_grad(set_to_none=False) in one launch: every p.grad is a slice of `flat`."""
+        self.flat.zero_()
+
     def check_alias(self) -> bool:
         """True while every p.grad still aliases the bucket (zero_grad(set_to_none=True) breaks it)."""
         o = 0

@@ -485,12 +485,16 @@ class DeviceGraph:
     calls, or immediately with TMPNN_STRICT_GRAPH=1.  An invalid graph is presented to the kernels as empty."""
 
     def __init__(self, N: int, device, cap: Optional[int] = None):
-        lib = _lib.load()
         self.N = int(N)
-        self.cap = int(cap if cap is not None else N)
-        self.arena = torch.empty((int(lib.tmpnn_dgraph_ints(self.cap)),), dtype=torch.int32, device=device)
-        self.c = _lib.CDGraph()
-        _lib.call('tmpnn_dgraph_bind', self.arena.data_ptr(), self.cap, self.N, C.byref(self.c))
+        self.cap = cap = int(cap if cap is not None else N)
+        # the layout of tmpnn_dgraph_bind, restated (tests/test_abi.py checks it against the library)
+        c = (cap + 1 + 3) & ~3
+        nbytes = (((cap + 3) // 4) + 3) & ~3
+        self.arena = torch.empty((8 + nbytes + 10 * c,), dtype=torch.int32, device=device)
+        b = self.arena.data_ptr()
+        o = b + 32 + 4 * nbytes
+        self.c = _lib.CDGraph(self.N, cap, b, b + 32, o, o + 4 * c, o + 8 * c, o + 12 * c, o + 16 * c, o + 20 * c,
+                              o + 24 * c, o + 28 * c, o + 32 * c)
         self._meta = None
         self._frame = None
 
@@ -547,14 +551,16 @@ class DeviceGraph:
 def _coo_parts(adj: torch.Tensor, device):
     """(indices int64 [2, nnz] contiguous, values fp32 [nnz]) of a dense or sparse-COO adjacency, on `device`;
     sparse tensors are taken as stored (uncoalesced is fine: the converter sums duplicate diagonal entries)."""
-    adj = adj.detach()
     if adj.is_sparse:
         idx, val = adj._indices(), adj._values()
+        if idx.device == device and val.dtype == torch.float32 and idx.is_contiguous() and val.is_contiguous():
+            return idx, val                      # the common case (utils/graph.py hands over sparse CUDA tensors)
     else:
+        adj = adj.detach()
         idx = torch.nonzero(adj).t()
         val = adj[idx[0], idx[1]]
-    idx = idx.to(device=device, dtype=torch.int64)
-    val = val.to(device=device, dtype=torch.float32)
+    idx = idx.detach().to(device=device, dtype=torch.int64)
+    val = val.detach().to(device=device, dtype=torch.float32)
     return (idx if idx.is_contiguous() else idx.contiguous()), (val if val.is_contiguous() else val.contiguous())
 
 
@@ -564,6 +570,7 @@ def device_graph_from_adjacency(node_adj: torch.Tensor, edge_adj: Optional[torch
     N = int(node_adj.shape[0])
     if N > DG_MAX_ROWS:
         raise ValueError(f'device_graph_from_adjacency: N={N} > {DG_MAX_ROWS}; use graph_from_adjacency')
+    device = torch.device(device)
     g = DeviceGraph(N, device)
     nidx, nval = _coo_parts(node_adj, device)
     if edge_adj is not None:

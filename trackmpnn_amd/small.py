@@ -3,7 +3,7 @@
 The reference calls the model once per timestep on a single tracking window (train.py:92-107, infer.py:60-87).  At
 that size the cost of a call is launches and host bookkeeping, not flops, so this path keeps both minimal:
 the graph is a `DeviceGraph` (sizes stay on the device, no host round trip), the iteration is two launches forward and
-three backward (csrc/small.hip), parameters travel as one cached pointer struct, and everything saved for the backward
+two backward (csrc/small.hip), parameters travel as one cached pointer struct, and everything saved for the backward
 lives in one buffer.  Eligible calls: K = 0 attention heads, H in {32, 64}, N <= 4096 rows, one BatchNorm segment;
 anything else takes the staged path of functional.py.  There is no fallback to torch ops or to the oracle.
 """
@@ -42,6 +42,7 @@ class SmallPath:
         self.cparams = None
         self.prep = None
         self._grad_struct_cache = {}
+        self.f_fwd = self.f_bwd = None
         # layout of the flat gradient buffer (256-byte aligned slices), in param_names() order
         sizes, offs = [], [0]
         named = dict(model.named_parameters())
@@ -70,8 +71,13 @@ class SmallPath:
     def params(self, plist) -> _lib.CMpParams:
         """Pointer struct of the parameters (+ BatchNorm buffers) and fresh operand images; cached by data pointers
         and version counters."""
-        key = tuple(p.data_ptr() for p in plist)
-        if key != self._ptr_key:
+        if self.f_fwd is None:
+            self.f_fwd, self.f_bwd = _lib.fn('tmpnn_mp_iter_fwd'), _lib.fn('tmpnn_mp_iter_bwd')
+        k = self._ptr_key
+        if k is not None and (plist[0].data_ptr() != k[0] or plist[-1].data_ptr() != k[-1]):
+            self.invalidate()                # storage replaced behind our back (p.data = ...): cheap sentinel check
+        if self._ptr_key is None:
+            key = tuple(p.data_ptr() for p in plist)
             for nm, p in zip(self.names, plist):
                 if not p.is_cuda or p.dtype != torch.float32 or not p.is_contiguous():
                     raise RuntimeError(f'{nm}: the HIP path needs contiguous fp32 parameters on the GPU (no CPU or '
@@ -83,18 +89,26 @@ class SmallPath:
             for g in range(self.spec.G):
                 st.run_mean[g] = bufs[f'input_transforms.{g}.1.running_mean'].data_ptr()
                 st.run_var[g] = bufs[f'input_transforms.{g}.1.running_var'].data_ptr()
+                st.num_batches_tracked[g] = bufs[f'input_transforms.{g}.1.num_batches_tracked'].data_ptr()
             self.cparams, self._ptr_key, self._ver_key = st, key, None
             self._w_idx = [i for i, nm in enumerate(self.names) if nm.endswith(('gru.weight_ih', 'gru.weight_hh'))]
         vkey = tuple(plist[i]._version for i in self._w_idx)
-        if vkey != self._ver_key:
+        capturing = torch.cuda.is_current_stream_capturing()
+        if vkey != self._ver_key or capturing:
             lib = _lib.load()
             spec = self.spec
             if self.prep is None or self.prep.device != plist[0].device:
                 self.prep = torch.empty((int(lib.tmpnn_mp_iter_prep_floats(spec.G, spec.H, spec.IN_e)),),
                                         dtype=torch.float32, device=plist[0].device)
             _lib.call('tmpnn_mp_iter_prepare', C.byref(self.cparams), self.prep.data_ptr(), _stream())
-            self._ver_key = vkey
+            self._ver_key = None if capturing else vkey
         return self.cparams
+
+    def invalidate(self) -> None:
+        """Parameter / buffer storage may have moved (Module._apply, load_state_dict(assign=True)): re-read pointers."""
+        self._ptr_key = None
+        self._ver_key = None
+        self._grad_struct_cache.clear()
 
     def grad_struct(self, tensors) -> _lib.CMpParams:
         """Pointer struct over a list of gradient tensors (param_names() order); cached by their data pointers."""
@@ -114,6 +128,8 @@ class _SmallIter(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, call, x, h_in, *params):
+        # params: every parameter in param_names() order, or -- when gradients are accumulated in place -- ONE
+        # dummy tensor that only tells autograd the outputs need a backward
         sp: SmallPath = call['small']
         spec = sp.spec
         dg: DeviceGraph = call['graph']
@@ -133,7 +149,7 @@ class _SmallIter(torch.autograd.Function):
         training = call['training']
         if training and n == 1:
             raise ValueError(f'Expected more than 1 value per channel when training, got input size [1, {H}]')
-        cp = sp.params(params)
+        cp = sp.params(call['param_objs'])
         xd = x.detach()
         if xd.dtype != torch.float32 or not xd.is_contiguous():
             xd = xd.float().contiguous()
@@ -157,25 +173,23 @@ class _SmallIter(torch.autograd.Function):
         spare_out = call['spare']
         buf = torch.empty(((N + spare_out) * GH,), **opts)
         h_out = torch.empty(0, **opts).set_(buf.untyped_storage(), 0, (N, GH), (GH, 1))
-        ls = torch.empty((2, max(N, 1)), **opts)
+        logits = torch.empty((N, 1), **opts)
+        scores = torch.empty((N, 1), **opts)
         save = None
         nsave = 0
         if need_grad or n > 0:
-            nsave = int(lib.tmpnn_mp_iter_save_floats(N, n, G, H))
+            nsave = save_floats(N, n, G, H)
             save = torch.empty((nsave,), **opts)
-        _lib.call('tmpnn_mp_iter_fwd', C.byref(cp), sp.prep.data_ptr(), dg.cref(), n, xd.data_ptr() if n > 0 else None,
-                  int(xd.shape[1]) if n > 0 else 0, h_cat.data_ptr(), int(training), h_out.data_ptr(), ls[0].data_ptr(),
-                  ls[1].data_ptr(), _lib.ptr(save), nsave, _stream())
-        if training and n > 0:
-            for g in range(G):
-                call['buffers'][f'input_transforms.{g}.1.num_batches_tracked'] += 1
+        rc = sp.f_fwd(C.byref(cp), sp.prep.data_ptr(), dg.cref(), n, xd.data_ptr() if n > 0 else None,
+                  int(xd.shape[1]) if n > 0 else 0, h_cat.data_ptr(), int(training), h_out.data_ptr(), logits.data_ptr(),
+                  scores.data_ptr(), _lib.ptr(save), nsave, _stream())
+        if rc:
+            raise RuntimeError(f'tmpnn_mp_iter_fwd failed (code {rc}): {_lib.last_error()}')
         ctx.call = call
-        ctx.saved = (xd, h_cat, h_out, ls, save, cp) if need_grad else None
+        ctx.saved = (xd, h_cat, h_out, scores, save, cp) if need_grad else None
         ctx.has_h = h_in is not None
         ctx.n = n
         ctx.set_materialize_grads(False)
-        logits = ls[0, :N].unsqueeze(1)
-        scores = ls[1, :N].unsqueeze(1)
         return scores, logits, h_out
 
     @staticmethod
@@ -186,7 +200,7 @@ class _SmallIter(torch.autograd.Function):
         dg: DeviceGraph = call['graph']
         call['check_pending']()                      # deferred graph validation (one host read for the whole chunk)
         lib = _lib.load()
-        xd, h_cat, h_out, ls, save, cp = ctx.saved
+        xd, h_cat, h_out, scores, save, cp = ctx.saved
         ctx.saved = None
         H, G = spec.H, spec.G
         GH = G * H
@@ -200,14 +214,27 @@ class _SmallIter(torch.autograd.Function):
         def f32c(t):
             return t if (t.dtype == torch.float32 and t.is_contiguous()) else t.float().contiguous()
 
-        ds = f32c(d_scores.reshape(-1)) if d_scores is not None else None
-        dl = f32c(d_logits.reshape(-1)) if d_logits is not None else None
+        def strided(t):
+            """(tensor, element stride) of an [N, 1] / [N] gradient; expanded (stride 0) and strided views are
+            passed as they are -- the gradient of a sum or of a slice never has to be materialised"""
+            if t is None:
+                return None, 0
+            if t.dtype != torch.float32:
+                t = t.float()
+            st = t.stride(0) if t.numel() > 1 else 1
+            if st < 0:
+                t, st = t.contiguous(), 1
+            return t, st
+
+        ds, st_ds = strided(d_scores)
+        dl, st_dl = strided(d_logits)
         dh = f32c(d_hout) if d_hout is not None else None
-        inplace = (call['inplace'] and all(need[3:])
-                   and all(p.grad is not None and p.grad.dtype == torch.float32 and p.grad.is_contiguous()
-                           and p.grad.device == dev for p in objs))
+        inplace = call['anchored']
         if inplace:
             gts = [p.grad for p in objs]
+            if any(g is None for g in gts):
+                raise RuntimeError('in-place parameter gradients: a p.grad buffer disappeared between forward and '
+                                   'backward (use zero_grad(set_to_none=False))')
             flat = None
         else:
             flat = torch.zeros((sp.grad_total,), **opts)
@@ -216,19 +243,33 @@ class _SmallIter(torch.autograd.Function):
         d_h = torch.empty((N, GH), **opts)
         need_x = need[1] and n > 0
         d_x = torch.empty((n, spec.F_total), **opts) if need_x else None
-        wsb = int(lib.tmpnn_mp_iter_bwd_ws(N, n, G, H, spec.IN_e))
+        wsb = bwd_ws_bytes(N, n, G, H, spec.IN_e)
         ws = torch.empty((wsb // 4 + 4,), **opts)
-        _lib.call('tmpnn_mp_iter_bwd', C.byref(cp), sp.prep.data_ptr(), dg.cref(), n, xd.data_ptr() if n > 0 else None,
-                  int(xd.shape[1]) if n > 0 else 0, h_cat.data_ptr(), h_out.data_ptr(), ls[1].data_ptr(), save.data_ptr(),
-                  int(call['training']), _lib.ptr(ds), _lib.ptr(dl), _lib.ptr(dh), d_h.data_ptr(), _lib.ptr(d_x),
+        rc = sp.f_bwd(C.byref(cp), sp.prep.data_ptr(), dg.cref(), n, xd.data_ptr() if n > 0 else None,
+                  int(xd.shape[1]) if n > 0 else 0, h_cat.data_ptr(), h_out.data_ptr(), scores.data_ptr(), save.data_ptr(),
+                  int(call['training']), _lib.ptr(ds), st_ds, _lib.ptr(dl), st_dl, _lib.ptr(dh), d_h.data_ptr(), _lib.ptr(d_x),
                   C.byref(gst), ws.data_ptr(), wsb, _stream())
+        if rc:
+            raise RuntimeError(f'tmpnn_mp_iter_bwd failed (code {rc}): {_lib.last_error()}')
         if need[1] and d_x is None:
             d_x = torch.zeros((n, spec.F_total), **opts)
         d_h_in = d_h[:N - n] if (ctx.has_h and need[2] and N - n > 0) else None
         if inplace:
-            return (None, d_x, d_h_in) + (None,) * len(names)
+            return (None, d_x, d_h_in, None)
         named = dict(zip(names, objs))
         return (None, d_x, d_h_in) + tuple(g.view(named[nm].shape) for nm, g in zip(names, gts))
+
+
+def save_floats(N: int, n: int, G: int, H: int) -> int:
+    """tmpnn_mp_iter_save_floats restated (one ctypes call less per forward; tests/test_abi.py checks the two agree)."""
+    return G * 4 * N * H + G * N * H + G * max(n, 1) * H + 2 * G * H + G * (n + 1) + 4
+
+
+def bwd_ws_bytes(N: int, n: int, G: int, H: int, IN_e: int) -> int:
+    """tmpnn_mp_iter_bwd_ws restated."""
+    nb = min(max((N + 15) // 16 + 2, 2), 96)
+    slab = 3 * H * (IN_e + H) + 7 * H + 4
+    return 4 * (N * G * IN_e + nb * G * slab + G * 2 * n * H + 16)
 
 
 def small_eligible(model, N: int) -> bool:

@@ -95,7 +95,22 @@ class TrackMPNN(nn.Module):
         self._small = SmallPath(self)          # batch-1 path state (pointer structs, operand images)
         self._plist = None
         self._bufs = None
+        self._anchor = None
         self._pending_graphs = []              # DeviceGraphs whose validation status has not been read back yet
+
+    def _apply(self, fn, *args, **kwargs):
+        # .cuda() / .to() / .float(): parameter storage moves -> drop every cached device pointer
+        out = super()._apply(fn, *args, **kwargs)
+        self._small.invalidate()
+        self._plist = self._bufs = self._anchor = None
+        self._graph_cache = None
+        return out
+
+    def load_state_dict(self, *args, **kwargs):
+        out = super().load_state_dict(*args, **kwargs)
+        self._small.invalidate()
+        self._plist = self._bufs = None
+        return out
 
     def get_input_transform(self, n_in, n_out):
         lin1 = nn.Linear(n_in, n_out, bias=True)
@@ -145,9 +160,9 @@ class TrackMPNN(nn.Module):
     def check_graphs(self) -> None:
         """Read back the validation status of every adjacency converted since the last check (ONE host round trip)
         and raise ValueError for the first invalid one.  Called automatically before a backward and every 64 calls."""
+        if not self._pending_graphs or torch.cuda.is_current_stream_capturing():
+            return                                   # (a capture cannot synchronise: the check happens after it)
         pending, self._pending_graphs = self._pending_graphs, []
-        if not pending:
-            return
         metas = torch.stack([g.arena[:8] for g in pending]).tolist()
         for g, m in zip(pending, metas):
             g._meta = (m[4], m[5], m[2])
@@ -164,8 +179,15 @@ class TrackMPNN(nn.Module):
             self._plist = [named[nm] for nm in self.spec.param_names()]
             self._bufs = dict(self.named_buffers())
         params = self._plist
-        need_grad = torch.is_grad_enabled() and (
-            x.requires_grad or (h_in is not None and h_in.requires_grad) or any(p.requires_grad for p in params))
+        grad_on = torch.is_grad_enabled()
+        pgrad = grad_on and any(p.requires_grad for p in params)
+        need_grad = grad_on and (pgrad or x.requires_grad or (h_in is not None and h_in.requires_grad))
+        # in-place accumulation (GradBucket): the parameters are not autograd inputs -- one dummy tensor stands in
+        anchored = False
+        if pgrad and (self.inplace_param_grads or _functional.INPLACE_GRADS):
+            dev = x.device
+            anchored = all(p.requires_grad and p.grad is not None and p.grad.dtype == torch.float32
+                           and p.grad.is_contiguous() and p.grad.device == dev for p in params)
         spare = max(256, graph.N)
         # the carried state is extended IN PLACE when it came out of this path (it has spare rows behind it) and has
         # not been continued from before; a second continuation from the same tensor copies instead
@@ -175,9 +197,13 @@ class TrackMPNN(nn.Module):
         if append:
             h_in._tmpnn_consumed = True
         call = dict(small=self._small, graph=graph, training=self.training, need_grad=need_grad, spare=spare, append=append,
-                    buffers=self._bufs, param_objs=params,
-                    inplace=self.inplace_param_grads or _functional.INPLACE_GRADS, check_pending=self.check_graphs)
-        scores, logits, h_out = _SmallIter.apply(call, x, h_in, *params)
+                    param_objs=params, anchored=anchored, check_pending=self.check_graphs)
+        if anchored:
+            if self._anchor is None or self._anchor.device != x.device:
+                self._anchor = torch.zeros(1, device=x.device, requires_grad=True)
+            scores, logits, h_out = _SmallIter.apply(call, x, h_in, self._anchor)
+        else:
+            scores, logits, h_out = _SmallIter.apply(call, x, h_in, *params)
         h_out._tmpnn_spare_rows = spare
         return scores, logits, h_out, (None,) * self.spec.G
 
@@ -194,8 +220,7 @@ class TrackMPNN(nn.Module):
                                '(no CPU or torch fallback exists)')
         N = int(node_adj.shape[0])
         small = SMALL_PATH and small_eligible(self, N)
-        key = (id(node_adj), id(edge_adj), N, getattr(node_adj, '_version', 0), getattr(edge_adj, '_version', 0),
-               str(x.device), small)
+        key = (id(node_adj), id(edge_adj), N, node_adj._version, edge_adj._version, x.device, small)
         if self._graph_cache is not None and self._graph_cache[0] == key:
             graph = self._graph_cache[1]
         else:
