@@ -205,70 +205,21 @@ def pmc_traffic(stage, E):
     return None
 
 
-def cpu_baseline(frames, mean_dets, max_dets, F, H, seed, budget_s=15.0):
-    """The oracle (CPU restatement, kind 'port') on the host cores, one window at a time as the reference
-    runs them (batch size 1, utils/graph.py:117), same call pattern, bounded sample."""
-    from oracle import trackmpnn_oracle as orc
-    from trackmpnn_amd import WindowBuilder, batch_windows, synth_window
-    import torch.nn.functional as Fnn
-    cfg = orc.OracleConfig('2d', F - 5, H, 0, 'diff')
-    p = orc.random_params(cfg, seed=0, scale=0.05)
-    for k, v in p.items():
-        if v.dtype.is_floating_point and not k.endswith(orc.BUFFER_SUFFIXES):
-            v.requires_grad_(True)
-    cases = []
-    for s in range(64):
-        calls = WindowBuilder(synth_window(seed * 1000 + s, frames, mean_dets, max_dets)).calls()
-        plans, refs = batch_windows([calls])
-        gen = torch.Generator().manual_seed(s)
-        graphs, xs = [], []
-        for plan, ref in zip(plans, refs):
-            g = plan.graph
-            graphs.append(orc.OracleGraph(g.N, g.is_edge.numpy().astype(bool), g.src.numpy().astype(np.int64),
-                                          g.dst.numpy().astype(np.int64), g.edge_row.numpy().astype(np.int64),
-                                          g.det_row.numpy().astype(np.int64)))
-            x = torch.zeros(plan.n_new, F)
-            x[plan.new_det_local] = torch.randn(len(ref), F, generator=gen)
-            xs.append(x)
-        cases.append((graphs, xs))
-
-    def run(case):
-        graphs, xs = case
-        h = None
-        loss = 0.0
-        for g, x in zip(graphs, xs):
-            s, l, h, _ = orc.forward(p, cfg, x, h, g, training=True)
-            loss = loss + Fnn.binary_cross_entropy_with_logits(l, torch.zeros_like(l), reduction='sum')
-        for v in p.values():
-            v.grad = None
-        loss.backward()
-        return sum(g.E for g in graphs)
-
-    run(cases[0])
-    results = {}
-    ncpu = os.cpu_count() or 1
-    for nthreads in sorted({1, min(8, ncpu), min(16, ncpu)}):   # more threads only slow these tiny per-window ops down
-        torch.set_num_threads(nthreads)
-        run(cases[0])
-        t0 = time.perf_counter()
-        edges = nwin = 0
-        done = False
-        while not done:
-            for case in cases:
-                edges += run(case)
-                nwin += 1
-                if time.perf_counter() - t0 > budget_s / 3:
-                    done = True
-                    break
-        dt = time.perf_counter() - t0
-        results[nthreads] = (edges / dt, nwin, edges, dt)
-    best = max(results, key=lambda k: results[k][0])
-    v, nwin, edges, dt = results[best]
-    others = ', '.join(f'{k} threads: {r[0]:.0f}/s' for k, r in results.items())
-    return dict(value=v, unit='graph-edges/s', cores=best, kind='port',
-                sample=f'{nwin} windows of the same C2 generator run one at a time (batch 1 as the reference), '
-                       f'{edges} edge-iterations in {dt:.1f} s, torch-CPU fp32 oracle fwd+bwd; best of [{others}] '
-                       f'on a {ncpu}-core host')
+def cpu_baseline(frames, mean_dets, max_dets, F, H, seed, budget_s=20.0):
+    """The oracle (CPU restatement, kind 'port') on the host cores, same C2 generator and call pattern, bounded
+    sample, in three forms (oracle/cpu_bench.py): one core at batch 1 (how the reference runs, utils/graph.py:117),
+    P batch-1 processes over the box's CPU share, and block-diagonal batches with all threads.  The BEST form is the
+    stated baseline; the others ride along in `forms`."""
+    from oracle import cpu_bench
+    best, forms = cpu_bench.measure(frames, mean_dets, max_dets, F, H, seed, budget_s=budget_s)
+    b = forms[best]
+    desc = {'single': 'one window at a time on one core (batch 1 as the reference)',
+            'procs': f"{b['cores']} independent batch-1 worker processes, one core each",
+            'batched': f"block-diagonal batches of 256 windows, {b['cores']} threads"}[best]
+    return dict(value=b['value'], unit='graph-edges/s', cores=b['cores'], kind='port',
+                sample=f"C2 generator, torch-CPU fp32 oracle fwd+bwd, {desc}: {b['edge_iterations']} edge-iterations "
+                       f"in {b['seconds']} s; best of single / procs / batched on a {os.cpu_count()}-core host",
+                forms={k: dict(value=round(v['value'], 1), cores=v['cores']) for k, v in forms.items()})
 
 
 def latency_batch1():
