@@ -208,7 +208,8 @@ def pmc_traffic(stage, E):
 def cpu_baseline(frames, mean_dets, max_dets, F, H, seed, budget_s=20.0):
     """The oracle (CPU restatement, kind 'port') on the host cores, same C2 generator and call pattern, bounded
     sample, in three forms (oracle/cpu_bench.py): one core at batch 1 (how the reference runs, utils/graph.py:117),
-    P batch-1 processes over the box's CPU share, and block-diagonal batches with all threads.  The BEST form is the
+    4 batch-1 worker processes (a GPU box admits 6 processes on the card, and importing torch opens it), and
+    block-diagonal batches of 256 windows with all 16 threads of the box's CPU share.  The BEST form is the
     stated baseline; the others ride along in `forms`."""
     from oracle import cpu_bench
     best, forms = cpu_bench.measure(frames, mean_dets, max_dets, F, H, seed, budget_s=budget_s)

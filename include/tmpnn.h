@@ -339,6 +339,11 @@ int tmpnn_graph_from_coo(int N, const int64_t* node_idx, const float* node_val, 
                          const int64_t* edge_idx, const float* edge_val, int64_t nnz_edge,
                          const tmpnn_dgraph* g, tmpnn_stream stream);
 
+/* The same index form from the ROW form of a graph (type mask + the two endpoint rows of every edge row): what the
+ * tracker-side operations below edit.  Same validation, same status bits. */
+int tmpnn_graph_from_rows(int N, const uint8_t* is_edge, const int32_t* row_src, const int32_t* row_dst,
+                          const tmpnn_dgraph* g, tmpnn_stream stream);
+
 /* Parameters of the model as device pointers in the reference's layouts (state_dict keys of SURVEY 8(b)); the same
  * struct with gradient buffers is what tmpnn_mp_iter_bwd accumulates into (+=).  G <= 3 feature groups. */
 typedef struct tmpnn_mp_params {
@@ -380,6 +385,44 @@ int tmpnn_mp_iter_bwd(const tmpnn_mp_params* P, const float* prep, const tmpnn_d
                       const float* d_scores, int st_dscores, const float* d_logits, int st_dlogits,
                       const float* d_hout, float* d_h, float* d_x, const tmpnn_mp_params* grads,
                       void* ws, size_t ws_bytes, tmpnn_stream stream);
+
+/* ======================================================================================================
+ * Tracker-side graph maintenance on the device (csrc/trackops.hip).  Between two model
+ * calls the reference moves a DENSE N x N adjacency and the hidden state to the host and back
+ * (utils/graph.py:216-221,326-332 and :420-425,532-537).  Here the graph lives in HBM in ROW form, one entry per
+ * state row, all int32 unless noted (capacity <= TMPNN_DG_MAX_ROWS rows):
+ *     ts, det_id, assoc            y_pred[:, 0..2]: timestep (-1 on edge rows), detection id, associated next detection id
+ *     is_edge (uint8), row_src, row_dst   the +1 / -1 det ROW of an edge row (-1 on det rows)
+ *     labels (uint8)               ground-truth class (training; may be NULL at inference)
+ * and its index form is re-derived with tmpnn_graph_from_rows after every edit.  score: P(positive) per row, fp32
+ * (scores[:, 1] of the reference).  Hungarian matching and the walk that finalises tracks stay on the host.
+ * ====================================================================================================== */
+/* y_pred[:, 2].  mode 0 (training, utils/graph.py:229-245): through the one label-positive future edge; false
+ * positives point at themselves; status bit 0 is set if a det has more than one positive future edge.
+ * mode 1 (inference, greedy: :251-268 and :437-454): best-scoring future edge (>= 0.5, to a det >= 0.5) of the nearest
+ * timestep. */
+int tmpnn_track_associate(const tmpnn_dgraph* g, const int32_t* det_id, const uint8_t* labels, const float* score,
+                          int mode, int32_t* assoc, int32_t* status, tmpnn_stream stream);
+/* Active set at time t (utils/graph.py:270-278): rows in ascending order into active[], their number into count[0]. */
+int tmpnn_track_active(int N, const int32_t* ts, const int32_t* assoc, const float* score, int mode, int t,
+                       int32_t* active, int32_t* count, tmpnn_stream stream);
+/* Append the block of timestep t behind row N (utils/graph.py:283-325): A x D edge rows (src-major) then D det rows
+ * with ids new_ids[D]; labels from track[det id] (int32 [ND] track of every detection, -1 = false positive; NULL at
+ * inference).  The row arrays must have room for N + A*D + D entries. */
+int tmpnn_track_append(int N, int A, int D, const int32_t* active, const int32_t* new_ids, int t, const int32_t* track,
+                       int32_t* ts, int32_t* det_id, int32_t* assoc, uint8_t* is_edge, int32_t* row_src,
+                       int32_t* row_dst, uint8_t* labels, tmpnn_stream stream);
+/* The rows decode_tracks deletes (utils/graph.py:492-512) as a stream compaction: keep[] = kept rows (ascending),
+ * count[0] = their number, o_* = the compacted row form with renumbered endpoints. */
+int tmpnn_track_delete(int N, const int32_t* ts, const int32_t* det_id, const int32_t* assoc, const float* score,
+                       const uint8_t* is_edge, const int32_t* row_src, const int32_t* row_dst, const uint8_t* labels,
+                       int t_upto, int ret_win, int32_t* keep, int32_t* count, int32_t* o_ts, int32_t* o_det_id,
+                       int32_t* o_assoc, uint8_t* o_is_edge, int32_t* o_src, int32_t* o_dst, uint8_t* o_labels,
+                       tmpnn_stream stream);
+/* out[q][0:W] = in[keep[q]][0:W] for q < count[0] (count read on the device; the launch covers max_rows): the hidden
+ * state and the scores follow the deletion without leaving HBM (utils/graph.py:514,519). */
+int tmpnn_track_gather(const float* in, int ld_in, int W, int max_rows, const int32_t* keep, const int32_t* count,
+                       float* out, int ld_out, tmpnn_stream stream);
 
 #ifdef __cplusplus
 }

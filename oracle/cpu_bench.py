@@ -87,7 +87,10 @@ def timed(cfg, p, cases, seconds):
 def measure(frames, mean_dets, max_dets, F, H, seed, budget_s=20.0, procs=None):
     """The three CPU forms; returns a dict with the best one on top."""
     ncpu = os.cpu_count() or 1
-    procs = procs or min(16, ncpu)               # the GPU box's CPU share for one GPU
+    threads = min(16, ncpu)                      # the GPU box's CPU share for one GPU
+    # worker PROCESSES: importing torch opens the GPU device node, and a GPU box admits at most 6 processes with the
+    # card open (bench.py itself is one of them) -- so 4 workers; the batched form below uses all threads instead
+    procs = procs or min(4, ncpu)
     cfg, p = _params(F, H)
     out = {}
     # (1) one core, batch 1
@@ -116,10 +119,10 @@ def measure(frames, mean_dets, max_dets, F, H, seed, budget_s=20.0, procs=None):
         out['procs'] = dict(value=tot_e / max_t, cores=ok, edge_iterations=tot_e, seconds=round(max_t, 2),
                             wall_incl_startup=round(time.perf_counter() - t0, 1))
     # (3) block-diagonal batches, all threads of the share
-    torch.set_num_threads(procs)
+    torch.set_num_threads(threads)
     casesB = build_cases(frames, mean_dets, max_dets, F, seed, nwin=256, batch=256)
     e, t, n = timed(cfg, p, casesB, budget_s / 4)
-    out['batched'] = dict(value=e / t, cores=procs, windows_per_batch=256, edge_iterations=e, seconds=round(t, 2))
+    out['batched'] = dict(value=e / t, cores=threads, windows_per_batch=256, edge_iterations=e, seconds=round(t, 2))
     torch.set_num_threads(1)
     best = max(out, key=lambda k: out[k]['value'])
     return best, out

@@ -97,28 +97,29 @@ def _gpu_worker(rank, world, port, q):
 
     shards = [bench.build_batch(32, 7, 6.0, 20, 8, seed=r + 1, device=dev)[:2] for r in range(world)]
     model, bucket, opt = make()
-    for _ in range(2):
+    g_first = None
+    for it in range(2):
         bucket.zero()
         fwd_bwd(model, bucket, *shards[rank])
         allreduce_grads(model, bucket, world)
+        if it == 0:
+            g_first = bucket.flat.clone()
         opt.step()
     mine = torch.cat([p.detach().reshape(-1) for p in model.parameters()]).cpu()
     # every replica must hold the same parameters ...
     both = [torch.zeros_like(mine) for _ in range(world)]
     dist.all_gather(both, mine)
     same = all(torch.equal(both[0], b) for b in both)
-    # ... and they must be what ONE process computes from both shards (mean gradient, same Adam)
+    # ... and the averaged gradient must be what ONE process computes from both shards.  (Gradients, not parameters:
+    # Adam turns the rounding noise of exactly-zero gradients -- the pre-BatchNorm bias -- into +-lr updates.)
     ok_ref = True
     if rank == 0:
-        ref, rb, ropt = make()
-        for _ in range(2):
-            rb.zero()
-            for r in range(world):
-                fwd_bwd(ref, rb, *shards[r])          # gradients of both shards accumulate in the bucket
-            rb.flat.mul_(1.0 / world)
-            ropt.step()
-        refp = torch.cat([p.detach().reshape(-1) for p in ref.parameters()]).cpu()
-        ok_ref = bool(torch.allclose(refp, mine, rtol=1e-5, atol=1e-7))
+        ref, rb, _ = make()
+        rb.zero()
+        for r in range(world):
+            fwd_bwd(ref, rb, *shards[r])              # gradients of both shards accumulate in the bucket
+        rb.flat.mul_(1.0 / world)
+        ok_ref = bool((rb.flat - g_first).abs().max() <= 1e-5 * rb.flat.abs().max())
     q.put((rank, same and ok_ref and bool(torch.isfinite(mine).all())))
     dist.destroy_process_group()
 

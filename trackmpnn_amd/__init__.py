@@ -7,6 +7,7 @@ from .graph import (CallPlan, DeviceGraph, FrameGraph, device_graph_from_adjacen
 from .capture import CapturedWindow
 from .loss import CELoss, FocalLoss, create_targets
 from .track_mpnn import SparseAttention, TrackMPNN
+from .tracking import TrackGraph
 
-__all__ = ['TrackMPNN', 'CapturedWindow', 'SparseAttention', 'create_targets', 'CELoss', 'FocalLoss', 'FrameGraph', 'CallPlan', 'graph_from_adjacency', 'graph_from_edges',
+__all__ = ['TrackMPNN', 'CapturedWindow', 'TrackGraph', 'SparseAttention', 'create_targets', 'CELoss', 'FocalLoss', 'FrameGraph', 'CallPlan', 'graph_from_adjacency', 'graph_from_edges',
            'plan_single', 'DeviceGraph', 'device_graph_from_adjacency', 'WindowBuilder', 'batch_windows', 'synth_window', 'dense_static_graph', 'concat_static_graphs']

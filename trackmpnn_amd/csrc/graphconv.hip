@@ -42,10 +42,16 @@ __device__ __forceinline__ int block_excl_scan(int v, int* s_wave /* [17] */, in
     return res;
 }
 
+// FROM_ROWS: the input is the row form (type mask + per-row endpoints) instead of the COO entries: the tracker-side
+// operations (csrc/trackops.hip: append / delete) edit the graph row-wise and re-derive the index form with this.
+template <bool FROM_ROWS>
 __global__ __launch_bounds__(GC_THREADS) void k_graph_from_coo(int N, const int64_t* __restrict__ nidx,
                                                                const float* __restrict__ nval, long nnz_n,
                                                                const int64_t* __restrict__ eidx,
                                                                const float* __restrict__ eval_, long nnz_e,
+                                                               const uint8_t* __restrict__ r_is_edge,
+                                                               const int32_t* __restrict__ r_src,
+                                                               const int32_t* __restrict__ r_dst,
                                                                tmpnn_dgraph g) {
     extern __shared__ int lds[];
     float* s_diag = reinterpret_cast<float*>(lds);   // [N]  sum of the diagonal entries of node_adj
@@ -63,9 +69,21 @@ __global__ __launch_bounds__(GC_THREADS) void k_graph_from_coo(int N, const int6
     if (tid == 0) { s_flags = 0; s_off = 0; }
     __syncthreads();
 
-    // 1. scatter node_adj
+    // 1. scatter node_adj (or take the rows as given)
     int flags = 0;
-    for (long i = tid; i < nnz_n; i += GC_THREADS) {
+    if (FROM_ROWS) {
+        for (int r = tid; r < N; r += GC_THREADS) {
+            const bool e = r_is_edge[r] != 0;
+            s_diag[r] = e ? 0.f : 1.f;
+            s_cnt[r] = e ? 0x10001 : 0;
+            const int s = e ? r_src[r] : -1, d = e ? r_dst[r] : -1;
+            const bool ok = s >= 0 && s < N && d >= 0 && d < N;
+            if (e && !ok) flags |= TMPNN_DG_BAD_VALUE;
+            s_src[r] = ok ? s : -1;
+            s_dst[r] = ok ? d : -1;
+        }
+    }
+    for (long i = tid; !FROM_ROWS && i < nnz_n; i += GC_THREADS) {
         const float v = nval[i];
         if (v == 0.f) continue;                                    // explicit zeros (I_node = eye - I_edge)
         const long r = nidx[i], c = nidx[nnz_n + i];
@@ -233,10 +251,26 @@ int tmpnn_graph_from_coo(int N, const int64_t* node_idx, const float* node_val, 
     TM_REQUIRE(nnz_node >= 0 && (nnz_node == 0 || (node_idx && node_val)), "graph_from_coo: node_adj entries");
     TM_REQUIRE(nnz_edge >= 0 && (edge_idx == nullptr || nnz_edge == 0 || edge_val), "graph_from_coo: edge_adj entries");
     const size_t shm = sizeof(int) * ((size_t)8 * N + 1);
-    TM_SHM_ONCE(k_graph_from_coo, 160 * 1024 - 256);
-    hipLaunchKernelGGL(k_graph_from_coo, dim3(1), dim3(GC_THREADS), shm, as_stream(stream), N, node_idx, node_val,
-                       (long)nnz_node, edge_idx, edge_val, (long)nnz_edge, *g);
+    TM_SHM_ONCE(k_graph_from_coo<false>, 160 * 1024 - 256);
+    hipLaunchKernelGGL(k_graph_from_coo<false>, dim3(1), dim3(GC_THREADS), shm, as_stream(stream), N, node_idx, node_val,
+                       (long)nnz_node, edge_idx, edge_val, (long)nnz_edge, (const uint8_t*)nullptr, (const int32_t*)nullptr,
+                       (const int32_t*)nullptr, *g);
     return check_launch("graph_from_coo");
+}
+
+int tmpnn_graph_from_rows(int N, const uint8_t* is_edge, const int32_t* row_src, const int32_t* row_dst,
+                          const tmpnn_dgraph* g, tmpnn_stream stream) {
+    TM_REQUIRE(g != nullptr && g->meta && g->is_edge && g->pos && g->src && g->dst && g->src_pos && g->dst_pos &&
+                   g->edge_row && g->det_row && g->rowptr && g->inc, "graph_from_rows: unbound graph");
+    TM_REQUIRE(N >= 0 && N <= TMPNN_DG_MAX_ROWS && N <= g->cap && N == g->N,
+               "graph_from_rows: N=%d (limit %d, graph N=%d cap=%d)", N, TMPNN_DG_MAX_ROWS, g->N, g->cap);
+    TM_REQUIRE(N == 0 || (is_edge && row_src && row_dst), "graph_from_rows: null row arrays");
+    const size_t shm = sizeof(int) * ((size_t)8 * N + 1);
+    TM_SHM_ONCE(k_graph_from_coo<true>, 160 * 1024 - 256);
+    hipLaunchKernelGGL(k_graph_from_coo<true>, dim3(1), dim3(GC_THREADS), shm, as_stream(stream), N,
+                       (const int64_t*)nullptr, (const float*)nullptr, 0L, (const int64_t*)nullptr, (const float*)nullptr, 0L,
+                       is_edge, row_src, row_dst, *g);
+    return check_launch("graph_from_rows");
 }
 
 }  // extern "C"

@@ -1,0 +1,316 @@
+// Tracker-side graph maintenance on the device: what the reference does between two
+// model calls on the host with a DENSE N x N numpy adjacency and two PCIe crossings per timestep
+// (utils/graph.py:189-334 update_graph, :392-539 decode_tracks) is here a handful of small kernels over the ROW form
+// of the graph, which stays in HBM next to the hidden state:
+//
+//     ts[N]       timestep of a det row, -1 on edge rows            (y_pred[:, 0])
+//     det_id[N]   index of the detection in the sequence, -1 edges  (y_pred[:, 1])
+//     assoc[N]    det_id of the associated next detection, or -1    (y_pred[:, 2])
+//     is_edge[N], row_src[N], row_dst[N]                            (node_adj: +1 / -1 column of an edge row)
+//     labels[N]   ground-truth class of the row (training)
+//
+//   tmpnn_track_associate   utils/graph.py:227-268 / :431-454  y_pred[:, 2] from the labels (train) or the scores (greedy)
+//   tmpnn_track_active      :270-278                           the dets offered for association at time t (compacted)
+//   tmpnn_track_append      :283-325                           A x D new edge rows (src-major) + D new det rows, labels
+//   tmpnn_track_delete      :492-520                           which rows decode_tracks drops; compacted row form
+//   tmpnn_track_gather      :514-519                           stream compaction of the state rows (h, scores) by the kept rows
+//
+// The index form (CSR etc.) is re-derived from the rows by tmpnn_graph_from_rows (csrc/graphconv.hip).  The Hungarian
+// matching and the linked-list walk that finalises tracks stay on the host (tens of detections, scipy).  Integer work,
+// HBM/latency bound, graphs of <= TMPNN_DG_MAX_ROWS rows: single-workgroup kernels with LDS scans.
+#include "common.h"
+
+namespace tmpnn {
+
+static constexpr int TK_THREADS = 1024;
+
+__device__ __forceinline__ int tk_block_scan(int v, int* s_wave, int* total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int inc = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int t = __shfl_up(inc, off);
+        if (lane >= off) inc += t;
+    }
+    if (lane == 63) s_wave[wave] = inc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int run = 0;
+        for (int w = 0; w < TK_THREADS / 64; ++w) { const int t = s_wave[w]; s_wave[w] = run; run += t; }
+        s_wave[TK_THREADS / 64] = run;
+    }
+    __syncthreads();
+    const int res = s_wave[wave] + inc - v;
+    *total = s_wave[TK_THREADS / 64];
+    __syncthreads();
+    return res;
+}
+
+// ---- y_pred[:, 2] ------------------------------------------------------------------------------------------
+// mode 0 (train, utils/graph.py:229-245): a true-positive det is associated through its ONE label-positive future
+//   edge (more than one: status bit 1); a false positive is "associated" with itself so that it stays inactive.
+// mode 1 (inference, greedy, :251-268 / :437-454): a det scored >= 0.5 looks at its future edges scored >= 0.5 that
+//   lead to a det scored >= 0.5, keeps those of the NEAREST timestep (rows before the first det row after the first
+//   such edge) and takes the highest score (first of equals).
+__global__ __launch_bounds__(256) void k_track_associate(tmpnn_dgraph g, const int32_t* __restrict__ det_id,
+                                                         const uint8_t* __restrict__ labels,
+                                                         const float* __restrict__ score, int mode,
+                                                         int32_t* __restrict__ assoc, int32_t* __restrict__ status) {
+    const int N = g.N, Dn = g.meta[1];
+    for (int r = blockIdx.x * 256 + threadIdx.x; r < N; r += gridDim.x * 256)
+        if (g.is_edge[r]) assoc[r] = -1;
+    for (int d = blockIdx.x * 256 + threadIdx.x; d < Dn; d += gridDim.x * 256) {
+        const int row = g.det_row[d];
+        const int p0 = g.rowptr[d], p1 = g.rowptr[d + 1];
+        int out = -1;
+        if (mode == 0) {
+            if (labels[row]) {
+                int cnt = 0;
+                for (int p = p0; p < p1; ++p) {
+                    const int key = g.inc[p];
+                    if (key < 0) continue;                        // past edge (this det is its later endpoint)
+                    if (labels[key]) { ++cnt; out = det_id[g.dst[g.pos[key]]]; }
+                }
+                if (cnt > 1) { atomicOr(status, 1); }
+                if (cnt != 1) out = cnt == 0 ? -1 : out;
+            } else {
+                out = det_id[row];
+            }
+        } else if (score[row] >= 0.5f) {
+            int first = -1;
+            for (int p = p0; p < p1 && first < 0; ++p) {
+                const int key = g.inc[p];
+                if (key < 0) continue;
+                if (score[key] >= 0.5f && score[g.dst[g.pos[key]]] >= 0.5f) first = key;
+            }
+            if (first >= 0) {
+                // first det row after `first`: det_row is ascending -> binary search
+                int lo = 0, hi = Dn;
+                while (lo < hi) { const int mid = (lo + hi) >> 1; if (g.det_row[mid] > first) hi = mid; else lo = mid + 1; }
+                const int limit = lo < Dn ? g.det_row[lo] : N;
+                float best = -1.f;
+                int best_e = -1;
+                for (int p = p0; p < p1; ++p) {
+                    const int key = g.inc[p];
+                    if (key < 0 || key < first || key >= limit) continue;
+                    const float s = score[key];
+                    if (s >= 0.5f && score[g.dst[g.pos[key]]] >= 0.5f && s > best) { best = s; best_e = key; }
+                }
+                if (best_e >= 0) out = det_id[g.dst[g.pos[best_e]]];
+            }
+        }
+        assoc[row] = out;
+    }
+}
+
+// ---- active set (utils/graph.py:270-278), ascending rows ----------------------------------------------------------
+// train: det rows not yet associated, or of the last timestep before t.   inference: unassociated dets scored >= 0.5.
+__global__ __launch_bounds__(TK_THREADS) void k_track_active(int N, const int32_t* __restrict__ ts,
+                                                             const int32_t* __restrict__ assoc,
+                                                             const float* __restrict__ score, int mode, int t,
+                                                             int32_t* __restrict__ active, int32_t* __restrict__ count) {
+    __shared__ int s_wave[TK_THREADS / 64 + 1];
+    __shared__ int s_tprev;
+    const int tid = threadIdx.x;
+    if (tid == 0) s_tprev = -2147483647;
+    __syncthreads();
+    if (mode == 0) {
+        int m = -2147483647;
+        for (int r = tid; r < N; r += TK_THREADS) { const int v = ts[r]; if (v < t && v > m) m = v; }
+        atomicMax(&s_tprev, m);
+        __syncthreads();
+    }
+    const int tprev = s_tprev;
+    const int IT = (N + TK_THREADS - 1) / TK_THREADS;
+    const int r0 = tid * IT, r1 = min(N, r0 + IT);
+    auto is_active = [&](int r) {
+        const int v = ts[r];
+        if (v == -1) return false;
+        if (mode == 0) return assoc[r] == -1 || v == tprev;
+        return assoc[r] == -1 && score[r] >= 0.5f;
+    };
+    int mine = 0;
+    for (int r = r0; r < r1; ++r) mine += is_active(r) ? 1 : 0;
+    int total;
+    int p = tk_block_scan(mine, s_wave, &total);
+    for (int r = r0; r < r1; ++r)
+        if (is_active(r)) active[p++] = r;
+    if (tid == 0) count[0] = total;
+}
+
+// ---- append the block of timestep t (utils/graph.py:283-325) ------------------------------------------------------
+// rows [N, N + A*D): edge (a, j) at N + a*D + j with src = active[a], dst = N + A*D + j ; rows [N + A*D, N + A*D + D): dets.
+// labels (training): det j is positive iff its track id >= 0; edge (a, j) iff both belong to the same track.
+__global__ __launch_bounds__(256) void k_track_append(int N, int A, int D, const int32_t* __restrict__ active,
+                                                      const int32_t* __restrict__ new_ids, int t,
+                                                      const int32_t* __restrict__ track /* [ND] or NULL */,
+                                                      int32_t* __restrict__ ts, int32_t* __restrict__ det_id,
+                                                      int32_t* __restrict__ assoc, uint8_t* __restrict__ is_edge,
+                                                      int32_t* __restrict__ row_src, int32_t* __restrict__ row_dst,
+                                                      uint8_t* __restrict__ labels) {
+    const int n = A * D + D;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        const int r = N + i;
+        assoc[r] = -1;
+        if (i < A * D) {
+            const int a = i / D, j = i % D;
+            const int s = active[a];
+            ts[r] = -1; det_id[r] = -1; is_edge[r] = 1;
+            row_src[r] = s; row_dst[r] = N + A * D + j;
+            if (labels) {
+                const int ta = track ? track[det_id[s]] : -1, tj = track ? track[new_ids[j]] : -1;
+                labels[r] = (tj != -1 && ta == tj) ? 1 : 0;
+            }
+        } else {
+            const int j = i - A * D;
+            ts[r] = t; det_id[r] = new_ids[j]; is_edge[r] = 0;
+            row_src[r] = -1; row_dst[r] = -1;
+            if (labels) labels[r] = (track && track[new_ids[j]] >= 0) ? 1 : 0;
+        }
+    }
+}
+
+// ---- rows decode_tracks deletes (utils/graph.py:492-512) + the compacted row form ------------------------------
+// max_id = 1 + the last det row before t_upto.  Deleted: every row < max_id except the dets RETAINED for later
+// association (unassociated, scored >= 0.5, not older than t_upto - ret_win); and every edge row >= max_id that
+// starts at a deleted det.  Kept rows are renumbered in order; row_src / row_dst follow.
+__global__ __launch_bounds__(TK_THREADS) void k_track_delete(int N, const int32_t* __restrict__ ts,
+                                                             const int32_t* __restrict__ det_id,
+                                                             const int32_t* __restrict__ assoc,
+                                                             const float* __restrict__ score,
+                                                             const uint8_t* __restrict__ is_edge,
+                                                             const int32_t* __restrict__ row_src,
+                                                             const int32_t* __restrict__ row_dst,
+                                                             const uint8_t* __restrict__ labels, int t_upto, int ret_win,
+                                                             int32_t* __restrict__ keep /* [N]: kept rows, ascending */,
+                                                             int32_t* __restrict__ count,
+                                                             int32_t* __restrict__ o_ts, int32_t* __restrict__ o_det_id,
+                                                             int32_t* __restrict__ o_assoc, uint8_t* __restrict__ o_is_edge,
+                                                             int32_t* __restrict__ o_src, int32_t* __restrict__ o_dst,
+                                                             uint8_t* __restrict__ o_labels) {
+    extern __shared__ int s_new[];                         // [N] new index of a kept row, -1 if deleted
+    __shared__ int s_wave[TK_THREADS / 64 + 1];
+    __shared__ int s_max;
+    const int tid = threadIdx.x;
+    if (tid == 0) s_max = 0;
+    __syncthreads();
+    int m = 0;
+    for (int r = tid; r < N; r += TK_THREADS) { const int v = ts[r]; if (v != -1 && v < t_upto) m = max(m, r + 1); }
+    atomicMax(&s_max, m);
+    __syncthreads();
+    const int max_id = s_max;
+    auto retained = [&](int r) {       // det row < max_id that survives
+        return assoc[r] == -1 && score[r] >= 0.5f && ts[r] >= t_upto - ret_win;
+    };
+    auto kept = [&](int r) {
+        if (r < max_id) return !is_edge[r] && retained(r);
+        if (!is_edge[r]) return true;
+        const int s = row_src[r];                           // an edge at or after max_id: dropped with its start det
+        return !(s < max_id && !retained(s));
+    };
+    const int IT = (N + TK_THREADS - 1) / TK_THREADS;
+    const int r0 = tid * IT, r1 = min(N, r0 + IT);
+    int mine = 0;
+    for (int r = r0; r < r1; ++r) mine += kept(r) ? 1 : 0;
+    int total;
+    int p = tk_block_scan(mine, s_wave, &total);
+    for (int r = r0; r < r1; ++r) {
+        if (kept(r)) { s_new[r] = p; keep[p] = r; ++p; }
+        else s_new[r] = -1;
+    }
+    __syncthreads();
+    for (int r = tid; r < N; r += TK_THREADS) {
+        const int q = s_new[r];
+        if (q < 0) continue;
+        o_ts[q] = ts[r]; o_det_id[q] = det_id[r]; o_assoc[q] = assoc[r]; o_is_edge[q] = is_edge[r];
+        if (o_labels) o_labels[q] = labels ? labels[r] : 0;
+        if (is_edge[r]) { o_src[q] = s_new[row_src[r]]; o_dst[q] = s_new[row_dst[r]]; }
+        else { o_src[q] = -1; o_dst[q] = -1; }
+    }
+    if (tid == 0) count[0] = total;
+}
+
+// out[q, :] = in[keep[q], :] for q < count (count read on the device: the launch is sized for the worst case)
+__global__ __launch_bounds__(256) void k_track_gather(const float* __restrict__ in, int ld_in, int W,
+                                                      const int32_t* __restrict__ keep, const int32_t* __restrict__ count,
+                                                      float* __restrict__ out, int ld_out) {
+    const int n = count[0];
+    const int lpr = (W + 3) / 4;
+    const long total = (long)n * lpr;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int q = (int)(i / lpr), c = (int)(i % lpr) * 4;
+        const float* src = in + (size_t)keep[q] * ld_in + c;
+        float* dst = out + (size_t)q * ld_out + c;
+        if (c + 4 <= W && ((ld_in | ld_out) & 3) == 0) *reinterpret_cast<float4*>(dst) = *reinterpret_cast<const float4*>(src);
+        else for (int k = 0; k < 4 && c + k < W; ++k) dst[k] = src[k];
+    }
+}
+
+}  // namespace tmpnn
+
+using namespace tmpnn;
+
+extern "C" {
+
+int tmpnn_track_associate(const tmpnn_dgraph* g, const int32_t* det_id, const uint8_t* labels, const float* score,
+                          int mode, int32_t* assoc, int32_t* status, tmpnn_stream stream) {
+    TM_REQUIRE(g && g->meta && det_id && assoc && status, "track_associate: null pointer");
+    TM_REQUIRE(mode == 0 ? labels != nullptr : (mode == 1 && score != nullptr), "track_associate: mode %d needs %s", mode,
+               mode == 0 ? "labels" : "scores");
+    if (g->N == 0) return TMPNN_OK;
+    hipLaunchKernelGGL(k_track_associate, dim3(ceil_div(g->N, 256)), dim3(256), 0, as_stream(stream), *g, det_id, labels,
+                       score, mode, assoc, status);
+    return check_launch("track_associate");
+}
+
+int tmpnn_track_active(int N, const int32_t* ts, const int32_t* assoc, const float* score, int mode, int t,
+                       int32_t* active, int32_t* count, tmpnn_stream stream) {
+    TM_REQUIRE(N >= 0 && N <= TMPNN_DG_MAX_ROWS, "track_active: N=%d (limit %d)", N, TMPNN_DG_MAX_ROWS);
+    TM_REQUIRE(ts && assoc && active && count && (mode == 0 || score), "track_active: null pointer");
+    hipLaunchKernelGGL(k_track_active, dim3(1), dim3(TK_THREADS), 0, as_stream(stream), N, ts, assoc, score, mode, t,
+                       active, count);
+    return check_launch("track_active");
+}
+
+int tmpnn_track_append(int N, int A, int D, const int32_t* active, const int32_t* new_ids, int t, const int32_t* track,
+                       int32_t* ts, int32_t* det_id, int32_t* assoc, uint8_t* is_edge, int32_t* row_src,
+                       int32_t* row_dst, uint8_t* labels, tmpnn_stream stream) {
+    TM_REQUIRE(N >= 0 && A >= 0 && D >= 0 && (long)N + (long)A * D + D <= TMPNN_DG_MAX_ROWS,
+               "track_append: N=%d A=%d D=%d exceeds %d rows", N, A, D, TMPNN_DG_MAX_ROWS);
+    if (D == 0) return TMPNN_OK;
+    TM_REQUIRE((A == 0 || active) && new_ids && ts && det_id && assoc && is_edge && row_src && row_dst,
+               "track_append: null pointer");
+    const int n = A * D + D;
+    hipLaunchKernelGGL(k_track_append, dim3(ceil_div(n, 256)), dim3(256), 0, as_stream(stream), N, A, D, active, new_ids,
+                       t, track, ts, det_id, assoc, is_edge, row_src, row_dst, labels);
+    return check_launch("track_append");
+}
+
+int tmpnn_track_delete(int N, const int32_t* ts, const int32_t* det_id, const int32_t* assoc, const float* score,
+                       const uint8_t* is_edge, const int32_t* row_src, const int32_t* row_dst, const uint8_t* labels,
+                       int t_upto, int ret_win, int32_t* keep, int32_t* count, int32_t* o_ts, int32_t* o_det_id,
+                       int32_t* o_assoc, uint8_t* o_is_edge, int32_t* o_src, int32_t* o_dst, uint8_t* o_labels,
+                       tmpnn_stream stream) {
+    TM_REQUIRE(N >= 0 && N <= TMPNN_DG_MAX_ROWS, "track_delete: N=%d (limit %d)", N, TMPNN_DG_MAX_ROWS);
+    TM_REQUIRE(ts && det_id && assoc && score && is_edge && row_src && row_dst && keep && count && o_ts && o_det_id &&
+                   o_assoc && o_is_edge && o_src && o_dst, "track_delete: null pointer");
+    hipLaunchKernelGGL(k_track_delete, dim3(1), dim3(TK_THREADS), sizeof(int) * (size_t)(N > 0 ? N : 1), as_stream(stream),
+                       N, ts, det_id, assoc, score, is_edge, row_src, row_dst, labels, t_upto, ret_win, keep, count, o_ts,
+                       o_det_id, o_assoc, o_is_edge, o_src, o_dst, o_labels);
+    return check_launch("track_delete");
+}
+
+int tmpnn_track_gather(const float* in, int ld_in, int W, int max_rows, const int32_t* keep, const int32_t* count,
+                       float* out, int ld_out, tmpnn_stream stream) {
+    TM_REQUIRE(W > 0 && ld_in >= W && ld_out >= W && max_rows >= 0, "track_gather: W=%d ld_in=%d ld_out=%d", W, ld_in, ld_out);
+    if (max_rows == 0) return TMPNN_OK;
+    TM_REQUIRE(in && keep && count && out, "track_gather: null pointer");
+    TM_REQUIRE(aligned16(in) && aligned16(out), "track_gather: 16-byte alignment");
+    long blocks = ((long)max_rows * ((W + 3) / 4) + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(k_track_gather, dim3((int)blocks), dim3(256), 0, as_stream(stream), in, ld_in, W, keep, count, out,
+                       ld_out);
+    return check_launch("track_gather");
+}
+
+}  // extern "C"

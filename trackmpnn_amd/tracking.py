@@ -1,0 +1,265 @@
+"""The rolling tracking graph kept ON THE DEVICE between model calls.
+
+Mirror of the reference's graph bookkeeping -- `initialize_graph`, `update_graph`, `decode_tracks`
+(reference/utils/graph.py:96-186, 189-334, 392-539) -- with the same arguments' meaning and the same results, but
+the graph and the hidden state never visit the host: the graph lives in HBM in row form (csrc/trackops.hip), is
+edited by small kernels (association rule, active set, block append, row deletion as a stream compaction) and its index
+form (`DeviceGraph`) is re-derived on the device after every edit.  What stays on the host is what the reference itself
+solves with scipy / Python on a few dozen detections: the Hungarian matching and the walk that finalises tracks
+(`y_out`); they read a handful of int32 per row, never the state.
+
+    tg, feats, t_st, t_end = TrackGraph.initialize(X, y, t_st=0, mode='test', device='cuda:0')
+    scores, logits, h, _ = model.forward_dgraph(feats, None, tg.graph)
+    for t in range(t_st, t_end):
+        feats = tg.update(scores[:, 0], X, y, t, mode='test')                   # update_graph
+        scores, logits, h, _ = model.forward_dgraph(feats, h, tg.graph)
+        h, sc = tg.decode(h, scores[:, 0], y_out, t - cur_win + 2, ret_win)    # decode_tracks
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib
+from .graph import DG_MAX_ROWS, DeviceGraph
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+class TrackGraph:
+    """Row form (+ index form) of one sequence's rolling graph on the device."""
+
+    def __init__(self, device, cap: int = DG_MAX_ROWS):
+        self.device = torch.device(device)
+        self.cap = cap
+        self.N = 0
+        i32 = dict(dtype=torch.int32, device=self.device)
+        u8 = dict(dtype=torch.uint8, device=self.device)
+        # two sets of row arrays: deletion compacts from one into the other
+        self._rows = [dict(ts=torch.empty(cap, **i32), det_id=torch.empty(cap, **i32), assoc=torch.empty(cap, **i32),
+                           is_edge=torch.empty(cap, **u8), src=torch.empty(cap, **i32), dst=torch.empty(cap, **i32),
+                           labels=torch.empty(cap, **u8)) for _ in range(2)]
+        self._cur = 0
+        self._active = torch.empty(cap, **i32)
+        self._keep = torch.empty(cap, **i32)
+        self._small = torch.zeros(4, **i32)              # [0] count, [1] status
+        self.track: Optional[torch.Tensor] = None        # int32 [ND] track id of every detection (training labels)
+        self.graph: Optional[DeviceGraph] = None
+
+    @property
+    def rows(self):
+        return self._rows[self._cur]
+
+    def y_pred(self) -> torch.Tensor:
+        """[N, 3] int64 as the reference keeps it (ts, det id, associated det id)."""
+        r = self.rows
+        return torch.stack([r['ts'][:self.N], r['det_id'][:self.N], r['assoc'][:self.N]], 1).long()
+
+    def labels(self) -> torch.Tensor:
+        return self.rows['labels'][:self.N].long()
+
+    def _rebuild(self) -> None:
+        r = self.rows
+        g = DeviceGraph(self.N, self.device)
+        _lib.call('tmpnn_graph_from_rows', self.N, r['is_edge'].data_ptr(), r['src'].data_ptr(), r['dst'].data_ptr(),
+                  g.cref(), _stream())
+        self.graph = g
+
+    # ---------------------------------------------------------------------------------------------------------------
+    @classmethod
+    def initialize(cls, X: torch.Tensor, y: torch.Tensor, t_st: int = 0, mode: str = 'test', device='cuda:0'):
+        """reference initialize_graph (utils/graph.py:96-186): the first two non-empty timesteps at or after t_st.
+        Returns (graph, feats [N, F] on the device, next timestep, end timestep) or None where the reference returns
+        Nones.  (Built on the host: there is no device state yet and the block is a few dozen rows.)"""
+        assert X.shape[0] == y.shape[0] == 1 and X.shape[1] == y.shape[1], 'Only batch size 1 supported!'
+        yy = y[0].detach().cpu().numpy().astype(np.int64)
+        times = np.unique(yy[:, 0])
+        later = times[times >= t_st]
+        if later.size < 2 or ((yy[:, 1] == -1).all() and mode == 'train'):
+            return None
+        t0, t1, tN = int(later[0]), int(later[1]), int(times[-1])
+        ids0, ids1 = np.nonzero(yy[:, 0] == t0)[0], np.nonzero(yy[:, 0] == t1)[0]
+        n0, n1 = ids0.size, ids1.size
+        N = n0 + n0 * n1 + n1
+        if N > DG_MAX_ROWS:
+            raise ValueError(f'TrackGraph: {N} rows exceed the device-resident limit of {DG_MAX_ROWS}')
+        ts = np.full(N, -1, np.int32)
+        did = np.full(N, -1, np.int32)
+        ts[:n0], ts[n0 + n0 * n1:] = t0, t1
+        did[:n0], did[n0 + n0 * n1:] = ids0, ids1
+        is_edge = (ts == -1).astype(np.uint8)
+        src = np.full(N, -1, np.int32)
+        dst = np.full(N, -1, np.int32)
+        src[n0:n0 + n0 * n1] = np.repeat(np.arange(n0), n1)
+        dst[n0:n0 + n0 * n1] = n0 + n0 * n1 + np.tile(np.arange(n1), n0)
+        lab = np.zeros(N, np.uint8)
+        trk = yy[:, 1]
+        lab[:n0] = trk[ids0] >= 0
+        lab[n0 + n0 * n1:] = trk[ids1] >= 0
+        same = (trk[ids0][:, None] == trk[ids1][None, :]) & (trk[ids1][None, :] != -1)
+        if (same.sum(0) > 1).any():
+            raise AssertionError('More than one detection from same timestep assinged to same track!')
+        lab[n0:n0 + n0 * n1] = same.reshape(-1)
+        tg = cls(device)
+        tg.N = N
+        r = tg.rows
+        for key, arr in (('ts', ts), ('det_id', did), ('is_edge', is_edge), ('src', src), ('dst', dst), ('labels', lab)):
+            r[key][:N].copy_(torch.from_numpy(arr))
+        r['assoc'][:N].fill_(-1)
+        tg.track = torch.from_numpy(trk.astype(np.int32)).to(tg.device)
+        tg._rebuild()
+        Xd = X[0].to(tg.device)
+        feats = torch.zeros((N, X.shape[2]), dtype=Xd.dtype, device=tg.device)
+        feats[:n0] = Xd[torch.from_numpy(ids0).to(tg.device)]
+        feats[n0 + n0 * n1:] = Xd[torch.from_numpy(ids1).to(tg.device)]
+        return tg, feats, t1 + 1, tN + 1
+
+    # ---------------------------------------------------------------------------------------------------------------
+    def _associate(self, score_pos: Optional[torch.Tensor], mode: str, use_hungarian: bool) -> None:
+        r = self.rows
+        if mode != 'train' and use_hungarian:
+            self._hungarian(score_pos)
+            return
+        self._small[1] = 0
+        _lib.call('tmpnn_track_associate', self.graph.cref(), r['det_id'].data_ptr(),
+                  r['labels'].data_ptr() if mode == 'train' else None,
+                  score_pos.data_ptr() if mode != 'train' else None, 0 if mode == 'train' else 1,
+                  r['assoc'].data_ptr(), self._small[1:].data_ptr(), _stream())
+
+    def _hungarian(self, score_pos: torch.Tensor) -> None:
+        """Frame-by-frame optimal assignment (reference hungarian(), utils/graph.py:33-93) on the host: a few dozen
+        detections, scipy's linear_sum_assignment; cost of an association = P(edge is negative) = 1 - score."""
+        from scipy.optimize import linear_sum_assignment
+        g = self.graph.frame_graph()
+        N = self.N
+        r = self.rows
+        ts = r['ts'][:N].cpu().numpy()
+        did = r['det_id'][:N].cpu().numpy()
+        sc = score_pos[:N].detach().float().cpu().numpy()
+        src, dst, erow = g.src.cpu().numpy(), g.dst.cpu().numpy(), g.edge_row.cpu().numpy()
+        assoc = np.full(N, -1, np.int32)
+        det_ts = ts[ts >= 0]
+        if det_ts.size:
+            for t in range(int(ts[0]), int(ts[N - 1]) + 1):
+                cur = np.nonzero(ts == t)[0]
+                if cur.size == 0:
+                    continue
+                into = np.isin(dst, cur)
+                prev = np.unique(src[into])
+                prev = prev[assoc[prev] == -1]                   # already associated earlier in this sweep: taken
+                if prev.size == 0 or not into.any():
+                    continue
+                cost = np.full((prev.size, cur.size), 100.0, np.float32)
+                pi = {int(p): i for i, p in enumerate(prev)}
+                ci = {int(c): j for j, c in enumerate(cur)}
+                for e in np.nonzero(into)[0]:
+                    i = pi.get(int(src[e]))
+                    if i is not None:
+                        cost[i, ci[int(dst[e])]] = 1.0 - sc[erow[e]]
+                for i, j in zip(*linear_sum_assignment(cost)):
+                    if cost[i, j] <= 0.5:
+                        assoc[prev[i]] = did[cur[j]]
+        r['assoc'][:N].copy_(torch.from_numpy(assoc))
+
+    def update(self, score_pos: Optional[torch.Tensor], X: torch.Tensor, y: torch.Tensor, t: int, mode: str = 'test',
+               use_hungarian: bool = False) -> torch.Tensor:
+        """reference update_graph (utils/graph.py:189-334): re-derive the associations, pick the active dets, append
+        the A x D_t edge rows and the D_t det rows of timestep t.  score_pos: P(positive) per row [N] (unused in
+        training).  Returns the features of the new rows [A*D_t + D_t, F] (zeros on edge rows), on the device.
+        One host read: the size of the active set."""
+        sp = None
+        if mode != 'train':
+            sp = score_pos.detach().reshape(-1).float().contiguous()
+        r = self.rows
+        N = self.N
+        self._associate(sp, mode, use_hungarian)
+        _lib.call('tmpnn_track_active', N, r['ts'].data_ptr(), r['assoc'].data_ptr(), _lib.ptr(sp),
+                  0 if mode == 'train' else 1, int(t), self._active.data_ptr(), self._small.data_ptr(), _stream())
+        yy = y[0].detach().cpu().numpy()
+        ids_t = np.nonzero(yy[:, 0] == t)[0]
+        D = int(ids_t.size)
+        A, status = self._small[:2].tolist()
+        if status & 1:
+            raise AssertionError('More than one GT edge from same node!')
+        n_new = A * D + D
+        Xd = X[0]
+        if D == 0:
+            return torch.zeros((0, X.shape[2]), dtype=Xd.dtype, device=self.device)
+        if N + n_new > self.cap:
+            raise ValueError(f'TrackGraph: {N + n_new} rows exceed the device-resident limit of {self.cap}')
+        ids_dev = torch.from_numpy(ids_t.astype(np.int32)).to(self.device)
+        _lib.call('tmpnn_track_append', N, A, D, self._active.data_ptr(), ids_dev.data_ptr(), int(t),
+                  self.track.data_ptr() if self.track is not None else None,
+                  r['ts'].data_ptr(), r['det_id'].data_ptr(), r['assoc'].data_ptr(), r['is_edge'].data_ptr(),
+                  r['src'].data_ptr(), r['dst'].data_ptr(), r['labels'].data_ptr(), _stream())
+        self.N = N + n_new
+        self._rebuild()
+        feats = torch.zeros((n_new, X.shape[2]), dtype=Xd.dtype, device=self.device)
+        feats[A * D:] = Xd.to(self.device)[ids_dev.long()]
+        return feats
+
+    # ---------------------------------------------------------------------------------------------------------------
+    def decode(self, h: torch.Tensor, score_pos: torch.Tensor, y_out: np.ndarray, t_upto: int, ret_win_size: int,
+               use_hungarian: bool = False) -> Tuple[torch.Tensor, torch.Tensor]:
+        """reference decode_tracks (utils/graph.py:392-539): re-derive the associations from the scores, finalise
+        tracks up to t_upto into y_out (host array [ND, 2], updated in place) and delete the decoded part of the
+        graph.  The hidden state `h` [N, G*H] and the scores are compacted ON THE DEVICE; returns (h', score_pos')."""
+        N = self.N
+        sp = score_pos.detach().reshape(-1).float().contiguous()
+        r = self.rows
+        self._associate(sp, 'test', use_hungarian)
+        # ---- host: which detections join which track (a walk along the association links)
+        ts = r['ts'][:N].cpu().numpy()
+        did = r['det_id'][:N].cpu().numpy()
+        assoc = r['assoc'][:N].cpu().numpy()
+        sc = sp[:N].cpu().numpy()
+        row_of = {int(d): i for i, d in enumerate(did) if d >= 0}
+        next_track = int(y_out[:, 1].max()) + 1
+        seen = np.zeros(y_out.shape[0], bool)
+        for det in range(y_out.shape[0]):
+            row = row_of.get(det)
+            if row is None or ts[row] >= t_upto or sc[row] < 0.5 or seen[det]:
+                seen[det] = seen[det] or row is None or ts[row] >= t_upto or sc[row] < 0.5
+                continue
+            if y_out[det, 1] == -1:
+                track, next_track = next_track, next_track + 1
+            else:
+                track = int(y_out[det, 1])
+            d = det
+            while True:
+                seen[d] = True
+                y_out[d, 1] = track
+                nxt = int(assoc[row_of[d]])
+                if nxt == -1 or (y_out[d, 0] >= t_upto and y_out[nxt, 0] >= t_upto):
+                    break
+                d = nxt
+        # ---- device: deletion as a stream compaction of rows, state and scores
+        o = self._rows[1 - self._cur]
+        _lib.call('tmpnn_track_delete', N, r['ts'].data_ptr(), r['det_id'].data_ptr(), r['assoc'].data_ptr(),
+                  sp.data_ptr(), r['is_edge'].data_ptr(), r['src'].data_ptr(), r['dst'].data_ptr(),
+                  r['labels'].data_ptr(), int(t_upto), int(ret_win_size), self._keep.data_ptr(), self._small.data_ptr(),
+                  o['ts'].data_ptr(), o['det_id'].data_ptr(), o['assoc'].data_ptr(), o['is_edge'].data_ptr(),
+                  o['src'].data_ptr(), o['dst'].data_ptr(), o['labels'].data_ptr(), _stream())
+        hd = h.detach()
+        hd = hd if (hd.dtype == torch.float32 and hd.is_contiguous()) else hd.float().contiguous()
+        W = int(hd.shape[1])
+        h_new = torch.empty((N, W), dtype=torch.float32, device=self.device)
+        s_new = torch.empty((N, 1), dtype=torch.float32, device=self.device)
+        _lib.call('tmpnn_track_gather', hd.data_ptr(), W, W, N, self._keep.data_ptr(), self._small.data_ptr(),
+                  h_new.data_ptr(), W, _stream())
+        _lib.call('tmpnn_track_gather', sp.data_ptr(), 1, 1, N, self._keep.data_ptr(), self._small.data_ptr(),
+                  s_new.data_ptr(), 1, _stream())
+        n_keep = int(self._small[0].item())
+        self._cur = 1 - self._cur
+        self.N = n_keep
+        self._rebuild()
+        return h_new[:n_keep], s_new[:n_keep, 0]
+
+    def kept_rows(self) -> torch.Tensor:
+        """Rows of the previous graph that the last decode() kept (ascending)."""
+        return self._keep[:self.N].long()
