@@ -11,6 +11,7 @@
 // CSR run in a fixed order and combines the row groups with xor-shuffles, so results are bitwise
 // reproducible (no float atomics anywhere).
 #include "common.h"
+#include <stdlib.h>
 
 namespace tmpnn {
 
@@ -150,6 +151,195 @@ __global__ __launch_bounds__(256) void k_segsum(int Dn, const int32_t* __restric
     }
 }
 
+
+// ------------------------------------------------------------------------------------------
+// Software-pipelined forms (round 2).  Both row movers are chains of DEPENDENT loads -- index -> row for the gather,
+// visiting order -> rowptr -> incidence -> row for the segment sum -- and with one chain per lane group in flight
+// the memory system idles while the indices travel (measured: the edge rows are fetched from HBM exactly once and the
+// det table comes out of L2, yet both kernels sat at 3.0-3.2 TB/s of algorithmic traffic).  Here every lane group
+// issues the index loads of its NEXT item(s) right behind the row loads of the current one, so the row loads of
+// consecutive items follow each other without an index round trip in between.  Same arithmetic, same summation
+// order, bit-identical results.
+// ------------------------------------------------------------------------------------------
+template <bool CONCAT, bool ACC>
+__global__ __launch_bounds__(256) void k_gather_pipe(int E, const int32_t* __restrict__ src,
+                                                     const int32_t* __restrict__ dst,
+                                                     const int32_t* __restrict__ edge_row,
+                                                     const float* __restrict__ in, int ld_in,
+                                                     float* __restrict__ out, int ld_out, int H) {
+    const int lpr = H >> 2;
+    const int rpb = 256 / lpr;
+    const int c4 = (threadIdx.x % lpr) * 4;
+    const int slot = threadIdx.x / lpr;
+    constexpr int U = 4;
+    // a block owns CONSECUTIVE chunks of U * rpb edges: the dets an edge block refers to (one src per D_t consecutive
+    // edges, the same D_t dst rows over and over) stay in this CU's L1 across the chunk
+    const long chunk = (long)rpb * U;
+    long e0 = (long)blockIdx.x * chunk + slot;
+    const long step = (long)gridDim.x * chunk;
+    int s[U], d[U], r[U];
+    auto load_ids = [&](long base) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const long e = base + (long)u * rpb;
+            const long ec = e < E ? e : (E - 1);
+            s[u] = src[ec]; d[u] = dst[ec]; r[u] = edge_row[ec];
+        }
+    };
+    if (e0 < E) load_ids(e0);
+    for (; e0 < E; e0 += step) {
+        float4 a[U], b[U];
+        int rr[U];
+        bool ok[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            ok[u] = e0 + (long)u * rpb < E;
+            rr[u] = r[u];
+            a[u] = *reinterpret_cast<const float4*>(in + (size_t)s[u] * ld_in + c4);
+            b[u] = *reinterpret_cast<const float4*>(in + (size_t)d[u] * ld_in + c4);
+        }
+        if (e0 + step < E) load_ids(e0 + step);            // next chunk's indices travel while the rows arrive
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (!ok[u]) continue;
+            float* o = out + (size_t)rr[u] * ld_out + c4;
+            if (!CONCAT) {
+                float4 v = make_float4(a[u].x - b[u].x, a[u].y - b[u].y, a[u].z - b[u].z, a[u].w - b[u].w);
+                if (ACC) {
+                    const float4 p = *reinterpret_cast<const float4*>(o);
+                    v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w;
+                }
+                *reinterpret_cast<float4*>(o) = v;
+            } else {
+                float4 va = a[u], vb = b[u];
+                if (ACC) {
+                    const float4 p = *reinterpret_cast<const float4*>(o);
+                    const float4 q = *reinterpret_cast<const float4*>(o + H);
+                    va.x += p.x; va.y += p.y; va.z += p.z; va.w += p.w;
+                    vb.x += q.x; vb.y += q.y; vb.z += q.z; vb.w += q.w;
+                }
+                *reinterpret_cast<float4*>(o) = va;
+                *reinterpret_cast<float4*>(o + H) = vb;
+            }
+        }
+    }
+}
+
+template <bool ACC>
+__global__ __launch_bounds__(256) void k_segsum_pipe(int Dn, const int32_t* __restrict__ det_row,
+                                                     const int32_t* __restrict__ rowptr,
+                                                     const int32_t* __restrict__ inc,
+                                                     const int32_t* __restrict__ det_order,
+                                                     const float* __restrict__ in, int ld_in,
+                                                     float* __restrict__ out, int ld_out, int H,
+                                                     float wneg, int cneg, int compact_out) {
+    const int lane = threadIdx.x & 63;
+    const int lpr = H >> 2;
+    const int ngrp = 64 / lpr;
+    const int grp = lane / lpr;
+    const int c4 = (lane % lpr) * 4;
+    constexpr int U = 4;
+    constexpr int SEG_CHUNK = 64;
+    const int wv = threadIdx.x >> 6;
+    // a wave's dets: positions base + wv, base + wv + 4, ... of consecutive 64-entry chunks of the visiting order,
+    // flattened into one sequence so that the pipeline runs across chunk boundaries
+    const long nchunk = (Dn + SEG_CHUNK - 1) / SEG_CHUNK;
+    auto item_pos = [&](long k) -> long {             // k-th det position of this wave, or -1
+        const long per = SEG_CHUNK / 4;                // 16 dets of a chunk per wave
+        const long ch = (long)blockIdx.x + (k / per) * gridDim.x;
+        if (ch >= nchunk) return -1;
+        const long i = ch * SEG_CHUNK + wv + (k % per) * 4;
+        return i < Dn ? i : -2;                        // -2: hole at the tail of the last chunk (skip, keep going)
+    };
+    // stage A: det id ; stage B: its CSR range ; stage C: its first U incidences per group
+    long kA = 0;
+    int dA = -1, dB = -1, p0B = 0, p1B = 0, dC = -1, p0C = 0, p1C = 0, vC[U];
+    auto fetchA = [&]() {
+        long pos;
+        do { pos = item_pos(kA++); } while (pos == -2);
+        dA = pos < 0 ? -1 : (det_order ? det_order[pos] : (int)pos);
+    };
+    auto advanceB = [&]() {
+        dB = dA;
+        if (dB >= 0) { p0B = rowptr[dB]; p1B = rowptr[dB + 1]; }
+    };
+    auto advanceC = [&]() {
+        dC = dB; p0C = p0B; p1C = p1B;
+        if (dC >= 0) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int p = p0C + grp + u * ngrp;
+                vC[u] = p < p1C ? inc[p] : 0x7fffffff;
+            }
+        }
+    };
+    fetchA(); advanceB(); fetchA(); advanceC(); advanceB(); fetchA();
+    while (dC >= 0) {
+        const int d = dC, p0 = p0C, p1 = p1C;
+        float4 x[U];
+        bool live[U];
+        float w[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            live[u] = vC[u] != 0x7fffffff;
+            const int row = live[u] ? (vC[u] & 0x7fffffff) : 0;
+            w[u] = vC[u] < 0 ? wneg : 1.0f;
+            x[u] = *reinterpret_cast<const float4*>(in + (size_t)row * ld_in + (vC[u] < 0 ? cneg : 0) + c4);
+        }
+        // the next dets' index loads are issued behind this det's row loads
+        advanceC(); advanceB(); fetchA();
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (live[u]) { x[u].x *= w[u]; x[u].y *= w[u]; x[u].z *= w[u]; x[u].w *= w[u]; }
+            else x[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) { acc.x += x[u].x; acc.y += x[u].y; acc.z += x[u].z; acc.w += x[u].w; }
+        // long runs: the remaining passes, as in k_segsum (same order of additions)
+        for (int pb = p0 + grp + ngrp * U; pb < p1; pb += ngrp * U) {
+            int v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int p = pb + u * ngrp;
+                v[u] = p < p1 ? inc[p] : 0x7fffffff;
+            }
+            float4 y[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const bool lv = v[u] != 0x7fffffff;
+                const int row = lv ? (v[u] & 0x7fffffff) : 0;
+                y[u] = *reinterpret_cast<const float4*>(in + (size_t)row * ld_in + (v[u] < 0 ? cneg : 0) + c4);
+                const float ww = v[u] < 0 ? wneg : 1.0f;
+                if (lv) { y[u].x *= ww; y[u].y *= ww; y[u].z *= ww; y[u].w *= ww; }
+                else y[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) { acc.x += y[u].x; acc.y += y[u].y; acc.z += y[u].z; acc.w += y[u].w; }
+        }
+        for (int off = lpr; off < 64; off <<= 1) {
+            acc.x += __shfl_xor(acc.x, off);
+            acc.y += __shfl_xor(acc.y, off);
+            acc.z += __shfl_xor(acc.z, off);
+            acc.w += __shfl_xor(acc.w, off);
+        }
+        if (grp == 0) {
+            float* o = out + (size_t)(compact_out ? d : det_row[d]) * ld_out + c4;
+            if (ACC) {
+                const float4 p = *reinterpret_cast<const float4*>(o);
+                acc.x += p.x; acc.y += p.y; acc.z += p.z; acc.w += p.w;
+            }
+            *reinterpret_cast<float4*>(o) = acc;
+        }
+    }
+}
+
+// TMPNN_AGG=0 keeps the round-1 kernels (A/B measurements); default: the pipelined forms
+static int agg_variant() {
+    static const int v = [] { const char* e = getenv("TMPNN_AGG"); return (e && e[0] == '0') ? 0 : 1; }();
+    return v;
+}
+
 __global__ void k_transpose(const float* __restrict__ in, int rows, int cols, float* __restrict__ out) {
     __shared__ float tile[32][33];
     const int bx = blockIdx.x * 32, by = blockIdx.y * 32;
@@ -241,9 +431,15 @@ static int gather(const tmpnn_graph* g, const float* in, int ld_in, float* out, 
     const int rpb = 256 / (H >> 2);
     dim3 grid(grid_for(g->E, rpb)), block(256);
     hipStream_t st = as_stream(stream);
-#define L(C, A) hipLaunchKernelGGL((k_gather<C, A>), grid, block, 0, st, g->E, g->src, g->dst, g->edge_row, in, ld_in, out, ld_out, H)
-    if (concat) { if (accumulate) L(true, true); else L(true, false); }
-    else        { if (accumulate) L(false, true); else L(false, false); }
+#define L(K, C, A) hipLaunchKernelGGL((K<C, A>), grid, block, 0, st, g->E, g->src, g->dst, g->edge_row, in, ld_in, out, ld_out, H)
+    if (agg_variant()) {
+        grid = dim3(grid_for(g->E, rpb * 4));
+        if (concat) { if (accumulate) L(k_gather_pipe, true, true); else L(k_gather_pipe, true, false); }
+        else        { if (accumulate) L(k_gather_pipe, false, true); else L(k_gather_pipe, false, false); }
+    } else {
+        if (concat) { if (accumulate) L(k_gather, true, true); else L(k_gather, true, false); }
+        else        { if (accumulate) L(k_gather, false, true); else L(k_gather, false, false); }
+    }
 #undef L
     return check_launch("gather");
 }
@@ -257,12 +453,10 @@ static int segsum(const tmpnn_graph* g, const float* in, int ld_in, float* out, 
     if (g->Dn == 0) return TMPNN_OK;
     hipStream_t st = as_stream(stream);
     dim3 grid(grid_for(g->Dn, 64)), block(256);
-    if (accumulate)
-        hipLaunchKernelGGL((k_segsum<true>), grid, block, 0, st, g->Dn, g->det_row, g->rowptr, g->inc, g->det_order, in,
-                           ld_in, out, ld_out, H, wneg, cneg, compact_out);
-    else
-        hipLaunchKernelGGL((k_segsum<false>), grid, block, 0, st, g->Dn, g->det_row, g->rowptr, g->inc, g->det_order, in,
-                           ld_in, out, ld_out, H, wneg, cneg, compact_out);
+#define LS(K, A) hipLaunchKernelGGL((K<A>), grid, block, 0, st, g->Dn, g->det_row, g->rowptr, g->inc, g->det_order, in, ld_in, out, ld_out, H, wneg, cneg, compact_out)
+    if (agg_variant()) { if (accumulate) LS(k_segsum_pipe, true); else LS(k_segsum_pipe, false); }
+    else               { if (accumulate) LS(k_segsum, true); else LS(k_segsum, false); }
+#undef LS
     return check_launch("segsum");
 }
 
