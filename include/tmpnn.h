@@ -424,6 +424,31 @@ int tmpnn_track_delete(int N, const int32_t* ts, const int32_t* det_id, const in
 int tmpnn_track_gather(const float* in, int ld_in, int W, int max_rows, const int32_t* keep, const int32_t* count,
                        float* out, int ld_out, tmpnn_stream stream);
 
+/* ======================================================================================================
+ * Wide cells (H = 128 / 256, diff messages; BASELINE.json C5) as LDS-tiled GEMMs on bf16x6 split products
+ * (csrc/wide.hip).  Same arithmetic contract as the H <= 64 kernels: fp32 in / out, fp32 accumulate, error no larger
+ * than the f32 MFMA chain.  tmpnn_wide_prepare splits the cell's two weight matrices into their MFMA operand images
+ * once per optimizer step (prep: tmpnn_wide_prep_bytes bytes, 16-byte aligned).
+ * ====================================================================================================== */
+int tmpnn_wide_supported(int H, int IN);
+size_t tmpnn_wide_prep_bytes(int H, int IN);
+int tmpnn_wide_prepare(const float* w_ih /* [3H][IN] */, const float* w_hh /* [3H][H] */, int IN, int H, void* prep,
+                       tmpnn_stream stream);
+/* Forward of one cell over the rows `rows[R]` with the diff message taken through the projected det rows (rows E + H'
+ * + I): P [Dn][3H] = h[det_rows] W_ih^T is written here; gi = P[src_pos[r]] - P[dst_pos[r]] (det INDICES),
+ * gh = h[rows[r]] W_hh^T, h_out[rows[r]] = GRUCell; gates: NULL or the 4 planes of tmpnn_gru_fwd. */
+int tmpnn_wide_gru_fwd(const void* prep, const int32_t* det_rows, int Dn, const int32_t* rows, int R,
+                       const int32_t* src_pos, const int32_t* dst_pos, const float* h, int ld_h, int H,
+                       const float* b_ih, const float* b_hh, float* P, float* h_out, int ld_out, float* gates,
+                       size_t gate_plane, tmpnn_stream stream);
+/* Data gradient (as tmpnn_gru_bwd_data with IN = H, no fused adjoint): d_msg[rows[r]][0:H] = d_gi W_ih,
+ * d_h[rows[r]] = dh z + d_gh W_hh.  ws: tmpnn_wide_gru_bwd_data_ws(R, H) bytes (the materialised d_gi, d_gh). */
+size_t tmpnn_wide_gru_bwd_data_ws(int R, int H);
+int tmpnn_wide_gru_bwd_data(const void* prep, const int32_t* rows, int R, const float* h, int ld_h, int H,
+                            const float* gates, size_t gate_plane, const float* d_hout, int ld_dhout, const float* dy,
+                            const float* w_head, float* d_msg, int ld_dmsg, float* d_h, int ld_dh, void* ws,
+                            size_t ws_bytes, tmpnn_stream stream);
+
 #ifdef __cplusplus
 }
 #endif

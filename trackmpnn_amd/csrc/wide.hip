@@ -1,0 +1,513 @@
+// Wide GRU cells (H = 128 / 256; BASELINE.json C5: H = 256, 4.4 M edge rows per iteration) on the bf16 matrix pipe.
+//
+// At H <= 64 the cell's weight matrices fit the LDS and the kernels of gru.hip keep them resident.  At H = 256 they
+// are 0.8 MB each, so round 1 streamed them from L2 into f32-input MFMAs (64 / 45 TFLOP/s forward / backward-data).
+// Here the products are LDS-tiled GEMMs on bf16x6 split products (three bf16 pieces per fp32 operand, six
+// v_mfma_f32_32x32x16_bf16 per fp32 product, fp32 accumulate: as accurate as the f32 MFMA chain, see gru.hip), 2.7x
+// the f32-MFMA ceiling:
+//
+//   block tile 128 rows x 128 (or 3 x 64) columns, K step 32; 8 waves, each a 32 x 64 (or 32 x 3 x 32) sub-tile;
+//   A rows (fp32, optionally gathered through a row list) are split into pieces on their way into the LDS;
+//   B = the weights, split ONCE per forward call into piece images laid out [K/32][piece][N][32] so that a tile is a
+//   linear 16-byte copy (tmpnn_wide_prepare); the next K-step's operands are loaded into registers behind the
+//   current step's MFMAs and written to the second LDS buffer afterwards (one barrier per step).
+//
+//   forward   P = h[dets] W_ih^T (Dn rows) ; per edge row gi = P[src] - P[dst] (linearity of the diff message) and
+//             gh = h W_hh^T by the tiled GEMM with the GRU gates, the merge and the saved gate planes in its epilogue
+//   backward  d_gi / d_gh are formed once by an elementwise pass (the gates are read exactly once), then
+//             d_x = d_gi W_ih and d_h = dh z + d_gh W_hh are two tiled GEMMs with plain / accumulating stores.
+// The weight gradient keeps the output-tiled kernel of gru.hip.
+#include "common.h"
+
+namespace tmpnn {
+
+typedef __bf16 wbf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 wbf16x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ float w_sigm(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+__device__ __forceinline__ float w_tanh(float x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(2.0f * x)); }
+
+__device__ __forceinline__ uint32_t w_pk(float lo, float hi) {
+    wbf16x2 v;
+    v[0] = (__bf16)lo; v[1] = (__bf16)hi;
+    return __builtin_bit_cast(uint32_t, v);
+}
+// two fp32 -> three packed-bf16 pieces (round-to-nearest residuals)
+__device__ __forceinline__ void w_split2(float x0, float x1, uint32_t& p1, uint32_t& p2, uint32_t& p3) {
+    p1 = w_pk(x0, x1);
+    float r0 = x0 - __uint_as_float(p1 << 16), r1 = x1 - __uint_as_float(p1 & 0xFFFF0000u);
+    p2 = w_pk(r0, r1);
+    r0 -= __uint_as_float(p2 << 16);
+    r1 -= __uint_as_float(p2 & 0xFFFF0000u);
+    p3 = w_pk(r0, r1);
+}
+__device__ __forceinline__ f32x16 w_mfma(const uint4& a, const uint4& b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(wbf16x8, a), __builtin_bit_cast(wbf16x8, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ int w_acc_row(int reg, int half) { return (reg & 3) + 8 * (reg >> 2) + 4 * half; }
+
+// ------------------------------------------------------------------------------------------------------------
+// weight images: img[((kt * 3 + piece) * N + n) * 32 + kk] (bf16) = piece of B[32 kt + kk][n]
+// ------------------------------------------------------------------------------------------------------------
+// B[k][n] = W[n * ldw + k] (TRANS: forward, B = W^T) or W[k * ldw + n] (backward-data, B = W)
+__global__ __launch_bounds__(256) void k_wide_prep(const float* __restrict__ W, int ldw, int K, int N, int trans,
+                                                   uint16_t* __restrict__ img) {
+    const long total = (long)K * N;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int k = (int)(i / N), n = (int)(i % N);
+        const float v = trans ? W[(size_t)n * ldw + k] : W[(size_t)k * ldw + n];
+        uint32_t p1, p2, p3;
+        w_split2(v, 0.f, p1, p2, p3);
+        const int kt = k >> 5, kk = k & 31;
+        const size_t base = ((size_t)kt * 3 * N + n) * 32 + kk;
+        img[base] = (uint16_t)p1;
+        img[base + (size_t)N * 32] = (uint16_t)p2;
+        img[base + (size_t)2 * N * 32] = (uint16_t)p3;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// the tiled product
+// ------------------------------------------------------------------------------------------------------------
+static constexpr int W_BM = 128, W_KT = 32, W_LD = 40;     // LDS row stride in bf16 (80 B: 16-byte aligned, off the 64-B grid)
+
+struct WideArgs {
+    // A: R rows of K fp32, row r at A + (a_rows ? a_rows[r] : r) * lda
+    const float* A; int lda; const int32_t* a_rows; int R; int K;
+    const uint16_t* img; int N;                 // weight image [K/32][3][N][32]
+    // STORE epilogue: C[(c_rows ? c_rows[r] : r) * ldc + n] (=|+=) acc
+    float* C; int ldc; const int32_t* c_rows; int accumulate;
+    // GRU epilogue (forward): P [Dn][3H] projected det rows, src/dst det INDEX per row, state, biases, outputs
+    const float* P; int ldp; const int32_t* src_pos; const int32_t* dst_pos;
+    const float* h; int ld_h; int H; const float* b_ih; const float* b_hh;
+    float* h_out; int ld_out; float* gates; size_t gate_plane; const int32_t* rows;
+};
+
+// One K-step of operands in registers: the global loads are issued BEFORE the MFMAs of the previous step and
+// consumed (split, written to the other LDS buffer) after them.  512 threads: A 128 rows x 32 k -> 8 floats per
+// thread; B NSEG * 64 columns x 32 k x 3 pieces -> NSEG * 768 chunks of 16 bytes.
+template <int NSEG>
+__device__ __forceinline__ void wide_load(const WideArgs& a, int r0, int kt, int n_base, int seg_stride, float4& qa0, float4& qa1,
+                                          uint4 (&qb)[(NSEG * 768 + 511) / 512]) {
+    const int tid = threadIdx.x;
+    const int row = tid >> 2, kq = tid & 3;
+    const int r = r0 + row;
+    if (r < a.R) {
+        const float4* p = reinterpret_cast<const float4*>(a.A + (size_t)(a.a_rows ? a.a_rows[r] : r) * a.lda + kt * W_KT + 8 * kq);
+        qa0 = p[0]; qa1 = p[1];
+    } else {
+        qa0 = make_float4(0.f, 0.f, 0.f, 0.f); qa1 = qa0;
+    }
+    constexpr int CH = NSEG * 64 * 4;               // 16-byte chunks per piece
+    constexpr int NB = (3 * CH + 511) / 512;
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+        const int idx = min(tid + i * 512, 3 * CH - 1);      // (the surplus threads of the last pass re-load a valid chunk)
+        const int p = idx / CH, c = idx % CH;
+        const int col = c >> 2, qq = c & 3;
+        const int n = min(n_base + (col >> 6) * seg_stride + (col & 63), a.N - 1);     // segment s starts at n_base + s * seg_stride
+        const uint4 v = *reinterpret_cast<const uint4*>(a.img + (((size_t)kt * 3 + p) * a.N + n) * 32 + 8 * qq);
+        qb[i] = v;
+    }
+}
+
+template <int NSEG>
+__device__ __forceinline__ void wide_store(const float4& qa0, const float4& qa1, const uint4 (&qb)[(NSEG * 768 + 511) / 512],
+                                           uint16_t* sA, uint16_t* sB) {
+    const int tid = threadIdx.x;
+    {
+        const int row = tid >> 2, kq = tid & 3;
+        uint32_t q1[4], q2[4], q3[4];
+        w_split2(qa0.x, qa0.y, q1[0], q2[0], q3[0]);
+        w_split2(qa0.z, qa0.w, q1[1], q2[1], q3[1]);
+        w_split2(qa1.x, qa1.y, q1[2], q2[2], q3[2]);
+        w_split2(qa1.z, qa1.w, q1[3], q2[3], q3[3]);
+        uint16_t* d = sA + row * W_LD + 8 * kq;
+        constexpr int PL = W_BM * W_LD;
+        *reinterpret_cast<uint4*>(d) = make_uint4(q1[0], q1[1], q1[2], q1[3]);
+        *reinterpret_cast<uint4*>(d + PL) = make_uint4(q2[0], q2[1], q2[2], q2[3]);
+        *reinterpret_cast<uint4*>(d + 2 * PL) = make_uint4(q3[0], q3[1], q3[2], q3[3]);
+    }
+    constexpr int CH = NSEG * 64 * 4;
+    constexpr int PLB = NSEG * 64 * W_LD;
+    constexpr int NB = (3 * CH + 511) / 512;
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+        const int idx = tid + i * 512;
+        if (idx < 3 * CH) {
+            const int p = idx / CH, c = idx % CH;
+            const int col = c >> 2, qq = c & 3;
+            *reinterpret_cast<uint4*>(sB + p * PLB + col * W_LD + 8 * qq) = qb[i];
+        }
+    }
+}
+
+// acc[ct] += A(32 rows of this wave) x B(column tiles of this wave) over the staged K-step
+// (column tile ct of the wave sits at LDS image row bcol_first + ct * BSTEP: 32 apart for the plain product, 64 apart --
+//  one gate segment -- for the GRU product)
+template <int NCT, int NSEG>
+__device__ __forceinline__ void wide_mma(const uint16_t* sA, const uint16_t* sB, int arow0, int bcol_first, int lane,
+                                         f32x16 (&acc)[NCT]) {
+    constexpr int BSTEP = NSEG == 3 ? 64 : 32;
+    constexpr int PL = W_BM * W_LD, PLB = NSEG * 64 * W_LD;
+    const int r = lane & 31, hh = lane >> 5;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        uint4 af[3], bf[NCT][3];
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+            af[p] = *reinterpret_cast<const uint4*>(sA + p * PL + (arow0 + r) * W_LD + 16 * s + 8 * hh);
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+                bf[ct][p] = *reinterpret_cast<const uint4*>(sB + p * PLB + (bcol_first + ct * BSTEP + r) * W_LD + 16 * s + 8 * hh);
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) {
+            f32x16 c = acc[ct];
+            c = w_mfma(af[2], bf[ct][0], c);       // smallest terms first
+            c = w_mfma(af[0], bf[ct][2], c);
+            c = w_mfma(af[1], bf[ct][1], c);
+            c = w_mfma(af[1], bf[ct][0], c);
+            c = w_mfma(af[0], bf[ct][1], c);
+            c = w_mfma(af[0], bf[ct][0], c);
+            acc[ct] = c;
+        }
+    }
+}
+
+// the K loop: register prefetch of step kt + 1 behind the MFMAs of step kt, two LDS buffers, one barrier per step
+template <int NCT, int NSEG>
+__device__ __forceinline__ void wide_kloop(const WideArgs& a, int r0, int n_base, int seg_stride, uint16_t* lds, int arow0,
+                                           int bcol_first, int lane, f32x16 (&acc)[NCT]) {
+    constexpr int SA = 3 * W_BM * W_LD, SB = 3 * NSEG * 64 * W_LD, BUF = SA + SB;
+    // two register sets: the loads of step kt + 2 are issued while step kt computes, so every load has two MFMA
+    // phases to land (one phase is shorter than an HBM round trip under load: measured, the K-step waited for it)
+    constexpr int NB = (NSEG * 768 + 511) / 512;
+    float4 xa0, xa1, ya0, ya1;
+    uint4 xb[NB], yb[NB];
+    const int nk = a.K / W_KT;
+    uint16_t* buf0 = lds;
+    uint16_t* buf1 = lds + BUF;
+    wide_load<NSEG>(a, r0, 0, n_base, seg_stride, xa0, xa1, xb);
+    if (nk > 1) wide_load<NSEG>(a, r0, 1, n_base, seg_stride, ya0, ya1, yb);
+    wide_store<NSEG>(xa0, xa1, xb, buf0, buf0 + SA);
+    __syncthreads();
+    for (int kt = 0; kt < nk; kt += 2) {
+        if (kt + 2 < nk) wide_load<NSEG>(a, r0, kt + 2, n_base, seg_stride, xa0, xa1, xb);
+        wide_mma<NCT, NSEG>(buf0, buf0 + SA, arow0, bcol_first, lane, acc);
+        if (kt + 1 < nk) wide_store<NSEG>(ya0, ya1, yb, buf1, buf1 + SA);
+        __syncthreads();
+        if (kt + 1 >= nk) break;
+        if (kt + 3 < nk) wide_load<NSEG>(a, r0, kt + 3, n_base, seg_stride, ya0, ya1, yb);
+        wide_mma<NCT, NSEG>(buf1, buf1 + SA, arow0, bcol_first, lane, acc);
+        if (kt + 2 < nk) wide_store<NSEG>(xa0, xa1, xb, buf0, buf0 + SA);
+        __syncthreads();
+    }
+}
+
+// XCD-aware tile order.  Blocks are dealt round-robin over the 8 XCDs (each with its own L2), so the gx column blocks of
+// one row tile -- which read the SAME A rows -- are given ids that differ by 8: same XCD, dispatched back to back, and
+// the rows are fetched from HBM once instead of gx times.  1-D grid of gx * 8 * ceil(gy / 8) blocks.
+__device__ __forceinline__ bool wide_tile(int gx, int gy, int& bx, int& by) {
+    const int b = blockIdx.x;
+    const int xcd = b & 7, s = b >> 3;
+    bx = s % gx;
+    by = (s / gx) * 8 + xcd;
+    return by < gy;
+}
+static int wide_grid(int gx, int gy) { return gx * 8 * ((gy + 7) / 8); }
+
+static constexpr size_t W_STORE_SHM = sizeof(uint16_t) * 2 * (3 * W_BM * W_LD + 3 * 128 * W_LD);
+static constexpr size_t W_GRU_SHM = sizeof(uint16_t) * 2 * (3 * W_BM * W_LD + 3 * 192 * W_LD);
+
+// C = A B with a plain (or accumulating) store.  Tiles (ceil(N / 128) x ceil(R / 128)) in wide_tile order, 8 waves:
+// wave = (32-row group, 64-column half)
+__global__ __launch_bounds__(512) void k_wide_gemm_store(WideArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint16_t w_dyn[];
+    int bx, by;
+    if (!wide_tile((a.N + 127) / 128, (a.R + W_BM - 1) / W_BM, bx, by)) return;
+    const int r0 = by * W_BM, n0 = bx * 128;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wr = wave & 3, wc = wave >> 2;
+    f32x16 acc[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[j][q] = 0.f;
+    wide_kloop<2, 2>(a, r0, n0, 64, w_dyn, 32 * wr, 64 * wc, lane, acc);
+    // epilogue through the (now free) LDS: the accumulators hold one column per lane; rows leave as 16-byte accesses
+    constexpr int LDC = 128 + 4;
+    float* sC = reinterpret_cast<float*>(w_dyn);
+    {
+        const int c = lane & 31, half = lane >> 5;
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg)
+                sC[(32 * wr + w_acc_row(reg, half)) * LDC + 64 * wc + 32 * ct + c] = acc[ct][reg];
+    }
+    __syncthreads();
+    for (int it = threadIdx.x; it < W_BM * 32; it += 512) {
+        const int row = it >> 5, q = it & 31;
+        const int r = r0 + row, n = n0 + 4 * q;
+        if (r >= a.R || n >= a.N) continue;
+        float4 v = *reinterpret_cast<const float4*>(sC + row * LDC + 4 * q);
+        float* o = a.C + (size_t)(a.c_rows ? a.c_rows[r] : r) * a.ldc + n;
+        if (a.accumulate) {
+            const float4 p = *reinterpret_cast<const float4*>(o);
+            v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w;
+        }
+        *reinterpret_cast<float4*>(o) = v;
+    }
+}
+
+// gh = h W_hh^T for 64 hidden units (3 x 64 gate columns) of 128 rows, GRU gates in the epilogue.
+// Tiles (H / 64 hidden chunks x ceil(R / 128)) in wide_tile order: the hidden chunks of a row tile run on one XCD, so
+// the A rows they share come out of its L2.  8 waves: wave = (32-row group, 32-hidden-unit half).
+__global__ __launch_bounds__(512) void k_wide_gru_fwd(WideArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint16_t w_dyn[];
+    __shared__ int sRow[W_BM], sS[W_BM], sD[W_BM];
+    const int H = a.H;
+    int bx, by;
+    if (!wide_tile(H / 64, (a.R + W_BM - 1) / W_BM, bx, by)) return;
+    const int r0 = by * W_BM, hc0 = bx * 64;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wr = wave & 3, wc = wave >> 2;
+    if (threadIdx.x < W_BM) {
+        const int r = r0 + threadIdx.x;
+        const int rc = r < a.R ? r : a.R - 1;
+        sRow[threadIdx.x] = a.rows[rc];
+        sS[threadIdx.x] = a.src_pos[rc];
+        sD[threadIdx.x] = a.dst_pos[rc];
+    }
+    f32x16 acc[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[j][q] = 0.f;
+    wide_kloop<3, 3>(a, r0, hc0, H, w_dyn, 32 * wr, 32 * wc, lane, acc);
+    // epilogue through the (now free) LDS: gh tile [128 rows][3 gates x 64 hidden] fp32, then one thread per
+    // (row, 4 hidden units): every global access of the gate math is a 16-byte one
+    constexpr int LDC = 192 + 4;
+    float* sC = reinterpret_cast<float*>(w_dyn);
+    {
+        const int c = lane & 31, half = lane >> 5;
+#pragma unroll
+        for (int gate = 0; gate < 3; ++gate)
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg)
+                sC[(32 * wr + w_acc_row(reg, half)) * LDC + 64 * gate + 32 * wc + c] = acc[gate][reg];
+    }
+    __syncthreads();
+    for (int it = threadIdx.x; it < W_BM * 16; it += 512) {
+        const int lr = it >> 4, q = it & 15;
+        if (r0 + lr >= a.R) continue;
+        const int grow = sRow[lr];
+        const int col = hc0 + 4 * q;
+        const float* ps = a.P + (size_t)sS[lr] * a.ldp + col;
+        const float* pd = a.P + (size_t)sD[lr] * a.ldp + col;
+        const float4 sr = *reinterpret_cast<const float4*>(ps), dr_ = *reinterpret_cast<const float4*>(pd);
+        const float4 sz = *reinterpret_cast<const float4*>(ps + H), dz_ = *reinterpret_cast<const float4*>(pd + H);
+        const float4 sn = *reinterpret_cast<const float4*>(ps + 2 * H), dn_ = *reinterpret_cast<const float4*>(pd + 2 * H);
+        const float4 hp4 = *reinterpret_cast<const float4*>(a.h + (size_t)grow * a.ld_h + col);
+        const float4 bir = *reinterpret_cast<const float4*>(a.b_ih + col), biz = *reinterpret_cast<const float4*>(a.b_ih + H + col);
+        const float4 bin_ = *reinterpret_cast<const float4*>(a.b_ih + 2 * H + col);
+        const float4 bhr = *reinterpret_cast<const float4*>(a.b_hh + col), bhz = *reinterpret_cast<const float4*>(a.b_hh + H + col);
+        const float4 bhn = *reinterpret_cast<const float4*>(a.b_hh + 2 * H + col);
+        const float4 ghr = *reinterpret_cast<const float4*>(sC + lr * LDC + 4 * q);
+        const float4 ghz = *reinterpret_cast<const float4*>(sC + lr * LDC + 64 + 4 * q);
+        const float4 ghn = *reinterpret_cast<const float4*>(sC + lr * LDC + 128 + 4 * q);
+        const float gir[4] = {sr.x - dr_.x, sr.y - dr_.y, sr.z - dr_.z, sr.w - dr_.w};
+        const float giz[4] = {sz.x - dz_.x, sz.y - dz_.y, sz.z - dz_.z, sz.w - dz_.w};
+        const float gin[4] = {sn.x - dn_.x, sn.y - dn_.y, sn.z - dn_.z, sn.w - dn_.w};
+        const float vr[4] = {ghr.x + bhr.x + bir.x, ghr.y + bhr.y + bir.y, ghr.z + bhr.z + bir.z, ghr.w + bhr.w + bir.w};
+        const float vz[4] = {ghz.x + bhz.x + biz.x, ghz.y + bhz.y + biz.y, ghz.z + bhz.z + biz.z, ghz.w + bhz.w + biz.w};
+        const float vhn[4] = {ghn.x + bhn.x, ghn.y + bhn.y, ghn.z + bhn.z, ghn.w + bhn.w};
+        const float vbn[4] = {bin_.x, bin_.y, bin_.z, bin_.w}, hpv[4] = {hp4.x, hp4.y, hp4.z, hp4.w};
+        float orr[4], ozz[4], onn[4], oh[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            orr[j] = w_sigm(gir[j] + vr[j]);
+            ozz[j] = w_sigm(giz[j] + vz[j]);
+            onn[j] = w_tanh(gin[j] + vbn[j] + orr[j] * vhn[j]);
+            oh[j] = (1.0f - ozz[j]) * onn[j] + ozz[j] * hpv[j];
+        }
+        *reinterpret_cast<float4*>(a.h_out + (size_t)grow * a.ld_out + col) = make_float4(oh[0], oh[1], oh[2], oh[3]);
+        if (a.gates) {
+            float* gp = a.gates + (size_t)grow * H + col;
+            *reinterpret_cast<float4*>(gp) = make_float4(orr[0], orr[1], orr[2], orr[3]);
+            *reinterpret_cast<float4*>(gp + a.gate_plane) = make_float4(ozz[0], ozz[1], ozz[2], ozz[3]);
+            *reinterpret_cast<float4*>(gp + 2 * a.gate_plane) = make_float4(onn[0], onn[1], onn[2], onn[3]);
+            *reinterpret_cast<float4*>(gp + 3 * a.gate_plane) = make_float4(vhn[0], vhn[1], vhn[2], vhn[3]);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// backward, elementwise pass: d_gi = [dr | dz | dn], d_gh = [dr | dz | dn r] (compact rows), d_h[row] = dh z
+// ------------------------------------------------------------------------------------------------------------
+struct WideBwdArgs {
+    const int32_t* rows; int R; int H;
+    const float* h; int ld_h;
+    const float* gates; size_t gate_plane;
+    const float* d_hout; int ld_dhout; const float* dy; const float* w_head;
+    float* dgi; float* dgh;          // [R][3H]
+    float* d_h; int ld_dh;
+};
+
+__global__ __launch_bounds__(256) void k_wide_gates_bwd(WideBwdArgs a) {
+    const int H = a.H, lpr = H >> 2;
+    const long total = (long)a.R * lpr;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int r = (int)(i / lpr), c4 = (int)(i % lpr) * 4;
+        const int row = a.rows[r];
+        float4 dh = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (a.d_hout) dh = *reinterpret_cast<const float4*>(a.d_hout + (size_t)row * a.ld_dhout + c4);
+        if (a.dy) {
+            const float d = a.dy[row];
+            const float4 w = *reinterpret_cast<const float4*>(a.w_head + c4);
+            dh.x += d * w.x; dh.y += d * w.y; dh.z += d * w.z; dh.w += d * w.w;
+        }
+        const float* gp = a.gates + (size_t)row * H + c4;
+        const float4 gr = *reinterpret_cast<const float4*>(gp);
+        const float4 gz = *reinterpret_cast<const float4*>(gp + a.gate_plane);
+        const float4 gn = *reinterpret_cast<const float4*>(gp + 2 * a.gate_plane);
+        const float4 gh = *reinterpret_cast<const float4*>(gp + 3 * a.gate_plane);
+        const float4 hp = *reinterpret_cast<const float4*>(a.h + (size_t)row * a.ld_h + c4);
+        const float dv[4] = {dh.x, dh.y, dh.z, dh.w}, rv[4] = {gr.x, gr.y, gr.z, gr.w}, zv[4] = {gz.x, gz.y, gz.z, gz.w};
+        const float nv[4] = {gn.x, gn.y, gn.z, gn.w}, hv[4] = {gh.x, gh.y, gh.z, gh.w}, pv[4] = {hp.x, hp.y, hp.z, hp.w};
+        float dr[4], dz[4], dn[4], dnr[4], dhz[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float t = dv[j] * (1.0f - zv[j]) * (1.0f - nv[j] * nv[j]);
+            dn[j] = t;
+            dnr[j] = t * rv[j];
+            dr[j] = t * hv[j] * rv[j] * (1.0f - rv[j]);
+            dz[j] = dv[j] * (pv[j] - nv[j]) * zv[j] * (1.0f - zv[j]);
+            dhz[j] = dv[j] * zv[j];
+        }
+        float* gi = a.dgi + (size_t)r * 3 * H + c4;
+        float* gg = a.dgh + (size_t)r * 3 * H + c4;
+        *reinterpret_cast<float4*>(gi) = make_float4(dr[0], dr[1], dr[2], dr[3]);
+        *reinterpret_cast<float4*>(gi + H) = make_float4(dz[0], dz[1], dz[2], dz[3]);
+        *reinterpret_cast<float4*>(gi + 2 * H) = make_float4(dn[0], dn[1], dn[2], dn[3]);
+        *reinterpret_cast<float4*>(gg) = make_float4(dr[0], dr[1], dr[2], dr[3]);
+        *reinterpret_cast<float4*>(gg + H) = make_float4(dz[0], dz[1], dz[2], dz[3]);
+        *reinterpret_cast<float4*>(gg + 2 * H) = make_float4(dnr[0], dnr[1], dnr[2], dnr[3]);
+        *reinterpret_cast<float4*>(a.d_h + (size_t)row * a.ld_dh + c4) = make_float4(dhz[0], dhz[1], dhz[2], dhz[3]);
+    }
+}
+
+static int launch_store(const WideArgs& a, hipStream_t st) {
+    dim3 grid(wide_grid(ceil_div(a.N, 128), ceil_div(a.R, W_BM)));
+    TM_SHM_ONCE(k_wide_gemm_store, W_STORE_SHM);
+    hipLaunchKernelGGL(k_wide_gemm_store, grid, dim3(512), W_STORE_SHM, st, a);
+    return check_launch("wide_gemm_store");
+}
+
+}  // namespace tmpnn
+
+using namespace tmpnn;
+
+extern "C" {
+
+int tmpnn_wide_supported(int H, int IN) { return ((H == 128 || H == 256) && IN == H) ? 1 : 0; }
+
+// bytes of the four weight images of one cell: forward hh (K = H, N = 3H), forward ih (K = IN, N = 3H),
+// backward ih (K = 3H, N = IN), backward hh (K = 3H, N = H)
+size_t tmpnn_wide_prep_bytes(int H, int IN) {
+    if (H <= 0 || IN <= 0) return 0;
+    return sizeof(uint16_t) * 3 * ((size_t)H * 3 * H + (size_t)IN * 3 * H + (size_t)3 * H * IN + (size_t)3 * H * H);
+}
+
+int tmpnn_wide_prepare(const float* w_ih, const float* w_hh, int IN, int H, void* prep, tmpnn_stream stream) {
+    TM_REQUIRE(tmpnn_wide_supported(H, IN), "wide_prepare: H=%d IN=%d (need H in {128, 256}, IN = H)", H, IN);
+    TM_REQUIRE(w_ih && w_hh && prep && aligned16(prep), "wide_prepare: null / misaligned pointer");
+    hipStream_t st = as_stream(stream);
+    uint16_t* f_hh = reinterpret_cast<uint16_t*>(prep);
+    uint16_t* f_ih = f_hh + (size_t)3 * H * 3 * H;
+    uint16_t* b_ih = f_ih + (size_t)3 * IN * 3 * H;
+    uint16_t* b_hh = b_ih + (size_t)3 * 3 * H * IN;
+    const int g1 = ceil_div((long)H * 3 * H, 256), g2 = ceil_div((long)IN * 3 * H, 256);
+    hipLaunchKernelGGL(k_wide_prep, dim3(g1), dim3(256), 0, st, w_hh, H, H, 3 * H, 1, f_hh);
+    hipLaunchKernelGGL(k_wide_prep, dim3(g2), dim3(256), 0, st, w_ih, IN, IN, 3 * H, 1, f_ih);
+    hipLaunchKernelGGL(k_wide_prep, dim3(g2), dim3(256), 0, st, w_ih, IN, 3 * H, IN, 0, b_ih);
+    hipLaunchKernelGGL(k_wide_prep, dim3(g1), dim3(256), 0, st, w_hh, H, 3 * H, H, 0, b_hh);
+    return check_launch("wide_prepare");
+}
+
+/* Edge (or any) cell forward, diff message through the projected det rows:
+ *   P [Dn][3H] = h[det_rows] W_ih^T (written here) ; for r < R: gi = P[src_pos[r]] - P[dst_pos[r]], gh = h[rows[r]] W_hh^T,
+ *   h_out[rows[r]] = GRU gates ; gates: NULL or 4 planes.  */
+int tmpnn_wide_gru_fwd(const void* prep, const int32_t* det_rows, int Dn, const int32_t* rows, int R,
+                       const int32_t* src_pos, const int32_t* dst_pos, const float* h, int ld_h, int H,
+                       const float* b_ih, const float* b_hh, float* P, float* h_out, int ld_out, float* gates,
+                       size_t gate_plane, tmpnn_stream stream) {
+    TM_REQUIRE(tmpnn_wide_supported(H, H), "wide_gru_fwd: H=%d", H);
+    if (R == 0) return TMPNN_OK;
+    TM_REQUIRE(prep && det_rows && rows && src_pos && dst_pos && h && b_ih && b_hh && P && h_out && Dn > 0 && R > 0,
+               "wide_gru_fwd: null pointer / empty det table");
+    TM_REQUIRE(aligned16(prep) && aligned16(h) && (ld_h & 3) == 0 && ld_h >= H && ld_out >= H && aligned16(P) &&
+                   aligned16(h_out) && (ld_out & 3) == 0 && aligned16(b_ih) && aligned16(b_hh) &&
+                   (gates == nullptr || (aligned16(gates) && (gate_plane & 3) == 0)), "wide_gru_fwd: layout (16-byte alignment)");
+    TM_REQUIRE(gates == nullptr || gate_plane >= (size_t)H, "wide_gru_fwd: gate_plane too small");
+    hipStream_t st = as_stream(stream);
+    const uint16_t* f_hh = reinterpret_cast<const uint16_t*>(prep);
+    const uint16_t* f_ih = f_hh + (size_t)3 * H * 3 * H;
+    WideArgs p{};
+    p.A = h; p.lda = ld_h; p.a_rows = det_rows; p.R = Dn; p.K = H; p.img = f_ih; p.N = 3 * H;
+    p.C = P; p.ldc = 3 * H; p.c_rows = nullptr; p.accumulate = 0;
+    int rc = launch_store(p, st);
+    if (rc) return rc;
+    WideArgs a{};
+    a.A = h; a.lda = ld_h; a.a_rows = rows; a.R = R; a.K = H; a.img = f_hh; a.N = 3 * H;
+    a.P = P; a.ldp = 3 * H; a.src_pos = src_pos; a.dst_pos = dst_pos; a.h = h; a.ld_h = ld_h; a.H = H;
+    a.b_ih = b_ih; a.b_hh = b_hh; a.h_out = h_out; a.ld_out = ld_out; a.gates = gates; a.gate_plane = gate_plane; a.rows = rows;
+    TM_SHM_ONCE(k_wide_gru_fwd, W_GRU_SHM);
+    hipLaunchKernelGGL(k_wide_gru_fwd, dim3(wide_grid(H / 64, ceil_div(R, W_BM))), dim3(512), W_GRU_SHM, st, a);
+    return check_launch("wide_gru_fwd");
+}
+
+size_t tmpnn_wide_gru_bwd_data_ws(int R, int H) { return R > 0 ? sizeof(float) * 2 * (size_t)R * 3 * H : 0; }
+
+/* Data gradient of the cell (arguments as tmpnn_gru_bwd_data, IN = H): d_msg[rows[r]][0:H] = d_gi W_ih,
+ * d_h[rows[r]] = dh z + d_gh W_hh.  ws: tmpnn_wide_gru_bwd_data_ws bytes. */
+int tmpnn_wide_gru_bwd_data(const void* prep, const int32_t* rows, int R, const float* h, int ld_h, int H,
+                            const float* gates, size_t gate_plane, const float* d_hout, int ld_dhout, const float* dy,
+                            const float* w_head, float* d_msg, int ld_dmsg, float* d_h, int ld_dh, void* ws,
+                            size_t ws_bytes, tmpnn_stream stream) {
+    TM_REQUIRE(tmpnn_wide_supported(H, H), "wide_gru_bwd_data: H=%d", H);
+    if (R == 0) return TMPNN_OK;
+    TM_REQUIRE(prep && rows && h && gates && d_msg && d_h && ws, "wide_gru_bwd_data: null pointer");
+    TM_REQUIRE(d_hout != nullptr || dy != nullptr, "wide_gru_bwd_data: no upstream gradient");
+    TM_REQUIRE(dy == nullptr || (w_head != nullptr && aligned16(w_head)), "wide_gru_bwd_data: dy needs a 16-byte aligned w_head");
+    TM_REQUIRE(aligned16(h) && aligned16(gates) && aligned16(d_h) && aligned16(ws) && (ld_h & 3) == 0 && (ld_dh & 3) == 0 &&
+                   aligned16(d_msg) && (ld_dmsg & 3) == 0 &&
+                   (gate_plane & 3) == 0 && (d_hout == nullptr || (aligned16(d_hout) && (ld_dhout & 3) == 0)),
+               "wide_gru_bwd_data: 16-byte alignment");
+    if (ws_bytes < tmpnn_wide_gru_bwd_data_ws(R, H))
+        return set_error(TMPNN_EWORKSPACE, "wide_gru_bwd_data: workspace %zu < %zu bytes", ws_bytes,
+                         tmpnn_wide_gru_bwd_data_ws(R, H));
+    hipStream_t st = as_stream(stream);
+    float* dgi = reinterpret_cast<float*>(ws);
+    float* dgh = dgi + (size_t)R * 3 * H;
+    WideBwdArgs b{rows, R, H, h, ld_h, gates, gate_plane, d_hout, ld_dhout, dy, w_head, dgi, dgh, d_h, ld_dh};
+    long blocks = ((long)R * (H / 4) + 255) / 256;
+    if (blocks > 256L * 32) blocks = 256L * 32;
+    hipLaunchKernelGGL(k_wide_gates_bwd, dim3((int)blocks), dim3(256), 0, st, b);
+    int rc = check_launch("wide_gates_bwd");
+    if (rc) return rc;
+    const uint16_t* f_hh = reinterpret_cast<const uint16_t*>(prep);
+    const uint16_t* b_ih = f_hh + (size_t)3 * H * 3 * H + (size_t)3 * H * 3 * H;
+    const uint16_t* b_hh = b_ih + (size_t)3 * 3 * H * H;
+    WideArgs x{};
+    x.A = dgi; x.lda = 3 * H; x.a_rows = nullptr; x.R = R; x.K = 3 * H; x.img = b_ih; x.N = H;
+    x.C = d_msg; x.ldc = ld_dmsg; x.c_rows = rows; x.accumulate = 0;
+    if ((rc = launch_store(x, st))) return rc;
+    WideArgs y = x;
+    y.A = dgh; y.img = b_hh; y.C = d_h; y.ldc = ld_dh; y.accumulate = 1;
+    return launch_store(y, st);
+}
+
+}  // extern "C"

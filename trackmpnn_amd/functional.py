@@ -26,6 +26,33 @@ ATT_DROPOUT_P = 0.5
 # environment variable TMPNN_INPLACE_GRADS=1 for every module.  Default: off -- real gradients are returned.
 INPLACE_GRADS = os.environ.get('TMPNN_INPLACE_GRADS', '0') == '1'
 FUSED_BWD = os.environ.get('TMPNN_FUSED_BWD', '0') == '1'     # see mp_backward
+# H = 128 / 256 edge cells as LDS-tiled bf16x6 GEMMs (csrc/wide.hip); TMPNN_WIDE=0 keeps round 1's f32-MFMA kernels
+WIDE = os.environ.get('TMPNN_WIDE', '1') != '0' and os.environ.get('TMPNN_SPLIT', '1')[:1] != '0'
+
+
+_wide_ws: Dict[torch.device, torch.Tensor] = {}
+
+
+def _wide_workspace(nbytes: int, dev) -> torch.Tensor:
+    """The materialised gate gradients of a wide cell's backward (24 H bytes per row: 27 GB at C5) live in ONE
+    grow-only buffer per device, reused by every call (all users are ordered on the stream): handing tens of GB back
+    and forth through the caching allocator cost up to 200 ms per C5 step in allocator stalls."""
+    dev = torch.device(dev)
+    ws = _wide_ws.get(dev)
+    if ws is None or ws.numel() * 4 < nbytes + 16:
+        _wide_ws.pop(dev, None)
+        ws = torch.empty((nbytes // 4 + 4,), dtype=torch.float32, device=dev)
+        _wide_ws[dev] = ws
+    return ws
+
+
+def _wide_prep(w_ih: torch.Tensor, w_hh: torch.Tensor, H: int) -> torch.Tensor:
+    """MFMA operand images of one wide cell's weights (tmpnn_wide_prepare: four small launches).  Rebuilt on every
+    forward call -- microseconds next to a wide cell's work, and never stale; the backward reuses the call's images."""
+    nb = int(_lib.load().tmpnn_wide_prep_bytes(H, H))
+    prep = torch.empty((nb // 4 + 4,), dtype=torch.float32, device=w_ih.device)
+    _lib.call('tmpnn_wide_prepare', w_ih.data_ptr(), w_hh.data_ptr(), H, H, prep.data_ptr(), _stream())
+    return prep
 
 
 @dataclass(frozen=True)
@@ -175,6 +202,8 @@ def mp_forward(spec: ModelSpec, plan: CallPlan, x: torch.Tensor, h_in: Optional[
     plane = N * H
     lib = _lib.load()
     use_proj = spec.msg_type == 'diff' and H <= 64 and g.src_pos is not None and Dn > 0
+    use_wide = WIDE and spec.msg_type == 'diff' and H in (128, 256) and g.src_pos is not None and Dn > 0 and E > 0
+    wide_preps = []
     # output head fused into the cells' epilogues where the LDS-resident kernel runs (else tmpnn_heads_fwd)
     cw = min(lib.tmpnn_gru_fwd_head_parts(H, spec.IN_e, 3 if use_proj else xmode), lib.tmpnn_gru_fwd_head_parts(H, H, 0))
     parts = torch.empty((G * cw, N), **opts) if cw > 0 else None
@@ -192,7 +221,16 @@ def mp_forward(spec: ModelSpec, plan: CallPlan, x: torch.Tensor, h_in: Optional[
         #  hand a freed block to the very next allocation)
         e_wih_t, e_whh_t = _transpose(P[f + 'edge_gru.weight_ih']), _transpose(P[f + 'edge_gru.weight_hh'])
         n_wih_t, n_whh_t = _transpose(P[f + 'node_gru.weight_ih']), _transpose(P[f + 'node_gru.weight_hh'])
-        if use_proj:
+        if use_wide:
+            # H = 128 / 256: LDS-tiled bf16x6 GEMMs, the diff message through the projected det rows (csrc/wide.hip)
+            prep = _wide_prep(P[f + 'edge_gru.weight_ih'], P[f + 'edge_gru.weight_hh'], H)
+            wide_preps.append(prep)
+            proj = torch.empty((Dn, 3 * H), **opts)
+            _lib.call('tmpnn_wide_gru_fwd', prep.data_ptr(), g.det_row.data_ptr(), Dn, g.edge_row.data_ptr(), E,
+                      g.src_pos.data_ptr(), g.dst_pos.data_ptr(), hg, GH, H,
+                      P[f + 'edge_gru.bias_ih'].data_ptr(), P[f + 'edge_gru.bias_hh'].data_ptr(),
+                      proj.data_ptr(), og, GH, gp, plane, st)
+        elif use_proj:
             # (h[src]-h[dst]) W_ih^T = P[src] - P[dst] with P = h[dets] W_ih^T: the x-half of the edge cell's
             # forward GEMM runs over the Dn det rows instead of the E edge rows
             proj = torch.empty((Dn, 3 * H), **opts)
@@ -248,7 +286,8 @@ def mp_forward(spec: ModelSpec, plan: CallPlan, x: torch.Tensor, h_in: Optional[
                   P['output_transform_edge.weight'].data_ptr(), P['output_transform_edge.bias'].data_ptr(),
                   logits.data_ptr(), scores.data_ptr(), st)
     if save:
-        saved.update(h_cat=h_cat, gates=gates, es=es_all, att=att_saved, h_out=h_out, scores=scores)
+        saved.update(h_cat=h_cat, gates=gates, es=es_all, att=att_saved, h_out=h_out, scores=scores,
+                     wide=wide_preps if use_wide else None)
     return scores, logits, h_out, alphas, saved
 
 
@@ -353,7 +392,15 @@ def mp_backward(spec: ModelSpec, plan: CallPlan, saved: dict, P: Dict[str, torch
                       ws_w.data_ptr(), ws_w.numel() * 4, st)
             # edge GRU backward: d_ns -> dmsg[edge rows, 0:IN_e], d_hcat[edge rows]; without attention the
             # adjoint of the edge -> node sum (d_es[src] - d_es[dst], read from dmsg's det rows) rides along
-            _lib.call('tmpnn_gru_bwd_data', g.edge_row.data_ptr(), E, IN_e, hg, GH, H,
+            if saved.get('wide'):
+                wsb = int(lib.tmpnn_wide_gru_bwd_data_ws(E, H))
+                ws_wide = _wide_workspace(wsb, dev)
+                _lib.call('tmpnn_wide_gru_bwd_data', saved['wide'][gi].data_ptr(), g.edge_row.data_ptr(), E, hg, GH, H,
+                          gp, plane, dog, GH, dyp, we, dmsg.data_ptr(), IN_e, dhg, GH, ws_wide.data_ptr(), wsb, st)
+                if fuse:
+                    _lib.call('tmpnn_gather_diff_fwd', g.cref(), dmsg.data_ptr(), IN_e, dhg, GH, H, 1, st)
+            else:
+              _lib.call('tmpnn_gru_bwd_data', g.edge_row.data_ptr(), E, IN_e, hg, GH, H,
                       P[f + 'edge_gru.weight_ih'].data_ptr(), P[f + 'edge_gru.weight_hh'].data_ptr(),
                       gp, plane, dog, GH, dyp, we, dmsg.data_ptr(), IN_e, dhg, GH,
                       g.src.data_ptr() if fuse else None, g.dst.data_ptr() if fuse else None,
