@@ -189,19 +189,22 @@ def _pmc_kernel(stage):
 
 
 def pmc_traffic(stage, E):
-    """HBM bytes per launch of the stage's kernel from the committed rocprofv3 PMC passes (FETCH_SIZE and
-    WRITE_SIZE, separate runs of tools/stage_bench.py; raw counters, see the note in the file).  None unless the
-    profile was taken on a graph of exactly this size."""
-    path = os.path.join(ROOT, 'profiles', 'r01_pmc_traffic_stage_kernels.json')
-    try:
-        prof = json.load(open(path))
-    except OSError:
-        return None
-    if prof.get('graph', {}).get('E') != E:
-        return None
-    for name, v in prof['kernels'].items():
-        if _pmc_kernel(stage) in name and v.get('WRITE_SIZE_KB') is not None:
-            return (v['FETCH_SIZE_KB'] + v['WRITE_SIZE_KB']) * 1024.0
+    """HBM bytes per launch of the stage's kernel from the committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE
+    in two separate runs of tools/stage_bench.py, profiles/r02_pmc_traffic_stage_kernels.json), corrected as
+    MI355X_MICROARCH.md prescribes for gfx950: FETCH_SIZE tallies the 128-byte requests of a wide coalesced stream
+    (16 B per lane -- every row stream of these kernels) at 64 bytes, so reads = 2 x FETCH_SIZE; WRITE_SIZE is exact for
+    16-byte-per-lane stores.  None unless the profile was taken on a graph of exactly this size."""
+    for tag in ('r02', 'r01'):
+        path = os.path.join(ROOT, 'profiles', f'{tag}_pmc_traffic_stage_kernels.json')
+        try:
+            prof = json.load(open(path))
+        except OSError:
+            continue
+        if prof.get('graph', {}).get('E') != E:
+            continue
+        for name, v in prof['kernels'].items():
+            if _pmc_kernel(stage) in name and v.get('WRITE_SIZE_KB') is not None:
+                return (2.0 * v['FETCH_SIZE_KB'] + v['WRITE_SIZE_KB']) * 1024.0
     return None
 
 
@@ -417,6 +420,14 @@ def main():
             gather_GBs=nbytes['gather_diff'] / (t['gather_diff'] * 1e-3) / 1e9,
             segsum_GBs=nbytes['segsum'] / (t['segsum'] * 1e-3) / 1e9)
         extra['stage_ms'] = {k: round(v, 4) for k, v in t.items()}
+        # what ONE edge row costs per forward call + its share of the backward in the staged step (algorithmic bytes of
+        # the kernels as the step runs them: edge forward, folded backward-data, backward-weights, row F and its
+        # adjoint) against the aggregation-only model of SURVEY 8(d) (16H + 36): saving the gates dominates
+        gE = float(plans[-1].graph.E)
+        extra['step_bytes_per_edge_iteration'] = dict(
+            staged_step=round((nbytes['gru_fwd_edge'] + nbytes['gru_bwd_data_edge_folded'] + nbytes['gru_bwd_weights_edge']
+                               + 2 * nbytes['segsum']) / gE, 1),
+            survey_aggregation_model=16 * H + 36)
         from trackmpnn_amd import _lib as _l
         extra['weights_kernel'] = {1: 'bf16x6', 0: 'f32-mfma'}[_l.load().tmpnn_gru_bwd_weights_choice()]
         extra['stage_graph'] = dict(N=plans[-1].graph.N, E=plans[-1].graph.E, Dn=plans[-1].graph.Dn)

@@ -339,6 +339,11 @@ int tmpnn_graph_from_coo(int N, const int64_t* node_idx, const float* node_val, 
                          const int64_t* edge_idx, const float* edge_val, int64_t nnz_edge,
                          const tmpnn_dgraph* g, tmpnn_stream stream);
 
+/* tmpnn_graph_from_coo on an arena of tmpnn_dgraph_ints(cap) int32 (= tmpnn_dgraph_bind + the conversion, one call) */
+int tmpnn_graph_from_coo_arena(int N, const int64_t* node_idx, const float* node_val, int64_t nnz_node,
+                               const int64_t* edge_idx, const float* edge_val, int64_t nnz_edge, void* arena, int cap,
+                               tmpnn_stream stream);
+
 /* The same index form from the ROW form of a graph (type mask + the two endpoint rows of every edge row): what the
  * tracker-side operations below edit.  Same validation, same status bits. */
 int tmpnn_graph_from_rows(int N, const uint8_t* is_edge, const int32_t* row_src, const int32_t* row_dst,

@@ -31,11 +31,11 @@ def pmc(path, name):
 fetch = pmc(f'gpurun_out/{tag}_fetch/runc/*_counter_collection.csv', 'FETCH_SIZE')
 write = pmc(f'gpurun_out/{tag}_write/runc/*_counter_collection.csv', 'WRITE_SIZE')
 stages = json.loads([l for l in open(f'gpurun_out/{tag}_write.log', errors='ignore') if l.startswith('{"E"')][0])
-out = {'command': 'rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE (two separate passes) -- python3 tools/stage_bench.py --windows 16384',
+out = {'command': 'rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE (two separate passes, --kernel-trace only) -- python3 tools/stage_bench.py --windows 16384',
        'graph': {k: stages[k] for k in ('E', 'Dn', 'N')},
-       'note': 'per-launch averages; KB as reported by rocprofv3 (x1024 = bytes), uncorrected. On known byte counts FETCH_SIZE read '
-               '1.00x for k_segsum but ~0.5x for the 16-byte-per-lane row streams of the GRU backward kernels (MI355X_MICROARCH.md, '
-               'HBM section: gfx950 tallies 128-B requests of wide coalesced reads at 64 B).',
+       'note': 'per-launch averages; KB as reported by rocprofv3 (x1024 = bytes), RAW. gfx950 tallies the 128-B requests of wide '
+               'coalesced reads (16 B per lane) at 64 B (MI355X_MICROARCH.md, HBM section): bench.py prices reads as 2 x FETCH_SIZE '
+               'and writes as WRITE_SIZE.',
        'kernels': {k[:90]: dict(FETCH_SIZE_KB=fetch[k], WRITE_SIZE_KB=write.get(k)) for k in fetch if 'tmpnn' in k}}
 json.dump(out, open(f'profiles/{tag}_pmc_traffic_stage_kernels.json', 'w'), indent=1)
 d = json.loads(line)

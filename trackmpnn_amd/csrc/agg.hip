@@ -274,8 +274,10 @@ __global__ __launch_bounds__(256) void k_segsum_pipe(int Dn, const int32_t* __re
         }
     };
     fetchA(); advanceB(); fetchA(); advanceC(); advanceB(); fetchA();
+    int pbC = p0C + grp;                       // first CSR position of this lane group in the current pass
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     while (dC >= 0) {
-        const int d = dC, p0 = p0C, p1 = p1C;
+        const int d = dC;
         float4 x[U];
         bool live[U];
         float w[U];
@@ -286,9 +288,20 @@ __global__ __launch_bounds__(256) void k_segsum_pipe(int Dn, const int32_t* __re
             w[u] = vC[u] < 0 ? wneg : 1.0f;
             x[u] = *reinterpret_cast<const float4*>(in + (size_t)row * ld_in + (vC[u] < 0 ? cneg : 0) + c4);
         }
-        // the next dets' index loads are issued behind this det's row loads
-        advanceC(); advanceB(); fetchA();
-        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        // the next item's index loads are issued behind this pass's row loads: the det's next pass (a long CSR run
+        // takes several) or, after its last pass, the next det of the pipeline
+        const bool last = (pbC - grp) + ngrp * U >= p1C;          // wave-uniform
+        if (!last) {
+            pbC += ngrp * U;
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int p = pbC + u * ngrp;
+                vC[u] = p < p1C ? inc[p] : 0x7fffffff;
+            }
+        } else {
+            advanceC(); advanceB(); fetchA();
+            pbC = p0C + grp;
+        }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             if (live[u]) { x[u].x *= w[u]; x[u].y *= w[u]; x[u].z *= w[u]; x[u].w *= w[u]; }
@@ -296,27 +309,7 @@ __global__ __launch_bounds__(256) void k_segsum_pipe(int Dn, const int32_t* __re
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) { acc.x += x[u].x; acc.y += x[u].y; acc.z += x[u].z; acc.w += x[u].w; }
-        // long runs: the remaining passes, as in k_segsum (same order of additions)
-        for (int pb = p0 + grp + ngrp * U; pb < p1; pb += ngrp * U) {
-            int v[U];
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int p = pb + u * ngrp;
-                v[u] = p < p1 ? inc[p] : 0x7fffffff;
-            }
-            float4 y[U];
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const bool lv = v[u] != 0x7fffffff;
-                const int row = lv ? (v[u] & 0x7fffffff) : 0;
-                y[u] = *reinterpret_cast<const float4*>(in + (size_t)row * ld_in + (v[u] < 0 ? cneg : 0) + c4);
-                const float ww = v[u] < 0 ? wneg : 1.0f;
-                if (lv) { y[u].x *= ww; y[u].y *= ww; y[u].z *= ww; y[u].w *= ww; }
-                else y[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-            }
-#pragma unroll
-            for (int u = 0; u < U; ++u) { acc.x += y[u].x; acc.y += y[u].y; acc.z += y[u].z; acc.w += y[u].w; }
-        }
+        if (!last) continue;
         for (int off = lpr; off < 64; off <<= 1) {
             acc.x += __shfl_xor(acc.x, off);
             acc.y += __shfl_xor(acc.y, off);
@@ -331,6 +324,7 @@ __global__ __launch_bounds__(256) void k_segsum_pipe(int Dn, const int32_t* __re
             }
             *reinterpret_cast<float4*>(o) = acc;
         }
+        acc = make_float4(0.f, 0.f, 0.f, 0.f);
     }
 }
 

@@ -258,6 +258,15 @@ int tmpnn_graph_from_coo(int N, const int64_t* node_idx, const float* node_val, 
     return check_launch("graph_from_coo");
 }
 
+int tmpnn_graph_from_coo_arena(int N, const int64_t* node_idx, const float* node_val, int64_t nnz_node,
+                               const int64_t* edge_idx, const float* edge_val, int64_t nnz_edge, void* arena, int cap,
+                               tmpnn_stream stream) {
+    tmpnn_dgraph g;
+    const int rc = tmpnn_dgraph_bind(arena, cap, N, &g);
+    if (rc) return rc;
+    return tmpnn_graph_from_coo(N, node_idx, node_val, nnz_node, edge_idx, edge_val, nnz_edge, &g, stream);
+}
+
 int tmpnn_graph_from_rows(int N, const uint8_t* is_edge, const int32_t* row_src, const int32_t* row_dst,
                           const tmpnn_dgraph* g, tmpnn_stream stream) {
     TM_REQUIRE(g != nullptr && g->meta && g->is_edge && g->pos && g->src && g->dst && g->src_pos && g->dst_pos &&

@@ -1,0 +1,186 @@
+// Host-side autograd node of the batch-1 path in C++ (built with g++ against libtorch; no device code here).
+//
+// trackmpnn_amd/small.py implements the same node in Python (`_SmallIter`); at batch 1 the Python bookkeeping of a
+// forward + backward pair (~100 us: Function.apply, a dozen tensor allocations, two ctypes calls) exceeds the GPU time
+// of the four launches it enqueues.  This node does the identical sequence -- allocate, call the C ABI
+// (tmpnn_mp_iter_fwd / tmpnn_mp_iter_bwd through function pointers handed over from Python), keep what the backward
+// needs -- without the interpreter.  Only the in-place-gradient mode is handled here (GradBucket: parameter
+// gradients go straight into p.grad, one dummy `anchor` tensor tells autograd the outputs need a backward); every
+// other case stays on the Python node.  torch is plumbing: memory, autograd edges, nothing else.
+#include <torch/extension.h>
+
+#include <cstdint>
+
+#include "tmpnn.h"
+
+namespace {
+
+using fwd_fn = int (*)(const tmpnn_mp_params*, const float*, const tmpnn_dgraph*, int, const float*, int, float*, int,
+                       float*, float*, float*, float*, size_t, tmpnn_stream);
+using bwd_fn = int (*)(const tmpnn_mp_params*, const float*, const tmpnn_dgraph*, int, const float*, int, const float*,
+                       const float*, const float*, const float*, int, const float*, int, const float*, int, const float*,
+                       float*, float*, const tmpnn_mp_params*, void*, size_t, tmpnn_stream);
+using err_fn = const char* (*)(void);
+using bind_fn = int (*)(void*, int, int, tmpnn_dgraph*);
+
+struct CallInfo {
+    int64_t f_fwd, f_bwd, f_err;   // function addresses in libtmpnn.so
+    int64_t params, grads;         // tmpnn_mp_params* (parameters / gradient buffers), owned by Python
+    int64_t prep;                  // float* operand images
+    int64_t f_bind;                // tmpnn_dgraph_bind
+    int64_t N, G, H, IN_e, F_total;
+    int64_t stream;
+    int64_t spare;                 // spare rows behind h_out
+    bool training, need_grad, append;
+};
+
+inline size_t save_floats(int64_t N, int64_t n, int64_t G, int64_t H) {
+    return (size_t)(G * 4 * N * H + G * N * H + G * (n > 0 ? n : 1) * H + 2 * G * H + G * (n + 1) + 4);
+}
+inline size_t bwd_ws_bytes(int64_t N, int64_t n, int64_t G, int64_t H, int64_t IN_e) {
+    int64_t nb = (N + 15) / 16 + 2;
+    if (nb > 96) nb = 96;
+    if (nb < 2) nb = 2;
+    const int64_t slab = 3 * H * (IN_e + H) + 7 * H + 4;
+    return (size_t)(4 * (N * G * IN_e + nb * G * slab + G * 2 * n * H + 16));
+}
+
+class SmallIterFn : public torch::autograd::Function<SmallIterFn> {
+   public:
+    static torch::autograd::variable_list forward(torch::autograd::AutogradContext* ctx, torch::Tensor x,
+                                                  c10::optional<torch::Tensor> h_in, torch::Tensor anchor,
+                                                  torch::Tensor arena, std::vector<int64_t> info) {
+        (void)anchor;
+        CallInfo ci;
+        TORCH_CHECK(info.size() == 17, "fast_iter: bad call descriptor");
+        ci.f_fwd = info[0]; ci.f_bwd = info[1]; ci.f_err = info[2]; ci.params = info[3]; ci.grads = info[4];
+        ci.prep = info[5]; ci.f_bind = info[6]; ci.N = info[7]; ci.G = info[8]; ci.H = info[9]; ci.IN_e = info[10];
+        ci.F_total = info[11]; ci.stream = info[12]; ci.spare = info[13];
+        ci.training = info[14] != 0; ci.need_grad = info[15] != 0; ci.append = info[16] != 0;
+        const int64_t N = ci.N, GH = ci.G * ci.H, n = x.size(0), N_old = N - n;
+        const bool has_h = h_in.has_value() && h_in->defined();
+        if (!has_h) {
+            TORCH_CHECK_VALUE(N_old == 0, "h_in is None but the graph has ", N_old, " rows that are not new");
+        } else {
+            TORCH_CHECK_VALUE(h_in->size(0) == N_old && h_in->size(1) == GH, "h_in must be [", N_old, ", ", GH, "] (N - n, G*H)");
+        }
+        if (n > 0) { TORCH_CHECK_VALUE(x.size(1) == ci.F_total, "x must be [", n, ", ", ci.F_total, "]"); }
+        TORCH_CHECK_VALUE(!(ci.training && n == 1), "Expected more than 1 value per channel when training, got input size [1, ", ci.H, "]");
+        tmpnn_dgraph dg;       // the graph's arrays live in `arena` (kept alive by this node); the struct is rebuilt from it
+        TORCH_CHECK(reinterpret_cast<bind_fn>(ci.f_bind)(arena.data_ptr(), (int)N, (int)N, &dg) == 0, "tmpnn_dgraph_bind failed");
+        auto opts = x.options().dtype(torch::kFloat32).requires_grad(false);
+        torch::Tensor xd = x.detach();
+        if (xd.scalar_type() != torch::kFloat32 || !xd.is_contiguous()) xd = xd.to(torch::kFloat32).contiguous();
+        // the state the iteration reads
+        torch::Tensor h_cat;
+        if (ci.append && has_h) {
+            torch::Tensor hd = h_in->detach();
+            if (hd.is_contiguous() && hd.scalar_type() == torch::kFloat32)
+                h_cat = at::empty({0}, opts).set_(hd.storage(), hd.storage_offset(), {N, GH}, {GH, 1});
+        }
+        if (!h_cat.defined()) {
+            if (has_h && n == 0) {
+                torch::Tensor hd = h_in->detach();
+                h_cat = (hd.is_contiguous() && hd.scalar_type() == torch::kFloat32) ? hd : hd.to(torch::kFloat32).contiguous();
+            } else {
+                h_cat = at::empty({N, GH}, opts);
+                if (N_old > 0) h_cat.narrow(0, 0, N_old).copy_(h_in->detach());
+            }
+        }
+        torch::Tensor buf = at::empty({(N + ci.spare) * GH}, opts);
+        torch::Tensor h_out = at::empty({0}, opts).set_(buf.storage(), 0, {N, GH}, {GH, 1});
+        torch::Tensor logits = at::empty({N, 1}, opts), scores = at::empty({N, 1}, opts);
+        torch::Tensor save;
+        size_t nsave = 0;
+        if (ci.need_grad || n > 0) {
+            nsave = save_floats(N, n, ci.G, ci.H);
+            save = at::empty({(int64_t)nsave}, opts);
+        }
+        const int rc = reinterpret_cast<fwd_fn>(ci.f_fwd)(
+            reinterpret_cast<const tmpnn_mp_params*>(ci.params), reinterpret_cast<const float*>(ci.prep),
+            &dg, (int)n, n > 0 ? xd.data_ptr<float>() : nullptr,
+            n > 0 ? (int)xd.size(1) : 0, h_cat.data_ptr<float>(), ci.training ? 1 : 0, h_out.data_ptr<float>(),
+            logits.data_ptr<float>(), scores.data_ptr<float>(), save.defined() ? save.data_ptr<float>() : nullptr, nsave,
+            reinterpret_cast<tmpnn_stream>(ci.stream));
+        TORCH_CHECK(rc == 0, "tmpnn_mp_iter_fwd failed (code ", rc, "): ", reinterpret_cast<err_fn>(ci.f_err)());
+        if (ci.need_grad) {
+            ctx->saved_data["info"] = info;
+            ctx->saved_data["n"] = n;
+            ctx->saved_data["has_h"] = has_h;
+            ctx->saved_data["x_needs"] = x.requires_grad();
+            // plain (non-variable) tensors kept alive by the node: they are internal buffers, not autograd values
+            ctx->saved_data["xd"] = xd;
+            ctx->saved_data["h_cat"] = h_cat;
+            ctx->saved_data["save"] = save;
+            ctx->saved_data["arena"] = arena;
+            ctx->save_for_backward({scores});          // an OUTPUT: saved through the autograd mechanism (no cycle)
+        }
+        ctx->set_materialize_grads(false);
+        return {scores, logits, h_out};
+    }
+
+    static torch::autograd::variable_list backward(torch::autograd::AutogradContext* ctx,
+                                                   torch::autograd::variable_list grad_outputs) {
+        auto info = ctx->saved_data["info"].toIntVector();
+        const int64_t n = ctx->saved_data["n"].toInt();
+        const bool has_h = ctx->saved_data["has_h"].toBool();
+        const bool x_needs = ctx->saved_data["x_needs"].toBool();
+        torch::Tensor xd = ctx->saved_data["xd"].toTensor();
+        torch::Tensor h_cat = ctx->saved_data["h_cat"].toTensor();
+        torch::Tensor scores = ctx->get_saved_variables()[0];
+        torch::Tensor save = ctx->saved_data["save"].toTensor();
+        torch::Tensor arena = ctx->saved_data["arena"].toTensor();
+        const int64_t N = info[7], G = info[8], H = info[9], IN_e = info[10], F_total = info[11];
+        const int64_t GH = G * H;
+        auto opts = h_cat.options();
+        tmpnn_dgraph dg;
+        TORCH_CHECK(reinterpret_cast<bind_fn>(info[6])(arena.data_ptr(), (int)N, (int)N, &dg) == 0, "tmpnn_dgraph_bind failed");
+        auto strided = [](const torch::Tensor& t, torch::Tensor& keep, int& st) -> const float* {
+            if (!t.defined()) { st = 0; return nullptr; }
+            keep = t.scalar_type() == torch::kFloat32 ? t : t.to(torch::kFloat32);
+            int64_t s = keep.numel() > 1 ? keep.stride(0) : 1;
+            if (s < 0) { keep = keep.contiguous(); s = 1; }
+            st = (int)s;
+            return keep.data_ptr<float>();
+        };
+        torch::Tensor k_ds, k_dl, k_dh;
+        int st_ds = 0, st_dl = 0;
+        const float* ds = strided(grad_outputs[0], k_ds, st_ds);
+        const float* dl = strided(grad_outputs[1], k_dl, st_dl);
+        const float* dh = nullptr;
+        if (grad_outputs[2].defined()) {
+            k_dh = (grad_outputs[2].scalar_type() == torch::kFloat32 && grad_outputs[2].is_contiguous())
+                       ? grad_outputs[2] : grad_outputs[2].to(torch::kFloat32).contiguous();
+            dh = k_dh.data_ptr<float>();
+        }
+        torch::Tensor d_h = at::empty({N, GH}, opts);
+        torch::Tensor d_x;
+        const bool need_x = x_needs && n > 0;
+        if (need_x) d_x = at::empty({n, F_total}, opts);
+        const size_t wsb = bwd_ws_bytes(N, n, G, H, IN_e);
+        torch::Tensor ws = at::empty({(int64_t)(wsb / 4 + 4)}, opts);
+        const int rc = reinterpret_cast<bwd_fn>(info[1])(
+            reinterpret_cast<const tmpnn_mp_params*>(info[3]), reinterpret_cast<const float*>(info[5]),
+            &dg, (int)n, n > 0 ? xd.data_ptr<float>() : nullptr,
+            n > 0 ? (int)xd.size(1) : 0, h_cat.data_ptr<float>(), nullptr, scores.data_ptr<float>(),
+            save.data_ptr<float>(), info[14] != 0 ? 1 : 0, ds, st_ds, dl, st_dl, dh, d_h.data_ptr<float>(),
+            need_x ? d_x.data_ptr<float>() : nullptr, reinterpret_cast<const tmpnn_mp_params*>(info[4]), ws.data_ptr<float>(),
+            wsb, reinterpret_cast<tmpnn_stream>(info[12]));
+        TORCH_CHECK(rc == 0, "tmpnn_mp_iter_bwd failed (code ", rc, "): ", reinterpret_cast<err_fn>(info[2])());
+        if (x_needs && !need_x) d_x = at::zeros({n, F_total}, opts);
+        torch::Tensor d_h_in;
+        if (has_h && N - n > 0) d_h_in = d_h.narrow(0, 0, N - n);
+        return {d_x, d_h_in, torch::Tensor(), torch::Tensor(), torch::Tensor()};
+    }
+};
+
+std::vector<torch::Tensor> small_iter(torch::Tensor x, c10::optional<torch::Tensor> h_in, torch::Tensor anchor,
+                                      torch::Tensor arena, std::vector<int64_t> info) {
+    return SmallIterFn::apply(x, h_in, anchor, arena, info);
+}
+
+}  // namespace
+
+PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
+    m.def("small_iter", &small_iter, "fused TrackMPNN iteration on one small graph (in-place gradient mode)");
+}

@@ -491,12 +491,21 @@ class DeviceGraph:
         c = (cap + 1 + 3) & ~3
         nbytes = (((cap + 3) // 4) + 3) & ~3
         self.arena = torch.empty((8 + nbytes + 10 * c,), dtype=torch.int32, device=device)
-        b = self.arena.data_ptr()
-        o = b + 32 + 4 * nbytes
-        self.c = _lib.CDGraph(self.N, cap, b, b + 32, o, o + 4 * c, o + 8 * c, o + 12 * c, o + 16 * c, o + 20 * c,
-                              o + 24 * c, o + 28 * c, o + 32 * c)
+        self._layout = (nbytes, c)
+        self._c = None
         self._meta = None
         self._frame = None
+
+    @property
+    def c(self) -> '_lib.CDGraph':
+        """struct tmpnn_dgraph over the arena (built on first use: the fused C++ node re-binds the arena itself)."""
+        if self._c is None:
+            nbytes, c = self._layout
+            b = self.arena.data_ptr()
+            o = b + 32 + 4 * nbytes
+            self._c = _lib.CDGraph(self.N, self.cap, b, b + 32, o, o + 4 * c, o + 8 * c, o + 12 * c, o + 16 * c, o + 20 * c,
+                                   o + 24 * c, o + 28 * c, o + 32 * c)
+        return self._c
 
     @property
     def device(self):
@@ -564,6 +573,16 @@ def _coo_parts(adj: torch.Tensor, device):
     return (idx if idx.is_contiguous() else idx.contiguous()), (val if val.is_contiguous() else val.contiguous())
 
 
+_f_from_coo = None
+
+
+def _from_coo():
+    global _f_from_coo
+    if _f_from_coo is None:
+        _f_from_coo = _lib.fn('tmpnn_graph_from_coo_arena')
+    return _f_from_coo
+
+
 def device_graph_from_adjacency(node_adj: torch.Tensor, edge_adj: Optional[torch.Tensor], device) -> DeviceGraph:
     """One-launch conversion of the reference's adjacency pair (N <= DG_MAX_ROWS) on `device`; no host round trip
     for sparse inputs (a dense input costs the `nonzero` that sparsifies it)."""
@@ -579,7 +598,9 @@ def device_graph_from_adjacency(node_adj: torch.Tensor, edge_adj: Optional[torch
     else:
         eidx = eval_ = None
         ep, ev, en = None, None, 0
-    _lib.call('tmpnn_graph_from_coo', N, nidx.data_ptr(), nval.data_ptr(), int(nval.numel()), ep, ev, en, g.cref(),
-              torch.cuda.current_stream(device).cuda_stream)
+    rc = _from_coo()(N, nidx.data_ptr(), nval.data_ptr(), int(nval.numel()), ep, ev, en, g.arena.data_ptr(), g.cap,
+                     torch.cuda.current_stream(device).cuda_stream)
+    if rc:
+        raise RuntimeError(f'tmpnn_graph_from_coo_arena failed (code {rc}): {_lib.last_error()}')
     g._keep = (nidx, nval, eidx, eval_)       # until the launch has consumed them (freed with the graph)
     return g

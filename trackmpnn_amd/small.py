@@ -26,6 +26,31 @@ def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
 
+_fast_mod = False       # False: not tried yet ; None: unavailable
+
+
+def fast_module():
+    """The C++ autograd node (trackmpnn_amd/lib/_tmpnn_fast.so, built by __graft_entry__.build_host from
+    csrc_host/fast_iter.cpp): the same node as `_SmallIter` without the interpreter, for the in-place-gradient mode.
+    TMPNN_FAST=0 (or a missing / unloadable extension) keeps the Python node -- both drive the same HIP kernels."""
+    global _fast_mod
+    if _fast_mod is False:
+        _fast_mod = None
+        import os
+        if os.environ.get('TMPNN_FAST', '1') != '0':
+            path = os.path.join(os.path.dirname(_lib.LIB_PATH), '_tmpnn_fast.so')
+            if os.path.exists(path):
+                try:
+                    import importlib.util
+                    spec = importlib.util.spec_from_file_location('_tmpnn_fast', path)
+                    mod = importlib.util.module_from_spec(spec)
+                    spec.loader.exec_module(mod)
+                    _fast_mod = mod
+                except Exception:      # noqa: BLE001  (ABI mismatch with the installed torch: stay on the Python node)
+                    _fast_mod = None
+    return _fast_mod
+
+
 class SmallPath:
     """Per-model cache of what a fused call needs: the parameter pointer struct, the MFMA operand images of the GRU
     weights (rebuilt when a weight's version counter changes, i.e. once per optimizer step) and the layout of the
@@ -43,6 +68,7 @@ class SmallPath:
         self.prep = None
         self._grad_struct_cache = {}
         self.f_fwd = self.f_bwd = None
+        self._fast_addrs = None
         # layout of the flat gradient buffer (256-byte aligned slices), in param_names() order
         sizes, offs = [], [0]
         named = dict(model.named_parameters())
@@ -103,6 +129,19 @@ class SmallPath:
             _lib.call('tmpnn_mp_iter_prepare', C.byref(self.cparams), self.prep.data_ptr(), _stream())
             self._ver_key = None if capturing else vkey
         return self.cparams
+
+    def fast_info(self, plist, graph, n_grad_struct, training: bool, need_grad: bool, append: bool, spare: int):
+        """The 17-integer call descriptor of the C++ node (function addresses, struct addresses, sizes, flags)."""
+        cp = self.params(plist)
+        if self._fast_addrs is None:
+            lib = _lib.load()
+            addr = lambda f: C.cast(f, C.c_void_p).value
+            self._fast_addrs = (addr(lib.tmpnn_mp_iter_fwd), addr(lib.tmpnn_mp_iter_bwd), addr(lib.tmpnn_last_error),
+                                addr(lib.tmpnn_dgraph_bind))
+        a = self._fast_addrs
+        spec = self.spec
+        return [a[0], a[1], a[2], C.addressof(cp), C.addressof(n_grad_struct), self.prep.data_ptr(), a[3], graph.N,
+                spec.G, spec.H, spec.IN_e, spec.F_total, _stream(), spare, int(training), int(need_grad), int(append)]
 
     def invalidate(self) -> None:
         """Parameter / buffer storage may have moved (Module._apply, load_state_dict(assign=True)): re-read pointers."""

@@ -21,7 +21,7 @@ from .functional import MPIteration, ModelSpec
 from .graph import (CallPlan, DeviceGraph, FrameGraph, device_graph_from_adjacency, graph_from_adjacency,
                     plan_single)
 from .layers import FactorGraphGRU
-from .small import SmallPath, _SmallIter, small_eligible
+from .small import SmallPath, _SmallIter, fast_module, small_eligible
 
 STRICT_GRAPH = os.environ.get('TMPNN_STRICT_GRAPH', '0') == '1'     # validate every adjacency at once (host sync)
 SMALL_PATH = os.environ.get('TMPNN_SMALL_PATH', '1') != '0'         # fused batch-1 iteration for eligible calls
@@ -96,6 +96,9 @@ class TrackMPNN(nn.Module):
         self._plist = None
         self._bufs = None
         self._anchor = None
+        self._anch_key = None
+        self._anch_calls = 0
+        self._gst = None
         self._pending_graphs = []              # DeviceGraphs whose validation status has not been read back yet
 
     def _apply(self, fn, *args, **kwargs):
@@ -103,6 +106,7 @@ class TrackMPNN(nn.Module):
         out = super()._apply(fn, *args, **kwargs)
         self._small.invalidate()
         self._plist = self._bufs = self._anchor = None
+        self._anch_key = None
         self._graph_cache = None
         return out
 
@@ -185,9 +189,19 @@ class TrackMPNN(nn.Module):
         # in-place accumulation (GradBucket): the parameters are not autograd inputs -- one dummy tensor stands in
         anchored = False
         if pgrad and (self.inplace_param_grads or _functional.INPLACE_GRADS):
-            dev = x.device
-            anchored = all(p.requires_grad and p.grad is not None and p.grad.dtype == torch.float32
-                           and p.grad.is_contiguous() and p.grad.device == dev for p in params)
+            # every parameter must own a usable .grad buffer; checked in full when the first / last buffer moves and
+            # every 64th call, by two sentinel pointers otherwise
+            g0, g1 = params[0].grad, params[-1].grad
+            key = (g0.data_ptr(), g1.data_ptr()) if (g0 is not None and g1 is not None) else None
+            self._anch_calls += 1
+            if key is not None and key == self._anch_key and (self._anch_calls & 63):
+                anchored = True
+            else:
+                dev = x.device
+                anchored = all(p.requires_grad and p.grad is not None and p.grad.dtype == torch.float32
+                               and p.grad.is_contiguous() and p.grad.device == dev for p in params)
+                self._anch_key = key if anchored else None
+                self._gst = self._small.grad_struct([p.grad for p in params]) if anchored else None
         spare = max(256, graph.N)
         # the carried state is extended IN PLACE when it came out of this path (it has spare rows behind it) and has
         # not been continued from before; a second continuation from the same tensor copies instead
@@ -201,7 +215,14 @@ class TrackMPNN(nn.Module):
         if anchored:
             if self._anchor is None or self._anchor.device != x.device:
                 self._anchor = torch.zeros(1, device=x.device, requires_grad=True)
-            scores, logits, h_out = _SmallIter.apply(call, x, h_in, self._anchor)
+            fast = fast_module()
+            if fast is not None and graph.cap == graph.N:
+                # C++ autograd node (csrc_host/fast_iter.cpp): same kernels, no interpreter between the allocations
+                sp = self._small
+                info = sp.fast_info(params, graph, self._gst, self.training, need_grad, append, spare)
+                scores, logits, h_out = fast.small_iter(x, h_in, self._anchor, graph.arena, info)
+            else:
+                scores, logits, h_out = _SmallIter.apply(call, x, h_in, self._anchor)
         else:
             scores, logits, h_out = _SmallIter.apply(call, x, h_in, *params)
         h_out._tmpnn_spare_rows = spare
