@@ -236,25 +236,34 @@ struct IterFwdArgs {
     float* es;                 // [G][N][H]   or NULL (nothing saved)
 };
 
-// gi/gh MFMA loop of one column slice: acc[gate] += A(tile rows, K = W) x image
+// gi/gh MFMA loop of one column slice: acc[gate] += A(tile rows, K = W) x image.  The weight operands (3 gates x W/16
+// float4 per lane, L2-resident) are requested up front in one burst: issued inside the loop, every 16-k step waited
+// for its own L2 round trip (measured: 8 such waits were a third of the kernel at N = 375).
 template <int W, int H>
-__device__ __forceinline__ void cell_gemm(const float* __restrict__ sA, int ldA, const float* __restrict__ img, int cs,
-                                          int lane, f32x4 (&acc)[3]) {
+struct CellB { float4 v[3][W / 16]; };
+
+template <int W, int H>
+__device__ __forceinline__ void cell_load_b(const float* __restrict__ img, int cs, int lane, CellB<W, H>& b) {
+#pragma unroll
+    for (int gate = 0; gate < 3; ++gate)
+#pragma unroll
+        for (int i = 0; i < W / 16; ++i)
+            b.v[gate][i] = *reinterpret_cast<const float4*>(img + ((size_t)((gate * (H / 16) + cs) * (W / 16) + i) * 64 + lane) * 4);
+}
+
+template <int W, int H>
+__device__ __forceinline__ void cell_gemm(const float* __restrict__ sA, int ldA, const CellB<W, H>& b, int lane, f32x4 (&acc)[3]) {
     const int row = lane & 15, kh = lane >> 4;
     const float* ap = sA + row * ldA + kh * (W / 4);
-#pragma unroll 2
+#pragma unroll
     for (int i = 0; i < W / 16; ++i) {
         const float4 av = *reinterpret_cast<const float4*>(ap + 4 * i);
-        float4 bv[3];
-#pragma unroll
-        for (int gate = 0; gate < 3; ++gate)
-            bv[gate] = *reinterpret_cast<const float4*>(img + ((size_t)((gate * (H / 16) + cs) * (W / 16) + i) * 64 + lane) * 4);
 #pragma unroll
         for (int gate = 0; gate < 3; ++gate) {
-            acc[gate] = mfma16(av.x, bv[gate].x, acc[gate]);
-            acc[gate] = mfma16(av.y, bv[gate].y, acc[gate]);
-            acc[gate] = mfma16(av.z, bv[gate].z, acc[gate]);
-            acc[gate] = mfma16(av.w, bv[gate].w, acc[gate]);
+            acc[gate] = mfma16(av.x, b.v[gate][i].x, acc[gate]);
+            acc[gate] = mfma16(av.y, b.v[gate][i].y, acc[gate]);
+            acc[gate] = mfma16(av.z, b.v[gate][i].z, acc[gate]);
+            acc[gate] = mfma16(av.w, b.v[gate][i].w, acc[gate]);
         }
     }
 }
@@ -291,6 +300,25 @@ __global__ __launch_bounds__(256) void k_small_iter_fwd(IterFwdArgs a) {
     __syncthreads();
     for (int gi = 0; gi < G; ++gi) {
         const float* hg = a.h + gi * H;
+        const float* img = a.prep + (size_t)gi * PL.per_group;
+        const float* img_ih = img + (is_e ? PL.e_ih_f : PL.n_ih_f);
+        const float* img_hh = img + (is_e ? PL.e_hh_f : PL.n_hh_f);
+        const float* b_ih = is_e ? a.P.e_bih[gi] : a.P.n_bih[gi];
+        const float* b_hh = is_e ? a.P.e_bhh[gi] : a.P.n_bhh[gi];
+        // weight operands of this wave's column slice (one slice per wave at H = 64): requested now, consumed after
+        // the tile has been staged
+        CellB<IN_E, H> bI_e;
+        CellB<H, H> bI_n, bH;
+        float bir = 0.f, biz = 0.f, bin_ = 0.f, bhr = 0.f, bhz = 0.f, bhn = 0.f, wh = 0.f;
+        if (wave < H / 16) {
+            if (is_e) cell_load_b<IN_E, H>(img_ih, wave, lane, bI_e);
+            else cell_load_b<H, H>(img_ih, wave, lane, bI_n);
+            cell_load_b<H, H>(img_hh, wave, lane, bH);
+            const int col0 = 16 * wave + (lane & 15);
+            bir = b_ih[col0]; biz = b_ih[H + col0]; bin_ = b_ih[2 * H + col0];
+            bhr = b_hh[col0]; bhz = b_hh[H + col0]; bhn = b_hh[2 * H + col0];
+            wh = w_head[gi * H + col0];
+        }
         // ---- stage the operand tiles
         if (tid < TR * (H / 4)) {
             const int row = tid / (H / 4), c4 = tid % (H / 4);
@@ -336,22 +364,14 @@ __global__ __launch_bounds__(256) void k_small_iter_fwd(IterFwdArgs a) {
             }
         }
         __syncthreads();
-        const float* img = a.prep + (size_t)gi * PL.per_group;
-        const float* img_ih = img + (is_e ? PL.e_ih_f : PL.n_ih_f);
-        const float* img_hh = img + (is_e ? PL.e_hh_f : PL.n_hh_f);
-        const float* b_ih = is_e ? a.P.e_bih[gi] : a.P.n_bih[gi];
-        const float* b_hh = is_e ? a.P.e_bhh[gi] : a.P.n_bhh[gi];
         for (int cs = wave; cs < H / 16; cs += 4) {
             f32x4 gi_[3], gh_[3];
 #pragma unroll
             for (int q = 0; q < 3; ++q) { gi_[q] = (f32x4){0.f, 0.f, 0.f, 0.f}; gh_[q] = gi_[q]; }
-            if (is_e) cell_gemm<IN_E, H>(sX, LDX, img_ih, cs, lane, gi_);
-            else cell_gemm<H, H>(sX, LDX, img_ih, cs, lane, gi_);
-            cell_gemm<H, H>(sH, LDH, img_hh, cs, lane, gh_);
+            if (is_e) cell_gemm<IN_E, H>(sX, LDX, bI_e, lane, gi_);
+            else cell_gemm<H, H>(sX, LDX, bI_n, lane, gi_);
+            cell_gemm<H, H>(sH, LDH, bH, lane, gh_);
             const int col = 16 * cs + (lane & 15);
-            const float bir = b_ih[col], biz = b_ih[H + col], bin_ = b_ih[2 * H + col];
-            const float bhr = b_hh[col], bhz = b_hh[H + col], bhn = b_hh[2 * H + col];
-            const float wh = w_head[gi * H + col];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = 4 * (lane >> 4) + r;
@@ -422,7 +442,7 @@ struct IterBwdArgs {
 };
 
 template <int H, int IN_E>
-__global__ __launch_bounds__(256) void k_small_iter_bwd(IterBwdArgs a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_small_iter_bwd(IterBwdArgs a) {
     const int E = a.g.meta[0], Dn = a.g.meta[1];
     const int nEt = (E + TR - 1) / TR, nDt = (Dn + TR - 1) / TR;
     const int nb = gridDim.x;
@@ -437,6 +457,7 @@ __global__ __launch_bounds__(256) void k_small_iter_bwd(IterBwdArgs a) {
     constexpr int LDX = IN_E + 4, LDH = H + 4, LDG = 3 * H + 4;
     constexpr int NJT = (3 * H / 16 + 3) / 4;          // j-tiles (16 rows of dW) per wave
     constexpr int NCT_I = IN_E / 16, NCT_H = H / 16;   // column tiles of dW_ih (edge cell) / dW_hh
+    constexpr int NDT = (NCT_I + NCT_H + 3) / 4;       // data-gradient column tiles per wave
     constexpr int O_X = 0, O_H = O_X + TR * LDX, O_GI = O_H + TR * LDH, O_GH = O_GI + TR * LDG, O_DHZ = O_GH + TR * LDG,
                   O_END = O_DHZ + TR * (H + 1);
     constexpr int RED = TR * (5 * H + 1);              // the end-of-group column sums reuse the tile images
@@ -472,6 +493,20 @@ __global__ __launch_bounds__(256) void k_small_iter_bwd(IterBwdArgs a) {
         const float* img = a.prep + (size_t)gi * PL.per_group;
         const float* img_ih = img + (is_e ? PL.e_ih_b : PL.n_ih_b);
         const float* img_hh = img + (is_e ? PL.e_hh_b : PL.n_hh_b);
+        // the weight operands of this wave's data-gradient column tiles stay in registers for the whole tile loop (the
+        // block has one wave per SIMD and 512 registers each: loading them per tile cost an L2 round trip per 16-k step)
+        float4 wB[NDT][3 * H / 16];
+#pragma unroll
+        for (int cq = 0; cq < NDT; ++cq) {
+            const int ct = wave + 4 * cq;
+            const bool ih = ct < nct_i;
+            const int c = ih ? ct : ct - nct_i;
+            const float* im = (ih ? img_ih : img_hh) + (size_t)c * (3 * H / 16) * 256;
+#pragma unroll
+            for (int i = 0; i < 3 * H / 16; ++i)
+                wB[cq][i] = (ct < nct_i + NCT_H && my0 < ntiles) ? *reinterpret_cast<const float4*>(im + ((size_t)i * 64 + lane) * 4)
+                                                                : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
         for (int tile = my0; tile < ntiles; tile += mystride) {
             const int r0 = tile * TR;
             __syncthreads();                               // the previous tile's LDS reads are done
@@ -554,16 +589,18 @@ __global__ __launch_bounds__(256) void k_small_iter_bwd(IterBwdArgs a) {
             // ---- data gradients: d_x = d_gi W_ih (IN columns), d_hprev = dh z + d_gh W_hh (H columns)
             {
                 const int row = lane & 15, kh = lane >> 4;
-                for (int ct = wave; ct < nct_i + NCT_H; ct += 4) {
+#pragma unroll
+                for (int cq = 0; cq < NDT; ++cq) {
+                    const int ct = wave + 4 * cq;
+                    if (ct >= nct_i + NCT_H) continue;
                     const bool ih = ct < nct_i;
                     const int c = ih ? ct : ct - nct_i;
                     const float* sA = (ih ? sGi : sGh) + row * LDG + kh * (3 * H / 4);
-                    const float* im = (ih ? img_ih : img_hh) + (size_t)c * (3 * H / 16) * 256;
                     f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll 4
+#pragma unroll
                     for (int i = 0; i < 3 * H / 16; ++i) {
                         const float4 av = *reinterpret_cast<const float4*>(sA + 4 * i);
-                        const float4 bv = *reinterpret_cast<const float4*>(im + ((size_t)i * 64 + lane) * 4);
+                        const float4 bv = wB[cq][i];
                         acc = mfma16(av.x, bv.x, acc);
                         acc = mfma16(av.y, bv.y, acc);
                         acc = mfma16(av.z, bv.z, acc);
@@ -721,8 +758,9 @@ __device__ __forceinline__ float4 adjoint_at(const FinishArgs& a, int row, int g
 
 // input-transform backward of feature group gi by ONE block (models/track_mpnn.py:45-52,59-61 reversed).
 // B0 / B1: [nd][ldb] work arrays (LDS when the new det rows fit, else global scratch).
+static constexpr int BN_LDS_ROWS_C = 120;
 template <int H, int IN_E>
-__device__ void bn_bwd_block(const FinishArgs& a, int gi, float* B0, float* B1, int ldb) {
+__device__ void bn_bwd_block(const FinishArgs& a, int gi, float* B0, float* B1, int ldb, float* stage /* LDS, BN_STAGE floats */) {
     const int N = a.g.N, n = a.n_new, N_old = N - n;
     const int F = a.P.F[gi], Ft = a.P.F_total;
     int f0 = 0;
@@ -744,6 +782,26 @@ __device__ void bn_bwd_block(const FinishArgs& a, int gi, float* B0, float* B1, 
         s_rstd[tid] = a.rstd[(size_t)gi * H + tid];
         s_gam[tid] = a.P.gamma[gi][tid];
     }
+    // the small operands every later step re-reads -- W2 [H][H], W1 [H][F], the det rows' features [nd][F] -- are
+    // copied into the LDS in ONE burst of independent loads, behind which the dependent index chain of step 1 hides;
+    // each later step then costs LDS latencies instead of an L2 round trip (wide feature groups keep reading L2)
+    const bool staged = F <= 16 && nd <= BN_LDS_ROWS_C;
+    const float* W2 = a.P.w2[gi];
+    const float* W1 = a.P.w1[gi];
+    const float* xs = a.x + f0;
+    int ldxs = a.ld_x;
+    float* sW2 = stage;
+    for (int idx = tid; idx < H * H; idx += 256) sW2[idx] = W2[idx];
+    W2 = sW2;
+    if (staged) {
+        float* sW1 = stage + H * H;
+        float* sx = sW1 + H * 16;
+        for (int idx = tid; idx < H * F; idx += 256) sW1[idx] = W1[idx];
+        for (int idx = tid; idx < nd * F; idx += 256) sx[idx] = a.x[(size_t)newdet[idx / F] * a.ld_x + f0 + idx % F];
+        W1 = sW1;
+        xs = sx;
+        ldxs = F;
+    }
     __syncthreads();
     // 1. d_out (complete gradient of the new det rows' state) and the recomputed activations a
     {
@@ -764,12 +822,23 @@ __device__ void bn_bwd_block(const FinishArgs& a, int gi, float* B0, float* B1, 
     // 2. dW2[c][k] += sum_i d_out[i][c] a[i][k] ; db2[c] += sum_i d_out[i][c]
     {
         float* dW2 = a.grads.w2[gi];
-        for (int idx = tid; idx < H * H; idx += 256) {
+        // (all partial sums first, then the read-modify-writes back to back: interleaved, every += waited for its own
+        //  L2 round trip -- 16 of them in a row were half of this kernel)
+        constexpr int NQ = H * H / 256;
+        float sacc[NQ];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int idx = tid + q * 256;
             const int cc = idx / H, k = idx % H;
             float s = 0.f;
             for (int i = 0; i < nd; ++i) s = fmaf(B0[(size_t)i * ldb + cc], B1[(size_t)i * ldb + k], s);
-            dW2[idx] += s;
+            sacc[q] = s;
         }
+        float old[NQ];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) old[q] = dW2[tid + q * 256];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) dW2[tid + q * 256] = old[q] + sacc[q];
         if (tid < H) {
             float s = 0.f;
             for (int i = 0; i < nd; ++i) s += B0[(size_t)i * ldb + tid];
@@ -779,7 +848,6 @@ __device__ void bn_bwd_block(const FinishArgs& a, int gi, float* B0, float* B1, 
     __syncthreads();
     // 3. d_a = d_out W2 ; d_pre = d_a [a > 0]  (overwrites a in B1)
     {
-        const float* W2 = a.P.w2[gi];
         for (int i = sub; i < nd; i += NSUB) {
             float s = 0.f;
 #pragma unroll 8
@@ -818,11 +886,23 @@ __device__ void bn_bwd_block(const FinishArgs& a, int gi, float* B0, float* B1, 
     // 6. dW1[k][f] += sum_i d_y1[i][k] x[i][f] ; db1[k] += sum_i d_y1[i][k] + nz * d_y1_zero[k]
     {
         float* dW1 = a.grads.w1[gi];
-        for (int idx = tid; idx < H * F; idx += 256) {
-            const int k = idx / F, f = idx % F;
-            float s = 0.f;
-            for (int i = 0; i < nd; ++i) s = fmaf(B0[(size_t)i * ldb + k], a.x[(size_t)newdet[i] * a.ld_x + f0 + f], s);
-            dW1[idx] += s;
+        for (int base = 0; base < H * F; base += 256 * 8) {
+            float sacc[8], old[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int idx = base + tid + q * 256;
+                float s = 0.f;
+                if (idx < H * F) {
+                    const int k = idx / F, f = idx % F;
+                    for (int i = 0; i < nd; ++i)
+                        s = fmaf(B0[(size_t)i * ldb + k], staged ? xs[i * ldxs + f] : a.x[(size_t)newdet[i] * a.ld_x + f0 + f], s);
+                }
+                sacc[q] = s;
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) { const int idx = base + tid + q * 256; old[q] = idx < H * F ? dW1[idx] : 0.f; }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) { const int idx = base + tid + q * 256; if (idx < H * F) dW1[idx] = old[q] + sacc[q]; }
         }
         if (tid < H) {
             float s = nz * s_dyz[tid];
@@ -832,7 +912,6 @@ __device__ void bn_bwd_block(const FinishArgs& a, int gi, float* B0, float* B1, 
     }
     // 7. d_x: det rows  d_y1 W1 ; zero rows  d_y1_zero W1 (what reaches them through the batch statistics)
     if (a.d_x) {
-        const float* W1 = a.P.w1[gi];
         for (int idx = tid; idx < n * F; idx += 256) {
             const int i = idx / F, f = idx % F;
             if (!a.g.is_edge[N_old + i]) continue;
@@ -850,6 +929,8 @@ __device__ void bn_bwd_block(const FinishArgs& a, int gi, float* B0, float* B1, 
 }
 
 static constexpr int BN_LDS_ROWS = 120;      // new det rows whose two work arrays fit the LDS (2 x 120 x 65 floats)
+// LDS staging area of bn_bwd_block: W2 [H][H] + W1 [H][16] + features [120][16]
+__host__ __device__ constexpr int bn_stage_floats(int H) { return H * H + H * 16 + BN_LDS_ROWS * 16; }
 
 template <int H, int IN_E>
 __global__ __launch_bounds__(256) void k_small_bwd_finish(FinishArgs a) {
@@ -875,10 +956,11 @@ __global__ __launch_bounds__(256) void k_small_bwd_finish(FinishArgs a) {
         const int gi = blockIdx.x - a.row_blocks - a.red_blocks;
         extern __shared__ float dyn[];
         const int nd = a.newdet[(size_t)gi * (a.n_new + 1) + a.n_new];
-        if (nd <= BN_LDS_ROWS) bn_bwd_block<H, IN_E>(a, gi, dyn, dyn + BN_LDS_ROWS * (H + 1), H + 1);
+        float* stage = dyn + 2 * BN_LDS_ROWS * (H + 1);
+        if (nd <= BN_LDS_ROWS) bn_bwd_block<H, IN_E>(a, gi, dyn, dyn + BN_LDS_ROWS * (H + 1), H + 1, stage);
         else {
             float* B0 = a.scratch + (size_t)gi * 2 * a.n_new * H;
-            bn_bwd_block<H, IN_E>(a, gi, B0, B0 + (size_t)a.n_new * H, H);
+            bn_bwd_block<H, IN_E>(a, gi, B0, B0 + (size_t)a.n_new * H, H, stage);
         }
         return;
     }
@@ -892,27 +974,46 @@ __global__ __launch_bounds__(256) void k_small_bwd_finish(FinishArgs a) {
     const size_t total = per_g * G;
     const int rb = a.red_blocks;
     const int bid = blockIdx.x - a.row_blocks;
-    for (size_t idx = (size_t)bid * 256 + tid; idx < total; idx += (size_t)rb * 256) {
-        const int gi = (int)(idx / per_g);
-        size_t q = idx % per_g;
-        const bool edge = q < n_e;
-        if (!edge) q -= n_e;
-        const int IN = edge ? IN_E : H;
-        const int b0 = edge ? 0 : nbE, b1 = edge ? usedE : nbE + usedD;
-        float s = 0.f;
-        for (int b = b0; b < b1; ++b) s += a.slabs[((size_t)b * G + gi) * SLF + q];
-        const size_t nih = (size_t)3 * H * IN, nhh = (size_t)3 * H * H;
-        float* dst;
-        if (q < nih) dst = (edge ? a.grads.e_wih[gi] : a.grads.n_wih[gi]) + q;
-        else if (q < nih + nhh) dst = (edge ? a.grads.e_whh[gi] : a.grads.n_whh[gi]) + (q - nih);
-        else {
-            const size_t k = q - nih - nhh;
-            if (k < (size_t)3 * H) dst = (edge ? a.grads.e_bih[gi] : a.grads.n_bih[gi]) + k;
-            else if (k < (size_t)6 * H) dst = (edge ? a.grads.e_bhh[gi] : a.grads.n_bhh[gi]) + (k - 3 * H);
-            else if (k < (size_t)7 * H) dst = (edge ? a.grads.w_edge : a.grads.w_node) + gi * H + (k - 6 * H);
-            else dst = nullptr;                        // head bias: one scalar per cell type, below
+    constexpr int UR = 4;
+    for (size_t idx0 = (size_t)bid * 256 + tid; idx0 < total; idx0 += (size_t)rb * 256 * UR) {
+        float* dst[UR];
+        float old[UR], sum[UR];
+        const float* sp[UR];
+        int nb0[UR], nb1[UR];
+#pragma unroll
+        for (int u = 0; u < UR; ++u) {
+            const size_t idx = idx0 + (size_t)u * rb * 256;
+            dst[u] = nullptr; sp[u] = a.slabs; nb0[u] = nb1[u] = 0;
+            if (idx >= total) continue;
+            const int gi = (int)(idx / per_g);
+            size_t q = idx % per_g;
+            const bool edge = q < n_e;
+            if (!edge) q -= n_e;
+            const int IN = edge ? IN_E : H;
+            nb0[u] = edge ? 0 : nbE; nb1[u] = edge ? usedE : nbE + usedD;
+            sp[u] = a.slabs + (size_t)gi * SLF + q;
+            const size_t nih = (size_t)3 * H * IN, nhh = (size_t)3 * H * H;
+            if (q < nih) dst[u] = (edge ? a.grads.e_wih[gi] : a.grads.n_wih[gi]) + q;
+            else if (q < nih + nhh) dst[u] = (edge ? a.grads.e_whh[gi] : a.grads.n_whh[gi]) + (q - nih);
+            else {
+                const size_t k = q - nih - nhh;
+                if (k < (size_t)3 * H) dst[u] = (edge ? a.grads.e_bih[gi] : a.grads.n_bih[gi]) + k;
+                else if (k < (size_t)6 * H) dst[u] = (edge ? a.grads.e_bhh[gi] : a.grads.n_bhh[gi]) + (k - 3 * H);
+                else if (k < (size_t)7 * H) dst[u] = (edge ? a.grads.w_edge : a.grads.w_node) + gi * H + (k - 6 * H);
+                // k == 7H: head bias, one scalar per cell type, below
+            }
         }
-        if (dst) *dst += s;
+#pragma unroll
+        for (int u = 0; u < UR; ++u) old[u] = dst[u] ? *dst[u] : 0.f;            // the old values travel with the slab loads
+#pragma unroll
+        for (int u = 0; u < UR; ++u) {
+            float s = 0.f;
+            for (int b = nb0[u]; b < nb1[u]; ++b) s += sp[u][(size_t)b * G * SLF];
+            sum[u] = s;
+        }
+#pragma unroll
+        for (int u = 0; u < UR; ++u)
+            if (dst[u]) *dst[u] = old[u] + sum[u];
     }
     // head biases: the same dy sums appear in every group's slab; take group 0
     if (bid == 0 && tid < 2) {
@@ -1091,7 +1192,7 @@ int tmpnn_mp_iter_bwd(const tmpnn_mp_params* P, const float* prep, const tmpnn_d
     FinishArgs f{*P, *grads, *g, d_msg, d_h, slabs, nb, row_blocks, red_blocks, n_new, training, x, ld_x,
                  save + SL.ysave, save + SL.mean, save + SL.rstd, reinterpret_cast<const int*>(save + SL.total), d_x,
                  bn_scratch};
-    const size_t shm = sizeof(float) * 2 * BN_LDS_ROWS * (H + 1);
+    const size_t shm = sizeof(float) * (2 * BN_LDS_ROWS * (H + 1) + bn_stage_floats(H));
     const dim3 fgrid(row_blocks + red_blocks + bn_blocks);
 #define LF(HH, II)                                                                                           \
     do {                                                                                                     \
