@@ -6,7 +6,7 @@ Same call surface as the reference (`train.py:73-81,112-120`):
     loss_c  = CELoss()(logits, targets, node_adj, idx_node)
     loss_f  = FocalLoss(gamma=0)(scores[idx_node, 0], targets[idx_node]) + ...
 
-`node_adj` may also be a `FrameGraph` (or `CallPlan`), which skips the adjacency conversion; `idx_node`
+`node_adj` may also be a `FrameGraph`, `CallPlan` or `DeviceGraph` (e.g. `TrackGraph.graph`), which skips the adjacency conversion; `idx_node`
 is accepted for signature compatibility and ignored (the graph knows its det rows).
 """
 from __future__ import annotations
@@ -17,17 +17,21 @@ import torch
 import torch.nn as nn
 
 from . import _lib
-from .graph import CallPlan, FrameGraph, graph_from_adjacency
+from .graph import CallPlan, DeviceGraph, FrameGraph, graph_from_adjacency
 
 _cache = {}
 
 
-def _as_graph(adj: Union[torch.Tensor, FrameGraph, CallPlan]) -> FrameGraph:
+def _as_graph(adj: Union[torch.Tensor, FrameGraph, CallPlan, DeviceGraph]) -> FrameGraph:
     if isinstance(adj, CallPlan):
         return adj.graph
     if isinstance(adj, FrameGraph):
         return adj
-    key = id(adj)
+    if isinstance(adj, DeviceGraph):
+        return adj.frame_graph()
+    # one-entry cache for the three calls of a timestep (create_targets, CELoss, ...) on the same adjacency object;
+    # an in-place edit bumps the version counter and misses
+    key = (id(adj), getattr(adj, '_version', 0), adj.device)
     hit = _cache.get('k')
     if hit is not None and hit[0] == key and hit[2] is adj:
         return hit[1]

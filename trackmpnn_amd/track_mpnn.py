@@ -25,6 +25,7 @@ from .small import SmallPath, _SmallIter, fast_module, small_eligible
 
 STRICT_GRAPH = os.environ.get('TMPNN_STRICT_GRAPH', '0') == '1'     # validate every adjacency at once (host sync)
 SMALL_PATH = os.environ.get('TMPNN_SMALL_PATH', '1') != '0'         # fused batch-1 iteration for eligible calls
+DEBUG_INPUTS = os.environ.get('TMPNN_DEBUG', '0') == '1'            # check the all-zero contract of x's edge rows (host sync)
 
 
 class SparseAttention:
@@ -256,6 +257,13 @@ class TrackMPNN(nn.Module):
             else:
                 graph = graph_from_adjacency(node_adj.to(x.device), edge_adj.to(x.device))
             self._graph_cache = (key, graph, node_adj, edge_adj)   # keep the tensors alive: id() stays unique
+        if DEBUG_INPUTS and x.shape[0] > 0:
+            fg = graph.frame_graph() if isinstance(graph, DeviceGraph) else graph
+            new_edges = fg.is_edge[N - int(x.shape[0]):] != 0
+            if bool(new_edges.any()) and float(x[new_edges].abs().max()) != 0.0:
+                raise ValueError('x has non-zero features on new EDGE rows: the reference would feed them to the BatchNorm '
+                                 'statistics (utils/graph.py:148,291 always passes zeros); this implementation reads det '
+                                 'rows only')
         if small:
             return self.forward_dgraph(x, h_in, graph)
         plan = plan_single(graph, int(x.shape[0]))
