@@ -1891,15 +1891,22 @@ __global__ __launch_bounds__(256, 2) void k_gru_bwd_weights_chunk(GruBwdWArgs a,
 
 
 // ==========================================================================================
-// Fused backward of one cell (H = 64, IN = H): data gradient AND weight gradient from ONE pass over
-// the gates.  The two stand-alone kernels each stream dh, the four gate planes and h (1.5 KB per row);
-// here a 32-row tile of d_g = [dr|dz|dn|dn*r], [x|h] and dh*z is formed once in LDS and consumed by
-//   waves 0-3: dW_ih / dW_hh tiles (A = d_g^T, B = [x|h]; 6 accumulator tiles each, kept over all tiles
-//              of the persistent block, one slab per block at the end);
-//   waves 4-7: the four 32x32 output tiles of d_msg = d_gi W_ih and d_h = d_gh W_hh (+ dh*z + fused
-//              row-F adjoint), weights (96 KiB) resident in LDS, transposed accumulator (lane = row).
-// Both groups issue 96 MFMAs per tile and wave w shares its SIMD with wave w+4, so every SIMD runs one
-// wave of each kind.  The next tile's global loads are in flight during the MFMA phase.
+// One-pass backward of one cell (H = 64, IN = H, bf16x6 products): data gradient AND weight gradient from ONE
+// read of dh, the four gate planes and h.  The two stand-alone kernels stream those six planes twice (56H bytes per
+// row together); this one moves 32H.  What kept the two apart was LDS: 150 KiB of transposed weight pieces (data)
+// and 72 KiB of operand images (weights) do not fit together.  Here the WEIGHTS LIVE IN REGISTERS: a block is four
+// waves, one per SIMD, each with the full 512-register budget; wave w owns one 32-column tile of the 128 output
+// columns [d_msg | d_h] and keeps its 32 x 192 slice of W_ih / W_hh as MFMA A operands (three bf16 pieces, 144
+// registers) for the whole kernel.  Per 32-row tile
+//   * every thread forms 8 columns of one row of d_g = [dr|dz|dn|dn*r], [x|h] and dh*z (+ the fused row-F adjoint),
+//     splits them into bf16 pieces and stores them row-major into ONE set of LDS images (80 KiB, double buffered)
+//     that serves both products: `ds_read_b128` with lane = row gives the B operand of the data product,
+//     `ds_read_b64_tr_b16` gives d_g^T and [x|h] as the operands of dW (image (b) of the guide's dual-use layout:
+//     16-byte chunk ch of row r sits at ch ^ (((r&3)<<2) | ((r>>2)&3)), conflict-free for both kinds of read);
+//   * wave w runs its 72 data MFMAs (transposed accumulator, lane = row) and its 72 weight-gradient MFMAs (six
+//     accumulator tiles kept over all tiles of the persistent block, one slab per block at the end);
+//   * the rows of tile i+2 are requested as soon as tile i+1's registers have been consumed, so every load has a
+//     whole tile time to land; one barrier per tile.
 // ==========================================================================================
 struct GruBwdFusedArgs {
     const int32_t* rows; int R; const int32_t* src; const int32_t* dst;
@@ -1913,63 +1920,175 @@ struct GruBwdFusedArgs {
     float* slab_w; float* slab_b;
 };
 
-struct FRaw { float4 dh, r, z, n, hn, hp, x; int orow; bool valid; };
+__device__ __forceinline__ int dui_swz(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
+// element index of (row, col) in a [32][128] bf16 dual-use image
+__device__ __forceinline__ int dui_off(int row, int col) {
+    return row * 128 + ((((col >> 3) ^ dui_swz(row)) << 3) | (col & 7));
+}
 
-template <int H, int XMODE, int UP>
-__device__ __forceinline__ void fused_issue(const GruBwdFusedArgs& a, int tile, int srow, int f4, FRaw& q) {
-    const int lpos_raw = tile * 32 + srow;
-    q.valid = lpos_raw < a.R;
-    const int lpos = q.valid ? lpos_raw : a.R - 1;
-    const int orow = a.rows[lpos];
-    q.orow = orow;
+struct OneIds { int lpos, orow, s, d, as, ad; bool valid; };
+struct OneRaw { float4 dh[2], r[2], z[2], n[2], hn[2], hp[2], xa[2], xb[2], ea[2], eb[2]; float dy; };
+
+template <int XMODE, bool FUSE>
+__device__ __forceinline__ OneIds one_ids(const GruBwdFusedArgs& a, int tile, bool tv, int srow) {
+    OneIds w;
+    const int lr = tile * 32 + srow;
+    w.valid = tv && lr < a.R;
+    w.lpos = w.valid ? lr : a.R - 1;
+    w.orow = a.rows[w.lpos];
+    w.s = XMODE != 0 ? a.src[w.lpos] : 0;
+    w.d = XMODE != 0 ? a.dst[w.lpos] : 0;
+    w.as = FUSE ? a.add_src[w.lpos] : 0;
+    w.ad = FUSE ? a.add_dst[w.lpos] : 0;
+    return w;
+}
+
+template <int XMODE, int UP, bool FUSE>
+__device__ __forceinline__ void one_issue(const GruBwdFusedArgs& a, const OneIds& w, int f8, OneRaw& q) {
+    constexpr int H = 64;
     const size_t gp = a.gate_plane;
-    float4 u = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (UP & 1) u = *reinterpret_cast<const float4*>(a.up.d_hout + (size_t)orow * a.up.ld_dhout + f4);
-    if (UP & 2) {
-        const float d = a.up.dy[orow];
-        const float4 w = *reinterpret_cast<const float4*>(a.up.w_head + f4);
-        u.x += d * w.x; u.y += d * w.y; u.z += d * w.z; u.w += d * w.w;
+    const float4* p;
+    if (UP & 1) {
+        p = reinterpret_cast<const float4*>(a.up.d_hout + (size_t)w.orow * a.up.ld_dhout + f8);
+        q.dh[0] = p[0]; q.dh[1] = p[1];
     }
-    q.dh = u;
-    const float* g0 = a.gates + (size_t)orow * H + f4;
-    q.r = *reinterpret_cast<const float4*>(g0);
-    q.z = *reinterpret_cast<const float4*>(g0 + gp);
-    q.n = *reinterpret_cast<const float4*>(g0 + 2 * gp);
-    q.hn = *reinterpret_cast<const float4*>(g0 + 3 * gp);
-    q.hp = *reinterpret_cast<const float4*>(a.h + (size_t)orow * a.ld_h + f4);
+    if (UP & 2) q.dy = a.up.dy[w.orow];
+    p = reinterpret_cast<const float4*>(a.gates + (size_t)w.orow * H + f8);
+    q.r[0] = p[0]; q.r[1] = p[1];
+    p = reinterpret_cast<const float4*>(a.gates + gp + (size_t)w.orow * H + f8);
+    q.z[0] = p[0]; q.z[1] = p[1];
+    p = reinterpret_cast<const float4*>(a.gates + 2 * gp + (size_t)w.orow * H + f8);
+    q.n[0] = p[0]; q.n[1] = p[1];
+    p = reinterpret_cast<const float4*>(a.gates + 3 * gp + (size_t)w.orow * H + f8);
+    q.hn[0] = p[0]; q.hn[1] = p[1];
+    p = reinterpret_cast<const float4*>(a.h + (size_t)w.orow * a.ld_h + f8);
+    q.hp[0] = p[0]; q.hp[1] = p[1];
     if (XMODE == 0) {
-        q.x = *reinterpret_cast<const float4*>(a.msg + (size_t)(a.msg_compact ? lpos : orow) * a.ld_msg + f4);
+        p = reinterpret_cast<const float4*>(a.msg + (size_t)(a.msg_compact ? w.lpos : w.orow) * a.ld_msg + f8);
+        q.xa[0] = p[0]; q.xa[1] = p[1];
     } else {
-        const float4 s = *reinterpret_cast<const float4*>(a.h + (size_t)a.src[lpos] * a.ld_h + f4);
-        const float4 d = *reinterpret_cast<const float4*>(a.h + (size_t)a.dst[lpos] * a.ld_h + f4);
-        q.x = make_float4(s.x - d.x, s.y - d.y, s.z - d.z, s.w - d.w);
+        p = reinterpret_cast<const float4*>(a.h + (size_t)w.s * a.ld_h + f8);
+        q.xa[0] = p[0]; q.xa[1] = p[1];
+        p = reinterpret_cast<const float4*>(a.h + (size_t)w.d * a.ld_h + f8);
+        q.xb[0] = p[0]; q.xb[1] = p[1];
+    }
+    if (FUSE) {
+        p = reinterpret_cast<const float4*>(a.add_msg + (size_t)w.as * a.ld_add + f8);
+        q.ea[0] = p[0]; q.ea[1] = p[1];
+        p = reinterpret_cast<const float4*>(a.add_msg + (size_t)w.ad * a.ld_add + f8);
+        q.eb[0] = p[0]; q.eb[1] = p[1];
     }
 }
 
-template <int H, int XMODE, int UP, bool FUSE>
-__global__ __launch_bounds__(512) void k_gru_bwd_fused(GruBwdFusedArgs a, int ntiles) {
-    static_assert(H == 64, "fused backward is written for H = 64");
-    extern __shared__ float lds[];
-    constexpr int DGS = 4 * H + 4;       // d_g row stride: 260 floats = 4 mod 64 -> conflict-free ds_read_b128 per row
-    constexpr int XHS = 2 * H + 4;
-    constexpr int DZS = H + 4;
-    float* sWih = lds;                   // [3H][H]
-    float* sWhh = sWih + 3 * H * H;      // [3H][H]
-    float* s_dg = sWhh + 3 * H * H;      // [32][DGS]  dr | dz | dn | dn*r
-    float* s_xh = s_dg + 32 * DGS;       // [32][XHS]  x | h
-    float* s_dz = s_xh + 32 * XHS;       // [32][DZS]  dh * z
-    const int tid = threadIdx.x;
-    for (int i = tid * 4; i < 3 * H * H; i += 512 * 4) {
-        *reinterpret_cast<float4*>(sWih + i) = *reinterpret_cast<const float4*>(a.w_ih + i);
-        *reinterpret_cast<float4*>(sWhh + i) = *reinterpret_cast<const float4*>(a.w_hh + i);
+// the seven 8-wide arrays one thread contributes to a tile
+struct OneVals { float dr[8], dz[8], dn[8], dnr[8], x[8], hp[8], ex[8]; };
+
+template <int XMODE, int UP, bool FUSE>
+__device__ __forceinline__ void one_vals(const OneRaw& q, bool valid, const float* head8, OneVals& v) {
+    float dh[8], r[8], z[8], n[8], hn[8];
+    if (UP & 1) f4_to_arr(q.dh[0], q.dh[1], dh);
+    else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) dh[i] = 0.f;
     }
-    const int wave = tid >> 6, lane = tid & 63;
+    f4_to_arr(q.r[0], q.r[1], r); f4_to_arr(q.z[0], q.z[1], z); f4_to_arr(q.n[0], q.n[1], n);
+    f4_to_arr(q.hn[0], q.hn[1], hn); f4_to_arr(q.hp[0], q.hp[1], v.hp);
+    f4_to_arr(q.xa[0], q.xa[1], v.x);
+    if (XMODE != 0) {
+        float x2[8];
+        f4_to_arr(q.xb[0], q.xb[1], x2);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v.x[i] -= x2[i];
+    }
+    float e1[8], e2[8];
+    if (FUSE) { f4_to_arr(q.ea[0], q.ea[1], e1); f4_to_arr(q.eb[0], q.eb[1], e2); }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        float d0 = dh[i];
+        if (UP & 2) d0 += q.dy * head8[i];
+        d0 = valid ? d0 : 0.f;
+        const float t = d0 * (1.0f - z[i]) * (1.0f - n[i] * n[i]);
+        v.dn[i] = t;
+        v.dnr[i] = t * r[i];
+        v.dr[i] = t * hn[i] * r[i] * (1.0f - r[i]);
+        v.dz[i] = d0 * (v.hp[i] - n[i]) * z[i] * (1.0f - z[i]);
+        v.ex[i] = d0 * z[i];
+        if (FUSE) v.ex[i] += e1[i] - e2[i];
+    }
+}
+
+__device__ __forceinline__ float dot2_ones(uint32_t two_bf16, float acc) {
+    return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, two_bf16), __builtin_bit_cast(bf16x2, 0x3F803F80u), acc, false);
+}
+
+__device__ __forceinline__ void one_put(uint16_t* img, int off, int pstride, const float* arr) {
+    const Split8 sp = split8_arr(arr);
+    *reinterpret_cast<uint4*>(img + off) = sp.p1;
+    *reinterpret_cast<uint4*>(img + off + pstride) = sp.p2;
+    *reinterpret_cast<uint4*>(img + off + 2 * pstride) = sp.p3;
+}
+
+template <int XMODE, int UP, bool FUSE>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
+void k_gru_bwd_one(GruBwdFusedArgs a, int ntiles, int dbg) {
+    constexpr int H = 64;
+    constexpr int SUB = 32 * 128;                  // elements of one [32][128] image
+    constexpr int PA = 2 * SUB, PB = SUB;          // piece strides of the d_g (two images) and [x|h] (one) sets
+    constexpr int OFF_B = 3 * PA, OFF_E = OFF_B + 3 * PB;          // in uint16 elements
+    constexpr int BUF = OFF_E + 32 * 64 * 2;       // 40960 elements = 80 KiB per buffer
+    extern __shared__ float lds[];
+    uint16_t* const lds16 = reinterpret_cast<uint16_t*>(lds);
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int c = lane & 31, half = lane >> 5;
-    const int srow = tid >> 4, f4 = (tid & 15) * 4;         // staging: 16 threads x float4 per row
-    const bool wgrad = wave < 4;
-    // weight-gradient waves: as in k_gru_bwd_weights_lds
-    const int which = (wave >> 1) & 1;
+    const int srow = tid >> 3, f8 = (tid & 7) * 8;
+    // ---- roles
+    const bool is_dx = wave < 2;                   // data product: waves 0,1 -> d_msg columns, 2,3 -> d_h columns
+    const int n0 = (wave & 1) * 32;
+    const int which = wave >> 1;                   // weight gradient: waves 0,1 -> dW_ih, 2,3 -> dW_hh
     const int jt0 = (wave & 1) * 3;
+    // ---- this wave's slice of W^T as A operands: lane (c, half), k-step ks: W[16 ks + 8 half + i][n0 + c]
+    uint4 wq[12][3];
+    {
+        const float* W = is_dx ? a.w_ih : a.w_hh;
+#pragma unroll
+        for (int ks = 0; ks < 12; ++ks) {
+            float v[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = W[(size_t)(16 * ks + 8 * half + i) * H + n0 + c];
+            const Split8 s = split8_arr(v);
+            wq[ks][0] = s.p1; wq[ks][1] = s.p2; wq[ks][2] = s.p3;
+        }
+    }
+    float head8[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) head8[i] = (UP & 2) ? a.up.w_head[f8 + i] : 0.f;
+    // ---- staging offsets of this thread (row srow, columns f8..f8+7 of each 64-column plane)
+    const int st0 = dui_off(srow, f8), st1 = dui_off(srow, 64 + f8);
+    const int stE0 = srow * 64 + ((((f8 >> 2)) ^ (srow & 15)) << 2), stE1 = srow * 64 + ((((f8 >> 2) + 1) ^ (srow & 15)) << 2);
+    // ---- data product reads: lane = row c
+    const int swzc = dui_swz(c), rowc = c * 128;
+    const int hix = is_dx ? 0 : 64;                // d_h takes dn*r (image columns 192..255) for the n gate
+    // ---- transposed reads (weight gradient): rows 8 half + tq (+4) of a 16-row block, columns 16 tg + 4 tp
+    const int i16 = lane & 15, tq = i16 >> 2, tp = i16 & 3, tg = (lane >> 4) & 1;
+    const int trow = (8 * half + tq) * 128, tsw0 = (tq << 2) | (2 * half), tsw1 = tsw0 | 1;
+    int offA[3][2], offB[2][2];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const int jj0 = (jt0 + j) * 32;
+        const int col = (which == 1 && jj0 >= 2 * H) ? jj0 + H : jj0;        // image column of the tile's first d_g column
+        const int ch = ((col & 127) >> 3) + 2 * tg + (tp >> 1);
+        offA[j][0] = (col >> 7) * SUB + trow + ((ch ^ tsw0) << 3) + 4 * (tp & 1);
+        offA[j][1] = (col >> 7) * SUB + trow + 4 * 128 + ((ch ^ tsw1) << 3) + 4 * (tp & 1);
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int ch = ((which * H + t * 32) >> 3) + 2 * tg + (tp >> 1);
+        offB[t][0] = OFF_B + trow + ((ch ^ tsw0) << 3) + 4 * (tp & 1);
+        offB[t][1] = OFF_B + trow + 4 * 128 + ((ch ^ tsw1) << 3) + 4 * (tp & 1);
+    }
+    const int eoff = c * 64;                       // dh*z image: float index of row c
+
     f32x16 acc[3][2];
 #pragma unroll
     for (int j = 0; j < 3; ++j)
@@ -1977,155 +2096,175 @@ __global__ __launch_bounds__(512) void k_gru_bwd_fused(GruBwdFusedArgs a, int nt
         for (int t = 0; t < 2; ++t)
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[j][t][i] = 0.f;
-    float csum = 0.f;
-    int colA[3];
-#pragma unroll
-    for (int j = 0; j < 3; ++j) {
-        const int jj = (jt0 + j) * 32 + c;
-        colA[j] = (which == 1 && jj >= 2 * H) ? jj + H : jj;
-    }
-    const int colB0 = which * H + c;
-    // data-gradient waves: output tile ot = wave - 4 : 0,1 -> d_msg columns [0,32),[32,64) ; 2,3 -> d_h
-    const int ot = wave & 3;
-    const bool is_dx = ot < 2;
-    const int n0 = (ot & 1) * 32;
-    const float* sW = is_dx ? sWih : sWhh;
+    // bias gradients = column sums of d_g: taken from the A operands of the weight gradient (a lane holds 8 rows of
+    // one column as bf16 pieces; v_dot2c_f32_bf16 against (1, 1) adds two of them per instruction)
+    float bsum[3] = {0.f, 0.f, 0.f};
 
-    FRaw q;
-    int tile = blockIdx.x;
-    if (tile < ntiles) fused_issue<H, XMODE, UP>(a, tile, srow, f4, q);
-    __syncthreads();                                         // weights are in LDS
-    for (; tile < ntiles; tile += gridDim.x) {
-        // ---- elementwise: 4 features of one row per thread
-        float4 dr, dz, dn, dnr, dhz;
-        {
-            const float dh[4] = {q.dh.x, q.dh.y, q.dh.z, q.dh.w}, r[4] = {q.r.x, q.r.y, q.r.z, q.r.w};
-            const float z[4] = {q.z.x, q.z.y, q.z.z, q.z.w}, n[4] = {q.n.x, q.n.y, q.n.z, q.n.w};
-            const float hn[4] = {q.hn.x, q.hn.y, q.hn.z, q.hn.w}, hp[4] = {q.hp.x, q.hp.y, q.hp.z, q.hp.w};
-            float o_r[4], o_z[4], o_n[4], o_nr[4], o_dz[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const float d0 = q.valid ? dh[i] : 0.f;
-                const float t = d0 * (1.0f - z[i]) * (1.0f - n[i] * n[i]);
-                o_n[i] = t;
-                o_nr[i] = t * r[i];
-                o_r[i] = t * hn[i] * r[i] * (1.0f - r[i]);
-                o_z[i] = d0 * (hp[i] - n[i]) * z[i] * (1.0f - z[i]);
-                o_dz[i] = d0 * z[i];
-            }
-            dr = make_float4(o_r[0], o_r[1], o_r[2], o_r[3]);
-            dz = make_float4(o_z[0], o_z[1], o_z[2], o_z[3]);
-            dn = make_float4(o_n[0], o_n[1], o_n[2], o_n[3]);
-            dnr = make_float4(o_nr[0], o_nr[1], o_nr[2], o_nr[3]);
-            dhz = make_float4(o_dz[0], o_dz[1], o_dz[2], o_dz[3]);
-        }
-        const float4 xq = q.x, hq = q.hp;
-        __syncthreads();                                     // previous tile's readers are done with the LDS tiles
-        {
-            float* d = s_dg + srow * DGS + f4;
-            *reinterpret_cast<float4*>(d) = dr;
-            *reinterpret_cast<float4*>(d + H) = dz;
-            *reinterpret_cast<float4*>(d + 2 * H) = dn;
-            *reinterpret_cast<float4*>(d + 3 * H) = dnr;
-            float* e = s_xh + srow * XHS + f4;
-            *reinterpret_cast<float4*>(e) = xq;
-            *reinterpret_cast<float4*>(e + H) = hq;
-            *reinterpret_cast<float4*>(s_dz + srow * DZS + f4) = dhz;
-        }
-        __syncthreads();
-        // ---- next tile's rows are requested now and land during the MFMA phase
-        if (tile + (int)gridDim.x < ntiles) fused_issue<H, XMODE, UP>(a, tile + gridDim.x, srow, f4, q);
-        __builtin_amdgcn_sched_barrier(0);
-        if (wgrad) {
-            if (tid < 4 * H) {
-#pragma unroll 8
-                for (int rr = 0; rr < 32; ++rr) csum += s_dg[rr * DGS + tid];
-            }
-#pragma unroll 4
-            for (int s = 0; s < 16; ++s) {
-                const float* ar = s_dg + (2 * s + half) * DGS;
-                const float* br = s_xh + (2 * s + half) * XHS + colB0;
-                float av[3], bv[2];
-#pragma unroll
-                for (int j = 0; j < 3; ++j) av[j] = ar[colA[j]];
-#pragma unroll
-                for (int t = 0; t < 2; ++t) bv[t] = br[t * 32];
-#pragma unroll
-                for (int j = 0; j < 3; ++j)
-#pragma unroll
-                    for (int t = 0; t < 2; ++t) acc[j][t] = mfma32(av[j], bv[t], acc[j][t]);
-            }
-        } else {
-            // out^T[col][row] = sum_j W[j][n0 + col] * d_g[row][j] ; lane (c, half) owns row c of the tile.
-            // k enumeration: block m (8 consecutive j), lane half takes j = 8m + 4*half + t, t = 0..3
-            f32x16 o;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) o[i] = 0.f;
-            const float* drow = s_dg + c * DGS;
-#pragma unroll 2
-            for (int m = 0; m < 3 * H / 8; ++m) {
-                const int j0 = 8 * m + 4 * half;                       // gate g = j0 / H
-                const int col = (!is_dx && j0 >= 2 * H) ? j0 + H : j0;  // d_h uses the dn*r block for the n gate
-                const float4 dv = *reinterpret_cast<const float4*>(drow + col);
-                const float* wr = sW + j0 * H + n0 + c;
-                o = mfma32(wr[0], dv.x, o);
-                o = mfma32(wr[H], dv.y, o);
-                o = mfma32(wr[2 * H], dv.z, o);
-                o = mfma32(wr[3 * H], dv.w, o);
-            }
-            const int tr0 = tile * 32;
-            const bool live = tr0 + c < a.R;
-            const int lp = min(tr0 + c, a.R - 1);
-            const int orow = a.rows[lp];
-            if (is_dx) {
-                if (live) {
-#pragma unroll
-                    for (int qq = 0; qq < 4; ++qq)
-                        *reinterpret_cast<float4*>(a.d_msg + (size_t)orow * a.ld_dmsg + n0 + 8 * qq + 4 * half) =
-                            make_float4(o[4 * qq], o[4 * qq + 1], o[4 * qq + 2], o[4 * qq + 3]);
-                }
-            } else {
-                int sr = 0, dr2 = 0;
-                if (FUSE) { sr = a.add_src[lp]; dr2 = a.add_dst[lp]; }
-                float4 ex[4];
-#pragma unroll
-                for (int qq = 0; qq < 4; ++qq) {
-                    const int col = n0 + 8 * qq + 4 * half;
-                    ex[qq] = *reinterpret_cast<const float4*>(s_dz + c * DZS + col);
-                    if (FUSE) {
-                        const float4 u = *reinterpret_cast<const float4*>(a.add_msg + (size_t)sr * a.ld_add + col);
-                        const float4 v = *reinterpret_cast<const float4*>(a.add_msg + (size_t)dr2 * a.ld_add + col);
-                        ex[qq].x += u.x - v.x; ex[qq].y += u.y - v.y; ex[qq].z += u.z - v.z; ex[qq].w += u.w - v.w;
-                    }
-                }
-                if (live) {
-#pragma unroll
-                    for (int qq = 0; qq < 4; ++qq)
-                        *reinterpret_cast<float4*>(a.d_h + (size_t)orow * a.ld_dh + n0 + 8 * qq + 4 * half) =
-                            make_float4(o[4 * qq] + ex[qq].x, o[4 * qq + 1] + ex[qq].y, o[4 * qq + 2] + ex[qq].z,
-                                        o[4 * qq + 3] + ex[qq].w);
-                }
-            }
-        }
+    const int G = gridDim.x;
+    const int nmine = (ntiles - (int)blockIdx.x + G - 1) / G;      // >= 1: the grid never exceeds ntiles
+    OneRaw raw;
+    OneVals vals;
+    // ---- prologue: tile 0 staged into buffer 0, tile 1 requested, ids of tile 2 fetched
+    bool valid_next;
+    {
+        const OneIds id0 = one_ids<XMODE, FUSE>(a, blockIdx.x, true, srow);
+        one_issue<XMODE, UP, FUSE>(a, id0, f8, raw);
+        const OneIds id1 = one_ids<XMODE, FUSE>(a, blockIdx.x + G, 1 < nmine, srow);
+        one_vals<XMODE, UP, FUSE>(raw, id0.valid, head8, vals);
+        one_issue<XMODE, UP, FUSE>(a, id1, f8, raw);
+        valid_next = id1.valid;
+        uint16_t* b0 = lds16;
+        one_put(b0, st0, PA, vals.dr);  one_put(b0, st1, PA, vals.dz);
+        one_put(b0, SUB + st0, PA, vals.dn);  one_put(b0, SUB + st1, PA, vals.dnr);
+        one_put(b0 + OFF_B, st0, PB, vals.x);  one_put(b0 + OFF_B, st1, PB, vals.hp);
+        float* e = reinterpret_cast<float*>(b0 + OFF_E);
+        *reinterpret_cast<float4*>(e + stE0) = make_float4(vals.ex[0], vals.ex[1], vals.ex[2], vals.ex[3]);
+        *reinterpret_cast<float4*>(e + stE1) = make_float4(vals.ex[4], vals.ex[5], vals.ex[6], vals.ex[7]);
     }
-    // ---- one slab per block (weight-gradient waves)
-    if (wgrad) {
-        float* sw = a.slab_w + (size_t)blockIdx.x * (3 * H) * (2 * H);
+    OneIds idn = one_ids<XMODE, FUSE>(a, blockIdx.x + 2 * G, 2 < nmine, srow);
+    // epilogue row of tile 0 (lane = row c)
+    int elp = min((int)blockIdx.x * 32 + c, a.R - 1);
+    int erow = a.rows[elp];
+    bool elive = (int)blockIdx.x * 32 + c < a.R;
+    __syncthreads();
+
+    for (int it = 0; it < nmine; ++it) {
+        const int tile = blockIdx.x + it * G;
+        uint16_t* const cur = lds16 + (it & 1) * BUF;
+        uint16_t* const nxt = lds16 + ((it & 1) ^ 1) * BUF;
+        // 1. the next tile's arrays from the registers its rows landed in, 2. split and stored into `nxt`,
+        // 3. the rows of the tile after it requested: they have the matrix phase, the epilogue and the barrier to land
+        one_vals<XMODE, UP, FUSE>(raw, valid_next, head8, vals);
+        one_put(nxt, st0, PA, vals.dr); one_put(nxt, st1, PA, vals.dz);
+        one_put(nxt, SUB + st0, PA, vals.dn); one_put(nxt, SUB + st1, PA, vals.dnr);
+        one_put(nxt + OFF_B, st0, PB, vals.x); one_put(nxt + OFF_B, st1, PB, vals.hp);
+        {
+            float* e = reinterpret_cast<float*>(nxt + OFF_E);
+            *reinterpret_cast<float4*>(e + stE0) = make_float4(vals.ex[0], vals.ex[1], vals.ex[2], vals.ex[3]);
+            *reinterpret_cast<float4*>(e + stE1) = make_float4(vals.ex[4], vals.ex[5], vals.ex[6], vals.ex[7]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (!(dbg & 2)) one_issue<XMODE, UP, FUSE>(a, idn, f8, raw);
+        __builtin_amdgcn_sched_barrier(0);
+        valid_next = idn.valid;
+        idn = one_ids<XMODE, FUSE>(a, tile + 3 * G, it + 3 < nmine, srow);
+        const int elp_n = min((tile + G) * 32 + c, a.R - 1);
+        const int erow_n = a.rows[elp_n];
+        const bool elive_n = (it + 1 < nmine) && ((tile + G) * 32 + c < a.R);
+
+        // 4. matrix phase on `cur`: 12 k-steps of the data product (D) and 6 (16-row block, A tile) groups of the weight
+        //    gradient (W) in the order D D W D D W ...; the operands of a step are requested one step ahead
+        f32x16 accd;
 #pragma unroll
-        for (int j = 0; j < 3; ++j)
+        for (int i = 0; i < 16; ++i) accd[i] = 0.f;
+        Split8 bD[2], bt[2];
+        uint4 aW[2][3];
+#define ONE_LD_D(ks, dst)                                                                                    \
+    do {                                                                                                     \
+        int inrow_ = ((2 * ((ks) & 7) + half) ^ swzc) << 3;                                                  \
+        if ((ks) >= 8) inrow_ ^= hix;                                                                        \
+        const uint16_t* p_ = cur + ((ks) >> 3) * SUB + rowc + inrow_;                                        \
+        (dst).p1 = *reinterpret_cast<const uint4*>(p_);                                                      \
+        (dst).p2 = *reinterpret_cast<const uint4*>(p_ + PA);                                                 \
+        (dst).p3 = *reinterpret_cast<const uint4*>(p_ + 2 * PA);                                             \
+    } while (0)
+#define ONE_LD_TR(base0, base1, pstride, q1, q2, q3)                                                         \
+    do {                                                                                                     \
+        const uint16_t* p0_ = (base0);                                                                       \
+        const uint16_t* p1_ = (base1);                                                                       \
+        const uint2 u0_ = lds_read_tr(p0_), u1_ = lds_read_tr(p1_);                                          \
+        const uint2 v0_ = lds_read_tr(p0_ + (pstride)), v1_ = lds_read_tr(p1_ + (pstride));                 \
+        const uint2 w0_ = lds_read_tr(p0_ + 2 * (pstride)), w1_ = lds_read_tr(p1_ + 2 * (pstride));         \
+        (q1) = make_uint4(u0_.x, u0_.y, u1_.x, u1_.y);                                                       \
+        (q2) = make_uint4(v0_.x, v0_.y, v1_.x, v1_.y);                                                       \
+        (q3) = make_uint4(w0_.x, w0_.y, w1_.x, w1_.y);                                                       \
+    } while (0)
+#define ONE_LD_BT(kb)                                                                                        \
+    do {                                                                                                     \
+        ONE_LD_TR(cur + (kb) * 2048 + offB[0][0], cur + (kb) * 2048 + offB[0][1], PB, bt[0].p1, bt[0].p2, bt[0].p3); \
+        ONE_LD_TR(cur + (kb) * 2048 + offB[1][0], cur + (kb) * 2048 + offB[1][1], PB, bt[1].p1, bt[1].p2, bt[1].p3); \
+    } while (0)
+#define ONE_LD_A(g, dst)                                                                                     \
+    ONE_LD_TR(cur + ((g) / 3) * 2048 + offA[(g) % 3][0], cur + ((g) / 3) * 2048 + offA[(g) % 3][1], PA, (dst)[0], (dst)[1], (dst)[2])
+        if (!(dbg & 1)) {
+        ONE_LD_D(0, bD[0]);
+        ONE_LD_BT(0);
+        ONE_LD_A(0, aW[0]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int grp = 0; grp < 6; ++grp) {
+            ONE_LD_D(2 * grp + 1, bD[1]);
+            accd = mfma_x6(wq[2 * grp][0], wq[2 * grp][1], wq[2 * grp][2], bD[0], accd);
+            __builtin_amdgcn_sched_barrier(0);
+            if (grp < 5) ONE_LD_A(grp + 1, aW[(grp + 1) & 1]);
+            accd = mfma_x6(wq[2 * grp + 1][0], wq[2 * grp + 1][1], wq[2 * grp + 1][2], bD[1], accd);
+            __builtin_amdgcn_sched_barrier(0);
+            if (grp < 5) ONE_LD_D(2 * grp + 2, bD[0]);
 #pragma unroll
             for (int t = 0; t < 2; ++t)
+                acc[grp % 3][t] = mfma_x6(aW[grp & 1][0], aW[grp & 1][1], aW[grp & 1][2], bt[t], acc[grp % 3][t]);
 #pragma unroll
-                for (int reg = 0; reg < 16; ++reg) {
-                    const int jj = (jt0 + j) * 32 + acc_row(reg, half);
-                    sw[(size_t)jj * (2 * H) + which * H + t * 32 + c] = acc[j][t][reg];
-                }
-        if (tid < 4 * H) {
-            float* sb = a.slab_b + (size_t)blockIdx.x * 6 * H;
-            const int g = tid / H, f = tid % H;
-            if (g < 3) sb[g * H + f] = csum;
-            if (g < 2) sb[3 * H + g * H + f] = csum;
-            if (g == 3) sb[3 * H + 2 * H + f] = csum;
+            for (int pc = 0; pc < 3; ++pc) {
+                const uint4 q = aW[grp & 1][pc];
+                bsum[grp % 3] = dot2_ones(q.x, bsum[grp % 3]); bsum[grp % 3] = dot2_ones(q.y, bsum[grp % 3]);
+                bsum[grp % 3] = dot2_ones(q.z, bsum[grp % 3]); bsum[grp % 3] = dot2_ones(q.w, bsum[grp % 3]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (grp == 2) ONE_LD_BT(1);
+        }
+        }
+#undef ONE_LD_A
+#undef ONE_LD_BT
+#undef ONE_LD_TR
+#undef ONE_LD_D
+        // 5. epilogue: lane = row c; register 4q+i <-> column 8q + 4 half + i of the wave's 32-column tile
+        if (is_dx) {
+            if (elive) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    *reinterpret_cast<float4*>(a.d_msg + (size_t)erow * a.ld_dmsg + n0 + 8 * q + 4 * half) =
+                        make_float4(accd[4 * q], accd[4 * q + 1], accd[4 * q + 2], accd[4 * q + 3]);
+            }
+        } else {
+            const float* e = reinterpret_cast<const float*>(cur + OFF_E) + eoff;
+            float4 ex4[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) ex4[q] = *reinterpret_cast<const float4*>(e + ((((n0 + 8 * q + 4 * half) >> 2) ^ (c & 15)) << 2));
+            if (elive) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    *reinterpret_cast<float4*>(a.d_h + (size_t)erow * a.ld_dh + n0 + 8 * q + 4 * half) =
+                        make_float4(accd[4 * q] + ex4[q].x, accd[4 * q + 1] + ex4[q].y, accd[4 * q + 2] + ex4[q].z,
+                                    accd[4 * q + 3] + ex4[q].w);
+            }
+        }
+        erow = erow_n; elive = elive_n;
+        __syncthreads();
+    }
+    // ---- one slab per block: [3H][IN+H] weights, then [2][3H] biases
+    float* sw = a.slab_w + (size_t)blockIdx.x * (3 * H) * (2 * H);
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int jj = (jt0 + j) * 32 + acc_row(reg, half);
+                sw[(size_t)jj * (2 * H) + which * H + t * 32 + c] = acc[j][t][reg];
+            }
+    // bias slabs: column m = lane & 31 of A tile jt0 + j; the two lane halves hold rows 8 half .. 8 half + 7 of every block
+    float* sb = a.slab_b + (size_t)blockIdx.x * 6 * H;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const float tot = bsum[j] + __shfl_xor(bsum[j], 32);
+        const int col = (jt0 + j) * 32 + c;                 // 0..191 in the wave's own gate order
+        if (half == 0) {
+            if (which == 0) {                               // d_gi = dr | dz | dn ; dr and dz are also the first two of d_gh
+                sb[col] = tot;
+                if (col < 2 * H) sb[3 * H + col] = tot;
+            } else if (col >= 2 * H) {                      // d_gh's n gate: dn * r
+                sb[3 * H + col] = tot;
+            }
         }
     }
 }
@@ -2444,14 +2583,15 @@ int tmpnn_gru_bwd_fused(const int32_t* rows, int R, int xmode, const int32_t* sr
                       DhSrc{d_hout, ld_dhout, dy, w_head}, d_msg, ld_dmsg, d_h, ld_dh, add_src, add_dst, add_msg, ld_add,
                       slab_w, slab_b};
     const int ntiles = ceil_div(R, 32);
-    const size_t shm = sizeof(float) * ((size_t)6 * H * H + 32 * (4 * H + 4) + 32 * (2 * H + 4) + 32 * (H + 4));
+    const size_t shm = 163840;                               // two 80 KiB operand-image sets: the whole LDS of a CU
+    const int dbg_ = getenv("TMPNN_ONE_DBG") ? atoi(getenv("TMPNN_ONE_DBG")) : 0;
     hipStream_t st = as_stream(stream);
     const int up = (d_hout ? 1 : 0) | (dy ? 2 : 0);
     const bool fuse = add_msg != nullptr;
 #define LF(X, U, F)                                                                                          \
     do {                                                                                                     \
-        TM_SHM_ONCE((k_gru_bwd_fused<64, X, U, F>), shm);                     \
-        hipLaunchKernelGGL((k_gru_bwd_fused<64, X, U, F>), dim3(n_rs), dim3(512), shm, st, a, ntiles);       \
+        TM_SHM_ONCE((k_gru_bwd_one<X, U, F>), shm);                                                          \
+        hipLaunchKernelGGL((k_gru_bwd_one<X, U, F>), dim3(n_rs), dim3(256), shm, st, a, ntiles, dbg_);             \
     } while (0)
 #define LU(X, F) do { if (up == 1) LF(X, 1, F); else if (up == 2) LF(X, 2, F); else LF(X, 3, F); } while (0)
     if (xmode == 0) { if (fuse) LU(0, true); else LU(0, false); }
