@@ -131,6 +131,16 @@ def stage_profile(model, plan, H):
                   H, h.data_ptr(), H, H, gates.data_ptr(), N * H, dout.data_ptr(), H, None, None, gW[0].data_ptr(),
                   gW[1].data_ptr(), gW[2].data_ptr(), gW[3].data_ptr(), ws.data_ptr(), wsb, st)
 
+    fwsb = _lib.load().tmpnn_gru_bwd_fused_ws(E, H, H) if _lib.load().tmpnn_gru_bwd_fused_available(H, H, 1) else 0
+    fws = torch.empty(fwsb // 4 + 1, device=dev)
+
+    def gru_bwd_one():              # as the training step runs it: ONE pass for data + weights, head folded, row F fused
+        _lib.call('tmpnn_gru_bwd_fused', g.edge_row.data_ptr(), E, 1, g.src.data_ptr(), g.dst.data_ptr(), None, 0, 0, H,
+                  h.data_ptr(), H, H, wih.data_ptr(), whh.data_ptr(), gates.data_ptr(), N * H, dout.data_ptr(), H,
+                  dyv.data_ptr(), w_head.data_ptr(), dmsg.data_ptr(), H, dh.data_ptr(), H, g.src.data_ptr(),
+                  g.dst.data_ptr(), dmsg.data_ptr(), H, gW[0].data_ptr(), gW[1].data_ptr(), gW[2].data_ptr(),
+                  gW[3].data_ptr(), fws.data_ptr(), fwsb, st)
+
     def gru_bwd_w_variant(v):
         def run():
             _lib.call('tmpnn_gru_bwd_weights_variant', g.edge_row.data_ptr(), E, 1, g.src.data_ptr(), g.dst.data_ptr(),
@@ -151,11 +161,11 @@ def stage_profile(model, plan, H):
                                                ('gru_bwd_weights_edge_f32mfma', gru_bwd_w_variant(0)),
                                                ('gru_bwd_weights_edge_bf16x6', gru_bwd_w_variant(1)),
                                                ('gather_diff', gather),
-                                               ('segsum', segsum))}
+                                               ('segsum', segsum)) + ((('gru_bwd_one_edge', gru_bwd_one),) if fwsb else ())}
     flops = {'gru_fwd_edge': 12.0 * H * H * E, 'gru_bwd_data_edge': 12.0 * H * H * E,
              'gru_bwd_data_edge_folded': 12.0 * H * H * E,
              'gru_bwd_weights_edge': 12.0 * H * H * E, 'gru_bwd_weights_edge_f32mfma': 12.0 * H * H * E,
-             'gru_bwd_weights_edge_bf16x6': 12.0 * H * H * E}
+             'gru_bwd_weights_edge_bf16x6': 12.0 * H * H * E, 'gru_bwd_one_edge': 24.0 * H * H * E}
     # SURVEY 8(d) algorithmic bytes per launch (every array counted once; det-row gathers count the det table once)
     b_gather = 4.0 * H * E + 4.0 * H * Dn + 8.0 * E
     b_segsum = 4.0 * H * E + 4.0 * H * Dn + 4.0 * (2 * E + Dn + 1) + 2.0 * E
@@ -168,6 +178,8 @@ def stage_profile(model, plan, H):
               'gru_bwd_data_edge_folded': (32.0 * H + 16.0) * E + 4.0 * H * Dn,
               # per edge: dh 4H + gates 16H + h 4H in, 3 ids; h[src], h[dst] from the det table (once)
               'gru_bwd_weights_edge': (24.0 * H + 12.0) * E + 4.0 * H * Dn}
+    # one pass: dh 4H + gates 16H + h 4H in, d_msg 4H + d_h 4H out, dy and three ids; h and d_es det tables once
+    nbytes['gru_bwd_one_edge'] = (32.0 * H + 16.0) * E + 8.0 * H * Dn
     nbytes['gru_bwd_weights_edge_f32mfma'] = nbytes['gru_bwd_weights_edge_bf16x6'] = nbytes['gru_bwd_weights_edge']
     return t, flops, nbytes
 
@@ -182,7 +194,8 @@ def _pmc_kernel(stage):
     if split_enabled():
         return {'gru_fwd_edge': 'k_gru_fwd_split<64, 8>', 'gru_bwd_data_edge': 'k_gru_bwd_data_split<64, 1, false>',
                 'gru_bwd_data_edge_folded': 'k_gru_bwd_data_split<64, 3, true>',
-                'gru_bwd_weights_edge': 'k_gru_bwd_weights_split<1, 1>'}.get(stage, '?')
+                'gru_bwd_weights_edge': 'k_gru_bwd_weights_split<1, 1>',
+                'gru_bwd_one_edge': 'k_gru_bwd_one<1, 3, true>'}.get(stage, '?')
     return {'gru_fwd_edge': 'k_gru_fwd_lds<64, 64, 3,', 'gru_bwd_data_edge': 'k_gru_bwd_data_lds<64, 64, 1, false>',
             'gru_bwd_data_edge_folded': 'k_gru_bwd_data_lds<64, 64, 3, true>',
             'gru_bwd_weights_edge': 'k_gru_bwd_weights_lds<64, 1, 1>'}.get(stage, '?')
@@ -393,7 +406,13 @@ def main():
     extra = {}
     if rank == 0 and not args.no_stage_profile:
         t, flops, nbytes = stage_profile(model, plans[-1], H)
-        dom = max((k for k in flops if not k.endswith(('_f32mfma', '_bf16x6'))), key=lambda k: t[k])
+        # the dominant kernel AMONG THOSE THE STEP RUNS: with the one-pass backward (default) the two stand-alone
+        # backward kernels are measured for comparison only
+        from trackmpnn_amd import functional as _F
+        one_pass = bool(_F.FUSED_BWD) and 'gru_bwd_one_edge' in t
+        on_step = ('gru_fwd_edge', 'gru_bwd_one_edge') if one_pass else \
+            ('gru_fwd_edge', 'gru_bwd_data_edge_folded', 'gru_bwd_weights_edge')
+        dom = max(on_step, key=lambda k: t[k])
         # the dominant kernel against BOTH roofs; the one it sits closer to is reported as its bound.  Matrix-pipe
         # time: f32-equivalent flops at the f32-input MFMA rate, or 6 bf16 MFMAs (1/16 of the f32 cost each) per
         # f32 MFMA of work on the split path.
@@ -425,11 +444,13 @@ def main():
         # adjoint) against the aggregation-only model of SURVEY 8(d) (16H + 36): saving the gates dominates
         gE = float(plans[-1].graph.E)
         extra['step_bytes_per_edge_iteration'] = dict(
-            staged_step=round((nbytes['gru_fwd_edge'] + nbytes['gru_bwd_data_edge_folded'] + nbytes['gru_bwd_weights_edge']
+            staged_step=round((nbytes['gru_fwd_edge'] + (nbytes['gru_bwd_one_edge'] if one_pass else
+                                                         nbytes['gru_bwd_data_edge_folded'] + nbytes['gru_bwd_weights_edge'])
                                + 2 * nbytes['segsum']) / gE, 1),
             survey_aggregation_model=16 * H + 36)
         from trackmpnn_amd import _lib as _l
         extra['weights_kernel'] = {1: 'bf16x6', 0: 'f32-mfma'}[_l.load().tmpnn_gru_bwd_weights_choice()]
+        extra['backward'] = 'one-pass (tmpnn_gru_bwd_fused)' if one_pass else 'data + weights kernels'
         extra['stage_graph'] = dict(N=plans[-1].graph.N, E=plans[-1].graph.E, Dn=plans[-1].graph.Dn)
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -182,7 +182,8 @@ int tmpnn_gru_bwd_weights_variant(const int32_t* rows, int R, int xmode, const i
 
 /* Fused backward of one cell: tmpnn_gru_bwd_data + tmpnn_gru_bwd_weights in ONE pass over the gates
  * (arguments as in those two; available when tmpnn_gru_bwd_fused_available(H, IN, xmode) != 0, i.e. H = 64,
- * IN = H, xmode 0 or 1).  ws: tmpnn_gru_bwd_fused_ws(R, IN, H) bytes. */
+ * IN = H, xmode 0 or 1).  With xmode 1 the fused row-F adjoint gathers through the cell's own endpoints:
+ * add_src / add_dst must be the src / dst arrays.  ws: tmpnn_gru_bwd_fused_ws(R, IN, H) bytes. */
 int tmpnn_gru_bwd_fused_available(int H, int IN, int xmode);
 size_t tmpnn_gru_bwd_fused_ws(int R, int IN, int H);
 int tmpnn_gru_bwd_fused(const int32_t* rows, int R, int xmode, const int32_t* src, const int32_t* dst,

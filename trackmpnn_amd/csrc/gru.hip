@@ -1926,94 +1926,151 @@ __device__ __forceinline__ int dui_off(int row, int col) {
     return row * 128 + ((((col >> 3) ^ dui_swz(row)) << 3) | (col & 7));
 }
 
-struct OneIds { int lpos, orow, s, d, as, ad; bool valid; };
-struct OneRaw { float4 dh[2], r[2], z[2], n[2], hn[2], hp[2], xa[2], xb[2], ea[2], eb[2]; float dy; };
+// One thread stages 4 columns of one row in each HALF of a tile (rows 0..15 = stream A, 16..31 = stream B); the two
+// streams are requested, consumed and re-requested half a tile apart, so that only one half's arrays are alive at a time.
+struct HalfIds { int orow, s, d, mrow; bool valid; };
+struct HalfRaw { float4 dh, r, z, n, hn, hp, xa, xb, ea, eb; float dy; };
+struct HalfVals { float dr[4], dz[4], dn[4], dnr[4], x[4], hp[4], ex[4]; };
 
 template <int XMODE, bool FUSE>
-__device__ __forceinline__ OneIds one_ids(const GruBwdFusedArgs& a, int tile, bool tv, int srow) {
-    OneIds w;
-    const int lr = tile * 32 + srow;
+__device__ __forceinline__ HalfIds half_ids(const GruBwdFusedArgs& a, int tile, bool tv, int row) {
+    HalfIds w;
+    const int lr = tile * 32 + row;
     w.valid = tv && lr < a.R;
-    w.lpos = w.valid ? lr : a.R - 1;
-    w.orow = a.rows[w.lpos];
-    w.s = XMODE != 0 ? a.src[w.lpos] : 0;
-    w.d = XMODE != 0 ? a.dst[w.lpos] : 0;
-    w.as = FUSE ? a.add_src[w.lpos] : 0;
-    w.ad = FUSE ? a.add_dst[w.lpos] : 0;
+    const int lpos = w.valid ? lr : a.R - 1;
+    w.orow = a.rows[lpos];
+    // with XMODE != 0 the fused adjoint gathers through the cell's own src / dst (checked on the host)
+    w.s = XMODE != 0 ? a.src[lpos] : (FUSE ? a.add_src[lpos] : 0);
+    w.d = XMODE != 0 ? a.dst[lpos] : (FUSE ? a.add_dst[lpos] : 0);
+    w.mrow = XMODE == 0 ? (a.msg_compact ? lpos : w.orow) : 0;
     return w;
 }
 
-template <int XMODE, int UP, bool FUSE>
-__device__ __forceinline__ void one_issue(const GruBwdFusedArgs& a, const OneIds& w, int f8, OneRaw& q) {
+// the row's own planes ...
+template <int UP>
+__device__ __forceinline__ void half_issue_main(const GruBwdFusedArgs& a, const HalfIds& w, int f4, HalfRaw& q) {
     constexpr int H = 64;
     const size_t gp = a.gate_plane;
-    const float4* p;
-    if (UP & 1) {
-        p = reinterpret_cast<const float4*>(a.up.d_hout + (size_t)w.orow * a.up.ld_dhout + f8);
-        q.dh[0] = p[0]; q.dh[1] = p[1];
-    }
+    if (UP & 1) q.dh = *reinterpret_cast<const float4*>(a.up.d_hout + (size_t)w.orow * a.up.ld_dhout + f4);
     if (UP & 2) q.dy = a.up.dy[w.orow];
-    p = reinterpret_cast<const float4*>(a.gates + (size_t)w.orow * H + f8);
-    q.r[0] = p[0]; q.r[1] = p[1];
-    p = reinterpret_cast<const float4*>(a.gates + gp + (size_t)w.orow * H + f8);
-    q.z[0] = p[0]; q.z[1] = p[1];
-    p = reinterpret_cast<const float4*>(a.gates + 2 * gp + (size_t)w.orow * H + f8);
-    q.n[0] = p[0]; q.n[1] = p[1];
-    p = reinterpret_cast<const float4*>(a.gates + 3 * gp + (size_t)w.orow * H + f8);
-    q.hn[0] = p[0]; q.hn[1] = p[1];
-    p = reinterpret_cast<const float4*>(a.h + (size_t)w.orow * a.ld_h + f8);
-    q.hp[0] = p[0]; q.hp[1] = p[1];
+    const float* g0 = a.gates + (size_t)w.orow * H + f4;
+    q.r = *reinterpret_cast<const float4*>(g0);
+    q.z = *reinterpret_cast<const float4*>(g0 + gp);
+    q.n = *reinterpret_cast<const float4*>(g0 + 2 * gp);
+    q.hn = *reinterpret_cast<const float4*>(g0 + 3 * gp);
+    q.hp = *reinterpret_cast<const float4*>(a.h + (size_t)w.orow * a.ld_h + f4);
+}
+// ... and what it gathers from its endpoints (det rows, mostly L2 hits: requested later, consumed last)
+template <int XMODE, bool FUSE>
+__device__ __forceinline__ void half_issue_gather(const GruBwdFusedArgs& a, const HalfIds& w, int f4, HalfRaw& q) {
     if (XMODE == 0) {
-        p = reinterpret_cast<const float4*>(a.msg + (size_t)(a.msg_compact ? w.lpos : w.orow) * a.ld_msg + f8);
-        q.xa[0] = p[0]; q.xa[1] = p[1];
+        q.xa = *reinterpret_cast<const float4*>(a.msg + (size_t)w.mrow * a.ld_msg + f4);
     } else {
-        p = reinterpret_cast<const float4*>(a.h + (size_t)w.s * a.ld_h + f8);
-        q.xa[0] = p[0]; q.xa[1] = p[1];
-        p = reinterpret_cast<const float4*>(a.h + (size_t)w.d * a.ld_h + f8);
-        q.xb[0] = p[0]; q.xb[1] = p[1];
+        q.xa = *reinterpret_cast<const float4*>(a.h + (size_t)w.s * a.ld_h + f4);
+        q.xb = *reinterpret_cast<const float4*>(a.h + (size_t)w.d * a.ld_h + f4);
     }
-    if (FUSE) {
-        p = reinterpret_cast<const float4*>(a.add_msg + (size_t)w.as * a.ld_add + f8);
-        q.ea[0] = p[0]; q.ea[1] = p[1];
-        p = reinterpret_cast<const float4*>(a.add_msg + (size_t)w.ad * a.ld_add + f8);
-        q.eb[0] = p[0]; q.eb[1] = p[1];
+    if (FUSE) {                                   // the fused row-F adjoint gathers through the cell's own src / dst
+        q.ea = *reinterpret_cast<const float4*>(a.add_msg + (size_t)w.s * a.ld_add + f4);
+        q.eb = *reinterpret_cast<const float4*>(a.add_msg + (size_t)w.d * a.ld_add + f4);
     }
 }
-
-// the seven 8-wide arrays one thread contributes to a tile
-struct OneVals { float dr[8], dz[8], dn[8], dnr[8], x[8], hp[8], ex[8]; };
+template <int XMODE, int UP, bool FUSE>
+__device__ __forceinline__ void half_issue(const GruBwdFusedArgs& a, const HalfIds& w, int f4, HalfRaw& q) {
+    half_issue_main<UP>(a, w, f4, q);
+    half_issue_gather<XMODE, FUSE>(a, w, f4, q);
+}
 
 template <int XMODE, int UP, bool FUSE>
-__device__ __forceinline__ void one_vals(const OneRaw& q, bool valid, const float* head8, OneVals& v) {
-    float dh[8], r[8], z[8], n[8], hn[8];
-    if (UP & 1) f4_to_arr(q.dh[0], q.dh[1], dh);
-    else {
+__device__ __forceinline__ void half_vals(const HalfRaw& q, bool valid, const float* head4, HalfVals& v) {
+    const float dh[4] = {q.dh.x, q.dh.y, q.dh.z, q.dh.w}, r[4] = {q.r.x, q.r.y, q.r.z, q.r.w};
+    const float z[4] = {q.z.x, q.z.y, q.z.z, q.z.w}, n[4] = {q.n.x, q.n.y, q.n.z, q.n.w};
+    const float hn[4] = {q.hn.x, q.hn.y, q.hn.z, q.hn.w}, hp[4] = {q.hp.x, q.hp.y, q.hp.z, q.hp.w};
+    const float xa[4] = {q.xa.x, q.xa.y, q.xa.z, q.xa.w}, xb[4] = {q.xb.x, q.xb.y, q.xb.z, q.xb.w};
+    const float ea[4] = {q.ea.x, q.ea.y, q.ea.z, q.ea.w}, eb[4] = {q.eb.x, q.eb.y, q.eb.z, q.eb.w};
 #pragma unroll
-        for (int i = 0; i < 8; ++i) dh[i] = 0.f;
-    }
-    f4_to_arr(q.r[0], q.r[1], r); f4_to_arr(q.z[0], q.z[1], z); f4_to_arr(q.n[0], q.n[1], n);
-    f4_to_arr(q.hn[0], q.hn[1], hn); f4_to_arr(q.hp[0], q.hp[1], v.hp);
-    f4_to_arr(q.xa[0], q.xa[1], v.x);
-    if (XMODE != 0) {
-        float x2[8];
-        f4_to_arr(q.xb[0], q.xb[1], x2);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) v.x[i] -= x2[i];
-    }
-    float e1[8], e2[8];
-    if (FUSE) { f4_to_arr(q.ea[0], q.ea[1], e1); f4_to_arr(q.eb[0], q.eb[1], e2); }
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        float d0 = dh[i];
-        if (UP & 2) d0 += q.dy * head8[i];
+    for (int i = 0; i < 4; ++i) {
+        float d0 = (UP & 1) ? dh[i] : 0.f;
+        if (UP & 2) d0 += q.dy * head4[i];
         d0 = valid ? d0 : 0.f;
         const float t = d0 * (1.0f - z[i]) * (1.0f - n[i] * n[i]);
         v.dn[i] = t;
         v.dnr[i] = t * r[i];
         v.dr[i] = t * hn[i] * r[i] * (1.0f - r[i]);
-        v.dz[i] = d0 * (v.hp[i] - n[i]) * z[i] * (1.0f - z[i]);
+        v.dz[i] = d0 * (hp[i] - n[i]) * z[i] * (1.0f - z[i]);
         v.ex[i] = d0 * z[i];
-        if (FUSE) v.ex[i] += e1[i] - e2[i];
+        if (FUSE) v.ex[i] += ea[i] - eb[i];
+        v.hp[i] = hp[i];
+        v.x[i] = XMODE != 0 ? xa[i] - xb[i] : xa[i];
+    }
+}
+
+// four consecutive columns of one row -> three bf16 pieces, 8 bytes each
+__device__ __forceinline__ void half_put(uint16_t* img, int off, int pstride, const float* arr) {
+    uint2 p1, p2, p3;
+    split_pair(arr[0], arr[1], p1.x, p2.x, p3.x);
+    split_pair(arr[2], arr[3], p1.y, p2.y, p3.y);
+    *reinterpret_cast<uint2*>(img + off) = p1;
+    *reinterpret_cast<uint2*>(img + off + pstride) = p2;
+    *reinterpret_cast<uint2*>(img + off + 2 * pstride) = p3;
+}
+
+#define ONE_PIN4(q) asm volatile("" : "+v"((q).x), "+v"((q).y), "+v"((q).z), "+v"((q).w))
+// One sixth of a stream's staging, computed from the landed rows right where it is stored (the empty asm pins the work
+// to its half-group: left alone the compiler forms and splits all arrays up front and carries ~60 registers of pieces
+// through the matrix phase).  d0 = upstream gradient, t = d0 (1-z)(1-n^2) are carried from slice 0 to the later ones.
+template <int XMODE, int UP, bool FUSE>
+__device__ __forceinline__ void half_slice(int SL, HalfRaw& q, bool valid, const float* head4, float (&d0)[4], float (&t)[4],
+                                           uint16_t* img, int s0, int s1, int se, int SUB, int PA, int PB, int OFF_B,
+                                           int OFF_E) {
+    float o[4];
+    if (SL == 0) {
+        if (UP & 1) ONE_PIN4(q.dh);
+        ONE_PIN4(q.z); ONE_PIN4(q.n); ONE_PIN4(q.hn); ONE_PIN4(q.r);
+        const float dh[4] = {q.dh.x, q.dh.y, q.dh.z, q.dh.w}, r[4] = {q.r.x, q.r.y, q.r.z, q.r.w};
+        const float z[4] = {q.z.x, q.z.y, q.z.z, q.z.w}, n[4] = {q.n.x, q.n.y, q.n.z, q.n.w};
+        const float hn[4] = {q.hn.x, q.hn.y, q.hn.z, q.hn.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float d = (UP & 1) ? dh[i] : 0.f;
+            if (UP & 2) d += q.dy * head4[i];
+            d0[i] = valid ? d : 0.f;
+            t[i] = d0[i] * (1.0f - z[i]) * (1.0f - n[i] * n[i]);
+            o[i] = t[i] * hn[i] * r[i] * (1.0f - r[i]);
+        }
+        half_put(img, s0, PA, o);
+    } else if (SL == 1) {
+        ONE_PIN4(q.hp);
+        const float z[4] = {q.z.x, q.z.y, q.z.z, q.z.w}, n[4] = {q.n.x, q.n.y, q.n.z, q.n.w};
+        const float hp[4] = {q.hp.x, q.hp.y, q.hp.z, q.hp.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[i] = d0[i] * (hp[i] - n[i]) * z[i] * (1.0f - z[i]);
+        half_put(img, s1, PA, o);
+    } else if (SL == 2) {
+        asm volatile("" : "+v"(t[0]), "+v"(t[1]), "+v"(t[2]), "+v"(t[3]));
+        half_put(img, SUB + s0, PA, t);
+    } else if (SL == 3) {
+        asm volatile("" : "+v"(t[0]), "+v"(t[1]), "+v"(t[2]), "+v"(t[3]));
+        const float r[4] = {q.r.x, q.r.y, q.r.z, q.r.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[i] = t[i] * r[i];
+        half_put(img, SUB + s1, PA, o);
+    } else if (SL == 4) {
+        ONE_PIN4(q.xa);
+        const float xa[4] = {q.xa.x, q.xa.y, q.xa.z, q.xa.w}, xb[4] = {q.xb.x, q.xb.y, q.xb.z, q.xb.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[i] = XMODE != 0 ? xa[i] - xb[i] : xa[i];
+        half_put(img + OFF_B, s0, PB, o);
+    } else {
+        ONE_PIN4(q.hp);
+        const float hp[4] = {q.hp.x, q.hp.y, q.hp.z, q.hp.w}, z[4] = {q.z.x, q.z.y, q.z.z, q.z.w};
+        half_put(img + OFF_B, s1, PB, hp);
+        const float ea[4] = {q.ea.x, q.ea.y, q.ea.z, q.ea.w}, eb[4] = {q.eb.x, q.eb.y, q.eb.z, q.eb.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            o[i] = d0[i] * z[i];
+            if (FUSE) o[i] += ea[i] - eb[i];
+        }
+        *reinterpret_cast<float4*>(reinterpret_cast<float*>(img + OFF_E) + se) = make_float4(o[0], o[1], o[2], o[3]);
     }
 }
 
@@ -2021,16 +2078,20 @@ __device__ __forceinline__ float dot2_ones(uint32_t two_bf16, float acc) {
     return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, two_bf16), __builtin_bit_cast(bf16x2, 0x3F803F80u), acc, false);
 }
 
-__device__ __forceinline__ void one_put(uint16_t* img, int off, int pstride, const float* arr) {
-    const Split8 sp = split8_arr(arr);
-    *reinterpret_cast<uint4*>(img + off) = sp.p1;
-    *reinterpret_cast<uint4*>(img + off + pstride) = sp.p2;
-    *reinterpret_cast<uint4*>(img + off + 2 * pstride) = sp.p3;
+// product `c` of the six that make one fp32 product (smallest terms first; see mfma_x6)
+template <int C>
+__device__ __forceinline__ f32x16 mfma_c(const uint4 (&a)[3], const Split8& b, f32x16 acc) {
+    if (C == 0) return mfma_bf16(a[2], b.p1, acc);
+    if (C == 1) return mfma_bf16(a[0], b.p3, acc);
+    if (C == 2) return mfma_bf16(a[1], b.p2, acc);
+    if (C == 3) return mfma_bf16(a[1], b.p1, acc);
+    if (C == 4) return mfma_bf16(a[0], b.p2, acc);
+    return mfma_bf16(a[0], b.p1, acc);
 }
 
 template <int XMODE, int UP, bool FUSE>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
-void k_gru_bwd_one(GruBwdFusedArgs a, int ntiles, int dbg) {
+void k_gru_bwd_one(GruBwdFusedArgs a, int ntiles) {
     constexpr int H = 64;
     constexpr int SUB = 32 * 128;                  // elements of one [32][128] image
     constexpr int PA = 2 * SUB, PB = SUB;          // piece strides of the d_g (two images) and [x|h] (one) sets
@@ -2041,7 +2102,7 @@ void k_gru_bwd_one(GruBwdFusedArgs a, int ntiles, int dbg) {
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int c = lane & 31, half = lane >> 5;
-    const int srow = tid >> 3, f8 = (tid & 7) * 8;
+    const int hr = tid >> 4, f4 = (tid & 15) * 4;  // staging: row hr (stream A) / 16 + hr (stream B), columns f4..f4+3
     // ---- roles
     const bool is_dx = wave < 2;                   // data product: waves 0,1 -> d_msg columns, 2,3 -> d_h columns
     const int n0 = (wave & 1) * 32;
@@ -2060,12 +2121,13 @@ void k_gru_bwd_one(GruBwdFusedArgs a, int ntiles, int dbg) {
             wq[ks][0] = s.p1; wq[ks][1] = s.p2; wq[ks][2] = s.p3;
         }
     }
-    float head8[8];
+    float head4[4];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) head8[i] = (UP & 2) ? a.up.w_head[f8 + i] : 0.f;
-    // ---- staging offsets of this thread (row srow, columns f8..f8+7 of each 64-column plane)
-    const int st0 = dui_off(srow, f8), st1 = dui_off(srow, 64 + f8);
-    const int stE0 = srow * 64 + ((((f8 >> 2)) ^ (srow & 15)) << 2), stE1 = srow * 64 + ((((f8 >> 2) + 1) ^ (srow & 15)) << 2);
+    for (int i = 0; i < 4; ++i) head4[i] = (UP & 2) ? a.up.w_head[f4 + i] : 0.f;
+    // ---- staging offsets: rows hr and 16 + hr have the same chunk permutation up to the (row >> 2) & 3 bits
+    const int stA0 = dui_off(hr, f4), stA1 = dui_off(hr, 64 + f4);
+    const int seA = hr * 64 + (((f4 >> 2) ^ (hr & 15)) << 2);
+    constexpr int stB = 16 * 128, seB = 16 * 64;   // row 16 + hr has row hr's chunk permutation: a constant offset
     // ---- data product reads: lane = row c
     const int swzc = dui_swz(c), rowc = c * 128;
     const int hix = is_dx ? 0 : 64;                // d_h takes dn*r (image columns 192..255) for the n gate
@@ -2102,29 +2164,37 @@ void k_gru_bwd_one(GruBwdFusedArgs a, int ntiles, int dbg) {
 
     const int G = gridDim.x;
     const int nmine = (ntiles - (int)blockIdx.x + G - 1) / G;      // >= 1: the grid never exceeds ntiles
-    OneRaw raw;
-    OneVals vals;
+    HalfRaw rawA, rawB;
+    HalfVals v;
+#define ONE_STAGE(img, s0, s1, se)                                                                           \
+    do {                                                                                                     \
+        half_put((img), (s0), PA, v.dr); half_put((img), (s1), PA, v.dz);                                    \
+        half_put((img), SUB + (s0), PA, v.dn); half_put((img), SUB + (s1), PA, v.dnr);                       \
+        half_put((img) + OFF_B, (s0), PB, v.x); half_put((img) + OFF_B, (s1), PB, v.hp);                     \
+        *reinterpret_cast<float4*>(reinterpret_cast<float*>((img) + OFF_E) + (se)) =                         \
+            make_float4(v.ex[0], v.ex[1], v.ex[2], v.ex[3]);                                                 \
+    } while (0)
     // ---- prologue: tile 0 staged into buffer 0, tile 1 requested, ids of tile 2 fetched
-    bool valid_next;
+    bool validA, validB;
+    HalfIds idA, idB;
     {
-        const OneIds id0 = one_ids<XMODE, FUSE>(a, blockIdx.x, true, srow);
-        one_issue<XMODE, UP, FUSE>(a, id0, f8, raw);
-        const OneIds id1 = one_ids<XMODE, FUSE>(a, blockIdx.x + G, 1 < nmine, srow);
-        one_vals<XMODE, UP, FUSE>(raw, id0.valid, head8, vals);
-        one_issue<XMODE, UP, FUSE>(a, id1, f8, raw);
-        valid_next = id1.valid;
-        uint16_t* b0 = lds16;
-        one_put(b0, st0, PA, vals.dr);  one_put(b0, st1, PA, vals.dz);
-        one_put(b0, SUB + st0, PA, vals.dn);  one_put(b0, SUB + st1, PA, vals.dnr);
-        one_put(b0 + OFF_B, st0, PB, vals.x);  one_put(b0 + OFF_B, st1, PB, vals.hp);
-        float* e = reinterpret_cast<float*>(b0 + OFF_E);
-        *reinterpret_cast<float4*>(e + stE0) = make_float4(vals.ex[0], vals.ex[1], vals.ex[2], vals.ex[3]);
-        *reinterpret_cast<float4*>(e + stE1) = make_float4(vals.ex[4], vals.ex[5], vals.ex[6], vals.ex[7]);
+        const HalfIds a0 = half_ids<XMODE, FUSE>(a, blockIdx.x, true, hr), b0 = half_ids<XMODE, FUSE>(a, blockIdx.x, true, 16 + hr);
+        half_issue<XMODE, UP, FUSE>(a, a0, f4, rawA);
+        half_issue<XMODE, UP, FUSE>(a, b0, f4, rawB);
+        const HalfIds a1 = half_ids<XMODE, FUSE>(a, blockIdx.x + G, 1 < nmine, hr);
+        const HalfIds b1 = half_ids<XMODE, FUSE>(a, blockIdx.x + G, 1 < nmine, 16 + hr);
+        half_vals<XMODE, UP, FUSE>(rawA, a0.valid, head4, v);
+        ONE_STAGE(lds16, stA0, stA1, seA);
+        half_issue<XMODE, UP, FUSE>(a, a1, f4, rawA);
+        half_vals<XMODE, UP, FUSE>(rawB, b0.valid, head4, v);
+        ONE_STAGE(lds16, stA0 + stB, stA1 + stB, seA + seB);
+        half_issue<XMODE, UP, FUSE>(a, b1, f4, rawB);
+        validA = a1.valid; validB = b1.valid;
+        idA = half_ids<XMODE, FUSE>(a, blockIdx.x + 2 * G, 2 < nmine, hr);
+        idB = b1;                                  // stream B's gathers of tile 1 are requested (again) at hs 5 of tile 0
     }
-    OneIds idn = one_ids<XMODE, FUSE>(a, blockIdx.x + 2 * G, 2 < nmine, srow);
     // epilogue row of tile 0 (lane = row c)
-    int elp = min((int)blockIdx.x * 32 + c, a.R - 1);
-    int erow = a.rows[elp];
+    int erow = a.rows[min((int)blockIdx.x * 32 + c, a.R - 1)];
     bool elive = (int)blockIdx.x * 32 + c < a.R;
     __syncthreads();
 
@@ -2132,41 +2202,17 @@ void k_gru_bwd_one(GruBwdFusedArgs a, int ntiles, int dbg) {
         const int tile = blockIdx.x + it * G;
         uint16_t* const cur = lds16 + (it & 1) * BUF;
         uint16_t* const nxt = lds16 + ((it & 1) ^ 1) * BUF;
-        // 1. the next tile's arrays from the registers its rows landed in, 2. split and stored into `nxt`,
-        // 3. the rows of the tile after it requested: they have the matrix phase, the epilogue and the barrier to land
-        one_vals<XMODE, UP, FUSE>(raw, valid_next, head8, vals);
-        one_put(nxt, st0, PA, vals.dr); one_put(nxt, st1, PA, vals.dz);
-        one_put(nxt, SUB + st0, PA, vals.dn); one_put(nxt, SUB + st1, PA, vals.dnr);
-        one_put(nxt + OFF_B, st0, PB, vals.x); one_put(nxt + OFF_B, st1, PB, vals.hp);
-        {
-            float* e = reinterpret_cast<float*>(nxt + OFF_E);
-            *reinterpret_cast<float4*>(e + stE0) = make_float4(vals.ex[0], vals.ex[1], vals.ex[2], vals.ex[3]);
-            *reinterpret_cast<float4*>(e + stE1) = make_float4(vals.ex[4], vals.ex[5], vals.ex[6], vals.ex[7]);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        if (!(dbg & 2)) one_issue<XMODE, UP, FUSE>(a, idn, f8, raw);
-        __builtin_amdgcn_sched_barrier(0);
-        valid_next = idn.valid;
-        idn = one_ids<XMODE, FUSE>(a, tile + 3 * G, it + 3 < nmine, srow);
-        const int elp_n = min((tile + G) * 32 + c, a.R - 1);
-        const int erow_n = a.rows[elp_n];
-        const bool elive_n = (it + 1 < nmine) && ((tile + G) * 32 + c < a.R);
-
-        // 4. matrix phase on `cur`: 12 k-steps of the data product (D) and 6 (16-row block, A tile) groups of the weight
-        //    gradient (W) in the order D D W D D W ...; the operands of a step are requested one step ahead
-        f32x16 accd;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) accd[i] = 0.f;
+        // operand reads of the matrix phase
         Split8 bD[2], bt[2];
-        uint4 aW[2][3];
-#define ONE_LD_D(ks, dst)                                                                                    \
+        uint4 aW[1][3];
+#define ONE_LD_D(ks)                                                                                         \
     do {                                                                                                     \
         int inrow_ = ((2 * ((ks) & 7) + half) ^ swzc) << 3;                                                  \
         if ((ks) >= 8) inrow_ ^= hix;                                                                        \
         const uint16_t* p_ = cur + ((ks) >> 3) * SUB + rowc + inrow_;                                        \
-        (dst).p1 = *reinterpret_cast<const uint4*>(p_);                                                      \
-        (dst).p2 = *reinterpret_cast<const uint4*>(p_ + PA);                                                 \
-        (dst).p3 = *reinterpret_cast<const uint4*>(p_ + 2 * PA);                                             \
+        bD[(ks) & 1].p1 = *reinterpret_cast<const uint4*>(p_);                                               \
+        bD[(ks) & 1].p2 = *reinterpret_cast<const uint4*>(p_ + PA);                                          \
+        bD[(ks) & 1].p3 = *reinterpret_cast<const uint4*>(p_ + 2 * PA);                                      \
     } while (0)
 #define ONE_LD_TR(base0, base1, pstride, q1, q2, q3)                                                         \
     do {                                                                                                     \
@@ -2184,40 +2230,79 @@ void k_gru_bwd_one(GruBwdFusedArgs a, int ntiles, int dbg) {
         ONE_LD_TR(cur + (kb) * 2048 + offB[0][0], cur + (kb) * 2048 + offB[0][1], PB, bt[0].p1, bt[0].p2, bt[0].p3); \
         ONE_LD_TR(cur + (kb) * 2048 + offB[1][0], cur + (kb) * 2048 + offB[1][1], PB, bt[1].p1, bt[1].p2, bt[1].p3); \
     } while (0)
-#define ONE_LD_A(g, dst)                                                                                     \
-    ONE_LD_TR(cur + ((g) / 3) * 2048 + offA[(g) % 3][0], cur + ((g) / 3) * 2048 + offA[(g) % 3][1], PA, (dst)[0], (dst)[1], (dst)[2])
-        if (!(dbg & 1)) {
-        ONE_LD_D(0, bD[0]);
+#define ONE_LD_A(g)                                                                                          \
+    ONE_LD_TR(cur + ((g) / 3) * 2048 + offA[(g) % 3][0], cur + ((g) / 3) * 2048 + offA[(g) % 3][1], PA,      \
+              aW[0][0], aW[0][1], aW[0][2])
+        ONE_LD_D(0);
         ONE_LD_BT(0);
-        ONE_LD_A(0, aW[0]);
-        __builtin_amdgcn_sched_barrier(0);
+        ONE_LD_A(0);
+        const int erow_n = a.rows[min((tile + G) * 32 + c, a.R - 1)];
+        const bool elive_n = (it + 1 < nmine) && ((tile + G) * 32 + c < a.R);
+
+        f32x16 accd;
 #pragma unroll
-        for (int grp = 0; grp < 6; ++grp) {
-            ONE_LD_D(2 * grp + 1, bD[1]);
-            accd = mfma_x6(wq[2 * grp][0], wq[2 * grp][1], wq[2 * grp][2], bD[0], accd);
-            __builtin_amdgcn_sched_barrier(0);
-            if (grp < 5) ONE_LD_A(grp + 1, aW[(grp + 1) & 1]);
-            accd = mfma_x6(wq[2 * grp + 1][0], wq[2 * grp + 1][1], wq[2 * grp + 1][2], bD[1], accd);
-            __builtin_amdgcn_sched_barrier(0);
-            if (grp < 5) ONE_LD_D(2 * grp + 2, bD[0]);
+        for (int i = 0; i < 16; ++i) accd[i] = 0.f;
+        float d0[4], tt[4];
+        // 12 half-groups: k-step hs of the data product (6 MFMAs, one chain) interleaved with half of weight-gradient
+        // group hs/2 (6 MFMAs on two chains); the staging of one array of the next tile rides along with each
 #pragma unroll
-            for (int t = 0; t < 2; ++t)
-                acc[grp % 3][t] = mfma_x6(aW[grp & 1][0], aW[grp & 1][1], aW[grp & 1][2], bt[t], acc[grp % 3][t]);
+        for (int hs = 0; hs < 12; ++hs) {
+            const int g = hs >> 1, kk = hs & 1, j = g % 3;
+            if (hs + 1 < 12) ONE_LD_D(hs + 1);
+            if (kk == 0) {
+                acc[j][0] = mfma_c<0>(aW[0], bt[0], acc[j][0]);  accd = mfma_c<0>(wq[hs], bD[hs & 1], accd);
+                acc[j][1] = mfma_c<0>(aW[0], bt[1], acc[j][1]);  accd = mfma_c<1>(wq[hs], bD[hs & 1], accd);
+                acc[j][0] = mfma_c<1>(aW[0], bt[0], acc[j][0]);  accd = mfma_c<2>(wq[hs], bD[hs & 1], accd);
+                acc[j][1] = mfma_c<1>(aW[0], bt[1], acc[j][1]);  accd = mfma_c<3>(wq[hs], bD[hs & 1], accd);
+                acc[j][0] = mfma_c<2>(aW[0], bt[0], acc[j][0]);  accd = mfma_c<4>(wq[hs], bD[hs & 1], accd);
+                acc[j][1] = mfma_c<2>(aW[0], bt[1], acc[j][1]);  accd = mfma_c<5>(wq[hs], bD[hs & 1], accd);
 #pragma unroll
-            for (int pc = 0; pc < 3; ++pc) {
-                const uint4 q = aW[grp & 1][pc];
-                bsum[grp % 3] = dot2_ones(q.x, bsum[grp % 3]); bsum[grp % 3] = dot2_ones(q.y, bsum[grp % 3]);
-                bsum[grp % 3] = dot2_ones(q.z, bsum[grp % 3]); bsum[grp % 3] = dot2_ones(q.w, bsum[grp % 3]);
+                for (int pc = 0; pc < 3; ++pc) {
+                    const uint4 q = aW[0][pc];
+                    bsum[j] = dot2_ones(q.x, bsum[j]); bsum[j] = dot2_ones(q.y, bsum[j]);
+                    bsum[j] = dot2_ones(q.z, bsum[j]); bsum[j] = dot2_ones(q.w, bsum[j]);
+                }
+            } else {
+                accd = mfma_c<0>(wq[hs], bD[hs & 1], accd);  acc[j][0] = mfma_c<3>(aW[0], bt[0], acc[j][0]);
+                accd = mfma_c<1>(wq[hs], bD[hs & 1], accd);  acc[j][1] = mfma_c<3>(aW[0], bt[1], acc[j][1]);
+                accd = mfma_c<2>(wq[hs], bD[hs & 1], accd);  acc[j][0] = mfma_c<4>(aW[0], bt[0], acc[j][0]);
+                accd = mfma_c<3>(wq[hs], bD[hs & 1], accd);  acc[j][1] = mfma_c<4>(aW[0], bt[1], acc[j][1]);
+                accd = mfma_c<4>(wq[hs], bD[hs & 1], accd);  acc[j][0] = mfma_c<5>(aW[0], bt[0], acc[j][0]);
+                accd = mfma_c<5>(wq[hs], bD[hs & 1], accd);  acc[j][1] = mfma_c<5>(aW[0], bt[1], acc[j][1]);
             }
+            if (kk == 1 && g + 1 < 6) ONE_LD_A(g + 1);
+            if (hs == 5) ONE_LD_BT(1);
+            // staging of the next tile: stream A (rows 0..15) in half-groups 0..5, stream B (rows 16..31) in 6..11; a
+            // stream's rows are requested again as soon as its last slice has consumed them (half a tile ahead of use)
+            if (hs < 6)
+                half_slice<XMODE, UP, FUSE>(hs % 6, rawA, validA, head4, d0, tt, nxt, stA0, stA1, seA, SUB, PA, PB, OFF_B, OFF_E);
+            else
+                half_slice<XMODE, UP, FUSE>(hs % 6, rawB, validB, head4, d0, tt, nxt, stA0 + stB, stA1 + stB, seA + seB, SUB,
+                                                    PA, PB, OFF_B, OFF_E);
             __builtin_amdgcn_sched_barrier(0);
-            if (grp == 2) ONE_LD_BT(1);
-        }
+            // stream A: own planes re-requested after its last slice (hs 5), its gathers half a tile later (hs 11);
+            // stream B: own planes at hs 11, gathers at hs 5 of the next tile -- only one stream's gather registers
+            // are alive at a time
+            if (hs == 5) {
+                half_issue_main<UP>(a, idA, f4, rawA);
+                half_issue_gather<XMODE, FUSE>(a, idB, f4, rawB);
+                __builtin_amdgcn_sched_barrier(0);
+                validB = idB.valid;
+                idB = half_ids<XMODE, FUSE>(a, tile + 2 * G, it + 2 < nmine, 16 + hr);
+            }
+            if (hs == 11) {
+                half_issue_main<UP>(a, idB, f4, rawB);
+                half_issue_gather<XMODE, FUSE>(a, idA, f4, rawA);
+                __builtin_amdgcn_sched_barrier(0);
+                validA = idA.valid;
+                idA = half_ids<XMODE, FUSE>(a, tile + 3 * G, it + 3 < nmine, hr);
+            }
         }
 #undef ONE_LD_A
 #undef ONE_LD_BT
 #undef ONE_LD_TR
 #undef ONE_LD_D
-        // 5. epilogue: lane = row c; register 4q+i <-> column 8q + 4 half + i of the wave's 32-column tile
+        // epilogue: lane = row c; register 4q+i <-> column 8q + 4 half + i of the wave's 32-column tile
         if (is_dx) {
             if (elive) {
 #pragma unroll
@@ -2241,6 +2326,7 @@ void k_gru_bwd_one(GruBwdFusedArgs a, int ntiles, int dbg) {
         erow = erow_n; elive = elive_n;
         __syncthreads();
     }
+#undef ONE_STAGE
     // ---- one slab per block: [3H][IN+H] weights, then [2][3H] biases
     float* sw = a.slab_w + (size_t)blockIdx.x * (3 * H) * (2 * H);
 #pragma unroll
@@ -2571,6 +2657,8 @@ int tmpnn_gru_bwd_fused(const int32_t* rows, int R, int xmode, const int32_t* sr
                    (ld_dmsg & 3) == 0 && aligned16(d_msg) && (ld_dh & 3) == 0 && aligned16(d_h) &&
                    (add_msg == nullptr || ((ld_add & 3) == 0 && aligned16(add_msg) && add_src && add_dst)),
                "gru_bwd_fused: rows must be 16-byte aligned");
+    TM_REQUIRE(xmode == 0 || add_msg == nullptr || (add_src == src && add_dst == dst),
+               "gru_bwd_fused: with xmode != 0 the fused adjoint gathers through src / dst (pass the same arrays)");
     const size_t need = tmpnn_gru_bwd_fused_ws(R, IN, H);
     if (ws == nullptr || ws_bytes < need)
         return set_error(TMPNN_EWORKSPACE, "gru_bwd_fused: workspace %zu < %zu bytes", ws_bytes, need);
@@ -2584,14 +2672,13 @@ int tmpnn_gru_bwd_fused(const int32_t* rows, int R, int xmode, const int32_t* sr
                       slab_w, slab_b};
     const int ntiles = ceil_div(R, 32);
     const size_t shm = 163840;                               // two 80 KiB operand-image sets: the whole LDS of a CU
-    const int dbg_ = getenv("TMPNN_ONE_DBG") ? atoi(getenv("TMPNN_ONE_DBG")) : 0;
     hipStream_t st = as_stream(stream);
     const int up = (d_hout ? 1 : 0) | (dy ? 2 : 0);
     const bool fuse = add_msg != nullptr;
 #define LF(X, U, F)                                                                                          \
     do {                                                                                                     \
         TM_SHM_ONCE((k_gru_bwd_one<X, U, F>), shm);                                                          \
-        hipLaunchKernelGGL((k_gru_bwd_one<X, U, F>), dim3(n_rs), dim3(256), shm, st, a, ntiles, dbg_);             \
+        hipLaunchKernelGGL((k_gru_bwd_one<X, U, F>), dim3(n_rs), dim3(256), shm, st, a, ntiles);             \
     } while (0)
 #define LU(X, F) do { if (up == 1) LF(X, 1, F); else if (up == 2) LF(X, 2, F); else LF(X, 3, F); } while (0)
     if (xmode == 0) { if (fuse) LU(0, true); else LU(0, false); }

@@ -25,7 +25,7 @@ ATT_DROPOUT_P = 0.5
 # `GradBucket(model)` (trackmpnn_amd.dist) turns it on for its module (`module.inplace_param_grads = True`), the
 # environment variable TMPNN_INPLACE_GRADS=1 for every module.  Default: off -- real gradients are returned.
 INPLACE_GRADS = os.environ.get('TMPNN_INPLACE_GRADS', '0') == '1'
-FUSED_BWD = os.environ.get('TMPNN_FUSED_BWD', '0') == '1'     # see mp_backward
+FUSED_BWD = os.environ.get('TMPNN_FUSED_BWD', '1') == '1'     # one-pass cell backward (see mp_backward)
 # H = 128 / 256 edge cells as LDS-tiled bf16x6 GEMMs (csrc/wide.hip); TMPNN_WIDE=0 keeps round 1's f32-MFMA kernels
 WIDE = os.environ.get('TMPNN_WIDE', '1') != '0' and os.environ.get('TMPNN_SPLIT', '1')[:1] != '0'
 
@@ -344,9 +344,9 @@ def mp_backward(spec: ModelSpec, plan: CallPlan, saved: dict, P: Dict[str, torch
     plane = N * H
     ws_e = lib.tmpnn_gru_bwd_weights_ws(E, IN_e, H)
     ws_n = lib.tmpnn_gru_bwd_weights_ws(Dn, H, H)
-    # The single-pass backward (tmpnn_gru_bwd_fused) reads the gates once instead of twice but, with one
-    # barrier-synchronised block per CU, measured 7 % SLOWER than the two stand-alone kernels on MI355X
-    # (3.60 vs 3.36 ms per 3 M rows, round 1) -- opt-in until its staging is double-buffered.
+    # The one-pass backward (tmpnn_gru_bwd_fused: H = 64, K-independent) reads dh, the gates and h ONCE for the data
+    # and the weight gradient: 2.39 vs 2.85 ms per 3 M edge rows for the two stand-alone kernels, 35.3 vs 37.9 ms per
+    # C2 step (round 2).  TMPNN_FUSED_BWD=0 keeps the two kernels.
     use_fused_bwd = (FUSED_BWD and lib.tmpnn_gru_bwd_fused_available(H, H, 0)
                      and lib.tmpnn_gru_bwd_fused_available(H, IN_e, xmode))
     ws_f = max(lib.tmpnn_gru_bwd_fused_ws(E, IN_e, H), lib.tmpnn_gru_bwd_fused_ws(Dn, H, H)) if use_fused_bwd else 0
