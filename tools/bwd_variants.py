@@ -38,3 +38,11 @@ def ffn():
               dmsg.data_ptr(), H, dh.data_ptr(), H, g.src.data_ptr(), g.dst.data_ptr(), dmsg.data_ptr(), H,
               gW[0].data_ptr(), gW[1].data_ptr(), gW[2].data_ptr(), gW[3].data_ptr(), fws.data_ptr(), fwsb, st)
 print('FUSED data+weights up3_fuse', round(bench.time_stage(ffn), 3), 'ms', flush=True)
+for nm, dho, dy in (('up1', 1, 0), ('up2', 0, 1), ('up3', 1, 1)):
+    def ffn2(dho=dho, dy=dy):
+        _lib.call('tmpnn_gru_bwd_fused', g.edge_row.data_ptr(), E, 1, g.src.data_ptr(), g.dst.data_ptr(), None, 0, 0, H, h.data_ptr(), H, H,
+                  wih.data_ptr(), whh.data_ptr(), gates.data_ptr(), N*H, dout.data_ptr() if dho else None, H,
+                  dyv.data_ptr() if dy else None, w_head.data_ptr() if dy else None,
+                  dmsg.data_ptr(), H, dh.data_ptr(), H, g.src.data_ptr(), g.dst.data_ptr(), dmsg.data_ptr(), H,
+                  gW[0].data_ptr(), gW[1].data_ptr(), gW[2].data_ptr(), gW[3].data_ptr(), fws.data_ptr(), fwsb, st)
+    print('one-pass', nm, 'fuse', round(bench.time_stage(ffn2), 3), 'ms', flush=True)
