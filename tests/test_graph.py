@@ -168,7 +168,7 @@ def test_state_dict_keys_match_oracle_shapes():
             assert tuple(v.shape) == shapes[k], k
         assert sorted(m.spec.param_names()) == sorted(k for k, _ in m.named_parameters())
     with pytest.raises(ValueError):
-        TrackMPNN('2d', 3, 48, 0, 'diff')
+        TrackMPNN('2d', 3, 257, 0, 'diff')
     with pytest.raises(AssertionError):
         TrackMPNN('2d', 3, 32, 0, 'sum')
 
@@ -194,3 +194,31 @@ def test_initial_weights_bit_equal_to_reference():
     sd = TrackMPNN('2d', 3, 32, 0, 'diff').state_dict()
     for k, v in sd.items():
         assert np.array_equal(v.numpy(), d['full/' + k]), k
+
+
+def test_any_hidden_width_is_accepted_and_keeps_reference_shapes():
+    """nhidden is any int in the reference (utils/training_options.py:22): widths between the instantiated kernel
+    widths keep the reference's parameter shapes (state_dict compatibility) and run zero-padded."""
+    from trackmpnn_amd import TrackMPNN
+    m = TrackMPNN('2d+temp', 3, 48, 1, 'concat')
+    assert (m.nhidden, m.hpad, m.spec.H) == (48, 64, 64)
+    sd = m.state_dict()
+    assert sd['factor_grus.0.edge_gru.weight_ih'].shape == (3 * 48, 2 * 48)
+    assert sd['factor_grus.1.gat.0.W_att'].shape == (48, 48) and sd['factor_grus.1.gat.0.a'].shape == (48, 1)
+    assert sd['output_transform_edge.weight'].shape == (1, 2 * 48)
+    assert sd['input_transforms.0.1.running_var'].shape == (48,)
+    named = dict(m.named_parameters())
+    padded = m._pad_params([named[k] for k in m.spec.param_names()])
+    shapes = {k: tuple(t.shape) for k, t in zip(m.spec.param_names(), padded)}
+    assert shapes['factor_grus.0.edge_gru.weight_ih'] == (192, 128) and shapes['factor_grus.0.node_gru.weight_hh'] == (192, 64)
+    assert shapes['output_transform_node.weight'] == (1, 128) and shapes['input_transforms.1.3.weight'] == (64, 64)
+    w, wp = named['factor_grus.0.edge_gru.weight_ih'], padded[m.spec.param_names().index('factor_grus.0.edge_gru.weight_ih')]
+    # gate g, unit i, input block b, column j  ->  row g*64 + i, column b*64 + j ; everything else exactly zero
+    assert torch.equal(wp.reshape(3, 64, 2, 64)[:, :48, :, :48], w.reshape(3, 48, 2, 48))
+    assert float(wp.abs().sum()) == float(w.abs().sum())
+    h = torch.randn(5, 2 * 48)
+    assert torch.equal(m._unpad_state(m._pad_state(h)), h)
+    assert TrackMPNN('2d', 3, 64, 0, 'diff')._padded is False
+    import pytest
+    with pytest.raises(ValueError):
+        TrackMPNN('2d', 3, 300, 0, 'diff')

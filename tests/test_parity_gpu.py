@@ -159,6 +159,12 @@ def _batched_case(B, frames, mean, max_dets, F, seed0=0, static=False):
     ('2d', 3, 64, 0, 'concat', True),         # concat at the headline width (generic forward, output-tiled dW kernel)
     ('2d', 3, 32, 0, 'diff', True),           # H = 32 instances of the LDS / bf16x6 kernels
     ('2d', 3, 32, 1, 'concat', False),
+    # widths the kernels are not instantiated for run zero-padded to the next one (reference: any int,
+    # utils/training_options.py:22)
+    ('2d', 3, 48, 0, 'diff', True),
+    ('2d', 3, 20, 0, 'concat', True),
+    ('2d+temp+vis', 3, 48, 0, 'diff', True),
+    ('2d', 3, 100, 2, 'diff', False),
 ])
 def test_batched_windows_vs_oracle(features, ncat, H, K, msg, train):
     """Block-diagonal batches of KITTI-shaped rolling windows (per-window BatchNorm segments), fwd + bwd."""

@@ -23,6 +23,8 @@ from .graph import (CallPlan, DeviceGraph, FrameGraph, device_graph_from_adjacen
 from .layers import FactorGraphGRU
 from .small import SmallPath, _SmallIter, fast_module, small_eligible
 
+KERNEL_WIDTHS = (32, 64, 128, 256)          # hidden widths the HIP kernels are instantiated for
+
 STRICT_GRAPH = os.environ.get('TMPNN_STRICT_GRAPH', '0') == '1'     # validate every adjacency at once (host sync)
 SMALL_PATH = os.environ.get('TMPNN_SMALL_PATH', '1') != '0'         # fused batch-1 iteration for eligible calls
 DEBUG_INPUTS = os.environ.get('TMPNN_DEBUG', '0') == '1'            # check the all-zero contract of x's edge rows (host sync)
@@ -65,8 +67,14 @@ class SparseAttention:
 class TrackMPNN(nn.Module):
     def __init__(self, features, ncategories, nhidden, nattheads, msg_type):
         super().__init__()
-        if nhidden not in (32, 64, 128, 256):
-            raise ValueError(f'nhidden={nhidden}: the gfx950 kernels support 32, 64, 128 or 256')
+        nhidden = int(nhidden)
+        if not 1 <= nhidden <= KERNEL_WIDTHS[-1]:
+            raise ValueError(f'nhidden={nhidden}: the gfx950 kernels cover 1 .. {KERNEL_WIDTHS[-1]} hidden units')
+        # the kernels are instantiated for KERNEL_WIDTHS; any other width runs zero-padded to the next one (exact:
+        # a padded unit has zero weights and biases everywhere, so it stays 0 through BatchNorm, both GRU cells,
+        # the attention scores and the heads -- see _pad_params)
+        self.hpad = next(w for w in KERNEL_WIDTHS if nhidden <= w)
+        self._padded = self.hpad != nhidden
         self.input_transforms = nn.ModuleList([])
         self.factor_grus = nn.ModuleList([])
         self.feature_idx = []
@@ -89,7 +97,7 @@ class TrackMPNN(nn.Module):
         self.output_transform_edge.weight.data.normal_(mean=0.0, std=0.01)
         self.output_transform_edge.bias.data.uniform_(-4.595, -4.595)
         self.output_activation = nn.Sigmoid()
-        self.spec = ModelSpec(tuple(groups), nhidden, max(int(nattheads), 0), msg_type)
+        self.spec = ModelSpec(tuple(groups), self.hpad, max(int(nattheads), 0), msg_type)
         self._graph_cache = None
         # set by trackmpnn_amd.dist.GradBucket: parameter gradients are added straight into p.grad (functional.py)
         self.inplace_param_grads = False
@@ -133,6 +141,49 @@ class TrackMPNN(nn.Module):
         buffers = dict(self.named_buffers())
         return params, buffers
 
+    # ------------------------------------------------------------------------------------------
+    # nhidden outside KERNEL_WIDTHS: the call runs on zero-padded copies of the parameters (differentiable torch ops, so
+    # autograd hands the true parameters their gradients); the carried state keeps the reference's [N, G * nhidden] shape
+    # ------------------------------------------------------------------------------------------
+    def _pad_params(self, params):
+        H, Hp, G, K = self.nhidden, self.hpad, self.spec.G, self.spec.K
+        d = Hp - H
+        nb_e = 2 if self.spec.msg_type == 'concat' else 1
+        pad = torch.nn.functional.pad
+
+        def gru_w(w, nb):                      # [3H, nb*H] -> [3Hp, nb*Hp], gate by gate and input block by block
+            return pad(w.reshape(3, H, nb, H), (0, d, 0, 0, 0, d)).reshape(3 * Hp, nb * Hp)
+
+        def gru_b(b):
+            return pad(b.reshape(3, H), (0, d)).reshape(3 * Hp)
+
+        it = iter(params)
+        out = []
+        for _ in range(G):
+            w1, b1, gam, bet, w2, b2 = (next(it) for _ in range(6))
+            out += [pad(w1, (0, 0, 0, d)), pad(b1, (0, d)), pad(gam, (0, d)), pad(bet, (0, d)),
+                    pad(w2, (0, d, 0, d)), pad(b2, (0, d))]
+        for _ in range(G):
+            w_ih, w_hh, b_ih, b_hh = (next(it) for _ in range(4))
+            out += [gru_w(w_ih, nb_e), gru_w(w_hh, 1), gru_b(b_ih), gru_b(b_hh)]
+            for _k in range(K):
+                W_att, a = next(it), next(it)
+                out += [pad(W_att, (0, d, 0, d)), pad(a, (0, 0, 0, d))]
+            w_ih, w_hh, b_ih, b_hh = (next(it) for _ in range(4))
+            out += [gru_w(w_ih, 1), gru_w(w_hh, 1), gru_b(b_ih), gru_b(b_hh)]
+        for _ in range(2):
+            w, b = next(it), next(it)
+            out += [pad(w.reshape(1, G, H), (0, d)).reshape(1, G * Hp), b]
+        return [t.contiguous() for t in out]
+
+    def _pad_state(self, h):
+        N, G = h.shape[0], self.spec.G
+        return torch.nn.functional.pad(h.reshape(N, G, self.nhidden), (0, self.hpad - self.nhidden)).reshape(N, G * self.hpad)
+
+    def _unpad_state(self, h):
+        N, G = h.shape[0], self.spec.G
+        return h.reshape(N, G, self.hpad)[:, :, :self.nhidden].reshape(N, G * self.nhidden)
+
     def forward_graph(self, x: torch.Tensor, h_in: Optional[torch.Tensor], plan: CallPlan,
                       dropout_keep: Optional[Sequence[torch.Tensor]] = None, reserve_rows: int = 0):
         """One message-passing call on a prebuilt CallPlan (see trackmpnn_amd.graph).
@@ -149,11 +200,27 @@ class TrackMPNN(nn.Module):
         params, buffers = self._params_and_buffers()
         need_grad = torch.is_grad_enabled() and (
             x.requires_grad or (h_in is not None and h_in.requires_grad) or any(p.requires_grad for p in params))
+        true_buffers = None
+        if self._padded:
+            params = self._pad_params(params)
+            h_in = self._pad_state(h_in) if h_in is not None else None
+            d = self.hpad - self.nhidden
+            true_buffers, buffers = buffers, dict(buffers)
+            for k, b in true_buffers.items():            # BatchNorm running statistics of the padded units: (0, 1)
+                if k.endswith('running_mean') or k.endswith('running_var'):
+                    buffers[k] = torch.nn.functional.pad(b, (0, d), value=1.0 if k.endswith('var') else 0.0)
+            reserve_rows = 0
         call = dict(spec=self.spec, plan=plan, buffers=buffers, training=self.training, need_grad=need_grad,
                     keep=dropout_keep, reserve=reserve_rows,
                     h_spare=getattr(h_in, '_tmpnn_spare_rows', 0) if h_in is not None else 0,
-                    param_objs=params, inplace=self.inplace_param_grads)
+                    param_objs=params, inplace=self.inplace_param_grads and not self._padded)
         scores, logits, h_out = MPIteration.apply(call, x, h_in, *params)
+        if self._padded:
+            with torch.no_grad():
+                for k, b in true_buffers.items():
+                    if buffers[k] is not b:
+                        b.copy_(buffers[k][:self.nhidden])
+            h_out = self._unpad_state(h_out)
         h_out._tmpnn_spare_rows = max(int(reserve_rows), 0)
         attention = tuple(None if a is None else [SparseAttention(plan.graph, ak) for ak in a]
                           for a in call['alphas'])
@@ -179,6 +246,8 @@ class TrackMPNN(nn.Module):
         if not x.is_cuda:
             raise RuntimeError(f'x is on {x.device}: trackmpnn_amd runs on the MI355X HIP kernels only '
                                '(no CPU or torch fallback exists)')
+        if self._padded:
+            return self.forward_graph(x, h_in, plan_single(graph.frame_graph(), int(x.shape[0])))
         if self._plist is None:
             named = dict(self.named_parameters())
             self._plist = [named[nm] for nm in self.spec.param_names()]
@@ -241,7 +310,7 @@ class TrackMPNN(nn.Module):
             raise RuntimeError(f'x is on {x.device}: trackmpnn_amd runs on the MI355X HIP kernels only '
                                '(no CPU or torch fallback exists)')
         N = int(node_adj.shape[0])
-        small = SMALL_PATH and small_eligible(self, N)
+        small = SMALL_PATH and not self._padded and small_eligible(self, N)
         key = (id(node_adj), id(edge_adj), N, node_adj._version, edge_adj._version, x.device, small)
         if self._graph_cache is not None and self._graph_cache[0] == key:
             graph = self._graph_cache[1]
