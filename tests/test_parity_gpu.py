@@ -665,3 +665,68 @@ def test_gradients_bitwise_equal_across_processes():
         assert line, r.stdout[-1500:]
         digests.append(line[-1])
     assert digests[0] == digests[1]
+
+
+@pytest.mark.parametrize('R', [1, 31, 32, 33, 255, 4097, 8191 + 32 * 300])
+def test_one_pass_backward_ragged_sizes_match_the_two_kernels(R):
+    """tmpnn_gru_bwd_fused (one read of the gates) against tmpnn_gru_bwd_data + tmpnn_gru_bwd_weights on row counts
+    around its tile (32 rows), pipeline (prologue stages tile 0 and requests tile 1) and grid (256 persistent blocks)
+    boundaries: every xmode / upstream / fused-adjoint variant, scattered row ids, outputs outside `rows` untouched."""
+    from trackmpnn_amd import _lib
+    lib = _lib.load()
+    H = 64
+    gen = torch.Generator().manual_seed(R)
+    N = 2 * R + 7                                                   # rows of the state; `rows` is a scattered subset
+    perm = torch.randperm(N, generator=gen)
+    rows = perm[:R].sort().values.to(torch.int32).to(DEV)
+    others = perm[R:]                                               # endpoints are never rows of the cell (dets vs edges)
+    src = others[torch.randint(0, N - R, (R,), generator=gen)].to(torch.int32).to(DEV)
+    dst = others[torch.randint(0, N - R, (R,), generator=gen)].to(torch.int32).to(DEV)
+    r32 = lambda *s: torch.randn(*s, generator=gen).to(DEV)         # noqa: E731
+    h, dout, dyv, w_head, msg = r32(N, H), r32(N, H), r32(N), r32(H), r32(R, H)
+    gates = torch.cat([torch.sigmoid(r32(2, N, H)), torch.tanh(r32(1, N, H)), r32(1, N, H)], 0).contiguous()
+    wih, whh = 0.3 * r32(3 * H, H), 0.3 * r32(3 * H, H)
+    st = torch.cuda.current_stream().cuda_stream
+    ws_b = max(lib.tmpnn_gru_bwd_weights_ws(R, H, H), lib.tmpnn_gru_bwd_fused_ws(R, H, H))
+    ws = torch.empty(ws_b // 4 + 1, device=DEV)
+    dmsg_init = r32(N, H)
+    for xmode in (0, 1):
+        for up in (1, 2, 3):
+            for fuse in (False, True):
+                dho = dout.data_ptr() if up & 1 else None
+                dyp, whp = (dyv.data_ptr(), w_head.data_ptr()) if up & 2 else (None, None)
+                sp, dp = (src.data_ptr(), dst.data_ptr()) if xmode else (None, None)
+                mp = msg.data_ptr() if xmode == 0 else None
+                outs = []
+                inside = torch.isin(torch.arange(N, device=DEV), rows.long())
+                base = torch.where(inside[:, None], torch.full((N, H), 7.0, device=DEV), dmsg_init)
+                for one_pass in (False, True):
+                    dmsg = base.clone()
+                    add = dmsg                                        # as the model calls it: the adjoint's table IS d_msg
+                    dh = torch.full((N, H), 5.0, device=DEV)
+                    gW = [torch.full((3 * H, H), 0.5, device=DEV), torch.full((3 * H, H), 0.25, device=DEV),
+                          torch.full((3 * H,), 1.0, device=DEV), torch.full((3 * H,), 2.0, device=DEV)]
+                    fa = (src.data_ptr(), dst.data_ptr(), add.data_ptr()) if fuse else (None, None, None)
+                    if one_pass:
+                        _lib.call('tmpnn_gru_bwd_fused', rows.data_ptr(), R, xmode, sp, dp, mp, H, 1, H, h.data_ptr(), H, H,
+                                  wih.data_ptr(), whh.data_ptr(), gates.data_ptr(), N * H, dho, H, dyp, whp,
+                                  dmsg.data_ptr(), H, dh.data_ptr(), H, fa[0], fa[1], fa[2], H,
+                                  gW[0].data_ptr(), gW[1].data_ptr(), gW[2].data_ptr(), gW[3].data_ptr(),
+                                  ws.data_ptr(), ws.numel() * 4, st)
+                    else:
+                        _lib.call('tmpnn_gru_bwd_data', rows.data_ptr(), R, H, h.data_ptr(), H, H, wih.data_ptr(),
+                                  whh.data_ptr(), gates.data_ptr(), N * H, dho, H, dyp, whp, dmsg.data_ptr(), H,
+                                  dh.data_ptr(), H, fa[0], fa[1], fa[2], H, st)
+                        _lib.call('tmpnn_gru_bwd_weights', rows.data_ptr(), R, xmode, sp, dp, mp, H, 1, H, h.data_ptr(), H, H,
+                                  gates.data_ptr(), N * H, dho, H, dyp, whp, gW[0].data_ptr(), gW[1].data_ptr(),
+                                  gW[2].data_ptr(), gW[3].data_ptr(), ws.data_ptr(), ws.numel() * 4, st)
+                    torch.cuda.synchronize()
+                    outs.append((dmsg, dh, gW))
+                (m0, h0, g0), (m1, h1, g1) = outs
+                tag = (R, xmode, up, fuse)
+                scale = max(1.0, float(h0.abs().max()), float(m0.abs().max()))
+                assert float((m0 - m1).abs().max()) <= 2e-5 * scale, tag
+                assert float((h0 - h1).abs().max()) <= 2e-5 * scale, tag
+                for a, b in zip(g0, g1):
+                    assert float((a - b).abs().max()) <= 2e-5 * max(1.0, float(a.abs().max())), tag
+                assert bool((h1[~inside] == 5.0).all()) and bool((m1[~inside] == base[~inside]).all()), tag
