@@ -455,6 +455,14 @@ int tmpnn_wide_gru_bwd_data(const void* prep, const int32_t* rows, int R, const 
                             const float* w_head, float* d_msg, int ld_dmsg, float* d_h, int ld_dh, void* ws,
                             size_t ws_bytes, tmpnn_stream stream);
 
+/* Weight gradient of the same cell from the gate gradients tmpnn_wide_gru_bwd_data left in ITS workspace (`dg_ws`, read
+ * only): dW_ih += d_gi^T (h[src] - h[dst]), dW_hh += d_gh^T h[rows], db_ih / db_hh += column sums (replaces
+ * tmpnn_gru_bwd_weights for the wide cells: layers.py:84-116 backward).  ws: tmpnn_wide_gru_bwd_weights_ws(R, H) bytes. */
+size_t tmpnn_wide_gru_bwd_weights_ws(int R, int H);
+int tmpnn_wide_gru_bwd_weights(const void* dg_ws, const int32_t* rows, int R, const int32_t* src, const int32_t* dst,
+                               const float* h, int ld_h, int H, float* dW_ih, float* dW_hh, float* db_ih, float* db_hh,
+                               void* ws, size_t ws_bytes, tmpnn_stream stream);
+
 #ifdef __cplusplus
 }
 #endif

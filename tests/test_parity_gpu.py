@@ -156,6 +156,7 @@ def _batched_case(B, frames, mean, max_dets, F, seed0=0, static=False):
     ('2d', 3, 128, 0, 'concat', True),
     ('2d+temp+vis', 3, 64, 0, 'diff', True),
     ('2d', 3, 256, 0, 'diff', True),          # C5 width
+    ('2d', 3, 128, 0, 'diff', True),          # wide cells at H = 128 (one 128-column operand tile per block)
     ('2d', 3, 64, 0, 'concat', True),         # concat at the headline width (generic forward, output-tiled dW kernel)
     ('2d', 3, 32, 0, 'diff', True),           # H = 32 instances of the LDS / bf16x6 kernels
     ('2d', 3, 32, 1, 'concat', False),

@@ -128,14 +128,15 @@ with open(f'profiles/{tag}_c5_dense_stress.md', 'w') as f:
 | round 1 (f32-input MFMA, weights streamed from L2) | 622 | 28.4 M | 67.0 | 97.6 GB |
 | round 2 (edge cell: LDS-tiled bf16x6 GEMMs, csrc/wide.hip) | **{c5['ms_per_step']:.0f}** | **{c5['edges_per_s']/1e6:.1f} M** | **{c5['tflops']:.1f}** | {c5['mem_GB']:.1f} GB |
 
-Per iteration (rocprofv3 --kernel-trace --stats of the same command, gpurun_out/prof_c5e): edge forward 19.6 ms (round 1:
-54), backward data 10 + 2 x 12.7 = 35 ms (round 1: 77), weight gradient 36 ms (unchanged: the f32-MFMA output-tiled
-kernel), aggregations 13 ms.  The two new GEMM kernels reach ~25-35 % of the bf16x6 matrix rate: the forward is held by its
+Per iteration (rocprofv3 --kernel-trace --stats of the same command): edge forward 19.1 ms (round 1: 54), backward data
+9.7 (gate gradients) + 2 x 8.0 = 26 ms (round 1: 77), weight gradient 2 x 11.7 = 23 ms (`k_wide_dw`, bf16x6 from the
+materialised gate gradients; round 1 and the first half of round 2: 36 ms on the f32-MFMA output-tiled kernel, 409 ms
+per step), aggregations 7 ms.  The two new GEMM kernels reach ~25-35 % of the bf16x6 matrix rate: the forward is held by its
 memory-system traffic (the P gathers of the diff projection, 6 KB per row from L2 / Infinity Cache, plus four gate planes
 written), the backward products by reading the materialised gate gradients (3 KB per row per product).  Tried without
 effect: one- and two-deep register prefetch of the next K-step, XCD-aware tile order (the column blocks of a row tile on
 one XCD).  What helped: stores and gathers as 16-byte accesses through an LDS-staged epilogue (gemm 17 -> 12.7 ms).  The
-reference cannot run this configuration at all (dense N x N adjacency: 4.4 M^2 floats).  Next: the weight gradient on
-bf16x6 from the already materialised gate gradients.
+reference cannot run this configuration at all (dense N x N adjacency: 4.4 M^2 floats).  Next: gate gradients stored as
+bf16 pieces once, so that the four GEMM launches that read them stop splitting them again.
 ''')
 print(d['value'], d['ms_per_step'], d['roofline'], d['roofline_aggregation']['frac'], d['cpu_baseline']['value'])

@@ -143,6 +143,9 @@ _SIGNATURES = {
     'tmpnn_wide_gru_bwd_data_ws': (c_size_t, [c_int, c_int]),
     'tmpnn_wide_gru_bwd_data': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_size_t, c_void_p, c_int,
                                         c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
+    'tmpnn_wide_gru_bwd_weights_ws': (c_size_t, [c_int, c_int]),
+    'tmpnn_wide_gru_bwd_weights': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p,
+                                           c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     'tmpnn_mp_iter_prep_floats': (c_size_t, [c_int, c_int, c_int]),
     'tmpnn_mp_iter_prepare': (c_int, [_MPP, c_void_p, c_void_p]),
     'tmpnn_mp_iter_save_floats': (c_size_t, [c_int, c_int, c_int, c_int]),

@@ -16,7 +16,7 @@
 //             gh = h W_hh^T by the tiled GEMM with the GRU gates, the merge and the saved gate planes in its epilogue
 //   backward  d_gi / d_gh are formed once by an elementwise pass (the gates are read exactly once), then
 //             d_x = d_gi W_ih and d_h = dh z + d_gh W_hh are two tiled GEMMs with plain / accumulating stores.
-// The weight gradient keeps the output-tiled kernel of gru.hip.
+//             dW = d_g^T [x | h] from the same materialised gate gradients: k_wide_dw (K = rows, transposing LDS reads).
 #include "common.h"
 
 namespace tmpnn {
@@ -399,6 +399,182 @@ __global__ __launch_bounds__(256) void k_wide_gates_bwd(WideBwdArgs a) {
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------
+// weight gradient from the materialised gate gradients: dW[j][k] = sum_r dg[r][j] * X[r][k]   (bf16x6, K = rows)
+// ------------------------------------------------------------------------------------------------------------
+// Block (mt, nt, slab): 192 gate columns x 128 operand columns, streamed over the slab's rows in 32-row chunks.  The
+// product contracts over ROWS, so both MFMA operands need 8 consecutive rows of one column per lane -- the transpose of
+// the HBM layout: a chunk is staged row-major as bf16 pieces (16 threads per row; dg [32][256 (192 used)], X [32][128];
+// 64-byte chunks XOR-swizzled by row & 3 as in k_gru_bwd_weights_split) and fetched with ds_read_b64_tr_b16.  8 waves,
+// each 3 (A tiles) x 1 (B tile) accumulator tiles over the whole slab; the next chunk's rows are in registers behind the
+// current chunk's MFMAs and go to the second LDS buffer afterwards (one barrier per chunk).  One [3H][H] slab per
+// row slab, bias = column sums of dg taken by the staging threads (blocks with nt = 0).
+typedef short ws16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint2 w_read_tr(const uint16_t* p) {
+    const ws16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) ws16x4*)(p));
+    return __builtin_bit_cast(uint2, v);
+}
+template <int COLS>
+__device__ __forceinline__ int w_swz(int row, int col) { return row * COLS + ((((col >> 5) ^ (row & 3)) << 5) | (col & 31)); }
+
+struct WideDwArgs {
+    const float* dg; int ldg;                       // [R][3H] compact gate gradients
+    const float* X; int ldx;                        // operand rows: X[xa[r]] (- X[xb[r]] when xb != NULL)
+    const int32_t* xa; const int32_t* xb;
+    int R; int H; int rows_per_slab;
+    float* slabs; float* bslabs;                    // [n_slab][3H][H], [n_slab][3H]
+};
+
+static constexpr int DW_A = 3 * 32 * 256, DW_B = 3 * 32 * 128;          // elements of one A / B image set
+static constexpr int DW_SHM = 2 * (DW_A + DW_B) * 2;                    // two buffers, bf16
+
+struct DwRaw { float4 a[3]; float4 b0[2], b1[2]; bool valid; };
+
+__device__ __forceinline__ void dw_issue(const WideDwArgs& q, int r, int r_end, int ca, int cb, DwRaw& w) {
+    w.valid = r < r_end;
+    const int rr = w.valid ? r : r_end - 1;
+    const float4* pa = reinterpret_cast<const float4*>(q.dg + (size_t)rr * q.ldg + ca);
+    w.a[0] = pa[0]; w.a[1] = pa[1]; w.a[2] = pa[2];
+    const float4* pb = reinterpret_cast<const float4*>(q.X + (size_t)q.xa[rr] * q.ldx + cb);
+    w.b0[0] = pb[0]; w.b0[1] = pb[1];
+    if (q.xb) {
+        const float4* pc = reinterpret_cast<const float4*>(q.X + (size_t)q.xb[rr] * q.ldx + cb);
+        w.b1[0] = pc[0]; w.b1[1] = pc[1];
+    }
+}
+
+__global__ __launch_bounds__(512) void k_wide_dw(WideDwArgs q, int mt_count, int nt_count) {
+    extern __shared__ float lds[];
+    uint16_t* const base = reinterpret_cast<uint16_t*>(lds);
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int c = lane & 31, half = lane >> 5;
+    const int tile = blockIdx.x, mt = tile / nt_count, nt = tile % nt_count, slab = blockIdx.y;
+    const int H = q.H;
+    const int srow = tid >> 4, c16 = tid & 15;
+    const int ca = mt * 192 + c16 * 12, cb = nt * 128 + c16 * 8;      // this thread's global columns of dg / X
+    const int r_lo = slab * q.rows_per_slab, r_end = min(q.R, r_lo + q.rows_per_slab);
+    // roles: A tiles 3 * (wave & 1) + {0, 1, 2} (32 gate columns each), B tile wave >> 1 (32 operand columns)
+    const int jt0 = (wave & 1) * 3, bt = wave >> 1;
+    const int i16 = lane & 15, tq = i16 >> 2, tp = i16 & 3, tg = (lane >> 4) & 1;
+    f32x16 acc[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[j][i] = 0.f;
+    float cs[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) cs[i] = 0.f;
+
+    auto stage = [&](const DwRaw& w, uint16_t* sA, uint16_t* sB) {
+        float av[12], bv[8];
+        const float4* a4 = w.a;
+#pragma unroll
+        for (int g = 0; g < 3; ++g) {
+            av[4 * g] = a4[g].x; av[4 * g + 1] = a4[g].y; av[4 * g + 2] = a4[g].z; av[4 * g + 3] = a4[g].w;
+        }
+        bv[0] = w.b0[0].x; bv[1] = w.b0[0].y; bv[2] = w.b0[0].z; bv[3] = w.b0[0].w;
+        bv[4] = w.b0[1].x; bv[5] = w.b0[1].y; bv[6] = w.b0[1].z; bv[7] = w.b0[1].w;
+        if (q.xb) {
+            bv[0] -= w.b1[0].x; bv[1] -= w.b1[0].y; bv[2] -= w.b1[0].z; bv[3] -= w.b1[0].w;
+            bv[4] -= w.b1[1].x; bv[5] -= w.b1[1].y; bv[6] -= w.b1[1].z; bv[7] -= w.b1[1].w;
+        }
+#pragma unroll
+        for (int i = 0; i < 12; ++i) { av[i] = w.valid ? av[i] : 0.f; cs[i] += av[i]; }
+#pragma unroll
+        for (int g = 0; g < 3; ++g) {                    // four columns = 8 bytes per piece
+            uint2 p1, p2, p3;
+            w_split2(av[4 * g], av[4 * g + 1], p1.x, p2.x, p3.x);
+            w_split2(av[4 * g + 2], av[4 * g + 3], p1.y, p2.y, p3.y);
+            const int off = w_swz<256>(srow, c16 * 12 + 4 * g);
+            *reinterpret_cast<uint2*>(sA + off) = p1;
+            *reinterpret_cast<uint2*>(sA + 32 * 256 + off) = p2;
+            *reinterpret_cast<uint2*>(sA + 2 * 32 * 256 + off) = p3;
+        }
+        {
+            uint4 p1, p2, p3;
+            w_split2(bv[0], bv[1], p1.x, p2.x, p3.x); w_split2(bv[2], bv[3], p1.y, p2.y, p3.y);
+            w_split2(bv[4], bv[5], p1.z, p2.z, p3.z); w_split2(bv[6], bv[7], p1.w, p2.w, p3.w);
+            const int off = w_swz<128>(srow, c16 * 8);
+            *reinterpret_cast<uint4*>(sB + off) = p1;
+            *reinterpret_cast<uint4*>(sB + 32 * 128 + off) = p2;
+            *reinterpret_cast<uint4*>(sB + 2 * 32 * 128 + off) = p3;
+        }
+    };
+
+    DwRaw raw;
+    const int nchunk = r_end > r_lo ? (r_end - r_lo + 31) / 32 : 0;
+    if (nchunk > 0) {
+        dw_issue(q, r_lo + srow, r_end, ca, cb, raw);
+        stage(raw, base, base + DW_A);
+        if (nchunk > 1) dw_issue(q, r_lo + 32 + srow, r_end, ca, cb, raw);
+    }
+    __syncthreads();
+    for (int ch = 0; ch < nchunk; ++ch) {
+        uint16_t* sA = base + (ch & 1) * (DW_A + DW_B);
+        uint16_t* sB = sA + DW_A;
+        uint16_t* nA = base + ((ch & 1) ^ 1) * (DW_A + DW_B);
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            const int row0 = kb * 16 + 8 * half + tq;
+            uint4 b1, b2, b3;
+            {
+                const int col = bt * 32 + 16 * tg + 4 * tp;
+                const uint16_t* p0 = sB + w_swz<128>(row0, col);
+                const uint16_t* p1 = sB + w_swz<128>(row0 + 4, col);
+                const uint2 u0 = w_read_tr(p0), u1 = w_read_tr(p1);
+                const uint2 v0 = w_read_tr(p0 + 32 * 128), v1 = w_read_tr(p1 + 32 * 128);
+                const uint2 w0 = w_read_tr(p0 + 2 * 32 * 128), w1 = w_read_tr(p1 + 2 * 32 * 128);
+                b1 = make_uint4(u0.x, u0.y, u1.x, u1.y); b2 = make_uint4(v0.x, v0.y, v1.x, v1.y);
+                b3 = make_uint4(w0.x, w0.y, w1.x, w1.y);
+            }
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const int col = (jt0 + j) * 32 + 16 * tg + 4 * tp;
+                const uint16_t* p0 = sA + w_swz<256>(row0, col);
+                const uint16_t* p1 = sA + w_swz<256>(row0 + 4, col);
+                const uint2 u0 = w_read_tr(p0), u1 = w_read_tr(p1);
+                const uint2 v0 = w_read_tr(p0 + 32 * 256), v1 = w_read_tr(p1 + 32 * 256);
+                const uint2 w0 = w_read_tr(p0 + 2 * 32 * 256), w1 = w_read_tr(p1 + 2 * 32 * 256);
+                const uint4 a1 = make_uint4(u0.x, u0.y, u1.x, u1.y), a2 = make_uint4(v0.x, v0.y, v1.x, v1.y);
+                const uint4 a3 = make_uint4(w0.x, w0.y, w1.x, w1.y);
+                acc[j] = w_mfma(a3, b1, acc[j]);
+                acc[j] = w_mfma(a1, b3, acc[j]);
+                acc[j] = w_mfma(a2, b2, acc[j]);
+                acc[j] = w_mfma(a2, b1, acc[j]);
+                acc[j] = w_mfma(a1, b2, acc[j]);
+                acc[j] = w_mfma(a1, b1, acc[j]);
+            }
+        }
+        if (ch + 1 < nchunk) {
+            stage(raw, nA, nA + DW_A);
+            if (ch + 2 < nchunk) dw_issue(q, r_lo + (ch + 2) * 32 + srow, r_end, ca, cb, raw);
+        }
+        __syncthreads();
+    }
+    // ---- the block's 192 x 128 tile of this slab
+    float* sw = q.slabs + (size_t)slab * 3 * H * H;
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const int jj = mt * 192 + (jt0 + j) * 32 + w_acc_row(reg, half);
+            sw[(size_t)jj * H + nt * 128 + bt * 32 + c] = acc[j][reg];
+        }
+    if (nt == 0) {                                           // bias gradient: column sums of dg over the slab's rows
+        float* red = lds;                                    // [32][192] floats (the images are dead)
+#pragma unroll
+        for (int i = 0; i < 12; ++i) red[srow * 192 + c16 * 12 + i] = cs[i];
+        __syncthreads();
+        if (tid < 192) {
+            float sum = 0.f;
+#pragma unroll 8
+            for (int rr = 0; rr < 32; ++rr) sum += red[rr * 192 + tid];
+            q.bslabs[(size_t)slab * 3 * H + mt * 192 + tid] = sum;
+        }
+    }
+}
+
 static int launch_store(const WideArgs& a, hipStream_t st) {
     dim3 grid(wide_grid(ceil_div(a.N, 128), ceil_div(a.R, W_BM)));
     TM_SHM_ONCE(k_wide_gemm_store, W_STORE_SHM);
@@ -508,6 +684,60 @@ int tmpnn_wide_gru_bwd_data(const void* prep, const int32_t* rows, int R, const 
     WideArgs y = x;
     y.A = dgh; y.img = b_hh; y.C = d_h; y.ldc = ld_dh; y.accumulate = 1;
     return launch_store(y, st);
+}
+
+static int dw_slabs(int R, int H) {
+    const int tiles = (3 * H / 192) * (H / 128);
+    int s = 256 / tiles;
+    const int by_rows = (R + 2047) / 2048;                 // at least 2048 rows per slab
+    if (s > by_rows) s = by_rows;
+    return s < 1 ? 1 : s;
+}
+
+size_t tmpnn_wide_gru_bwd_weights_ws(int R, int H) {
+    if (R <= 0) return 0;
+    const int n = dw_slabs(R, H);
+    const size_t per = (size_t)3 * H * H + (size_t)3 * H;
+    return sizeof(float) * ((size_t)n * per + reduce_slabs_ws_floats(n, (size_t)3 * H * H));
+}
+
+/* Weight gradient of the cell from the gate gradients tmpnn_wide_gru_bwd_data left in ITS workspace (`dg_ws`: d_gi then
+ * d_gh, [R][3H] each): dW_ih += d_gi^T (h[src] - h[dst]), dW_hh += d_gh^T h[rows], db_* += column sums.  */
+int tmpnn_wide_gru_bwd_weights(const void* dg_ws, const int32_t* rows, int R, const int32_t* src, const int32_t* dst,
+                               const float* h, int ld_h, int H, float* dW_ih, float* dW_hh, float* db_ih, float* db_hh,
+                               void* ws, size_t ws_bytes, tmpnn_stream stream) {
+    TM_REQUIRE(tmpnn_wide_supported(H, H), "wide_gru_bwd_weights: H=%d", H);
+    if (R == 0) return TMPNN_OK;
+    TM_REQUIRE(dg_ws && rows && src && dst && h && dW_ih && dW_hh && db_ih && db_hh && ws && R > 0,
+               "wide_gru_bwd_weights: null pointer");
+    TM_REQUIRE(aligned16(dg_ws) && aligned16(h) && (ld_h & 3) == 0 && ld_h >= H && aligned16(ws),
+               "wide_gru_bwd_weights: 16-byte alignment");
+    if (ws_bytes < tmpnn_wide_gru_bwd_weights_ws(R, H))
+        return set_error(TMPNN_EWORKSPACE, "wide_gru_bwd_weights: workspace %zu < %zu bytes", ws_bytes,
+                         tmpnn_wide_gru_bwd_weights_ws(R, H));
+    hipStream_t st = as_stream(stream);
+    const int n = dw_slabs(R, H);
+    const int mt = 3 * H / 192, nt = H / 128;
+    const int rps = ((R + n - 1) / n + 31) / 32 * 32;
+    const float* dgi = reinterpret_cast<const float*>(dg_ws);
+    const float* dgh = dgi + (size_t)R * 3 * H;
+    float* slabs = reinterpret_cast<float*>(ws);
+    float* bslabs = slabs + (size_t)n * 3 * H * H;
+    float* fold = bslabs + (size_t)n * 3 * H;
+    const int nslab = (R + rps - 1) / rps;
+    TM_SHM_ONCE(k_wide_dw, DW_SHM);
+    for (int which = 0; which < 2; ++which) {
+        WideDwArgs q{which == 0 ? dgi : dgh, 3 * H, h, ld_h, which == 0 ? src : rows, which == 0 ? dst : nullptr, R, H, rps,
+                     slabs, bslabs};
+        hipLaunchKernelGGL(k_wide_dw, dim3(mt * nt, nslab), dim3(512), DW_SHM, st, q, mt, nt);
+        int rc = check_launch("wide_dw");
+        if (rc) return rc;
+        if ((rc = launch_reduce_slabs(slabs, (size_t)3 * H * H, nslab, which == 0 ? dW_ih : dW_hh, (size_t)3 * H * H, 1, st, fold)))
+            return rc;
+        if ((rc = launch_reduce_slabs(bslabs, (size_t)3 * H, nslab, which == 0 ? db_ih : db_hh, (size_t)3 * H, 1, st, fold)))
+            return rc;
+    }
+    return TMPNN_OK;
 }
 
 }  // extern "C"

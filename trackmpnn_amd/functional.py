@@ -25,6 +25,7 @@ ATT_DROPOUT_P = 0.5
 # `GradBucket(model)` (trackmpnn_amd.dist) turns it on for its module (`module.inplace_param_grads = True`), the
 # environment variable TMPNN_INPLACE_GRADS=1 for every module.  Default: off -- real gradients are returned.
 INPLACE_GRADS = os.environ.get('TMPNN_INPLACE_GRADS', '0') == '1'
+WIDE_DW = os.environ.get('TMPNN_WIDE_DW', '1') == '1'        # wide cells: dW from the materialised gate gradients
 FUSED_BWD = os.environ.get('TMPNN_FUSED_BWD', '1') == '1'     # one-pass cell backward (see mp_backward)
 # H = 128 / 256 edge cells as LDS-tiled bf16x6 GEMMs (csrc/wide.hip); TMPNN_WIDE=0 keeps round 1's f32-MFMA kernels
 WIDE = os.environ.get('TMPNN_WIDE', '1') != '0' and os.environ.get('TMPNN_SPLIT', '1')[:1] != '0'
@@ -33,16 +34,16 @@ WIDE = os.environ.get('TMPNN_WIDE', '1') != '0' and os.environ.get('TMPNN_SPLIT'
 _wide_ws: Dict[torch.device, torch.Tensor] = {}
 
 
-def _wide_workspace(nbytes: int, dev) -> torch.Tensor:
+def _wide_workspace(nbytes: int, dev, slot: int = 0) -> torch.Tensor:
     """The materialised gate gradients of a wide cell's backward (24 H bytes per row: 27 GB at C5) live in ONE
     grow-only buffer per device, reused by every call (all users are ordered on the stream): handing tens of GB back
     and forth through the caching allocator cost up to 200 ms per C5 step in allocator stalls."""
-    dev = torch.device(dev)
-    ws = _wide_ws.get(dev)
+    key = (torch.device(dev), slot)           # slot 0: gate gradients; slot 1: the weight-gradient slabs that read them
+    ws = _wide_ws.get(key)
     if ws is None or ws.numel() * 4 < nbytes + 16:
-        _wide_ws.pop(dev, None)
+        _wide_ws.pop(key, None)
         ws = torch.empty((nbytes // 4 + 4,), dtype=torch.float32, device=dev)
-        _wide_ws[dev] = ws
+        _wide_ws[key] = ws
     return ws
 
 
@@ -405,11 +406,21 @@ def mp_backward(spec: ModelSpec, plan: CallPlan, saved: dict, P: Dict[str, torch
                       gp, plane, dog, GH, dyp, we, dmsg.data_ptr(), IN_e, dhg, GH,
                       g.src.data_ptr() if fuse else None, g.dst.data_ptr() if fuse else None,
                       dmsg.data_ptr() if fuse else None, IN_e, st)
-            _lib.call('tmpnn_gru_bwd_weights', g.edge_row.data_ptr(), E, xmode, g.src.data_ptr(), g.dst.data_ptr(),
-                      None, 0, 0, IN_e, hg, GH, H, gp, plane, dog, GH, dyp, we,
-                      grads[f + 'edge_gru.weight_ih'].data_ptr(), grads[f + 'edge_gru.weight_hh'].data_ptr(),
-                      grads[f + 'edge_gru.bias_ih'].data_ptr(), grads[f + 'edge_gru.bias_hh'].data_ptr(),
-                      ws_w.data_ptr(), ws_w.numel() * 4, st)
+            if saved.get('wide') and WIDE_DW:
+                # ... and the weight gradient from the gate gradients that call left in its workspace
+                ws2b = int(lib.tmpnn_wide_gru_bwd_weights_ws(E, H))
+                ws2 = _wide_workspace(ws2b, dev, slot=1)
+                _lib.call('tmpnn_wide_gru_bwd_weights', ws_wide.data_ptr(), g.edge_row.data_ptr(), E, g.src.data_ptr(),
+                          g.dst.data_ptr(), hg, GH, H,
+                          grads[f + 'edge_gru.weight_ih'].data_ptr(), grads[f + 'edge_gru.weight_hh'].data_ptr(),
+                          grads[f + 'edge_gru.bias_ih'].data_ptr(), grads[f + 'edge_gru.bias_hh'].data_ptr(),
+                          ws2.data_ptr(), ws2b, st)
+            else:
+                _lib.call('tmpnn_gru_bwd_weights', g.edge_row.data_ptr(), E, xmode, g.src.data_ptr(), g.dst.data_ptr(),
+                          None, 0, 0, IN_e, hg, GH, H, gp, plane, dog, GH, dyp, we,
+                          grads[f + 'edge_gru.weight_ih'].data_ptr(), grads[f + 'edge_gru.weight_hh'].data_ptr(),
+                          grads[f + 'edge_gru.bias_ih'].data_ptr(), grads[f + 'edge_gru.bias_hh'].data_ptr(),
+                          ws_w.data_ptr(), ws_w.numel() * 4, st)
         if K > 0:
             W, a, kp, ws_ha, score, alpha = saved['att'][gi]
             dW = torch.zeros_like(W)
