@@ -2629,7 +2629,24 @@ static int fused_blocks(int R) {
     return ntiles < 256 ? ntiles : 256;
 }
 
-int tmpnn_gru_bwd_fused_available(int H, int IN, int xmode) { return (H == 64 && IN == 64 && (xmode == 0 || xmode == 1)) ? 1 : 0; }
+// the one-pass kernel takes the whole LDS of a CU (two 80 KiB operand-image sets): only offered where a block may have it
+static bool device_gives_160k() {
+    static std::atomic<int> cache[16];               // 0 unknown, 1 yes, 2 no   (a constant of the device)
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    int v = cache[dev & 15].load(std::memory_order_relaxed);
+    if (v == 0) {
+        int bytes = 0;
+        if (hipDeviceGetAttribute(&bytes, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) != hipSuccess) bytes = 0;
+        v = bytes >= 163840 ? 1 : 2;
+        cache[dev & 15].store(v, std::memory_order_relaxed);
+    }
+    return v == 1;
+}
+
+int tmpnn_gru_bwd_fused_available(int H, int IN, int xmode) {
+    return (H == 64 && IN == 64 && (xmode == 0 || xmode == 1) && device_gives_160k()) ? 1 : 0;
+}
 
 size_t tmpnn_gru_bwd_fused_ws(int R, int IN, int H) {
     if (R <= 0) return 0;
