@@ -451,6 +451,14 @@ def main():
         from trackmpnn_amd import _lib as _l
         extra['weights_kernel'] = {1: 'bf16x6', 0: 'f32-mfma'}[_l.load().tmpnn_gru_bwd_weights_choice()]
         extra['backward'] = 'one-pass (tmpnn_gru_bwd_fused)' if one_pass else 'data + weights kernels'
+        if one_pass:
+            two = t['gru_bwd_data_edge_folded'] + t['gru_bwd_weights_edge']
+            extra['roofline_note'] = (
+                f"the one-pass backward ({t['gru_bwd_one_edge']:.2f} ms) replaces the data + weights kernels ({two:.2f} ms "
+                f"together at {nbytes['gru_bwd_data_edge_folded'] / (t['gru_bwd_data_edge_folded'] * 1e6) / HBM_PEAK_GBS:.2f} / "
+                f"{nbytes['gru_bwd_weights_edge'] / (t['gru_bwd_weights_edge'] * 1e6) / HBM_PEAK_GBS:.2f} of the HBM peak): it moves "
+                f"{nbytes['gru_bwd_one_edge'] / 1e9:.1f} GB instead of {(nbytes['gru_bwd_data_edge_folded'] + nbytes['gru_bwd_weights_edge']) / 1e9:.1f} "
+                'and is bound by instruction issue (one 512-register wave per SIMD), not by HBM -- DESIGN.md section 4')
         extra['stage_graph'] = dict(N=plans[-1].graph.N, E=plans[-1].graph.E, Dn=plans[-1].graph.Dn)
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
