@@ -395,6 +395,10 @@ def main():
     run_infer_fixture('infer_greedy_w4_r2', args.out, 501, T=10, dmean=5, cur_win=4, ret_win=2, hungarian=False, H=64)
     run_infer_fixture('infer_hungarian_w3_r1', args.out, 502, T=9, dmean=4, cur_win=3, ret_win=1, hungarian=True)
     run_init_fixture(args.out)
+    # hidden widths between the instantiated kernel widths (the reference takes any int, utils/training_options.py:22):
+    # the GPU path runs them zero-padded to 64 / 32
+    run_fixture('roll_2d_diff_k0_train_h48', args.out, '2d', 3, 48, 0, 'diff', 'train', 600)
+    run_fixture('roll_2d-temp_concat_k2_eval_h20', args.out, '2d+temp', 3, 20, 2, 'concat', 'eval', 601)
 
 
 def run_c1(out_dir):
