@@ -294,7 +294,16 @@ class TrackMPNN(nn.Module):
             else:
                 scores, logits, h_out = _SmallIter.apply(call, x, h_in, self._anchor)
         else:
-            scores, logits, h_out = _SmallIter.apply(call, x, h_in, *params)
+            fast = fast_module() if not need_grad else None
+            if fast is not None and graph.cap == graph.N:
+                # inference (nothing needs a gradient): the native node as well -- it saves nothing and records nothing
+                if self._anchor is None or self._anchor.device != x.device:
+                    self._anchor = torch.zeros(1, device=x.device, requires_grad=True)
+                sp = self._small
+                info = sp.fast_info(params, graph, sp.params(params), self.training, False, append, spare)
+                scores, logits, h_out = fast.small_iter(x, h_in, self._anchor, graph.arena, info)
+            else:
+                scores, logits, h_out = _SmallIter.apply(call, x, h_in, *params)
         h_out._tmpnn_spare_rows = spare
         return scores, logits, h_out, (None,) * self.spec.G
 
