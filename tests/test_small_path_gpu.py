@@ -267,3 +267,63 @@ def test_captured_window_replay_equals_eager_steps():
     assert losses == l_ref
     for (k, a), (_, b) in zip(model.state_dict().items(), m_ref.state_dict().items()):
         assert torch.equal(a, b), k
+
+
+def test_gradient_sink_keeps_the_autograd_contract():
+    """Default gradient mode on the native node (no GradBucket): every call returns its parameter gradients as ONE flat
+    buffer to the model's gradient sink, which hands the slices to the parameters once per backward pass.  Checked here:
+    torch.autograd.grad leaves .grad alone and equals .backward(); a tensor hook fires once per pass with the TOTAL
+    gradient; two windows accumulated without an optimizer step (the sink node runs backward twice) give twice the
+    gradient; a parameter update makes a fresh sink; a frozen parameter falls back to the Python node with equal results."""
+    from tests.test_parity_gpu import build_model
+    gold = Golden('roll_2d_diff_k0_train')
+    model = build_model(gold.meta, gold.params())
+    assert model.inplace_param_grads is False
+    calls = [(gold.t(f'c{c}/x').to(DEV), gold.adjacency(c, 'node_adj', DEV), gold.adjacency(c, 'edge_adj', DEV))
+             for c in range(gold.ncalls)]
+
+    def window_loss(m=model):
+        h, loss = None, 0.0
+        for x, na, ea in calls:
+            s, l, h, _ = m(x, h, na, ea)
+            loss = loss + (l * l).sum() + s.sum()
+        return loss + h.sum()
+
+    params = list(model.parameters())
+    for p in params:
+        p.grad = torch.full_like(p, 3.0)
+    grads = torch.autograd.grad(window_loss(), params)
+    assert model._sink is not None                                   # the native sink path was taken
+    assert all(bool((p.grad == 3.0).all()) for p in params)
+    gscale = max(float(g.abs().max()) for g in grads)
+    fired = []
+    hook = params[4].register_hook(lambda g: fired.append(g.clone()))
+    for p in params:
+        p.grad = None
+    sink0 = model._sink
+    window_loss().backward()
+    assert len(fired) == 1 and float((fired[0] - grads[4]).abs().max()) <= 1e-6 * gscale
+    for p, g in zip(params, grads):
+        assert float((p.grad - g).abs().max()) <= 1e-6 * gscale
+    window_loss().backward()                                         # accumulate a second window, no step in between
+    assert model._sink is sink0 and len(fired) == 2
+    for p, g in zip(params, grads):
+        assert float((p.grad - 2 * g).abs().max()) <= 2e-6 * gscale
+    hook.remove()
+    with torch.no_grad():
+        params[0].mul_(1.0)                                          # an in-place update moves the version counter
+    for p in params:
+        p.grad = None
+    window_loss().backward()
+    assert model._sink is not sink0
+    for p, g in zip(params, grads):
+        assert float((p.grad - g).abs().max()) <= 1e-6 * gscale
+    # a frozen parameter: Python node (gradients per parameter), same numbers for the others
+    frozen = build_model(gold.meta, gold.params())
+    fp = list(frozen.parameters())
+    fp[2].requires_grad_(False)
+    window_loss(frozen).backward()
+    assert frozen._sink is None and fp[2].grad is None
+    for i, (p, g) in enumerate(zip(fp, grads)):
+        if i != 2:
+            assert float((p.grad - g).abs().max()) <= 1e-5 * gscale, i

@@ -78,3 +78,22 @@ for name, fn in (('7 conversions', conv), ('7 forward_dgraph, no grad', fwd_only
                  ('forward_dgraph + loss + backward', fwd_loss_bwd), ('model(x, h, node_adj, edge_adj) + loss + backward', full)):
     enq, tot = timed(fn)
     print(f'{name:55s} host enqueue {enq:.3f} ms   wall {tot:.3f} ms', flush=True)
+
+# the same window WITHOUT GradBucket (a reference loop that only swaps the import: optimizer.zero_grad() + loss.backward(),
+# gradients returned to autograd -- the Python autograd node)
+model2 = build_model(gold.meta, gold.params())
+opt2 = torch.optim.Adam(model2.parameters(), lr=1e-5)
+
+
+def plain():
+    h, outs = None, []
+    for x, na, ea in calls:
+        s, l, h, _ = model2(x, h, na, ea)
+        outs.append(l)
+    loss = torch.cat(outs).sum()
+    opt2.zero_grad()
+    loss.backward()
+
+
+enq, tot = timed(plain)
+print(f"{'plain loop (no GradBucket): fwd + loss + backward':55s} host enqueue {enq:.3f} ms   wall {tot:.3f} ms", flush=True)

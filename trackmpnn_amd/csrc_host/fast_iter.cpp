@@ -4,9 +4,12 @@
 // forward + backward pair (~100 us: Function.apply, a dozen tensor allocations, two ctypes calls) exceeds the GPU time
 // of the four launches it enqueues.  This node does the identical sequence -- allocate, call the C ABI
 // (tmpnn_mp_iter_fwd / tmpnn_mp_iter_bwd through function pointers handed over from Python), keep what the backward
-// needs -- without the interpreter.  Only the in-place-gradient mode is handled here (GradBucket: parameter
-// gradients go straight into p.grad, one dummy `anchor` tensor tells autograd the outputs need a backward); every
-// other case stays on the Python node.  torch is plumbing: memory, autograd edges, nothing else.
+// needs -- without the interpreter.  Two gradient modes: IN PLACE (GradBucket: parameter gradients go straight into
+// p.grad, the third input is a dummy `anchor` that only tells autograd the outputs need a backward) and SINK (default
+// autograd semantics: the third input is the model's gradient sink, a tensor whose VALUES nobody reads and whose
+// gradient is all parameter gradients of this call in one flat buffer; trackmpnn_amd/small.py:_ParamSink hands the
+// slices to the parameters, so autograd accumulates one tensor per call instead of one per parameter per call).
+// torch is plumbing: memory, autograd edges, nothing else.
 #include <torch/extension.h>
 
 #include <cstdint>
@@ -37,6 +40,23 @@ struct CallInfo {
 inline size_t save_floats(int64_t N, int64_t n, int64_t G, int64_t H) {
     return (size_t)(G * 4 * N * H + G * N * H + G * (n > 0 ? n : 1) * H + 2 * G * H + G * (n + 1) + 4);
 }
+// gradient struct of the SINK mode: `tmpl` holds 1 + byte offset into the flat buffer where a pointer goes (0 = NULL)
+inline void rebase(float*& p, char* base) {
+    const uintptr_t v = reinterpret_cast<uintptr_t>(p);
+    p = v ? reinterpret_cast<float*>(base + (v - 1)) : nullptr;
+}
+inline tmpnn_mp_params rebased(const tmpnn_mp_params* tmpl, void* flat) {
+    tmpnn_mp_params s = *tmpl;
+    char* b = static_cast<char*>(flat);
+    for (int g = 0; g < 3; ++g) {
+        rebase(s.w1[g], b); rebase(s.b1[g], b); rebase(s.gamma[g], b); rebase(s.beta[g], b); rebase(s.w2[g], b); rebase(s.b2[g], b);
+        s.run_mean[g] = nullptr; s.run_var[g] = nullptr; s.num_batches_tracked[g] = nullptr;
+        rebase(s.e_wih[g], b); rebase(s.e_whh[g], b); rebase(s.e_bih[g], b); rebase(s.e_bhh[g], b);
+        rebase(s.n_wih[g], b); rebase(s.n_whh[g], b); rebase(s.n_bih[g], b); rebase(s.n_bhh[g], b);
+    }
+    rebase(s.w_node, b); rebase(s.b_node, b); rebase(s.w_edge, b); rebase(s.b_edge, b);
+    return s;
+}
 inline size_t bwd_ws_bytes(int64_t N, int64_t n, int64_t G, int64_t H, int64_t IN_e) {
     int64_t nb = (N + 15) / 16 + 2;
     if (nb > 96) nb = 96;
@@ -52,7 +72,7 @@ class SmallIterFn : public torch::autograd::Function<SmallIterFn> {
                                                   torch::Tensor arena, std::vector<int64_t> info) {
         (void)anchor;
         CallInfo ci;
-        TORCH_CHECK(info.size() == 17, "fast_iter: bad call descriptor");
+        TORCH_CHECK(info.size() == 18, "fast_iter: bad call descriptor");
         ci.f_fwd = info[0]; ci.f_bwd = info[1]; ci.f_err = info[2]; ci.params = info[3]; ci.grads = info[4];
         ci.prep = info[5]; ci.f_bind = info[6]; ci.N = info[7]; ci.G = info[8]; ci.H = info[9]; ci.IN_e = info[10];
         ci.F_total = info[11]; ci.stream = info[12]; ci.spare = info[13];
@@ -159,18 +179,28 @@ class SmallIterFn : public torch::autograd::Function<SmallIterFn> {
         if (need_x) d_x = at::empty({n, F_total}, opts);
         const size_t wsb = bwd_ws_bytes(N, n, G, H, IN_e);
         torch::Tensor ws = at::empty({(int64_t)(wsb / 4 + 4)}, opts);
+        // SINK mode: this call's parameter gradients land in one fresh flat buffer, returned as the sink's gradient
+        const int64_t sink_total = info[17];
+        torch::Tensor gflat;
+        tmpnn_mp_params gs;
+        const tmpnn_mp_params* grads = reinterpret_cast<const tmpnn_mp_params*>(info[4]);
+        if (sink_total > 0) {
+            gflat = at::zeros({sink_total}, opts);
+            gs = rebased(grads, gflat.data_ptr());
+            grads = &gs;
+        }
         const int rc = reinterpret_cast<bwd_fn>(info[1])(
             reinterpret_cast<const tmpnn_mp_params*>(info[3]), reinterpret_cast<const float*>(info[5]),
             &dg, (int)n, n > 0 ? xd.data_ptr<float>() : nullptr,
             n > 0 ? (int)xd.size(1) : 0, h_cat.data_ptr<float>(), nullptr, scores.data_ptr<float>(),
             save.data_ptr<float>(), info[14] != 0 ? 1 : 0, ds, st_ds, dl, st_dl, dh, d_h.data_ptr<float>(),
-            need_x ? d_x.data_ptr<float>() : nullptr, reinterpret_cast<const tmpnn_mp_params*>(info[4]), ws.data_ptr<float>(),
+            need_x ? d_x.data_ptr<float>() : nullptr, grads, ws.data_ptr<float>(),
             wsb, reinterpret_cast<tmpnn_stream>(info[12]));
         TORCH_CHECK(rc == 0, "tmpnn_mp_iter_bwd failed (code ", rc, "): ", reinterpret_cast<err_fn>(info[2])());
         if (x_needs && !need_x) d_x = at::zeros({n, F_total}, opts);
         torch::Tensor d_h_in;
         if (has_h && N - n > 0) d_h_in = d_h.narrow(0, 0, N - n);
-        return {d_x, d_h_in, torch::Tensor(), torch::Tensor(), torch::Tensor()};
+        return {d_x, d_h_in, gflat, torch::Tensor(), torch::Tensor()};
     }
 };
 
@@ -182,5 +212,5 @@ std::vector<torch::Tensor> small_iter(torch::Tensor x, c10::optional<torch::Tens
 }  // namespace
 
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
-    m.def("small_iter", &small_iter, "fused TrackMPNN iteration on one small graph (in-place gradient mode)");
+    m.def("small_iter", &small_iter, "fused TrackMPNN iteration on one small graph (in-place or sink gradient mode)");
 }

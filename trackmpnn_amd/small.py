@@ -67,6 +67,7 @@ class SmallPath:
         self.cparams = None
         self.prep = None
         self._grad_struct_cache = {}
+        self._tmpl = None
         self.f_fwd = self.f_bwd = None
         self._fast_addrs = None
         # layout of the flat gradient buffer (256-byte aligned slices), in param_names() order
@@ -130,8 +131,10 @@ class SmallPath:
             self._ver_key = None if capturing else vkey
         return self.cparams
 
-    def fast_info(self, plist, graph, n_grad_struct, training: bool, need_grad: bool, append: bool, spare: int):
-        """The 17-integer call descriptor of the C++ node (function addresses, struct addresses, sizes, flags)."""
+    def fast_info(self, plist, graph, n_grad_struct, training: bool, need_grad: bool, append: bool, spare: int,
+                  sink_total: int = 0):
+        """The 18-integer call descriptor of the C++ node (function addresses, struct addresses, sizes, flags;
+        sink_total > 0: n_grad_struct is the offset template of the gradient sink, see grad_template)."""
         cp = self.params(plist)
         if self._fast_addrs is None:
             lib = _lib.load()
@@ -141,7 +144,24 @@ class SmallPath:
         a = self._fast_addrs
         spec = self.spec
         return [a[0], a[1], a[2], C.addressof(cp), C.addressof(n_grad_struct), self.prep.data_ptr(), a[3], graph.N,
-                spec.G, spec.H, spec.IN_e, spec.F_total, _stream(), spare, int(training), int(need_grad), int(append)]
+                spec.G, spec.H, spec.IN_e, spec.F_total, _stream(), spare, int(training), int(need_grad), int(append),
+                int(sink_total)]
+
+    def grad_template(self, plist):
+        """(offset template, total floats, offsets, shapes) of the gradient SINK: a tmpnn_mp_params whose pointer fields
+        hold 1 + the byte offset of that parameter's gradient inside one flat buffer (param_names() order, every slice
+        16-byte aligned); the C++ node rebases it onto the buffer it allocates in its backward."""
+        if self._tmpl is None:
+            offs, shapes, o = [], [], 0
+            for p in plist:
+                offs.append(o)
+                shapes.append(tuple(p.shape))
+                o += (p.numel() + 3) & ~3
+            st = _lib.CMpParams()
+            enc = dict(zip(self.names, (1 + 4 * v for v in offs)))
+            self._fill(st, enc.__getitem__)
+            self._tmpl = (st, o, offs, shapes)
+        return self._tmpl
 
     def invalidate(self) -> None:
         """Parameter / buffer storage may have moved (Module._apply, load_state_dict(assign=True)): re-read pointers."""
@@ -160,6 +180,29 @@ class SmallPath:
             self._fill(st, dict(zip(self.names, key)).__getitem__)
             self._grad_struct_cache[key] = st
         return st
+
+
+class _ParamSink(torch.autograd.Function):
+    """The model's gradient sink: a tensor nobody reads (uninitialised, no kernel) that the native call nodes take as an
+    input.  Each node's backward returns ALL parameter gradients of its call as one flat buffer; autograd sums those per
+    call, and this node hands the slices to the parameters ONCE per backward pass -- hooks, torch.autograd.grad and DDP
+    see ordinary gradients, at 6 + 22 small launches per window instead of 154 (7 calls x 22 parameters)."""
+
+    @staticmethod
+    def forward(ctx, total, offs, shapes, *params):
+        ctx.meta = (offs, shapes)
+        return params[0].new_empty((total,))
+
+    @staticmethod
+    def backward(ctx, g):
+        offs, shapes = ctx.meta
+        out = []
+        for o, shp in zip(offs, shapes):
+            n = 1
+            for d in shp:
+                n *= d
+            out.append(g[o:o + n].view(shp))
+        return (None, None, None) + tuple(out)
 
 
 class _SmallIter(torch.autograd.Function):

@@ -21,7 +21,7 @@ from .functional import MPIteration, ModelSpec
 from .graph import (CallPlan, DeviceGraph, FrameGraph, device_graph_from_adjacency, graph_from_adjacency,
                     plan_single)
 from .layers import FactorGraphGRU
-from .small import SmallPath, _SmallIter, fast_module, small_eligible
+from .small import SmallPath, _ParamSink, _SmallIter, fast_module, small_eligible
 
 KERNEL_WIDTHS = (32, 64, 128, 256)          # hidden widths the HIP kernels are instantiated for
 
@@ -105,6 +105,8 @@ class TrackMPNN(nn.Module):
         self._plist = None
         self._bufs = None
         self._anchor = None
+        self._sink = None                      # gradient sink of the native node (default gradient mode)
+        self._sink_key = None
         self._anch_key = None
         self._anch_calls = 0
         self._gst = None
@@ -115,6 +117,7 @@ class TrackMPNN(nn.Module):
         out = super()._apply(fn, *args, **kwargs)
         self._small.invalidate()
         self._plist = self._bufs = self._anchor = None
+        self._sink = self._sink_key = None
         self._anch_key = None
         self._graph_cache = None
         return out
@@ -123,6 +126,7 @@ class TrackMPNN(nn.Module):
         out = super().load_state_dict(*args, **kwargs)
         self._small.invalidate()
         self._plist = self._bufs = None
+        self._sink = self._sink_key = None
         return out
 
     def get_input_transform(self, n_in, n_out):
@@ -293,6 +297,17 @@ class TrackMPNN(nn.Module):
                 scores, logits, h_out = fast.small_iter(x, h_in, self._anchor, graph.arena, info)
             else:
                 scores, logits, h_out = _SmallIter.apply(call, x, h_in, self._anchor)
+        elif pgrad and fast_module() is not None and graph.cap == graph.N and all(p.requires_grad for p in params):
+            # default gradient semantics on the native node: one gradient SINK per set of parameter values (a fresh one
+            # whenever a parameter's version counter moved, i.e. after every optimizer step)
+            sp = self._small
+            tmpl, total, offs, shapes = sp.grad_template(params)
+            key = tuple(p._version for p in params)
+            if self._sink is None or self._sink_key != key or self._sink.device != x.device:
+                self._sink = _ParamSink.apply(total, offs, shapes, *params)
+                self._sink_key = key
+            info = sp.fast_info(params, graph, tmpl, self.training, need_grad, append, spare, sink_total=total)
+            scores, logits, h_out = fast_module().small_iter(x, h_in, self._sink, graph.arena, info)
         else:
             fast = fast_module() if not need_grad else None
             if fast is not None and graph.cap == graph.N:
