@@ -93,7 +93,7 @@ class ModelSpec:
 
 
 def _stream() -> int:
-    return torch.cuda.current_stream().cuda_stream
+    return _lib.raw_stream()
 
 
 def _require_device(t: torch.Tensor, what: str):

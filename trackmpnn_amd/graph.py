@@ -599,7 +599,7 @@ def device_graph_from_adjacency(node_adj: torch.Tensor, edge_adj: Optional[torch
         eidx = eval_ = None
         ep, ev, en = None, None, 0
     rc = _from_coo()(N, nidx.data_ptr(), nval.data_ptr(), int(nval.numel()), ep, ev, en, g.arena.data_ptr(), g.cap,
-                     torch.cuda.current_stream(device).cuda_stream)
+                     _lib.raw_stream(device))
     if rc:
         raise RuntimeError(f'tmpnn_graph_from_coo_arena failed (code {rc}): {_lib.last_error()}')
     g._keep = (nidx, nval, eidx, eval_)       # until the launch has consumed them (freed with the graph)

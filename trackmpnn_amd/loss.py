@@ -41,7 +41,7 @@ def _as_graph(adj: Union[torch.Tensor, FrameGraph, CallPlan, DeviceGraph]) -> Fr
 
 
 def _stream() -> int:
-    return torch.cuda.current_stream().cuda_stream
+    return _lib.raw_stream()
 
 
 def _need_cuda(t: torch.Tensor, what: str):

@@ -23,7 +23,7 @@ _PTR_FIELDS = ('w1', 'b1', 'gamma', 'beta', 'w2', 'b2', 'run_mean', 'run_var', '
 
 
 def _stream() -> int:
-    return torch.cuda.current_stream().cuda_stream
+    return _lib.raw_stream()
 
 
 _fast_mod = False       # False: not tried yet ; None: unavailable

@@ -112,6 +112,17 @@ class TrackMPNN(nn.Module):
         self._gst = None
         self._pending_graphs = []              # DeviceGraphs whose validation status has not been read back yet
 
+    # per-call bookkeeping of the batch-1 path (plain Python values, reassigned on every forward call): kept out of
+    # nn.Module.__setattr__'s parameter / buffer / sub-module checks (~2.5 us per assignment, twice per call)
+    _PLAIN = frozenset(('_graph_cache', '_anchor', '_anch_key', '_anch_calls', '_gst', '_sink', '_sink_key', '_plist',
+                        '_bufs', '_pending_graphs'))
+
+    def __setattr__(self, name, value):
+        if name in TrackMPNN._PLAIN:
+            object.__setattr__(self, name, value)
+        else:
+            super().__setattr__(name, value)
+
     def _apply(self, fn, *args, **kwargs):
         # .cuda() / .to() / .float(): parameter storage moves -> drop every cached device pointer
         out = super()._apply(fn, *args, **kwargs)

@@ -28,7 +28,7 @@ from .graph import DG_MAX_ROWS, DeviceGraph
 
 
 def _stream() -> int:
-    return torch.cuda.current_stream().cuda_stream
+    return _lib.raw_stream()
 
 
 class TrackGraph:
