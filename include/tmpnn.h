@@ -295,10 +295,11 @@ int tmpnn_focal_loss_bwd(const int32_t* rows, int R, const float* scores, const 
  *       host never waits for E / Dn, so nothing synchronises between calls;
  *   (2) the whole message-passing iteration is two launches forward (input transform; edge + node cells with the
  *       aggregation, the merge and the output heads fused) and two backward: tmpnn_mp_iter_fwd / _bwd.
- * Limits: N <= TMPNN_DG_MAX_ROWS rows, H in {32, 64}, no attention heads (the staged entry points above cover the
+ * Limits: N <= TMPNN_DG_BIG_ROWS rows, H in {32, 64}, no attention heads (the staged entry points above cover the
  * rest).  Arithmetic: fp32 throughout (v_mfma_f32_16x16x4_f32 = an fmaf chain), reductions in a fixed order.
  * ====================================================================================================== */
 #define TMPNN_DG_MAX_ROWS 4096
+#define TMPNN_DG_BIG_ROWS 65535    /* fused iteration and tmpnn_graph_from_coo_arena_ws (work arrays in a global scratch) */
 #define TMPNN_DG_META 8      /* ints in tmpnn_dgraph.meta: [0] E, [1] Dn, [2] status, [3] N, rest reserved */
 /* status bits (0 = the adjacency is a TrackMPNN factor graph, SURVEY 8 "graph invariants") */
 #define TMPNN_DG_BAD_VALUE 1     /* an off-diagonal entry is not +-1, or an index is out of range */
@@ -344,6 +345,13 @@ int tmpnn_graph_from_coo(int N, const int64_t* node_idx, const float* node_val, 
 int tmpnn_graph_from_coo_arena(int N, const int64_t* node_idx, const float* node_val, int64_t nnz_node,
                                const int64_t* edge_idx, const float* edge_val, int64_t nnz_edge, void* arena, int cap,
                                tmpnn_stream stream);
+/* The same conversion for graphs of up to TMPNN_DG_BIG_ROWS rows (dense scenes): above TMPNN_DG_MAX_ROWS the work
+ * arrays do not fit the LDS and live in `ws` (tmpnn_graph_from_coo_ws_ints(N) ints, 0 for small N: then this is
+ * tmpnn_graph_from_coo_arena). */
+size_t tmpnn_graph_from_coo_ws_ints(int N);
+int tmpnn_graph_from_coo_arena_ws(int N, const int64_t* node_idx, const float* node_val, int64_t nnz_node,
+                                  const int64_t* edge_idx, const float* edge_val, int64_t nnz_edge, void* arena, int cap,
+                                  void* ws, size_t ws_ints, tmpnn_stream stream);
 
 /* The same index form from the ROW form of a graph (type mask + the two endpoint rows of every edge row): what the
  * tracker-side operations below edit.  Same validation, same status bits. */

@@ -327,3 +327,82 @@ def test_gradient_sink_keeps_the_autograd_contract():
     for i, (p, g) in enumerate(zip(fp, grads)):
         if i != 2:
             assert float((p.grad - g).abs().max()) <= 1e-5 * gscale, i
+
+
+def _dense_window_calls(seed, frames, mean_dets, max_dets, F):
+    """A dense synthetic chunk (BDD-like density) as the reference would hand it over: per call (x, node_adj, edge_adj)
+    with the adjacency pair as sparse COO tensors (+1 / -1 on an edge row's src / dst column, 1 on det diagonals;
+    edge_adj = the transpose off the diagonal, 1 on edge diagonals)."""
+    from trackmpnn_amd import WindowBuilder, synth_window
+    y = synth_window(seed, frames, mean_dets, max_dets)
+    gen = torch.Generator().manual_seed(seed)
+    X = torch.randn(y.shape[0], F, generator=gen)
+    is_edge = np.zeros(0, bool)
+    src = np.zeros(0, np.int64)
+    dst = np.zeros(0, np.int64)
+    calls = []
+    for call in WindowBuilder(y).calls():
+        n_old = is_edge.size
+        is_edge = np.concatenate([is_edge, call.new_is_edge])
+        src = np.concatenate([src, call.new_src])
+        dst = np.concatenate([dst, call.new_dst])
+        N = is_edge.size
+        er = torch.from_numpy(np.nonzero(is_edge)[0])
+        dr = torch.from_numpy(np.nonzero(~is_edge)[0])
+        s, d = torch.from_numpy(src), torch.from_numpy(dst)
+        ni = torch.stack([torch.cat([er, er, dr]), torch.cat([s, d, dr])])
+        nv = torch.cat([torch.ones(er.numel()), -torch.ones(er.numel()), torch.ones(dr.numel())])
+        ei = torch.stack([torch.cat([s, d, er]), torch.cat([er, er, er])])
+        ev = torch.cat([torch.ones(er.numel()), -torch.ones(er.numel()), torch.ones(er.numel())])
+        na = torch.sparse_coo_tensor(ni, nv, (N, N)).to(DEV)
+        ea = torch.sparse_coo_tensor(ei, ev, (N, N)).to(DEV)
+        x = torch.zeros(call.n_new, F)
+        x[~call.new_is_edge] = X[call.det_ids]
+        calls.append((x.to(DEV), na, ea))
+    return calls
+
+
+def test_dense_scene_above_4096_rows(monkeypatch):
+    """Windows of dense scenes (tens of dets per frame) exceed the 4096 rows whose conversion work arrays fit the LDS:
+    tmpnn_graph_from_coo_arena_ws keeps them in a global scratch (up to 65535 rows) and the fused iteration takes the
+    graph as it is.  Conversion against the torch-ops converter, then the fused path against the staged kernels."""
+    from trackmpnn_amd import TrackMPNN, device_graph_from_adjacency, graph_from_adjacency
+    calls = _dense_window_calls(seed=3, frames=8, mean_dets=32, max_dets=45, F=8)
+    sizes = [int(na.shape[0]) for _, na, _ in calls]
+    assert sizes[-1] > 4096 and sizes[-1] <= 65535, sizes
+    for _, na, ea in calls:
+        if na.shape[0] <= 4096:
+            continue
+        ref = graph_from_adjacency(na, ea)
+        dg = device_graph_from_adjacency(na, ea, DEV)
+        assert dg.status() == 0
+        g = dg.frame_graph()
+        assert (g.N, g.E, g.Dn) == (ref.N, ref.E, ref.Dn)
+        for f in ('src', 'dst', 'edge_row', 'det_row', 'rowptr', 'inc', 'is_edge', 'pos', 'src_pos', 'dst_pos'):
+            assert torch.equal(getattr(g, f).cpu(), getattr(ref, f).cpu()), f
+    # an invalid big graph is still reported: flip one sign
+    _, na, ea = calls[-1]
+    vals = na._values().clone()
+    vals[0] = -vals[0]
+    bad = torch.sparse_coo_tensor(na._indices(), vals, na.shape)
+    assert device_graph_from_adjacency(bad, None, DEV).status() != 0
+    gen = torch.Generator().manual_seed(7)
+    weights = [(torch.randn(n, 1, generator=gen).to(DEV), torch.randn(n, 1, generator=gen).to(DEV)) for n in sizes]
+    weights.append(torch.randn(sizes[-1], 64, generator=gen).to(DEV))
+    res = []
+    for small in (False, True):
+        torch.manual_seed(5)
+        model = TrackMPNN('2d', 3, 64, 0, 'diff').to(DEV).train()
+        with torch.no_grad():
+            for p in model.parameters():
+                p.add_(0.05 * torch.randn(p.shape, generator=torch.Generator().manual_seed(p.numel())).to(DEV))
+        res.append(_run_model(model, calls, small, monkeypatch, weights))
+    (o0, g0, x0), (o1, g1, x1) = res
+    for c, (a, b) in enumerate(zip(o0, o1)):
+        assert (a[0] - b[0]).abs().max().item() <= 1e-5, f'scores call {c}'
+        assert torch.allclose(a[1], b[1], atol=2e-4, rtol=2e-5), f'logits call {c}'
+        assert torch.allclose(a[2], b[2], atol=2e-4, rtol=2e-5), f'h_out call {c}'
+    gscale = max(1.0, max(v.abs().max().item() for v in g0.values()))
+    for k in g0:
+        tol = 1e-4 * gscale * (10 if (k.endswith('.0.bias') and k.startswith('input_')) else 1)
+        assert (g0[k] - g1[k]).abs().max().item() <= tol, f'grad {k}: {(g0[k] - g1[k]).abs().max().item()} > {tol}'

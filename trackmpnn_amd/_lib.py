@@ -128,6 +128,9 @@ _SIGNATURES = {
     'tmpnn_dgraph_bind': (c_int, [c_void_p, c_int, c_int, _DGP]),
     'tmpnn_graph_from_coo': (c_int, [c_int, c_void_p, c_void_p, C.c_int64, c_void_p, c_void_p, C.c_int64, _DGP, c_void_p]),
     'tmpnn_graph_from_coo_arena': (c_int, [c_int, c_void_p, c_void_p, C.c_int64, c_void_p, c_void_p, C.c_int64, c_void_p, c_int, c_void_p]),
+    'tmpnn_graph_from_coo_ws_ints': (c_size_t, [c_int]),
+    'tmpnn_graph_from_coo_arena_ws': (c_int, [c_int, c_void_p, c_void_p, C.c_int64, c_void_p, c_void_p, C.c_int64, c_void_p, c_int,
+                                              c_void_p, c_size_t, c_void_p]),
     'tmpnn_graph_from_rows': (c_int, [c_int, c_void_p, c_void_p, c_void_p, _DGP, c_void_p]),
     'tmpnn_track_associate': (c_int, [_DGP, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     'tmpnn_track_active': (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),

@@ -32,7 +32,7 @@ class CapturedWindow:
         nmax = max(int(na.shape[0]) for _, na, _ in calls)
         if getattr(model, '_padded', False) or not small_eligible(model, nmax):
             raise RuntimeError('CapturedWindow records the fused batch-1 path only: no attention heads, nhidden 32 or 64 '
-                               f'(this model: nhidden={model.nhidden}, heads={model.spec.K}), at most 4096 rows per call '
+                               f'(this model: nhidden={model.nhidden}, heads={model.spec.K}), at most 65535 rows per call '
                                f'(this window: {nmax}); other models run eagerly')
         self.static_x: List[torch.Tensor] = [x.detach().clone() for x, _, _ in calls]
         self.graphs: List[DeviceGraph] = [device_graph_from_adjacency(na, ea, dev) for _, na, ea in calls]

@@ -44,7 +44,9 @@ __device__ __forceinline__ int block_excl_scan(int v, int* s_wave /* [17] */, in
 
 // FROM_ROWS: the input is the row form (type mask + per-row endpoints) instead of the COO entries: the tracker-side
 // operations (csrc/trackops.hip: append / delete) edit the graph row-wise and re-derive the index form with this.
-template <bool FROM_ROWS>
+// BIG: the work arrays (8 N + 1 ints) live in a caller-provided global scratch instead of the LDS (N > TMPNN_DG_MAX_ROWS:
+// dense scenes, up to TMPNN_DG_BIG_ROWS rows); same code, global atomics, still one workgroup.
+template <bool FROM_ROWS, bool BIG = false>
 __global__ __launch_bounds__(GC_THREADS) void k_graph_from_coo(int N, const int64_t* __restrict__ nidx,
                                                                const float* __restrict__ nval, long nnz_n,
                                                                const int64_t* __restrict__ eidx,
@@ -52,8 +54,9 @@ __global__ __launch_bounds__(GC_THREADS) void k_graph_from_coo(int N, const int6
                                                                const uint8_t* __restrict__ r_is_edge,
                                                                const int32_t* __restrict__ r_src,
                                                                const int32_t* __restrict__ r_dst,
-                                                               tmpnn_dgraph g) {
-    extern __shared__ int lds[];
+                                                               tmpnn_dgraph g, int* __restrict__ scratch) {
+    extern __shared__ int lds_dyn[];
+    int* const lds = BIG ? scratch : lds_dyn;
     float* s_diag = reinterpret_cast<float*>(lds);   // [N]  sum of the diagonal entries of node_adj
     int* s_src = lds + N;                            // [N]  by ROW: column of the +1 entry
     int* s_dst = s_src + N;                          // [N]  by ROW: column of the -1 entry
@@ -254,8 +257,29 @@ int tmpnn_graph_from_coo(int N, const int64_t* node_idx, const float* node_val, 
     TM_SHM_ONCE(k_graph_from_coo<false>, 160 * 1024 - 256);
     hipLaunchKernelGGL(k_graph_from_coo<false>, dim3(1), dim3(GC_THREADS), shm, as_stream(stream), N, node_idx, node_val,
                        (long)nnz_node, edge_idx, edge_val, (long)nnz_edge, (const uint8_t*)nullptr, (const int32_t*)nullptr,
-                       (const int32_t*)nullptr, *g);
+                       (const int32_t*)nullptr, *g, (int*)nullptr);
     return check_launch("graph_from_coo");
+}
+
+size_t tmpnn_graph_from_coo_ws_ints(int N) { return N > TMPNN_DG_MAX_ROWS ? (size_t)8 * N + 1 : 0; }
+
+int tmpnn_graph_from_coo_arena_ws(int N, const int64_t* node_idx, const float* node_val, int64_t nnz_node,
+                                  const int64_t* edge_idx, const float* edge_val, int64_t nnz_edge, void* arena, int cap,
+                                  void* ws, size_t ws_ints, tmpnn_stream stream) {
+    if (N <= TMPNN_DG_MAX_ROWS)
+        return tmpnn_graph_from_coo_arena(N, node_idx, node_val, nnz_node, edge_idx, edge_val, nnz_edge, arena, cap, stream);
+    TM_REQUIRE(N <= TMPNN_DG_BIG_ROWS, "graph_from_coo: N=%d exceeds %d rows", N, TMPNN_DG_BIG_ROWS);
+    tmpnn_dgraph g;
+    const int rc = tmpnn_dgraph_bind(arena, cap, N, &g);
+    if (rc) return rc;
+    TM_REQUIRE(nnz_node >= 0 && (nnz_node == 0 || (node_idx && node_val)), "graph_from_coo: node_adj entries");
+    TM_REQUIRE(nnz_edge >= 0 && (edge_idx == nullptr || nnz_edge == 0 || edge_val), "graph_from_coo: edge_adj entries");
+    if (ws == nullptr || ws_ints < tmpnn_graph_from_coo_ws_ints(N))
+        return set_error(TMPNN_EWORKSPACE, "graph_from_coo: workspace %zu < %zu ints", ws_ints, tmpnn_graph_from_coo_ws_ints(N));
+    hipLaunchKernelGGL((k_graph_from_coo<false, true>), dim3(1), dim3(GC_THREADS), 0, as_stream(stream), N, node_idx, node_val,
+                       (long)nnz_node, edge_idx, edge_val, (long)nnz_edge, (const uint8_t*)nullptr, (const int32_t*)nullptr,
+                       (const int32_t*)nullptr, g, reinterpret_cast<int*>(ws));
+    return check_launch("graph_from_coo (global scratch)");
 }
 
 int tmpnn_graph_from_coo_arena(int N, const int64_t* node_idx, const float* node_val, int64_t nnz_node,
@@ -278,7 +302,7 @@ int tmpnn_graph_from_rows(int N, const uint8_t* is_edge, const int32_t* row_src,
     TM_SHM_ONCE(k_graph_from_coo<true>, 160 * 1024 - 256);
     hipLaunchKernelGGL(k_graph_from_coo<true>, dim3(1), dim3(GC_THREADS), shm, as_stream(stream), N,
                        (const int64_t*)nullptr, (const float*)nullptr, 0L, (const int64_t*)nullptr, (const float*)nullptr, 0L,
-                       is_edge, row_src, row_dst, *g);
+                       is_edge, row_src, row_dst, *g, (int*)nullptr);
     return check_launch("graph_from_rows");
 }
 

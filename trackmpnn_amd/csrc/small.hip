@@ -1049,8 +1049,8 @@ static int check_params(const tmpnn_mp_params* P, const char* what, bool grads) 
 static int check_dgraph(const tmpnn_dgraph* g, const char* what) {
     TM_REQUIRE(g != nullptr && g->meta && g->is_edge && g->pos && g->src && g->dst && g->edge_row && g->det_row &&
                    g->rowptr && g->inc, "%s: unbound graph", what);
-    TM_REQUIRE(g->N >= 0 && g->N <= TMPNN_DG_MAX_ROWS && g->N <= g->cap, "%s: graph N=%d cap=%d (limit %d)", what,
-               g->N, g->cap, TMPNN_DG_MAX_ROWS);
+    TM_REQUIRE(g->N >= 0 && g->N <= TMPNN_DG_BIG_ROWS && g->N <= g->cap, "%s: graph N=%d cap=%d (limit %d)", what,
+               g->N, g->cap, TMPNN_DG_BIG_ROWS);
     return TMPNN_OK;
 }
 

@@ -465,7 +465,8 @@ def batch_windows(windows: Sequence[Sequence[WindowCall]], static: bool = False,
 # ----------------------------------------------------------------------------------------------
 # batch-1 path: graphs whose sizes stay on the device (struct tmpnn_dgraph, include/tmpnn.h)
 # ----------------------------------------------------------------------------------------------
-DG_MAX_ROWS = 4096          # TMPNN_DG_MAX_ROWS
+DG_MAX_ROWS = 4096          # TMPNN_DG_MAX_ROWS: conversion work arrays in LDS, tracker-side operations
+DG_BIG_ROWS = 65535         # TMPNN_DG_BIG_ROWS: fused iteration, conversion with its work arrays in a global scratch
 _DG_STATUS = ((1, 'an off-diagonal adjacency entry is not +-1 (or an index is out of range)'),
               (2, 'node_adj is not a TrackMPNN factor graph: every edge row needs exactly one +1 and one -1 '
                   'off-diagonal entry and det rows none'),
@@ -584,11 +585,11 @@ def _from_coo():
 
 
 def device_graph_from_adjacency(node_adj: torch.Tensor, edge_adj: Optional[torch.Tensor], device) -> DeviceGraph:
-    """One-launch conversion of the reference's adjacency pair (N <= DG_MAX_ROWS) on `device`; no host round trip
+    """One-launch conversion of the reference's adjacency pair (N <= DG_BIG_ROWS) on `device`; no host round trip
     for sparse inputs (a dense input costs the `nonzero` that sparsifies it)."""
     N = int(node_adj.shape[0])
-    if N > DG_MAX_ROWS:
-        raise ValueError(f'device_graph_from_adjacency: N={N} > {DG_MAX_ROWS}; use graph_from_adjacency')
+    if N > DG_BIG_ROWS:
+        raise ValueError(f'device_graph_from_adjacency: N={N} > {DG_BIG_ROWS}; use graph_from_adjacency')
     device = torch.device(device)
     g = DeviceGraph(N, device)
     nidx, nval = _coo_parts(node_adj, device)
@@ -598,9 +599,16 @@ def device_graph_from_adjacency(node_adj: torch.Tensor, edge_adj: Optional[torch
     else:
         eidx = eval_ = None
         ep, ev, en = None, None, 0
-    rc = _from_coo()(N, nidx.data_ptr(), nval.data_ptr(), int(nval.numel()), ep, ev, en, g.arena.data_ptr(), g.cap,
-                     _lib.raw_stream(device))
+    if N <= DG_MAX_ROWS:
+        ws = None
+        rc = _from_coo()(N, nidx.data_ptr(), nval.data_ptr(), int(nval.numel()), ep, ev, en, g.arena.data_ptr(), g.cap,
+                         _lib.raw_stream(device))
+    else:                                     # dense scene: the work arrays (8 N + 1 ints) in a global scratch
+        ws = torch.empty((8 * N + 1,), dtype=torch.int32, device=device)
+        rc = _lib.fn('tmpnn_graph_from_coo_arena_ws')(N, nidx.data_ptr(), nval.data_ptr(), int(nval.numel()), ep, ev, en,
+                                                      g.arena.data_ptr(), g.cap, ws.data_ptr(), ws.numel(),
+                                                      _lib.raw_stream(device))
     if rc:
         raise RuntimeError(f'tmpnn_graph_from_coo_arena failed (code {rc}): {_lib.last_error()}')
-    g._keep = (nidx, nval, eidx, eval_)       # until the launch has consumed them (freed with the graph)
+    g._keep = (nidx, nval, eidx, eval_, ws)   # until the launch has consumed them (freed with the graph)
     return g

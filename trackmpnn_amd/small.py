@@ -4,7 +4,7 @@ The reference calls the model once per timestep on a single tracking window (tra
 that size the cost of a call is launches and host bookkeeping, not flops, so this path keeps both minimal:
 the graph is a `DeviceGraph` (sizes stay on the device, no host round trip), the iteration is two launches forward and
 two backward (csrc/small.hip), parameters travel as one cached pointer struct, and everything saved for the backward
-lives in one buffer.  Eligible calls: K = 0 attention heads, H in {32, 64}, N <= 4096 rows, one BatchNorm segment;
+lives in one buffer.  Eligible calls: K = 0 attention heads, H in {32, 64}, N <= 65535 rows, one BatchNorm segment;
 anything else takes the staged path of functional.py.  There is no fallback to torch ops or to the oracle.
 """
 from __future__ import annotations
@@ -16,7 +16,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from .graph import DG_MAX_ROWS, DeviceGraph
+from .graph import DG_BIG_ROWS, DeviceGraph
 
 _PTR_FIELDS = ('w1', 'b1', 'gamma', 'beta', 'w2', 'b2', 'run_mean', 'run_var', 'e_wih', 'e_whh', 'e_bih', 'e_bhh',
                'n_wih', 'n_whh', 'n_bih', 'n_bhh')
@@ -356,4 +356,4 @@ def bwd_ws_bytes(N: int, n: int, G: int, H: int, IN_e: int) -> int:
 
 def small_eligible(model, N: int) -> bool:
     sp = model._small
-    return sp.eligible and 0 < N <= DG_MAX_ROWS
+    return sp.eligible and 0 < N <= DG_BIG_ROWS
