@@ -15,6 +15,7 @@ import torch
 import torch.nn as nn
 
 import os
+import weakref
 
 from . import functional as _functional
 from .functional import MPIteration, ModelSpec
@@ -346,9 +347,13 @@ class TrackMPNN(nn.Module):
                                '(no CPU or torch fallback exists)')
         N = int(node_adj.shape[0])
         small = SMALL_PATH and not self._padded and small_eligible(self, N)
-        key = (id(node_adj), id(edge_adj), N, node_adj._version, edge_adj._version, x.device, small)
-        if self._graph_cache is not None and self._graph_cache[0] == key:
-            graph = self._graph_cache[1]
+        # the last call's graph is reused when the SAME adjacency objects come again unmodified (the static-window pattern:
+        # several MP iterations on one graph).  Weak references: the cache pins neither a dense N x N adjacency nor its
+        # device copy, and a recycled id() cannot alias (a dead reference never matches).
+        key = (N, node_adj._version, edge_adj._version, x.device, small)
+        c = self._graph_cache
+        if c is not None and c[0]() is node_adj and c[1]() is edge_adj and c[2] == key:
+            graph = c[3]
         else:
             if small:
                 graph = device_graph_from_adjacency(node_adj, edge_adj, x.device)
@@ -360,7 +365,7 @@ class TrackMPNN(nn.Module):
                         self.check_graphs()
             else:
                 graph = graph_from_adjacency(node_adj.to(x.device), edge_adj.to(x.device))
-            self._graph_cache = (key, graph, node_adj, edge_adj)   # keep the tensors alive: id() stays unique
+            self._graph_cache = (weakref.ref(node_adj), weakref.ref(edge_adj), key, graph)
         if DEBUG_INPUTS and x.shape[0] > 0:
             fg = graph.frame_graph() if isinstance(graph, DeviceGraph) else graph
             new_edges = fg.is_edge[N - int(x.shape[0]):] != 0
