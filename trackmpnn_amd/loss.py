@@ -13,6 +13,8 @@ from __future__ import annotations
 
 from typing import Optional, Union
 
+import weakref
+
 import torch
 import torch.nn as nn
 
@@ -31,12 +33,13 @@ def _as_graph(adj: Union[torch.Tensor, FrameGraph, CallPlan, DeviceGraph]) -> Fr
         return adj.frame_graph()
     # one-entry cache for the three calls of a timestep (create_targets, CELoss, ...) on the same adjacency object;
     # an in-place edit bumps the version counter and misses
-    key = (id(adj), getattr(adj, '_version', 0), adj.device)
+    # (a weak reference: the cache does not keep a dense N x N adjacency alive, and a recycled id() cannot alias)
+    key = (getattr(adj, '_version', 0), adj.device)
     hit = _cache.get('k')
-    if hit is not None and hit[0] == key and hit[2] is adj:
-        return hit[1]
+    if hit is not None and hit[0]() is adj and hit[1] == key:
+        return hit[2]
     g = graph_from_adjacency(adj if adj.is_cuda else adj.cuda(), None)
-    _cache['k'] = (key, g, adj)
+    _cache['k'] = (weakref.ref(adj), key, g)
     return g
 
 
