@@ -161,7 +161,7 @@ __global__ __launch_bounds__(256) void k_segsum(int Dn, const int32_t* __restric
 // consecutive items follow each other without an index round trip in between.  Same arithmetic, same summation
 // order, bit-identical results.
 // ------------------------------------------------------------------------------------------
-template <bool CONCAT, bool ACC>
+template <bool CONCAT, bool ACC, int U = 4>
 __global__ __launch_bounds__(256) void k_gather_pipe(int E, const int32_t* __restrict__ src,
                                                      const int32_t* __restrict__ dst,
                                                      const int32_t* __restrict__ edge_row,
@@ -171,7 +171,6 @@ __global__ __launch_bounds__(256) void k_gather_pipe(int E, const int32_t* __res
     const int rpb = 256 / lpr;
     const int c4 = (threadIdx.x % lpr) * 4;
     const int slot = threadIdx.x / lpr;
-    constexpr int U = 4;
     // a block owns CONSECUTIVE chunks of U * rpb edges: the dets an edge block refers to (one src per D_t consecutive
     // edges, the same D_t dst rows over and over) stay in this CU's L1 across the chunk
     const long chunk = (long)rpb * U;
@@ -425,6 +424,11 @@ static int gather(const tmpnn_graph* g, const float* in, int ld_in, float* out, 
     dim3 grid(grid_for(g->E, rpb)), block(256);
     hipStream_t st = as_stream(stream);
 #define L(K, C, A) hipLaunchKernelGGL((K<C, A>), grid, block, 0, st, g->E, g->src, g->dst, g->edge_row, in, ld_in, out, ld_out, H)
+    if (agg_variant() && !concat) {                 // eight edge rows in flight per thread (16 row loads): +4 % over four
+        grid = dim3(grid_for(g->E, rpb * 8));
+        if (accumulate) hipLaunchKernelGGL((k_gather_pipe<false, true, 8>), grid, block, 0, st, g->E, g->src, g->dst, g->edge_row, in, ld_in, out, ld_out, H);
+        else hipLaunchKernelGGL((k_gather_pipe<false, false, 8>), grid, block, 0, st, g->E, g->src, g->dst, g->edge_row, in, ld_in, out, ld_out, H);
+    } else
     if (agg_variant()) {
         grid = dim3(grid_for(g->E, rpb * 4));
         if (concat) { if (accumulate) L(k_gather_pipe, true, true); else L(k_gather_pipe, true, false); }
