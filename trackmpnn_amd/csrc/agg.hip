@@ -224,7 +224,7 @@ __global__ __launch_bounds__(256) void k_gather_pipe(int E, const int32_t* __res
     }
 }
 
-template <bool ACC, int U = 4>
+template <bool ACC, int U = 4, int SEG_CHUNK = 32>
 __global__ __launch_bounds__(256) void k_segsum_pipe(int Dn, const int32_t* __restrict__ det_row,
                                                      const int32_t* __restrict__ rowptr,
                                                      const int32_t* __restrict__ inc,
@@ -237,7 +237,6 @@ __global__ __launch_bounds__(256) void k_segsum_pipe(int Dn, const int32_t* __re
     const int ngrp = 64 / lpr;
     const int grp = lane / lpr;
     const int c4 = (lane % lpr) * 4;
-    constexpr int SEG_CHUNK = 64;
     const int wv = threadIdx.x >> 6;
     // a wave's dets: positions base + wv, base + wv + 4, ... of consecutive 64-entry chunks of the visiting order,
     // flattened into one sequence so that the pipeline runs across chunk boundaries
@@ -452,16 +451,23 @@ static int segsum(const tmpnn_graph* g, const float* in, int ld_in, float* out, 
     hipStream_t st = as_stream(stream);
     dim3 grid(grid_for(g->Dn, 64)), block(256);
 #define LS(K, A) hipLaunchKernelGGL((K<A>), grid, block, 0, st, g->Dn, g->det_row, g->rowptr, g->inc, g->det_order, in, ld_in, out, ld_out, H, wneg, cneg, compact_out)
-#define LS8(A) hipLaunchKernelGGL((k_segsum_pipe<A, 8>), grid, block, 0, st, g->Dn, g->det_row, g->rowptr, g->inc, g->det_order, in, ld_in, out, ld_out, H, wneg, cneg, compact_out)
+#define LSP(A, UU, CH)                                                                                       \
+    do {                                                                                                     \
+        grid = dim3(grid_for(g->Dn, CH));                                                                    \
+        hipLaunchKernelGGL((k_segsum_pipe<A, UU, CH>), grid, block, 0, st, g->Dn, g->det_row, g->rowptr, g->inc, \
+                           g->det_order, in, ld_in, out, ld_out, H, wneg, cneg, compact_out);                \
+    } while (0)
     // rows in flight per lane group and pass: 4 covers a C2-like det (16 incidences at H = 64) in one pass; graphs whose
     // dets average more than 24 incidences (C3: 34) take 8, i.e. two passes instead of three (same box: 0.43 -> 0.45 of
     // 8 TB/s on the C3 shape; on C2 4 is the faster one).  A property of the graph, not of a measurement.
+    // A block walks 32-entry chunks of the visiting order (8 dets per wave; 64: 0.44 -> 0.42 ms per 6 M edges).
     const bool deep = (long)2 * g->E > (long)24 * g->Dn;
-    if (agg_variant() && deep) { if (accumulate) LS8(true); else LS8(false); }
-    else
-    if (agg_variant()) { if (accumulate) LS(k_segsum_pipe, true); else LS(k_segsum_pipe, false); }
+    if (agg_variant()) {                 // (high-degree graphs: 16-entry chunks, 4 dets per wave: 0.47 -> 0.49 on the C3 shape)
+        if (deep) { if (accumulate) LSP(true, 8, 16); else LSP(false, 8, 16); }
+        else      { if (accumulate) LSP(true, 4, 32); else LSP(false, 4, 32); }
+    }
     else               { if (accumulate) LS(k_segsum, true); else LS(k_segsum, false); }
-#undef LS8
+#undef LSP
 #undef LS
     return check_launch("segsum");
 }
