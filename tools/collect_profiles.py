@@ -110,9 +110,10 @@ the two stand-alone backward kernels and `gather_diff` are measured for comparis
         f.write(f"| {k} | {v['ms']} | {v['GBs']} | {v['hbm_frac']} | {r1.get(k, '')} |\n")
     f.write('''
 Dets here have ~34 incident edges (C2: ~16): the segment sum takes three passes per det; round 2's kernel pipelines the
-index loads of every pass (and of the next det) behind the row loads of the current one.  Across gpurun boxes the same
-binary measured segsum at 0.385 - 0.433 and gather at 0.423 - 0.437 of 8 TB/s on this shape (the boxes differ by up to
-15 % on these latency-sensitive row movers).
+index loads of every pass (and of the next det) behind the row loads of the current one, keeps eight rows in flight per
+lane group on such high-degree graphs (two passes) and walks 16-entry chunks of the visiting order per block.  History of
+this shape on the same binary family: 0.34 (round 1) -> 0.39-0.43 (pipelined) -> 0.47-0.49 (rows in flight, chunking, finer
+grids); the boxes differ by up to 10 % on these latency-sensitive row movers.
 ''')
 
 # ---- C5
