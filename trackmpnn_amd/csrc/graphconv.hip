@@ -18,6 +18,7 @@
 namespace tmpnn {
 
 static constexpr int GC_THREADS = 1024;
+static constexpr int GC_RUN = 2048;         // BIG mode: incidences of one det ranked out of a per-wave LDS slice (16 x 8 KiB)
 
 // exclusive scan of one int per thread over the workgroup (16 waves); returns the prefix, *total = sum
 __device__ __forceinline__ int block_excl_scan(int v, int* s_wave /* [17] */, int* total) {
@@ -160,6 +161,26 @@ __global__ __launch_bounds__(GC_THREADS) void k_graph_from_coo(int N, const int6
         const int lane = tid & 63, wave = tid >> 6;
         for (int d = wave; d < Dn; d += GC_THREADS / 64) {
             const int base = s_ptr[d], L = s_ptr[d + 1] - base;
+            if (BIG && L + 3 <= GC_RUN) {
+                // the work arrays are in global memory here, but the LDS is free: the det's run is ranked from this wave's
+                // LDS slice (the L^2 comparisons of a 300-edge det out of L2 were 45 % of a 10 k-row conversion)
+                int* const w_keys = lds_dyn + wave * GC_RUN;
+                const int L4 = (L + 3) & ~3;                    // padded with rows no key is smaller than
+                for (int i = lane; i < L4; i += 64) w_keys[i] = i < L ? (s_inc[base + i] & 0x7fffffff) : 0x7fffffff;
+                __builtin_amdgcn_wave_barrier();
+                for (int i = lane; i < L; i += 64) {
+                    const int key = s_inc[base + i];
+                    const int row = key & 0x7fffffff;
+                    int rank = 0;
+                    for (int j = 0; j < L4; j += 4) {          // four keys per (broadcast) 16-byte LDS read
+                        const int4 k4 = *reinterpret_cast<const int4*>(w_keys + j);
+                        rank += (k4.x < row) + (k4.y < row) + (k4.z < row) + (k4.w < row);
+                    }
+                    g.inc[base + rank] = key;
+                }
+                __builtin_amdgcn_wave_barrier();
+                continue;
+            }
             for (int i = lane; i < L; i += 64) {
                 const int key = s_inc[base + i];
                 const int row = key & 0x7fffffff;
@@ -276,7 +297,9 @@ int tmpnn_graph_from_coo_arena_ws(int N, const int64_t* node_idx, const float* n
     TM_REQUIRE(nnz_edge >= 0 && (edge_idx == nullptr || nnz_edge == 0 || edge_val), "graph_from_coo: edge_adj entries");
     if (ws == nullptr || ws_ints < tmpnn_graph_from_coo_ws_ints(N))
         return set_error(TMPNN_EWORKSPACE, "graph_from_coo: workspace %zu < %zu ints", ws_ints, tmpnn_graph_from_coo_ws_ints(N));
-    hipLaunchKernelGGL((k_graph_from_coo<false, true>), dim3(1), dim3(GC_THREADS), 0, as_stream(stream), N, node_idx, node_val,
+    const size_t shm_big = sizeof(int) * (GC_THREADS / 64) * GC_RUN;          // 128 KiB: per-wave ranking slices
+    TM_SHM_ONCE((k_graph_from_coo<false, true>), shm_big);
+    hipLaunchKernelGGL((k_graph_from_coo<false, true>), dim3(1), dim3(GC_THREADS), shm_big, as_stream(stream), N, node_idx, node_val,
                        (long)nnz_node, edge_idx, edge_val, (long)nnz_edge, (const uint8_t*)nullptr, (const int32_t*)nullptr,
                        (const int32_t*)nullptr, g, reinterpret_cast<int*>(ws));
     return check_launch("graph_from_coo (global scratch)");
