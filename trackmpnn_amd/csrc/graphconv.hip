@@ -117,6 +117,12 @@ __global__ __launch_bounds__(GC_THREADS) void k_graph_from_coo(int N, const int6
         e_idx += is_det ? 0 : 1;
     }
     const int E = E_total, Dn = N - E_total;
+    // BIG: the degree counters / fill cursors take hundreds of atomics per det (a det of a dense scene has ~300 incident
+    // edges): in global memory those serialise at L2 (600 k of the 1.4 M cycles of a 10.9 k-row conversion); the LDS,
+    // idle until the ranking phase, holds them instead whenever the dets fit
+    const bool deg_lds = BIG && Dn <= (GC_THREADS / 64) * GC_RUN;
+    if (deg_lds)
+        for (int d = tid; d < Dn; d += GC_THREADS) lds_dyn[d] = 0;
     __syncthreads();
     for (int r = tid; r < N; r += GC_THREADS) {
         const bool is_det = s_diag[r] != 0.f;
@@ -133,8 +139,8 @@ __global__ __launch_bounds__(GC_THREADS) void k_graph_from_coo(int N, const int6
         g.dst[p] = d;
         g.src_pos[p] = s_cnt[s];
         g.dst_pos[p] = s_cnt[d];
-        atomicAdd(&s_deg[s_cnt[s]], 1);
-        atomicAdd(&s_deg[s_cnt[d]], 1);
+        if (deg_lds) { atomicAdd(&lds_dyn[s_cnt[s]], 1); atomicAdd(&lds_dyn[s_cnt[d]], 1); }
+        else { atomicAdd(&s_deg[s_cnt[s]], 1); atomicAdd(&s_deg[s_cnt[d]], 1); }
     }
     __syncthreads();
 
@@ -142,10 +148,15 @@ __global__ __launch_bounds__(GC_THREADS) void k_graph_from_coo(int N, const int6
     {
         const int d0 = tid * IT, d1 = min(Dn, d0 + IT);
         int mine = 0;
-        for (int d = d0; d < d1; ++d) mine += s_deg[d];
+        for (int d = d0; d < d1; ++d) mine += deg_lds ? lds_dyn[d] : s_deg[d];
         int total;
         int run = block_excl_scan(mine, s_wave, &total);
-        for (int d = d0; d < d1; ++d) { const int t = s_deg[d]; s_ptr[d] = run; s_deg[d] = run; run += t; }
+        for (int d = d0; d < d1; ++d) {
+            const int t = deg_lds ? lds_dyn[d] : s_deg[d];
+            s_ptr[d] = run;
+            if (deg_lds) lds_dyn[d] = run; else s_deg[d] = run;
+            run += t;
+        }
         if (tid == 0) s_ptr[Dn] = total;
     }
     __syncthreads();
@@ -153,8 +164,13 @@ __global__ __launch_bounds__(GC_THREADS) void k_graph_from_coo(int N, const int6
         if (s_diag[r] != 0.f) continue;
         const int s = s_src[r], d = s_dst[r];
         if (s < 0) continue;
-        s_inc[atomicAdd(&s_deg[s_cnt[s]], 1)] = r;                          // + : d is the earlier det
-        s_inc[atomicAdd(&s_deg[s_cnt[d]], 1)] = r | (int)0x80000000u;       // - : d is the later det
+        if (deg_lds) {
+            s_inc[atomicAdd(&lds_dyn[s_cnt[s]], 1)] = r;
+            s_inc[atomicAdd(&lds_dyn[s_cnt[d]], 1)] = r | (int)0x80000000u;
+        } else {
+            s_inc[atomicAdd(&s_deg[s_cnt[s]], 1)] = r;                          // + : d is the earlier det
+            s_inc[atomicAdd(&s_deg[s_cnt[d]], 1)] = r | (int)0x80000000u;       // - : d is the later det
+        }
     }
     __syncthreads();
     {
