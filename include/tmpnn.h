@@ -300,6 +300,7 @@ int tmpnn_focal_loss_bwd(const int32_t* rows, int R, const float* scores, const 
  * ====================================================================================================== */
 #define TMPNN_DG_MAX_ROWS 4096
 #define TMPNN_DG_BIG_ROWS 65535    /* fused iteration and tmpnn_graph_from_coo_arena_ws (work arrays in a global scratch) */
+#define TMPNN_TRACK_MAX_ROWS 32768 /* tracker-side operations tmpnn_track_* (row deletion keeps an N-int table in the LDS) */
 #define TMPNN_DG_META 8      /* ints in tmpnn_dgraph.meta: [0] E, [1] Dn, [2] status, [3] N, rest reserved */
 /* status bits (0 = the adjacency is a TrackMPNN factor graph, SURVEY 8 "graph invariants") */
 #define TMPNN_DG_BAD_VALUE 1     /* an off-diagonal entry is not +-1, or an index is out of range */
@@ -357,6 +358,9 @@ int tmpnn_graph_from_coo_arena_ws(int N, const int64_t* node_idx, const float* n
  * tracker-side operations below edit.  Same validation, same status bits. */
 int tmpnn_graph_from_rows(int N, const uint8_t* is_edge, const int32_t* row_src, const int32_t* row_dst,
                           const tmpnn_dgraph* g, tmpnn_stream stream);
+/* ... for graphs of up to TMPNN_DG_BIG_ROWS rows (`ws`: tmpnn_graph_from_coo_ws_ints(N) ints, as for tmpnn_graph_from_coo_arena_ws). */
+int tmpnn_graph_from_rows_ws(int N, const uint8_t* is_edge, const int32_t* row_src, const int32_t* row_dst,
+                             const tmpnn_dgraph* g, void* ws, size_t ws_ints, tmpnn_stream stream);
 
 /* Parameters of the model as device pointers in the reference's layouts (state_dict keys of SURVEY 8(b)); the same
  * struct with gradient buffers is what tmpnn_mp_iter_bwd accumulates into (+=).  G <= 3 feature groups. */
@@ -404,7 +408,7 @@ int tmpnn_mp_iter_bwd(const tmpnn_mp_params* P, const float* prep, const tmpnn_d
  * Tracker-side graph maintenance on the device (csrc/trackops.hip).  Between two model
  * calls the reference moves a DENSE N x N adjacency and the hidden state to the host and back
  * (utils/graph.py:216-221,326-332 and :420-425,532-537).  Here the graph lives in HBM in ROW form, one entry per
- * state row, all int32 unless noted (capacity <= TMPNN_DG_MAX_ROWS rows):
+ * state row, all int32 unless noted (capacity <= TMPNN_TRACK_MAX_ROWS rows):
  *     ts, det_id, assoc            y_pred[:, 0..2]: timestep (-1 on edge rows), detection id, associated next detection id
  *     is_edge (uint8), row_src, row_dst   the +1 / -1 det ROW of an edge row (-1 on det rows)
  *     labels (uint8)               ground-truth class (training; may be NULL at inference)

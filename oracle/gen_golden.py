@@ -226,11 +226,19 @@ def window_sequence(seed, frames, mean_dets, max_dets, ncat):
     return X, y
 
 
-def run_infer_fixture(name, out_dir, seed, T, dmean, cur_win, ret_win, hungarian, H=32, K=0, msg='diff'):
+def node_adj_diag_zero(na):
+    """bool [N]: rows of node_adj whose diagonal entry is 0, i.e. the edge rows."""
+    d = na.to_dense() if na.is_sparse else na
+    return torch.diagonal(d) == 0
+
+
+def run_infer_fixture(name, out_dir, seed, T, dmean, cur_win, ret_win, hungarian, H=32, K=0, msg='diff', light=False):
     """The inference loop of infer.py:48-87 on the real reference: eval-mode model, update_graph(mode='test'),
     decode_tracks(cuda=False) with its row deletion between calls.  Every forward call is stored with ITS inputs
     (x, the row-deleted carried state, the adjacency pair as produced) and outputs; every decode step with the rows
-    it kept (read off a marker array passed as `labels`), y_pred before / after and the finalised tracks y_out."""
+    it kept (read off a marker array passed as `labels`), y_pred before / after and the finalised tracks y_out.
+    light=True (dense scenes, thousands of rows): only what drives and checks the graph maintenance is kept -- the
+    scores of every call, y_pred, kept rows, y_out -- no states, adjacency or parameters."""
     from models.track_mpnn import TrackMPNN
     from utils.graph import decode_tracks, initialize_graph, update_graph
 
@@ -249,8 +257,9 @@ def run_infer_fixture(name, out_dir, seed, T, dmean, cur_win, ret_win, hungarian
                 b.copy_(0.5 + torch.rand(b.shape, generator=gp))
     model.eval()
     out = {}
-    for k, v in model.state_dict().items():
-        out['param/' + k] = v.detach().numpy().copy()
+    if not light:
+        for k, v in model.state_dict().items():
+            out['param/' + k] = v.detach().numpy().copy()
     X, y = synth_sequence(seed, T, dmean, 3, '2d', fp_rate=0.2)
     out['X'] = X.numpy().copy()
     out['y'] = y.numpy().copy()
@@ -260,6 +269,12 @@ def run_infer_fixture(name, out_dir, seed, T, dmean, cur_win, ret_win, hungarian
     def record_call(c, x, h_in, na, ea, scores, logits, h, y_pred):
         pre = f'c{c}/'
         out[pre + 'x'] = x.detach().numpy().copy()
+        if light:
+            out[pre + 'N'] = np.int64(logits.shape[0])
+            out[pre + 'E'] = np.int64(int((node_adj_diag_zero(na)).sum()))
+            out[pre + 'scores'] = scores.detach().numpy().copy()
+            out[pre + 'y_pred'] = y_pred.numpy().astype(np.int32)
+            return
         out[pre + 'has_h_in'] = np.int64(h_in is not None)
         if h_in is not None:
             out[pre + 'h_in'] = h_in.detach().numpy().copy()
@@ -306,17 +321,23 @@ def run_infer_fixture(name, out_dir, seed, T, dmean, cur_win, ret_win, hungarian
                 states, node_adj, marker, scores, y_pred, y_out, t_upto, ret_win, use_hungraian=hungarian, cuda=False)
             labels = labels[kept]
             pre = f'd{c}/'
-            out[pre + 'keep'] = kept.numpy().copy()
+            out[pre + 'keep'] = kept.numpy().astype(np.int32) if light else kept.numpy().copy()
             out[pre + 't_upto'] = np.int64(t_upto)
-            out[pre + 'y_pred_before'] = y_pred_b.numpy().copy()
-            out[pre + 'y_pred_after'] = y_pred.numpy().copy()
-            out[pre + 'y_out'] = y_out.copy()
-            out[pre + 'h_kept'] = states.numpy().copy()
+            if light:
+                out[pre + 'n_before'] = np.int64(y_pred_b.shape[0])
+                out[pre + 'y_pred_after'] = y_pred.numpy().astype(np.int32)
+                out[pre + 'y_out'] = y_out.astype(np.int32)
+            else:
+                out[pre + 'y_pred_before'] = y_pred_b.numpy().copy()
+                out[pre + 'y_pred_after'] = y_pred.numpy().copy()
+                out[pre + 'y_out'] = y_out.copy()
+                out[pre + 'h_kept'] = states.numpy().copy()
             nsteps += 1
     ncalls = c + 1
-    n_del = sum(int(out[f'd{i}/y_pred_before'].shape[0] - out[f'd{i}/keep'].shape[0]) for i in range(1, ncalls))
+    n_del = sum(int((out[f'd{i}/n_before'] if light else out[f'd{i}/y_pred_before'].shape[0]) - out[f'd{i}/keep'].shape[0])
+                for i in range(1, ncalls))
     frac_pos = float(np.mean(np.concatenate([out[f'c{i}/scores'].ravel() for i in range(ncalls)]) >= 0.5))
-    meta = dict(name=name, kind='infer', features='2d', ncategories=3, nhidden=H, nattheads=K, msg_type=msg, mode='eval',
+    meta = dict(name=name, kind='infer_light' if light else 'infer', features='2d', ncategories=3, nhidden=H, nattheads=K, msg_type=msg, mode='eval',
                 ncalls=ncalls, seed=seed, T=T, cur_win_size=cur_win, ret_win_size=ret_win, hungarian=bool(hungarian),
                 rows_deleted=n_del, torch=torch.__version__, reference='arangesh/TrackMPNN infer.py:48-87 loop')
     out['meta'] = np.array(json.dumps(meta))
@@ -399,6 +420,8 @@ def main():
     # the GPU path runs them zero-padded to 64 / 32
     run_fixture('roll_2d_diff_k0_train_h48', args.out, '2d', 3, 48, 0, 'diff', 'train', 600)
     run_fixture('roll_2d-temp_concat_k2_eval_h20', args.out, '2d+temp', 3, 20, 2, 'concat', 'eval', 601)
+    # a dense scene (~70 dets per frame): inference graphs beyond 4096 rows, graph maintenance only (light)
+    run_infer_fixture('dense_infer_greedy_w3_r1', args.out, 700, T=6, dmean=70, cur_win=3, ret_win=1, hungarian=False, light=True)
 
 
 def run_c1(out_dir):

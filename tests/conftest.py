@@ -14,7 +14,7 @@ def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
 
 
-_OTHER_KINDS = ('loss_', 'infer_', 'init_')
+_OTHER_KINDS = ('loss_', 'infer_', 'init_', 'dense_')
 
 
 def golden_names():

@@ -329,7 +329,7 @@ def test_gradient_sink_keeps_the_autograd_contract():
             assert float((p.grad - g).abs().max()) <= 1e-5 * gscale, i
 
 
-def _dense_window_calls(seed, frames, mean_dets, max_dets, F):
+def _dense_window_calls(seed, frames, mean_dets, max_dets, F, with_sequence=False):
     """A dense synthetic chunk (BDD-like density) as the reference would hand it over: per call (x, node_adj, edge_adj)
     with the adjacency pair as sparse COO tensors (+1 / -1 on an edge row's src / dst column, 1 on det diagonals;
     edge_adj = the transpose off the diagonal, 1 on edge diagonals)."""
@@ -359,6 +359,8 @@ def _dense_window_calls(seed, frames, mean_dets, max_dets, F):
         x = torch.zeros(call.n_new, F)
         x[~call.new_is_edge] = X[call.det_ids]
         calls.append((x.to(DEV), na, ea))
+    if with_sequence:
+        return calls, X, torch.from_numpy(y)
     return calls
 
 

@@ -132,6 +132,7 @@ _SIGNATURES = {
     'tmpnn_graph_from_coo_arena_ws': (c_int, [c_int, c_void_p, c_void_p, C.c_int64, c_void_p, c_void_p, C.c_int64, c_void_p, c_int,
                                               c_void_p, c_size_t, c_void_p]),
     'tmpnn_graph_from_rows': (c_int, [c_int, c_void_p, c_void_p, c_void_p, _DGP, c_void_p]),
+    'tmpnn_graph_from_rows_ws': (c_int, [c_int, c_void_p, c_void_p, c_void_p, _DGP, c_void_p, c_size_t, c_void_p]),
     'tmpnn_track_associate': (c_int, [_DGP, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     'tmpnn_track_active': (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     'tmpnn_track_append': (c_int, [c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p,

@@ -345,4 +345,22 @@ int tmpnn_graph_from_rows(int N, const uint8_t* is_edge, const int32_t* row_src,
     return check_launch("graph_from_rows");
 }
 
+int tmpnn_graph_from_rows_ws(int N, const uint8_t* is_edge, const int32_t* row_src, const int32_t* row_dst,
+                             const tmpnn_dgraph* g, void* ws, size_t ws_ints, tmpnn_stream stream) {
+    if (N <= TMPNN_DG_MAX_ROWS) return tmpnn_graph_from_rows(N, is_edge, row_src, row_dst, g, stream);
+    TM_REQUIRE(g != nullptr && g->meta && g->is_edge && g->pos && g->src && g->dst && g->src_pos && g->dst_pos &&
+                   g->edge_row && g->det_row && g->rowptr && g->inc, "graph_from_rows: unbound graph");
+    TM_REQUIRE(N <= TMPNN_DG_BIG_ROWS && N <= g->cap && N == g->N, "graph_from_rows: N=%d (limit %d, graph N=%d cap=%d)", N,
+               TMPNN_DG_BIG_ROWS, g->N, g->cap);
+    TM_REQUIRE(is_edge && row_src && row_dst, "graph_from_rows: null row arrays");
+    if (ws == nullptr || ws_ints < tmpnn_graph_from_coo_ws_ints(N))
+        return set_error(TMPNN_EWORKSPACE, "graph_from_rows: workspace %zu < %zu ints", ws_ints, tmpnn_graph_from_coo_ws_ints(N));
+    const size_t shm_big = sizeof(int) * (GC_THREADS / 64) * GC_RUN;
+    TM_SHM_ONCE((k_graph_from_coo<true, true>), shm_big);
+    hipLaunchKernelGGL((k_graph_from_coo<true, true>), dim3(1), dim3(GC_THREADS), shm_big, as_stream(stream), N,
+                       (const int64_t*)nullptr, (const float*)nullptr, 0L, (const int64_t*)nullptr, (const float*)nullptr, 0L,
+                       is_edge, row_src, row_dst, *g, reinterpret_cast<int*>(ws));
+    return check_launch("graph_from_rows (global scratch)");
+}
+
 }  // extern "C"

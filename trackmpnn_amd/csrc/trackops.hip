@@ -17,7 +17,7 @@
 //
 // The index form (CSR etc.) is re-derived from the rows by tmpnn_graph_from_rows (csrc/graphconv.hip).  The Hungarian
 // matching and the linked-list walk that finalises tracks stay on the host (tens of detections, scipy).  Integer work,
-// HBM/latency bound, graphs of <= TMPNN_DG_MAX_ROWS rows: single-workgroup kernels with LDS scans.
+// HBM/latency bound, graphs of <= TMPNN_TRACK_MAX_ROWS rows: single-workgroup kernels with LDS scans.
 #include "common.h"
 
 namespace tmpnn {
@@ -265,7 +265,7 @@ int tmpnn_track_associate(const tmpnn_dgraph* g, const int32_t* det_id, const ui
 
 int tmpnn_track_active(int N, const int32_t* ts, const int32_t* assoc, const float* score, int mode, int t,
                        int32_t* active, int32_t* count, tmpnn_stream stream) {
-    TM_REQUIRE(N >= 0 && N <= TMPNN_DG_MAX_ROWS, "track_active: N=%d (limit %d)", N, TMPNN_DG_MAX_ROWS);
+    TM_REQUIRE(N >= 0 && N <= TMPNN_TRACK_MAX_ROWS, "track_active: N=%d (limit %d)", N, TMPNN_TRACK_MAX_ROWS);
     TM_REQUIRE(ts && assoc && active && count && (mode == 0 || score), "track_active: null pointer");
     hipLaunchKernelGGL(k_track_active, dim3(1), dim3(TK_THREADS), 0, as_stream(stream), N, ts, assoc, score, mode, t,
                        active, count);
@@ -275,8 +275,8 @@ int tmpnn_track_active(int N, const int32_t* ts, const int32_t* assoc, const flo
 int tmpnn_track_append(int N, int A, int D, const int32_t* active, const int32_t* new_ids, int t, const int32_t* track,
                        int32_t* ts, int32_t* det_id, int32_t* assoc, uint8_t* is_edge, int32_t* row_src,
                        int32_t* row_dst, uint8_t* labels, tmpnn_stream stream) {
-    TM_REQUIRE(N >= 0 && A >= 0 && D >= 0 && (long)N + (long)A * D + D <= TMPNN_DG_MAX_ROWS,
-               "track_append: N=%d A=%d D=%d exceeds %d rows", N, A, D, TMPNN_DG_MAX_ROWS);
+    TM_REQUIRE(N >= 0 && A >= 0 && D >= 0 && (long)N + (long)A * D + D <= TMPNN_TRACK_MAX_ROWS,
+               "track_append: N=%d A=%d D=%d exceeds %d rows", N, A, D, TMPNN_TRACK_MAX_ROWS);
     if (D == 0) return TMPNN_OK;
     TM_REQUIRE((A == 0 || active) && new_ids && ts && det_id && assoc && is_edge && row_src && row_dst,
                "track_append: null pointer");
@@ -291,9 +291,10 @@ int tmpnn_track_delete(int N, const int32_t* ts, const int32_t* det_id, const in
                        int t_upto, int ret_win, int32_t* keep, int32_t* count, int32_t* o_ts, int32_t* o_det_id,
                        int32_t* o_assoc, uint8_t* o_is_edge, int32_t* o_src, int32_t* o_dst, uint8_t* o_labels,
                        tmpnn_stream stream) {
-    TM_REQUIRE(N >= 0 && N <= TMPNN_DG_MAX_ROWS, "track_delete: N=%d (limit %d)", N, TMPNN_DG_MAX_ROWS);
+    TM_REQUIRE(N >= 0 && N <= TMPNN_TRACK_MAX_ROWS, "track_delete: N=%d (limit %d)", N, TMPNN_TRACK_MAX_ROWS);
     TM_REQUIRE(ts && det_id && assoc && score && is_edge && row_src && row_dst && keep && count && o_ts && o_det_id &&
                    o_assoc && o_is_edge && o_src && o_dst, "track_delete: null pointer");
+    TM_SHM_ONCE(k_track_delete, sizeof(int) * TMPNN_TRACK_MAX_ROWS);          // up to 128 KiB: the renumbering table
     hipLaunchKernelGGL(k_track_delete, dim3(1), dim3(TK_THREADS), sizeof(int) * (size_t)(N > 0 ? N : 1), as_stream(stream),
                        N, ts, det_id, assoc, score, is_edge, row_src, row_dst, labels, t_upto, ret_win, keep, count, o_ts,
                        o_det_id, o_assoc, o_is_edge, o_src, o_dst, o_labels);

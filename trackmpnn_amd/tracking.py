@@ -26,6 +26,8 @@ import torch
 from . import _lib
 from .graph import DG_MAX_ROWS, DeviceGraph
 
+TRACK_MAX_ROWS = 32768       # TMPNN_TRACK_MAX_ROWS
+
 
 def _stream() -> int:
     return _lib.raw_stream()
@@ -34,7 +36,7 @@ def _stream() -> int:
 class TrackGraph:
     """Row form (+ index form) of one sequence's rolling graph on the device."""
 
-    def __init__(self, device, cap: int = DG_MAX_ROWS):
+    def __init__(self, device, cap: int = TRACK_MAX_ROWS):
         self.device = torch.device(device)
         self.cap = cap
         self.N = 0
@@ -66,8 +68,14 @@ class TrackGraph:
     def _rebuild(self) -> None:
         r = self.rows
         g = DeviceGraph(self.N, self.device)
-        _lib.call('tmpnn_graph_from_rows', self.N, r['is_edge'].data_ptr(), r['src'].data_ptr(), r['dst'].data_ptr(),
-                  g.cref(), _stream())
+        if self.N <= DG_MAX_ROWS:
+            _lib.call('tmpnn_graph_from_rows', self.N, r['is_edge'].data_ptr(), r['src'].data_ptr(), r['dst'].data_ptr(),
+                      g.cref(), _stream())
+        else:                                     # dense scene: the conversion's work arrays in a global scratch
+            ws = torch.empty((8 * self.N + 1,), dtype=torch.int32, device=self.device)
+            _lib.call('tmpnn_graph_from_rows_ws', self.N, r['is_edge'].data_ptr(), r['src'].data_ptr(), r['dst'].data_ptr(),
+                      g.cref(), ws.data_ptr(), ws.numel(), _stream())
+            g._keep = (ws,)
         self.graph = g
 
     # ---------------------------------------------------------------------------------------------------------------
@@ -86,8 +94,8 @@ class TrackGraph:
         ids0, ids1 = np.nonzero(yy[:, 0] == t0)[0], np.nonzero(yy[:, 0] == t1)[0]
         n0, n1 = ids0.size, ids1.size
         N = n0 + n0 * n1 + n1
-        if N > DG_MAX_ROWS:
-            raise ValueError(f'TrackGraph: {N} rows exceed the device-resident limit of {DG_MAX_ROWS}')
+        if N > TRACK_MAX_ROWS:
+            raise ValueError(f'TrackGraph: {N} rows exceed the device-resident limit of {TRACK_MAX_ROWS}')
         ts = np.full(N, -1, np.int32)
         did = np.full(N, -1, np.int32)
         ts[:n0], ts[n0 + n0 * n1:] = t0, t1
