@@ -1,0 +1,44 @@
+"""One KITTI-sized window (fixture roll_c2_kitti_car_w5, 7 calls) through the drop-in call for models OUTSIDE the fused
+batch-1 path -- attention heads, wide cells, padded widths: the staged kernels behind the one-launch adjacency conversion."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from tests.golden_util import Golden
+from tests.test_parity_gpu import DEV
+from trackmpnn_amd import TrackMPNN
+
+gold = Golden('roll_c2_kitti_car_w5')
+calls = []
+for c in range(gold.ncalls):
+    na, ea = gold.adjacency(c, 'node_adj', DEV), gold.adjacency(c, 'edge_adj', DEV)
+    if not na.is_sparse:
+        na, ea = na.to_sparse(), ea.to_sparse()
+    calls.append((gold.t(f'c{c}/x').to(DEV), na, ea))
+for desc, kw in (('K=2 heads, H=64', dict(nattheads=2, nhidden=64)), ('K=0, H=128', dict(nattheads=0, nhidden=128)),
+                 ('K=0, H=48 (padded)', dict(nattheads=0, nhidden=48))):
+    torch.manual_seed(5)
+    model = TrackMPNN('2d', 3, kw['nhidden'], kw['nattheads'], 'diff').to(DEV).train()
+
+    def infer():
+        h = None
+        with torch.no_grad():
+            for x, na, ea in calls:
+                s, l, h, _ = model(x, h, na, ea)
+
+    def train():
+        h, outs = None, []
+        for x, na, ea in calls:
+            s, l, h, _ = model(x, h, na, ea)
+            outs.append(l)
+        model.zero_grad(set_to_none=True)
+        torch.cat(outs).sum().backward()
+
+    for name, fn in (('inference', infer), ('fwd + loss + bwd', train)):
+        for _ in range(5):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(30):
+            fn()
+        torch.cuda.synchronize()
+        print(f'{desc:22s} {name:18s} {(time.perf_counter() - t0) / 30 * 1e3:.3f} ms per window', flush=True)

@@ -19,7 +19,7 @@ import weakref
 
 from . import functional as _functional
 from .functional import MPIteration, ModelSpec
-from .graph import (CallPlan, DeviceGraph, FrameGraph, device_graph_from_adjacency, graph_from_adjacency,
+from .graph import (DG_BIG_ROWS, CallPlan, DeviceGraph, FrameGraph, device_graph_from_adjacency, graph_from_adjacency,
                     plan_single)
 from .layers import FactorGraphGRU
 from .small import SmallPath, _ParamSink, _SmallIter, fast_module, small_eligible
@@ -363,6 +363,11 @@ class TrackMPNN(nn.Module):
                     self._pending_graphs.append(graph)
                     if len(self._pending_graphs) >= 64:
                         self.check_graphs()
+            elif N <= DG_BIG_ROWS:
+                # staged path (attention heads, wide or padded cells): the same one-launch conversion, validated at
+                # once (one host round trip for E / Dn, which the staged kernels' launch sizes need) -- the torch-ops
+                # converter it replaces took 2 of the 2.4 ms of such a call on a KITTI-sized window
+                graph = device_graph_from_adjacency(node_adj, edge_adj, x.device).frame_graph()
             else:
                 graph = graph_from_adjacency(node_adj.to(x.device), edge_adj.to(x.device))
             self._graph_cache = (weakref.ref(node_adj), weakref.ref(edge_adj), key, graph)
