@@ -475,6 +475,21 @@ int tmpnn_wide_gru_bwd_weights(const void* dg_ws, const int32_t* rows, int R, co
                                const float* h, int ld_h, int H, float* dW_ih, float* dW_hh, float* db_ih, float* db_hh,
                                void* ws, size_t ws_bytes, tmpnn_stream stream);
 
+/* The whole backward of a wide EDGE cell under the diff message x[e] = h[src e] - h[dst e] (models/layers.py:90-95, 107),
+ * with both W_ih products taken on the det side by linearity -- the backward twin of the forward's projected det rows:
+ *     S[d] = sum_{e: src = d} d_gi[e] - sum_{e: dst = d} d_gi[e]
+ *     d_h[det_row[d]] += S[d] W_ih                 (the message adjoint: replaces d_x = d_gi W_ih + tmpnn_gather_diff_bwd)
+ *     dW_ih += S^T h[det rows]                     (replaces d_gi^T (h[src] - h[dst]) over the E edge rows)
+ * and, over the edge rows, d_h[edge_row[e]] = dh z + d_gh W_hh (plain store), dW_hh += d_gh^T h, db_ih / db_hh += column
+ * sums.  The gate gradients are materialised once as [N][4H] = [dr | dz | dn | dn r] indexed by graph row.
+ * Replaces tmpnn_wide_gru_bwd_data + tmpnn_wide_gru_bwd_weights + tmpnn_gather_diff_bwd for this cell: two of the four
+ * (E x 3H x H) products run over Dn rows.  ws: tmpnn_wide_gru_bwd_diff_ws(N, E, Dn, H) bytes. */
+size_t tmpnn_wide_gru_bwd_diff_ws(int N, int E, int Dn, int H);
+int tmpnn_wide_gru_bwd_diff(const void* prep, const tmpnn_graph* g, const float* h, int ld_h, int H, const float* gates,
+                            size_t gate_plane, const float* d_hout, int ld_dhout, const float* dy, const float* w_head,
+                            float* d_h, int ld_dh, float* dW_ih, float* dW_hh, float* db_ih, float* db_hh, void* ws,
+                            size_t ws_bytes, tmpnn_stream stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -74,6 +74,7 @@ static constexpr int W_BM = 128, W_KT = 32, W_LD = 40;     // LDS row stride in 
 struct WideArgs {
     // A: R rows of K fp32, row r at A + (a_rows ? a_rows[r] : r) * lda
     const float* A; int lda; const int32_t* a_rows; int R; int K;
+    int kskip_at, kskip;                        // A column of product index k: k < kskip_at ? k : k + kskip (kskip = 0: plain)
     const uint16_t* img; int N;                 // weight image [K/32][3][N][32]
     // STORE epilogue: C[(c_rows ? c_rows[r] : r) * ldc + n] (=|+=) acc
     float* C; int ldc; const int32_t* c_rows; int accumulate;
@@ -93,7 +94,9 @@ __device__ __forceinline__ void wide_load(const WideArgs& a, int r0, int kt, int
     const int row = tid >> 2, kq = tid & 3;
     const int r = r0 + row;
     if (r < a.R) {
-        const float4* p = reinterpret_cast<const float4*>(a.A + (size_t)(a.a_rows ? a.a_rows[r] : r) * a.lda + kt * W_KT + 8 * kq);
+        int kc = kt * W_KT + 8 * kq;
+        if (kc >= a.kskip_at) kc += a.kskip;
+        const float4* p = reinterpret_cast<const float4*>(a.A + (size_t)(a.a_rows ? a.a_rows[r] : r) * a.lda + kc);
         qa0 = p[0]; qa1 = p[1];
     } else {
         qa0 = make_float4(0.f, 0.f, 0.f, 0.f); qa1 = qa0;
@@ -399,6 +402,64 @@ __global__ __launch_bounds__(256) void k_wide_gates_bwd(WideBwdArgs a) {
     }
 }
 
+// The same pass for the det-side form of the W_ih products (tmpnn_wide_gru_bwd_diff): ONE image per row, indexed by the
+// graph row, dg4[row] = [dr | dz | dn | dn r] (4H floats: d_gi = columns 0..3H, d_gh = columns 0..2H and 3H..4H), and the
+// column sums of dn (the third of db_ih that the W_hh-side weight-gradient launch does not see) as one [H] slab per block:
+// gridDim.x * 256 is a multiple of H / 4, so a thread keeps its four columns over the whole grid stride.
+__global__ __launch_bounds__(256) void k_wide_gates_bwd4(WideBwdArgs a, float* __restrict__ dn_slabs) {
+    __shared__ float red[256 * 4];
+    const int H = a.H, lpr = H >> 2;
+    const long total = (long)a.R * lpr;
+    float cs[4] = {0.f, 0.f, 0.f, 0.f};
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int r = (int)(i / lpr), c4 = (int)(i % lpr) * 4;
+        const int row = a.rows[r];
+        float4 dh = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (a.d_hout) dh = *reinterpret_cast<const float4*>(a.d_hout + (size_t)row * a.ld_dhout + c4);
+        if (a.dy) {
+            const float d = a.dy[row];
+            const float4 w = *reinterpret_cast<const float4*>(a.w_head + c4);
+            dh.x += d * w.x; dh.y += d * w.y; dh.z += d * w.z; dh.w += d * w.w;
+        }
+        const float* gp = a.gates + (size_t)row * H + c4;
+        const float4 gr = *reinterpret_cast<const float4*>(gp);
+        const float4 gz = *reinterpret_cast<const float4*>(gp + a.gate_plane);
+        const float4 gn = *reinterpret_cast<const float4*>(gp + 2 * a.gate_plane);
+        const float4 gh = *reinterpret_cast<const float4*>(gp + 3 * a.gate_plane);
+        const float4 hp = *reinterpret_cast<const float4*>(a.h + (size_t)row * a.ld_h + c4);
+        const float dv[4] = {dh.x, dh.y, dh.z, dh.w}, rv[4] = {gr.x, gr.y, gr.z, gr.w}, zv[4] = {gz.x, gz.y, gz.z, gz.w};
+        const float nv[4] = {gn.x, gn.y, gn.z, gn.w}, hv[4] = {gh.x, gh.y, gh.z, gh.w}, pv[4] = {hp.x, hp.y, hp.z, hp.w};
+        float dr[4], dz[4], dn[4], dnr[4], dhz[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float t = dv[j] * (1.0f - zv[j]) * (1.0f - nv[j] * nv[j]);
+            dn[j] = t;
+            dnr[j] = t * rv[j];
+            dr[j] = t * hv[j] * rv[j] * (1.0f - rv[j]);
+            dz[j] = dv[j] * (pv[j] - nv[j]) * zv[j] * (1.0f - zv[j]);
+            dhz[j] = dv[j] * zv[j];
+            cs[j] += t;
+        }
+        float* gi = a.dgi + (size_t)row * 4 * H + c4;
+        *reinterpret_cast<float4*>(gi) = make_float4(dr[0], dr[1], dr[2], dr[3]);
+        *reinterpret_cast<float4*>(gi + H) = make_float4(dz[0], dz[1], dz[2], dz[3]);
+        *reinterpret_cast<float4*>(gi + 2 * H) = make_float4(dn[0], dn[1], dn[2], dn[3]);
+        *reinterpret_cast<float4*>(gi + 3 * H) = make_float4(dnr[0], dnr[1], dnr[2], dnr[3]);
+        *reinterpret_cast<float4*>(a.d_h + (size_t)row * a.ld_dh + c4) = make_float4(dhz[0], dhz[1], dhz[2], dhz[3]);
+    }
+    // fixed-order sum over the 256 / lpr threads that share a column group
+#pragma unroll
+    for (int j = 0; j < 4; ++j) red[threadIdx.x * 4 + j] = cs[j];
+    __syncthreads();
+    if ((int)threadIdx.x < lpr) {
+        float s4[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int t = threadIdx.x; t < 256; t += lpr)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) s4[j] += red[t * 4 + j];
+        *reinterpret_cast<float4*>(dn_slabs + (size_t)blockIdx.x * H + 4 * threadIdx.x) = make_float4(s4[0], s4[1], s4[2], s4[3]);
+    }
+}
+
 
 // ------------------------------------------------------------------------------------------------------------
 // weight gradient from the materialised gate gradients: dW[j][k] = sum_r dg[r][j] * X[r][k]   (bf16x6, K = rows)
@@ -419,7 +480,8 @@ template <int COLS>
 __device__ __forceinline__ int w_swz(int row, int col) { return row * COLS + ((((col >> 5) ^ (row & 3)) << 5) | (col & 31)); }
 
 struct WideDwArgs {
-    const float* dg; int ldg;                       // [R][3H] compact gate gradients
+    const float* dg; int ldg;                       // gate gradients: row r at dg + (grows ? grows[r] : r) * ldg, product column
+    const int32_t* grows; int gskip_at, gskip;      // j at image column j < gskip_at ? j : j + gskip (the 4H image's d_gh)
     const float* X; int ldx;                        // operand rows: X[xa[r]] (- X[xb[r]] when xb != NULL)
     const int32_t* xa; const int32_t* xb;
     int R; int H; int rows_per_slab;
@@ -434,8 +496,13 @@ struct DwRaw { float4 a[3]; float4 b0[2], b1[2]; bool valid; };
 __device__ __forceinline__ void dw_issue(const WideDwArgs& q, int r, int r_end, int ca, int cb, DwRaw& w) {
     w.valid = r < r_end;
     const int rr = w.valid ? r : r_end - 1;
-    const float4* pa = reinterpret_cast<const float4*>(q.dg + (size_t)rr * q.ldg + ca);
-    w.a[0] = pa[0]; w.a[1] = pa[1]; w.a[2] = pa[2];
+    const float* pa = q.dg + (size_t)(q.grows ? q.grows[rr] : rr) * q.ldg;
+#pragma unroll
+    for (int g = 0; g < 3; ++g) {
+        int cg = ca + 4 * g;
+        if (cg >= q.gskip_at) cg += q.gskip;
+        w.a[g] = *reinterpret_cast<const float4*>(pa + cg);
+    }
     const float4* pb = reinterpret_cast<const float4*>(q.X + (size_t)q.xa[rr] * q.ldx + cb);
     w.b0[0] = pb[0]; w.b0[1] = pb[1];
     if (q.xb) {
@@ -727,8 +794,8 @@ int tmpnn_wide_gru_bwd_weights(const void* dg_ws, const int32_t* rows, int R, co
     const int nslab = (R + rps - 1) / rps;
     TM_SHM_ONCE(k_wide_dw, DW_SHM);
     for (int which = 0; which < 2; ++which) {
-        WideDwArgs q{which == 0 ? dgi : dgh, 3 * H, h, ld_h, which == 0 ? src : rows, which == 0 ? dst : nullptr, R, H, rps,
-                     slabs, bslabs};
+        WideDwArgs q{which == 0 ? dgi : dgh, 3 * H, nullptr, 3 * H, 0, h, ld_h, which == 0 ? src : rows,
+                     which == 0 ? dst : nullptr, R, H, rps, slabs, bslabs};
         hipLaunchKernelGGL(k_wide_dw, dim3(mt * nt, nslab), dim3(512), DW_SHM, st, q, mt, nt);
         int rc = check_launch("wide_dw");
         if (rc) return rc;
@@ -736,6 +803,124 @@ int tmpnn_wide_gru_bwd_weights(const void* dg_ws, const int32_t* rows, int R, co
             return rc;
         if ((rc = launch_reduce_slabs(bslabs, (size_t)3 * H, nslab, which == 0 ? db_ih : db_hh, (size_t)3 * H, 1, st, fold)))
             return rc;
+    }
+    return TMPNN_OK;
+}
+
+// ---- det-side form of the W_ih products -------------------------------------------------------------------
+static int gates4_blocks(int R, int H) {
+    long blocks = ((long)R * (H / 4) + 255) / 256;
+    if (blocks > 256L * 32) blocks = 256L * 32;
+    return (int)(blocks < 1 ? 1 : blocks);
+}
+// floats: dg4 [N][4H] | S [Dn][3H] | dn slabs [nb][H] | dW slabs + bias slabs | fold
+static void diff_ws_layout(int N, int R, int Dn, int H, size_t* o_S, size_t* o_dn, size_t* o_slabs, size_t* o_bslabs,
+                           size_t* o_fold, size_t* total) {
+    const int nb = gates4_blocks(R, H);
+    const int n_e = dw_slabs(R, H), n_d = dw_slabs(Dn, H);
+    const int n = n_e > n_d ? n_e : n_d;
+    size_t fold = reduce_slabs_ws_floats(n, (size_t)3 * H * H);
+    const size_t f2 = reduce_slabs_ws_floats(nb, (size_t)H);
+    if (f2 > fold) fold = f2;
+    auto up = [](size_t v) { return (v + 63) / 64 * 64; };          // 256-byte aligned sections
+    size_t o = 0;
+    o += up((size_t)N * 4 * H);          *o_S = o;
+    o += up((size_t)Dn * 3 * H);         *o_dn = o;
+    o += up((size_t)nb * H);             *o_slabs = o;
+    o += up((size_t)n * 3 * H * H);      *o_bslabs = o;
+    o += up((size_t)n * 3 * H);          *o_fold = o;
+    o += up(fold);
+    *total = o;
+}
+
+size_t tmpnn_wide_gru_bwd_diff_ws(int N, int R, int Dn, int H) {
+    if (N <= 0 || R <= 0 || Dn <= 0 || !tmpnn_wide_supported(H, H)) return 0;
+    size_t a, b, c, d, e, total;
+    diff_ws_layout(N, R, Dn, H, &a, &b, &c, &d, &e, &total);
+    return sizeof(float) * total;
+}
+
+/* Whole backward of a wide EDGE cell whose input is the diff message x[e] = h[src e] - h[dst e], with both W_ih products
+ * taken on the DET side by linearity (the backward twin of the forward's projected det rows):
+ *     S[d] = sum_{e: src = d} d_gi[e] - sum_{e: dst = d} d_gi[e]            (signed segment sum over the det's CSR run)
+ *     message adjoint   d_h[det_row[d]] += S[d] W_ih          instead of  d_x = d_gi W_ih per edge + its segment sum
+ *     dW_ih += S^T h[det rows]                                 instead of  d_gi^T (h[src] - h[dst]) over the edges
+ * i.e. two of the four (R x 3H x H) products run over Dn rows instead of E (C5: 15 000 instead of 4.4 M).
+ * d_h[edge_row[e]] = dh z + d_gh W_hh (plain store), dW_hh += d_gh^T h[edge rows], db_ih / db_hh += column sums. */
+int tmpnn_wide_gru_bwd_diff(const void* prep, const tmpnn_graph* g, const float* h, int ld_h, int H, const float* gates,
+                            size_t gate_plane, const float* d_hout, int ld_dhout, const float* dy, const float* w_head,
+                            float* d_h, int ld_dh, float* dW_ih, float* dW_hh, float* db_ih, float* db_hh, void* ws,
+                            size_t ws_bytes, tmpnn_stream stream) {
+    TM_REQUIRE(tmpnn_wide_supported(H, H), "wide_gru_bwd_diff: H=%d", H);
+    TM_REQUIRE(g != nullptr, "wide_gru_bwd_diff: graph is null");
+    const int N = g->N, R = g->E, Dn = g->Dn;
+    if (R == 0) return TMPNN_OK;
+    TM_REQUIRE(N > 0 && Dn > 0 && (long)R + Dn == N && g->edge_row && g->det_row && g->rowptr && g->inc,
+               "wide_gru_bwd_diff: graph arrays (N=%d E=%d Dn=%d)", N, R, Dn);
+    TM_REQUIRE(prep && h && gates && d_h && dW_ih && dW_hh && db_ih && db_hh && ws, "wide_gru_bwd_diff: null pointer");
+    TM_REQUIRE(d_hout != nullptr || dy != nullptr, "wide_gru_bwd_diff: no upstream gradient");
+    TM_REQUIRE(dy == nullptr || (w_head != nullptr && aligned16(w_head)), "wide_gru_bwd_diff: dy needs a 16-byte aligned w_head");
+    TM_REQUIRE(aligned16(prep) && aligned16(h) && aligned16(gates) && aligned16(d_h) && aligned16(ws) && (ld_h & 3) == 0 &&
+                   ld_h >= H && (ld_dh & 3) == 0 && ld_dh >= H && (gate_plane & 3) == 0 && gate_plane >= (size_t)H &&
+                   (d_hout == nullptr || (aligned16(d_hout) && (ld_dhout & 3) == 0)),
+               "wide_gru_bwd_diff: layout (16-byte alignment)");
+    size_t oS, odn, oslabs, obslabs, ofold, total;
+    diff_ws_layout(N, R, Dn, H, &oS, &odn, &oslabs, &obslabs, &ofold, &total);
+    if (ws_bytes < sizeof(float) * total)
+        return set_error(TMPNN_EWORKSPACE, "wide_gru_bwd_diff: workspace %zu < %zu bytes", ws_bytes, sizeof(float) * total);
+    hipStream_t st = as_stream(stream);
+    float* base = reinterpret_cast<float*>(ws);
+    float* dg4 = base;
+    float* S = base + oS;
+    float* dn_slabs = base + odn;
+    float* slabs = base + oslabs;
+    float* bslabs = base + obslabs;
+    float* fold = base + ofold;
+    int rc;
+    // 1. gate gradients, once: dg4[row] = [dr | dz | dn | dn r], d_h[row] = dh z, column sums of dn
+    const int nb = gates4_blocks(R, H);
+    WideBwdArgs b{g->edge_row, R, H, h, ld_h, gates, gate_plane, d_hout, ld_dhout, dy, w_head, dg4, nullptr, d_h, ld_dh};
+    hipLaunchKernelGGL(k_wide_gates_bwd4, dim3(nb), dim3(256), 0, st, b, dn_slabs);
+    if ((rc = check_launch("wide_gates_bwd4"))) return rc;
+    if ((rc = launch_reduce_slabs(dn_slabs, (size_t)H, nb, db_ih + 2 * H, (size_t)H, 1, st, fold))) return rc;
+    // 2. d_h[edge rows] += d_gh W_hh   (d_gh = image columns 0..2H and 3H..4H)
+    const uint16_t* f_hh = reinterpret_cast<const uint16_t*>(prep);
+    const uint16_t* b_ih = f_hh + (size_t)3 * H * 3 * H + (size_t)3 * H * 3 * H;
+    const uint16_t* b_hh = b_ih + (size_t)3 * 3 * H * H;
+    WideArgs y{};
+    y.A = dg4; y.lda = 4 * H; y.a_rows = g->edge_row; y.R = R; y.K = 3 * H; y.kskip_at = 2 * H; y.kskip = H;
+    y.img = b_hh; y.N = H; y.C = d_h; y.ldc = ld_dh; y.c_rows = g->edge_row; y.accumulate = 1;
+    if ((rc = launch_store(y, st))) return rc;
+    // 3. S[d] = signed segment sum of d_gi (image columns 0..3H) over the det's incident edges, compact rows
+    for (int k = 0; k < 3; ++k)
+        if ((rc = tmpnn_segsum_fwd(g, dg4 + (size_t)k * H, 4 * H, S + (size_t)k * H, 3 * H, H, 0, 1, stream))) return rc;
+    // 4. message adjoint on the det rows: d_h[det_row[d]] += S[d] W_ih
+    WideArgs x{};
+    x.A = S; x.lda = 3 * H; x.a_rows = nullptr; x.R = Dn; x.K = 3 * H; x.kskip_at = 3 * H; x.kskip = 0;
+    x.img = b_ih; x.N = H; x.C = d_h; x.ldc = ld_dh; x.c_rows = g->det_row; x.accumulate = 1;
+    if ((rc = launch_store(x, st))) return rc;
+    // 5. weight gradients: dW_hh over the edge rows (bias sums: db_hh, and db_ih's r / z thirds), dW_ih over the det rows
+    const int mt = 3 * H / 192, nt = H / 128;
+    TM_SHM_ONCE(k_wide_dw, DW_SHM);
+    {
+        const int n = dw_slabs(R, H);
+        const int rps = ((R + n - 1) / n + 31) / 32 * 32;
+        const int nslab = (R + rps - 1) / rps;
+        WideDwArgs q{dg4, 4 * H, g->edge_row, 2 * H, H, h, ld_h, g->edge_row, nullptr, R, H, rps, slabs, bslabs};
+        hipLaunchKernelGGL(k_wide_dw, dim3(mt * nt, nslab), dim3(512), DW_SHM, st, q, mt, nt);
+        if ((rc = check_launch("wide_dw"))) return rc;
+        if ((rc = launch_reduce_slabs(slabs, (size_t)3 * H * H, nslab, dW_hh, (size_t)3 * H * H, 1, st, fold))) return rc;
+        if ((rc = launch_reduce_slabs(bslabs, (size_t)3 * H, nslab, db_hh, (size_t)3 * H, 1, st, fold))) return rc;
+        if ((rc = launch_reduce_slabs(bslabs, (size_t)3 * H, nslab, db_ih, (size_t)2 * H, 1, st, fold))) return rc;
+    }
+    {
+        const int n = dw_slabs(Dn, H);
+        const int rps = ((Dn + n - 1) / n + 31) / 32 * 32;
+        const int nslab = (Dn + rps - 1) / rps;
+        WideDwArgs q{S, 3 * H, nullptr, 3 * H, 0, h, ld_h, g->det_row, nullptr, Dn, H, rps, slabs, bslabs};
+        hipLaunchKernelGGL(k_wide_dw, dim3(mt * nt, nslab), dim3(512), DW_SHM, st, q, mt, nt);
+        if ((rc = check_launch("wide_dw"))) return rc;
+        if ((rc = launch_reduce_slabs(slabs, (size_t)3 * H * H, nslab, dW_ih, (size_t)3 * H * H, 1, st, fold))) return rc;
     }
     return TMPNN_OK;
 }

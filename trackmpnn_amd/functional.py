@@ -26,6 +26,9 @@ ATT_DROPOUT_P = 0.5
 # environment variable TMPNN_INPLACE_GRADS=1 for every module.  Default: off -- real gradients are returned.
 INPLACE_GRADS = os.environ.get('TMPNN_INPLACE_GRADS', '0') == '1'
 WIDE_DW = os.environ.get('TMPNN_WIDE_DW', '1') == '1'        # wide cells: dW from the materialised gate gradients
+# wide cells: both W_ih products of the backward on the DET side (linearity of the diff message, tmpnn_wide_gru_bwd_diff);
+# TMPNN_WIDE_DET=0 keeps the per-edge products (tmpnn_wide_gru_bwd_data + _weights + the message adjoint's segment sum)
+WIDE_DET = os.environ.get('TMPNN_WIDE_DET', '1') == '1'
 FUSED_BWD = os.environ.get('TMPNN_FUSED_BWD', '1') == '1'     # one-pass cell backward (see mp_backward)
 # H = 128 / 256 edge cells as LDS-tiled bf16x6 GEMMs (csrc/wide.hip); TMPNN_WIDE=0 keeps round 1's f32-MFMA kernels
 WIDE = os.environ.get('TMPNN_WIDE', '1') != '0' and os.environ.get('TMPNN_SPLIT', '1')[:1] != '0'
@@ -393,7 +396,19 @@ def mp_backward(spec: ModelSpec, plan: CallPlan, saved: dict, P: Dict[str, torch
                       ws_w.data_ptr(), ws_w.numel() * 4, st)
             # edge GRU backward: d_ns -> dmsg[edge rows, 0:IN_e], d_hcat[edge rows]; without attention the
             # adjoint of the edge -> node sum (d_es[src] - d_es[dst], read from dmsg's det rows) rides along
-            if saved.get('wide'):
+            wide_det = bool(saved.get('wide')) and WIDE_DET
+            if wide_det:
+                # whole edge-cell backward in one call; the message adjoint lands on d_hcat's det rows directly
+                wsb = int(lib.tmpnn_wide_gru_bwd_diff_ws(N, E, Dn, H))
+                ws_wide = _wide_workspace(wsb, dev)
+                _lib.call('tmpnn_wide_gru_bwd_diff', saved['wide'][gi].data_ptr(), g.cref(), hg, GH, H, gp, plane, dog, GH,
+                          dyp, we, dhg, GH,
+                          grads[f + 'edge_gru.weight_ih'].data_ptr(), grads[f + 'edge_gru.weight_hh'].data_ptr(),
+                          grads[f + 'edge_gru.bias_ih'].data_ptr(), grads[f + 'edge_gru.bias_hh'].data_ptr(),
+                          ws_wide.data_ptr(), wsb, st)
+                if fuse:
+                    _lib.call('tmpnn_gather_diff_fwd', g.cref(), dmsg.data_ptr(), IN_e, dhg, GH, H, 1, st)
+            elif saved.get('wide'):
                 wsb = int(lib.tmpnn_wide_gru_bwd_data_ws(E, H))
                 ws_wide = _wide_workspace(wsb, dev)
                 _lib.call('tmpnn_wide_gru_bwd_data', saved['wide'][gi].data_ptr(), g.edge_row.data_ptr(), E, hg, GH, H,
@@ -406,7 +421,9 @@ def mp_backward(spec: ModelSpec, plan: CallPlan, saved: dict, P: Dict[str, torch
                       gp, plane, dog, GH, dyp, we, dmsg.data_ptr(), IN_e, dhg, GH,
                       g.src.data_ptr() if fuse else None, g.dst.data_ptr() if fuse else None,
                       dmsg.data_ptr() if fuse else None, IN_e, st)
-            if saved.get('wide') and WIDE_DW:
+            if wide_det:
+                pass
+            elif saved.get('wide') and WIDE_DW:
                 # ... and the weight gradient from the gate gradients that call left in its workspace
                 ws2b = int(lib.tmpnn_wide_gru_bwd_weights_ws(E, H))
                 ws2 = _wide_workspace(ws2b, dev, slot=1)
@@ -440,9 +457,10 @@ def mp_backward(spec: ModelSpec, plan: CallPlan, saved: dict, P: Dict[str, torch
                 else:
                     grads[f + f'gat.{k}.W_att'] = dW[k]
                     grads[f + f'gat.{k}.a'] = da[k].reshape(-1, 1)
-        # adjoint of the node -> edge message: into d_hcat[det rows]
+        # adjoint of the node -> edge message: into d_hcat[det rows] (the det-side wide backward has already put it there)
         name = 'tmpnn_gather_concat_bwd' if spec.msg_type == 'concat' else 'tmpnn_gather_diff_bwd'
-        _lib.call(name, g.cref(), dmsg.data_ptr(), IN_e, dhg, GH, H, 1, st)
+        if not (not use_fused_bwd and saved.get('wide') and WIDE_DET):
+            _lib.call(name, g.cref(), dmsg.data_ptr(), IN_e, dhg, GH, H, 1, st)
 
     d_x = None
     if n > 0:
