@@ -439,6 +439,85 @@ def check_attention(H, K, training, g, gd):
     return res
 
 
+def check_wide(H, g, gd):
+    """Wide edge cell (csrc/wide.hip), diff message: forward through the projected det rows, then BOTH backward forms --
+    per-edge products (tmpnn_wide_gru_bwd_data + _weights + the message adjoint's segment sum) and the det-side form
+    (tmpnn_wide_gru_bwd_diff) -- against autograd on the CPU."""
+    torch.manual_seed(1000 + H)
+    ld = 2 * H
+    hfull = torch.randn(g.N, ld)
+    hleaf = hfull[:, H:2 * H].clone().requires_grad_(True)
+    rows, dets = idx(g.edge_row), idx(g.det_row)
+    src, dst = idx(g.src), idx(g.dst)
+    R, Dn = rows.numel(), dets.numel()
+    sc = 1.0 / H ** 0.5
+    wih = (sc * torch.randn(3 * H, H)).requires_grad_(True)
+    whh = (sc * torch.randn(3 * H, H)).requires_grad_(True)
+    bih = (0.3 * torch.randn(3 * H)).requires_grad_(True)
+    bhh = (0.3 * torch.randn(3 * H)).requires_grad_(True)
+    out, (r, z, n, hn) = gru_ref(hleaf[src] - hleaf[dst], hleaf[rows], wih, whh, bih, bhh)
+    dout = torch.randn(R, H)
+    out.backward(dout)
+    d = lambda t: t.detach().to(DEV).contiguous()
+    hD = d(hfull)
+    lib = _lib.load()
+    prep = torch.empty(int(lib.tmpnn_wide_prep_bytes(H, H)), dtype=torch.uint8, device=DEV)
+    wihD, whhD, bihD, bhhD = d(wih), d(whh), d(bih), d(bhh)
+    _lib.call('tmpnn_wide_prepare', wihD.data_ptr(), whhD.data_ptr(), H, H, prep.data_ptr(), st())
+    P = torch.empty(Dn, 3 * H, device=DEV)
+    outD = torch.zeros(g.N, ld, device=DEV)
+    gates = torch.zeros(4, g.N, H, device=DEV)
+    _lib.call('tmpnn_wide_gru_fwd', prep.data_ptr(), gd.det_row.data_ptr(), Dn, gd.edge_row.data_ptr(), R,
+              gd.src_pos.data_ptr(), gd.dst_pos.data_ptr(), hD.data_ptr() + 4 * H, ld, H, bihD.data_ptr(), bhhD.data_ptr(),
+              P.data_ptr(), outD.data_ptr() + 4 * H, ld, gates.data_ptr(), g.N * H, st())
+    res = {'fwd': (outD.cpu()[rows, H:2 * H] - out.detach()).abs().max().item()}
+    gc = gates.cpu()
+    res['gates'] = max((gc[i][rows] - t.detach()).abs().max().item() for i, t in enumerate((r, z, n, hn)))
+    doutD = torch.zeros(g.N, ld, device=DEV)
+    doutD[gd.edge_row.long(), H:2 * H] = dout.to(DEV)
+    pre = torch.randn(g.N, H)                  # what the det rows of d_h hold before the call (the node cell's gradient)
+    ref_dh = hleaf.grad.clone()
+    ref_dh[dets] += pre[dets]
+    gsc = lambda t: max(1.0, t.abs().max().item())
+
+    def fresh():
+        dh = torch.full((g.N, ld), 7.0, device=DEV)
+        dh[gd.det_row.long(), H:2 * H] = pre[dets].to(DEV)
+        return dh, [torch.zeros(3 * H, H, device=DEV), torch.zeros(3 * H, H, device=DEV),
+                    torch.zeros(3 * H, device=DEV), torch.zeros(3 * H, device=DEV)]
+
+    def compare(tag, dh, gr):
+        res[tag + ' d_h'] = (dh.cpu()[:, H:2 * H] - ref_dh).abs().max().item() / gsc(ref_dh)
+        res[tag + ' untouched'] = (dh.cpu()[:, :H] - 7.0).abs().max().item()
+        for nm, a, b in zip(('dW_ih', 'dW_hh', 'db_ih', 'db_hh'), gr, (wih, whh, bih, bhh)):
+            res[f'{tag} {nm}'] = (a.cpu() - b.grad).abs().max().item() / gsc(b.grad)
+
+    # det-side form
+    dh, gr = fresh()
+    wsb = int(lib.tmpnn_wide_gru_bwd_diff_ws(g.N, R, Dn, H))
+    ws = torch.empty(wsb // 4 + 1, device=DEV)
+    _lib.call('tmpnn_wide_gru_bwd_diff', prep.data_ptr(), gd.cref(), hD.data_ptr() + 4 * H, ld, H, gates.data_ptr(), g.N * H,
+              doutD.data_ptr() + 4 * H, ld, None, None, dh.data_ptr() + 4 * H, ld, gr[0].data_ptr(), gr[1].data_ptr(),
+              gr[2].data_ptr(), gr[3].data_ptr(), ws.data_ptr(), wsb, st())
+    compare('det-side', dh, gr)
+    # per-edge form
+    dh, gr = fresh()
+    wsb = int(lib.tmpnn_wide_gru_bwd_data_ws(R, H))
+    ws = torch.empty(wsb // 4 + 1, device=DEV)
+    dmsg = torch.zeros(g.N, H, device=DEV)
+    _lib.call('tmpnn_wide_gru_bwd_data', prep.data_ptr(), gd.edge_row.data_ptr(), R, hD.data_ptr() + 4 * H, ld, H,
+              gates.data_ptr(), g.N * H, doutD.data_ptr() + 4 * H, ld, None, None, dmsg.data_ptr(), H,
+              dh.data_ptr() + 4 * H, ld, ws.data_ptr(), wsb, st())
+    _lib.call('tmpnn_gather_diff_bwd', gd.cref(), dmsg.data_ptr(), H, dh.data_ptr() + 4 * H, ld, H, 1, st())
+    ws2b = int(lib.tmpnn_wide_gru_bwd_weights_ws(R, H))
+    ws2 = torch.empty(ws2b // 4 + 1, device=DEV)
+    _lib.call('tmpnn_wide_gru_bwd_weights', ws.data_ptr(), gd.edge_row.data_ptr(), R, gd.src.data_ptr(), gd.dst.data_ptr(),
+              hD.data_ptr() + 4 * H, ld, H, gr[0].data_ptr(), gr[1].data_ptr(), gr[2].data_ptr(), gr[3].data_ptr(),
+              ws2.data_ptr(), ws2b, st())
+    compare('per-edge', dh, gr)
+    return res
+
+
 def run_all(report=print):
     """Yield (name, worst error, tolerance) for every stage/width combination."""
     g = make_graph()
@@ -461,6 +540,9 @@ def run_all(report=print):
             r = check_gru(H, xmode, g, gd, kind)
             for k, v in r.items():
                 rec(f'gru H={H} xmode={xmode} rows={kind} {k}', v, 0.0 if k == 'untouched' else 2e-4)
+    for H in (128, 256):
+        for k, v in check_wide(H, g, gd).items():
+            rec(f'wide cell H={H} {k}', v, 0.0 if k.endswith('untouched') else 2e-4)
     for C in (32, 64, 96, 192, 256, 768):
         for k, v in check_heads(C, g, gd).items():
             rec(f'heads C={C} {k}', v, 2e-4)
