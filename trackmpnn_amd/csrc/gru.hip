@@ -2355,6 +2355,383 @@ void k_gru_bwd_one(GruBwdFusedArgs a, int ntiles) {
     }
 }
 
+// ==========================================================================================
+// The one-pass backward at TWO waves per SIMD (k_gru_bwd_two): the same LDS images, the same products and slabs as
+// k_gru_bwd_one, but a block is eight 256-register waves, so that on every SIMD one wave's LDS reads, staging arithmetic
+// and waits run under the other's MFMAs (k_gru_bwd_one, one 512-register wave per SIMD, issues everything itself and its
+// parts add up).  What makes 256 registers enough:
+//   * waves 0-3 take the W_ih side (d_msg, dW_ih), waves 4-7 the W_hh side (d_h, dW_hh); wave q of a side owns 16 output
+//     columns of the data product on v_mfma_f32_16x16x32_bf16 (its W^T slice: 16 x 192 x three pieces = 72 registers,
+//     half of the 32-column slice) and three of the side's twelve 32 x 32 tiles of dW (48 registers);
+//   * a thread stages ONE row (32 rows x 16 threads), slice by slice between the MFMA groups; every plane is requested
+//     again right after the slice that consumed it last, so each load has 2/3 of a tile period or more to land and no
+//     second register set holds rows in flight;
+//   * operand fragments are read one MFMA group ahead at most.
+// The data product's row read of a [32][128] image takes the four 16-byte chunks {4 kq + s} (not {4 s + kq}) for k-step s,
+// lane group kq: all lanes of a ds_read_b128 service group then XOR the same chunk bits into the row swizzle and the read
+// is conflict-free (the plain assignment is 2-way on this layout); W's k order is permuted to match.
+// ==========================================================================================
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4 mfma16_bf16(const uint4& a, const uint4& b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+template <int C>
+__device__ __forceinline__ f32x4 mfma16_c(const uint4 (&a)[3], const uint4 (&b)[3], f32x4 acc) {
+    if (C == 0) return mfma16_bf16(a[2], b[0], acc);
+    if (C == 1) return mfma16_bf16(a[0], b[2], acc);
+    if (C == 2) return mfma16_bf16(a[1], b[1], acc);
+    if (C == 3) return mfma16_bf16(a[1], b[0], acc);
+    if (C == 4) return mfma16_bf16(a[0], b[1], acc);
+    return mfma16_bf16(a[0], b[0], acc);
+}
+template <int C>
+__device__ __forceinline__ f32x16 mfma32_c(const uint4 (&a)[3], const uint4 (&b)[3], f32x16 acc) {
+    if (C == 0) return mfma_bf16(a[2], b[0], acc);
+    if (C == 1) return mfma_bf16(a[0], b[2], acc);
+    if (C == 2) return mfma_bf16(a[1], b[1], acc);
+    if (C == 3) return mfma_bf16(a[1], b[0], acc);
+    if (C == 4) return mfma_bf16(a[0], b[1], acc);
+    return mfma_bf16(a[0], b[0], acc);
+}
+
+struct TwoRaw { float4 dh, r, z, n, hn, hp, xa, xb, ea, eb; float dy; };
+
+#ifndef TWO_SLEEP
+#define TWO_SLEEP 0        // stagger of the SIMD partners: waves 4-7 start every tile 64 * TWO_SLEEP cycles late
+#endif
+#ifndef TWO_SCHED
+#define TWO_SCHED 1     // 1: a group's staging slice sits between its operand reads and its MFMAs with no scheduling fence (the
+                        // compiler spreads it under the MFMAs: 2.10 -> 2.00 ms per 3 M rows); 0: fenced, slice after the MFMAs
+#endif
+#ifndef TWO_EXP
+#define TWO_EXP 0          // build-time elimination experiments (1: no global requests, 2: no staging, 4: no MFMAs)
+#endif
+template <int XMODE, int UP, bool FUSE>
+__global__ __launch_bounds__(512) void k_gru_bwd_two(GruBwdFusedArgs a, int ntiles) {
+    constexpr int exp_ = TWO_EXP;
+    constexpr int H = 64;
+    constexpr int SUB = 32 * 128;
+    constexpr int PA = 2 * SUB, PB = SUB;
+    constexpr int OFF_B = 3 * PA, OFF_E = OFF_B + 3 * PB;
+    constexpr int BUF = OFF_E + 32 * 64 * 2;       // 80 KiB per buffer (uint16 elements)
+    extern __shared__ float lds[];
+    uint16_t* const lds16 = reinterpret_cast<uint16_t*>(lds);
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int srow = tid >> 4, f4 = (tid & 15) * 4;          // staging: one row, four columns
+    const int role = wave >> 2, q = wave & 3;                 // role 0: W_ih side, 1: W_hh side
+    // ---- data product (16x16x32): lane (j = tile row within a 16-row half, kq = k group)
+    const int j16 = lane & 15, kq = lane >> 4;
+    const int n0 = 16 * q;
+    uint4 wq[6][3];
+    {
+        const float* W = role == 0 ? a.w_ih : a.w_hh;
+#pragma unroll
+        for (int s6 = 0; s6 < 6; ++s6) {
+            const int ch = s6 < 4 ? 4 * kq + s6 : 16 + 4 * (s6 - 4) + kq;      // 8-column chunk of the 192 gate columns
+            float v[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = W[(size_t)(8 * ch + i) * H + n0 + j16];
+            const Split8 sp = split8_arr(v);
+            wq[s6][0] = sp.p1; wq[s6][1] = sp.p2; wq[s6][2] = sp.p3;
+        }
+    }
+    const float headl = (UP & 2) ? a.up.w_head[lane] : 0.f;   // w_head[lane]; a thread's four come by ds_bpermute in slice 0
+    const int st0 = dui_off(srow, f4);                         // columns 64 + f4: st0 ^ 64
+    const int se0 = srow * 64 + (((f4 >> 2) ^ (srow & 15)) << 2);
+    // row reads of the data product: rows j16 and 16 + j16 share the swizzle
+    const int swzj = dui_swz(j16), rowj = j16 * 128;
+    const int hix = role == 0 ? 0 : 64;                        // d_h takes dn*r (image columns 192..255) for the n gate
+    // ---- weight gradient (32x32x16, transposed reads): A tiles jt0 + {0,1,2} of the side's six, operand tile t
+    const int half = lane >> 5, c32 = lane & 31;
+    const int jt0 = (q >> 1) * 3, tt = q & 1;
+    const int i16 = lane & 15, tq = i16 >> 2, tp = i16 & 3, tg = (lane >> 4) & 1;
+    const int trow = (8 * half + tq) * 128, tsw0 = (tq << 2) | (2 * half);
+    int offA[3], offB;                                         // second read of a pair: (off ^ 8) + 4 * 128
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const int jj0 = (jt0 + j) * 32;
+        const int col = (role == 1 && jj0 >= 2 * H) ? jj0 + H : jj0;
+        const int ch = ((col & 127) >> 3) + 2 * tg + (tp >> 1);
+        offA[j] = (col >> 7) * SUB + trow + ((ch ^ tsw0) << 3) + 4 * (tp & 1);
+    }
+    {
+        const int ch = ((role * H + tt * 32) >> 3) + 2 * tg + (tp >> 1);
+        offB = OFF_B + trow + ((ch ^ tsw0) << 3) + 4 * (tp & 1);
+    }
+    f32x16 acc[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[j][i] = 0.f;
+    float bsum[3] = {0.f, 0.f, 0.f};
+
+    const int G = gridDim.x;
+    const int nmine = (ntiles - (int)blockIdx.x + G - 1) / G;       // >= 1
+    TwoRaw raw;
+    float d0[4], tv[4];
+    // ids: a tile's row id is needed for its own planes (requested one tile ahead of its staging), its endpoints for the
+    // gathers (requested half a tile ahead)
+    auto row_of = [&](int tile, bool tvld, bool& vld) -> int {
+        const int lr = tile * 32 + srow;
+        vld = tvld && lr < a.R;
+        return vld ? lr : a.R - 1;
+    };
+    // ---- the six staging slices of one row; what a slice consumes last is requested again right behind it
+#define TWO_SLICE(SL, img, vld)                                                                              \
+    do {                                                                                                     \
+        float o_[4];                                                                                         \
+        if ((SL) == 0) {                                                                                     \
+            const float dh_[4] = {raw.dh.x, raw.dh.y, raw.dh.z, raw.dh.w}, r_[4] = {raw.r.x, raw.r.y, raw.r.z, raw.r.w}; \
+            const float z_[4] = {raw.z.x, raw.z.y, raw.z.z, raw.z.w}, n_[4] = {raw.n.x, raw.n.y, raw.n.z, raw.n.w}; \
+            const float hn_[4] = {raw.hn.x, raw.hn.y, raw.hn.z, raw.hn.w};                                   \
+            float q_[4];                                                                                     \
+            _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                  \
+                float d_ = (UP & 1) ? dh_[i] : 0.f;                                                          \
+                if (UP & 2) d_ += raw.dy * __shfl(headl, f4 + i);                                                        \
+                d0[i] = (vld) ? d_ : 0.f;                                                                    \
+                tv[i] = d0[i] * (1.0f - z_[i]) * (1.0f - n_[i] * n_[i]);                                     \
+                q_[i] = tv[i] * r_[i];                                                                       \
+                o_[i] = q_[i] * hn_[i] * (1.0f - r_[i]);                                                     \
+            }                                                                                                \
+            half_put((img), st0, PA, o_);                                                                    \
+            half_put((img), SUB + (st0 ^ 64), PA, q_);                                                       \
+        } else if ((SL) == 1) {                                                                              \
+            const float z_[4] = {raw.z.x, raw.z.y, raw.z.z, raw.z.w}, n_[4] = {raw.n.x, raw.n.y, raw.n.z, raw.n.w}; \
+            const float hp_[4] = {raw.hp.x, raw.hp.y, raw.hp.z, raw.hp.w};                                   \
+            float e_[4];                                                                                     \
+            _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                  \
+                o_[i] = d0[i] * (hp_[i] - n_[i]) * z_[i] * (1.0f - z_[i]);                                   \
+                e_[i] = d0[i] * z_[i];                                                                       \
+            }                                                                                                \
+            half_put((img), st0 ^ 64, PA, o_);                                                               \
+            *reinterpret_cast<float4*>(reinterpret_cast<float*>((img) + OFF_E) + se0) = make_float4(e_[0], e_[1], e_[2], e_[3]); \
+        } else if ((SL) == 2) {                                                                              \
+            half_put((img), SUB + st0, PA, tv);                                                              \
+        } else if ((SL) == 3) {                                                                              \
+            const float hp_[4] = {raw.hp.x, raw.hp.y, raw.hp.z, raw.hp.w};                                   \
+            half_put((img) + OFF_B, st0 ^ 64, PB, hp_);                                                      \
+        } else if ((SL) == 5) {                                                                              \
+            const float xa_[4] = {raw.xa.x, raw.xa.y, raw.xa.z, raw.xa.w}, xb_[4] = {raw.xb.x, raw.xb.y, raw.xb.z, raw.xb.w}; \
+            _Pragma("unroll") for (int i = 0; i < 4; ++i) o_[i] = XMODE != 0 ? xa_[i] - xb_[i] : xa_[i];     \
+            half_put((img) + OFF_B, st0, PB, o_);                                                            \
+            if (FUSE) {                                                                                      \
+                float4* ep_ = reinterpret_cast<float4*>(reinterpret_cast<float*>((img) + OFF_E) + se0);      \
+                float4 e4_ = *ep_;                                                                           \
+                e4_.x += raw.ea.x - raw.eb.x; e4_.y += raw.ea.y - raw.eb.y;                                  \
+                e4_.z += raw.ea.z - raw.eb.z; e4_.w += raw.ea.w - raw.eb.w;                                  \
+                *ep_ = e4_;                                                                                  \
+            }                                                                                                \
+        }                                                                                                    \
+    } while (0)
+    // the planes slice SL consumed last, requested for row position lp (orow = a.rows[lp])
+#define TWO_ISSUE_MAIN(SL, orow_)                                                                            \
+    do {                                                                                                     \
+        const size_t gp_ = a.gate_plane;                                                                     \
+        const float* g0_ = a.gates + (size_t)(orow_) * H + f4;                                               \
+        if ((SL) == 0) {                                                                                     \
+            if (UP & 1) raw.dh = *reinterpret_cast<const float4*>(a.up.d_hout + (size_t)(orow_) * a.up.ld_dhout + f4); \
+            if (UP & 2) raw.dy = a.up.dy[(orow_)];                                                           \
+            raw.hn = *reinterpret_cast<const float4*>(g0_ + 3 * gp_);                                        \
+            raw.r = *reinterpret_cast<const float4*>(g0_);                                                   \
+        } else if ((SL) == 1) {                                                                              \
+            raw.n = *reinterpret_cast<const float4*>(g0_ + 2 * gp_);                                         \
+            raw.z = *reinterpret_cast<const float4*>(g0_ + gp_);                                             \
+        } else if ((SL) == 3) {                                                                              \
+            raw.hp = *reinterpret_cast<const float4*>(a.h + (size_t)(orow_) * a.ld_h + f4);                  \
+        }                                                                                                    \
+    } while (0)
+    // a row's gathers (its endpoints' rows / its message row), requested half a tile ahead of slice 5; the ids themselves
+    // (gs_, gd_) were fetched a tile earlier: a load chain inside the phase would drain every request in flight
+#define TWO_ISSUE_GATHER(gs_, gd_)                                                                           \
+    do {                                                                                                     \
+        if (XMODE == 0) raw.xa = *reinterpret_cast<const float4*>(a.msg + (size_t)(gs_) * a.ld_msg + f4);    \
+        if (XMODE != 0) {                                                                                    \
+            raw.xa = *reinterpret_cast<const float4*>(a.h + (size_t)(gs_) * a.ld_h + f4);                    \
+            raw.xb = *reinterpret_cast<const float4*>(a.h + (size_t)(gd_) * a.ld_h + f4);                    \
+            if (FUSE) {                                                                                      \
+                raw.ea = *reinterpret_cast<const float4*>(a.add_msg + (size_t)(gs_) * a.ld_add + f4);        \
+                raw.eb = *reinterpret_cast<const float4*>(a.add_msg + (size_t)(gd_) * a.ld_add + f4);        \
+            }                                                                                                \
+        }                                                                                                    \
+    } while (0)
+    // XMODE 0: gs = the message row (FUSE with XMODE 0 is not offered: the node cell has no fused adjoint)
+#define TWO_GATHER_IDS(lp_, gs_, gd_)                                                                        \
+    do {                                                                                                     \
+        if (XMODE == 0) { (gs_) = a.msg_compact ? (lp_) : a.rows[(lp_)]; (gd_) = 0; }                        \
+        else { (gs_) = a.src[(lp_)]; (gd_) = a.dst[(lp_)]; }                                                 \
+    } while (0)
+
+    // ---- prologue: tile 0 staged into buffer 0, tile 1's planes requested
+    bool valid_cur, valid_n;
+    int gs_cur, gd_cur;                           // endpoints (message row) of the tile being staged, for its gathers
+    int orow_n;                                   // row id of the tile after that (for its planes)
+    {
+        bool v0, v1;
+        const int lp0 = row_of(blockIdx.x, true, v0);
+        const int o0 = a.rows[lp0];
+        TWO_GATHER_IDS(lp0, gs_cur, gd_cur);
+        TWO_ISSUE_MAIN(0, o0); TWO_ISSUE_MAIN(1, o0); TWO_ISSUE_MAIN(3, o0); TWO_ISSUE_GATHER(gs_cur, gd_cur);
+        const int lp1 = row_of(blockIdx.x + G, 1 < nmine, v1);
+        const int o1 = a.rows[lp1];
+        TWO_SLICE(0, lds16, v0); TWO_ISSUE_MAIN(0, o1);
+        TWO_SLICE(1, lds16, v0); TWO_ISSUE_MAIN(1, o1);
+        TWO_SLICE(2, lds16, v0);
+        TWO_SLICE(3, lds16, v0); TWO_ISSUE_MAIN(3, o1);
+        TWO_SLICE(5, lds16, v0);
+        valid_cur = v1;
+        TWO_GATHER_IDS(lp1, gs_cur, gd_cur);
+        const int lp2 = row_of(blockIdx.x + 2 * G, 2 < nmine, valid_n);
+        orow_n = a.rows[lp2];
+    }
+    // epilogue rows of tile 0: lane -> rows j16 and 16 + j16
+    int er0 = a.rows[min((int)blockIdx.x * 32 + j16, a.R - 1)], er1 = a.rows[min((int)blockIdx.x * 32 + 16 + j16, a.R - 1)];
+    bool el0 = (int)blockIdx.x * 32 + j16 < a.R, el1 = (int)blockIdx.x * 32 + 16 + j16 < a.R;
+    __syncthreads();
+
+    // The SIMD partners (waves w and w + 4: one of each side) are staggered by half a group: the W_hh side stages its slice
+    // BEFORE its MFMA group, the W_ih side after, so that one wave's staging arithmetic runs beside the other's MFMAs
+    // instead of both reaching the matrix pipe together (the slice writes the other buffer: any place in the phase is legal)
+#define TWO_STAGE(ROLE_)                                                                                     \
+    do {                                                                                                     \
+            if ((ROLE_) == 0) {                                                                                  \
+                if (!(exp_ & 2)) TWO_SLICE(s6, nxt, valid_cur);                                                  \
+                if (!(exp_ & 1)) {                                                                               \
+                    TWO_ISSUE_MAIN(s6, orow_n);                                                                  \
+                    if (s6 == 2) TWO_ISSUE_GATHER(gs_cur, gd_cur);  /* half a tile ahead of slice 5 (L2 hits mostly) */ \
+                }                                                                                                \
+                if (TWO_SCHED == 0) __builtin_amdgcn_sched_barrier(0);                                           \
+            }                                                                                             \
+    } while (0)
+    for (int it = 0; it < nmine; ++it) {
+        const int tile = blockIdx.x + it * G;
+        uint16_t* const cur = lds16 + (it & 1) * BUF;
+        uint16_t* const nxt = lds16 + ((it & 1) ^ 1) * BUF;
+        f32x4 accd[2];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { accd[0][i] = 0.f; accd[1][i] = 0.f; }
+#pragma unroll
+        for (int s6 = 0; s6 < 6; ++s6) {
+            const int kb = s6 / 3, j = s6 % 3;
+            uint4 bd[3], aw[3], bt[3];
+            const uint16_t* pd;
+            {
+                const int chunk = s6 < 4 ? 4 * kq + s6 : 4 * (s6 - 4) + kq;
+                int inrow = (chunk ^ swzj) << 3;
+                if (s6 >= 4) inrow ^= hix;
+                pd = cur + (s6 >= 4 ? SUB : 0) + rowj + inrow;
+            }
+            // the dW group first: its operands are dead once its six MFMAs have issued, and the row operand of the data
+            // product arrives under them (one operand set alive at a time)
+            {
+                const uint16_t* p0 = cur + kb * 2048 + offB;
+                const uint16_t* p1 = cur + kb * 2048 + (offB ^ 8) + 4 * 128;
+#pragma unroll
+                for (int pc = 0; pc < 3; ++pc) {
+                    const uint2 u0 = lds_read_tr(p0 + pc * PB), u1 = lds_read_tr(p1 + pc * PB);
+                    bt[pc] = make_uint4(u0.x, u0.y, u1.x, u1.y);
+                }
+            }
+            {
+                const uint16_t* p0 = cur + kb * 2048 + offA[j];
+                const uint16_t* p1 = cur + kb * 2048 + (offA[j] ^ 8) + 4 * 128;
+#pragma unroll
+                for (int pc = 0; pc < 3; ++pc) {
+                    const uint2 u0 = lds_read_tr(p0 + pc * PA), u1 = lds_read_tr(p1 + pc * PA);
+                    aw[pc] = make_uint4(u0.x, u0.y, u1.x, u1.y);
+                }
+            }
+            if (TWO_SCHED == 1) TWO_STAGE(0);
+            if (!(exp_ & 4)) {
+            acc[j] = mfma32_c<0>(aw, bt, acc[j]); acc[j] = mfma32_c<1>(aw, bt, acc[j]);
+            acc[j] = mfma32_c<2>(aw, bt, acc[j]); acc[j] = mfma32_c<3>(aw, bt, acc[j]);
+            acc[j] = mfma32_c<4>(aw, bt, acc[j]); acc[j] = mfma32_c<5>(aw, bt, acc[j]);
+            } else { acc[j][0] += __uint_as_float(aw[0].x ^ bt[0].x ^ aw[1].y ^ bt[1].y ^ aw[2].z ^ bt[2].z); }
+            if (tt == 0 && !(exp_ & 8)) {                       // bias gradient: column sums from the A operands
+#pragma unroll
+                for (int pc = 0; pc < 3; ++pc) {
+                    const uint4 v = aw[pc];
+                    bsum[j] = dot2_ones(v.x, bsum[j]); bsum[j] = dot2_ones(v.y, bsum[j]);
+                    bsum[j] = dot2_ones(v.z, bsum[j]); bsum[j] = dot2_ones(v.w, bsum[j]);
+                }
+            }
+            if (TWO_SCHED == 0) __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int pc = 0; pc < 3; ++pc) bd[pc] = *reinterpret_cast<const uint4*>(pd + pc * PA);
+            if (!(exp_ & 4)) {
+            accd[0] = mfma16_c<0>(wq[s6], bd, accd[0]); accd[0] = mfma16_c<1>(wq[s6], bd, accd[0]);
+            accd[0] = mfma16_c<2>(wq[s6], bd, accd[0]); accd[0] = mfma16_c<3>(wq[s6], bd, accd[0]);
+            accd[0] = mfma16_c<4>(wq[s6], bd, accd[0]); accd[0] = mfma16_c<5>(wq[s6], bd, accd[0]);
+            } else { accd[0][0] += __uint_as_float(bd[0].x ^ bd[1].y ^ bd[2].z); }
+            if (TWO_SCHED == 0) __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int pc = 0; pc < 3; ++pc) bd[pc] = *reinterpret_cast<const uint4*>(pd + pc * PA + 16 * 128);
+            if (!(exp_ & 4)) {
+            accd[1] = mfma16_c<0>(wq[s6], bd, accd[1]); accd[1] = mfma16_c<1>(wq[s6], bd, accd[1]);
+            accd[1] = mfma16_c<2>(wq[s6], bd, accd[1]); accd[1] = mfma16_c<3>(wq[s6], bd, accd[1]);
+            accd[1] = mfma16_c<4>(wq[s6], bd, accd[1]); accd[1] = mfma16_c<5>(wq[s6], bd, accd[1]);
+            } else { accd[1][0] += __uint_as_float(bd[0].x ^ bd[1].y ^ bd[2].z); }
+            if (TWO_SCHED == 0) __builtin_amdgcn_sched_barrier(0);
+            // ---- staging slice s6 of the next tile; what it freed is requested for the tile after that
+            if (TWO_SCHED == 0) TWO_STAGE(0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // the staged tile's successor becomes the tile being staged; its successor's row id is fetched
+        {
+            bool vnn;
+            const int lp2 = row_of(tile + 2 * G, it + 2 < nmine, vnn);
+            TWO_GATHER_IDS(lp2, gs_cur, gd_cur);
+            valid_cur = valid_n;
+            const int lp3 = row_of(tile + 3 * G, it + 3 < nmine, valid_n);
+            orow_n = a.rows[lp3];
+            (void)vnn;
+        }
+        // ---- epilogue: lane (j16, kq) holds columns n0 + 4 kq .. + 3 of rows j16 and 16 + j16
+        if (role == 0) {
+            if (el0) *reinterpret_cast<float4*>(a.d_msg + (size_t)er0 * a.ld_dmsg + n0 + 4 * kq) =
+                         make_float4(accd[0][0], accd[0][1], accd[0][2], accd[0][3]);
+            if (el1) *reinterpret_cast<float4*>(a.d_msg + (size_t)er1 * a.ld_dmsg + n0 + 4 * kq) =
+                         make_float4(accd[1][0], accd[1][1], accd[1][2], accd[1][3]);
+        } else {
+            const float* e = reinterpret_cast<const float*>(cur + OFF_E);
+            const int cq = (n0 + 4 * kq) >> 2;
+            const float4 x0 = *reinterpret_cast<const float4*>(e + j16 * 64 + ((cq ^ j16) << 2));
+            const float4 x1 = *reinterpret_cast<const float4*>(e + (16 + j16) * 64 + ((cq ^ j16) << 2));
+            if (el0) *reinterpret_cast<float4*>(a.d_h + (size_t)er0 * a.ld_dh + n0 + 4 * kq) =
+                         make_float4(accd[0][0] + x0.x, accd[0][1] + x0.y, accd[0][2] + x0.z, accd[0][3] + x0.w);
+            if (el1) *reinterpret_cast<float4*>(a.d_h + (size_t)er1 * a.ld_dh + n0 + 4 * kq) =
+                         make_float4(accd[1][0] + x1.x, accd[1][1] + x1.y, accd[1][2] + x1.z, accd[1][3] + x1.w);
+        }
+        er0 = a.rows[min((tile + G) * 32 + j16, a.R - 1)]; er1 = a.rows[min((tile + G) * 32 + 16 + j16, a.R - 1)];
+        el0 = (it + 1 < nmine) && ((tile + G) * 32 + j16 < a.R);
+        el1 = (it + 1 < nmine) && ((tile + G) * 32 + 16 + j16 < a.R);
+        __syncthreads();
+        if (TWO_SLEEP > 0 && role == 1) __builtin_amdgcn_s_sleep(TWO_SLEEP);
+    }
+#undef TWO_STAGE
+#undef TWO_GATHER_IDS
+#undef TWO_ISSUE_GATHER
+#undef TWO_ISSUE_MAIN
+#undef TWO_SLICE
+    // ---- one slab per block: [3H][IN+H] weights, then [2][3H] biases
+    float* sw = a.slab_w + (size_t)blockIdx.x * (3 * H) * (2 * H);
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const int jj = (jt0 + j) * 32 + acc_row(reg, half);
+            sw[(size_t)jj * (2 * H) + role * H + tt * 32 + c32] = acc[j][reg];
+        }
+    if (tt == 0) {
+        float* sb = a.slab_b + (size_t)blockIdx.x * 6 * H;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const float tot = bsum[j] + __shfl_xor(bsum[j], 32);
+            if (half == 0) sb[role * 3 * H + (jt0 + j) * 32 + c32] = tot;
+        }
+    }
+}
+
 // dW_ih[j][k] += sum_rs slab[rs][j][k], k < IN ; dW_hh[j][k-IN] += ... ; biases likewise
 __global__ void k_gru_reduce_w(const float* __restrict__ slab_w, const float* __restrict__ slab_b, int n_rs,
                                int IN, int H, float* __restrict__ dW_ih, float* __restrict__ dW_hh,
@@ -2624,6 +3001,13 @@ static int weights_chunk_slabs(int R, int IN, int H) {
 }
 
 
+// the one-pass backward's form: eight 256-register waves per block (k_gru_bwd_two) or four 512-register waves
+// (k_gru_bwd_one); a constant of the process (TMPNN_BWD_TWO), never a measurement
+static bool fused_two_waves() {
+    static const bool v = [] { const char* e = getenv("TMPNN_BWD_TWO"); return e == nullptr || e[0] != '0'; }();
+    return v;
+}
+
 static int fused_blocks(int R) {
     const int ntiles = ceil_div(R, 32);
     return ntiles < 256 ? ntiles : 256;
@@ -2694,8 +3078,13 @@ int tmpnn_gru_bwd_fused(const int32_t* rows, int R, int xmode, const int32_t* sr
     const bool fuse = add_msg != nullptr;
 #define LF(X, U, F)                                                                                          \
     do {                                                                                                     \
-        TM_SHM_ONCE((k_gru_bwd_one<X, U, F>), shm);                                                          \
-        hipLaunchKernelGGL((k_gru_bwd_one<X, U, F>), dim3(n_rs), dim3(256), shm, st, a, ntiles);             \
+        if (fused_two_waves() && !((X) == 0 && (F))) {     /* (message cell + fused adjoint: four-wave form only) */ \
+            TM_SHM_ONCE((k_gru_bwd_two<X, U, F>), shm);                                                      \
+            hipLaunchKernelGGL((k_gru_bwd_two<X, U, F>), dim3(n_rs), dim3(512), shm, st, a, ntiles);         \
+        } else {                                                                                             \
+            TM_SHM_ONCE((k_gru_bwd_one<X, U, F>), shm);                                                      \
+            hipLaunchKernelGGL((k_gru_bwd_one<X, U, F>), dim3(n_rs), dim3(256), shm, st, a, ntiles);         \
+        }                                                                                                    \
     } while (0)
 #define LU(X, F) do { if (up == 1) LF(X, 1, F); else if (up == 2) LF(X, 2, F); else LF(X, 3, F); } while (0)
     if (xmode == 0) { if (fuse) LU(0, true); else LU(0, false); }
