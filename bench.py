@@ -195,7 +195,8 @@ def _pmc_kernel(stage):
         return {'gru_fwd_edge': 'k_gru_fwd_split<64, 8>', 'gru_bwd_data_edge': 'k_gru_bwd_data_split<64, 1, false>',
                 'gru_bwd_data_edge_folded': 'k_gru_bwd_data_split<64, 3, true>',
                 'gru_bwd_weights_edge': 'k_gru_bwd_weights_split<1, 1>',
-                'gru_bwd_one_edge': 'k_gru_bwd_one<1, 3, true>'}.get(stage, '?')
+                'gru_bwd_one_edge': ('k_gru_bwd_one<1, 3, true>' if os.environ.get('TMPNN_BWD_TWO', '1')[:1] == '0'
+                                     else 'k_gru_bwd_two<1, 3, true>')}.get(stage, '?')
     return {'gru_fwd_edge': 'k_gru_fwd_lds<64, 64, 3,', 'gru_bwd_data_edge': 'k_gru_bwd_data_lds<64, 64, 1, false>',
             'gru_bwd_data_edge_folded': 'k_gru_bwd_data_lds<64, 64, 3, true>',
             'gru_bwd_weights_edge': 'k_gru_bwd_weights_lds<64, 1, 1>'}.get(stage, '?')
@@ -477,7 +478,8 @@ def main():
                 f"together at {nbytes['gru_bwd_data_edge_folded'] / (t['gru_bwd_data_edge_folded'] * 1e6) / HBM_PEAK_GBS:.2f} / "
                 f"{nbytes['gru_bwd_weights_edge'] / (t['gru_bwd_weights_edge'] * 1e6) / HBM_PEAK_GBS:.2f} of the HBM peak): it moves "
                 f"{nbytes['gru_bwd_one_edge'] / 1e9:.1f} GB instead of {(nbytes['gru_bwd_data_edge_folded'] + nbytes['gru_bwd_weights_edge']) / 1e9:.1f} "
-                'and is bound by instruction issue (one 512-register wave per SIMD), not by HBM -- DESIGN.md section 4')
+                'and is bound by instruction issue and the matrix pipe (k_gru_bwd_two: two 256-register waves per SIMD; the '
+                'MFMAs alone hold the pipe for ~45 % of the kernel), not by HBM -- DESIGN.md section 4')
         extra['stage_graph'] = dict(N=plans[-1].graph.N, E=plans[-1].graph.E, Dn=plans[-1].graph.Dn)
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -27,7 +27,7 @@ d = json.loads(line)
 plain = json_line(f'gpurun_out/{tag}_bench_plain.json')
 open(f'profiles/{tag}_bench_line_unprofiled.json', 'w').write(plain)
 du = json.loads(plain)
-stage_kernel = {'gru_fwd_edge': 'k_gru_fwd_split<64, 8>', 'gru_bwd_one_edge': 'k_gru_bwd_one<1, 3, true>',
+stage_kernel = {'gru_fwd_edge': 'k_gru_fwd_split<64, 8>', 'gru_bwd_one_edge': 'k_gru_bwd_two<1, 3, true>',
                 'gru_bwd_data_edge_folded': 'k_gru_bwd_data_split<64, 3, true>',
                 'gru_bwd_data_edge': 'k_gru_bwd_data_split<64, 1, false>',
                 'gru_bwd_weights_edge': 'k_gru_bwd_weights_split<1, 1>',

@@ -13,7 +13,7 @@ agg=collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(R+'/gpurun_out/onepmc/*/**/*counter_collection.csv', recursive=True):
     for r in csv.DictReader(open(f)):
         k=r['Kernel_Name']
-        if 'bwd_one' in k or 'bwd_data_split' in k or 'bwd_weights_split' in k:
+        if 'bwd_one' in k or 'bwd_two' in k or 'bwd_data_split' in k or 'bwd_weights_split' in k:
             agg[k[:60]][r['Counter_Name']].append(float(r['Counter_Value']))
 for k,d in agg.items():
     print(k)

@@ -2396,9 +2396,6 @@ __device__ __forceinline__ f32x16 mfma32_c(const uint4 (&a)[3], const uint4 (&b)
 
 struct TwoRaw { float4 dh, r, z, n, hn, hp, xa, xb, ea, eb; float dy; };
 
-#ifndef TWO_SLEEP
-#define TWO_SLEEP 0        // stagger of the SIMD partners: waves 4-7 start every tile 64 * TWO_SLEEP cycles late
-#endif
 #ifndef TWO_SCHED
 #define TWO_SCHED 1     // 1: a group's staging slice sits between its operand reads and its MFMAs with no scheduling fence (the
                         // compiler spreads it under the MFMAs: 2.10 -> 2.00 ms per 3 M rows); 0: fenced, slice after the MFMAs
@@ -2418,10 +2415,13 @@ __global__ __launch_bounds__(512) void k_gru_bwd_two(GruBwdFusedArgs a, int ntil
     uint16_t* const lds16 = reinterpret_cast<uint16_t*>(lds);
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-    const int srow = tid >> 4, f4 = (tid & 15) * 4;          // staging: one row, four columns
     const int role = wave >> 2, q = wave & 3;                 // role 0: W_ih side, 1: W_hh side
     // ---- data product (16x16x32): lane (j = tile row within a 16-row half, kq = k group)
     const int j16 = lane & 15, kq = lane >> 4;
+    // staging: thread tid takes row tid >> 4, columns 4 (tid & 15) .. + 3 -- written through (wave, kq, j16), which the
+    // matrix phase keeps alive anyway (a separate copy of the thread id ends up in scratch, and a scratch reload waits for
+    // EVERY request in flight)
+    const int srow = 4 * wave + kq, f4 = 4 * j16;
     const int n0 = 16 * q;
     uint4 wq[6][3];
     {
@@ -2507,10 +2507,10 @@ __global__ __launch_bounds__(512) void k_gru_bwd_two(GruBwdFusedArgs a, int ntil
             half_put((img), st0 ^ 64, PA, o_);                                                               \
             *reinterpret_cast<float4*>(reinterpret_cast<float*>((img) + OFF_E) + se0) = make_float4(e_[0], e_[1], e_[2], e_[3]); \
         } else if ((SL) == 2) {                                                                              \
-            half_put((img), SUB + st0, PA, tv);                                                              \
-        } else if ((SL) == 3) {                                                                              \
             const float hp_[4] = {raw.hp.x, raw.hp.y, raw.hp.z, raw.hp.w};                                   \
             half_put((img) + OFF_B, st0 ^ 64, PB, hp_);                                                      \
+        } else if ((SL) == 3) {                                                                              \
+            half_put((img), SUB + st0, PA, tv);                                                              \
         } else if ((SL) == 5) {                                                                              \
             const float xa_[4] = {raw.xa.x, raw.xa.y, raw.xa.z, raw.xa.w}, xb_[4] = {raw.xb.x, raw.xb.y, raw.xb.z, raw.xb.w}; \
             _Pragma("unroll") for (int i = 0; i < 4; ++i) o_[i] = XMODE != 0 ? xa_[i] - xb_[i] : xa_[i];     \
@@ -2537,7 +2537,7 @@ __global__ __launch_bounds__(512) void k_gru_bwd_two(GruBwdFusedArgs a, int ntil
         } else if ((SL) == 1) {                                                                              \
             raw.n = *reinterpret_cast<const float4*>(g0_ + 2 * gp_);                                         \
             raw.z = *reinterpret_cast<const float4*>(g0_ + gp_);                                             \
-        } else if ((SL) == 3) {                                                                              \
+        } else if ((SL) == 2) {                                                                              \
             raw.hp = *reinterpret_cast<const float4*>(a.h + (size_t)(orow_) * a.ld_h + f4);                  \
         }                                                                                                    \
     } while (0)
@@ -2571,42 +2571,43 @@ __global__ __launch_bounds__(512) void k_gru_bwd_two(GruBwdFusedArgs a, int ntil
         const int lp0 = row_of(blockIdx.x, true, v0);
         const int o0 = a.rows[lp0];
         TWO_GATHER_IDS(lp0, gs_cur, gd_cur);
-        TWO_ISSUE_MAIN(0, o0); TWO_ISSUE_MAIN(1, o0); TWO_ISSUE_MAIN(3, o0); TWO_ISSUE_GATHER(gs_cur, gd_cur);
+        TWO_ISSUE_MAIN(0, o0); TWO_ISSUE_MAIN(1, o0); TWO_ISSUE_MAIN(2, o0); TWO_ISSUE_GATHER(gs_cur, gd_cur);
         const int lp1 = row_of(blockIdx.x + G, 1 < nmine, v1);
         const int o1 = a.rows[lp1];
         TWO_SLICE(0, lds16, v0); TWO_ISSUE_MAIN(0, o1);
         TWO_SLICE(1, lds16, v0); TWO_ISSUE_MAIN(1, o1);
-        TWO_SLICE(2, lds16, v0);
-        TWO_SLICE(3, lds16, v0); TWO_ISSUE_MAIN(3, o1);
+        TWO_SLICE(2, lds16, v0); TWO_ISSUE_MAIN(2, o1);
+        TWO_SLICE(3, lds16, v0);
         TWO_SLICE(5, lds16, v0);
         valid_cur = v1;
         TWO_GATHER_IDS(lp1, gs_cur, gd_cur);
         const int lp2 = row_of(blockIdx.x + 2 * G, 2 < nmine, valid_n);
         orow_n = a.rows[lp2];
     }
-    // epilogue rows of tile 0: lane -> rows j16 and 16 + j16
-    int er0 = a.rows[min((int)blockIdx.x * 32 + j16, a.R - 1)], er1 = a.rows[min((int)blockIdx.x * 32 + 16 + j16, a.R - 1)];
-    bool el0 = (int)blockIdx.x * 32 + j16 < a.R, el1 = (int)blockIdx.x * 32 + 16 + j16 < a.R;
     __syncthreads();
 
-    // The SIMD partners (waves w and w + 4: one of each side) are staggered by half a group: the W_hh side stages its slice
-    // BEFORE its MFMA group, the W_ih side after, so that one wave's staging arithmetic runs beside the other's MFMAs
-    // instead of both reaching the matrix pipe together (the slice writes the other buffer: any place in the phase is legal)
+    // one group's share of the staging: slice s6 of the next tile, then the requests for what it freed.  (Staggering the
+    // SIMD partners -- the W_hh side staging before its MFMA group, or waves 4-7 / odd waves started a few hundred cycles
+    // late every tile -- was measured and changed nothing)
 #define TWO_STAGE(ROLE_)                                                                                     \
     do {                                                                                                     \
-            if ((ROLE_) == 0) {                                                                                  \
-                if (!(exp_ & 2)) TWO_SLICE(s6, nxt, valid_cur);                                                  \
-                if (!(exp_ & 1)) {                                                                               \
-                    TWO_ISSUE_MAIN(s6, orow_n);                                                                  \
-                    if (s6 == 2) TWO_ISSUE_GATHER(gs_cur, gd_cur);  /* half a tile ahead of slice 5 (L2 hits mostly) */ \
-                }                                                                                                \
-                if (TWO_SCHED == 0) __builtin_amdgcn_sched_barrier(0);                                           \
-            }                                                                                             \
+        if (!(exp_ & 2)) TWO_SLICE(s6, nxt, valid_cur);                                                      \
+        if (!(exp_ & 1)) {                                                                                   \
+            TWO_ISSUE_MAIN(s6, orow_n);                                                                      \
+            /* the gathers two groups ahead of slice 5 (det rows: mostly L2 hits); held over the whole phase they */ \
+            /* push a dozen registers into scratch, and a scratch reload waits for every request in flight        */ \
+            if (s6 == 3) TWO_ISSUE_GATHER(gs_cur, gd_cur);                                                   \
+        }                                                                                                    \
+        if (TWO_SCHED == 0) __builtin_amdgcn_sched_barrier(0);                                               \
     } while (0)
     for (int it = 0; it < nmine; ++it) {
         const int tile = blockIdx.x + it * G;
         uint16_t* const cur = lds16 + (it & 1) * BUF;
         uint16_t* const nxt = lds16 + ((it & 1) ^ 1) * BUF;
+        // epilogue rows of this tile (lane -> rows j16 and 16 + j16), requested FIRST in the phase: at the epilogue the wait
+        // then leaves every later request of the phase (the next tiles' planes) in flight
+        const int er0 = a.rows[min(tile * 32 + j16, a.R - 1)], er1 = a.rows[min(tile * 32 + 16 + j16, a.R - 1)];
+        const bool el0 = tile * 32 + j16 < a.R, el1 = tile * 32 + 16 + j16 < a.R;
         f32x4 accd[2];
 #pragma unroll
         for (int i = 0; i < 4; ++i) { accd[0][i] = 0.f; accd[1][i] = 0.f; }
@@ -2641,7 +2642,7 @@ __global__ __launch_bounds__(512) void k_gru_bwd_two(GruBwdFusedArgs a, int ntil
                     aw[pc] = make_uint4(u0.x, u0.y, u1.x, u1.y);
                 }
             }
-            if (TWO_SCHED == 1) TWO_STAGE(0);
+            if (TWO_SCHED >= 1) TWO_STAGE(0);
             if (!(exp_ & 4)) {
             acc[j] = mfma32_c<0>(aw, bt, acc[j]); acc[j] = mfma32_c<1>(aw, bt, acc[j]);
             acc[j] = mfma32_c<2>(aw, bt, acc[j]); acc[j] = mfma32_c<3>(aw, bt, acc[j]);
@@ -2687,26 +2688,24 @@ __global__ __launch_bounds__(512) void k_gru_bwd_two(GruBwdFusedArgs a, int ntil
             (void)vnn;
         }
         // ---- epilogue: lane (j16, kq) holds columns n0 + 4 kq .. + 3 of rows j16 and 16 + j16
+        int cofs = n0 + 4 * kq;
+        asm volatile("" : "+v"(cofs));             // (kept as ONE register: hoisted, the two 64-bit column bases are spilled)
         if (role == 0) {
-            if (el0) *reinterpret_cast<float4*>(a.d_msg + (size_t)er0 * a.ld_dmsg + n0 + 4 * kq) =
+            if (el0) *reinterpret_cast<float4*>(a.d_msg + ((size_t)er0 * a.ld_dmsg + cofs)) =
                          make_float4(accd[0][0], accd[0][1], accd[0][2], accd[0][3]);
-            if (el1) *reinterpret_cast<float4*>(a.d_msg + (size_t)er1 * a.ld_dmsg + n0 + 4 * kq) =
+            if (el1) *reinterpret_cast<float4*>(a.d_msg + ((size_t)er1 * a.ld_dmsg + cofs)) =
                          make_float4(accd[1][0], accd[1][1], accd[1][2], accd[1][3]);
         } else {
             const float* e = reinterpret_cast<const float*>(cur + OFF_E);
-            const int cq = (n0 + 4 * kq) >> 2;
+            const int cq = cofs >> 2;
             const float4 x0 = *reinterpret_cast<const float4*>(e + j16 * 64 + ((cq ^ j16) << 2));
             const float4 x1 = *reinterpret_cast<const float4*>(e + (16 + j16) * 64 + ((cq ^ j16) << 2));
-            if (el0) *reinterpret_cast<float4*>(a.d_h + (size_t)er0 * a.ld_dh + n0 + 4 * kq) =
+            if (el0) *reinterpret_cast<float4*>(a.d_h + ((size_t)er0 * a.ld_dh + cofs)) =
                          make_float4(accd[0][0] + x0.x, accd[0][1] + x0.y, accd[0][2] + x0.z, accd[0][3] + x0.w);
-            if (el1) *reinterpret_cast<float4*>(a.d_h + (size_t)er1 * a.ld_dh + n0 + 4 * kq) =
+            if (el1) *reinterpret_cast<float4*>(a.d_h + ((size_t)er1 * a.ld_dh + cofs)) =
                          make_float4(accd[1][0] + x1.x, accd[1][1] + x1.y, accd[1][2] + x1.z, accd[1][3] + x1.w);
         }
-        er0 = a.rows[min((tile + G) * 32 + j16, a.R - 1)]; er1 = a.rows[min((tile + G) * 32 + 16 + j16, a.R - 1)];
-        el0 = (it + 1 < nmine) && ((tile + G) * 32 + j16 < a.R);
-        el1 = (it + 1 < nmine) && ((tile + G) * 32 + 16 + j16 < a.R);
         __syncthreads();
-        if (TWO_SLEEP > 0 && role == 1) __builtin_amdgcn_s_sleep(TWO_SLEEP);
     }
 #undef TWO_STAGE
 #undef TWO_GATHER_IDS
