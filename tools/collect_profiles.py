@@ -129,15 +129,20 @@ with open(f'profiles/{tag}_c5_dense_stress.md', 'w') as f:
 | round 1 (f32-input MFMA, weights streamed from L2) | 622 | 28.4 M | 67.0 | 97.6 GB |
 | round 2 (edge cell: LDS-tiled bf16x6 GEMMs, csrc/wide.hip) | **{c5['ms_per_step']:.0f}** | **{c5['edges_per_s']/1e6:.1f} M** | **{c5['tflops']:.1f}** | {c5['mem_GB']:.1f} GB |
 
-Per iteration (rocprofv3 --kernel-trace --stats of the same command): edge forward 19.1 ms (round 1: 54), backward data
-9.7 (gate gradients) + 2 x 8.0 = 26 ms (round 1: 77), weight gradient 2 x 11.7 = 23 ms (`k_wide_dw`, bf16x6 from the
-materialised gate gradients; round 1 and the first half of round 2: 36 ms on the f32-MFMA output-tiled kernel, 409 ms
-per step), aggregations 7 ms.  The two new GEMM kernels reach ~25-35 % of the bf16x6 matrix rate: the forward is held by its
-memory-system traffic (the P gathers of the diff projection, 6 KB per row from L2 / Infinity Cache, plus four gate planes
-written), the backward products by reading the materialised gate gradients (3 KB per row per product).  Tried without
-effect: one- and two-deep register prefetch of the next K-step, XCD-aware tile order (the column blocks of a row tile on
-one XCD).  What helped: stores and gathers as 16-byte accesses through an LDS-staged epilogue (gemm 17 -> 12.7 ms).  The
-reference cannot run this configuration at all (dense N x N adjacency: 4.4 M^2 floats).  Next: gate gradients stored as
-bf16 pieces once, so that the four GEMM launches that read them stop splitting them again.
+The step through round 2: 622 (round 1) -> 409 (forward + backward-data on LDS-tiled bf16x6 GEMMs) -> 349-366 (weight gradient
+from the materialised gate gradients, `k_wide_dw`) -> **265** (both W_ih products of the backward on the DET side,
+`tmpnn_wide_gru_bwd_diff`: by linearity of the diff message x = h[src] - h[dst], sum_e d_gi[e]^T x[e] = sum_d S[d]^T h[d] and the
+message adjoint is S W_ih with S[d] = signed segment sum of d_gi over the det's incident edges -- two of the four
+(4.41 M x 768 x 256) products run over 15 000 rows instead) -> ~255 with the per-segment BatchNorm reductions on row groups
+(a one-window batch is ONE segment of 15 000 dets: 7.4 + 4.1 ms per step on one thread per column before).
+
+Per iteration (`rocprofv3 --kernel-trace --stats -- python3 tools/c5_bench.py`, gpurun_out/r02_c5prof): edge forward 19.1 ms
+(round 1: 54), gate gradients 8.5 (one [N][4H] image = [dr | dz | dn | dn r]; 9.7 as two [E][3H] images), d_gh W_hh 12.7,
+weight gradient dW_hh 11.9 (`k_wide_dw`), signed segment sum of d_gi 3 x 1.5 = 4.6, the two det-side products < 0.5, the
+other aggregations 3.3.  The forward is held by its memory-system traffic (the P gathers of the diff projection, 6 KB per
+row from L2 / Infinity Cache, plus four gate planes written), the W_hh products by reading the materialised gate gradients
+(3 KB per row per product).  Tried without effect: one- and two-deep register prefetch of the next K-step, XCD-aware tile
+order.  What helped: stores and gathers as 16-byte accesses through an LDS-staged epilogue (gemm 17 -> 12.7 ms).  The
+reference cannot run this configuration at all (dense N x N adjacency: 4.4 M^2 floats).
 ''')
 print(d['value'], d['ms_per_step'], d['roofline'], d['roofline_aggregation']['frac'], d['cpu_baseline']['value'])
