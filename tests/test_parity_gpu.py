@@ -49,6 +49,21 @@ def test_stage_checks_f32_mfma_path():
     assert r.returncode == 0, tail + r.stderr[-2000:]
 
 
+def test_stage_checks_four_wave_one_pass_backward():
+    """The stage checks (they run tmpnn_gru_bwd_fused wherever it is offered) with TMPNN_BWD_TWO=0: the one-pass backward as
+    four 512-register waves per block (k_gru_bwd_one) instead of the default eight 256-register waves (k_gru_bwd_two).  The
+    switch is read once per process, hence the child process."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, TMPNN_BWD_TWO='0', PYTHONPATH=root + os.pathsep + os.environ.get('PYTHONPATH', ''))
+    r = subprocess.run([sys.executable, os.path.join(root, 'tests', 'gpu_stage_checks.py')], env=env, cwd=root,
+                       capture_output=True, text=True, timeout=600)
+    tail = '\n'.join([ln for ln in r.stdout.splitlines() if ln.startswith('FAIL')] + r.stdout.splitlines()[-2:])
+    assert r.returncode == 0, tail + r.stderr[-2000:]
+
+
 def build_model(meta, params):
     from trackmpnn_amd import TrackMPNN
     m = TrackMPNN(meta['features'], meta['ncategories'], meta['nhidden'], meta['nattheads'], meta['msg_type'])
