@@ -424,6 +424,20 @@ def main():
 
     roofline = None
     extra = {}
+    if world > 1:
+        # the step's one collective on its own (flat fp32 gradient bucket, SUM), outside the timed region:
+        # median of 20 all-reduces bracketed by device syncs, max over ranks
+        ts = []
+        for _ in range(22):
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            dist.all_reduce(bucket.flat, op=dist.ReduceOp.SUM)
+            torch.cuda.synchronize()
+            ts.append(time.perf_counter() - t1)
+        ar = torch.tensor([sorted(ts[2:])[10]], device=dev, dtype=torch.float64)
+        dist.all_reduce(ar, op=dist.ReduceOp.MAX)
+        extra['allreduce'] = dict(us=round(ar.item() * 1e6, 1), bytes=int(bucket.flat.numel()) * 4,
+                                  backend=args.backend, note='one flat-bucket all_reduce(SUM) per optimizer step')
     if rank == 0 and not args.no_stage_profile:
         t, flops, nbytes = stage_profile(model, plans[-1], H)
         # the dominant kernel AMONG THOSE THE STEP RUNS: with the one-pass backward (default) the two stand-alone
