@@ -41,6 +41,12 @@ def test_argument_validation_needs_no_gpu(lib):
     rc = lib.tmpnn_gru_fwd(None, 4, 1, None, None, None, 0, 0, 64, None, 64, 48, None, None, None, None, None, 64,
                            None, 0, None, None, 0, None)
     assert rc == -1 and b'unsupported H' in lib.tmpnn_last_error()
+    # the det-side backward of the wide cells: unsupported width, inconsistent graph, short workspace
+    rc = lib.tmpnn_wide_gru_bwd_diff(None, ctypes.byref(g), None, 64, 64, None, 0, None, 0, None, None, None, 64, None, None,
+                                     None, None, None, 0, None)
+    assert rc == -1 and b'wide_gru_bwd_diff' in lib.tmpnn_last_error()
+    assert lib.tmpnn_wide_gru_bwd_diff_ws(100, 90, 10, 256) >= 4 * (100 * 4 * 256 + 10 * 3 * 256)
+    assert lib.tmpnn_wide_gru_bwd_diff_ws(100, 90, 10, 64) == 0          # H = 64 is not a wide cell
     assert lib.tmpnn_gru_bwd_weights_ws(1000, 64, 64) > 0
     assert lib.tmpnn_heads_bwd_ws(1000, 64) > 0
     assert lib.tmpnn_gru_fwd_head_parts(64, 64, 3) == 2 and lib.tmpnn_gru_fwd_head_parts(256, 256, 1) == 0
