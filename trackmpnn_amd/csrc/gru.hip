@@ -2648,7 +2648,8 @@ __global__ __launch_bounds__(512) void k_gru_bwd_two(GruBwdFusedArgs a, int ntil
             acc[j] = mfma32_c<2>(aw, bt, acc[j]); acc[j] = mfma32_c<3>(aw, bt, acc[j]);
             acc[j] = mfma32_c<4>(aw, bt, acc[j]); acc[j] = mfma32_c<5>(aw, bt, acc[j]);
             } else { acc[j][0] += __uint_as_float(aw[0].x ^ bt[0].x ^ aw[1].y ^ bt[1].y ^ aw[2].z ^ bt[2].z); }
-            if (tt == 0 && !(exp_ & 8)) {                       // bias gradient: column sums from the A operands
+            if (kb == tt && !(exp_ & 8)) {                      // bias gradient: column sums from the A operands (the two waves
+                                                                // that read the same A tiles take one 16-row block each)
 #pragma unroll
                 for (int pc = 0; pc < 3; ++pc) {
                     const uint4 v = aw[pc];
@@ -2721,12 +2722,20 @@ __global__ __launch_bounds__(512) void k_gru_bwd_two(GruBwdFusedArgs a, int ntil
             const int jj = (jt0 + j) * 32 + acc_row(reg, half);
             sw[(size_t)jj * (2 * H) + role * H + tt * 32 + c32] = acc[j][reg];
         }
-    if (tt == 0) {
-        float* sb = a.slab_b + (size_t)blockIdx.x * 6 * H;
+    // bias slabs: wave (tt = 0) + wave (tt = 1) of the same A tiles, in that order, through the now idle LDS
+    {
+        float* red = lds;                                      // [8 waves][96]
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
             const float tot = bsum[j] + __shfl_xor(bsum[j], 32);
-            if (half == 0) sb[role * 3 * H + (jt0 + j) * 32 + c32] = tot;
+            if (half == 0) red[wave * 96 + j * 32 + c32] = tot;
+        }
+        __syncthreads();
+        if (tt == 0 && half == 0) {
+            float* sb = a.slab_b + (size_t)blockIdx.x * 6 * H;
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+                sb[role * 3 * H + (jt0 + j) * 32 + c32] = red[wave * 96 + j * 32 + c32] + red[(wave + 1) * 96 + j * 32 + c32];
         }
     }
 }
