@@ -832,35 +832,68 @@ __global__ __launch_bounds__(WPB * 64) void k_gru_fwd_split(GruFwdArgs a) {
         for (int q = 0; q < 4; ++q)
             hp4[q] = *reinterpret_cast<const float4*>(a.h + (size_t)row * a.ld_h + cw0 + 8 * q + 4 * half);
         f32x16 outv;
+        {
+            // The projected det rows P[src], P[dst] are gathered GATE by gate: the four 16-byte pieces a lane takes from one
+            // 128-byte line (its row's 32 columns of one gate) are requested back to back, so the line is fetched from L2
+            // once.  Column chunk by chunk (all three gates of one chunk, then the next chunk) the other five line sets of
+            // the item -- and the seven other waves' items -- pass through the 32 KiB L1 between two touches of a line.
+            const float* ps0 = a.msg + (size_t)ix.s * a.ld_msg + cw0 + 4 * half;
+            const float* pd0 = a.msg + (size_t)ix.d * a.ld_msg + cw0 + 4 * half;
+            float4 gs[4], gd[4], hs[4], hd[4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int col = cw0 + 8 * q + 4 * half;
-            const float4 b4r = *reinterpret_cast<const float4*>(sBias + col);
-            const float4 b4z = *reinterpret_cast<const float4*>(sBias + H + col);
-            const float4 b4i = *reinterpret_cast<const float4*>(sBias + 2 * H + col);
-            const float4 b4h = *reinterpret_cast<const float4*>(sBias + 3 * H + col);
-            const float br[4] = {b4r.x, b4r.y, b4r.z, b4r.w};
-            const float bz[4] = {b4z.x, b4z.y, b4z.z, b4z.w};
-            const float bi[4] = {b4i.x, b4i.y, b4i.z, b4i.w};
-            const float bh[4] = {b4h.x, b4h.y, b4h.z, b4h.w};
-            const float hp[4] = {hp4[q].x, hp4[q].y, hp4[q].z, hp4[q].w};
-            const float* ps = a.msg + (size_t)ix.s * a.ld_msg + col;
-            const float* pd = a.msg + (size_t)ix.d * a.ld_msg + col;
-            const float4 sr = *reinterpret_cast<const float4*>(ps), dr = *reinterpret_cast<const float4*>(pd);
-            const float4 sz = *reinterpret_cast<const float4*>(ps + H), dz = *reinterpret_cast<const float4*>(pd + H);
-            const float4 sn = *reinterpret_cast<const float4*>(ps + 2 * H), dn = *reinterpret_cast<const float4*>(pd + 2 * H);
-            const float xr[4] = {sr.x - dr.x, sr.y - dr.y, sr.z - dr.z, sr.w - dr.w};
-            const float xz[4] = {sz.x - dz.x, sz.y - dz.y, sz.z - dz.z, sz.w - dz.w};
-            const float xn[4] = {sn.x - dn.x, sn.y - dn.y, sn.z - dn.z, sn.w - dn.w};
+            for (int q = 0; q < 4; ++q) gs[q] = *reinterpret_cast<const float4*>(ps0 + 8 * q);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int reg = 4 * q + i;
-                const float ro = sigmoidf_(acc_r[reg] + xr[i] + br[i]);
-                const float zo = sigmoidf_(acc_z[reg] + xz[i] + bz[i]);
-                const float ho = acc_hn[reg] + bh[i];
-                const float no = tanhf_(xn[i] + bi[i] + ro * ho);
-                outv[reg] = (1.0f - zo) * no + zo * hp[i];
-                acc_r[reg] = ro; acc_z[reg] = zo; acc_hn[reg] = ho; acc_in[reg] = no;
+            for (int q = 0; q < 4; ++q) gd[q] = *reinterpret_cast<const float4*>(pd0 + 8 * q);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) hs[q] = *reinterpret_cast<const float4*>(ps0 + H + 8 * q);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) hd[q] = *reinterpret_cast<const float4*>(pd0 + H + 8 * q);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {                       // r: pre-activation in place
+                const float4 b4 = *reinterpret_cast<const float4*>(sBias + cw0 + 8 * q + 4 * half);
+                acc_r[4 * q + 0] = acc_r[4 * q + 0] + (gs[q].x - gd[q].x) + b4.x;
+                acc_r[4 * q + 1] = acc_r[4 * q + 1] + (gs[q].y - gd[q].y) + b4.y;
+                acc_r[4 * q + 2] = acc_r[4 * q + 2] + (gs[q].z - gd[q].z) + b4.z;
+                acc_r[4 * q + 3] = acc_r[4 * q + 3] + (gs[q].w - gd[q].w) + b4.w;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) gs[q] = *reinterpret_cast<const float4*>(ps0 + 2 * H + 8 * q);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) gd[q] = *reinterpret_cast<const float4*>(pd0 + 2 * H + 8 * q);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {                       // z
+                const float4 b4 = *reinterpret_cast<const float4*>(sBias + H + cw0 + 8 * q + 4 * half);
+                acc_z[4 * q + 0] = acc_z[4 * q + 0] + (hs[q].x - hd[q].x) + b4.x;
+                acc_z[4 * q + 1] = acc_z[4 * q + 1] + (hs[q].y - hd[q].y) + b4.y;
+                acc_z[4 * q + 2] = acc_z[4 * q + 2] + (hs[q].z - hd[q].z) + b4.z;
+                acc_z[4 * q + 3] = acc_z[4 * q + 3] + (hs[q].w - hd[q].w) + b4.w;
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {                       // n: input part
+                const float4 b4 = *reinterpret_cast<const float4*>(sBias + 2 * H + cw0 + 8 * q + 4 * half);
+                acc_in[4 * q + 0] = (gs[q].x - gd[q].x) + b4.x;
+                acc_in[4 * q + 1] = (gs[q].y - gd[q].y) + b4.y;
+                acc_in[4 * q + 2] = (gs[q].z - gd[q].z) + b4.z;
+                acc_in[4 * q + 3] = (gs[q].w - gd[q].w) + b4.w;
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 b4h = *reinterpret_cast<const float4*>(sBias + 3 * H + cw0 + 8 * q + 4 * half);
+                const float bh[4] = {b4h.x, b4h.y, b4h.z, b4h.w};
+                const float hp[4] = {hp4[q].x, hp4[q].y, hp4[q].z, hp4[q].w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int reg = 4 * q + i;
+                    const float ro = sigmoidf_(acc_r[reg]);
+                    const float zo = sigmoidf_(acc_z[reg]);
+                    const float ho = acc_hn[reg] + bh[i];
+                    const float no = tanhf_(acc_in[reg] + ro * ho);
+                    outv[reg] = (1.0f - zo) * no + zo * hp[i];
+                    acc_r[reg] = ro; acc_z[reg] = zo; acc_hn[reg] = ho; acc_in[reg] = no;
+                }
             }
         }
         if (a.logit_part) {
