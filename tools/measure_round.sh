@@ -13,6 +13,7 @@ echo "[measure] write"; rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-forma
 cd $R
 [ "$2" = "prof" ] && { echo "[measure] done (profiles only)"; exit 0; }
 echo "[measure] c3"; python3 tools/c3_profile.py > gpurun_out/${T}_c3.json 2> gpurun_out/${T}_c3.err || exit 1
+echo "[measure] c4"; python3 tools/c4_profile.py > gpurun_out/${T}_c4.json 2> gpurun_out/${T}_c4.err || exit 1
 echo "[measure] c5"; python3 tools/c5_bench.py --steps 3 > gpurun_out/${T}_c5.json 2> gpurun_out/${T}_c5.err || exit 1
 echo "[measure] plain bench"; python3 bench.py > gpurun_out/${T}_bench_plain.json 2> gpurun_out/${T}_bench_plain.err || exit 1
 echo "[measure] done"
