@@ -145,4 +145,29 @@ row from L2 / Infinity Cache, plus four gate planes written), the W_hh products 
 order.  What helped: stores and gathers as 16-byte accesses through an LDS-staged epilogue (gemm 17 -> 12.7 ms).  The
 reference cannot run this configuration at all (dense N x N adjacency: 4.4 M^2 floats).
 ''')
+
+# ---- C4 (optional: written when tools/measure_round.sh produced it)
+if os.path.exists(f'gpurun_out/{tag}_c4.json'):
+    c4 = json.loads(json_line(f'gpurun_out/{tag}_c4.json', '{"workload"'))
+    with open(f'profiles/{tag}_c4_bdd_shape.md', 'w') as f:
+        f.write(f"""# C4 (BASELINE.json configs[3]) -- BDD100K All / libra-shaped windows, per-GPU step, {tag}, 1x MI355X
+
+`python tools/c4_profile.py` -- 4096 windows x 7 frames, D_t ~ clip(Poisson(12), 1, 40), 8 categories => F = 13, H = 64, K = 0,
+diff; rolling forward (6 calls, state carried) + one backward + Adam, batched block-diagonally: {c4['rows_final']:,} rows,
+{c4['edges_final']:,} edges in the last call, {c4['edge_iterations_per_step']:,} edge-iterations per step.  BASELINE's C4 is this step on
+each of 8 ranks plus ONE flat-bucket all-reduce of 55 234 floats per step (bench.py --gpus 8; no 8-GPU node was available to the
+builder: DESIGN.md section 6).
+
+| | ms / step | graph-edges/s | peak HBM |
+|---|---|---|---|
+| round 2 | {c4['ms_per_step']:.1f} | {c4['graph_edges_per_s']/1e6:.0f} M | {c4['mem_GB']:.1f} GB |
+
+Stage kernels on the last call's graph (HIP events, algorithmic bytes as in DESIGN.md section 4, roof = 8 TB/s); dets here have
+~29 incident edges (C2: ~16):
+
+| kernel | ms | GB/s | of 8 TB/s |
+|---|---|---|---|
+""")
+        for k, v in c4['stages'].items():
+            f.write(f"| {k} | {v['ms']} | {v['GBs']} | {v['hbm_frac']} |\n")
 print(d['value'], d['ms_per_step'], d['roofline'], d['roofline_aggregation']['frac'], d['cpu_baseline']['value'])
