@@ -25,28 +25,54 @@ __global__ __launch_bounds__(256) void k_gemm(GemmArgs g, int kper, float* slab)
     const int kbeg = blockIdx.z * kper;
     const int kend = min(g.K, kbeg + kper);
     float acc[4][4] = {};
+    // 16-byte alignment of the contiguous dimension of A / B (kbeg is a multiple of 16)
+    const bool va = (reinterpret_cast<uintptr_t>(g.A) & 15) == 0 && ((g.sak == 1 ? g.sam : g.sak) & 3) == 0;
+    const bool vb = (reinterpret_cast<uintptr_t>(g.B) & 15) == 0 && ((g.sbn == 1 ? g.sbk : g.sbn) & 3) == 0;
     for (int k0 = kbeg; k0 < kend; k0 += 16) {
+        // tile loads: 16-byte accesses where a whole 64 x 16 tile is in range and the contiguous dimension is aligned
+        // (row lists, ragged edges and odd strides take the element-wise path); the sums below do not depend on which
+        const bool fullk = k0 + 16 <= kend;
+        if (fullk && m0 + 64 <= g.M && !g.a_krows && g.sak == 1 && va) {          // A row-major: k contiguous
+            const int m = tid >> 2, kq = (tid & 3) * 4;
+            const long ar = g.a_rows ? g.a_rows[m0 + m] : (m0 + m);
+            const float4 v = *reinterpret_cast<const float4*>(g.A + ar * g.sam + k0 + kq);
+            As[kq][m] = v.x; As[kq + 1][m] = v.y; As[kq + 2][m] = v.z; As[kq + 3][m] = v.w;
+        } else if (fullk && m0 + 64 <= g.M && !g.a_rows && g.sam == 1 && va) {    // A column-major: m contiguous
+            const int k = tid >> 4, mq = (tid & 15) * 4;
+            const long ak = g.a_krows ? g.a_krows[k0 + k] : (k0 + k);
+            *reinterpret_cast<float4*>(&As[k][mq]) = *reinterpret_cast<const float4*>(g.A + ak * g.sak + m0 + mq);
+        } else {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int idx = tid + i * 256;
-            int m, k;
-            if (g.sak == 1) { k = idx & 15; m = idx >> 4; } else { m = idx & 63; k = idx >> 6; }
-            float v = 0.f;
-            if (m0 + m < g.M && k0 + k < kend) {
-                const long ar = g.a_rows ? g.a_rows[m0 + m] : (m0 + m);
-                const long ak = g.a_krows ? g.a_krows[k0 + k] : (k0 + k);
-                v = g.A[ar * g.sam + ak * g.sak];
+            for (int i = 0; i < 4; ++i) {
+                const int idx = tid + i * 256;
+                int m, k;
+                if (g.sak == 1) { k = idx & 15; m = idx >> 4; } else { m = idx & 63; k = idx >> 6; }
+                float v = 0.f;
+                if (m0 + m < g.M && k0 + k < kend) {
+                    const long ar = g.a_rows ? g.a_rows[m0 + m] : (m0 + m);
+                    const long ak = g.a_krows ? g.a_krows[k0 + k] : (k0 + k);
+                    v = g.A[ar * g.sam + ak * g.sak];
+                }
+                As[k][m] = v;
             }
-            As[k][m] = v;
         }
+        if (fullk && n0 + 64 <= g.N && g.sbn == 1 && vb) {                         // B: n contiguous
+            const int k = tid >> 4, nq = (tid & 15) * 4;
+            *reinterpret_cast<float4*>(&Bs[k][nq]) = *reinterpret_cast<const float4*>(g.B + (long)(k0 + k) * g.sbk + n0 + nq);
+        } else if (fullk && n0 + 64 <= g.N && g.sbk == 1 && vb) {                  // B: k contiguous
+            const int n = tid >> 2, kq = (tid & 3) * 4;
+            const float4 v = *reinterpret_cast<const float4*>(g.B + (long)(n0 + n) * g.sbn + k0 + kq);
+            Bs[kq][n] = v.x; Bs[kq + 1][n] = v.y; Bs[kq + 2][n] = v.z; Bs[kq + 3][n] = v.w;
+        } else {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int idx = tid + i * 256;
-            int n, k;
-            if (g.sbn == 1) { n = idx & 63; k = idx >> 6; } else { k = idx & 15; n = idx >> 4; }
-            float v = 0.f;
-            if (n0 + n < g.N && k0 + k < kend) v = g.B[(long)(k0 + k) * g.sbk + (long)(n0 + n) * g.sbn];
-            Bs[k][n] = v;
+            for (int i = 0; i < 4; ++i) {
+                const int idx = tid + i * 256;
+                int n, k;
+                if (g.sbn == 1) { n = idx & 63; k = idx >> 6; } else { k = idx & 15; n = idx >> 4; }
+                float v = 0.f;
+                if (n0 + n < g.N && k0 + k < kend) v = g.B[(long)(k0 + k) * g.sbk + (long)(n0 + n) * g.sbn];
+                Bs[k][n] = v;
+            }
         }
         __syncthreads();
 #pragma unroll
@@ -61,10 +87,31 @@ __global__ __launch_bounds__(256) void k_gemm(GemmArgs g, int kper, float* slab)
         }
         __syncthreads();
     }
+    const bool vc = n0 + tx * 4 + 3 < g.N &&
+                    (slab ? (g.N & 3) == 0 && (reinterpret_cast<uintptr_t>(slab) & 15) == 0
+                          : (g.ldc & 3) == 0 && (reinterpret_cast<uintptr_t>(g.C) & 15) == 0 &&
+                                (!g.bias || (reinterpret_cast<uintptr_t>(g.bias) & 15) == 0));
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int m = m0 + ty * 4 + i;
         if (m >= g.M) continue;
+        if (vc) {                                   // four columns in one 16-byte access (same values as below)
+            const int n = n0 + tx * 4;
+            float4 v = make_float4(acc[i][0], acc[i][1], acc[i][2], acc[i][3]);
+            if (slab) {
+                *reinterpret_cast<float4*>(slab + (size_t)blockIdx.z * g.M * g.N + (size_t)m * g.N + n) = v;
+            } else {
+                if (g.bias) {
+                    const float4 b = *reinterpret_cast<const float4*>(g.bias + n);
+                    v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+                }
+                const long cr = g.c_rows ? g.c_rows[m] : m;
+                float4* p = reinterpret_cast<float4*>(g.C + cr * g.ldc + n);
+                if (g.accumulate) { const float4 o = *p; v.x = o.x + v.x; v.y = o.y + v.y; v.z = o.z + v.z; v.w = o.w + v.w; }
+                *p = v;
+            }
+            continue;
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int n = n0 + tx * 4 + j;
