@@ -308,18 +308,26 @@ __device__ __forceinline__ int seg_of(const int32_t* __restrict__ seg_ptr, int S
 
 // yhat = (y - mean) * rstd ; a = relu(yhat * gamma + beta).  mean/rstd per segment (training) or
 // running (eval: seg_ptr == nullptr, mean/rstd hold one row).
+// (four columns of one row per thread: H is a multiple of 4 and every buffer is 16-byte aligned; `nd * H / 4` threads)
 __global__ void k_bn_apply(const float* __restrict__ y, int nd, int H, const int32_t* __restrict__ seg_ptr, int S,
                            const int32_t* __restrict__ seg_of_det,
                            const float* __restrict__ mean, const float* __restrict__ rstd,
                            const float* __restrict__ gamma, const float* __restrict__ beta,
                            float* __restrict__ yhat_out, float* __restrict__ a_out) {
-    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t idx = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
     if (idx >= (size_t)nd * H) return;
     const int i = (int)(idx / H), j = (int)(idx % H);
     const int s = seg_ptr ? (seg_of_det ? seg_of_det[i] : seg_of(seg_ptr, S, i)) : 0;
-    const float yh = (y[idx] - mean[(size_t)s * H + j]) * rstd[(size_t)s * H + j];
-    if (yhat_out) yhat_out[idx] = yh;
-    if (a_out) a_out[idx] = fmaxf(yh * gamma[j] + beta[j], 0.f);
+    const float4 yv = *reinterpret_cast<const float4*>(y + idx);
+    const float4 m = *reinterpret_cast<const float4*>(mean + (size_t)s * H + j);
+    const float4 r = *reinterpret_cast<const float4*>(rstd + (size_t)s * H + j);
+    const float4 yh = make_float4((yv.x - m.x) * r.x, (yv.y - m.y) * r.y, (yv.z - m.z) * r.z, (yv.w - m.w) * r.w);
+    if (yhat_out) *reinterpret_cast<float4*>(yhat_out + idx) = yh;
+    if (a_out) {
+        const float4 g = *reinterpret_cast<const float4*>(gamma + j), b = *reinterpret_cast<const float4*>(beta + j);
+        *reinterpret_cast<float4*>(a_out + idx) = make_float4(fmaxf(yh.x * g.x + b.x, 0.f), fmaxf(yh.y * g.y + b.y, 0.f),
+                                                              fmaxf(yh.z * g.z + b.z, 0.f), fmaxf(yh.w * g.w + b.w, 0.f));
+    }
 }
 
 __global__ void k_running_to_stats(const float* __restrict__ rm, const float* __restrict__ rv, int H,
@@ -334,13 +342,15 @@ __global__ void k_running_to_stats(const float* __restrict__ rm, const float* __
 __global__ void k_bn_bwd_act(float* __restrict__ da, const float* __restrict__ yhat, int nd, int H,
                              const float* __restrict__ gamma, const float* __restrict__ beta,
                              float* __restrict__ dz_out) {
-    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t idx = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;      // four columns of one row per thread
     if (idx >= (size_t)nd * H) return;
     const int j = (int)(idx % H);
-    const float pre = yhat[idx] * gamma[j] + beta[j];
-    const float dz = pre > 0.f ? da[idx] : 0.f;
-    dz_out[idx] = dz;
-    da[idx] = dz * gamma[j];
+    const float4 yh = *reinterpret_cast<const float4*>(yhat + idx), d = *reinterpret_cast<const float4*>(da + idx);
+    const float4 g = *reinterpret_cast<const float4*>(gamma + j), b = *reinterpret_cast<const float4*>(beta + j);
+    const float4 dz = make_float4(yh.x * g.x + b.x > 0.f ? d.x : 0.f, yh.y * g.y + b.y > 0.f ? d.y : 0.f,
+                                  yh.z * g.z + b.z > 0.f ? d.z : 0.f, yh.w * g.w + b.w > 0.f ? d.w : 0.f);
+    *reinterpret_cast<float4*>(dz_out + idx) = dz;
+    *reinterpret_cast<float4*>(da + idx) = make_float4(dz.x * g.x, dz.y * g.y, dz.z * g.z, dz.w * g.w);
 }
 
 // per segment: s1 = sum dyhat, s2 = sum dyhat*yhat (zero rows contribute nothing: their output is
@@ -378,17 +388,25 @@ __global__ void k_bn_bwd_dy(float* __restrict__ dyhat, const float* __restrict__
                             const int32_t* __restrict__ seg_of_det,
                             const float* __restrict__ rstd, const float* __restrict__ s1,
                             const float* __restrict__ s2, int training) {
-    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t idx = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;      // four columns of one row per thread
     if (idx >= (size_t)nd * H) return;
     const int i = (int)(idx / H), j = (int)(idx % H);
+    float4 d = *reinterpret_cast<const float4*>(dyhat + idx);
     if (!training) {
-        dyhat[idx] *= rstd[j];
+        const float4 r = *reinterpret_cast<const float4*>(rstd + j);
+        *reinterpret_cast<float4*>(dyhat + idx) = make_float4(d.x * r.x, d.y * r.y, d.z * r.z, d.w * r.w);
         return;
     }
     const int s = seg_of_det ? seg_of_det[i] : seg_of(seg_ptr, S, i);
     const float cnt = (float)seg_cnt[s];
     const size_t sj = (size_t)s * H + j;
-    dyhat[idx] = rstd[sj] / cnt * (cnt * dyhat[idx] - s1[sj] - yhat[idx] * s2[sj]);
+    const float4 r = *reinterpret_cast<const float4*>(rstd + sj), a1 = *reinterpret_cast<const float4*>(s1 + sj);
+    const float4 a2 = *reinterpret_cast<const float4*>(s2 + sj), yh = *reinterpret_cast<const float4*>(yhat + idx);
+    d.x = r.x / cnt * (cnt * d.x - a1.x - yh.x * a2.x);
+    d.y = r.y / cnt * (cnt * d.y - a1.y - yh.y * a2.y);
+    d.z = r.z / cnt * (cnt * d.z - a1.z - yh.z * a2.z);
+    d.w = r.w / cnt * (cnt * d.w - a1.w - yh.w * a2.w);
+    *reinterpret_cast<float4*>(dyhat + idx) = d;
 }
 
 // dy0[s][j] = rstd/cnt * (-s1 - yhat0*s2), yhat0 = (b1 - mean)*rstd ; written over s1.
@@ -409,10 +427,10 @@ __global__ void k_bn_bwd_dy0(float* __restrict__ s1, float* __restrict__ s2, con
 
 __global__ void k_gather_rows(const float* __restrict__ src, long ld, const int32_t* __restrict__ rows, int n, int H,
                               float* __restrict__ dst) {
-    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t idx = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;      // four columns of one row per thread
     if (idx >= (size_t)n * H) return;
     const int i = (int)(idx / H), j = (int)(idx % H);
-    dst[idx] = src[(size_t)rows[i] * ld + j];
+    *reinterpret_cast<float4*>(dst + idx) = *reinterpret_cast<const float4*>(src + (size_t)rows[i] * ld + j);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -583,6 +601,8 @@ int tmpnn_input_bn_fwd(const float* xdet, int ld_x, int F, int nd, const int32_t
     int rc;
     if (nd > 0) {
         TM_REQUIRE(xdet && y_save && ws_a && out_row && h_new && ld_x >= F && ld_h >= H, "input_bn_fwd: null/short buffers");
+        TM_REQUIRE(aligned16(y_save) && aligned16(ws_a) && aligned16(mean) && aligned16(rstd) && aligned16(gamma) && aligned16(beta),
+                   "input_bn_fwd: y_save / ws_a / mean / rstd / gamma / beta must be 16-byte aligned");
         GemmArgs g{xdet, ld_x, 1, nullptr, nullptr, w1, 1, F, b1, y_save, H, nullptr, nd, H, F, 0};   // y = x W1^T + b1
         if ((rc = launch_gemm(g, st))) return rc;
     }
@@ -598,7 +618,7 @@ int tmpnn_input_bn_fwd(const float* xdet, int ld_x, int F, int nd, const int32_t
         if ((rc = check_launch("running_to_stats"))) return rc;
     }
     if (nd == 0) return TMPNN_OK;
-    hipLaunchKernelGGL(k_bn_apply, dim3(ceil_div((long)nd * H, 256)), dim3(256), 0, st, y_save, nd, H,
+    hipLaunchKernelGGL(k_bn_apply, dim3(ceil_div((long)nd * H / 4, 256)), dim3(256), 0, st, y_save, nd, H,
                        training ? seg_ptr : nullptr, S, seg_of_det, mean, rstd, gamma, beta, (float*)nullptr, ws_a);
     if ((rc = check_launch("bn_apply"))) return rc;
     GemmArgs g2{ws_a, H, 1, nullptr, nullptr, w2, 1, H, b2, h_new, ld_h, out_row, nd, H, H, 0};        // out = a W2^T + b2
@@ -624,6 +644,9 @@ int tmpnn_input_bn_bwd(const float* xdet, int ld_x, int F, int nd, const int32_t
     const size_t ndH = (size_t)nd * H, SH = (size_t)(S > 0 ? S : 1) * H;
     const size_t need = tmpnn_input_bn_bwd_ws(nd, S, H, F);
     if (ws_floats < need) return set_error(TMPNN_EWORKSPACE, "input_bn_bwd: workspace %zu < %zu floats", ws_floats, need);
+    TM_REQUIRE(aligned16(y_save) && aligned16(mean) && aligned16(rstd) && aligned16(gamma) && aligned16(beta) && aligned16(ws) &&
+                   aligned16(d_h) && (ld_dh & 3) == 0,
+               "input_bn_bwd: y_save / mean / rstd / gamma / beta / ws / d_h must be 16-byte aligned (ld_dh a multiple of 4)");
     float* B0 = ws;              // d_out -> dy
     float* B1 = B0 + ndH;        // yhat
     float* B2 = B1 + ndH;        // a -> da -> dyhat
@@ -631,7 +654,7 @@ int tmpnn_input_bn_bwd(const float* xdet, int ld_x, int F, int nd, const int32_t
     float* s2 = s1 + SH;
     float* scratch = s2 + SH;
     const size_t scratch_n = ws_floats - (3 * ndH + 2 * SH);
-    const int gridE = ceil_div((long)ndH, 256);
+    const int gridE = ceil_div((long)ndH / 4, 256);          // four columns per thread
     int rc;
     hipLaunchKernelGGL(k_gather_rows, dim3(gridE), dim3(256), 0, st, d_h, (long)ld_dh, out_row, nd, H, B0);
     if ((rc = check_launch("gather_rows"))) return rc;
