@@ -63,6 +63,25 @@ typedef struct tmpnn_graph {
                                 endpoint) are issued from the same CU close in time */
 } tmpnn_graph;
 
+/*
+ * Edge tiles: the edge rows of a graph cut into tiles of `rows_per_tile` rows chosen so that a tile touches FEW distinct
+ * dets.  The rolling graph's frame blocks are dense [A srcs x D_t dsts] row sets in src-major order
+ * (utils/graph.py:141-156, 285-301), so a tile of (8 srcs x 16 dsts) needs 24 rows of a per-det table where 128
+ * consecutive rows of a wide block need up to 129, and every gather of h[src] / h[dst] (models/layers.py:90-95) or of
+ * their projections becomes a read from an LDS copy of the tile's det list.  Built once per graph
+ * (trackmpnn_amd.graph.build_edge_tiles); any tiling that covers every edge row exactly once is valid -- ragged
+ * (post-decode) graphs simply get longer det lists.
+ */
+typedef struct tmpnn_edge_tiles {
+    int32_t T;              /* tiles */
+    int32_t rows_per_tile;  /* 128 (wide cells) or 32 (H <= 64 cells) */
+    const int32_t* t_row;   /* [T * rows_per_tile] graph row of each slot; -1 = padding (last tile only) */
+    const int32_t* t_loc;   /* [T * rows_per_tile] (position of the slot's src det in the tile's det list) |
+                               (position of its dst det) << 16 */
+    const int32_t* t_dptr;  /* [T + 1] offsets into t_dets */
+    const int32_t* t_dets;  /* [t_dptr[T]] det INDEX (0..Dn-1, = row of a per-det table), ascending within a tile */
+} tmpnn_edge_tiles;
+
 int tmpnn_abi_version(void);
 const char* tmpnn_last_error(void);
 
@@ -459,6 +478,11 @@ int tmpnn_wide_gru_fwd(const void* prep, const int32_t* det_rows, int Dn, const 
                        const int32_t* src_pos, const int32_t* dst_pos, const float* h, int ld_h, int H,
                        const float* b_ih, const float* b_hh, float* P, float* h_out, int ld_out, float* gates,
                        size_t gate_plane, tmpnn_stream stream);
+/* The same forward over edge tiles (rows_per_tile = 128; tiles cover the graph's R edge rows): P rows of a tile's det
+ * list are staged in LDS once per tile and hidden chunk instead of gathered per edge row; bit-identical results. */
+int tmpnn_wide_gru_fwd_tiled(const void* prep, const int32_t* det_rows, int Dn, const tmpnn_edge_tiles* tiles, int R,
+                             const float* h, int ld_h, int H, const float* b_ih, const float* b_hh, float* P,
+                             float* h_out, int ld_out, float* gates, size_t gate_plane, tmpnn_stream stream);
 /* Data gradient (as tmpnn_gru_bwd_data with IN = H, no fused adjoint): d_msg[rows[r]][0:H] = d_gi W_ih,
  * d_h[rows[r]] = dh z + d_gh W_hh.  ws: tmpnn_wide_gru_bwd_data_ws(R, H) bytes (the materialised d_gi, d_gh). */
 size_t tmpnn_wide_gru_bwd_data_ws(int R, int H);

@@ -518,6 +518,43 @@ def check_wide(H, g, gd):
     return res
 
 
+def check_wide_tiled(H, g):
+    """tmpnn_wide_gru_fwd_tiled (edge tiles, projected det rows staged in LDS / read through the tile's det list) must
+    reproduce tmpnn_wide_gru_fwd BIT FOR BIT: same products in the same order, only the gathers differ."""
+    from trackmpnn_amd.graph import build_edge_tiles
+    torch.manual_seed(2000 + H)
+    gd = g.to(DEV)
+    ld = 2 * H
+    hD = torch.randn(g.N, ld, device=DEV)
+    R, Dn = g.E, g.Dn
+    sc = 1.0 / H ** 0.5
+    wih, whh = sc * torch.randn(3 * H, H, device=DEV), sc * torch.randn(3 * H, H, device=DEV)
+    bih, bhh = 0.3 * torch.randn(3 * H, device=DEV), 0.3 * torch.randn(3 * H, device=DEV)
+    lib = _lib.load()
+    prep = torch.empty(int(lib.tmpnn_wide_prep_bytes(H, H)), dtype=torch.uint8, device=DEV)
+    _lib.call('tmpnn_wide_prepare', wih.data_ptr(), whh.data_ptr(), H, H, prep.data_ptr(), st())
+    outs = []
+    tiles = build_edge_tiles(gd, 128, stats=True)
+    for tiled in (False, True):
+        P = torch.empty(Dn, 3 * H, device=DEV)
+        out = torch.full((g.N, ld), 3.0, device=DEV)
+        gates = torch.full((4, g.N, H), 5.0, device=DEV)
+        if tiled:
+            _lib.call('tmpnn_wide_gru_fwd_tiled', prep.data_ptr(), gd.det_row.data_ptr(), Dn, tiles.cref(), R,
+                      hD.data_ptr() + 4 * H, ld, H, bih.data_ptr(), bhh.data_ptr(), P.data_ptr(),
+                      out.data_ptr() + 4 * H, ld, gates.data_ptr(), g.N * H, st())
+        else:
+            _lib.call('tmpnn_wide_gru_fwd', prep.data_ptr(), gd.det_row.data_ptr(), Dn, gd.edge_row.data_ptr(), R,
+                      gd.src_pos.data_ptr(), gd.dst_pos.data_ptr(), hD.data_ptr() + 4 * H, ld, H, bih.data_ptr(),
+                      bhh.data_ptr(), P.data_ptr(), out.data_ptr() + 4 * H, ld, gates.data_ptr(), g.N * H, st())
+        torch.cuda.synchronize()
+        outs.append((out.cpu(), gates.cpu()))
+    cnt = (tiles.t_dptr[1:] - tiles.t_dptr[:-1])
+    return {'h_out bits': float(not torch.equal(outs[0][0], outs[1][0])),
+            'gates bits': float(not torch.equal(outs[0][1], outs[1][1])),
+            'staged tiles': int((cnt <= 40).sum()), 'listed tiles': int((cnt > 40).sum())}
+
+
 def run_all(report=print):
     """Yield (name, worst error, tolerance) for every stage/width combination."""
     g = make_graph()
@@ -543,6 +580,15 @@ def run_all(report=print):
     for H in (128, 256):
         for k, v in check_wide(H, g, gd).items():
             rec(f'wide cell H={H} {k}', v, 0.0 if k.endswith('untouched') else 2e-4)
+    from trackmpnn_amd.graph import dense_static_graph
+    for H in (128, 256):
+        # a dense 3-block window (tiles staged in LDS), a larger ragged batch (both kinds) and the small batch (one tile)
+        for tag, gt in (('dense 4x40', dense_static_graph(4, 40)), ('ragged batch', make_graph(B=40, frames=7, mean=7, seed=3)),
+                        ('small batch', g)):
+            r = check_wide_tiled(H, gt)
+            rec(f'wide tiled H={H} {tag} h_out bit-equal', r['h_out bits'], 0.0)
+            rec(f'wide tiled H={H} {tag} gates bit-equal', r['gates bits'], 0.0)
+            report(f'     tiles staged in LDS / read through their det list: {r["staged tiles"]} / {r["listed tiles"]}')
     for C in (32, 64, 96, 192, 256, 768):
         for k, v in check_heads(C, g, gd).items():
             rec(f'heads C={C} {k}', v, 2e-4)

@@ -222,3 +222,52 @@ def test_any_hidden_width_is_accepted_and_keeps_reference_shapes():
     import pytest
     with pytest.raises(ValueError):
         TrackMPNN('2d', 3, 300, 0, 'diff')
+
+
+def _check_tiles(g, tiles, R):
+    """Every edge row exactly once; each slot's (src, dst) recoverable through the tile's det list; lists ascending."""
+    E = g.E
+    T = tiles.T
+    assert T == (E + R - 1) // R and tiles.rows_per_tile == R
+    rows = tiles.t_row.long().view(T, R)
+    valid = rows >= 0
+    assert int(valid.sum()) == E and bool(valid.view(-1)[:E].all())        # padding only at the very end
+    assert torch.equal(torch.sort(rows[valid]).values, g.edge_row.long())
+    dptr = tiles.t_dptr.long()
+    assert dptr[0] == 0 and dptr[-1] == tiles.t_dets.numel() and bool((dptr[1:] > dptr[:-1]).all())
+    epos = torch.full((g.N,), -1, dtype=torch.long)
+    epos[g.edge_row.long()] = torch.arange(E)
+    loc = tiles.t_loc.long().view(T, R)
+    ls, ld = loc & 0xFFFF, loc >> 16
+    for t in range(T):
+        dets = tiles.t_dets.long()[dptr[t]:dptr[t + 1]]
+        assert bool((dets[1:] > dets[:-1]).all())
+        assert int(ls[t].max()) < dets.numel() and int(ld[t].max()) < dets.numel()
+        v = valid[t]
+        e = epos[rows[t][v]]
+        assert torch.equal(dets[ls[t][v]], g.src_pos.long()[e]) and torch.equal(dets[ld[t][v]], g.dst_pos.long()[e])
+        assert set(dets.tolist()) == set(g.src_pos.long()[e].tolist()) | set(g.dst_pos.long()[e].tolist())
+    return int((dptr[1:] - dptr[:-1]).max())
+
+
+def test_edge_tiles_cover_every_edge_and_index_their_dets():
+    """struct tmpnn_edge_tiles (include/tmpnn.h): built by build_edge_tiles for the wide cells (128 rows) and the
+    H <= 64 cells (32 rows); a dense frame block gives (8 srcs x 16 dsts) tiles over at most 8 + 16 dets away from the
+    seams, a ragged batch of small windows still covers every edge once."""
+    from trackmpnn_amd import WindowBuilder, batch_windows, synth_window
+    from trackmpnn_amd.graph import build_edge_tiles, dense_static_graph, edge_tiles
+    g = dense_static_graph(4, 40)                       # 3 blocks of 40 x 40 edges
+    tiles = build_edge_tiles(g, 128, stats=True)
+    worst = _check_tiles(g, tiles, 128)
+    assert worst == tiles.max_dets <= 48
+    cnt = (tiles.t_dptr[1:] - tiles.t_dptr[:-1]).long()
+    assert int((cnt <= 40).sum()) >= int(0.8 * tiles.T)   # what the kernel stages in LDS (WT_DMAX = 40)
+    # consecutive rows would touch up to 128 + 1 dets per tile on a 300-wide block; here a block of 40 still needs 40 + 4
+    wins = [WindowBuilder(synth_window(s, 6, 5, 10)).calls() for s in range(5)]
+    plans, _ = batch_windows(wins)
+    gr = plans[-1].graph
+    _check_tiles(gr, build_edge_tiles(gr, 128), 128)
+    _check_tiles(gr, build_edge_tiles(gr, 32, 4, 8), 32)
+    assert edge_tiles(gr, 128) is edge_tiles(gr, 128)   # cached on the graph
+    empty = dense_static_graph(1, 5)
+    assert build_edge_tiles(empty, 128).T == 0

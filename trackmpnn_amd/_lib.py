@@ -34,6 +34,15 @@ class CGraph(C.Structure):
 _GP = C.POINTER(CGraph)
 
 
+class CEdgeTiles(C.Structure):
+    """struct tmpnn_edge_tiles (include/tmpnn.h)."""
+    _fields_ = [('T', C.c_int32), ('rows_per_tile', C.c_int32), ('t_row', c_void_p), ('t_loc', c_void_p),
+                ('t_dptr', c_void_p), ('t_dets', c_void_p)]
+
+
+_TP = C.POINTER(CEdgeTiles)
+
+
 class CDGraph(C.Structure):
     """struct tmpnn_dgraph (include/tmpnn.h): index-form graph whose sizes live on the device."""
     _fields_ = [('N', C.c_int32), ('cap', C.c_int32), ('meta', c_void_p), ('is_edge', c_void_p), ('pos', c_void_p),
@@ -146,6 +155,8 @@ _SIGNATURES = {
     'tmpnn_wide_prepare': (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     'tmpnn_wide_gru_fwd': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int,
                                    c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
+    'tmpnn_wide_gru_fwd_tiled': (c_int, [c_void_p, c_void_p, c_int, _TP, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p,
+                                         c_void_p, c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
     'tmpnn_wide_gru_bwd_data_ws': (c_size_t, [c_int, c_int]),
     'tmpnn_wide_gru_bwd_data': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_size_t, c_void_p, c_int,
                                         c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_size_t, c_void_p]),

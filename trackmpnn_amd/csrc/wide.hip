@@ -47,7 +47,7 @@ __device__ __forceinline__ f32x16 w_mfma(const uint4& a, const uint4& b, f32x16 
 __device__ __forceinline__ int w_acc_row(int reg, int half) { return (reg & 3) + 8 * (reg >> 2) + 4 * half; }
 
 // ------------------------------------------------------------------------------------------------------------
-// weight images: img[((kt * 3 + piece) * N + n) * 32 + kk] (bf16) = piece of B[32 kt + kk][n]
+// weight images: img[((kt * 3 + piece) * N + n) * 32 + sw(kk, n)] (bf16) = piece of B[32 kt + kk][n]
 // ------------------------------------------------------------------------------------------------------------
 // B[k][n] = W[n * ldw + k] (TRANS: forward, B = W^T) or W[k * ldw + n] (backward-data, B = W)
 __global__ __launch_bounds__(256) void k_wide_prep(const float* __restrict__ W, int ldw, int K, int N, int trans,
@@ -59,7 +59,9 @@ __global__ __launch_bounds__(256) void k_wide_prep(const float* __restrict__ W, 
         uint32_t p1, p2, p3;
         w_split2(v, 0.f, p1, p2, p3);
         const int kt = k >> 5, kk = k & 31;
-        const size_t base = ((size_t)kt * 3 * N + n) * 32 + kk;
+        // the 16-byte chunk (kk >> 3) of column n is stored at chunk position (kk >> 3) ^ ((n >> 2) & 3): the LDS
+        // swizzle of w_sw, applied here once so that every consumer copies a tile LINEARLY (registers or LDS-DMA)
+        const size_t base = ((size_t)kt * 3 * N + n) * 32 + ((((kk >> 3) ^ ((n >> 2) & 3)) << 3) | (kk & 7));
         img[base] = (uint16_t)p1;
         img[base + (size_t)N * 32] = (uint16_t)p2;
         img[base + (size_t)2 * N * 32] = (uint16_t)p3;
@@ -69,7 +71,12 @@ __global__ __launch_bounds__(256) void k_wide_prep(const float* __restrict__ W, 
 // ------------------------------------------------------------------------------------------------------------
 // the tiled product
 // ------------------------------------------------------------------------------------------------------------
-static constexpr int W_BM = 128, W_KT = 32, W_LD = 40;     // LDS row stride in bf16 (80 B: 16-byte aligned, off the 64-B grid)
+static constexpr int W_BM = 128, W_KT = 32, W_LD = 32;     // LDS rows of 32 bf16 = 64 B = four 16-byte chunks, no padding
+// Chunk c of image row r sits at chunk c ^ ((r >> 2) & 3): the 16 lanes that ds_read_b128 serves together (lanes
+// {0-3, 12-15, 20-27}, ... of a wave whose lane = row) then cover all sixteen 16-byte slots of the 256-byte bank row
+// (rows equal mod 4 share a 64-byte quarter and differ in (r >> 2) & 3), and the 8-lane groups of ds_write_b128 (two
+// rows x four chunks) still write 128 contiguous bytes.  Round 2 padded the rows to 80 B instead: 25 % more LDS.
+__device__ __forceinline__ int w_sw(int row, int chunk) { return row * W_LD + ((chunk ^ ((row >> 2) & 3)) << 3); }
 
 struct WideArgs {
     // A: R rows of K fp32, row r at A + (a_rows ? a_rows[r] : r) * lda
@@ -125,7 +132,7 @@ __device__ __forceinline__ void wide_store(const float4& qa0, const float4& qa1,
         w_split2(qa0.z, qa0.w, q1[1], q2[1], q3[1]);
         w_split2(qa1.x, qa1.y, q1[2], q2[2], q3[2]);
         w_split2(qa1.z, qa1.w, q1[3], q2[3], q3[3]);
-        uint16_t* d = sA + row * W_LD + 8 * kq;
+        uint16_t* d = sA + w_sw(row, kq);
         constexpr int PL = W_BM * W_LD;
         *reinterpret_cast<uint4*>(d) = make_uint4(q1[0], q1[1], q1[2], q1[3]);
         *reinterpret_cast<uint4*>(d + PL) = make_uint4(q2[0], q2[1], q2[2], q2[3]);
@@ -140,7 +147,7 @@ __device__ __forceinline__ void wide_store(const float4& qa0, const float4& qa1,
         if (idx < 3 * CH) {
             const int p = idx / CH, c = idx % CH;
             const int col = c >> 2, qq = c & 3;
-            *reinterpret_cast<uint4*>(sB + p * PLB + col * W_LD + 8 * qq) = qb[i];
+            *reinterpret_cast<uint4*>(sB + p * PLB + col * W_LD + 8 * qq) = qb[i];      // (the image is pre-swizzled)
         }
     }
 }
@@ -159,12 +166,12 @@ __device__ __forceinline__ void wide_mma(const uint16_t* sA, const uint16_t* sB,
         uint4 af[3], bf[NCT][3];
 #pragma unroll
         for (int p = 0; p < 3; ++p)
-            af[p] = *reinterpret_cast<const uint4*>(sA + p * PL + (arow0 + r) * W_LD + 16 * s + 8 * hh);
+            af[p] = *reinterpret_cast<const uint4*>(sA + p * PL + w_sw(arow0 + r, 2 * s + hh));
 #pragma unroll
         for (int ct = 0; ct < NCT; ++ct)
 #pragma unroll
             for (int p = 0; p < 3; ++p)
-                bf[ct][p] = *reinterpret_cast<const uint4*>(sB + p * PLB + (bcol_first + ct * BSTEP + r) * W_LD + 16 * s + 8 * hh);
+                bf[ct][p] = *reinterpret_cast<const uint4*>(sB + p * PLB + w_sw(bcol_first + ct * BSTEP + r, 2 * s + hh));
 #pragma unroll
         for (int ct = 0; ct < NCT; ++ct) {
             f32x16 c = acc[ct];
@@ -344,6 +351,268 @@ __global__ __launch_bounds__(512) void k_wide_gru_fwd(WideArgs a) {
             *reinterpret_cast<float4*>(gp + 2 * a.gate_plane) = make_float4(onn[0], onn[1], onn[2], onn[3]);
             *reinterpret_cast<float4*>(gp + 3 * a.gate_plane) = make_float4(vhn[0], vhn[1], vhn[2], vhn[3]);
         }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// the same cell over EDGE TILES (struct tmpnn_edge_tiles): block-structured, LDS-staged projected det rows
+// ------------------------------------------------------------------------------------------------------------
+// A frame block of the rolling graph is a dense [A srcs x D_t dsts] set of edge rows (utils/graph.py:285-301), so 128
+// edge rows chosen as (8 srcs x 16 dsts) touch 24 rows of the projected table P instead of 256 gathered ones.  The tile
+// list (built once per graph: trackmpnn_amd.graph.build_edge_tiles) gives, per tile, its 128 graph rows, the list of the
+// DISTINCT det indices it touches and each row's two positions in that list.  A persistent block walks tiles; for each
+// of the H / 64 hidden chunks of a tile it runs the K loop of k_wide_gru_fwd and an epilogue that takes P[src] - P[dst]
+// from an LDS copy of the tile's distinct P rows (coalesced 256-byte row segments, fetched once per item while the first
+// K-step computes), the gate biases from LDS and the previous state from registers requested two K-steps before the
+// loop ends -- no global load is left on the epilogue's critical path.  The first two K-steps of the NEXT item are
+// requested before the epilogue, so a block's pipeline never drains between items.  A tile whose det list exceeds
+// WT_DMAX rows (ragged graphs, the seams between frame blocks) reads P through the list from global memory instead.
+struct WideTiles {
+    const int32_t* t_row; const int32_t* t_loc; const int32_t* t_dptr; const int32_t* t_dets; int T;
+};
+static constexpr int WT_DMAX = 40;
+static constexpr size_t W_TILED_SHM = W_GRU_SHM + sizeof(float) * (WT_DMAX * 192 + 6 * 64) + sizeof(int) * (128 + 128 + 256);
+
+// (opaque(): the index arithmetic below is invariant over the kernel's persistent loop; hoisted out of it, the offsets
+//  of all its call sites pile up in registers the K loop needs and the A operand in flight gets spilled)
+__device__ __forceinline__ int opaque(int v) { asm volatile("" : "+v"(v)); return v; }
+// LDS-DMA: 16 bytes per lane from a per-lane global address to (wave-uniform LDS byte address) + 16 * lane; no register
+// holds the data and no ds_write is issued.  Written as inline asm ON PURPOSE: hipcc waits vmcnt(0) before every LDS read
+// that follows a __builtin_amdgcn_global_load_lds it cannot disambiguate (here: before the first ds_read of every K-step,
+// i.e. the DMA of step k + 1 never ran under the MFMAs of step k).  An asm DMA is not in hipcc's bookkeeping, so its
+// completion is waited for by hand: wait_dma() in every wave, then the barrier, then the ds_reads.
+__device__ __forceinline__ uint32_t lds_addr(const void* p) {
+    return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)(const char*)p;
+}
+__device__ __forceinline__ void glds16(const void* gsrc, uint32_t lds_wave_base) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_wave_base) : "memory");
+}
+__device__ __forceinline__ void wait_dma() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+// the A rows of K-step kt (this thread: 8 floats of its tile row; a padding slot, a_row = -1, reads row 0: whatever
+// its MFMA rows produce is never stored)
+typedef float wf32x4 __attribute__((ext_vector_type(4)));
+struct WideA { wf32x4 lo, hi; };
+__device__ __forceinline__ WideA tiled_load_a(const WideArgs& a, int a_row, int kt) {
+    const wf32x4* p = reinterpret_cast<const wf32x4*>(a.A + (size_t)max(a_row, 0) * a.lda + kt * W_KT + 8 * (opaque(threadIdx.x) & 3));
+    WideA r;
+    r.lo = p[0]; r.hi = p[1];
+    return r;
+}
+// the weight tile of K-step kt (3 pieces x 192 columns x 64 B = 2304 chunks) straight into the LDS image: the global
+// image is pre-swizzled (k_wide_prep), so chunk idx of the tile lands at byte 16 * idx
+__device__ __forceinline__ void tiled_dma_b(const WideArgs& a, int kt, int hc0, uint16_t* sB) {
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = opaque(threadIdx.x & 63);
+    constexpr int CH = 3 * 64 * 4;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        const int idx0 = i * 512 + wave * 64;
+        if (idx0 < 3 * CH) {                                  // wave-uniform (the fifth pass is waves 0-3 only)
+            const int idx = idx0 + lane;
+            const int p = idx / CH, c = idx % CH;
+            const int col = c >> 2, qq = c & 3;
+            const int n = hc0 + (col >> 6) * a.H + (col & 63);
+            glds16(a.img + (((size_t)kt * 3 + p) * a.N + n) * 32 + 8 * qq, lds_addr(sB) + 16u * idx0);
+        }
+    }
+}
+__device__ __forceinline__ void tiled_store_a(const WideA& x, uint16_t* sA) {
+    const int ts = opaque(threadIdx.x), row = ts >> 2, kq = ts & 3;
+    uint32_t q1[4], q2[4], q3[4];
+    w_split2(x.lo[0], x.lo[1], q1[0], q2[0], q3[0]);
+    w_split2(x.lo[2], x.lo[3], q1[1], q2[1], q3[1]);
+    w_split2(x.hi[0], x.hi[1], q1[2], q2[2], q3[2]);
+    w_split2(x.hi[2], x.hi[3], q1[3], q2[3], q3[3]);
+    uint16_t* d = sA + w_sw(row, kq);
+    constexpr int PL = W_BM * W_LD;
+    *reinterpret_cast<uint4*>(d) = make_uint4(q1[0], q1[1], q1[2], q1[3]);
+    *reinterpret_cast<uint4*>(d + PL) = make_uint4(q2[0], q2[1], q2[2], q2[3]);
+    *reinterpret_cast<uint4*>(d + 2 * PL) = make_uint4(q3[0], q3[1], q3[2], q3[3]);
+}
+
+__device__ __forceinline__ void gru_gate4(const float4& ps_r, const float4& pd_r, const float4& ps_z, const float4& pd_z,
+                                          const float4& ps_n, const float4& pd_n, const float4& ghr, const float4& ghz,
+                                          const float4& ghn, const float* sBias, int q, const float4& hp4, float4& o_h,
+                                          float4& o_r, float4& o_z, float4& o_n, float4& o_hn) {
+    const float4 bir = *reinterpret_cast<const float4*>(sBias + 4 * q), biz = *reinterpret_cast<const float4*>(sBias + 64 + 4 * q);
+    const float4 bin_ = *reinterpret_cast<const float4*>(sBias + 128 + 4 * q);
+    const float4 bhr = *reinterpret_cast<const float4*>(sBias + 192 + 4 * q), bhz = *reinterpret_cast<const float4*>(sBias + 256 + 4 * q);
+    const float4 bhn = *reinterpret_cast<const float4*>(sBias + 320 + 4 * q);
+    const float gir[4] = {ps_r.x - pd_r.x, ps_r.y - pd_r.y, ps_r.z - pd_r.z, ps_r.w - pd_r.w};
+    const float giz[4] = {ps_z.x - pd_z.x, ps_z.y - pd_z.y, ps_z.z - pd_z.z, ps_z.w - pd_z.w};
+    const float gin[4] = {ps_n.x - pd_n.x, ps_n.y - pd_n.y, ps_n.z - pd_n.z, ps_n.w - pd_n.w};
+    const float vr[4] = {ghr.x + bhr.x + bir.x, ghr.y + bhr.y + bir.y, ghr.z + bhr.z + bir.z, ghr.w + bhr.w + bir.w};
+    const float vz[4] = {ghz.x + bhz.x + biz.x, ghz.y + bhz.y + biz.y, ghz.z + bhz.z + biz.z, ghz.w + bhz.w + biz.w};
+    const float vhn[4] = {ghn.x + bhn.x, ghn.y + bhn.y, ghn.z + bhn.z, ghn.w + bhn.w};
+    const float vbn[4] = {bin_.x, bin_.y, bin_.z, bin_.w}, hpv[4] = {hp4.x, hp4.y, hp4.z, hp4.w};
+    float orr[4], ozz[4], onn[4], oh[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        orr[j] = w_sigm(gir[j] + vr[j]);
+        ozz[j] = w_sigm(giz[j] + vz[j]);
+        onn[j] = w_tanh(gin[j] + vbn[j] + orr[j] * vhn[j]);
+        oh[j] = (1.0f - ozz[j]) * onn[j] + ozz[j] * hpv[j];
+    }
+    o_h = make_float4(oh[0], oh[1], oh[2], oh[3]);
+    o_r = make_float4(orr[0], orr[1], orr[2], orr[3]);
+    o_z = make_float4(ozz[0], ozz[1], ozz[2], ozz[3]);
+    o_n = make_float4(onn[0], onn[1], onn[2], onn[3]);
+    o_hn = make_float4(vhn[0], vhn[1], vhn[2], vhn[3]);
+}
+
+__global__ __launch_bounds__(512) void k_wide_gru_fwd_tiled(WideArgs a, WideTiles tl) {
+    extern __shared__ __attribute__((aligned(16))) uint16_t w_dyn[];
+    constexpr int SA = 3 * W_BM * W_LD, SB = 3 * 192 * W_LD, BUF = SA + SB;
+    uint16_t* const buf0 = w_dyn;
+    uint16_t* const buf1 = w_dyn + BUF;
+    float* const sC = reinterpret_cast<float*>(w_dyn);               // [128][192], aliases the operand buffers
+    float* const sP = reinterpret_cast<float*>(w_dyn + 2 * BUF);     // [WT_DMAX][3 gates x 64]
+    float* const sBias = sP + WT_DMAX * 192;                         // b_ih r, z, n | b_hh r, z, n of the hidden chunk
+    int* const sRow = reinterpret_cast<int*>(sBias + 6 * 64);
+    int* const sLoc = sRow + 128;
+    int* const sDet = sLoc + 128;
+    const int H = a.H, nchunk = H >> 6, nk = H / W_KT;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wr = wave & 3, wc = wave >> 2;
+    const int G = gridDim.x;
+    int t = blockIdx.x;
+    if (t >= tl.T) return;
+    // descriptor of the first tile, in registers (d_*: what this thread will put into the LDS arrays)
+    int d_row = tid < 128 ? tl.t_row[(size_t)t * 128 + tid] : 0;
+    int d_loc = tid < 128 ? tl.t_loc[(size_t)t * 128 + tid] : 0;
+    int dp0 = tl.t_dptr[t], nd_next = tl.t_dptr[t + 1] - dp0;
+    int d_det = (tid < 256 && tid < nd_next) ? tl.t_dets[dp0 + tid] : 0;
+    int a_row_next = tl.t_row[(size_t)t * 128 + (tid >> 2)];
+    int a_row = a_row_next, nd = 0;
+    // ONE A operand set: step k + 1 is requested before the MFMAs of step k and written to the other buffer after them
+    WideA xa = tiled_load_a(a, a_row, 0);
+    tiled_dma_b(a, 0, 0, buf0 + SA);
+    for (int bx = 0;;) {
+        const int hc0 = bx << 6;
+        if (bx == 0) {
+            if (tid < 128) { sRow[tid] = d_row; sLoc[tid] = d_loc; }
+            if (tid < 256) sDet[tid] = d_det;
+            nd = nd_next;
+        }
+        if (tid < 384) sBias[tid] = (tid < 192 ? a.b_ih : a.b_hh)[((tid % 192) >> 6) * H + hc0 + (tid & 63)];
+        tiled_store_a(xa, buf0);
+        wait_dma();
+        __syncthreads();
+        const bool last_chunk = bx + 1 == nchunk;
+        const bool more_tiles = t + G < tl.T;
+        if (last_chunk && more_tiles) {                       // the next tile's descriptor, a whole item ahead of its use
+            const int tn = t + G;
+            d_row = tid < 128 ? tl.t_row[(size_t)tn * 128 + tid] : 0;
+            d_loc = tid < 128 ? tl.t_loc[(size_t)tn * 128 + tid] : 0;
+            dp0 = tl.t_dptr[tn]; nd_next = tl.t_dptr[tn + 1] - dp0;
+            d_det = (tid < 256 && tid < nd_next) ? tl.t_dets[dp0 + tid] : 0;
+            a_row_next = tl.t_row[(size_t)tn * 128 + (tid >> 2)];
+        }
+        const bool staged = nd <= WT_DMAX;
+        if (staged) {                                         // the tile's distinct P rows, this chunk's 3 x 64 columns:
+#pragma unroll                                                // chunk idx of the [nd][48] copy lands at byte 16 * idx
+            for (int i = 0; i < 4; ++i) {
+                const int idx0 = 512 * i + 64 * __builtin_amdgcn_readfirstlane(wave);
+                const int idx = idx0 + opaque(lane);
+                if (idx < nd * 48) {
+                    const int rw = idx / 48, c = idx % 48;
+                    glds16(a.P + (size_t)sDet[rw] * a.ldp + (c >> 4) * H + hc0 + 4 * (c & 15), lds_addr(sP) + 16u * idx0);
+                }
+            }
+        }
+        f32x16 acc[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[j][q] = 0.f;
+        wf32x4 hp[4];
+        for (int kt = 0; kt < nk; kt += 2) {
+            tiled_dma_b(a, kt + 1, hc0, buf1 + SA);
+            xa = tiled_load_a(a, a_row, kt + 1);
+            __builtin_amdgcn_sched_barrier(0);                // (the requests stay above the MFMAs, their consumer below:
+            wide_mma<3, 3>(buf0, buf0 + SA, 32 * wr, 32 * wc, lane, acc);
+            __builtin_amdgcn_sched_barrier(0);                //  left alone hipcc sinks the load to its first use)
+            tiled_store_a(xa, buf1);
+            wait_dma();
+            __syncthreads();
+            if (kt + 2 < nk) {
+                tiled_dma_b(a, kt + 2, hc0, buf0 + SA);
+                xa = tiled_load_a(a, a_row, kt + 2);
+            } else {                                          // previous state of the epilogue's rows (L2 hits: the A tile)
+                const int th = opaque(tid);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int grow = sRow[(th >> 4) + 32 * i];
+                    hp[i] = *reinterpret_cast<const wf32x4*>(a.h + (size_t)max(grow, 0) * a.ld_h + hc0 + 4 * (th & 15));
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            wide_mma<3, 3>(buf1, buf1 + SA, 32 * wr, 32 * wc, lane, acc);
+            __builtin_amdgcn_sched_barrier(0);
+            if (kt + 2 < nk) tiled_store_a(xa, buf0);
+            wait_dma();
+            __syncthreads();
+        }
+        // the next item's first A K-step flies under the epilogue (its weight tile follows the epilogue: sC aliases it)
+        const int nbx = last_chunk ? 0 : bx + 1;
+        const bool more = !last_chunk || more_tiles;
+        if (more) xa = tiled_load_a(a, last_chunk ? a_row_next : a_row, 0);
+        {
+            const int lw = opaque(lane), c = lw & 31, half = lw >> 5;
+#pragma unroll
+            for (int gate = 0; gate < 3; ++gate)
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg)
+                    sC[(32 * wr + w_acc_row(reg, half)) * 192 + 64 * gate + 32 * wc + c] = acc[gate][reg];
+        }
+        __syncthreads();
+        {
+            const int te = opaque(tid), q = te & 15;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int lr = (te >> 4) + 32 * i;
+                const int grow = sRow[lr];
+                if (grow < 0) continue;
+                const int loc = sLoc[lr];
+                const int ls = loc & 0xFFFF, ldd = loc >> 16;
+                float4 s_r, s_z, s_n, d_r, d_z, d_n;
+                if (staged) {
+                    const float* ps = sP + ls * 192 + 4 * q;
+                    const float* pd = sP + ldd * 192 + 4 * q;
+                    s_r = *reinterpret_cast<const float4*>(ps); s_z = *reinterpret_cast<const float4*>(ps + 64);
+                    s_n = *reinterpret_cast<const float4*>(ps + 128);
+                    d_r = *reinterpret_cast<const float4*>(pd); d_z = *reinterpret_cast<const float4*>(pd + 64);
+                    d_n = *reinterpret_cast<const float4*>(pd + 128);
+                } else {
+                    const float* ps = a.P + (size_t)sDet[ls] * a.ldp + hc0 + 4 * q;
+                    const float* pd = a.P + (size_t)sDet[ldd] * a.ldp + hc0 + 4 * q;
+                    s_r = *reinterpret_cast<const float4*>(ps); s_z = *reinterpret_cast<const float4*>(ps + H);
+                    s_n = *reinterpret_cast<const float4*>(ps + 2 * H);
+                    d_r = *reinterpret_cast<const float4*>(pd); d_z = *reinterpret_cast<const float4*>(pd + H);
+                    d_n = *reinterpret_cast<const float4*>(pd + 2 * H);
+                }
+                const float4 ghr = *reinterpret_cast<const float4*>(sC + lr * 192 + 4 * q);
+                const float4 ghz = *reinterpret_cast<const float4*>(sC + lr * 192 + 64 + 4 * q);
+                const float4 ghn = *reinterpret_cast<const float4*>(sC + lr * 192 + 128 + 4 * q);
+                float4 o_h, o_r, o_z, o_n, o_hn;
+                gru_gate4(s_r, d_r, s_z, d_z, s_n, d_n, ghr, ghz, ghn, sBias, q, make_float4(hp[i][0], hp[i][1], hp[i][2], hp[i][3]), o_h, o_r, o_z, o_n, o_hn);
+                const int col = hc0 + 4 * q;
+                *reinterpret_cast<float4*>(a.h_out + (size_t)grow * a.ld_out + col) = o_h;
+                if (a.gates) {
+                    float* gp = a.gates + (size_t)grow * H + col;
+                    *reinterpret_cast<float4*>(gp) = o_r;
+                    *reinterpret_cast<float4*>(gp + a.gate_plane) = o_z;
+                    *reinterpret_cast<float4*>(gp + 2 * a.gate_plane) = o_n;
+                    *reinterpret_cast<float4*>(gp + 3 * a.gate_plane) = o_hn;
+                }
+            }
+        }
+        __syncthreads();
+        if (!more) break;
+        if (last_chunk) { t += G; a_row = a_row_next; }
+        bx = nbx;
+        tiled_dma_b(a, 0, bx << 6, buf0 + SA);                // (lands under the A split + store and is waited at the barrier)
     }
 }
 
@@ -710,6 +979,45 @@ int tmpnn_wide_gru_fwd(const void* prep, const int32_t* det_rows, int Dn, const 
     TM_SHM_ONCE(k_wide_gru_fwd, W_GRU_SHM);
     hipLaunchKernelGGL(k_wide_gru_fwd, dim3(wide_grid(H / 64, ceil_div(R, W_BM))), dim3(512), W_GRU_SHM, st, a);
     return check_launch("wide_gru_fwd");
+}
+
+/* The same cell over edge tiles (struct tmpnn_edge_tiles, rows_per_tile = 128): results bit-identical to
+ * tmpnn_wide_gru_fwd; the projected det rows of a tile are staged in LDS once instead of gathered per edge row. */
+int tmpnn_wide_gru_fwd_tiled(const void* prep, const int32_t* det_rows, int Dn, const tmpnn_edge_tiles* tiles, int R,
+                             const float* h, int ld_h, int H, const float* b_ih, const float* b_hh, float* P,
+                             float* h_out, int ld_out, float* gates, size_t gate_plane, tmpnn_stream stream) {
+    TM_REQUIRE(tmpnn_wide_supported(H, H), "wide_gru_fwd_tiled: H=%d", H);
+    if (R == 0) return TMPNN_OK;
+    TM_REQUIRE(tiles != nullptr, "wide_gru_fwd_tiled: tiles is null");
+    TM_REQUIRE(tiles->rows_per_tile == 128 && tiles->T > 0 && (long)tiles->T * 128 >= R && (long)(tiles->T - 1) * 128 < R &&
+                   tiles->t_row && tiles->t_loc && tiles->t_dptr && tiles->t_dets,
+               "wide_gru_fwd_tiled: tile list (T=%d, rows_per_tile=%d) does not cover R=%d rows in 128-row tiles",
+               tiles->T, tiles->rows_per_tile, R);
+    TM_REQUIRE(prep && det_rows && h && b_ih && b_hh && P && h_out && Dn > 0 && R > 0,
+               "wide_gru_fwd_tiled: null pointer / empty det table");
+    TM_REQUIRE(aligned16(prep) && aligned16(h) && (ld_h & 3) == 0 && ld_h >= H && ld_out >= H && aligned16(P) &&
+                   aligned16(h_out) && (ld_out & 3) == 0 && aligned16(b_ih) && aligned16(b_hh) &&
+                   (gates == nullptr || (aligned16(gates) && (gate_plane & 3) == 0)), "wide_gru_fwd_tiled: layout (16-byte alignment)");
+    TM_REQUIRE(gates == nullptr || gate_plane >= (size_t)H, "wide_gru_fwd_tiled: gate_plane too small");
+    hipStream_t st = as_stream(stream);
+    const uint16_t* f_hh = reinterpret_cast<const uint16_t*>(prep);
+    const uint16_t* f_ih = f_hh + (size_t)3 * H * 3 * H;
+    WideArgs p{};
+    p.A = h; p.lda = ld_h; p.a_rows = det_rows; p.R = Dn; p.K = H; p.img = f_ih; p.N = 3 * H;
+    p.C = P; p.ldc = 3 * H; p.c_rows = nullptr; p.accumulate = 0;
+    int rc = launch_store(p, st);
+    if (rc) return rc;
+    WideArgs a{};
+    a.A = h; a.lda = ld_h; a.R = R; a.K = H; a.img = f_hh; a.N = 3 * H;
+    a.P = P; a.ldp = 3 * H; a.h = h; a.ld_h = ld_h; a.H = H;
+    a.b_ih = b_ih; a.b_hh = b_hh; a.h_out = h_out; a.ld_out = ld_out; a.gates = gates; a.gate_plane = gate_plane;
+    WideTiles tl{tiles->t_row, tiles->t_loc, tiles->t_dptr, tiles->t_dets, tiles->T};
+    TM_SHM_ONCE(k_wide_gru_fwd_tiled, W_TILED_SHM);
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    const int grid = tiles->T < cus ? tiles->T : cus;          // one persistent block per CU (157 KB of LDS each)
+    hipLaunchKernelGGL(k_wide_gru_fwd_tiled, dim3(grid), dim3(512), W_TILED_SHM, st, a, tl);
+    return check_launch("wide_gru_fwd_tiled");
 }
 
 size_t tmpnn_wide_gru_bwd_data_ws(int R, int H) { return R > 0 ? sizeof(float) * 2 * (size_t)R * 3 * H : 0; }

@@ -15,7 +15,7 @@ from typing import Dict, List, Optional, Sequence, Tuple
 import torch
 
 from . import _lib
-from .graph import CallPlan
+from .graph import CallPlan, edge_tiles
 
 ATT_DROPOUT_P = 0.5
 # OPT-IN fast path: accumulate parameter gradients straight into existing p.grad buffers (the kernels add into their
@@ -32,6 +32,8 @@ WIDE_DET = os.environ.get('TMPNN_WIDE_DET', '1') == '1'
 FUSED_BWD = os.environ.get('TMPNN_FUSED_BWD', '1') == '1'     # one-pass cell backward (see mp_backward)
 # H = 128 / 256 edge cells as LDS-tiled bf16x6 GEMMs (csrc/wide.hip); TMPNN_WIDE=0 keeps round 1's f32-MFMA kernels
 WIDE = os.environ.get('TMPNN_WIDE', '1') != '0' and os.environ.get('TMPNN_SPLIT', '1')[:1] != '0'
+# wide cells: forward over edge tiles (projected det rows staged in LDS); TMPNN_WIDE_TILED=0 keeps the per-row gathers
+WIDE_TILED = os.environ.get('TMPNN_WIDE_TILED', '1') != '0'
 
 
 _wide_ws: Dict[torch.device, torch.Tensor] = {}
@@ -230,10 +232,15 @@ def mp_forward(spec: ModelSpec, plan: CallPlan, x: torch.Tensor, h_in: Optional[
             prep = _wide_prep(P[f + 'edge_gru.weight_ih'], P[f + 'edge_gru.weight_hh'], H)
             wide_preps.append(prep)
             proj = torch.empty((Dn, 3 * H), **opts)
-            _lib.call('tmpnn_wide_gru_fwd', prep.data_ptr(), g.det_row.data_ptr(), Dn, g.edge_row.data_ptr(), E,
-                      g.src_pos.data_ptr(), g.dst_pos.data_ptr(), hg, GH, H,
-                      P[f + 'edge_gru.bias_ih'].data_ptr(), P[f + 'edge_gru.bias_hh'].data_ptr(),
-                      proj.data_ptr(), og, GH, gp, plane, st)
+            if WIDE_TILED:
+                _lib.call('tmpnn_wide_gru_fwd_tiled', prep.data_ptr(), g.det_row.data_ptr(), Dn, edge_tiles(g, 128).cref(), E,
+                          hg, GH, H, P[f + 'edge_gru.bias_ih'].data_ptr(), P[f + 'edge_gru.bias_hh'].data_ptr(),
+                          proj.data_ptr(), og, GH, gp, plane, st)
+            else:
+                _lib.call('tmpnn_wide_gru_fwd', prep.data_ptr(), g.det_row.data_ptr(), Dn, g.edge_row.data_ptr(), E,
+                          g.src_pos.data_ptr(), g.dst_pos.data_ptr(), hg, GH, H,
+                          P[f + 'edge_gru.bias_ih'].data_ptr(), P[f + 'edge_gru.bias_hh'].data_ptr(),
+                          proj.data_ptr(), og, GH, gp, plane, st)
         elif use_proj:
             # (h[src]-h[dst]) W_ih^T = P[src] - P[dst] with P = h[dets] W_ih^T: the x-half of the edge cell's
             # forward GEMM runs over the Dn det rows instead of the E edge rows

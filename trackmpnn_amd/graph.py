@@ -77,6 +77,80 @@ class FrameGraph:
         return epos[row], endpoint
 
 
+@dataclass
+class EdgeTiles:
+    """struct tmpnn_edge_tiles: the edge rows cut into tiles that touch few distinct dets (include/tmpnn.h)."""
+    T: int
+    rows_per_tile: int
+    t_row: torch.Tensor      # int32 [T * rows_per_tile]  graph row of each slot, -1 = padding
+    t_loc: torch.Tensor      # int32 [T * rows_per_tile]  src position | dst position << 16 in the tile's det list
+    t_dptr: torch.Tensor     # int32 [T + 1]
+    t_dets: torch.Tensor     # int32 [t_dptr[T]]          det indices, ascending within a tile
+    max_dets: int = 0        # longest det list (diagnostics; filled by build_edge_tiles(stats=True))
+    _c: Optional[_lib.CEdgeTiles] = field(default=None, repr=False, compare=False)
+
+    def cref(self):
+        if self._c is None:
+            self._c = _lib.CEdgeTiles(self.T, self.rows_per_tile, self.t_row.data_ptr(), self.t_loc.data_ptr(),
+                                      self.t_dptr.data_ptr(), self.t_dets.data_ptr())
+        return C.byref(self._c)
+
+
+def build_edge_tiles(graph: FrameGraph, rows_per_tile: int = 128, src_group: int = 8, dst_group: int = 16,
+                     stats: bool = False) -> EdgeTiles:
+    """Cut the graph's edge rows into tiles of `rows_per_tile` rows that touch few distinct dets.
+
+    A frame block of the rolling graph is a dense [A srcs x D_t dsts] set of rows in src-major order
+    (reference/utils/graph.py:141-156, 285-301).  The edges are ordered by (dst // dst_group, src // src_group, src, dst)
+    and cut every `rows_per_tile`: where blocks are dense a tile is (src_group x dst_group) edges over
+    src_group + dst_group dets; ragged graphs (after decode_tracks' row deletion) just get longer det lists.  Index
+    plumbing only (torch ops on the graph's device, no host round trip unless `stats`)."""
+    if graph.src_pos is None or graph.dst_pos is None:
+        raise ValueError('build_edge_tiles: the graph carries no src_pos / dst_pos')
+    dev = graph.device
+    E, R = graph.E, int(rows_per_tile)
+    T = (E + R - 1) // R
+    i32 = lambda t: t.to(torch.int32).contiguous()
+    if T == 0:
+        z = torch.zeros(0, dtype=torch.int32, device=dev)
+        return EdgeTiles(0, R, z, z.clone(), torch.zeros(1, dtype=torch.int32, device=dev), z.clone())
+    s, d = graph.src_pos.long(), graph.dst_pos.long()
+    ns = graph.Dn // src_group + 1
+    key = (((d // dst_group) * ns + s // src_group) * src_group + s % src_group) * dst_group + d % dst_group
+    order = torch.argsort(key)
+    pad = T * R - E
+    so, do, ro = s[order], d[order], graph.edge_row.long()[order]
+    if pad:
+        so = torch.cat([so, so[-1:].expand(pad)])            # padding slots repeat the last edge's dets (no new det)
+        do = torch.cat([do, do[-1:].expand(pad)])
+        ro = torch.cat([ro, torch.full((pad,), -1, dtype=torch.long, device=dev)])
+    both = torch.cat([so.view(T, R), do.view(T, R)], 1)      # [T, 2R]
+    vals, perm = both.sort(1)
+    first = torch.ones_like(vals, dtype=torch.bool)
+    first[:, 1:] = vals[:, 1:] != vals[:, :-1]
+    rank = first.long().cumsum(1) - 1                        # position in the tile's det list, per sorted element
+    local = torch.empty_like(rank)
+    local.scatter_(1, perm, rank)
+    cnt = rank[:, -1] + 1
+    dptr = torch.zeros(T + 1, dtype=torch.long, device=dev)
+    dptr[1:] = cnt.cumsum(0)
+    loc = local[:, :R] | (local[:, R:] << 16)
+    tiles = EdgeTiles(T, R, i32(ro), i32(loc.reshape(-1)), i32(dptr), i32(vals[first]))
+    if stats:
+        tiles.max_dets = int(cnt.max())
+    return tiles
+
+
+def edge_tiles(graph: FrameGraph, rows_per_tile: int = 128) -> EdgeTiles:
+    """The graph's cached tile list (built on first use)."""
+    cache = graph.__dict__.setdefault('_tiles', {})
+    t = cache.get(rows_per_tile)
+    if t is None:
+        t = cache[rows_per_tile] = (build_edge_tiles(graph, rows_per_tile) if rows_per_tile == 128 else
+                                    build_edge_tiles(graph, rows_per_tile, 4, 8))
+    return t
+
+
 def set_det_groups(graph: FrameGraph, det_group) -> FrameGraph:
     """Visit the dets group by group in the det -> edge reductions (struct tmpnn_graph, det_order).
 
