@@ -143,3 +143,63 @@ def test_two_ranks_real_steps_keep_replicas_identical():
         p.join(timeout=120)
         assert p.exitcode == 0
     assert all(ok for _, ok in res), res
+
+
+def test_shard_windows_balances_edge_work():
+    """variable graph sizes are dealt by sum of E (longest-processing-time greedy); every rank computes the
+    same partition, it covers every window once, and the heaviest rank stays within one window of the mean."""
+    import numpy as np
+    from trackmpnn_amd.dist import shard_windows
+    rng = np.random.RandomState(0)
+    for world in (2, 4, 8):
+        counts = np.concatenate([rng.poisson(800, 40), rng.poisson(9000, 9), [60000]]).tolist()   # KITTI-, BDD-sized, one huge
+        shards = [shard_windows(len(counts), r, world, counts) for r in range(world)]
+        assert sorted(i for s in shards for i in s) == list(range(len(counts)))
+        loads = [sum(counts[i] for i in s) for s in shards]
+        mean = sum(counts) / world
+        assert max(loads) <= max(mean + max(c for c in counts if c < 60000), 60000)
+        naive = [sum(counts[i] for i in range(r, len(counts), world)) for r in range(world)]
+        assert max(loads) <= max(naive)
+        assert all(s == sorted(s) for s in shards)
+    assert shard_windows(5, 1, 2) == [1, 3]
+    assert shard_windows(3, 0, 4, [5, 5, 5]) == [0] and shard_windows(3, 3, 4, [5, 5, 5]) == []
+    with pytest.raises(ValueError):
+        shard_windows(3, 0, 2, [1, 2])
+
+
+def _nccl_worker(port, q):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from trackmpnn_amd import TrackMPNN
+    from trackmpnn_amd.dist import GradBucket, allreduce_grads
+    torch.cuda.set_device(0)
+    dist.init_process_group('nccl', rank=0, world_size=1)
+    torch.manual_seed(5)
+    model = TrackMPNN('2d', 3, 64, 0, 'diff').to('cuda:0')
+    bucket = GradBucket(model)
+    bucket.flat.copy_(torch.arange(bucket.flat.numel(), device='cuda:0', dtype=torch.float32) % 97)
+    before = bucket.flat.clone()
+    allreduce_grads(model, bucket, 1)
+    torch.cuda.synchronize()
+    ok = torch.equal(bucket.flat, before) and bucket.check_alias() and dist.get_backend() == 'nccl'
+    q.put(bool(ok))
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_bucket_allreduce_through_rccl_world1():
+    """The collective of the N > 1 path on the backend it will use: `nccl` (= RCCL on ROCm) initialised at world size 1
+    on cuda:0, the flat gradient bucket handed to all_reduce -- RCCL loads, accepts the bucket and returns it unchanged.
+    (A gpurun box has one GPU; the multi-rank exchange itself is covered over gloo above.)"""
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU')
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    p = ctx.Process(target=_nccl_worker, args=(_free_port(), q))
+    p.start()
+    ok = q.get(timeout=300)
+    p.join(timeout=120)
+    assert p.exitcode == 0 and ok

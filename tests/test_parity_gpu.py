@@ -746,3 +746,59 @@ def test_one_pass_backward_ragged_sizes_match_the_two_kernels(R):
                 for a, b in zip(g0, g1):
                     assert float((a - b).abs().max()) <= 2e-5 * max(1.0, float(a.abs().max())), tag
                 assert bool((h1[~inside] == 5.0).all()) and bool((m1[~inside] == base[~inside]).all()), tag
+
+
+@pytest.mark.parametrize('H', [64, 256])
+def test_split_products_are_fp32_accurate_on_wide_dynamic_range(H):
+    """The "bf16x6" products (three bf16 pieces per fp32 operand, six bf16 MFMAs, fp32 accumulate) against an
+    fp64 product on operands whose magnitudes span 2^-20 .. 2^20 within a row: error relative to sum |a||b| within 1e-6
+    and no worse than 1.5 x torch's own fp32 matmul on the same data (+ 1e-7); Inf / NaN inputs give non-finite outputs
+    in exactly the rows where an fp32 product does (an Inf comes out as NaN: its residual is Inf - Inf), and leave every
+    other row's bits alone.  H = 64: tmpnn_rows_linear (k_rows_gemm_split); H = 256: the wide cells' projection
+    (k_wide_gemm_store), read back from tmpnn_wide_gru_fwd's P."""
+    from trackmpnn_amd import _lib
+    torch.manual_seed(7 + H)
+    R = 3000
+    st = torch.cuda.current_stream().cuda_stream
+    scale = lambda shape: torch.randn(shape, dtype=torch.float64) * torch.pow(2.0, torch.empty(shape, dtype=torch.float64).uniform_(-20, 20))
+    a = scale((R, H)).float()
+    w = scale((3 * H, H)).float()                    # weight [3H][H]; the product is a @ w^T
+    rows = torch.arange(R, dtype=torch.int32, device=DEV)
+
+    def product(a_host):
+        aD, wD = a_host.to(DEV), w.to(DEV)
+        out = torch.empty(R, 3 * H, device=DEV)
+        if H == 64:
+            wt = wD.t().contiguous()
+            _lib.call('tmpnn_rows_linear', rows.data_ptr(), R, aD.data_ptr(), H, H, wt.data_ptr(), 3 * H, out.data_ptr(), 3 * H, st)
+        else:
+            lib = _lib.load()
+            prep = torch.empty(int(lib.tmpnn_wide_prep_bytes(H, H)), dtype=torch.uint8, device=DEV)
+            _lib.call('tmpnn_wide_prepare', wD.data_ptr(), wD.data_ptr(), H, H, prep.data_ptr(), st)
+            # one edge row (row R) between dets 0 and 1: the call writes P = a @ w^T for the R det rows
+            hh = torch.cat([aD, torch.zeros(1, H, device=DEV)])
+            e_row = torch.tensor([R], dtype=torch.int32, device=DEV)
+            z = torch.zeros(1, dtype=torch.int32, device=DEV)
+            o = torch.ones(1, dtype=torch.int32, device=DEV)
+            b = torch.zeros(3 * H, device=DEV)
+            hout = torch.empty(R + 1, H, device=DEV)
+            _lib.call('tmpnn_wide_gru_fwd', prep.data_ptr(), rows.data_ptr(), R, e_row.data_ptr(), 1, z.data_ptr(), o.data_ptr(),
+                      hh.data_ptr(), H, H, b.data_ptr(), b.data_ptr(), out.data_ptr(), hout.data_ptr(), H, None, 0, st)
+        torch.cuda.synchronize()
+        return out.cpu()
+
+    got = product(a)
+    ref64 = a.double() @ w.double().t()
+    denom = a.double().abs() @ w.double().abs().t()
+    err = ((got.double() - ref64).abs() / denom).max().item()
+    err_torch = (((a @ w.t()).double() - ref64).abs() / denom).max().item()
+    assert err <= 1e-6 and err <= 1.5 * err_torch + 1e-7, (err, err_torch)
+    # non-finite inputs
+    a2 = a.clone()
+    a2[5, 3] = float('inf')
+    a2[17, 0] = float('nan')
+    a2[40, H - 1] = -float('inf')
+    got2 = product(a2)
+    bad = ~torch.isfinite(a2 @ w.t()).all(1)
+    assert bad.sum() == 3 and bool((~torch.isfinite(got2[bad])).all())
+    assert torch.equal(got2[~bad], got[~bad])

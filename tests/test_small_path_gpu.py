@@ -90,6 +90,33 @@ def test_device_conversion_rejects_invalid_graphs():
         model.check_graphs()
 
 
+@pytest.mark.parametrize('mode', ['sink', 'bucket'])
+def test_invalid_adjacency_cannot_reach_the_optimizer(mode):
+    """A training forward on an adjacency that fails validation (reported late on the batch-1 path) returns NaN -- never
+    uninitialised memory -- and the backward raises BEFORE any native node runs: default gradient mode (gradient sink)
+    and GradBucket (anchored node), both through csrc_host/fast_iter.cpp when it is built."""
+    from trackmpnn_amd import TrackMPNN
+    from trackmpnn_amd.dist import GradBucket
+    a = torch.zeros(4, 4)
+    a[0, 0] = a[3, 3] = 1
+    a[1, 0] = 1                          # edge row with only a +1
+    a[2, 0], a[2, 3] = 1, -1
+    e = a.t().clone()
+    e[0, 0] = e[3, 3] = 0
+    e[1, 1] = e[2, 2] = 1
+    model = TrackMPNN('2d', 3, 64, 0, 'diff').to(DEV).train()
+    if mode == 'bucket':
+        GradBucket(model)
+    x = torch.zeros(4, 8, device=DEV)
+    x[0] = 1.0
+    x[3] = -1.0
+    s, l, h, _ = model(x, None, a.to(DEV), e.to(DEV))
+    assert bool(torch.isnan(s).all()) and bool(torch.isnan(l).all()) and bool(torch.isnan(h).all())
+    with pytest.raises(ValueError, match='factor graph'):
+        (l.sum() + h.sum()).backward()
+    model._pending_graphs = []
+
+
 def _run_model(model, calls, small, monkeypatch, weights=None):
     import trackmpnn_amd.track_mpnn as tm
     monkeypatch.setattr(tm, 'SMALL_PATH', small)

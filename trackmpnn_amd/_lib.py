@@ -13,7 +13,8 @@ import re
 from typing import Dict, List, Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'lib', 'libtmpnn.so')
+# TMPNN_LIB_PATH: load another build of the SAME library (kernel experiments of tools/build_variant.sh); never a fallback
+LIB_PATH = os.environ.get('TMPNN_LIB_PATH') or os.path.join(_HERE, 'lib', 'libtmpnn.so')
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), 'include', 'tmpnn.h')
 
 ABI_VERSION = 1

@@ -270,6 +270,15 @@ __device__ __forceinline__ void cell_gemm(const float* __restrict__ sA, int ldA,
 
 template <int H, int IN_E>
 __global__ __launch_bounds__(256) void k_small_iter_fwd(IterFwdArgs a) {
+    if (a.g.meta[2] != 0) {
+        // the adjacency failed validation (tmpnn_graph_from_coo presents it as empty): nothing may look like a result
+        // until the host reads the status -- every output row becomes NaN
+        const float qnan = __int_as_float(0x7fc00000);
+        const long total = (long)a.g.N * a.P.G * H;
+        for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) a.h_out[i] = qnan;
+        for (int i = blockIdx.x * 256 + threadIdx.x; i < a.g.N; i += gridDim.x * 256) { a.logits[i] = qnan; a.scores[i] = qnan; }
+        return;
+    }
     const int E = a.g.meta[0], Dn = a.g.meta[1];
     const int nEt = (E + TR - 1) / TR, nDt = (Dn + TR - 1) / TR;
     const int b = blockIdx.x;

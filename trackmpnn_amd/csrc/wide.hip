@@ -68,6 +68,26 @@ __global__ __launch_bounds__(256) void k_wide_prep(const float* __restrict__ W, 
     }
 }
 
+// Half-step image of the forward W_hh operand for the ring kernel: img16[((j * 3 + piece) * N + n) * 16 + pos] = piece of
+// B[16 j + kk][n], the two 16-byte chunks of a column swapped where (n >> 4) & 1 (pos = ((kk >> 3) ^ ((n >> 4) & 1)) * 8 +
+// (kk & 7)): a [piece][192 columns][16] tile is a LINEAR copy and ds_read_b128 of chunk c ^ ((col >> 4) & 1) with
+// lane = column is conflict-free (32-byte rows: the 16 lanes served together sit 2 r + c slots apart mod 16).
+__global__ __launch_bounds__(256) void k_wide_prep16(const float* __restrict__ W, int ldw, int K, int N,
+                                                     uint16_t* __restrict__ img) {
+    const long total = (long)K * N;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int k = (int)(i / N), n = (int)(i % N);
+        const float v = W[(size_t)n * ldw + k];                 // B = W^T
+        uint32_t p1, p2, p3;
+        w_split2(v, 0.f, p1, p2, p3);
+        const int j = k >> 4, kk = k & 15;
+        const size_t base = ((size_t)j * 3 * N + n) * 16 + ((((kk >> 3) ^ ((n >> 4) & 1)) << 3) | (kk & 7));
+        img[base] = (uint16_t)p1;
+        img[base + (size_t)N * 16] = (uint16_t)p2;
+        img[base + (size_t)2 * N * 16] = (uint16_t)p3;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // the tiled product
 // ------------------------------------------------------------------------------------------------------------
@@ -361,17 +381,18 @@ __global__ __launch_bounds__(512) void k_wide_gru_fwd(WideArgs a) {
 // edge rows chosen as (8 srcs x 16 dsts) touch 24 rows of the projected table P instead of 256 gathered ones.  The tile
 // list (built once per graph: trackmpnn_amd.graph.build_edge_tiles) gives, per tile, its 128 graph rows, the list of the
 // DISTINCT det indices it touches and each row's two positions in that list.  A persistent block walks tiles; for each
-// of the H / 64 hidden chunks of a tile it runs the K loop of k_wide_gru_fwd and an epilogue that takes P[src] - P[dst]
-// from an LDS copy of the tile's distinct P rows (coalesced 256-byte row segments, fetched once per item while the first
-// K-step computes), the gate biases from LDS and the previous state from registers requested two K-steps before the
-// loop ends -- no global load is left on the epilogue's critical path.  The first two K-steps of the NEXT item are
-// requested before the epilogue, so a block's pipeline never drains between items.  A tile whose det list exceeds
-// WT_DMAX rows (ragged graphs, the seams between frame blocks) reads P through the list from global memory instead.
+// of the H / 64 hidden chunks of a tile it runs a K loop and an epilogue that takes P[src] - P[dst] from an LDS copy of
+// the tile's distinct P rows (fetched once per item by LDS-DMA while the K loop runs), the gate biases from LDS and the
+// previous state from registers requested before the loop ends -- no global load is left on the epilogue's critical
+// path.  A tile whose det list exceeds WT_DMAX rows (ragged graphs, the seams between frame blocks) reads P through the
+// list from global memory instead.
 struct WideTiles {
     const int32_t* t_row; const int32_t* t_loc; const int32_t* t_dptr; const int32_t* t_dets; int T;
 };
 static constexpr int WT_DMAX = 40;
-static constexpr size_t W_TILED_SHM = W_GRU_SHM + sizeof(float) * (WT_DMAX * 192 + 6 * 64) + sizeof(int) * (128 + 128 + 256);
+// build-time ablations of k_wide_gru_fwd_ring (tools/build_variant.sh wide -DWT_NOEPI ...; timing only, wrong results):
+// WT_NOEPI no gate math / stores, WT_NOMMA no MFMAs, WT_NODMA no operand DMA in the K loop, WT_NOREAD / WT_NOSPLIT no
+// fragment reads / A split, WT_NOBAR no K-loop barriers.  The numbers they produced: profiles/r03_c5_wide_forward.md
 
 // (opaque(): the index arithmetic below is invariant over the kernel's persistent loop; hoisted out of it, the offsets
 //  of all its call sites pile up in registers the K loop needs and the A operand in flight gets spilled)
@@ -386,51 +407,13 @@ __device__ __forceinline__ uint32_t lds_addr(const void* p) {
 }
 __device__ __forceinline__ void glds16(const void* gsrc, uint32_t lds_wave_base) {
     unsigned keep;
+    lds_wave_base = __builtin_amdgcn_readfirstlane(lds_wave_base);
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(gsrc), "s"(lds_wave_base) : "memory");
 }
 __device__ __forceinline__ void wait_dma() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
-// the A rows of K-step kt (this thread: 8 floats of its tile row; a padding slot, a_row = -1, reads row 0: whatever
-// its MFMA rows produce is never stored)
 typedef float wf32x4 __attribute__((ext_vector_type(4)));
-struct WideA { wf32x4 lo, hi; };
-__device__ __forceinline__ WideA tiled_load_a(const WideArgs& a, int a_row, int kt) {
-    const wf32x4* p = reinterpret_cast<const wf32x4*>(a.A + (size_t)max(a_row, 0) * a.lda + kt * W_KT + 8 * (opaque(threadIdx.x) & 3));
-    WideA r;
-    r.lo = p[0]; r.hi = p[1];
-    return r;
-}
-// the weight tile of K-step kt (3 pieces x 192 columns x 64 B = 2304 chunks) straight into the LDS image: the global
-// image is pre-swizzled (k_wide_prep), so chunk idx of the tile lands at byte 16 * idx
-__device__ __forceinline__ void tiled_dma_b(const WideArgs& a, int kt, int hc0, uint16_t* sB) {
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = opaque(threadIdx.x & 63);
-    constexpr int CH = 3 * 64 * 4;
-#pragma unroll
-    for (int i = 0; i < 5; ++i) {
-        const int idx0 = i * 512 + wave * 64;
-        if (idx0 < 3 * CH) {                                  // wave-uniform (the fifth pass is waves 0-3 only)
-            const int idx = idx0 + lane;
-            const int p = idx / CH, c = idx % CH;
-            const int col = c >> 2, qq = c & 3;
-            const int n = hc0 + (col >> 6) * a.H + (col & 63);
-            glds16(a.img + (((size_t)kt * 3 + p) * a.N + n) * 32 + 8 * qq, lds_addr(sB) + 16u * idx0);
-        }
-    }
-}
-__device__ __forceinline__ void tiled_store_a(const WideA& x, uint16_t* sA) {
-    const int ts = opaque(threadIdx.x), row = ts >> 2, kq = ts & 3;
-    uint32_t q1[4], q2[4], q3[4];
-    w_split2(x.lo[0], x.lo[1], q1[0], q2[0], q3[0]);
-    w_split2(x.lo[2], x.lo[3], q1[1], q2[1], q3[1]);
-    w_split2(x.hi[0], x.hi[1], q1[2], q2[2], q3[2]);
-    w_split2(x.hi[2], x.hi[3], q1[3], q2[3], q3[3]);
-    uint16_t* d = sA + w_sw(row, kq);
-    constexpr int PL = W_BM * W_LD;
-    *reinterpret_cast<uint4*>(d) = make_uint4(q1[0], q1[1], q1[2], q1[3]);
-    *reinterpret_cast<uint4*>(d + PL) = make_uint4(q2[0], q2[1], q2[2], q2[3]);
-    *reinterpret_cast<uint4*>(d + 2 * PL) = make_uint4(q3[0], q3[1], q3[2], q3[3]);
-}
 
 __device__ __forceinline__ void gru_gate4(const float4& ps_r, const float4& pd_r, const float4& ps_z, const float4& pd_z,
                                           const float4& ps_n, const float4& pd_n, const float4& ghr, const float4& ghz,
@@ -462,62 +445,226 @@ __device__ __forceinline__ void gru_gate4(const float4& ps_r, const float4& pd_r
     o_hn = make_float4(vhn[0], vhn[1], vhn[2], vhn[3]);
 }
 
-__global__ __launch_bounds__(512) void k_wide_gru_fwd_tiled(WideArgs a, WideTiles tl) {
+// ------------------------------------------------------------------------------------------------------------
+// the tiled cell, second form: everything by LDS-DMA into a ring of four HALF K-steps
+// ------------------------------------------------------------------------------------------------------------
+// Measured on the first tiled kernel (C5, per 4.41 M rows): 13.2 ms; without the gate epilogue 10.2; without the MFMAs
+// 9.7; without the operand traffic 9.4 -- the operand pipeline and the matrix phase each take ~6.5 ms and mostly ADD UP:
+// a step's tiles are requested at the start of the step before and waited for at its end (one ~1 us phase of cover for a
+// ~1.5 us round trip), and every phase has a vector-ALU head (DMA addresses) and tail (wait, A split, ds_write) that both
+// waves of a SIMD run at the same time, between the barriers.  This form removes both:
+//   * the A tile comes in by LDS-DMA too, as RAW fp32 rows (no register staging, no split + ds_write pass: each wave
+//     splits its own 32 x 16 fragment after the ds_read -- twice the split work, but in front of the wave's own MFMAs
+//     where the other wave of the SIMD can run under it -- and reads 2 instead of 3 A operands per step);
+//   * K advances in half steps of 16 through a ring of FOUR slots (8 KB of A + 18 KB of weights each): the DMA of half
+//     step j + 3 is issued in half step j, so every tile has three matrix phases to land, and a wave waits with a COUNTED
+//     vmcnt (the two youngest half steps stay in flight) before a raw s_barrier.
+// Products, their order and the split are those of k_wide_gru_fwd: bit-identical results.
+static constexpr int RG_A = 128 * 64, RG_B = 3 * 192 * 32, RG_SLOT = RG_A + RG_B;      // bytes
+static constexpr size_t W_RING_SHM = 4 * RG_SLOT + sizeof(float) * (WT_DMAX * 192 + 6 * 64) + sizeof(int) * (128 + 128 + 256);
+
+// 16 bytes per lane from (uniform 64-bit base) + (per-lane 32-bit byte offset) to LDS (uniform address) + 16 * lane
+__device__ __forceinline__ const void* uniform_ptr(const void* p) {          // (values hipcc cannot prove wave-uniform
+    const uint64_t v = reinterpret_cast<uint64_t>(p);                        //  would reach an "s" operand in a VGPR)
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    return reinterpret_cast<const void*>(((uint64_t)hi << 32) | lo);
+}
+__device__ __forceinline__ void glds16_so(const void* sbase, uint32_t voff, uint32_t lds_wave_base) {
+    unsigned keep;
+    sbase = uniform_ptr(sbase);
+    lds_wave_base = __builtin_amdgcn_readfirstlane(lds_wave_base);
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_wave_base) : "memory");
+}
+__device__ __forceinline__ void glds4(const void* gsrc, uint32_t lds_wave_base) {      // 4 bytes per lane
+    unsigned keep;
+    lds_wave_base = __builtin_amdgcn_readfirstlane(lds_wave_base);
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_wave_base) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void ring_wait_barrier() {       // own DMAs down to the N youngest, own LDS writes, then the barrier
+    if constexpr (N >= 12) asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)" ::: "memory");
+    else if constexpr (N >= 8) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+    else if constexpr (N >= 4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#ifndef WT_NOBAR
+    __builtin_amdgcn_s_barrier();
+#endif
+    asm volatile("" ::: "memory");
+}
+
+struct RingCtx {
+    const char* pa;              // this thread's A source: row a_row, floats 4 * (slot chunk) of half step 0
+    uint32_t ob0, ob1, ob2;      // this thread's three weight-tile chunks (byte offsets within a half-step image)
+    uint32_t lds_a, lds_b0, lds_b1, lds_b2;   // wave-uniform LDS addresses within slot 0
+    bool b2_on;
+};
+
+// DMA of half step j of (tile rows pa, hidden chunk hc0) into ring slot `slot`: 1 A + 3 weight instructions per wave
+__device__ __forceinline__ void ring_dma(const WideArgs& a, const RingCtx& c, int j, int hc0, int slot) {
+    const uint32_t so = (uint32_t)slot * RG_SLOT;
+    glds16(c.pa + (size_t)j * 64, c.lds_a + so);
+    const char* wb = reinterpret_cast<const char*>(a.img) + ((size_t)j * 3 * a.N + hc0) * 32;
+    glds16_so(wb, c.ob0, c.lds_b0 + so);
+    glds16_so(wb, c.ob1, c.lds_b1 + so);
+    if (c.b2_on) glds16_so(wb, c.ob2, c.lds_b2 + so);      // (lanes 0-15: the tile's last 128 chunks, 16 per wave)
+    else asm volatile("s_nop 0" ::: "memory");
+}
+
+// One half step in two parts, so that a wave can fetch step p + 1's operands while its MFMAs of step p run:
+//   ring_read   : the A fragment (raw fp32, two 16-byte reads) and the nine weight fragments of a slot into registers
+//   ring_split  : raw A -> three bf16 pieces (vector ALU; independent of the MFMAs it is scheduled between)
+//   ring_compute: 18 MFMAs on operands that are all in registers
+struct RingOps { float4 lo, hi; uint4 af[3]; uint4 bf[9]; };
+__device__ __forceinline__ void ring_read(const char* slot_base, int a_off0, int a_off1, int b_off, RingOps& o) {
+#ifdef WT_NOREAD
+    return;
+#endif
+    o.lo = *reinterpret_cast<const float4*>(slot_base + a_off0);
+    o.hi = *reinterpret_cast<const float4*>(slot_base + a_off1);
+    const char* sb = slot_base + RG_A + b_off;
+#pragma unroll
+    for (int ct = 0; ct < 3; ++ct)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) o.bf[ct * 3 + p] = *reinterpret_cast<const uint4*>(sb + ct * 64 * 32 + p * 192 * 32);
+}
+__device__ __forceinline__ void ring_split(RingOps& o) {
+#ifdef WT_NOSPLIT
+    return;
+#endif
+    w_split2(o.lo.x, o.lo.y, o.af[0].x, o.af[1].x, o.af[2].x);
+    w_split2(o.lo.z, o.lo.w, o.af[0].y, o.af[1].y, o.af[2].y);
+    w_split2(o.hi.x, o.hi.y, o.af[0].z, o.af[1].z, o.af[2].z);
+    w_split2(o.hi.z, o.hi.w, o.af[0].w, o.af[1].w, o.af[2].w);
+}
+// (the pieces are pinned where they are formed: left alone, hipcc sinks the whole split into the next step, in front of
+//  the MFMAs that consume it, and the wave runs split and MFMAs back to back again)
+__device__ __forceinline__ void ring_pin(RingOps& o) {
+    asm volatile("" : "+v"(o.af[0].x), "+v"(o.af[0].y), "+v"(o.af[0].z), "+v"(o.af[0].w), "+v"(o.af[1].x), "+v"(o.af[1].y),
+                      "+v"(o.af[1].z), "+v"(o.af[1].w), "+v"(o.af[2].x), "+v"(o.af[2].y), "+v"(o.af[2].z), "+v"(o.af[2].w));
+}
+__device__ __forceinline__ void ring_compute(const RingOps& o, f32x16 (&acc)[3]) {
+#pragma unroll
+    for (int ct = 0; ct < 3; ++ct) {
+        f32x16 c = acc[ct];
+        c = w_mfma(o.af[2], o.bf[ct * 3], c);       // smallest terms first (as wide_mma)
+        c = w_mfma(o.af[0], o.bf[ct * 3 + 2], c);
+        c = w_mfma(o.af[1], o.bf[ct * 3 + 1], c);
+        c = w_mfma(o.af[1], o.bf[ct * 3], c);
+        c = w_mfma(o.af[0], o.bf[ct * 3 + 1], c);
+        c = w_mfma(o.af[0], o.bf[ct * 3], c);
+        acc[ct] = c;
+    }
+}
+
+#if defined(WT_NOMMA)
+#define RING_MMA(...) asm volatile("" ::: "memory")
+#else
+#define RING_MMA(...) ring_compute(__VA_ARGS__)
+#endif
+#if defined(WT_NODMA)
+#define RING_DMA(...) asm volatile("" ::: "memory")
+#else
+#define RING_DMA(...) ring_dma(__VA_ARGS__)
+#endif
+// the next step's A split (about 50 vector-ALU instructions) woven between this step's 18 MFMAs: three MFMAs cover the
+// LDS round trip of the raw fragment, then three vector instructions per MFMA
+#define RING_WEAVE()                                                                                   \
+    do {                                                                                               \
+        __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);                                             \
+        _Pragma("unroll") for (int w_ = 0; w_ < 15; ++w_) {                                            \
+            __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);                                         \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                         \
+        }                                                                                              \
+    } while (0)
+__global__ __launch_bounds__(512) void k_wide_gru_fwd_ring(WideArgs a, WideTiles tl) {
     extern __shared__ __attribute__((aligned(16))) uint16_t w_dyn[];
-    constexpr int SA = 3 * W_BM * W_LD, SB = 3 * 192 * W_LD, BUF = SA + SB;
-    uint16_t* const buf0 = w_dyn;
-    uint16_t* const buf1 = w_dyn + BUF;
-    float* const sC = reinterpret_cast<float*>(w_dyn);               // [128][192], aliases the operand buffers
-    float* const sP = reinterpret_cast<float*>(w_dyn + 2 * BUF);     // [WT_DMAX][3 gates x 64]
-    float* const sBias = sP + WT_DMAX * 192;                         // b_ih r, z, n | b_hh r, z, n of the hidden chunk
+    char* const ring = reinterpret_cast<char*>(w_dyn);
+    float* const sC = reinterpret_cast<float*>(w_dyn);                    // [128][192], aliases the ring
+    float* const sP = reinterpret_cast<float*>(ring + 4 * RG_SLOT);       // [WT_DMAX][3 gates x 64]
+    float* const sBias = sP + WT_DMAX * 192;
     int* const sRow = reinterpret_cast<int*>(sBias + 6 * 64);
     int* const sLoc = sRow + 128;
     int* const sDet = sLoc + 128;
-    const int H = a.H, nchunk = H >> 6, nk = H / W_KT;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wr = wave & 3, wc = wave >> 2;
+    const int H = a.H, nchunk = H >> 6, nsub = H >> 4;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), wr = wave & 3, wc = wave >> 2;
     const int G = gridDim.x;
     int t = blockIdx.x;
     if (t >= tl.T) return;
-    // descriptor of the first tile, in registers (d_*: what this thread will put into the LDS arrays)
+    // ---- per-thread constants of the DMA and of the fragment reads
+    RingCtx c;
+    {
+        const int N = a.N;
+        auto boff = [&](int idx) {                         // chunk idx of a [3][192][2 x 16 B] weight tile -> image byte offset
+            const int p = idx / 384, rem = idx % 384, col = rem >> 1, q = rem & 1;
+            return (uint32_t)((p * N + (col >> 6) * H + (col & 63)) * 32 + q * 16);
+        };
+        c.ob0 = boff(tid); c.ob1 = boff(512 + tid);
+        c.b2_on = lane < 16;
+        c.ob2 = boff(1024 + 16 * wave + (lane & 15));
+        const uint32_t base = lds_addr(ring);
+        c.lds_a = base + 1024u * wave;
+        c.lds_b0 = base + RG_A + 1024u * wave;
+        c.lds_b1 = base + RG_A + 8192u + 1024u * wave;
+        c.lds_b2 = base + RG_A + 16384u + 256u * wave;
+    }
+    const int r = lane & 31, hh = lane >> 5;
+    const int arow = 32 * wr + r, fa = (arow >> 2) & 3;
+    const int a_off0 = arow * 64 + (((2 * hh) ^ fa) << 4), a_off1 = arow * 64 + (((2 * hh + 1) ^ fa) << 4);
+    const int b_off = (32 * wc + r) * 32 + ((hh ^ ((r >> 4) & 1)) << 4);
+    const int drow = tid >> 2, dchunk = (tid & 3) ^ ((drow >> 2) & 3);        // A DMA: LDS chunk tid <- source chunk dchunk
+    // ---- descriptor of the first tile
     int d_row = tid < 128 ? tl.t_row[(size_t)t * 128 + tid] : 0;
     int d_loc = tid < 128 ? tl.t_loc[(size_t)t * 128 + tid] : 0;
     int dp0 = tl.t_dptr[t], nd_next = tl.t_dptr[t + 1] - dp0;
     int d_det = (tid < 256 && tid < nd_next) ? tl.t_dets[dp0 + tid] : 0;
-    int a_row_next = tl.t_row[(size_t)t * 128 + (tid >> 2)];
-    int a_row = a_row_next, nd = 0;
-    // ONE A operand set: step k + 1 is requested before the MFMAs of step k and written to the other buffer after them
-    WideA xa = tiled_load_a(a, a_row, 0);
-    tiled_dma_b(a, 0, 0, buf0 + SA);
+    int a_row_next = tl.t_row[(size_t)t * 128 + drow];
+    // (the det-list bounds of the tile AFTER the next one: loaded a tile early, so that the next tile's descriptor
+    //  request is not a chain of two dependent loads whose first wait would also drain every DMA in flight)
+    const int tq = min(t + G, tl.T - 1);
+    int dq0 = tl.t_dptr[tq], dq1 = tl.t_dptr[tq + 1];
+    int nd = 0;
+    const char* pa_next = nullptr;
+    c.pa = reinterpret_cast<const char*>(a.A + (size_t)max(a_row_next, 0) * a.lda + 4 * dchunk);
+    // the gate biases of a hidden chunk (b_ih r, z, n | b_hh r, z, n; 64 each) by 4-byte DMA: waves 0-5, one gate per wave
+    auto bias_dma = [&](int hc0) {
+        if (wave < 6) glds4((wave < 3 ? a.b_ih : a.b_hh) + (wave % 3) * H + hc0 + lane, lds_addr(sBias) + 256u * wave);
+    };
+    bias_dma(0);
+    ring_dma(a, c, 0, 0, 0);
+    ring_dma(a, c, 1, 0, 1);
+    ring_dma(a, c, 2, 0, 2);
+    ring_dma(a, c, 3, 0, 3);
     for (int bx = 0;;) {
         const int hc0 = bx << 6;
         if (bx == 0) {
             if (tid < 128) { sRow[tid] = d_row; sLoc[tid] = d_loc; }
             if (tid < 256) sDet[tid] = d_det;
-            nd = nd_next;
+            nd = __builtin_amdgcn_readfirstlane(nd_next);
         }
-        if (tid < 384) sBias[tid] = (tid < 192 ? a.b_ih : a.b_hh)[((tid % 192) >> 6) * H + hc0 + (tid & 63)];
-        tiled_store_a(xa, buf0);
-        wait_dma();
-        __syncthreads();
+        ring_wait_barrier<12>();                              // half step 0 has landed; descriptor + biases visible
         const bool last_chunk = bx + 1 == nchunk;
         const bool more_tiles = t + G < tl.T;
         if (last_chunk && more_tiles) {                       // the next tile's descriptor, a whole item ahead of its use
             const int tn = t + G;
             d_row = tid < 128 ? tl.t_row[(size_t)tn * 128 + tid] : 0;
             d_loc = tid < 128 ? tl.t_loc[(size_t)tn * 128 + tid] : 0;
-            dp0 = tl.t_dptr[tn]; nd_next = tl.t_dptr[tn + 1] - dp0;
+            dp0 = dq0; nd_next = dq1 - dq0;
             d_det = (tid < 256 && tid < nd_next) ? tl.t_dets[dp0 + tid] : 0;
-            a_row_next = tl.t_row[(size_t)tn * 128 + (tid >> 2)];
+            a_row_next = tl.t_row[(size_t)tn * 128 + drow];
+            const int tq2 = min(tn + G, tl.T - 1);
+            dq0 = tl.t_dptr[tq2]; dq1 = tl.t_dptr[tq2 + 1];
         }
         const bool staged = nd <= WT_DMAX;
-        if (staged) {                                         // the tile's distinct P rows, this chunk's 3 x 64 columns:
-#pragma unroll                                                // chunk idx of the [nd][48] copy lands at byte 16 * idx
+        if (staged) {                                         // the tile's distinct P rows, this chunk's 3 x 64 columns
+#pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const int idx0 = 512 * i + 64 * __builtin_amdgcn_readfirstlane(wave);
+                const int idx0 = 512 * i + 64 * wave;
                 const int idx = idx0 + opaque(lane);
                 if (idx < nd * 48) {
-                    const int rw = idx / 48, c = idx % 48;
-                    glds16(a.P + (size_t)sDet[rw] * a.ldp + (c >> 4) * H + hc0 + 4 * (c & 15), lds_addr(sP) + 16u * idx0);
+                    const int rw = idx / 48, cc = idx % 48;
+                    glds16(a.P + (size_t)sDet[rw] * a.ldp + (cc >> 4) * H + hc0 + 4 * (cc & 15), lds_addr(sP) + 16u * idx0);
                 }
             }
         }
@@ -527,46 +674,79 @@ __global__ __launch_bounds__(512) void k_wide_gru_fwd_tiled(WideArgs a, WideTile
 #pragma unroll
             for (int q = 0; q < 16; ++q) acc[j][q] = 0.f;
         wf32x4 hp[4];
-        for (int kt = 0; kt < nk; kt += 2) {
-            tiled_dma_b(a, kt + 1, hc0, buf1 + SA);
-            xa = tiled_load_a(a, a_row, kt + 1);
-            __builtin_amdgcn_sched_barrier(0);                // (the requests stay above the MFMAs, their consumer below:
-            wide_mma<3, 3>(buf0, buf0 + SA, 32 * wr, 32 * wc, lane, acc);
-            __builtin_amdgcn_sched_barrier(0);                //  left alone hipcc sinks the load to its first use)
-            tiled_store_a(xa, buf1);
-            wait_dma();
-            __syncthreads();
-            if (kt + 2 < nk) {
-                tiled_dma_b(a, kt + 2, hc0, buf0 + SA);
-                xa = tiled_load_a(a, a_row, kt + 2);
-            } else {                                          // previous state of the epilogue's rows (L2 hits: the A tile)
-                const int th = opaque(tid);
+        RingOps R[2];
+        // Step p: DMA of step p + 4 into the slot step p's operands have just left (they sit in R[p & 1]); fetch step
+        // p + 1's operands into R[(p + 1) & 1] and split its A fragment UNDER the MFMAs of step p; then wait until step
+        // p + 2 has landed (steps p + 3, p + 4 stay in flight) and until this wave's LDS reads have returned; barrier.
+        ring_read(ring, a_off0, a_off1, b_off, R[0]);
+        ring_split(R[0]);
+        ring_wait_barrier<8>();                               // step 1 has landed; every wave has step 0 in registers
+        int p0 = 0;
+        for (; p0 + 8 <= nsub; p0 += 4) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int grow = sRow[(th >> 4) + 32 * i];
-                    hp[i] = *reinterpret_cast<const wf32x4*>(a.h + (size_t)max(grow, 0) * a.ld_h + hc0 + 4 * (th & 15));
-                }
+            for (int u = 0; u < 4; ++u) {
+                RING_DMA(a, c, p0 + u + 4, hc0, u);
+                ring_read(ring + ((u + 1) & 3) * RG_SLOT, a_off0, a_off1, b_off, R[(u + 1) & 1]);
+                __builtin_amdgcn_sched_barrier(0);            // requests first; then the MFMAs with the split woven in
+                RING_MMA(R[u & 1], acc);
+                ring_split(R[(u + 1) & 1]);
+                RING_WEAVE();
+                __builtin_amdgcn_sched_barrier(0);
+                ring_pin(R[(u + 1) & 1]);
+                ring_wait_barrier<8>();
             }
-            __builtin_amdgcn_sched_barrier(0);
-            wide_mma<3, 3>(buf1, buf1 + SA, 32 * wr, 32 * wc, lane, acc);
-            __builtin_amdgcn_sched_barrier(0);
-            if (kt + 2 < nk) tiled_store_a(xa, buf0);
-            wait_dma();
-            __syncthreads();
         }
-        // the next item's first A K-step flies under the epilogue (its weight tile follows the epilogue: sC aliases it)
+        // ---- the last four steps (p0 = nsub - 4): nothing left to request
+        ring_read(ring + RG_SLOT, a_off0, a_off1, b_off, R[1]);
+        __builtin_amdgcn_sched_barrier(0);
+        RING_MMA(R[0], acc);
+        ring_split(R[1]);
+        RING_WEAVE();
+        __builtin_amdgcn_sched_barrier(0);
+        ring_pin(R[1]);
+        ring_wait_barrier<4>();                               // step nsub - 2 has landed
+        ring_read(ring + 2 * RG_SLOT, a_off0, a_off1, b_off, R[0]);
+        __builtin_amdgcn_sched_barrier(0);
+        RING_MMA(R[1], acc);
+        ring_split(R[0]);
+        RING_WEAVE();
+        __builtin_amdgcn_sched_barrier(0);
+        ring_pin(R[0]);
+        ring_wait_barrier<0>();                               // step nsub - 1 has landed
+        {                                                     // previous state of the epilogue's rows (L2 hits: the A tile)
+            const int th = opaque(tid);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int grow = sRow[(th >> 4) + 32 * i];
+                hp[i] = *reinterpret_cast<const wf32x4*>(a.h + (size_t)max(grow, 0) * a.ld_h + hc0 + 4 * (th & 15));
+            }
+        }
+        ring_read(ring + 3 * RG_SLOT, a_off0, a_off1, b_off, R[1]);
+        __builtin_amdgcn_sched_barrier(0);
+        RING_MMA(R[0], acc);
+        ring_split(R[1]);
+        RING_WEAVE();
+        __builtin_amdgcn_sched_barrier(0);
+        ring_pin(R[1]);
+        // (the next tile's A source is formed HERE, where the queue is drained anyway: hipcc waits vmcnt(0) at the first
+        //  use of the row id it loaded an item ago, and anywhere else that wait would drain the DMAs in flight)
+        if (last_chunk && more_tiles) pa_next = reinterpret_cast<const char*>(a.A + (size_t)max(a_row_next, 0) * a.lda + 4 * dchunk);
+        ring_wait_barrier<0>();                               // every wave has its last operands: sC may overwrite the ring
+        RING_MMA(R[1], acc);
         const int nbx = last_chunk ? 0 : bx + 1;
         const bool more = !last_chunk || more_tiles;
-        if (more) xa = tiled_load_a(a, last_chunk ? a_row_next : a_row, 0);
         {
-            const int lw = opaque(lane), c = lw & 31, half = lw >> 5;
+            const int lw = opaque(lane), cl = lw & 31, half = lw >> 5;
 #pragma unroll
             for (int gate = 0; gate < 3; ++gate)
 #pragma unroll
                 for (int reg = 0; reg < 16; ++reg)
-                    sC[(32 * wr + w_acc_row(reg, half)) * 192 + 64 * gate + 32 * wc + c] = acc[gate][reg];
+                    sC[(32 * wr + w_acc_row(reg, half)) * 192 + 64 * gate + 32 * wc + cl] = acc[gate][reg];
         }
         __syncthreads();
+#if defined(WT_NOEPI)
+        if (a.gates == reinterpret_cast<float*>(8)) sC[tid] = hp[0][0] + hp[1][1] + hp[2][2] + hp[3][3];
+#else
         {
             const int te = opaque(tid), q = te & 15;
 #pragma unroll
@@ -598,7 +778,13 @@ __global__ __launch_bounds__(512) void k_wide_gru_fwd_tiled(WideArgs a, WideTile
                 float4 o_h, o_r, o_z, o_n, o_hn;
                 gru_gate4(s_r, d_r, s_z, d_z, s_n, d_n, ghr, ghz, ghn, sBias, q, make_float4(hp[i][0], hp[i][1], hp[i][2], hp[i][3]), o_h, o_r, o_z, o_n, o_hn);
                 const int col = hc0 + 4 * q;
+#if defined(WT_NOSTORE)
+                if (o_h.x + o_r.y + o_z.z + o_n.w + o_hn.x == 123.456f)
+#endif
                 *reinterpret_cast<float4*>(a.h_out + (size_t)grow * a.ld_out + col) = o_h;
+#if defined(WT_NOSTORE)
+                if (o_h.x + o_r.y + o_z.z + o_n.w + o_hn.x == 123.456f)
+#endif
                 if (a.gates) {
                     float* gp = a.gates + (size_t)grow * H + col;
                     *reinterpret_cast<float4*>(gp) = o_r;
@@ -608,11 +794,19 @@ __global__ __launch_bounds__(512) void k_wide_gru_fwd_tiled(WideArgs a, WideTile
                 }
             }
         }
+#endif
         __syncthreads();
         if (!more) break;
-        if (last_chunk) { t += G; a_row = a_row_next; }
+        if (last_chunk) {
+            t += G;
+            c.pa = pa_next;
+        }
         bx = nbx;
-        tiled_dma_b(a, 0, bx << 6, buf0 + SA);                // (lands under the A split + store and is waited at the barrier)
+        bias_dma(bx << 6);
+        ring_dma(a, c, 0, bx << 6, 0);                        // the next item's first four half steps
+        ring_dma(a, c, 1, bx << 6, 1);
+        ring_dma(a, c, 2, bx << 6, 2);
+        ring_dma(a, c, 3, bx << 6, 3);
     }
 }
 
@@ -930,7 +1124,8 @@ int tmpnn_wide_supported(int H, int IN) { return ((H == 128 || H == 256) && IN =
 // backward ih (K = 3H, N = IN), backward hh (K = 3H, N = H)
 size_t tmpnn_wide_prep_bytes(int H, int IN) {
     if (H <= 0 || IN <= 0) return 0;
-    return sizeof(uint16_t) * 3 * ((size_t)H * 3 * H + (size_t)IN * 3 * H + (size_t)3 * H * IN + (size_t)3 * H * H);
+    // + the half-step image of the forward W_hh operand (k_wide_gru_fwd_ring)
+    return sizeof(uint16_t) * 3 * ((size_t)H * 3 * H + (size_t)IN * 3 * H + (size_t)3 * H * IN + (size_t)3 * H * H + (size_t)H * 3 * H);
 }
 
 int tmpnn_wide_prepare(const float* w_ih, const float* w_hh, int IN, int H, void* prep, tmpnn_stream stream) {
@@ -946,6 +1141,7 @@ int tmpnn_wide_prepare(const float* w_ih, const float* w_hh, int IN, int H, void
     hipLaunchKernelGGL(k_wide_prep, dim3(g2), dim3(256), 0, st, w_ih, IN, IN, 3 * H, 1, f_ih);
     hipLaunchKernelGGL(k_wide_prep, dim3(g2), dim3(256), 0, st, w_ih, IN, 3 * H, IN, 0, b_ih);
     hipLaunchKernelGGL(k_wide_prep, dim3(g1), dim3(256), 0, st, w_hh, H, 3 * H, H, 0, b_hh);
+    hipLaunchKernelGGL(k_wide_prep16, dim3(g1), dim3(256), 0, st, w_hh, H, H, 3 * H, b_hh + (size_t)3 * 3 * H * H);
     return check_launch("wide_prepare");
 }
 
@@ -1012,11 +1208,12 @@ int tmpnn_wide_gru_fwd_tiled(const void* prep, const int32_t* det_rows, int Dn, 
     a.P = P; a.ldp = 3 * H; a.h = h; a.ld_h = ld_h; a.H = H;
     a.b_ih = b_ih; a.b_hh = b_hh; a.h_out = h_out; a.ld_out = ld_out; a.gates = gates; a.gate_plane = gate_plane;
     WideTiles tl{tiles->t_row, tiles->t_loc, tiles->t_dptr, tiles->t_dets, tiles->T};
-    TM_SHM_ONCE(k_wide_gru_fwd_tiled, W_TILED_SHM);
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    const int grid = tiles->T < cus ? tiles->T : cus;          // one persistent block per CU (157 KB of LDS each)
-    hipLaunchKernelGGL(k_wide_gru_fwd_tiled, dim3(grid), dim3(512), W_TILED_SHM, st, a, tl);
+    const int grid = tiles->T < cus ? tiles->T : cus;          // one persistent block per CU (LDS)
+    a.img = f_hh + (size_t)3 * (3 * H * H + 3 * H * H + 3 * H * H + 3 * H * H);      // the half-step image (fifth of prep)
+    TM_SHM_ONCE(k_wide_gru_fwd_ring, W_RING_SHM);
+    hipLaunchKernelGGL(k_wide_gru_fwd_ring, dim3(grid), dim3(512), W_RING_SHM, st, a, tl);
     return check_launch("wide_gru_fwd_tiled");
 }
 

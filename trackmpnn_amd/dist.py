@@ -10,7 +10,7 @@ as in the reference (it has no SyncBN).
 """
 from __future__ import annotations
 
-from typing import List
+from typing import List, Optional, Sequence
 
 import torch
 import torch.distributed as dist
@@ -58,6 +58,28 @@ def allreduce_grads(module: torch.nn.Module, bucket: GradBucket, world: int) -> 
     bucket.flat.mul_(1.0 / world)
 
 
-def shard_windows(n_windows: int, rank: int, world: int) -> List[int]:
-    """Rank r takes windows {i : i mod world == r} (reference shuffles chunks, train.py:22)."""
-    return list(range(rank, n_windows, world))
+def shard_windows(n_windows: int, rank: int, world: int, edge_counts: Optional[Sequence[int]] = None) -> List[int]:
+    """The windows (tracking chunks / sequences) rank `rank` of `world` owns.
+
+    Without `edge_counts`: windows {i : i mod world == r} (the reference shuffles chunks, train.py:22, so any fixed
+    deal is balanced in expectation).  With `edge_counts[i]` = sum of E over the forward calls of window i (the unit of
+    the metric and of the work): longest-processing-time greedy -- windows in descending order of work, each to the
+    rank with the least work so far, ties to the lowest rank -- so that every rank's step takes about the same time
+    (graph sizes vary by an order of magnitude between KITTI and BDD scenes).  Deterministic: every rank
+    computes the same partition from the same counts; each rank's list is returned in ascending window order."""
+    if edge_counts is None:
+        return list(range(rank, n_windows, world))
+    if len(edge_counts) != n_windows:
+        raise ValueError(f'shard_windows: {len(edge_counts)} edge counts for {n_windows} windows')
+    if not 0 <= rank < world:
+        raise ValueError(f'shard_windows: rank {rank} of {world}')
+    import heapq
+    order = sorted(range(n_windows), key=lambda i: (-int(edge_counts[i]), i))
+    heap = [(0, r) for r in range(world)]              # (work so far, rank)
+    mine: List[int] = []
+    for i in order:
+        load, r = heapq.heappop(heap)
+        if r == rank:
+            mine.append(i)
+        heapq.heappush(heap, (load + int(edge_counts[i]), r))
+    return sorted(mine)

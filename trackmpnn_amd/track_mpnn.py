@@ -247,7 +247,9 @@ class TrackMPNN(nn.Module):
     # ------------------------------------------------------------------------------------------
     def check_graphs(self) -> None:
         """Read back the validation status of every adjacency converted since the last check (ONE host round trip)
-        and raise ValueError for the first invalid one.  Called automatically before a backward and every 64 calls."""
+        and raise ValueError for the first invalid one.  Called automatically before a backward (a gradient hook on the
+        outputs of every call whose adjacency is still unchecked) and every 64 calls; until then an invalid graph's outputs
+        are NaN (k_small_iter_fwd fills them), never stale memory."""
         if not self._pending_graphs or torch.cuda.is_current_stream_capturing():
             return                                   # (a capture cannot synchronise: the check happens after it)
         pending, self._pending_graphs = self._pending_graphs, []
@@ -332,7 +334,17 @@ class TrackMPNN(nn.Module):
             else:
                 scores, logits, h_out = _SmallIter.apply(call, x, h_in, *params)
         h_out._tmpnn_spare_rows = spare
+        if need_grad and self._pending_graphs:
+            # deferred validation must have happened before ANY backward node of this call runs (the native node does
+            # not check): the first gradient that reaches one of the outputs triggers the one host round trip
+            for t in (scores, logits, h_out):
+                if t.requires_grad:
+                    t.register_hook(self._check_graphs_hook)
         return scores, logits, h_out, (None,) * self.spec.G
+
+    def _check_graphs_hook(self, grad):
+        self.check_graphs()
+        return None
 
     def forward(self, x, h_in, node_adj, edge_adj):
         """reference/models/track_mpnn.py:54-75.  node_adj / edge_adj: dense or sparse-COO [N, N].
