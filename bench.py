@@ -106,12 +106,20 @@ def stage_profile(model, plan, H):
 
     proj = torch.empty(Dn, 3 * H, device=dev)
 
-    def gru_fwd():      # as the training step runs it: det rows projected once, edge cell gathers P[src] - P[dst]
+    from trackmpnn_amd import functional as _fn
+    from trackmpnn_amd.graph import edge_tiles
+    tiles32 = edge_tiles(g, 32) if _fn.FWD_TILED else None
+
+    def gru_fwd():      # as the training step runs it: det rows projected once, edge cell takes P[src] - P[dst] per edge tile
         _lib.call('tmpnn_rows_linear', g.det_row.data_ptr(), Dn, h.data_ptr(), H, H, wih_t.data_ptr(), 3 * H,
                   proj.data_ptr(), 3 * H, st)
-        _lib.call('tmpnn_gru_fwd', g.edge_row.data_ptr(), E, 3, g.src_pos.data_ptr(), g.dst_pos.data_ptr(),
-                  proj.data_ptr(), 3 * H, 0, H, h.data_ptr(), H, H, None, whh_t.data_ptr(), bih.data_ptr(),
-                  bhh.data_ptr(), out.data_ptr(), H, gates.data_ptr(), N * H, None, None, 0, st)
+        if tiles32 is not None:
+            _lib.call('tmpnn_gru_fwd_tiles', tiles32.cref(), E, proj.data_ptr(), 3 * H, h.data_ptr(), H, H, whh_t.data_ptr(),
+                      bih.data_ptr(), bhh.data_ptr(), out.data_ptr(), H, gates.data_ptr(), N * H, None, None, 0, st)
+        else:
+            _lib.call('tmpnn_gru_fwd', g.edge_row.data_ptr(), E, 3, g.src_pos.data_ptr(), g.dst_pos.data_ptr(),
+                      proj.data_ptr(), 3 * H, 0, H, h.data_ptr(), H, H, None, whh_t.data_ptr(), bih.data_ptr(),
+                      bhh.data_ptr(), out.data_ptr(), H, gates.data_ptr(), N * H, None, None, 0, st)
 
     def gru_bwd_data():
         _lib.call('tmpnn_gru_bwd_data', g.edge_row.data_ptr(), E, H, h.data_ptr(), H, H, wih.data_ptr(), whh.data_ptr(),

@@ -215,6 +215,14 @@ int tmpnn_gru_bwd_fused(const int32_t* rows, int R, int xmode, const int32_t* sr
                         float* dW_ih, float* dW_hh, float* db_ih, float* db_hh,
                         void* ws, size_t ws_bytes, tmpnn_stream stream);
 
+/* tmpnn_gru_fwd's xmode 3 (edge cell over the projected det rows `proj` [Dn][ld_proj >= 3H] of tmpnn_rows_linear) over
+ * EDGE TILES (rows_per_tile = 32, covering the graph's R edge rows): the distinct projected rows of a tile are staged in
+ * LDS an item ahead instead of gathered per edge row after the matrix phase.  H in {32, 64}; bit-identical to
+ * tmpnn_gru_fwd(rows = edge_row, xmode = 3, src / dst = det indices).  layers.py:90-97, rows E + H' + I + J. */
+int tmpnn_gru_fwd_tiles(const tmpnn_edge_tiles* tiles, int R, const float* proj, int ld_proj, const float* h, int ld_h, int H,
+                        const float* whh_t, const float* b_ih, const float* b_hh, float* h_out, int ld_out, float* gates,
+                        size_t gate_plane, const float* w_head, float* logit_part, size_t part_stride, tmpnn_stream stream);
+
 /* out[r, 0:NOUT] = in[rows[r], 0:H] @ wt[H][NOUT]  (compact output rows; H in {32, 64}, NOUT = 3H):
  * the det-row projection P of tmpnn_gru_fwd's xmode 3. */
 int tmpnn_rows_linear(const int32_t* rows, int R, const float* in, int ld_in, int H, const float* wt, int NOUT,

@@ -555,6 +555,46 @@ def check_wide_tiled(H, g):
             'staged tiles': int((cnt <= 40).sum()), 'listed tiles': int((cnt > 40).sum())}
 
 
+def check_fwd_tiles(H, g, order=None):
+    """tmpnn_gru_fwd_tiles (32-row edge tiles, projected det rows staged in LDS an item ahead; big tiles through their det
+    list) must reproduce tmpnn_gru_fwd's xmode 3 BIT FOR BIT: h_out, the four gate planes and the fused head partials."""
+    from trackmpnn_amd.graph import build_edge_tiles, edge_tiles
+    torch.manual_seed(3000 + H)
+    gd = g.to(DEV)
+    ld = H + 32
+    hD = torch.randn(g.N, ld, device=DEV)
+    E, Dn = g.E, g.Dn
+    sc = 1.0 / H ** 0.5
+    wih_t, whh_t = sc * torch.randn(H, 3 * H, device=DEV), sc * torch.randn(H, 3 * H, device=DEV)
+    bih, bhh = 0.3 * torch.randn(3 * H, device=DEV), 0.3 * torch.randn(3 * H, device=DEV)
+    w_head = torch.randn(H, device=DEV)
+    proj = torch.empty(Dn, 3 * H, device=DEV)
+    _lib.call('tmpnn_rows_linear', gd.det_row.data_ptr(), Dn, hD.data_ptr(), ld, H, wih_t.data_ptr(), 3 * H,
+              proj.data_ptr(), 3 * H, st())
+    tiles = edge_tiles(gd, 32) if order is None else build_edge_tiles(gd, 32, 4, 8, order=order)
+    cw = H // 32
+    outs = []
+    for tiled in (False, True):
+        out = torch.full((g.N, ld), 3.0, device=DEV)
+        gates = torch.full((4, g.N, H), 5.0, device=DEV)
+        parts = torch.full((cw, g.N), 7.0, device=DEV)
+        if tiled:
+            _lib.call('tmpnn_gru_fwd_tiles', tiles.cref(), E, proj.data_ptr(), 3 * H, hD.data_ptr(), ld, H, whh_t.data_ptr(),
+                      bih.data_ptr(), bhh.data_ptr(), out.data_ptr(), ld, gates.data_ptr(), g.N * H, w_head.data_ptr(),
+                      parts.data_ptr(), g.N, st())
+        else:
+            _lib.call('tmpnn_gru_fwd', gd.edge_row.data_ptr(), E, 3, gd.src_pos.data_ptr(), gd.dst_pos.data_ptr(),
+                      proj.data_ptr(), 3 * H, 0, H, hD.data_ptr(), ld, H, None, whh_t.data_ptr(), bih.data_ptr(), bhh.data_ptr(),
+                      out.data_ptr(), ld, gates.data_ptr(), g.N * H, w_head.data_ptr(), parts.data_ptr(), g.N, st())
+        torch.cuda.synchronize()
+        outs.append((out.cpu(), gates.cpu(), parts.cpu()))
+    cnt = (tiles.t_dptr[1:] - tiles.t_dptr[:-1])
+    return {'h_out bits': float(not torch.equal(outs[0][0], outs[1][0])),
+            'gates bits': float(not torch.equal(outs[0][1], outs[1][1])),
+            'head bits': float(not torch.equal(outs[0][2], outs[1][2])),
+            'staged tiles': int((cnt <= 24).sum()), 'listed tiles': int((cnt > 24).sum())}
+
+
 def run_all(report=print):
     """Yield (name, worst error, tolerance) for every stage/width combination."""
     g = make_graph()
@@ -588,6 +628,14 @@ def run_all(report=print):
             r = check_wide_tiled(H, gt)
             rec(f'wide tiled H={H} {tag} h_out bit-equal', r['h_out bits'], 0.0)
             rec(f'wide tiled H={H} {tag} gates bit-equal', r['gates bits'], 0.0)
+            report(f'     tiles staged in LDS / read through their det list: {r["staged tiles"]} / {r["listed tiles"]}')
+    for H in (32, 64):
+        for tag, gt, order in (('small batch', g, None), ('ragged batch', make_graph(B=40, frames=7, mean=7, seed=3), None),
+                               ('dense 4x40, blocks', dense_static_graph(4, 40), 'blocks'),
+                               ('dense 3x70, rows', dense_static_graph(3, 70), 'rows')):
+            r = check_fwd_tiles(H, gt, order)
+            for k in ('h_out bits', 'gates bits', 'head bits'):
+                rec(f'fwd tiles H={H} {tag} {k[:-5]} bit-equal', r[k], 0.0)
             report(f'     tiles staged in LDS / read through their det list: {r["staged tiles"]} / {r["listed tiles"]}')
     for C in (32, 64, 96, 192, 256, 768):
         for k, v in check_heads(C, g, gd).items():

@@ -918,6 +918,292 @@ __global__ __launch_bounds__(WPB * 64) void k_gru_fwd_split(GruFwdArgs a) {
     }
 }
 
+// ---- the same forward over EDGE TILES (struct tmpnn_edge_tiles, rows_per_tile = 32) ----------------------------------
+// What holds k_gru_fwd_split is not bytes but a dependent chain inside a wave: after an item's 72 MFMAs the epilogue asks
+// for 24 scattered 16-byte pieces of P[src] / P[dst] per lane and waits for them (s_memtime, round 1: 15.5 k of an item's
+// 31.5 k cycles), and there is no register left to request them any earlier.  Here the DISTINCT projected det rows of the
+// item's tile (16-18 on the KITTI-shaped batches, tile list from trackmpnn_amd.graph.build_edge_tiles) are brought into a
+// per-wave LDS area by LDS-DMA -- no register holds them -- a whole item ahead: the DMA for item i + 1 is issued when item
+// i's stores have left the staging tile (the area IS the staging tile: P is consumed before the outputs are staged) and
+// lands under item i + 1's operand split and matrix phase; the epilogue reads P[src] - P[dst] with ds_read_b128.
+// Rows of 3 gates x 32 columns sit 400 bytes apart (16 consecutive det positions -> 16 different 16-byte slots of the bank
+// row).  A tile with more than TCAP distinct dets takes the gathers of k_gru_fwd_split.  Same products, same order, same
+// epilogue arithmetic: bit-identical results.
+struct FwdTiles { const int32_t* t_row; const int32_t* t_loc; const int32_t* t_dptr; const int32_t* t_dets; int T; };
+static constexpr int TCAP = 24, TP_LD = 100;                   // dets staged per item; floats per staged row
+static constexpr int TP_AREA = TCAP * TP_LD;                   // floats per wave (>= 32 * STG_LD: the output staging tile)
+
+__device__ __forceinline__ uint32_t lds_addr_g(const void* p) {
+    return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)(const char*)p;
+}
+// 16 bytes per lane: per-lane global address -> (wave-uniform LDS byte address) + 16 * lane.  Inline asm on purpose: hipcc
+// would wait vmcnt(0) before every later LDS read (the weight operands of the matrix phase) for a builtin DMA it cannot
+// disambiguate; this one is waited for by hand where the epilogue needs it.
+__device__ __forceinline__ void glds16_g(const void* gsrc, uint32_t lds_wave_base) {
+    unsigned keep;
+    lds_wave_base = __builtin_amdgcn_readfirstlane(lds_wave_base);
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_wave_base) : "memory");
+}
+
+struct TiledIdx { int row, loc, det, nd; };
+__device__ __forceinline__ TiledIdx tiled_idx(const FwdTiles& tl, int R, int t, int c, int lane) {
+    TiledIdx x;
+    const int li = min(32 * t + c, R - 1);                     // (padding slots: the tile's last valid row, never stored)
+    x.row = tl.t_row[li];
+    x.loc = tl.t_loc[li];
+    const int dp0 = tl.t_dptr[t];
+    x.nd = tl.t_dptr[t + 1] - dp0;
+    x.det = lane < x.nd ? tl.t_dets[dp0 + lane] : 0;
+    return x;
+}
+// request the staged copy of a tile's distinct P rows (columns cw0 .. cw0 + 31 of the three gates) into the wave's area
+template <int H>
+__device__ __forceinline__ void tiled_stage_p(const GruFwdArgs& a, const TiledIdx& x, int cw0, int lane, uint32_t area) {
+    const int nchunk = x.nd * 25;                              // 24 chunks of 16 B per det + one of padding
+#pragma unroll 1
+    for (int i0 = 0; i0 < nchunk; i0 += 64) {
+        const int idx = i0 + lane;
+        const int j = idx / 25, rem = idx - 25 * j;
+        const int det = __shfl(x.det, j, 64);
+        if (idx < nchunk && rem < 24)
+            glds16_g(a.msg + (size_t)det * a.ld_msg + (rem >> 3) * H + cw0 + 4 * (rem & 7), area + 16u * i0);
+    }
+}
+
+template <int H, int WPB>
+__global__ __launch_bounds__(WPB * 64) void k_gru_fwd_split_tiled(GruFwdArgs a, FwdTiles tl) {
+    extern __shared__ float lds[];
+    constexpr int H3 = 3 * H, KP = H + 8, NKB = H / 16, CW = H / 32, NQ4 = H / 8;
+    uint16_t* sW = reinterpret_cast<uint16_t*>(lds);                  // [3][3H][KP]
+    for (int i = threadIdx.x; i < H * H3 / 4; i += WPB * 64) {
+        const int k = i / (H3 / 4), j0 = (i % (H3 / 4)) * 4;
+        const float4 w = *reinterpret_cast<const float4*>(a.whh_t + (size_t)k * H3 + j0);
+        const float wv[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            uint16_t q1, q2, q3;
+            split1(wv[e], q1, q2, q3);
+            sW[(0 * H3 + j0 + e) * KP + k] = q1;
+            sW[(1 * H3 + j0 + e) * KP + k] = q2;
+            sW[(2 * H3 + j0 + e) * KP + k] = q3;
+        }
+    }
+    float* area_base = reinterpret_cast<float*>(sW + 3 * H3 * KP);
+    int* next_item = reinterpret_cast<int*>(area_base + WPB * TP_AREA);
+    float* sBias = reinterpret_cast<float*>(next_item + 4);
+    for (int i = threadIdx.x; i < H; i += WPB * 64) {
+        sBias[i] = a.b_ih[i] + a.b_hh[i];
+        sBias[H + i] = a.b_ih[H + i] + a.b_hh[H + i];
+        sBias[2 * H + i] = a.b_ih[2 * H + i];
+        sBias[3 * H + i] = a.b_hh[2 * H + i];
+        sBias[4 * H + i] = a.logit_part ? a.w_head[i] : 0.f;
+    }
+    if (threadIdx.x == 0) *next_item = 0;
+    __syncthreads();
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int c = lane & 31, half = lane >> 5;
+    {
+        const int grp = __builtin_amdgcn_readfirstlane(wave) >> 2;
+        if (grp == 0) __builtin_amdgcn_s_setprio(3);
+        else if (grp == 1) __builtin_amdgcn_s_setprio(2);
+        else if (grp == 2) __builtin_amdgcn_s_setprio(1);
+    }
+    const int items_total = tl.T * CW;
+    const int per_block = (items_total + gridDim.x - 1) / gridDim.x;
+    const int item_lo = blockIdx.x * per_block;
+    const int item_hi = min(items_total, item_lo + per_block);
+
+    int item = 0;
+    if (lane == 0) item = atomicAdd(next_item, 1);
+    item = __builtin_amdgcn_readfirstlane(item) + item_lo;
+    if (item >= item_hi) return;
+    int cw0 = (item % CW) * 32;
+    int t = item / CW;
+    TiledIdx ix = tiled_idx(tl, a.R, t, c, lane);
+    float* stg = area_base + wave * TP_AREA;                   // staged P rows, then the output staging tile
+    const uint32_t area = lds_addr_g(stg);
+    if (ix.nd <= TCAP) tiled_stage_p<H>(a, ix, cw0, lane, area);
+    float4 raw[NQ4];
+    {
+        const float4* xr = reinterpret_cast<const float4*>(a.h + (size_t)ix.row * a.ld_h + (H / 2) * half);
+#pragma unroll
+        for (int i = 0; i < NQ4; ++i) raw[i] = xr[i];
+    }
+
+    for (;;) {
+        int nitem = 0;
+        if (lane == 0) nitem = atomicAdd(next_item, 1);
+        nitem = __builtin_amdgcn_readfirstlane(nitem) + item_lo;
+        const bool nvalid = nitem < item_hi;
+        const int ncw0 = (nitem % CW) * 32;
+        const int nt = nvalid ? nitem / CW : t;
+        const int r0 = 32 * t;
+        const int row = ix.row;
+        const bool staged = ix.nd <= TCAP;
+        Split8 b[NKB];
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb) b[kb] = split8(raw[2 * kb], raw[2 * kb + 1]);
+        const TiledIdx nix = tiled_idx(tl, a.R, nt, c, lane);
+        if (nvalid) {
+            const float4* xr = reinterpret_cast<const float4*>(a.h + (size_t)nix.row * a.ld_h + (H / 2) * half);
+#pragma unroll
+            for (int i = 0; i < NQ4; ++i) raw[i] = xr[i];
+        }
+#ifdef FT_HP_EARLY
+        // (measured, same box: requesting the merge term's previous state before the matrix phase instead of after it
+        //  changes nothing -- 2.66 vs 2.60 ms per 6.03 M rows; kept behind this switch)
+        float4 hp4[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            hp4[q] = *reinterpret_cast<const float4*>(a.h + (size_t)row * a.ld_h + cw0 + 8 * q + 4 * half);
+        __builtin_amdgcn_sched_barrier(0);                     // (left alone hipcc sinks these loads to the end of the MFMAs)
+#endif
+        f32x16 acc_r, acc_z, acc_hn, acc_in;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { acc_r[i] = 0.f; acc_z[i] = 0.f; acc_hn[i] = 0.f; }
+        {
+            const uint16_t* wp0 = sW + (cw0 + c) * KP + (H / 2) * half;
+#pragma unroll
+            for (int kb = 0; kb < NKB; ++kb) {
+                const uint16_t* wp = wp0 + 8 * kb;
+#pragma unroll
+                for (int g = 0; g < 3; ++g) {
+                    const uint4 w1 = *reinterpret_cast<const uint4*>(wp + (g * H) * KP);
+                    const uint4 w2 = *reinterpret_cast<const uint4*>(wp + (H3 + g * H) * KP);
+                    const uint4 w3 = *reinterpret_cast<const uint4*>(wp + (2 * H3 + g * H) * KP);
+                    if (g == 0) acc_r = mfma_x6(w1, w2, w3, b[kb], acc_r);
+                    else if (g == 1) acc_z = mfma_x6(w1, w2, w3, b[kb], acc_z);
+                    else acc_hn = mfma_x6(w1, w2, w3, b[kb], acc_hn);
+                }
+            }
+        }
+        // the staged P rows were requested an item ago; only the loads issued since (the next item's operand and index
+        // loads, at least NQ4 of them) may still be in flight
+        if (staged) {
+            if (nvalid) {
+                if constexpr (NQ4 == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+        }
+#ifndef FT_HP_EARLY
+        float4 hp4[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            hp4[q] = *reinterpret_cast<const float4*>(a.h + (size_t)row * a.ld_h + cw0 + 8 * q + 4 * half);
+#endif
+        f32x16 outv;
+        {
+            float4 gs[4], gd[4], hs[4], hd[4];
+            const int ls = ix.loc & 0xFFFF, ld_ = ix.loc >> 16;
+            // the tile's det list sits one entry per lane: the global det index of a position is a cross-lane read
+            const int sdet = __shfl(ix.det, ls, 64), ddet = __shfl(ix.det, ld_, 64);
+            const float* ps0 = a.msg + (size_t)sdet * a.ld_msg + cw0 + 4 * half;       // (the gather path of big tiles)
+            const float* pd0 = a.msg + (size_t)ddet * a.ld_msg + cw0 + 4 * half;
+            if (staged) {
+                const float* ls0 = stg + ls * TP_LD + 4 * half;
+                const float* ld0 = stg + ld_ * TP_LD + 4 * half;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) gs[q] = *reinterpret_cast<const float4*>(ls0 + 8 * q);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) gd[q] = *reinterpret_cast<const float4*>(ld0 + 8 * q);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) hs[q] = *reinterpret_cast<const float4*>(ls0 + 32 + 8 * q);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) hd[q] = *reinterpret_cast<const float4*>(ld0 + 32 + 8 * q);
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) gs[q] = *reinterpret_cast<const float4*>(ps0 + 8 * q);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) gd[q] = *reinterpret_cast<const float4*>(pd0 + 8 * q);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) hs[q] = *reinterpret_cast<const float4*>(ps0 + H + 8 * q);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) hd[q] = *reinterpret_cast<const float4*>(pd0 + H + 8 * q);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {                       // r: pre-activation in place
+                const float4 b4 = *reinterpret_cast<const float4*>(sBias + cw0 + 8 * q + 4 * half);
+                acc_r[4 * q + 0] = acc_r[4 * q + 0] + (gs[q].x - gd[q].x) + b4.x;
+                acc_r[4 * q + 1] = acc_r[4 * q + 1] + (gs[q].y - gd[q].y) + b4.y;
+                acc_r[4 * q + 2] = acc_r[4 * q + 2] + (gs[q].z - gd[q].z) + b4.z;
+                acc_r[4 * q + 3] = acc_r[4 * q + 3] + (gs[q].w - gd[q].w) + b4.w;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (staged) {
+                const float* ls0 = stg + ls * TP_LD + 4 * half + 64;
+                const float* ld0 = stg + ld_ * TP_LD + 4 * half + 64;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) gs[q] = *reinterpret_cast<const float4*>(ls0 + 8 * q);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) gd[q] = *reinterpret_cast<const float4*>(ld0 + 8 * q);
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) gs[q] = *reinterpret_cast<const float4*>(ps0 + 2 * H + 8 * q);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) gd[q] = *reinterpret_cast<const float4*>(pd0 + 2 * H + 8 * q);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {                       // z
+                const float4 b4 = *reinterpret_cast<const float4*>(sBias + H + cw0 + 8 * q + 4 * half);
+                acc_z[4 * q + 0] = acc_z[4 * q + 0] + (hs[q].x - hd[q].x) + b4.x;
+                acc_z[4 * q + 1] = acc_z[4 * q + 1] + (hs[q].y - hd[q].y) + b4.y;
+                acc_z[4 * q + 2] = acc_z[4 * q + 2] + (hs[q].z - hd[q].z) + b4.z;
+                acc_z[4 * q + 3] = acc_z[4 * q + 3] + (hs[q].w - hd[q].w) + b4.w;
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {                       // n: input part
+                const float4 b4 = *reinterpret_cast<const float4*>(sBias + 2 * H + cw0 + 8 * q + 4 * half);
+                acc_in[4 * q + 0] = (gs[q].x - gd[q].x) + b4.x;
+                acc_in[4 * q + 1] = (gs[q].y - gd[q].y) + b4.y;
+                acc_in[4 * q + 2] = (gs[q].z - gd[q].z) + b4.z;
+                acc_in[4 * q + 3] = (gs[q].w - gd[q].w) + b4.w;
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 b4h = *reinterpret_cast<const float4*>(sBias + 3 * H + cw0 + 8 * q + 4 * half);
+                const float bh[4] = {b4h.x, b4h.y, b4h.z, b4h.w};
+                const float hp[4] = {hp4[q].x, hp4[q].y, hp4[q].z, hp4[q].w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int reg = 4 * q + i;
+                    const float ro = sigmoidf_(acc_r[reg]);
+                    const float zo = sigmoidf_(acc_z[reg]);
+                    const float ho = acc_hn[reg] + bh[i];
+                    const float no = tanhf_(acc_in[reg] + ro * ho);
+                    outv[reg] = (1.0f - zo) * no + zo * hp[i];
+                    acc_r[reg] = ro; acc_z[reg] = zo; acc_hn[reg] = ho; acc_in[reg] = no;
+                }
+            }
+        }
+        if (a.logit_part) {
+            float p = 0.f;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 w = *reinterpret_cast<const float4*>(sBias + 4 * H + cw0 + 8 * q + 4 * half);
+                p += outv[4 * q] * w.x + outv[4 * q + 1] * w.y + outv[4 * q + 2] * w.z + outv[4 * q + 3] * w.w;
+            }
+            p += __shfl_xor(p, 32);
+            if (half == 0 && r0 + c < a.R) a.logit_part[(size_t)(cw0 / 32) * a.part_stride + row] = p;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // every read of the staged P rows is back: the area is free
+        stage_store32(stg, c, half, lane, outv, a.h_out, a.ld_out, cw0, row, r0, a.R);
+        if (a.gates) {
+            stage_store32<true>(stg, c, half, lane, acc_r, a.gates, H, cw0, row, r0, a.R);
+            stage_store32<true>(stg, c, half, lane, acc_z, a.gates + a.gate_plane, H, cw0, row, r0, a.R);
+            stage_store32<true>(stg, c, half, lane, acc_in, a.gates + 2 * a.gate_plane, H, cw0, row, r0, a.R);
+            stage_store32<true>(stg, c, half, lane, acc_hn, a.gates + 3 * a.gate_plane, H, cw0, row, r0, a.R);
+        }
+        if (!nvalid) break;
+        cw0 = ncw0; t = nt; ix = nix;
+        if (ix.nd <= TCAP) tiled_stage_p<H>(a, ix, cw0, lane, area);      // (the staging tile's last reads are back: stage_store32)
+    }
+}
+
 // out[r][0:NOUT] = in[rows[r]][0:H] @ Wt[H][NOUT]   (no bias; H <= 64; NOUT multiple of 32).  Used to
 // project the det rows once per call (P = h[dets] W_ih^T) for the XMODE 3 forward.
 template <int H, int NT>     // NT = NOUT / 32 column tiles, all owned by one wave
@@ -2921,6 +3207,41 @@ generic:
     else         { if (xmode == 0) L(1, 0); else if (xmode == 1) L(1, 1); else L(1, 2); }
 #undef L
     return check_launch("gru_fwd");
+}
+
+int tmpnn_gru_fwd_tiles(const tmpnn_edge_tiles* tiles, int R, const float* proj, int ld_proj, const float* h, int ld_h, int H,
+                        const float* whh_t, const float* b_ih, const float* b_hh, float* h_out, int ld_out, float* gates,
+                        size_t gate_plane, const float* w_head, float* logit_part, size_t part_stride, tmpnn_stream stream) {
+    TM_REQUIRE(H == 32 || H == 64, "gru_fwd_tiles: H=%d (the tiled forward serves the LDS-resident cells, H in {32, 64})", H);
+    TM_REQUIRE(R >= 0, "gru_fwd_tiles: R=%d", R);
+    if (R == 0) return TMPNN_OK;
+    TM_REQUIRE(split_enabled(), "gru_fwd_tiles: the tiled forward is the bf16x6 form (TMPNN_SPLIT=0 keeps tmpnn_gru_fwd)");
+    TM_REQUIRE(tiles != nullptr, "gru_fwd_tiles: tiles is null");
+    TM_REQUIRE(tiles->rows_per_tile == 32 && tiles->T > 0 && (long)tiles->T * 32 >= R && (long)(tiles->T - 1) * 32 < R &&
+                   tiles->t_row && tiles->t_loc && tiles->t_dptr && tiles->t_dets,
+               "gru_fwd_tiles: tile list (T=%d, rows_per_tile=%d) does not cover R=%d rows in 32-row tiles", tiles->T,
+               tiles->rows_per_tile, R);
+    TM_REQUIRE(proj && h && whh_t && b_ih && b_hh && h_out, "gru_fwd_tiles: null pointer");
+    TM_REQUIRE(ld_proj >= 3 * H && (ld_proj & 3) == 0 && aligned16(proj) && ld_h >= H && ld_out >= H && (ld_h & 3) == 0 &&
+                   aligned16(h) && aligned16(whh_t) && aligned16(h_out) && (ld_out & 3) == 0 && aligned16(b_ih) && aligned16(b_hh) &&
+                   (gates == nullptr || (aligned16(gates) && (gate_plane & 3) == 0 && gate_plane >= (size_t)H)),
+               "gru_fwd_tiles: layout (16-byte alignment, leading dimensions)");
+    TM_REQUIRE(logit_part == nullptr || (w_head != nullptr && aligned16(w_head)), "gru_fwd_tiles: fused head needs a 16-byte aligned w_head");
+    GruFwdArgs a{nullptr, R, nullptr, nullptr, proj, ld_proj, H, 0, h, ld_h, H, nullptr, whh_t, b_ih, b_hh, h_out, ld_out, gates,
+                 gate_plane, w_head, logit_part, part_stride};
+    FwdTiles tl{tiles->t_row, tiles->t_loc, tiles->t_dptr, tiles->t_dets, tiles->T};
+    hipStream_t st = as_stream(stream);
+    const int ntiles = ceil_div(R, (H == 64) ? 192 : 256);
+    dim3 pgrid(ntiles < 256 ? ntiles : 256);
+    const size_t shm = (size_t)3 * 3 * H * (H + 8) * 2 + sizeof(float) * ((size_t)8 * TP_AREA + 4 + 5 * H);
+    if (H == 64) {
+        TM_SHM_ONCE((k_gru_fwd_split_tiled<64, 8>), shm);
+        hipLaunchKernelGGL((k_gru_fwd_split_tiled<64, 8>), pgrid, dim3(512), shm, st, a, tl);
+    } else {
+        TM_SHM_ONCE((k_gru_fwd_split_tiled<32, 8>), shm);
+        hipLaunchKernelGGL((k_gru_fwd_split_tiled<32, 8>), pgrid, dim3(512), shm, st, a, tl);
+    }
+    return check_launch("gru_fwd_split_tiled");
 }
 
 int tmpnn_rows_linear(const int32_t* rows, int R, const float* in, int ld_in, int H, const float* wt, int NOUT,

@@ -34,6 +34,9 @@ FUSED_BWD = os.environ.get('TMPNN_FUSED_BWD', '1') == '1'     # one-pass cell ba
 WIDE = os.environ.get('TMPNN_WIDE', '1') != '0' and os.environ.get('TMPNN_SPLIT', '1')[:1] != '0'
 # wide cells: forward over edge tiles (projected det rows staged in LDS); TMPNN_WIDE_TILED=0 keeps the per-row gathers
 WIDE_TILED = os.environ.get('TMPNN_WIDE_TILED', '1') != '0'
+# H <= 64 edge cells: forward over 32-row edge tiles (projected det rows staged in LDS an item ahead); TMPNN_FWD_TILED=0
+# keeps the per-row gathers of tmpnn_gru_fwd (xmode 3)
+FWD_TILED = os.environ.get('TMPNN_FWD_TILED', '1') != '0' and os.environ.get('TMPNN_SPLIT', '1')[:1] != '0'
 
 
 _wide_ws: Dict[torch.device, torch.Tensor] = {}
@@ -247,10 +250,15 @@ def mp_forward(spec: ModelSpec, plan: CallPlan, x: torch.Tensor, h_in: Optional[
             proj = torch.empty((Dn, 3 * H), **opts)
             _lib.call('tmpnn_rows_linear', g.det_row.data_ptr(), Dn, hg, GH, H, e_wih_t.data_ptr(), 3 * H,
                       proj.data_ptr(), 3 * H, st)
-            _lib.call('tmpnn_gru_fwd', g.edge_row.data_ptr(), E, 3, g.src_pos.data_ptr(), g.dst_pos.data_ptr(),
-                      proj.data_ptr(), 3 * H, 0, H, hg, GH, H, None, e_whh_t.data_ptr(),
-                      P[f + 'edge_gru.bias_ih'].data_ptr(), P[f + 'edge_gru.bias_hh'].data_ptr(),
-                      og, GH, gp, plane, we_g, part_g, N, st)
+            if FWD_TILED and E > 0:
+                _lib.call('tmpnn_gru_fwd_tiles', edge_tiles(g, 32).cref(), E, proj.data_ptr(), 3 * H, hg, GH, H,
+                          e_whh_t.data_ptr(), P[f + 'edge_gru.bias_ih'].data_ptr(), P[f + 'edge_gru.bias_hh'].data_ptr(),
+                          og, GH, gp, plane, we_g, part_g, N, st)
+            else:
+                _lib.call('tmpnn_gru_fwd', g.edge_row.data_ptr(), E, 3, g.src_pos.data_ptr(), g.dst_pos.data_ptr(),
+                          proj.data_ptr(), 3 * H, 0, H, hg, GH, H, None, e_whh_t.data_ptr(),
+                          P[f + 'edge_gru.bias_ih'].data_ptr(), P[f + 'edge_gru.bias_hh'].data_ptr(),
+                          og, GH, gp, plane, we_g, part_g, N, st)
         else:
             _lib.call('tmpnn_gru_fwd', g.edge_row.data_ptr(), E, xmode, g.src.data_ptr(), g.dst.data_ptr(),
                       None, 0, 0, spec.IN_e, hg, GH, H,

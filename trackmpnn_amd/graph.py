@@ -97,14 +97,17 @@ class EdgeTiles:
 
 
 def build_edge_tiles(graph: FrameGraph, rows_per_tile: int = 128, src_group: int = 8, dst_group: int = 16,
-                     stats: bool = False) -> EdgeTiles:
+                     stats: bool = False, order: str = 'blocks') -> EdgeTiles:
     """Cut the graph's edge rows into tiles of `rows_per_tile` rows that touch few distinct dets.
 
     A frame block of the rolling graph is a dense [A srcs x D_t dsts] set of rows in src-major order
     (reference/utils/graph.py:141-156, 285-301).  The edges are ordered by (dst // dst_group, src // src_group, src, dst)
     and cut every `rows_per_tile`: where blocks are dense a tile is (src_group x dst_group) edges over
-    src_group + dst_group dets; ragged graphs (after decode_tracks' row deletion) just get longer det lists.  Index
-    plumbing only (torch ops on the graph's device, no host round trip unless `stats`)."""
+    src_group + dst_group dets; ragged graphs (after decode_tracks' row deletion) just get longer det lists.
+    `order='rows'` keeps the graph's own row order instead (tiles of consecutive edge rows): the better choice when a
+    src's run of edges is much shorter than a tile, as in batches of small windows (KITTI: ~6 dets per frame, 32
+    consecutive rows touch ~16 dets, any regrouping touches more).  Index plumbing only (torch ops on the graph's
+    device, no host round trip unless `stats`)."""
     if graph.src_pos is None or graph.dst_pos is None:
         raise ValueError('build_edge_tiles: the graph carries no src_pos / dst_pos')
     dev = graph.device
@@ -116,10 +119,13 @@ def build_edge_tiles(graph: FrameGraph, rows_per_tile: int = 128, src_group: int
         return EdgeTiles(0, R, z, z.clone(), torch.zeros(1, dtype=torch.int32, device=dev), z.clone())
     s, d = graph.src_pos.long(), graph.dst_pos.long()
     ns = graph.Dn // src_group + 1
-    key = (((d // dst_group) * ns + s // src_group) * src_group + s % src_group) * dst_group + d % dst_group
-    order = torch.argsort(key)
+    if order == 'rows':
+        so, do, ro = s, d, graph.edge_row.long()
+    else:
+        key = (((d // dst_group) * ns + s // src_group) * src_group + s % src_group) * dst_group + d % dst_group
+        perm = torch.argsort(key)
+        so, do, ro = s[perm], d[perm], graph.edge_row.long()[perm]
     pad = T * R - E
-    so, do, ro = s[order], d[order], graph.edge_row.long()[order]
     if pad:
         so = torch.cat([so, so[-1:].expand(pad)])            # padding slots repeat the last edge's dets (no new det)
         do = torch.cat([do, do[-1:].expand(pad)])
@@ -146,8 +152,17 @@ def edge_tiles(graph: FrameGraph, rows_per_tile: int = 128) -> EdgeTiles:
     cache = graph.__dict__.setdefault('_tiles', {})
     t = cache.get(rows_per_tile)
     if t is None:
-        t = cache[rows_per_tile] = (build_edge_tiles(graph, rows_per_tile) if rows_per_tile == 128 else
-                                    build_edge_tiles(graph, rows_per_tile, 4, 8))
+        # dense frame blocks (a src's run of edges spans a good part of a tile) are cut into src x dst sub-blocks; graphs of
+        # small windows keep their row order.  The mean run length costs one host round trip, once per graph.
+        runs = 1
+        if graph.E > 1:
+            runs = 1 + int((graph.src_pos[1:] != graph.src_pos[:-1]).sum())
+        blocks = graph.E / runs >= rows_per_tile / 2
+        if rows_per_tile == 128:
+            t = build_edge_tiles(graph, 128, 8, 16, order='blocks' if blocks else 'rows')
+        else:
+            t = build_edge_tiles(graph, rows_per_tile, 4, 8, order='blocks' if blocks else 'rows')
+        cache[rows_per_tile] = t
     return t
 
 
