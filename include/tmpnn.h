@@ -468,6 +468,17 @@ int tmpnn_track_delete(int N, const int32_t* ts, const int32_t* det_id, const in
  * state and the scores follow the deletion without leaving HBM (utils/graph.py:514,519). */
 int tmpnn_track_gather(const float* in, int ld_in, int W, int max_rows, const int32_t* keep, const int32_t* count,
                        float* out, int ld_out, tmpnn_stream stream);
+/* decode_tracks' track finalisation (utils/graph.py:456-490) on the device: y_track [ND] = y_out[:, 1] of the sequence
+ * (int32, -1 = no track yet; it stays in device memory between calls), updated for the window's dets from the
+ * association links assoc[] (det ids, the output of tmpnn_track_associate or of the Hungarian matching), the scores and
+ * t_upto exactly as the reference's walk over all detections does.  pos_of_det [ND]: scratch (det id -> position among
+ * the graph's dets; entries of dets outside the graph are never read).  ws: tmpnn_track_finalize_ws(N) bytes, only
+ * needed when the graph may hold more than 4096 dets (0 otherwise). */
+size_t tmpnn_track_finalize_ws(int max_dets);
+int tmpnn_track_finalize(const tmpnn_dgraph* g, const int32_t* ts, const int32_t* det_id, const int32_t* assoc,
+                         const float* score, int t_upto, int32_t* y_track, int ND, int32_t* pos_of_det, void* ws,
+                         size_t ws_bytes, tmpnn_stream stream);
+
 
 /* ======================================================================================================
  * Wide cells (H = 128 / 256, diff messages; BASELINE.json C5) as LDS-tiled GEMMs on bf16x6 split products

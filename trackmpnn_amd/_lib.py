@@ -153,6 +153,9 @@ _SIGNATURES = {
                                    c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                    c_void_p, c_void_p, c_void_p]),
     'tmpnn_track_gather': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    'tmpnn_track_finalize_ws': (c_size_t, [c_int]),
+    'tmpnn_track_finalize': (c_int, [_DGP, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p,
+                                     c_size_t, c_void_p]),
     'tmpnn_wide_supported': (c_int, [c_int, c_int]),
     'tmpnn_wide_prep_bytes': (c_size_t, [c_int, c_int]),
     'tmpnn_wide_prepare': (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),

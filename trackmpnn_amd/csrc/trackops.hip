@@ -15,8 +15,10 @@
 //   tmpnn_track_delete      :492-520                           which rows decode_tracks drops; compacted row form
 //   tmpnn_track_gather      :514-519                           stream compaction of the state rows (h, scores) by the kept rows
 //
+//   tmpnn_track_finalize    :456-490                           y_out[:, 1]: the walk along the association links
+//
 // The index form (CSR etc.) is re-derived from the rows by tmpnn_graph_from_rows (csrc/graphconv.hip).  The Hungarian
-// matching and the linked-list walk that finalises tracks stay on the host (tens of detections, scipy).  Integer work,
+// matching stays on the host (tens of detections, scipy).  Integer work,
 // HBM/latency bound, graphs of <= TMPNN_TRACK_MAX_ROWS rows: single-workgroup kernels with LDS scans.
 #include "common.h"
 
@@ -246,6 +248,88 @@ __global__ __launch_bounds__(256) void k_track_gather(const float* __restrict__ 
     }
 }
 
+
+// ---- track finalisation (utils/graph.py:456-490): y_out[:, 1] from the association links, on the device ------------------
+// The reference walks, for every detection of the sequence in id order, the linked list det -> y_pred[det, 2] -> ... from
+// each not-yet-visited det before t_upto scored >= 0.5, writing the walk's track id (the start's existing id, else the
+// next free one) over EVERYTHING on its path -- also over dets an earlier walk of the same call has labelled: the last
+// walk through a det wins.  Links lead to later detections, and the graph's det rows are in time order, so one forward
+// pass over the window's dets computes the same thing: a det is "reached" when an on-path predecessor's walk continues
+// into it, it starts a walk when it is eligible and not reached, and its label is that of the LATEST start among the
+// walks through it.  Dn is tens to hundreds: the pass is one thread over LDS-resident arrays (all other steps -- the
+// id -> position table, the scan for the next free id, the label write-back -- are parallel), and the host is not
+// involved: y_out stays on the device for the whole sequence.
+static constexpr int FIN_LDS_DETS = 4096;
+
+__global__ __launch_bounds__(TK_THREADS) void k_track_finalize(tmpnn_dgraph g, const int32_t* __restrict__ ts,
+                                                               const int32_t* __restrict__ det_id,
+                                                               const int32_t* __restrict__ assoc,
+                                                               const float* __restrict__ score, int t_upto,
+                                                               int32_t* __restrict__ y_track, int ND,
+                                                               int32_t* __restrict__ pos_of_det, int32_t* __restrict__ ws) {
+    __shared__ int s_next[FIN_LDS_DETS], s_best[FIN_LDS_DETS], s_tid[FIN_LDS_DETS], s_old[FIN_LDS_DETS];
+    __shared__ unsigned char s_flag[FIN_LDS_DETS];         // bit 0 eligible start, bit 1 reached, bit 2 on a path
+    __shared__ int s_max;
+    const int tid = threadIdx.x;
+    const int Dn = g.meta[1];
+    // arrays of the pass: LDS up to FIN_LDS_DETS dets, the caller's scratch beyond (same code through generic pointers)
+    int* nextk = Dn <= FIN_LDS_DETS ? s_next : ws;
+    int* best = Dn <= FIN_LDS_DETS ? s_best : ws + Dn;
+    int* tidv = Dn <= FIN_LDS_DETS ? s_tid : ws + 2 * (size_t)Dn;
+    int* oldv = Dn <= FIN_LDS_DETS ? s_old : ws + 3 * (size_t)Dn;
+    unsigned char* flag = Dn <= FIN_LDS_DETS ? s_flag : reinterpret_cast<unsigned char*>(ws + 4 * (size_t)Dn);
+    if (tid == 0) s_max = -1;
+    __syncthreads();
+    {   // next free track id = max(y_out[:, 1]) + 1 (utils/graph.py:457)
+        int m = -1;
+        for (int i = tid; i < ND; i += TK_THREADS) m = max(m, y_track[i]);
+        for (int off = 32; off > 0; off >>= 1) m = max(m, __shfl_xor(m, off));
+        if ((tid & 63) == 0) atomicMax(&s_max, m);
+    }
+    for (int k = tid; k < Dn; k += TK_THREADS) pos_of_det[det_id[g.det_row[k]]] = k;
+    __threadfence_block();
+    __syncthreads();
+    for (int k = tid; k < Dn; k += TK_THREADS) {
+        const int r = g.det_row[k];
+        const int a = assoc[r];
+        int nk = -1;
+        if (a >= 0) {
+            const int ka = pos_of_det[a];
+            // the walk stops between two detections that are both at or after t_upto (utils/graph.py:486-487)
+            if (!(ts[r] >= t_upto && ts[g.det_row[ka]] >= t_upto)) nk = ka;
+        }
+        nextk[k] = nk;
+        best[k] = -1;
+        oldv[k] = y_track[det_id[r]];
+        flag[k] = (ts[r] < t_upto && score[r] >= 0.5f) ? 1 : 0;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int next_id = s_max + 1;
+        for (int k = 0; k < Dn; ++k) {
+            unsigned char f = flag[k];
+            if (!(f & 2) && (f & 1)) {                          // starts a walk: an existing track continues, or a new id
+                best[k] = k;
+                tidv[k] = oldv[k] != -1 ? oldv[k] : next_id++;
+                f |= 4;
+            } else if (f & 2) {
+                f |= 4;
+            }
+            flag[k] = f;
+            if (f & 4) {
+                const int nk = nextk[k];
+                if (nk > k) {                                   // (links lead forward in time; anything else ends the walk)
+                    flag[nk] |= 2;
+                    if (best[k] > best[nk]) best[nk] = best[k];
+                }
+            }
+        }
+    }
+    __syncthreads();
+    for (int k = tid; k < Dn; k += TK_THREADS)
+        if (flag[k] & 4) y_track[det_id[g.det_row[k]]] = tidv[best[k]];
+}
+
 }  // namespace tmpnn
 
 using namespace tmpnn;
@@ -312,6 +396,24 @@ int tmpnn_track_gather(const float* in, int ld_in, int W, int max_rows, const in
     hipLaunchKernelGGL(k_track_gather, dim3((int)blocks), dim3(256), 0, as_stream(stream), in, ld_in, W, keep, count, out,
                        ld_out);
     return check_launch("track_gather");
+}
+
+size_t tmpnn_track_finalize_ws(int max_dets) { return max_dets > FIN_LDS_DETS ? sizeof(int32_t) * 5 * (size_t)max_dets : 0; }
+
+int tmpnn_track_finalize(const tmpnn_dgraph* g, const int32_t* ts, const int32_t* det_id, const int32_t* assoc,
+                         const float* score, int t_upto, int32_t* y_track, int ND, int32_t* pos_of_det, void* ws,
+                         size_t ws_bytes, tmpnn_stream stream) {
+    TM_REQUIRE(g && g->meta && g->det_row && ts && det_id && assoc && score && y_track && pos_of_det && ND > 0,
+               "track_finalize: null pointer / empty sequence");
+    TM_REQUIRE(g->N >= 0 && g->N <= TMPNN_TRACK_MAX_ROWS, "track_finalize: N=%d (limit %d)", g->N, TMPNN_TRACK_MAX_ROWS);
+    if (g->N == 0) return TMPNN_OK;
+    // (the det count lives on the device; beyond FIN_LDS_DETS dets the pass needs 5 ints per det of scratch)
+    TM_REQUIRE(g->N <= FIN_LDS_DETS || (ws != nullptr && ws_bytes >= tmpnn_track_finalize_ws(g->N)),
+               "track_finalize: %d rows may hold more than %d dets: workspace of tmpnn_track_finalize_ws(N) bytes needed", g->N,
+               FIN_LDS_DETS);
+    hipLaunchKernelGGL(k_track_finalize, dim3(1), dim3(TK_THREADS), 0, as_stream(stream), *g, ts, det_id, assoc, score, t_upto,
+                       y_track, ND, pos_of_det, reinterpret_cast<int32_t*>(ws));
+    return check_launch("track_finalize");
 }
 
 }  // extern "C"

@@ -4,16 +4,18 @@ Mirror of the reference's graph bookkeeping -- `initialize_graph`, `update_graph
 (reference/utils/graph.py:96-186, 189-334, 392-539) -- with the same arguments' meaning and the same results, but
 the graph and the hidden state never visit the host: the graph lives in HBM in row form (csrc/trackops.hip), is
 edited by small kernels (association rule, active set, block append, row deletion as a stream compaction) and its index
-form (`DeviceGraph`) is re-derived on the device after every edit.  What stays on the host is what the reference itself
-solves with scipy / Python on a few dozen detections: the Hungarian matching and the walk that finalises tracks
-(`y_out`); they read a handful of int32 per row, never the state.
+form (`DeviceGraph`) is re-derived on the device after every edit; the walk that finalises tracks into `y_out` runs on
+the device too and `y_out` stays there until the sequence is done.  What stays on the host is what the reference itself
+solves with scipy on a few dozen detections: the Hungarian matching (it reads a handful of int32 per row, never the
+state).  Host reads per timestep in greedy mode: the size of the active set (update) and the number of kept rows (decode).
 
     tg, feats, t_st, t_end = TrackGraph.initialize(X, y, t_st=0, mode='test', device='cuda:0')
     scores, logits, h, _ = model.forward_dgraph(feats, None, tg.graph)
     for t in range(t_st, t_end):
         feats = tg.update(scores[:, 0], X, y, t, mode='test')                   # update_graph
         scores, logits, h, _ = model.forward_dgraph(feats, h, tg.graph)
-        h, sc = tg.decode(h, scores[:, 0], y_out, t - cur_win + 2, ret_win)    # decode_tracks
+        h, sc = tg.decode(h, scores[:, 0], None, t - cur_win + 2, ret_win)     # decode_tracks
+    y_out[:, 1] = tg.tracks()
 """
 from __future__ import annotations
 
@@ -52,6 +54,14 @@ class TrackGraph:
         self._small = torch.zeros(4, **i32)              # [0] count, [1] status
         self.track: Optional[torch.Tensor] = None        # int32 [ND] track id of every detection (training labels)
         self.graph: Optional[DeviceGraph] = None
+        # per sequence, set by initialize(): the finalised tracks y_out[:, 1] (device, -1 = none yet), the detections of
+        # every timestep (device ids sorted by time + host offsets) and the features, uploaded ONCE
+        self.y_track: Optional[torch.Tensor] = None
+        self._pos_of_det: Optional[torch.Tensor] = None
+        self._ids_sorted: Optional[torch.Tensor] = None
+        self._t_range: dict = {}
+        self._Xd: Optional[torch.Tensor] = None
+        self._fin_ws: Optional[torch.Tensor] = None
 
     @property
     def rows(self):
@@ -121,11 +131,33 @@ class TrackGraph:
         r['assoc'][:N].fill_(-1)
         tg.track = torch.from_numpy(trk.astype(np.int32)).to(tg.device)
         tg._rebuild()
-        Xd = X[0].to(tg.device)
+        tg._sequence(X, yy)
+        Xd = tg._Xd
         feats = torch.zeros((N, X.shape[2]), dtype=Xd.dtype, device=tg.device)
         feats[:n0] = Xd[torch.from_numpy(ids0).to(tg.device)]
         feats[n0 + n0 * n1:] = Xd[torch.from_numpy(ids1).to(tg.device)]
         return tg, feats, t1 + 1, tN + 1
+
+    def _sequence(self, X: torch.Tensor, yy: np.ndarray) -> None:
+        """Per-sequence device state, uploaded once: features, the detections of every timestep, y_out[:, 1]."""
+        ND = int(yy.shape[0])
+        self._Xd = X[0].to(self.device)
+        order = np.argsort(yy[:, 0], kind='stable')
+        self._ids_sorted = torch.from_numpy(order.astype(np.int32)).to(self.device)
+        ts_sorted = yy[order, 0]
+        self._t_range = {}
+        if ND:
+            cut = np.flatnonzero(np.diff(ts_sorted)) + 1
+            lo = np.concatenate([[0], cut])
+            hi = np.concatenate([cut, [ND]])
+            self._t_range = {int(ts_sorted[a]): (int(a), int(b)) for a, b in zip(lo, hi)}
+        self.y_track = torch.full((max(ND, 1),), -1, dtype=torch.int32, device=self.device)
+        self._pos_of_det = torch.zeros((max(ND, 1),), dtype=torch.int32, device=self.device)
+        self._time_sorted = bool((np.diff(yy[:, 0]) >= 0).all())
+
+    def tracks(self) -> np.ndarray:
+        """y_out[:, 1] of the sequence so far (one device -> host copy; call it when the sequence is done)."""
+        return self.y_track.cpu().numpy().astype(np.int64)
 
     # ---------------------------------------------------------------------------------------------------------------
     def _associate(self, score_pos: Optional[torch.Tensor], mode: str, use_hungarian: bool) -> None:
@@ -133,7 +165,7 @@ class TrackGraph:
         if mode != 'train' and use_hungarian:
             self._hungarian(score_pos)
             return
-        self._small[1] = 0
+        self._small[1:2].zero_()                               # (a Python scalar written into a device tensor is a synchronising copy)
         _lib.call('tmpnn_track_associate', self.graph.cref(), r['det_id'].data_ptr(),
                   r['labels'].data_ptr() if mode == 'train' else None,
                   score_pos.data_ptr() if mode != 'train' else None, 0 if mode == 'train' else 1,
@@ -188,64 +220,53 @@ class TrackGraph:
         self._associate(sp, mode, use_hungarian)
         _lib.call('tmpnn_track_active', N, r['ts'].data_ptr(), r['assoc'].data_ptr(), _lib.ptr(sp),
                   0 if mode == 'train' else 1, int(t), self._active.data_ptr(), self._small.data_ptr(), _stream())
-        yy = y[0].detach().cpu().numpy()
-        ids_t = np.nonzero(yy[:, 0] == t)[0]
-        D = int(ids_t.size)
-        A, status = self._small[:2].tolist()
+        lo, hi = self._t_range.get(int(t), (0, 0))
+        D = hi - lo
+        Xd = self._Xd
+        if D == 0:
+            return torch.zeros((0, Xd.shape[1]), dtype=Xd.dtype, device=self.device)
+        A, status = self._small[:2].tolist()               # the ONE host read of an update: the size of the active set
         if status & 1:
             raise AssertionError('More than one GT edge from same node!')
         n_new = A * D + D
-        Xd = X[0]
-        if D == 0:
-            return torch.zeros((0, X.shape[2]), dtype=Xd.dtype, device=self.device)
         if N + n_new > self.cap:
             raise ValueError(f'TrackGraph: {N + n_new} rows exceed the device-resident limit of {self.cap}')
-        ids_dev = torch.from_numpy(ids_t.astype(np.int32)).to(self.device)
+        ids_dev = self._ids_sorted[lo:hi]
         _lib.call('tmpnn_track_append', N, A, D, self._active.data_ptr(), ids_dev.data_ptr(), int(t),
                   self.track.data_ptr() if self.track is not None else None,
                   r['ts'].data_ptr(), r['det_id'].data_ptr(), r['assoc'].data_ptr(), r['is_edge'].data_ptr(),
                   r['src'].data_ptr(), r['dst'].data_ptr(), r['labels'].data_ptr(), _stream())
         self.N = N + n_new
         self._rebuild()
-        feats = torch.zeros((n_new, X.shape[2]), dtype=Xd.dtype, device=self.device)
-        feats[A * D:] = Xd.to(self.device)[ids_dev.long()]
+        feats = torch.zeros((n_new, Xd.shape[1]), dtype=Xd.dtype, device=self.device)
+        feats[A * D:] = Xd[ids_dev.long()]
         return feats
 
     # ---------------------------------------------------------------------------------------------------------------
-    def decode(self, h: torch.Tensor, score_pos: torch.Tensor, y_out: np.ndarray, t_upto: int, ret_win_size: int,
+    def decode(self, h: torch.Tensor, score_pos: torch.Tensor, y_out: Optional[np.ndarray], t_upto: int, ret_win_size: int,
                use_hungarian: bool = False) -> Tuple[torch.Tensor, torch.Tensor]:
         """reference decode_tracks (utils/graph.py:392-539): re-derive the associations from the scores, finalise
-        tracks up to t_upto into y_out (host array [ND, 2], updated in place) and delete the decoded part of the
-        graph.  The hidden state `h` [N, G*H] and the scores are compacted ON THE DEVICE; returns (h', score_pos')."""
+        tracks up to t_upto and delete the decoded part of the graph -- all on the device (tmpnn_track_associate,
+        tmpnn_track_finalize, tmpnn_track_delete, tmpnn_track_gather); ONE host read: the number of kept rows.  The
+        finalised tracks live in `self.y_track` (fetch them with tracks() when the sequence is done); pass a host array
+        `y_out` [ND, 2] only where it must be current after every call (tests): it costs a device -> host copy.
+        Returns the compacted (h', score_pos')."""
         N = self.N
         sp = score_pos.detach().reshape(-1).float().contiguous()
         r = self.rows
         self._associate(sp, 'test', use_hungarian)
-        # ---- host: which detections join which track (a walk along the association links)
-        ts = r['ts'][:N].cpu().numpy()
-        did = r['det_id'][:N].cpu().numpy()
-        assoc = r['assoc'][:N].cpu().numpy()
-        sc = sp[:N].cpu().numpy()
-        row_of = {int(d): i for i, d in enumerate(did) if d >= 0}
-        next_track = int(y_out[:, 1].max()) + 1
-        seen = np.zeros(y_out.shape[0], bool)
-        for det in range(y_out.shape[0]):
-            row = row_of.get(det)
-            if row is None or ts[row] >= t_upto or sc[row] < 0.5 or seen[det]:
-                seen[det] = seen[det] or row is None or ts[row] >= t_upto or sc[row] < 0.5
-                continue
-            if y_out[det, 1] == -1:
-                track, next_track = next_track, next_track + 1
-            else:
-                track = int(y_out[det, 1])
-            d = det
-            while True:
-                seen[d] = True
-                y_out[d, 1] = track
-                nxt = int(assoc[row_of[d]])
-                if nxt == -1 or (y_out[d, 0] >= t_upto and y_out[nxt, 0] >= t_upto):
-                    break
-                d = nxt
+        if not self._time_sorted:
+            raise ValueError('TrackGraph.decode: the detections of the sequence must be listed in time order '
+                             '(dataset/kitti_mot.py lists them frame by frame)')
+        ND = int(self.y_track.numel())
+        wsb = int(_lib.load().tmpnn_track_finalize_ws(N))
+        if wsb and (self._fin_ws is None or self._fin_ws.numel() * 4 < wsb):
+            self._fin_ws = torch.empty((wsb // 4 + 1,), dtype=torch.int32, device=self.device)
+        _lib.call('tmpnn_track_finalize', self.graph.cref(), r['ts'].data_ptr(), r['det_id'].data_ptr(), r['assoc'].data_ptr(),
+                  sp.data_ptr(), int(t_upto), self.y_track.data_ptr(), ND, self._pos_of_det.data_ptr(),
+                  _lib.ptr(self._fin_ws) if wsb else None, wsb, _stream())
+        if y_out is not None:
+            y_out[:, 1] = self.y_track[:y_out.shape[0]].cpu().numpy()
         # ---- device: deletion as a stream compaction of rows, state and scores
         o = self._rows[1 - self._cur]
         _lib.call('tmpnn_track_delete', N, r['ts'].data_ptr(), r['det_id'].data_ptr(), r['assoc'].data_ptr(),
