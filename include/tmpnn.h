@@ -458,7 +458,8 @@ int tmpnn_track_append(int N, int A, int D, const int32_t* active, const int32_t
                        int32_t* ts, int32_t* det_id, int32_t* assoc, uint8_t* is_edge, int32_t* row_src,
                        int32_t* row_dst, uint8_t* labels, tmpnn_stream stream);
 /* The rows decode_tracks deletes (utils/graph.py:492-512) as a stream compaction: keep[] = kept rows (ascending),
- * count[0] = their number, o_* = the compacted row form with renumbered endpoints. */
+ * count[0] = their number, count[2] = how many of them are det rows (count: >= 3 ints), o_* = the compacted row form with
+ * renumbered endpoints. */
 int tmpnn_track_delete(int N, const int32_t* ts, const int32_t* det_id, const int32_t* assoc, const float* score,
                        const uint8_t* is_edge, const int32_t* row_src, const int32_t* row_dst, const uint8_t* labels,
                        int t_upto, int ret_win, int32_t* keep, int32_t* count, int32_t* o_ts, int32_t* o_det_id,

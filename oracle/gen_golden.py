@@ -216,6 +216,70 @@ def run_loss_fixture(name, out_dir, seed, T=5, dmean=4):
 
 
 
+def run_train_chunk_fixture(name, out_dir, seed, H=64, sequence=None, T=6, dmean=4):
+    """One training chunk of train.py:54-135 on the real reference: initialize_graph / update_graph(mode='train'), the
+    model in train mode with the hidden state carried, create_targets + CELoss + FocalLoss (node and edge, the default
+    --tp-classifier) after every forward, ONE backward of loss_c + loss_f.  Stored: the sequence, the parameters, the
+    loss terms of every call, the total and every parameter gradient (and the BatchNorm buffers after the chunk)."""
+    from models.loss import CELoss, FocalLoss, create_targets
+    from models.track_mpnn import TrackMPNN
+    from utils.graph import initialize_graph, update_graph
+
+    torch.manual_seed(5)
+    model = TrackMPNN('2d', 3, H, 0, 'diff')
+    gp = torch.Generator().manual_seed(seed + 77)
+    with torch.no_grad():
+        for k, prm in model.named_parameters():
+            prm.add_(0.1 * torch.randn(prm.shape, generator=gp))
+            if k.startswith('output_transform') and k.endswith('bias'):
+                prm.copy_(0.5 * torch.randn(prm.shape, generator=gp))    # scores on both sides of 0.5
+    model.train()
+    out = {}
+    for k, v in model.state_dict().items():
+        out['param/' + k] = v.detach().numpy().copy()
+    X, y = sequence if sequence is not None else synth_sequence(seed, T, dmean, 3, '2d', fp_rate=0.25)
+    out['X'] = X.numpy().copy()
+    out['y'] = y.numpy().copy()
+    ce_loss, focal_node, focal_edge = CELoss(), FocalLoss(gamma=0), FocalLoss(gamma=0)
+
+    def terms(scores, logits, labels, node_adj, y_pred):
+        idx_edge = torch.nonzero((y_pred[:, 0] == -1))[:, 0]
+        idx_node = torch.nonzero((y_pred[:, 0] != -1))[:, 0]
+        targets = create_targets(labels, node_adj, idx_node)
+        lc = ce_loss(logits, targets, node_adj, idx_node)
+        lf = focal_node(scores[idx_node, 0], targets[idx_node]) + focal_edge(scores[idx_edge, 0], targets[idx_edge])
+        return lc, lf
+
+    y_pred, feats, node_adj, edge_adj, labels, t_st, t_end = initialize_graph(X, y, 0, 'train', cuda=False)
+    scores, logits, states, _ = model(feats, None, node_adj, edge_adj)
+    loss_c, loss_f = terms(scores, logits, labels, node_adj, y_pred)
+    per_call = [(float(loss_c), float(loss_f), int(logits.shape[0]))]
+    for t_cur in range(t_st, t_end):
+        scores2 = torch.cat((1 - scores, scores), dim=1)
+        y_pred, feats, node_adj, edge_adj, labels = update_graph(node_adj, labels, scores2, y_pred, X, y, t_cur,
+                                                                 use_hungraian=False, mode='train', cuda=False)
+        scores, logits, states, _ = model(feats, states, node_adj, edge_adj)
+        lc, lf = terms(scores, logits, labels, node_adj, y_pred)
+        loss_c, loss_f = loss_c + lc, loss_f + lf
+        per_call.append((float(lc), float(lf), int(logits.shape[0])))
+    loss = loss_c + loss_f
+    loss.backward()
+    out['loss_c'] = np.float64(loss_c.item())
+    out['loss_f'] = np.float64(loss_f.item())
+    out['per_call'] = np.asarray(per_call, dtype=np.float64)
+    for k, prm in model.named_parameters():
+        out['grad/' + k] = prm.grad.numpy().copy()
+    for k, b in model.named_buffers():
+        out['buf_after/' + k] = b.detach().numpy().copy()
+    meta = dict(name=name, kind='train_chunk', features='2d', ncategories=3, nhidden=H, nattheads=0, msg_type='diff',
+                ncalls=len(per_call), seed=seed, torch=torch.__version__, reference='arangesh/TrackMPNN train.py:54-135 chunk')
+    out['meta'] = np.array(json.dumps(meta))
+    path = os.path.join(out_dir, name + '.npz')
+    np.savez_compressed(path, **out)
+    print(f'{name}: calls={len(per_call)} N_final={per_call[-1][2]} loss_c={loss_c.item():.4f} loss_f={loss_f.item():.4f} '
+          f'-> {os.path.getsize(path) / 1024:.0f} KiB')
+
+
 def window_sequence(seed, frames, mean_dets, max_dets, ncat):
     """One KITTI/BDD-shaped chunk of the bench generator: y from trackmpnn_amd.graph.synth_window
     (a pure numpy function: track survival 0.9, 10 % false positives, 20 % missed detections), X ~ N(0, 1)."""
@@ -232,7 +296,8 @@ def node_adj_diag_zero(na):
     return torch.diagonal(d) == 0
 
 
-def run_infer_fixture(name, out_dir, seed, T, dmean, cur_win, ret_win, hungarian, H=32, K=0, msg='diff', light=False):
+def run_infer_fixture(name, out_dir, seed, T, dmean, cur_win, ret_win, hungarian, H=32, K=0, msg='diff', light=False,
+                      gap=None):
     """The inference loop of infer.py:48-87 on the real reference: eval-mode model, update_graph(mode='test'),
     decode_tracks(cuda=False) with its row deletion between calls.  Every forward call is stored with ITS inputs
     (x, the row-deleted carried state, the adjacency pair as produced) and outputs; every decode step with the rows
@@ -261,10 +326,16 @@ def run_infer_fixture(name, out_dir, seed, T, dmean, cur_win, ret_win, hungarian
         for k, v in model.state_dict().items():
             out['param/' + k] = v.detach().numpy().copy()
     X, y = synth_sequence(seed, T, dmean, 3, '2d', fp_rate=0.2)
+    if gap is not None:
+        # no detections at timesteps gap[0] .. gap[1] - 1: the rolling window runs empty and infer.py:62-68 starts the
+        # graph again from the next two non-empty timesteps
+        keep_det = (y[0, :, 0] < gap[0]) | (y[0, :, 0] >= gap[1])
+        X, y = X[:, keep_det], y[:, keep_det]
     out['X'] = X.numpy().copy()
     out['y'] = y.numpy().copy()
     y_out = y.squeeze(0).numpy().astype('int64').copy()
     y_out[:, 1] = -1
+    n_reinit = 0
 
     def record_call(c, x, h_in, na, ea, scores, logits, h, y_pred):
         pre = f'c{c}/'
@@ -305,6 +376,7 @@ def run_infer_fixture(name, out_dir, seed, T, dmean, cur_win, ret_win, hungarian
                 if y_pred is None:
                     break
                 states = None
+                n_reinit += 1
             else:
                 y_pred, feats, node_adj, edge_adj, labels = update_graph(
                     node_adj, labels, scores, y_pred, X, y, t_cur, use_hungraian=hungarian, mode='test', cuda=False)
@@ -339,7 +411,8 @@ def run_infer_fixture(name, out_dir, seed, T, dmean, cur_win, ret_win, hungarian
     frac_pos = float(np.mean(np.concatenate([out[f'c{i}/scores'].ravel() for i in range(ncalls)]) >= 0.5))
     meta = dict(name=name, kind='infer_light' if light else 'infer', features='2d', ncategories=3, nhidden=H, nattheads=K, msg_type=msg, mode='eval',
                 ncalls=ncalls, seed=seed, T=T, cur_win_size=cur_win, ret_win_size=ret_win, hungarian=bool(hungarian),
-                rows_deleted=n_del, torch=torch.__version__, reference='arangesh/TrackMPNN infer.py:48-87 loop')
+                rows_deleted=n_del, reinitialisations=n_reinit, torch=torch.__version__,
+                reference='arangesh/TrackMPNN infer.py:48-87 loop')
     out['meta'] = np.array(json.dumps(meta))
     path = os.path.join(out_dir, name + '.npz')
     np.savez_compressed(path, **out)
@@ -378,11 +451,20 @@ def main():
     ap.add_argument('--reference-path', default='/root/reference')
     ap.add_argument('--out', default=os.path.join(os.path.dirname(HERE), 'tests', 'golden'))
     ap.add_argument('--only-new', action='store_true', help='skip the round-1 fixtures (debugging aid)')
+    ap.add_argument('--only', default='', help='generate only the fixture of this name (round-3 additions)')
     args = ap.parse_args()
     sys.dont_write_bytecode = True
     sys.path.insert(0, args.reference_path)
     os.makedirs(args.out, exist_ok=True)
     torch.set_num_threads(1)
+    if args.only.startswith('chunk_'):
+        run_train_chunk_fixture('chunk_c2_kitti_car_w5', args.out, 800, H=64, sequence=window_sequence(1001, 7, 6.0, 20, 3))
+        run_train_chunk_fixture('chunk_small_h32', args.out, 801, H=32)
+        return
+    if args.only == 'infer_greedy_w3_r0_reinit':
+        run_infer_fixture('infer_greedy_w3_r0_reinit', args.out, 503, T=14, dmean=4, cur_win=3, ret_win=0, hungarian=False,
+                          gap=(5, 10))
+        return
     seed = 0
     for feats, ncat in (('2d', 3), ('2d+temp+vis', 3)):
         for msg in ('diff', 'concat'):
@@ -422,6 +504,13 @@ def main():
     run_fixture('roll_2d-temp_concat_k2_eval_h20', args.out, '2d+temp', 3, 20, 2, 'concat', 'eval', 601)
     # a dense scene (~70 dets per frame): inference graphs beyond 4096 rows, graph maintenance only (light)
     run_infer_fixture('dense_infer_greedy_w3_r1', args.out, 700, T=6, dmean=70, cur_win=3, ret_win=1, hungarian=False, light=True)
+    # round 3: whole training chunks (train.py:54-135 with the reference's own targets and losses)
+    run_train_chunk_fixture('chunk_c2_kitti_car_w5', args.out, 800, H=64, sequence=window_sequence(1001, 7, 6.0, 20, 3))
+    run_train_chunk_fixture('chunk_small_h32', args.out, 801, H=32)
+    # round 3: a sequence with five empty timesteps in the middle -- the window runs empty and the loop takes the
+    # re-initialisation branch (infer.py:62-68)
+    run_infer_fixture('infer_greedy_w3_r0_reinit', args.out, 503, T=14, dmean=4, cur_win=3, ret_win=0, hungarian=False,
+                      gap=(5, 10))
 
 
 def run_c1(out_dir):

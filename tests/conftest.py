@@ -14,7 +14,7 @@ def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
 
 
-_OTHER_KINDS = ('loss_', 'infer_', 'init_', 'dense_')
+_OTHER_KINDS = ('loss_', 'infer_', 'init_', 'dense_', 'chunk_')
 
 
 def golden_names():
@@ -30,6 +30,11 @@ def infer_golden_names():
 def loss_golden_names():
     """targets / loss fixtures (reference models/loss.py)"""
     return sorted(f[:-4] for f in os.listdir(GOLDEN_DIR) if f.endswith('.npz') and f.startswith('loss_'))
+
+
+def chunk_golden_names():
+    """whole training chunks (reference train.py:54-135 with models/loss.py's targets and losses)"""
+    return sorted(f[:-4] for f in os.listdir(GOLDEN_DIR) if f.endswith('.npz') and f.startswith('chunk_'))
 
 
 @pytest.fixture(scope='session')

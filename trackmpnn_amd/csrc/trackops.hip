@@ -192,9 +192,9 @@ __global__ __launch_bounds__(TK_THREADS) void k_track_delete(int N, const int32_
                                                              uint8_t* __restrict__ o_labels) {
     extern __shared__ int s_new[];                         // [N] new index of a kept row, -1 if deleted
     __shared__ int s_wave[TK_THREADS / 64 + 1];
-    __shared__ int s_max;
+    __shared__ int s_max, s_dets;
     const int tid = threadIdx.x;
-    if (tid == 0) s_max = 0;
+    if (tid == 0) { s_max = 0; s_dets = 0; }
     __syncthreads();
     int m = 0;
     for (int r = tid; r < N; r += TK_THREADS) { const int v = ts[r]; if (v != -1 && v < t_upto) m = max(m, r + 1); }
@@ -212,8 +212,13 @@ __global__ __launch_bounds__(TK_THREADS) void k_track_delete(int N, const int32_
     };
     const int IT = (N + TK_THREADS - 1) / TK_THREADS;
     const int r0 = tid * IT, r1 = min(N, r0 + IT);
-    int mine = 0;
-    for (int r = r0; r < r1; ++r) mine += kept(r) ? 1 : 0;
+    int mine = 0, mine_dets = 0;
+    for (int r = r0; r < r1; ++r) {
+        const bool k = kept(r);
+        mine += k ? 1 : 0;
+        mine_dets += (k && !is_edge[r]) ? 1 : 0;
+    }
+    if (mine_dets) atomicAdd(&s_dets, mine_dets);
     int total;
     int p = tk_block_scan(mine, s_wave, &total);
     for (int r = r0; r < r1; ++r) {
@@ -229,7 +234,7 @@ __global__ __launch_bounds__(TK_THREADS) void k_track_delete(int N, const int32_
         if (is_edge[r]) { o_src[q] = s_new[row_src[r]]; o_dst[q] = s_new[row_dst[r]]; }
         else { o_src[q] = -1; o_dst[q] = -1; }
     }
-    if (tid == 0) count[0] = total;
+    if (tid == 0) { count[0] = total; count[2] = s_dets; }        // kept rows; kept DET rows (the host's E / Dn bookkeeping)
 }
 
 // out[q, :] = in[keep[q], :] for q < count (count read on the device: the launch is sized for the worst case)

@@ -1,0 +1,161 @@
+"""The reference's two per-timestep loops, composed from the device-resident pieces.
+
+    train_chunk     reference/train.py:54-135   one tracking chunk: initialize_graph -> model -> targets + CE + focal
+                                                losses, then per timestep update_graph(mode='train') -> model -> losses
+                                                (hidden state carried, BPTT), ONE backward for the chunk
+    infer_sequence  reference/infer.py:35-87    one sequence: per timestep update_graph(mode='test', greedy or Hungarian)
+                                                -> model -> decode_tracks (track finalisation + rolling-window deletion)
+
+Same order of operations, same arguments' meaning and the same results as the reference's drivers (which cannot be imported:
+they parse the command line at import) -- but the graph, the hidden state, the losses' inputs and the tracks stay
+in HBM: `TrackGraph` (tracking.py), the batch-1 model path (`TrackMPNN.forward_dgraph`) and the HIP losses (loss.py).  The
+drivers' logging (F1 per forward, prints) is not part of the loop here or in the timings it is compared with.
+
+`stages`, when given, is a dict that accumulates wall time per stage with a device synchronisation around each stage
+(an instrumented pass: its total is larger than an un-instrumented one).
+"""
+from __future__ import annotations
+
+import time
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+
+from .loss import CELoss, FocalLoss, create_targets
+from .tracking import TrackGraph
+
+
+class _Stages:
+    def __init__(self, acc: Optional[Dict[str, float]]):
+        self.acc = acc
+        self.t = 0.0
+
+    def start(self):
+        if self.acc is not None:
+            torch.cuda.synchronize()
+            self.t = time.perf_counter()
+
+    def stop(self, name: str):
+        if self.acc is not None:
+            torch.cuda.synchronize()
+            now = time.perf_counter()
+            self.acc[name] = self.acc.get(name, 0.0) + (now - self.t)
+            self.t = now
+
+
+def _loss_terms(tg: TrackGraph, scores, logits, ce, focal_node, focal_edge, tp_classifier: bool):
+    """train.py:70-81 / :109-120 for one forward call."""
+    g = tg.graph
+    labels = tg.labels()
+    targets = create_targets(labels, g)
+    loss_c = ce(logits, targets, g)
+    fg = g.frame_graph()
+    idx_edge = fg.edge_row.long()
+    loss_f = focal_edge(scores[idx_edge, 0], targets[idx_edge])
+    if tp_classifier:
+        idx_node = fg.det_row.long()
+        loss_f = focal_node(scores[idx_node, 0], targets[idx_node]) + loss_f
+    return loss_c, loss_f
+
+
+def train_chunk(model, X: torch.Tensor, y: torch.Tensor, device='cuda:0', tp_classifier: bool = True,
+                stages: Optional[Dict[str, float]] = None):
+    """One chunk of train.py:54-135 up to and including loss.backward().  X [1, ND, F], y [1, ND, 2] (host or device).
+    Returns (loss, number of forward calls, sum of E over them) or None where the reference skips the chunk."""
+    st = _Stages(stages)
+    ce, focal_node, focal_edge = CELoss(), FocalLoss(gamma=0, alpha=None), FocalLoss(gamma=0, alpha=None)
+    st.start()
+    init = TrackGraph.initialize(X, y, 0, 'train', device)
+    if init is None:
+        return None
+    tg, feats, t_st, t_end = init
+    st.stop('graph')
+    scores, logits, h, _ = model.forward_dgraph(feats, None, tg.graph)
+    st.stop('model_fwd')
+    loss_c, loss_f = _loss_terms(tg, scores, logits, ce, focal_node, focal_edge, tp_classifier)
+    st.stop('targets_losses')
+    ncalls, edge_iters = 1, tg.E
+    t_skip = t_st
+    for t_cur in range(t_st, t_end):
+        if t_cur < t_skip:
+            continue
+        if feats.shape[0] == 0 and h.shape[0] == 0:            # train.py:95-100: nothing carried over -> start again
+            init = TrackGraph.initialize(X, y, t_cur, 'train', device)
+            if init is None:
+                break
+            tg, feats, t_skip, _ = init
+            h = None
+        else:
+            feats = tg.update(None, X, y, t_cur, mode='train')
+        st.stop('graph')
+        scores, logits, h, _ = model.forward_dgraph(feats, h, tg.graph)
+        st.stop('model_fwd')
+        lc, lf = _loss_terms(tg, scores, logits, ce, focal_node, focal_edge, tp_classifier)
+        loss_c, loss_f = loss_c + lc, loss_f + lf
+        st.stop('targets_losses')
+        ncalls += 1
+        edge_iters += tg.E
+    loss = loss_c + loss_f
+    loss.backward()
+    st.stop('backward')
+    return loss, ncalls, edge_iters
+
+
+def infer_sequence(model, X: torch.Tensor, y: torch.Tensor, cur_win_size: int = 5, ret_win_size: int = 0,
+                   use_hungarian: bool = False, device='cuda:0', tp_classifier: bool = True,
+                   stages: Optional[Dict[str, float]] = None):
+    """One sequence of infer.py:35-87 (model in eval mode).  Returns (y_out [ND, 2] int64 as the reference keeps it, number
+    of forward calls, sum of E over them)."""
+    st = _Stages(stages)
+    yy = y[0].detach().cpu().numpy().astype('int64')
+    y_out = yy.copy()
+    y_out[:, 1] = -1
+    with torch.no_grad():
+        st.start()
+        init = TrackGraph.initialize(X, y, 0, 'test', device)
+        if init is None:
+            return y_out, 0, 0
+        tg, feats, t_st, t_end = init
+        st.stop('graph')
+        scores, logits, h, _ = model.forward_dgraph(feats, None, tg.graph)
+        sc = _pos_score(tg, scores, tp_classifier)
+        st.stop('model_fwd')
+        ncalls, edge_iters = 1, tg.E
+        done = []                                              # TrackGraphs abandoned by a re-initialisation
+        t_skip = t_st
+        for t_cur in range(t_st, t_end):
+            if t_cur < t_skip:
+                continue
+            if feats.shape[0] == 0 and h.shape[0] == 0:        # infer.py:62-68: the graph emptied -> initialise again
+                init = TrackGraph.initialize(X, y, t_cur, 'test', device)
+                if init is None:
+                    break
+                done.append(tg)
+                prev = tg
+                tg, feats, t_skip, _ = init
+                tg.y_track.copy_(prev.y_track)                 # (the tracks finalised so far belong to the sequence)
+                h = None
+            else:
+                feats = tg.update(sc, X, y, t_cur, mode='test', use_hungarian=use_hungarian)
+            st.stop('graph')
+            scores, logits, h, _ = model.forward_dgraph(feats, h, tg.graph)
+            sc = _pos_score(tg, scores, tp_classifier)
+            st.stop('model_fwd')
+            ncalls += 1
+            edge_iters += tg.E
+            t_upto = t_end if t_cur == t_end - 1 else t_cur - cur_win_size + 2
+            h, sc = tg.decode(h, sc, None, t_upto, ret_win_size, use_hungarian=use_hungarian)
+            st.stop('decode')
+        y_out[:, 1] = tg.tracks()[:y_out.shape[0]]
+        st.stop('decode')
+    return y_out, ncalls, edge_iters
+
+
+def _pos_score(tg: TrackGraph, scores: torch.Tensor, tp_classifier: bool) -> torch.Tensor:
+    """P(positive) per row; without the TP classifier every detection counts as a true positive (infer.py:53-56)."""
+    sc = scores[:, 0]
+    if not tp_classifier:
+        sc = sc.clone()
+        sc[tg.graph.frame_graph().det_row.long()] = 1.0
+    return sc

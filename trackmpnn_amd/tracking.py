@@ -49,6 +49,8 @@ class TrackGraph:
                            is_edge=torch.empty(cap, **u8), src=torch.empty(cap, **i32), dst=torch.empty(cap, **i32),
                            labels=torch.empty(cap, **u8)) for _ in range(2)]
         self._cur = 0
+        self.E = 0
+        self.Dn = 0
         self._active = torch.empty(cap, **i32)
         self._keep = torch.empty(cap, **i32)
         self._small = torch.zeros(4, **i32)              # [0] count, [1] status
@@ -86,6 +88,9 @@ class TrackGraph:
             _lib.call('tmpnn_graph_from_rows_ws', self.N, r['is_edge'].data_ptr(), r['src'].data_ptr(), r['dst'].data_ptr(),
                       g.cref(), ws.data_ptr(), ws.numel(), _stream())
             g._keep = (ws,)
+        # the host knows E and Dn of its own graph (initial block, appended blocks, the delete kernel's counts): nothing
+        # downstream (staged kernels, losses) has to read them back; graphs built by these kernels are valid by construction
+        g._meta = (self.E, self.Dn, 0)
         self.graph = g
 
     # ---------------------------------------------------------------------------------------------------------------
@@ -124,7 +129,7 @@ class TrackGraph:
             raise AssertionError('More than one detection from same timestep assinged to same track!')
         lab[n0:n0 + n0 * n1] = same.reshape(-1)
         tg = cls(device)
-        tg.N = N
+        tg.N, tg.E, tg.Dn = N, n0 * n1, n0 + n1
         r = tg.rows
         for key, arr in (('ts', ts), ('det_id', did), ('is_edge', is_edge), ('src', src), ('dst', dst), ('labels', lab)):
             r[key][:N].copy_(torch.from_numpy(arr))
@@ -236,7 +241,7 @@ class TrackGraph:
                   self.track.data_ptr() if self.track is not None else None,
                   r['ts'].data_ptr(), r['det_id'].data_ptr(), r['assoc'].data_ptr(), r['is_edge'].data_ptr(),
                   r['src'].data_ptr(), r['dst'].data_ptr(), r['labels'].data_ptr(), _stream())
-        self.N = N + n_new
+        self.N, self.E, self.Dn = N + n_new, self.E + A * D, self.Dn + D
         self._rebuild()
         feats = torch.zeros((n_new, Xd.shape[1]), dtype=Xd.dtype, device=self.device)
         feats[A * D:] = Xd[ids_dev.long()]
@@ -283,9 +288,9 @@ class TrackGraph:
                   h_new.data_ptr(), W, _stream())
         _lib.call('tmpnn_track_gather', sp.data_ptr(), 1, 1, N, self._keep.data_ptr(), self._small.data_ptr(),
                   s_new.data_ptr(), 1, _stream())
-        n_keep = int(self._small[0].item())
+        n_keep, _, n_det = self._small[:3].tolist()        # the ONE host read of a decode: kept rows (and how many are dets)
         self._cur = 1 - self._cur
-        self.N = n_keep
+        self.N, self.E, self.Dn = n_keep, n_keep - n_det, n_det
         self._rebuild()
         return h_new[:n_keep], s_new[:n_keep, 0]
 
