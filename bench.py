@@ -355,6 +355,94 @@ def latency_batch1():
     return out
 
 
+LOOP_SHAPES = {'C2': dict(frames=7, mean=6.0, mx=20, ncat=3, win=5), 'C3': dict(frames=12, mean=8.0, mx=25, ncat=3, win=10),
+               'C4': dict(frames=7, mean=12.0, mx=40, ncat=8, win=5)}
+LOOP_INFER_FRAMES = 40
+
+
+def loop_batch1(budget_s=1.5):
+    """The reference's two REAL per-timestep loops, end to end at batch 1 (SURVEY 8(f) rows 1-3 composed,
+    trackmpnn_amd/loops.py), on the synthetic sequences oracle/time_reference_loops.py times the real reference on
+    (BASELINE.md has those numbers; the reference cannot run on the GPU box):
+      train chunk (train.py:54-135): initialize_graph, then per timestep update_graph(mode='train') -> model ->
+        create_targets + CELoss + FocalLoss; one backward + Adam step -- C2 / C3 / C4-shaped chunks;
+      inference (infer.py:35-87): update_graph(mode='test') -> model -> decode_tracks over a 40-frame sequence, greedy
+        and Hungarian association.
+    Per case: the un-instrumented wall time and, from a second pass with a device synchronisation around every stage,
+    where it goes (graph maintenance / model forward / targets + losses / backward + optimizer / decode)."""
+    from trackmpnn_amd import TrackMPNN
+    from trackmpnn_amd.graph import synth_window
+    from trackmpnn_amd.loops import infer_sequence, train_chunk
+    dev = torch.device('cuda', torch.cuda.current_device())
+
+    def sequence(seed, frames, mean, mx, ncat):
+        yy = synth_window(seed, frames, mean, mx)
+        y = torch.from_numpy(yy)[None]
+        X = torch.randn(1, yy.shape[0], ncat + 5, generator=torch.Generator().manual_seed(seed + 1000))
+        return X, y
+
+    def perturb(model, seed):        # scores on both sides of 0.5; the same code as oracle/time_reference_loops.py
+        gp = torch.Generator().manual_seed(seed)
+        with torch.no_grad():
+            for k, prm in model.named_parameters():
+                prm.add_(0.1 * torch.randn(prm.shape, generator=gp))
+                if k.startswith('output_transform') and k.endswith('bias'):
+                    prm.copy_(0.5 * torch.randn(prm.shape, generator=gp))
+
+    def timed(fn):
+        for _ in range(3):
+            r = fn()
+        torch.cuda.synchronize()
+        n, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < budget_s or n < 3:
+            r = fn()
+            n += 1
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / n * 1e3, r
+
+    out = dict(train={}, infer={})
+    for tag, s in LOOP_SHAPES.items():
+        torch.manual_seed(5)
+        model = TrackMPNN('2d', s['ncat'], 64, 0, 'diff')
+        perturb(model, 4242)
+        model = model.to(dev)
+        X, y = sequence(1001, s['frames'], s['mean'], s['mx'], s['ncat'])
+        Xi, yi = sequence(2001, LOOP_INFER_FRAMES, s['mean'], s['mx'], s['ncat'])
+        model.train()
+        opt = torch.optim.Adam(model.parameters(), lr=1e-4, weight_decay=5e-4)
+
+        def chunk(stages=None):
+            opt.zero_grad(set_to_none=True)
+            r = train_chunk(model, X, y, dev, stages=stages)
+            if stages is not None:
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+            opt.step()
+            if stages is not None:
+                torch.cuda.synchronize()
+                stages['optimizer'] = stages.get('optimizer', 0.0) + time.perf_counter() - t1
+            return r
+
+        ms, (loss, ncalls, edges) = timed(chunk)
+        st = {}
+        chunk(st)
+        out['train'][tag] = dict(ms_per_chunk=round(ms, 3), calls=ncalls, edge_iterations=edges, edges_per_s=round(edges / ms * 1e3),
+                                 stages_ms={k: round(v * 1e3, 3) for k, v in st.items()})
+        model.eval()
+        for hung in (False, True):
+            ms, (y_out, ncalls, edges) = timed(lambda: infer_sequence(model, Xi, yi, s['win'], 0, hung, dev))
+            st = {}
+            infer_sequence(model, Xi, yi, s['win'], 0, hung, dev, stages=st)
+            out['infer'][f"{tag}/{'hungarian' if hung else 'greedy'}"] = dict(
+                ms_per_sequence=round(ms, 3), frames=LOOP_INFER_FRAMES, ms_per_timestep=round(ms / LOOP_INFER_FRAMES, 4),
+                calls=ncalls, edge_iterations=edges, tracks=int(y_out[:, 1].max()) + 1,
+                stages_ms={k: round(v * 1e3, 3) for k, v in st.items()})
+    out['note'] = ('batch 1, fp32, one process; ms_* = un-instrumented wall time incl. every host read; stages_ms = a second, '
+                   'instrumented pass (device sync around each stage: its sum exceeds the wall time).  The real reference on '
+                   'the same sequences: BASELINE.md section 5 (build-container CPU; it cannot travel to this box)')
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -364,6 +452,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-stage-profile', action='store_true')
     ap.add_argument('--no-latency', action='store_true', help='skip the batch-1 latency block')
+    ap.add_argument('--no-loops', action='store_true', help='skip the loop_batch1 block (train chunk / inference loop)')
     ap.add_argument('--backend', default='nccl', help='torch.distributed backend (nccl = RCCL; gloo only to rehearse '
                     'the N > 1 code path with several ranks sharing one GPU)')
     ap.add_argument('--single-device', action='store_true', help='rehearsal: every rank uses cuda:0')
@@ -525,6 +614,7 @@ def main():
                    roofline=roofline, cpu_baseline=cpu)
         out.update(extra)
         out['latency_batch1'] = lat
+        out['loop_batch1'] = loop_batch1() if (world == 1 and not args.no_loops) else None
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -178,37 +178,37 @@ class TrackGraph:
 
     def _hungarian(self, score_pos: torch.Tensor) -> None:
         """Frame-by-frame optimal assignment (reference hungarian(), utils/graph.py:33-93) on the host: a few dozen
-        detections, scipy's linear_sum_assignment; cost of an association = P(edge is negative) = 1 - score."""
+        detections per frame, scipy's linear_sum_assignment; cost of an association = P(edge is negative) = 1 - score.
+        ONE device -> host copy (row form + edge list + scores, packed) and one copy back; the cost blocks are filled
+        with array indexing, no per-edge Python."""
         from scipy.optimize import linear_sum_assignment
         g = self.graph.frame_graph()
-        N = self.N
+        N, E = self.N, self.E
         r = self.rows
-        ts = r['ts'][:N].cpu().numpy()
-        did = r['det_id'][:N].cpu().numpy()
-        sc = score_pos[:N].detach().float().cpu().numpy()
-        src, dst, erow = g.src.cpu().numpy(), g.dst.cpu().numpy(), g.edge_row.cpu().numpy()
+        packed = torch.cat([r['ts'][:N], r['det_id'][:N], g.src[:E], g.dst[:E], g.edge_row[:E],
+                            score_pos[:N].detach().float().contiguous().view(torch.int32)]).cpu().numpy()
+        ts, did = packed[:N], packed[N:2 * N]
+        src, dst, erow = packed[2 * N:2 * N + E], packed[2 * N + E:2 * N + 2 * E], packed[2 * N + 2 * E:2 * N + 3 * E]
+        sc = packed[2 * N + 3 * E:].view(np.float32)
         assoc = np.full(N, -1, np.int32)
-        det_ts = ts[ts >= 0]
-        if det_ts.size:
-            for t in range(int(ts[0]), int(ts[N - 1]) + 1):
-                cur = np.nonzero(ts == t)[0]
-                if cur.size == 0:
+        if E:
+            e_t = ts[dst]                                          # timestep an edge leads into
+            e_cost = (1.0 - sc[erow]).astype(np.float32)
+            order = np.argsort(e_t, kind='stable')
+            bounds = np.flatnonzero(np.diff(e_t[order])) + 1
+            for grp in np.split(order, bounds):                    # ascending timestep, as the reference sweeps
+                s_g, d_g = src[grp], dst[grp]
+                free = assoc[s_g] == -1                            # associated earlier in this sweep: taken
+                if not free.any():
                     continue
-                into = np.isin(dst, cur)
-                prev = np.unique(src[into])
-                prev = prev[assoc[prev] == -1]                   # already associated earlier in this sweep: taken
-                if prev.size == 0 or not into.any():
-                    continue
+                s_g, d_g, c_g = s_g[free], d_g[free], e_cost[grp][free]
+                prev, pi = np.unique(s_g, return_inverse=True)
+                cur = np.flatnonzero(ts == e_t[grp[0]])            # EVERY det of the timestep is a column, as in the reference
                 cost = np.full((prev.size, cur.size), 100.0, np.float32)
-                pi = {int(p): i for i, p in enumerate(prev)}
-                ci = {int(c): j for j, c in enumerate(cur)}
-                for e in np.nonzero(into)[0]:
-                    i = pi.get(int(src[e]))
-                    if i is not None:
-                        cost[i, ci[int(dst[e])]] = 1.0 - sc[erow[e]]
-                for i, j in zip(*linear_sum_assignment(cost)):
-                    if cost[i, j] <= 0.5:
-                        assoc[prev[i]] = did[cur[j]]
+                cost[pi, np.searchsorted(cur, d_g)] = c_g
+                rows_i, cols_j = linear_sum_assignment(cost)
+                ok = cost[rows_i, cols_j] <= 0.5
+                assoc[prev[rows_i[ok]]] = did[cur[cols_j[ok]]]
         r['assoc'][:N].copy_(torch.from_numpy(assoc))
 
     def update(self, score_pos: Optional[torch.Tensor], X: torch.Tensor, y: torch.Tensor, t: int, mode: str = 'test',
