@@ -291,11 +291,19 @@ def check_heads(C, g, gd):
     return res
 
 
-def check_input_bn(H, F_, training, S=4):
+def check_input_bn(H, F_, training, S=4, fused=False):
+    """fused=False: the staged launches of tmpnn_input_bn_*; fused=True: tmpnn_input_tf_* (one launch per direction), with
+    enough segments that several workgroups and several chunks per workgroup take part."""
     torch.manual_seed(H + F_)
     # S segments, each with nd_s det rows and some zero rows
-    nds = [3, 1, 5, 2][:S]
-    cnts = [n + z for n, z in zip(nds, [6, 4, 0, 9][:S])]
+    if S == 4:
+        nds = [3, 1, 5, 2]
+        cnts = [n + z for n, z in zip(nds, [6, 4, 0, 9])]
+    else:
+        rs = np.random.RandomState(S)
+        nds = [int(v) for v in rs.randint(1, 40, S)]
+        cnts = [n + int(z) for n, z in zip(nds, rs.randint(0, 30, S))]
+        cnts = [max(c, 2) for c in cnts]
     nd = sum(nds)
     Ft = F_ + 3                                   # group columns embedded in a wider feature row
     xdet = torch.randn(nd, Ft)
@@ -334,12 +342,19 @@ def check_input_bn(H, F_, training, S=4):
     Nrows, ld = nd + 5, 2 * H
     out_row = torch.tensor(np.random.RandomState(0).permutation(Nrows)[:nd], dtype=torch.int32, device=DEV)
     h_new = torch.zeros(Nrows, ld, device=DEV)
-    seg_of_det = torch.repeat_interleave(torch.arange(S, dtype=torch.int32), torch.tensor(nds)).to(DEV) if H != 32 else None
-    _lib.call('tmpnn_input_bn_fwd', xD.data_ptr() + 4, Ft, F_, nd, seg_ptr.data_ptr(), seg_cnt.data_ptr(), _lib.ptr(seg_of_det), S, H,
-              int(training), P[t + '0.weight'].data_ptr(), P[t + '0.bias'].data_ptr(), P[t + '1.weight'].data_ptr(),
-              P[t + '1.bias'].data_ptr(), P[t + '1.running_mean'].data_ptr(), P[t + '1.running_var'].data_ptr(),
-              P[t + '3.weight'].data_ptr(), P[t + '3.bias'].data_ptr(), y_save.data_ptr(), mean.data_ptr(),
-              rstd.data_ptr(), ws_a.data_ptr(), out_row.data_ptr(), h_new.data_ptr() + 4 * H, ld, st())
+    seg_of_det = torch.repeat_interleave(torch.arange(S, dtype=torch.int32), torch.tensor(nds)).to(DEV) if (H != 32 or fused) else None
+    if fused:
+        _lib.call('tmpnn_input_tf_fwd', xD.data_ptr() + 4, Ft, F_, nd, seg_ptr.data_ptr(), seg_cnt.data_ptr(), _lib.ptr(seg_of_det), S,
+                  max(nds), H, int(training), P[t + '0.weight'].data_ptr(), P[t + '0.bias'].data_ptr(), P[t + '1.weight'].data_ptr(),
+                  P[t + '1.bias'].data_ptr(), P[t + '1.running_mean'].data_ptr(), P[t + '1.running_var'].data_ptr(),
+                  P[t + '3.weight'].data_ptr(), P[t + '3.bias'].data_ptr(), y_save.data_ptr(), mean.data_ptr(),
+                  rstd.data_ptr(), out_row.data_ptr(), h_new.data_ptr() + 4 * H, ld, st())
+    else:
+        _lib.call('tmpnn_input_bn_fwd', xD.data_ptr() + 4, Ft, F_, nd, seg_ptr.data_ptr(), seg_cnt.data_ptr(), _lib.ptr(seg_of_det), S, H,
+                  int(training), P[t + '0.weight'].data_ptr(), P[t + '0.bias'].data_ptr(), P[t + '1.weight'].data_ptr(),
+                  P[t + '1.bias'].data_ptr(), P[t + '1.running_mean'].data_ptr(), P[t + '1.running_var'].data_ptr(),
+                  P[t + '3.weight'].data_ptr(), P[t + '3.bias'].data_ptr(), y_save.data_ptr(), mean.data_ptr(),
+                  rstd.data_ptr(), ws_a.data_ptr(), out_row.data_ptr(), h_new.data_ptr() + 4 * H, ld, st())
     res = {}
     got = h_new.cpu()[out_row.long().cpu(), H:2 * H]
     res['fwd'] = (got - out[is_det].detach()).abs().max().item()
@@ -352,15 +367,26 @@ def check_input_bn(H, F_, training, S=4):
     grads = {k: torch.zeros_like(P[t + k]) for k in ('0.weight', '0.bias', '1.weight', '1.bias', '3.weight', '3.bias')}
     d_xdet = torch.zeros(nd, Ft, device=DEV)
     d_xzero = torch.zeros(S, F_, device=DEV)
-    wsn = _lib.load().tmpnn_input_bn_bwd_ws(nd, S, H, F_)
-    ws = torch.empty(wsn + 1, device=DEV)
-    _lib.call('tmpnn_input_bn_bwd', xD.data_ptr() + 4, Ft, F_, nd, seg_ptr.data_ptr(), seg_cnt.data_ptr(), _lib.ptr(seg_of_det), S, H,
-              int(training), P[t + '0.weight'].data_ptr(), P[t + '0.bias'].data_ptr(), P[t + '1.weight'].data_ptr(),
-              P[t + '1.bias'].data_ptr(), P[t + '3.weight'].data_ptr(), y_save.data_ptr(), mean.data_ptr(),
-              rstd.data_ptr(), out_row.data_ptr(), d_hD.data_ptr() + 4 * H, ld, d_xdet.data_ptr() + 4, Ft,
-              d_xzero.data_ptr(), grads['0.weight'].data_ptr(), grads['0.bias'].data_ptr(),
-              grads['1.weight'].data_ptr(), grads['1.bias'].data_ptr(), grads['3.weight'].data_ptr(),
-              grads['3.bias'].data_ptr(), ws.data_ptr(), wsn + 1, st())
+    if fused:
+        wsb = int(_lib.load().tmpnn_input_tf_bwd_ws(nd, S, H, F_, int(training)))
+        ws = torch.empty(wsb // 4 + 1, device=DEV)
+        _lib.call('tmpnn_input_tf_bwd', xD.data_ptr() + 4, Ft, F_, nd, seg_ptr.data_ptr(), seg_cnt.data_ptr(), _lib.ptr(seg_of_det), S,
+                  max(nds), H, int(training), P[t + '0.weight'].data_ptr(), P[t + '0.bias'].data_ptr(), P[t + '1.weight'].data_ptr(),
+                  P[t + '1.bias'].data_ptr(), P[t + '3.weight'].data_ptr(), y_save.data_ptr(), mean.data_ptr(),
+                  rstd.data_ptr(), out_row.data_ptr(), d_hD.data_ptr() + 4 * H, ld, d_xdet.data_ptr() + 4, Ft,
+                  d_xzero.data_ptr(), grads['0.weight'].data_ptr(), grads['0.bias'].data_ptr(),
+                  grads['1.weight'].data_ptr(), grads['1.bias'].data_ptr(), grads['3.weight'].data_ptr(),
+                  grads['3.bias'].data_ptr(), ws.data_ptr(), wsb, st())
+    else:
+        wsn = _lib.load().tmpnn_input_bn_bwd_ws(nd, S, H, F_)
+        ws = torch.empty(wsn + 1, device=DEV)
+        _lib.call('tmpnn_input_bn_bwd', xD.data_ptr() + 4, Ft, F_, nd, seg_ptr.data_ptr(), seg_cnt.data_ptr(), _lib.ptr(seg_of_det), S, H,
+                  int(training), P[t + '0.weight'].data_ptr(), P[t + '0.bias'].data_ptr(), P[t + '1.weight'].data_ptr(),
+                  P[t + '1.bias'].data_ptr(), P[t + '3.weight'].data_ptr(), y_save.data_ptr(), mean.data_ptr(),
+                  rstd.data_ptr(), out_row.data_ptr(), d_hD.data_ptr() + 4 * H, ld, d_xdet.data_ptr() + 4, Ft,
+                  d_xzero.data_ptr(), grads['0.weight'].data_ptr(), grads['0.bias'].data_ptr(),
+                  grads['1.weight'].data_ptr(), grads['1.bias'].data_ptr(), grads['3.weight'].data_ptr(),
+                  grads['3.bias'].data_ptr(), ws.data_ptr(), wsn + 1, st())
     gs = max(1.0, max(pg[t + k].grad.abs().max().item() for k in grads))
     for k in grads:
         res['d' + k] = (grads[k].cpu() - pg[t + k].grad).abs().max().item() / gs
@@ -645,6 +671,10 @@ def run_all(report=print):
         for training in (True, False):
             for k, v in check_input_bn(H, F_, training).items():
                 rec(f'input_bn H={H} F={F_} train={training} {k}', v, 2e-4)
+    for H, F_, S in ((64, 8, 4), (64, 8, 150), (32, 13, 70), (64, 128, 40), (32, 2, 4)):
+        for training in (True, False):
+            for k, v in check_input_bn(H, F_, training, S=S, fused=True).items():
+                rec(f'input_tf (one launch) H={H} F={F_} S={S} train={training} {k}', v, 2e-4)
     for H, K in ((64, 2), (32, 1), (128, 3)):
         for training in (False, True):
             for k, v in check_attention(H, K, training, g, gd).items():

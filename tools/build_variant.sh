@@ -7,7 +7,7 @@ tag=$1; f=$2; shift 2
 O=$ROOT/trackmpnn_amd/lib/obj
 /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -fPIC -std=c++17 -I$ROOT/include "$@" -c $ROOT/trackmpnn_amd/csrc/$f.hip -o $O/${f}_$tag.o
 objs=""
-for x in agg att dense graphconv gru loss small trackops wide; do
+for x in agg att dense graphconv gru intf loss small trackops wide; do
     if [ "$x" = "$f" ]; then objs="$objs $O/${f}_$tag.o"; else objs="$objs $O/$x.o"; fi
 done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -fPIC -shared -o $ROOT/trackmpnn_amd/lib/libtmpnn_$tag.so $objs

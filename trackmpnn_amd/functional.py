@@ -37,6 +37,9 @@ WIDE_TILED = os.environ.get('TMPNN_WIDE_TILED', '1') != '0'
 # H <= 64 edge cells: forward over 32-row edge tiles (projected det rows staged in LDS an item ahead); TMPNN_FWD_TILED=0
 # keeps the per-row gathers of tmpnn_gru_fwd (xmode 3)
 FWD_TILED = os.environ.get('TMPNN_FWD_TILED', '1') != '0' and os.environ.get('TMPNN_SPLIT', '1')[:1] != '0'
+# input transform in one launch per direction where every window adds few det rows (csrc/intf.hip); TMPNN_INPUT_TF=0 keeps
+# the staged launches of tmpnn_input_bn_*
+INPUT_TF = os.environ.get('TMPNN_INPUT_TF', '1') != '0'
 
 
 _wide_ws: Dict[torch.device, torch.Tensor] = {}
@@ -53,6 +56,12 @@ def _wide_workspace(nbytes: int, dev, slot: int = 0) -> torch.Tensor:
         ws = torch.empty((nbytes // 4 + 4,), dtype=torch.float32, device=dev)
         _wide_ws[key] = ws
     return ws
+
+
+def _input_tf(plan: CallPlan, H: int, F: int) -> bool:
+    """The one-launch input transform serves plans whose windows each add at most 128 det rows (H in {32, 64})."""
+    return (INPUT_TF and plan.max_seg_nd >= 0 and plan.seg_of_det is not None
+            and bool(_lib.load().tmpnn_input_tf_supported(H, F, plan.max_seg_nd)))
 
 
 def _wide_prep(w_ih: torch.Tensor, w_hh: torch.Tensor, H: int) -> torch.Tensor:
@@ -180,14 +189,24 @@ def mp_forward(spec: ModelSpec, plan: CallPlan, x: torch.Tensor, h_in: Optional[
             SS = S if training else 1
             mean = torch.empty((SS, H), **opts)
             rstd = torch.empty((SS, H), **opts)
-            _lib.call('tmpnn_input_bn_fwd', xdet.data_ptr() + 4 * f0, spec.F_total, F, nd,
-                      plan.seg_ptr.data_ptr(), plan.seg_cnt.data_ptr(), _lib.ptr(plan.seg_of_det), S, H, int(training),
-                      P[t + '0.weight'].data_ptr(), P[t + '0.bias'].data_ptr(),
-                      P[t + '1.weight'].data_ptr(), P[t + '1.bias'].data_ptr(),
-                      buffers[t + '1.running_mean'].data_ptr(), buffers[t + '1.running_var'].data_ptr(),
-                      P[t + '3.weight'].data_ptr(), P[t + '3.bias'].data_ptr(),
-                      y_save.data_ptr(), mean.data_ptr(), rstd.data_ptr(), ws_a.data_ptr(),
-                      plan.new_det_row.data_ptr(), h_cat.data_ptr() + 4 * gi * H, GH, st)
+            if _input_tf(plan, H, F):
+                _lib.call('tmpnn_input_tf_fwd', xdet.data_ptr() + 4 * f0, spec.F_total, F, nd,
+                          plan.seg_ptr.data_ptr(), plan.seg_cnt.data_ptr(), _lib.ptr(plan.seg_of_det), S, plan.max_seg_nd, H,
+                          int(training), P[t + '0.weight'].data_ptr(), P[t + '0.bias'].data_ptr(),
+                          P[t + '1.weight'].data_ptr(), P[t + '1.bias'].data_ptr(),
+                          buffers[t + '1.running_mean'].data_ptr(), buffers[t + '1.running_var'].data_ptr(),
+                          P[t + '3.weight'].data_ptr(), P[t + '3.bias'].data_ptr(),
+                          y_save.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                          plan.new_det_row.data_ptr(), h_cat.data_ptr() + 4 * gi * H, GH, st)
+            else:
+                _lib.call('tmpnn_input_bn_fwd', xdet.data_ptr() + 4 * f0, spec.F_total, F, nd,
+                          plan.seg_ptr.data_ptr(), plan.seg_cnt.data_ptr(), _lib.ptr(plan.seg_of_det), S, H, int(training),
+                          P[t + '0.weight'].data_ptr(), P[t + '0.bias'].data_ptr(),
+                          P[t + '1.weight'].data_ptr(), P[t + '1.bias'].data_ptr(),
+                          buffers[t + '1.running_mean'].data_ptr(), buffers[t + '1.running_var'].data_ptr(),
+                          P[t + '3.weight'].data_ptr(), P[t + '3.bias'].data_ptr(),
+                          y_save.data_ptr(), mean.data_ptr(), rstd.data_ptr(), ws_a.data_ptr(),
+                          plan.new_det_row.data_ptr(), h_cat.data_ptr() + 4 * gi * H, GH, st)
             if training:
                 buffers[t + '1.num_batches_tracked'] += S
             y_saves.append(y_save)
@@ -488,10 +507,28 @@ def mp_backward(spec: ModelSpec, plan: CallPlan, saved: dict, P: Dict[str, torch
         f0 = 0
         for gi, (_, F) in enumerate(spec.groups):
             t = f'input_transforms.{gi}.'
-            wsn = lib.tmpnn_input_bn_bwd_ws(nd, S, H, F)
-            ws = torch.empty((max(wsn, 1),), **opts)
             # d_xzero is [S][F] per group: write into a per-group buffer, then place it
             dz_g = torch.empty((max(S, 1), F), **opts) if need_x else None
+            if _input_tf(plan, H, F):
+                wsb = int(lib.tmpnn_input_tf_bwd_ws(nd, S, H, F, int(training)))
+                ws = torch.empty((wsb // 4 + 1,), **opts)
+                _lib.call('tmpnn_input_tf_bwd', xdet.data_ptr() + 4 * f0, Ft, F, nd,
+                          plan.seg_ptr.data_ptr(), plan.seg_cnt.data_ptr(), _lib.ptr(plan.seg_of_det), S, plan.max_seg_nd, H,
+                          int(training), P[t + '0.weight'].data_ptr(), P[t + '0.bias'].data_ptr(),
+                          P[t + '1.weight'].data_ptr(), P[t + '1.bias'].data_ptr(), P[t + '3.weight'].data_ptr(),
+                          saved['y_save'][gi].data_ptr(), saved['mean'][gi].data_ptr(), saved['rstd'][gi].data_ptr(),
+                          plan.new_det_row.data_ptr(), d_hcat.data_ptr() + 4 * gi * H, GH,
+                          (d_xdet.data_ptr() + 4 * f0) if need_x else None, Ft, _lib.ptr(dz_g),
+                          grads[t + '0.weight'].data_ptr(), grads[t + '0.bias'].data_ptr(),
+                          grads[t + '1.weight'].data_ptr(), grads[t + '1.bias'].data_ptr(),
+                          grads[t + '3.weight'].data_ptr(), grads[t + '3.bias'].data_ptr(),
+                          ws.data_ptr(), wsb, st)
+                if need_x:
+                    d_xzero[:, f0:f0 + F] = dz_g
+                f0 += F
+                continue
+            wsn = lib.tmpnn_input_bn_bwd_ws(nd, S, H, F)
+            ws = torch.empty((max(wsn, 1),), **opts)
             _lib.call('tmpnn_input_bn_bwd', xdet.data_ptr() + 4 * f0, Ft, F, nd,
                       plan.seg_ptr.data_ptr(), plan.seg_cnt.data_ptr(), _lib.ptr(plan.seg_of_det), S, H, int(training),
                       P[t + '0.weight'].data_ptr(), P[t + '0.bias'].data_ptr(),

@@ -404,6 +404,7 @@ class CallPlan:
     seg_of_new: torch.Tensor      # int64 [n_new] window of each new row
     min_seg_cnt: int
     seg_of_det: Optional[torch.Tensor] = None   # int32 [nd] window of each new det row
+    max_seg_nd: int = -1                        # most new det rows of one window (-1: unknown -> staged input transform)
 
     @property
     def S(self) -> int:
@@ -413,7 +414,7 @@ class CallPlan:
         return CallPlan(self.graph.to(device), self.n_new, self.new_det_local.to(device),
                         self.new_det_row.to(device), self.seg_ptr.to(device), self.seg_cnt.to(device),
                         self.seg_of_new.to(device), self.min_seg_cnt,
-                        None if self.seg_of_det is None else self.seg_of_det.to(device))
+                        None if self.seg_of_det is None else self.seg_of_det.to(device), self.max_seg_nd)
 
 
 def plan_single(graph: FrameGraph, n_new: int) -> CallPlan:
@@ -427,7 +428,7 @@ def plan_single(graph: FrameGraph, n_new: int) -> CallPlan:
                     seg_ptr=torch.tensor([0, nd], dtype=torch.int32, device=dev),
                     seg_cnt=torch.tensor([n_new], dtype=torch.int32, device=dev),
                     seg_of_new=torch.zeros(n_new, dtype=torch.long, device=dev), min_seg_cnt=n_new,
-                    seg_of_det=torch.zeros(nd, dtype=torch.int32, device=dev))
+                    seg_of_det=torch.zeros(nd, dtype=torch.int32, device=dev), max_seg_nd=nd)
 
 
 
@@ -474,7 +475,7 @@ def concat_static_graphs(graphs: Sequence[FrameGraph], device='cpu') -> Tuple[Fr
                     seg_ptr=torch.from_numpy(np.concatenate([[0], np.cumsum(seg_nd)]).astype(np.int32)).to(device),
                     seg_cnt=torch.from_numpy(np.asarray(seg_cnt, np.int32)).to(device),
                     seg_of_new=torch.from_numpy(seg_ids).to(device), min_seg_cnt=int(min(seg_cnt)),
-                    seg_of_det=torch.from_numpy(seg_ids[loc].astype(np.int32)).to(device))
+                    seg_of_det=torch.from_numpy(seg_ids[loc].astype(np.int32)).to(device), max_seg_nd=int(max(seg_nd)))
     return graph, plan
 
 
@@ -546,7 +547,8 @@ def batch_windows(windows: Sequence[Sequence[WindowCall]], static: bool = False,
             seg_cnt=torch.from_numpy(np.asarray(seg_cnt, dtype=np.int32)).to(device),
             seg_of_new=torch.from_numpy(np.concatenate(seg_ids) if seg_ids else np.zeros(0, np.int64)).to(device),
             min_seg_cnt=int(min(seg_cnt)) if seg_cnt else 0,
-            seg_of_det=torch.from_numpy((np.concatenate(seg_ids)[loc] if seg_ids else np.zeros(0)).astype(np.int32)).to(device)))
+            seg_of_det=torch.from_numpy((np.concatenate(seg_ids)[loc] if seg_ids else np.zeros(0)).astype(np.int32)).to(device),
+            max_seg_nd=int(max(seg_nd)) if seg_nd else 0))
         det_refs.append(np.concatenate(refs) if refs else np.zeros((0, 2), np.int64))
     return plans, det_refs
 
