@@ -43,11 +43,21 @@ def main():
     for k, v in p.items():
         if v.dtype.is_floating_point and not k.endswith(orc.BUFFER_SUFFIXES):
             v.requires_grad_(True)
+    shape = sys.argv[1] if len(sys.argv) > 1 else 'C2'
+    frames, mean, mx, ncat, nwin = {'C2': (7, 6.0, 20, 3, 16), 'C3': (12, 8.0, 25, 3, 6), 'C4': (7, 12.0, 40, 8, 6)}[shape]
+    if ncat != 3:
+        torch.manual_seed(5)
+        model = TrackMPNN('2d', ncat, 64, 0, 'diff').train()
+        cfg = orc.OracleConfig('2d', ncat, 64, 0, 'diff')
+        p = {k: v.clone() for k, v in model.state_dict().items()}
+        for k, v in p.items():
+            if v.dtype.is_floating_point and not k.endswith(orc.BUFFER_SUFFIXES):
+                v.requires_grad_(True)
     wins = []
-    for s in range(16):
-        yy = synth_window(1000 + s, 7, 6.0, 20)
+    for s in range(nwin):
+        yy = synth_window(1000 + s, frames, mean, mx)
         y = torch.from_numpy(yy)[None]
-        X = torch.randn(1, yy.shape[0], 8, generator=torch.Generator().manual_seed(s))
+        X = torch.randn(1, yy.shape[0], ncat + 5, generator=torch.Generator().manual_seed(s))
         calls = ref_window(model, X, y)
         graphs = [orc.graph_from_adjacency(c[1], c[2]) for c in calls]
         wins.append((calls, graphs))
@@ -74,7 +84,7 @@ def main():
                 v.grad = None
             loss.backward()
 
-    print(f'C2 windows: 16, edge-iterations per pass: {edges}; host: {os.cpu_count()} cores, torch {torch.__version__}')
+    print(f'{shape} windows: {nwin}, edge-iterations per pass: {edges}; host: {os.cpu_count()} cores, torch {torch.__version__}')
     for nt in (1, 8):
         torch.set_num_threads(nt)
         for name, fn in (('reference', run_ref), ('oracle', run_orc)):
@@ -85,7 +95,7 @@ def main():
                 fn()
                 reps += 1
             dt = (time.perf_counter() - t0) / reps
-            print(f'{name:9s} threads={nt}: {edges / dt:10.0f} graph-edges/s  ({dt * 1e3 / 16:.2f} ms / window)')
+            print(f'{name:9s} threads={nt}: {edges / dt:10.0f} graph-edges/s  ({dt * 1e3 / nwin:.2f} ms / window)')
 
 
 if __name__ == '__main__':

@@ -1,6 +1,7 @@
 """GPU parity tests (run with -m gpu on an MI355X): the HIP path, called through the C ABI, against
 (1) the reference-generated golden fixtures, (2) the CPU oracle on seeded inputs, (3) size-independent
 properties at the bench sizes."""
+import os
 import numpy as np
 import pytest
 import torch
@@ -49,10 +50,14 @@ def test_stage_checks_f32_mfma_path():
     assert r.returncode == 0, tail + r.stderr[-2000:]
 
 
+@pytest.mark.skipif(__import__('os').environ.get('TMPNN_TEST_VARIANTS') != '1',
+                    reason='comparison kernels are compiled only with -DTMPNN_KEEP_VARIANTS (tools/build_variant.sh); '
+                           'set TMPNN_TEST_VARIANTS=1 with TMPNN_LIB_PATH pointing at such a build')
 def test_stage_checks_four_wave_one_pass_backward():
     """The stage checks (they run tmpnn_gru_bwd_fused wherever it is offered) with TMPNN_BWD_TWO=0: the one-pass backward as
     four 512-register waves per block (k_gru_bwd_one) instead of the default eight 256-register waves (k_gru_bwd_two).  The
-    switch is read once per process, hence the child process."""
+    switch is read once per process, hence the child process.  Round 3: k_gru_bwd_one and the round-1 aggregation kernels
+    are no longer in the shipped library (build flag TMPNN_KEEP_VARIANTS)."""
     import os
     import subprocess
     import sys
@@ -709,6 +714,8 @@ def test_one_pass_backward_ragged_sizes_match_the_two_kernels(R):
     for xmode in (0, 1):
         for up in (1, 2, 3):
             for fuse in (False, True):
+                if fuse and xmode == 0 and os.environ.get('TMPNN_TEST_VARIANTS', '0') != '1':
+                    continue                                          # (compact messages + fused adjoint: variant builds only)
                 dho = dout.data_ptr() if up & 1 else None
                 dyp, whp = (dyv.data_ptr(), w_head.data_ptr()) if up & 2 else (None, None)
                 sp, dp = (src.data_ptr(), dst.data_ptr()) if xmode else (None, None)

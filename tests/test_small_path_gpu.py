@@ -117,6 +117,33 @@ def test_invalid_adjacency_cannot_reach_the_optimizer(mode):
     model._pending_graphs = []
 
 
+def test_nonzero_edge_row_features_are_rejected_not_ignored():
+    """The reference runs every new row of x through Lin1 and the batch statistics (track_mpnn.py:59); its graph code always
+    passes zeros on edge rows (utils/graph.py:148-149, 291-292) and this implementation reads det rows only.  A non-zero
+    edge row is therefore an invalid call on the batch-1 path: NaN outputs and a ValueError at the next check, not a silent
+    divergence."""
+    from trackmpnn_amd import TrackMPNN
+    b = torch.zeros(3, 3)
+    b[0, 0] = b[2, 2] = 1
+    b[1, 0], b[1, 2] = 1, -1
+    e = b.t().clone()
+    e[0, 0] = e[2, 2] = 0
+    e[1, 1] = 1
+    model = TrackMPNN('2d', 3, 64, 0, 'diff').to(DEV).eval()
+    x = torch.randn(3, 8, device=DEV)
+    x[1] = 0
+    with torch.no_grad():
+        s, l, h, _ = model(x, None, b.to(DEV), e.to(DEV))
+    model.check_graphs()
+    assert bool(torch.isfinite(s).all())
+    x[1, 3] = 0.25                       # the edge row
+    with torch.no_grad():
+        s, l, h, _ = model(x, None, b.clone().to(DEV), e.clone().to(DEV))
+    assert bool(torch.isnan(s).all())
+    with pytest.raises(ValueError, match='EDGE rows'):
+        model.check_graphs()
+
+
 def _run_model(model, calls, small, monkeypatch, weights=None):
     import trackmpnn_amd.track_mpnn as tm
     monkeypatch.setattr(tm, 'SMALL_PATH', small)

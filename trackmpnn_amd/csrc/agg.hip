@@ -28,6 +28,7 @@ int set_error(int code, const char* fmt, ...) {
 // ------------------------------------------------------------------------------------------
 // gather: out[edge_row[e]] = in[src[e]] - in[dst[e]]        (CONCAT: [in[src] | in[dst]])
 // ------------------------------------------------------------------------------------------
+#ifdef TMPNN_KEEP_VARIANTS      // round-1 row movers (not pipelined): comparison builds only (TMPNN_AGG=0)
 template <bool CONCAT, bool ACC>
 __global__ __launch_bounds__(256) void k_gather(int E, const int32_t* __restrict__ src,
                                                 const int32_t* __restrict__ dst,
@@ -151,6 +152,8 @@ __global__ __launch_bounds__(256) void k_segsum(int Dn, const int32_t* __restric
     }
 }
 
+
+#endif  // TMPNN_KEEP_VARIANTS
 
 // ------------------------------------------------------------------------------------------
 // Software-pipelined forms (round 2).  Both row movers are chains of DEPENDENT loads -- index -> row for the gather,
@@ -326,10 +329,14 @@ __global__ __launch_bounds__(256) void k_segsum_pipe(int Dn, const int32_t* __re
 }
 
 // TMPNN_AGG=0 keeps the round-1 kernels (A/B measurements); default: the pipelined forms
+#ifdef TMPNN_KEEP_VARIANTS
 static int agg_variant() {
     static const int v = [] { const char* e = getenv("TMPNN_AGG"); return (e && e[0] == '0') ? 0 : 1; }();
     return v;
 }
+#else
+static constexpr int agg_variant() { return 1; }
+#endif
 
 __global__ void k_transpose(const float* __restrict__ in, int rows, int cols, float* __restrict__ out) {
     __shared__ float tile[32][33];
@@ -433,10 +440,13 @@ static int gather(const tmpnn_graph* g, const float* in, int ld_in, float* out, 
         grid = dim3(grid_for(g->E, rpb * 4));
         if (concat) { if (accumulate) L(k_gather_pipe, true, true); else L(k_gather_pipe, true, false); }
         else        { if (accumulate) L(k_gather_pipe, false, true); else L(k_gather_pipe, false, false); }
-    } else {
+    }
+#ifdef TMPNN_KEEP_VARIANTS
+    else {
         if (concat) { if (accumulate) L(k_gather, true, true); else L(k_gather, true, false); }
         else        { if (accumulate) L(k_gather, false, true); else L(k_gather, false, false); }
     }
+#endif
 #undef L
     return check_launch("gather");
 }
@@ -466,7 +476,9 @@ static int segsum(const tmpnn_graph* g, const float* in, int ld_in, float* out, 
         if (deep) { if (accumulate) LSP(true, 8, 16); else LSP(false, 8, 16); }
         else      { if (accumulate) LSP(true, 4, 32); else LSP(false, 4, 32); }
     }
+#ifdef TMPNN_KEEP_VARIANTS
     else               { if (accumulate) LS(k_segsum, true); else LS(k_segsum, false); }
+#endif
 #undef LSP
 #undef LS
     return check_launch("segsum");

@@ -2408,6 +2408,7 @@ __device__ __forceinline__ f32x16 mfma_c(const uint4 (&a)[3], const Split8& b, f
     return mfma_bf16(a[0], b.p1, acc);
 }
 
+#ifdef TMPNN_KEEP_VARIANTS      // the round-2 four-wave form of the one-pass backward: comparison builds only
 template <int XMODE, int UP, bool FUSE>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void k_gru_bwd_one(GruBwdFusedArgs a, int ntiles) {
@@ -2673,6 +2674,7 @@ void k_gru_bwd_one(GruBwdFusedArgs a, int ntiles) {
         }
     }
 }
+#endif  // TMPNN_KEEP_VARIANTS
 
 // ==========================================================================================
 // The one-pass backward at TWO waves per SIMD (k_gru_bwd_two): the same LDS images, the same products and slabs as
@@ -3365,10 +3367,12 @@ static int weights_chunk_slabs(int R, int IN, int H) {
 
 // the one-pass backward's form: eight 256-register waves per block (k_gru_bwd_two) or four 512-register waves
 // (k_gru_bwd_one); a constant of the process (TMPNN_BWD_TWO), never a measurement
+#ifdef TMPNN_KEEP_VARIANTS
 static bool fused_two_waves() {
     static const bool v = [] { const char* e = getenv("TMPNN_BWD_TWO"); return e == nullptr || e[0] != '0'; }();
     return v;
 }
+#endif
 
 static int fused_blocks(int R) {
     const int ntiles = ceil_div(R, 32);
@@ -3438,6 +3442,7 @@ int tmpnn_gru_bwd_fused(const int32_t* rows, int R, int xmode, const int32_t* sr
     hipStream_t st = as_stream(stream);
     const int up = (d_hout ? 1 : 0) | (dy ? 2 : 0);
     const bool fuse = add_msg != nullptr;
+#ifdef TMPNN_KEEP_VARIANTS
 #define LF(X, U, F)                                                                                          \
     do {                                                                                                     \
         if (fused_two_waves() && !((X) == 0 && (F))) {     /* (message cell + fused adjoint: four-wave form only) */ \
@@ -3448,6 +3453,17 @@ int tmpnn_gru_bwd_fused(const int32_t* rows, int R, int xmode, const int32_t* sr
             hipLaunchKernelGGL((k_gru_bwd_one<X, U, F>), dim3(n_rs), dim3(256), shm, st, a, ntiles);         \
         }                                                                                                    \
     } while (0)
+#else
+    // (a message cell -- xmode 0 -- with the fused adjoint exists only in the four-wave comparison build; nothing asks for it)
+    TM_REQUIRE(!(xmode == 0 && fuse), "gru_bwd_fused: xmode 0 with a fused adjoint needs a TMPNN_KEEP_VARIANTS build");
+#define LF(X, U, F)                                                                                          \
+    do {                                                                                                     \
+        if (!((X) == 0 && (F))) {                                                                            \
+            TM_SHM_ONCE((k_gru_bwd_two<X, U, F>), shm);                                                      \
+            hipLaunchKernelGGL((k_gru_bwd_two<X, U, F>), dim3(n_rs), dim3(512), shm, st, a, ntiles);         \
+        }                                                                                                    \
+    } while (0)
+#endif
 #define LU(X, F) do { if (up == 1) LF(X, 1, F); else if (up == 2) LF(X, 2, F); else LF(X, 3, F); } while (0)
     if (xmode == 0) { if (fuse) LU(0, true); else LU(0, false); }
     else            { if (fuse) LU(1, true); else LU(1, false); }

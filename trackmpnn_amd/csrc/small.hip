@@ -151,6 +151,18 @@ __global__ __launch_bounds__(256) void k_small_bn_fwd(BnFwdArgs a) {
     }
     const int nd = s_wsum[4];
     if (tid == 0) newdet[n] = nd;
+    // The new EDGE rows of x must be all-zero (utils/graph.py:148-149, 291-292 always builds them so): only det rows are
+    // read here, while the reference would run whatever an edge row holds through Lin1 and into the batch statistics.
+    // A non-zero edge row therefore marks the call invalid (status bit 64: NaN outputs, ValueError at the next check)
+    // instead of diverging silently.
+    {
+        bool bad = false;
+        for (int idx = tid; idx < n * F; idx += 256) {
+            const int i = idx / F, f = idx - i * F;
+            if (a.g.is_edge[N_old + i] && a.x[(size_t)i * a.ld_x + f0 + f] != 0.f) bad = true;
+        }
+        if (bad) atomicOr(&a.g.meta[2], 64);
+    }
     // new edge rows start at zero (track_mpnn.py:61); new det rows are written below
     for (int idx = tid; idx < n * (H / 4); idx += 256) {
         const int i = idx / (H / 4), c4 = idx % (H / 4);

@@ -72,12 +72,12 @@ __global__ __launch_bounds__(256) void k_wide_prep(const float* __restrict__ W, 
 // B[16 j + kk][n], the two 16-byte chunks of a column swapped where (n >> 4) & 1 (pos = ((kk >> 3) ^ ((n >> 4) & 1)) * 8 +
 // (kk & 7)): a [piece][192 columns][16] tile is a LINEAR copy and ds_read_b128 of chunk c ^ ((col >> 4) & 1) with
 // lane = column is conflict-free (32-byte rows: the 16 lanes served together sit 2 r + c slots apart mod 16).
-__global__ __launch_bounds__(256) void k_wide_prep16(const float* __restrict__ W, int ldw, int K, int N,
+__global__ __launch_bounds__(256) void k_wide_prep16(const float* __restrict__ W, int ldw, int K, int N, int trans,
                                                      uint16_t* __restrict__ img) {
     const long total = (long)K * N;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
         const int k = (int)(i / N), n = (int)(i % N);
-        const float v = W[(size_t)n * ldw + k];                 // B = W^T
+        const float v = trans ? W[(size_t)n * ldw + k] : W[(size_t)k * ldw + n];      // B = W^T (forward) or W (backward-data)
         uint32_t p1, p2, p3;
         w_split2(v, 0.f, p1, p2, p3);
         const int j = k >> 4, kk = k & 15;
@@ -811,6 +811,203 @@ __global__ __launch_bounds__(512) void k_wide_gru_fwd_ring(WideArgs a, WideTiles
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// C (+)= A B with the ring structure of k_wide_gru_fwd_ring (the backward product d_h += d_gh W_hh: 4.41 M x 768 x 256)
+// ------------------------------------------------------------------------------------------------------------
+// k_wide_gemm_store stages both operands through registers with a barrier per 32-deep K-step (12.7 ms per C5 iteration for
+// 5.6 ms of matrix-pipe time).  Here: 128 x 128 output tiles, K in half steps of 16 through a ring of four LDS slots
+// (8 KB of raw fp32 A rows -- gathered through a row list, with the column skip of the [dr | dz | dn | dn r] image -- and
+// 12 KB of pre-swizzled weight pieces), everything by LDS-DMA three half steps ahead, operands of step p + 1 fetched into
+// registers and the A split woven under the MFMAs of step p; a persistent block takes the N / 128 column blocks of a row
+// tile back to back (the second read of its A rows comes from L2).  Same products in the same order as
+// k_wide_gemm_store: bit-identical.
+static constexpr int GR_A = 128 * 64, GR_B = 3 * 128 * 32, GR_SLOT = GR_A + GR_B;       // bytes
+static constexpr size_t W_GEMM_RING_SHM = 4 * GR_SLOT;                                   // sC [128][132] fp32 aliases it
+
+struct GRingOps { float4 lo, hi; uint4 af[3]; uint4 bf[6]; };
+__device__ __forceinline__ void gring_read(const char* slot_base, int a_off0, int a_off1, int b_off, GRingOps& o) {
+    o.lo = *reinterpret_cast<const float4*>(slot_base + a_off0);
+    o.hi = *reinterpret_cast<const float4*>(slot_base + a_off1);
+    const char* sb = slot_base + GR_A + b_off;
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) o.bf[ct * 3 + p] = *reinterpret_cast<const uint4*>(sb + ct * 32 * 32 + p * 128 * 32);
+}
+__device__ __forceinline__ void gring_split(GRingOps& o) {
+    w_split2(o.lo.x, o.lo.y, o.af[0].x, o.af[1].x, o.af[2].x);
+    w_split2(o.lo.z, o.lo.w, o.af[0].y, o.af[1].y, o.af[2].y);
+    w_split2(o.hi.x, o.hi.y, o.af[0].z, o.af[1].z, o.af[2].z);
+    w_split2(o.hi.z, o.hi.w, o.af[0].w, o.af[1].w, o.af[2].w);
+}
+__device__ __forceinline__ void gring_pin(GRingOps& o) {
+    asm volatile("" : "+v"(o.af[0].x), "+v"(o.af[0].y), "+v"(o.af[0].z), "+v"(o.af[0].w), "+v"(o.af[1].x), "+v"(o.af[1].y),
+                      "+v"(o.af[1].z), "+v"(o.af[1].w), "+v"(o.af[2].x), "+v"(o.af[2].y), "+v"(o.af[2].z), "+v"(o.af[2].w));
+}
+__device__ __forceinline__ void gring_compute(const GRingOps& o, f32x16 (&acc)[2]) {
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+        f32x16 c = acc[ct];
+        c = w_mfma(o.af[2], o.bf[ct * 3], c);
+        c = w_mfma(o.af[0], o.bf[ct * 3 + 2], c);
+        c = w_mfma(o.af[1], o.bf[ct * 3 + 1], c);
+        c = w_mfma(o.af[1], o.bf[ct * 3], c);
+        c = w_mfma(o.af[0], o.bf[ct * 3 + 1], c);
+        c = w_mfma(o.af[0], o.bf[ct * 3], c);
+        acc[ct] = c;
+    }
+}
+template <int N>
+__device__ __forceinline__ void gring_wait_barrier() {      // three DMA instructions per wave and half step
+    if constexpr (N >= 9) asm volatile("s_waitcnt vmcnt(9) lgkmcnt(0)" ::: "memory");
+    else if constexpr (N >= 6) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+    else if constexpr (N >= 3) asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+#define GRING_WEAVE()                                                                                  \
+    do {                                                                                               \
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                                             \
+        _Pragma("unroll") for (int w_ = 0; w_ < 10; ++w_) {                                            \
+            __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);                                         \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                         \
+        }                                                                                              \
+    } while (0)
+
+__global__ __launch_bounds__(512) void k_wide_gemm_ring(WideArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint16_t w_dyn[];
+    char* const ring = reinterpret_cast<char*>(w_dyn);
+    float* const sC = reinterpret_cast<float*>(w_dyn);                    // [128][132], aliases the ring
+    constexpr int LDC = 128 + 4;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), wr = wave & 3, wc = wave >> 2;
+    const int nchunk = a.N >> 7, nsub = a.K >> 4;
+    const int ntile = (a.R + 127) >> 7;
+    const int G = gridDim.x;
+    int t = blockIdx.x;
+    if (t >= ntile) return;
+    const uint32_t base = lds_addr(ring);
+    const uint32_t lds_a = base + 1024u * wave, lds_b0 = base + GR_A + 1024u * wave, lds_b1 = base + GR_A + 8192u + 512u * wave;
+    // weight-tile chunks of this thread: idx = (p * 128 + col) * 2 + q -> image byte offset
+    auto boff = [&](int idx) { const int p = idx >> 8, rem = idx & 255; return (uint32_t)((p * a.N + (rem >> 1)) * 32 + (rem & 1) * 16); };
+    const uint32_t ob0 = boff(tid), ob1 = boff(512 + 32 * wave + (lane & 31));
+    const bool b1_on = lane < 32;
+    const int r = lane & 31, hh = lane >> 5;
+    const int arow = 32 * wr + r, fa = (arow >> 2) & 3;
+    const int a_off0 = arow * 64 + (((2 * hh) ^ fa) << 4), a_off1 = arow * 64 + (((2 * hh + 1) ^ fa) << 4);
+    const int b_off = (64 * wc + r) * 32 + ((hh ^ ((r >> 4) & 1)) << 4);
+    const int drow = tid >> 2, dchunk = (tid & 3) ^ ((drow >> 2) & 3);
+    auto a_row = [&](int tile) {
+        const int rr = min(tile * 128 + drow, a.R - 1);                   // (rows past R repeat the last one: never stored)
+        return a.a_rows ? a.a_rows[rr] : rr;
+    };
+    auto a_src = [&](int row) { return reinterpret_cast<const char*>(a.A + (size_t)row * a.lda + 4 * dchunk); };
+    const char* pa = a_src(a_row(t));
+    int row_next = 0;
+    auto dma = [&](int j, int n0, int slot) {
+        const uint32_t so = (uint32_t)slot * GR_SLOT;
+        int kc = 16 * j;
+        if (kc >= a.kskip_at) kc += a.kskip;
+        glds16(pa + (size_t)kc * 4, lds_a + so);
+        const char* wb = reinterpret_cast<const char*>(a.img) + ((size_t)j * 3 * a.N + n0) * 32;
+        glds16_so(wb, ob0, lds_b0 + so);
+        if (b1_on) glds16_so(wb, ob1, lds_b1 + so);
+        else asm volatile("s_nop 0" ::: "memory");
+    };
+    dma(0, 0, 0); dma(1, 0, 1); dma(2, 0, 2); dma(3, 0, 3);
+    for (int bx = 0;;) {
+        const int n0 = bx << 7;
+        gring_wait_barrier<9>();                                 // half step 0 has landed
+        const bool last_chunk = bx + 1 == nchunk;
+        const bool more_tiles = t + G < ntile;
+        f32x16 acc[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[j][q] = 0.f;
+        GRingOps R[2];
+        gring_read(ring, a_off0, a_off1, b_off, R[0]);
+        gring_split(R[0]);
+        gring_wait_barrier<6>();                                 // step 1 has landed; every wave has step 0 in registers
+        int p0 = 0;
+        for (; p0 + 8 <= nsub; p0 += 4) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                dma(p0 + u + 4, n0, u);
+                gring_read(ring + ((u + 1) & 3) * GR_SLOT, a_off0, a_off1, b_off, R[(u + 1) & 1]);
+                __builtin_amdgcn_sched_barrier(0);
+                gring_compute(R[u & 1], acc);
+                gring_split(R[(u + 1) & 1]);
+                GRING_WEAVE();
+                __builtin_amdgcn_sched_barrier(0);
+                gring_pin(R[(u + 1) & 1]);
+                gring_wait_barrier<6>();
+            }
+        }
+        gring_read(ring + GR_SLOT, a_off0, a_off1, b_off, R[1]);
+        __builtin_amdgcn_sched_barrier(0);
+        gring_compute(R[0], acc); gring_split(R[1]); GRING_WEAVE();
+        __builtin_amdgcn_sched_barrier(0);
+        gring_pin(R[1]);
+        gring_wait_barrier<3>();
+        gring_read(ring + 2 * GR_SLOT, a_off0, a_off1, b_off, R[0]);
+        __builtin_amdgcn_sched_barrier(0);
+        gring_compute(R[1], acc); gring_split(R[0]); GRING_WEAVE();
+        __builtin_amdgcn_sched_barrier(0);
+        gring_pin(R[0]);
+        gring_wait_barrier<0>();
+        gring_read(ring + 3 * GR_SLOT, a_off0, a_off1, b_off, R[1]);
+        __builtin_amdgcn_sched_barrier(0);
+        gring_compute(R[0], acc); gring_split(R[1]); GRING_WEAVE();
+        __builtin_amdgcn_sched_barrier(0);
+        gring_pin(R[1]);
+        gring_wait_barrier<0>();                                 // every wave has its last operands: sC may overwrite the ring
+        if (last_chunk && more_tiles) row_next = a_row(t + G);   // (requested with nothing in flight, used after the epilogue)
+        gring_compute(R[1], acc);
+        const int r0 = t * 128;
+        // the accumulate operand of the epilogue's rows, requested before the tile is staged
+        float4 cprev[8];
+        int crow[8];
+        {
+            const int te = opaque(tid);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int rr = min(r0 + (te >> 5) + 16 * i, a.R - 1);
+                crow[i] = a.c_rows ? a.c_rows[rr] : rr;
+            }
+            if (a.accumulate) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) cprev[i] = *reinterpret_cast<const float4*>(a.C + (size_t)crow[i] * a.ldc + n0 + 4 * (te & 31));
+            }
+        }
+        {
+            const int lw = opaque(lane), cl = lw & 31, half = lw >> 5;
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg)
+                    sC[(32 * wr + w_acc_row(reg, half)) * LDC + 64 * wc + 32 * ct + cl] = acc[ct][reg];
+        }
+        __syncthreads();
+        {
+            const int te = opaque(tid), q = te & 31;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int lr = (te >> 5) + 16 * i;
+                if (r0 + lr >= a.R) continue;
+                float4 v = *reinterpret_cast<const float4*>(sC + lr * LDC + 4 * q);
+                if (a.accumulate) { v.x += cprev[i].x; v.y += cprev[i].y; v.z += cprev[i].z; v.w += cprev[i].w; }
+                *reinterpret_cast<float4*>(a.C + (size_t)crow[i] * a.ldc + n0 + 4 * q) = v;
+            }
+        }
+        __syncthreads();
+        if (last_chunk && !more_tiles) break;
+        if (last_chunk) { t += G; pa = a_src(row_next); bx = 0; } else ++bx;
+        const int nn = bx << 7;
+        dma(0, nn, 0); dma(1, nn, 1); dma(2, nn, 2); dma(3, nn, 3);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // backward, elementwise pass: d_gi = [dr | dz | dn], d_gh = [dr | dz | dn r] (compact rows), d_h[row] = dh z
 // ------------------------------------------------------------------------------------------------------------
 struct WideBwdArgs {
@@ -1105,6 +1302,16 @@ __global__ __launch_bounds__(512) void k_wide_dw(WideDwArgs q, int mt_count, int
     }
 }
 
+// the ring form needs whole 128-column blocks, K in whole groups of four half steps (>= 8) and 16-byte aligned rows
+static int launch_gemm_ring(const WideArgs& a, hipStream_t st) {
+    TM_SHM_ONCE(k_wide_gemm_ring, W_GEMM_RING_SHM);
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    const int ntile = ceil_div(a.R, 128);
+    hipLaunchKernelGGL(k_wide_gemm_ring, dim3(ntile < cus ? ntile : cus), dim3(512), W_GEMM_RING_SHM, st, a);
+    return check_launch("wide_gemm_ring");
+}
+
 static int launch_store(const WideArgs& a, hipStream_t st) {
     dim3 grid(wide_grid(ceil_div(a.N, 128), ceil_div(a.R, W_BM)));
     TM_SHM_ONCE(k_wide_gemm_store, W_STORE_SHM);
@@ -1124,8 +1331,8 @@ int tmpnn_wide_supported(int H, int IN) { return ((H == 128 || H == 256) && IN =
 // backward ih (K = 3H, N = IN), backward hh (K = 3H, N = H)
 size_t tmpnn_wide_prep_bytes(int H, int IN) {
     if (H <= 0 || IN <= 0) return 0;
-    // + the half-step image of the forward W_hh operand (k_wide_gru_fwd_ring)
-    return sizeof(uint16_t) * 3 * ((size_t)H * 3 * H + (size_t)IN * 3 * H + (size_t)3 * H * IN + (size_t)3 * H * H + (size_t)H * 3 * H);
+    // + the half-step images of the forward and backward-data W_hh operands (k_wide_gru_fwd_ring, k_wide_gemm_ring)
+    return sizeof(uint16_t) * 3 * ((size_t)H * 3 * H + (size_t)IN * 3 * H + (size_t)3 * H * IN + (size_t)3 * H * H + 2 * (size_t)H * 3 * H);
 }
 
 int tmpnn_wide_prepare(const float* w_ih, const float* w_hh, int IN, int H, void* prep, tmpnn_stream stream) {
@@ -1141,7 +1348,9 @@ int tmpnn_wide_prepare(const float* w_ih, const float* w_hh, int IN, int H, void
     hipLaunchKernelGGL(k_wide_prep, dim3(g2), dim3(256), 0, st, w_ih, IN, IN, 3 * H, 1, f_ih);
     hipLaunchKernelGGL(k_wide_prep, dim3(g2), dim3(256), 0, st, w_ih, IN, 3 * H, IN, 0, b_ih);
     hipLaunchKernelGGL(k_wide_prep, dim3(g1), dim3(256), 0, st, w_hh, H, 3 * H, H, 0, b_hh);
-    hipLaunchKernelGGL(k_wide_prep16, dim3(g1), dim3(256), 0, st, w_hh, H, H, 3 * H, b_hh + (size_t)3 * 3 * H * H);
+    uint16_t* f_hh16 = b_hh + (size_t)3 * 3 * H * H;
+    hipLaunchKernelGGL(k_wide_prep16, dim3(g1), dim3(256), 0, st, w_hh, H, H, 3 * H, 1, f_hh16);
+    hipLaunchKernelGGL(k_wide_prep16, dim3(g1), dim3(256), 0, st, w_hh, H, 3 * H, H, 0, f_hh16 + (size_t)3 * H * 3 * H);
     return check_launch("wide_prepare");
 }
 
@@ -1395,7 +1604,13 @@ int tmpnn_wide_gru_bwd_diff(const void* prep, const tmpnn_graph* g, const float*
     WideArgs y{};
     y.A = dg4; y.lda = 4 * H; y.a_rows = g->edge_row; y.R = R; y.K = 3 * H; y.kskip_at = 2 * H; y.kskip = H;
     y.img = b_hh; y.N = H; y.C = d_h; y.ldc = ld_dh; y.c_rows = g->edge_row; y.accumulate = 1;
+#ifndef WT_GEMM_STORE
+    // (the E-row product of the backward: the ring form; its weight image is the sixth of prep)
+    y.img = f_hh + (size_t)3 * (4 * 3 * H * H) + (size_t)3 * H * 3 * H;
+    if ((rc = launch_gemm_ring(y, st))) return rc;
+#else
     if ((rc = launch_store(y, st))) return rc;
+#endif
     // 3. S[d] = signed segment sum of d_gi (image columns 0..3H) over the det's incident edges, compact rows
     for (int k = 0; k < 3; ++k)
         if ((rc = tmpnn_segsum_fwd(g, dg4 + (size_t)k * H, 4 * H, S + (size_t)k * H, 3 * H, H, 0, 1, stream))) return rc;

@@ -564,7 +564,9 @@ _DG_STATUS = ((1, 'an off-diagonal adjacency entry is not +-1 (or an index is ou
               (4, 'edge endpoint is not a det row'),
               (8, 'expected src row < edge row < dst row (utils/graph.py:153-156,298-301)'),
               (16, 'diag(edge_adj) does not complement diag(node_adj)'),
-              (32, 'edge_adj is not node_adj^T off the diagonal'))
+              (32, 'edge_adj is not node_adj^T off the diagonal'),
+              (64, 'x has non-zero features on new EDGE rows: the reference would feed them to the BatchNorm statistics '
+                   '(utils/graph.py:148,291 always passes zeros); this implementation reads det rows only'))
 
 
 class DeviceGraph:

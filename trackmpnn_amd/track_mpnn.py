@@ -350,8 +350,9 @@ class TrackMPNN(nn.Module):
         """reference/models/track_mpnn.py:54-75.  node_adj / edge_adj: dense or sparse-COO [N, N].
 
         Contract on x (as produced by utils/graph.py:148-149,291-292): rows of new EDGE nodes are all-zero; only the
-        new det rows are read (a non-zero edge row would enter the reference's BatchNorm statistics; here it is
-        ignored).  Graphs of up to 65535 rows without attention heads take the fused batch-1 path: the adjacency is
+        new det rows are read.  A non-zero edge row would enter the reference's BatchNorm statistics: on the batch-1 path
+        such a call is marked invalid on the device (NaN outputs, ValueError at the next check_graphs()); the staged
+        path checks it under TMPNN_DEBUG=1.  Graphs of up to 65535 rows without attention heads take the fused batch-1 path: the adjacency is
         converted on the device in one launch and validated LATE (check_graphs(); TMPNN_STRICT_GRAPH=1 validates
         at once), everything else is converted with torch index ops and validated immediately."""
         if not x.is_cuda:
