@@ -482,7 +482,12 @@ __device__ __forceinline__ void stage_store32(float* stg, int c, int half, int l
         const int rr = idx >> 3, ch = idx & 7;
         const float4 x = *reinterpret_cast<const float4*>(stg + rr * STG_LD + ch * 4);
         const int orow = __shfl(row, rr, 64);               // lane rr (< 32) owns row r0 + rr
+#ifdef FT_EXP_NOSTORE
+        asm volatile("" :: "v"(x.x), "v"(x.y), "v"(x.z), "v"(x.w), "v"(orow));
+        if (false) {
+#else
         if (r0 + rr < R) {
+#endif
             float* p = dst + (size_t)orow * ld + col0 + ch * 4;
             if (NT) {      // streamed once, read back only by the backward pass: keep it out of the way of L2
                 __builtin_nontemporal_store(x.x, p); __builtin_nontemporal_store(x.y, p + 1);
@@ -929,6 +934,16 @@ __global__ __launch_bounds__(WPB * 64) void k_gru_fwd_split(GruFwdArgs a) {
 // Rows of 3 gates x 32 columns sit 400 bytes apart (16 consecutive det positions -> 16 different 16-byte slots of the bank
 // row).  A tile with more than TCAP distinct dets takes the gathers of k_gru_fwd_split.  Same products, same order, same
 // epilogue arithmetic: bit-identical results.
+#ifdef FT_TIMELINE            // build-time instrument (tools/isa_timeline.py --fwd-tiles): per-phase s_memtime sums of every wave
+__device__ unsigned long long g_ft_timeline[16];
+#define FT_MARK(i)                                                            \
+    do {                                                                      \
+        const unsigned long long now_ = __builtin_amdgcn_s_memtime();         \
+        ft_acc[(i)] += now_ - ft_last; ft_last = now_;                        \
+    } while (0)
+#else
+#define FT_MARK(i) do { } while (0)
+#endif
 struct FwdTiles { const int32_t* t_row; const int32_t* t_loc; const int32_t* t_dptr; const int32_t* t_dets; int T; };
 static constexpr int TCAP = 24, TP_LD = 100;                   // dets staged per item; floats per staged row
 static constexpr int TP_AREA = TCAP * TP_LD;                   // floats per wave (>= 32 * STG_LD: the output staging tile)
@@ -965,8 +980,23 @@ __device__ __forceinline__ void tiled_stage_p(const GruFwdArgs& a, const TiledId
     for (int i0 = 0; i0 < nchunk; i0 += 64) {
         const int idx = i0 + lane;
         const int j = idx / 25, rem = idx - 25 * j;
+#ifdef FT_DMA_SHFL
         const int det = __shfl(x.det, j, 64);
+#else
+        // the 64 chunks of a pass belong to four det rows at most: their ids by v_readlane (a cross-lane read through the
+        // LDS pipe here is a round trip per pass, 2.9 k of an item's 21 k cycles in the s_memtime profile)
+        const int j0 = i0 / 25;
+        const int d0 = __builtin_amdgcn_readlane(x.det, j0), d1 = __builtin_amdgcn_readlane(x.det, j0 + 1);
+        const int d2 = __builtin_amdgcn_readlane(x.det, j0 + 2), d3 = __builtin_amdgcn_readlane(x.det, min(j0 + 3, 63));
+        const int dj = j - j0;
+        const int det = dj == 0 ? d0 : dj == 1 ? d1 : dj == 2 ? d2 : d3;
+#endif
+#ifdef FT_EXP_NODMA
+        asm volatile("" :: "v"(det));
+        if (false)
+#else
         if (idx < nchunk && rem < 24)
+#endif
             glds16_g(a.msg + (size_t)det * a.ld_msg + (rem >> 3) * H + cw0 + 4 * (rem & 7), area + 16u * i0);
     }
 }
@@ -1031,6 +1061,11 @@ __global__ __launch_bounds__(WPB * 64) void k_gru_fwd_split_tiled(GruFwdArgs a, 
         for (int i = 0; i < NQ4; ++i) raw[i] = xr[i];
     }
 
+#ifdef FT_TIMELINE
+    unsigned long long ft_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long ft_last = __builtin_amdgcn_s_memtime();
+    unsigned long long ft_items = 0;
+#endif
     for (;;) {
         int nitem = 0;
         if (lane == 0) nitem = atomicAdd(next_item, 1);
@@ -1062,6 +1097,12 @@ __global__ __launch_bounds__(WPB * 64) void k_gru_fwd_split_tiled(GruFwdArgs a, 
         f32x16 acc_r, acc_z, acc_hn, acc_in;
 #pragma unroll
         for (int i = 0; i < 16; ++i) { acc_r[i] = 0.f; acc_z[i] = 0.f; acc_hn[i] = 0.f; }
+#ifdef FT_TIMELINE
+        asm volatile("" : "+v"(b[0].p1.x), "+v"(b[NKB - 1].p3.w));
+        __builtin_amdgcn_sched_barrier(0);
+        FT_MARK(0);                                             // item claim, operand wait + split, next item's requests
+        __builtin_amdgcn_sched_barrier(0);
+#endif
         {
             const uint16_t* wp0 = sW + (cw0 + c) * KP + (H / 2) * half;
 #pragma unroll
@@ -1078,6 +1119,12 @@ __global__ __launch_bounds__(WPB * 64) void k_gru_fwd_split_tiled(GruFwdArgs a, 
                 }
             }
         }
+#ifdef FT_TIMELINE
+        asm volatile("" : "+v"(acc_r[0]), "+v"(acc_z[0]), "+v"(acc_hn[0]));
+        __builtin_amdgcn_sched_barrier(0);
+        FT_MARK(1);                                             // matrix phase (until the last MFMA's result is readable)
+        __builtin_amdgcn_sched_barrier(0);
+#endif
         // the staged P rows were requested an item ago; only the loads issued since (the next item's operand and index
         // loads, at least NQ4 of them) may still be in flight
         if (staged) {
@@ -1088,6 +1135,11 @@ __global__ __launch_bounds__(WPB * 64) void k_gru_fwd_split_tiled(GruFwdArgs a, 
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
         }
+#ifdef FT_TIMELINE
+        __builtin_amdgcn_sched_barrier(0);
+        FT_MARK(2);                                             // wait for the staged P rows
+        __builtin_amdgcn_sched_barrier(0);
+#endif
 #ifndef FT_HP_EARLY
         float4 hp4[4];
 #pragma unroll
@@ -1180,6 +1232,12 @@ __global__ __launch_bounds__(WPB * 64) void k_gru_fwd_split_tiled(GruFwdArgs a, 
                 }
             }
         }
+#ifdef FT_TIMELINE
+        asm volatile("" : "+v"(outv[0]), "+v"(outv[15]), "+v"(acc_in[15]));
+        __builtin_amdgcn_sched_barrier(0);
+        FT_MARK(3);                                             // P reads from LDS, previous state from HBM, gate arithmetic
+        __builtin_amdgcn_sched_barrier(0);
+#endif
         if (a.logit_part) {
             float p = 0.f;
 #pragma unroll
@@ -1188,21 +1246,63 @@ __global__ __launch_bounds__(WPB * 64) void k_gru_fwd_split_tiled(GruFwdArgs a, 
                 p += outv[4 * q] * w.x + outv[4 * q + 1] * w.y + outv[4 * q + 2] * w.z + outv[4 * q + 3] * w.w;
             }
             p += __shfl_xor(p, 32);
+#ifdef FT_EXP_NOLOGITSTORE
+            asm volatile("" :: "v"(p));
+#else
             if (half == 0 && r0 + c < a.R) a.logit_part[(size_t)(cw0 / 32) * a.part_stride + row] = p;
+#endif
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // every read of the staged P rows is back: the area is free
+#ifdef FT_TIMELINE
+        __builtin_amdgcn_sched_barrier(0);
+        FT_MARK(4);                                             // output-head partial
+        __builtin_amdgcn_sched_barrier(0);
+#endif
         stage_store32(stg, c, half, lane, outv, a.h_out, a.ld_out, cw0, row, r0, a.R);
+#ifdef FT_TIMELINE
+        __builtin_amdgcn_sched_barrier(0);
+        FT_MARK(5);                                             // h_out through the staging tile
+        __builtin_amdgcn_sched_barrier(0);
+#endif
         if (a.gates) {
             stage_store32<true>(stg, c, half, lane, acc_r, a.gates, H, cw0, row, r0, a.R);
             stage_store32<true>(stg, c, half, lane, acc_z, a.gates + a.gate_plane, H, cw0, row, r0, a.R);
             stage_store32<true>(stg, c, half, lane, acc_in, a.gates + 2 * a.gate_plane, H, cw0, row, r0, a.R);
             stage_store32<true>(stg, c, half, lane, acc_hn, a.gates + 3 * a.gate_plane, H, cw0, row, r0, a.R);
         }
+#ifdef FT_TIMELINE
+        __builtin_amdgcn_sched_barrier(0);
+        FT_MARK(6);                                             // the four gate planes
+        __builtin_amdgcn_sched_barrier(0);
+        ++ft_items;
+#endif
         if (!nvalid) break;
         cw0 = ncw0; t = nt; ix = nix;
         if (ix.nd <= TCAP) tiled_stage_p<H>(a, ix, cw0, lane, area);      // (the staging tile's last reads are back: stage_store32)
+#ifdef FT_TIMELINE
+        __builtin_amdgcn_sched_barrier(0);
+        FT_MARK(7);                                             // DMA requests of the next item's P rows
+        __builtin_amdgcn_sched_barrier(0);
+#endif
     }
+#ifdef FT_TIMELINE
+    if (lane == 0) {
+        for (int i = 0; i < 8; ++i) atomicAdd(&g_ft_timeline[i], ft_acc[i]);
+        atomicAdd(&g_ft_timeline[8], ft_items);
+    }
+#endif
 }
+
+#ifdef FT_TIMELINE
+extern "C" int tmpnn_debug_ft_timeline(unsigned long long* out16, int reset) {
+    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_ft_timeline), sizeof(unsigned long long) * 16) != hipSuccess) return -1;
+    if (reset) {
+        unsigned long long z[16] = {};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_ft_timeline), z, sizeof(z)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif
 
 // out[r][0:NOUT] = in[rows[r]][0:H] @ Wt[H][NOUT]   (no bias; H <= 64; NOUT multiple of 32).  Used to
 // project the det rows once per call (P = h[dets] W_ih^T) for the XMODE 3 forward.

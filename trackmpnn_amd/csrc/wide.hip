@@ -787,10 +787,18 @@ __global__ __launch_bounds__(512) void k_wide_gru_fwd_ring(WideArgs a, WideTiles
 #endif
                 if (a.gates) {
                     float* gp = a.gates + (size_t)grow * H + col;
+#ifdef WT_NT_GATES     // the planes are next read by the backward pass: streamed past L2, where this block's A rows wait for reuse
+                    auto nt4 = [](float* p, const float4& v) {
+                        wf32x4 x; x[0] = v.x; x[1] = v.y; x[2] = v.z; x[3] = v.w;
+                        __builtin_nontemporal_store(x, reinterpret_cast<wf32x4*>(p));
+                    };
+                    nt4(gp, o_r); nt4(gp + a.gate_plane, o_z); nt4(gp + 2 * a.gate_plane, o_n); nt4(gp + 3 * a.gate_plane, o_hn);
+#else
                     *reinterpret_cast<float4*>(gp) = o_r;
                     *reinterpret_cast<float4*>(gp + a.gate_plane) = o_z;
                     *reinterpret_cast<float4*>(gp + 2 * a.gate_plane) = o_n;
                     *reinterpret_cast<float4*>(gp + 3 * a.gate_plane) = o_hn;
+#endif
                 }
             }
         }

@@ -40,6 +40,10 @@ FWD_TILED = os.environ.get('TMPNN_FWD_TILED', '1') != '0' and os.environ.get('TM
 # input transform in one launch per direction where every window adds few det rows (csrc/intf.hip); TMPNN_INPUT_TF=0 keeps
 # the staged launches of tmpnn_input_bn_*
 INPUT_TF = os.environ.get('TMPNN_INPUT_TF', '1') != '0'
+# Experiment ("save h only"): the H <= 64 edge cell's forward does not write its four gate planes; the
+# backward runs the forward kernel again into the gate planes (and a scratch state) right before the one-pass backward
+# reads them.  Same gradients bit for bit; measured SLOWER (numbers in DESIGN), so off by default.
+RECOMPUTE_GATES = os.environ.get('TMPNN_RECOMPUTE_GATES', '0') == '1'
 
 
 _wide_ws: Dict[torch.device, torch.Tensor] = {}
@@ -270,9 +274,12 @@ def mp_forward(spec: ModelSpec, plan: CallPlan, x: torch.Tensor, h_in: Optional[
             _lib.call('tmpnn_rows_linear', g.det_row.data_ptr(), Dn, hg, GH, H, e_wih_t.data_ptr(), 3 * H,
                       proj.data_ptr(), 3 * H, st)
             if FWD_TILED and E > 0:
+                recompute = RECOMPUTE_GATES and save
                 _lib.call('tmpnn_gru_fwd_tiles', edge_tiles(g, 32).cref(), E, proj.data_ptr(), 3 * H, hg, GH, H,
                           e_whh_t.data_ptr(), P[f + 'edge_gru.bias_ih'].data_ptr(), P[f + 'edge_gru.bias_hh'].data_ptr(),
-                          og, GH, gp, plane, we_g, part_g, N, st)
+                          og, GH, None if recompute else gp, plane, we_g, part_g, N, st)
+                if recompute:
+                    saved.setdefault('proj', {})[gi] = (proj, e_whh_t)
             else:
                 _lib.call('tmpnn_gru_fwd', g.edge_row.data_ptr(), E, 3, g.src_pos.data_ptr(), g.dst_pos.data_ptr(),
                           proj.data_ptr(), 3 * H, 0, H, hg, GH, H, None, e_whh_t.data_ptr(),
@@ -409,6 +416,13 @@ def mp_backward(spec: ModelSpec, plan: CallPlan, saved: dict, P: Dict[str, torch
                       grads[f + 'node_gru.weight_ih'].data_ptr(), grads[f + 'node_gru.weight_hh'].data_ptr(),
                       grads[f + 'node_gru.bias_ih'].data_ptr(), grads[f + 'node_gru.bias_hh'].data_ptr(),
                       ws_w.data_ptr(), ws_w.numel() * 4, st)
+            if saved.get('proj') and gi in saved['proj']:
+                # (RECOMPUTE_GATES) the edge rows of the gate planes, formed again from the saved state
+                proj_s, whh_t_s = saved['proj'][gi]
+                h_scr = _wide_workspace(4 * N * GH, dev, slot=2)
+                _lib.call('tmpnn_gru_fwd_tiles', edge_tiles(g, 32).cref(), E, proj_s.data_ptr(), 3 * H, hg, GH, H,
+                          whh_t_s.data_ptr(), P[f + 'edge_gru.bias_ih'].data_ptr(), P[f + 'edge_gru.bias_hh'].data_ptr(),
+                          h_scr.data_ptr() + 4 * gi * H, GH, gp, plane, None, None, 0, st)
             _lib.call('tmpnn_gru_bwd_fused', g.edge_row.data_ptr(), E, xmode, g.src.data_ptr(), g.dst.data_ptr(),
                       None, 0, 0, IN_e, hg, GH, H,
                       P[f + 'edge_gru.weight_ih'].data_ptr(), P[f + 'edge_gru.weight_hh'].data_ptr(),
