@@ -108,7 +108,7 @@ def stage_profile(model, plan, H):
 
     from trackmpnn_amd import functional as _fn
     from trackmpnn_amd.graph import edge_tiles
-    tiles32 = edge_tiles(g, 32) if _fn.FWD_TILED else None
+    tiles32 = edge_tiles(g, _fn.FWD_TILE_ROWS) if _fn.FWD_TILED else None
 
     def gru_fwd():      # as the training step runs it: det rows projected once, edge cell takes P[src] - P[dst] per edge tile
         _lib.call('tmpnn_rows_linear', g.det_row.data_ptr(), Dn, h.data_ptr(), H, H, wih_t.data_ptr(), 3 * H,

@@ -584,7 +584,7 @@ def check_wide_tiled(H, g):
             'staged tiles': int((cnt <= 40).sum()), 'listed tiles': int((cnt > 40).sum())}
 
 
-def check_fwd_tiles(H, g, order=None):
+def check_fwd_tiles(H, g, order=None, rows=32):
     """tmpnn_gru_fwd_tiles (32-row edge tiles, projected det rows staged in LDS an item ahead; big tiles through their det
     list) must reproduce tmpnn_gru_fwd's xmode 3 BIT FOR BIT: h_out, the four gate planes and the fused head partials."""
     from trackmpnn_amd.graph import build_edge_tiles, edge_tiles
@@ -600,7 +600,7 @@ def check_fwd_tiles(H, g, order=None):
     proj = torch.empty(Dn, 3 * H, device=DEV)
     _lib.call('tmpnn_rows_linear', gd.det_row.data_ptr(), Dn, hD.data_ptr(), ld, H, wih_t.data_ptr(), 3 * H,
               proj.data_ptr(), 3 * H, st())
-    tiles = edge_tiles(gd, 32) if order is None else build_edge_tiles(gd, 32, 4, 8, order=order)
+    tiles = edge_tiles(gd, rows) if order is None else build_edge_tiles(gd, rows, 4, 8 if rows == 32 else 4, order=order)
     cw = H // 32
     outs = []
     for tiled in (False, True):
@@ -618,6 +618,30 @@ def check_fwd_tiles(H, g, order=None):
         torch.cuda.synchronize()
         outs.append((out.cpu(), gates.cpu(), parts.cpu()))
     cnt = (tiles.t_dptr[1:] - tiles.t_dptr[:-1])
+    if rows == 16:
+        # the 16-row form sums 32 k per MFMA instead of 16: same split products, another order -> equal to rounding.  Both
+        # must sit within the bf16x6 bound of the fp64 result; rows outside the edge rows stay untouched bit for bit.
+        er = g.edge_row.long()
+        h64 = hD.double().cpu()[:, :H]
+        gh = h64[er] @ whh_t.double().cpu()
+        gi = proj.double().cpu()[g.src_pos.long()] - proj.double().cpu()[g.dst_pos.long()]
+        b_i, b_h = bih.double().cpu(), bhh.double().cpu()
+        r = torch.sigmoid(gi[:, :H] + b_i[:H] + gh[:, :H] + b_h[:H])
+        z = torch.sigmoid(gi[:, H:2 * H] + b_i[H:2 * H] + gh[:, H:2 * H] + b_h[H:2 * H])
+        hn = gh[:, 2 * H:] + b_h[2 * H:]
+        nn_ = torch.tanh(gi[:, 2 * H:] + b_i[2 * H:] + r * hn)
+        ho = (1 - z) * nn_ + z * h64[er]
+        res = {}
+        for name, (o, gt, pt) in (('ref32', outs[0]), ('t16', outs[1])):
+            res[f'{name} h_out vs fp64'] = (o[er, :H].double() - ho).abs().max().item()
+            res[f'{name} gates vs fp64'] = max((gt[i][er].double() - x).abs().max().item() for i, x in enumerate((r, z, nn_, hn)))
+            res[f'{name} head vs fp64'] = (pt.double().sum(0)[er] - ho @ w_head.double().cpu()).abs().max().item()
+        mask = torch.ones(g.N, dtype=torch.bool); mask[er] = False
+        res['untouched rows bits'] = float(not (torch.equal(outs[0][0][mask], outs[1][0][mask]) and
+                                                torch.equal(outs[0][1][:, mask], outs[1][1][:, mask]) and
+                                                torch.equal(outs[0][0][:, H:], outs[1][0][:, H:])))
+        res['t16 vs ref32 h_out'] = (outs[0][0] - outs[1][0]).abs().max().item()
+        return res
     return {'h_out bits': float(not torch.equal(outs[0][0], outs[1][0])),
             'gates bits': float(not torch.equal(outs[0][1], outs[1][1])),
             'head bits': float(not torch.equal(outs[0][2], outs[1][2])),
@@ -667,6 +691,12 @@ def run_all(report=print):
             for k in ('h_out bits', 'gates bits', 'head bits'):
                 rec(f'fwd tiles H={H} {tag} {k[:-5]} bit-equal', r[k], 0.0)
             report(f'     tiles staged in LDS / read through their det list: {r["staged tiles"]} / {r["listed tiles"]}')
+            # the 16-row form (TMPNN_FWD_TILE_ROWS=16): equal to rounding, both within the bf16x6 bound of the fp64 result
+            r = check_fwd_tiles(H, gt, order, rows=16)
+            rec(f'fwd tiles16 H={H} {tag} untouched rows', r['untouched rows bits'], 0.0)
+            for k, v in r.items():
+                if 'vs fp64' in k:
+                    rec(f'fwd tiles16 H={H} {tag} {k}', v, 6e-6 if 'head' in k else 3e-6)
     for C in (32, 64, 96, 192, 256, 768):
         for k, v in check_heads(C, g, gd).items():
             rec(f'heads C={C} {k}', v, 2e-4)

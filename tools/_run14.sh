@@ -1,5 +1,3 @@
 cd $GRAFT_REPO_ROOT
-for v in fttl fttl_ns fttl_nd; do
-echo "=== $v"
-TMPNN_LIB_PATH=$PWD/trackmpnn_amd/lib/libtmpnn_$v.so timeout -k 10 200 python3 tools/fwd_timeline.py 2>&1 | grep -v Warn | head -11
-done
+timeout -k 10 200 python3 tools/_t16_check.py 2>&1 | grep -v Warn | tail -3 &&
+TILE_ROWS=16 timeout -k 10 200 python3 tools/recompute_ab.py kernels 2>&1 | grep "^{"

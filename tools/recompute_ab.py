@@ -57,7 +57,7 @@ def kernels():
     bih, bhh = P[f + 'edge_gru.bias_ih'].detach(), P[f + 'edge_gru.bias_hh'].detach()
     proj = torch.empty(g.Dn, 3 * H, device=dev)
     _lib.call('tmpnn_rows_linear', g.det_row.data_ptr(), g.Dn, h.data_ptr(), H, H, wih_t.data_ptr(), 3 * H, proj.data_ptr(), 3 * H, st)
-    tl = edge_tiles(g, 32)
+    tl = edge_tiles(g, int(os.environ.get('TILE_ROWS', '32')))
     whead = torch.randn(H, device=dev); part = torch.empty(8, N, device=dev)
     def mk(save, head):
         def fn():

@@ -18,6 +18,7 @@
 #include <stdlib.h>
 
 namespace tmpnn {
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // sigmoid / tanh on the hardware transcendentals (v_exp_f32, v_rcp_f32: 1 ulp each).  Both stay within
 // ~3e-7 of the libm results, far inside the 1e-4 parity budget, at a fraction of the VALU cost
@@ -1303,6 +1304,311 @@ extern "C" int tmpnn_debug_ft_timeline(unsigned long long* out16, int reset) {
     return 0;
 }
 #endif
+
+// ---- the tiled forward at FOUR waves per SIMD (edge tiles of 16 rows) ------------------------------------------------------
+// The s_memtime profile of k_gru_fwd_split_tiled (tools/fwd_timeline.py) shows what holds it: an item is one dependent
+// chain per wave -- operand wait, split, 72 MFMAs (14 % of the item's time), P reads, gate arithmetic, five planes through
+// the staging tile, the next item's DMA requests -- and with 250 registers a SIMD holds two such chains; the vector ALU is
+// ~45 % busy, the matrix pipe ~20 %, and every in-order vmcnt wait on a fresh index load also waits for the 20 stores in
+// front of it.  Here an item is 16 rows x 32 columns on v_mfma_f32_16x16x32_bf16 with the WEIGHTS as the A operand:
+//   * lane (n = lane & 15, kg = lane >> 4) holds FOUR CONSECUTIVE COLUMNS of row n of each 16 x 16 result tile, so the five
+//     output planes leave as 16-byte stores straight from the accumulators -- no staging tile, no LDS round trips, no
+//     cross-lane row ids (a lane stores to its own row);
+//   * half the accumulators, operands and epilogue values per wave: <= 128 registers, sixteen waves per CU;
+//   * the tile descriptor (row, endpoint positions, det list) is requested TWO items ahead, the operand rows one item
+//     ahead from a row id that landed an item ago: no wait of the loop is on a load younger than an item.
+// K order inside a product differs from the 32 x 32 x 16 form (32 k per MFMA), so results match k_gru_fwd_split to
+// rounding, not bit for bit (both are the fp32-accurate bf16x6 split; tests bound both against fp64).
+// MEASURED (C2 stage graph, 6.03 M rows, same box): 2.74 ms with gates + head against 2.55 for the 32-row kernel; 1.51
+// against 1.59 without the gate planes.  Twice the waves did not shorten the launch: what a wave waits for is not latency
+// it could hide behind its neighbours but its own stores -- vmcnt retires loads and stores in issue order, so the first
+// wait on any load issued after an item's ten 1-KB stores is a wait for those stores, for every wave of the CU at once.
+// Kept as TMPNN_FWD_TILE_ROWS=16 (tiles of 16 rows); the default stays the 32-row kernel.  DESIGN.md section 4.
+static constexpr int T16_CAP = 12;                             // dets staged per item (C2 tiles: 8-10)
+static constexpr int T16_AREA = T16_CAP * TP_LD;               // floats per wave
+
+__device__ __forceinline__ f32x4 mfma16_x6(const uint4& a1, const uint4& a2, const uint4& a3, const Split8& b, f32x4 c) {
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a3), __builtin_bit_cast(bf16x8, b.p1), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a1), __builtin_bit_cast(bf16x8, b.p3), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a2), __builtin_bit_cast(bf16x8, b.p2), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a2), __builtin_bit_cast(bf16x8, b.p1), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a1), __builtin_bit_cast(bf16x8, b.p2), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a1), __builtin_bit_cast(bf16x8, b.p1), c, 0, 0, 0);
+    return c;
+}
+// descriptor of tile t for lane (n, .), in two parts so that no load of the loop depends on a load of the same iteration:
+// t16_idx (row, endpoint positions, det-list bounds: three loads) two items ahead, t16_det (the list entry of this lane: one
+// load, from bounds that landed an item ago) one item ahead.  Indices are clamped, never skipped: the counted waits rely
+// on a fixed number of memory operations per iteration.
+struct T16Idx { int row, loc, dp0, nd, det; };
+__device__ __forceinline__ T16Idx t16_idx(const FwdTiles& tl, int R, int t, int n) {
+    T16Idx x;
+    const int li = min(16 * t + n, R - 1);
+    x.row = tl.t_row[li];
+    x.loc = tl.t_loc[li];
+    typedef int i32x2u __attribute__((ext_vector_type(2), aligned(4)));
+    const i32x2u dp = *reinterpret_cast<const i32x2u*>(tl.t_dptr + t);      // ONE 8-byte load (hipcc merges the pair anyway)
+    x.dp0 = dp[0];
+    x.nd = dp[1] - dp[0];
+    x.det = 0;
+    return x;
+}
+__device__ __forceinline__ int t16_det(const FwdTiles& tl, const T16Idx& x, int lane) {
+    return tl.t_dets[x.dp0 + min(lane, max(x.nd - 1, 0))];
+}
+__device__ __forceinline__ void nt_store4(float* p, const f32x4& v) {
+#ifdef T16_PLAIN_STORES
+    *reinterpret_cast<f32x4*>(p) = v;
+#else
+    __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(p));
+#endif
+}
+
+template <int H, int WPB>
+__global__ __launch_bounds__(WPB * 64) void k_gru_fwd_split_t16(GruFwdArgs a, FwdTiles tl) {
+    extern __shared__ float lds[];
+    constexpr int H3 = 3 * H, NKS = H / 32, CW = H / 32;
+    // weight pieces as the A operand's fragments: sW[piece][k step s][k group kg][column][8 k] (k = 8 NKS kg + 8 s + j), 16 bytes
+    // per (column, fragment), no padding.  A ds_read_b128 is served in the lane groups {0-3, 12-15, 20-27}, {4-11, 16-19,
+    // 28-31}, ...: sixteen consecutive columns of TWO k groups -- sixteen consecutive 16-byte slots of planes that lie a
+    // multiple of 256 bytes apart: conflict-free (a [column][k] image with any row pitch is 2-way on these groups).
+    uint16_t* sW = reinterpret_cast<uint16_t*>(lds);
+    constexpr int PLANE = H3 * 8;                                     // elements per (piece, s, kg) plane
+    for (int i = threadIdx.x; i < H * H3 / 4; i += WPB * 64) {
+        const int k = i / (H3 / 4), j0 = (i % (H3 / 4)) * 4;
+        const float4 w = *reinterpret_cast<const float4*>(a.whh_t + (size_t)k * H3 + j0);
+        const float wv[4] = {w.x, w.y, w.z, w.w};
+        const int kgp = k / (8 * NKS), sp = (k / 8) % NKS, jp = k & 7;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            uint16_t q1, q2, q3;
+            split1(wv[e], q1, q2, q3);
+            const int o = ((sp * 4 + kgp) * H3 + j0 + e) * 8 + jp;
+            sW[o] = q1;
+            sW[NKS * 4 * PLANE + o] = q2;
+            sW[2 * NKS * 4 * PLANE + o] = q3;
+        }
+    }
+    float* area_base = reinterpret_cast<float*>(sW + 3 * NKS * 4 * PLANE);
+    int* next_item = reinterpret_cast<int*>(area_base + WPB * T16_AREA);
+    float* sBias = reinterpret_cast<float*>(next_item + 4);
+    for (int i = threadIdx.x; i < H; i += WPB * 64) {
+        sBias[i] = a.b_ih[i] + a.b_hh[i];
+        sBias[H + i] = a.b_ih[H + i] + a.b_hh[H + i];
+        sBias[2 * H + i] = a.b_ih[2 * H + i];
+        sBias[3 * H + i] = a.b_hh[2 * H + i];
+        sBias[4 * H + i] = a.logit_part ? a.w_head[i] : 0.f;
+    }
+    if (threadIdx.x == 0) *next_item = 0;
+    __syncthreads();
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int n = lane & 15, kg = lane >> 4;
+    const int items_total = tl.T * CW;
+    const int per_block = (items_total + gridDim.x - 1) / gridDim.x;
+    const int item_lo = blockIdx.x * per_block;
+    const int item_hi = min(items_total, item_lo + per_block);
+    auto claim = [&]() {
+        int v = 0;
+        if (lane == 0) v = atomicAdd(next_item, 1);
+        return __builtin_amdgcn_readfirstlane(v) + item_lo;
+    };
+    int item = claim();
+    if (item >= item_hi) return;
+    int nitem = claim();
+    const int last_t = (item_hi - 1) / CW;                           // (descriptors of items past the range: a valid tile's)
+    int t = item / CW, cw0 = (item % CW) * 32;
+    int nt = nitem < item_hi ? nitem / CW : last_t;
+    T16Idx ix = t16_idx(tl, a.R, t, n);
+    T16Idx nix = t16_idx(tl, a.R, nt, n);
+    ix.det = t16_det(tl, ix, lane);
+    float* stg = area_base + wave * T16_AREA;
+    const uint32_t area = lds_addr_g(stg);
+    auto stage_p = [&](const T16Idx& x, int c0) {
+        if (x.nd <= T16_CAP) tiled_stage_p<H>(a, TiledIdx{x.row, x.loc, x.det, x.nd}, c0, lane, area);
+    };
+    stage_p(ix, cw0);
+    float4 raw[2 * NKS];
+    {
+        const float4* xr = reinterpret_cast<const float4*>(a.h + (size_t)ix.row * a.ld_h + 8 * NKS * kg);
+#pragma unroll
+        for (int i = 0; i < 2 * NKS; ++i) raw[i] = xr[i];
+    }
+    // this item's previous state (the merge term): lane (n, kg) takes the columns it will hold after the matrix phase
+    f32x4 hp4[2];
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+        hp4[ct] = *reinterpret_cast<const f32x4*>(a.h + (size_t)ix.row * a.ld_h + cw0 + 16 * ct + 4 * kg);
+    // stores an item issues (h_out, four gate planes, head partial): all in flight when the next item waits for its P rows
+    const int nst = __builtin_amdgcn_readfirstlane(2 + (a.gates ? 8 : 0) + (a.logit_part ? 1 : 0));
+    bool first = true;
+    // the partner lane n ^ 8 of the output exchange below, and what this lane writes in the two store passes
+    const bool lo = n < 8;
+    const int colw = 16 * (n >> 3) + 4 * kg;                       // pass A: rows n & 7, pass B: rows 8 + (n & 7); 8 lanes = 128 B
+    for (;;) {
+        const bool nvalid = nitem < item_hi;
+        const int ncw0 = (nitem % CW) * 32;
+        const int row = ix.row;
+        const bool live = 16 * t + n < a.R;
+        const bool staged = ix.nd <= T16_CAP;
+        // ---- requests first: the next item's operand rows (its row id landed an item ago) and det-list entry, the
+        // descriptor of the item after that.  At least 2 NKS + 1 + 3 memory operations (the counted wait below assumes the
+        // minimum: more operations in flight only make it stricter).
+        Split8 b[NKS];
+#pragma unroll
+        for (int s_ = 0; s_ < NKS; ++s_) b[s_] = split8(raw[2 * s_], raw[2 * s_ + 1]);
+        {
+            const float4* xr = reinterpret_cast<const float4*>(a.h + (size_t)nix.row * a.ld_h + 8 * NKS * kg);
+#pragma unroll
+            for (int i = 0; i < 2 * NKS; ++i) raw[i] = xr[i];
+        }
+        nix.det = t16_det(tl, nix, lane);
+        const int n2item = claim();
+        const int n2t = n2item < item_hi ? n2item / CW : last_t;
+        const T16Idx n2ix = t16_idx(tl, a.R, n2t, n);
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- matrix phase: 3 gates x 2 column tiles x NKS steps x 6 products
+        f32x4 acc[3][2];
+#pragma unroll
+        for (int g = 0; g < 3; ++g)
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[g][ct][i] = 0.f;
+        {
+            const uint16_t* wp0 = sW + (kg * H3 + cw0 + n) * 8;
+#pragma unroll
+            for (int s_ = 0; s_ < NKS; ++s_)
+#pragma unroll
+                for (int g = 0; g < 3; ++g)
+#pragma unroll
+                    for (int ct = 0; ct < 2; ++ct) {
+                        const uint16_t* wp = wp0 + s_ * 4 * PLANE + (g * H + 16 * ct) * 8;
+                        const uint4 w1 = *reinterpret_cast<const uint4*>(wp);
+                        const uint4 w2 = *reinterpret_cast<const uint4*>(wp + NKS * 4 * PLANE);
+                        const uint4 w3 = *reinterpret_cast<const uint4*>(wp + 2 * NKS * 4 * PLANE);
+                        acc[g][ct] = mfma16_x6(w1, w2, w3, b[s_], acc[g][ct]);
+                    }
+        }
+        // The staged P rows and the previous state of THIS item were requested before the previous item's stores: they
+        // have landed once at most those stores and the 2 NKS + 4 requests above are in flight (vmcnt counts loads and stores
+        // in issue order).
+        if (first) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else if constexpr (NKS == 2) {
+            if (nst == 11) asm volatile("s_waitcnt vmcnt(19)" ::: "memory");
+            else if (nst == 10) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
+            else if (nst == 3) asm volatile("s_waitcnt vmcnt(11)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+        } else {
+            if (nst == 11) asm volatile("s_waitcnt vmcnt(17)" ::: "memory");
+            else if (nst == 10) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            else if (nst == 3) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        }
+        first = false;
+        f32x4 outv[2], o_r[2], o_z[2], o_n[2], o_hn[2];
+        {
+            const int ls = ix.loc & 0xFFFF, ld_ = ix.loc >> 16;
+            const int sdet = __shfl(ix.det, ls, 64), ddet = __shfl(ix.det, ld_, 64);      // (the gather path of big tiles)
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct) {
+                const int co = 16 * ct + 4 * kg;
+                f32x4 gi[3];
+                if (staged) {
+                    const float* ls0 = stg + ls * TP_LD + co;
+                    const float* ld0 = stg + ld_ * TP_LD + co;
+#pragma unroll
+                    for (int g = 0; g < 3; ++g)
+                        gi[g] = *reinterpret_cast<const f32x4*>(ls0 + 32 * g) - *reinterpret_cast<const f32x4*>(ld0 + 32 * g);
+                } else {
+                    const float* ps0 = a.msg + (size_t)sdet * a.ld_msg + cw0 + co;
+                    const float* pd0 = a.msg + (size_t)ddet * a.ld_msg + cw0 + co;
+#pragma unroll
+                    for (int g = 0; g < 3; ++g)
+                        gi[g] = *reinterpret_cast<const f32x4*>(ps0 + g * H) - *reinterpret_cast<const f32x4*>(pd0 + g * H);
+                }
+                const f32x4 b_r = *reinterpret_cast<const f32x4*>(sBias + cw0 + co);
+                const f32x4 b_z = *reinterpret_cast<const f32x4*>(sBias + H + cw0 + co);
+                const f32x4 b_n = *reinterpret_cast<const f32x4*>(sBias + 2 * H + cw0 + co);
+                const f32x4 b_h = *reinterpret_cast<const f32x4*>(sBias + 3 * H + cw0 + co);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float ro = sigmoidf_(acc[0][ct][i] + gi[0][i] + b_r[i]);
+                    const float zo = sigmoidf_(acc[1][ct][i] + gi[1][i] + b_z[i]);
+                    const float ho = acc[2][ct][i] + b_h[i];
+                    const float no = tanhf_((gi[2][i] + b_n[i]) + ro * ho);
+                    outv[ct][i] = (1.0f - zo) * no + zo * hp4[ct][i];
+                    o_r[ct][i] = ro; o_z[ct][i] = zo; o_n[ct][i] = no; o_hn[ct][i] = ho;
+                }
+            }
+        }
+        float p_head = 0.f;
+        if (a.logit_part) {
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct) {
+                const f32x4 w = *reinterpret_cast<const f32x4*>(sBias + 4 * H + cw0 + 16 * ct + 4 * kg);
+                p_head += outv[ct][0] * w[0] + outv[ct][1] * w[1] + outv[ct][2] * w[2] + outv[ct][3] * w[3];
+            }
+            p_head += __shfl_xor(p_head, 16);
+            p_head += __shfl_xor(p_head, 32);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // every read of the staged P rows is back: the area is free
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- the NEXT item's P rows and previous state are requested BEFORE this item's stores
+        const int cw_st = cw0, t_st = t;
+        if (nvalid) {
+            cw0 = ncw0; t = nt; ix = nix; nix = n2ix; nt = n2t; nitem = n2item;
+            stage_p(ix, cw0);
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct)
+                hp4[ct] = *reinterpret_cast<const f32x4*>(a.h + (size_t)ix.row * a.ld_h + cw0 + 16 * ct + 4 * kg);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- stores: lanes n and n ^ 8 exchange one column tile, so that eight lanes cover 128 contiguous bytes of a row
+        // and a store instruction writes 8 rows x 128 B (left as the MFMA leaves them it is 16 rows x 64 B: measured 3.4
+        // against 2.7 ms per launch)
+        {
+            constexpr int ROR8 = 0x128;                              // DPP row_ror:8 = lane n ^ 8 of the 16-lane row
+            const int prow = __builtin_amdgcn_update_dpp(0, row, ROR8, 0xF, 0xF, false);
+            const int plive = __builtin_amdgcn_update_dpp(0, (int)live, ROR8, 0xF, 0xF, false);
+            const int rowA = lo ? row : prow, rowB = lo ? prow : row;
+            const bool liveA = lo ? live : (plive != 0), liveB = lo ? (plive != 0) : live;
+            auto xchg = [&](const f32x4 (&v)[2], f32x4& va, f32x4& vb) {
+                f32x4 rcv;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float snd = lo ? v[1][i] : v[0][i];
+                    rcv[i] = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(snd), ROR8, 0xF, 0xF, false));
+                    va[i] = lo ? v[0][i] : rcv[i];
+                    vb[i] = lo ? rcv[i] : v[1][i];
+                }
+            };
+            f32x4 va, vb;
+            xchg(outv, va, vb);
+            if (liveA) *reinterpret_cast<f32x4*>(a.h_out + (size_t)rowA * a.ld_out + cw_st + colw) = va;
+            if (liveB) *reinterpret_cast<f32x4*>(a.h_out + (size_t)rowB * a.ld_out + cw_st + colw) = vb;
+            if (a.gates) {
+                float* gA = a.gates + (size_t)rowA * H + cw_st + colw;
+                float* gB = a.gates + (size_t)rowB * H + cw_st + colw;
+                xchg(o_r, va, vb);
+                if (liveA) nt_store4(gA, va);
+                if (liveB) nt_store4(gB, vb);
+                xchg(o_z, va, vb);
+                if (liveA) nt_store4(gA + a.gate_plane, va);
+                if (liveB) nt_store4(gB + a.gate_plane, vb);
+                xchg(o_n, va, vb);
+                if (liveA) nt_store4(gA + 2 * a.gate_plane, va);
+                if (liveB) nt_store4(gB + 2 * a.gate_plane, vb);
+                xchg(o_hn, va, vb);
+                if (liveA) nt_store4(gA + 3 * a.gate_plane, va);
+                if (liveB) nt_store4(gB + 3 * a.gate_plane, vb);
+            }
+            if (a.logit_part && kg == 0 && live) a.logit_part[(size_t)(cw_st / 32) * a.part_stride + row] = p_head;
+        }
+        (void)t_st;
+        if (!nvalid) break;
+    }
+}
 
 // out[r][0:NOUT] = in[rows[r]][0:H] @ Wt[H][NOUT]   (no bias; H <= 64; NOUT multiple of 32).  Used to
 // project the det rows once per call (P = h[dets] W_ih^T) for the XMODE 3 forward.
@@ -2792,7 +3098,6 @@ void k_gru_bwd_one(GruBwdFusedArgs a, int ntiles) {
 // lane group kq: all lanes of a ds_read_b128 service group then XOR the same chunk bits into the row swizzle and the read
 // is conflict-free (the plain assignment is 2-way on this layout); W's k order is permuted to match.
 // ==========================================================================================
-typedef float f32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ f32x4 mfma16_bf16(const uint4& a, const uint4& b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
@@ -3319,9 +3624,10 @@ int tmpnn_gru_fwd_tiles(const tmpnn_edge_tiles* tiles, int R, const float* proj,
     if (R == 0) return TMPNN_OK;
     TM_REQUIRE(split_enabled(), "gru_fwd_tiles: the tiled forward is the bf16x6 form (TMPNN_SPLIT=0 keeps tmpnn_gru_fwd)");
     TM_REQUIRE(tiles != nullptr, "gru_fwd_tiles: tiles is null");
-    TM_REQUIRE(tiles->rows_per_tile == 32 && tiles->T > 0 && (long)tiles->T * 32 >= R && (long)(tiles->T - 1) * 32 < R &&
+    const int RPT = tiles->rows_per_tile;
+    TM_REQUIRE((RPT == 32 || RPT == 16) && tiles->T > 0 && (long)tiles->T * RPT >= R && (long)(tiles->T - 1) * RPT < R &&
                    tiles->t_row && tiles->t_loc && tiles->t_dptr && tiles->t_dets,
-               "gru_fwd_tiles: tile list (T=%d, rows_per_tile=%d) does not cover R=%d rows in 32-row tiles", tiles->T,
+               "gru_fwd_tiles: tile list (T=%d, rows_per_tile=%d) does not cover R=%d rows in 16- or 32-row tiles", tiles->T,
                tiles->rows_per_tile, R);
     TM_REQUIRE(proj && h && whh_t && b_ih && b_hh && h_out, "gru_fwd_tiles: null pointer");
     TM_REQUIRE(ld_proj >= 3 * H && (ld_proj & 3) == 0 && aligned16(proj) && ld_h >= H && ld_out >= H && (ld_h & 3) == 0 &&
@@ -3335,6 +3641,17 @@ int tmpnn_gru_fwd_tiles(const tmpnn_edge_tiles* tiles, int R, const float* proj,
     hipStream_t st = as_stream(stream);
     const int ntiles = ceil_div(R, (H == 64) ? 192 : 256);
     dim3 pgrid(ntiles < 256 ? ntiles : 256);
+    if (RPT == 16) {         // sixteen 128-register waves per CU (k_gru_fwd_split_t16)
+        const size_t shm16 = (size_t)3 * 3 * H * H * 2 + sizeof(float) * ((size_t)16 * T16_AREA + 4 + 5 * H);
+        if (H == 64) {
+            TM_SHM_ONCE((k_gru_fwd_split_t16<64, 16>), shm16);
+            hipLaunchKernelGGL((k_gru_fwd_split_t16<64, 16>), pgrid, dim3(1024), shm16, st, a, tl);
+        } else {
+            TM_SHM_ONCE((k_gru_fwd_split_t16<32, 16>), shm16);
+            hipLaunchKernelGGL((k_gru_fwd_split_t16<32, 16>), pgrid, dim3(1024), shm16, st, a, tl);
+        }
+        return check_launch("gru_fwd_split_t16");
+    }
     const size_t shm = (size_t)3 * 3 * H * (H + 8) * 2 + sizeof(float) * ((size_t)8 * TP_AREA + 4 + 5 * H);
     if (H == 64) {
         TM_SHM_ONCE((k_gru_fwd_split_tiled<64, 8>), shm);

@@ -39,6 +39,9 @@ WIDE_TILED = os.environ.get('TMPNN_WIDE_TILED', '1') != '0'
 FWD_TILED = os.environ.get('TMPNN_FWD_TILED', '1') != '0' and os.environ.get('TMPNN_SPLIT', '1')[:1] != '0'
 # input transform in one launch per direction where every window adds few det rows (csrc/intf.hip); TMPNN_INPUT_TF=0 keeps
 # the staged launches of tmpnn_input_bn_*
+# rows per edge tile of the H <= 64 forward: 32 (k_gru_fwd_split_tiled, the default) or 16 (k_gru_fwd_split_t16, sixteen waves
+# per CU, stores straight from the accumulators: measured 7 % slower with the gate planes, 5 % faster without)
+FWD_TILE_ROWS = 16 if os.environ.get('TMPNN_FWD_TILE_ROWS', '32') == '16' else 32
 INPUT_TF = os.environ.get('TMPNN_INPUT_TF', '1') != '0'
 # Experiment ("save h only"): the H <= 64 edge cell's forward does not write its four gate planes; the
 # backward runs the forward kernel again into the gate planes (and a scratch state) right before the one-pass backward
@@ -275,7 +278,7 @@ def mp_forward(spec: ModelSpec, plan: CallPlan, x: torch.Tensor, h_in: Optional[
                       proj.data_ptr(), 3 * H, st)
             if FWD_TILED and E > 0:
                 recompute = RECOMPUTE_GATES and save
-                _lib.call('tmpnn_gru_fwd_tiles', edge_tiles(g, 32).cref(), E, proj.data_ptr(), 3 * H, hg, GH, H,
+                _lib.call('tmpnn_gru_fwd_tiles', edge_tiles(g, FWD_TILE_ROWS).cref(), E, proj.data_ptr(), 3 * H, hg, GH, H,
                           e_whh_t.data_ptr(), P[f + 'edge_gru.bias_ih'].data_ptr(), P[f + 'edge_gru.bias_hh'].data_ptr(),
                           og, GH, None if recompute else gp, plane, we_g, part_g, N, st)
                 if recompute:
@@ -420,7 +423,7 @@ def mp_backward(spec: ModelSpec, plan: CallPlan, saved: dict, P: Dict[str, torch
                 # (RECOMPUTE_GATES) the edge rows of the gate planes, formed again from the saved state
                 proj_s, whh_t_s = saved['proj'][gi]
                 h_scr = _wide_workspace(4 * N * GH, dev, slot=2)
-                _lib.call('tmpnn_gru_fwd_tiles', edge_tiles(g, 32).cref(), E, proj_s.data_ptr(), 3 * H, hg, GH, H,
+                _lib.call('tmpnn_gru_fwd_tiles', edge_tiles(g, FWD_TILE_ROWS).cref(), E, proj_s.data_ptr(), 3 * H, hg, GH, H,
                           whh_t_s.data_ptr(), P[f + 'edge_gru.bias_ih'].data_ptr(), P[f + 'edge_gru.bias_hh'].data_ptr(),
                           h_scr.data_ptr() + 4 * gi * H, GH, gp, plane, None, None, 0, st)
             _lib.call('tmpnn_gru_bwd_fused', g.edge_row.data_ptr(), E, xmode, g.src.data_ptr(), g.dst.data_ptr(),

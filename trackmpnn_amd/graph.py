@@ -160,6 +160,8 @@ def edge_tiles(graph: FrameGraph, rows_per_tile: int = 128) -> EdgeTiles:
         blocks = graph.E / runs >= rows_per_tile / 2
         if rows_per_tile == 128:
             t = build_edge_tiles(graph, 128, 8, 16, order='blocks' if blocks else 'rows')
+        elif rows_per_tile == 16:
+            t = build_edge_tiles(graph, 16, 4, 4, order='blocks' if blocks else 'rows')
         else:
             t = build_edge_tiles(graph, rows_per_tile, 4, 8, order='blocks' if blocks else 'rows')
         cache[rows_per_tile] = t
