@@ -462,3 +462,107 @@ def test_dense_scene_above_4096_rows(monkeypatch):
     for k in g0:
         tol = 1e-4 * gscale * (10 if (k.endswith('.0.bias') and k.startswith('input_')) else 1)
         assert (g0[k] - g1[k]).abs().max().item() <= tol, f'grad {k}: {(g0[k] - g1[k]).abs().max().item()} > {tol}'
+
+
+def _window(gold):
+    return [(gold.t(f'c{c}/x').to(DEV), gold.adjacency(c, 'node_adj', DEV), gold.adjacency(c, 'edge_adj', DEV))
+            for c in range(gold.ncalls)]
+
+
+def _run_window(model, calls):
+    h, loss = None, 0.0
+    for x, na, ea in calls:
+        s, l, h, _ = model(x, h, na, ea)
+        loss = loss + (l * l).sum() + s.sum()
+    return loss + h.sum()
+
+
+def test_model_can_be_copied_and_pickled_after_use():
+    """copy.deepcopy / pickle / torch.save of a module that has run the batch-1 path (its caches hold ctypes pointer
+    structs and a non-leaf sink tensor): the copy is a working, independent model with the same parameters."""
+    import copy
+    import io
+    import pickle
+    from tests.test_parity_gpu import build_model
+    gold = Golden('roll_2d_diff_k0_train')
+    model = build_model(gold.meta, gold.params())
+    calls = _window(gold)
+    ref = _run_window(model, calls)
+    ref.backward()
+    twin = copy.deepcopy(model)
+    again = pickle.loads(pickle.dumps(model))
+    buf = io.BytesIO()
+    torch.save(model, buf)
+    buf.seek(0)
+    loaded = torch.load(buf, weights_only=False)
+    for m in (twin, again, loaded):
+        assert m._small is not model._small and m._sink is None
+        out = _run_window(m, calls)
+        assert torch.equal(out.detach(), ref.detach())
+        out.backward()
+        for (n1, p1), (_, p2) in zip(model.named_parameters(), m.named_parameters()):
+            assert p1.data_ptr() != p2.data_ptr()
+            assert torch.allclose(p1.grad, p2.grad, rtol=1e-5, atol=1e-6), n1
+    # the copy is independent: changing it leaves the original's results alone
+    with torch.no_grad():
+        for p in twin.parameters():
+            p.mul_(0.5)
+    assert torch.equal(_run_window(model, calls).detach(), ref.detach())
+
+
+def test_refresh_weights_after_an_edit_through_data():
+    """The GRU operand images of the fused iteration follow the weights' version counters; `p.data` edits do not move
+    them.  TrackMPNN.refresh_weights() re-reads everything: results then equal a model built with the edited weights."""
+    from tests.test_parity_gpu import build_model
+    gold = Golden('roll_2d_diff_k0_train')
+    model = build_model(gold.meta, gold.params())
+    calls = _window(gold)
+    before = _run_window(model, calls).detach()
+    w = model.factor_grus[0].edge_gru.weight_hh
+    w.data.mul_(0.5)                                   # (no version bump)
+    model.refresh_weights()
+    after = _run_window(model, calls).detach()
+    params = {k: v.clone() for k, v in gold.params().items()}
+    params['factor_grus.0.edge_gru.weight_hh'] = params['factor_grus.0.edge_gru.weight_hh'] * 0.5
+    fresh = build_model(gold.meta, params)
+    assert not torch.equal(before, after)
+    assert torch.equal(after, _run_window(fresh, calls).detach())
+
+
+def test_frozen_model_in_grad_mode_returns_plain_tensors():
+    """infer.py runs the model without torch.no_grad(): with every parameter frozen nothing needs a gradient, and the
+    native node must hand back plain tensors (usable with .numpy()) exactly like the Python node."""
+    from tests.test_parity_gpu import build_model
+    gold = Golden('roll_2d_diff_k0_train')
+    model = build_model(gold.meta, gold.params()).eval()
+    for p in model.parameters():
+        p.requires_grad_(False)
+    assert torch.is_grad_enabled()
+    h = None
+    for x, na, ea in _window(gold):
+        s, l, h, _ = model(x, h, na, ea)
+        assert not s.requires_grad and not l.requires_grad and not h.requires_grad
+        s.cpu().numpy()
+
+
+def test_native_node_outlives_the_python_side_caches():
+    """The native node's backward reads its parameter structs from copies it owns: dropping every Python-side cache
+    (SmallPath.invalidate, what .to() / load_state_dict / a detected storage swap do) between forward and backward
+    changes nothing."""
+    from tests.test_parity_gpu import build_model
+    gold = Golden('roll_2d_diff_k0_train')
+    calls = _window(gold)
+    grads = []
+    for drop in (False, True):
+        model = build_model(gold.meta, gold.params())
+        loss = _run_window(model, calls)
+        if drop:
+            model._small.invalidate()
+            model._small.cparams = None
+            model._small._tmpl = None
+            import gc
+            gc.collect()
+        loss.backward()
+        grads.append([p.grad.clone() for p in model.parameters()])
+    for a, b in zip(*grads):
+        assert torch.equal(a, b)

@@ -13,6 +13,7 @@
 #include <torch/extension.h>
 
 #include <cstdint>
+#include <cstring>
 
 #include "tmpnn.h"
 
@@ -69,7 +70,8 @@ class SmallIterFn : public torch::autograd::Function<SmallIterFn> {
    public:
     static torch::autograd::variable_list forward(torch::autograd::AutogradContext* ctx, torch::Tensor x,
                                                   c10::optional<torch::Tensor> h_in, torch::Tensor anchor,
-                                                  torch::Tensor arena, std::vector<int64_t> info) {
+                                                  torch::Tensor arena, std::vector<int64_t> info,
+                                                  std::vector<torch::Tensor> keep) {
         (void)anchor;
         CallInfo ci;
         TORCH_CHECK(info.size() == 18, "fast_iter: bad call descriptor");
@@ -125,6 +127,17 @@ class SmallIterFn : public torch::autograd::Function<SmallIterFn> {
         TORCH_CHECK(rc == 0, "tmpnn_mp_iter_fwd failed (code ", rc, "): ", reinterpret_cast<err_fn>(ci.f_err)());
         if (ci.need_grad) {
             ctx->saved_data["info"] = info;
+            // What the backward dereferences must live as long as this node, not as long as the Python caches that built
+            // it: the two parameter structs are copied by value, the operand images and (in-place gradient mode) the
+            // gradient tensors are held by reference.
+            auto pod = [](int64_t addr) {
+                torch::Tensor t = at::empty({(int64_t)sizeof(tmpnn_mp_params)}, at::TensorOptions().dtype(torch::kByte));
+                std::memcpy(t.data_ptr(), reinterpret_cast<const void*>(addr), sizeof(tmpnn_mp_params));
+                return t;
+            };
+            ctx->saved_data["params_pod"] = pod(ci.params);
+            ctx->saved_data["grads_pod"] = pod(ci.grads);
+            ctx->saved_data["keep"] = keep;
             ctx->saved_data["n"] = n;
             ctx->saved_data["has_h"] = has_h;
             ctx->saved_data["x_needs"] = x.requires_grad();
@@ -141,7 +154,11 @@ class SmallIterFn : public torch::autograd::Function<SmallIterFn> {
 
     static torch::autograd::variable_list backward(torch::autograd::AutogradContext* ctx,
                                                    torch::autograd::variable_list grad_outputs) {
+        TORCH_CHECK(ctx->saved_data.count("info") != 0,
+                    "fast_iter: backward through a call that saved nothing (it was recorded with need_grad = false)");
         auto info = ctx->saved_data["info"].toIntVector();
+        torch::Tensor params_pod = ctx->saved_data["params_pod"].toTensor();
+        torch::Tensor grads_pod = ctx->saved_data["grads_pod"].toTensor();
         const int64_t n = ctx->saved_data["n"].toInt();
         const bool has_h = ctx->saved_data["has_h"].toBool();
         const bool x_needs = ctx->saved_data["x_needs"].toBool();
@@ -183,14 +200,14 @@ class SmallIterFn : public torch::autograd::Function<SmallIterFn> {
         const int64_t sink_total = info[17];
         torch::Tensor gflat;
         tmpnn_mp_params gs;
-        const tmpnn_mp_params* grads = reinterpret_cast<const tmpnn_mp_params*>(info[4]);
+        const tmpnn_mp_params* grads = reinterpret_cast<const tmpnn_mp_params*>(grads_pod.data_ptr());
         if (sink_total > 0) {
             gflat = at::zeros({sink_total}, opts);
             gs = rebased(grads, gflat.data_ptr());
             grads = &gs;
         }
         const int rc = reinterpret_cast<bwd_fn>(info[1])(
-            reinterpret_cast<const tmpnn_mp_params*>(info[3]), reinterpret_cast<const float*>(info[5]),
+            reinterpret_cast<const tmpnn_mp_params*>(params_pod.data_ptr()), reinterpret_cast<const float*>(info[5]),
             &dg, (int)n, n > 0 ? xd.data_ptr<float>() : nullptr,
             n > 0 ? (int)xd.size(1) : 0, h_cat.data_ptr<float>(), nullptr, scores.data_ptr<float>(),
             save.data_ptr<float>(), info[14] != 0 ? 1 : 0, ds, st_ds, dl, st_dl, dh, d_h.data_ptr<float>(),
@@ -200,13 +217,14 @@ class SmallIterFn : public torch::autograd::Function<SmallIterFn> {
         if (x_needs && !need_x) d_x = at::zeros({n, F_total}, opts);
         torch::Tensor d_h_in;
         if (has_h && N - n > 0) d_h_in = d_h.narrow(0, 0, N - n);
-        return {d_x, d_h_in, gflat, torch::Tensor(), torch::Tensor()};
+        return {d_x, d_h_in, gflat, torch::Tensor(), torch::Tensor(), torch::Tensor()};
     }
 };
 
+// keep: tensors the backward reads through raw pointers of `info` (operand images; in-place mode: the gradient tensors)
 std::vector<torch::Tensor> small_iter(torch::Tensor x, c10::optional<torch::Tensor> h_in, torch::Tensor anchor,
-                                      torch::Tensor arena, std::vector<int64_t> info) {
-    return SmallIterFn::apply(x, h_in, anchor, arena, info);
+                                      torch::Tensor arena, std::vector<int64_t> info, std::vector<torch::Tensor> keep) {
+    return SmallIterFn::apply(x, h_in, anchor, arena, info, keep);
 }
 
 }  // namespace

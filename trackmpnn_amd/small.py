@@ -9,6 +9,8 @@ anything else takes the staged path of functional.py.  There is no fallback to t
 """
 from __future__ import annotations
 
+import os
+
 import ctypes as C
 from typing import List, Optional
 
@@ -49,6 +51,9 @@ def fast_module():
                 except Exception:      # noqa: BLE001  (ABI mismatch with the installed torch: stay on the Python node)
                     _fast_mod = None
     return _fast_mod
+
+
+_DEBUG = os.environ.get('TMPNN_DEBUG', '0') == '1'
 
 
 class SmallPath:
@@ -121,7 +126,8 @@ class SmallPath:
             self._w_idx = [i for i, nm in enumerate(self.names) if nm.endswith(('gru.weight_ih', 'gru.weight_hh'))]
         vkey = tuple(plist[i]._version for i in self._w_idx)
         capturing = torch.cuda.is_current_stream_capturing()
-        if vkey != self._ver_key or capturing:
+        # (edits through `.data` do not move the version counters: TrackMPNN.refresh_weights(); TMPNN_DEBUG=1 rebuilds always)
+        if vkey != self._ver_key or capturing or _DEBUG:
             lib = _lib.load()
             spec = self.spec
             if self.prep is None or self.prep.device != plist[0].device:
@@ -170,7 +176,8 @@ class SmallPath:
         self._grad_struct_cache.clear()
 
     def grad_struct(self, tensors) -> _lib.CMpParams:
-        """Pointer struct over a list of gradient tensors (param_names() order); cached by their data pointers."""
+        """Pointer struct over a list of gradient tensors (param_names() order); cached by their data pointers.  The
+        tensors ride along on the struct (`_keep`): the native node holds them for as long as it may write through it."""
         key = tuple(t.data_ptr() for t in tensors)
         st = self._grad_struct_cache.get(key)
         if st is None:
@@ -178,8 +185,14 @@ class SmallPath:
                 self._grad_struct_cache.clear()
             st = _lib.CMpParams()
             self._fill(st, dict(zip(self.names, key)).__getitem__)
+            st._keep = list(tensors)
             self._grad_struct_cache[key] = st
         return st
+
+    def keep(self, gst=None) -> list:
+        """What a native node must keep alive besides its own buffers: the operand images and, in the in-place gradient
+        mode, the gradient tensors of `gst`."""
+        return [self.prep] + gst._keep if gst is not None and hasattr(gst, '_keep') else [self.prep]
 
 
 class _ParamSink(torch.autograd.Function):

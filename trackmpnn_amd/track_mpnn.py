@@ -124,6 +124,35 @@ class TrackMPNN(nn.Module):
         else:
             super().__setattr__(name, value)
 
+    def _drop_caches(self):
+        self._small.invalidate()
+        self._plist = self._bufs = self._anchor = None
+        self._sink = self._sink_key = None
+        self._anch_key = None
+        self._anch_calls = 0
+        self._gst = None
+        self._graph_cache = None
+        self._pending_graphs = []
+
+    def __getstate__(self):
+        # copy.deepcopy(model), pickle, torch.save(model): the batch-1 path's caches hold ctypes pointer structs, function
+        # pointers and a non-leaf sink tensor -- none of them copyable, all of them rebuilt on the next forward call
+        state = self.__dict__.copy()
+        for k in TrackMPNN._PLAIN:
+            state[k] = [] if k == '_pending_graphs' else (0 if k == '_anch_calls' else None)
+        state['_small'] = None
+        return state
+
+    def __setstate__(self, state):
+        self.__dict__.update(state)
+        object.__setattr__(self, '_small', SmallPath(self))
+
+    def refresh_weights(self):
+        """Re-read every parameter for the batch-1 path.  Its GRU operand images are rebuilt when a weight's version
+        counter moves (optimizer steps, in-place ops, load_state_dict); an edit through `.data` (`p.data.copy_`, an EMA
+        swap, `p.data.normal_()`) does not move it -- call this after such an edit.  TMPNN_DEBUG=1 rebuilds on every call."""
+        self._drop_caches()
+
     def _apply(self, fn, *args, **kwargs):
         # .cuda() / .to() / .float(): parameter storage moves -> drop every cached device pointer
         out = super()._apply(fn, *args, **kwargs)
@@ -308,7 +337,7 @@ class TrackMPNN(nn.Module):
                 # C++ autograd node (csrc_host/fast_iter.cpp): same kernels, no interpreter between the allocations
                 sp = self._small
                 info = sp.fast_info(params, graph, self._gst, self.training, need_grad, append, spare)
-                scores, logits, h_out = fast.small_iter(x, h_in, self._anchor, graph.arena, info)
+                scores, logits, h_out = fast.small_iter(x, h_in, self._anchor, graph.arena, info, sp.keep(self._gst))
             else:
                 scores, logits, h_out = _SmallIter.apply(call, x, h_in, self._anchor)
         elif pgrad and fast_module() is not None and graph.cap == graph.N and all(p.requires_grad for p in params):
@@ -321,16 +350,19 @@ class TrackMPNN(nn.Module):
                 self._sink = _ParamSink.apply(total, offs, shapes, *params)
                 self._sink_key = key
             info = sp.fast_info(params, graph, tmpl, self.training, need_grad, append, spare, sink_total=total)
-            scores, logits, h_out = fast_module().small_iter(x, h_in, self._sink, graph.arena, info)
+            scores, logits, h_out = fast_module().small_iter(x, h_in, self._sink, graph.arena, info, sp.keep())
         else:
             fast = fast_module() if not need_grad else None
             if fast is not None and graph.cap == graph.N:
                 # inference (nothing needs a gradient): the native node as well -- it saves nothing and records nothing
+                # (under no_grad: with grad mode on and a frozen model the node would otherwise hand back outputs that
+                #  require grad over a backward with nothing saved -- the Python node returns plain tensors there too)
                 if self._anchor is None or self._anchor.device != x.device:
                     self._anchor = torch.zeros(1, device=x.device, requires_grad=True)
                 sp = self._small
                 info = sp.fast_info(params, graph, sp.params(params), self.training, False, append, spare)
-                scores, logits, h_out = fast.small_iter(x, h_in, self._anchor, graph.arena, info)
+                with torch.no_grad():
+                    scores, logits, h_out = fast.small_iter(x, h_in, self._anchor, graph.arena, info, sp.keep())
             else:
                 scores, logits, h_out = _SmallIter.apply(call, x, h_in, *params)
         h_out._tmpnn_spare_rows = spare
