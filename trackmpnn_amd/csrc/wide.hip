@@ -1245,61 +1245,49 @@ __global__ __launch_bounds__(512) void k_wide_dw(WideDwArgs q, int mt_count, int
         if (nchunk > 1) dw_issue(q, r_lo + 32 + srow, r_end, ca, cb, raw);
     }
     __syncthreads();
-    // fragment reads of one (16-row k block, 32-column tile): three pieces, two transposing 8-byte reads each
-    auto read_b = [&](const uint16_t* sB, int kb, uint4 (&b)[3]) {
-        const int row0 = kb * 16 + 8 * half + tq, col = bt * 32 + 16 * tg + 4 * tp;
-        const uint16_t* p0 = sB + w_swz<128>(row0, col);
-        const uint16_t* p1 = sB + w_swz<128>(row0 + 4, col);
-#pragma unroll
-        for (int pc = 0; pc < 3; ++pc) {
-            const uint2 u0 = w_read_tr(p0 + pc * 32 * 128), u1 = w_read_tr(p1 + pc * 32 * 128);
-            b[pc] = make_uint4(u0.x, u0.y, u1.x, u1.y);
-        }
-    };
-    auto read_a = [&](const uint16_t* sA, int kb, int j, uint4 (&a)[3]) {
-        const int row0 = kb * 16 + 8 * half + tq, col = (jt0 + j) * 32 + 16 * tg + 4 * tp;
-        const uint16_t* p0 = sA + w_swz<256>(row0, col);
-        const uint16_t* p1 = sA + w_swz<256>(row0 + 4, col);
-#pragma unroll
-        for (int pc = 0; pc < 3; ++pc) {
-            const uint2 u0 = w_read_tr(p0 + pc * 32 * 256), u1 = w_read_tr(p1 + pc * 32 * 256);
-            a[pc] = make_uint4(u0.x, u0.y, u1.x, u1.y);
-        }
-    };
+    // (measured and not kept: the fragments of step s + 1 requested before the MFMAs of step s through two rotating operand
+    //  sets, the next chunk's staging moved into the middle of the matrix phase -- bit-identical and 1 ms per C5 iteration
+    //  SLOWER than the compiler's own placement below, same box)
     for (int ch = 0; ch < nchunk; ++ch) {
         uint16_t* sA = base + (ch & 1) * (DW_A + DW_B);
         uint16_t* sB = sA + DW_A;
         uint16_t* nA = base + ((ch & 1) ^ 1) * (DW_A + DW_B);
-        // six steps (k block kb, gate tile j) of six MFMAs; the fragments of step s + 1 are requested before the MFMAs of
-        // step s (a wave issues in order: read at the point of use, every step began with an LDS round trip), and the next
-        // chunk's staging -- split, 15 LDS writes -- sits in the middle of the matrix phase, where the compiler can place it
-        // under the MFMAs (DW_STAGE_LAST keeps it behind them)
-        uint4 bq[2][3], aq[2][3];
-        read_b(sB, 0, bq[0]);
-        read_a(sA, 0, 0, aq[0]);
 #pragma unroll
-        for (int s_ = 0; s_ < 6; ++s_) {
-            const int kb = s_ / 3, j = s_ % 3;
-            if (s_ < 5) read_a(sA, (s_ + 1) / 3, (s_ + 1) % 3, aq[(s_ + 1) & 1]);
-            if (s_ == 1) read_b(sB, 1, bq[1]);
-            __builtin_amdgcn_sched_barrier(0);
-            const uint4 (&a)[3] = aq[s_ & 1];
-            const uint4 (&b)[3] = bq[kb];
-            acc[j] = w_mfma(a[2], b[0], acc[j]);
-            acc[j] = w_mfma(a[0], b[2], acc[j]);
-            acc[j] = w_mfma(a[1], b[1], acc[j]);
-            acc[j] = w_mfma(a[1], b[0], acc[j]);
-            acc[j] = w_mfma(a[0], b[1], acc[j]);
-            acc[j] = w_mfma(a[0], b[0], acc[j]);
-#ifndef DW_STAGE_LAST
-            if (s_ == 2 && ch + 1 < nchunk) stage(raw, nA, nA + DW_A);
-#endif
-            if (s_ != 2) __builtin_amdgcn_sched_barrier(0);
+        for (int kb = 0; kb < 2; ++kb) {
+            const int row0 = kb * 16 + 8 * half + tq;
+            uint4 b1, b2, b3;
+            {
+                const int col = bt * 32 + 16 * tg + 4 * tp;
+                const uint16_t* p0 = sB + w_swz<128>(row0, col);
+                const uint16_t* p1 = sB + w_swz<128>(row0 + 4, col);
+                const uint2 u0 = w_read_tr(p0), u1 = w_read_tr(p1);
+                const uint2 v0 = w_read_tr(p0 + 32 * 128), v1 = w_read_tr(p1 + 32 * 128);
+                const uint2 w0 = w_read_tr(p0 + 2 * 32 * 128), w1 = w_read_tr(p1 + 2 * 32 * 128);
+                b1 = make_uint4(u0.x, u0.y, u1.x, u1.y); b2 = make_uint4(v0.x, v0.y, v1.x, v1.y);
+                b3 = make_uint4(w0.x, w0.y, w1.x, w1.y);
+            }
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const int col = (jt0 + j) * 32 + 16 * tg + 4 * tp;
+                const uint16_t* p0 = sA + w_swz<256>(row0, col);
+                const uint16_t* p1 = sA + w_swz<256>(row0 + 4, col);
+                const uint2 u0 = w_read_tr(p0), u1 = w_read_tr(p1);
+                const uint2 v0 = w_read_tr(p0 + 32 * 256), v1 = w_read_tr(p1 + 32 * 256);
+                const uint2 w0 = w_read_tr(p0 + 2 * 32 * 256), w1 = w_read_tr(p1 + 2 * 32 * 256);
+                const uint4 a1 = make_uint4(u0.x, u0.y, u1.x, u1.y), a2 = make_uint4(v0.x, v0.y, v1.x, v1.y);
+                const uint4 a3 = make_uint4(w0.x, w0.y, w1.x, w1.y);
+                acc[j] = w_mfma(a3, b1, acc[j]);
+                acc[j] = w_mfma(a1, b3, acc[j]);
+                acc[j] = w_mfma(a2, b2, acc[j]);
+                acc[j] = w_mfma(a2, b1, acc[j]);
+                acc[j] = w_mfma(a1, b2, acc[j]);
+                acc[j] = w_mfma(a1, b1, acc[j]);
+            }
         }
-#ifdef DW_STAGE_LAST
-        if (ch + 1 < nchunk) stage(raw, nA, nA + DW_A);
-#endif
-        if (ch + 2 < nchunk) dw_issue(q, r_lo + (ch + 2) * 32 + srow, r_end, ca, cb, raw);
+        if (ch + 1 < nchunk) {
+            stage(raw, nA, nA + DW_A);
+            if (ch + 2 < nchunk) dw_issue(q, r_lo + (ch + 2) * 32 + srow, r_end, ca, cb, raw);
+        }
         __syncthreads();
     }
     // ---- the block's 192 x 128 tile of this slab
