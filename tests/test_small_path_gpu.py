@@ -566,3 +566,82 @@ def test_native_node_outlives_the_python_side_caches():
         grads.append([p.grad.clone() for p in model.parameters()])
     for a, b in zip(*grads):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize('desc,nhidden,heads,train', [('wide cells', 128, 0, True), ('padded width', 48, 0, True),
+                                                      ('attention heads, eval', 64, 2, False)])
+def test_captured_window_records_models_outside_the_fused_path(desc, nhidden, heads, train):
+    """CapturedWindow on models the fused batch-1 iteration does not cover (attention heads, nhidden 128, a padded width):
+    the staged kernels on plans built before the capture.  A replay gives the gradients and the loss of the eager step
+    through model(x, h, node_adj, edge_adj) bit for bit (deterministic kernels; the attention model in eval mode, where no
+    dropout mask is drawn)."""
+    from trackmpnn_amd import CapturedWindow, TrackMPNN
+    gold = Golden('roll_c2_kitti_car_w5')
+    calls = []
+    for c in range(gold.ncalls):
+        na, ea = gold.adjacency(c, 'node_adj', DEV), gold.adjacency(c, 'edge_adj', DEV)
+        if not na.is_sparse:
+            na, ea = na.to_sparse(), ea.to_sparse()
+        calls.append((gold.t(f'c{c}/x').to(DEV), na, ea))
+    loss_fn = lambda outs, h: torch.cat([l for _, l in outs]).square().mean() + h.square().mean()      # noqa: E731
+
+    def make():
+        torch.manual_seed(11)
+        m = TrackMPNN('2d', 3, nhidden, heads, 'diff').to(DEV)
+        return m.train() if train else m.eval()
+
+    from trackmpnn_amd.dist import GradBucket
+    ref = make()
+    if not getattr(ref, '_padded', False):
+        GradBucket(ref)            # a captured step accumulates in place (kernels add into .grad): compare like with like
+    h, outs = None, []
+    for x, na, ea in calls:
+        s, l, h, _ = ref(x, h, na, ea)
+        outs.append((s, l))
+    loss_ref = loss_fn(outs, h)
+    loss_ref.backward()
+    model = make()
+    h, outs = None, []
+    for x, na, ea in calls:                                  # a first backward creates the .grad buffers the graph bakes in
+        s, l, h, _ = model(x, h, na, ea)
+        outs.append((s, l))
+    loss_fn(outs, h).backward()
+    if getattr(model, '_padded', False):
+        del s, l, h, outs                                    # (padded widths: no autograd graph of the model may be alive)
+    if train:                                                # (BatchNorm running statistics moved: start both from the same)
+        model.load_state_dict(make().state_dict())
+    win = CapturedWindow(model, calls, loss_fn, optimizer=None, bucket=None, warmup=2)
+    assert win.staged
+    first = win.replay().item()                              # (the returned tensor is static: read it before the next replay)
+    assert first == loss_ref.item()
+    for (k, p), (_, q) in zip(model.named_parameters(), ref.named_parameters()):
+        assert torch.equal(p.grad, q.grad), k
+    xs2 = [x * 0.5 for x, _, _ in calls]
+    assert win.replay(xs2).item() != first                   # refreshed features are picked up
+
+
+def test_captured_window_draws_fresh_attention_dropout_per_replay():
+    """Train mode with attention heads: the dropout masks are drawn inside the captured region, so every replay draws new
+    ones (the generator's offset advances per replay) -- two replays of the same step differ, both finite."""
+    from trackmpnn_amd import CapturedWindow, TrackMPNN
+    gold = Golden('roll_c2_kitti_car_w5')
+    calls = []
+    for c in range(gold.ncalls):
+        na, ea = gold.adjacency(c, 'node_adj', DEV), gold.adjacency(c, 'edge_adj', DEV)
+        if not na.is_sparse:
+            na, ea = na.to_sparse(), ea.to_sparse()
+        calls.append((gold.t(f'c{c}/x').to(DEV), na, ea))
+    torch.manual_seed(3)
+    model = TrackMPNN('2d', 3, 64, 2, 'diff').to(DEV).train()
+    with torch.no_grad():
+        for p in model.parameters():
+            p.add_(0.2 * torch.randn_like(p))                # (the default init makes the heads' output nearly input-independent)
+    loss_fn = lambda outs, h: torch.cat([l for _, l in outs]).square().mean() + h.square().mean()      # noqa: E731
+    h, outs = None, []
+    for x, na, ea in calls:
+        s, l, h, _ = model(x, h, na, ea)
+        outs.append((s, l))
+    loss_fn(outs, h).backward()
+    win = CapturedWindow(model, calls, loss_fn, optimizer=None, bucket=None, warmup=2)
+    a, b = win.replay().item(), win.replay().item()
+    assert np.isfinite(a) and np.isfinite(b) and a != b

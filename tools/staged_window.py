@@ -42,3 +42,25 @@ for desc, kw in (('K=2 heads, H=64', dict(nattheads=2, nhidden=64)), ('K=0, H=12
             fn()
         torch.cuda.synchronize()
         print(f'{desc:22s} {name:18s} {(time.perf_counter() - t0) / 30 * 1e3:.3f} ms per window', flush=True)
+
+    # the same training step recorded once (CapturedWindow, staged kernels on prebuilt plans) and replayed
+    from trackmpnn_amd import CapturedWindow
+    from trackmpnn_amd.dist import GradBucket
+    try:
+        torch.manual_seed(5)
+        model = TrackMPNN('2d', 3, kw['nhidden'], kw['nattheads'], 'diff').to(DEV).train()
+        bucket = GradBucket(model) if (not getattr(model, "_padded", False) and os.environ.get("NOBUCKET") != "1") else None
+        if bucket is None:
+            train(); model.zero_grad(set_to_none=False)
+        loss_fn = lambda outs, h: torch.cat([l for _, l in outs]).sum()      # noqa: E731
+        win = CapturedWindow(model, calls, loss_fn, optimizer=None, bucket=bucket)
+        for _ in range(5):
+            win.replay()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(50):
+            win.replay()
+        torch.cuda.synchronize()
+        print(f'{desc:22s} {"captured replay":18s} {(time.perf_counter() - t0) / 50 * 1e3:.3f} ms per window', flush=True)
+    except Exception as e:                                    # noqa: BLE001
+        print(f'{desc:22s} capture failed: {type(e).__name__}: {str(e)[:300]}', flush=True)
