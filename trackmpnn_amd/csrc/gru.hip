@@ -1002,6 +1002,30 @@ __device__ __forceinline__ void tiled_stage_p(const GruFwdArgs& a, const TiledId
     }
 }
 
+// The same requests at a fifth of the vector instructions (the loop above is ~50 per pass -- a division, four cross-lane
+// reads, three selects, 64-bit address arithmetic -- seven passes per item: a quarter of the item's vector work, measured
+// 8 % of its time with the DMA instructions themselves removed).  TWO det rows per pass: lanes 0-23 take the 24 chunks of
+// row 2 k, lanes 25-48 those of row 2 k + 1 (lane 24 is the first row's padding chunk), so a lane's (row half, gate,
+// chunk) never changes and the LDS image -- 25-chunk rows, a pass = 50 consecutive slots -- is the one the general loop
+// writes.
+template <int H>
+__device__ __forceinline__ void tiled_stage_p2(const GruFwdArgs& a, const TiledIdx& x, int cw0, int lane, uint32_t area) {
+    const int sub = lane >= 25 ? 1 : 0, rem = lane - 25 * sub;
+    const int goff = (rem >> 3) * H + cw0 + 4 * (rem & 7);
+    const bool lane_on = rem < 24 && lane < 49;
+#pragma unroll 1
+    for (int k = 0; 2 * k < x.nd; ++k) {
+        const int d0 = __builtin_amdgcn_readlane(x.det, 2 * k), d1 = __builtin_amdgcn_readlane(x.det, min(2 * k + 1, 63));
+        const int det = sub ? d1 : d0;
+        if (lane_on && 2 * k + sub < x.nd) glds16_g(a.msg + (size_t)det * a.ld_msg + goff, area + 800u * k);
+    }
+}
+
+#ifdef FT_DMA_OLD            // comparison builds: the general request loop
+#define FT_STAGE_P tiled_stage_p
+#else
+#define FT_STAGE_P tiled_stage_p2
+#endif
 template <int H, int WPB>
 __global__ __launch_bounds__(WPB * 64) void k_gru_fwd_split_tiled(GruFwdArgs a, FwdTiles tl) {
     extern __shared__ float lds[];
@@ -1054,7 +1078,7 @@ __global__ __launch_bounds__(WPB * 64) void k_gru_fwd_split_tiled(GruFwdArgs a, 
     TiledIdx ix = tiled_idx(tl, a.R, t, c, lane);
     float* stg = area_base + wave * TP_AREA;                   // staged P rows, then the output staging tile
     const uint32_t area = lds_addr_g(stg);
-    if (ix.nd <= TCAP) tiled_stage_p<H>(a, ix, cw0, lane, area);
+    if (ix.nd <= TCAP) FT_STAGE_P<H>(a, ix, cw0, lane, area);
     float4 raw[NQ4];
     {
         const float4* xr = reinterpret_cast<const float4*>(a.h + (size_t)ix.row * a.ld_h + (H / 2) * half);
@@ -1279,7 +1303,7 @@ __global__ __launch_bounds__(WPB * 64) void k_gru_fwd_split_tiled(GruFwdArgs a, 
 #endif
         if (!nvalid) break;
         cw0 = ncw0; t = nt; ix = nix;
-        if (ix.nd <= TCAP) tiled_stage_p<H>(a, ix, cw0, lane, area);      // (the staging tile's last reads are back: stage_store32)
+        if (ix.nd <= TCAP) FT_STAGE_P<H>(a, ix, cw0, lane, area);      // (the staging tile's last reads are back: stage_store32)
 #ifdef FT_TIMELINE
         __builtin_amdgcn_sched_barrier(0);
         FT_MARK(7);                                             // DMA requests of the next item's P rows
