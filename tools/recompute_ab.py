@@ -52,7 +52,8 @@ def kernels():
     g = plans[-1].graph; H = 64; N, E = g.N, g.E
     st = torch.cuda.current_stream().cuda_stream
     P = dict(model.named_parameters()); f = 'factor_grus.0.'
-    h = torch.randn(N, H, device=dev); out = torch.empty(N, H, device=dev); gates = torch.empty(4, N, H, device=dev)
+    pad = int(os.environ.get('PLANE_PAD', '0'))                  # floats between two gate planes (channel-alignment experiment)
+    h = torch.randn(N, H, device=dev); out = torch.empty(N, H, device=dev); gates = torch.empty(4 * (N * H + pad), device=dev)
     wih_t = P[f + 'edge_gru.weight_ih'].detach().t().contiguous(); whh_t = P[f + 'edge_gru.weight_hh'].detach().t().contiguous()
     bih, bhh = P[f + 'edge_gru.bias_ih'].detach(), P[f + 'edge_gru.bias_hh'].detach()
     proj = torch.empty(g.Dn, 3 * H, device=dev)
@@ -62,10 +63,10 @@ def kernels():
     def mk(save, head):
         def fn():
             _lib.call('tmpnn_gru_fwd_tiles', tl.cref(), E, proj.data_ptr(), 3 * H, h.data_ptr(), H, H, whh_t.data_ptr(),
-                      bih.data_ptr(), bhh.data_ptr(), out.data_ptr(), H, gates.data_ptr() if save else None, N * H,
+                      bih.data_ptr(), bhh.data_ptr(), out.data_ptr(), H, gates.data_ptr() if save else None, N * H + pad,
                       whead.data_ptr() if head else None, part.data_ptr() if head else None, N, st)
         return fn
-    res = dict(E=E, N=N)
+    res = dict(E=E, N=N, plane_pad_floats=pad)
     for name, a in (('fwd_tiles gates+head', (1, 1)), ('fwd_tiles no gates, head', (0, 1)), ('fwd_tiles gates, no head', (1, 0))):
         res[name + ' ms'] = round(bench.time_stage(mk(*a)), 4)
     print(json.dumps(res), flush=True)
