@@ -349,10 +349,46 @@ def latency_batch1():
                         eager_edges_per_s=E / eager * 1e3, captured_edges_per_s=E / captured * 1e3,
                         speedup_vs_cpu_oracle_eager=round(cpu_ms / eager, 2),
                         speedup_vs_cpu_oracle_captured=round(cpu_ms / captured, 2))
+    # models OUTSIDE the fused batch-1 path on the same C2 window: staged kernels per call, eager and replayed from one hipGraph
+    try:
+        var = {}
+        for vtag, H_, K_ in (('k2_heads_h64', 64, 2), ('k0_h128', 128, 0)):
+            torch.manual_seed(5)
+            model = TrackMPNN('2d', 3, H_, K_, 'diff').to(dev).train()
+            bucket = GradBucket(model)
+
+            def vstep():
+                h, outs = None, []
+                for x, na, ea in calls:
+                    s, l, h, _ = model(x, h, na, ea)
+                    outs.append((s, l))
+                bucket.zero()
+                loss_fn(outs, h).backward()
+            for _ in range(3):
+                vstep()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(10):
+                vstep()
+            torch.cuda.synchronize()
+            eager_v = (time.perf_counter() - t0) / 10 * 1e3
+            win = CapturedWindow(model, calls, loss_fn, optimizer=None, bucket=bucket)
+            for _ in range(3):
+                win.replay()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(20):
+                win.replay()
+            torch.cuda.synchronize()
+            var[vtag] = dict(eager_ms=round(eager_v, 3), captured_ms=round((time.perf_counter() - t0) / 20 * 1e3, 3))
+        out['c2_window_staged_models'] = var
+    except Exception as e:                                    # noqa: BLE001  (a reporting extra must not sink the bench line)
+        out['c2_window_staged_models'] = dict(error=f'{type(e).__name__}: {e}'[:200])
     out['note'] = ('fwd + loss + bwd of ONE window, fp32; eager = model(x, h, node_adj, edge_adj) per call incl. the '
                    'adjacency conversion, gradients accumulated in place (GradBucket: one extra line in the training loop); '
                    'eager_plain = the import swap alone (gradients returned to autograd); captured = the eager step '
-                   'replayed from one hipGraph; cpu oracle: 1 thread')
+                   'replayed from one hipGraph; cpu oracle: 1 thread; c2_window_staged_models = the same window for models the '
+                   'fused iteration does not cover (attention heads, nhidden 128): staged kernels, eager / captured')
     return out
 
 
@@ -545,6 +581,19 @@ def main():
         on_step = ('gru_fwd_edge', 'gru_bwd_one_edge') if one_pass else \
             ('gru_fwd_edge', 'gru_bwd_data_edge_folded', 'gru_bwd_weights_edge')
         dom = max(on_step, key=lambda k: t[k])
+        # the box's own device-copy rate (quote the measured peak next to the 8 TB/s spec): a 2 GiB -> 2 GiB
+        # torch copy (read + write counted) and a fill (write only), HIP events
+        try:
+            src_ = torch.empty(1 << 29, dtype=torch.float32, device=dev)
+            dst_ = torch.empty_like(src_)
+            t_copy = time_stage(lambda: dst_.copy_(src_), iters=5)
+            t_fill = time_stage(lambda: dst_.fill_(1.0), iters=5)
+            extra['hbm_measured'] = dict(copy_GBs=round(2 * src_.numel() * 4 / (t_copy * 1e-3) / 1e9, 0),
+                                         fill_GBs=round(src_.numel() * 4 / (t_fill * 1e-3) / 1e9, 0),
+                                         note='2 GiB device copy (read + write) / fill, same box, this run')
+            del src_, dst_
+        except RuntimeError:
+            pass
         # the dominant kernel against BOTH roofs; the one it sits closer to is reported as its bound.  Matrix-pipe
         # time: f32-equivalent flops at the f32-input MFMA rate, or 6 bf16 MFMAs (1/16 of the f32 cost each) per
         # f32 MFMA of work on the split path.
@@ -556,6 +605,8 @@ def main():
             roofline = dict(bound='hbm', kernel=dom, achieved=gbs, peak=HBM_PEAK_GBS, unit='GB/s', frac=hbm_frac,
                             traffic=pmc_traffic(dom, plans[-1].graph.E), ms=t[dom], algorithmic_bytes=nbytes[dom],
                             matrix_pipe_frac=pipe_frac, f32_equiv_tflops=tf)
+            if 'hbm_measured' in extra:        # the same achieved rate against what a plain device copy reaches on this box
+                roofline['frac_of_measured_copy'] = round(gbs / extra['hbm_measured']['copy_GBs'], 3)
         else:
             roofline = dict(bound='mfma', kernel=dom, achieved=tf, peak=MFMA_F32_PEAK_TF, unit='TFLOP/s', frac=pipe_frac,
                             traffic=pmc_traffic(dom, plans[-1].graph.E), ms=t[dom], hbm_frac=hbm_frac)
@@ -571,6 +622,7 @@ def main():
             gather_GBs=nbytes['gather_diff'] / (t['gather_diff'] * 1e-3) / 1e9,
             segsum_GBs=nbytes['segsum'] / (t['segsum'] * 1e-3) / 1e9)
         extra['stage_ms'] = {k: round(v, 4) for k, v in t.items()}
+
         # what ONE edge row costs per forward call + its share of the backward in the staged step (algorithmic bytes of
         # the kernels as the step runs them: edge forward, folded backward-data, backward-weights, row F and its
         # adjoint) against the aggregation-only model of SURVEY 8(d) (16H + 36): saving the gates dominates
