@@ -118,3 +118,33 @@ def test_focal_loss_empty_selection_matches_reference_semantics():
     assert out.item() == 0.0
     out.backward()
     assert s.grad.shape == (0,)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('gamma,alpha,mean', [(0, None, True), (2, 0.25, False)])
+def test_focal_loss_over_a_row_list_equals_the_gathered_form(gamma, alpha, mean):
+    """FocalLoss(scores_full, targets_full, rows=idx) == FocalLoss(scores_full[idx], targets_full[idx]) -- train.py:76-81's
+    selections without the gathers: same value bit for bit, same gradient on the full score vector (zero outside idx);
+    byte targets (create_targets(as_bytes=True)) are taken as they are; an empty list behaves like an empty selection."""
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU')
+    from trackmpnn_amd.loss import FocalLoss
+    gen = torch.Generator().manual_seed(7)
+    N = 5000
+    s0 = torch.rand(N, 1, generator=gen).to('cuda:0')
+    t = (torch.rand(N, generator=gen) < 0.3).to('cuda:0')
+    idx = torch.randperm(N, generator=gen)[:1777].sort().values.to('cuda:0')
+    loss = FocalLoss(gamma=gamma, alpha=alpha, size_average=mean)
+    a = s0.clone().requires_grad_(True)
+    la = loss(a[idx, 0], t[idx].long())
+    la.backward()
+    b = s0.clone().requires_grad_(True)
+    lb = loss(b[:, 0], t.to(torch.uint8), rows=idx.to(torch.int32))
+    lb.backward()
+    assert la.item() == lb.item()
+    assert torch.equal(a.grad, b.grad)
+    outside = torch.ones(N, dtype=torch.bool, device='cuda:0')
+    outside[idx] = False
+    assert float(b.grad[outside].abs().max()) == 0.0
+    empty = loss(b[:, 0], t.to(torch.uint8), rows=idx[:0].to(torch.int32))
+    assert torch.isnan(empty) if mean else empty.item() == 0.0

@@ -83,6 +83,13 @@ if have(f'gpurun_out/{tag}_stats/**/*_kernel_stats.csv', f'gpurun_out/{tag}_benc
                     '`oracle/time_reference_loops.py`).\n\n```json\n')
             f.write(json.dumps(lb, indent=1))
             f.write('\n```\n')
+            if du.get('latency_batch1'):
+                f.write('\n## One window through the drop-in call (`latency_batch1`: fwd + loss + bwd; eager / captured; models outside the '
+                        'fused path in `c2_window_staged_models`)\n\n```json\n')
+                f.write(json.dumps(du['latency_batch1'], indent=1))
+                f.write('\n```\n')
+            if du.get('hbm_measured'):
+                f.write(f"\nDevice-copy rate of the same box, same run: {json.dumps(du['hbm_measured'])}\n")
     print('bench:', d['value'], d['ms_per_step'], d['roofline'], '| plain:', du['value'], du['ms_per_step'])
 
 # ------------------------------------------------------------------------------------------------ PMC traffic of the stage kernels

@@ -48,14 +48,14 @@ def _loss_terms(tg: TrackGraph, scores, logits, ce, focal_node, focal_edge, tp_c
     """train.py:70-81 / :109-120 for one forward call."""
     g = tg.graph
     labels = tg.labels()
-    targets = create_targets(labels, g)
+    targets = create_targets(labels, g, as_bytes=True)
     loss_c = ce(logits, targets, g)
     fg = g.frame_graph()
-    idx_edge = fg.edge_row.long()
-    loss_f = focal_edge(scores[idx_edge, 0], targets[idx_edge])
+    # train.py:76-81 selects `scores[idx_edge, 0]`, `targets[idx_edge]` (and the det rows): the loss kernels take the row list
+    sc = scores[:, 0]
+    loss_f = focal_edge(sc, targets, rows=fg.edge_row)
     if tp_classifier:
-        idx_node = fg.det_row.long()
-        loss_f = focal_node(scores[idx_node, 0], targets[idx_node]) + loss_f
+        loss_f = focal_node(sc, targets, rows=fg.det_row) + loss_f
     return loss_c, loss_f
 
 

@@ -53,14 +53,23 @@ def _need_cuda(t: torch.Tensor, what: str):
                            '(no CPU or torch fallback exists)')
 
 
-def create_targets(labels: torch.Tensor, node_adj, idx_node=None) -> torch.Tensor:
-    """reference models/loss.py:8-44.  labels int64 [N] -> targets int64 [N]."""
+def create_targets(labels: torch.Tensor, node_adj, idx_node=None, as_bytes: bool = False) -> torch.Tensor:
+    """reference models/loss.py:8-44.  labels int64 [N] -> targets int64 [N] (as_bytes: uint8 0 / 1, what the loss kernels
+    read -- CELoss / FocalLoss take them without another conversion)."""
     _need_cuda(labels, 'labels')
     g = _as_graph(node_adj)
-    lab = (labels != 0).to(torch.uint8).contiguous()
+    lab = labels if (labels.dtype == torch.uint8 and labels.is_contiguous()) else (labels != 0).to(torch.uint8).contiguous()
     out = torch.empty_like(lab)
     _lib.call('tmpnn_targets', g.cref(), lab.data_ptr(), out.data_ptr(), _stream())
-    return out.to(labels.dtype)
+    return out if as_bytes else out.to(labels.dtype)
+
+
+def _as_u8(targets: torch.Tensor) -> torch.Tensor:
+    """0 / 1 bytes of a target vector (create_targets(..., as_bytes=True) hands them over as they are)."""
+    t = targets.reshape(-1)
+    if t.dtype == torch.uint8 and t.is_contiguous():
+        return t
+    return (t != 0).to(torch.uint8).contiguous()
 
 
 class _CE(torch.autograd.Function):
@@ -94,15 +103,16 @@ class CELoss(nn.Module):
     def forward(self, outputs, targets, node_adj, idx_node=None):
         _need_cuda(outputs, 'outputs')
         g = _as_graph(node_adj)
-        t8 = (targets.reshape(-1) != 0).to(torch.uint8).contiguous()
-        return _CE.apply(outputs, t8, g)
+        return _CE.apply(outputs, _as_u8(targets), g)
 
 
 class _Focal(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, outputs, targets_u8, gamma, use_alpha, a0, a1, mean):
+    def forward(ctx, outputs, targets_u8, gamma, use_alpha, a0, a1, mean, rows=None):
+        # rows (int32, device): the loss runs over outputs[rows] / targets[rows] -- the kernels take the row list, so the
+        # reference's `scores[idx, 0]`, `targets[idx]` selections (train.py:76-81) cost no gather and no scatter-add
         s = outputs.detach().reshape(-1).float().contiguous()
-        R = s.numel()
+        R = s.numel() if rows is None else int(rows.numel())
         ctx.shape = outputs.shape
         ctx.R = R
         if R == 0:
@@ -111,7 +121,8 @@ class _Focal(torch.autograd.Function):
         loss = torch.empty((1,), dtype=torch.float32, device=s.device)
         wsn = _lib.load().tmpnn_focal_loss_ws(R)
         ws = torch.empty((wsn,), dtype=torch.float32, device=s.device)
-        rows = torch.arange(R, dtype=torch.int32, device=s.device)
+        if rows is None:
+            rows = torch.arange(R, dtype=torch.int32, device=s.device)
         _lib.call('tmpnn_focal_loss_fwd', rows.data_ptr(), R, s.data_ptr(), targets_u8.data_ptr(), float(gamma),
                   int(use_alpha), float(a0), float(a1), loss.data_ptr(), ws.data_ptr(), wsn, _stream())
         ctx.s, ctx.t, ctx.rows, ctx.args = s, targets_u8, rows, (float(gamma), int(use_alpha), float(a0), float(a1))
@@ -121,13 +132,13 @@ class _Focal(torch.autograd.Function):
     @staticmethod
     def backward(ctx, d_loss):
         if ctx.R == 0:
-            return d_loss.new_zeros(ctx.shape), None, None, None, None, None, None
+            return d_loss.new_zeros(ctx.shape), None, None, None, None, None, None, None
         d = torch.zeros_like(ctx.s)
         dl = d_loss.reshape(1).float().contiguous()
         gamma, ua, a0, a1 = ctx.args
-        _lib.call('tmpnn_focal_loss_bwd', ctx.rows.data_ptr(), ctx.s.numel(), ctx.s.data_ptr(), ctx.t.data_ptr(), gamma,
+        _lib.call('tmpnn_focal_loss_bwd', ctx.rows.data_ptr(), ctx.R, ctx.s.data_ptr(), ctx.t.data_ptr(), gamma,
                   ua, a0, a1, dl.data_ptr(), float(ctx.scale), d.data_ptr(), _stream())
-        return d.reshape(ctx.shape), None, None, None, None, None, None
+        return d.reshape(ctx.shape), None, None, None, None, None, None, None
 
 
 class FocalLoss(nn.Module):
@@ -142,9 +153,17 @@ class FocalLoss(nn.Module):
         self.size_average = size_average
         self.eps = 1e-10
 
-    def forward(self, outputs, targets):
+    def forward(self, outputs, targets, rows=None):
+        """rows=None: the reference's call, `loss(outputs[idx], targets[idx])` on selections made by the caller.
+        rows (int32 device tensor): `outputs` / `targets` are the FULL per-row vectors and the loss runs over those rows
+        (equal to the former, without the gathers and their scatter-add backward)."""
         _need_cuda(outputs, 'outputs')
-        t8 = (targets.reshape(-1) != 0).to(torch.uint8).contiguous()
+        t8 = _as_u8(targets)
         ua = self.alpha is not None
         a0, a1 = (float(self.alpha[0]), float(self.alpha[1])) if ua else (1.0, 1.0)
-        return _Focal.apply(outputs, t8, self.gamma, ua, a0, a1, self.size_average)
+        if rows is not None:
+            if rows.dtype != torch.int32 or not rows.is_contiguous():
+                rows = rows.to(torch.int32).contiguous()
+            if t8.numel() != outputs.numel():
+                raise ValueError('FocalLoss(rows=...): outputs and targets must be the full per-row vectors')
+        return _Focal.apply(outputs, t8, self.gamma, ua, a0, a1, self.size_average, rows)
