@@ -167,8 +167,14 @@ def test_state_dict_keys_match_oracle_shapes():
         for k, v in sd.items():
             assert tuple(v.shape) == shapes[k], k
         assert sorted(m.spec.param_names()) == sorted(k for k, _ in m.named_parameters())
-    with pytest.raises(ValueError):
-        TrackMPNN('2d', 3, 257, 0, 'diff')
+    # widths: 1 .. 1024; above 256 the diff message without attention heads only (padded to the next multiple of 128)
+    wide = TrackMPNN('2d', 3, 257, 0, 'diff')
+    assert wide.hpad == 384 and wide._padded and tuple(wide.state_dict()['factor_grus.0.edge_gru.weight_hh'].shape) == (771, 257)
+    assert TrackMPNN('2d', 3, 512, 0, 'diff').hpad == 512
+    for bad in (dict(nhidden=1025, nattheads=0, msg_type='diff'), dict(nhidden=384, nattheads=2, msg_type='diff'),
+                dict(nhidden=384, nattheads=0, msg_type='concat')):
+        with pytest.raises(ValueError):
+            TrackMPNN('2d', 3, bad['nhidden'], bad['nattheads'], bad['msg_type'])
     with pytest.raises(AssertionError):
         TrackMPNN('2d', 3, 32, 0, 'sum')
 
@@ -219,9 +225,11 @@ def test_any_hidden_width_is_accepted_and_keeps_reference_shapes():
     h = torch.randn(5, 2 * 48)
     assert torch.equal(m._unpad_state(m._pad_state(h)), h)
     assert TrackMPNN('2d', 3, 64, 0, 'diff')._padded is False
+    big = TrackMPNN('2d', 3, 300, 0, 'diff')                     # above 256: padded to the next multiple of 128
+    assert (big.nhidden, big.hpad, big._padded) == (300, 384, True)
     import pytest
     with pytest.raises(ValueError):
-        TrackMPNN('2d', 3, 300, 0, 'diff')
+        TrackMPNN('2d', 3, 1100, 0, 'diff')
 
 
 def _check_tiles(g, tiles, R):

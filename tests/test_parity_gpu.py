@@ -186,6 +186,12 @@ def _batched_case(B, frames, mean, max_dets, F, seed0=0, static=False):
     ('2d', 3, 20, 0, 'concat', True),
     ('2d+temp+vis', 3, 48, 0, 'diff', True),
     ('2d', 3, 100, 2, 'diff', False),
+    # widths above 256 (multiples of 128 native, others zero-padded to the next one): diff messages, no attention heads
+    ('2d', 3, 384, 0, 'diff', True),
+    ('2d', 3, 300, 0, 'diff', True),
+    ('2d+temp+vis', 3, 512, 0, 'diff', False),
+    ('2d', 3, 640, 0, 'diff', True),
+    ('2d', 3, 1024, 0, 'diff', False),
 ])
 def test_batched_windows_vs_oracle(features, ncat, H, K, msg, train):
     """Block-diagonal batches of KITTI-shaped rolling windows (per-window BatchNorm segments), fwd + bwd."""

@@ -493,8 +493,24 @@ extern "C" {
 int tmpnn_abi_version(void) { return TMPNN_ABI_VERSION; }
 const char* tmpnn_last_error(void) { return tmpnn::g_err; }
 
+// H > 256 (multiples of 128): the row movers run once per slice of <= 256 columns (a row is moved by H / 4 adjacent lanes of
+// ONE wave); rows are strided, so a slice is the same call on shifted pointers.  Not for the concat forms (their second half
+// sits H columns further on).
+#define TM_SLICED(H_, call_)                                                              \
+    do {                                                                                  \
+        if (supported_H_big(H_)) {                                                        \
+            for (int c0 = 0; c0 < (H_); c0 += 256) {                                      \
+                const int w = (H_) - c0 < 256 ? (H_) - c0 : 256;                          \
+                const int rc_ = call_;                                                    \
+                if (rc_) return rc_;                                                      \
+            }                                                                             \
+            return TMPNN_OK;                                                              \
+        }                                                                                 \
+    } while (0)
+
 int tmpnn_gather_diff_fwd(const tmpnn_graph* g, const float* in, int ld_in, float* out, int ld_out, int H,
                           int accumulate, tmpnn_stream stream) {
+    TM_SLICED(H, gather(g, in + c0, ld_in, out + c0, ld_out, w, accumulate, false, stream));
     return gather(g, in, ld_in, out, ld_out, H, accumulate, false, stream);
 }
 int tmpnn_gather_concat_fwd(const tmpnn_graph* g, const float* in, int ld_in, float* out, int ld_out, int H,
@@ -503,6 +519,7 @@ int tmpnn_gather_concat_fwd(const tmpnn_graph* g, const float* in, int ld_in, fl
 }
 int tmpnn_gather_diff_bwd(const tmpnn_graph* g, const float* d_out, int ld_dout, float* d_in, int ld_din, int H,
                           int accumulate, tmpnn_stream stream) {
+    TM_SLICED(H, segsum(g, d_out + c0, ld_dout, d_in + c0, ld_din, w, accumulate, -1.0f, 0, 0, stream));
     return segsum(g, d_out, ld_dout, d_in, ld_din, H, accumulate, -1.0f, 0, 0, stream);
 }
 int tmpnn_gather_concat_bwd(const tmpnn_graph* g, const float* d_out, int ld_dout, float* d_in, int ld_din, int H,
@@ -511,10 +528,12 @@ int tmpnn_gather_concat_bwd(const tmpnn_graph* g, const float* d_out, int ld_dou
 }
 int tmpnn_segsum_fwd(const tmpnn_graph* g, const float* in, int ld_in, float* out, int ld_out, int H, int accumulate,
                      int compact_out, tmpnn_stream stream) {
+    TM_SLICED(H, segsum(g, in + c0, ld_in, out + c0, ld_out, w, accumulate, -1.0f, 0, compact_out, stream));
     return segsum(g, in, ld_in, out, ld_out, H, accumulate, -1.0f, 0, compact_out, stream);
 }
 int tmpnn_segsum_bwd(const tmpnn_graph* g, const float* d_out, int ld_dout, float* d_in, int ld_din, int H,
                      int accumulate, tmpnn_stream stream) {
+    TM_SLICED(H, gather(g, d_out + c0, ld_dout, d_in + c0, ld_din, w, accumulate, false, stream));
     return gather(g, d_out, ld_dout, d_in, ld_din, H, accumulate, false, stream);
 }
 

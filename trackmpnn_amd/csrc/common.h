@@ -40,6 +40,10 @@ inline int check_launch(const char* what) {
 }
 
 inline bool supported_H(int H) { return H == 32 || H == 64 || H == 128 || H == 256; }
+// widths above 256 (reference: any int, utils/training_options.py:22): multiples of 128 up to 1024 on the H-generic kernels --
+// the wide edge cell, the f32-MFMA node cell, the strided GEMMs; the row movers take them in 256-column slices
+inline bool supported_H_big(int H) { return H > 256 && H <= 1024 && H % 128 == 0; }
+inline bool supported_H_cell(int H) { return supported_H(H) || supported_H_big(H); }
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 inline hipStream_t as_stream(tmpnn_stream s) { return reinterpret_cast<hipStream_t>(s); }
 inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }

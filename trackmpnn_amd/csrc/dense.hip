@@ -592,7 +592,7 @@ int tmpnn_input_bn_fwd(const float* xdet, int ld_x, int F, int nd, const int32_t
                        const float* beta, float* running_mean, float* running_var, const float* w2, const float* b2,
                        float* y_save, float* mean, float* rstd, float* ws_a, const int32_t* out_row, float* h_new,
                        int ld_h, tmpnn_stream stream) {
-    TM_REQUIRE(supported_H(H), "input_bn_fwd: unsupported H=%d", H);
+    TM_REQUIRE(supported_H_cell(H), "input_bn_fwd: unsupported H=%d", H);
     TM_REQUIRE(F > 0 && nd >= 0 && S >= 0, "input_bn_fwd: F=%d nd=%d S=%d", F, nd, S);
     TM_REQUIRE(w1 && b1 && gamma && beta && running_mean && running_var && w2 && b2 && mean && rstd,
                "input_bn_fwd: null parameter pointer");
@@ -631,7 +631,7 @@ int tmpnn_input_bn_bwd(const float* xdet, int ld_x, int F, int nd, const int32_t
                        const int32_t* out_row, const float* d_h, int ld_dh, float* d_xdet, int ld_dx, float* d_xzero,
                        float* dw1, float* db1, float* dgamma, float* dbeta, float* dw2, float* db2, float* ws,
                        size_t ws_floats, tmpnn_stream stream) {
-    TM_REQUIRE(supported_H(H), "input_bn_bwd: unsupported H=%d", H);
+    TM_REQUIRE(supported_H_cell(H), "input_bn_bwd: unsupported H=%d", H);
     TM_REQUIRE(F > 0 && nd >= 0 && S >= 0, "input_bn_bwd: F=%d nd=%d S=%d", F, nd, S);
     TM_REQUIRE(w1 && b1 && gamma && beta && w2 && mean && rstd && dw1 && db1 && dgamma && dbeta && dw2 && db2,
                "input_bn_bwd: null parameter pointer");

@@ -3587,7 +3587,7 @@ int tmpnn_gru_fwd(const int32_t* rows, int R, int xmode, const int32_t* src, con
                   int ld_msg, int msg_compact, int IN, const float* h, int ld_h, int H, const float* wih_t, const float* whh_t,
                   const float* b_ih, const float* b_hh, float* h_out, int ld_out, float* gates, size_t gate_plane,
                   const float* w_head, float* logit_part, size_t part_stride, tmpnn_stream stream) {
-    TM_REQUIRE(supported_H(H), "gru_fwd: unsupported H=%d", H);
+    TM_REQUIRE(supported_H_cell(H), "gru_fwd: unsupported H=%d", H);
     TM_REQUIRE(R >= 0, "gru_fwd: R=%d", R);
     if (R == 0) return TMPNN_OK;
     TM_REQUIRE(xmode >= 0 && xmode <= 3, "gru_fwd: xmode=%d", xmode);
@@ -3736,7 +3736,7 @@ int tmpnn_gru_bwd_data(const int32_t* rows, int R, int IN, const float* h, int l
                        const float* dy, const float* w_head, float* d_msg, int ld_dmsg, float* d_h, int ld_dh,
                        const int32_t* add_src, const int32_t* add_dst, const float* add_msg, int ld_add,
                        tmpnn_stream stream) {
-    TM_REQUIRE(supported_H(H), "gru_bwd_data: unsupported H=%d", H);
+    TM_REQUIRE(supported_H_cell(H), "gru_bwd_data: unsupported H=%d", H);
     if (R == 0) return TMPNN_OK;
     TM_REQUIRE(R > 0 && IN > 0 && IN % 32 == 0 && (H % 64 != 0 || IN % 64 == 0), "gru_bwd_data: R=%d IN=%d", R, IN);
     TM_REQUIRE(rows && h && w_ih && w_hh && gates && d_msg && d_h, "gru_bwd_data: null pointer");
@@ -3972,7 +3972,7 @@ int tmpnn_gru_bwd_weights_variant(const int32_t* rows, int R, int xmode, const i
                                   float* db_ih, float* db_hh, void* ws, size_t ws_bytes, int variant,
                                   tmpnn_stream stream) {
     TM_REQUIRE(variant >= -1 && variant <= 1, "gru_bwd_weights: variant %d (need -1, 0 or 1)", variant);
-    TM_REQUIRE(supported_H(H), "gru_bwd_weights: unsupported H=%d", H);
+    TM_REQUIRE(supported_H_cell(H), "gru_bwd_weights: unsupported H=%d", H);
     if (R == 0) return TMPNN_OK;
     TM_REQUIRE(R > 0 && xmode >= 0 && xmode <= 2 && IN % 32 == 0 && IN > 0, "gru_bwd_weights: R=%d xmode=%d IN=%d", R,
                xmode, IN);

@@ -1072,15 +1072,16 @@ __global__ __launch_bounds__(256) void k_wide_gates_bwd(WideBwdArgs a) {
 
 // The same pass for the det-side form of the W_ih products (tmpnn_wide_gru_bwd_diff): ONE image per row, indexed by the
 // graph row, dg4[row] = [dr | dz | dn | dn r] (4H floats: d_gi = columns 0..3H, d_gh = columns 0..2H and 3H..4H), and the
-// column sums of dn (the third of db_ih that the W_hh-side weight-gradient launch does not see) as one [H] slab per block:
-// gridDim.x * 256 is a multiple of H / 4, so a thread keeps its four columns over the whole grid stride.
+// column sums of dn (the third of db_ih that the W_hh-side weight-gradient launch does not see) as one [H] slab per block.
 __global__ __launch_bounds__(256) void k_wide_gates_bwd4(WideBwdArgs a, float* __restrict__ dn_slabs) {
     __shared__ float red[256 * 4];
-    const int H = a.H, lpr = H >> 2;
-    const long total = (long)a.R * lpr;
+    // thread = (row slot, column group): 256 / lpr rows per pass (the surplus threads of widths whose H / 4 does not divide
+    // 256 -- 384, 640, ... -- idle), so that a thread keeps its four columns over the whole grid stride
+    const int H = a.H, lpr = H >> 2, rpb = 256 / lpr;
+    const int slot = threadIdx.x / lpr, c4 = (threadIdx.x % lpr) * 4;
     float cs[4] = {0.f, 0.f, 0.f, 0.f};
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-        const int r = (int)(i / lpr), c4 = (int)(i % lpr) * 4;
+    for (long rl = (long)blockIdx.x * rpb + slot; slot < rpb && rl < a.R; rl += (long)gridDim.x * rpb) {
+        const int r = (int)rl;
         const int row = a.rows[r];
         float4 dh = make_float4(0.f, 0.f, 0.f, 0.f);
         if (a.d_hout) dh = *reinterpret_cast<const float4*>(a.d_hout + (size_t)row * a.ld_dhout + c4);
@@ -1121,7 +1122,7 @@ __global__ __launch_bounds__(256) void k_wide_gates_bwd4(WideBwdArgs a, float* _
     __syncthreads();
     if ((int)threadIdx.x < lpr) {
         float s4[4] = {0.f, 0.f, 0.f, 0.f};
-        for (int t = threadIdx.x; t < 256; t += lpr)
+        for (int t = threadIdx.x; t < rpb * lpr; t += lpr)
 #pragma unroll
             for (int j = 0; j < 4; ++j) s4[j] += red[t * 4 + j];
         *reinterpret_cast<float4*>(dn_slabs + (size_t)blockIdx.x * H + 4 * threadIdx.x) = make_float4(s4[0], s4[1], s4[2], s4[3]);
@@ -1336,7 +1337,7 @@ using namespace tmpnn;
 
 extern "C" {
 
-int tmpnn_wide_supported(int H, int IN) { return ((H == 128 || H == 256) && IN == H) ? 1 : 0; }
+int tmpnn_wide_supported(int H, int IN) { return (H >= 128 && H <= 1024 && H % 128 == 0 && IN == H) ? 1 : 0; }
 
 // bytes of the four weight images of one cell: forward hh (K = H, N = 3H), forward ih (K = IN, N = 3H),
 // backward ih (K = 3H, N = IN), backward hh (K = 3H, N = H)

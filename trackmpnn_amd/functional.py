@@ -237,7 +237,8 @@ def mp_forward(spec: ModelSpec, plan: CallPlan, x: torch.Tensor, h_in: Optional[
     plane = N * H
     lib = _lib.load()
     use_proj = spec.msg_type == 'diff' and H <= 64 and g.src_pos is not None and Dn > 0
-    use_wide = WIDE and spec.msg_type == 'diff' and H in (128, 256) and g.src_pos is not None and Dn > 0 and E > 0
+    use_wide = (WIDE and spec.msg_type == 'diff' and H >= 128 and bool(lib.tmpnn_wide_supported(H, H))
+                and g.src_pos is not None and Dn > 0 and E > 0)
     wide_preps = []
     # output head fused into the cells' epilogues where the LDS-resident kernel runs (else tmpnn_heads_fwd)
     cw = min(lib.tmpnn_gru_fwd_head_parts(H, spec.IN_e, 3 if use_proj else xmode), lib.tmpnn_gru_fwd_head_parts(H, H, 0))
@@ -372,16 +373,22 @@ def mp_backward(spec: ModelSpec, plan: CallPlan, saved: dict, P: Dict[str, torch
     dy = None
     if d_scores is not None or d_logits is not None:
         dy = torch.empty((N,), **opts)
-        ws_b = lib.tmpnn_heads_bwd_ws(N, GH)
-        ws = torch.empty((max(ws_b // 4, 1),), **opts)
         dl = _f32c(d_logits) if d_logits is not None else None
         ds = _f32c(d_scores) if d_scores is not None else None
-        _lib.call('tmpnn_heads_bwd', h_out.data_ptr(), GH, GH, N, g.is_edge.data_ptr(),
-                  P['output_transform_node.weight'].data_ptr(), P['output_transform_edge.weight'].data_ptr(),
-                  saved['scores'].data_ptr(), _lib.ptr(dl), _lib.ptr(ds), dy.data_ptr(), None, 0, 0,
-                  grads['output_transform_node.weight'].data_ptr(), grads['output_transform_node.bias'].data_ptr(),
-                  grads['output_transform_edge.weight'].data_ptr(), grads['output_transform_edge.bias'].data_ptr(),
-                  ws.data_ptr(), ws_b, st)
+        # (the kernel takes up to 1024 columns of h_out per call: wider states -- three feature groups above nhidden 256 --
+        #  go in column slices; dy is the same in every slice, the two bias gradients are taken from the first)
+        for c0 in range(0, GH, 1024):
+            cw_ = min(1024, GH - c0)
+            ws_b = lib.tmpnn_heads_bwd_ws(N, cw_)
+            ws = torch.empty((max(ws_b // 4, 1),), **opts)
+            db_n = grads['output_transform_node.bias'] if c0 == 0 else torch.zeros((1,), **opts)
+            db_e = grads['output_transform_edge.bias'] if c0 == 0 else torch.zeros((1,), **opts)
+            _lib.call('tmpnn_heads_bwd', h_out.data_ptr() + 4 * c0, GH, cw_, N, g.is_edge.data_ptr(),
+                      P['output_transform_node.weight'].data_ptr() + 4 * c0, P['output_transform_edge.weight'].data_ptr() + 4 * c0,
+                      saved['scores'].data_ptr(), _lib.ptr(dl), _lib.ptr(ds), dy.data_ptr(), None, 0, 0,
+                      grads['output_transform_node.weight'].data_ptr() + 4 * c0, db_n.data_ptr(),
+                      grads['output_transform_edge.weight'].data_ptr() + 4 * c0, db_e.data_ptr(),
+                      ws.data_ptr(), ws_b, st)
     elif dh_up is None:
         dh_up = torch.zeros((N, GH), **opts)
 

@@ -24,7 +24,9 @@ from .graph import (DG_BIG_ROWS, CallPlan, DeviceGraph, FrameGraph, device_graph
 from .layers import FactorGraphGRU
 from .small import SmallPath, _ParamSink, _SmallIter, fast_module, small_eligible
 
-KERNEL_WIDTHS = (32, 64, 128, 256)          # hidden widths the HIP kernels are instantiated for
+# hidden widths the kernels run natively; above 256 (multiples of 128, csrc/common.h supported_H_big) only the diff message
+# without attention heads is served: the wide edge cell and the H-generic f32 kernels, row movers in 256-column slices
+KERNEL_WIDTHS = (32, 64, 128, 256, 384, 512, 640, 768, 896, 1024)
 
 STRICT_GRAPH = os.environ.get('TMPNN_STRICT_GRAPH', '0') == '1'     # validate every adjacency at once (host sync)
 SMALL_PATH = os.environ.get('TMPNN_SMALL_PATH', '1') != '0'         # fused batch-1 iteration for eligible calls
@@ -71,6 +73,9 @@ class TrackMPNN(nn.Module):
         nhidden = int(nhidden)
         if not 1 <= nhidden <= KERNEL_WIDTHS[-1]:
             raise ValueError(f'nhidden={nhidden}: the gfx950 kernels cover 1 .. {KERNEL_WIDTHS[-1]} hidden units')
+        if nhidden > 256 and (msg_type != 'diff' or int(nattheads) > 0):
+            raise ValueError(f'nhidden={nhidden} > 256 is served for msg_type="diff" without attention heads only '
+                             f'(got msg_type={msg_type!r}, nattheads={nattheads})')
         # the kernels are instantiated for KERNEL_WIDTHS; any other width runs zero-padded to the next one (exact:
         # a padded unit has zero weights and biases everywhere, so it stays 0 through BatchNorm, both GRU cells,
         # the attention scores and the heads -- see _pad_params)
@@ -289,11 +294,14 @@ class TrackMPNN(nn.Module):
             g.check()
 
     def forward_dgraph(self, x: torch.Tensor, h_in: Optional[torch.Tensor], graph: DeviceGraph):
-        """One message-passing call on a DeviceGraph through the fused iteration (K = 0, H in {32, 64})."""
+        """One message-passing call on a DeviceGraph: the fused iteration (K = 0, H in {32, 64}), the staged kernels for
+        every other model."""
         if not x.is_cuda:
             raise RuntimeError(f'x is on {x.device}: trackmpnn_amd runs on the MI355X HIP kernels only '
                                '(no CPU or torch fallback exists)')
-        if self._padded:
+        if self._padded or not small_eligible(self, graph.N):
+            # models the fused iteration does not cover (attention heads, nhidden >= 128, padded widths): the staged kernels
+            # on the same device-resident graph (frame_graph() reads E and Dn back: their launch sizes are host values)
             return self.forward_graph(x, h_in, plan_single(graph.frame_graph(), int(x.shape[0])))
         if self._plist is None:
             named = dict(self.named_parameters())
