@@ -18,9 +18,10 @@
  *   - return value: TMPNN_OK (0) or a negative TMPNN_E* code; `tmpnn_last_error()` gives the
  *     thread-local message of the last failure.  Nothing is ever thrown across the boundary.
  *   - supported hidden widths: H in {32, 64, 128, 256}; additionally the multiples of 128 up to 1024 in the entry points of
- *     the diff-message path without attention: tmpnn_gru_{fwd,bwd_data,bwd_weights} (H-generic f32 kernels), tmpnn_wide_*,
- *     tmpnn_input_bn_*, tmpnn_heads_* (<= 1024 columns per call), tmpnn_gather_diff_* / tmpnn_segsum_* (served internally in
- *     256-column slices).  tmpnn_att_*, the concat gathers and the fused / tiled H <= 64 forms keep the four widths.
+ *     the paths without attention: tmpnn_gru_{fwd,bwd_data,bwd_weights} (H-generic f32 kernels), tmpnn_wide_*,
+ *     tmpnn_input_bn_*, tmpnn_heads_* (<= 1024 columns per call), tmpnn_gather_diff_* / tmpnn_gather_concat_bwd / tmpnn_segsum_*
+ *     (served internally in 256-column slices).  tmpnn_att_*, tmpnn_gather_concat_fwd and the fused / tiled H <= 64 forms keep
+ *     the four widths.
  *   - no entry point measures, tunes or keeps data between calls; the only process state is the thread-local
  *     error string and idempotent per-kernel function attributes.
  */

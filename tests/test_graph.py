@@ -167,12 +167,12 @@ def test_state_dict_keys_match_oracle_shapes():
         for k, v in sd.items():
             assert tuple(v.shape) == shapes[k], k
         assert sorted(m.spec.param_names()) == sorted(k for k, _ in m.named_parameters())
-    # widths: 1 .. 1024; above 256 the diff message without attention heads only (padded to the next multiple of 128)
+    # widths: 1 .. 1024; above 256 without attention heads only (padded to the next multiple of 128)
     wide = TrackMPNN('2d', 3, 257, 0, 'diff')
     assert wide.hpad == 384 and wide._padded and tuple(wide.state_dict()['factor_grus.0.edge_gru.weight_hh'].shape) == (771, 257)
     assert TrackMPNN('2d', 3, 512, 0, 'diff').hpad == 512
-    for bad in (dict(nhidden=1025, nattheads=0, msg_type='diff'), dict(nhidden=384, nattheads=2, msg_type='diff'),
-                dict(nhidden=384, nattheads=0, msg_type='concat')):
+    assert TrackMPNN('2d', 3, 384, 0, 'concat').hpad == 384
+    for bad in (dict(nhidden=1025, nattheads=0, msg_type='diff'), dict(nhidden=384, nattheads=2, msg_type='diff')):
         with pytest.raises(ValueError):
             TrackMPNN('2d', 3, bad['nhidden'], bad['nattheads'], bad['msg_type'])
     with pytest.raises(AssertionError):

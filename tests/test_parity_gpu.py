@@ -192,6 +192,7 @@ def _batched_case(B, frames, mean, max_dets, F, seed0=0, static=False):
     ('2d+temp+vis', 3, 512, 0, 'diff', False),
     ('2d', 3, 640, 0, 'diff', True),
     ('2d', 3, 1024, 0, 'diff', False),
+    ('2d', 3, 384, 0, 'concat', True),
 ])
 def test_batched_windows_vs_oracle(features, ncat, H, K, msg, train):
     """Block-diagonal batches of KITTI-shaped rolling windows (per-window BatchNorm segments), fwd + bwd."""

@@ -524,6 +524,8 @@ int tmpnn_gather_diff_bwd(const tmpnn_graph* g, const float* d_out, int ld_dout,
 }
 int tmpnn_gather_concat_bwd(const tmpnn_graph* g, const float* d_out, int ld_dout, float* d_in, int ld_din, int H,
                             int accumulate, tmpnn_stream stream) {
+    // (slices of the two halves [h[src] | h[dst]] of a 2H-wide row: the second half stays H columns further on)
+    TM_SLICED(H, segsum(g, d_out + c0, ld_dout, d_in + c0, ld_din, w, accumulate, 1.0f, H, 0, stream));
     return segsum(g, d_out, ld_dout, d_in, ld_din, H, accumulate, 1.0f, H, 0, stream);
 }
 int tmpnn_segsum_fwd(const tmpnn_graph* g, const float* in, int ld_in, float* out, int ld_out, int H, int accumulate,

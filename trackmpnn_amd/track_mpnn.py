@@ -24,8 +24,8 @@ from .graph import (DG_BIG_ROWS, CallPlan, DeviceGraph, FrameGraph, device_graph
 from .layers import FactorGraphGRU
 from .small import SmallPath, _ParamSink, _SmallIter, fast_module, small_eligible
 
-# hidden widths the kernels run natively; above 256 (multiples of 128, csrc/common.h supported_H_big) only the diff message
-# without attention heads is served: the wide edge cell and the H-generic f32 kernels, row movers in 256-column slices
+# hidden widths the kernels run natively; above 256 (multiples of 128, csrc/common.h supported_H_big) models without
+# attention heads are served: the wide edge cell and the H-generic f32 kernels, row movers in 256-column slices
 KERNEL_WIDTHS = (32, 64, 128, 256, 384, 512, 640, 768, 896, 1024)
 
 STRICT_GRAPH = os.environ.get('TMPNN_STRICT_GRAPH', '0') == '1'     # validate every adjacency at once (host sync)
@@ -73,9 +73,8 @@ class TrackMPNN(nn.Module):
         nhidden = int(nhidden)
         if not 1 <= nhidden <= KERNEL_WIDTHS[-1]:
             raise ValueError(f'nhidden={nhidden}: the gfx950 kernels cover 1 .. {KERNEL_WIDTHS[-1]} hidden units')
-        if nhidden > 256 and (msg_type != 'diff' or int(nattheads) > 0):
-            raise ValueError(f'nhidden={nhidden} > 256 is served for msg_type="diff" without attention heads only '
-                             f'(got msg_type={msg_type!r}, nattheads={nattheads})')
+        if nhidden > 256 and int(nattheads) > 0:
+            raise ValueError(f'nhidden={nhidden} > 256 is served without attention heads only (got nattheads={nattheads})')
         # the kernels are instantiated for KERNEL_WIDTHS; any other width runs zero-padded to the next one (exact:
         # a padded unit has zero weights and biases everywhere, so it stays 0 through BatchNorm, both GRU cells,
         # the attention scores and the heads -- see _pad_params)
