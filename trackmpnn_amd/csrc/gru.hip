@@ -3144,6 +3144,18 @@ __device__ __forceinline__ f32x16 mfma32_c(const uint4 (&a)[3], const uint4 (&b)
     return mfma_bf16(a[0], b[0], acc);
 }
 
+#ifdef TWO_TIMELINE           // build-time instrument (tools/bwd_timeline.py): per-phase s_memtime sums, by role (W_ih / W_hh side)
+__device__ unsigned long long g_two_timeline[2][8];
+#define TWO_MARK(i)                                                           \
+    do {                                                                      \
+        __builtin_amdgcn_sched_barrier(0);                                    \
+        const unsigned long long now_ = __builtin_amdgcn_s_memtime();         \
+        tw_acc[(i)] += now_ - tw_last; tw_last = now_;                        \
+        __builtin_amdgcn_sched_barrier(0);                                    \
+    } while (0)
+#else
+#define TWO_MARK(i) do { } while (0)
+#endif
 struct TwoRaw { float4 dh, r, z, n, hn, hp, xa, xb, ea, eb; float dy; };
 // the gate planes are read exactly once (written by the forward a whole step earlier): TWO_NT_LOADS requests them nontemporal
 // (measured, same box: 3.87-3.88 vs 3.87-3.90 ms per 6.03 M rows -- nothing; the L1's pending-request queue is full either way)
@@ -3177,6 +3189,12 @@ __global__ __launch_bounds__(512) void k_gru_bwd_two(GruBwdFusedArgs a, int ntil
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int role = wave >> 2, q = wave & 3;                 // role 0: W_ih side, 1: W_hh side
+#ifdef TWO_PRIO
+    // (experiment: the s_memtime profile shows the W_ih-side waves 19 % of a tile at the barrier, waiting for their SIMD
+    //  partners of the W_hh side, which are slower in every phase)
+    if (TWO_PRIO == 1) { if (role == 1) __builtin_amdgcn_s_setprio(3); }
+    else if (TWO_PRIO == 2) { if (role == 0) __builtin_amdgcn_s_setprio(3); }
+#endif
     // ---- data product (16x16x32): lane (j = tile row within a 16-row half, kq = k group)
     const int j16 = lane & 15, kq = lane >> 4;
     // staging: thread tid takes row tid >> 4, columns 4 (tid & 15) .. + 3 -- written through (wave, kq, j16), which the
@@ -3361,6 +3379,10 @@ __global__ __launch_bounds__(512) void k_gru_bwd_two(GruBwdFusedArgs a, int ntil
         }                                                                                                    \
         if (TWO_SCHED == 0) __builtin_amdgcn_sched_barrier(0);                                               \
     } while (0)
+#ifdef TWO_TIMELINE
+    unsigned long long tw_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tw_last = __builtin_amdgcn_s_memtime();
+#endif
     for (int it = 0; it < nmine; ++it) {
         const int tile = blockIdx.x + it * G;
         uint16_t* const cur = lds16 + (it & 1) * BUF;
@@ -3403,7 +3425,9 @@ __global__ __launch_bounds__(512) void k_gru_bwd_two(GruBwdFusedArgs a, int ntil
                     aw[pc] = make_uint4(u0.x, u0.y, u1.x, u1.y);
                 }
             }
+            TWO_MARK(0);                                        // dW operand reads (transposing LDS reads) issued and back
             if (TWO_SCHED >= 1) TWO_STAGE(0);
+            TWO_MARK(1);                                        // staging slice of the next tile (waits for its rows) + re-requests
             if (!(exp_ & 4)) {
             acc[j] = mfma32_c<0>(aw, bt, acc[j]); acc[j] = mfma32_c<1>(aw, bt, acc[j]);
             acc[j] = mfma32_c<2>(aw, bt, acc[j]); acc[j] = mfma32_c<3>(aw, bt, acc[j]);
@@ -3419,6 +3443,10 @@ __global__ __launch_bounds__(512) void k_gru_bwd_two(GruBwdFusedArgs a, int ntil
                 }
             }
             if (TWO_SCHED == 0) __builtin_amdgcn_sched_barrier(0);
+#ifdef TWO_TIMELINE
+            asm volatile("" : "+v"(acc[j][0]));
+#endif
+            TWO_MARK(2);                                        // six 32 x 32 x 16 MFMAs of dW + the bias dot products
 #pragma unroll
             for (int pc = 0; pc < 3; ++pc) bd[pc] = *reinterpret_cast<const uint4*>(pd + pc * PA);
             if (!(exp_ & 4)) {
@@ -3438,6 +3466,10 @@ __global__ __launch_bounds__(512) void k_gru_bwd_two(GruBwdFusedArgs a, int ntil
             // ---- staging slice s6 of the next tile; what it freed is requested for the tile after that
             if (TWO_SCHED == 0) TWO_STAGE(0);
             __builtin_amdgcn_sched_barrier(0);
+#ifdef TWO_TIMELINE
+            asm volatile("" : "+v"(accd[0][0]), "+v"(accd[1][0]));
+#endif
+            TWO_MARK(3);                                        // row operand reads + twelve 16 x 16 x 32 MFMAs of the data product
         }
         // the staged tile's successor becomes the tile being staged; its successor's row id is fetched
         {
@@ -3467,8 +3499,16 @@ __global__ __launch_bounds__(512) void k_gru_bwd_two(GruBwdFusedArgs a, int ntil
             if (el1) *reinterpret_cast<float4*>(a.d_h + ((size_t)er1 * a.ld_dh + cofs)) =
                          make_float4(accd[1][0] + x1.x, accd[1][1] + x1.y, accd[1][2] + x1.z, accd[1][3] + x1.w);
         }
+        TWO_MARK(4);                                            // next ids + epilogue (row ids wait, stores)
         __syncthreads();
+        TWO_MARK(5);                                            // barrier
     }
+#ifdef TWO_TIMELINE
+    if (lane == 0) {
+        for (int i = 0; i < 6; ++i) atomicAdd(&g_two_timeline[role][i], tw_acc[i]);
+        atomicAdd(&g_two_timeline[role][6], (unsigned long long)nmine);
+    }
+#endif
 #undef TWO_STAGE
 #undef TWO_GATHER_IDS
 #undef TWO_ISSUE_GATHER
@@ -3500,6 +3540,17 @@ __global__ __launch_bounds__(512) void k_gru_bwd_two(GruBwdFusedArgs a, int ntil
         }
     }
 }
+
+#ifdef TWO_TIMELINE
+extern "C" int tmpnn_debug_two_timeline(unsigned long long* out16, int reset) {
+    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_two_timeline), sizeof(unsigned long long) * 16) != hipSuccess) return -1;
+    if (reset) {
+        unsigned long long z[16] = {};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_two_timeline), z, sizeof(z)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif
 
 // dW_ih[j][k] += sum_rs slab[rs][j][k], k < IN ; dW_hh[j][k-IN] += ... ; biases likewise
 __global__ void k_gru_reduce_w(const float* __restrict__ slab_w, const float* __restrict__ slab_b, int n_rs,
