@@ -148,3 +148,44 @@ def test_focal_loss_over_a_row_list_equals_the_gathered_form(gamma, alpha, mean)
     assert float(b.grad[outside].abs().max()) == 0.0
     empty = loss(b[:, 0], t.to(torch.uint8), rows=idx[:0].to(torch.int32))
     assert torch.isnan(empty) if mean else empty.item() == 0.0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('tp', [True, False])
+def test_train_losses_equals_the_separate_modules(tp):
+    """trackmpnn_amd.loss.train_losses (one autograd node for create_targets + CELoss + the focal terms, as
+    trackmpnn_amd.loops uses it) against the reference-shaped sequence of calls (train.py:70-81): same two losses and the
+    same gradients on scores and logits, bit for bit."""
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU')
+    from trackmpnn_amd.graph import synth_window
+    from trackmpnn_amd.loss import CELoss, FocalLoss, create_targets, train_losses
+    from trackmpnn_amd.tracking import TrackGraph
+    dev = 'cuda:0'
+    yy = synth_window(777, 6, 6.0, 15)
+    y = torch.from_numpy(yy)[None]
+    X = torch.randn(1, yy.shape[0], 8, generator=torch.Generator().manual_seed(3))
+    tg, feats, t_st, t_end = TrackGraph.initialize(X, y, 0, 'train', dev)
+    for t_cur in range(t_st, min(t_st + 2, t_end)):
+        tg.update(None, X, y, t_cur, mode='train')
+    g = tg.graph.frame_graph()
+    gen = torch.Generator().manual_seed(11)
+    s0 = torch.rand(g.N, 1, generator=gen).to(dev)
+    l0 = torch.randn(g.N, 1, generator=gen).to(dev)
+    labels = tg.labels()
+    # the separate modules, as train.py calls them
+    sa, la = s0.clone().requires_grad_(True), l0.clone().requires_grad_(True)
+    targets = create_targets(labels, g)
+    loss_c = CELoss()(la, targets, g)
+    idx_e, idx_n = g.edge_row.long(), g.det_row.long()
+    loss_f = FocalLoss(gamma=0, alpha=None)(sa[idx_e, 0], targets[idx_e])
+    if tp:
+        loss_f = FocalLoss(gamma=0, alpha=None)(sa[idx_n, 0], targets[idx_n]) + loss_f
+    (loss_c * 0.7 + loss_f * 1.3).backward()
+    # the composed node
+    sb, lb = s0.clone().requires_grad_(True), l0.clone().requires_grad_(True)
+    c2, f2 = train_losses(sb, lb, tg.labels_u8(), g, tp)
+    (c2 * 0.7 + f2 * 1.3).backward()
+    assert c2.item() == loss_c.item() and f2.item() == loss_f.item()
+    assert torch.equal(la.grad, lb.grad)
+    assert torch.equal(sa.grad, sb.grad)

@@ -22,7 +22,7 @@ from typing import Dict, Optional
 import numpy as np
 import torch
 
-from .loss import CELoss, FocalLoss, create_targets
+from .loss import CELoss, FocalLoss, train_losses
 from .tracking import TrackGraph
 
 
@@ -46,17 +46,9 @@ class _Stages:
 
 def _loss_terms(tg: TrackGraph, scores, logits, ce, focal_node, focal_edge, tp_classifier: bool):
     """train.py:70-81 / :109-120 for one forward call."""
-    g = tg.graph
-    labels = tg.labels()
-    targets = create_targets(labels, g, as_bytes=True)
-    loss_c = ce(logits, targets, g)
-    fg = g.frame_graph()
-    # train.py:76-81 selects `scores[idx_edge, 0]`, `targets[idx_edge]` (and the det rows): the loss kernels take the row list
-    sc = scores[:, 0]
-    loss_f = focal_edge(sc, targets, rows=fg.edge_row)
-    if tp_classifier:
-        loss_f = focal_node(sc, targets, rows=fg.det_row) + loss_f
-    return loss_c, loss_f
+    # one autograd node for targets + CE + the focal terms (trackmpnn_amd.loss.train_losses: the same C entry points as the
+    # CELoss / FocalLoss modules `ce`, `focal_node`, `focal_edge` -- train.py's gamma = 0, alpha = None -- would call one by one)
+    return train_losses(scores, logits, tg.labels_u8(), tg.graph.frame_graph(), tp_classifier)
 
 
 def train_chunk(model, X: torch.Tensor, y: torch.Tensor, device='cuda:0', tp_classifier: bool = True,

@@ -167,3 +167,83 @@ class FocalLoss(nn.Module):
             if t8.numel() != outputs.numel():
                 raise ValueError('FocalLoss(rows=...): outputs and targets must be the full per-row vectors')
         return _Focal.apply(outputs, t8, self.gamma, ua, a0, a1, self.size_average, rows)
+
+
+class _TrainLosses(torch.autograd.Function):
+    """train.py:70-81 / :109-120 for one forward call as ONE autograd node: create_targets, CELoss over the logits and the
+    two FocalLoss terms (gamma = 0, no alpha: what train.py constructs) over the scores of the edge rows and -- with the TP
+    classifier -- of the det rows, through the same C entry points as the separate modules, with one buffer for every
+    workspace and one pass of torch bookkeeping instead of four.  Returns (loss_c, loss_f); values and gradients equal the
+    separate calls bit for bit."""
+
+    @staticmethod
+    def forward(ctx, logits, scores, labels_u8, graph, tp_classifier):
+        g: FrameGraph = graph
+        lib = _lib.load()
+        dev = logits.device
+        st = _stream()
+        N, E, Dn = g.N, g.E, g.Dn
+        lg = logits.detach().reshape(-1).float().contiguous()
+        sc = scores.detach().reshape(-1).float().contiguous()
+        targets = torch.empty_like(labels_u8)
+        _lib.call('tmpnn_targets', g.cref(), labels_u8.data_ptr(), targets.data_ptr(), st)
+        n_ce, n_fe, n_fd = int(lib.tmpnn_ce_loss_ws(Dn)), int(lib.tmpnn_focal_loss_ws(E)), int(lib.tmpnn_focal_loss_ws(Dn))
+        buf = torch.empty((max(Dn, 1) * 8 + 4 + n_ce + n_fe + n_fd,), dtype=torch.float32, device=dev)
+        stats = buf[:max(Dn, 1) * 8]
+        out = buf[max(Dn, 1) * 8:max(Dn, 1) * 8 + 4]            # loss_c, focal(edge rows) sum, focal(det rows) sum
+        o = max(Dn, 1) * 8 + 4
+        _lib.call('tmpnn_ce_loss_fwd', g.cref(), lg.data_ptr(), targets.data_ptr(), stats.data_ptr(), out.data_ptr(),
+                  buf.data_ptr() + 4 * o, n_ce, st)
+        mean_e = mean_d = None
+        if E > 0:
+            _lib.call('tmpnn_focal_loss_fwd', g.edge_row.data_ptr(), E, sc.data_ptr(), targets.data_ptr(), 0.0, 0, 1.0, 1.0,
+                      out.data_ptr() + 4, buf.data_ptr() + 4 * (o + n_ce), n_fe, st)
+            mean_e = out[1] * (1.0 / E)
+        else:
+            mean_e = sc.new_full((), float('nan'))             # loss.mean() of an empty selection (models/loss.py:71-74)
+        loss_f = mean_e
+        if tp_classifier:
+            if Dn > 0:
+                _lib.call('tmpnn_focal_loss_fwd', g.det_row.data_ptr(), Dn, sc.data_ptr(), targets.data_ptr(), 0.0, 0, 1.0, 1.0,
+                          out.data_ptr() + 8, buf.data_ptr() + 4 * (o + n_ce + n_fe), n_fd, st)
+                mean_d = out[2] * (1.0 / Dn)
+            else:
+                mean_d = sc.new_full((), float('nan'))
+            loss_f = mean_d + mean_e                           # train.py:81: focal_node(...) + focal_edge(...)
+        ctx.g, ctx.lg, ctx.sc, ctx.targets, ctx.stats = g, lg, sc, targets, stats
+        ctx.tp, ctx.shapes = bool(tp_classifier), (logits.shape, scores.shape)
+        return out[0].clone().reshape(()), loss_f.reshape(())
+
+    @staticmethod
+    def backward(ctx, d_c, d_f):
+        g: FrameGraph = ctx.g
+        st = _stream()
+        d_logits = d_scores = None
+        if d_c is not None:
+            d_logits = torch.zeros_like(ctx.lg)
+            dl = d_c.reshape(1).float().contiguous()
+            _lib.call('tmpnn_ce_loss_bwd', g.cref(), _lib.ptr(g.src_pos), _lib.ptr(g.dst_pos), ctx.lg.data_ptr(),
+                      ctx.stats.data_ptr(), dl.data_ptr(), d_logits.data_ptr(), st)
+            d_logits = d_logits.reshape(ctx.shapes[0])
+        if d_f is not None:
+            d_scores = torch.zeros_like(ctx.sc)
+            df = d_f.reshape(1).float().contiguous()
+            if g.E > 0:
+                _lib.call('tmpnn_focal_loss_bwd', g.edge_row.data_ptr(), g.E, ctx.sc.data_ptr(), ctx.targets.data_ptr(), 0.0,
+                          0, 1.0, 1.0, df.data_ptr(), 1.0 / g.E, d_scores.data_ptr(), st)
+            if ctx.tp and g.Dn > 0:
+                _lib.call('tmpnn_focal_loss_bwd', g.det_row.data_ptr(), g.Dn, ctx.sc.data_ptr(), ctx.targets.data_ptr(), 0.0,
+                          0, 1.0, 1.0, df.data_ptr(), 1.0 / g.Dn, d_scores.data_ptr(), st)
+            d_scores = d_scores.reshape(ctx.shapes[1])
+        return d_logits, d_scores, None, None, None
+
+
+def train_losses(scores: torch.Tensor, logits: torch.Tensor, labels: torch.Tensor, node_adj, tp_classifier: bool = True):
+    """(loss_c, loss_f) of one forward call as train.py:70-81 computes them (CELoss on the logits; FocalLoss(gamma=0) on the
+    scores of the edge rows, plus that of the det rows with the TP classifier) from the row labels."""
+    _need_cuda(scores, 'scores')
+    g = _as_graph(node_adj)
+    lab = labels.reshape(-1)
+    lab = lab if (lab.dtype == torch.uint8 and lab.is_contiguous()) else (lab != 0).to(torch.uint8).contiguous()
+    sc = scores[:, 0] if scores.dim() == 2 else scores
+    return _TrainLosses.apply(logits, sc, lab, g, bool(tp_classifier))

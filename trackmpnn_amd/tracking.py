@@ -77,6 +77,11 @@ class TrackGraph:
     def labels(self) -> torch.Tensor:
         return self.rows['labels'][:self.N].long()
 
+    def labels_u8(self) -> torch.Tensor:
+        """The row labels as the 0 / 1 bytes the loss kernels read (no int64 round trip)."""
+        lab = self.rows['labels'][:self.N]
+        return lab if lab.dtype == torch.uint8 else (lab != 0).to(torch.uint8)
+
     def _rebuild(self) -> None:
         r = self.rows
         g = DeviceGraph(self.N, self.device)
