@@ -3397,6 +3397,13 @@ __global__ __launch_bounds__(512) void k_gru_bwd_two(GruBwdFusedArgs a, int ntil
 #pragma unroll
         for (int s6 = 0; s6 < 6; ++s6) {
             const int kb = s6 / 3, j = s6 % 3;
+#ifdef TWO_PRIO
+            // alternate who wins the issue arbitration, group by group (3) or tile by tile (4) -- measured, same box, 3.91 ms
+            // default: fixed priority for either role 3.92-3.95, alternating per group 4.12, per tile 3.95: arbitration is not
+            // what makes the W_hh side slow
+            if (TWO_PRIO == 3) { if (role == (s6 & 1)) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(0); }
+            if (TWO_PRIO == 4 && s6 == 0) { if (role == (it & 1)) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(0); }
+#endif
             uint4 bd[3], aw[3], bt[3];
             const uint16_t* pd;
             {
