@@ -3189,6 +3189,11 @@ __global__ __launch_bounds__(512) void k_gru_bwd_two(GruBwdFusedArgs a, int ntil
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int role = wave >> 2, q = wave & 3;                 // role 0: W_ih side, 1: W_hh side
+#ifdef TWO_EXP_SAMEWORK        // timing experiment (wrong results): the W_hh-side waves read exactly what the W_ih side reads
+    const int lrole = 0;
+#else
+    const int lrole = role;
+#endif
 #ifdef TWO_PRIO
     // (experiment: the s_memtime profile shows the W_ih-side waves 19 % of a tile at the barrier, waiting for their SIMD
     //  partners of the W_hh side, which are slower in every phase)
@@ -3220,7 +3225,7 @@ __global__ __launch_bounds__(512) void k_gru_bwd_two(GruBwdFusedArgs a, int ntil
     const int se0 = srow * 64 + (((f4 >> 2) ^ (srow & 15)) << 2);
     // row reads of the data product: rows j16 and 16 + j16 share the swizzle
     const int swzj = dui_swz(j16), rowj = j16 * 128;
-    const int hix = role == 0 ? 0 : 64;                        // d_h takes dn*r (image columns 192..255) for the n gate
+    const int hix = lrole == 0 ? 0 : 64;                       // d_h takes dn*r (image columns 192..255) for the n gate
     // ---- weight gradient (32x32x16, transposed reads): A tiles jt0 + {0,1,2} of the side's six, operand tile t
     const int half = lane >> 5, c32 = lane & 31;
     const int jt0 = (q >> 1) * 3, tt = q & 1;
@@ -3230,12 +3235,12 @@ __global__ __launch_bounds__(512) void k_gru_bwd_two(GruBwdFusedArgs a, int ntil
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
         const int jj0 = (jt0 + j) * 32;
-        const int col = (role == 1 && jj0 >= 2 * H) ? jj0 + H : jj0;
+        const int col = (lrole == 1 && jj0 >= 2 * H) ? jj0 + H : jj0;
         const int ch = ((col & 127) >> 3) + 2 * tg + (tp >> 1);
         offA[j] = (col >> 7) * SUB + trow + ((ch ^ tsw0) << 3) + 4 * (tp & 1);
     }
     {
-        const int ch = ((role * H + tt * 32) >> 3) + 2 * tg + (tp >> 1);
+        const int ch = ((lrole * H + tt * 32) >> 3) + 2 * tg + (tp >> 1);
         offB = OFF_B + trow + ((ch ^ tsw0) << 3) + 4 * (tp & 1);
     }
     f32x16 acc[3];
