@@ -557,6 +557,15 @@ int tmpnn_wide_gru_bwd_diff(const void* prep, const tmpnn_graph* g, const float*
                             size_t gate_plane, const float* d_hout, int ld_dhout, const float* dy, const float* w_head,
                             float* d_h, int ld_dh, float* dW_ih, float* dW_hh, float* db_ih, float* db_hh, void* ws,
                             size_t ws_bytes, tmpnn_stream stream);
+/* The same call with the det-side branch (the signed segment sums of d_gi and the message adjoint) enqueued on a SECOND
+ * stream next to the two E-row matrix kernels: forked from `stream` after the gate gradients, joined before the det-side
+ * weight gradient, so `stream` order alone still covers every output.  Results are bit-identical to tmpnn_wide_gru_bwd_diff.
+ * aux_stream must differ from stream; do not use while `stream` is being captured into a graph. */
+int tmpnn_wide_gru_bwd_diff_aux(const void* prep, const tmpnn_graph* g, const float* h, int ld_h, int H, const float* gates,
+                            size_t gate_plane, const float* d_hout, int ld_dhout, const float* dy, const float* w_head,
+                            float* d_h, int ld_dh, float* dW_ih, float* dW_hh, float* db_ih, float* db_hh, void* ws,
+                            size_t ws_bytes, tmpnn_stream stream,
+                                tmpnn_stream aux_stream);
 
 #ifdef __cplusplus
 }

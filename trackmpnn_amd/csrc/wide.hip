@@ -1573,10 +1573,10 @@ size_t tmpnn_wide_gru_bwd_diff_ws(int N, int R, int Dn, int H) {
  *     dW_ih += S^T h[det rows]                                 instead of  d_gi^T (h[src] - h[dst]) over the edges
  * i.e. two of the four (R x 3H x H) products run over Dn rows instead of E (C5: 15 000 instead of 4.4 M).
  * d_h[edge_row[e]] = dh z + d_gh W_hh (plain store), dW_hh += d_gh^T h[edge rows], db_ih / db_hh += column sums. */
-int tmpnn_wide_gru_bwd_diff(const void* prep, const tmpnn_graph* g, const float* h, int ld_h, int H, const float* gates,
-                            size_t gate_plane, const float* d_hout, int ld_dhout, const float* dy, const float* w_head,
-                            float* d_h, int ld_dh, float* dW_ih, float* dW_hh, float* db_ih, float* db_hh, void* ws,
-                            size_t ws_bytes, tmpnn_stream stream) {
+static int wide_gru_bwd_diff_impl(const void* prep, const tmpnn_graph* g, const float* h, int ld_h, int H, const float* gates,
+                                  size_t gate_plane, const float* d_hout, int ld_dhout, const float* dy, const float* w_head,
+                                  float* d_h, int ld_dh, float* dW_ih, float* dW_hh, float* db_ih, float* db_hh, void* ws,
+                                  size_t ws_bytes, tmpnn_stream stream, tmpnn_stream aux_stream) {
     TM_REQUIRE(tmpnn_wide_supported(H, H), "wide_gru_bwd_diff: H=%d", H);
     TM_REQUIRE(g != nullptr, "wide_gru_bwd_diff: graph is null");
     const int N = g->N, R = g->E, Dn = g->Dn;
@@ -1613,24 +1613,44 @@ int tmpnn_wide_gru_bwd_diff(const void* prep, const tmpnn_graph* g, const float*
     const uint16_t* f_hh = reinterpret_cast<const uint16_t*>(prep);
     const uint16_t* b_ih = f_hh + (size_t)3 * H * 3 * H + (size_t)3 * H * 3 * H;
     const uint16_t* b_hh = b_ih + (size_t)3 * 3 * H * H;
+    // With an auxiliary stream the det-side branch (3, 4: the signed segment sums of d_gi and the message adjoint -- row movers
+    // and a Dn-row product, 4.9 ms per C5 iteration) runs NEXT TO the two E-row matrix kernels (2, 5a: 22.6 ms, matrix-pipe
+    // bound): both only read dg4 and write disjoint rows of d_h.  Fork after 1, join before 5b (which reads S and reuses the
+    // slab buffer).  Same kernels on the same data in the same order per buffer: bit-identical to the one-stream form.
+    hipStream_t sx = aux_stream ? as_stream(aux_stream) : st;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    if (aux_stream) {
+        if (hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&ev_join, hipEventDisableTiming) != hipSuccess)
+            return set_error(TMPNN_ELAUNCH, "wide_gru_bwd_diff: event creation failed");
+        (void)hipEventRecord(ev_fork, st);
+        (void)hipStreamWaitEvent(sx, ev_fork, 0);
+    }
+    auto done = [&](int code) {                    // (events are released once their pending work has completed)
+        if (ev_fork) (void)hipEventDestroy(ev_fork);
+        if (ev_join) (void)hipEventDestroy(ev_join);
+        return code;
+    };
     WideArgs y{};
     y.A = dg4; y.lda = 4 * H; y.a_rows = g->edge_row; y.R = R; y.K = 3 * H; y.kskip_at = 2 * H; y.kskip = H;
     y.img = b_hh; y.N = H; y.C = d_h; y.ldc = ld_dh; y.c_rows = g->edge_row; y.accumulate = 1;
 #ifndef WT_GEMM_STORE
     // (the E-row product of the backward: the ring form; its weight image is the sixth of prep)
     y.img = f_hh + (size_t)3 * (4 * 3 * H * H) + (size_t)3 * H * 3 * H;
-    if ((rc = launch_gemm_ring(y, st))) return rc;
+    if ((rc = launch_gemm_ring(y, st))) return done(rc);
 #else
-    if ((rc = launch_store(y, st))) return rc;
+    if ((rc = launch_store(y, st))) return done(rc);
 #endif
     // 3. S[d] = signed segment sum of d_gi (image columns 0..3H) over the det's incident edges, compact rows
     for (int k = 0; k < 3; ++k)
-        if ((rc = tmpnn_segsum_fwd(g, dg4 + (size_t)k * H, 4 * H, S + (size_t)k * H, 3 * H, H, 0, 1, stream))) return rc;
+        if ((rc = tmpnn_segsum_fwd(g, dg4 + (size_t)k * H, 4 * H, S + (size_t)k * H, 3 * H, H, 0, 1,
+                                   aux_stream ? aux_stream : stream))) return done(rc);
     // 4. message adjoint on the det rows: d_h[det_row[d]] += S[d] W_ih
     WideArgs x{};
     x.A = S; x.lda = 3 * H; x.a_rows = nullptr; x.R = Dn; x.K = 3 * H; x.kskip_at = 3 * H; x.kskip = 0;
     x.img = b_ih; x.N = H; x.C = d_h; x.ldc = ld_dh; x.c_rows = g->det_row; x.accumulate = 1;
-    if ((rc = launch_store(x, st))) return rc;
+    if ((rc = launch_store(x, sx))) return done(rc);
+    if (aux_stream) (void)hipEventRecord(ev_join, sx);
     // 5. weight gradients: dW_hh over the edge rows (bias sums: db_hh, and db_ih's r / z thirds), dW_ih over the det rows
     const int mt = 3 * H / 192, nt = H / 128;
     TM_SHM_ONCE(k_wide_dw, DW_SHM);
@@ -1640,21 +1660,39 @@ int tmpnn_wide_gru_bwd_diff(const void* prep, const tmpnn_graph* g, const float*
         const int nslab = (R + rps - 1) / rps;
         WideDwArgs q{dg4, 4 * H, g->edge_row, 2 * H, H, h, ld_h, g->edge_row, nullptr, R, H, rps, slabs, bslabs};
         hipLaunchKernelGGL(k_wide_dw, dim3(mt * nt, nslab), dim3(512), DW_SHM, st, q, mt, nt);
-        if ((rc = check_launch("wide_dw"))) return rc;
-        if ((rc = launch_reduce_slabs(slabs, (size_t)3 * H * H, nslab, dW_hh, (size_t)3 * H * H, 1, st, fold))) return rc;
-        if ((rc = launch_reduce_slabs(bslabs, (size_t)3 * H, nslab, db_hh, (size_t)3 * H, 1, st, fold))) return rc;
-        if ((rc = launch_reduce_slabs(bslabs, (size_t)3 * H, nslab, db_ih, (size_t)2 * H, 1, st, fold))) return rc;
+        if ((rc = check_launch("wide_dw"))) return done(rc);
+        if ((rc = launch_reduce_slabs(slabs, (size_t)3 * H * H, nslab, dW_hh, (size_t)3 * H * H, 1, st, fold))) return done(rc);
+        if ((rc = launch_reduce_slabs(bslabs, (size_t)3 * H, nslab, db_hh, (size_t)3 * H, 1, st, fold))) return done(rc);
+        if ((rc = launch_reduce_slabs(bslabs, (size_t)3 * H, nslab, db_ih, (size_t)2 * H, 1, st, fold))) return done(rc);
     }
+    if (aux_stream) (void)hipStreamWaitEvent(st, ev_join, 0);          // S is complete, d_h's det rows are final
     {
         const int n = dw_slabs(Dn, H);
         const int rps = ((Dn + n - 1) / n + 31) / 32 * 32;
         const int nslab = (Dn + rps - 1) / rps;
         WideDwArgs q{S, 3 * H, nullptr, 3 * H, 0, h, ld_h, g->det_row, nullptr, Dn, H, rps, slabs, bslabs};
         hipLaunchKernelGGL(k_wide_dw, dim3(mt * nt, nslab), dim3(512), DW_SHM, st, q, mt, nt);
-        if ((rc = check_launch("wide_dw"))) return rc;
-        if ((rc = launch_reduce_slabs(slabs, (size_t)3 * H * H, nslab, dW_ih, (size_t)3 * H * H, 1, st, fold))) return rc;
+        if ((rc = check_launch("wide_dw"))) return done(rc);
+        if ((rc = launch_reduce_slabs(slabs, (size_t)3 * H * H, nslab, dW_ih, (size_t)3 * H * H, 1, st, fold))) return done(rc);
     }
-    return TMPNN_OK;
+    return done(TMPNN_OK);
+}
+
+int tmpnn_wide_gru_bwd_diff(const void* prep, const tmpnn_graph* g, const float* h, int ld_h, int H, const float* gates,
+                            size_t gate_plane, const float* d_hout, int ld_dhout, const float* dy, const float* w_head,
+                            float* d_h, int ld_dh, float* dW_ih, float* dW_hh, float* db_ih, float* db_hh, void* ws,
+                            size_t ws_bytes, tmpnn_stream stream) {
+    return wide_gru_bwd_diff_impl(prep, g, h, ld_h, H, gates, gate_plane, d_hout, ld_dhout, dy, w_head, d_h, ld_dh, dW_ih, dW_hh,
+                                  db_ih, db_hh, ws, ws_bytes, stream, nullptr);
+}
+
+int tmpnn_wide_gru_bwd_diff_aux(const void* prep, const tmpnn_graph* g, const float* h, int ld_h, int H, const float* gates,
+                                size_t gate_plane, const float* d_hout, int ld_dhout, const float* dy, const float* w_head,
+                                float* d_h, int ld_dh, float* dW_ih, float* dW_hh, float* db_ih, float* db_hh, void* ws,
+                                size_t ws_bytes, tmpnn_stream stream, tmpnn_stream aux_stream) {
+    TM_REQUIRE(aux_stream != nullptr && aux_stream != stream, "wide_gru_bwd_diff_aux: needs a second stream");
+    return wide_gru_bwd_diff_impl(prep, g, h, ld_h, H, gates, gate_plane, d_hout, ld_dhout, dy, w_head, d_h, ld_dh, dW_ih, dW_hh,
+                                  db_ih, db_hh, ws, ws_bytes, stream, aux_stream);
 }
 
 }  // extern "C"

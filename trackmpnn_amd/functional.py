@@ -47,6 +47,24 @@ INPUT_TF = os.environ.get('TMPNN_INPUT_TF', '1') != '0'
 # backward runs the forward kernel again into the gate planes (and a scratch state) right before the one-pass backward
 # reads them.  Same gradients bit for bit; measured SLOWER (numbers in DESIGN), so off by default.
 RECOMPUTE_GATES = os.environ.get('TMPNN_RECOMPUTE_GATES', '0') == '1'
+# wide cells: the det-side branch of the backward on a second stream next to the E-row matrix kernels (tmpnn_wide_gru_bwd_diff_aux)
+WIDE_OVERLAP = os.environ.get('TMPNN_WIDE_OVERLAP', '1') != '0'
+_aux_streams: Dict[torch.device, 'torch.cuda.Stream'] = {}
+
+
+def _aux_stream(dev) -> Optional[int]:
+    """Raw handle of this device's auxiliary stream, or None while the current stream is being captured (a forked stream
+    inside a capture does not survive hipStreamEndCapture on this stack) or when the current stream is the auxiliary one."""
+    if not WIDE_OVERLAP or torch.cuda.is_current_stream_capturing():
+        return None
+    key = torch.device(dev)
+    s = _aux_streams.get(key)
+    if s is None:
+        s = torch.cuda.Stream(key)
+        _aux_streams[key] = s
+    if s.cuda_stream == torch.cuda.current_stream(key).cuda_stream:
+        return None
+    return s.cuda_stream
 
 
 _wide_ws: Dict[torch.device, torch.Tensor] = {}
@@ -459,11 +477,17 @@ def mp_backward(spec: ModelSpec, plan: CallPlan, saved: dict, P: Dict[str, torch
                 # whole edge-cell backward in one call; the message adjoint lands on d_hcat's det rows directly
                 wsb = int(lib.tmpnn_wide_gru_bwd_diff_ws(N, E, Dn, H))
                 ws_wide = _wide_workspace(wsb, dev)
-                _lib.call('tmpnn_wide_gru_bwd_diff', saved['wide'][gi].data_ptr(), g.cref(), hg, GH, H, gp, plane, dog, GH,
-                          dyp, we, dhg, GH,
-                          grads[f + 'edge_gru.weight_ih'].data_ptr(), grads[f + 'edge_gru.weight_hh'].data_ptr(),
-                          grads[f + 'edge_gru.bias_ih'].data_ptr(), grads[f + 'edge_gru.bias_hh'].data_ptr(),
-                          ws_wide.data_ptr(), wsb, st)
+                aux = _aux_stream(dev)
+                args = (saved['wide'][gi].data_ptr(), g.cref(), hg, GH, H, gp, plane, dog, GH, dyp, we, dhg, GH,
+                        grads[f + 'edge_gru.weight_ih'].data_ptr(), grads[f + 'edge_gru.weight_hh'].data_ptr(),
+                        grads[f + 'edge_gru.bias_ih'].data_ptr(), grads[f + 'edge_gru.bias_hh'].data_ptr(),
+                        ws_wide.data_ptr(), wsb, st)
+                if aux is not None:
+                    # (every buffer the auxiliary stream touches was allocated on, and is next used on, the current stream,
+                    #  which the call leaves waiting for the auxiliary work: no record_stream needed)
+                    _lib.call('tmpnn_wide_gru_bwd_diff_aux', *args, aux)
+                else:
+                    _lib.call('tmpnn_wide_gru_bwd_diff', *args)
                 if fuse:
                     _lib.call('tmpnn_gather_diff_fwd', g.cref(), dmsg.data_ptr(), IN_e, dhg, GH, H, 1, st)
             elif saved.get('wide'):
