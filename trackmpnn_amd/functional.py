@@ -275,6 +275,18 @@ def mp_forward(spec: ModelSpec, plan: CallPlan, x: torch.Tensor, h_in: Optional[
         #  hand a freed block to the very next allocation)
         e_wih_t, e_whh_t = _transpose(P[f + 'edge_gru.weight_ih']), _transpose(P[f + 'edge_gru.weight_hh'])
         n_wih_t, n_whh_t = _transpose(P[f + 'node_gru.weight_ih']), _transpose(P[f + 'node_gru.weight_hh'])
+        # wide cells without attention: the det-side chain (row F, then the node cell: row movers + a Dn-row cell) goes to the
+        # auxiliary stream next to the edge cell's persistent matrix kernel -- both only read h_cat and write disjoint rows of
+        # h_out / the gate planes; nothing is allocated under the auxiliary stream
+        st_det, aux_obj = st, None
+        if use_wide and K == 0:
+            aux = _aux_stream(dev)
+            if aux is not None:
+                aux_obj = _aux_streams[torch.device(dev)]
+                fork = torch.cuda.Event()
+                fork.record()
+                aux_obj.wait_event(fork)
+                st_det = aux
         if use_wide:
             # H = 128 / 256: LDS-tiled bf16x6 GEMMs, the diff message through the projected det rows (csrc/wide.hip)
             prep = _wide_prep(P[f + 'edge_gru.weight_ih'], P[f + 'edge_gru.weight_hh'], H)
@@ -316,7 +328,7 @@ def mp_forward(spec: ModelSpec, plan: CallPlan, x: torch.Tensor, h_in: Optional[
         # edge -> node aggregation                              (layers.py:99-112)
         es = es_all[gi]
         if K == 0:
-            _lib.call('tmpnn_segsum_fwd', g.cref(), hg, GH, es.data_ptr(), H, H, 0, 1, st)
+            _lib.call('tmpnn_segsum_fwd', g.cref(), hg, GH, es.data_ptr(), H, H, 0, 1, st_det)
             alphas.append(None)
         else:
             W = torch.stack([P[f + f'gat.{k}.W_att'] for k in range(K)]).contiguous()
@@ -340,7 +352,11 @@ def mp_forward(spec: ModelSpec, plan: CallPlan, x: torch.Tensor, h_in: Optional[
                   es.data_ptr(), H, 1, H, hg, GH, H,
                   n_wih_t.data_ptr(), n_whh_t.data_ptr(),
                   P[f + 'node_gru.bias_ih'].data_ptr(), P[f + 'node_gru.bias_hh'].data_ptr(),
-                  og, GH, gp, plane, wn_g, part_g, N, st)
+                  og, GH, gp, plane, wn_g, part_g, N, st_det)
+        if aux_obj is not None:
+            join = torch.cuda.Event()
+            join.record(aux_obj)
+            torch.cuda.current_stream(dev).wait_event(join)
     logits = torch.empty((N, 1), **opts)
     scores = torch.empty((N, 1), **opts)
     if cw > 0:
