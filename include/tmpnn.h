@@ -566,6 +566,15 @@ int tmpnn_wide_gru_bwd_diff_aux(const void* prep, const tmpnn_graph* g, const fl
                             float* d_h, int ld_dh, float* dW_ih, float* dW_hh, float* db_ih, float* db_hh, void* ws,
                             size_t ws_bytes, tmpnn_stream stream,
                                 tmpnn_stream aux_stream);
+/* ... and with the adjoint of row F (models/layers.py:103: d_h[e] += add_msg[src[e]] - add_msg[dst[e]], what
+ * tmpnn_gather_diff_fwd(g, add_msg, ld_add, d_h, ld_dh, H, accumulate = 1) would add afterwards) taken in the epilogue of the
+ * E-row product: one read-modify-write pass over d_h's edge rows less.  add_msg: the table whose det rows hold d_es (>= H
+ * columns); aux_stream may be NULL (one stream).  Bit-identical to the two calls. */
+int tmpnn_wide_gru_bwd_diff_fused(const void* prep, const tmpnn_graph* g, const float* h, int ld_h, int H, const float* gates,
+                                  size_t gate_plane, const float* d_hout, int ld_dhout, const float* dy, const float* w_head,
+                                  float* d_h, int ld_dh, float* dW_ih, float* dW_hh, float* db_ih, float* db_hh, void* ws,
+                                  size_t ws_bytes, const float* add_msg, int ld_add, tmpnn_stream stream,
+                                  tmpnn_stream aux_stream);
 
 #ifdef __cplusplus
 }

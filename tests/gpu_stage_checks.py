@@ -529,6 +529,24 @@ def check_wide(H, g, gd):
               doutD.data_ptr() + 4 * H, ld, None, None, dh.data_ptr() + 4 * H, ld, gr[0].data_ptr(), gr[1].data_ptr(),
               gr[2].data_ptr(), gr[3].data_ptr(), ws.data_ptr(), wsb, st())
     compare('det-side', dh, gr)
+    # the same call with its det-side branch on a second stream, and with the adjoint of row F (add_msg[src] - add_msg[dst]
+    # into the edge rows of d_h) taken in the epilogue of the E-row product: bit-identical to the plain call (+ the gather)
+    addm = torch.randn(g.N, H + 8, device=DEV)
+    _lib.call('tmpnn_gather_diff_fwd', gd.cref(), addm.data_ptr(), H + 8, dh.data_ptr() + 4 * H, ld, H, 1, st())
+    aux = torch.cuda.Stream(DEV)
+    for tag, use_aux, fused in (('aux stream', True, False), ('fused adjoint', False, True), ('fused adjoint + aux', True, True)):
+        dh2, gr2 = fresh()
+        args = (prep.data_ptr(), gd.cref(), hD.data_ptr() + 4 * H, ld, H, gates.data_ptr(), g.N * H,
+                doutD.data_ptr() + 4 * H, ld, None, None, dh2.data_ptr() + 4 * H, ld, gr2[0].data_ptr(), gr2[1].data_ptr(),
+                gr2[2].data_ptr(), gr2[3].data_ptr(), ws.data_ptr(), wsb)
+        if fused:
+            _lib.call('tmpnn_wide_gru_bwd_diff_fused', *args, addm.data_ptr(), H + 8, st(), aux.cuda_stream if use_aux else None)
+        else:
+            _lib.call('tmpnn_wide_gru_bwd_diff_aux', *args, st(), aux.cuda_stream)
+            _lib.call('tmpnn_gather_diff_fwd', gd.cref(), addm.data_ptr(), H + 8, dh2.data_ptr() + 4 * H, ld, H, 1, st())
+        torch.cuda.synchronize()
+        same = torch.equal(dh2, dh) and all(torch.equal(a, b) for a, b in zip(gr2, gr))
+        res[f'det-side, {tag}: bits'] = 0.0 if same else 1.0
     # per-edge form
     dh, gr = fresh()
     wsb = int(lib.tmpnn_wide_gru_bwd_data_ws(R, H))
@@ -672,7 +690,7 @@ def run_all(report=print):
                 rec(f'gru H={H} xmode={xmode} rows={kind} {k}', v, 0.0 if k == 'untouched' else 2e-4)
     for H in (128, 256):
         for k, v in check_wide(H, g, gd).items():
-            rec(f'wide cell H={H} {k}', v, 0.0 if k.endswith('untouched') else 2e-4)
+            rec(f'wide cell H={H} {k}', v, 0.0 if (k.endswith('untouched') or k.endswith('bits')) else 2e-4)
     from trackmpnn_amd.graph import dense_static_graph
     for H in (128, 256):
         # a dense 3-block window (tiles staged in LDS), a larger ragged batch (both kinds) and the small batch (one tile)

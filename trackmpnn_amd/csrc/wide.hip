@@ -105,6 +105,8 @@ struct WideArgs {
     const uint16_t* img; int N;                 // weight image [K/32][3][N][32]
     // STORE epilogue: C[(c_rows ? c_rows[r] : r) * ldc + n] (=|+=) acc
     float* C; int ldc; const int32_t* c_rows; int accumulate;
+    // ... plus, in the ring form, the adjoint of row F: C[row r] += add_msg[add_src[r]] - add_msg[add_dst[r]] (columns n)
+    const float* add_msg; int ld_add; const int32_t* add_src; const int32_t* add_dst;
     // GRU epilogue (forward): P [Dn][3H] projected det rows, src/dst det INDEX per row, state, biases, outputs
     const float* P; int ldp; const int32_t* src_pos; const int32_t* dst_pos;
     const float* h; int ld_h; int H; const float* b_ih; const float* b_hh;
@@ -974,13 +976,14 @@ __global__ __launch_bounds__(512) void k_wide_gemm_ring(WideArgs a) {
         const int r0 = t * 128;
         // the accumulate operand of the epilogue's rows, requested before the tile is staged
         float4 cprev[8];
-        int crow[8];
+        int crow[8], asrc[8], adst[8];
         {
             const int te = opaque(tid);
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 const int rr = min(r0 + (te >> 5) + 16 * i, a.R - 1);
                 crow[i] = a.c_rows ? a.c_rows[rr] : rr;
+                if (a.add_msg) { asrc[i] = a.add_src[rr]; adst[i] = a.add_dst[rr]; }
             }
             if (a.accumulate) {
 #pragma unroll
@@ -1004,6 +1007,11 @@ __global__ __launch_bounds__(512) void k_wide_gemm_ring(WideArgs a) {
                 if (r0 + lr >= a.R) continue;
                 float4 v = *reinterpret_cast<const float4*>(sC + lr * LDC + 4 * q);
                 if (a.accumulate) { v.x += cprev[i].x; v.y += cprev[i].y; v.z += cprev[i].z; v.w += cprev[i].w; }
+                if (a.add_msg) {       // (det rows of add_msg: L2-resident; the sum in the order of tmpnn_gather_diff_fwd(accumulate))
+                    const float4 ms = *reinterpret_cast<const float4*>(a.add_msg + (size_t)asrc[i] * a.ld_add + n0 + 4 * q);
+                    const float4 md = *reinterpret_cast<const float4*>(a.add_msg + (size_t)adst[i] * a.ld_add + n0 + 4 * q);
+                    v.x = (ms.x - md.x) + v.x; v.y = (ms.y - md.y) + v.y; v.z = (ms.z - md.z) + v.z; v.w = (ms.w - md.w) + v.w;
+                }
                 *reinterpret_cast<float4*>(a.C + (size_t)crow[i] * a.ldc + n0 + 4 * q) = v;
             }
         }
@@ -1576,8 +1584,11 @@ size_t tmpnn_wide_gru_bwd_diff_ws(int N, int R, int Dn, int H) {
 static int wide_gru_bwd_diff_impl(const void* prep, const tmpnn_graph* g, const float* h, int ld_h, int H, const float* gates,
                                   size_t gate_plane, const float* d_hout, int ld_dhout, const float* dy, const float* w_head,
                                   float* d_h, int ld_dh, float* dW_ih, float* dW_hh, float* db_ih, float* db_hh, void* ws,
-                                  size_t ws_bytes, tmpnn_stream stream, tmpnn_stream aux_stream) {
+                                  size_t ws_bytes, tmpnn_stream stream, tmpnn_stream aux_stream, const float* add_msg,
+                                  int ld_add) {
     TM_REQUIRE(tmpnn_wide_supported(H, H), "wide_gru_bwd_diff: H=%d", H);
+    TM_REQUIRE(add_msg == nullptr || (aligned16(add_msg) && (ld_add & 3) == 0 && ld_add >= H && g && g->src && g->dst),
+               "wide_gru_bwd_diff: fused row-F adjoint needs a 16-byte aligned table of >= H columns and the graph's src / dst");
     TM_REQUIRE(g != nullptr, "wide_gru_bwd_diff: graph is null");
     const int N = g->N, R = g->E, Dn = g->Dn;
     if (R == 0) return TMPNN_OK;
@@ -1637,8 +1648,10 @@ static int wide_gru_bwd_diff_impl(const void* prep, const tmpnn_graph* g, const 
 #ifndef WT_GEMM_STORE
     // (the E-row product of the backward: the ring form; its weight image is the sixth of prep)
     y.img = f_hh + (size_t)3 * (4 * 3 * H * H) + (size_t)3 * H * 3 * H;
+    y.add_msg = add_msg; y.ld_add = ld_add; y.add_src = g->src; y.add_dst = g->dst;
     if ((rc = launch_gemm_ring(y, st))) return done(rc);
 #else
+    if (add_msg) return done(set_error(TMPNN_EINVAL, "wide_gru_bwd_diff: the store-GEMM build has no fused adjoint"));
     if ((rc = launch_store(y, st))) return done(rc);
 #endif
     // 3. S[d] = signed segment sum of d_gi (image columns 0..3H) over the det's incident edges, compact rows
@@ -1683,7 +1696,7 @@ int tmpnn_wide_gru_bwd_diff(const void* prep, const tmpnn_graph* g, const float*
                             float* d_h, int ld_dh, float* dW_ih, float* dW_hh, float* db_ih, float* db_hh, void* ws,
                             size_t ws_bytes, tmpnn_stream stream) {
     return wide_gru_bwd_diff_impl(prep, g, h, ld_h, H, gates, gate_plane, d_hout, ld_dhout, dy, w_head, d_h, ld_dh, dW_ih, dW_hh,
-                                  db_ih, db_hh, ws, ws_bytes, stream, nullptr);
+                                  db_ih, db_hh, ws, ws_bytes, stream, nullptr, nullptr, 0);
 }
 
 int tmpnn_wide_gru_bwd_diff_aux(const void* prep, const tmpnn_graph* g, const float* h, int ld_h, int H, const float* gates,
@@ -1692,7 +1705,18 @@ int tmpnn_wide_gru_bwd_diff_aux(const void* prep, const tmpnn_graph* g, const fl
                                 size_t ws_bytes, tmpnn_stream stream, tmpnn_stream aux_stream) {
     TM_REQUIRE(aux_stream != nullptr && aux_stream != stream, "wide_gru_bwd_diff_aux: needs a second stream");
     return wide_gru_bwd_diff_impl(prep, g, h, ld_h, H, gates, gate_plane, d_hout, ld_dhout, dy, w_head, d_h, ld_dh, dW_ih, dW_hh,
-                                  db_ih, db_hh, ws, ws_bytes, stream, aux_stream);
+                                  db_ih, db_hh, ws, ws_bytes, stream, aux_stream, nullptr, 0);
+}
+
+int tmpnn_wide_gru_bwd_diff_fused(const void* prep, const tmpnn_graph* g, const float* h, int ld_h, int H, const float* gates,
+                                  size_t gate_plane, const float* d_hout, int ld_dhout, const float* dy, const float* w_head,
+                                  float* d_h, int ld_dh, float* dW_ih, float* dW_hh, float* db_ih, float* db_hh, void* ws,
+                                  size_t ws_bytes, const float* add_msg, int ld_add, tmpnn_stream stream,
+                                  tmpnn_stream aux_stream) {
+    TM_REQUIRE(add_msg != nullptr, "wide_gru_bwd_diff_fused: add_msg is null");
+    TM_REQUIRE(aux_stream != stream || aux_stream == nullptr, "wide_gru_bwd_diff_fused: aux_stream must differ from stream (or be null)");
+    return wide_gru_bwd_diff_impl(prep, g, h, ld_h, H, gates, gate_plane, d_hout, ld_dhout, dy, w_head, d_h, ld_dh, dW_ih, dW_hh,
+                                  db_ih, db_hh, ws, ws_bytes, stream, aux_stream, add_msg, ld_add);
 }
 
 }  // extern "C"

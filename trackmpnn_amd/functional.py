@@ -49,6 +49,7 @@ INPUT_TF = os.environ.get('TMPNN_INPUT_TF', '1') != '0'
 RECOMPUTE_GATES = os.environ.get('TMPNN_RECOMPUTE_GATES', '0') == '1'
 # wide cells: the det-side branch of the backward on a second stream next to the E-row matrix kernels (tmpnn_wide_gru_bwd_diff_aux)
 WIDE_OVERLAP = os.environ.get('TMPNN_WIDE_OVERLAP', '1') != '0'
+WIDE_FUSED_ADJOINT = os.environ.get('TMPNN_WIDE_FUSED_ADJOINT', '1') != '0'
 _aux_streams: Dict[torch.device, 'torch.cuda.Stream'] = {}
 
 
@@ -498,14 +499,18 @@ def mp_backward(spec: ModelSpec, plan: CallPlan, saved: dict, P: Dict[str, torch
                         grads[f + 'edge_gru.weight_ih'].data_ptr(), grads[f + 'edge_gru.weight_hh'].data_ptr(),
                         grads[f + 'edge_gru.bias_ih'].data_ptr(), grads[f + 'edge_gru.bias_hh'].data_ptr(),
                         ws_wide.data_ptr(), wsb, st)
-                if aux is not None:
-                    # (every buffer the auxiliary stream touches was allocated on, and is next used on, the current stream,
-                    #  which the call leaves waiting for the auxiliary work: no record_stream needed)
-                    _lib.call('tmpnn_wide_gru_bwd_diff_aux', *args, aux)
+                # (every buffer the auxiliary stream touches was allocated on, and is next used on, the current stream,
+                #  which the call leaves waiting for the auxiliary work: no record_stream needed)
+                if fuse and WIDE_FUSED_ADJOINT:
+                    # the adjoint of the edge -> node sum rides in the epilogue of the E-row product (no separate pass over d_h)
+                    _lib.call('tmpnn_wide_gru_bwd_diff_fused', *args[:-1], dmsg.data_ptr(), IN_e, st, aux)
                 else:
-                    _lib.call('tmpnn_wide_gru_bwd_diff', *args)
-                if fuse:
-                    _lib.call('tmpnn_gather_diff_fwd', g.cref(), dmsg.data_ptr(), IN_e, dhg, GH, H, 1, st)
+                    if aux is not None:
+                        _lib.call('tmpnn_wide_gru_bwd_diff_aux', *args, aux)
+                    else:
+                        _lib.call('tmpnn_wide_gru_bwd_diff', *args)
+                    if fuse:
+                        _lib.call('tmpnn_gather_diff_fwd', g.cref(), dmsg.data_ptr(), IN_e, dhg, GH, H, 1, st)
             elif saved.get('wide'):
                 wsb = int(lib.tmpnn_wide_gru_bwd_data_ws(E, H))
                 ws_wide = _wide_workspace(wsb, dev)
