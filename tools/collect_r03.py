@@ -188,6 +188,10 @@ if have(f'gpurun_out/{tag}_c5/kernel_stats.csv', f'gpurun_out/{tag}_c5/plain.log
 MFMA-pipe fraction: 6 bf16 products per fp32 product (bf16x6, fp32-accurate) x 2 flops / duration against the dense bf16 peak of
 2.5 PFLOP/s -- the matrix pipe is what bounds them (their floor at the ~1.8 GHz the chip holds under MFMA load is 5.6 ms).
 PMC traffic = 2 x FETCH_SIZE + WRITE_SIZE (KB x 1024; gfx950 correction for 16-byte-per-lane streams).
+Since the det-side branches run on a second stream (DESIGN 11.2), `k_segsum_pipe` / the Dn-row `k_wide_gemm_store` / `k_gru_fwd<2, 0>`
+execute CONCURRENTLY with `k_wide_gru_fwd_ring`, `k_wide_gemm_ring` and `k_wide_dw`: a kernel's duration below includes the time it
+shares the GPU (alone: ring forward 12.0, ring GEMM 10.6 + 1.7 for the adjoint it now carries, segment sum 1.5 ms), so the
+fractions of overlapped kernels understate what each reaches alone.
 
 | kernel | launches / step | avg ms | % of GPU time | algorithmic GB | GB/s | of 8 TB/s | bf16-MFMA TFLOP/s | of 2.5 PF | PMC traffic GB | traffic / algorithmic |
 |---|---|---|---|---|---|---|---|---|---|---|
