@@ -105,7 +105,7 @@ class CapturedWindow:
         else:
             grads = [p.grad for p in self.model.parameters() if p.grad is not None]
             if grads:
-                torch._foreach_zero_(grads)             # (fill kernels: one memset NODE per parameter does not survive capture on this stack)
+                torch._foreach_zero_(grads)             # (a few fused fill launches instead of one memset per parameter)
         if self.inplace:
             loss.backward()                             # (in-place mode: the kernels add into p.grad, no parameter is an autograd input)
         else:
