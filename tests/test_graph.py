@@ -279,3 +279,26 @@ def test_edge_tiles_cover_every_edge_and_index_their_dets():
     assert edge_tiles(gr, 128) is edge_tiles(gr, 128)   # cached on the graph
     empty = dense_static_graph(1, 5)
     assert build_edge_tiles(empty, 128).T == 0
+
+
+def test_module_copy_and_pickle_on_the_host():
+    """copy.deepcopy / pickle of the module (what EMA copies, best-model snapshots and torch.save(model) do): the batch-1
+    path's caches (ctypes pointer structs, function pointers, a non-leaf sink tensor) are dropped and rebuilt, parameters
+    and buffers are copied, the copy is independent.  (The GPU variant -- after the caches have been populated -- is
+    tests/test_small_path_gpu.py::test_model_can_be_copied_and_pickled_after_use.)"""
+    import copy
+    import pickle
+    from trackmpnn_amd import TrackMPNN
+    m = TrackMPNN('2d+temp', 3, 64, 1, 'diff')
+    m._anch_calls = 5
+    m._pending_graphs.append('x')
+    for twin in (copy.deepcopy(m), pickle.loads(pickle.dumps(m))):
+        assert twin._small is not m._small and twin._small.model is twin
+        assert twin._anch_calls == 0 and twin._pending_graphs == [] and twin._sink is None
+        for (k, a), (_, b) in zip(m.state_dict().items(), twin.state_dict().items()):
+            assert torch.equal(a, b) and (a.data_ptr() != b.data_ptr() or a.numel() == 0), k
+        with torch.no_grad():
+            twin.factor_grus[0].edge_gru.weight_hh.mul_(0.0)
+        assert float(m.factor_grus[0].edge_gru.weight_hh.abs().sum()) > 0
+    m.refresh_weights()                                # drops every cached pointer; nothing to rebuild on the host
+    assert m._plist is None and m._sink is None
