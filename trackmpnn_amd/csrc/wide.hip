@@ -1322,6 +1322,185 @@ __global__ __launch_bounds__(512) void k_wide_dw(WideDwArgs q, int mt_count, int
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// The same weight gradient on a 384 x 128 block tile in 16-row chunks (k_wide_dw2, default; -DWT_DW_OLD keeps k_wide_dw)
+// ------------------------------------------------------------------------------------------------------------
+// k_wide_dw's 192 x 128 tile makes every wave read 4 operand fragments sets per 3 output tiles and the launch read dg
+// twice and X four times (45 GB at C5).  Here a wave owns 3 x 2 output tiles (96 accumulators): 5 fragment sets per 6 tiles
+// (30 transposing LDS reads per 36 MFMAs instead of 48), dg is read twice and X twice (36 GB), a thread stages 16 values per
+// chunk instead of 20; chunks are ONE 16-row k block, so the MFMAs between two barriers stay 36 per wave and the two image
+// sets fit in 96 KB.  Per accumulator the 16-row products come in the same order as in k_wide_dw; the slab partition (and with
+// it the order of the final ordered reduction) differs.
+static constexpr int DW2_A = 3 * 16 * 384, DW2_B = 3 * 16 * 128;        // elements of one A / B image set
+static constexpr int DW2_SHM = 2 * (DW2_A + DW2_B) * 2;                 // two buffers, bf16
+
+struct Dw2Raw { float4 a[3]; float4 b0, b1; bool valid; };
+
+__device__ __forceinline__ void dw2_issue(const WideDwArgs& q, int r, int r_end, int ca, int cb, Dw2Raw& w) {
+    w.valid = r < r_end;
+    const int rr = w.valid ? r : r_end - 1;
+    const float* pa = q.dg + (size_t)(q.grows ? q.grows[rr] : rr) * q.ldg;
+#pragma unroll
+    for (int g = 0; g < 3; ++g) {
+        int cg = ca + 4 * g;
+        if (cg >= q.gskip_at) cg += q.gskip;
+        w.a[g] = *reinterpret_cast<const float4*>(pa + cg);
+    }
+    w.b0 = *reinterpret_cast<const float4*>(q.X + (size_t)q.xa[rr] * q.ldx + cb);
+    if (q.xb) w.b1 = *reinterpret_cast<const float4*>(q.X + (size_t)q.xb[rr] * q.ldx + cb);
+}
+
+__global__ __launch_bounds__(512) void k_wide_dw2(WideDwArgs q, int mt_count, int nt_count) {
+    extern __shared__ float lds[];
+    uint16_t* const base = reinterpret_cast<uint16_t*>(lds);
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int c = lane & 31, half = lane >> 5;
+    const int tile = blockIdx.x, mt = tile / nt_count, nt = tile % nt_count, slab = blockIdx.y;
+    const int H = q.H;
+    const int srow = tid >> 5, c32 = tid & 31;                       // staging: 16 rows x 32 threads
+    const int ca = mt * 384 + c32 * 12, cb = nt * 128 + c32 * 4;     // this thread's global columns of dg / X
+    const int r_lo = slab * q.rows_per_slab, r_end = min(q.R, r_lo + q.rows_per_slab);
+    // roles: A tiles 3 * (wave & 3) + {0, 1, 2} of the block's twelve, B tiles 2 * (wave >> 2) + {0, 1} of its four
+    const int jt0 = (wave & 3) * 3, bt0 = (wave >> 2) * 2;
+    const int i16 = lane & 15, tq = i16 >> 2, tp = i16 & 3, tg = (lane >> 4) & 1;
+    f32x16 acc[3][2];
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[j][b][i] = 0.f;
+    float cs[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) cs[i] = 0.f;
+
+    auto stage = [&](const Dw2Raw& w, uint16_t* sA, uint16_t* sB) {
+        float av[12];
+#pragma unroll
+        for (int g = 0; g < 3; ++g) {
+            av[4 * g] = w.a[g].x; av[4 * g + 1] = w.a[g].y; av[4 * g + 2] = w.a[g].z; av[4 * g + 3] = w.a[g].w;
+        }
+        float bv[4] = {w.b0.x, w.b0.y, w.b0.z, w.b0.w};
+        if (q.xb) { bv[0] -= w.b1.x; bv[1] -= w.b1.y; bv[2] -= w.b1.z; bv[3] -= w.b1.w; }
+#pragma unroll
+        for (int i = 0; i < 12; ++i) { av[i] = w.valid ? av[i] : 0.f; cs[i] += av[i]; }
+#pragma unroll
+        for (int g = 0; g < 3; ++g) {                    // four columns = 8 bytes per piece
+            uint2 p1, p2, p3;
+            w_split2(av[4 * g], av[4 * g + 1], p1.x, p2.x, p3.x);
+            w_split2(av[4 * g + 2], av[4 * g + 3], p1.y, p2.y, p3.y);
+            const int off = w_swz<384>(srow, c32 * 12 + 4 * g);
+            *reinterpret_cast<uint2*>(sA + off) = p1;
+            *reinterpret_cast<uint2*>(sA + 16 * 384 + off) = p2;
+            *reinterpret_cast<uint2*>(sA + 2 * 16 * 384 + off) = p3;
+        }
+        {
+            uint2 p1, p2, p3;
+            w_split2(bv[0], bv[1], p1.x, p2.x, p3.x); w_split2(bv[2], bv[3], p1.y, p2.y, p3.y);
+            const int off = w_swz<128>(srow, c32 * 4);
+            *reinterpret_cast<uint2*>(sB + off) = p1;
+            *reinterpret_cast<uint2*>(sB + 16 * 128 + off) = p2;
+            *reinterpret_cast<uint2*>(sB + 2 * 16 * 128 + off) = p3;
+        }
+    };
+
+    Dw2Raw raw;
+    const int nchunk = r_end > r_lo ? (r_end - r_lo + 15) / 16 : 0;
+    if (nchunk > 0) {
+        dw2_issue(q, r_lo + srow, r_end, ca, cb, raw);
+        stage(raw, base, base + DW2_A);
+        if (nchunk > 1) dw2_issue(q, r_lo + 16 + srow, r_end, ca, cb, raw);
+    }
+    __syncthreads();
+    const int row0 = 8 * half + tq;
+    for (int ch = 0; ch < nchunk; ++ch) {
+        uint16_t* sA = base + (ch & 1) * (DW2_A + DW2_B);
+        uint16_t* sB = sA + DW2_A;
+        uint16_t* nA = base + ((ch & 1) ^ 1) * (DW2_A + DW2_B);
+        uint4 bq[2][3];
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int col = (bt0 + b) * 32 + 16 * tg + 4 * tp;
+            const uint16_t* p0 = sB + w_swz<128>(row0, col);
+            const uint16_t* p1 = sB + w_swz<128>(row0 + 4, col);
+#pragma unroll
+            for (int pc = 0; pc < 3; ++pc) {
+                const uint2 u0 = w_read_tr(p0 + pc * 16 * 128), u1 = w_read_tr(p1 + pc * 16 * 128);
+                bq[b][pc] = make_uint4(u0.x, u0.y, u1.x, u1.y);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int col = (jt0 + j) * 32 + 16 * tg + 4 * tp;
+            const uint16_t* p0 = sA + w_swz<384>(row0, col);
+            const uint16_t* p1 = sA + w_swz<384>(row0 + 4, col);
+            uint4 aq[3];
+#pragma unroll
+            for (int pc = 0; pc < 3; ++pc) {
+                const uint2 u0 = w_read_tr(p0 + pc * 16 * 384), u1 = w_read_tr(p1 + pc * 16 * 384);
+                aq[pc] = make_uint4(u0.x, u0.y, u1.x, u1.y);
+            }
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                f32x16 v = acc[j][b];
+                v = w_mfma(aq[2], bq[b][0], v);
+                v = w_mfma(aq[0], bq[b][2], v);
+                v = w_mfma(aq[1], bq[b][1], v);
+                v = w_mfma(aq[1], bq[b][0], v);
+                v = w_mfma(aq[0], bq[b][1], v);
+                v = w_mfma(aq[0], bq[b][0], v);
+                acc[j][b] = v;
+            }
+        }
+        if (ch + 1 < nchunk) {
+            stage(raw, nA, nA + DW2_A);
+            if (ch + 2 < nchunk) dw2_issue(q, r_lo + (ch + 2) * 16 + srow, r_end, ca, cb, raw);
+        }
+        __syncthreads();
+    }
+    // ---- the block's 384 x 128 tile of this slab
+    float* sw = q.slabs + (size_t)slab * 3 * H * H;
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int jj = mt * 384 + (jt0 + j) * 32 + w_acc_row(reg, half);
+                sw[(size_t)jj * H + nt * 128 + (bt0 + b) * 32 + c] = acc[j][b][reg];
+            }
+    if (nt == 0) {                                           // bias gradient: column sums of dg over the slab's rows
+        float* red = lds;                                    // [16][384] floats (the images are dead)
+#pragma unroll
+        for (int i = 0; i < 12; ++i) red[srow * 384 + c32 * 12 + i] = cs[i];
+        __syncthreads();
+        if (tid < 384) {
+            float sum = 0.f;
+#pragma unroll 8
+            for (int rr = 0; rr < 16; ++rr) sum += red[rr * 384 + tid];
+            q.bslabs[(size_t)slab * 3 * H + mt * 384 + tid] = sum;
+        }
+    }
+}
+
+#ifdef WT_DW_OLD
+static constexpr int DW_TILE_M = 192, DW_CHUNK = 32;
+#else
+static constexpr int DW_TILE_M = 384, DW_CHUNK = 16;
+#endif
+// one launch of the weight-gradient kernel over q.R rows in nslab slabs of q.rows_per_slab rows
+static int launch_dw(const WideDwArgs& q, int nslab, hipStream_t st) {
+    const int mt = 3 * q.H / DW_TILE_M, nt = q.H / 128;
+#ifdef WT_DW_OLD
+    TM_SHM_ONCE(k_wide_dw, DW_SHM);
+    hipLaunchKernelGGL(k_wide_dw, dim3(mt * nt, nslab), dim3(512), DW_SHM, st, q, mt, nt);
+#else
+    TM_SHM_ONCE(k_wide_dw2, DW2_SHM);
+    hipLaunchKernelGGL(k_wide_dw2, dim3(mt * nt, nslab), dim3(512), DW2_SHM, st, q, mt, nt);
+#endif
+    return check_launch("wide_dw");
+}
+
 // the ring form needs whole 128-column blocks, K in whole groups of four half steps (>= 8) and 16-byte aligned rows
 static int launch_gemm_ring(const WideArgs& a, hipStream_t st) {
     TM_SHM_ONCE(k_wide_gemm_ring, W_GEMM_RING_SHM);
@@ -1488,7 +1667,7 @@ int tmpnn_wide_gru_bwd_data(const void* prep, const int32_t* rows, int R, const 
 }
 
 static int dw_slabs(int R, int H) {
-    const int tiles = (3 * H / 192) * (H / 128);
+    const int tiles = (3 * H / DW_TILE_M) * (H / 128);
     int s = 256 / tiles;
     const int by_rows = (R + 2047) / 2048;                 // at least 2048 rows per slab
     if (s > by_rows) s = by_rows;
@@ -1518,7 +1697,6 @@ int tmpnn_wide_gru_bwd_weights(const void* dg_ws, const int32_t* rows, int R, co
                          tmpnn_wide_gru_bwd_weights_ws(R, H));
     hipStream_t st = as_stream(stream);
     const int n = dw_slabs(R, H);
-    const int mt = 3 * H / 192, nt = H / 128;
     const int rps = ((R + n - 1) / n + 31) / 32 * 32;
     const float* dgi = reinterpret_cast<const float*>(dg_ws);
     const float* dgh = dgi + (size_t)R * 3 * H;
@@ -1526,12 +1704,10 @@ int tmpnn_wide_gru_bwd_weights(const void* dg_ws, const int32_t* rows, int R, co
     float* bslabs = slabs + (size_t)n * 3 * H * H;
     float* fold = bslabs + (size_t)n * 3 * H;
     const int nslab = (R + rps - 1) / rps;
-    TM_SHM_ONCE(k_wide_dw, DW_SHM);
     for (int which = 0; which < 2; ++which) {
         WideDwArgs q{which == 0 ? dgi : dgh, 3 * H, nullptr, 3 * H, 0, h, ld_h, which == 0 ? src : rows,
                      which == 0 ? dst : nullptr, R, H, rps, slabs, bslabs};
-        hipLaunchKernelGGL(k_wide_dw, dim3(mt * nt, nslab), dim3(512), DW_SHM, st, q, mt, nt);
-        int rc = check_launch("wide_dw");
+        int rc = launch_dw(q, nslab, st);
         if (rc) return rc;
         if ((rc = launch_reduce_slabs(slabs, (size_t)3 * H * H, nslab, which == 0 ? dW_ih : dW_hh, (size_t)3 * H * H, 1, st, fold)))
             return rc;
@@ -1665,15 +1841,12 @@ static int wide_gru_bwd_diff_impl(const void* prep, const tmpnn_graph* g, const 
     if ((rc = launch_store(x, sx))) return done(rc);
     if (aux_stream) (void)hipEventRecord(ev_join, sx);
     // 5. weight gradients: dW_hh over the edge rows (bias sums: db_hh, and db_ih's r / z thirds), dW_ih over the det rows
-    const int mt = 3 * H / 192, nt = H / 128;
-    TM_SHM_ONCE(k_wide_dw, DW_SHM);
     {
         const int n = dw_slabs(R, H);
         const int rps = ((R + n - 1) / n + 31) / 32 * 32;
         const int nslab = (R + rps - 1) / rps;
         WideDwArgs q{dg4, 4 * H, g->edge_row, 2 * H, H, h, ld_h, g->edge_row, nullptr, R, H, rps, slabs, bslabs};
-        hipLaunchKernelGGL(k_wide_dw, dim3(mt * nt, nslab), dim3(512), DW_SHM, st, q, mt, nt);
-        if ((rc = check_launch("wide_dw"))) return done(rc);
+        if ((rc = launch_dw(q, nslab, st))) return done(rc);
         if ((rc = launch_reduce_slabs(slabs, (size_t)3 * H * H, nslab, dW_hh, (size_t)3 * H * H, 1, st, fold))) return done(rc);
         if ((rc = launch_reduce_slabs(bslabs, (size_t)3 * H, nslab, db_hh, (size_t)3 * H, 1, st, fold))) return done(rc);
         if ((rc = launch_reduce_slabs(bslabs, (size_t)3 * H, nslab, db_ih, (size_t)2 * H, 1, st, fold))) return done(rc);
@@ -1684,8 +1857,7 @@ static int wide_gru_bwd_diff_impl(const void* prep, const tmpnn_graph* g, const 
         const int rps = ((Dn + n - 1) / n + 31) / 32 * 32;
         const int nslab = (Dn + rps - 1) / rps;
         WideDwArgs q{S, 3 * H, nullptr, 3 * H, 0, h, ld_h, g->det_row, nullptr, Dn, H, rps, slabs, bslabs};
-        hipLaunchKernelGGL(k_wide_dw, dim3(mt * nt, nslab), dim3(512), DW_SHM, st, q, mt, nt);
-        if ((rc = check_launch("wide_dw"))) return done(rc);
+        if ((rc = launch_dw(q, nslab, st))) return done(rc);
         if ((rc = launch_reduce_slabs(slabs, (size_t)3 * H * H, nslab, dW_ih, (size_t)3 * H * H, 1, st, fold))) return done(rc);
     }
     return done(TMPNN_OK);
