@@ -833,29 +833,34 @@ __global__ __launch_bounds__(512) void k_wide_gru_fwd_ring(WideArgs a, WideTiles
 static constexpr int GR_A = 128 * 64, GR_B = 3 * 128 * 32, GR_SLOT = GR_A + GR_B;       // bytes
 static constexpr size_t W_GEMM_RING_SHM = 4 * GR_SLOT;                                   // sC [128][132] fp32 aliases it
 
-struct GRingOps { float4 lo, hi; uint4 af[3]; uint4 bf[6]; };
-__device__ __forceinline__ void gring_read(const char* slot_base, int a_off0, int a_off1, int b_off, GRingOps& o) {
+template <int NCT> struct GRingOpsT { float4 lo, hi; uint4 af[3]; uint4 bf[3 * NCT]; };   // NCT 32-column tiles per wave
+using GRingOps = GRingOpsT<2>;
+template <int NCT>
+__device__ __forceinline__ void gring_read(const char* slot_base, int a_off0, int a_off1, int b_off, GRingOpsT<NCT>& o) {
     o.lo = *reinterpret_cast<const float4*>(slot_base + a_off0);
     o.hi = *reinterpret_cast<const float4*>(slot_base + a_off1);
     const char* sb = slot_base + GR_A + b_off;
 #pragma unroll
-    for (int ct = 0; ct < 2; ++ct)
+    for (int ct = 0; ct < NCT; ++ct)
 #pragma unroll
-        for (int p = 0; p < 3; ++p) o.bf[ct * 3 + p] = *reinterpret_cast<const uint4*>(sb + ct * 32 * 32 + p * 128 * 32);
+        for (int p = 0; p < 3; ++p) o.bf[ct * 3 + p] = *reinterpret_cast<const uint4*>(sb + ct * 32 * 32 + p * (64 * NCT) * 32);
 }
-__device__ __forceinline__ void gring_split(GRingOps& o) {
+template <int NCT>
+__device__ __forceinline__ void gring_split(GRingOpsT<NCT>& o) {
     w_split2(o.lo.x, o.lo.y, o.af[0].x, o.af[1].x, o.af[2].x);
     w_split2(o.lo.z, o.lo.w, o.af[0].y, o.af[1].y, o.af[2].y);
     w_split2(o.hi.x, o.hi.y, o.af[0].z, o.af[1].z, o.af[2].z);
     w_split2(o.hi.z, o.hi.w, o.af[0].w, o.af[1].w, o.af[2].w);
 }
-__device__ __forceinline__ void gring_pin(GRingOps& o) {
+template <int NCT>
+__device__ __forceinline__ void gring_pin(GRingOpsT<NCT>& o) {
     asm volatile("" : "+v"(o.af[0].x), "+v"(o.af[0].y), "+v"(o.af[0].z), "+v"(o.af[0].w), "+v"(o.af[1].x), "+v"(o.af[1].y),
                       "+v"(o.af[1].z), "+v"(o.af[1].w), "+v"(o.af[2].x), "+v"(o.af[2].y), "+v"(o.af[2].z), "+v"(o.af[2].w));
 }
-__device__ __forceinline__ void gring_compute(const GRingOps& o, f32x16 (&acc)[2]) {
+template <int NCT>
+__device__ __forceinline__ void gring_compute(const GRingOpsT<NCT>& o, f32x16 (&acc)[NCT]) {
 #pragma unroll
-    for (int ct = 0; ct < 2; ++ct) {
+    for (int ct = 0; ct < NCT; ++ct) {
         f32x16 c = acc[ct];
         c = w_mfma(o.af[2], o.bf[ct * 3], c);
         c = w_mfma(o.af[0], o.bf[ct * 3 + 2], c);
@@ -1019,6 +1024,170 @@ __global__ __launch_bounds__(512) void k_wide_gemm_ring(WideArgs a) {
         if (last_chunk && !more_tiles) break;
         if (last_chunk) { t += G; pa = a_src(row_next); bx = 0; } else ++bx;
         const int nn = bx << 7;
+        dma(0, nn, 0); dma(1, nn, 1); dma(2, nn, 2); dma(3, nn, 3);
+    }
+}
+
+// The same ring on 128 x 256 output tiles, for N in whole 256-column blocks (H = 256, 512, ...): a wave owns 32 rows x 128
+// columns, so one split of its A rows feeds 24 MFMAs instead of 12 and the A rows of a tile are fetched once per 256
+// columns.  Slots of 8 KB + 24 KB (four: 128 KB), four DMA instructions per wave and half step; sC [128][256] aliases
+// the ring exactly, with the column-bit-5 flip on rows 4..7 (mod 8) that keeps the two halves of a wave on different
+// banks without the pad.  Same products in the same order: bit-identical to the 128-column form.
+static constexpr int GR_B4 = 3 * 256 * 32, GR_SLOT4 = GR_A + GR_B4;
+static constexpr size_t W_GEMM_RING4_SHM = 4 * GR_SLOT4;
+template <int N>
+__device__ __forceinline__ void gring4_wait_barrier() {
+    if constexpr (N >= 12) asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)" ::: "memory");
+    else if constexpr (N >= 8) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+    else if constexpr (N >= 4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+#define GRING4_WEAVE()                                                                                 \
+    do {                                                                                               \
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                                             \
+        _Pragma("unroll") for (int w_ = 0; w_ < 22; ++w_) {                                            \
+            __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);                                         \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                         \
+        }                                                                                              \
+    } while (0)
+
+__global__ __launch_bounds__(512) void k_wide_gemm_ring256(WideArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint16_t w_dyn[];
+    char* const ring = reinterpret_cast<char*>(w_dyn);
+    float* const sC = reinterpret_cast<float*>(w_dyn);                    // [128][256], aliases the ring
+    constexpr int LDC = 256;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), wr = wave & 3, wc = wave >> 2;
+    const int nchunk = a.N >> 8, nsub = a.K >> 4;
+    const int ntile = (a.R + 127) >> 7;
+    const int G = gridDim.x;
+    int t = blockIdx.x;
+    if (t >= ntile) return;
+    const uint32_t base = lds_addr(ring);
+    const uint32_t lds_a = base + 1024u * wave, lds_b = base + GR_A + 1024u * wave;      // piece p at lds_b + 8192 p
+    // weight-tile chunks of this thread: idx = (p * 256 + col) * 2 + q, p = 0..2 -> image byte offset of piece 0
+    const uint32_t ob = (uint32_t)((tid >> 1) * 32 + (tid & 1) * 16);
+    const uint32_t piece = (uint32_t)a.N * 32u;
+    const int r = lane & 31, hh = lane >> 5;
+    const int arow = 32 * wr + r, fa = (arow >> 2) & 3;
+    const int a_off0 = arow * 64 + (((2 * hh) ^ fa) << 4), a_off1 = arow * 64 + (((2 * hh + 1) ^ fa) << 4);
+    const int b_off = (128 * wc + r) * 32 + ((hh ^ ((r >> 4) & 1)) << 4);
+    const int drow = tid >> 2, dchunk = (tid & 3) ^ ((drow >> 2) & 3);
+    auto a_row = [&](int tile) {
+        const int rr = min(tile * 128 + drow, a.R - 1);                   // (rows past R repeat the last one: never stored)
+        return a.a_rows ? a.a_rows[rr] : rr;
+    };
+    auto a_src = [&](int row) { return reinterpret_cast<const char*>(a.A + (size_t)row * a.lda + 4 * dchunk); };
+    const char* pa = a_src(a_row(t));
+    int row_next = 0;
+    auto dma = [&](int j, int n0, int slot) {
+        const uint32_t so = (uint32_t)slot * GR_SLOT4;
+        int kc = 16 * j;
+        if (kc >= a.kskip_at) kc += a.kskip;
+        glds16(pa + (size_t)kc * 4, lds_a + so);
+        const char* wb = reinterpret_cast<const char*>(a.img) + ((size_t)j * 3 * a.N + n0) * 32;
+        glds16_so(wb, ob, lds_b + so);
+        glds16_so(wb, ob + piece, lds_b + so + 8192u);
+        glds16_so(wb, ob + 2u * piece, lds_b + so + 16384u);
+    };
+    dma(0, 0, 0); dma(1, 0, 1); dma(2, 0, 2); dma(3, 0, 3);
+    for (int bx = 0;;) {
+        const int n0 = bx << 8;
+        gring4_wait_barrier<12>();                               // half step 0 has landed
+        const bool last_chunk = bx + 1 == nchunk;
+        const bool more_tiles = t + G < ntile;
+        f32x16 acc[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[j][q] = 0.f;
+        GRingOpsT<4> R[2];
+        gring_read(ring, a_off0, a_off1, b_off, R[0]);
+        gring_split(R[0]);
+        gring4_wait_barrier<8>();                                // step 1 has landed; every wave has step 0 in registers
+        int p0 = 0;
+        for (; p0 + 8 <= nsub; p0 += 4) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                dma(p0 + u + 4, n0, u);
+                gring_read(ring + ((u + 1) & 3) * GR_SLOT4, a_off0, a_off1, b_off, R[(u + 1) & 1]);
+                __builtin_amdgcn_sched_barrier(0);
+                gring_compute(R[u & 1], acc);
+                gring_split(R[(u + 1) & 1]);
+                GRING4_WEAVE();
+                __builtin_amdgcn_sched_barrier(0);
+                gring_pin(R[(u + 1) & 1]);
+                gring4_wait_barrier<8>();
+            }
+        }
+        gring_read(ring + GR_SLOT4, a_off0, a_off1, b_off, R[1]);
+        __builtin_amdgcn_sched_barrier(0);
+        gring_compute(R[0], acc); gring_split(R[1]); GRING4_WEAVE();
+        __builtin_amdgcn_sched_barrier(0);
+        gring_pin(R[1]);
+        gring4_wait_barrier<4>();
+        gring_read(ring + 2 * GR_SLOT4, a_off0, a_off1, b_off, R[0]);
+        __builtin_amdgcn_sched_barrier(0);
+        gring_compute(R[1], acc); gring_split(R[0]); GRING4_WEAVE();
+        __builtin_amdgcn_sched_barrier(0);
+        gring_pin(R[0]);
+        gring4_wait_barrier<0>();
+        gring_read(ring + 3 * GR_SLOT4, a_off0, a_off1, b_off, R[1]);
+        __builtin_amdgcn_sched_barrier(0);
+        gring_compute(R[0], acc); gring_split(R[1]); GRING4_WEAVE();
+        __builtin_amdgcn_sched_barrier(0);
+        gring_pin(R[1]);
+        gring4_wait_barrier<0>();                                // every wave has its last operands: sC may overwrite the ring
+        if (last_chunk && more_tiles) row_next = a_row(t + G);   // (requested with nothing in flight, used after the epilogue)
+        gring_compute(R[1], acc);
+        const int r0 = t * 128;
+        // epilogue rows of this wave: wave + 8 i (wave-uniform: the row lists come through the scalar unit)
+        const int q = opaque(lane);                              // float4 column 0..63
+        int crow[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int rr = min(r0 + wave + 8 * i, a.R - 1);
+            crow[i] = a.c_rows ? a.c_rows[rr] : rr;
+        }
+        {
+            const int cl = q & 31, half = q >> 5;
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    const int row = 32 * wr + w_acc_row(reg, half);
+                    sC[row * LDC + ((128 * wc + 32 * ct + cl) ^ (((row >> 2) & 1) << 5))] = acc[ct][reg];
+                }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            float4 cprev[8];
+            if (a.accumulate) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) cprev[i] = *reinterpret_cast<const float4*>(a.C + (size_t)crow[8 * e + i] * a.ldc + n0 + 4 * q);
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int lr = wave + 8 * (8 * e + i);
+                if (r0 + lr >= a.R) continue;
+                float4 v = *reinterpret_cast<const float4*>(sC + lr * LDC + ((4 * q) ^ (((lr >> 2) & 1) << 5)));
+                if (a.accumulate) { v.x += cprev[i].x; v.y += cprev[i].y; v.z += cprev[i].z; v.w += cprev[i].w; }
+                if (a.add_msg) {       // (det rows of add_msg: L2-resident; the sum in the order of tmpnn_gather_diff_fwd(accumulate))
+                    const int rr = r0 + lr;
+                    const int as = a.add_src[rr], ad = a.add_dst[rr];
+                    const float4 ms = *reinterpret_cast<const float4*>(a.add_msg + (size_t)as * a.ld_add + n0 + 4 * q);
+                    const float4 md = *reinterpret_cast<const float4*>(a.add_msg + (size_t)ad * a.ld_add + n0 + 4 * q);
+                    v.x = (ms.x - md.x) + v.x; v.y = (ms.y - md.y) + v.y; v.z = (ms.z - md.z) + v.z; v.w = (ms.w - md.w) + v.w;
+                }
+                *reinterpret_cast<float4*>(a.C + (size_t)crow[8 * e + i] * a.ldc + n0 + 4 * q) = v;
+            }
+        }
+        __syncthreads();
+        if (last_chunk && !more_tiles) break;
+        if (last_chunk) { t += G; pa = a_src(row_next); bx = 0; } else ++bx;
+        const int nn = bx << 8;
         dma(0, nn, 0); dma(1, nn, 1); dma(2, nn, 2); dma(3, nn, 3);
     }
 }
@@ -1503,10 +1672,17 @@ static int launch_dw(const WideDwArgs& q, int nslab, hipStream_t st) {
 
 // the ring form needs whole 128-column blocks, K in whole groups of four half steps (>= 8) and 16-byte aligned rows
 static int launch_gemm_ring(const WideArgs& a, hipStream_t st) {
-    TM_SHM_ONCE(k_wide_gemm_ring, W_GEMM_RING_SHM);
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     const int ntile = ceil_div(a.R, 128);
+#ifndef WT_GEMM_RING128
+    if (a.N % 256 == 0) {
+        TM_SHM_ONCE(k_wide_gemm_ring256, W_GEMM_RING4_SHM);
+        hipLaunchKernelGGL(k_wide_gemm_ring256, dim3(ntile < cus ? ntile : cus), dim3(512), W_GEMM_RING4_SHM, st, a);
+        return check_launch("wide_gemm_ring256");
+    }
+#endif
+    TM_SHM_ONCE(k_wide_gemm_ring, W_GEMM_RING_SHM);
     hipLaunchKernelGGL(k_wide_gemm_ring, dim3(ntile < cus ? ntile : cus), dim3(512), W_GEMM_RING_SHM, st, a);
     return check_launch("wide_gemm_ring");
 }
