@@ -190,7 +190,7 @@ MFMA-pipe fraction: 6 bf16 products per fp32 product (bf16x6, fp32-accurate) x 2
 PMC traffic = 2 x FETCH_SIZE + WRITE_SIZE (KB x 1024; gfx950 correction for 16-byte-per-lane streams).
 Since the det-side branches run on a second stream (DESIGN 11.2), `k_segsum_pipe` / the Dn-row `k_wide_gemm_store` / `k_gru_fwd<2, 0>`
 execute CONCURRENTLY with `k_wide_gru_fwd_ring`, `k_wide_gemm_ring` and `k_wide_dw`: a kernel's duration below includes the time it
-shares the GPU (alone: ring forward 12.0, ring GEMM 10.6 + 1.7 for the adjoint it now carries, segment sum 1.5 ms), so the
+shares the GPU (alone: ring forward 12.0, the 256-column ring GEMM ~9.1 + 1.7 for the adjoint it now carries, segment sum 1.5 ms), so the
 fractions of overlapped kernels understate what each reaches alone.
 
 | kernel | launches / step | avg ms | % of GPU time | algorithmic GB | GB/s | of 8 TB/s | bf16-MFMA TFLOP/s | of 2.5 PF | PMC traffic GB | traffic / algorithmic |

@@ -394,7 +394,7 @@ struct WideTiles {
 static constexpr int WT_DMAX = 40;
 // build-time ablations of k_wide_gru_fwd_ring (tools/build_variant.sh wide -DWT_NOEPI ...; timing only, wrong results):
 // WT_NOEPI no gate math / stores, WT_NOMMA no MFMAs, WT_NODMA no operand DMA in the K loop, WT_NOREAD / WT_NOSPLIT no
-// fragment reads / A split, WT_NOBAR no K-loop barriers.  The numbers they produced: profiles/r03_c5_wide_forward.md
+// fragment reads / A split, WT_NOBAR no K-loop barriers.  The numbers they produced: DESIGN.md section 11.2
 
 // (opaque(): the index arithmetic below is invariant over the kernel's persistent loop; hoisted out of it, the offsets
 //  of all its call sites pile up in registers the K loop needs and the A operand in flight gets spilled)
