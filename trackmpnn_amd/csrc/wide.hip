@@ -1503,28 +1503,57 @@ __global__ __launch_bounds__(512) void k_wide_dw(WideDwArgs q, int mt_count, int
 static constexpr int DW2_A = 3 * 16 * 384, DW2_B = 3 * 16 * 128;        // elements of one A / B image set
 static constexpr int DW2_SHM = 2 * (DW2_A + DW2_B) * 2;                 // two buffers, bf16
 
-struct Dw2Raw { float4 a[3]; float4 b0, b1; bool valid; };
+struct Dw2Raw { wf32x4 a[3]; wf32x4 b0, b1; bool valid; int ig, ia, ib, rr; bool vnext; };
 
-__device__ __forceinline__ void dw2_issue(const WideDwArgs& q, int r, int r_end, int ca, int cb, Dw2Raw& w) {
-    w.valid = r < r_end;
-    const int rr = w.valid ? r : r_end - 1;
-    const float* pa = q.dg + (size_t)(q.grows ? q.grows[rr] : rr) * q.ldg;
+// The rows of a chunk are addressed through row lists (edge_row, det_row): index load -> row load is a dependent chain,
+// and the wait for the index in front of the row requests is a wait for EVERYTHING older in the in-order queue.  So the
+// indices are requested a chunk before the rows that use them (they have landed when the rows are requested), and both
+// are unconditional (rows past the slab's end repeat its last row and are staged as zeros).
+template <bool XB>
+__device__ __forceinline__ void dw2_index(const WideDwArgs& q, int r, int r_end, Dw2Raw& w) {
+    w.vnext = r < r_end;
+    const int rr = min(r, r_end - 1);
+    w.rr = rr;
+    w.ig = (q.grows ? q.grows : q.xa)[rr];               // (always a load, the select where it is used: a branch here would
+    w.ia = q.xa[rr];                                     //  make the index a phi whose copy -- and wait -- sits behind the load)
+    if constexpr (XB) w.ib = q.xb[rr]; else w.ib = 0;
+}
+template <bool XB>
+__device__ __forceinline__ void dw2_rows(const WideDwArgs& q, int ca, int cb, Dw2Raw& w) {
+    w.valid = w.vnext;
+    // (the indices are first USED here: left alone, hipcc forms the row addresses earlier and waits for the index there --
+    //  and with it for the row requests in front of it in the queue)
+    asm volatile("" : "+v"(w.ig), "+v"(w.ia), "+v"(w.ib) : : "memory");
+    const float* pa = q.dg + (size_t)(q.grows ? w.ig : w.rr) * q.ldg;
 #pragma unroll
     for (int g = 0; g < 3; ++g) {
         int cg = ca + 4 * g;
         if (cg >= q.gskip_at) cg += q.gskip;
-        w.a[g] = *reinterpret_cast<const float4*>(pa + cg);
+        w.a[g] = *reinterpret_cast<const wf32x4*>(pa + cg);
     }
-    w.b0 = *reinterpret_cast<const float4*>(q.X + (size_t)q.xa[rr] * q.ldx + cb);
-    if (q.xb) w.b1 = *reinterpret_cast<const float4*>(q.X + (size_t)q.xb[rr] * q.ldx + cb);
+    w.b0 = *reinterpret_cast<const wf32x4*>(q.X + (size_t)w.ia * q.ldx + cb);
+    if constexpr (XB) w.b1 = *reinterpret_cast<const wf32x4*>(q.X + (size_t)w.ib * q.ldx + cb);
 }
 
+template <bool XB>
 __global__ __launch_bounds__(512) void k_wide_dw2(WideDwArgs q, int mt_count, int nt_count) {
     extern __shared__ float lds[];
     uint16_t* const base = reinterpret_cast<uint16_t*>(lds);
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int c = lane & 31, half = lane >> 5;
-    const int tile = blockIdx.x, mt = tile / nt_count, nt = tile % nt_count, slab = blockIdx.y;
+    // The tiles of a slab read the same dg / X rows (dg once per column tile, X once per row tile).  Workgroups go to the
+    // eight XCDs round-robin in launch order: with the slab count a multiple of eight, a slab's tiles take consecutive
+    // slots of ONE XCD, so the second reader of a row finds it in that XCD's L2 (same partition and sums: only the
+    // placement of the blocks changes; -DWT_DW_PLAIN_ORDER keeps tile = blockIdx.x, slab = blockIdx.y).
+    int tile = blockIdx.x, slab = blockIdx.y;
+#ifndef WT_DW_PLAIN_ORDER
+    if ((gridDim.y & 7) == 0) {
+        const int id = blockIdx.x + gridDim.x * blockIdx.y, slot = id >> 3;
+        tile = slot % (int)gridDim.x;
+        slab = (id & 7) + 8 * (slot / (int)gridDim.x);
+    }
+#endif
+    const int mt = tile / nt_count, nt = tile % nt_count;
     const int H = q.H;
     const int srow = tid >> 5, c32 = tid & 31;                       // staging: 16 rows x 32 threads
     const int ca = mt * 384 + c32 * 12, cb = nt * 128 + c32 * 4;     // this thread's global columns of dg / X
@@ -1550,7 +1579,7 @@ __global__ __launch_bounds__(512) void k_wide_dw2(WideDwArgs q, int mt_count, in
             av[4 * g] = w.a[g].x; av[4 * g + 1] = w.a[g].y; av[4 * g + 2] = w.a[g].z; av[4 * g + 3] = w.a[g].w;
         }
         float bv[4] = {w.b0.x, w.b0.y, w.b0.z, w.b0.w};
-        if (q.xb) { bv[0] -= w.b1.x; bv[1] -= w.b1.y; bv[2] -= w.b1.z; bv[3] -= w.b1.w; }
+        if constexpr (XB) { bv[0] -= w.b1.x; bv[1] -= w.b1.y; bv[2] -= w.b1.z; bv[3] -= w.b1.w; }
 #pragma unroll
         for (int i = 0; i < 12; ++i) { av[i] = w.valid ? av[i] : 0.f; cs[i] += av[i]; }
 #pragma unroll
@@ -1573,19 +1602,29 @@ __global__ __launch_bounds__(512) void k_wide_dw2(WideDwArgs q, int mt_count, in
         }
     };
 
-    Dw2Raw raw;
+    // The rows of a chunk are requested TWO chunks before they are staged (two register sets A / B, the loop unrolled by
+    // two; their indices two chunks before that): a chunk's matrix phase (~1.5 us) is shorter than a loaded memory round
+    // trip, and with one chunk of cover a launch took matrix time + memory time (11.3 ms at C5, 6.3 for the MFMAs alone).
+    // Everything is unconditional: rows past the slab's end repeat its last row and are staged as zeros, a chunk past
+    // its end is zeros into a buffer nobody reads.
+    Dw2Raw rawA, rawB;
+    rawA.b1 = rawB.b1 = wf32x4{0.f, 0.f, 0.f, 0.f};
     const int nchunk = r_end > r_lo ? (r_end - r_lo + 15) / 16 : 0;
     if (nchunk > 0) {
-        dw2_issue(q, r_lo + srow, r_end, ca, cb, raw);
-        stage(raw, base, base + DW2_A);
-        if (nchunk > 1) dw2_issue(q, r_lo + 16 + srow, r_end, ca, cb, raw);
+        dw2_index<XB>(q, r_lo + srow, r_end, rawA);
+        dw2_index<XB>(q, r_lo + 16 + srow, r_end, rawB);
+        dw2_rows<XB>(q, ca, cb, rawA);                   // chunk 0
+        dw2_index<XB>(q, r_lo + 32 + srow, r_end, rawA);
+        stage(rawA, base, base + DW2_A);
+        dw2_rows<XB>(q, ca, cb, rawB);                   // chunk 1 (staged by the iteration of chunk 0)
+        dw2_index<XB>(q, r_lo + 48 + srow, r_end, rawB);
+        dw2_rows<XB>(q, ca, cb, rawA);                   // chunk 2
+        dw2_index<XB>(q, r_lo + 64 + srow, r_end, rawA);
     }
     __syncthreads();
     const int row0 = 8 * half + tq;
-    for (int ch = 0; ch < nchunk; ++ch) {
-        uint16_t* sA = base + (ch & 1) * (DW2_A + DW2_B);
-        uint16_t* sB = sA + DW2_A;
-        uint16_t* nA = base + ((ch & 1) ^ 1) * (DW2_A + DW2_B);
+    auto compute = [&](const uint16_t* sA) {
+        const uint16_t* sB = sA + DW2_A;
         uint4 bq[2][3];
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
@@ -1612,6 +1651,11 @@ __global__ __launch_bounds__(512) void k_wide_dw2(WideDwArgs q, int mt_count, in
 #pragma unroll
             for (int b = 0; b < 2; ++b) {
                 f32x16 v = acc[j][b];
+#ifdef WT_DW_NOMMA                                          // (timing ablations, wrong results: -DWT_DW_NOMMA / NOSTAGE / NOLOAD)
+                v[0] += __uint_as_float(aq[0].x ^ aq[1].y ^ aq[2].z ^ bq[b][0].x ^ bq[b][1].y ^ bq[b][2].z);
+                acc[j][b] = v;
+                continue;
+#endif
                 v = w_mfma(aq[2], bq[b][0], v);
                 v = w_mfma(aq[0], bq[b][2], v);
                 v = w_mfma(aq[1], bq[b][1], v);
@@ -1621,11 +1665,29 @@ __global__ __launch_bounds__(512) void k_wide_dw2(WideDwArgs q, int mt_count, in
                 acc[j][b] = v;
             }
         }
-        if (ch + 1 < nchunk) {
-            stage(raw, nA, nA + DW2_A);
-            if (ch + 2 < nchunk) dw2_issue(q, r_lo + (ch + 2) * 16 + srow, r_end, ca, cb, raw);
-        }
+    };
+    // iteration of chunk ch with the register set that holds chunk ch + 1 (B for even ch, A for odd ch)
+    // (Also measured: the two waves of a SIMD taking the matrix phase and the staging in opposite order, so that one's ~150
+    //  vector instructions run under the other's MFMAs -- 10.8 ms against 10.1: the extra branch costs more than it hides.)
+    auto body = [&](int ch, Dw2Raw& raw) {
+        compute(base + (ch & 1) * (DW2_A + DW2_B));
+        // (the rows are first USED here: the split is pure arithmetic, and hipcc otherwise puts it -- with the wait for the
+        //  rows -- in front of the MFMAs; nor may a copy of a loaded register wait at the loop's back edge)
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("" : "+v"(raw.a[0]), "+v"(raw.a[1]), "+v"(raw.a[2]), "+v"(raw.b0), "+v"(raw.b1) : : "memory");
+        uint16_t* nA = base + ((ch & 1) ^ 1) * (DW2_A + DW2_B);
+#ifndef WT_DW_NOSTAGE
+        stage(raw, nA, nA + DW2_A);                      // chunk ch + 1
+#endif
+#ifndef WT_DW_NOLOAD
+        dw2_rows<XB>(q, ca, cb, raw);                    // chunk ch + 3 (its indices: requested two chunks ago)
+        dw2_index<XB>(q, r_lo + (ch + 5) * 16 + srow, r_end, raw);
+#endif
         __syncthreads();
+    };
+    for (int ch = 0; ch < nchunk; ch += 2) {
+        body(ch, rawB);
+        if (ch + 1 < nchunk) body(ch + 1, rawA);
     }
     // ---- the block's 384 x 128 tile of this slab
     float* sw = q.slabs + (size_t)slab * 3 * H * H;
@@ -1664,8 +1726,13 @@ static int launch_dw(const WideDwArgs& q, int nslab, hipStream_t st) {
     TM_SHM_ONCE(k_wide_dw, DW_SHM);
     hipLaunchKernelGGL(k_wide_dw, dim3(mt * nt, nslab), dim3(512), DW_SHM, st, q, mt, nt);
 #else
-    TM_SHM_ONCE(k_wide_dw2, DW2_SHM);
-    hipLaunchKernelGGL(k_wide_dw2, dim3(mt * nt, nslab), dim3(512), DW2_SHM, st, q, mt, nt);
+    if (q.xb) {
+        TM_SHM_ONCE(k_wide_dw2<true>, DW2_SHM);
+        hipLaunchKernelGGL(k_wide_dw2<true>, dim3(mt * nt, nslab), dim3(512), DW2_SHM, st, q, mt, nt);
+    } else {
+        TM_SHM_ONCE(k_wide_dw2<false>, DW2_SHM);
+        hipLaunchKernelGGL(k_wide_dw2<false>, dim3(mt * nt, nslab), dim3(512), DW2_SHM, st, q, mt, nt);
+    }
 #endif
     return check_launch("wide_dw");
 }
