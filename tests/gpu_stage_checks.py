@@ -692,6 +692,13 @@ def run_all(report=print):
         for k, v in check_wide(H, g, gd).items():
             rec(f'wide cell H={H} {k}', v, 0.0 if (k.endswith('untouched') or k.endswith('bits')) else 2e-4)
     from trackmpnn_amd.graph import dense_static_graph
+    # E = 16 384 rows: eight weight-gradient slabs -- the slab -> XCD placement of k_wide_dw2 applies from a slab count
+    # that is a multiple of eight -- and 128 full row tiles of the ring products (N = 256: the 256-column form)
+    g8 = dense_static_graph(5, 64)
+    g8d = g8.to(DEV)
+    for H in (128, 256):
+        for k, v in check_wide(H, g8, g8d).items():
+            rec(f'wide cell H={H}, 5x64 window (8 slabs) {k}', v, 0.0 if (k.endswith('untouched') or k.endswith('bits')) else 2e-4)
     for H in (128, 256):
         # a dense 3-block window (tiles staged in LDS), a larger ragged batch (both kinds) and the small batch (one tile)
         for tag, gt in (('dense 4x40', dense_static_graph(4, 40)), ('ragged batch', make_graph(B=40, frames=7, mean=7, seed=3)),
