@@ -13,6 +13,7 @@ from typing import Callable, List, Optional, Sequence, Tuple
 
 import torch
 
+from .functional import weight_cache
 from .graph import DeviceGraph, device_graph_from_adjacency
 
 
@@ -93,12 +94,13 @@ class CapturedWindow:
 
     def _step_inner(self):
         h, outs = None, []
-        for c, (x, g) in enumerate(zip(self.static_x, self.graphs)):
-            if self.staged:
-                s, l, h, _ = self.model.forward_graph(x, h, self.plans[c])
-            else:
-                s, l, h, _ = self.model.forward_dgraph(x, h, g)
-            outs.append((s, l))
+        with weight_cache():                            # (the weights are constant over the forward calls of one step)
+            for c, (x, g) in enumerate(zip(self.static_x, self.graphs)):
+                if self.staged:
+                    s, l, h, _ = self.model.forward_graph(x, h, self.plans[c])
+                else:
+                    s, l, h, _ = self.model.forward_dgraph(x, h, g)
+                outs.append((s, l))
         loss = self.loss_fn(outs, h)
         if self.bucket is not None:
             self.bucket.zero()

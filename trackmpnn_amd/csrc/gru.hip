@@ -203,15 +203,26 @@ __global__ __launch_bounds__(256, 2) void k_gru_fwd(GruFwdArgs a) {
         float av[16];
         load_x16<XMODE>(a, li, row, f0, av);
         const float* __restrict__ b0 = a.wih_t + (size_t)f0 * H3 + col0 + c;
+        // (the weights of eight k-steps are requested together: written step by step, every MFMA waited for the one weight
+        //  load in front of it -- a full L2 round trip per step, 140 us for the 40 det rows of a KITTI window at IN = 128)
 #pragma unroll
-        for (int s = 0; s < 16; ++s) {
-            const float* __restrict__ b = b0 + (size_t)s * H3;
+        for (int s0 = 0; s0 < 16; s0 += 8) {
+            float bw[8][3 * CT];
 #pragma unroll
-            for (int t = 0; t < CT; ++t) {
-                acc_r[t] = mfma32(av[s], b[t * 32], acc_r[t]);
-                acc_z[t] = mfma32(av[s], b[H + t * 32], acc_z[t]);
-                acc_in[t] = mfma32(av[s], b[2 * H + t * 32], acc_in[t]);
+            for (int u = 0; u < 8; ++u) {
+                const float* __restrict__ b = b0 + (size_t)(s0 + u) * H3;
+#pragma unroll
+                for (int t = 0; t < CT; ++t) { bw[u][3 * t] = b[t * 32]; bw[u][3 * t + 1] = b[H + t * 32]; bw[u][3 * t + 2] = b[2 * H + t * 32]; }
             }
+            __builtin_amdgcn_sched_barrier(0);          // (or the scheduler pairs every load with its MFMA again)
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+#pragma unroll
+                for (int t = 0; t < CT; ++t) {
+                    acc_r[t] = mfma32(av[s0 + u], bw[u][3 * t], acc_r[t]);
+                    acc_z[t] = mfma32(av[s0 + u], bw[u][3 * t + 1], acc_z[t]);
+                    acc_in[t] = mfma32(av[s0 + u], bw[u][3 * t + 2], acc_in[t]);
+                }
         }
     }
     // ---- h part:  gh = h @ W_hh^T
@@ -221,14 +232,23 @@ __global__ __launch_bounds__(256, 2) void k_gru_fwd(GruFwdArgs a) {
         load16(a.h + (size_t)row * a.ld_h + f0, av);
         const float* __restrict__ b0 = a.whh_t + (size_t)f0 * H3 + col0 + c;
 #pragma unroll
-        for (int s = 0; s < 16; ++s) {
-            const float* __restrict__ b = b0 + (size_t)s * H3;
+        for (int s0 = 0; s0 < 16; s0 += 8) {
+            float bw[8][3 * CT];
 #pragma unroll
-            for (int t = 0; t < CT; ++t) {
-                acc_r[t] = mfma32(av[s], b[t * 32], acc_r[t]);
-                acc_z[t] = mfma32(av[s], b[H + t * 32], acc_z[t]);
-                acc_hn[t] = mfma32(av[s], b[2 * H + t * 32], acc_hn[t]);
+            for (int u = 0; u < 8; ++u) {
+                const float* __restrict__ b = b0 + (size_t)(s0 + u) * H3;
+#pragma unroll
+                for (int t = 0; t < CT; ++t) { bw[u][3 * t] = b[t * 32]; bw[u][3 * t + 1] = b[H + t * 32]; bw[u][3 * t + 2] = b[2 * H + t * 32]; }
             }
+            __builtin_amdgcn_sched_barrier(0);          // (or the scheduler pairs every load with its MFMA again)
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+#pragma unroll
+                for (int t = 0; t < CT; ++t) {
+                    acc_r[t] = mfma32(av[s0 + u], bw[u][3 * t], acc_r[t]);
+                    acc_z[t] = mfma32(av[s0 + u], bw[u][3 * t + 1], acc_z[t]);
+                    acc_hn[t] = mfma32(av[s0 + u], bw[u][3 * t + 2], acc_hn[t]);
+                }
         }
     }
     // ---- gate epilogue, merge-by-row store
@@ -322,14 +342,27 @@ __global__ __launch_bounds__(256) void k_gru_bwd_data(GruBwdDataArgs a) {
         const float* __restrict__ wr = W + (size_t)f0 * ldw + n0 + c;
         const float* __restrict__ wz = W + (size_t)(H + f0) * ldw + n0 + c;
         const float* __restrict__ wn = W + (size_t)(2 * H + f0) * ldw + n0 + c;
+        // (weights of four k-steps requested together, as in k_gru_fwd)
 #pragma unroll
-        for (int s = 0; s < 16; ++s) {
+        for (int s0 = 0; s0 < 16; s0 += 4) {
+            float bw[4][3 * NT];
 #pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                acc[t] = mfma32(ar[s], wr[(size_t)s * ldw + t * 32], acc[t]);
-                acc[t] = mfma32(az[s], wz[(size_t)s * ldw + t * 32], acc[t]);
-                acc[t] = mfma32(an[s], wn[(size_t)s * ldw + t * 32], acc[t]);
-            }
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    bw[u][3 * t] = wr[(size_t)(s0 + u) * ldw + t * 32];
+                    bw[u][3 * t + 1] = wz[(size_t)(s0 + u) * ldw + t * 32];
+                    bw[u][3 * t + 2] = wn[(size_t)(s0 + u) * ldw + t * 32];
+                }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    acc[t] = mfma32(ar[s0 + u], bw[u][3 * t], acc[t]);
+                    acc[t] = mfma32(az[s0 + u], bw[u][3 * t + 1], acc[t]);
+                    acc[t] = mfma32(an[s0 + u], bw[u][3 * t + 2], acc[t]);
+                }
         }
     }
 #pragma unroll

@@ -8,6 +8,7 @@ index plumbing only -- every flop of the path runs in libtmpnn.so, and there is 
 """
 from __future__ import annotations
 
+import contextlib
 import os
 from dataclasses import dataclass
 from typing import Dict, List, Optional, Sequence, Tuple
@@ -90,13 +91,43 @@ def _input_tf(plan: CallPlan, H: int, F: int) -> bool:
             and bool(_lib.load().tmpnn_input_tf_supported(H, F, plan.max_seg_nd)))
 
 
+_weight_images = None      # inside weight_cache(): {key: (source tensors kept alive, derived tensor)}
+
+
+@contextlib.contextmanager
+def weight_cache():
+    """Within the context a weight's derived images (the transposes, the wide cells' MFMA operand images) are built once
+    per source tensor instead of once per forward call -- for callers that KNOW the weights do not change inside: the
+    forward calls of one training step (CapturedWindow: 4-6 launches less per call of a window).  Nothing outlives the
+    context, so nothing can go stale; outside it every forward call rebuilds them."""
+    global _weight_images
+    prev = _weight_images
+    _weight_images = {}
+    try:
+        yield
+    finally:
+        _weight_images = prev
+
+
+def _cached(key, sources, build):
+    if _weight_images is None:
+        return build()
+    hit = _weight_images.get(key)
+    if hit is None:                                  # (the sources stay referenced: their addresses cannot be reused)
+        hit = _weight_images[key] = (sources, build())
+    return hit[1]
+
+
 def _wide_prep(w_ih: torch.Tensor, w_hh: torch.Tensor, H: int) -> torch.Tensor:
     """MFMA operand images of one wide cell's weights (tmpnn_wide_prepare: four small launches).  Rebuilt on every
-    forward call -- microseconds next to a wide cell's work, and never stale; the backward reuses the call's images."""
-    nb = int(_lib.load().tmpnn_wide_prep_bytes(H, H))
-    prep = torch.empty((nb // 4 + 4,), dtype=torch.float32, device=w_ih.device)
-    _lib.call('tmpnn_wide_prepare', w_ih.data_ptr(), w_hh.data_ptr(), H, H, prep.data_ptr(), _stream())
-    return prep
+    forward call -- microseconds next to a wide cell's work, and never stale (weight_cache() narrows that to once per
+    context); the backward reuses the call's images."""
+    def build():
+        nb = int(_lib.load().tmpnn_wide_prep_bytes(H, H))
+        prep = torch.empty((nb // 4 + 4,), dtype=torch.float32, device=w_ih.device)
+        _lib.call('tmpnn_wide_prepare', w_ih.data_ptr(), w_hh.data_ptr(), H, H, prep.data_ptr(), _stream())
+        return prep
+    return _cached(('wide', w_ih.data_ptr(), w_hh.data_ptr(), H), (w_ih, w_hh), build)
 
 
 @dataclass(frozen=True)
@@ -152,9 +183,11 @@ def _f32c(t: torch.Tensor) -> torch.Tensor:
 
 
 def _transpose(w: torch.Tensor) -> torch.Tensor:
-    out = torch.empty((w.shape[1], w.shape[0]), dtype=torch.float32, device=w.device)
-    _lib.call('tmpnn_transpose', w.data_ptr(), w.shape[0], w.shape[1], out.data_ptr(), _stream())
-    return out
+    def build():
+        out = torch.empty((w.shape[1], w.shape[0]), dtype=torch.float32, device=w.device)
+        _lib.call('tmpnn_transpose', w.data_ptr(), w.shape[0], w.shape[1], out.data_ptr(), _stream())
+        return out
+    return _cached(('t', w.data_ptr(), w.shape[0], w.shape[1]), (w,), build)
 
 
 def mp_forward(spec: ModelSpec, plan: CallPlan, x: torch.Tensor, h_in: Optional[torch.Tensor],
