@@ -365,15 +365,19 @@ def mp_forward(spec: ModelSpec, plan: CallPlan, x: torch.Tensor, h_in: Optional[
             _lib.call('tmpnn_segsum_fwd', g.cref(), hg, GH, es.data_ptr(), H, H, 0, 1, st_det)
             alphas.append(None)
         else:
-            W = torch.stack([P[f + f'gat.{k}.W_att'] for k in range(K)]).contiguous()
-            a = torch.stack([P[f + f'gat.{k}.a'].reshape(-1) for k in range(K)]).contiguous()
+            Ws = [P[f + f'gat.{k}.W_att'] for k in range(K)]
+            As = [P[f + f'gat.{k}.a'] for k in range(K)]
+            # (the heads' weights stacked for the kernels: one copy per call, or per weight_cache() context)
+            W = _cached(('attW', tuple(t.data_ptr() for t in Ws)), tuple(Ws), lambda: torch.stack(Ws).contiguous())
+            a = _cached(('atta', tuple(t.data_ptr() for t in As)), tuple(As),
+                        lambda: torch.stack([t.reshape(-1) for t in As]).contiguous())
             ws_ha = torch.empty((K, max(Dn, 1), H), **opts)
-            score = torch.zeros((K, max(N, 1)), **opts)
+            score = torch.empty((K, max(N, 1)), **opts)      # (k_att_score writes every edge row's entry; no other is read)
             alpha = torch.empty((K, max(2 * E, 1)), **opts)
             kp = None
             if training:
                 if keep is None or keep[gi] is None:
-                    kp = (torch.rand((K, max(2 * E, 1)), device=dev) >= ATT_DROPOUT_P).to(torch.uint8)
+                    kp = torch.empty((K, max(2 * E, 1)), dtype=torch.uint8, device=dev).bernoulli_(1.0 - ATT_DROPOUT_P)
                 else:
                     kp = keep[gi].to(torch.uint8).contiguous()
             _lib.call('tmpnn_att_fwd', g.cref(), g.pos.data_ptr(), hg, GH, H, K, W.data_ptr(), a.data_ptr(),
@@ -581,7 +585,7 @@ def mp_backward(spec: ModelSpec, plan: CallPlan, saved: dict, P: Dict[str, torch
             ws_n_att = lib.tmpnn_att_bwd_ws(E, Dn, H, K)
             ws_att = torch.empty((max(ws_n_att, 1),), **opts)
             ws_dha = torch.empty((K, max(Dn, 1), H), **opts)
-            ws_edge = torch.zeros((K, max(N, 1)), **opts)
+            ws_edge = torch.empty((K, max(N, 1)), **opts)    # (every edge row's entry is assigned by the src-side pass)
             _lib.call('tmpnn_att_bwd', g.cref(), g.pos.data_ptr(), hg, GH, H, K, W.data_ptr(), a.data_ptr(),
                       _lib.ptr(kp), ATT_DROPOUT_P, ws_ha.data_ptr(), score.data_ptr(), alpha.data_ptr(),
                       dmsg.data_ptr(), IN_e, ws_att.data_ptr(), ws_att.numel(), ws_dha.data_ptr(), ws_edge.data_ptr(),
