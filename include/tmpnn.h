@@ -137,6 +137,15 @@ int tmpnn_att_bwd(const tmpnn_graph* g, const int32_t* pos, const float* h, int 
                   const float* d_out, int ld_dout,
                   float* ws, size_t ws_floats, float* ws_dha, float* ws_edge,
                   float* d_h, int ld_dh, float* dW_att, float* da, tmpnn_stream stream);
+/* The same with one output pointer per head (host arrays of K device pointers: dW_heads[k] [H][H] (+=), da_heads[k] [H]
+ * (+=)) -- the heads' parameters are separate tensors (models/layers.py:7-24, 67: a ModuleList of GraphAttentionLayer, one per head), so their
+ * .grad buffers can be accumulated in place without a stacked temporary. */
+int tmpnn_att_bwd_heads(const tmpnn_graph* g, const int32_t* pos, const float* h, int ld_h, int H, int K,
+                        const float* W_att, const float* a, const uint8_t* keep, float p_drop,
+                        const float* ws_ha, const float* score, const float* alpha,
+                        const float* d_out, int ld_dout,
+                        float* ws, size_t ws_floats, float* ws_dha, float* ws_edge,
+                        float* d_h, int ld_dh, float* const* dW_heads, float* const* da_heads, tmpnn_stream stream);
 
 /* ---- rows H', I: GRU cells with row indirection + type-masked merge ----------------------
  * (torch.nn.GRUCell as used at models/layers.py:97,114; merge layers.py:116).

@@ -465,6 +465,23 @@ def check_attention(H, K, training, g, gd):
         1.0, max(p[f'gat.{k}.W_att'].grad.abs().max().item() for k in range(K)))
     res['da'] = max((da.cpu()[k] - p[f'gat.{k}.a'].grad[:, 0]).abs().max().item() for k in range(K)) / max(
         1.0, max(p[f'gat.{k}.a'].grad.abs().max().item() for k in range(K)))
+    # the same backward with one gradient pointer per head (accumulating into buffers that already hold something, as
+    # p.grad does; uninitialised ws_edge: every entry that is read is assigned first): bit-identical sums
+    import ctypes
+    base_W = [torch.randn(H, H, device=DEV) for _ in range(K)]
+    base_a = [torch.randn(H, 1, device=DEV) for _ in range(K)]
+    gW, ga = [t.clone() for t in base_W], [t.clone() for t in base_a]
+    d_h2 = d(pre)
+    ws_edge2 = torch.full((K, g.N), float('nan'), device=DEV)
+    pW = (ctypes.c_void_p * K)(*[t.data_ptr() for t in gW])
+    pa = (ctypes.c_void_p * K)(*[t.data_ptr() for t in ga])
+    _lib.call('tmpnn_att_bwd_heads', gd.cref(), gd.pos.data_ptr(), hD.data_ptr() + 4 * H, ld, H, K, W.data_ptr(),
+              a.data_ptr(), _lib.ptr(keepD), 0.5, ws_ha.data_ptr(), score.data_ptr(), alpha.data_ptr(),
+              dmsgD.data_ptr(), H + 4, ws.data_ptr(), wsn + 1, ws_dha.data_ptr(), ws_edge2.data_ptr(),
+              d_h2.data_ptr() + 4 * H, ld, ctypes.cast(pW, ctypes.c_void_p), ctypes.cast(pa, ctypes.c_void_p), st())
+    res['heads entry: d_h bits'] = float(not torch.equal(d_h2, d_h))
+    res['heads entry: dW'] = max(((gW[k] - base_W[k]) - dW[k]).abs().max().item() for k in range(K)) / max(1.0, dW.abs().max().item())
+    res['heads entry: da'] = max(((ga[k] - base_a[k])[:, 0] - da[k]).abs().max().item() for k in range(K)) / max(1.0, da.abs().max().item())
     return res
 
 

@@ -83,6 +83,9 @@ _SIGNATURES = {
     'tmpnn_att_bwd': (c_int, [_GP, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_float,
                               c_void_p, c_void_p, c_void_p, c_void_p, c_int,
                               c_void_p, c_size_t, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
+    'tmpnn_att_bwd_heads': (c_int, [_GP, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_float,
+                                    c_void_p, c_void_p, c_void_p, c_void_p, c_int,
+                                    c_void_p, c_size_t, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     'tmpnn_gru_fwd': (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                               c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                               c_void_p, c_int, c_void_p, c_size_t, c_void_p, c_void_p, c_size_t, c_void_p]),

@@ -344,15 +344,20 @@ int tmpnn_att_fwd(const tmpnn_graph* g, const int32_t* pos, const float* h, int 
     return check_launch("att_fwd_agg");
 }
 
-int tmpnn_att_bwd(const tmpnn_graph* g, const int32_t* pos, const float* h, int ld_h, int H, int K,
-                  const float* W_att, const float* a, const uint8_t* keep, float p_drop, const float* ws_ha,
-                  const float* score, const float* alpha, const float* d_out, int ld_dout, float* ws, size_t ws_floats,
-                  float* ws_dha, float* ws_edge, float* d_h, int ld_dh, float* dW_att, float* da,
-                  tmpnn_stream stream) {
+}  // extern "C"
+
+// dW_att / da: the stacked outputs [K][H][H] / [K][H], or (NULL) one pointer per head in dW_heads / da_heads (host arrays)
+static int att_bwd_impl(const tmpnn_graph* g, const int32_t* pos, const float* h, int ld_h, int H, int K,
+                        const float* W_att, const float* a, const uint8_t* keep, float p_drop, const float* ws_ha,
+                        const float* score, const float* alpha, const float* d_out, int ld_dout, float* ws, size_t ws_floats,
+                        float* ws_dha, float* ws_edge, float* d_h, int ld_dh, float* dW_att, float* da,
+                        float* const* dW_heads, float* const* da_heads, tmpnn_stream stream) {
     int rc = check_att(g, pos, h, ld_h, H, K);
     if (rc) return rc;
-    TM_REQUIRE(W_att && a && ws_ha && score && alpha && d_out && ws && ws_dha && ws_edge && d_h && dW_att && da,
-               "att_bwd: null pointer");
+    TM_REQUIRE(W_att && a && ws_ha && score && alpha && d_out && ws && ws_dha && ws_edge && d_h &&
+                   ((dW_att && da) || (dW_heads && da_heads)), "att_bwd: null pointer");
+    if (!dW_att)
+        for (int k = 0; k < K; ++k) TM_REQUIRE(dW_heads[k] && da_heads[k], "att_bwd_heads: null gradient pointer of head %d", k);
     TM_REQUIRE((ld_dout & 3) == 0 && (ld_dh & 3) == 0 && aligned16(d_out) && aligned16(d_h) && aligned16(ws_dha),
                "att_bwd: rows must be 16-byte aligned");
     if (g->Dn == 0 || g->E == 0) return TMPNN_OK;
@@ -379,14 +384,19 @@ int tmpnn_att_bwd(const tmpnn_graph* g, const int32_t* pos, const float* h, int 
     const int slots = 256 / (H >> 2);
     hipLaunchKernelGGL(k_att_bwd_edge, dim3(nb), blk, sizeof(float) * slots * H, st, A, ws_edge, per, ws);
     if ((rc = check_launch("att_bwd_edge"))) return rc;
-    if ((rc = launch_reduce_slabs(ws, (size_t)K * H, nb, da, (size_t)K * H, 1, st))) return rc;
+    if (da) {
+        if ((rc = launch_reduce_slabs(ws, (size_t)K * H, nb, da, (size_t)K * H, 1, st))) return rc;
+    } else {
+        for (int k = 0; k < K; ++k)
+            if ((rc = launch_reduce_slabs(ws + (size_t)k * H, (size_t)K * H, nb, da_heads[k], (size_t)H, 1, st))) return rc;
+    }
     hipLaunchKernelGGL(k_att_bwd_dha, dim3(att_grid((long)g->Dn * K)), blk, 0, st, A, ws_edge, ws_dha);
     if ((rc = check_launch("att_bwd_dha"))) return rc;
     for (int k = 0; k < K; ++k) {
         const float* dha = ws_dha + (size_t)k * g->Dn * H;
         // dW_k[i][j] += sum_d h[det d][i] * d_ha_k[d][j]
-        GemmArgs gw{h, 1, ld_h, nullptr, g->det_row, dha, H, 1, nullptr, dW_att + (size_t)k * H * H, H, nullptr,
-                    H, H, g->Dn, 1};
+        GemmArgs gw{h, 1, ld_h, nullptr, g->det_row, dha, H, 1, nullptr, dW_att ? dW_att + (size_t)k * H * H : dW_heads[k], H,
+                    nullptr, H, H, g->Dn, 1};
         if ((rc = launch_gemm_splitk(gw, ws, ws_floats, st))) return rc;
         // d_h[det rows] += d_ha_k @ W_k^T
         GemmArgs gh{dha, H, 1, nullptr, nullptr, W_att + (size_t)k * H * H, 1, H, nullptr, d_h, ld_dh, g->det_row,
@@ -394,6 +404,28 @@ int tmpnn_att_bwd(const tmpnn_graph* g, const int32_t* pos, const float* h, int 
         if ((rc = launch_gemm(gh, st))) return rc;
     }
     return TMPNN_OK;
+}
+
+extern "C" {
+
+int tmpnn_att_bwd(const tmpnn_graph* g, const int32_t* pos, const float* h, int ld_h, int H, int K,
+                  const float* W_att, const float* a, const uint8_t* keep, float p_drop, const float* ws_ha,
+                  const float* score, const float* alpha, const float* d_out, int ld_dout, float* ws, size_t ws_floats,
+                  float* ws_dha, float* ws_edge, float* d_h, int ld_dh, float* dW_att, float* da,
+                  tmpnn_stream stream) {
+    TM_REQUIRE(dW_att && da, "att_bwd: null pointer");
+    return att_bwd_impl(g, pos, h, ld_h, H, K, W_att, a, keep, p_drop, ws_ha, score, alpha, d_out, ld_dout, ws, ws_floats, ws_dha,
+                        ws_edge, d_h, ld_dh, dW_att, da, nullptr, nullptr, stream);
+}
+
+int tmpnn_att_bwd_heads(const tmpnn_graph* g, const int32_t* pos, const float* h, int ld_h, int H, int K,
+                        const float* W_att, const float* a, const uint8_t* keep, float p_drop, const float* ws_ha,
+                        const float* score, const float* alpha, const float* d_out, int ld_dout, float* ws, size_t ws_floats,
+                        float* ws_dha, float* ws_edge, float* d_h, int ld_dh, float* const* dW_heads, float* const* da_heads,
+                        tmpnn_stream stream) {
+    TM_REQUIRE(dW_heads && da_heads, "att_bwd_heads: null pointer");
+    return att_bwd_impl(g, pos, h, ld_h, H, K, W_att, a, keep, p_drop, ws_ha, score, alpha, d_out, ld_dout, ws, ws_floats, ws_dha,
+                        ws_edge, d_h, ld_dh, nullptr, nullptr, dW_heads, da_heads, stream);
 }
 
 }  // extern "C"

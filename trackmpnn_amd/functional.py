@@ -9,6 +9,7 @@ index plumbing only -- every flop of the path runs in libtmpnn.so, and there is 
 from __future__ import annotations
 
 import contextlib
+import ctypes
 import os
 from dataclasses import dataclass
 from typing import Dict, List, Optional, Sequence, Tuple
@@ -580,23 +581,34 @@ def mp_backward(spec: ModelSpec, plan: CallPlan, saved: dict, P: Dict[str, torch
                           ws_w.data_ptr(), ws_w.numel() * 4, st)
         if K > 0:
             W, a, kp, ws_ha, score, alpha = saved['att'][gi]
-            dW = torch.zeros_like(W)
-            da = torch.zeros_like(a)
             ws_n_att = lib.tmpnn_att_bwd_ws(E, Dn, H, K)
             ws_att = torch.empty((max(ws_n_att, 1),), **opts)
             ws_dha = torch.empty((K, max(Dn, 1), H), **opts)
             ws_edge = torch.empty((K, max(N, 1)), **opts)    # (every edge row's entry is assigned by the src-side pass)
-            _lib.call('tmpnn_att_bwd', g.cref(), g.pos.data_ptr(), hg, GH, H, K, W.data_ptr(), a.data_ptr(),
-                      _lib.ptr(kp), ATT_DROPOUT_P, ws_ha.data_ptr(), score.data_ptr(), alpha.data_ptr(),
-                      dmsg.data_ptr(), IN_e, ws_att.data_ptr(), ws_att.numel(), ws_dha.data_ptr(), ws_edge.data_ptr(),
-                      dhg, GH, dW.data_ptr(), da.data_ptr(), st)
-            for k in range(K):
-                if grad_out is not None:
-                    grads[f + f'gat.{k}.W_att'].add_(dW[k])
-                    grads[f + f'gat.{k}.a'].add_(da[k].reshape(-1, 1))
-                else:
-                    grads[f + f'gat.{k}.W_att'] = dW[k]
-                    grads[f + f'gat.{k}.a'] = da[k].reshape(-1, 1)
+            gW = [grads.get(f + f'gat.{k}.W_att') for k in range(K)] if grad_out is not None else []
+            ga = [grads.get(f + f'gat.{k}.a') for k in range(K)] if grad_out is not None else []
+            if grad_out is not None and all(t is not None and t.is_contiguous() for t in gW + ga):
+                # in-place mode: the heads' gradient buffers are accumulated directly (no stacked temporary, no adds)
+                pW = (ctypes.c_void_p * K)(*[t.data_ptr() for t in gW])
+                pa = (ctypes.c_void_p * K)(*[t.data_ptr() for t in ga])
+                _lib.call('tmpnn_att_bwd_heads', g.cref(), g.pos.data_ptr(), hg, GH, H, K, W.data_ptr(), a.data_ptr(),
+                          _lib.ptr(kp), ATT_DROPOUT_P, ws_ha.data_ptr(), score.data_ptr(), alpha.data_ptr(),
+                          dmsg.data_ptr(), IN_e, ws_att.data_ptr(), ws_att.numel(), ws_dha.data_ptr(), ws_edge.data_ptr(),
+                          dhg, GH, ctypes.cast(pW, ctypes.c_void_p), ctypes.cast(pa, ctypes.c_void_p), st)
+            else:
+                dW = torch.zeros_like(W)
+                da = torch.zeros_like(a)
+                _lib.call('tmpnn_att_bwd', g.cref(), g.pos.data_ptr(), hg, GH, H, K, W.data_ptr(), a.data_ptr(),
+                          _lib.ptr(kp), ATT_DROPOUT_P, ws_ha.data_ptr(), score.data_ptr(), alpha.data_ptr(),
+                          dmsg.data_ptr(), IN_e, ws_att.data_ptr(), ws_att.numel(), ws_dha.data_ptr(), ws_edge.data_ptr(),
+                          dhg, GH, dW.data_ptr(), da.data_ptr(), st)
+                for k in range(K):
+                    if grad_out is not None:
+                        grads[f + f'gat.{k}.W_att'].add_(dW[k])
+                        grads[f + f'gat.{k}.a'].add_(da[k].reshape(-1, 1))
+                    else:
+                        grads[f + f'gat.{k}.W_att'] = dW[k]
+                        grads[f + f'gat.{k}.a'] = da[k].reshape(-1, 1)
         # adjoint of the node -> edge message: into d_hcat[det rows] (the det-side wide backward has already put it there)
         name = 'tmpnn_gather_concat_bwd' if spec.msg_type == 'concat' else 'tmpnn_gather_diff_bwd'
         if not (not use_fused_bwd and saved.get('wide') and WIDE_DET):
