@@ -161,6 +161,7 @@ int launch_gemm_splitk(const GemmArgs& g, float* ws, size_t ws_floats, hipStream
     const int ns = splitk_plan(g.K, &kper);
     if (ws_floats < gemm_splitk_ws_floats(g.M, g.N, g.K))
         return set_error(TMPNN_EWORKSPACE, "gemm_splitk: workspace too small");
+    if (ns == 1) return launch_gemm(g, st);      // one slab: the same sum straight into C (a launch less on batch-1 graphs)
     float* ws2 = ws + (size_t)ns * g.M * g.N;
     dim3 grid(ceil_div(g.N, 64), ceil_div(g.M, 64), ns), block(256);
     hipLaunchKernelGGL(k_gemm, grid, block, 0, st, g, kper, ws);
