@@ -3740,7 +3740,10 @@ int tmpnn_gru_fwd(const int32_t* rows, int R, int xmode, const int32_t* src, con
 generic:
     TM_REQUIRE(logit_part == nullptr, "gru_fwd: fused head requested but the LDS path is unavailable (alignment)");
     TM_REQUIRE(xmode != 3, "gru_fwd: xmode 3 is only available on the LDS path (H <= 64, 16-byte aligned buffers)");
-    const int CT = (H % 64 == 0) ? 2 : 1;
+    // (a wave walks the whole K range alone: on a batch-1 graph -- a handful of blocks -- narrower column blocks halve each
+    //  wave's chain of dependent MFMAs; the sums per output are the same)
+    int CT = (H % 64 == 0) ? 2 : 1;
+    if (CT == 2 && (long)ceil_div(R, 128) * (H / 64) < 128) CT = 1;
     dim3 grid(ceil_div(R, 128), H / (32 * CT)), block(256);
 #define L(C, X) hipLaunchKernelGGL((k_gru_fwd<C, X>), grid, block, 0, st, a)
     if (CT == 2) { if (xmode == 0) L(2, 0); else if (xmode == 1) L(2, 1); else L(2, 2); }
@@ -3890,7 +3893,8 @@ int tmpnn_gru_bwd_data(const int32_t* rows, int R, int IN, const float* h, int l
         return check_launch("gru_bwd_data_lds");
     }
     // wider column blocks re-read (and re-derive) the gate planes fewer times
-    const int NT = (H % 128 == 0 && IN % 128 == 0) ? 4 : (H % 64 == 0) ? 2 : 1;
+    int NT = (H % 128 == 0 && IN % 128 == 0) ? 4 : (H % 64 == 0) ? 2 : 1;
+    if (NT > 1 && (long)ceil_div(R, 128) * ((IN + H) / (32 * NT)) < 128) NT = 1;      // (batch-1 graphs: see tmpnn_gru_fwd)
     dim3 grid(ceil_div(R, 128), (IN + H) / (32 * NT)), block(256);
     if (NT == 4) hipLaunchKernelGGL((k_gru_bwd_data<4>), grid, block, 0, st, a);
     else if (NT == 2) hipLaunchKernelGGL((k_gru_bwd_data<2>), grid, block, 0, st, a);
