@@ -49,6 +49,7 @@ INPUT_TF = os.environ.get('TMPNN_INPUT_TF', '1') != '0'
 # backward runs the forward kernel again into the gate planes (and a scratch state) right before the one-pass backward
 # reads them.  Same gradients bit for bit; measured SLOWER (numbers in DESIGN), so off by default.
 RECOMPUTE_GATES = os.environ.get('TMPNN_RECOMPUTE_GATES', '0') == '1'
+CONCAT_PROJ = os.environ.get('TMPNN_CONCAT_PROJ', '1') != '0'
 # wide cells: the det-side branch of the backward on a second stream next to the E-row matrix kernels (tmpnn_wide_gru_bwd_diff_aux)
 WIDE_OVERLAP = os.environ.get('TMPNN_WIDE_OVERLAP', '1') != '0'
 WIDE_FUSED_ADJOINT = os.environ.get('TMPNN_WIDE_FUSED_ADJOINT', '1') != '0'
@@ -290,11 +291,16 @@ def mp_forward(spec: ModelSpec, plan: CallPlan, x: torch.Tensor, h_in: Optional[
     plane = N * H
     lib = _lib.load()
     use_proj = spec.msg_type == 'diff' and H <= 64 and g.src_pos is not None and Dn > 0
+    # concat: [h_src | h_dst] W_ih^T = P1[src] + P2[dst] -- the same tiled kernel on a stacked table [P1; -P2] and tile lists
+    # whose dst entries are offset by Dn (TMPNN_CONCAT_PROJ=0 keeps the per-edge GEMM over IN = 2H)
+    use_proj_cat = (CONCAT_PROJ and spec.msg_type == 'concat' and H <= 64 and FWD_TILED and g.src_pos is not None
+                    and Dn > 0 and E > 0)
     use_wide = (WIDE and spec.msg_type == 'diff' and H >= 128 and bool(lib.tmpnn_wide_supported(H, H))
                 and g.src_pos is not None and Dn > 0 and E > 0)
     wide_preps = []
     # output head fused into the cells' epilogues where the LDS-resident kernel runs (else tmpnn_heads_fwd)
-    cw = min(lib.tmpnn_gru_fwd_head_parts(H, spec.IN_e, 3 if use_proj else xmode), lib.tmpnn_gru_fwd_head_parts(H, H, 0))
+    cw = min(lib.tmpnn_gru_fwd_head_parts(H, H if use_proj_cat else spec.IN_e, 3 if (use_proj or use_proj_cat) else xmode),
+             lib.tmpnn_gru_fwd_head_parts(H, H, 0))
     parts = torch.empty((G * cw, N), **opts) if cw > 0 else None
     w_node, w_edge = P['output_transform_node.weight'], P['output_transform_edge.weight']
     for gi in range(G):
@@ -336,6 +342,16 @@ def mp_forward(spec: ModelSpec, plan: CallPlan, x: torch.Tensor, h_in: Optional[
                           g.src_pos.data_ptr(), g.dst_pos.data_ptr(), hg, GH, H,
                           P[f + 'edge_gru.bias_ih'].data_ptr(), P[f + 'edge_gru.bias_hh'].data_ptr(),
                           proj.data_ptr(), og, GH, gp, plane, st)
+        elif use_proj_cat:
+            proj = torch.empty((2 * Dn, 3 * H), **opts)
+            _lib.call('tmpnn_rows_linear', g.det_row.data_ptr(), Dn, hg, GH, H, e_wih_t.data_ptr(), 3 * H,
+                      proj.data_ptr(), 3 * H, st)
+            _lib.call('tmpnn_rows_linear', g.det_row.data_ptr(), Dn, hg, GH, H, e_wih_t.data_ptr() + 4 * H * 3 * H, 3 * H,
+                      proj.data_ptr() + 4 * Dn * 3 * H, 3 * H, st)
+            proj[Dn:].neg_()                                  # (the kernel forms P[src] - P[dst])
+            _lib.call('tmpnn_gru_fwd_tiles', edge_tiles(g, FWD_TILE_ROWS, dst_offset=Dn).cref(), E, proj.data_ptr(), 3 * H, hg, GH,
+                      H, e_whh_t.data_ptr(), P[f + 'edge_gru.bias_ih'].data_ptr(), P[f + 'edge_gru.bias_hh'].data_ptr(),
+                      og, GH, gp, plane, we_g, part_g, N, st)
         elif use_proj:
             # (h[src]-h[dst]) W_ih^T = P[src] - P[dst] with P = h[dets] W_ih^T: the x-half of the edge cell's
             # forward GEMM runs over the Dn det rows instead of the E edge rows

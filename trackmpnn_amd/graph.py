@@ -97,7 +97,7 @@ class EdgeTiles:
 
 
 def build_edge_tiles(graph: FrameGraph, rows_per_tile: int = 128, src_group: int = 8, dst_group: int = 16,
-                     stats: bool = False, order: str = 'blocks') -> EdgeTiles:
+                     stats: bool = False, order: str = 'blocks', dst_offset: int = 0) -> EdgeTiles:
     """Cut the graph's edge rows into tiles of `rows_per_tile` rows that touch few distinct dets.
 
     A frame block of the rolling graph is a dense [A srcs x D_t dsts] set of rows in src-major order
@@ -107,7 +107,10 @@ def build_edge_tiles(graph: FrameGraph, rows_per_tile: int = 128, src_group: int
     `order='rows'` keeps the graph's own row order instead (tiles of consecutive edge rows): the better choice when a
     src's run of edges is much shorter than a tile, as in batches of small windows (KITTI: ~6 dets per frame, 32
     consecutive rows touch ~16 dets, any regrouping touches more).  Index plumbing only (torch ops on the graph's
-    device, no host round trip unless `stats`)."""
+    device, no host round trip unless `stats`).
+
+    `dst_offset`: added to every dst entry of the det lists -- the concat message reads its src half and its dst half from two
+    different projected tables, stacked as rows [0, Dn) and [Dn, 2 Dn) of one (dst_offset = Dn)."""
     if graph.src_pos is None or graph.dst_pos is None:
         raise ValueError('build_edge_tiles: the graph carries no src_pos / dst_pos')
     dev = graph.device
@@ -130,7 +133,7 @@ def build_edge_tiles(graph: FrameGraph, rows_per_tile: int = 128, src_group: int
         so = torch.cat([so, so[-1:].expand(pad)])            # padding slots repeat the last edge's dets (no new det)
         do = torch.cat([do, do[-1:].expand(pad)])
         ro = torch.cat([ro, torch.full((pad,), -1, dtype=torch.long, device=dev)])
-    both = torch.cat([so.view(T, R), do.view(T, R)], 1)      # [T, 2R]
+    both = torch.cat([so.view(T, R), do.view(T, R) + int(dst_offset)], 1)      # [T, 2R]
     vals, perm = both.sort(1)
     first = torch.ones_like(vals, dtype=torch.bool)
     first[:, 1:] = vals[:, 1:] != vals[:, :-1]
@@ -147,10 +150,11 @@ def build_edge_tiles(graph: FrameGraph, rows_per_tile: int = 128, src_group: int
     return tiles
 
 
-def edge_tiles(graph: FrameGraph, rows_per_tile: int = 128) -> EdgeTiles:
+def edge_tiles(graph: FrameGraph, rows_per_tile: int = 128, dst_offset: int = 0) -> EdgeTiles:
     """The graph's cached tile list (built on first use)."""
     cache = graph.__dict__.setdefault('_tiles', {})
-    t = cache.get(rows_per_tile)
+    key = rows_per_tile if not dst_offset else (rows_per_tile, int(dst_offset))
+    t = cache.get(key)
     if t is None:
         # dense frame blocks (a src's run of edges spans a good part of a tile) are cut into src x dst sub-blocks; graphs of
         # small windows keep their row order.  The mean run length costs one host round trip, once per graph.
@@ -158,13 +162,14 @@ def edge_tiles(graph: FrameGraph, rows_per_tile: int = 128) -> EdgeTiles:
         if graph.E > 1:
             runs = 1 + int((graph.src_pos[1:] != graph.src_pos[:-1]).sum())
         blocks = graph.E / runs >= rows_per_tile / 2
+        od = 'blocks' if blocks else 'rows'
         if rows_per_tile == 128:
-            t = build_edge_tiles(graph, 128, 8, 16, order='blocks' if blocks else 'rows')
+            t = build_edge_tiles(graph, 128, 8, 16, order=od, dst_offset=dst_offset)
         elif rows_per_tile == 16:
-            t = build_edge_tiles(graph, 16, 4, 4, order='blocks' if blocks else 'rows')
+            t = build_edge_tiles(graph, 16, 4, 4, order=od, dst_offset=dst_offset)
         else:
-            t = build_edge_tiles(graph, rows_per_tile, 4, 8, order='blocks' if blocks else 'rows')
-        cache[rows_per_tile] = t
+            t = build_edge_tiles(graph, rows_per_tile, 4, 8, order=od, dst_offset=dst_offset)
+        cache[key] = t
     return t
 
 
