@@ -232,7 +232,7 @@ def test_any_hidden_width_is_accepted_and_keeps_reference_shapes():
         TrackMPNN('2d', 3, 1100, 0, 'diff')
 
 
-def _check_tiles(g, tiles, R):
+def _check_tiles(g, tiles, R, dst_offset=0):
     """Every edge row exactly once; each slot's (src, dst) recoverable through the tile's det list; lists ascending."""
     E = g.E
     T = tiles.T
@@ -253,8 +253,8 @@ def _check_tiles(g, tiles, R):
         assert int(ls[t].max()) < dets.numel() and int(ld[t].max()) < dets.numel()
         v = valid[t]
         e = epos[rows[t][v]]
-        assert torch.equal(dets[ls[t][v]], g.src_pos.long()[e]) and torch.equal(dets[ld[t][v]], g.dst_pos.long()[e])
-        assert set(dets.tolist()) == set(g.src_pos.long()[e].tolist()) | set(g.dst_pos.long()[e].tolist())
+        assert torch.equal(dets[ls[t][v]], g.src_pos.long()[e]) and torch.equal(dets[ld[t][v]], g.dst_pos.long()[e] + dst_offset)
+        assert set(dets.tolist()) == set(g.src_pos.long()[e].tolist()) | set((g.dst_pos.long()[e] + dst_offset).tolist())
     return int((dptr[1:] - dptr[:-1]).max())
 
 
@@ -277,6 +277,10 @@ def test_edge_tiles_cover_every_edge_and_index_their_dets():
     _check_tiles(gr, build_edge_tiles(gr, 128), 128)
     _check_tiles(gr, build_edge_tiles(gr, 32, 4, 8), 32)
     assert edge_tiles(gr, 128) is edge_tiles(gr, 128)   # cached on the graph
+    # the concat message's lists: dst entries offset by Dn (rows [Dn, 2 Dn) of the stacked projected table), cached apart
+    _check_tiles(gr, build_edge_tiles(gr, 32, 4, 8, dst_offset=gr.Dn), 32, dst_offset=gr.Dn)
+    _check_tiles(g, build_edge_tiles(g, 128, dst_offset=g.Dn), 128, dst_offset=g.Dn)
+    assert edge_tiles(gr, 32, dst_offset=gr.Dn) is edge_tiles(gr, 32, dst_offset=gr.Dn) is not edge_tiles(gr, 32)
     empty = dense_static_graph(1, 5)
     assert build_edge_tiles(empty, 128).T == 0
 
