@@ -716,6 +716,13 @@ def run_all(report=print):
     for H in (128, 256):
         for k, v in check_wide(H, g8, g8d).items():
             rec(f'wide cell H={H}, 5x64 window (8 slabs) {k}', v, 0.0 if (k.endswith('untouched') or k.endswith('bits')) else 2e-4)
+    # odd sizes: fewer rows than one 16-row chunk of the weight gradient / one 128-row tile, a row count that ends a slab
+    # mid-chunk, det counts that are no multiple of anything
+    for T, D in ((2, 3), (3, 17), (2, 47)):
+        go = dense_static_graph(T, D)
+        god = go.to(DEV)
+        for k, v in check_wide(128, go, god).items():
+            rec(f'wide cell H=128, {T}x{D} window (E={go.E}) {k}', v, 0.0 if (k.endswith('untouched') or k.endswith('bits')) else 2e-4)
     for H in (128, 256):
         # a dense 3-block window (tiles staged in LDS), a larger ragged batch (both kinds) and the small batch (one tile)
         for tag, gt in (('dense 4x40', dense_static_graph(4, 40)), ('ragged batch', make_graph(B=40, frames=7, mean=7, seed=3)),
