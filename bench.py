@@ -192,6 +192,71 @@ def stage_profile(model, plan, H):
     return t, flops, nbytes
 
 
+def att_bytes(E, Dn, H, K, train):
+    """Algorithmic bytes of the attention stage per launch sequence (every array counted once; the det tables once).
+    SURVEY 8(d): per head a 4 E score, 8 E of alpha per incidence; this implementation reads h[e] ONCE for all heads.
+    forward  = GEMM (h dets in, ha out) + score (ha table, 3 ids, score out) + det pass (h edge rows, score, CSR + order,
+               keep, alpha out, es + per-head es + stats out);
+    backward = det pass (h edge rows, CSR + order + det rows, score, keep, d_es / es_k / stats, record out) + edge pass
+               (record, score, 5 ids, d_es and ha tables, d_h edge rows read + written, dpre out) + det pass (CSR, other
+               endpoints, dpre, ha table, d_ha out) + two GEMMs (d_ha twice, h dets, d_h dets read + written)."""
+    kb = 2.0 * K if train else 0.0
+    fwd = E * (4.0 * H + 16.0 * K + 20.0 + kb) + Dn * (8.0 * H + 12.0 * K * H + 8.0 * K + 8.0)
+    bwd = E * (12.0 * H + 32.0 * K + 60.0 + kb) + Dn * (20.0 * H + 24.0 * K * H + 8.0 * K + 12.0)
+    return fwd, bwd
+
+
+def att_stage_profile(g, H, K, train, iters=5):
+    """HIP-event timing of tmpnn_att_fwd / tmpnn_att_bwd (and the plain segment sum + its adjoint, which they replace)
+    on graph `g`: ({stage: ms}, {stage: algorithmic bytes})."""
+    from trackmpnn_amd import _lib
+    dev = g.device
+    N, E, Dn = g.N, g.E, g.Dn
+    st = torch.cuda.current_stream().cuda_stream
+    gen = torch.Generator(device=dev).manual_seed(3)
+    h = torch.randn(N, H, device=dev, generator=gen)
+    W = 0.3 * torch.randn(H, K * H, device=dev, generator=gen)
+    av = 0.3 * torch.randn(K, H, device=dev, generator=gen)
+    ha = torch.empty(Dn, K * H, device=dev)
+    score = torch.empty(2 * E, K, device=dev)
+    stats = torch.empty(Dn, K, 2, device=dev)
+    esk = torch.empty(K, Dn, H, device=dev)
+    alpha = torch.empty(K, 2 * E, device=dev)
+    es = torch.empty(Dn, H, device=dev)
+    keep = torch.empty(K, 2 * E, dtype=torch.uint8, device=dev).bernoulli_(0.5) if train else None
+    d_out = torch.randn(N, H, device=dev, generator=gen)
+    d_h = torch.zeros(N, H, device=dev)
+    dW = torch.zeros(K, H, H, device=dev)
+    da = torch.zeros(K, H, device=dev)
+    wsn = _lib.load().tmpnn_att_bwd_ws(E, Dn, H, K)
+    ws = torch.empty(wsn + 4, device=dev)
+    erec, inc_other = g.att_index()
+
+    def att_fwd():
+        _lib.call('tmpnn_att_fwd', g.cref(), erec.data_ptr(), h.data_ptr(), H, H, K, W.data_ptr(),
+                  av.data_ptr(), _lib.ptr(keep), 0.5, ha.data_ptr(), score.data_ptr(), stats.data_ptr(), esk.data_ptr(),
+                  alpha.data_ptr(), es.data_ptr(), H, st)
+
+    def att_bwd():
+        _lib.call('tmpnn_att_bwd', g.cref(), erec.data_ptr(), inc_other.data_ptr(), h.data_ptr(), H,
+                  H, K, W.data_ptr(), av.data_ptr(), _lib.ptr(keep), 0.5, ha.data_ptr(), score.data_ptr(), stats.data_ptr(),
+                  esk.data_ptr(), d_out.data_ptr(), H, ws.data_ptr(), wsn, d_h.data_ptr(), H, dW.data_ptr(), da.data_ptr(), st)
+
+    def segsum():
+        _lib.call('tmpnn_segsum_fwd', g.cref(), h.data_ptr(), H, es.data_ptr(), H, H, 0, 1, st)
+
+    def gather():
+        _lib.call('tmpnn_gather_diff_fwd', g.cref(), d_out.data_ptr(), H, d_h.data_ptr(), H, H, 1, st)
+
+    t = {name: time_stage(fn, iters) for name, fn in (('att_fwd', att_fwd), ('att_bwd', att_bwd), ('segsum', segsum),
+                                                       ('segsum_adjoint', gather))}
+    bf, bb = att_bytes(E, Dn, H, K, train)
+    nbytes = {'att_fwd': bf, 'att_bwd': bb,
+              'segsum': 4.0 * H * E + 4.0 * H * Dn + 4.0 * (2 * E + Dn + 1) + 2.0 * E,
+              'segsum_adjoint': 8.0 * H * E + 4.0 * H * Dn + 12.0 * E}
+    return t, nbytes
+
+
 def split_enabled():
     """The library default: GRU GEMMs on the bf16 matrix pipe as fp32-accurate 3 x 3 split products (bf16x6,
     csrc/gru.hip); TMPNN_SPLIT=0 keeps them on the f32-input MFMA."""

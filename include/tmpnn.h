@@ -115,36 +115,45 @@ int tmpnn_segsum_bwd(const tmpnn_graph* g, const float* d_out, int ld_dout, floa
                      int H, int accumulate, tmpnn_stream stream);
 
 /* ---- row G: attention-weighted aggregation (models/layers.py:26-43, 105-112) -------------
- * K heads (1..8); W_att [K][H][H] (in x out, as stored by the reference), a [K][H].
- *   ha    = h[det rows] @ W_k                       (ws_ha [K][Dn][H])
- *   s_e   = LeakyReLU_0.2(|ha[src]-ha[dst]| . a_k)  (score [K][N], written at edge rows)
- *   alpha = softmax over each det's incident edges  (alpha [K][2E], CSR order, AFTER dropout)
+ * K heads (1..8), all served by the same passes.  W_cat [H][K*H]: head k's W_att ([H][H], in x out, as the reference
+ * stores it) in columns k*H .. (k+1)*H; a [K][H].
+ *   ha    = h[det rows] @ W_cat                       (ha [Dn][K*H]: the heads of a det side by side)
+ *   s_e   = LeakyReLU_0.2(|ha_k[src]-ha_k[dst]| . a_k)  (score [2E][K] per CSR POSITION: an edge's score is stored at both
+ *                                                      of its positions, so a det reads its run's scores contiguously)
+ *   alpha = softmax over each det's incident edges    (alpha [K][2E], CSR order, AFTER dropout)
  *   out[d, 0:H] = 1/K sum_k sum_p sign_p * alpha_kp * h[inc row p]     (COMPACT rows: d, not det_row[d])
+ * Also saved for the backward: stats [Dn][K][2] = the softmax's (max, sum exp) per det and head, and esk [K][Dn][H] = the
+ * per-head aggregate 1/K sum_p sign_p alpha_kp h[row p] (out = sum_k esk[k]).
  * keep: NULL (eval / no dropout) or uint8 [K][2E] in CSR order (kept entries scaled 1/(1-p_drop)).
- * pos [N]: row -> index of the row within its type (det index for det rows, edge index e for
- * edge rows). */
-int tmpnn_att_fwd(const tmpnn_graph* g, const int32_t* pos, const float* h, int ld_h, int H, int K,
-                  const float* W_att, const float* a, const uint8_t* keep, float p_drop,
-                  float* ws_ha, float* score, float* alpha, float* out, int ld_out, tmpnn_stream stream);
+ * erec [E][8]: everything an edge-owned pass needs to know about edge e, as one 32-byte record: the DET INDICES of its
+ *   src / dst endpoint, its CSR positions in the src det's and in the dst det's run (the inverse of inc) | the graph rows
+ *   of src, dst and of the edge itself, 0.
+ * One read of h[inc row p] per CSR position serves every head; launches: 1 GEMM + 2 kernels. */
+int tmpnn_att_fwd(const tmpnn_graph* g, const int32_t* erec, const float* h, int ld_h, int H, int K,
+                  const float* W_cat, const float* a, const uint8_t* keep, float p_drop,
+                  float* ha, float* score, float* stats, float* esk, float* alpha, float* out, int ld_out,
+                  tmpnn_stream stream);
 /* Backward of tmpnn_att_fwd.  d_out [N rows, ld_dout] is read at det rows (row-indexed).
- * Accumulates: d_h (+=, edge rows through the values, det rows through ha), dW_att [K][H][H] (+=),
- * da [K][H] (+=).  Workspaces (fp32): ws [tmpnn_att_bwd_ws(E, Dn, H, K) floats],
- * ws_dha [K][Dn][H], ws_edge [K][N]. */
+ * Accumulates: d_h (+=, edge rows through the values, det rows through ha), dW_att [K][H][H] (+=, one [H][H] block per
+ * head in the reference's layout), da [K][H] (+=).  ws: tmpnn_att_bwd_ws(E, Dn, H, K) floats, 16-byte aligned.
+ * inc_other [2E]: det index of the OTHER endpoint of every CSR position (the src det's positions hold dst_pos[e] and vice
+ * versa), bit 31 set on dst-side positions.  One edge-owned pass (reads h[row e] once, updates d_h[row e]) + one det-owned
+ * pass over the projected det table + two Dn-row GEMMs. */
 size_t tmpnn_att_bwd_ws(int E, int Dn, int H, int K);
-int tmpnn_att_bwd(const tmpnn_graph* g, const int32_t* pos, const float* h, int ld_h, int H, int K,
-                  const float* W_att, const float* a, const uint8_t* keep, float p_drop,
-                  const float* ws_ha, const float* score, const float* alpha,
-                  const float* d_out, int ld_dout,
-                  float* ws, size_t ws_floats, float* ws_dha, float* ws_edge,
+int tmpnn_att_bwd(const tmpnn_graph* g, const int32_t* erec, const int32_t* inc_other,
+                  const float* h, int ld_h, int H, int K,
+                  const float* W_cat, const float* a, const uint8_t* keep, float p_drop,
+                  const float* ha, const float* score, const float* stats, const float* esk,
+                  const float* d_out, int ld_dout, float* ws, size_t ws_floats,
                   float* d_h, int ld_dh, float* dW_att, float* da, tmpnn_stream stream);
 /* The same with one output pointer per head (host arrays of K device pointers: dW_heads[k] [H][H] (+=), da_heads[k] [H]
  * (+=)) -- the heads' parameters are separate tensors (models/layers.py:7-24, 67: a ModuleList of GraphAttentionLayer, one per head), so their
  * .grad buffers can be accumulated in place without a stacked temporary. */
-int tmpnn_att_bwd_heads(const tmpnn_graph* g, const int32_t* pos, const float* h, int ld_h, int H, int K,
-                        const float* W_att, const float* a, const uint8_t* keep, float p_drop,
-                        const float* ws_ha, const float* score, const float* alpha,
-                        const float* d_out, int ld_dout,
-                        float* ws, size_t ws_floats, float* ws_dha, float* ws_edge,
+int tmpnn_att_bwd_heads(const tmpnn_graph* g, const int32_t* erec, const int32_t* inc_other,
+                        const float* h, int ld_h, int H, int K,
+                        const float* W_cat, const float* a, const uint8_t* keep, float p_drop,
+                        const float* ha, const float* score, const float* stats, const float* esk,
+                        const float* d_out, int ld_dout, float* ws, size_t ws_floats,
                         float* d_h, int ld_dh, float* const* dW_heads, float* const* da_heads, tmpnn_stream stream);
 
 /* ---- rows H', I: GRU cells with row indirection + type-masked merge ----------------------

@@ -78,14 +78,14 @@ _SIGNATURES = {
     'tmpnn_segsum_fwd': (c_int, [_GP, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     'tmpnn_segsum_bwd': (c_int, [_GP, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p]),
     'tmpnn_att_fwd': (c_int, [_GP, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_float,
-                              c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+                              c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     'tmpnn_att_bwd_ws': (c_size_t, [c_int, c_int, c_int, c_int]),
-    'tmpnn_att_bwd': (c_int, [_GP, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_float,
-                              c_void_p, c_void_p, c_void_p, c_void_p, c_int,
-                              c_void_p, c_size_t, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
-    'tmpnn_att_bwd_heads': (c_int, [_GP, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_float,
-                                    c_void_p, c_void_p, c_void_p, c_void_p, c_int,
-                                    c_void_p, c_size_t, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
+    'tmpnn_att_bwd': (c_int, [_GP, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
+                              c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_size_t,
+                              c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
+    'tmpnn_att_bwd_heads': (c_int, [_GP, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p,
+                                    c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
+                                    c_size_t, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     'tmpnn_gru_fwd': (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                               c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                               c_void_p, c_int, c_void_p, c_size_t, c_void_p, c_void_p, c_size_t, c_void_p]),

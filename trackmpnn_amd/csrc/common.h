@@ -70,6 +70,17 @@ int launch_gemm(const GemmArgs& g, hipStream_t st);
 // split-K variant for K >> M,N (weight gradients): partial products go to `ws`, then reduced into C (+=).
 size_t gemm_splitk_ws_floats(int M, int N, int K);
 int launch_gemm_splitk(const GemmArgs& g, float* ws, size_t ws_floats, hipStream_t st);
+// MFMA row products of the small dense stages (csrc/gru.hip, bf16x6 = fp32-accurate, see there):
+//   out[orow(r)][0:NOUT] (=|+=) in[irow(r)][0:KD] @ W,  W[k][n] = wt[k ld_wt + n] or (wt_trans) wt[n ld_wt + k];
+//   KD in {32, 64}; NOUT / 32 in {2, 4, 6} (KD 64) or {1, 2, 3} (KD 32); rows / out_rows: optional row lists (NULL = r).
+bool rows_gemm_supported(int KD, int NOUT);
+int launch_rows_gemm(const int32_t* rows, int R, const float* in, int ld_in, int KD, const float* wt, int ld_wt, int wt_trans,
+                     int NOUT, float* out, int ld_out, const int32_t* out_rows, int accumulate, hipStream_t st);
+// C[i][n] (+)= sum_r X[xrow(r)][i] * Y[r][n]  (i < M <= 256, n < N; contraction over R rows; f32 MFMA, operands straight from
+// global memory: both are row-contiguous for this orientation).  Per-slab partial tiles in `ws`, ordered reduction.
+size_t rows_outer_ws_floats(int M, int N, int R);
+int launch_rows_outer(const float* X, int ldx, const int32_t* x_rows, const float* Y, int ldy, int R, int M, int N, float* C,
+                      int ldc, int accumulate, float* ws, size_t ws_floats, hipStream_t st);
 // dst[j] (+)= sum_i src[i*ld + j] * (mul ? mul[i*ldm + j] : 1)     (two level, deterministic)
 size_t colsum_ws_floats(int rows, int cols);
 int launch_colsum(const float* src, long ld, const float* mul, long ldm, int rows, int cols, float* dst,

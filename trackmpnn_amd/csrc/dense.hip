@@ -179,6 +179,105 @@ int launch_gemm_splitk(const GemmArgs& g, float* ws, size_t ws_floats, hipStream
 }
 
 // ------------------------------------------------------------------------------------------
+// rows-contracting product on the matrix pipe:  C[i][n] (+)= sum_r X[xrow(r)][i] * Y[r][n]      (weight gradients of the
+// attention projections: X = h[det rows], Y = d_ha).  v_mfma_f32_32x32x2_f32 takes A[m][k] from lane (m = l % 32,
+// k = l / 32) and B[k][n] from lane (n = l % 32, k = l / 32): with k = two consecutive ROWS r both operands are 32
+// consecutive floats of one row per half wave -- coalesced straight from global memory, no transpose, no LDS.  A wave owns
+// a (32 MT) x (32 NT) output tile over a slab of rows (exact fp32 products and accumulation); slabs are combined in a fixed
+// order by launch_reduce_slabs.
+// ------------------------------------------------------------------------------------------
+typedef float f32x16_d __attribute__((ext_vector_type(16)));
+template <int MT, int NT>
+__global__ __launch_bounds__(256) void k_rows_outer(const float* __restrict__ X, int ldx, const int32_t* __restrict__ x_rows,
+                                                    const float* __restrict__ Y, int ldy, int R, int rows_per_slab,
+                                                    int M, int N, float* __restrict__ slabs) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int c = lane & 31, half = lane >> 5;
+    const int slab = blockIdx.x * 4 + wv;
+    const int i0 = blockIdx.y * (32 * MT), n0 = blockIdx.z * (32 * NT);
+    const int r_lo = slab * rows_per_slab, r_hi = min(R, r_lo + rows_per_slab);
+    f32x16_d acc[MT][NT];
+#pragma unroll
+    for (int a = 0; a < MT; ++a)
+#pragma unroll
+        for (int b = 0; b < NT; ++b)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
+    constexpr int UN = 8;                                  // row pairs in flight
+    for (int r = r_lo; r < r_hi; r += 2 * UN) {
+        float av[UN][MT], bv[UN][NT];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const int rr = r + 2 * u + half;
+            const bool ok = rr < r_hi;
+            const int rc = ok ? rr : r_lo;
+            const long xr = x_rows ? x_rows[rc] : rc;
+#pragma unroll
+            for (int a = 0; a < MT; ++a) { const float t = X[xr * ldx + i0 + 32 * a + c]; av[u][a] = ok ? t : 0.f; }
+#pragma unroll
+            for (int b = 0; b < NT; ++b) { const float t = Y[(size_t)rc * ldy + n0 + 32 * b + c]; bv[u][b] = ok ? t : 0.f; }
+        }
+#pragma unroll
+        for (int u = 0; u < UN; ++u)
+#pragma unroll
+            for (int a = 0; a < MT; ++a)
+#pragma unroll
+                for (int b = 0; b < NT; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u][a], bv[u][b], acc[a][b], 0, 0, 0);
+    }
+    // accumulator register i of lane (c, half): row 8 (i / 4) + 4 half + (i % 4), column c of the 32 x 32 tile
+    float* o = slabs + (size_t)slab * M * N;
+#pragma unroll
+    for (int a = 0; a < MT; ++a)
+#pragma unroll
+        for (int b = 0; b < NT; ++b)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int row = i0 + 32 * a + 8 * (i >> 2) + 4 * half + (i & 3);
+                o[(size_t)row * N + n0 + 32 * b + c] = acc[a][b][i];
+            }
+}
+
+static int rows_outer_plan(int R, int* per) {
+    int ns = (R + 255) / 256;                 // >= 256 rows per slab
+    if (ns > 1024) ns = 1024;
+    if (ns < 1) ns = 1;
+    ns = (ns + 3) & ~3;                        // four slabs (waves) per block
+    int p = (R + ns - 1) / ns;
+    p = (p + 1) & ~1;                          // row pairs
+    if (p < 2) p = 2;
+    *per = p;
+    return ns;
+}
+
+size_t rows_outer_ws_floats(int M, int N, int R) {
+    int per;
+    const int ns = rows_outer_plan(R > 0 ? R : 1, &per);
+    return (size_t)ns * M * N + reduce_slabs_ws_floats(ns, (size_t)M * N);
+}
+
+int launch_rows_outer(const float* X, int ldx, const int32_t* x_rows, const float* Y, int ldy, int R, int M, int N, float* C,
+                      int ldc, int accumulate, float* ws, size_t ws_floats, hipStream_t st) {
+    if (M <= 0 || N <= 0) return TMPNN_OK;
+    TM_REQUIRE(M % 32 == 0 && N % 32 == 0 && ldc == N, "rows_outer: M=%d N=%d must be multiples of 32, C dense", M, N);
+    if (ws_floats < rows_outer_ws_floats(M, N, R)) return set_error(TMPNN_EWORKSPACE, "rows_outer: workspace too small");
+    int per;
+    const int ns = rows_outer_plan(R > 0 ? R : 1, &per);
+    // small tiles: the slab memory (ns x M x N) does not depend on the tiling, and (M / 32) x (N / 64) times as many waves keep
+    // more row requests in flight (a 64 x 128 tile per wave left one wave per SIMD: 0.32 ms per 734 k rows, latency-bound)
+    const int mt = 1;
+    const int nt = (N % 64 == 0) ? 2 : 1;
+    dim3 grid(ns / 4, M / (32 * mt), N / (32 * nt)), block(256);
+#define RO(A_, B_) hipLaunchKernelGGL((k_rows_outer<A_, B_>), grid, block, 0, st, X, ldx, x_rows, Y, ldy, R, per, M, N, ws)
+    if (mt == 2) { if (nt == 4) RO(2, 4); else if (nt == 2) RO(2, 2); else RO(2, 1); }
+    else         { if (nt == 4) RO(1, 4); else if (nt == 2) RO(1, 2); else RO(1, 1); }
+#undef RO
+    int rc = check_launch("rows_outer");
+    if (rc) return rc;
+    return launch_reduce_slabs(ws, (size_t)M * N, ns, C, (size_t)M * N, accumulate, st, ws + (size_t)ns * M * N);
+}
+
+// ------------------------------------------------------------------------------------------
 // column sums
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_colsum_partial(const float* __restrict__ src, long ld,

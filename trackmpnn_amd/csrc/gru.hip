@@ -502,7 +502,7 @@ __global__ __launch_bounds__(256) void k_gru_bwd_weights(GruBwdWArgs a) {
 // so that lane l of pass k holds 16 bytes of row (64k + l)/8 -- eight lanes cover one 128-byte row segment.
 // The staging row stride of 36 floats keeps both the writes and the reads bank-conflict free.
 constexpr int STG_LD = 36;
-template <bool NT = false>
+template <bool NT = false, bool ACC = false>
 __device__ __forceinline__ void stage_store32(float* stg, int c, int half, int lane, const f32x16& v,
                                               float* dst, int ld, int col0, int row, int r0, int R) {
 #pragma unroll
@@ -526,6 +526,9 @@ __device__ __forceinline__ void stage_store32(float* stg, int c, int half, int l
             if (NT) {      // streamed once, read back only by the backward pass: keep it out of the way of L2
                 __builtin_nontemporal_store(x.x, p); __builtin_nontemporal_store(x.y, p + 1);
                 __builtin_nontemporal_store(x.z, p + 2); __builtin_nontemporal_store(x.w, p + 3);
+            } else if (ACC) {
+                const float4 o = *reinterpret_cast<const float4*>(p);
+                *reinterpret_cast<float4*>(p) = make_float4(o.x + x.x, o.y + x.y, o.z + x.z, o.w + x.w);
             } else {
                 *reinterpret_cast<float4*>(p) = x;
             }
@@ -1716,25 +1719,40 @@ __global__ __launch_bounds__(512) void k_rows_gemm_lds(const int32_t* __restrict
 // bf16 with k contiguous (rows padded by 16 bytes: conflict-free ds_read_b128), a lane's 8 operand values per
 // MFMA are 8 consecutive k of its row.  k is enumerated as k = (H/2)*(lane>>5) + 8*kb + j, so a lane reads H/2
 // CONTIGUOUS floats of its row.
+// General form (round 4: also the attention projections): out[orow(r)][0:NOUT] (=|+=) in[irow(r)][0:H] @ W, with
+//   W[k][n] = wt[k * ld_wt + n]  (wt_trans = 0)  or  wt[n * ld_wt + k]  (wt_trans = 1: a weight used transposed, no copy),
+//   irow(r) = rows ? rows[r] : r,  orow(r) = out_rows ? out_rows[r] : r.
 template <int H, int NT>
 __global__ __launch_bounds__(512) void k_rows_gemm_split(const int32_t* __restrict__ rows, int R,
                                                          const float* __restrict__ in, int ld_in,
-                                                         const float* __restrict__ wt, float* __restrict__ out,
-                                                         int ld_out, int ntiles) {
+                                                         const float* __restrict__ wt, int ld_wt, int wt_trans,
+                                                         float* __restrict__ out, int ld_out,
+                                                         const int32_t* __restrict__ out_rows, int accumulate, int ntiles) {
     extern __shared__ float lds[];
     constexpr int NOUT = NT * 32, KP = H + 8, NKB = H / 16;
     uint16_t* sW = reinterpret_cast<uint16_t*>(lds);          // [3][NOUT][KP]
-    for (int i = threadIdx.x; i < H * NOUT / 4; i += 512) {
-        const int k = i / (NOUT / 4), j0 = (i % (NOUT / 4)) * 4;
-        const float4 w = *reinterpret_cast<const float4*>(wt + (size_t)k * NOUT + j0);
-        const float wv[4] = {w.x, w.y, w.z, w.w};
+    if (!wt_trans) {
+        for (int i = threadIdx.x; i < H * NOUT / 4; i += 512) {
+            const int k = i / (NOUT / 4), j0 = (i % (NOUT / 4)) * 4;
+            const float4 w = *reinterpret_cast<const float4*>(wt + (size_t)k * ld_wt + j0);
+            const float wv[4] = {w.x, w.y, w.z, w.w};
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
+            for (int e = 0; e < 4; ++e) {
+                uint16_t q1, q2, q3;
+                split1(wv[e], q1, q2, q3);
+                sW[(0 * NOUT + j0 + e) * KP + k] = q1;
+                sW[(1 * NOUT + j0 + e) * KP + k] = q2;
+                sW[(2 * NOUT + j0 + e) * KP + k] = q3;
+            }
+        }
+    } else {
+        for (int i = threadIdx.x; i < H * NOUT; i += 512) {
+            const int n = i / H, k = i % H;
             uint16_t q1, q2, q3;
-            split1(wv[e], q1, q2, q3);
-            sW[(0 * NOUT + j0 + e) * KP + k] = q1;
-            sW[(1 * NOUT + j0 + e) * KP + k] = q2;
-            sW[(2 * NOUT + j0 + e) * KP + k] = q3;
+            split1(wt[(size_t)n * ld_wt + k], q1, q2, q3);
+            sW[(0 * NOUT + n) * KP + k] = q1;
+            sW[(1 * NOUT + n) * KP + k] = q2;
+            sW[(2 * NOUT + n) * KP + k] = q3;
         }
     }
     __syncthreads();
@@ -1745,7 +1763,8 @@ __global__ __launch_bounds__(512) void k_rows_gemm_split(const int32_t* __restri
         const int r0 = (tile * 8 + wave) * 32;
         if (r0 >= R) continue;
         const int li = min(r0 + c, R - 1);
-        const int row = rows[li];
+        const int row = rows ? rows[li] : li;
+        const int orow = out_rows ? out_rows[li] : li;
         const float4* xr = reinterpret_cast<const float4*>(in + (size_t)row * ld_in + (H / 2) * half);
         Split8 b[NKB];
 #pragma unroll
@@ -1766,9 +1785,12 @@ __global__ __launch_bounds__(512) void k_rows_gemm_split(const int32_t* __restri
                 acc[t] = mfma_x6(w1, w2, w3, b[kb], acc[t]);
             }
         }
+        if (accumulate) {
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            stage_store32(stg, c, half, lane, acc[t], out, ld_out, t * 32, li, r0, R);
+            for (int t = 0; t < NT; ++t) stage_store32<false, true>(stg, c, half, lane, acc[t], out, ld_out, t * 32, orow, r0, R);
+        } else {
+#pragma unroll
+            for (int t = 0; t < NT; ++t) stage_store32(stg, c, half, lane, acc[t], out, ld_out, t * 32, orow, r0, R);
         }
     }
 }
@@ -3638,6 +3660,33 @@ static bool split_enabled() {
     static const int on = [] { const char* e = getenv("TMPNN_SPLIT"); return (e && e[0] == '0') ? 0 : 1; }();
     return on != 0;
 }
+
+bool rows_gemm_supported(int KD, int NOUT) {
+    if (!split_enabled() || NOUT <= 0 || NOUT % 32) return false;
+    const int nt = NOUT / 32;
+    return (KD == 64 && (nt == 2 || nt == 4 || nt == 6)) || (KD == 32 && nt >= 1 && nt <= 3);
+}
+int launch_rows_gemm(const int32_t* rows, int R, const float* in, int ld_in, int KD, const float* wt, int ld_wt, int wt_trans,
+                     int NOUT, float* out, int ld_out, const int32_t* out_rows, int accumulate, hipStream_t st) {
+    if (R <= 0) return TMPNN_OK;
+    if (!rows_gemm_supported(KD, NOUT)) return set_error(TMPNN_EINVAL, "rows_gemm: unsupported shape KD=%d NOUT=%d", KD, NOUT);
+    TM_REQUIRE(in && wt && out && ld_in >= KD && (ld_in & 3) == 0 && aligned16(in) && (ld_out & 3) == 0 && aligned16(out) &&
+                   (wt_trans || ((ld_wt & 3) == 0 && aligned16(wt))), "rows_gemm: rows must be 16-byte aligned");
+    const int ntiles = ceil_div(R, 256);
+    dim3 grid(ntiles < 256 ? ntiles : 256), block(512);
+    const size_t shm2 = (size_t)3 * NOUT * (KD + 8) * 2 + sizeof(float) * 8 * 32 * STG_LD;
+#define RG(HH, NN)                                                                                                  \
+    do {                                                                                                            \
+        TM_SHM_ONCE((k_rows_gemm_split<HH, NN>), shm2);                                                             \
+        hipLaunchKernelGGL((k_rows_gemm_split<HH, NN>), grid, block, shm2, st, rows, R, in, ld_in, wt, ld_wt, wt_trans, out, \
+                           ld_out, out_rows, accumulate, ntiles);                                                   \
+    } while (0)
+    const int nt = NOUT / 32;
+    if (KD == 64) { if (nt == 2) RG(64, 2); else if (nt == 4) RG(64, 4); else RG(64, 6); }
+    else          { if (nt == 1) RG(32, 1); else if (nt == 2) RG(32, 2); else RG(32, 3); }
+#undef RG
+    return check_launch("rows_gemm_split");
+}
 // H = 64 weight-gradient kernel: 1 = bf16x6 split products (default), 0 = f32-input MFMA.  A constant of the process,
 // read from the environment when the library is loaded (TMPNN_SPLIT_WEIGHTS=0/1; TMPNN_SPLIT=0 implies 0): every
 // rank and every run uses the same kernel, so gradients are bitwise reproducible across processes.
@@ -3810,17 +3859,7 @@ int tmpnn_rows_linear(const int32_t* rows, int R, const float* in, int ld_in, in
     const int ntiles = ceil_div(R, 256);
     dim3 grid(ntiles < 256 ? ntiles : 256), block(512);
     hipStream_t st = as_stream(stream);
-    if (split_enabled()) {
-        const size_t shm2 = (size_t)3 * NOUT * (H + 8) * 2 + sizeof(float) * 8 * 32 * STG_LD;
-        if (H == 64) {
-            TM_SHM_ONCE((k_rows_gemm_split<64, 6>), shm2);
-            hipLaunchKernelGGL((k_rows_gemm_split<64, 6>), grid, block, shm2, st, rows, R, in, ld_in, wt, out, ld_out, ntiles);
-        } else {
-            TM_SHM_ONCE((k_rows_gemm_split<32, 3>), shm2);
-            hipLaunchKernelGGL((k_rows_gemm_split<32, 3>), grid, block, shm2, st, rows, R, in, ld_in, wt, out, ld_out, ntiles);
-        }
-        return check_launch("rows_linear_split");
-    }
+    if (split_enabled()) return launch_rows_gemm(rows, R, in, ld_in, H, wt, NOUT, 0, NOUT, out, ld_out, nullptr, 0, st);
     const size_t shm = sizeof(float) * ((size_t)H * NOUT + 8 * 32 * STG_LD);
     if (H == 64) {
         TM_SHM_ONCE((k_rows_gemm_lds<64, 6>), shm);

@@ -384,12 +384,15 @@ def mp_forward(spec: ModelSpec, plan: CallPlan, x: torch.Tensor, h_in: Optional[
         else:
             Ws = [P[f + f'gat.{k}.W_att'] for k in range(K)]
             As = [P[f + f'gat.{k}.a'] for k in range(K)]
-            # (the heads' weights stacked for the kernels: one copy per call, or per weight_cache() context)
-            W = _cached(('attW', tuple(t.data_ptr() for t in Ws)), tuple(Ws), lambda: torch.stack(Ws).contiguous())
+            # (the heads' weights side by side for the kernels: one copy per call, or per weight_cache() context)
+            W = _cached(('attW', tuple(t.data_ptr() for t in Ws)), tuple(Ws), lambda: torch.cat(Ws, 1).contiguous())
             a = _cached(('atta', tuple(t.data_ptr() for t in As)), tuple(As),
                         lambda: torch.stack([t.reshape(-1) for t in As]).contiguous())
-            ws_ha = torch.empty((K, max(Dn, 1), H), **opts)
-            score = torch.empty((K, max(N, 1)), **opts)      # (k_att_score writes every edge row's entry; no other is read)
+            ws_ha = torch.empty((max(Dn, 1), K * H), **opts)
+            score = torch.empty((max(2 * E, 1), K), **opts)  # (k_att_score writes both CSR positions of every edge)
+            erec, inc_other = g.att_index() if E > 0 else (None, None)
+            stats = torch.empty((max(Dn, 1), K, 2), **opts)
+            esk = torch.empty((K, max(Dn, 1), H), **opts)
             alpha = torch.empty((K, max(2 * E, 1)), **opts)
             kp = None
             if training:
@@ -397,11 +400,11 @@ def mp_forward(spec: ModelSpec, plan: CallPlan, x: torch.Tensor, h_in: Optional[
                     kp = torch.empty((K, max(2 * E, 1)), dtype=torch.uint8, device=dev).bernoulli_(1.0 - ATT_DROPOUT_P)
                 else:
                     kp = keep[gi].to(torch.uint8).contiguous()
-            _lib.call('tmpnn_att_fwd', g.cref(), g.pos.data_ptr(), hg, GH, H, K, W.data_ptr(), a.data_ptr(),
-                      _lib.ptr(kp), ATT_DROPOUT_P, ws_ha.data_ptr(), score.data_ptr(), alpha.data_ptr(),
-                      es.data_ptr(), H, st)
+            _lib.call('tmpnn_att_fwd', g.cref(), _lib.ptr(erec), hg, GH, H, K, W.data_ptr(),
+                      a.data_ptr(), _lib.ptr(kp), ATT_DROPOUT_P, ws_ha.data_ptr(), score.data_ptr(), stats.data_ptr(),
+                      esk.data_ptr(), alpha.data_ptr(), es.data_ptr(), H, st)
             alphas.append([alpha[k, :2 * E] for k in range(K)])
-            att_saved.append((W, a, kp, ws_ha, score, alpha))
+            att_saved.append((W, a, kp, ws_ha, score, stats, esk))
         # node update: GRU(es, h[d])                            (layers.py:114)
         _lib.call('tmpnn_gru_fwd', g.det_row.data_ptr(), Dn, 0, None, None,
                   es.data_ptr(), H, 1, H, hg, GH, H,
@@ -596,28 +599,24 @@ def mp_backward(spec: ModelSpec, plan: CallPlan, saved: dict, P: Dict[str, torch
                           grads[f + 'edge_gru.bias_ih'].data_ptr(), grads[f + 'edge_gru.bias_hh'].data_ptr(),
                           ws_w.data_ptr(), ws_w.numel() * 4, st)
         if K > 0:
-            W, a, kp, ws_ha, score, alpha = saved['att'][gi]
+            W, a, kp, ws_ha, score, stats, esk = saved['att'][gi]
             ws_n_att = lib.tmpnn_att_bwd_ws(E, Dn, H, K)
             ws_att = torch.empty((max(ws_n_att, 1),), **opts)
-            ws_dha = torch.empty((K, max(Dn, 1), H), **opts)
-            ws_edge = torch.empty((K, max(N, 1)), **opts)    # (every edge row's entry is assigned by the src-side pass)
+            erec, inc_other = g.att_index() if E > 0 else (None, None)
             gW = [grads.get(f + f'gat.{k}.W_att') for k in range(K)] if grad_out is not None else []
             ga = [grads.get(f + f'gat.{k}.a') for k in range(K)] if grad_out is not None else []
+            args = (g.cref(), _lib.ptr(erec), _lib.ptr(inc_other), hg, GH, H, K, W.data_ptr(),
+                    a.data_ptr(), _lib.ptr(kp), ATT_DROPOUT_P, ws_ha.data_ptr(), score.data_ptr(), stats.data_ptr(),
+                    esk.data_ptr(), dmsg.data_ptr(), IN_e, ws_att.data_ptr(), ws_att.numel(), dhg, GH)
             if grad_out is not None and all(t is not None and t.is_contiguous() for t in gW + ga):
                 # in-place mode: the heads' gradient buffers are accumulated directly (no stacked temporary, no adds)
                 pW = (ctypes.c_void_p * K)(*[t.data_ptr() for t in gW])
                 pa = (ctypes.c_void_p * K)(*[t.data_ptr() for t in ga])
-                _lib.call('tmpnn_att_bwd_heads', g.cref(), g.pos.data_ptr(), hg, GH, H, K, W.data_ptr(), a.data_ptr(),
-                          _lib.ptr(kp), ATT_DROPOUT_P, ws_ha.data_ptr(), score.data_ptr(), alpha.data_ptr(),
-                          dmsg.data_ptr(), IN_e, ws_att.data_ptr(), ws_att.numel(), ws_dha.data_ptr(), ws_edge.data_ptr(),
-                          dhg, GH, ctypes.cast(pW, ctypes.c_void_p), ctypes.cast(pa, ctypes.c_void_p), st)
+                _lib.call('tmpnn_att_bwd_heads', *args, ctypes.cast(pW, ctypes.c_void_p), ctypes.cast(pa, ctypes.c_void_p), st)
             else:
-                dW = torch.zeros_like(W)
+                dW = torch.zeros((K, H, H), **opts)
                 da = torch.zeros_like(a)
-                _lib.call('tmpnn_att_bwd', g.cref(), g.pos.data_ptr(), hg, GH, H, K, W.data_ptr(), a.data_ptr(),
-                          _lib.ptr(kp), ATT_DROPOUT_P, ws_ha.data_ptr(), score.data_ptr(), alpha.data_ptr(),
-                          dmsg.data_ptr(), IN_e, ws_att.data_ptr(), ws_att.numel(), ws_dha.data_ptr(), ws_edge.data_ptr(),
-                          dhg, GH, dW.data_ptr(), da.data_ptr(), st)
+                _lib.call('tmpnn_att_bwd', *args, dW.data_ptr(), da.data_ptr(), st)
                 for k in range(K):
                     if grad_out is not None:
                         grads[f + f'gat.{k}.W_att'].add_(dW[k])

@@ -68,6 +68,32 @@ class FrameGraph:
     def cref(self):
         return C.byref(self.cstruct())
 
+    def att_index(self) -> Tuple[torch.Tensor, torch.Tensor]:
+        """(erec int32 [E][8], inc_other int32 [2E]) for the attention kernels (tmpnn_att_fwd / _bwd).  erec[e] = (src det
+        index, dst det index, CSR position of e in the src det's run, ... in the dst det's run | src row, dst row, edge row,
+        0): everything an edge-owned pass needs as one 32-byte record; inc_other[p] = det INDEX of the OTHER endpoint of CSR
+        position p (a src det's positions hold dst_pos[e] and vice versa) with bit 31 set on dst-side positions.
+        Index plumbing (torch ops on the device, no host round trip), built on first use and cached on the graph."""
+        t = self.__dict__.get('_att_index')
+        if t is None:
+            if self.src_pos is None or self.dst_pos is None:
+                raise ValueError('att_index: the graph carries no src_pos / dst_pos')
+            e = self.pos.long()[(self.inc & 0x7FFFFFFF).long()]
+            neg = self.inc < 0
+            other = torch.where(neg, self.src_pos[e] | torch.tensor(-2 ** 31, dtype=torch.int32, device=self.device),
+                                self.dst_pos[e]).to(torch.int32).contiguous()
+            erec = torch.zeros((max(self.E, 1), 8), dtype=torch.int32, device=self.device)
+            if self.E > 0:
+                erec[:, 0] = self.src_pos
+                erec[:, 1] = self.dst_pos
+                erec[e, 2 + neg.long()] = torch.arange(2 * self.E, dtype=torch.int32, device=self.device)
+                erec[:, 4] = self.src
+                erec[:, 5] = self.dst
+                erec[:, 6] = self.edge_row
+            t = (erec, other)
+            self.__dict__['_att_index'] = t
+        return t
+
     def inc_edge_endpoint(self) -> Tuple[torch.Tensor, torch.Tensor]:
         """For every CSR position: (edge index e, endpoint 0 = src side / 1 = dst side)."""
         row = (self.inc & 0x7FFFFFFF).long()
