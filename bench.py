@@ -193,16 +193,18 @@ def stage_profile(model, plan, H):
 
 
 def att_bytes(E, Dn, H, K, train):
-    """Algorithmic bytes of the attention stage per launch sequence (every array counted once; the det tables once).
-    SURVEY 8(d): per head a 4 E score, 8 E of alpha per incidence; this implementation reads h[e] ONCE for all heads.
-    forward  = GEMM (h dets in, ha out) + score (ha table, 3 ids, score out) + det pass (h edge rows, score, CSR + order,
-               keep, alpha out, es + per-head es + stats out);
-    backward = det pass (h edge rows, CSR + order + det rows, score, keep, d_es / es_k / stats, record out) + edge pass
-               (record, score, 5 ids, d_es and ha tables, d_h edge rows read + written, dpre out) + det pass (CSR, other
-               endpoints, dpre, ha table, d_ha out) + two GEMMs (d_ha twice, h dets, d_h dets read + written)."""
-    kb = 2.0 * K if train else 0.0
-    fwd = E * (4.0 * H + 16.0 * K + 20.0 + kb) + Dn * (8.0 * H + 12.0 * K * H + 8.0 * K + 8.0)
-    bwd = E * (12.0 * H + 32.0 * K + 60.0 + kb) + Dn * (20.0 * H + 24.0 * K * H + 8.0 * K + 12.0)
+    """Algorithmic bytes of the attention stage per call (every array counted once; the det tables once).
+    SURVEY 8(d) budgets, per head, a 4 E score, 8 E of alpha per incidence and ANOTHER 4 H E read of h[e]; this implementation
+    reads h[e] once for all heads in the forward and once in the backward.
+    forward  = row GEMM (h dets in, ha out) + score (ha table, 16-byte edge record, score out at both positions) + det pass
+               (h edge rows, score, incidences, rowptr + order, keep byte, alpha out, es + per-head es + statistics out);
+    backward = det records (d_es, es_k, statistics in, 16 K out) + edge pass (32-byte edge record, h[e], d_h[e] read +
+               written, d_es / ha / record tables, score at one position, two keep bytes, dpre out at both positions) +
+               det pass (other endpoints, dpre, ha table, rowptr + order, d_ha out) + three row products (d_ha twice,
+               h dets, d_h dets read + written)."""
+    kb = 2.0 if train else 0.0
+    fwd = E * (4.0 * H + 24.0 * K + 24.0 + kb) + Dn * (8.0 * H + 12.0 * K * H + 8.0 * K + 8.0)
+    bwd = E * (12.0 * H + 20.0 * K + 40.0 + kb) + Dn * (20.0 * H + 24.0 * K * H + 40.0 * K + 8.0)
     return fwd, bwd
 
 
@@ -223,7 +225,7 @@ def att_stage_profile(g, H, K, train, iters=5):
     esk = torch.empty(K, Dn, H, device=dev)
     alpha = torch.empty(K, 2 * E, device=dev)
     es = torch.empty(Dn, H, device=dev)
-    keep = torch.empty(K, 2 * E, dtype=torch.uint8, device=dev).bernoulli_(0.5) if train else None
+    keep = torch.empty(2 * E, dtype=torch.uint8, device=dev).random_(0, 1 << K) if train else None
     d_out = torch.randn(N, H, device=dev, generator=gen)
     d_h = torch.zeros(N, H, device=dev)
     dW = torch.zeros(K, H, H, device=dev)
@@ -687,6 +689,16 @@ def main():
             gather_GBs=nbytes['gather_diff'] / (t['gather_diff'] * 1e-3) / 1e9,
             segsum_GBs=nbytes['segsum'] / (t['segsum'] * 1e-3) / 1e9)
         extra['stage_ms'] = {k: round(v, 4) for k, v in t.items()}
+        # SURVEY 8(a) row G on the same graph (the bench model has no heads: the stage is timed through the C ABI with K = 2,
+        # train-mode dropout mask, as tools/att_bench.py): tmpnn_att_fwd / tmpnn_att_bwd against their byte model
+        try:
+            ta, nba = att_stage_profile(plans[-1].graph, H, 2, True)
+            for k in ('att_fwd', 'att_bwd'):
+                extra['stage_roofs'][k] = dict(ms=round(ta[k], 4), GBs=round(nba[k] / (ta[k] * 1e-3) / 1e9, 1),
+                                               hbm_frac=round(nba[k] / (ta[k] * 1e-3) / 1e9 / HBM_PEAK_GBS, 3),
+                                               f32_equiv_tflops=None, heads=2)
+        except RuntimeError as e:                                   # noqa: BLE001  (a reporting extra must not sink the line)
+            extra['stage_roofs']['att_error'] = str(e)[:200]
 
         # what ONE edge row costs per forward call + its share of the backward in the staged step (algorithmic bytes of
         # the kernels as the step runs them: edge forward, folded backward-data, backward-weights, row F and its

@@ -124,7 +124,8 @@ int tmpnn_segsum_bwd(const tmpnn_graph* g, const float* d_out, int ld_dout, floa
  *   out[d, 0:H] = 1/K sum_k sum_p sign_p * alpha_kp * h[inc row p]     (COMPACT rows: d, not det_row[d])
  * Also saved for the backward: stats [Dn][K][2] = the softmax's (max, sum exp) per det and head, and esk [K][Dn][H] = the
  * per-head aggregate 1/K sum_p sign_p alpha_kp h[row p] (out = sum_k esk[k]).
- * keep: NULL (eval / no dropout) or uint8 [K][2E] in CSR order (kept entries scaled 1/(1-p_drop)).
+ * keep: NULL (eval / no dropout) or uint8 [2E] in CSR order, bit k set = head k keeps the position (kept entries scaled
+ *   1/(1-p_drop)): one byte per position serves every head.
  * erec [E][8]: everything an edge-owned pass needs to know about edge e, as one 32-byte record: the DET INDICES of its
  *   src / dst endpoint, its CSR positions in the src det's and in the dst det's run (the inverse of inc) | the graph rows
  *   of src, dst and of the edge itself, 0.

@@ -427,8 +427,9 @@ def check_attention(H, K, training, g, gd):
     d = lambda t: t.detach().to(DEV).contiguous()
     e_of_p, ep = gd.inc_edge_endpoint()
     keepD = None
-    if keep is not None:
-        keepD = d(keep)[:, e_of_p, ep].contiguous()
+    if keep is not None:                   # [K, 2E] in CSR order -> one byte per position, bit k = head k keeps it
+        kk = d(keep)[:, e_of_p, ep]
+        keepD = sum(kk[k] << k for k in range(K)).to(torch.uint8).contiguous()
     W = d(torch.cat([p[f'gat.{k}.W_att'] for k in range(K)], 1))          # [H][K*H]: the heads side by side
     a = d(torch.stack([p[f'gat.{k}.a'].reshape(-1) for k in range(K)]))
     hD = d(hfull)

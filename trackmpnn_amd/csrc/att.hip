@@ -17,7 +17,6 @@
 //              (det-owned: d_ha[d] = a o sum_p dpre_p sgn(ha[d] - ha[other_p]) and the da partials) -> two Dn-row GEMMs.
 // Every reduction has a fixed order (no float atomics): results are bitwise reproducible.
 #include "common.h"
-#include <stdlib.h>
 
 namespace tmpnn {
 
@@ -60,7 +59,7 @@ struct AttArgs {
     const int32_t* inc_other;   // [2E] det index of the OTHER endpoint of each CSR position | bit 31 = dst side (backward)
     const float* h; int ld_h;
     const float* a;             // [K][H]
-    const uint8_t* keep;        // [K][2E] or null
+    const uint8_t* keep;        // [2E] bit k = head k keeps the position, or null
     float scale;                // 1/(1-p) when keep != null
     const float* ha;            // [Dn][K*H]
     float* score;               // [2E][K] per CSR POSITION (an edge's score sits at both of its positions)
@@ -90,15 +89,18 @@ __global__ __launch_bounds__(256) void k_att_score(AttArgs A) {
     const long chunk = (long)rpb * U;
     long e0 = (long)blockIdx.x * chunk + slot;
     const long step = (long)gridDim.x * chunk;
-    int4 id[U];                          // (src det, dst det, src position, dst position)
+    const int lane = threadIdx.x & 63, lg = threadIdx.x % lpr, gbase = lane - lg;
+    int4 idn[U];                         // (src det, dst det, src position, dst position), held by lane 0 of the group
     auto load_ids = [&](long base) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const long e = base + (long)u * rpb;
             const long ec = e < A.E ? e : (A.E - 1);
-            id[u] = *reinterpret_cast<const int4*>(A.erec + 8 * ec);
+            idn[u] = *reinterpret_cast<const int4*>(A.erec + 8 * ec);
         }
     };
+#pragma unroll
+    for (int u = 0; u < U; ++u) idn[u] = make_int4(0, 0, 0, 0);
     if (e0 < A.E) load_ids(e0);
     for (; e0 < A.E; e0 += step) {
         float4 x[U][KT], y[U][KT];
@@ -107,9 +109,10 @@ __global__ __launch_bounds__(256) void k_att_score(AttArgs A) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             ok[u] = e0 + (long)u * rpb < A.E;
-            pq[u] = make_int2(id[u].z, id[u].w);
-            const float* ps = A.ha + (size_t)id[u].x * KH + c4;
-            const float* pd = A.ha + (size_t)id[u].y * KH + c4;
+            const int sdet = __shfl(idn[u].x, gbase), ddet = __shfl(idn[u].y, gbase);
+            pq[u] = make_int2(__shfl(idn[u].z, gbase), __shfl(idn[u].w, gbase));
+            const float* ps = A.ha + (size_t)sdet * KH + c4;
+            const float* pd = A.ha + (size_t)ddet * KH + c4;
 #pragma unroll
             for (int k = 0; k < KT; ++k) { x[u][k] = ld4(ps + k * H); y[u][k] = ld4(pd + k * H); }
         }
@@ -125,7 +128,6 @@ __global__ __launch_bounds__(256) void k_att_score(AttArgs A) {
                 sc[k] = t > 0.f ? t : LEAKY * t;
             }
             // lane 0 of the group writes the src-side copy, lane 1 the dst-side copy
-            const int lg = threadIdx.x % lpr;
             if (ok[u] && lg < 2) {
                 float* o = A.score + (size_t)(lg == 0 ? pq[u].x : pq[u].y) * KT;
 #pragma unroll
@@ -195,17 +197,21 @@ __global__ __launch_bounds__(256) void k_att_fwd(AttArgs A, float* __restrict__ 
         moreB = moreA; dB = dA; p0B = p1B = 0;
         if (dB >= 0) { p0B = A.rowptr[dB]; p1B = A.rowptr[dB + 1]; }
     };
+    const uint8_t* kbase = A.keep ? A.keep : reinterpret_cast<const uint8_t*>(A.inc);     // (any readable 2E bytes when there is no mask)
     auto load_pos = [&](int p, int p1, int& v, unsigned& kb, float (&s)[KT]) {
+        // (clamped index + select instead of a conditional load: that is a branch, and hipcc drains the request queue at its join)
         const bool ok = p < p1;
-        v = ok ? A.inc[p] : NONE;
-        kb = 0;
-        if (A.keep) {
+        const int pc = ok ? p : 0;
+        const int vl = A.inc[pc];
+        const unsigned kl = kbase[pc];
+        const float* sp = A.score + (size_t)pc * KT;
+        float sl[KT];
 #pragma unroll
-            for (int k = 0; k < KT; ++k) kb |= (ok && A.keep[(size_t)k * E2 + p]) ? (1u << k) : 0u;
-        }
-        const float* sp = A.score + (size_t)(ok ? p : 0) * KT;
+        for (int k = 0; k < KT; ++k) sl[k] = sp[k];
+        v = ok ? vl : NONE;
+        kb = (ok && A.keep) ? kl : 0u;
 #pragma unroll
-        for (int k = 0; k < KT; ++k) s[k] = ok ? sp[k] : -INFINITY;
+        for (int k = 0; k < KT; ++k) s[k] = ok ? sl[k] : -INFINITY;
     };
     auto advanceC = [&]() {
         moreC = moreB; dC = dB; p0C = p0B; p1C = p1B;
@@ -270,7 +276,9 @@ __global__ __launch_bounds__(256) void k_att_fwd(AttArgs A, float* __restrict__ 
                 for (int u = 0; u < U; ++u) {
                     const int q = j * U + u;
                     const int vq = __shfl(vv, gbase + q);
-                    x[u] = q < Lc ? ld4(A.h + (size_t)(vq & 0x7fffffff) * A.ld_h + c4) : zero4();
+                    const bool okq = q < Lc;
+                    const float4 xl = ld4(A.h + (size_t)(okq ? (vq & 0x7fffffff) : 0) * A.ld_h + c4);
+                    x[u] = okq ? xl : zero4();
                 }
                 if (!advanced) { advance(); advanced = true; }      // the next round's index loads travel behind the rows
 #pragma unroll
@@ -353,51 +361,59 @@ __global__ __launch_bounds__(256) void k_att_bwd_edge(AttArgs A, const float* __
     const int H = A.H, KH = KT * H;
     const int lpr = H >> 2, slots = 256 / lpr;
     const int lg = threadIdx.x % lpr, c4 = lg * 4, slot = threadIdx.x / lpr;
-    const int lane = threadIdx.x & 63, gbase = lane - lg, side = lg & 1;
+    const int lane = threadIdx.x & 63, gbase = lane - lg;
     constexpr int U = KT <= 2 ? 2 : 1;
     const float invK = 1.0f / (float)KT;
-    const size_t E2 = (size_t)2 * A.E;
+    const uint8_t* kbase = A.keep ? A.keep : reinterpret_cast<const uint8_t*>(A.erec);
     const int e_lo = blockIdx.x * edges_per_block;
     const int e_hi = min(A.E, e_lo + edges_per_block);
     float4 dacc[KT];
 #pragma unroll
     for (int k = 0; k < KT; ++k) dacc[k] = zero4();
-    int4 ia[U], ib[U];                   // erec: (src det, dst det, src position, dst position) | (src row, dst row, edge row, -)
+    // erec of the next iteration's edges: even lanes of a group hold (src det, dst det, src position, dst position), odd lanes
+    // (src row, dst row, edge row, -): one 16-byte load per lane instead of two
+    int4 idn[U];
     auto load_ids = [&](int base) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int e = base + u * slots;
             const int ec = e < e_hi ? e : (e_hi - 1);
-            ia[u] = *reinterpret_cast<const int4*>(A.erec + 8 * (size_t)ec);
-            ib[u] = *reinterpret_cast<const int4*>(A.erec + 8 * (size_t)ec + 4);
+            idn[u] = *reinterpret_cast<const int4*>(A.erec + 8 * (size_t)ec + 4 * (lg & 1));
         }
     };
+#pragma unroll
+    for (int u = 0; u < U; ++u) idn[u] = make_int4(0, 0, 0, 0);
     int e0 = e_lo + slot;
     if (e_lo < e_hi) load_ids(e0);
     for (; e0 - slot < e_hi; e0 += slots * U) {           // (block-uniform trip count: every thread reaches the barriers below)
         float4 x[U], gs[U], gd[U], cur[U], hs[U][KT], hd[U][KT], R[U][KT];
         float sc[U][KT];
         unsigned kb[U];
-        int rr[U], ps[U], pd[U];
+        int rr[U], pmine[U];
         bool ok[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             ok[u] = e0 + u * slots < e_hi;
-            rr[u] = ib[u].z; ps[u] = ia[u].z; pd[u] = ia[u].w;
-            x[u] = ld4(A.h + (size_t)ib[u].z * A.ld_h + c4);
-            cur[u] = ld4(d_h + (size_t)ib[u].z * ld_dh + c4);
-            gs[u] = ld4(d_out + (size_t)ib[u].x * ld_dout + c4);
-            gd[u] = ld4(d_out + (size_t)ib[u].y * ld_dout + c4);
-            const float* hps = A.ha + (size_t)ia[u].x * KH + c4;
-            const float* hpd = A.ha + (size_t)ia[u].y * KH + c4;
-            const int det = side ? ia[u].y : ia[u].x, pos = side ? ia[u].w : ia[u].z;
-            kb[u] = 0;
+            const int sdet = __shfl(idn[u].x, gbase), ddet = __shfl(idn[u].y, gbase);
+            const int spos = __shfl(idn[u].z, gbase), dpos = __shfl(idn[u].w, gbase);
+            const int srow = __shfl(idn[u].x, gbase + 1), drow = __shfl(idn[u].y, gbase + 1), erow = __shfl(idn[u].z, gbase + 1);
+            rr[u] = erow;
+            x[u] = ld4(A.h + (size_t)erow * A.ld_h + c4);
+            cur[u] = ld4(d_h + (size_t)erow * ld_dh + c4);
+            gs[u] = ld4(d_out + (size_t)srow * ld_dout + c4);
+            gd[u] = ld4(d_out + (size_t)drow * ld_dout + c4);
+            const float* hps = A.ha + (size_t)sdet * KH + c4;
+            const float* hpd = A.ha + (size_t)ddet * KH + c4;
+#pragma unroll
+            for (int k = 0; k < KT; ++k) { hs[u][k] = ld4(hps + k * H); hd[u][k] = ld4(hpd + k * H); }
+            // the per-edge scalar work: lane 0 takes the src side, lane 1 the dst side
+            const int det = (lg & 1) ? ddet : sdet;
+            pmine[u] = (lg & 1) ? dpos : spos;
+            kb[u] = A.keep ? kbase[pmine[u]] : 0u;
 #pragma unroll
             for (int k = 0; k < KT; ++k) {
-                hs[u][k] = ld4(hps + k * H); hd[u][k] = ld4(hpd + k * H);
                 R[u][k] = ld4(detrec + ((size_t)det * KT + k) * 4);
-                sc[u][k] = A.score[(size_t)ia[u].z * KT + k];
-                if (A.keep) kb[u] |= A.keep[(size_t)k * E2 + pos] ? (1u << k) : 0u;
+                sc[u][k] = A.score[(size_t)spos * KT + k];
             }
         }
         if (e0 - slot + slots * U < e_hi) load_ids(e0 + slots * U);
@@ -405,27 +421,28 @@ __global__ __launch_bounds__(256) void k_att_bwd_edge(AttArgs A, const float* __
         for (int u = 0; u < U; ++u) {
             const float ts = group_sum(dot4(gs[u], x[u]), lpr);
             const float td = group_sum(dot4(gd[u], x[u]), lpr);
-            const float sgt = side ? -invK * td : invK * ts;         // sign_p t_p / K of this lane's side
             float wsum = 0.f, ds[KT], dp_[KT];
+            {
+                const float sgt = (lg & 1) ? -invK * td : invK * ts;       // sign_p t_p / K of this lane's side
 #pragma unroll
-            for (int k = 0; k < KT; ++k) {
-                const float al = expf(sc[u][k] - R[u][k].x) / R[u][k].y;
-                const float mk = A.keep ? (((kb[u] >> k) & 1u) ? A.scale : 0.f) : 1.0f;
-                wsum += al * mk;
-                ds[k] = al * (mk * sgt - R[u][k].z);
+                for (int k = 0; k < KT; ++k) {
+                    const float al = expf(sc[u][k] - R[u][k].x) / R[u][k].y;
+                    const float mk = A.keep ? (((kb[u] >> k) & 1u) ? A.scale : 0.f) : 1.0f;
+                    wsum += al * mk;
+                    ds[k] = al * (mk * sgt - R[u][k].z) * (sc[u][k] > 0.f ? 1.0f : LEAKY);
+                }
+                wsum *= invK;
             }
-            wsum *= invK;
             const float ws_ = __shfl(wsum, gbase), wd_ = __shfl(wsum, gbase + 1);
 #pragma unroll
-            for (int k = 0; k < KT; ++k)
-                dp_[k] = (__shfl(ds[k], gbase) + __shfl(ds[k], gbase + 1)) * (sc[u][k] > 0.f ? 1.0f : LEAKY);
+            for (int k = 0; k < KT; ++k) dp_[k] = __shfl(ds[k], gbase) + __shfl(ds[k], gbase + 1);
             if (!ok[u]) continue;
             float4 c = cur[u];
             c.x += ws_ * gs[u].x - wd_ * gd[u].x; c.y += ws_ * gs[u].y - wd_ * gd[u].y;
             c.z += ws_ * gs[u].z - wd_ * gd[u].z; c.w += ws_ * gs[u].w - wd_ * gd[u].w;
             *reinterpret_cast<float4*>(d_h + (size_t)rr[u] * ld_dh + c4) = c;
             if (lg < 2) {
-                float* o = dpre + (size_t)(lg == 0 ? ps[u] : pd[u]) * KT;
+                float* o = dpre + (size_t)pmine[u] * KT;
 #pragma unroll
                 for (int k = 0; k < KT; ++k) o[k] = dp_[k];
             }
@@ -479,10 +496,15 @@ __global__ __launch_bounds__(256) void k_att_bwd_dha(AttArgs A, const float* __r
     };
     auto load_pos = [&](int p, int p1, int& o, bool& ok, float (&f)[KT]) {
         ok = p < p1;
-        o = ok ? A.inc_other[p] : 0;
-        const float* fp = dpre + (size_t)(ok ? p : 0) * KT;
+        const int pc = ok ? p : 0;
+        const int ol = A.inc_other[pc];
+        const float* fp = dpre + (size_t)pc * KT;
+        float fl[KT];
 #pragma unroll
-        for (int k = 0; k < KT; ++k) f[k] = ok ? fp[k] : 0.f;
+        for (int k = 0; k < KT; ++k) fl[k] = fp[k];
+        o = ok ? ol : 0;
+#pragma unroll
+        for (int k = 0; k < KT; ++k) f[k] = ok ? fl[k] : 0.f;
     };
     auto advanceC = [&]() {
         moreC = moreB; dC = dB; p0C = p0B; p1C = p1B;
@@ -519,8 +541,10 @@ __global__ __launch_bounds__(256) void k_att_bwd_dha(AttArgs A, const float* __r
                     const int q = j * U + u;
                     oq[u] = __shfl(oo, gbase + q);
 #pragma unroll
-                    for (int k = 0; k < KT; ++k)
-                        x[u][k] = q < Lc ? ld4(A.ha + (size_t)(oq[u] & 0x7fffffff) * KH + k * H + c4) : zero4();
+                    for (int k = 0; k < KT; ++k) {
+                        const float4 xl = ld4(A.ha + (size_t)(q < Lc ? (oq[u] & 0x7fffffff) : 0) * KH + k * H + c4);
+                        x[u][k] = q < Lc ? xl : zero4();
+                    }
                 }
                 if (!advanced) { advance(); advanced = true; }
 #pragma unroll
@@ -567,8 +591,7 @@ __global__ void k_att_heads_add(const float* __restrict__ dWcat, const float* __
 
 static int att_grid(long dets) {
     long b = (dets + ATT_CHUNK - 1) / ATT_CHUNK;
-    static const long cap = [] { const char* e = getenv("ATT_EXP_GRID"); return e ? atol(e) : 256L * 64; }();   // EXPERIMENT
-    if (b > cap) b = cap;
+    if (b > 256L * 64) b = 256L * 64;
     if (b < 1) b = 1;
     return (int)b;
 }

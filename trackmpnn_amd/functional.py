@@ -172,6 +172,22 @@ def _stream() -> int:
     return _lib.raw_stream()
 
 
+def _keep_bits(keep, K: int, n: int, dev) -> torch.Tensor:
+    """The attention dropout mask as the kernels take it: uint8 [n], bit k set = head k keeps the position.  `keep` None:
+    drawn here (p = 0.5: every bit of a uniform byte is an independent fair coin -- one launch for all heads); else a
+    [K, n] mask (the reference's drawn mask in the parity tests) packed."""
+    n = max(n, 1)
+    if keep is None:
+        if ATT_DROPOUT_P == 0.5:
+            return torch.empty((n,), dtype=torch.uint8, device=dev).random_(0, 1 << K)
+        keep = torch.empty((K, n), dtype=torch.uint8, device=dev).bernoulli_(1.0 - ATT_DROPOUT_P)
+    keep = (keep != 0).to(torch.uint8)
+    bits = keep[0].clone()
+    for k in range(1, K):
+        bits |= keep[k] << k
+    return bits.contiguous()
+
+
 def _require_device(t: torch.Tensor, what: str):
     if not t.is_cuda:
         raise RuntimeError(f'{what} is on {t.device}: trackmpnn_amd runs on the MI355X HIP kernels only '
@@ -396,10 +412,7 @@ def mp_forward(spec: ModelSpec, plan: CallPlan, x: torch.Tensor, h_in: Optional[
             alpha = torch.empty((K, max(2 * E, 1)), **opts)
             kp = None
             if training:
-                if keep is None or keep[gi] is None:
-                    kp = torch.empty((K, max(2 * E, 1)), dtype=torch.uint8, device=dev).bernoulli_(1.0 - ATT_DROPOUT_P)
-                else:
-                    kp = keep[gi].to(torch.uint8).contiguous()
+                kp = _keep_bits(None if keep is None else keep[gi], K, 2 * E, dev)
             _lib.call('tmpnn_att_fwd', g.cref(), _lib.ptr(erec), hg, GH, H, K, W.data_ptr(),
                       a.data_ptr(), _lib.ptr(kp), ATT_DROPOUT_P, ws_ha.data_ptr(), score.data_ptr(), stats.data_ptr(),
                       esk.data_ptr(), alpha.data_ptr(), es.data_ptr(), H, st)
