@@ -419,7 +419,7 @@ def latency_batch1():
     # models OUTSIDE the fused batch-1 path on the same C2 window: staged kernels per call, eager and replayed from one hipGraph
     try:
         var = {}
-        for vtag, H_, K_ in (('k2_heads_h64', 64, 2), ('k0_h128', 128, 0)):
+        for vtag, H_, K_ in (('k2_heads_h64', 64, 2), ('k0_h128', 128, 0), ('k0_h48_padded', 48, 0)):
             torch.manual_seed(5)
             model = TrackMPNN('2d', 3, H_, K_, 'diff').to(dev).train()
             bucket = GradBucket(model)
@@ -455,7 +455,7 @@ def latency_batch1():
                    'adjacency conversion, gradients accumulated in place (GradBucket: one extra line in the training loop); '
                    'eager_plain = the import swap alone (gradients returned to autograd); captured = the eager step '
                    'replayed from one hipGraph; cpu oracle: 1 thread; c2_window_staged_models = the same window for models the '
-                   'fused iteration does not cover (attention heads, nhidden 128): staged kernels, eager / captured')
+                   'fused iteration does not cover (attention heads, nhidden 128, a zero-padded width): staged kernels, eager / captured')
     return out
 
 

@@ -43,6 +43,7 @@ extern "C" {
 #define TMPNN_EWORKSPACE (-3) /* workspace too small */
 
 typedef void* tmpnn_stream; /* hipStream_t */
+typedef void* tmpnn_event;  /* hipEvent_t, created and owned by the caller (the library only records / waits on it) */
 
 /*
  * Index form of the reference's adjacency pair (utils/graph.py:151-163, 294-308): every edge
@@ -579,21 +580,23 @@ int tmpnn_wide_gru_bwd_diff(const void* prep, const tmpnn_graph* g, const float*
 /* The same call with the det-side branch (the signed segment sums of d_gi and the message adjoint) enqueued on a SECOND
  * stream next to the two E-row matrix kernels: forked from `stream` after the gate gradients, joined before the det-side
  * weight gradient, so `stream` order alone still covers every output.  Results are bit-identical to tmpnn_wide_gru_bwd_diff.
- * aux_stream must differ from stream; do not use while `stream` is being captured into a graph. */
+ * aux_stream must differ from stream; do not use while `stream` is being captured into a graph.  ev_fork / ev_join: two
+ * events of the caller (hipEventDisableTiming is enough) that the call records and waits on -- the library creates, destroys
+ * and synchronises nothing; on return (also with an error code) `stream` waits for everything enqueued on aux_stream. */
 int tmpnn_wide_gru_bwd_diff_aux(const void* prep, const tmpnn_graph* g, const float* h, int ld_h, int H, const float* gates,
                             size_t gate_plane, const float* d_hout, int ld_dhout, const float* dy, const float* w_head,
                             float* d_h, int ld_dh, float* dW_ih, float* dW_hh, float* db_ih, float* db_hh, void* ws,
                             size_t ws_bytes, tmpnn_stream stream,
-                                tmpnn_stream aux_stream);
+                                tmpnn_stream aux_stream, tmpnn_event ev_fork, tmpnn_event ev_join);
 /* ... and with the adjoint of row F (models/layers.py:103: d_h[e] += add_msg[src[e]] - add_msg[dst[e]], what
  * tmpnn_gather_diff_fwd(g, add_msg, ld_add, d_h, ld_dh, H, accumulate = 1) would add afterwards) taken in the epilogue of the
  * E-row product: one read-modify-write pass over d_h's edge rows less.  add_msg: the table whose det rows hold d_es (>= H
- * columns); aux_stream may be NULL (one stream).  Bit-identical to the two calls. */
+ * columns); aux_stream may be NULL (one stream; the events are then unused).  Bit-identical to the two calls. */
 int tmpnn_wide_gru_bwd_diff_fused(const void* prep, const tmpnn_graph* g, const float* h, int ld_h, int H, const float* gates,
                                   size_t gate_plane, const float* d_hout, int ld_dhout, const float* dy, const float* w_head,
                                   float* d_h, int ld_dh, float* dW_ih, float* dW_hh, float* db_ih, float* db_hh, void* ws,
                                   size_t ws_bytes, const float* add_msg, int ld_add, tmpnn_stream stream,
-                                  tmpnn_stream aux_stream);
+                                  tmpnn_stream aux_stream, tmpnn_event ev_fork, tmpnn_event ev_join);
 
 #ifdef __cplusplus
 }

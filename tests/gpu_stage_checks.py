@@ -556,15 +556,20 @@ def check_wide(H, g, gd):
     addm = torch.randn(g.N, H + 8, device=DEV)
     _lib.call('tmpnn_gather_diff_fwd', gd.cref(), addm.data_ptr(), H + 8, dh.data_ptr() + 4 * H, ld, H, 1, st())
     aux = torch.cuda.Stream(DEV)
+    evs = [torch.cuda.Event(enable_timing=False) for _ in range(2)]       # the caller's fork / join events
+    for e in evs:
+        e.record()
+    evf, evj = evs[0].cuda_event, evs[1].cuda_event
     for tag, use_aux, fused in (('aux stream', True, False), ('fused adjoint', False, True), ('fused adjoint + aux', True, True)):
         dh2, gr2 = fresh()
         args = (prep.data_ptr(), gd.cref(), hD.data_ptr() + 4 * H, ld, H, gates.data_ptr(), g.N * H,
                 doutD.data_ptr() + 4 * H, ld, None, None, dh2.data_ptr() + 4 * H, ld, gr2[0].data_ptr(), gr2[1].data_ptr(),
                 gr2[2].data_ptr(), gr2[3].data_ptr(), ws.data_ptr(), wsb)
         if fused:
-            _lib.call('tmpnn_wide_gru_bwd_diff_fused', *args, addm.data_ptr(), H + 8, st(), aux.cuda_stream if use_aux else None)
+            _lib.call('tmpnn_wide_gru_bwd_diff_fused', *args, addm.data_ptr(), H + 8, st(), aux.cuda_stream if use_aux else None,
+                      evf if use_aux else None, evj if use_aux else None)
         else:
-            _lib.call('tmpnn_wide_gru_bwd_diff_aux', *args, st(), aux.cuda_stream)
+            _lib.call('tmpnn_wide_gru_bwd_diff_aux', *args, st(), aux.cuda_stream, evf, evj)
             _lib.call('tmpnn_gather_diff_fwd', gd.cref(), addm.data_ptr(), H + 8, dh2.data_ptr() + 4 * H, ld, H, 1, st())
         torch.cuda.synchronize()
         same = torch.equal(dh2, dh) and all(torch.equal(a, b) for a, b in zip(gr2, gr))

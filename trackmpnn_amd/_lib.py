@@ -189,10 +189,10 @@ _SIGNATURES = {
                                         c_void_p, c_size_t, c_void_p]),
     'tmpnn_wide_gru_bwd_diff_aux': (c_int, [c_void_p, _GP, c_void_p, c_int, c_int, c_void_p, c_size_t, c_void_p, c_int,
                                             c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
-                                            c_void_p, c_size_t, c_void_p, c_void_p]),
+                                            c_void_p, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p]),
     'tmpnn_wide_gru_bwd_diff_fused': (c_int, [c_void_p, _GP, c_void_p, c_int, c_int, c_void_p, c_size_t, c_void_p, c_int,
                                               c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
-                                              c_void_p, c_size_t, c_void_p, c_int, c_void_p, c_void_p]),
+                                              c_void_p, c_size_t, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     'tmpnn_mp_iter_prep_floats': (c_size_t, [c_int, c_int, c_int]),
     'tmpnn_mp_iter_prepare': (c_int, [_MPP, c_void_p, c_void_p]),
     'tmpnn_mp_iter_save_floats': (c_size_t, [c_int, c_int, c_int, c_int]),

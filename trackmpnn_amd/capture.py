@@ -94,6 +94,8 @@ class CapturedWindow:
 
     def _step_inner(self):
         h, outs = None, []
+        if getattr(self.model, '_pad_cache', None) is not None:
+            self.model._pad_cache = None                # (zero-padded copies of an earlier step must not enter this one)
         with weight_cache():                            # (the weights are constant over the forward calls of one step)
             for c, (x, g) in enumerate(zip(self.static_x, self.graphs)):
                 if self.staged:
@@ -121,6 +123,8 @@ class CapturedWindow:
                 torch._foreach_add_([a for a, _ in pairs], [g for _, g in pairs])
         if self.optimizer is not None:
             self.optimizer.step()
+        if getattr(self.model, '_pad_cache', None) is not None:
+            self.model._pad_cache = None
         return loss.detach(), [(s.detach(), l.detach()) for s, l in outs], h.detach()
 
     def replay(self, xs: Optional[Sequence[torch.Tensor]] = None) -> torch.Tensor:

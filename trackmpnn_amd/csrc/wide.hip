@@ -2010,7 +2010,7 @@ size_t tmpnn_wide_gru_bwd_diff_ws(int N, int R, int Dn, int H) {
 static int wide_gru_bwd_diff_impl(const void* prep, const tmpnn_graph* g, const float* h, int ld_h, int H, const float* gates,
                                   size_t gate_plane, const float* d_hout, int ld_dhout, const float* dy, const float* w_head,
                                   float* d_h, int ld_dh, float* dW_ih, float* dW_hh, float* db_ih, float* db_hh, void* ws,
-                                  size_t ws_bytes, tmpnn_stream stream, tmpnn_stream aux_stream, const float* add_msg,
+                                  size_t ws_bytes, tmpnn_stream stream, tmpnn_stream aux_stream, tmpnn_event ev_fork_, tmpnn_event ev_join_, const float* add_msg,
                                   int ld_add) {
     TM_REQUIRE(tmpnn_wide_supported(H, H), "wide_gru_bwd_diff: H=%d", H);
     TM_REQUIRE(add_msg == nullptr || (aligned16(add_msg) && (ld_add & 3) == 0 && ld_add >= H && g && g->src && g->dst),
@@ -2055,18 +2055,23 @@ static int wide_gru_bwd_diff_impl(const void* prep, const tmpnn_graph* g, const 
     // bound): both only read dg4 and write disjoint rows of d_h.  Fork after 1, join before 5b (which reads S and reuses the
     // slab buffer).  Same kernels on the same data in the same order per buffer: bit-identical to the one-stream form.
     hipStream_t sx = aux_stream ? as_stream(aux_stream) : st;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    if (aux_stream) {
-        if (hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&ev_join, hipEventDisableTiming) != hipSuccess)
-            return set_error(TMPNN_ELAUNCH, "wide_gru_bwd_diff: event creation failed");
-        (void)hipEventRecord(ev_fork, st);
-        (void)hipStreamWaitEvent(sx, ev_fork, 0);
+    hipEvent_t ev_fork = reinterpret_cast<hipEvent_t>(ev_fork_), ev_join = reinterpret_cast<hipEvent_t>(ev_join_);
+    if (aux_stream) {                              // the caller's events: nothing is created or destroyed here
+        TM_REQUIRE(ev_fork && ev_join, "wide_gru_bwd_diff: the two-stream form needs the caller's fork / join events");
+        if (hipEventRecord(ev_fork, st) != hipSuccess || hipStreamWaitEvent(sx, ev_fork, 0) != hipSuccess)
+            return set_error(TMPNN_ELAUNCH, "wide_gru_bwd_diff: fork onto the auxiliary stream failed");
     }
-    auto done = [&](int code) {                    // (events are released once their pending work has completed)
-        if (ev_fork) (void)hipEventDestroy(ev_fork);
-        if (ev_join) (void)hipEventDestroy(ev_join);
-        return code;
+    bool joined = false;
+    auto join = [&]() -> int {                     // `stream` waits for everything enqueued on the auxiliary stream
+        if (!aux_stream || joined) return TMPNN_OK;
+        joined = true;
+        if (hipEventRecord(ev_join, sx) != hipSuccess || hipStreamWaitEvent(st, ev_join, 0) != hipSuccess)
+            return set_error(TMPNN_ELAUNCH, "wide_gru_bwd_diff: join of the auxiliary stream failed");
+        return TMPNN_OK;
+    };
+    auto done = [&](int code) {                    // on an error path too: never return with the auxiliary stream un-joined
+        const int j = join();
+        return code ? code : j;
     };
     WideArgs y{};
     y.A = dg4; y.lda = 4 * H; y.a_rows = g->edge_row; y.R = R; y.K = 3 * H; y.kskip_at = 2 * H; y.kskip = H;
@@ -2089,7 +2094,6 @@ static int wide_gru_bwd_diff_impl(const void* prep, const tmpnn_graph* g, const 
     x.A = S; x.lda = 3 * H; x.a_rows = nullptr; x.R = Dn; x.K = 3 * H; x.kskip_at = 3 * H; x.kskip = 0;
     x.img = b_ih; x.N = H; x.C = d_h; x.ldc = ld_dh; x.c_rows = g->det_row; x.accumulate = 1;
     if ((rc = launch_store(x, sx))) return done(rc);
-    if (aux_stream) (void)hipEventRecord(ev_join, sx);
     // 5. weight gradients: dW_hh over the edge rows (bias sums: db_hh, and db_ih's r / z thirds), dW_ih over the det rows
     {
         const int n = dw_slabs(R, H);
@@ -2101,7 +2105,7 @@ static int wide_gru_bwd_diff_impl(const void* prep, const tmpnn_graph* g, const 
         if ((rc = launch_reduce_slabs(bslabs, (size_t)3 * H, nslab, db_hh, (size_t)3 * H, 1, st, fold))) return done(rc);
         if ((rc = launch_reduce_slabs(bslabs, (size_t)3 * H, nslab, db_ih, (size_t)2 * H, 1, st, fold))) return done(rc);
     }
-    if (aux_stream) (void)hipStreamWaitEvent(st, ev_join, 0);          // S is complete, d_h's det rows are final
+    if ((rc = join())) return rc;                                       // S is complete, d_h's det rows are final
     {
         const int n = dw_slabs(Dn, H);
         const int rps = ((Dn + n - 1) / n + 31) / 32 * 32;
@@ -2118,27 +2122,27 @@ int tmpnn_wide_gru_bwd_diff(const void* prep, const tmpnn_graph* g, const float*
                             float* d_h, int ld_dh, float* dW_ih, float* dW_hh, float* db_ih, float* db_hh, void* ws,
                             size_t ws_bytes, tmpnn_stream stream) {
     return wide_gru_bwd_diff_impl(prep, g, h, ld_h, H, gates, gate_plane, d_hout, ld_dhout, dy, w_head, d_h, ld_dh, dW_ih, dW_hh,
-                                  db_ih, db_hh, ws, ws_bytes, stream, nullptr, nullptr, 0);
+                                  db_ih, db_hh, ws, ws_bytes, stream, nullptr, nullptr, nullptr, nullptr, 0);
 }
 
 int tmpnn_wide_gru_bwd_diff_aux(const void* prep, const tmpnn_graph* g, const float* h, int ld_h, int H, const float* gates,
                                 size_t gate_plane, const float* d_hout, int ld_dhout, const float* dy, const float* w_head,
                                 float* d_h, int ld_dh, float* dW_ih, float* dW_hh, float* db_ih, float* db_hh, void* ws,
-                                size_t ws_bytes, tmpnn_stream stream, tmpnn_stream aux_stream) {
+                                size_t ws_bytes, tmpnn_stream stream, tmpnn_stream aux_stream, tmpnn_event ev_fork, tmpnn_event ev_join) {
     TM_REQUIRE(aux_stream != nullptr && aux_stream != stream, "wide_gru_bwd_diff_aux: needs a second stream");
     return wide_gru_bwd_diff_impl(prep, g, h, ld_h, H, gates, gate_plane, d_hout, ld_dhout, dy, w_head, d_h, ld_dh, dW_ih, dW_hh,
-                                  db_ih, db_hh, ws, ws_bytes, stream, aux_stream, nullptr, 0);
+                                  db_ih, db_hh, ws, ws_bytes, stream, aux_stream, ev_fork, ev_join, nullptr, 0);
 }
 
 int tmpnn_wide_gru_bwd_diff_fused(const void* prep, const tmpnn_graph* g, const float* h, int ld_h, int H, const float* gates,
                                   size_t gate_plane, const float* d_hout, int ld_dhout, const float* dy, const float* w_head,
                                   float* d_h, int ld_dh, float* dW_ih, float* dW_hh, float* db_ih, float* db_hh, void* ws,
                                   size_t ws_bytes, const float* add_msg, int ld_add, tmpnn_stream stream,
-                                  tmpnn_stream aux_stream) {
+                                  tmpnn_stream aux_stream, tmpnn_event ev_fork, tmpnn_event ev_join) {
     TM_REQUIRE(add_msg != nullptr, "wide_gru_bwd_diff_fused: add_msg is null");
     TM_REQUIRE(aux_stream != stream || aux_stream == nullptr, "wide_gru_bwd_diff_fused: aux_stream must differ from stream (or be null)");
     return wide_gru_bwd_diff_impl(prep, g, h, ld_h, H, gates, gate_plane, d_hout, ld_dhout, dy, w_head, d_h, ld_dh, dW_ih, dW_hh,
-                                  db_ih, db_hh, ws, ws_bytes, stream, aux_stream, add_msg, ld_add);
+                                  db_ih, db_hh, ws, ws_bytes, stream, aux_stream, ev_fork, ev_join, add_msg, ld_add);
 }
 
 }  // extern "C"

@@ -66,7 +66,12 @@ def shard_windows(n_windows: int, rank: int, world: int, edge_counts: Optional[S
     the metric and of the work): longest-processing-time greedy -- windows in descending order of work, each to the
     rank with the least work so far, ties to the lowest rank -- so that every rank's step takes about the same time
     (graph sizes vary by an order of magnitude between KITTI and BDD scenes).  Deterministic: every rank
-    computes the same partition from the same counts; each rank's list is returned in ascending window order."""
+    computes the same partition from the same counts; each rank's list is returned in ascending window order.
+
+    Contract of the balanced deal: ranks may hold DIFFERENT NUMBERS of windows (a rank can even get none), so the training
+    loop must issue exactly ONE `allreduce_grads` per rank and optimizer step over the rank's whole shard -- never one per
+    window -- and the shard's loss must be a SUM over its windows (`allreduce_grads` divides the summed gradient by `world`,
+    not by a window count): a per-rank mean would weight windows of small shards more.  bench.py's step does both."""
     if edge_counts is None:
         return list(range(rank, n_windows, world))
     if len(edge_counts) != n_windows:

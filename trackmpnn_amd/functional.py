@@ -71,6 +71,23 @@ def _aux_stream(dev) -> Optional[int]:
     return s.cuda_stream
 
 
+_aux_events: Dict[torch.device, tuple] = {}
+
+
+def _aux_event_pair(dev):
+    """The device's fork / join events for the two-stream forms (created once, under the device, and recorded once so that
+    their native handles exist): the C entry points only record and wait on what the caller hands them."""
+    key = torch.device(dev)
+    ev = _aux_events.get(key)
+    if ev is None:
+        with torch.cuda.device(key):
+            ev = (torch.cuda.Event(enable_timing=False), torch.cuda.Event(enable_timing=False))
+            for e in ev:
+                e.record(torch.cuda.current_stream(key))
+        _aux_events[key] = ev
+    return ev
+
+
 _wide_ws: Dict[torch.device, torch.Tensor] = {}
 
 
@@ -340,8 +357,8 @@ def mp_forward(spec: ModelSpec, plan: CallPlan, x: torch.Tensor, h_in: Optional[
             aux = _aux_stream(dev)
             if aux is not None:
                 aux_obj = _aux_streams[torch.device(dev)]
-                fork = torch.cuda.Event()
-                fork.record()
+                fork, _ = _aux_event_pair(dev)
+                fork.record(torch.cuda.current_stream(dev))
                 aux_obj.wait_event(fork)
                 st_det = aux
         if use_wide:
@@ -425,7 +442,7 @@ def mp_forward(spec: ModelSpec, plan: CallPlan, x: torch.Tensor, h_in: Optional[
                   P[f + 'node_gru.bias_ih'].data_ptr(), P[f + 'node_gru.bias_hh'].data_ptr(),
                   og, GH, gp, plane, wn_g, part_g, N, st_det)
         if aux_obj is not None:
-            join = torch.cuda.Event()
+            _, join = _aux_event_pair(dev)
             join.record(aux_obj)
             torch.cuda.current_stream(dev).wait_event(join)
     logits = torch.empty((N, 1), **opts)
@@ -571,12 +588,18 @@ def mp_backward(spec: ModelSpec, plan: CallPlan, saved: dict, P: Dict[str, torch
                         ws_wide.data_ptr(), wsb, st)
                 # (every buffer the auxiliary stream touches was allocated on, and is next used on, the current stream,
                 #  which the call leaves waiting for the auxiliary work: no record_stream needed)
+                evf = evj = None
+                if aux is not None:
+                    ef, ej = _aux_event_pair(dev)
+                    evf, evj = ef.cuda_event, ej.cuda_event
+                    if not evf or not evj:                     # (no native handle: one stream)
+                        aux = evf = evj = None
                 if fuse and WIDE_FUSED_ADJOINT:
                     # the adjoint of the edge -> node sum rides in the epilogue of the E-row product (no separate pass over d_h)
-                    _lib.call('tmpnn_wide_gru_bwd_diff_fused', *args[:-1], dmsg.data_ptr(), IN_e, st, aux)
+                    _lib.call('tmpnn_wide_gru_bwd_diff_fused', *args[:-1], dmsg.data_ptr(), IN_e, st, aux, evf, evj)
                 else:
                     if aux is not None:
-                        _lib.call('tmpnn_wide_gru_bwd_diff_aux', *args, aux)
+                        _lib.call('tmpnn_wide_gru_bwd_diff_aux', *args, aux, evf, evj)
                     else:
                         _lib.call('tmpnn_wide_gru_bwd_diff', *args)
                     if fuse:

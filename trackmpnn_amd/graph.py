@@ -186,6 +186,10 @@ def edge_tiles(graph: FrameGraph, rows_per_tile: int = 128, dst_offset: int = 0)
         # small windows keep their row order.  The mean run length costs one host round trip, once per graph.
         runs = 1
         if graph.E > 1:
+            if graph.src_pos.is_cuda and torch.cuda.is_current_stream_capturing():
+                raise RuntimeError('edge_tiles: the tile list of this graph is not built yet and building it reads one '
+                                   'count back to the host, which a stream capture cannot do -- run one eager call on the '
+                                   'graph (CapturedWindow does) before capturing')
             runs = 1 + int((graph.src_pos[1:] != graph.src_pos[:-1]).sum())
         blocks = graph.E / runs >= rows_per_tile / 2
         od = 'blocks' if blocks else 'rows'

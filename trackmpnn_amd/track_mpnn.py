@@ -116,11 +116,12 @@ class TrackMPNN(nn.Module):
         self._anch_calls = 0
         self._gst = None
         self._pending_graphs = []              # DeviceGraphs whose validation status has not been read back yet
+        self._pad_cache = None                 # (key, padded parameter copies) of the zero-padded widths
 
     # per-call bookkeeping of the batch-1 path (plain Python values, reassigned on every forward call): kept out of
     # nn.Module.__setattr__'s parameter / buffer / sub-module checks (~2.5 us per assignment, twice per call)
     _PLAIN = frozenset(('_graph_cache', '_anchor', '_anch_key', '_anch_calls', '_gst', '_sink', '_sink_key', '_plist',
-                        '_bufs', '_pending_graphs'))
+                        '_bufs', '_pending_graphs', '_pad_cache'))
 
     def __setattr__(self, name, value):
         if name in TrackMPNN._PLAIN:
@@ -129,6 +130,11 @@ class TrackMPNN(nn.Module):
             super().__setattr__(name, value)
 
     def _drop_caches(self):
+        # adjacencies converted by earlier eager calls and not yet checked are validated NOW (one host round trip) instead of
+        # being forgotten: the caller is promised a ValueError for an invalid graph, not just NaN outputs
+        if self._pending_graphs and torch.cuda.is_available() and not torch.cuda.is_current_stream_capturing():
+            self.check_graphs()
+        self._pad_cache = None
         self._small.invalidate()
         self._plist = self._bufs = self._anchor = None
         self._sink = self._sink_key = None
@@ -160,6 +166,7 @@ class TrackMPNN(nn.Module):
     def _apply(self, fn, *args, **kwargs):
         # .cuda() / .to() / .float(): parameter storage moves -> drop every cached device pointer
         out = super()._apply(fn, *args, **kwargs)
+        self._pad_cache = None
         self._small.invalidate()
         self._plist = self._bufs = self._anchor = None
         self._sink = self._sink_key = None
@@ -169,6 +176,7 @@ class TrackMPNN(nn.Module):
 
     def load_state_dict(self, *args, **kwargs):
         out = super().load_state_dict(*args, **kwargs)
+        self._pad_cache = None
         self._small.invalidate()
         self._plist = self._bufs = None
         self._sink = self._sink_key = None
@@ -225,6 +233,32 @@ class TrackMPNN(nn.Module):
             out += [pad(w.reshape(1, G, H), (0, d)).reshape(1, G * Hp), b]
         return [t.contiguous() for t in out]
 
+    def _padded_params(self, params):
+        """The zero-padded parameter copies of a non-native width, built ONCE per set of parameter values (every parameter's
+        version counter) instead of once per forward call: the calls of a window share one set of copies, so the ~30 pad
+        kernels (and their backward) run once per step; autograd still hands the true parameters their gradients through
+        the copies.  Dropped when a backward pass reaches the copies (their graph is spent), when a version moves, and by
+        refresh_weights() / .to() / load_state_dict()."""
+        key = (torch.is_grad_enabled(), tuple((id(p), p._version, p.requires_grad) for p in params))
+        c = self._pad_cache
+        if c is not None and c[0] == key:
+            return c[1]
+        out = self._pad_params(params)
+        token = object()
+        self._pad_cache = (key, out, token)
+        if torch.is_grad_enabled():
+            live = [t for t in out if t.requires_grad]
+            if live:
+                import weakref
+                me = weakref.ref(self)                 # (no reference cycle tensor -> hook -> copies -> tensor)
+
+                def spent(_g, me=me, token=token):
+                    m = me()
+                    if m is not None and m._pad_cache is not None and m._pad_cache[2] is token:
+                        m._pad_cache = None
+                live[0].register_hook(spent)
+        return out
+
     def _pad_state(self, h):
         N, G = h.shape[0], self.spec.G
         return torch.nn.functional.pad(h.reshape(N, G, self.nhidden), (0, self.hpad - self.nhidden)).reshape(N, G * self.hpad)
@@ -251,7 +285,7 @@ class TrackMPNN(nn.Module):
             x.requires_grad or (h_in is not None and h_in.requires_grad) or any(p.requires_grad for p in params))
         true_buffers = None
         if self._padded:
-            params = self._pad_params(params)
+            params = self._padded_params(params)
             h_in = self._pad_state(h_in) if h_in is not None else None
             d = self.hpad - self.nhidden
             true_buffers, buffers = buffers, dict(buffers)

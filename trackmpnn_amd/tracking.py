@@ -142,6 +142,13 @@ class TrackGraph:
         tg.track = torch.from_numpy(trk.astype(np.int32)).to(tg.device)
         tg._rebuild()
         tg._sequence(X, yy)
+        tg._X_src, tg._y_src = X, y
+        if mode != 'train' and not tg._time_sorted:
+            # decode()'s finalisation walk runs on the device in graph-row order, which equals the reference's det-id order
+            # (utils/graph.py:456-490) only when the detections are listed frame by frame -- say so BEFORE any forward call
+            raise ValueError('TrackGraph.initialize(mode="test"): the detections of the sequence must be listed in time '
+                             'order (dataset/kitti_mot.py and bdd100k_mot.py list them frame by frame); sort X / y by '
+                             'y[..., 0] first')
         Xd = tg._Xd
         feats = torch.zeros((N, X.shape[2]), dtype=Xd.dtype, device=tg.device)
         feats[:n0] = Xd[torch.from_numpy(ids0).to(tg.device)]
@@ -222,6 +229,13 @@ class TrackGraph:
         the A x D_t edge rows and the D_t det rows of timestep t.  score_pos: P(positive) per row [N] (unused in
         training).  Returns the features of the new rows [A*D_t + D_t, F] (zeros on edge rows), on the device.
         One host read: the size of the active set."""
+        # features and per-timestep detection ids were uploaded ONCE at initialize(): a different X / y here would be
+        # silently ignored, so refuse it (the reference's loops pass the same sequence tensors every step)
+        for given, kept, nm in ((X, getattr(self, '_X_src', None), 'X'), (y, getattr(self, '_y_src', None), 'y')):
+            if kept is not None and given is not kept and not (
+                    given.shape == kept.shape and given.data_ptr() == kept.data_ptr() and given._version == kept._version):
+                raise ValueError(f'TrackGraph.update: {nm} must be the tensor initialize() was given (its contents are cached '
+                                 'on the device once per sequence); start a new TrackGraph for new data')
         sp = None
         if mode != 'train':
             sp = score_pos.detach().reshape(-1).float().contiguous()
@@ -234,6 +248,8 @@ class TrackGraph:
         D = hi - lo
         Xd = self._Xd
         if D == 0:
+            if mode == 'train' and (self._small[1:2].tolist()[0] & 1):     # (the label rule's assertion holds on empty timesteps too)
+                raise AssertionError('More than one GT edge from same node!')
             return torch.zeros((0, Xd.shape[1]), dtype=Xd.dtype, device=self.device)
         A, status = self._small[:2].tolist()               # the ONE host read of an update: the size of the active set
         if status & 1:
