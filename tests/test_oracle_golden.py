@@ -126,3 +126,30 @@ def test_oracle_matches_reference_inference_loop(name):
             assert torch.allclose(h, gold.t(f'c{c}/h_out'), atol=TOL, rtol=RTOL), f'h_out call {c}'
             # y_pred marks the type of every row (ts == -1 on edge rows, utils/graph.py:141-145,285-287)
             assert np.array_equal(gold.d[f'c{c}/y_pred'][:, 0] == -1, graph.is_edge)
+
+
+REFERENCE = '/root/reference'
+
+
+@pytest.mark.skipif(not __import__('os').path.isdir(REFERENCE), reason='the reference only exists in the build container')
+def test_committed_fixtures_regenerate_from_the_reference(tmp_path):
+    """oracle/gen_golden.py, run against the real reference, reproduces EVERY committed fixture -- every array and the meta
+    string (the .npz containers themselves carry zip timestamps and cannot be byte-compared).  This is what pins the
+    fixtures (and through them the oracle) to outputs of the reference itself; it runs wherever /root/reference exists."""
+    import glob
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PYTHONDONTWRITEBYTECODE='1')
+    subprocess.run([sys.executable, os.path.join(root, 'oracle', 'gen_golden.py'), '--reference-path', REFERENCE,
+                    '--out', str(tmp_path)], check=True, env=env, cwd=root, stdout=subprocess.DEVNULL)
+    committed = sorted(glob.glob(os.path.join(root, 'tests', 'golden', '*.npz')))
+    fresh = sorted(glob.glob(os.path.join(str(tmp_path), '*.npz')))
+    assert [os.path.basename(f) for f in fresh] == [os.path.basename(f) for f in committed]
+    for fc, ff in zip(committed, fresh):
+        a, b = np.load(fc, allow_pickle=False), np.load(ff, allow_pickle=False)
+        assert sorted(a.files) == sorted(b.files), os.path.basename(fc)
+        for k in a.files:
+            assert a[k].dtype == b[k].dtype and a[k].shape == b[k].shape and np.array_equal(a[k], b[k]), \
+                f'{os.path.basename(fc)}: {k} differs from what the reference produces now'

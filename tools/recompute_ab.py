@@ -81,4 +81,4 @@ if __name__ == '__main__':
         me = os.path.abspath(__file__)
         subprocess.run([sys.executable, me, 'kernels'], check=True)
         for v in ('0', '1', '0', '1'):
-            subprocess.run([sys.executable, me, 'child'], check=True, env=dict(os.environ, TMPNN_RECOMPUTE_GATES=v))
+            subprocess.run([sys.executable, me, 'child'], check=True, env=dict(os.environ, TMPNN_KEEP_VARIANTS='1', TMPNN_RECOMPUTE_GATES=v))

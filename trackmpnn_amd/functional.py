@@ -27,32 +27,43 @@ ATT_DROPOUT_P = 0.5
 # `GradBucket(model)` (trackmpnn_amd.dist) turns it on for its module (`module.inplace_param_grads = True`), the
 # environment variable TMPNN_INPLACE_GRADS=1 for every module.  Default: off -- real gradients are returned.
 INPLACE_GRADS = os.environ.get('TMPNN_INPLACE_GRADS', '0') == '1'
-WIDE_DW = os.environ.get('TMPNN_WIDE_DW', '1') == '1'        # wide cells: dW from the materialised gate gradients
+FUSED_BWD = os.environ.get('TMPNN_FUSED_BWD', '1') == '1'     # one-pass cell backward (see mp_backward); its A/B is a test
+# wide cells: the det-side branch of the backward on a second stream next to the E-row matrix kernels (tmpnn_wide_gru_bwd_diff_aux)
+WIDE_OVERLAP = os.environ.get('TMPNN_WIDE_OVERLAP', '1') != '0'
+_SPLIT = os.environ.get('TMPNN_SPLIT', '1')[:1] != '0'        # TMPNN_SPLIT=0: every GEMM on the f32-input MFMA (tested)
+
+# Switches whose A/B has been run and lost (DESIGN sections 4, 11): they are constants of a normal process and only read from the
+# environment when TMPNN_KEEP_VARIANTS=1 (the Python side of the -DTMPNN_KEEP_VARIANTS build flag; tools/ set it for comparisons).
+_VARIANTS = os.environ.get('TMPNN_KEEP_VARIANTS', '0') == '1'
+
+
+def _variant(name: str, default: str) -> str:
+    return os.environ.get(name, default) if _VARIANTS else default
+
+
+WIDE_DW = _variant('TMPNN_WIDE_DW', '1') == '1'              # wide cells: dW from the materialised gate gradients
 # wide cells: both W_ih products of the backward on the DET side (linearity of the diff message, tmpnn_wide_gru_bwd_diff);
 # TMPNN_WIDE_DET=0 keeps the per-edge products (tmpnn_wide_gru_bwd_data + _weights + the message adjoint's segment sum)
-WIDE_DET = os.environ.get('TMPNN_WIDE_DET', '1') == '1'
-FUSED_BWD = os.environ.get('TMPNN_FUSED_BWD', '1') == '1'     # one-pass cell backward (see mp_backward)
+WIDE_DET = _variant('TMPNN_WIDE_DET', '1') == '1'
 # H = 128 / 256 edge cells as LDS-tiled bf16x6 GEMMs (csrc/wide.hip); TMPNN_WIDE=0 keeps round 1's f32-MFMA kernels
-WIDE = os.environ.get('TMPNN_WIDE', '1') != '0' and os.environ.get('TMPNN_SPLIT', '1')[:1] != '0'
+WIDE = _variant('TMPNN_WIDE', '1') != '0' and _SPLIT
 # wide cells: forward over edge tiles (projected det rows staged in LDS); TMPNN_WIDE_TILED=0 keeps the per-row gathers
-WIDE_TILED = os.environ.get('TMPNN_WIDE_TILED', '1') != '0'
+WIDE_TILED = _variant('TMPNN_WIDE_TILED', '1') != '0'
 # H <= 64 edge cells: forward over 32-row edge tiles (projected det rows staged in LDS an item ahead); TMPNN_FWD_TILED=0
 # keeps the per-row gathers of tmpnn_gru_fwd (xmode 3)
-FWD_TILED = os.environ.get('TMPNN_FWD_TILED', '1') != '0' and os.environ.get('TMPNN_SPLIT', '1')[:1] != '0'
-# input transform in one launch per direction where every window adds few det rows (csrc/intf.hip); TMPNN_INPUT_TF=0 keeps
-# the staged launches of tmpnn_input_bn_*
+FWD_TILED = _variant('TMPNN_FWD_TILED', '1') != '0' and _SPLIT
 # rows per edge tile of the H <= 64 forward: 32 (k_gru_fwd_split_tiled, the default) or 16 (k_gru_fwd_split_t16, sixteen waves
 # per CU, stores straight from the accumulators: measured 7 % slower with the gate planes, 5 % faster without)
-FWD_TILE_ROWS = 16 if os.environ.get('TMPNN_FWD_TILE_ROWS', '32') == '16' else 32
-INPUT_TF = os.environ.get('TMPNN_INPUT_TF', '1') != '0'
+FWD_TILE_ROWS = 16 if _variant('TMPNN_FWD_TILE_ROWS', '32') == '16' else 32
+# input transform in one launch per direction where every window adds few det rows (csrc/intf.hip); TMPNN_INPUT_TF=0 keeps
+# the staged launches of tmpnn_input_bn_*
+INPUT_TF = _variant('TMPNN_INPUT_TF', '1') != '0'
 # Experiment ("save h only"): the H <= 64 edge cell's forward does not write its four gate planes; the
 # backward runs the forward kernel again into the gate planes (and a scratch state) right before the one-pass backward
 # reads them.  Same gradients bit for bit; measured SLOWER (numbers in DESIGN), so off by default.
-RECOMPUTE_GATES = os.environ.get('TMPNN_RECOMPUTE_GATES', '0') == '1'
-CONCAT_PROJ = os.environ.get('TMPNN_CONCAT_PROJ', '1') != '0'
-# wide cells: the det-side branch of the backward on a second stream next to the E-row matrix kernels (tmpnn_wide_gru_bwd_diff_aux)
-WIDE_OVERLAP = os.environ.get('TMPNN_WIDE_OVERLAP', '1') != '0'
-WIDE_FUSED_ADJOINT = os.environ.get('TMPNN_WIDE_FUSED_ADJOINT', '1') != '0'
+RECOMPUTE_GATES = _variant('TMPNN_RECOMPUTE_GATES', '0') == '1'
+CONCAT_PROJ = _variant('TMPNN_CONCAT_PROJ', '1') != '0'
+WIDE_FUSED_ADJOINT = _variant('TMPNN_WIDE_FUSED_ADJOINT', '1') != '0'
 _aux_streams: Dict[torch.device, 'torch.cuda.Stream'] = {}
 
 
