@@ -2722,6 +2722,7 @@ struct GruBwdFusedArgs {
     float* d_msg; int ld_dmsg; float* d_h; int ld_dh;
     const int32_t* add_src; const int32_t* add_dst; const float* add_msg; int ld_add;
     float* slab_w; float* slab_b;
+    int ld_wih;            // row stride of w_ih (= IN; the concat message's two halves are passed as column slices of [3H][2H])
 };
 
 __device__ __forceinline__ int dui_swz(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
@@ -3231,7 +3232,12 @@ __device__ __forceinline__ float4 two_ld4_nt(const float* p) {
 #ifndef TWO_EXP
 #define TWO_EXP 0          // build-time elimination experiments (1: no global requests, 2: no staging, 4: no MFMAs, 16: no epilogue stores)
 #endif
-template <int XMODE, int UP, bool FUSE>
+// XMODE 2 (round 4, the concat message [h[src] | h[dst]], IN = 2H): the cell's backward as TWO launches over column halves of
+// W_ih -- x = h[src[r]] alone, w_ih / d_msg / dW_ih pointing at the half -- the second with HHS = false: nothing of the W_hh
+// side leaves the kernel (no d_h, no dW_hh, no bias sums: the first launch has them).  Its W_hh-side waves still run their
+// products: skipping them on a wave-uniform branch cost 28-72 bytes of scratch inside the loop and made the launch SLOWER
+// than a full one (485 vs 383 us per 0.8 M rows) -- a scratch reload drains every row request in flight.
+template <int XMODE, int UP, bool FUSE, bool HHS = true>
 __global__ __launch_bounds__(512) void k_gru_bwd_two(GruBwdFusedArgs a, int ntiles) {
     constexpr int exp_ = TWO_EXP;
     constexpr int H = 64;
@@ -3265,12 +3271,13 @@ __global__ __launch_bounds__(512) void k_gru_bwd_two(GruBwdFusedArgs a, int ntil
     uint4 wq[6][3];
     {
         const float* W = role == 0 ? a.w_ih : a.w_hh;
+        const int ldw = role == 0 ? a.ld_wih : H;
 #pragma unroll
         for (int s6 = 0; s6 < 6; ++s6) {
             const int ch = s6 < 4 ? 4 * kq + s6 : 16 + 4 * (s6 - 4) + kq;      // 8-column chunk of the 192 gate columns
             float v[8];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) v[i] = W[(size_t)(8 * ch + i) * H + n0 + j16];
+            for (int i = 0; i < 8; ++i) v[i] = W[(size_t)(8 * ch + i) * ldw + n0 + j16];
             const Split8 sp = split8_arr(v);
             wq[s6][0] = sp.p1; wq[s6][1] = sp.p2; wq[s6][2] = sp.p3;
         }
@@ -3352,7 +3359,7 @@ __global__ __launch_bounds__(512) void k_gru_bwd_two(GruBwdFusedArgs a, int ntil
             half_put((img), SUB + st0, PA, tv);                                                              \
         } else if ((SL) == 5) {                                                                              \
             const float xa_[4] = {raw.xa.x, raw.xa.y, raw.xa.z, raw.xa.w}, xb_[4] = {raw.xb.x, raw.xb.y, raw.xb.z, raw.xb.w}; \
-            _Pragma("unroll") for (int i = 0; i < 4; ++i) o_[i] = XMODE != 0 ? xa_[i] - xb_[i] : xa_[i];     \
+            _Pragma("unroll") for (int i = 0; i < 4; ++i) o_[i] = XMODE == 1 ? xa_[i] - xb_[i] : xa_[i];     \
             half_put((img) + OFF_B, st0, PB, o_);                                                            \
             if (FUSE) {                                                                                      \
                 float4* ep_ = reinterpret_cast<float4*>(reinterpret_cast<float*>((img) + OFF_E) + se0);      \
@@ -3387,7 +3394,7 @@ __global__ __launch_bounds__(512) void k_gru_bwd_two(GruBwdFusedArgs a, int ntil
         if (XMODE == 0) raw.xa = *reinterpret_cast<const float4*>(a.msg + (size_t)(gs_) * a.ld_msg + f4);    \
         if (XMODE != 0) {                                                                                    \
             raw.xa = *reinterpret_cast<const float4*>(a.h + (size_t)(gs_) * a.ld_h + f4);                    \
-            raw.xb = *reinterpret_cast<const float4*>(a.h + (size_t)(gd_) * a.ld_h + f4);                    \
+            if (XMODE == 1) raw.xb = *reinterpret_cast<const float4*>(a.h + (size_t)(gd_) * a.ld_h + f4);    \
             if (FUSE) {                                                                                      \
                 raw.ea = *reinterpret_cast<const float4*>(a.add_msg + (size_t)(gs_) * a.ld_add + f4);        \
                 raw.eb = *reinterpret_cast<const float4*>(a.add_msg + (size_t)(gd_) * a.ld_add + f4);        \
@@ -3500,7 +3507,7 @@ __global__ __launch_bounds__(512) void k_gru_bwd_two(GruBwdFusedArgs a, int ntil
             acc[j] = mfma32_c<2>(aw, bt, acc[j]); acc[j] = mfma32_c<3>(aw, bt, acc[j]);
             acc[j] = mfma32_c<4>(aw, bt, acc[j]); acc[j] = mfma32_c<5>(aw, bt, acc[j]);
             } else { acc[j][0] += __uint_as_float(aw[0].x ^ bt[0].x ^ aw[1].y ^ bt[1].y ^ aw[2].z ^ bt[2].z); }
-            if (kb == tt && !(exp_ & 8)) {                      // bias gradient: column sums from the A operands (the two waves
+            if (HHS && kb == tt && !(exp_ & 8)) {               // bias gradient: column sums from the A operands (the two waves
                                                                 // that read the same A tiles take one 16-row block each)
 #pragma unroll
                 for (int pc = 0; pc < 3; ++pc) {
@@ -3558,7 +3565,7 @@ __global__ __launch_bounds__(512) void k_gru_bwd_two(GruBwdFusedArgs a, int ntil
                          make_float4(accd[0][0], accd[0][1], accd[0][2], accd[0][3]);
             if (el1) *reinterpret_cast<float4*>(a.d_msg + ((size_t)er1 * a.ld_dmsg + cofs)) =
                          make_float4(accd[1][0], accd[1][1], accd[1][2], accd[1][3]);
-        } else {
+        } else if (HHS) {
             const float* e = reinterpret_cast<const float*>(cur + OFF_E);
             const int cq = cofs >> 2;
             const float4 x0 = *reinterpret_cast<const float4*>(e + j16 * 64 + ((cq ^ j16) << 2));
@@ -3585,13 +3592,15 @@ __global__ __launch_bounds__(512) void k_gru_bwd_two(GruBwdFusedArgs a, int ntil
 #undef TWO_SLICE
     // ---- one slab per block: [3H][IN+H] weights, then [2][3H] biases
     float* sw = a.slab_w + (size_t)blockIdx.x * (3 * H) * (2 * H);
+    if (HHS || role == 0) {
 #pragma unroll
-    for (int j = 0; j < 3; ++j)
+        for (int j = 0; j < 3; ++j)
 #pragma unroll
-        for (int reg = 0; reg < 16; ++reg) {
-            const int jj = (jt0 + j) * 32 + acc_row(reg, half);
-            sw[(size_t)jj * (2 * H) + role * H + tt * 32 + c32] = acc[j][reg];
-        }
+            for (int reg = 0; reg < 16; ++reg) {
+                const int jj = (jt0 + j) * 32 + acc_row(reg, half);
+                sw[(size_t)jj * (2 * H) + role * H + tt * 32 + c32] = acc[j][reg];
+            }
+    }
     // bias slabs: wave (tt = 0) + wave (tt = 1) of the same A tiles, in that order, through the now idle LDS
     {
         float* red = lds;                                      // [8 waves][96]
@@ -3601,7 +3610,7 @@ __global__ __launch_bounds__(512) void k_gru_bwd_two(GruBwdFusedArgs a, int ntil
             if (half == 0) red[wave * 96 + j * 32 + c32] = tot;
         }
         __syncthreads();
-        if (tt == 0 && half == 0) {
+        if (HHS && tt == 0 && half == 0) {
             float* sb = a.slab_b + (size_t)blockIdx.x * 6 * H;
 #pragma unroll
             for (int j = 0; j < 3; ++j)
@@ -3635,6 +3644,30 @@ __global__ void k_gru_reduce_w(const float* __restrict__ slab_w, const float* __
         if (col < IN) dW_ih[(size_t)j * IN + col] += s;
         else dW_hh[(size_t)j * H + (col - IN)] += s;
     } else if (i < nW + (size_t)6 * H) {
+        const int b = (int)(i - nW);
+        float s = 0.f;
+        for (int k = 0; k < n_rs; ++k) s += slab_b[(size_t)k * 6 * H + b];
+        if (b < 3 * H) db_ih[b] += s;
+        else db_hh[b - 3 * H] += s;
+    }
+}
+
+// the same for one launch of a concat cell (slabs [3H][H | H], IN = H per launch): the W_ih block into the column half
+// dW_ih points at (row stride ld_dwih); the W_hh block and the biases only from the launch that computed them (full)
+__global__ void k_gru_reduce_w_half(const float* __restrict__ slab_w, const float* __restrict__ slab_b, int n_rs, int H,
+                                    float* __restrict__ dW_ih, int ld_dwih, float* __restrict__ dW_hh,
+                                    float* __restrict__ db_ih, float* __restrict__ db_hh, int full) {
+    const int XH = 2 * H;
+    const size_t nW = (size_t)3 * H * XH;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < nW) {
+        const int j = (int)(i / XH), col = (int)(i % XH);
+        if (col >= H && !full) return;
+        float s = 0.f;
+        for (int k = 0; k < n_rs; ++k) s += slab_w[(size_t)k * nW + i];
+        if (col < H) dW_ih[(size_t)j * ld_dwih + col] += s;
+        else dW_hh[(size_t)j * H + (col - H)] += s;
+    } else if (full && i < nW + (size_t)6 * H) {
         const int b = (int)(i - nW);
         float s = 0.f;
         for (int k = 0; k < n_rs; ++k) s += slab_b[(size_t)k * 6 * H + b];
@@ -3988,7 +4021,10 @@ static bool device_gives_160k() {
 }
 
 int tmpnn_gru_bwd_fused_available(int H, int IN, int xmode) {
-    return (H == 64 && IN == 64 && (xmode == 0 || xmode == 1) && device_gives_160k()) ? 1 : 0;
+#ifdef TMPNN_KEEP_VARIANTS
+    if (xmode == 2 && !fused_two_waves()) return 0;          // (the concat halves exist in the eight-wave form only)
+#endif
+    return (H == 64 && ((IN == 64 && (xmode == 0 || xmode == 1)) || (IN == 128 && xmode == 2)) && device_gives_160k()) ? 1 : 0;
 }
 
 size_t tmpnn_gru_bwd_fused_ws(int R, int IN, int H) {
@@ -3996,6 +4032,54 @@ size_t tmpnn_gru_bwd_fused_ws(int R, int IN, int H) {
     const int n = fused_blocks(R);
     const size_t per = (size_t)3 * H * (IN + H) + (size_t)6 * H;
     return ((size_t)n * per + reduce_slabs_ws_floats(n, per)) * sizeof(float);
+}
+
+// The concat cell (xmode 2, IN = 2H): [h[src] | h[dst]] W_ih^T = h[src] W1^T + h[dst] W2^T with W_ih = [W1 | W2], so its backward
+// is the single-endpoint cell twice: launch A over (src, W1) does everything a diff cell's launch does (d_h, dW_hh, biases, the
+// fused row-F adjoint) and writes d_msg[:, 0:H], dW_ih[:, 0:H]; launch B over (dst, W2) only the W_ih side into the other halves.
+static int gru_bwd_fused_concat(GruBwdFusedArgs a, int R, int H, const int32_t* src, const int32_t* dst, const float* w_ih,
+                                float* d_msg, float* dW_ih, float* dW_hh, float* db_ih, float* db_hh, float* fold, int up,
+                                bool fuse, hipStream_t st) {
+    const int n_rs = fused_blocks(R);
+    const int ntiles = ceil_div(R, 32);
+    const size_t shm = 163840;
+    const size_t nW = (size_t)3 * H * 2 * H, nB = (size_t)6 * H;
+    int rc;
+    for (int half = 0; half < 2; ++half) {
+        a.src = half == 0 ? src : dst;
+        a.dst = half == 0 ? dst : src;                      // (read by the fused adjoint of launch A only)
+        a.w_ih = w_ih + (size_t)half * H;
+        a.ld_wih = 2 * H;
+        a.d_msg = d_msg + (size_t)half * H;
+#define LC(U, F, S)                                                                                          \
+    do {                                                                                                     \
+        TM_SHM_ONCE((k_gru_bwd_two<2, U, F, S>), shm);                                                       \
+        hipLaunchKernelGGL((k_gru_bwd_two<2, U, F, S>), dim3(n_rs), dim3(512), shm, st, a, ntiles);          \
+    } while (0)
+#define LCU(F, S) do { if (up == 1) LC(1, F, S); else if (up == 2) LC(2, F, S); else LC(3, F, S); } while (0)
+        if (half == 0) { if (fuse) LCU(true, true); else LCU(false, true); }
+        else LCU(false, false);
+#undef LCU
+#undef LC
+        if ((rc = check_launch("gru_bwd_fused_concat"))) return rc;
+        const float* rw = a.slab_w;
+        const float* rb = a.slab_b;
+        int nred = n_rs;
+        if (n_rs > 64) {
+            const int ng = ceil_div(n_rs, 32);
+            float* fw = fold;
+            float* fb = fold + (size_t)ng * nW;
+            hipLaunchKernelGGL(k_fold_slabs_gru, dim3(ceil_div((long)nW, 256), ng), dim3(256), 0, st, a.slab_w, nW, n_rs, fw, nW);
+            if (half == 0)
+                hipLaunchKernelGGL(k_fold_slabs_gru, dim3(ceil_div((long)nB, 256), ng), dim3(256), 0, st, a.slab_b, nB, n_rs, fb, nB);
+            if ((rc = check_launch("gru_fold"))) return rc;
+            rw = fw; rb = fb; nred = ng;
+        }
+        hipLaunchKernelGGL(k_gru_reduce_w_half, dim3(ceil_div((long)(nW + nB), 256)), dim3(256), 0, st, rw, rb, nred, H,
+                           dW_ih + (size_t)half * H, 2 * H, dW_hh, db_ih, db_hh, half == 0 ? 1 : 0);
+        if ((rc = check_launch("gru_reduce_w_half"))) return rc;
+    }
+    return TMPNN_OK;
 }
 
 int tmpnn_gru_bwd_fused(const int32_t* rows, int R, int xmode, const int32_t* src, const int32_t* dst, const float* msg,
@@ -4029,12 +4113,20 @@ int tmpnn_gru_bwd_fused(const int32_t* rows, int R, int xmode, const int32_t* sr
     float* fold = slab_b + (size_t)n_rs * nB;
     GruBwdFusedArgs a{rows, R, src, dst, msg, ld_msg, msg_compact, h, ld_h, w_ih, w_hh, gates, gate_plane,
                       DhSrc{d_hout, ld_dhout, dy, w_head}, d_msg, ld_dmsg, d_h, ld_dh, add_src, add_dst, add_msg, ld_add,
-                      slab_w, slab_b};
+                      slab_w, slab_b, IN};
     const int ntiles = ceil_div(R, 32);
     const size_t shm = 163840;                               // two 80 KiB operand-image sets: the whole LDS of a CU
     hipStream_t st = as_stream(stream);
     const int up = (d_hout ? 1 : 0) | (dy ? 2 : 0);
     const bool fuse = add_msg != nullptr;
+    if (xmode == 2) {
+        TM_REQUIRE(ld_dmsg >= 2 * H, "gru_bwd_fused: the concat cell writes d_msg [.., 2H]");
+        // (the slab layout of a launch is the IN = H one; the fold area sits behind the larger IN = 2H reservation's slabs)
+        float* sb = slab_w + (size_t)n_rs * 3 * H * 2 * H;
+        a.slab_b = sb;
+        return gru_bwd_fused_concat(a, R, H, src, dst, w_ih, d_msg, dW_ih, dW_hh, db_ih, db_hh, sb + (size_t)n_rs * nB, up,
+                                    fuse, st);
+    }
 #ifdef TMPNN_KEEP_VARIANTS
 #define LF(X, U, F)                                                                                          \
     do {                                                                                                     \

@@ -390,9 +390,11 @@ def mp_forward(spec: ModelSpec, plan: CallPlan, x: torch.Tensor, h_in: Optional[
             proj = torch.empty((2 * Dn, 3 * H), **opts)
             _lib.call('tmpnn_rows_linear', g.det_row.data_ptr(), Dn, hg, GH, H, e_wih_t.data_ptr(), 3 * H,
                       proj.data_ptr(), 3 * H, st)
-            _lib.call('tmpnn_rows_linear', g.det_row.data_ptr(), Dn, hg, GH, H, e_wih_t.data_ptr() + 4 * H * 3 * H, 3 * H,
+            # (the kernel forms P[src] - P[dst]: the dst half of the table is projected with -W2^T -- negating H x 3H weights
+            #  instead of Dn x 3H projected rows)
+            w2n = _cached(('negt', e_wih_t.data_ptr(), H), (e_wih_t,), lambda: e_wih_t[H:].neg().contiguous())
+            _lib.call('tmpnn_rows_linear', g.det_row.data_ptr(), Dn, hg, GH, H, w2n.data_ptr(), 3 * H,
                       proj.data_ptr() + 4 * Dn * 3 * H, 3 * H, st)
-            proj[Dn:].neg_()                                  # (the kernel forms P[src] - P[dst])
             _lib.call('tmpnn_gru_fwd_tiles', edge_tiles(g, FWD_TILE_ROWS, dst_offset=Dn).cref(), E, proj.data_ptr(), 3 * H, hg, GH,
                       H, e_whh_t.data_ptr(), P[f + 'edge_gru.bias_ih'].data_ptr(), P[f + 'edge_gru.bias_hh'].data_ptr(),
                       og, GH, gp, plane, we_g, part_g, N, st)
