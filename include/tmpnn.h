@@ -462,6 +462,17 @@ int tmpnn_mp_iter_fwd(const tmpnn_mp_params* P, const float* prep, const tmpnn_d
                       const float* x, int ld_x, float* h, int training,
                       float* h_out, float* logits, float* scores, float* save, size_t save_floats,
                       tmpnn_stream stream);
+/* The same call in PARTS, for models with attention heads (K > 0, models/layers.py:105-112): the attention-weighted
+ * aggregate replaces the signed sum between the call's two launches.  parts: bit 0 = skip the input transform launch,
+ * bit 1 = skip the iteration launch, bit 2 = the aggregate es [G][N][H] (by det INDEX, the layout of the save buffer at
+ * tmpnn_mp_iter_save_es_offset floats) has been written by the caller -- tmpnn_att_fwd(out = save + offset + g N H,
+ * ld_out = H) on the state `h` that the input transform launch completed -- and the det tiles read it instead of forming
+ * the signed sum.  Sequence: parts = 2, tmpnn_att_fwd per feature group, parts = 1 | 4.  parts = 0 is tmpnn_mp_iter_fwd. */
+size_t tmpnn_mp_iter_save_es_offset(int N, int n_new, int G, int H);
+int tmpnn_mp_iter_fwd_parts(const tmpnn_mp_params* P, const float* prep, const tmpnn_dgraph* g, int n_new,
+                            const float* x, int ld_x, float* h, int training,
+                            float* h_out, float* logits, float* scores, float* save, size_t save_floats, int parts,
+                            tmpnn_stream stream);
 /* Backward of tmpnn_mp_iter_fwd.  d_scores / d_logits (N values each, element stride st_* >= 0; 0 = one broadcast
  * value, the gradient of a plain sum) and d_hout [N][G*H] may each be NULL.  Writes d_h
  * [N][G*H] (gradient of the h the iteration read: its first N - n_new rows are the gradient of the carried state)
@@ -474,6 +485,17 @@ int tmpnn_mp_iter_bwd(const tmpnn_mp_params* P, const float* prep, const tmpnn_d
                       const float* d_scores, int st_dscores, const float* d_logits, int st_dlogits,
                       const float* d_hout, float* d_h, float* d_x, const tmpnn_mp_params* grads,
                       void* ws, size_t ws_bytes, tmpnn_stream stream);
+/* ... in PARTS: bit 0 = skip the tile launch (d_h, d_msg = the first N * G * IN_e floats of ws, weight-gradient slabs),
+ * bit 1 = skip the finish launch (adjoints of the aggregations on the carried rows, slab reduction, input transform
+ * backward), bit 2 = the finish launch does NOT add the adjoint of the edge -> node sum to d_h's edge rows: the caller has
+ * -- tmpnn_att_bwd(d_out = ws + g IN_e, ld_dout = G IN_e, d_h + g H, ld_dh = G H) per feature group between the two.
+ * Sequence: parts = 2, tmpnn_att_bwd per group, parts = 1 | 4. */
+int tmpnn_mp_iter_bwd_parts(const tmpnn_mp_params* P, const float* prep, const tmpnn_dgraph* g, int n_new,
+                            const float* x, int ld_x, const float* h, const float* h_out, const float* scores,
+                            const float* save, int training,
+                            const float* d_scores, int st_dscores, const float* d_logits, int st_dlogits,
+                            const float* d_hout, float* d_h, float* d_x, const tmpnn_mp_params* grads,
+                            void* ws, size_t ws_bytes, int parts, tmpnn_stream stream);
 
 /* ======================================================================================================
  * Tracker-side graph maintenance on the device (csrc/trackops.hip).  Between two model

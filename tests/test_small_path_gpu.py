@@ -163,11 +163,13 @@ def _run_model(model, calls, small, monkeypatch, weights=None):
     return outs, grads, [x.grad.clone() for x in xs]
 
 
-@pytest.mark.parametrize('name', [n for n in golden_names() if '_k0_' in n or n.startswith(('roll_c', 'c1_'))])
+@pytest.mark.parametrize('name', [n for n in golden_names() if '_k0_' in n or n.startswith(('roll_c', 'c1_'))
+                                  or ('_k2_eval' in n and n.startswith('roll_'))])
 def test_fused_iteration_matches_staged_kernels(name, monkeypatch):
     """Same fixture, same model: the fused batch-1 iteration against the staged C-ABI stages (round 1's path), forward
     of every call + gradients of every parameter and of x.  Covers diff / concat, 1 and 3 feature groups, H 32 / 64,
-    train / eval, the C1 static window and the C2 / C3 / C4-size rolling windows."""
+    train / eval, the C1 static window, the C2 / C3 / C4-size rolling windows and -- round 4 -- the models with attention
+    heads (eval fixtures: the drawn dropout masks of a training call cannot be shared between two runs through model())."""
     from tests.test_parity_gpu import build_model
     gold = Golden(name)
     if gold.meta['nhidden'] not in (32, 64):
@@ -571,10 +573,11 @@ def test_native_node_outlives_the_python_side_caches():
 @pytest.mark.parametrize('desc,nhidden,heads,train', [('wide cells', 128, 0, True), ('padded width', 48, 0, True),
                                                       ('attention heads, eval', 64, 2, False)])
 def test_captured_window_records_models_outside_the_fused_path(desc, nhidden, heads, train):
-    """CapturedWindow on models the fused batch-1 iteration does not cover (attention heads, nhidden 128, a padded width):
-    the staged kernels on plans built before the capture.  A replay gives the gradients and the loss of the eager step
-    through model(x, h, node_adj, edge_adj) bit for bit (deterministic kernels; the attention model in eval mode, where no
-    dropout mask is drawn)."""
+    """CapturedWindow on models the plain fused batch-1 iteration does not cover: nhidden 128 and a padded width go through
+    the staged kernels on plans built before the capture; attention heads (round 4) through the fused iteration with the
+    attention stage between its two launches.  A replay gives the gradients and the loss of the eager step through
+    model(x, h, node_adj, edge_adj) bit for bit (deterministic kernels; the attention model in eval mode, where no dropout
+    mask is drawn)."""
     from trackmpnn_amd import CapturedWindow, TrackMPNN
     gold = Golden('roll_c2_kitti_car_w5')
     calls = []
@@ -611,7 +614,7 @@ def test_captured_window_records_models_outside_the_fused_path(desc, nhidden, he
     if train:                                                # (BatchNorm running statistics moved: start both from the same)
         model.load_state_dict(make().state_dict())
     win = CapturedWindow(model, calls, loss_fn, optimizer=None, bucket=None, warmup=2)
-    assert win.staged
+    assert win.staged == (heads == 0)
     first = win.replay().item()                              # (the returned tensor is static: read it before the next replay)
     assert first == loss_ref.item()
     for (k, p), (_, q) in zip(model.named_parameters(), ref.named_parameters()):
@@ -645,3 +648,47 @@ def test_captured_window_draws_fresh_attention_dropout_per_replay():
     win = CapturedWindow(model, calls, loss_fn, optimizer=None, bucket=None, warmup=2)
     a, b = win.replay().item(), win.replay().item()
     assert np.isfinite(a) and np.isfinite(b) and a != b
+
+
+@pytest.mark.parametrize('name', ['roll_2d_diff_k2_train', 'roll_2d_concat_k2_train', 'roll_2d-temp-vis_concat_k2_train',
+                                  'roll_2d_diff_k2_eval', 'roll_2d-temp-vis_diff_k2_eval'])
+def test_fused_iteration_with_attention_heads_matches_the_reference(name):
+    """Models with attention heads through the batch-1 path (tmpnn_mp_iter_*_parts with the attention stage between the two
+    launches): every call of the reference's fixture (its drawn dropout mask injected), scores / logits / state, the
+    attention values, and every parameter / input gradient -- same tolerances as the staged path against the fixtures."""
+    from tests.test_parity_gpu import build_model
+    from trackmpnn_amd.graph import device_graph_from_adjacency
+    gold = Golden(name)
+    m = gold.meta
+    model = build_model(m, gold.params())
+    assert model._small.att and model._small.eligible
+    G = len(model.spec.groups)
+    h, loss, xs = None, 0.0, []
+    for c in range(gold.ncalls):
+        x = gold.t(f'c{c}/x').to(DEV).requires_grad_(True)
+        xs.append(x)
+        dg = device_graph_from_adjacency(gold.adjacency(c, 'node_adj', DEV), gold.adjacency(c, 'edge_adj', DEV), DEV)
+        fg = dg.frame_graph()
+        keep = None
+        if m['mode'] == 'train':
+            e, ep = fg.inc_edge_endpoint()
+            keep = [gold.t(f'c{c}/keep_g{g}').to(DEV)[:, e, ep].contiguous() for g in range(G)]
+        s, l, h, att = model.forward_dgraph(x, h, dg, dropout_keep=keep)
+        assert (s.detach().cpu() - gold.t(f'c{c}/scores')).abs().max().item() <= 1e-4, f'scores call {c}'
+        assert torch.allclose(l.detach().cpu(), gold.t(f'c{c}/logits'), atol=2e-4, rtol=2e-5), f'logits call {c}'
+        assert torch.allclose(h.detach().cpu(), gold.t(f'c{c}/h_out'), atol=2e-4, rtol=2e-5), f'h_out call {c}'
+        for g in range(G):
+            for k in range(m['nattheads']):
+                got = att[g][k].per_edge().cpu()                         # [E, 2]: (src side, dst side)
+                assert torch.allclose(got, gold.t(f'c{c}/att_g{g}_k{k}'), atol=1e-5, rtol=1e-4), (c, g, k)
+        loss = loss + (gold.t(f'c{c}/wl').to(DEV) * l).sum() + (gold.t(f'c{c}/ws').to(DEV) * s).sum()
+    loss = loss + (gold.t('V').to(DEV) * h).sum()
+    loss.backward()
+    grads = gold.grads()
+    gscale = max(1.0, max(v.abs().max().item() for k, v in grads.items() if k != 'X'))
+    for k, p in model.named_parameters():
+        tol = 2e-4 * gscale
+        if m['mode'] == 'train' and k.startswith('input_transforms.') and k.endswith('.0.bias'):
+            tol = 2e-3 * gscale      # exactly-zero true gradient (BatchNorm removes the mean): cancellation noise
+        err = (p.grad.cpu() - grads[k]).abs().max().item()
+        assert err <= tol, f'grad {k}: {err} > {tol}'

@@ -198,6 +198,12 @@ _SIGNATURES = {
     'tmpnn_mp_iter_save_floats': (c_size_t, [c_int, c_int, c_int, c_int]),
     'tmpnn_mp_iter_fwd': (c_int, [_MPP, c_void_p, _DGP, c_int, c_void_p, c_int, c_void_p, c_int,
                                   c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    'tmpnn_mp_iter_save_es_offset': (c_size_t, [c_int, c_int, c_int, c_int]),
+    'tmpnn_mp_iter_fwd_parts': (c_int, [_MPP, c_void_p, _DGP, c_int, c_void_p, c_int, c_void_p, c_int,
+                                        c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
+    'tmpnn_mp_iter_bwd_parts': (c_int, [_MPP, c_void_p, _DGP, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                                        c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, _MPP, c_void_p,
+                                        c_size_t, c_int, c_void_p]),
     'tmpnn_mp_iter_bwd_ws': (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
     'tmpnn_mp_iter_bwd': (c_int, [_MPP, c_void_p, _DGP, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                   c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, _MPP, c_void_p,

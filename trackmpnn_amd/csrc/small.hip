@@ -246,6 +246,8 @@ struct IterFwdArgs {
     float* logits; float* scores;
     float* gates;              // [G][4][N][H] or NULL
     float* es;                 // [G][N][H]   or NULL (nothing saved)
+    int es_given;              // != 0: es already holds the edge -> node aggregate of every det (the attention stage wrote it:
+                               // tmpnn_att_fwd between the two launches of tmpnn_mp_iter_fwd_parts); det tiles read it
 };
 
 // gi/gh MFMA loop of one column slice: acc[gate] += A(tile rows, K = W) x image.  The weight operands (3 gates x W/16
@@ -352,6 +354,9 @@ __global__ __launch_bounds__(256) void k_small_iter_fwd(IterFwdArgs a) {
                     x0 = *reinterpret_cast<const float4*>(hg + (size_t)sS[row] * GH + 4 * c4);
                     x1 = *reinterpret_cast<const float4*>(hg + (size_t)sD[row] * GH + 4 * c4);
                     if (IN_E == H) { x0.x -= x1.x; x0.y -= x1.y; x0.z -= x1.z; x0.w -= x1.w; }
+                } else if (a.es_given) {
+                    // attention-weighted aggregate (models/layers.py:105-112), computed by tmpnn_att_fwd into the save area
+                    x0 = *reinterpret_cast<const float4*>(a.es + ((size_t)gi * N + (r0 + row)) * H + 4 * c4);
                 } else {
                     // edge -> node aggregation (models/layers.py:103): signed sum over the det's incident edge rows,
                     // CSR order (ascending edge row), four rows in flight
@@ -738,6 +743,8 @@ struct FinishArgs {
     const int* newdet;         // [G][n_new + 1]
     float* d_x;                // [n_new][F_total] or NULL
     float* scratch;            // [G][2][n_new][H]: used when the new det rows do not fit the LDS
+    int skip_row_f;            // != 0: the adjoint of the edge -> node aggregation has been added to d_h already (tmpnn_att_bwd
+                               // between the two launches of tmpnn_mp_iter_bwd_parts)
 };
 
 // gradient of the iteration's input state at row `row`, group gi, columns 4 c4 ..: what k_small_iter_bwd wrote
@@ -751,9 +758,11 @@ __device__ __forceinline__ float4 adjoint_at(const FinishArgs& a, int row, int g
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     if (a.g.is_edge[row]) {
         // adjoint of row F: d h[e] += d_es[src(e)] - d_es[dst(e)]   (d_es = the node cell's d_x, stored at det rows)
-        const float4 u = *reinterpret_cast<const float4*>(dm + (size_t)a.g.src[p] * ldm);
-        const float4 v = *reinterpret_cast<const float4*>(dm + (size_t)a.g.dst[p] * ldm);
-        acc = make_float4(u.x - v.x, u.y - v.y, u.z - v.z, u.w - v.w);
+        if (!a.skip_row_f) {
+            const float4 u = *reinterpret_cast<const float4*>(dm + (size_t)a.g.src[p] * ldm);
+            const float4 v = *reinterpret_cast<const float4*>(dm + (size_t)a.g.dst[p] * ldm);
+            acc = make_float4(u.x - v.x, u.y - v.y, u.z - v.z, u.w - v.w);
+        }
     } else {
         // adjoint of row E: d h[d] += sum_{e: src=d} d_x[e][0:H] -/+ sum_{e: dst=d} d_x[e][0:H | H:2H]; CSR order
         const int p0 = a.g.rowptr[p], p1 = a.g.rowptr[p + 1];
@@ -1112,9 +1121,20 @@ size_t tmpnn_mp_iter_save_floats(int N, int n_new, int G, int H) {
     return save_layout(N, n_new, G, H).total + (size_t)G * (n_new + 1) + 4;
 }
 
+size_t tmpnn_mp_iter_save_es_offset(int N, int n_new, int G, int H) {
+    if (N < 0 || n_new < 0 || G <= 0 || H <= 0) return 0;
+    return save_layout(N, n_new, G, H).es;
+}
+
 int tmpnn_mp_iter_fwd(const tmpnn_mp_params* P, const float* prep, const tmpnn_dgraph* g, int n_new, const float* x,
                       int ld_x, float* h, int training, float* h_out, float* logits, float* scores, float* save,
                       size_t save_floats, tmpnn_stream stream) {
+    return tmpnn_mp_iter_fwd_parts(P, prep, g, n_new, x, ld_x, h, training, h_out, logits, scores, save, save_floats, 0, stream);
+}
+
+int tmpnn_mp_iter_fwd_parts(const tmpnn_mp_params* P, const float* prep, const tmpnn_dgraph* g, int n_new, const float* x,
+                            int ld_x, float* h, int training, float* h_out, float* logits, float* scores, float* save,
+                            size_t save_floats, int parts, tmpnn_stream stream) {
     int rc = check_params(P, "mp_iter_fwd", false);
     if (rc) return rc;
     if ((rc = check_dgraph(g, "mp_iter_fwd"))) return rc;
@@ -1134,7 +1154,9 @@ int tmpnn_mp_iter_fwd(const tmpnn_mp_params* P, const float* prep, const tmpnn_d
         TM_REQUIRE(aligned16(save), "mp_iter_fwd: save must be 16-byte aligned");
     }
     hipStream_t st = as_stream(stream);
-    if (n_new > 0) {
+    TM_REQUIRE((parts & ~7) == 0 && (!(parts & 4) || sv != nullptr), "mp_iter_fwd_parts: parts=%d (an aggregate given by the "
+               "caller lives in the save buffer)", parts);
+    if (n_new > 0 && !(parts & 1)) {
         TM_REQUIRE(sv != nullptr, "mp_iter_fwd: a call with new rows needs the save buffer (the input transform keeps its "
                                   "Lin1 outputs and statistics there), also in inference");
         BnFwdArgs b{*P, *g, n_new, training, x, ld_x, h, sv + SL.ysave, sv + SL.mean, sv + SL.rstd,
@@ -1144,7 +1166,9 @@ int tmpnn_mp_iter_fwd(const tmpnn_mp_params* P, const float* prep, const tmpnn_d
         else hipLaunchKernelGGL((k_small_bn_fwd<32>), dim3(G), dim3(256), shm, st, b);
         if ((rc = check_launch("small_bn_fwd"))) return rc;
     }
-    IterFwdArgs a{*P, *g, prep, h, h_out, logits, scores, sv ? sv + SL.gates : nullptr, sv ? sv + SL.es : nullptr};
+    if (parts & 2) return TMPNN_OK;
+    IterFwdArgs a{*P, *g, prep, h, h_out, logits, scores, sv ? sv + SL.gates : nullptr, sv ? sv + SL.es : nullptr,
+                  (parts & 4) ? 1 : 0};
     const int grid = (N + TR - 1) / TR + 2;
     if (H == 64 && P->IN_e == 64) hipLaunchKernelGGL((k_small_iter_fwd<64, 64>), dim3(grid), dim3(256), 0, st, a);
     else if (H == 64) hipLaunchKernelGGL((k_small_iter_fwd<64, 128>), dim3(grid), dim3(256), 0, st, a);
@@ -1172,6 +1196,15 @@ int tmpnn_mp_iter_bwd(const tmpnn_mp_params* P, const float* prep, const tmpnn_d
                       int ld_x, const float* h, const float* h_out, const float* scores, const float* save,
                       int training, const float* d_scores, int st_dscores, const float* d_logits, int st_dlogits,
                       const float* d_hout, float* d_h, float* d_x, const tmpnn_mp_params* grads, void* ws, size_t ws_bytes, tmpnn_stream stream) {
+    return tmpnn_mp_iter_bwd_parts(P, prep, g, n_new, x, ld_x, h, h_out, scores, save, training, d_scores, st_dscores, d_logits,
+                                   st_dlogits, d_hout, d_h, d_x, grads, ws, ws_bytes, 0, stream);
+}
+
+int tmpnn_mp_iter_bwd_parts(const tmpnn_mp_params* P, const float* prep, const tmpnn_dgraph* g, int n_new, const float* x,
+                            int ld_x, const float* h, const float* h_out, const float* scores, const float* save,
+                            int training, const float* d_scores, int st_dscores, const float* d_logits, int st_dlogits,
+                            const float* d_hout, float* d_h, float* d_x, const tmpnn_mp_params* grads, void* ws, size_t ws_bytes,
+                            int parts, tmpnn_stream stream) {
     int rc = check_params(P, "mp_iter_bwd", false);
     if (rc) return rc;
     if ((rc = check_params(grads, "mp_iter_bwd (grads)", true))) return rc;
@@ -1194,6 +1227,8 @@ int tmpnn_mp_iter_bwd(const tmpnn_mp_params* P, const float* prep, const tmpnn_d
     float* bn_scratch = slabs + (size_t)nb * G * slab_floats(H, IN_e);
     hipStream_t st = as_stream(stream);
     TM_REQUIRE(st_dscores >= 0 && st_dlogits >= 0, "mp_iter_bwd: negative gradient stride");
+    TM_REQUIRE((parts & ~7) == 0, "mp_iter_bwd_parts: parts=%d", parts);
+    if (!(parts & 1)) {
     IterBwdArgs a{*P, *g, prep, h, scores, save + SL.gates, save + SL.es, d_scores, d_logits, d_hout, st_dscores, st_dlogits,
                   d_h, d_msg, slabs};
     if (H == 64 && IN_e == 64) hipLaunchKernelGGL((k_small_iter_bwd<64, 64>), dim3(nb), dim3(256), 0, st, a);
@@ -1201,6 +1236,8 @@ int tmpnn_mp_iter_bwd(const tmpnn_mp_params* P, const float* prep, const tmpnn_d
     else if (IN_e == 32) hipLaunchKernelGGL((k_small_iter_bwd<32, 32>), dim3(nb), dim3(256), 0, st, a);
     else hipLaunchKernelGGL((k_small_iter_bwd<32, 64>), dim3(nb), dim3(256), 0, st, a);
     if ((rc = check_launch("small_iter_bwd"))) return rc;
+    }
+    if (parts & 2) return TMPNN_OK;
     const int rpb = 256 / (H / 4);
     int row_blocks = (N - n_new + rpb - 1) / rpb;
     if (row_blocks > 256) row_blocks = 256;
@@ -1212,7 +1249,7 @@ int tmpnn_mp_iter_bwd(const tmpnn_mp_params* P, const float* prep, const tmpnn_d
     if (n_new > 0) TM_REQUIRE(x != nullptr && ld_x >= P->F_total, "mp_iter_bwd: x");
     FinishArgs f{*P, *grads, *g, d_msg, d_h, slabs, nb, row_blocks, red_blocks, n_new, training, x, ld_x,
                  save + SL.ysave, save + SL.mean, save + SL.rstd, reinterpret_cast<const int*>(save + SL.total), d_x,
-                 bn_scratch};
+                 bn_scratch, (parts & 4) ? 1 : 0};
     const size_t shm = sizeof(float) * (2 * BN_LDS_ROWS * (H + 1) + bn_stage_floats(H));
     const dim3 fgrid(row_blocks + red_blocks + bn_blocks);
 #define LF(HH, II)                                                                                           \

@@ -66,7 +66,11 @@ class SmallPath:
         spec = model.spec
         self.spec = spec
         self.names: List[str] = spec.param_names()
-        self.eligible = spec.K == 0 and spec.H in (32, 64)
+        self.eligible = spec.H in (32, 64)
+        # attention heads (K > 0): the same two launches per direction with the attention stage (tmpnn_att_fwd / _bwd) between
+        # them (tmpnn_mp_iter_*_parts) -- through the Python node below; the C++ node serves K = 0
+        self.att = spec.K > 0
+        self.f_fwd_parts = self.f_bwd_parts = None
         self._ptr_key = None
         self._ver_key = None
         self.cparams = None
@@ -105,6 +109,7 @@ class SmallPath:
         and version counters."""
         if self.f_fwd is None:
             self.f_fwd, self.f_bwd = _lib.fn('tmpnn_mp_iter_fwd'), _lib.fn('tmpnn_mp_iter_bwd')
+            self.f_fwd_parts, self.f_bwd_parts = _lib.fn('tmpnn_mp_iter_fwd_parts'), _lib.fn('tmpnn_mp_iter_bwd_parts')
         k = self._ptr_key
         if k is not None and (plist[0].data_ptr() != k[0] or plist[-1].data_ptr() != k[-1]):
             self.invalidate()                # storage replaced behind our back (p.data = ...): cheap sentinel check
@@ -272,15 +277,26 @@ class _SmallIter(torch.autograd.Function):
         scores = torch.empty((N, 1), **opts)
         save = None
         nsave = 0
-        if need_grad or n > 0:
+        if need_grad or n > 0 or sp.att:
             nsave = save_floats(N, n, G, H)
             save = torch.empty((nsave,), **opts)
-        rc = sp.f_fwd(C.byref(cp), sp.prep.data_ptr(), dg.cref(), n, xd.data_ptr() if n > 0 else None,
-                  int(xd.shape[1]) if n > 0 else 0, h_cat.data_ptr(), int(training), h_out.data_ptr(), logits.data_ptr(),
-                  scores.data_ptr(), _lib.ptr(save), nsave, _stream())
+        fargs = (C.byref(cp), sp.prep.data_ptr(), dg.cref(), n, xd.data_ptr() if n > 0 else None,
+                 int(xd.shape[1]) if n > 0 else 0, h_cat.data_ptr(), int(training), h_out.data_ptr(), logits.data_ptr(),
+                 scores.data_ptr(), _lib.ptr(save), nsave)
+        att = None
+        if not sp.att:
+            rc = sp.f_fwd(*fargs, _stream())
+        else:
+            # attention heads: input transform | tmpnn_att_fwd per feature group (its aggregate lands in the save buffer's
+            # es area, where the det tiles of the iteration launch read it) | iteration
+            rc = sp.f_fwd_parts(*fargs, 2, _stream())
+            if not rc:
+                att = _att_forward(sp, call, dg, h_cat, save, N, n, training)
+                rc = sp.f_fwd_parts(*fargs, 1 | 4, _stream())
         if rc:
             raise RuntimeError(f'tmpnn_mp_iter_fwd failed (code {rc}): {_lib.last_error()}')
         ctx.call = call
+        ctx.att = att if need_grad else None
         ctx.saved = (xd, h_cat, h_out, scores, save, cp) if need_grad else None
         ctx.has_h = h_in is not None
         ctx.n = n
@@ -340,10 +356,19 @@ class _SmallIter(torch.autograd.Function):
         d_x = torch.empty((n, spec.F_total), **opts) if need_x else None
         wsb = bwd_ws_bytes(N, n, G, H, spec.IN_e)
         ws = torch.empty((wsb // 4 + 4,), **opts)
-        rc = sp.f_bwd(C.byref(cp), sp.prep.data_ptr(), dg.cref(), n, xd.data_ptr() if n > 0 else None,
-                  int(xd.shape[1]) if n > 0 else 0, h_cat.data_ptr(), h_out.data_ptr(), scores.data_ptr(), save.data_ptr(),
-                  int(call['training']), _lib.ptr(ds), st_ds, _lib.ptr(dl), st_dl, _lib.ptr(dh), d_h.data_ptr(), _lib.ptr(d_x),
-                  C.byref(gst), ws.data_ptr(), wsb, _stream())
+        bargs = (C.byref(cp), sp.prep.data_ptr(), dg.cref(), n, xd.data_ptr() if n > 0 else None,
+                 int(xd.shape[1]) if n > 0 else 0, h_cat.data_ptr(), h_out.data_ptr(), scores.data_ptr(), save.data_ptr(),
+                 int(call['training']), _lib.ptr(ds), st_ds, _lib.ptr(dl), st_dl, _lib.ptr(dh), d_h.data_ptr(), _lib.ptr(d_x),
+                 C.byref(gst), ws.data_ptr(), wsb)
+        if not sp.att:
+            rc = sp.f_bwd(*bargs, _stream())
+        else:
+            # tiles (d_h, d_x of every row at the head of ws) | tmpnn_att_bwd per feature group | finish without the row-F adjoint
+            rc = sp.f_bwd_parts(*bargs, 2, _stream())
+            if not rc:
+                _att_backward(sp, ctx.att, dg, h_cat, ws, d_h, dict(zip(names, gts)))
+                rc = sp.f_bwd_parts(*bargs, 1 | 4, _stream())
+            ctx.att = None
         if rc:
             raise RuntimeError(f'tmpnn_mp_iter_bwd failed (code {rc}): {_lib.last_error()}')
         if need[1] and d_x is None:
@@ -353,6 +378,71 @@ class _SmallIter(torch.autograd.Function):
             return (None, d_x, d_h_in, None)
         named = dict(zip(names, objs))
         return (None, d_x, d_h_in) + tuple(g.view(named[nm].shape) for nm, g in zip(names, gts))
+
+
+def _att_forward(sp: 'SmallPath', call: dict, dg: DeviceGraph, h_cat: torch.Tensor, save: torch.Tensor, N: int, n: int,
+                 training: bool):
+    """tmpnn_att_fwd per feature group on the state the input transform launch completed; the aggregate goes straight into
+    the save buffer's es area ([G][N][H] by det index).  Returns what the backward needs + the attention values."""
+    from . import functional as F_
+    spec = sp.spec
+    H, G, K = spec.H, spec.G, spec.K
+    GH = G * H
+    fg = dg.frame_graph()                      # (host-side E / Dn: the attention launches are sized from them)
+    E, Dn = fg.E, fg.Dn
+    dev = h_cat.device
+    opts = dict(dtype=torch.float32, device=dev)
+    named = dict(zip(sp.names, call['param_objs']))
+    erec, inc_other = fg.att_index() if E > 0 else (None, None)
+    es_off = G * 4 * N * H                     # tmpnn_mp_iter_save_es_offset restated (tests/test_abi.py)
+    keep = call.get('keep')
+    st = _stream()
+    out, alphas = [], []
+    for gi in range(G):
+        f = f'factor_grus.{gi}.'
+        Ws = [named[f + f'gat.{k}.W_att'].detach() for k in range(K)]
+        As = [named[f + f'gat.{k}.a'].detach() for k in range(K)]
+        W = F_._cached(('attW', tuple(t.data_ptr() for t in Ws)), tuple(Ws), lambda: torch.cat(Ws, 1).contiguous())
+        a = F_._cached(('atta', tuple(t.data_ptr() for t in As)), tuple(As),
+                       lambda: torch.stack([t.reshape(-1) for t in As]).contiguous())
+        ha = torch.empty((max(Dn, 1), K * H), **opts)
+        score = torch.empty((max(2 * E, 1), K), **opts)
+        stats = torch.empty((max(Dn, 1), K, 2), **opts)
+        esk = torch.empty((K, max(Dn, 1), H), **opts)
+        alpha = torch.empty((K, max(2 * E, 1)), **opts)
+        kp = F_._keep_bits(None if keep is None else keep[gi], K, 2 * E, dev) if training else None
+        _lib.call('tmpnn_att_fwd', fg.cref(), _lib.ptr(erec), h_cat.data_ptr() + 4 * gi * H, GH, H, K, W.data_ptr(), a.data_ptr(),
+                  _lib.ptr(kp), F_.ATT_DROPOUT_P, ha.data_ptr(), score.data_ptr(), stats.data_ptr(), esk.data_ptr(),
+                  alpha.data_ptr(), save.data_ptr() + 4 * (es_off + gi * N * H), H, st)
+        out.append((W, a, kp, ha, score, stats, esk))
+        alphas.append([alpha[k, :2 * E] for k in range(K)])
+    call['alphas'] = alphas
+    return (fg, erec, inc_other, out)
+
+
+def _att_backward(sp: 'SmallPath', att, dg: DeviceGraph, h_cat: torch.Tensor, ws: torch.Tensor, d_h: torch.Tensor, grads: dict):
+    """tmpnn_att_bwd per feature group between the two launches of the iteration's backward: d_es is read from the det rows
+    of the tile launch's d_x (the head of ws), d_h and the heads' gradient buffers are accumulated in place."""
+    from . import functional as F_
+    spec = sp.spec
+    H, G, K, IN_e = spec.H, spec.G, spec.K, spec.IN_e
+    GH = G * H
+    fg, erec, inc_other, per_group = att
+    E, Dn = fg.E, fg.Dn
+    lib = _lib.load()
+    st = _stream()
+    wsn = int(lib.tmpnn_att_bwd_ws(E, Dn, H, K))
+    ws_att = torch.empty((max(wsn, 1),), dtype=torch.float32, device=h_cat.device)
+    for gi, (W, a, kp, ha, score, stats, esk) in enumerate(per_group):
+        f = f'factor_grus.{gi}.'
+        gW = [grads[f + f'gat.{k}.W_att'] for k in range(K)]
+        ga = [grads[f + f'gat.{k}.a'] for k in range(K)]
+        pW = (C.c_void_p * K)(*[t.data_ptr() for t in gW])
+        pa = (C.c_void_p * K)(*[t.data_ptr() for t in ga])
+        _lib.call('tmpnn_att_bwd_heads', fg.cref(), _lib.ptr(erec), _lib.ptr(inc_other), h_cat.data_ptr() + 4 * gi * H, GH, H, K,
+                  W.data_ptr(), a.data_ptr(), _lib.ptr(kp), F_.ATT_DROPOUT_P, ha.data_ptr(), score.data_ptr(), stats.data_ptr(),
+                  esk.data_ptr(), ws.data_ptr() + 4 * gi * IN_e, G * IN_e, ws_att.data_ptr(), ws_att.numel(),
+                  d_h.data_ptr() + 4 * gi * H, GH, C.cast(pW, C.c_void_p), C.cast(pa, C.c_void_p), st)
 
 
 def save_floats(N: int, n: int, G: int, H: int) -> int:

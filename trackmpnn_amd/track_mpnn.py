@@ -326,16 +326,17 @@ class TrackMPNN(nn.Module):
         for g in pending:
             g.check()
 
-    def forward_dgraph(self, x: torch.Tensor, h_in: Optional[torch.Tensor], graph: DeviceGraph):
-        """One message-passing call on a DeviceGraph: the fused iteration (K = 0, H in {32, 64}), the staged kernels for
-        every other model."""
+    def forward_dgraph(self, x: torch.Tensor, h_in: Optional[torch.Tensor], graph: DeviceGraph,
+                       dropout_keep: Optional[Sequence[torch.Tensor]] = None):
+        """One message-passing call on a DeviceGraph: the fused iteration (H in {32, 64}; with attention heads the attention
+        stage runs between its two launches), the staged kernels for every other model.  dropout_keep: as forward_graph."""
         if not x.is_cuda:
             raise RuntimeError(f'x is on {x.device}: trackmpnn_amd runs on the MI355X HIP kernels only '
                                '(no CPU or torch fallback exists)')
         if self._padded or not small_eligible(self, graph.N):
             # models the fused iteration does not cover (attention heads, nhidden >= 128, padded widths): the staged kernels
             # on the same device-resident graph (frame_graph() reads E and Dn back: their launch sizes are host values)
-            return self.forward_graph(x, h_in, plan_single(graph.frame_graph(), int(x.shape[0])))
+            return self.forward_graph(x, h_in, plan_single(graph.frame_graph(), int(x.shape[0])), dropout_keep=dropout_keep)
         if self._plist is None:
             named = dict(self.named_parameters())
             self._plist = [named[nm] for nm in self.spec.param_names()]
@@ -369,11 +370,12 @@ class TrackMPNN(nn.Module):
         if append:
             h_in._tmpnn_consumed = True
         call = dict(small=self._small, graph=graph, training=self.training, need_grad=need_grad, spare=spare, append=append,
-                    param_objs=params, anchored=anchored, check_pending=self.check_graphs)
+                    param_objs=params, anchored=anchored, check_pending=self.check_graphs, keep=dropout_keep)
+        att = self._small.att                  # attention heads: the Python node (it sequences the attention stage)
         if anchored:
             if self._anchor is None or self._anchor.device != x.device:
                 self._anchor = torch.zeros(1, device=x.device, requires_grad=True)
-            fast = fast_module()
+            fast = fast_module() if not att else None
             if fast is not None and graph.cap == graph.N:
                 # C++ autograd node (csrc_host/fast_iter.cpp): same kernels, no interpreter between the allocations
                 sp = self._small
@@ -381,7 +383,7 @@ class TrackMPNN(nn.Module):
                 scores, logits, h_out = fast.small_iter(x, h_in, self._anchor, graph.arena, info, sp.keep(self._gst))
             else:
                 scores, logits, h_out = _SmallIter.apply(call, x, h_in, self._anchor)
-        elif pgrad and fast_module() is not None and graph.cap == graph.N and all(p.requires_grad for p in params):
+        elif not att and pgrad and fast_module() is not None and graph.cap == graph.N and all(p.requires_grad for p in params):
             # default gradient semantics on the native node: one gradient SINK per set of parameter values (a fresh one
             # whenever a parameter's version counter moved, i.e. after every optimizer step)
             sp = self._small
@@ -393,7 +395,7 @@ class TrackMPNN(nn.Module):
             info = sp.fast_info(params, graph, tmpl, self.training, need_grad, append, spare, sink_total=total)
             scores, logits, h_out = fast_module().small_iter(x, h_in, self._sink, graph.arena, info, sp.keep())
         else:
-            fast = fast_module() if not need_grad else None
+            fast = fast_module() if not (need_grad or att) else None
             if fast is not None and graph.cap == graph.N:
                 # inference (nothing needs a gradient): the native node as well -- it saves nothing and records nothing
                 # (under no_grad: with grad mode on and a frozen model the node would otherwise hand back outputs that
@@ -413,6 +415,9 @@ class TrackMPNN(nn.Module):
             for t in (scores, logits, h_out):
                 if t.requires_grad:
                     t.register_hook(self._check_graphs_hook)
+        if att:
+            fg = graph.frame_graph()
+            return scores, logits, h_out, tuple([SparseAttention(fg, ak) for ak in a] for a in call['alphas'])
         return scores, logits, h_out, (None,) * self.spec.G
 
     def _check_graphs_hook(self, grad):
