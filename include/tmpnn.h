@@ -142,6 +142,10 @@ int tmpnn_att_fwd(const tmpnn_graph* g, const int32_t* erec, const float* h, int
  * versa), bit 31 set on dst-side positions.  One edge-owned pass (reads h[row e] once, updates d_h[row e]) + one det-owned
  * pass over the projected det table + two Dn-row GEMMs. */
 size_t tmpnn_att_bwd_ws(int E, int Dn, int H, int K);
+/* erec [E][8] and inc_other [2E] of the two calls above from the graph's own arrays, in one launch.  pos [N]: row -> index
+ * within its type (edge index for edge rows); src_pos / dst_pos [E]: det indices of an edge's endpoints. */
+int tmpnn_att_index(const tmpnn_graph* g, const int32_t* pos, const int32_t* src_pos, const int32_t* dst_pos,
+                    int32_t* erec, int32_t* inc_other, tmpnn_stream stream);
 int tmpnn_att_bwd(const tmpnn_graph* g, const int32_t* erec, const int32_t* inc_other,
                   const float* h, int ld_h, int H, int K,
                   const float* W_cat, const float* a, const uint8_t* keep, float p_drop,

@@ -444,6 +444,9 @@ def check_attention(H, K, training, g, gd):
               W.data_ptr(), a.data_ptr(), _lib.ptr(keepD), 0.5, ws_ha.data_ptr(), score.data_ptr(), stats.data_ptr(),
               esk.data_ptr(), alpha.data_ptr(), out.data_ptr(), H, st())
     res = {'es': (out.cpu() - es[dr].detach()).abs().max().item()}
+    # the one-launch index arrays (tmpnn_att_index) against the torch index ops on the host copy of the graph
+    erec_h, other_h = g.att_index()
+    res['att_index bits'] = float(not (torch.equal(erec.cpu()[:g.E, :7], erec_h[:g.E, :7]) and torch.equal(inc_other.cpu()[:2 * g.E], other_h[:2 * g.E])))
     res['es = sum of the per-head aggregates'] = (esk.sum(0) - out).abs().max().item()
     al = torch.zeros(K, g.E, 2)
     al[:, e_of_p.cpu(), ep.cpu()] = alpha.cpu()

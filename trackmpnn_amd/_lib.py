@@ -80,6 +80,7 @@ _SIGNATURES = {
     'tmpnn_att_fwd': (c_int, [_GP, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_float,
                               c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     'tmpnn_att_bwd_ws': (c_size_t, [c_int, c_int, c_int, c_int]),
+    'tmpnn_att_index': (c_int, [_GP, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     'tmpnn_att_bwd': (c_int, [_GP, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
                               c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_size_t,
                               c_void_p, c_int, c_void_p, c_void_p, c_void_p]),

@@ -578,6 +578,27 @@ __global__ __launch_bounds__(256) void k_att_bwd_dha(AttArgs A, const float* __r
     }
 }
 
+// the index arrays of the attention passes in one launch (what FrameGraph.att_index() would take a dozen torch index ops for):
+// thread t < E fills the per-edge half of erec[t], thread t < 2E the position it owns (erec[e][2 + side] = t, inc_other[t])
+__global__ __launch_bounds__(256) void k_att_index(int E, const int32_t* __restrict__ inc, const int32_t* __restrict__ pos,
+                                                   const int32_t* __restrict__ src, const int32_t* __restrict__ dst,
+                                                   const int32_t* __restrict__ src_pos, const int32_t* __restrict__ dst_pos,
+                                                   const int32_t* __restrict__ edge_row, int32_t* __restrict__ erec,
+                                                   int32_t* __restrict__ inc_other) {
+    const long t = (long)blockIdx.x * 256 + threadIdx.x;
+    if (t < E) {
+        int32_t* r = erec + 8 * t;
+        r[0] = src_pos[t]; r[1] = dst_pos[t]; r[4] = src[t]; r[5] = dst[t]; r[6] = edge_row[t]; r[7] = 0;
+    }
+    if (t < 2L * E) {
+        const int v = inc[t];
+        const int e = pos[v & 0x7fffffff];
+        const int side = v < 0 ? 1 : 0;
+        erec[8 * (size_t)e + 2 + side] = (int)t;
+        inc_other[t] = side ? (src_pos[e] | (int)0x80000000) : dst_pos[e];
+    }
+}
+
 // the stacked temporaries into the heads' own gradient buffers: dW_k[i][j] += dWcat[i][k H + j], da_k[j] += da[k][j]
 struct HeadPtrs { float* w[KMAX]; float* a[KMAX]; };
 __global__ void k_att_heads_add(const float* __restrict__ dWcat, const float* __restrict__ da, int H, int K, HeadPtrs P) {
@@ -657,6 +678,17 @@ using namespace tmpnn;
 extern "C" {
 
 size_t tmpnn_att_bwd_ws(int E, int Dn, int H, int K) { return att_bwd_layout(E, Dn, H, K).total; }
+
+int tmpnn_att_index(const tmpnn_graph* g, const int32_t* pos, const int32_t* src_pos, const int32_t* dst_pos, int32_t* erec,
+                    int32_t* inc_other, tmpnn_stream stream) {
+    TM_REQUIRE(g && g->E >= 0, "att_index: graph");
+    if (g->E == 0) return TMPNN_OK;
+    TM_REQUIRE(pos && src_pos && dst_pos && erec && inc_other && g->inc && g->src && g->dst && g->edge_row && aligned16(erec),
+               "att_index: null pointer (erec 16-byte aligned)");
+    hipLaunchKernelGGL(k_att_index, dim3(ceil_div(2L * g->E, 256)), dim3(256), 0, as_stream(stream), g->E, g->inc, pos, g->src,
+                       g->dst, src_pos, dst_pos, g->edge_row, erec, inc_other);
+    return check_launch("att_index");
+}
 
 int tmpnn_att_fwd(const tmpnn_graph* g, const int32_t* erec, const float* h,
                   int ld_h, int H, int K, const float* W_cat, const float* a, const uint8_t* keep, float p_drop, float* ha, float* score,

@@ -78,19 +78,21 @@ class FrameGraph:
         if t is None:
             if self.src_pos is None or self.dst_pos is None:
                 raise ValueError('att_index: the graph carries no src_pos / dst_pos')
-            e = self.pos.long()[(self.inc & 0x7FFFFFFF).long()]
-            neg = self.inc < 0
-            other = torch.where(neg, self.src_pos[e] | torch.tensor(-2 ** 31, dtype=torch.int32, device=self.device),
-                                self.dst_pos[e]).to(torch.int32).contiguous()
-            erec = torch.zeros((max(self.E, 1), 8), dtype=torch.int32, device=self.device)
-            if self.E > 0:
-                erec[:, 0] = self.src_pos
-                erec[:, 1] = self.dst_pos
-                erec[e, 2 + neg.long()] = torch.arange(2 * self.E, dtype=torch.int32, device=self.device)
-                erec[:, 4] = self.src
-                erec[:, 5] = self.dst
-                erec[:, 6] = self.edge_row
-            t = (erec, other)
+            erec = torch.empty((max(self.E, 1), 8), dtype=torch.int32, device=self.device)
+            other = torch.empty((max(2 * self.E, 1),), dtype=torch.int32, device=self.device)
+            if self.device.type == 'cuda':
+                _lib.call('tmpnn_att_index', self.cref(), self.pos.data_ptr(), self.src_pos.data_ptr(), self.dst_pos.data_ptr(),
+                          erec.data_ptr(), other.data_ptr(), _lib.raw_stream(self.device))
+            else:                               # (host graphs, CPU tests: the same arrays with torch index ops)
+                e = self.pos.long()[(self.inc & 0x7FFFFFFF).long()]
+                neg = self.inc < 0
+                other = torch.where(neg, self.src_pos[e] | torch.tensor(-2 ** 31, dtype=torch.int32), self.dst_pos[e]).to(torch.int32)
+                erec.zero_()
+                if self.E > 0:
+                    erec[:, 0], erec[:, 1] = self.src_pos, self.dst_pos
+                    erec[e, 2 + neg.long()] = torch.arange(2 * self.E, dtype=torch.int32)
+                    erec[:, 4], erec[:, 5], erec[:, 6] = self.src, self.dst, self.edge_row
+            t = (erec, other.contiguous())
             self.__dict__['_att_index'] = t
         return t
 
