@@ -284,7 +284,7 @@ def pmc_traffic(stage, E):
     MI355X_MICROARCH.md prescribes for gfx950: FETCH_SIZE tallies the 128-byte requests of a wide coalesced stream
     (16 B per lane -- every row stream of these kernels) at 64 bytes, so reads = 2 x FETCH_SIZE; WRITE_SIZE is exact for
     16-byte-per-lane stores.  None unless the profile was taken on a graph of exactly this size."""
-    for tag in ('r03', 'r02', 'r01'):
+    for tag in ('r04', 'r03', 'r02', 'r01'):
         path = os.path.join(ROOT, 'profiles', f'{tag}_pmc_traffic_stage_kernels.json')
         try:
             prof = json.load(open(path))
