@@ -41,8 +41,7 @@ if have(f'gpurun_out/{tag}_stats/**/*_kernel_stats.csv', f'gpurun_out/{tag}_benc
                     'gru_bwd_data_edge_folded': 'k_gru_bwd_data_split<64, 3, true>',
                     'gru_bwd_data_edge': 'k_gru_bwd_data_split<64, 1, false>',
                     'gru_bwd_weights_edge': 'k_gru_bwd_weights_split<1, 1>',
-                    'gather_diff': 'k_gather_pipe<false, false', 'segsum': 'k_segsum_pipe<false',
-                    'att_fwd': 'k_att_fwd<2>', 'att_bwd': 'k_att_bwd_edge<2>'}
+                    'gather_diff': 'k_gather_pipe<false, false', 'segsum': 'k_segsum_pipe<false'}
     with open(f'profiles/{tag}_bench_kernel_stats.md', 'w') as f:
         f.write(f'# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 10 --warmup 2   ({tag}, 1x MI355X)\n\n')
         f.write('What the run contains: 12 steps of the C2 workload (16 384 windows; six forward calls on graphs of six sizes + '
