@@ -3213,17 +3213,9 @@ __device__ unsigned long long g_two_timeline[2][8];
 #define TWO_MARK(i) do { } while (0)
 #endif
 struct TwoRaw { float4 dh, r, z, n, hn, hp, xa, xb, ea, eb; float dy; };
-// the gate planes are read exactly once (written by the forward a whole step earlier): TWO_NT_LOADS requests them nontemporal
-// (measured, same box: 3.87-3.88 vs 3.87-3.90 ms per 6.03 M rows -- nothing; the L1's pending-request queue is full either way)
-__device__ __forceinline__ float4 two_ld4_nt(const float* p) {
-    const f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p));
-    return make_float4(v[0], v[1], v[2], v[3]);
-}
-#ifdef TWO_NT_LOADS
-#define TWO_LD4(p) two_ld4_nt(p)
-#else
+// (the gate planes are read exactly once; requesting them nontemporal was measured to change nothing: 3.87-3.88 vs 3.87-3.90 ms
+//  per 6.03 M rows, the L1's pending-request queue is full either way -- switch removed in round 4)
 #define TWO_LD4(p) (*reinterpret_cast<const float4*>(p))
-#endif
 
 #ifndef TWO_SCHED
 #define TWO_SCHED 1     // 1: a group's staging slice sits between its operand reads and its MFMAs with no scheduling fence (the
@@ -3250,17 +3242,7 @@ __global__ __launch_bounds__(512) void k_gru_bwd_two(GruBwdFusedArgs a, int ntil
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int role = wave >> 2, q = wave & 3;                 // role 0: W_ih side, 1: W_hh side
-#ifdef TWO_EXP_SAMEWORK        // timing experiment (wrong results): the W_hh-side waves read exactly what the W_ih side reads
-    const int lrole = 0;
-#else
     const int lrole = role;
-#endif
-#ifdef TWO_PRIO
-    // (experiment: the s_memtime profile shows the W_ih-side waves 19 % of a tile at the barrier, waiting for their SIMD
-    //  partners of the W_hh side, which are slower in every phase)
-    if (TWO_PRIO == 1) { if (role == 1) __builtin_amdgcn_s_setprio(3); }
-    else if (TWO_PRIO == 2) { if (role == 0) __builtin_amdgcn_s_setprio(3); }
-#endif
     // ---- data product (16x16x32): lane (j = tile row within a 16-row half, kq = k group)
     const int j16 = lane & 15, kq = lane >> 4;
     // staging: thread tid takes row tid >> 4, columns 4 (tid & 15) .. + 3 -- written through (wave, kq, j16), which the
@@ -3464,13 +3446,6 @@ __global__ __launch_bounds__(512) void k_gru_bwd_two(GruBwdFusedArgs a, int ntil
 #pragma unroll
         for (int s6 = 0; s6 < 6; ++s6) {
             const int kb = s6 / 3, j = s6 % 3;
-#ifdef TWO_PRIO
-            // alternate who wins the issue arbitration, group by group (3) or tile by tile (4) -- measured, same box, 3.91 ms
-            // default: fixed priority for either role 3.92-3.95, alternating per group 4.12, per tile 3.95: arbitration is not
-            // what makes the W_hh side slow
-            if (TWO_PRIO == 3) { if (role == (s6 & 1)) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(0); }
-            if (TWO_PRIO == 4 && s6 == 0) { if (role == (it & 1)) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(0); }
-#endif
             uint4 bd[3], aw[3], bt[3];
             const uint16_t* pd;
             {
