@@ -297,7 +297,7 @@ def node_adj_diag_zero(na):
 
 
 def run_infer_fixture(name, out_dir, seed, T, dmean, cur_win, ret_win, hungarian, H=32, K=0, msg='diff', light=False,
-                      gap=None):
+                      gap=None, shuffle=False):
     """The inference loop of infer.py:48-87 on the real reference: eval-mode model, update_graph(mode='test'),
     decode_tracks(cuda=False) with its row deletion between calls.  Every forward call is stored with ITS inputs
     (x, the row-deleted carried state, the adjacency pair as produced) and outputs; every decode step with the rows
@@ -331,6 +331,11 @@ def run_infer_fixture(name, out_dir, seed, T, dmean, cur_win, ret_win, hungarian
         # graph again from the next two non-empty timesteps
         keep_det = (y[0, :, 0] < gap[0]) | (y[0, :, 0] >= gap[1])
         X, y = X[:, keep_det], y[:, keep_det]
+    if shuffle:
+        # the detections listed in NO particular order (the reference indexes them by np.where(y[:, 0] == t) and finalises
+        # tracks in det-id order, utils/graph.py:456-490: the track numbering depends on that order)
+        perm = torch.randperm(y.shape[1], generator=torch.Generator().manual_seed(seed + 99))
+        X, y = X[:, perm], y[:, perm]
     out['X'] = X.numpy().copy()
     out['y'] = y.numpy().copy()
     y_out = y.squeeze(0).numpy().astype('int64').copy()
@@ -413,6 +418,8 @@ def run_infer_fixture(name, out_dir, seed, T, dmean, cur_win, ret_win, hungarian
                 ncalls=ncalls, seed=seed, T=T, cur_win_size=cur_win, ret_win_size=ret_win, hungarian=bool(hungarian),
                 rows_deleted=n_del, reinitialisations=n_reinit, torch=torch.__version__,
                 reference='arangesh/TrackMPNN infer.py:48-87 loop')
+    if shuffle:
+        meta['detections'] = 'listed in shuffled order'
     out['meta'] = np.array(json.dumps(meta))
     path = os.path.join(out_dir, name + '.npz')
     np.savez_compressed(path, **out)
@@ -465,6 +472,9 @@ def main():
         run_infer_fixture('infer_greedy_w3_r0_reinit', args.out, 503, T=14, dmean=4, cur_win=3, ret_win=0, hungarian=False,
                           gap=(5, 10))
         return
+    if args.only == 'unsorted':
+        run_unsorted_fixtures(args.out)
+        return
     seed = 0
     for feats, ncat in (('2d', 3), ('2d+temp+vis', 3)):
         for msg in ('diff', 'concat'):
@@ -511,6 +521,16 @@ def main():
     # re-initialisation branch (infer.py:62-68)
     run_infer_fixture('infer_greedy_w3_r0_reinit', args.out, 503, T=14, dmean=4, cur_win=3, ret_win=0, hungarian=False,
                       gap=(5, 10))
+    run_unsorted_fixtures(args.out)
+
+
+def run_unsorted_fixtures(out_dir):
+    """round 4: the detections of the sequence listed in shuffled order (the reference finalises tracks in det-id order,
+    utils/graph.py:456-490, so the track numbering depends on it)."""
+    run_infer_fixture('infer_greedy_w3_r0_unsorted', out_dir, 504, T=10, dmean=5, cur_win=3, ret_win=0, hungarian=False,
+                      shuffle=True)
+    run_infer_fixture('infer_hungarian_w4_r1_unsorted', out_dir, 505, T=9, dmean=4, cur_win=4, ret_win=1, hungarian=True,
+                      shuffle=True)
 
 
 def run_c1(out_dir):

@@ -264,6 +264,10 @@ __global__ __launch_bounds__(256) void k_track_gather(const float* __restrict__ 
 // walks through it.  Dn is tens to hundreds: the pass is one thread over LDS-resident arrays (all other steps -- the
 // id -> position table, the scan for the next free id, the label write-back -- are parallel), and the host is not
 // involved: y_out stays on the device for the whole sequence.
+// Where the window's det ids do NOT ascend with its rows (a sequence whose detections are listed in no particular order) the
+// order of the starts is the det-id order, a later start may begin in the middle of an earlier walk's path, and the numbering
+// depends on it: the kernel notices (one parallel comparison of neighbours) and runs the reference's loop literally -- the
+// window's dets ranked by id (a parallel count), then one thread starting the walks in that order over the same LDS arrays.
 static constexpr int FIN_LDS_DETS = 4096;
 
 __global__ __launch_bounds__(TK_THREADS) void k_track_finalize(tmpnn_dgraph g, const int32_t* __restrict__ ts,
@@ -274,7 +278,8 @@ __global__ __launch_bounds__(TK_THREADS) void k_track_finalize(tmpnn_dgraph g, c
                                                                int32_t* __restrict__ pos_of_det, int32_t* __restrict__ ws) {
     __shared__ int s_next[FIN_LDS_DETS], s_best[FIN_LDS_DETS], s_tid[FIN_LDS_DETS], s_old[FIN_LDS_DETS];
     __shared__ unsigned char s_flag[FIN_LDS_DETS];         // bit 0 eligible start, bit 1 reached, bit 2 on a path
-    __shared__ int s_max;
+    __shared__ int s_order[FIN_LDS_DETS];                  // (unsorted windows only) position of the det with the k-th smallest id
+    __shared__ int s_max, s_unsorted;
     const int tid = threadIdx.x;
     const int Dn = g.meta[1];
     // arrays of the pass: LDS up to FIN_LDS_DETS dets, the caller's scratch beyond (same code through generic pointers)
@@ -283,7 +288,8 @@ __global__ __launch_bounds__(TK_THREADS) void k_track_finalize(tmpnn_dgraph g, c
     int* tidv = Dn <= FIN_LDS_DETS ? s_tid : ws + 2 * (size_t)Dn;
     int* oldv = Dn <= FIN_LDS_DETS ? s_old : ws + 3 * (size_t)Dn;
     unsigned char* flag = Dn <= FIN_LDS_DETS ? s_flag : reinterpret_cast<unsigned char*>(ws + 4 * (size_t)Dn);
-    if (tid == 0) s_max = -1;
+    int* order = Dn <= FIN_LDS_DETS ? s_order : ws + 5 * (size_t)Dn;
+    if (tid == 0) { s_max = -1; s_unsorted = 0; }
     __syncthreads();
     {   // next free track id = max(y_out[:, 1]) + 1 (utils/graph.py:457)
         int m = -1;
@@ -307,8 +313,40 @@ __global__ __launch_bounds__(TK_THREADS) void k_track_finalize(tmpnn_dgraph g, c
         best[k] = -1;
         oldv[k] = y_track[det_id[r]];
         flag[k] = (ts[r] < t_upto && score[r] >= 0.5f) ? 1 : 0;
+        if (k + 1 < Dn && det_id[r] > det_id[g.det_row[k + 1]]) s_unsorted = 1;
     }
     __syncthreads();
+    if (s_unsorted) {                                           // block-uniform
+        // the reference's loop as written (utils/graph.py:458-490): starts in det-id order, labels read and written live
+        for (int k = tid; k < Dn; k += TK_THREADS) {
+            const int id = det_id[g.det_row[k]];
+            int rank = 0;
+            for (int j = 0; j < Dn; ++j) rank += det_id[g.det_row[j]] < id ? 1 : 0;
+            order[rank] = k;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            int next_id = s_max + 1;
+            for (int i = 0; i < Dn; ++i) {
+                int k = order[i];
+                const unsigned char f = flag[k];
+                if (!(f & 1)) { flag[k] = f | 2; continue; }    // not a start (at / after t_upto, or a false positive): visited
+                if (f & 2) continue;                            // an earlier walk came through
+                const int cur = oldv[k] != -1 ? oldv[k] : next_id++;
+                for (int steps = 0; steps < Dn; ++steps) {      // (a det links to a LATER det: no cycles; bounded anyway)
+                    flag[k] |= 2 | 4;
+                    oldv[k] = cur;
+                    const int nk = nextk[k];
+                    if (nk < 0) break;
+                    k = nk;
+                }
+            }
+        }
+        __syncthreads();
+        for (int k = tid; k < Dn; k += TK_THREADS)
+            if (flag[k] & 4) y_track[det_id[g.det_row[k]]] = oldv[k];
+        return;
+    }
     if (tid == 0) {
         int next_id = s_max + 1;
         for (int k = 0; k < Dn; ++k) {
@@ -403,7 +441,7 @@ int tmpnn_track_gather(const float* in, int ld_in, int W, int max_rows, const in
     return check_launch("track_gather");
 }
 
-size_t tmpnn_track_finalize_ws(int max_dets) { return max_dets > FIN_LDS_DETS ? sizeof(int32_t) * 5 * (size_t)max_dets : 0; }
+size_t tmpnn_track_finalize_ws(int max_dets) { return max_dets > FIN_LDS_DETS ? sizeof(int32_t) * 6 * (size_t)max_dets : 0; }
 
 int tmpnn_track_finalize(const tmpnn_dgraph* g, const int32_t* ts, const int32_t* det_id, const int32_t* assoc,
                          const float* score, int t_upto, int32_t* y_track, int ND, int32_t* pos_of_det, void* ws,
@@ -412,7 +450,7 @@ int tmpnn_track_finalize(const tmpnn_dgraph* g, const int32_t* ts, const int32_t
                "track_finalize: null pointer / empty sequence");
     TM_REQUIRE(g->N >= 0 && g->N <= TMPNN_TRACK_MAX_ROWS, "track_finalize: N=%d (limit %d)", g->N, TMPNN_TRACK_MAX_ROWS);
     if (g->N == 0) return TMPNN_OK;
-    // (the det count lives on the device; beyond FIN_LDS_DETS dets the pass needs 5 ints per det of scratch)
+    // (the det count lives on the device; beyond FIN_LDS_DETS dets the pass needs 6 ints per det of scratch)
     TM_REQUIRE(g->N <= FIN_LDS_DETS || (ws != nullptr && ws_bytes >= tmpnn_track_finalize_ws(g->N)),
                "track_finalize: %d rows may hold more than %d dets: workspace of tmpnn_track_finalize_ws(N) bytes needed", g->N,
                FIN_LDS_DETS);

@@ -143,12 +143,6 @@ class TrackGraph:
         tg._rebuild()
         tg._sequence(X, yy)
         tg._X_src, tg._y_src = X, y
-        if mode != 'train' and not tg._time_sorted:
-            # decode()'s finalisation walk runs on the device in graph-row order, which equals the reference's det-id order
-            # (utils/graph.py:456-490) only when the detections are listed frame by frame -- say so BEFORE any forward call
-            raise ValueError('TrackGraph.initialize(mode="test"): the detections of the sequence must be listed in time '
-                             'order (dataset/kitti_mot.py and bdd100k_mot.py list them frame by frame); sort X / y by '
-                             'y[..., 0] first')
         Xd = tg._Xd
         feats = torch.zeros((N, X.shape[2]), dtype=Xd.dtype, device=tg.device)
         feats[:n0] = Xd[torch.from_numpy(ids0).to(tg.device)]
@@ -170,7 +164,6 @@ class TrackGraph:
             self._t_range = {int(ts_sorted[a]): (int(a), int(b)) for a, b in zip(lo, hi)}
         self.y_track = torch.full((max(ND, 1),), -1, dtype=torch.int32, device=self.device)
         self._pos_of_det = torch.zeros((max(ND, 1),), dtype=torch.int32, device=self.device)
-        self._time_sorted = bool((np.diff(yy[:, 0]) >= 0).all())
 
     def tracks(self) -> np.ndarray:
         """y_out[:, 1] of the sequence so far (one device -> host copy; call it when the sequence is done)."""
@@ -281,9 +274,6 @@ class TrackGraph:
         sp = score_pos.detach().reshape(-1).float().contiguous()
         r = self.rows
         self._associate(sp, 'test', use_hungarian)
-        if not self._time_sorted:
-            raise ValueError('TrackGraph.decode: the detections of the sequence must be listed in time order '
-                             '(dataset/kitti_mot.py lists them frame by frame)')
         ND = int(self.y_track.numel())
         wsb = int(_lib.load().tmpnn_track_finalize_ws(N))
         if wsb and (self._fin_ws is None or self._fin_ws.numel() * 4 < wsb):
