@@ -550,6 +550,37 @@ int tmpnn_track_finalize(const tmpnn_dgraph* g, const int32_t* ts, const int32_t
                          const float* score, int t_upto, int32_t* y_track, int ND, int32_t* pos_of_det, void* ws,
                          size_t ws_bytes, tmpnn_stream stream);
 
+/* One call per phase of a timestep, as the reference's loops call update_graph / decode_tracks (train.py:102-104,
+ * infer.py:70-87): the kernels above enqueued back to back.  At batch 1 a timestep is bound by the number of calls and
+ * launches, not by their work.  `small`: int32 [4] in device memory -- [0] a count (active set / kept rows), [1] status bits
+ * of the label rule, [2] kept det rows, [3] the NEXT timestep's active-set size (tmpnn_track_retire with next_t >= 0). */
+typedef struct tmpnn_track_rows {   /* the row form (see above); labels may be NULL at inference */
+    int32_t *ts, *det_id, *assoc;
+    uint8_t* is_edge;
+    int32_t *src, *dst;
+    uint8_t* labels;
+} tmpnn_track_rows;
+/* update_graph, first half (utils/graph.py:227-278): the associations (skipped with associate = 0: rows->assoc is current)
+ * and the active set of timestep t -> active[], small[0]. */
+int tmpnn_track_select(const tmpnn_dgraph* g, const tmpnn_track_rows* rows, const float* score, int mode, int t,
+                       int associate, int32_t* active, int32_t* small, tmpnn_stream stream);
+/* update_graph, second half (:283-332): the block of timestep t appended behind row N (tmpnn_track_append), the features
+ * of the new rows written (feats [A*D + D][ld_f]: zeros on edge rows, X[new_ids[j]][0:F] on det rows; NULL: not written)
+ * and the index form of the grown graph derived into g_new (bound for N + A*D + D rows; ws / ws_ints as
+ * tmpnn_graph_from_rows_ws). */
+int tmpnn_track_extend(int N, int A, int D, const int32_t* active, const int32_t* new_ids, int t, const int32_t* track,
+                       const tmpnn_track_rows* rows, const float* X, int ld_x, int F, float* feats, int ld_f,
+                       const tmpnn_dgraph* g_new, void* ws, size_t ws_ints, tmpnn_stream stream);
+/* decode_tracks (:431-520): associations from the scores (associate = 0: rows->assoc holds them, e.g. from the Hungarian
+ * matching), track finalisation, row deletion into rows_out, the state rows and scores compacted (h_new [N][ld_hn],
+ * s_new [N]; small[0] / small[2] = kept rows / kept det rows).  next_t >= 0: also the active set of timestep next_t on
+ * the compacted rows by the inference rule (their associations carry over: deletion removes no future edge of a kept det)
+ * -> active[], small[3]; the caller then reads small once per timestep instead of twice. */
+int tmpnn_track_retire(const tmpnn_dgraph* g, const tmpnn_track_rows* rows, const float* score, int associate, int t_upto,
+                       int ret_win, int32_t* y_track, int ND, int32_t* pos_of_det, void* fin_ws, size_t fin_ws_bytes,
+                       int32_t* keep, int32_t* small, const tmpnn_track_rows* rows_out, const float* h, int ld_h, int W,
+                       float* h_new, int ld_hn, float* s_new, int next_t, int32_t* active, tmpnn_stream stream);
+
 
 /* ======================================================================================================
  * Wide cells (H = 128 / 256, diff messages; BASELINE.json C5) as LDS-tiled GEMMs on bf16x6 split products

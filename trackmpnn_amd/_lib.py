@@ -64,8 +64,15 @@ class CMpParams(C.Structure):
                 ('w_node', c_void_p), ('b_node', c_void_p), ('w_edge', c_void_p), ('b_edge', c_void_p)]
 
 
+class CTrackRows(C.Structure):
+    """struct tmpnn_track_rows (include/tmpnn.h): the row form of the rolling tracking graph."""
+    _fields_ = [('ts', c_void_p), ('det_id', c_void_p), ('assoc', c_void_p), ('is_edge', c_void_p), ('src', c_void_p),
+                ('dst', c_void_p), ('labels', c_void_p)]
+
+
 _DGP = C.POINTER(CDGraph)
 _MPP = C.POINTER(CMpParams)
+_TRP = C.POINTER(CTrackRows)
 
 # name -> (restype, argtypes); must mirror include/tmpnn.h (tests/test_abi.py cross-checks the names)
 _SIGNATURES = {
@@ -171,6 +178,12 @@ _SIGNATURES = {
     'tmpnn_track_finalize_ws': (c_size_t, [c_int]),
     'tmpnn_track_finalize': (c_int, [_DGP, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p,
                                      c_size_t, c_void_p]),
+    'tmpnn_track_select': (c_int, [_DGP, _TRP, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    'tmpnn_track_extend': (c_int, [c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, _TRP, c_void_p, c_int, c_int,
+                                   c_void_p, c_int, _DGP, c_void_p, c_size_t, c_void_p]),
+    'tmpnn_track_retire': (c_int, [_DGP, _TRP, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_size_t,
+                                   c_void_p, c_void_p, _TRP, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_int,
+                                   c_void_p, c_void_p]),
     'tmpnn_wide_supported': (c_int, [c_int, c_int]),
     'tmpnn_wide_prep_bytes': (c_size_t, [c_int, c_int]),
     'tmpnn_wide_prepare': (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),

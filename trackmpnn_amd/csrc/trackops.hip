@@ -107,11 +107,14 @@ __global__ __launch_bounds__(256) void k_track_associate(tmpnn_dgraph g, const i
 
 // ---- active set (utils/graph.py:270-278), ascending rows ----------------------------------------------------------
 // train: det rows not yet associated, or of the last timestep before t.   inference: unassociated dets scored >= 0.5.
-__global__ __launch_bounds__(TK_THREADS) void k_track_active(int N, const int32_t* __restrict__ ts,
+// n_dev (or NULL): the row count read on the device instead (the rows a deletion just compacted: the host has not seen it yet)
+__global__ __launch_bounds__(TK_THREADS) void k_track_active(int N, const int32_t* __restrict__ n_dev,
+                                                             const int32_t* __restrict__ ts,
                                                              const int32_t* __restrict__ assoc,
                                                              const float* __restrict__ score, int mode, int t,
                                                              int32_t* __restrict__ active, int32_t* __restrict__ count) {
     __shared__ int s_wave[TK_THREADS / 64 + 1];
+    if (n_dev) N = n_dev[0];
     __shared__ int s_tprev;
     const int tid = threadIdx.x;
     if (tid == 0) s_tprev = -2147483647;
@@ -149,8 +152,17 @@ __global__ __launch_bounds__(256) void k_track_append(int N, int A, int D, const
                                                       int32_t* __restrict__ ts, int32_t* __restrict__ det_id,
                                                       int32_t* __restrict__ assoc, uint8_t* __restrict__ is_edge,
                                                       int32_t* __restrict__ row_src, int32_t* __restrict__ row_dst,
-                                                      uint8_t* __restrict__ labels) {
+                                                      uint8_t* __restrict__ labels,
+                                                      const float* __restrict__ X /* [ND][ld_x] or NULL */, int ld_x, int F,
+                                                      float* __restrict__ feats /* [n][ld_f]: zeros on edge rows */, int ld_f) {
     const int n = A * D + D;
+    if (feats) {          // the new rows' features (utils/graph.py:291-293, 318): zeros on the edge rows, X[id] on the det rows
+        const long total = (long)n * F;
+        for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+            const int r = (int)(i / F), c = (int)(i % F);
+            feats[(size_t)r * ld_f + c] = r < A * D ? 0.f : X[(size_t)new_ids[r - A * D] * ld_x + c];
+        }
+    }
     for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
         const int r = N + i;
         assoc[r] = -1;
@@ -250,6 +262,27 @@ __global__ __launch_bounds__(256) void k_track_gather(const float* __restrict__ 
         float* dst = out + (size_t)q * ld_out + c;
         if (c + 4 <= W && ((ld_in | ld_out) & 3) == 0) *reinterpret_cast<float4*>(dst) = *reinterpret_cast<const float4*>(src);
         else for (int k = 0; k < 4 && c + k < W; ++k) dst[k] = src[k];
+    }
+}
+
+
+// the state rows AND the scores in one launch: out_h[q, :] = h[keep[q], :], out_s[q] = score[keep[q]]
+__global__ __launch_bounds__(256) void k_track_gather2(const float* __restrict__ h, int ld_h, int W,
+                                                       const float* __restrict__ score, const int32_t* __restrict__ keep,
+                                                       const int32_t* __restrict__ count, float* __restrict__ out_h,
+                                                       int ld_out, float* __restrict__ out_s) {
+    const int n = count[0];
+    const int lpr = (W + 3) / 4 + 1;                      // the last slot of a row moves its score
+    const long total = (long)n * lpr;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int q = (int)(i / lpr), k = (int)(i % lpr);
+        const int r = keep[q];
+        if (k == lpr - 1) { out_s[q] = score[r]; continue; }
+        const int c = k * 4;
+        const float* src = h + (size_t)r * ld_h + c;
+        float* dst = out_h + (size_t)q * ld_out + c;
+        if (c + 4 <= W && ((ld_h | ld_out) & 3) == 0) *reinterpret_cast<float4*>(dst) = *reinterpret_cast<const float4*>(src);
+        else for (int j = 0; j < 4 && c + j < W; ++j) dst[j] = src[j];
     }
 }
 
@@ -394,8 +427,8 @@ int tmpnn_track_active(int N, const int32_t* ts, const int32_t* assoc, const flo
                        int32_t* active, int32_t* count, tmpnn_stream stream) {
     TM_REQUIRE(N >= 0 && N <= TMPNN_TRACK_MAX_ROWS, "track_active: N=%d (limit %d)", N, TMPNN_TRACK_MAX_ROWS);
     TM_REQUIRE(ts && assoc && active && count && (mode == 0 || score), "track_active: null pointer");
-    hipLaunchKernelGGL(k_track_active, dim3(1), dim3(TK_THREADS), 0, as_stream(stream), N, ts, assoc, score, mode, t,
-                       active, count);
+    hipLaunchKernelGGL(k_track_active, dim3(1), dim3(TK_THREADS), 0, as_stream(stream), N, (const int32_t*)nullptr, ts, assoc,
+                       score, mode, t, active, count);
     return check_launch("track_active");
 }
 
@@ -409,7 +442,8 @@ int tmpnn_track_append(int N, int A, int D, const int32_t* active, const int32_t
                "track_append: null pointer");
     const int n = A * D + D;
     hipLaunchKernelGGL(k_track_append, dim3(ceil_div(n, 256)), dim3(256), 0, as_stream(stream), N, A, D, active, new_ids,
-                       t, track, ts, det_id, assoc, is_edge, row_src, row_dst, labels);
+                       t, track, ts, det_id, assoc, is_edge, row_src, row_dst, labels, (const float*)nullptr, 0, 0,
+                       (float*)nullptr, 0);
     return check_launch("track_append");
 }
 
@@ -457,6 +491,83 @@ int tmpnn_track_finalize(const tmpnn_dgraph* g, const int32_t* ts, const int32_t
     hipLaunchKernelGGL(k_track_finalize, dim3(1), dim3(TK_THREADS), 0, as_stream(stream), *g, ts, det_id, assoc, score, t_upto,
                        y_track, ND, pos_of_det, reinterpret_cast<int32_t*>(ws));
     return check_launch("track_finalize");
+}
+
+// ---- one call per phase of a timestep (the reference's update_graph / decode_tracks as the loops call them): the same kernels
+// as the entry points above, enqueued back to back -- a timestep is host-bound at batch 1 (a launch through the FFI costs more
+// than the kernel runs), so what matters is the number of calls and launches, not their work.
+static int rows_ok(const tmpnn_track_rows* r) {
+    return r && r->ts && r->det_id && r->assoc && r->is_edge && r->src && r->dst;
+}
+
+int tmpnn_track_select(const tmpnn_dgraph* g, const tmpnn_track_rows* rows, const float* score, int mode, int t,
+                       int associate, int32_t* active, int32_t* small, tmpnn_stream stream) {
+    TM_REQUIRE(g && rows_ok(rows) && active && small, "track_select: null pointer");
+    TM_REQUIRE(mode == 0 ? rows->labels != nullptr : (mode == 1 && score != nullptr), "track_select: mode %d needs %s", mode,
+               mode == 0 ? "labels" : "scores");
+    int rc;
+    if (associate) {
+        if (mode == 0 && hipMemsetAsync(small + 1, 0, sizeof(int32_t), as_stream(stream)) != hipSuccess)
+            return set_error(TMPNN_ELAUNCH, "track_select: clearing the status word failed");
+        if ((rc = tmpnn_track_associate(g, rows->det_id, mode == 0 ? rows->labels : nullptr, mode == 0 ? nullptr : score, mode,
+                                        rows->assoc, small + 1, stream))) return rc;
+    }
+    return tmpnn_track_active(g->N, rows->ts, rows->assoc, score, mode, t, active, small, stream);
+}
+
+int tmpnn_track_extend(int N, int A, int D, const int32_t* active, const int32_t* new_ids, int t, const int32_t* track,
+                       const tmpnn_track_rows* rows, const float* X, int ld_x, int F, float* feats, int ld_f,
+                       const tmpnn_dgraph* g_new, void* ws, size_t ws_ints, tmpnn_stream stream) {
+    TM_REQUIRE(N >= 0 && A >= 0 && D > 0 && (long)N + (long)A * D + D <= TMPNN_TRACK_MAX_ROWS,
+               "track_extend: N=%d A=%d D=%d exceeds %d rows", N, A, D, TMPNN_TRACK_MAX_ROWS);
+    TM_REQUIRE(rows_ok(rows) && (A == 0 || active) && new_ids && g_new, "track_extend: null pointer");
+    TM_REQUIRE(feats == nullptr || (X && F > 0 && ld_x >= F && ld_f >= F), "track_extend: feature arguments (F=%d ld_x=%d ld_f=%d)",
+               F, ld_x, ld_f);
+    const int n = A * D + D;
+    const long work = feats ? (long)n * F : (long)n;
+    long blocks = (work + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(k_track_append, dim3((int)blocks), dim3(256), 0, as_stream(stream), N, A, D, active, new_ids, t, track,
+                       rows->ts, rows->det_id, rows->assoc, rows->is_edge, rows->src, rows->dst, rows->labels, X, ld_x, F,
+                       feats, ld_f);
+    int rc = check_launch("track_extend");
+    if (rc) return rc;
+    return tmpnn_graph_from_rows_ws(N + n, rows->is_edge, rows->src, rows->dst, g_new, ws, ws_ints, stream);
+}
+
+int tmpnn_track_retire(const tmpnn_dgraph* g, const tmpnn_track_rows* rows, const float* score, int associate, int t_upto,
+                       int ret_win, int32_t* y_track, int ND, int32_t* pos_of_det, void* fin_ws, size_t fin_ws_bytes,
+                       int32_t* keep, int32_t* small, const tmpnn_track_rows* rows_out, const float* h, int ld_h, int W,
+                       float* h_new, int ld_hn, float* s_new, int next_t, int32_t* active, tmpnn_stream stream) {
+    TM_REQUIRE(g && rows_ok(rows) && rows_ok(rows_out) && score && keep && small && h && h_new && s_new,
+               "track_retire: null pointer");
+    TM_REQUIRE(W > 0 && ld_h >= W && ld_hn >= W && aligned16(h) && aligned16(h_new), "track_retire: W=%d ld_h=%d ld_hn=%d", W,
+               ld_h, ld_hn);
+    TM_REQUIRE(next_t < 0 || active, "track_retire: the next timestep's active set needs its buffer");
+    const int N = g->N;
+    int rc;
+    if (associate &&
+        (rc = tmpnn_track_associate(g, rows->det_id, nullptr, score, 1, rows->assoc, small + 1, stream))) return rc;
+    if ((rc = tmpnn_track_finalize(g, rows->ts, rows->det_id, rows->assoc, score, t_upto, y_track, ND, pos_of_det, fin_ws,
+                                   fin_ws_bytes, stream))) return rc;
+    if ((rc = tmpnn_track_delete(N, rows->ts, rows->det_id, rows->assoc, score, rows->is_edge, rows->src, rows->dst,
+                                 rows->labels, t_upto, ret_win, keep, small, rows_out->ts, rows_out->det_id, rows_out->assoc,
+                                 rows_out->is_edge, rows_out->src, rows_out->dst, rows_out->labels, stream))) return rc;
+    if (N > 0) {
+        long blocks = ((long)N * ((W + 3) / 4 + 1) + 255) / 256;
+        if (blocks > 1024) blocks = 1024;
+        hipLaunchKernelGGL(k_track_gather2, dim3((int)blocks), dim3(256), 0, as_stream(stream), h, ld_h, W, score, keep, small,
+                           h_new, ld_hn, s_new);
+        if ((rc = check_launch("track_retire (gather)"))) return rc;
+    }
+    if (next_t >= 0) {
+        // the active set of the next timestep on the compacted rows (inference rule): their number is on the device only
+        hipLaunchKernelGGL(k_track_active, dim3(1), dim3(TK_THREADS), 0, as_stream(stream), 0, (const int32_t*)small,
+                           (const int32_t*)rows_out->ts, (const int32_t*)rows_out->assoc, (const float*)s_new, 1, next_t, active,
+                           small + 3);
+        if ((rc = check_launch("track_retire (next active set)"))) return rc;
+    }
+    return TMPNN_OK;
 }
 
 }  // extern "C"

@@ -137,7 +137,8 @@ def infer_sequence(model, X: torch.Tensor, y: torch.Tensor, cur_win_size: int = 
             ncalls += 1
             edge_iters += tg.E
             t_upto = t_end if t_cur == t_end - 1 else t_cur - cur_win_size + 2
-            h, sc = tg.decode(h, sc, None, t_upto, ret_win_size, use_hungarian=use_hungarian)
+            h, sc = tg.decode(h, sc, None, t_upto, ret_win_size, use_hungarian=use_hungarian,
+                              next_t=t_cur + 1 if t_cur + 1 < t_end else None)
             st.stop('decode')
         y_out[:, 1] = tg.tracks()[:y_out.shape[0]]
         st.stop('decode')

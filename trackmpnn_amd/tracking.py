@@ -7,14 +7,14 @@ edited by small kernels (association rule, active set, block append, row deletio
 form (`DeviceGraph`) is re-derived on the device after every edit; the walk that finalises tracks into `y_out` runs on
 the device too and `y_out` stays there until the sequence is done.  What stays on the host is what the reference itself
 solves with scipy on a few dozen detections: the Hungarian matching (it reads a handful of int32 per row, never the
-state).  Host reads per timestep in greedy mode: the size of the active set (update) and the number of kept rows (decode).
+state).  Host reads per timestep in greedy mode: ONE -- decode's (kept rows + the next timestep's active-set size, `next_t`).
 
     tg, feats, t_st, t_end = TrackGraph.initialize(X, y, t_st=0, mode='test', device='cuda:0')
     scores, logits, h, _ = model.forward_dgraph(feats, None, tg.graph)
     for t in range(t_st, t_end):
-        feats = tg.update(scores[:, 0], X, y, t, mode='test')                   # update_graph
+        feats = tg.update(sc, X, y, t, mode='test')                             # update_graph
         scores, logits, h, _ = model.forward_dgraph(feats, h, tg.graph)
-        h, sc = tg.decode(h, scores[:, 0], None, t - cur_win + 2, ret_win)     # decode_tracks
+        h, sc = tg.decode(h, scores[:, 0], None, t - cur_win + 2, ret_win, next_t=t + 1)   # decode_tracks
     y_out[:, 1] = tg.tracks()
 """
 from __future__ import annotations
@@ -48,12 +48,15 @@ class TrackGraph:
         self._rows = [dict(ts=torch.empty(cap, **i32), det_id=torch.empty(cap, **i32), assoc=torch.empty(cap, **i32),
                            is_edge=torch.empty(cap, **u8), src=torch.empty(cap, **i32), dst=torch.empty(cap, **i32),
                            labels=torch.empty(cap, **u8)) for _ in range(2)]
+        self._crows = [_lib.CTrackRows(*(d[k].data_ptr() for k in ('ts', 'det_id', 'assoc', 'is_edge', 'src', 'dst', 'labels')))
+                       for d in self._rows]
         self._cur = 0
+        self._prefetch = None                            # (timestep, the score tensor decode() returned, active-set size)
         self.E = 0
         self.Dn = 0
         self._active = torch.empty(cap, **i32)
         self._keep = torch.empty(cap, **i32)
-        self._small = torch.zeros(4, **i32)              # [0] count, [1] status
+        self._small = torch.zeros(4, **i32)              # [0] count, [1] status, [2] kept dets, [3] next active-set size
         self.track: Optional[torch.Tensor] = None        # int32 [ND] track id of every detection (training labels)
         self.graph: Optional[DeviceGraph] = None
         # per sequence, set by initialize(): the finalised tracks y_out[:, 1] (device, -1 = none yet), the detections of
@@ -82,17 +85,20 @@ class TrackGraph:
         lab = self.rows['labels'][:self.N]
         return lab if lab.dtype == torch.uint8 else (lab != 0).to(torch.uint8)
 
+    def _new_graph(self, N: int):
+        """An unbuilt DeviceGraph for N rows (+ the conversion's global scratch beyond the LDS-resident size)."""
+        g = DeviceGraph(N, self.device)
+        ws = None
+        if N > DG_MAX_ROWS:                       # dense scene: the conversion's work arrays in a global scratch
+            ws = torch.empty((8 * N + 1,), dtype=torch.int32, device=self.device)
+            g._keep = (ws,)
+        return g, ws
+
     def _rebuild(self) -> None:
         r = self.rows
-        g = DeviceGraph(self.N, self.device)
-        if self.N <= DG_MAX_ROWS:
-            _lib.call('tmpnn_graph_from_rows', self.N, r['is_edge'].data_ptr(), r['src'].data_ptr(), r['dst'].data_ptr(),
-                      g.cref(), _stream())
-        else:                                     # dense scene: the conversion's work arrays in a global scratch
-            ws = torch.empty((8 * self.N + 1,), dtype=torch.int32, device=self.device)
-            _lib.call('tmpnn_graph_from_rows_ws', self.N, r['is_edge'].data_ptr(), r['src'].data_ptr(), r['dst'].data_ptr(),
-                      g.cref(), ws.data_ptr(), ws.numel(), _stream())
-            g._keep = (ws,)
+        g, ws = self._new_graph(self.N)
+        _lib.call('tmpnn_graph_from_rows_ws', self.N, r['is_edge'].data_ptr(), r['src'].data_ptr(), r['dst'].data_ptr(),
+                  g.cref(), _lib.ptr(ws), 0 if ws is None else ws.numel(), _stream())
         # the host knows E and Dn of its own graph (initial block, appended blocks, the delete kernel's counts): nothing
         # downstream (staged kernels, losses) has to read them back; graphs built by these kernels are valid by construction
         g._meta = (self.E, self.Dn, 0)
@@ -153,6 +159,8 @@ class TrackGraph:
         """Per-sequence device state, uploaded once: features, the detections of every timestep, y_out[:, 1]."""
         ND = int(yy.shape[0])
         self._Xd = X[0].to(self.device)
+        # (what the append kernel reads: fp32 rows)
+        self._Xf = self._Xd if (self._Xd.dtype == torch.float32 and self._Xd.is_contiguous()) else self._Xd.float().contiguous()
         order = np.argsort(yy[:, 0], kind='stable')
         self._ids_sorted = torch.from_numpy(order.astype(np.int32)).to(self.device)
         ts_sorted = yy[order, 0]
@@ -170,17 +178,6 @@ class TrackGraph:
         return self.y_track.cpu().numpy().astype(np.int64)
 
     # ---------------------------------------------------------------------------------------------------------------
-    def _associate(self, score_pos: Optional[torch.Tensor], mode: str, use_hungarian: bool) -> None:
-        r = self.rows
-        if mode != 'train' and use_hungarian:
-            self._hungarian(score_pos)
-            return
-        self._small[1:2].zero_()                               # (a Python scalar written into a device tensor is a synchronising copy)
-        _lib.call('tmpnn_track_associate', self.graph.cref(), r['det_id'].data_ptr(),
-                  r['labels'].data_ptr() if mode == 'train' else None,
-                  score_pos.data_ptr() if mode != 'train' else None, 0 if mode == 'train' else 1,
-                  r['assoc'].data_ptr(), self._small[1:].data_ptr(), _stream())
-
     def _hungarian(self, score_pos: torch.Tensor) -> None:
         """Frame-by-frame optimal assignment (reference hungarian(), utils/graph.py:33-93) on the host: a few dozen
         detections per frame, scipy's linear_sum_assignment; cost of an association = P(edge is negative) = 1 - score.
@@ -224,86 +221,96 @@ class TrackGraph:
         One host read: the size of the active set."""
         # features and per-timestep detection ids were uploaded ONCE at initialize(): a different X / y here would be
         # silently ignored, so refuse it (the reference's loops pass the same sequence tensors every step)
-        for given, kept, nm in ((X, getattr(self, '_X_src', None), 'X'), (y, getattr(self, '_y_src', None), 'y')):
-            if kept is not None and given is not kept and not (
-                    given.shape == kept.shape and given.data_ptr() == kept.data_ptr() and given._version == kept._version):
-                raise ValueError(f'TrackGraph.update: {nm} must be the tensor initialize() was given (its contents are cached '
-                                 'on the device once per sequence); start a new TrackGraph for new data')
-        sp = None
-        if mode != 'train':
-            sp = score_pos.detach().reshape(-1).float().contiguous()
-        r = self.rows
+        if X is not self._X_src or y is not self._y_src:
+            for given, kept, nm in ((X, self._X_src, 'X'), (y, self._y_src, 'y')):
+                if kept is not None and given is not kept and not (
+                        given.shape == kept.shape and given.data_ptr() == kept.data_ptr() and given._version == kept._version):
+                    raise ValueError(f'TrackGraph.update: {nm} must be the tensor initialize() was given (its contents are '
+                                     'cached on the device once per sequence); start a new TrackGraph for new data')
+        train = mode == 'train'
+        pf, self._prefetch = self._prefetch, None
         N = self.N
-        self._associate(sp, mode, use_hungarian)
-        _lib.call('tmpnn_track_active', N, r['ts'].data_ptr(), r['assoc'].data_ptr(), _lib.ptr(sp),
-                  0 if mode == 'train' else 1, int(t), self._active.data_ptr(), self._small.data_ptr(), _stream())
+        st = _stream()
         lo, hi = self._t_range.get(int(t), (0, 0))
         D = hi - lo
         Xd = self._Xd
-        if D == 0:
-            if mode == 'train' and (self._small[1:2].tolist()[0] & 1):     # (the label rule's assertion holds on empty timesteps too)
-                raise AssertionError('More than one GT edge from same node!')
-            return torch.zeros((0, Xd.shape[1]), dtype=Xd.dtype, device=self.device)
-        A, status = self._small[:2].tolist()               # the ONE host read of an update: the size of the active set
-        if status & 1:
+        if (pf is not None and not train and not use_hungarian and pf[0] == int(t) and score_pos is pf[1]
+                and score_pos._version == pf[3]):
+            # decode() already derived this timestep's active set on the compacted rows (their associations carry over)
+            A, status = pf[2], 0
+        else:
+            sp = None
+            if not train:
+                sp = score_pos.detach().reshape(-1).float().contiguous()
+            hung = not train and use_hungarian
+            if hung:
+                self._hungarian(sp)
+            _lib.call('tmpnn_track_select', self.graph.cref(), C.byref(self._crows[self._cur]), _lib.ptr(sp),
+                      0 if train else 1, int(t), 0 if hung else 1, self._active.data_ptr(), self._small.data_ptr(), st)
+            if D == 0 and not train:
+                return torch.zeros((0, Xd.shape[1]), dtype=Xd.dtype, device=self.device)
+            A, status = self._small[:2].tolist()           # the ONE host read of an update: the size of the active set
+        if train and (status & 1):                         # (the label rule's assertion holds on empty timesteps too)
             raise AssertionError('More than one GT edge from same node!')
+        if D == 0:
+            return torch.zeros((0, Xd.shape[1]), dtype=Xd.dtype, device=self.device)
         n_new = A * D + D
         if N + n_new > self.cap:
             raise ValueError(f'TrackGraph: {N + n_new} rows exceed the device-resident limit of {self.cap}')
-        ids_dev = self._ids_sorted[lo:hi]
-        _lib.call('tmpnn_track_append', N, A, D, self._active.data_ptr(), ids_dev.data_ptr(), int(t),
-                  self.track.data_ptr() if self.track is not None else None,
-                  r['ts'].data_ptr(), r['det_id'].data_ptr(), r['assoc'].data_ptr(), r['is_edge'].data_ptr(),
-                  r['src'].data_ptr(), r['dst'].data_ptr(), r['labels'].data_ptr(), _stream())
+        F = int(Xd.shape[1])
+        feats = torch.empty((n_new, F), dtype=torch.float32, device=self.device)
+        g, ws = self._new_graph(N + n_new)
+        _lib.call('tmpnn_track_extend', N, A, D, self._active.data_ptr(), self._ids_sorted.data_ptr() + 4 * lo, int(t),
+                  _lib.ptr(self.track), C.byref(self._crows[self._cur]), self._Xf.data_ptr(), F, F, feats.data_ptr(), F, g.cref(),
+                  _lib.ptr(ws), 0 if ws is None else ws.numel(), st)
         self.N, self.E, self.Dn = N + n_new, self.E + A * D, self.Dn + D
-        self._rebuild()
-        feats = torch.zeros((n_new, Xd.shape[1]), dtype=Xd.dtype, device=self.device)
-        feats[A * D:] = Xd[ids_dev.long()]
-        return feats
+        g._meta = (self.E, self.Dn, 0)
+        self.graph = g
+        return feats if Xd.dtype == torch.float32 else feats.to(Xd.dtype)
 
     # ---------------------------------------------------------------------------------------------------------------
     def decode(self, h: torch.Tensor, score_pos: torch.Tensor, y_out: Optional[np.ndarray], t_upto: int, ret_win_size: int,
-               use_hungarian: bool = False) -> Tuple[torch.Tensor, torch.Tensor]:
+               use_hungarian: bool = False, next_t: Optional[int] = None) -> Tuple[torch.Tensor, torch.Tensor]:
         """reference decode_tracks (utils/graph.py:392-539): re-derive the associations from the scores, finalise
-        tracks up to t_upto and delete the decoded part of the graph -- all on the device (tmpnn_track_associate,
-        tmpnn_track_finalize, tmpnn_track_delete, tmpnn_track_gather); ONE host read: the number of kept rows.  The
+        tracks up to t_upto and delete the decoded part of the graph -- all on the device, one call (tmpnn_track_retire:
+        associate, finalize, delete, gather); ONE host read: the number of kept rows.  `next_t` (greedy inference): the
+        timestep the loop will hand to update() next -- its active set is then derived here, on the compacted rows, and
+        read with the same host read, so that update(next_t) given the scores this call returns reads nothing.  The
         finalised tracks live in `self.y_track` (fetch them with tracks() when the sequence is done); pass a host array
         `y_out` [ND, 2] only where it must be current after every call (tests): it costs a device -> host copy.
         Returns the compacted (h', score_pos')."""
         N = self.N
+        self._prefetch = None
         sp = score_pos.detach().reshape(-1).float().contiguous()
-        r = self.rows
-        self._associate(sp, 'test', use_hungarian)
+        if use_hungarian:
+            self._hungarian(sp)
         ND = int(self.y_track.numel())
         wsb = int(_lib.load().tmpnn_track_finalize_ws(N))
         if wsb and (self._fin_ws is None or self._fin_ws.numel() * 4 < wsb):
             self._fin_ws = torch.empty((wsb // 4 + 1,), dtype=torch.int32, device=self.device)
-        _lib.call('tmpnn_track_finalize', self.graph.cref(), r['ts'].data_ptr(), r['det_id'].data_ptr(), r['assoc'].data_ptr(),
-                  sp.data_ptr(), int(t_upto), self.y_track.data_ptr(), ND, self._pos_of_det.data_ptr(),
-                  _lib.ptr(self._fin_ws) if wsb else None, wsb, _stream())
-        if y_out is not None:
-            y_out[:, 1] = self.y_track[:y_out.shape[0]].cpu().numpy()
-        # ---- device: deletion as a stream compaction of rows, state and scores
-        o = self._rows[1 - self._cur]
-        _lib.call('tmpnn_track_delete', N, r['ts'].data_ptr(), r['det_id'].data_ptr(), r['assoc'].data_ptr(),
-                  sp.data_ptr(), r['is_edge'].data_ptr(), r['src'].data_ptr(), r['dst'].data_ptr(),
-                  r['labels'].data_ptr(), int(t_upto), int(ret_win_size), self._keep.data_ptr(), self._small.data_ptr(),
-                  o['ts'].data_ptr(), o['det_id'].data_ptr(), o['assoc'].data_ptr(), o['is_edge'].data_ptr(),
-                  o['src'].data_ptr(), o['dst'].data_ptr(), o['labels'].data_ptr(), _stream())
         hd = h.detach()
         hd = hd if (hd.dtype == torch.float32 and hd.is_contiguous()) else hd.float().contiguous()
         W = int(hd.shape[1])
         h_new = torch.empty((N, W), dtype=torch.float32, device=self.device)
         s_new = torch.empty((N, 1), dtype=torch.float32, device=self.device)
-        _lib.call('tmpnn_track_gather', hd.data_ptr(), W, W, N, self._keep.data_ptr(), self._small.data_ptr(),
-                  h_new.data_ptr(), W, _stream())
-        _lib.call('tmpnn_track_gather', sp.data_ptr(), 1, 1, N, self._keep.data_ptr(), self._small.data_ptr(),
-                  s_new.data_ptr(), 1, _stream())
-        n_keep, _, n_det = self._small[:3].tolist()        # the ONE host read of a decode: kept rows (and how many are dets)
+        nt = -1 if (next_t is None or use_hungarian) else int(next_t)
+        # ---- device, one call: associations, finalisation walk, deletion as a stream compaction of rows, state and scores,
+        # and (next_t) the active set of the next timestep on the compacted rows
+        _lib.call('tmpnn_track_retire', self.graph.cref(), C.byref(self._crows[self._cur]), sp.data_ptr(),
+                  0 if use_hungarian else 1, int(t_upto), int(ret_win_size), self.y_track.data_ptr(), ND,
+                  self._pos_of_det.data_ptr(), _lib.ptr(self._fin_ws) if wsb else None, wsb, self._keep.data_ptr(),
+                  self._small.data_ptr(), C.byref(self._crows[1 - self._cur]), hd.data_ptr(), W, W, h_new.data_ptr(), W,
+                  s_new.data_ptr(), nt, self._active.data_ptr(), _stream())
+        if y_out is not None:
+            y_out[:, 1] = self.y_track[:y_out.shape[0]].cpu().numpy()
+        n_keep, _, n_det, a_next = self._small.tolist()    # the ONE host read of a decode: kept rows (how many are dets; next A)
         self._cur = 1 - self._cur
         self.N, self.E, self.Dn = n_keep, n_keep - n_det, n_det
         self._rebuild()
-        return h_new[:n_keep], s_new[:n_keep, 0]
+        sc = s_new[:n_keep, 0]
+        if nt >= 0:
+            self._prefetch = (nt, sc, a_next, sc._version)
+        return h_new[:n_keep], sc
 
     def kept_rows(self) -> torch.Tensor:
         """Rows of the previous graph that the last decode() kept (ascending)."""
