@@ -362,6 +362,22 @@ int tmpnn_focal_loss_fwd(const int32_t* rows, int R, const float* scores, const 
 int tmpnn_focal_loss_bwd(const int32_t* rows, int R, const float* scores, const uint8_t* targets, float gamma,
                          int use_alpha, float alpha0, float alpha1, const float* d_loss, float scale, float* d_scores,
                          tmpnn_stream stream);
+/* train.py:70-81 for one forward call of a batch-1 window in ONE launch each way: create_targets, the cross-entropy over the
+ * logits and the two focal terms with gamma = 0 and no alpha (edge rows; det rows too with the TP classifier), bit for bit
+ * the values tmpnn_targets / tmpnn_ce_loss_* / tmpnn_focal_loss_* produce (same expressions, sums in the same order).
+ * out [4]: loss_c, focal sum over the edge rows, focal sum over the det rows, loss_f (= mean + mean, NaN over an empty
+ * selection as loss.mean() gives).  targets [N] and stats [Dn][2][4] are kept for the backward.  ws: tmpnn_train_losses_ws
+ * floats.  Supported while E, Dn <= 8192 (tmpnn_train_losses_supported); larger graphs take the separate entry points.
+ * Backward: d_logits [N] / d_scores [N] (either may be NULL) are WRITTEN for every row (zeros where a row has no term);
+ * d_c / d_f: the two seeds (device scalars). */
+int tmpnn_train_losses_supported(int E, int Dn);
+size_t tmpnn_train_losses_ws(int E, int Dn);
+int tmpnn_train_losses_fwd(const tmpnn_graph* g, const float* logits, const float* scores, const uint8_t* labels,
+                           int tp_classifier, uint8_t* targets, float* stats, float* out, float* ws, size_t ws_floats,
+                           tmpnn_stream stream);
+int tmpnn_train_losses_bwd(const tmpnn_graph* g, const int32_t* src_pos, const int32_t* dst_pos, const float* logits,
+                           const float* scores, const uint8_t* targets, const float* stats, const float* d_c, const float* d_f,
+                           int tp_classifier, float* d_logits, float* d_scores, tmpnn_stream stream);
 
 /* ======================================================================================================
  * Batch-1 path (the reference's real call pattern, train.py:92-107 / infer.py:60-87: ONE small

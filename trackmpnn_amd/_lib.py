@@ -158,6 +158,12 @@ _SIGNATURES = {
                                      c_void_p, c_size_t, c_void_p]),
     'tmpnn_focal_loss_bwd': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_float, c_int, c_float, c_float, c_void_p,
                                      c_float, c_void_p, c_void_p]),
+    'tmpnn_train_losses_supported': (c_int, [c_int, c_int]),
+    'tmpnn_train_losses_ws': (c_size_t, [c_int, c_int]),
+    'tmpnn_train_losses_fwd': (c_int, [_GP, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                                       c_size_t, c_void_p]),
+    'tmpnn_train_losses_bwd': (c_int, [_GP, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                       c_int, c_void_p, c_void_p, c_void_p]),
     'tmpnn_dgraph_ints': (c_size_t, [c_int]),
     'tmpnn_dgraph_bind': (c_int, [c_void_p, c_int, c_int, _DGP]),
     'tmpnn_graph_from_coo': (c_int, [c_int, c_void_p, c_void_p, C.c_int64, c_void_p, c_void_p, C.c_int64, _DGP, c_void_p]),

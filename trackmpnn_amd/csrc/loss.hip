@@ -131,6 +131,167 @@ __global__ void k_focal_bwd(const int32_t* __restrict__ rows, int R, const float
     d_scores[row] += d_loss[0] * scale * dq * (t ? 1.0f : -1.0f);
 }
 
+
+// ---- train.py:70-81 for one forward call of a batch-1 window in ONE launch (and one for its adjoint) ---------------------------
+// create_targets, the cross-entropy over the logits and the two focal terms (gamma = 0, no alpha: what train.py constructs), with
+// their sums -- one block, phases separated by barriers.  At batch 1 a call's loss section was ~14 launches forward and ~8
+// backward of 1-5 us kernels, i.e. bound by the launches.  Every value is formed exactly as the separate kernels above form it
+// and the three sums are taken in launch_colsum's order (128-row chunks, four interleaved running sums per chunk, the chunks in
+// sequence), so the results equal the separate entry points bit for bit.  Limits: E, Dn <= TL_MAX_ROWS (64 chunks: no fold).
+static constexpr int TL_THREADS = 1024;
+static constexpr int TL_MAX_ROWS = 64 * 128;
+
+__device__ float tl_ordered_sum(const float* __restrict__ v, int R, float* s_part /* [64][4] */, float* s_chunk /* [64] */) {
+    const int tid = threadIdx.x;
+    const int nch = (R + 127) / 128;
+    if (tid < nch * 4) {
+        const int j = tid >> 2, slot = tid & 3;
+        const int r1 = min(R, j * 128 + 128);
+        float acc = 0.f;
+        for (int r = j * 128 + slot; r < r1; r += 4) acc += v[r];
+        s_part[tid] = acc;
+    }
+    __syncthreads();
+    if (tid < nch) s_chunk[tid] = s_part[4 * tid] + s_part[4 * tid + 1] + s_part[4 * tid + 2] + s_part[4 * tid + 3];
+    __syncthreads();
+    float total = 0.f;
+    if (tid == 0)
+        for (int k = 0; k < nch; ++k) total += s_chunk[k];
+    __syncthreads();
+    return total;                                            // valid on thread 0
+}
+
+__global__ __launch_bounds__(TL_THREADS) void k_train_losses_fwd(tmpnn_graph g, const float* __restrict__ logits,
+                                                                 const float* __restrict__ scores,
+                                                                 const uint8_t* __restrict__ labels, int tp, float inv_e,
+                                                                 float inv_d, uint8_t* __restrict__ targets,
+                                                                 float* __restrict__ stats, float* __restrict__ out,
+                                                                 float* __restrict__ ws) {
+    __shared__ float s_part[256], s_chunk[64];
+    const int tid = threadIdx.x;
+    const int N = g.N, E = g.E, Dn = g.Dn;
+    float* loss_det = ws;
+    float* fe = ws + (Dn > 0 ? Dn : 1);
+    float* fd = fe + (E > 0 ? E : 1);
+    for (int r = tid; r < N; r += TL_THREADS) targets[r] = 0;
+    __syncthreads();
+    // create_targets (k_targets)
+    for (int d = tid; d < Dn; d += TL_THREADS) {
+        const int drow = g.det_row[d];
+        targets[drow] = labels[drow];
+        int last_past = -1, first_future = -1;
+        for (int p = g.rowptr[d]; p < g.rowptr[d + 1]; ++p) {
+            const int v = g.inc[p];
+            const int row = v & 0x7fffffff;
+            if (!labels[row]) continue;
+            if (v < 0) last_past = row;
+            else if (first_future < 0) first_future = row;
+        }
+        if (last_past >= 0) targets[last_past] = 1;
+        if (first_future >= 0) targets[first_future] = 1;
+    }
+    __syncthreads();
+    // cross-entropy per det (k_ce_fwd)
+    for (int d = tid; d < Dn; d += TL_THREADS) {
+        const int p0 = g.rowptr[d], p1 = g.rowptr[d + 1];
+        float loss = 0.f;
+        for (int s = 0; s < 2; ++s) {
+            const bool want_neg = (s == 0);
+            float mx = -INFINITY;
+            int n = 0, trow = -1;
+            for (int p = p0; p < p1; ++p) {
+                const int v = g.inc[p];
+                if ((v < 0) != want_neg) continue;
+                const int row = v & 0x7fffffff;
+                mx = fmaxf(mx, logits[row]);
+                ++n;
+                if (targets[row]) {
+                    if (want_neg) trow = row;
+                    else if (trow < 0) trow = row;
+                }
+            }
+            float z = 0.f;
+            if (trow >= 0) {
+                for (int p = p0; p < p1; ++p) {
+                    const int v = g.inc[p];
+                    if ((v < 0) != want_neg) continue;
+                    z += expf(logits[v & 0x7fffffff] - mx);
+                }
+                loss += (logf(z) + mx - logits[trow]) / (float)n;
+            }
+            float* st = stats + ((size_t)d * 2 + s) * 4;
+            st[0] = mx; st[1] = z; st[2] = (float)trow; st[3] = (float)n;
+        }
+        loss_det[d] = loss;
+    }
+    // focal terms per row (k_focal_fwd with gamma = 0, no alpha: w = 1, at = 1)
+    for (int i = tid; i < E + (tp ? Dn : 0); i += TL_THREADS) {
+        const int row = i < E ? g.edge_row[i] : g.det_row[i - E];
+        const bool t = targets[row] != 0;
+        const float sc = scores[row];
+        const float logpt = logf((t ? sc : 1.0f - sc) + 1e-10f);
+        const float v = -1.0f * logpt * 1.0f;
+        if (i < E) fe[i] = v; else fd[i - E] = v;
+    }
+    __syncthreads();
+    const float lc = tl_ordered_sum(loss_det, Dn, s_part, s_chunk);
+    const float se = tl_ordered_sum(fe, E, s_part, s_chunk);
+    const float sd = tp ? tl_ordered_sum(fd, Dn, s_part, s_chunk) : 0.f;
+    if (tid == 0) {
+        out[0] = lc; out[1] = se; out[2] = sd;
+        // loss_f = focal_node(...) + focal_edge(...) (train.py:81), each a mean: sum * (1 / R), NaN over an empty selection
+        const float me = E > 0 ? se * inv_e : __builtin_nanf("");
+        const float md = Dn > 0 ? sd * inv_d : __builtin_nanf("");
+        out[3] = tp ? md + me : me;
+    }
+}
+
+// the adjoint of both losses, every row written once (no zero fill, no read-modify-write): items [0, E) are the edge rows,
+// [E, E + Dn) the det rows
+__global__ __launch_bounds__(256) void k_train_losses_bwd(tmpnn_graph g, const int32_t* __restrict__ src_pos,
+                                                          const int32_t* __restrict__ dst_pos,
+                                                          const float* __restrict__ logits, const float* __restrict__ scores,
+                                                          const uint8_t* __restrict__ targets, const float* __restrict__ stats,
+                                                          const float* __restrict__ d_c, const float* __restrict__ d_f, int tp,
+                                                          float inv_e, float inv_d, float* __restrict__ d_logits,
+                                                          float* __restrict__ d_scores) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int E = g.E, Dn = g.Dn;
+    if (i >= E + Dn) return;
+    const bool is_e = i < E;
+    const int row = is_e ? g.edge_row[i] : g.det_row[i - E];
+    if (d_logits) {
+        float v = 0.f;
+        if (is_e) {                                          // k_ce_bwd
+            const float l = logits[row];
+            float acc = 0.f;
+            {
+                const float* st = stats + ((size_t)src_pos[i] * 2 + 1) * 4;
+                const int trow = (int)st[2];
+                if (trow >= 0) acc += (expf(l - st[0]) / st[1] - (trow == row ? 1.f : 0.f)) / st[3];
+            }
+            {
+                const float* st = stats + ((size_t)dst_pos[i] * 2 + 0) * 4;
+                const int trow = (int)st[2];
+                if (trow >= 0) acc += (expf(l - st[0]) / st[1] - (trow == row ? 1.f : 0.f)) / st[3];
+            }
+            v = 0.f + d_c[0] * acc;
+        }
+        d_logits[row] = v;
+    }
+    if (d_scores) {
+        float v = 0.f;
+        if (is_e || tp) {                                    // k_focal_bwd, gamma = 0: dq = -1 / q
+            const bool t = targets[row] != 0;
+            const float sc = scores[row];
+            const float q = (t ? sc : 1.0f - sc) + 1e-10f;
+            const float dq = -1.0f / q;
+            v = 0.f + d_f[0] * (is_e ? inv_e : inv_d) * dq * (t ? 1.0f : -1.0f);
+        }
+        d_scores[row] = v;
+    }
+}
+
 }  // namespace tmpnn
 
 using namespace tmpnn;
@@ -208,6 +369,35 @@ int tmpnn_focal_loss_bwd(const int32_t* rows, int R, const float* scores, const 
     hipLaunchKernelGGL(k_focal_bwd, dim3(ceil_div(R, 256)), dim3(256), 0, as_stream(stream), rows, R, scores, targets,
                        gamma, use_alpha, alpha0, alpha1, d_loss, scale, d_scores);
     return check_launch("focal_bwd");
+}
+
+int tmpnn_train_losses_supported(int E, int Dn) { return (E >= 0 && Dn >= 0 && E <= TL_MAX_ROWS && Dn <= TL_MAX_ROWS) ? 1 : 0; }
+size_t tmpnn_train_losses_ws(int E, int Dn) { return (size_t)2 * (Dn > 0 ? Dn : 1) + (size_t)(E > 0 ? E : 1); }
+
+int tmpnn_train_losses_fwd(const tmpnn_graph* g, const float* logits, const float* scores, const uint8_t* labels,
+                           int tp_classifier, uint8_t* targets, float* stats, float* out, float* ws, size_t ws_floats,
+                           tmpnn_stream stream) {
+    TM_REQUIRE(g && logits && scores && labels && targets && stats && out && ws, "train_losses_fwd: null pointer");
+    TM_REQUIRE(tmpnn_train_losses_supported(g->E, g->Dn), "train_losses_fwd: E=%d Dn=%d (one-launch form: <= %d each)", g->E, g->Dn,
+               TL_MAX_ROWS);
+    if (ws_floats < tmpnn_train_losses_ws(g->E, g->Dn)) return set_error(TMPNN_EWORKSPACE, "train_losses_fwd: workspace too small");
+    const float inv_e = g->E > 0 ? (float)(1.0 / g->E) : 0.f, inv_d = g->Dn > 0 ? (float)(1.0 / g->Dn) : 0.f;
+    hipLaunchKernelGGL(k_train_losses_fwd, dim3(1), dim3(TL_THREADS), 0, as_stream(stream), *g, logits, scores, labels,
+                       tp_classifier ? 1 : 0, inv_e, inv_d, targets, stats, out, ws);
+    return check_launch("train_losses_fwd");
+}
+
+int tmpnn_train_losses_bwd(const tmpnn_graph* g, const int32_t* src_pos, const int32_t* dst_pos, const float* logits,
+                           const float* scores, const uint8_t* targets, const float* stats, const float* d_c, const float* d_f,
+                           int tp_classifier, float* d_logits, float* d_scores, tmpnn_stream stream) {
+    TM_REQUIRE(g && logits && scores && targets && stats, "train_losses_bwd: null pointer");
+    TM_REQUIRE((d_logits == nullptr || d_c) && (d_scores == nullptr || d_f), "train_losses_bwd: a gradient without its seed");
+    TM_REQUIRE(g->E == 0 || (src_pos && dst_pos), "train_losses_bwd: det indices of the edge endpoints are required");
+    if (g->N == 0 || (!d_logits && !d_scores)) return TMPNN_OK;
+    const float inv_e = g->E > 0 ? (float)(1.0 / g->E) : 0.f, inv_d = g->Dn > 0 ? (float)(1.0 / g->Dn) : 0.f;
+    hipLaunchKernelGGL(k_train_losses_bwd, dim3(ceil_div(g->N, 256)), dim3(256), 0, as_stream(stream), *g, src_pos, dst_pos,
+                       logits, scores, targets, stats, d_c, d_f, tp_classifier ? 1 : 0, inv_e, inv_d, d_logits, d_scores);
+    return check_launch("train_losses_bwd");
 }
 
 }  // extern "C"

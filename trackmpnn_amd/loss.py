@@ -186,6 +186,19 @@ class _TrainLosses(torch.autograd.Function):
         lg = logits.detach().reshape(-1).float().contiguous()
         sc = scores.detach().reshape(-1).float().contiguous()
         targets = torch.empty_like(labels_u8)
+        ctx.fused = bool(lib.tmpnn_train_losses_supported(E, Dn))
+        if ctx.fused:
+            # batch-1 windows: the whole section in ONE launch (csrc/loss.hip k_train_losses_fwd; same values bit for bit)
+            nd8 = max(Dn, 1) * 8
+            n_ws = int(lib.tmpnn_train_losses_ws(E, Dn))
+            buf = torch.empty((nd8 + 4 + n_ws,), dtype=torch.float32, device=dev)
+            stats, out = buf[:nd8], buf[nd8:nd8 + 4]
+            _lib.call('tmpnn_train_losses_fwd', g.cref(), lg.data_ptr(), sc.data_ptr(), labels_u8.data_ptr(),
+                      1 if tp_classifier else 0, targets.data_ptr(), stats.data_ptr(), out.data_ptr(),
+                      buf.data_ptr() + 4 * (nd8 + 4), n_ws, st)
+            ctx.g, ctx.lg, ctx.sc, ctx.targets, ctx.stats = g, lg, sc, targets, stats
+            ctx.tp, ctx.shapes = bool(tp_classifier), (logits.shape, scores.shape)
+            return out[0], out[3]
         _lib.call('tmpnn_targets', g.cref(), labels_u8.data_ptr(), targets.data_ptr(), st)
         n_ce, n_fe, n_fd = int(lib.tmpnn_ce_loss_ws(Dn)), int(lib.tmpnn_focal_loss_ws(E)), int(lib.tmpnn_focal_loss_ws(Dn))
         buf = torch.empty((max(Dn, 1) * 8 + 4 + n_ce + n_fe + n_fd,), dtype=torch.float32, device=dev)
@@ -219,6 +232,19 @@ class _TrainLosses(torch.autograd.Function):
         g: FrameGraph = ctx.g
         st = _stream()
         d_logits = d_scores = None
+        if ctx.fused:
+            # every row of both gradients written by one launch (no zero fills, no read-modify-write passes)
+            if d_c is not None:
+                d_logits = torch.empty_like(ctx.lg)
+                d_c = d_c.reshape(1).float().contiguous()
+            if d_f is not None:
+                d_scores = torch.empty_like(ctx.sc)
+                d_f = d_f.reshape(1).float().contiguous()
+            _lib.call('tmpnn_train_losses_bwd', g.cref(), _lib.ptr(g.src_pos), _lib.ptr(g.dst_pos), ctx.lg.data_ptr(),
+                      ctx.sc.data_ptr(), ctx.targets.data_ptr(), ctx.stats.data_ptr(), _lib.ptr(d_c), _lib.ptr(d_f),
+                      1 if ctx.tp else 0, _lib.ptr(d_logits), _lib.ptr(d_scores), st)
+            return (None if d_logits is None else d_logits.reshape(ctx.shapes[0]),
+                    None if d_scores is None else d_scores.reshape(ctx.shapes[1]), None, None, None)
         if d_c is not None:
             d_logits = torch.zeros_like(ctx.lg)
             dl = d_c.reshape(1).float().contiguous()

@@ -58,7 +58,7 @@ class TrackGraph:
         self._keep = torch.empty(cap, **i32)
         self._small = torch.zeros(4, **i32)              # [0] count, [1] status, [2] kept dets, [3] next active-set size
         self.track: Optional[torch.Tensor] = None        # int32 [ND] track id of every detection (training labels)
-        self.graph: Optional[DeviceGraph] = None
+        self._graph: Optional[DeviceGraph] = None        # index form of the rows; None: stale (re-derived on first use)
         # per sequence, set by initialize(): the finalised tracks y_out[:, 1] (device, -1 = none yet), the detections of
         # every timestep (device ids sorted by time + host offsets) and the features, uploaded ONCE
         self.y_track: Optional[torch.Tensor] = None
@@ -85,6 +85,14 @@ class TrackGraph:
         lab = self.rows['labels'][:self.N]
         return lab if lab.dtype == torch.uint8 else (lab != 0).to(torch.uint8)
 
+    @property
+    def graph(self) -> DeviceGraph:
+        """Index form (CSR etc.) of the current rows.  After a decode() it is derived on first use only: in the greedy loop
+        the next update() appends a block and derives the grown graph, the intermediate one is never looked at."""
+        if self._graph is None:
+            self._rebuild()
+        return self._graph
+
     def _new_graph(self, N: int):
         """An unbuilt DeviceGraph for N rows (+ the conversion's global scratch beyond the LDS-resident size)."""
         g = DeviceGraph(N, self.device)
@@ -102,7 +110,7 @@ class TrackGraph:
         # the host knows E and Dn of its own graph (initial block, appended blocks, the delete kernel's counts): nothing
         # downstream (staged kernels, losses) has to read them back; graphs built by these kernels are valid by construction
         g._meta = (self.E, self.Dn, 0)
-        self.graph = g
+        self._graph = g
 
     # ---------------------------------------------------------------------------------------------------------------
     @classmethod
@@ -265,7 +273,7 @@ class TrackGraph:
                   _lib.ptr(ws), 0 if ws is None else ws.numel(), st)
         self.N, self.E, self.Dn = N + n_new, self.E + A * D, self.Dn + D
         g._meta = (self.E, self.Dn, 0)
-        self.graph = g
+        self._graph = g
         return feats if Xd.dtype == torch.float32 else feats.to(Xd.dtype)
 
     # ---------------------------------------------------------------------------------------------------------------
@@ -306,7 +314,7 @@ class TrackGraph:
         n_keep, _, n_det, a_next = self._small.tolist()    # the ONE host read of a decode: kept rows (how many are dets; next A)
         self._cur = 1 - self._cur
         self.N, self.E, self.Dn = n_keep, n_keep - n_det, n_det
-        self._rebuild()
+        self._graph = None                                 # (derived on first use: see `graph`)
         sc = s_new[:n_keep, 0]
         if nt >= 0:
             self._prefetch = (nt, sc, a_next, sc._version)
