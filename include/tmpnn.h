@@ -576,6 +576,12 @@ typedef struct tmpnn_track_rows {   /* the row form (see above); labels may be N
     int32_t *src, *dst;
     uint8_t* labels;
 } tmpnn_track_rows;
+/* initialize_graph (utils/graph.py:96-186): the first block of a sequence from ONE packed upload -- packed [6][N] int32 =
+ * ts, det_id, is_edge, src, dst, labels rows; assoc = -1; feats [N][ld_f] = X[det id][0:F] on det rows, zeros on edge rows
+ * (NULL: not written); y_track [ND] = -1 (NULL: untouched); then the index form into g (as tmpnn_graph_from_rows_ws). */
+int tmpnn_track_load(int N, int ND, const int32_t* packed, const tmpnn_track_rows* rows, const float* X, int ld_x, int F,
+                     float* feats, int ld_f, int32_t* y_track, const tmpnn_dgraph* g, void* ws, size_t ws_ints,
+                     tmpnn_stream stream);
 /* update_graph, first half (utils/graph.py:227-278): the associations (skipped with associate = 0: rows->assoc is current)
  * and the active set of timestep t -> active[], small[0]. */
 int tmpnn_track_select(const tmpnn_dgraph* g, const tmpnn_track_rows* rows, const float* score, int mode, int t,

@@ -20,6 +20,8 @@
 // The index form (CSR etc.) is re-derived from the rows by tmpnn_graph_from_rows (csrc/graphconv.hip).  The Hungarian
 // matching stays on the host (tens of detections, scipy).  Integer work,
 // HBM/latency bound, graphs of <= TMPNN_TRACK_MAX_ROWS rows: single-workgroup kernels with LDS scans.
+#include <algorithm>
+
 #include "common.h"
 
 namespace tmpnn {
@@ -406,6 +408,34 @@ __global__ __launch_bounds__(TK_THREADS) void k_track_finalize(tmpnn_dgraph g, c
         if (flag[k] & 4) y_track[det_id[g.det_row[k]]] = tidv[best[k]];
 }
 
+
+// ---- the first block of a sequence (initialize_graph, utils/graph.py:96-186), uploaded as ONE packed int32 array ----------------
+// packed [6][N]: ts, det_id, is_edge, src, dst, labels.  Also: assoc = -1, the features of the block (X[det id] on det rows, zeros
+// on edge rows) and y_out[:, 1] = -1 for the whole sequence.
+__global__ __launch_bounds__(256) void k_track_load(int N, int ND, const int32_t* __restrict__ packed, int32_t* __restrict__ ts,
+                                                    int32_t* __restrict__ det_id, int32_t* __restrict__ assoc,
+                                                    uint8_t* __restrict__ is_edge, int32_t* __restrict__ row_src,
+                                                    int32_t* __restrict__ row_dst, uint8_t* __restrict__ labels,
+                                                    const float* __restrict__ X, int ld_x, int F, float* __restrict__ feats,
+                                                    int ld_f, int32_t* __restrict__ y_track) {
+    const long stride = (long)gridDim.x * 256;
+    const long i0 = (long)blockIdx.x * 256 + threadIdx.x;
+    for (long r = i0; r < N; r += stride) {
+        ts[r] = packed[r]; det_id[r] = packed[(size_t)N + r]; is_edge[r] = (uint8_t)packed[(size_t)2 * N + r];
+        row_src[r] = packed[(size_t)3 * N + r]; row_dst[r] = packed[(size_t)4 * N + r];
+        if (labels) labels[r] = (uint8_t)packed[(size_t)5 * N + r];
+        assoc[r] = -1;
+    }
+    if (feats)
+        for (long i = i0; i < (long)N * F; i += stride) {
+            const int r = (int)(i / F), c = (int)(i % F);
+            const int id = packed[(size_t)N + r];
+            feats[(size_t)r * ld_f + c] = id >= 0 ? X[(size_t)id * ld_x + c] : 0.f;
+        }
+    if (y_track)
+        for (long i = i0; i < ND; i += stride) y_track[i] = -1;
+}
+
 }  // namespace tmpnn
 
 using namespace tmpnn;
@@ -568,6 +598,23 @@ int tmpnn_track_retire(const tmpnn_dgraph* g, const tmpnn_track_rows* rows, cons
         if ((rc = check_launch("track_retire (next active set)"))) return rc;
     }
     return TMPNN_OK;
+}
+
+int tmpnn_track_load(int N, int ND, const int32_t* packed, const tmpnn_track_rows* rows, const float* X, int ld_x, int F,
+                     float* feats, int ld_f, int32_t* y_track, const tmpnn_dgraph* g, void* ws, size_t ws_ints,
+                     tmpnn_stream stream) {
+    TM_REQUIRE(N >= 0 && N <= TMPNN_TRACK_MAX_ROWS && ND >= 0, "track_load: N=%d (limit %d) ND=%d", N, TMPNN_TRACK_MAX_ROWS, ND);
+    TM_REQUIRE(rows_ok(rows) && (N == 0 || packed) && g, "track_load: null pointer");
+    TM_REQUIRE(feats == nullptr || (X && F > 0 && ld_x >= F && ld_f >= F), "track_load: feature arguments (F=%d ld_x=%d ld_f=%d)", F,
+               ld_x, ld_f);
+    const long work = std::max<long>(std::max<long>((long)N * (feats ? F : 1), ND), 1);
+    long blocks = (work + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(k_track_load, dim3((int)blocks), dim3(256), 0, as_stream(stream), N, ND, packed, rows->ts, rows->det_id,
+                       rows->assoc, rows->is_edge, rows->src, rows->dst, rows->labels, X, ld_x, F, feats, ld_f, y_track);
+    int rc = check_launch("track_load");
+    if (rc) return rc;
+    return tmpnn_graph_from_rows_ws(N, rows->is_edge, rows->src, rows->dst, g, ws, ws_ints, stream);
 }
 
 }  // extern "C"

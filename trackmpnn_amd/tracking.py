@@ -149,28 +149,36 @@ class TrackGraph:
         lab[n0:n0 + n0 * n1] = same.reshape(-1)
         tg = cls(device)
         tg.N, tg.E, tg.Dn = N, n0 * n1, n0 + n1
-        r = tg.rows
-        for key, arr in (('ts', ts), ('det_id', did), ('is_edge', is_edge), ('src', src), ('dst', dst), ('labels', lab)):
-            r[key][:N].copy_(torch.from_numpy(arr))
-        r['assoc'][:N].fill_(-1)
-        tg.track = torch.from_numpy(trk.astype(np.int32)).to(tg.device)
-        tg._rebuild()
-        tg._sequence(X, yy)
+        # ONE upload for the whole sequence: the block's rows, the detections sorted by time, their tracks and the features
+        ND, F = int(yy.shape[0]), int(X.shape[2])
+        order = np.argsort(yy[:, 0], kind='stable').astype(np.int32)
+        parts = [ts, did, is_edge.astype(np.int32), src, dst, lab.astype(np.int32), order, trk.astype(np.int32)]
+        x_host = not X.is_cuda
+        if x_host:
+            parts.append(np.ascontiguousarray(X[0].detach().float().numpy()).view(np.int32).reshape(-1))
+        pk = torch.from_numpy(np.concatenate(parts)).to(tg.device)
+        tg._ids_sorted = pk[6 * N:6 * N + ND]
+        tg.track = pk[6 * N + ND:6 * N + 2 * ND]
+        if x_host:
+            tg._Xf = pk[6 * N + 2 * ND:].view(torch.float32).view(ND, F)
+            tg._Xd = tg._Xf if X.dtype == torch.float32 else X[0].to(tg.device)
+        else:
+            tg._Xd = X[0].to(tg.device)
+            tg._Xf = tg._Xd if (tg._Xd.dtype == torch.float32 and tg._Xd.is_contiguous()) else tg._Xd.float().contiguous()
+        tg._sequence(yy, order)
         tg._X_src, tg._y_src = X, y
-        Xd = tg._Xd
-        feats = torch.zeros((N, X.shape[2]), dtype=Xd.dtype, device=tg.device)
-        feats[:n0] = Xd[torch.from_numpy(ids0).to(tg.device)]
-        feats[n0 + n0 * n1:] = Xd[torch.from_numpy(ids1).to(tg.device)]
-        return tg, feats, t1 + 1, tN + 1
+        feats = torch.empty((N, F), dtype=torch.float32, device=tg.device)
+        g, ws = tg._new_graph(N)
+        _lib.call('tmpnn_track_load', N, ND, pk.data_ptr(), C.byref(tg._crows[tg._cur]), tg._Xf.data_ptr(), F, F, feats.data_ptr(),
+                  F, tg.y_track.data_ptr(), g.cref(), _lib.ptr(ws), 0 if ws is None else ws.numel(), _stream())
+        g._meta = (tg.E, tg.Dn, 0)
+        tg._graph = g
+        tg._pk = pk                                        # (the views above keep it alive as well)
+        return tg, (feats if tg._Xd.dtype == torch.float32 else feats.to(tg._Xd.dtype)), t1 + 1, tN + 1
 
-    def _sequence(self, X: torch.Tensor, yy: np.ndarray) -> None:
-        """Per-sequence device state, uploaded once: features, the detections of every timestep, y_out[:, 1]."""
+    def _sequence(self, yy: np.ndarray, order: np.ndarray) -> None:
+        """Per-sequence host state: where each timestep's detections sit in the time-sorted id list; device scratch."""
         ND = int(yy.shape[0])
-        self._Xd = X[0].to(self.device)
-        # (what the append kernel reads: fp32 rows)
-        self._Xf = self._Xd if (self._Xd.dtype == torch.float32 and self._Xd.is_contiguous()) else self._Xd.float().contiguous()
-        order = np.argsort(yy[:, 0], kind='stable')
-        self._ids_sorted = torch.from_numpy(order.astype(np.int32)).to(self.device)
         ts_sorted = yy[order, 0]
         self._t_range = {}
         if ND:
@@ -178,8 +186,8 @@ class TrackGraph:
             lo = np.concatenate([[0], cut])
             hi = np.concatenate([cut, [ND]])
             self._t_range = {int(ts_sorted[a]): (int(a), int(b)) for a, b in zip(lo, hi)}
-        self.y_track = torch.full((max(ND, 1),), -1, dtype=torch.int32, device=self.device)
-        self._pos_of_det = torch.zeros((max(ND, 1),), dtype=torch.int32, device=self.device)
+        self.y_track = torch.empty((max(ND, 1),), dtype=torch.int32, device=self.device)     # (-1 everywhere: tmpnn_track_load)
+        self._pos_of_det = torch.empty((max(ND, 1),), dtype=torch.int32, device=self.device)
 
     def tracks(self) -> np.ndarray:
         """y_out[:, 1] of the sequence so far (one device -> host copy; call it when the sequence is done)."""
