@@ -52,6 +52,23 @@ typedef void* tmpnn_event;  /* hipEvent_t, created and owned by the caller (the 
  * entries are edge ROW indices with the sign of edge_adj[d, e] in bit 31 (set = -1 = d is the
  * later det of e).  Built once per call by the host from the adjacency the reference passes.
  */
+/* Optional plan of a DENSE graph for the edge -> det segment sum (csrc/agg.hip, k_segsum_tiles): the edge set cut into
+ * 8 src x 16 dst tiles over det indices, each summed by the workgroup that streams its rows, so that an edge row is read
+ * from HBM once instead of once per endpoint.  Built by the host once per graph (trackmpnn_amd.graph.dense_seg_plan); the
+ * caller owns every array including the partial-row buffer `ws` (one segment sum at a time per plan). */
+typedef struct tmpnn_seg_plan {
+    int32_t T;               /* tiles */
+    int32_t I;               /* work items: runs of consecutive tiles that share their 16 dsts */
+    int32_t nsplit;          /* = N of the graph: entries of inc2 at or above it address partial rows */
+    const int32_t* t_row;    /* [T][8][16] edge row of (src i, dst j) of a tile, -1 where the graph has no such edge */
+    const int32_t* items;    /* [I][2] first tile, tile count */
+    const int32_t* rowptr2;  /* [Dn+1] CSR of the second pass */
+    const int32_t* inc2;     /* per det: nsplit + partial row (tile t, src i: 8t + i; item k, dst j: 8T + 16k + j), or a
+                                plain edge row (< nsplit); sign bit as in tmpnn_graph.inc */
+    float* ws;               /* [8 T + 16 I][256] partial rows */
+    size_t ws_floats;
+} tmpnn_seg_plan;
+
 typedef struct tmpnn_graph {
     int32_t N;               /* rows of the state tensor (dets + edges) */
     int32_t E;               /* edge rows */
@@ -66,6 +83,8 @@ typedef struct tmpnn_graph {
                                 0..Dn-1).  Results do not depend on it; a host that batches independent windows lists
                                 each window's dets together, so that the two reads of an edge row (one from either
                                 endpoint) are issued from the same CU close in time */
+    const tmpnn_seg_plan* seg_plan; /* or NULL: dense graphs, H = 256 column blocks -- tmpnn_segsum_fwd and the wide cells'
+                                       backward then read every edge row once (see tmpnn_seg_plan) */
 } tmpnn_graph;
 
 /*

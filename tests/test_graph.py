@@ -306,3 +306,84 @@ def test_module_copy_and_pickle_on_the_host():
         assert float(m.factor_grus[0].edge_gru.weight_hh.abs().sum()) > 0
     m.refresh_weights()                                # drops every cached pointer; nothing to rebuild on the host
     assert m._plist is None and m._sink is None
+
+
+@pytest.mark.parametrize('T,D', [(4, 45), (3, 64), (5, 37)])
+def test_dense_seg_plan_covers_every_incidence_once(T, D):
+    """struct tmpnn_seg_plan (trackmpnn_amd.graph.build_seg_plan, consumed by csrc/agg.hip k_segsum_tiles +
+    k_segsum_pipe<DUAL>): emulate the two passes with torch ops -- per-tile src sums and per-item dst sums into partial rows,
+    then per det the signed sum over its second-pass CSR -- and compare with the plain signed segment sum
+    (models/layers.py:103) on integer-valued rows (exact in fp32 in any order)."""
+    from trackmpnn_amd.graph import build_seg_plan, dense_static_graph
+    g = dense_static_graph(T, D)
+    plan = build_seg_plan(g, item_tiles=3, min_fill=0.0)
+    assert plan is not None and plan.T > 0 and plan.nsplit == g.N
+    H = 8
+    x = torch.randint(-8, 9, (g.N, H), generator=torch.Generator().manual_seed(T * 100 + D)).float()
+    # reference: es[d] = sum over incident edges of (+x[e] if d is the src, -x[e] if the dst)
+    ref = torch.zeros(g.Dn, H)
+    ref.index_add_(0, g.src_pos.long(), x[g.edge_row.long()])
+    ref.index_add_(0, g.dst_pos.long(), -x[g.edge_row.long()])
+    # pass 1: every edge row sits in exactly one slot of one tile
+    t_row = plan.t_row.long().view(plan.T, 128)
+    live = t_row >= 0
+    assert int(live.sum()) == g.E and torch.equal(torch.sort(t_row[live])[0], torch.sort(g.edge_row.long())[0])
+    tiles = (x[t_row.clamp(min=0)] * live[..., None]).view(plan.T, 8, 16, H)
+    part = torch.zeros(8 * plan.T + 16 * plan.I, H)
+    part[:8 * plan.T] = tiles.sum(2).reshape(-1, H)
+    for k, (t0, nt) in enumerate(plan.items.tolist()):
+        part[8 * plan.T + 16 * k:8 * plan.T + 16 * k + 16] = tiles[t0:t0 + nt].sum((0, 1))
+    assert int(plan.items[:, 1].sum()) == plan.T and int(plan.items[:, 1].max()) <= 3
+    # pass 2
+    inc2 = plan.inc2.long()
+    neg = inc2 < 0
+    idx = torch.where(neg, inc2 + 2 ** 31, inc2)
+    assert bool((idx >= plan.nsplit).all())
+    rows = part[idx - plan.nsplit]
+    rows = torch.where(neg[:, None], -rows, rows)
+    det = torch.repeat_interleave(torch.arange(g.Dn), torch.diff(plan.rowptr2.long()))
+    out = torch.zeros(g.Dn, H)
+    out.index_add_(0, det, rows)
+    assert torch.equal(out, ref)
+    # a graph with an edge listed twice has no plan (a slot holds one row)
+    g2 = dense_static_graph(2, 20)
+    g2.src_pos[1], g2.dst_pos[1] = g2.src_pos[0], g2.dst_pos[0]
+    assert build_seg_plan(g2, min_fill=0.0) is None
+
+
+@pytest.mark.gpu
+def test_dense_segsum_reads_rows_once_and_matches_the_csr_kernel():
+    """tmpnn_segsum_fwd with a tmpnn_seg_plan on the graph (dense form: k_segsum_tiles + k_segsum_pipe<DUAL>) against the same
+    entry point without one (k_segsum_pipe over the graph's CSR): exact on integer-valued rows, 1e-5 relative on random rows
+    (another summation order), bitwise repeatable; compact and scattered output, accumulate on and off, a column block of a
+    wider row (the wide backward's d_gi planes)."""
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU')
+    from trackmpnn_amd import _lib
+    from trackmpnn_amd.graph import dense_seg_plan, dense_static_graph
+    dev = torch.device('cuda:0')
+    g = dense_static_graph(5, 150, device=dev)            # E = 90 000 (150 = 9 x 16 + 6 = 18 x 8 + 6: ragged borders too)
+    g0 = dense_static_graph(5, 150, device=dev)
+    plan = dense_seg_plan(g)
+    assert plan is not None and plan.T > 0 and 128 * plan.T > g.E        # (border tiles have empty slots)
+    H, LD = 256, 1024
+    st = _lib.raw_stream()
+    gen = torch.Generator().manual_seed(3)
+    for kind in ('int', 'rand'):
+        x = (torch.randint(-8, 9, (g.N, LD), generator=gen).float() if kind == 'int'
+             else torch.randn(g.N, LD, generator=gen)).to(dev)
+        for c0, compact, acc in ((0, 1, 0), (256, 1, 0), (512, 0, 1), (0, 0, 0)):
+            rows = g.Dn if compact else g.N
+            base = torch.randn(rows, H, generator=gen).to(dev) if acc else torch.zeros(rows, H, device=dev)
+            outs = []
+            for graph in (g, g0, g):
+                o = base.clone()
+                _lib.call('tmpnn_segsum_fwd', graph.cref(), x.data_ptr() + 4 * c0, LD, o.data_ptr(), H, H, acc, compact, st)
+                outs.append(o)
+            torch.cuda.synchronize()
+            assert torch.equal(outs[0], outs[2]), (kind, c0, compact, acc)
+            if kind == 'int' and not acc:
+                assert torch.equal(outs[0], outs[1]), (kind, c0, compact, acc)
+            else:
+                scale = outs[1].abs().max().item()
+                assert (outs[0] - outs[1]).abs().max().item() <= 1e-5 * scale, (kind, c0, compact, acc)

@@ -25,11 +25,17 @@ c_size_t = C.c_size_t
 c_float = C.c_float
 
 
+class CSegPlan(C.Structure):
+    """struct tmpnn_seg_plan (include/tmpnn.h): the single-read segment sum of a dense graph."""
+    _fields_ = [('T', C.c_int32), ('I', C.c_int32), ('nsplit', C.c_int32), ('t_row', c_void_p), ('items', c_void_p),
+                ('rowptr2', c_void_p), ('inc2', c_void_p), ('ws', c_void_p), ('ws_floats', c_size_t)]
+
+
 class CGraph(C.Structure):
     """struct tmpnn_graph (include/tmpnn.h)."""
     _fields_ = [('N', C.c_int32), ('E', C.c_int32), ('Dn', C.c_int32),
                 ('src', c_void_p), ('dst', c_void_p), ('edge_row', c_void_p), ('det_row', c_void_p),
-                ('rowptr', c_void_p), ('inc', c_void_p), ('det_order', c_void_p)]
+                ('rowptr', c_void_p), ('inc', c_void_p), ('det_order', c_void_p), ('seg_plan', c_void_p)]
 
 
 _GP = C.POINTER(CGraph)

@@ -227,14 +227,17 @@ __global__ __launch_bounds__(256) void k_gather_pipe(int E, const int32_t* __res
     }
 }
 
-template <bool ACC, int U = 4, int SEG_CHUNK = 32>
+// DUAL (the second pass of the dense form below): incidence entries >= nsplit address rows of `part` ([.][H], dense) instead of
+// rows of `in`
+template <bool ACC, int U = 4, int SEG_CHUNK = 32, bool DUAL = false>
 __global__ __launch_bounds__(256) void k_segsum_pipe(int Dn, const int32_t* __restrict__ det_row,
                                                      const int32_t* __restrict__ rowptr,
                                                      const int32_t* __restrict__ inc,
                                                      const int32_t* __restrict__ det_order,
                                                      const float* __restrict__ in, int ld_in,
                                                      float* __restrict__ out, int ld_out, int H,
-                                                     float wneg, int cneg, int compact_out) {
+                                                     float wneg, int cneg, int compact_out,
+                                                     const float* __restrict__ part = nullptr, int nsplit = 0) {
     const int lane = threadIdx.x & 63;
     const int lpr = H >> 2;
     const int ngrp = 64 / lpr;
@@ -286,7 +289,10 @@ __global__ __launch_bounds__(256) void k_segsum_pipe(int Dn, const int32_t* __re
             live[u] = vC[u] != 0x7fffffff;
             const int row = live[u] ? (vC[u] & 0x7fffffff) : 0;
             w[u] = vC[u] < 0 ? wneg : 1.0f;
-            x[u] = *reinterpret_cast<const float4*>(in + (size_t)row * ld_in + (vC[u] < 0 ? cneg : 0) + c4);
+            if (DUAL && row >= nsplit)
+                x[u] = *reinterpret_cast<const float4*>(part + (size_t)(row - nsplit) * H + c4);
+            else
+                x[u] = *reinterpret_cast<const float4*>(in + (size_t)row * ld_in + (vC[u] < 0 ? cneg : 0) + c4);
         }
         // the next item's index loads are issued behind this pass's row loads: the det's next pass (a long CSR run
         // takes several) or, after its last pass, the next det of the pipeline
@@ -451,6 +457,90 @@ static int gather(const tmpnn_graph* g, const float* in, int ld_in, float* out, 
     return check_launch("gather");
 }
 
+
+// ---- dense graphs (BASELINE C5: frame blocks of 300 x 300 edges): a segment sum that reads every edge row ONCE -----------------
+// k_segsum_pipe reads a row once from either endpoint; in a batch of small windows the second read is an L2 / MALL hit, in a
+// dense scene it is a second HBM read (PMC: 1.99 x the rows at C5, the kernel at ~5.9 TB/s of real traffic).  Here the edge set
+// is cut into 8 src x 16 dst TILES over det indices (struct tmpnn_seg_plan, built once per graph by the host:
+// trackmpnn_amd.graph.dense_seg_plan; a slot without an edge holds -1) and a tile is summed by the block that streams it: wave w keeps the running sums of dsts 4w .. 4w+3 in registers over a whole ITEM
+// (<= a few dozen consecutive tiles that share their 16 dsts) and forms, per tile, its share of the 8 src sums, which the four
+// waves combine through LDS in a fixed order.  Out go one partial row per (tile, src) and per (item, dst): 6 % + < 1 % of the
+// bytes read.  A second pass (k_segsum_pipe<DUAL>) sums, per det, its partial rows -- a CSR over them (plan->rowptr2 / inc2;
+// raw edge rows are allowed in it too).  fp32, no atomics, every sum in a fixed order.
+__global__ __launch_bounds__(256) void k_segsum_tiles(int I, int T, const int32_t* __restrict__ items,
+                                                      const int32_t* __restrict__ t_row, const float* __restrict__ in,
+                                                      int ld_in, float* __restrict__ part) {
+    __shared__ float4 S[4][8][64];                              // 32 KB: a wave's share of the tile's 8 src sums
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    auto add4 = [](float4 a, const float4& b) { a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; return a; };
+    for (int k = blockIdx.x; k < I; k += gridDim.x) {
+        const int t0 = items[2 * k], nt = items[2 * k + 1];
+        float4 ad[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) ad[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int t = t0; t < t0 + nt; ++t) {
+            const int32_t* tr = t_row + (size_t)t * 128 + 4 * w;
+            float4 ps[8];
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                float4 x[4][4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int row = tr[(half * 4 + i) * 16 + j];        // wave-uniform; -1: no such edge
+                        // (branch-free: a conditional load makes hipcc drain the request queue at the join)
+                        x[i][j] = *reinterpret_cast<const float4*>(in + (size_t)(row < 0 ? 0 : row) * ld_in + 4 * lane);
+                        if (row < 0) x[i][j] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    ps[half * 4 + i] = add4(add4(add4(x[i][0], x[i][1]), x[i][2]), x[i][3]);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) ad[j] = add4(ad[j], x[i][j]);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) S[w][i][lane] = ps[i];
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const int i = w + 4 * r;
+                const float4 v = add4(add4(add4(S[0][i][lane], S[1][i][lane]), S[2][i][lane]), S[3][i][lane]);
+                *reinterpret_cast<float4*>(part + ((size_t)t * 8 + i) * 256 + 4 * lane) = v;
+            }
+            __syncthreads();
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            *reinterpret_cast<float4*>(part + ((size_t)8 * T + (size_t)16 * k + 4 * w + j) * 256 + 4 * lane) = ad[j];
+    }
+}
+
+static int segsum_dense(const tmpnn_graph* g, const tmpnn_seg_plan* pl, const float* in, int ld_in, float* out, int ld_out,
+                        int accumulate, int compact_out, hipStream_t st) {
+    TM_REQUIRE(pl->T >= 0 && pl->I >= 0 && pl->nsplit == g->N && pl->rowptr2 && pl->inc2 && (pl->T == 0 || (pl->t_row && pl->items)),
+               "segsum (dense form): inconsistent plan (T=%d I=%d nsplit=%d N=%d)", pl->T, pl->I, pl->nsplit, g->N);
+    const size_t need = ((size_t)8 * pl->T + (size_t)16 * pl->I) * 256;
+    if (need > 0 && (pl->ws == nullptr || pl->ws_floats < need))
+        return set_error(TMPNN_EWORKSPACE, "segsum (dense form): the plan's partial buffer holds %zu floats, %zu needed", pl->ws_floats, need);
+    if (pl->I > 0) {
+        const int grid = pl->I < 256 * 4 ? pl->I : 256 * 4;
+        hipLaunchKernelGGL(k_segsum_tiles, dim3(grid), dim3(256), 0, st, pl->I, pl->T, pl->items, pl->t_row, in, ld_in, pl->ws);
+        int rc = check_launch("segsum_tiles");
+        if (rc) return rc;
+    }
+    dim3 grid(grid_for(g->Dn, 16)), block(256);
+    if (accumulate)
+        hipLaunchKernelGGL((k_segsum_pipe<true, 8, 16, true>), grid, block, 0, st, g->Dn, g->det_row, pl->rowptr2, pl->inc2,
+                           (const int32_t*)nullptr, in, ld_in, out, ld_out, 256, -1.0f, 0, compact_out, pl->ws, pl->nsplit);
+    else
+        hipLaunchKernelGGL((k_segsum_pipe<false, 8, 16, true>), grid, block, 0, st, g->Dn, g->det_row, pl->rowptr2, pl->inc2,
+                           (const int32_t*)nullptr, in, ld_in, out, ld_out, 256, -1.0f, 0, compact_out, pl->ws, pl->nsplit);
+    return check_launch("segsum (dense form, second pass)");
+}
+
 static int segsum(const tmpnn_graph* g, const float* in, int ld_in, float* out, int ld_out, int H, int accumulate,
                   float wneg, int cneg, int compact_out, tmpnn_stream stream) {
     int rc = check_graph(g);
@@ -459,6 +549,8 @@ static int segsum(const tmpnn_graph* g, const float* in, int ld_in, float* out, 
     if (rc) return rc;
     if (g->Dn == 0) return TMPNN_OK;
     hipStream_t st = as_stream(stream);
+    if (g->seg_plan && H == 256 && wneg == -1.0f && cneg == 0)        // dense graph with a plan: every edge row read once
+        return segsum_dense(g, g->seg_plan, in, ld_in, out, ld_out, accumulate, compact_out, st);
     dim3 grid(grid_for(g->Dn, 64)), block(256);
 #define LS(K, A) hipLaunchKernelGGL((K<A>), grid, block, 0, st, g->Dn, g->det_row, g->rowptr, g->inc, g->det_order, in, ld_in, out, ld_out, H, wneg, cneg, compact_out)
 #define LSP(A, UU, CH)                                                                                       \

@@ -17,7 +17,7 @@ from typing import Dict, List, Optional, Sequence, Tuple
 import torch
 
 from . import _lib
-from .graph import CallPlan, edge_tiles
+from .graph import CallPlan, dense_seg_plan, edge_tiles
 
 ATT_DROPOUT_P = 0.5
 # OPT-IN fast path: accumulate parameter gradients straight into existing p.grad buffers (the kernels add into their
@@ -341,6 +341,10 @@ def mp_forward(spec: ModelSpec, plan: CallPlan, x: torch.Tensor, h_in: Optional[
                     and Dn > 0 and E > 0)
     use_wide = (WIDE and spec.msg_type == 'diff' and H >= 128 and bool(lib.tmpnn_wide_supported(H, H))
                 and g.src_pos is not None and Dn > 0 and E > 0)
+    if use_wide and H % 256 == 0 and K == 0:
+        # dense scenes: the plan of the single-read segment sum rides on the graph's C struct (tmpnn_segsum_fwd here and inside
+        # the wide backward take it on 256-column blocks); None for ragged graphs
+        dense_seg_plan(g)
     wide_preps = []
     # output head fused into the cells' epilogues where the LDS-resident kernel runs (else tmpnn_heads_fwd)
     cw = min(lib.tmpnn_gru_fwd_head_parts(H, H if use_proj_cat else spec.IN_e, 3 if (use_proj or use_proj_cat) else xmode),

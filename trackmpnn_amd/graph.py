@@ -60,9 +60,11 @@ class FrameGraph:
 
     def cstruct(self) -> _lib.CGraph:
         if self._c is None:
+            plan = self.__dict__.get('_seg_plan')
             self._c = _lib.CGraph(self.N, self.E, self.Dn, self.src.data_ptr(), self.dst.data_ptr(),
                                   self.edge_row.data_ptr(), self.det_row.data_ptr(), self.rowptr.data_ptr(),
-                                  self.inc.data_ptr(), _lib.ptr(self.det_order))
+                                  self.inc.data_ptr(), _lib.ptr(self.det_order),
+                                  None if plan is None else C.addressof(plan.c))
         return self._c
 
     def cref(self):
@@ -203,6 +205,96 @@ def edge_tiles(graph: FrameGraph, rows_per_tile: int = 128, dst_offset: int = 0)
             t = build_edge_tiles(graph, rows_per_tile, 4, 8, order=od, dst_offset=dst_offset)
         cache[key] = t
     return t
+
+
+class SegPlan:
+    """struct tmpnn_seg_plan (include/tmpnn.h) with the tensors it points at."""
+
+    def __init__(self, T, I, nsplit, t_row, items, rowptr2, inc2, ws):
+        self.T, self.I, self.nsplit = int(T), int(I), int(nsplit)
+        self.t_row, self.items, self.rowptr2, self.inc2, self.ws = t_row, items, rowptr2, inc2, ws
+        self.c = _lib.CSegPlan(self.T, self.I, self.nsplit, t_row.data_ptr(), items.data_ptr(), rowptr2.data_ptr(),
+                               inc2.data_ptr(), ws.data_ptr(), ws.numel())
+
+
+SEG_ITEM_TILES = 13          # tiles per work item of the dense segment sum (a 300-src frame block: 37 tiles -> 13 + 12 + 12)
+
+
+def build_seg_plan(graph: FrameGraph, item_tiles: int = SEG_ITEM_TILES, min_fill: float = 0.5) -> Optional[SegPlan]:
+    """The single-read segment sum's plan of a DENSE graph (struct tmpnn_seg_plan; csrc/agg.hip k_segsum_tiles).
+
+    A frame block of the rolling graph is a dense [A srcs x D dsts] set of edge rows (reference/utils/graph.py:141-156,
+    285-301).  Over det INDICES, the cell (dst // 16, src // 8) of an edge is its TILE and (src % 8, dst % 16) its slot in
+    the tile's [8][16] row list (-1: no such edge -- block borders, deleted rows); the workgroup that streams a tile sums it.
+    Consecutive tiles of one dst group form work items of at most `item_tiles` tiles whose 16 dst sums stay in registers.  The
+    second pass's CSR lists, per det, its partial rows: one per tile it is a src of, one per item it is a dst of.  Returns
+    None where the tiles would be less than `min_fill` full (ragged graphs: k_segsum_pipe stays the better kernel) or an edge
+    is listed twice.  Index plumbing only, on the graph's device; two host reads (the tile / item counts size the arrays)."""
+    if graph.src_pos is None or graph.dst_pos is None or graph.E == 0:
+        return None
+    dev = graph.device
+    E, N, Dn = graph.E, graph.N, graph.Dn
+    s, d = graph.src_pos.long(), graph.dst_pos.long()
+    ns = Dn // 8 + 1
+    cell = (d // 16) * ns + s // 8
+    slot = (s % 8) * 16 + d % 16
+    ucell, tile_of = torch.unique(cell, return_inverse=True)     # sorted: tiles in (dst group, src group) order
+    T = int(ucell.numel())                                       # (host read)
+    if E < min_fill * 128 * T:
+        return None
+    t_row = torch.full((T * 128,), -1, dtype=torch.int32, device=dev)
+    flat = tile_of * 128 + slot
+    t_row[flat] = graph.edge_row.to(torch.int32)
+    dgrp = ucell // ns
+    # work items: runs of consecutive tiles of one dst group, cut every `item_tiles`
+    new_run = torch.ones(T, dtype=torch.bool, device=dev)
+    new_run[1:] = dgrp[1:] != dgrp[:-1]
+    run_start = torch.nonzero(new_run).flatten()
+    run_id = torch.cumsum(new_run.long(), 0) - 1
+    in_run = torch.arange(T, device=dev) - run_start[run_id]
+    item_start = torch.nonzero(in_run % int(item_tiles) == 0).flatten()
+    # (second host read, with the duplicate check: two edges in one slot would lose one of them)
+    I, filled = item_start.numel(), int((t_row >= 0).sum())
+    if filled != E:
+        return None
+    item_cnt = torch.diff(item_start, append=torch.tensor([T], device=dev))
+    items = torch.stack([item_start, item_cnt], 1).to(torch.int32).contiguous()
+    item_of_tile = torch.cumsum((in_run % int(item_tiles) == 0).long(), 0) - 1
+    # second pass: per det its partial rows -- (tile, src i) -> N + 8 t + i ; (item, dst j) -> N + 8 T + 16 k + j
+    src_slot = torch.unique(tile_of * 8 + s % 8)                  # the (tile, i) pairs that exist
+    src_det = (ucell[src_slot // 8] % ns) * 8 + src_slot % 8
+    dst_slot = torch.unique(item_of_tile[tile_of] * 16 + d % 16)  # the (item, j) pairs that exist
+    dst_det = dgrp[item_start[dst_slot // 16]] * 16 + dst_slot % 16
+    P = 8 * T + 16 * I
+    if N + P >= 2 ** 31:
+        return None
+    det_all = torch.cat([src_det, dst_det])
+    ent_all = torch.cat([N + src_slot, N + 8 * T + dst_slot])
+    neg_all = torch.cat([torch.zeros_like(src_det, dtype=torch.bool), torch.ones_like(dst_det, dtype=torch.bool)])
+    order = torch.argsort(det_all * (N + P + 1) + ent_all)
+    inc2 = torch.where(neg_all[order], ent_all[order] - 2 ** 31, ent_all[order]).to(torch.int32).contiguous()
+    counts = torch.bincount(det_all, minlength=Dn)
+    rowptr2 = torch.zeros(Dn + 1, dtype=torch.long, device=dev)
+    rowptr2[1:] = torch.cumsum(counts, 0)
+    ws = torch.empty((P * 256,), dtype=torch.float32, device=dev)
+    return SegPlan(T, I, N, t_row, items, rowptr2.to(torch.int32).contiguous(), inc2, ws)
+
+
+def dense_seg_plan(graph: FrameGraph) -> Optional[SegPlan]:
+    """The graph's cached single-read segment-sum plan (built on first use; None for ragged graphs), attached to the graph's C
+    struct so that tmpnn_segsum_fwd and the wide cells' backward take the dense form on 256-column blocks."""
+    d = graph.__dict__
+    if '_seg_plan' not in d:
+        if graph.E > 0 and graph.src_pos is not None and graph.src_pos.is_cuda and torch.cuda.is_current_stream_capturing():
+            raise RuntimeError('dense_seg_plan: the plan of this graph is not built yet and building it reads two counts back '
+                               'to the host, which a stream capture cannot do -- run one eager call on the graph before capturing')
+        plan = None
+        # (dense enough to be worth it: a src's run of edges spans a good part of a tile -- the test edge_tiles() makes)
+        if graph.E >= 128 * 64 and graph.E >= 32 * graph.Dn:
+            plan = build_seg_plan(graph)
+        d['_seg_plan'] = plan
+        graph._c = None                                           # (the C struct carries the plan's address)
+    return d['_seg_plan']
 
 
 def set_det_groups(graph: FrameGraph, det_group) -> FrameGraph:
