@@ -30,6 +30,8 @@ if __name__ == '__main__':
     t0 = time.perf_counter()
     for _ in range(a.steps): step()
     torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / a.steps
-    print(json.dumps(dict(workload=f'C5 static {a.frames}x{a.dets}, H={a.hidden}, {a.iters} iters', N=g.N, E=g.E, ms_per_step=dt * 1e3,
+    sp = g.__dict__.get('_seg_plan')
+    print(json.dumps(dict(workload=f'C5 static {a.frames}x{a.dets}, H={a.hidden}, {a.iters} iters', N=g.N, E=g.E, Dn=g.Dn,
+                          seg_plan=None if sp is None else dict(T=sp.T, I=sp.I), ms_per_step=dt * 1e3,
                           edges_per_s=g.E * a.iters / dt, tflops=36.0 * a.hidden ** 2 * g.E * a.iters / dt / 1e12,
                           mem_GB=torch.cuda.max_memory_allocated() / 2 ** 30)))
