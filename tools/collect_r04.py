@@ -186,7 +186,9 @@ fractions of the overlapped kernels understate what each reaches alone (the tabl
 Round 3 (`k_segsum_pipe<false, 8, 16>` over the graph's CSR, every edge row fetched once per endpoint): 1.53 ms per launch alone,
 PMC traffic 1.99 x the rows.  Round 4: `k_segsum_tiles` {single['k_segsum_tiles']:.3f} ms + `k_segsum_pipe<DUAL>`
 {single['k_segsum_pipe']:.3f} ms = **{single['k_segsum_tiles'] + single['k_segsum_pipe']:.3f} ms** per launch (16 launches per step).
-With the row movers this short the second stream no longer pays: four alternating un-profiled runs each, same box: one stream
-186.6 / 186.4 / 185.3 / 188.7 ms per step, two streams 189.0 / 189.2 / 188.1 / 187.6 -- the default is one stream again.
+With the row movers this short the second stream no longer pays for itself: four alternating un-profiled runs each on one box: one
+stream 186.6 / 186.4 / 185.3 / 188.7 ms per step, two streams 189.0 / 189.2 / 188.1 / 187.6; the pair of this profile (table
+above) has the two forms the other way round by 1.3 ms -- a wash within the box-to-box and run-to-run spread, so the default is the
+simpler one-stream form again.
 """)
     print('c5 r04:', c5o['ms_per_step'], c5s['ms_per_step'])

@@ -30,7 +30,8 @@ INPLACE_GRADS = os.environ.get('TMPNN_INPLACE_GRADS', '0') == '1'
 FUSED_BWD = os.environ.get('TMPNN_FUSED_BWD', '1') == '1'     # one-pass cell backward (see mp_backward); its A/B is a test
 # wide cells: the det-side branch of the backward on a second stream next to the E-row matrix kernels (tmpnn_wide_gru_bwd_diff_aux)
 # (det-side branches of the wide cells on a second stream: worth 1.5-6 ms of a 195-ms C5 step until round 4's single-read segment sum
-#  took most of what it hid -- since then one stream is 1-2 ms FASTER (4 alternating runs: 186.8 vs 188.5 ms); off by default)
+#  took most of what it hid -- since then the two forms are within the run-to-run spread (4 alternating pairs: 186.8 vs 188.5 ms, a
+#  later pair 184.7 vs 183.4); off by default: the simpler form)
 WIDE_OVERLAP = os.environ.get('TMPNN_WIDE_OVERLAP', '0') == '1'
 _SPLIT = os.environ.get('TMPNN_SPLIT', '1')[:1] != '0'        # TMPNN_SPLIT=0: every GEMM on the f32-input MFMA (tested)
 

@@ -271,5 +271,6 @@ def train_losses(scores: torch.Tensor, logits: torch.Tensor, labels: torch.Tenso
     g = _as_graph(node_adj)
     lab = labels.reshape(-1)
     lab = lab if (lab.dtype == torch.uint8 and lab.is_contiguous()) else (lab != 0).to(torch.uint8).contiguous()
-    sc = scores[:, 0] if scores.dim() == 2 else scores
+    # ([N, 1] scores: a reshape is a view both ways; scores[:, 0] would cost a zero fill + a copy in the backward)
+    sc = (scores.reshape(-1) if scores.shape[1] == 1 else scores[:, 0]) if scores.dim() == 2 else scores
     return _TrainLosses.apply(logits, sc, lab, g, bool(tp_classifier))
