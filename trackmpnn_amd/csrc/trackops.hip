@@ -56,14 +56,14 @@ __device__ __forceinline__ int tk_block_scan(int v, int* s_wave, int* total) {
 // mode 1 (inference, greedy, :251-268 / :437-454): a det scored >= 0.5 looks at its future edges scored >= 0.5 that
 //   lead to a det scored >= 0.5, keeps those of the NEAREST timestep (rows before the first det row after the first
 //   such edge) and takes the highest score (first of equals).
-__global__ __launch_bounds__(256) void k_track_associate(tmpnn_dgraph g, const int32_t* __restrict__ det_id,
+__device__ __forceinline__ void d_track_associate(tmpnn_dgraph g, const int32_t* __restrict__ det_id,
                                                          const uint8_t* __restrict__ labels,
                                                          const float* __restrict__ score, int mode,
-                                                         int32_t* __restrict__ assoc, int32_t* __restrict__ status) {
+                                                         int32_t* __restrict__ assoc, int32_t* __restrict__ status, int i0, int stride) {
     const int N = g.N, Dn = g.meta[1];
-    for (int r = blockIdx.x * 256 + threadIdx.x; r < N; r += gridDim.x * 256)
+    for (int r = i0; r < N; r += stride)
         if (g.is_edge[r]) assoc[r] = -1;
-    for (int d = blockIdx.x * 256 + threadIdx.x; d < Dn; d += gridDim.x * 256) {
+    for (int d = i0; d < Dn; d += stride) {
         const int row = g.det_row[d];
         const int p0 = g.rowptr[d], p1 = g.rowptr[d + 1];
         int out = -1;
@@ -106,11 +106,14 @@ __global__ __launch_bounds__(256) void k_track_associate(tmpnn_dgraph g, const i
         assoc[row] = out;
     }
 }
+__global__ __launch_bounds__(256) void k_track_associate(tmpnn_dgraph g, const int32_t* __restrict__ det_id, const uint8_t* __restrict__ labels, const float* __restrict__ score, int mode, int32_t* __restrict__ assoc, int32_t* __restrict__ status) {
+    d_track_associate(g, det_id, labels, score, mode, assoc, status, (int)(blockIdx.x * 256 + threadIdx.x), (int)(gridDim.x * 256));
+}
 
 // ---- active set (utils/graph.py:270-278), ascending rows ----------------------------------------------------------
 // train: det rows not yet associated, or of the last timestep before t.   inference: unassociated dets scored >= 0.5.
 // n_dev (or NULL): the row count read on the device instead (the rows a deletion just compacted: the host has not seen it yet)
-__global__ __launch_bounds__(TK_THREADS) void k_track_active(int N, const int32_t* __restrict__ n_dev,
+__device__ __forceinline__ void d_track_active(int N, const int32_t* __restrict__ n_dev,
                                                              const int32_t* __restrict__ ts,
                                                              const int32_t* __restrict__ assoc,
                                                              const float* __restrict__ score, int mode, int t,
@@ -143,6 +146,9 @@ __global__ __launch_bounds__(TK_THREADS) void k_track_active(int N, const int32_
     for (int r = r0; r < r1; ++r)
         if (is_active(r)) active[p++] = r;
     if (tid == 0) count[0] = total;
+}
+__global__ __launch_bounds__(TK_THREADS) void k_track_active(int N, const int32_t* __restrict__ n_dev, const int32_t* __restrict__ ts, const int32_t* __restrict__ assoc, const float* __restrict__ score, int mode, int t, int32_t* __restrict__ active, int32_t* __restrict__ count) {
+    d_track_active(N, n_dev, ts, assoc, score, mode, t, active, count);
 }
 
 // ---- append the block of timestep t (utils/graph.py:283-325) ------------------------------------------------------
@@ -190,7 +196,7 @@ __global__ __launch_bounds__(256) void k_track_append(int N, int A, int D, const
 // max_id = 1 + the last det row before t_upto.  Deleted: every row < max_id except the dets RETAINED for later
 // association (unassociated, scored >= 0.5, not older than t_upto - ret_win); and every edge row >= max_id that
 // starts at a deleted det.  Kept rows are renumbered in order; row_src / row_dst follow.
-__global__ __launch_bounds__(TK_THREADS) void k_track_delete(int N, const int32_t* __restrict__ ts,
+__device__ __forceinline__ void d_track_delete(int N, const int32_t* __restrict__ ts,
                                                              const int32_t* __restrict__ det_id,
                                                              const int32_t* __restrict__ assoc,
                                                              const float* __restrict__ score,
@@ -250,6 +256,9 @@ __global__ __launch_bounds__(TK_THREADS) void k_track_delete(int N, const int32_
     }
     if (tid == 0) { count[0] = total; count[2] = s_dets; }        // kept rows; kept DET rows (the host's E / Dn bookkeeping)
 }
+__global__ __launch_bounds__(TK_THREADS) void k_track_delete(int N, const int32_t* __restrict__ ts, const int32_t* __restrict__ det_id, const int32_t* __restrict__ assoc, const float* __restrict__ score, const uint8_t* __restrict__ is_edge, const int32_t* __restrict__ row_src, const int32_t* __restrict__ row_dst, const uint8_t* __restrict__ labels, int t_upto, int ret_win, int32_t* __restrict__ keep /* [N]: kept rows, ascending */, int32_t* __restrict__ count, int32_t* __restrict__ o_ts, int32_t* __restrict__ o_det_id, int32_t* __restrict__ o_assoc, uint8_t* __restrict__ o_is_edge, int32_t* __restrict__ o_src, int32_t* __restrict__ o_dst, uint8_t* __restrict__ o_labels) {
+    d_track_delete(N, ts, det_id, assoc, score, is_edge, row_src, row_dst, labels, t_upto, ret_win, keep, count, o_ts, o_det_id, o_assoc, o_is_edge, o_src, o_dst, o_labels);
+}
 
 // out[q, :] = in[keep[q], :] for q < count (count read on the device: the launch is sized for the worst case)
 __global__ __launch_bounds__(256) void k_track_gather(const float* __restrict__ in, int ld_in, int W,
@@ -269,14 +278,14 @@ __global__ __launch_bounds__(256) void k_track_gather(const float* __restrict__ 
 
 
 // the state rows AND the scores in one launch: out_h[q, :] = h[keep[q], :], out_s[q] = score[keep[q]]
-__global__ __launch_bounds__(256) void k_track_gather2(const float* __restrict__ h, int ld_h, int W,
+__device__ __forceinline__ void d_track_gather2(const float* __restrict__ h, int ld_h, int W,
                                                        const float* __restrict__ score, const int32_t* __restrict__ keep,
                                                        const int32_t* __restrict__ count, float* __restrict__ out_h,
-                                                       int ld_out, float* __restrict__ out_s) {
+                                                       int ld_out, float* __restrict__ out_s, long i0, long stride) {
     const int n = count[0];
     const int lpr = (W + 3) / 4 + 1;                      // the last slot of a row moves its score
     const long total = (long)n * lpr;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    for (long i = i0; i < total; i += stride) {
         const int q = (int)(i / lpr), k = (int)(i % lpr);
         const int r = keep[q];
         if (k == lpr - 1) { out_s[q] = score[r]; continue; }
@@ -286,6 +295,9 @@ __global__ __launch_bounds__(256) void k_track_gather2(const float* __restrict__
         if (c + 4 <= W && ((ld_h | ld_out) & 3) == 0) *reinterpret_cast<float4*>(dst) = *reinterpret_cast<const float4*>(src);
         else for (int j = 0; j < 4 && c + j < W; ++j) dst[j] = src[j];
     }
+}
+__global__ __launch_bounds__(256) void k_track_gather2(const float* __restrict__ h, int ld_h, int W, const float* __restrict__ score, const int32_t* __restrict__ keep, const int32_t* __restrict__ count, float* __restrict__ out_h, int ld_out, float* __restrict__ out_s) {
+    d_track_gather2(h, ld_h, W, score, keep, count, out_h, ld_out, out_s, (long)blockIdx.x * 256 + threadIdx.x, (long)gridDim.x * 256);
 }
 
 
@@ -305,7 +317,7 @@ __global__ __launch_bounds__(256) void k_track_gather2(const float* __restrict__
 // window's dets ranked by id (a parallel count), then one thread starting the walks in that order over the same LDS arrays.
 static constexpr int FIN_LDS_DETS = 4096;
 
-__global__ __launch_bounds__(TK_THREADS) void k_track_finalize(tmpnn_dgraph g, const int32_t* __restrict__ ts,
+__device__ __forceinline__ void d_track_finalize(tmpnn_dgraph g, const int32_t* __restrict__ ts,
                                                                const int32_t* __restrict__ det_id,
                                                                const int32_t* __restrict__ assoc,
                                                                const float* __restrict__ score, int t_upto,
@@ -407,7 +419,40 @@ __global__ __launch_bounds__(TK_THREADS) void k_track_finalize(tmpnn_dgraph g, c
     for (int k = tid; k < Dn; k += TK_THREADS)
         if (flag[k] & 4) y_track[det_id[g.det_row[k]]] = tidv[best[k]];
 }
+__global__ __launch_bounds__(TK_THREADS) void k_track_finalize(tmpnn_dgraph g, const int32_t* __restrict__ ts, const int32_t* __restrict__ det_id, const int32_t* __restrict__ assoc, const float* __restrict__ score, int t_upto, int32_t* __restrict__ y_track, int ND, int32_t* __restrict__ pos_of_det, int32_t* __restrict__ ws) {
+    d_track_finalize(g, ts, det_id, assoc, score, t_upto, y_track, ND, pos_of_det, ws);
+}
 
+
+// ---- decode_tracks in ONE launch for LDS-sized graphs: the five steps above as phases of one 1024-thread block ----------------
+// (a greedy timestep's GPU time is ~10 dependent launches of 2-8 us kernels; each launch saved is ~2 us of device gap and ~2 us
+//  of host time)
+__global__ __launch_bounds__(TK_THREADS) void k_track_retire(tmpnn_dgraph g, tmpnn_track_rows r, const float* __restrict__ score,
+                                                             int associate, int t_upto, int ret_win,
+                                                             int32_t* __restrict__ y_track, int ND,
+                                                             int32_t* __restrict__ pos_of_det, int32_t* __restrict__ keep,
+                                                             int32_t* __restrict__ small, tmpnn_track_rows o,
+                                                             const float* __restrict__ h, int ld_h, int W,
+                                                             float* __restrict__ h_new, int ld_hn, float* __restrict__ s_new,
+                                                             int next_t, int32_t* __restrict__ active,
+                                                             int32_t* __restrict__ fin_ws /* unused at this size; a kernel
+                                                             argument because a literal null in the LDS / global pointer
+                                                             select of the finalisation pass crashes hipcc */) {
+    if (associate) {
+        d_track_associate(g, r.det_id, nullptr, score, 1, r.assoc, small + 1, (int)threadIdx.x, TK_THREADS);
+        __syncthreads();
+    }
+    d_track_finalize(g, r.ts, r.det_id, r.assoc, score, t_upto, y_track, ND, pos_of_det, fin_ws);
+    __syncthreads();
+    d_track_delete(g.N, r.ts, r.det_id, r.assoc, score, r.is_edge, r.src, r.dst, r.labels, t_upto, ret_win, keep, small, o.ts,
+                   o.det_id, o.assoc, o.is_edge, o.src, o.dst, o.labels);
+    __syncthreads();
+    d_track_gather2(h, ld_h, W, score, keep, small, h_new, ld_hn, s_new, (long)threadIdx.x, (long)TK_THREADS);
+    if (next_t >= 0) {
+        __syncthreads();
+        d_track_active(0, small, o.ts, o.assoc, s_new, 1, next_t, active, small + 3);
+    }
+}
 
 // ---- the first block of a sequence (initialize_graph, utils/graph.py:96-186), uploaded as ONE packed int32 array ----------------
 // packed [6][N]: ts, det_id, is_edge, src, dst, labels.  Also: assoc = -1, the features of the block (X[det id] on det rows, zeros
@@ -576,6 +621,15 @@ int tmpnn_track_retire(const tmpnn_dgraph* g, const tmpnn_track_rows* rows, cons
     TM_REQUIRE(next_t < 0 || active, "track_retire: the next timestep's active set needs its buffer");
     const int N = g->N;
     int rc;
+    if (N > 0 && N <= FIN_LDS_DETS) {
+        // LDS-sized graphs (the reference's windows: a few hundred rows): all five steps as phases of one block
+        TM_REQUIRE(y_track && pos_of_det && ND > 0, "track_retire: null pointer / empty sequence");
+        TM_SHM_ONCE(k_track_retire, sizeof(int) * FIN_LDS_DETS);
+        hipLaunchKernelGGL(k_track_retire, dim3(1), dim3(TK_THREADS), sizeof(int) * (size_t)N, as_stream(stream), *g, *rows, score,
+                           associate ? 1 : 0, t_upto, ret_win, y_track, ND, pos_of_det, keep, small, *rows_out, h, ld_h, W, h_new,
+                           ld_hn, s_new, next_t, active, reinterpret_cast<int32_t*>(fin_ws));
+        return check_launch("track_retire");
+    }
     if (associate &&
         (rc = tmpnn_track_associate(g, rows->det_id, nullptr, score, 1, rows->assoc, small + 1, stream))) return rc;
     if ((rc = tmpnn_track_finalize(g, rows->ts, rows->det_id, rows->assoc, score, t_upto, y_track, ND, pos_of_det, fin_ws,
