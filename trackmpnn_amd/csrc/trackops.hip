@@ -454,6 +454,20 @@ __global__ __launch_bounds__(TK_THREADS) void k_track_retire(tmpnn_dgraph g, tmp
     }
 }
 
+// update_graph's first half in one launch (LDS-sized graphs): status word cleared, associations, active set
+__global__ __launch_bounds__(TK_THREADS) void k_track_select(tmpnn_dgraph g, tmpnn_track_rows r, const float* __restrict__ score,
+                                                             int mode, int t, int associate, int32_t* __restrict__ active,
+                                                             int32_t* __restrict__ small) {
+    if (associate) {
+        if (mode == 0 && threadIdx.x == 0) small[1] = 0;
+        __syncthreads();
+        d_track_associate(g, r.det_id, mode == 0 ? r.labels : nullptr, mode == 0 ? nullptr : score, mode, r.assoc, small + 1,
+                          (int)threadIdx.x, TK_THREADS);
+        __syncthreads();
+    }
+    d_track_active(g.N, nullptr, r.ts, r.assoc, score, mode, t, active, small);
+}
+
 // ---- the first block of a sequence (initialize_graph, utils/graph.py:96-186), uploaded as ONE packed int32 array ----------------
 // packed [6][N]: ts, det_id, is_edge, src, dst, labels.  Also: assoc = -1, the features of the block (X[det id] on det rows, zeros
 // on edge rows) and y_out[:, 1] = -1 for the whole sequence.
@@ -581,6 +595,11 @@ int tmpnn_track_select(const tmpnn_dgraph* g, const tmpnn_track_rows* rows, cons
     TM_REQUIRE(mode == 0 ? rows->labels != nullptr : (mode == 1 && score != nullptr), "track_select: mode %d needs %s", mode,
                mode == 0 ? "labels" : "scores");
     int rc;
+    if (g->N > 0 && g->N <= FIN_LDS_DETS) {
+        hipLaunchKernelGGL(k_track_select, dim3(1), dim3(TK_THREADS), 0, as_stream(stream), *g, *rows, score, mode, t,
+                           associate ? 1 : 0, active, small);
+        return check_launch("track_select");
+    }
     if (associate) {
         if (mode == 0 && hipMemsetAsync(small + 1, 0, sizeof(int32_t), as_stream(stream)) != hipSuccess)
             return set_error(TMPNN_ELAUNCH, "track_select: clearing the status word failed");
