@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define TMPNN_ABI_VERSION 1
+#define TMPNN_ABI_VERSION 2 /* 2: struct tmpnn_graph gained seg_plan (round 4) */
 
 #define TMPNN_OK 0
 #define TMPNN_EINVAL (-1)   /* bad shape / null pointer / unsupported width */

@@ -17,7 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('TMPNN_LIB_PATH') or os.path.join(_HERE, 'lib', 'libtmpnn.so')
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), 'include', 'tmpnn.h')
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 c_int = C.c_int
 c_void_p = C.c_void_p
