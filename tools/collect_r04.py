@@ -192,3 +192,33 @@ above) has the two forms the other way round by 1.3 ms -- a wash within the box-
 simpler one-stream form again.
 """)
     print('c5 r04:', c5o['ms_per_step'], c5s['ms_per_step'])
+
+
+# ------------------------------------------------------------------------------------------------ dispatches per timestep
+ttdir = f'gpurun_out/{tag}_tt'
+if all(os.path.exists(f'{ttdir}/{m}_{x}') for m in ('greedy', 'train') for x in ('stats.csv', 'plain.log')):
+    with open(f'profiles/{tag}_timestep_dispatches.md', 'w') as f:
+        f.write(f"""# Dispatches per model call of the two batch-1 loops ({tag}, 1x MI355X)
+
+`bash tools/timestep_profile.sh`: `tools/timestep_trace.py` (the C2 loop shapes of `bench.py`'s `loop_batch1`: greedy inference over a
+40-frame sequence, 39 model calls; one train chunk, 6 model calls, WITHOUT the optimizer step and without zeroing the gradients
+between repetitions -- the 18 gradient accumulations per chunk at the end of the train list are an artefact of that) un-profiled for
+the time, then under `rocprofv3 --kernel-trace --stats` (3 warm-up + 20 repetitions) for the dispatch counts.  Round 3 (`BENCH_r03`,
+review): ~45 launches and two host reads per greedy timestep.
+
+""")
+        for m, ncall in (('greedy', 39), ('train', 6)):
+            line = json.loads([l for l in open(f'{ttdir}/{m}_plain.log') if l.startswith('{')][-1])
+            rows = list(csv.DictReader(open(f'{ttdir}/{m}_stats.csv')))
+            div = 23 * ncall
+            tot = sum(int(r['Calls']) for r in rows)
+            f.write(f"## {m}: {line['ms_per_call']} ms per {'sequence' if m == 'greedy' else 'chunk'} = {line['ms_per_model_call']} ms per model call; "
+                    f"{tot / div:.1f} dispatches per model call\n\n| kernel | per model call | avg us |\n|---|---|---|\n")
+            for r in sorted(rows, key=lambda r: -int(r['Calls'])):
+                c = int(r['Calls']) / div
+                if c < 0.02:
+                    continue
+                short = r['Name'].split('(')[0].replace('void ', '').replace('tmpnn::', '')[:70]
+                f.write(f"| `{short}` | {c:.2f} | {float(r['AverageNs']) / 1e3:.1f} |\n")
+            f.write('\n')
+    print('timestep dispatches written')
