@@ -135,7 +135,7 @@ int tmpnn_segsum_bwd(const tmpnn_graph* g, const float* d_out, int ld_dout, floa
                      int H, int accumulate, tmpnn_stream stream);
 
 /* ---- row G: attention-weighted aggregation (models/layers.py:26-43, 105-112) -------------
- * K heads (1..8), all served by the same passes.  W_cat [H][K*H]: head k's W_att ([H][H], in x out, as the reference
+ * K heads (1..8 per call, all served by the same passes; a model with more runs groups of heads and combines their means: the output of a call is the MEAN over ITS heads).  W_cat [H][K*H]: head k's W_att ([H][H], in x out, as the reference
  * stores it) in columns k*H .. (k+1)*H; a [K][H].
  *   ha    = h[det rows] @ W_cat                       (ha [Dn][K*H]: the heads of a det side by side)
  *   s_e   = LeakyReLU_0.2(|ha_k[src]-ha_k[dst]| . a_k)  (score [2E][K] per CSR POSITION: an edge's score is stored at both

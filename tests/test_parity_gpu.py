@@ -186,6 +186,9 @@ def _batched_case(B, frames, mean, max_dets, F, seed0=0, static=False):
     ('2d', 3, 20, 0, 'concat', True),
     ('2d+temp+vis', 3, 48, 0, 'diff', True),
     ('2d', 3, 100, 2, 'diff', False),
+    # more heads than one attention call takes (8): groups of heads, means combined (reference: any number of heads)
+    ('2d', 3, 64, 11, 'diff', False),
+    ('2d', 3, 32, 9, 'concat', False),
     # widths above 256 (multiples of 128 native, others zero-padded to the next one): diff messages, no attention heads
     ('2d', 3, 384, 0, 'diff', True),
     ('2d', 3, 300, 0, 'diff', True),

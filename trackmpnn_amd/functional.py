@@ -33,6 +33,7 @@ FUSED_BWD = os.environ.get('TMPNN_FUSED_BWD', '1') == '1'     # one-pass cell ba
 #  took most of what it hid -- since then the two forms are within the run-to-run spread (4 alternating pairs: 186.8 vs 188.5 ms, a
 #  later pair 184.7 vs 183.4); off by default: the simpler form)
 WIDE_OVERLAP = os.environ.get('TMPNN_WIDE_OVERLAP', '0') == '1'
+ATT_KMAX = 8                 # heads per tmpnn_att_fwd / _bwd call (include/tmpnn.h)
 _SPLIT = os.environ.get('TMPNN_SPLIT', '1')[:1] != '0'        # TMPNN_SPLIT=0: every GEMM on the f32-input MFMA (tested)
 
 # Switches whose A/B has been run and lost (DESIGN sections 4, 11): they are constants of a normal process and only read from the
@@ -435,26 +436,39 @@ def mp_forward(spec: ModelSpec, plan: CallPlan, x: torch.Tensor, h_in: Optional[
             _lib.call('tmpnn_segsum_fwd', g.cref(), hg, GH, es.data_ptr(), H, H, 0, 1, st_det)
             alphas.append(None)
         else:
-            Ws = [P[f + f'gat.{k}.W_att'] for k in range(K)]
-            As = [P[f + f'gat.{k}.a'] for k in range(K)]
-            # (the heads' weights side by side for the kernels: one copy per call, or per weight_cache() context)
-            W = _cached(('attW', tuple(t.data_ptr() for t in Ws)), tuple(Ws), lambda: torch.cat(Ws, 1).contiguous())
-            a = _cached(('atta', tuple(t.data_ptr() for t in As)), tuple(As),
-                        lambda: torch.stack([t.reshape(-1) for t in As]).contiguous())
-            ws_ha = torch.empty((max(Dn, 1), K * H), **opts)
-            score = torch.empty((max(2 * E, 1), K), **opts)  # (k_att_score writes both CSR positions of every edge)
+            # the kernels take up to ATT_KMAX heads per call (all of them from one read of h[e]); more heads run in groups whose
+            # means are combined with their share K_g / K (reference: any number of heads, utils/training_options.py:23)
             erec, inc_other = g.att_index() if E > 0 else (None, None)
-            stats = torch.empty((max(Dn, 1), K, 2), **opts)
-            esk = torch.empty((K, max(Dn, 1), H), **opts)
-            alpha = torch.empty((K, max(2 * E, 1)), **opts)
-            kp = None
-            if training:
-                kp = _keep_bits(None if keep is None else keep[gi], K, 2 * E, dev)
-            _lib.call('tmpnn_att_fwd', g.cref(), _lib.ptr(erec), hg, GH, H, K, W.data_ptr(),
-                      a.data_ptr(), _lib.ptr(kp), ATT_DROPOUT_P, ws_ha.data_ptr(), score.data_ptr(), stats.data_ptr(),
-                      esk.data_ptr(), alpha.data_ptr(), es.data_ptr(), H, st)
-            alphas.append([alpha[k, :2 * E] for k in range(K)])
-            att_saved.append((W, a, kp, ws_ha, score, stats, esk))
+            groups, al = [], []
+            for k0 in range(0, K, ATT_KMAX):
+                Kg = min(ATT_KMAX, K - k0)
+                Ws = [P[f + f'gat.{k}.W_att'] for k in range(k0, k0 + Kg)]
+                As = [P[f + f'gat.{k}.a'] for k in range(k0, k0 + Kg)]
+                # (the heads' weights side by side for the kernels: one copy per call, or per weight_cache() context)
+                W = _cached(('attW', tuple(t.data_ptr() for t in Ws)), tuple(Ws), lambda: torch.cat(Ws, 1).contiguous())
+                a = _cached(('atta', tuple(t.data_ptr() for t in As)), tuple(As),
+                            lambda: torch.stack([t.reshape(-1) for t in As]).contiguous())
+                ws_ha = torch.empty((max(Dn, 1), Kg * H), **opts)
+                score = torch.empty((max(2 * E, 1), Kg), **opts)  # (k_att_score writes both CSR positions of every edge)
+                stats = torch.empty((max(Dn, 1), Kg, 2), **opts)
+                esk = torch.empty((Kg, max(Dn, 1), H), **opts)
+                alpha = torch.empty((Kg, max(2 * E, 1)), **opts)
+                kp = None
+                if training:
+                    kp = _keep_bits(None if keep is None else keep[gi][k0:k0 + Kg], Kg, 2 * E, dev)
+                out_g = es if Kg == K else torch.empty_like(es)
+                _lib.call('tmpnn_att_fwd', g.cref(), _lib.ptr(erec), hg, GH, H, Kg, W.data_ptr(),
+                          a.data_ptr(), _lib.ptr(kp), ATT_DROPOUT_P, ws_ha.data_ptr(), score.data_ptr(), stats.data_ptr(),
+                          esk.data_ptr(), alpha.data_ptr(), out_g.data_ptr(), H, st)
+                if Kg != K:
+                    if k0 == 0:
+                        torch.mul(out_g, Kg / K, out=es)
+                    else:
+                        es.add_(out_g, alpha=Kg / K)
+                al += [alpha[k, :2 * E] for k in range(Kg)]
+                groups.append((k0, Kg, W, a, kp, ws_ha, score, stats, esk))
+            alphas.append(al)
+            att_saved.append(groups)
         # node update: GRU(es, h[d])                            (layers.py:114)
         _lib.call('tmpnn_gru_fwd', g.det_row.data_ptr(), Dn, 0, None, None,
                   es.data_ptr(), H, 1, H, hg, GH, H,
@@ -655,31 +669,37 @@ def mp_backward(spec: ModelSpec, plan: CallPlan, saved: dict, P: Dict[str, torch
                           grads[f + 'edge_gru.bias_ih'].data_ptr(), grads[f + 'edge_gru.bias_hh'].data_ptr(),
                           ws_w.data_ptr(), ws_w.numel() * 4, st)
         if K > 0:
-            W, a, kp, ws_ha, score, stats, esk = saved['att'][gi]
-            ws_n_att = lib.tmpnn_att_bwd_ws(E, Dn, H, K)
-            ws_att = torch.empty((max(ws_n_att, 1),), **opts)
             erec, inc_other = g.att_index() if E > 0 else (None, None)
-            gW = [grads.get(f + f'gat.{k}.W_att') for k in range(K)] if grad_out is not None else []
-            ga = [grads.get(f + f'gat.{k}.a') for k in range(K)] if grad_out is not None else []
-            args = (g.cref(), _lib.ptr(erec), _lib.ptr(inc_other), hg, GH, H, K, W.data_ptr(),
-                    a.data_ptr(), _lib.ptr(kp), ATT_DROPOUT_P, ws_ha.data_ptr(), score.data_ptr(), stats.data_ptr(),
-                    esk.data_ptr(), dmsg.data_ptr(), IN_e, ws_att.data_ptr(), ws_att.numel(), dhg, GH)
-            if grad_out is not None and all(t is not None and t.is_contiguous() for t in gW + ga):
-                # in-place mode: the heads' gradient buffers are accumulated directly (no stacked temporary, no adds)
-                pW = (ctypes.c_void_p * K)(*[t.data_ptr() for t in gW])
-                pa = (ctypes.c_void_p * K)(*[t.data_ptr() for t in ga])
-                _lib.call('tmpnn_att_bwd_heads', *args, ctypes.cast(pW, ctypes.c_void_p), ctypes.cast(pa, ctypes.c_void_p), st)
-            else:
-                dW = torch.zeros((K, H, H), **opts)
-                da = torch.zeros_like(a)
-                _lib.call('tmpnn_att_bwd', *args, dW.data_ptr(), da.data_ptr(), st)
-                for k in range(K):
-                    if grad_out is not None:
-                        grads[f + f'gat.{k}.W_att'].add_(dW[k])
-                        grads[f + f'gat.{k}.a'].add_(da[k].reshape(-1, 1))
-                    else:
-                        grads[f + f'gat.{k}.W_att'] = dW[k]
-                        grads[f + f'gat.{k}.a'] = da[k].reshape(-1, 1)
+            for k0, Kg, W, a, kp, ws_ha, score, stats, esk in saved['att'][gi]:
+                ws_n_att = lib.tmpnn_att_bwd_ws(E, Dn, H, Kg)
+                ws_att = torch.empty((max(ws_n_att, 1),), **opts)
+                if Kg == K:
+                    d_out, ld_dout = dmsg.data_ptr(), IN_e
+                else:           # this group's share of the head mean: d es / d es_group = K_g / K
+                    d_es_g = torch.zeros((N, H), **opts)
+                    d_es_g[g.det_row.long()] = dmsg[g.det_row.long(), :H] * (Kg / K)
+                    d_out, ld_dout = d_es_g.data_ptr(), H
+                gW = [grads.get(f + f'gat.{k}.W_att') for k in range(k0, k0 + Kg)] if grad_out is not None else []
+                ga = [grads.get(f + f'gat.{k}.a') for k in range(k0, k0 + Kg)] if grad_out is not None else []
+                args = (g.cref(), _lib.ptr(erec), _lib.ptr(inc_other), hg, GH, H, Kg, W.data_ptr(),
+                        a.data_ptr(), _lib.ptr(kp), ATT_DROPOUT_P, ws_ha.data_ptr(), score.data_ptr(), stats.data_ptr(),
+                        esk.data_ptr(), d_out, ld_dout, ws_att.data_ptr(), ws_att.numel(), dhg, GH)
+                if grad_out is not None and all(t is not None and t.is_contiguous() for t in gW + ga):
+                    # in-place mode: the heads' gradient buffers are accumulated directly (no stacked temporary, no adds)
+                    pW = (ctypes.c_void_p * Kg)(*[t.data_ptr() for t in gW])
+                    pa = (ctypes.c_void_p * Kg)(*[t.data_ptr() for t in ga])
+                    _lib.call('tmpnn_att_bwd_heads', *args, ctypes.cast(pW, ctypes.c_void_p), ctypes.cast(pa, ctypes.c_void_p), st)
+                else:
+                    dW = torch.zeros((Kg, H, H), **opts)
+                    da = torch.zeros_like(a)
+                    _lib.call('tmpnn_att_bwd', *args, dW.data_ptr(), da.data_ptr(), st)
+                    for k in range(Kg):
+                        if grad_out is not None:
+                            grads[f + f'gat.{k0 + k}.W_att'].add_(dW[k])
+                            grads[f + f'gat.{k0 + k}.a'].add_(da[k].reshape(-1, 1))
+                        else:
+                            grads[f + f'gat.{k0 + k}.W_att'] = dW[k]
+                            grads[f + f'gat.{k0 + k}.a'] = da[k].reshape(-1, 1)
         # adjoint of the node -> edge message: into d_hcat[det rows] (the det-side wide backward has already put it there)
         name = 'tmpnn_gather_concat_bwd' if spec.msg_type == 'concat' else 'tmpnn_gather_diff_bwd'
         if not (not use_fused_bwd and saved.get('wide') and WIDE_DET):

@@ -66,7 +66,7 @@ class SmallPath:
         spec = model.spec
         self.spec = spec
         self.names: List[str] = spec.param_names()
-        self.eligible = spec.H in (32, 64)
+        self.eligible = spec.H in (32, 64) and spec.K <= 8      # (more than 8 heads: the staged kernels run them in groups)
         # attention heads (K > 0): the same two launches per direction with the attention stage (tmpnn_att_fwd / _bwd) between
         # them (tmpnn_mp_iter_*_parts) -- through the Python node below; the C++ node serves K = 0
         self.att = spec.K > 0
