@@ -227,8 +227,89 @@ std::vector<torch::Tensor> small_iter(torch::Tensor x, c10::optional<torch::Tens
     return SmallIterFn::apply(x, h_in, anchor, arena, info, keep);
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// One greedy inference timestep of infer.py:70-87 without the interpreter between its launches: update_graph's block append
+// (tmpnn_track_extend; the active set of this timestep was derived by the previous step's tmpnn_track_retire), the model call
+// in eval mode (tmpnn_mp_iter_fwd) and decode_tracks (tmpnn_track_retire, with the NEXT timestep's active set), then the one
+// host read of the timestep.  trackmpnn_amd/loops.py drives it for models on the fused path and graphs of LDS size; every other
+// case (Hungarian matching, attention heads, wide cells, re-initialisation, empty timesteps) takes TrackGraph.update / .decode.
+// Same kernels, same arguments: the results are those of the Python path bit for bit.
+using extend_fn = int (*)(int, int, int, const int32_t*, const int32_t*, int, const int32_t*, const tmpnn_track_rows*, const float*,
+                          int, int, float*, int, const tmpnn_dgraph*, void*, size_t, tmpnn_stream);
+using retire_fn = int (*)(const tmpnn_dgraph*, const tmpnn_track_rows*, const float*, int, int, int, int32_t*, int, int32_t*, void*,
+                          size_t, int32_t*, int32_t*, const tmpnn_track_rows*, const float*, int, int, float*, int, float*, int,
+                          int32_t*, tmpnn_stream);
+using ints_fn = size_t (*)(int);
+
+std::vector<torch::Tensor> greedy_step(std::vector<int64_t> ti, std::vector<int64_t> info, torch::Tensor h, int64_t cap_rows) {
+    TORCH_CHECK(ti.size() == 24 && info.size() == 18, "greedy_step: bad descriptors");
+    const auto f_extend = reinterpret_cast<extend_fn>(ti[0]);
+    const auto f_retire = reinterpret_cast<retire_fn>(ti[1]);
+    const auto f_ints = reinterpret_cast<ints_fn>(ti[2]);
+    const int N = (int)ti[3], A = (int)ti[4], D = (int)ti[5], t = (int)ti[6], t_upto = (int)ti[7], ret_win = (int)ti[8];
+    const int next_t = (int)ti[9];
+    auto* active = reinterpret_cast<int32_t*>(ti[10]);
+    const auto* new_ids = reinterpret_cast<const int32_t*>(ti[11]);
+    const auto* track = reinterpret_cast<const int32_t*>(ti[12]);
+    const auto* rows_cur = reinterpret_cast<const tmpnn_track_rows*>(ti[13]);
+    const auto* rows_out = reinterpret_cast<const tmpnn_track_rows*>(ti[14]);
+    const auto* X = reinterpret_cast<const float*>(ti[15]);
+    const int F = (int)ti[16];
+    auto* y_track = reinterpret_cast<int32_t*>(ti[17]);
+    const int ND = (int)ti[18];
+    auto* pos_of_det = reinterpret_cast<int32_t*>(ti[19]);
+    auto* keep_rows = reinterpret_cast<int32_t*>(ti[20]);
+    auto* small = reinterpret_cast<int32_t*>(ti[21]);
+    const int64_t spare_next = ti[22];
+    const auto stream = reinterpret_cast<tmpnn_stream>(ti[23]);
+    const auto f_fwd = reinterpret_cast<fwd_fn>(info[0]);
+    const auto f_err = reinterpret_cast<err_fn>(info[2]);
+    const auto f_bind = reinterpret_cast<bind_fn>(info[6]);
+    const int64_t G = info[8], H = info[9], GH = G * H;
+    TORCH_CHECK(h.defined() && h.dim() == 2 && h.size(0) == N && h.size(1) == GH && h.is_contiguous() &&
+                    h.scalar_type() == torch::kFloat32, "greedy_step: h must be a contiguous fp32 [", N, ", ", GH, "] tensor");
+    TORCH_CHECK(D > 0 && F == info[11], "greedy_step: D = ", D, ", F = ", F);
+    const int n_new = A * D + D, Nt = N + n_new;
+    auto opts = h.options().requires_grad(false);
+    auto iopts = opts.dtype(torch::kInt32);
+    // update_graph: the block of timestep t, its features, the grown graph's index form
+    torch::Tensor arena = at::empty({(int64_t)f_ints(Nt)}, iopts);
+    tmpnn_dgraph dg;
+    TORCH_CHECK(f_bind(arena.data_ptr(), Nt, Nt, &dg) == 0, "tmpnn_dgraph_bind failed");
+    torch::Tensor feats = at::empty({n_new, F}, opts);
+    int rc = f_extend(N, A, D, active, new_ids, t, track, rows_cur, X, F, F, feats.data_ptr<float>(), F, &dg, nullptr, 0, stream);
+    TORCH_CHECK(rc == 0, "tmpnn_track_extend failed (code ", rc, "): ", f_err());
+    // the model call (eval mode): the carried state extended in place where its storage has the room
+    torch::Tensor h_cat;
+    if (cap_rows >= Nt && (int64_t)h.storage().nbytes() >= (int64_t)((h.storage_offset() + (int64_t)Nt * GH) * sizeof(float))) {
+        h_cat = at::empty({0}, opts).set_(h.storage(), h.storage_offset(), {Nt, GH}, {GH, 1});
+    } else {
+        h_cat = at::empty({Nt, GH}, opts);
+        if (N > 0) h_cat.narrow(0, 0, N).copy_(h);
+    }
+    torch::Tensor h_out = at::empty({Nt, GH}, opts), logits = at::empty({Nt, 1}, opts), scores = at::empty({Nt, 1}, opts);
+    const size_t nsave = save_floats(Nt, n_new, G, H);
+    torch::Tensor save = at::empty({(int64_t)nsave}, opts);
+    rc = f_fwd(reinterpret_cast<const tmpnn_mp_params*>(info[3]), reinterpret_cast<const float*>(info[5]), &dg, n_new,
+               feats.data_ptr<float>(), F, h_cat.data_ptr<float>(), 0, h_out.data_ptr<float>(), logits.data_ptr<float>(),
+               scores.data_ptr<float>(), save.data_ptr<float>(), nsave, stream);
+    TORCH_CHECK(rc == 0, "tmpnn_mp_iter_fwd failed (code ", rc, "): ", f_err());
+    // decode_tracks + the next timestep's active set; the compacted state lands in a buffer with room for the next block
+    torch::Tensor hbuf = at::empty({(Nt + spare_next) * GH}, opts);
+    torch::Tensor h_new = at::empty({0}, opts).set_(hbuf.storage(), 0, {Nt, GH}, {GH, 1});
+    torch::Tensor s_new = at::empty({Nt, 1}, opts);
+    rc = f_retire(&dg, rows_cur, scores.data_ptr<float>(), 1, t_upto, ret_win, y_track, ND, pos_of_det, nullptr, 0, keep_rows,
+                  small, rows_out, h_out.data_ptr<float>(), (int)GH, (int)GH, h_new.data_ptr<float>(), (int)GH,
+                  s_new.data_ptr<float>(), next_t, active, stream);
+    TORCH_CHECK(rc == 0, "tmpnn_track_retire failed (code ", rc, "): ", f_err());
+    // the one host read of the timestep: kept rows, kept det rows, the next active-set size
+    torch::Tensor counts = at::from_blob(small, {4}, iopts).cpu();
+    return {h_new, s_new, counts, arena, scores, logits};
+}
+
 }  // namespace
 
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     m.def("small_iter", &small_iter, "fused TrackMPNN iteration on one small graph (in-place or sink gradient mode)");
+    m.def("greedy_step", &greedy_step, "one greedy inference timestep: block append, model call (eval), decode_tracks, one host read");
 }

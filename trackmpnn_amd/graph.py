@@ -721,6 +721,17 @@ class DeviceGraph:
         self._meta = None
         self._frame = None
 
+    @classmethod
+    def from_arena(cls, N: int, arena: torch.Tensor, meta=None) -> 'DeviceGraph':
+        """A DeviceGraph over an arena some native caller allocated and filled (tmpnn_dgraph_ints(N) int32)."""
+        self = cls.__new__(cls)
+        self.N = self.cap = int(N)
+        c = (self.cap + 1 + 3) & ~3
+        nbytes = (((self.cap + 3) // 4) + 3) & ~3
+        assert arena.numel() >= 8 + nbytes + 10 * c
+        self.arena, self._layout, self._c, self._meta, self._frame = arena, (nbytes, c), None, meta, None
+        return self
+
     @property
     def c(self) -> '_lib.CDGraph':
         """struct tmpnn_dgraph over the arena (built on first use: the fused C++ node re-binds the arena itself)."""

@@ -103,6 +103,7 @@ def infer_sequence(model, X: torch.Tensor, y: torch.Tensor, cur_win_size: int = 
     yy = y[0].detach().cpu().numpy().astype('int64')
     y_out = yy.copy()
     y_out[:, 1] = -1
+    fast, finfo, h_cap = _fast_greedy(model, use_hungarian, tp_classifier, stages)
     with torch.no_grad():
         st.start()
         init = TrackGraph.initialize(X, y, 0, 'test', device)
@@ -116,10 +117,11 @@ def infer_sequence(model, X: torch.Tensor, y: torch.Tensor, cur_win_size: int = 
         ncalls, edge_iters = 1, tg.E
         done = []                                              # TrackGraphs abandoned by a re-initialisation
         t_skip = t_st
+        n_added = int(feats.shape[0])                          # rows the last update added (feats.shape[0] of infer.py:62)
         for t_cur in range(t_st, t_end):
             if t_cur < t_skip:
                 continue
-            if feats.shape[0] == 0 and h.shape[0] == 0:        # infer.py:62-68: the graph emptied -> initialise again
+            if n_added == 0 and h.shape[0] == 0:               # infer.py:62-68: the graph emptied -> initialise again
                 init = TrackGraph.initialize(X, y, t_cur, 'test', device)
                 if init is None:
                     break
@@ -128,10 +130,24 @@ def infer_sequence(model, X: torch.Tensor, y: torch.Tensor, cur_win_size: int = 
                 tg, feats, t_skip, _ = init
                 tg.y_track.copy_(prev.y_track)                 # (the tracks finalised so far belong to the sequence)
                 h = None
+                n_added = int(feats.shape[0])
             else:
+                t_upto = t_end if t_cur == t_end - 1 else t_cur - cur_win_size + 2
+                if fast is not None and h is not None:
+                    # steady state: the whole timestep (append, model call, decode, the one host read) in the native driver
+                    r = tg.greedy_step_fast(fast, finfo(), h, h_cap, t_cur, t_upto, ret_win_size,
+                                            t_cur + 1 if t_cur + 1 < t_end else None)
+                    if r is not None:
+                        h, sc, h_cap = r
+                        n_added = 1                            # (a native step only runs with D_t > 0 new detections)
+                        ncalls += 1
+                        edge_iters += tg.last_E
+                        continue
                 feats = tg.update(sc, X, y, t_cur, mode='test', use_hungarian=use_hungarian)
+                n_added = int(feats.shape[0])
             st.stop('graph')
             scores, logits, h, _ = model.forward_dgraph(feats, h, tg.graph)
+            h_cap = 0
             sc = _pos_score(tg, scores, tp_classifier)
             st.stop('model_fwd')
             ncalls += 1
@@ -143,6 +159,34 @@ def infer_sequence(model, X: torch.Tensor, y: torch.Tensor, cur_win_size: int = 
         y_out[:, 1] = tg.tracks()[:y_out.shape[0]]
         st.stop('decode')
     return y_out, ncalls, edge_iters
+
+
+def _fast_greedy(model, use_hungarian: bool, tp_classifier: bool, stages):
+    """(native module, call-descriptor factory, 0) where a steady-state greedy timestep can run in csrc_host/fast_iter.cpp's
+    greedy_step: models on the fused batch-1 path without attention heads, eval mode, greedy association with the TP classifier,
+    no per-stage instrumentation; (None, None, 0) otherwise."""
+    from .small import fast_module, small_eligible
+    if use_hungarian or not tp_classifier or stages is not None or model.training or getattr(model, '_padded', False):
+        return None, None, 0
+    sp = getattr(model, '_small', None)
+    if sp is None or not sp.eligible or sp.att or not small_eligible(model, 1):
+        return None, None, 0
+    fast = fast_module()
+    if fast is None or not hasattr(fast, 'greedy_step'):
+        return None, None, 0
+    if model._plist is None:
+        named = dict(model.named_parameters())
+        model._plist = [named[nm] for nm in model.spec.param_names()]
+        model._bufs = dict(model.named_buffers())
+
+    class _G:                     # fast_info() only reads .N of the graph it is given (overwritten per step by the driver)
+        N = 0
+
+    def finfo():
+        params = model._plist
+        return sp.fast_info(params, _G, sp.params(params), False, False, False, 0)
+
+    return fast, finfo, 0
 
 
 def _pos_score(tg: TrackGraph, scores: torch.Tensor, tp_classifier: bool) -> torch.Tensor:

@@ -52,6 +52,7 @@ class TrackGraph:
                        for d in self._rows]
         self._cur = 0
         self._prefetch = None                            # (timestep, the score tensor decode() returned, active-set size)
+        self._fast_addrs = None
         self.E = 0
         self.Dn = 0
         self._active = torch.empty(cap, **i32)
@@ -327,6 +328,50 @@ class TrackGraph:
         if nt >= 0:
             self._prefetch = (nt, sc, a_next, sc._version)
         return h_new[:n_keep], sc
+
+    # ---------------------------------------------------------------------------------------------------------------
+    def greedy_step_fast(self, fast, model_info, h: torch.Tensor, cap_rows: int, t: int, t_upto: int, ret_win_size: int,
+                         next_t: Optional[int]):
+        """One steady-state greedy timestep (update -> eval model call -> decode) through the native driver
+        (csrc_host/fast_iter.cpp greedy_step): the same three tracker calls and the same model call as update() /
+        TrackMPNN.forward_dgraph / decode(), issued without the interpreter between them, then the timestep's one host read.
+        Preconditions (the caller checks them, else it takes the Python path): the previous decode / step prefetched this
+        timestep's active set (`_prefetch`), D_t > 0, the grown graph fits the one-launch kernels (<= 4096 rows).
+        Returns (h', score', capacity of h' in rows) or None when the preconditions do not hold."""
+        pf = self._prefetch
+        lo, hi = self._t_range.get(int(t), (0, 0))
+        D = hi - lo
+        if pf is None or pf[0] != int(t) or D == 0:
+            return None
+        A = pf[2]
+        N = self.N
+        n_new = A * D + D
+        if N == 0 or N + n_new > DG_MAX_ROWS or self._Xd.dtype != torch.float32:
+            return None
+        self._prefetch = None
+        if self._fast_addrs is None:
+            lib = _lib.load()
+            addr = lambda f: C.cast(f, C.c_void_p).value
+            self._fast_addrs = (addr(lib.tmpnn_track_extend), addr(lib.tmpnn_track_retire), addr(lib.tmpnn_dgraph_ints))
+        fa = self._fast_addrs
+        nt = -1 if next_t is None else int(next_t)
+        spare = 2 * n_new + 256                  # room behind the compacted state for the next block (else: one copy)
+        ti = [fa[0], fa[1], fa[2], N, A, D, int(t), int(t_upto), int(ret_win_size), nt, self._active.data_ptr(),
+              self._ids_sorted.data_ptr() + 4 * lo, self.track.data_ptr(), C.addressof(self._crows[self._cur]),
+              C.addressof(self._crows[1 - self._cur]), self._Xf.data_ptr(), int(self._Xf.shape[1]), self.y_track.data_ptr(),
+              int(self.y_track.numel()), self._pos_of_det.data_ptr(), self._keep.data_ptr(), self._small.data_ptr(), spare,
+              _stream()]
+        model_info[7] = N + n_new
+        h_new, s_new, counts, arena, scores, logits = fast.greedy_step(ti, model_info, h, int(cap_rows))
+        n_keep, _, n_det, a_next = counts.tolist()
+        self.last_E = self.E + A * D                       # (edges of the graph the model call ran on)
+        self._cur = 1 - self._cur
+        self.N, self.E, self.Dn = n_keep, n_keep - n_det, n_det
+        self._graph = None
+        sc = s_new[:n_keep, 0]
+        if nt >= 0:
+            self._prefetch = (nt, sc, a_next, sc._version)
+        return h_new[:n_keep], sc, N + n_new + spare
 
     def kept_rows(self) -> torch.Tensor:
         """Rows of the previous graph that the last decode() kept (ascending)."""
