@@ -4,6 +4,8 @@
 #                                     and over the attention stage (att_bench.py); the plain bench line
 #   bash tools/measure_r04.sh var     base / K = 2 / concat / G = 3 steps with kernel stats, one KITTI window eager / captured for the
 #                                     models outside the plain fused path, C3 / C4-shaped steps, the C5 step
+#   bash tools/c5_profile_r04.sh      C5: one stream (default) / auxiliary stream, kernel stats + FETCH / WRITE passes
+#   bash tools/timestep_profile.sh    dispatches per model call of the two batch-1 loops
 # then here: python tools/collect_r04.py   -> profiles/r04_*
 set -o pipefail
 R=$GRAFT_REPO_ROOT
