@@ -359,13 +359,30 @@ def test_dense_segsum_reads_rows_once_and_matches_the_csr_kernel():
     wider row (the wide backward's d_gi planes)."""
     if not torch.cuda.is_available():
         pytest.skip('no GPU')
-    from trackmpnn_amd import _lib
-    from trackmpnn_amd.graph import dense_seg_plan, dense_static_graph
+    from trackmpnn_amd.graph import dense_static_graph
     dev = torch.device('cuda:0')
-    g = dense_static_graph(5, 150, device=dev)            # E = 90 000 (150 = 9 x 16 + 6 = 18 x 8 + 6: ragged borders too)
-    g0 = dense_static_graph(5, 150, device=dev)
+    _dense_segsum_case(dense_static_graph(5, 150, device=dev), dense_static_graph(5, 150, device=dev))
+    # the same scene after decode_tracks-like damage: a random 15 % of the edge rows gone (holes inside the tiles)
+    from trackmpnn_amd.graph import graph_from_edges
+    full = dense_static_graph(4, 120)
+    gen = torch.Generator().manual_seed(17)
+    drop = torch.rand(full.E, generator=gen) < 0.15
+    keep_row = torch.ones(full.N, dtype=torch.bool)
+    keep_row[full.edge_row.long()[drop]] = False
+    new_index = torch.cumsum(keep_row.long(), 0) - 1
+    is_edge = full.is_edge.bool()[keep_row]
+    src = new_index[full.src.long()[~drop]]
+    dst = new_index[full.dst.long()[~drop]]
+    ragged = [graph_from_edges(int(keep_row.sum()), is_edge, src, dst, device=dev) for _ in range(2)]
+    _dense_segsum_case(*ragged)
+
+
+def _dense_segsum_case(g, g0):
+    from trackmpnn_amd import _lib
+    from trackmpnn_amd.graph import dense_seg_plan
+    dev = g.device
     plan = dense_seg_plan(g)
-    assert plan is not None and plan.T > 0 and 128 * plan.T > g.E        # (border tiles have empty slots)
+    assert plan is not None and plan.T > 0 and 128 * plan.T > g.E        # (border tiles / damaged tiles have empty slots)
     H, LD = 256, 1024
     st = _lib.raw_stream()
     gen = torch.Generator().manual_seed(3)
