@@ -779,7 +779,10 @@ static int att_bwd_impl(const tmpnn_graph* g, const int32_t* erec, const int32_t
     if ((rc = launch_rows_outer(h, ld_h, g->det_row, dha, K * H, g->Dn, H, K * H, dwc, K * H, 0, tail, L.total - L.tail, st)))
         return rc;
     // d_h[det rows] += d_ha @ Wcat^T, head by head on the matrix pipe (W_k used transposed in place)
-    if (rows_gemm_supported(H, H)) {
+    if (rows_gemm_supported(K * H, H)) {
+        // all heads in one product where K H <= 128 (one read-modify-write pass over d_h's det rows instead of K)
+        if ((rc = launch_rows_gemm(nullptr, g->Dn, dha, K * H, K * H, W_cat, K * H, 1, H, d_h, ld_dh, g->det_row, 1, st))) return rc;
+    } else if (rows_gemm_supported(H, H)) {
         for (int k = 0; k < K; ++k)
             if ((rc = launch_rows_gemm(nullptr, g->Dn, dha + (size_t)k * H, K * H, H, W_cat + (size_t)k * H, K * H, 1, H, d_h, ld_dh,
                                        g->det_row, 1, st))) return rc;

@@ -3672,7 +3672,7 @@ static bool split_enabled() {
 bool rows_gemm_supported(int KD, int NOUT) {
     if (!split_enabled() || NOUT <= 0 || NOUT % 32) return false;
     const int nt = NOUT / 32;
-    return (KD == 64 && (nt == 2 || nt == 4 || nt == 6)) || (KD == 32 && nt >= 1 && nt <= 3);
+    return (KD == 64 && (nt == 1 || nt == 2 || nt == 4 || nt == 6)) || (KD == 32 && nt >= 1 && nt <= 3) || (KD == 128 && (nt == 1 || nt == 2));
 }
 int launch_rows_gemm(const int32_t* rows, int R, const float* in, int ld_in, int KD, const float* wt, int ld_wt, int wt_trans,
                      int NOUT, float* out, int ld_out, const int32_t* out_rows, int accumulate, hipStream_t st) {
@@ -3690,8 +3690,9 @@ int launch_rows_gemm(const int32_t* rows, int R, const float* in, int ld_in, int
                            ld_out, out_rows, accumulate, ntiles);                                                   \
     } while (0)
     const int nt = NOUT / 32;
-    if (KD == 64) { if (nt == 2) RG(64, 2); else if (nt == 4) RG(64, 4); else RG(64, 6); }
-    else          { if (nt == 1) RG(32, 1); else if (nt == 2) RG(32, 2); else RG(32, 3); }
+    if (KD == 128)     { if (nt == 1) RG(128, 1); else RG(128, 2); }          // (d_h += d_ha Wcat^T over all heads of an attention call)
+    else if (KD == 64) { if (nt == 1) RG(64, 1); else if (nt == 2) RG(64, 2); else if (nt == 4) RG(64, 4); else RG(64, 6); }
+    else               { if (nt == 1) RG(32, 1); else if (nt == 2) RG(32, 2); else RG(32, 3); }
 #undef RG
     return check_launch("rows_gemm_split");
 }
