@@ -48,7 +48,8 @@ def _loss_terms(tg: TrackGraph, scores, logits, ce, focal_node, focal_edge, tp_c
     """train.py:70-81 / :109-120 for one forward call."""
     # one autograd node for targets + CE + the focal terms (trackmpnn_amd.loss.train_losses: the same C entry points as the
     # CELoss / FocalLoss modules `ce`, `focal_node`, `focal_edge` -- train.py's gamma = 0, alpha = None -- would call one by one)
-    return train_losses(scores, logits, tg.labels_u8(), tg.graph.frame_graph(), tp_classifier)
+    # (the DeviceGraph itself: the one-launch losses take its arrays through the C struct, no tensor views)
+    return train_losses(scores, logits, tg.labels_u8(), tg.graph, tp_classifier)
 
 
 def train_chunk(model, X: torch.Tensor, y: torch.Tensor, device='cuda:0', tp_classifier: bool = True,

@@ -15,6 +15,8 @@ from typing import Optional, Union
 
 import weakref
 
+import ctypes
+
 import torch
 import torch.nn as nn
 
@@ -240,7 +242,9 @@ class _TrainLosses(torch.autograd.Function):
             if d_f is not None:
                 d_scores = torch.empty_like(ctx.sc)
                 d_f = d_f.reshape(1).float().contiguous()
-            _lib.call('tmpnn_train_losses_bwd', g.cref(), _lib.ptr(g.src_pos), _lib.ptr(g.dst_pos), ctx.lg.data_ptr(),
+            sp = getattr(g, 'src_pos_ptr', None) or _lib.ptr(g.src_pos)
+            dp = getattr(g, 'dst_pos_ptr', None) or _lib.ptr(g.dst_pos)
+            _lib.call('tmpnn_train_losses_bwd', g.cref(), sp, dp, ctx.lg.data_ptr(),
                       ctx.sc.data_ptr(), ctx.targets.data_ptr(), ctx.stats.data_ptr(), _lib.ptr(d_c), _lib.ptr(d_f),
                       1 if ctx.tp else 0, _lib.ptr(d_logits), _lib.ptr(d_scores), st)
             return (None if d_logits is None else d_logits.reshape(ctx.shapes[0]),
@@ -264,11 +268,31 @@ class _TrainLosses(torch.autograd.Function):
         return d_logits, d_scores, None, None, None
 
 
+class _DGView:
+    """What the one-launch losses need of a DeviceGraph whose sizes the host knows: the sizes and a struct tmpnn_graph over its
+    arena -- no tensor views (DeviceGraph.frame_graph() builds a dozen of them: ~20 us per call of a batch-1 loop)."""
+
+    def __init__(self, dg: DeviceGraph):
+        E, Dn, _ = dg.meta()
+        c = dg.c
+        self.N, self.E, self.Dn = dg.N, E, Dn
+        self._c = _lib.CGraph(dg.N, E, Dn, c.src, c.dst, c.edge_row, c.det_row, c.rowptr, c.inc, None, None)
+        self.src_pos_ptr, self.dst_pos_ptr = c.src_pos, c.dst_pos
+        self._dg = dg                                    # (keeps the arena alive)
+
+    def cref(self):
+        return ctypes.byref(self._c)
+
+
 def train_losses(scores: torch.Tensor, logits: torch.Tensor, labels: torch.Tensor, node_adj, tp_classifier: bool = True):
     """(loss_c, loss_f) of one forward call as train.py:70-81 computes them (CELoss on the logits; FocalLoss(gamma=0) on the
     scores of the edge rows, plus that of the det rows with the TP classifier) from the row labels."""
     _need_cuda(scores, 'scores')
-    g = _as_graph(node_adj)
+    if (isinstance(node_adj, DeviceGraph) and node_adj._meta is not None and node_adj._meta[2] == 0
+            and _lib.load().tmpnn_train_losses_supported(node_adj._meta[0], node_adj._meta[1])):
+        g = _DGView(node_adj)
+    else:
+        g = _as_graph(node_adj)
     lab = labels.reshape(-1)
     lab = lab if (lab.dtype == torch.uint8 and lab.is_contiguous()) else (lab != 0).to(torch.uint8).contiguous()
     # ([N, 1] scores: a reshape is a view both ways; scores[:, 0] would cost a zero fill + a copy in the backward)
