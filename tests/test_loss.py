@@ -189,3 +189,9 @@ def test_train_losses_equals_the_separate_modules(tp):
     assert c2.item() == loss_c.item() and f2.item() == loss_f.item()
     assert torch.equal(la.grad, lb.grad)
     assert torch.equal(sa.grad, sb.grad)
+    # handed the DeviceGraph itself (as trackmpnn_amd.loops does): the native autograd node over the same two launches
+    sc, lc = s0.clone().requires_grad_(True), l0.clone().requires_grad_(True)
+    c3, f3 = train_losses(sc, lc, tg.labels_u8(), tg.graph, tp)
+    (c3 * 0.7 + f3 * 1.3).backward()
+    assert c3.item() == loss_c.item() and f3.item() == loss_f.item()
+    assert torch.equal(la.grad, lc.grad) and torch.equal(sa.grad, sc.grad)

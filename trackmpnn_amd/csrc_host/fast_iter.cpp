@@ -307,9 +307,93 @@ std::vector<torch::Tensor> greedy_step(std::vector<int64_t> ti, std::vector<int6
     return {h_new, s_new, counts, arena, scores, logits};
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// train.py:70-81 for one forward call as a native autograd node: tmpnn_train_losses_fwd / _bwd (one launch each way) without
+// the interpreter's Function.apply / backward bookkeeping (~50 us per call of a batch-1 train chunk).  trackmpnn_amd/loss.py
+// `_TrainLosses` is the same node in Python and stays the path for graphs the one-launch kernels do not take.
+using tl_fwd_fn = int (*)(const tmpnn_graph*, const float*, const float*, const uint8_t*, int, uint8_t*, float*, float*, float*,
+                          size_t, tmpnn_stream);
+using tl_bwd_fn = int (*)(const tmpnn_graph*, const int32_t*, const int32_t*, const float*, const float*, const uint8_t*,
+                          const float*, const float*, const float*, int, float*, float*, tmpnn_stream);
+
+class TrainLossesFn : public torch::autograd::Function<TrainLossesFn> {
+   public:
+    // info: f_fwd, f_bwd, f_err, address of a struct tmpnn_graph (copied here), tp_classifier, src_pos ptr, dst_pos ptr, stream,
+    //       workspace floats (tmpnn_train_losses_ws)
+    static torch::autograd::variable_list forward(torch::autograd::AutogradContext* ctx, torch::Tensor logits, torch::Tensor scores,
+                                                  torch::Tensor labels_u8, std::vector<int64_t> info,
+                                                  std::vector<torch::Tensor> keep) {
+        TORCH_CHECK(info.size() == 9, "train_losses: bad call descriptor");
+        tmpnn_graph g;
+        std::memcpy(&g, reinterpret_cast<const void*>(info[3]), sizeof(g));
+        const int64_t Dn = g.Dn;
+        auto opts = logits.options().dtype(torch::kFloat32).requires_grad(false);
+        torch::Tensor lg = logits.detach().reshape({-1});
+        if (lg.scalar_type() != torch::kFloat32 || !lg.is_contiguous()) lg = lg.to(torch::kFloat32).contiguous();
+        torch::Tensor sc = scores.detach().reshape({-1});
+        if (sc.scalar_type() != torch::kFloat32 || !sc.is_contiguous()) sc = sc.to(torch::kFloat32).contiguous();
+        TORCH_CHECK(lg.numel() == g.N && sc.numel() == g.N && labels_u8.numel() == g.N && labels_u8.scalar_type() == torch::kUInt8 &&
+                        labels_u8.is_contiguous(), "train_losses: logits / scores / labels must have one entry per row");
+        torch::Tensor targets = at::empty_like(labels_u8);
+        const int64_t nd8 = (Dn > 0 ? Dn : 1) * 8, n_ws = info[8];
+        torch::Tensor buf = at::empty({nd8 + 4 + n_ws}, opts);
+        float* base = buf.data_ptr<float>();
+        const int rc = reinterpret_cast<tl_fwd_fn>(info[0])(&g, lg.data_ptr<float>(), sc.data_ptr<float>(),
+                                                            labels_u8.data_ptr<uint8_t>(), (int)info[4], targets.data_ptr<uint8_t>(),
+                                                            base, base + nd8, base + nd8 + 4, (size_t)n_ws,
+                                                            reinterpret_cast<tmpnn_stream>(info[7]));
+        TORCH_CHECK(rc == 0, "tmpnn_train_losses_fwd failed (code ", rc, "): ", reinterpret_cast<err_fn>(info[2])());
+        ctx->saved_data["info"] = info;
+        torch::Tensor gpod = at::empty({(int64_t)sizeof(tmpnn_graph)}, at::TensorOptions().dtype(torch::kByte));
+        std::memcpy(gpod.data_ptr(), &g, sizeof(g));
+        ctx->saved_data["g"] = gpod;
+        ctx->saved_data["lg"] = lg;
+        ctx->saved_data["sc"] = sc;
+        ctx->saved_data["targets"] = targets;
+        ctx->saved_data["buf"] = buf;
+        ctx->saved_data["keep"] = keep;                     // (the graph's arena: the struct above points into it)
+        ctx->saved_data["lshape"] = logits.sizes().vec();
+        ctx->saved_data["sshape"] = scores.sizes().vec();
+        ctx->set_materialize_grads(false);
+        torch::Tensor out = buf.narrow(0, nd8, 4);
+        return {out.select(0, 0), out.select(0, 3)};
+    }
+
+    static torch::autograd::variable_list backward(torch::autograd::AutogradContext* ctx,
+                                                   torch::autograd::variable_list grad_outputs) {
+        std::vector<int64_t> info = ctx->saved_data["info"].toIntVector();
+        torch::Tensor gpod = ctx->saved_data["g"].toTensor();
+        const tmpnn_graph* g = reinterpret_cast<const tmpnn_graph*>(gpod.data_ptr());
+        torch::Tensor lg = ctx->saved_data["lg"].toTensor(), sc = ctx->saved_data["sc"].toTensor();
+        torch::Tensor targets = ctx->saved_data["targets"].toTensor(), buf = ctx->saved_data["buf"].toTensor();
+        auto seed = [](const torch::Tensor& t) {
+            torch::Tensor s = t.reshape({1});
+            return (s.scalar_type() == torch::kFloat32 && s.is_contiguous()) ? s : s.to(torch::kFloat32).contiguous();
+        };
+        torch::Tensor d_c, d_f, d_logits, d_scores;
+        if (grad_outputs[0].defined()) { d_c = seed(grad_outputs[0]); d_logits = at::empty_like(lg); }
+        if (grad_outputs[1].defined()) { d_f = seed(grad_outputs[1]); d_scores = at::empty_like(sc); }
+        const int rc = reinterpret_cast<tl_bwd_fn>(info[1])(
+            g, reinterpret_cast<const int32_t*>(info[5]), reinterpret_cast<const int32_t*>(info[6]), lg.data_ptr<float>(),
+            sc.data_ptr<float>(), targets.data_ptr<uint8_t>(), buf.data_ptr<float>(), d_c.defined() ? d_c.data_ptr<float>() : nullptr,
+            d_f.defined() ? d_f.data_ptr<float>() : nullptr, (int)info[4], d_logits.defined() ? d_logits.data_ptr<float>() : nullptr,
+            d_scores.defined() ? d_scores.data_ptr<float>() : nullptr, reinterpret_cast<tmpnn_stream>(info[7]));
+        TORCH_CHECK(rc == 0, "tmpnn_train_losses_bwd failed (code ", rc, "): ", reinterpret_cast<err_fn>(info[2])());
+        if (d_logits.defined()) d_logits = d_logits.reshape(ctx->saved_data["lshape"].toIntVector());
+        if (d_scores.defined()) d_scores = d_scores.reshape(ctx->saved_data["sshape"].toIntVector());
+        return {d_logits, d_scores, torch::Tensor(), torch::Tensor(), torch::Tensor()};
+    }
+};
+
+std::vector<torch::Tensor> train_losses(torch::Tensor logits, torch::Tensor scores, torch::Tensor labels_u8, std::vector<int64_t> info,
+                                        std::vector<torch::Tensor> keep) {
+    return TrainLossesFn::apply(logits, scores, labels_u8, info, keep);
+}
+
 }  // namespace
 
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
+    m.def("train_losses", &train_losses, "create_targets + CELoss + the focal terms of one forward call as one native autograd node");
     m.def("small_iter", &small_iter, "fused TrackMPNN iteration on one small graph (in-place or sink gradient mode)");
     m.def("greedy_step", &greedy_step, "one greedy inference timestep: block append, model call (eval), decode_tracks, one host read");
 }

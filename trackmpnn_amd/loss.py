@@ -297,4 +297,32 @@ def train_losses(scores: torch.Tensor, logits: torch.Tensor, labels: torch.Tenso
     lab = lab if (lab.dtype == torch.uint8 and lab.is_contiguous()) else (lab != 0).to(torch.uint8).contiguous()
     # ([N, 1] scores: a reshape is a view both ways; scores[:, 0] would cost a zero fill + a copy in the backward)
     sc = (scores.reshape(-1) if scores.shape[1] == 1 else scores[:, 0]) if scores.dim() == 2 else scores
+    if isinstance(g, _DGView):
+        fast = _fast_losses()
+        if fast is not None:
+            # the same two launches from a native autograd node (csrc_host/fast_iter.cpp TrainLossesFn)
+            a = _fast_addrs()
+            info = [a[0], a[1], a[2], ctypes.addressof(g._c), int(bool(tp_classifier)), g.src_pos_ptr or 0, g.dst_pos_ptr or 0,
+                    _stream(), int(_lib.load().tmpnn_train_losses_ws(g.E, g.Dn))]
+            loss_c, loss_f = fast.train_losses(logits, sc, lab, info, [g._dg.arena])
+            return loss_c, loss_f
     return _TrainLosses.apply(logits, sc, lab, g, bool(tp_classifier))
+
+
+_fast_state = {}
+
+
+def _fast_losses():
+    if 'mod' not in _fast_state:
+        from .small import fast_module
+        m = fast_module()
+        _fast_state['mod'] = m if (m is not None and hasattr(m, 'train_losses')) else None
+    return _fast_state['mod']
+
+
+def _fast_addrs():
+    if 'addrs' not in _fast_state:
+        lib = _lib.load()
+        addr = lambda f: ctypes.cast(f, ctypes.c_void_p).value
+        _fast_state['addrs'] = (addr(lib.tmpnn_train_losses_fwd), addr(lib.tmpnn_train_losses_bwd), addr(lib.tmpnn_last_error))
+    return _fast_state['addrs']
