@@ -278,24 +278,43 @@ def _pmc_kernel(stage):
             'gru_bwd_weights_edge': 'k_gru_bwd_weights_lds<64, 1, 1>'}.get(stage, '?')
 
 
+def kernel_source_digest(files=('gru.hip', 'common.h')):
+    """sha256 (first 16 hex digits) of the kernel sources a committed PMC pass belongs to: tools/collect_r05.py records it
+    next to the counters, `pmc_traffic` compares it with the tree that is running."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in files:
+        with open(os.path.join(ROOT, 'trackmpnn_amd', 'csrc', f), 'rb') as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def pmc_traffic(stage, E):
-    """HBM bytes per launch of the stage's kernel from the committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE
-    in two separate runs of tools/stage_bench.py, profiles/r03_pmc_traffic_stage_kernels.json), corrected as
+    """(bytes, source) -- HBM bytes per launch of the stage's kernel from the committed rocprofv3 PMC passes (FETCH_SIZE and
+    WRITE_SIZE in two separate runs of tools/stage_bench.py, profiles/rNN_pmc_traffic_stage_kernels.json), corrected as
     MI355X_MICROARCH.md prescribes for gfx950: FETCH_SIZE tallies the 128-byte requests of a wide coalesced stream
     (16 B per lane -- every row stream of these kernels) at 64 bytes, so reads = 2 x FETCH_SIZE; WRITE_SIZE is exact for
-    16-byte-per-lane stores.  None unless the profile was taken on a graph of exactly this size."""
-    for tag in ('r04', 'r03', 'r02', 'r01'):
-        path = os.path.join(ROOT, 'profiles', f'{tag}_pmc_traffic_stage_kernels.json')
+    16-byte-per-lane stores.  The counters are NOT collected inside the bench run (a --pmc pass serialises and slows every
+    kernel); `source` says where the number comes from (file, the date and HEAD of the pass, the digest of the kernel
+    sources it was taken on).  bytes is None when no profile was taken on a graph of exactly this size, or when the
+    profile records a source digest and the kernel sources have changed since (`source.stale`)."""
+    for tag in ('r05', 'r04', 'r03', 'r02', 'r01'):
+        name_ = f'{tag}_pmc_traffic_stage_kernels.json'
         try:
-            prof = json.load(open(path))
+            prof = json.load(open(os.path.join(ROOT, 'profiles', name_)))
         except OSError:
             continue
         if prof.get('graph', {}).get('E') != E:
             continue
+        src = dict(file='profiles/' + name_, collected=prof.get('collected'), head=prof.get('head'),
+                   kernel_source_digest=prof.get('kernel_source_digest'), method='committed rocprofv3 --pmc passes, not live')
+        if prof.get('kernel_source_digest') and prof['kernel_source_digest'] != kernel_source_digest():
+            src['stale'] = 'kernel sources changed since the pass (digest now %s)' % kernel_source_digest()
+            return None, src
         for name, v in prof['kernels'].items():
             if _pmc_kernel(stage) in name and v.get('WRITE_SIZE_KB') is not None:
-                return (2.0 * v['FETCH_SIZE_KB'] + v['WRITE_SIZE_KB']) * 1024.0
-    return None
+                return (2.0 * v['FETCH_SIZE_KB'] + v['WRITE_SIZE_KB']) * 1024.0, src
+    return None, None
 
 
 def cpu_baseline(frames, mean_dets, max_dets, F, H, seed, budget_s=20.0):
@@ -677,14 +696,16 @@ def main():
         pipe_frac = tf / MFMA_F32_PEAK_TF * (6.0 / 16.0 if split_enabled() else 1.0)
         hbm_frac = gbs / HBM_PEAK_GBS
         if hbm_frac >= pipe_frac:
+            traffic, traffic_source = pmc_traffic(dom, plans[-1].graph.E)
             roofline = dict(bound='hbm', kernel=dom, achieved=gbs, peak=HBM_PEAK_GBS, unit='GB/s', frac=hbm_frac,
-                            traffic=pmc_traffic(dom, plans[-1].graph.E), ms=t[dom], algorithmic_bytes=nbytes[dom],
+                            traffic=traffic, traffic_source=traffic_source, ms=t[dom], algorithmic_bytes=nbytes[dom],
                             matrix_pipe_frac=pipe_frac, f32_equiv_tflops=tf)
             if 'hbm_measured' in extra:        # the same achieved rate against what a plain device copy reaches on this box
                 roofline['frac_of_measured_copy'] = round(gbs / extra['hbm_measured']['copy_GBs'], 3)
         else:
+            traffic, traffic_source = pmc_traffic(dom, plans[-1].graph.E)
             roofline = dict(bound='mfma', kernel=dom, achieved=tf, peak=MFMA_F32_PEAK_TF, unit='TFLOP/s', frac=pipe_frac,
-                            traffic=pmc_traffic(dom, plans[-1].graph.E), ms=t[dom], hbm_frac=hbm_frac)
+                            traffic=traffic, traffic_source=traffic_source, ms=t[dom], hbm_frac=hbm_frac)
         extra['stage_roofs'] = {k: dict(ms=round(t[k], 4), GBs=round(nbytes[k] / (t[k] * 1e-3) / 1e9, 1),
                                         hbm_frac=round(nbytes[k] / (t[k] * 1e-3) / 1e9 / HBM_PEAK_GBS, 3),
                                         f32_equiv_tflops=round(flops[k] / (t[k] * 1e-3) / 1e12, 1) if k in flops else None)

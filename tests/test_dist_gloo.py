@@ -203,3 +203,38 @@ def test_bucket_allreduce_through_rccl_world1():
     ok = q.get(timeout=300)
     p.join(timeout=120)
     assert p.exitcode == 0 and ok
+
+
+@pytest.mark.gpu
+def test_bench_two_rank_branch_runs_end_to_end():
+    """bench.py's own world > 1 branch (process-group init, barrier around the build, MAX / SUM reductions of time and
+    edges, the `allreduce` block) launched the way the driver launches it -- `python -m torch.distributed.run
+    --nproc-per-node 2 bench.py --gpus 2` -- as a FRESH child process (the launcher starts before any GPU call of its
+    own), two ranks sharing cuda:0 over gloo.  One JSON line, n_gpus 2, value = both ranks' edges over the max time."""
+    import json
+    import subprocess
+    import sys
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU')
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_PORT'):
+        env.pop(k, None)
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', str(_free_port()), os.path.join(root, 'bench.py'), '--gpus', '2', '--backend', 'gloo',
+           '--single-device', '--windows', '256', '--steps', '2', '--warmup', '1', '--no-cpu-baseline', '--no-latency',
+           '--no-loops']
+    r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out['n_gpus'] == 2 and out['steps'] == 2 and out['scaling'] == 'weak'
+    assert out['config']['parallelism'] == 'sequence-dp2'
+    assert out['allreduce']['us'] > 0 and out['allreduce']['bytes'] == 4 * 54914 and out['allreduce']['backend'] == 'gloo'
+    # whole-job value: the SUM of both ranks' edge iterations over the MAX time (the ranks hold different seeds, so
+    # their counts differ a little: the total lies between 1.8 and 2.2 times rank 0's)
+    per_rank = out['config']['edge_iterations_per_gpu_step']
+    total = out['value'] * out['ms_per_step'] * 1e-3
+    assert 1.8 * per_rank < total < 2.2 * per_rank
+    assert out['roofline'] is not None and out['cpu_baseline'] is None
