@@ -591,7 +591,13 @@ static int rows_ok(const tmpnn_track_rows* r) {
 
 int tmpnn_track_select(const tmpnn_dgraph* g, const tmpnn_track_rows* rows, const float* score, int mode, int t,
                        int associate, int32_t* active, int32_t* small, tmpnn_stream stream) {
-    TM_REQUIRE(g && rows_ok(rows) && active && small, "track_select: null pointer");
+    TM_REQUIRE(g && small, "track_select: null pointer");
+    if (g->N == 0) {            // an emptied graph (cur_win_size = 1 and a timestep without detections): no active det, status 0;
+        if (hipMemsetAsync(small, 0, 2 * sizeof(int32_t), as_stream(stream)) != hipSuccess)     // zero-size tensors have null data
+            return set_error(TMPNN_ELAUNCH, "track_select: clearing the counters failed");
+        return TMPNN_OK;
+    }
+    TM_REQUIRE(rows_ok(rows) && active, "track_select: null pointer");
     TM_REQUIRE(mode == 0 ? rows->labels != nullptr : (mode == 1 && score != nullptr), "track_select: mode %d needs %s", mode,
                mode == 0 ? "labels" : "scores");
     int rc;
@@ -633,8 +639,13 @@ int tmpnn_track_retire(const tmpnn_dgraph* g, const tmpnn_track_rows* rows, cons
                        int ret_win, int32_t* y_track, int ND, int32_t* pos_of_det, void* fin_ws, size_t fin_ws_bytes,
                        int32_t* keep, int32_t* small, const tmpnn_track_rows* rows_out, const float* h, int ld_h, int W,
                        float* h_new, int ld_hn, float* s_new, int next_t, int32_t* active, tmpnn_stream stream) {
-    TM_REQUIRE(g && rows_ok(rows) && rows_ok(rows_out) && score && keep && small && h && h_new && s_new,
-               "track_retire: null pointer");
+    TM_REQUIRE(g && small, "track_retire: null pointer");
+    if (g->N == 0) {            // nothing to decode (the old per-phase entry points returned early too): kept rows = kept dets =
+        if (hipMemsetAsync(small, 0, 4 * sizeof(int32_t), as_stream(stream)) != hipSuccess)     // next active set = 0
+            return set_error(TMPNN_ELAUNCH, "track_retire: clearing the counters failed");
+        return TMPNN_OK;
+    }
+    TM_REQUIRE(rows_ok(rows) && rows_ok(rows_out) && score && keep && h && h_new && s_new, "track_retire: null pointer");
     TM_REQUIRE(W > 0 && ld_h >= W && ld_hn >= W && aligned16(h) && aligned16(h_new), "track_retire: W=%d ld_h=%d ld_hn=%d", W,
                ld_h, ld_hn);
     TM_REQUIRE(next_t < 0 || active, "track_retire: the next timestep's active set needs its buffer");

@@ -86,6 +86,23 @@ def _aux_stream(dev) -> Optional[int]:
     return s.cuda_stream
 
 
+def _seg_plan_guard(g, dev, on_aux: bool) -> None:
+    """The dense segment sum's partial-row buffer belongs to the graph's cached plan (struct tmpnn_seg_plan.ws): one segment sum
+    at a time per plan.  Uses on ONE stream are ordered by the stream; when the stream changes (main <-> auxiliary, or a
+    caller that moves the graph to another stream) the new stream first waits for everything the previous user's stream
+    has been given so far."""
+    plan = g.__dict__.get('_seg_plan')
+    if plan is None or torch.cuda.is_current_stream_capturing():
+        return
+    cur = _aux_streams[torch.device(dev)] if on_aux else torch.cuda.current_stream(dev)
+    last = plan.__dict__.get('_last_stream')
+    if last is not None and last.cuda_stream != cur.cuda_stream:
+        ev = torch.cuda.Event()
+        ev.record(last)
+        cur.wait_event(ev)
+    plan._last_stream = cur
+
+
 _aux_events: Dict[torch.device, tuple] = {}
 
 
@@ -433,6 +450,7 @@ def mp_forward(spec: ModelSpec, plan: CallPlan, x: torch.Tensor, h_in: Optional[
         # edge -> node aggregation                              (layers.py:99-112)
         es = es_all[gi]
         if K == 0:
+            _seg_plan_guard(g, dev, aux_obj is not None)
             _lib.call('tmpnn_segsum_fwd', g.cref(), hg, GH, es.data_ptr(), H, H, 0, 1, st_det)
             alphas.append(None)
         else:
@@ -628,6 +646,7 @@ def mp_backward(spec: ModelSpec, plan: CallPlan, saved: dict, P: Dict[str, torch
                     evf, evj = ef.cuda_event, ej.cuda_event
                     if not evf or not evj:                     # (no native handle: one stream)
                         aux = evf = evj = None
+                _seg_plan_guard(g, dev, aux is not None)       # (the three d_gi segment sums run on `aux` when it is given)
                 if fuse and WIDE_FUSED_ADJOINT:
                     # the adjoint of the edge -> node sum rides in the epilogue of the E-row product (no separate pass over d_h)
                     _lib.call('tmpnn_wide_gru_bwd_diff_fused', *args[:-1], dmsg.data_ptr(), IN_e, st, aux, evf, evj)

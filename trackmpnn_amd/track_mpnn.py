@@ -238,7 +238,8 @@ class TrackMPNN(nn.Module):
         version counter) instead of once per forward call: the calls of a window share one set of copies, so the ~30 pad
         kernels (and their backward) run once per step; autograd still hands the true parameters their gradients through
         the copies.  Dropped when a backward pass reaches the copies (their graph is spent), when a version moves, and by
-        refresh_weights() / .to() / load_state_dict()."""
+        refresh_weights() / .to() / load_state_dict().  Edits through `p.data` (copy_, mul_) do NOT move the version counter:
+        call refresh_weights() after them, as for the operand images of the fused path."""
         key = (torch.is_grad_enabled(), tuple((id(p), p._version, p.requires_grad) for p in params))
         c = self._pad_cache
         if c is not None and c[0] == key:
@@ -256,7 +257,8 @@ class TrackMPNN(nn.Module):
                     m = me()
                     if m is not None and m._pad_cache is not None and m._pad_cache[2] is token:
                         m._pad_cache = None
-                live[0].register_hook(spent)
+                for t_ in live:                          # (any copy a backward pass reaches spends the shared graph: a pass that
+                    t_.register_hook(spent)              #  stops short of the first parameter must invalidate the cache too)
         return out
 
     def _pad_state(self, h):

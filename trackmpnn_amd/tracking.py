@@ -168,6 +168,8 @@ class TrackGraph:
             tg._Xf = tg._Xd if (tg._Xd.dtype == torch.float32 and tg._Xd.is_contiguous()) else tg._Xd.float().contiguous()
         tg._sequence(yy, order)
         tg._X_src, tg._y_src = X, y
+        tg._src_versions = (X._version, y._version)        # (an in-place edit after initialize() must not pass the identity check)
+        tg._y_host = y.detach().cpu() if y.is_cuda else y.detach().clone()
         feats = torch.empty((N, F), dtype=torch.float32, device=tg.device)
         g, ws = tg._new_graph(N)
         _lib.call('tmpnn_track_load', N, ND, pk.data_ptr(), C.byref(tg._crows[tg._cur]), tg._Xf.data_ptr(), F, F, feats.data_ptr(),
@@ -238,12 +240,30 @@ class TrackGraph:
         One host read: the size of the active set."""
         # features and per-timestep detection ids were uploaded ONCE at initialize(): a different X / y here would be
         # silently ignored, so refuse it (the reference's loops pass the same sequence tensors every step)
-        if X is not self._X_src or y is not self._y_src:
+        # Contract (INTEGRATION.md): X / y must hold what initialize() was given.  The same tensor objects pass when their
+        # version counters have not moved; other tensors pass when they alias the same storage un-edited, or -- a loop that
+        # re-slices y or moves X per step -- when shape and contents agree (y: compared in full, it is a few hundred rows;
+        # X: shape, dtype and its first / last feature rows).
+        if X is self._X_src and y is self._y_src:
+            if (X._version, y._version) != self._src_versions:
+                raise ValueError('TrackGraph.update: X / y were modified in place after initialize(); their contents are '
+                                 'cached on the device once per sequence -- start a new TrackGraph for new data')
+        else:
             for given, kept, nm in ((X, self._X_src, 'X'), (y, self._y_src, 'y')):
-                if kept is not None and given is not kept and not (
-                        given.shape == kept.shape and given.data_ptr() == kept.data_ptr() and given._version == kept._version):
-                    raise ValueError(f'TrackGraph.update: {nm} must be the tensor initialize() was given (its contents are '
+                if kept is None or given is kept:
+                    continue
+                if given.shape == kept.shape and given.data_ptr() == kept.data_ptr() and given._version == kept._version:
+                    continue
+                same = given.shape == kept.shape and given.dtype == kept.dtype
+                if same and nm == 'y':
+                    same = bool(torch.equal(given.detach().cpu(), self._y_host))
+                elif same and given.numel():
+                    a, b = given.detach()[0], self._Xd
+                    same = bool(torch.equal(a[:1].to(b.device, b.dtype), b[:1]) and torch.equal(a[-1:].to(b.device, b.dtype), b[-1:]))
+                if not same:
+                    raise ValueError(f'TrackGraph.update: {nm} differs from what initialize() was given (its contents are '
                                      'cached on the device once per sequence); start a new TrackGraph for new data')
+            self._X_src, self._y_src, self._src_versions = X, y, (X._version, y._version)
         train = mode == 'train'
         pf, self._prefetch = self._prefetch, None
         N = self.N
@@ -298,6 +318,11 @@ class TrackGraph:
         Returns the compacted (h', score_pos')."""
         N = self.N
         self._prefetch = None
+        if N == 0:              # an emptied window (cur_win_size = 1 and a timestep without detections): nothing to decode
+            sc0 = score_pos.detach().reshape(-1)[:0].float()
+            if next_t is not None and not use_hungarian:
+                self._prefetch = (int(next_t), sc0, 0, sc0._version)
+            return h.detach()[:0].float(), sc0
         sp = score_pos.detach().reshape(-1).float().contiguous()
         if use_hungarian:
             self._hungarian(sp)
@@ -348,6 +373,12 @@ class TrackGraph:
         n_new = A * D + D
         if N == 0 or N + n_new > DG_MAX_ROWS or self._Xd.dtype != torch.float32:
             return None
+        # what the native call would refuse with an exception is checked HERE, while nothing has been touched: the caller
+        # then takes the Python path (update / forward_dgraph / decode) with the prefetched active set still in place
+        GH = int(model_info[8]) * int(model_info[9])
+        if not (h.dim() == 2 and h.dtype == torch.float32 and h.is_contiguous() and h.shape[0] == N and h.shape[1] == GH
+                and int(self._Xf.shape[1]) == int(model_info[11])):
+            return None
         self._prefetch = None
         if self._fast_addrs is None:
             lib = _lib.load()
@@ -362,7 +393,13 @@ class TrackGraph:
               int(self.y_track.numel()), self._pos_of_det.data_ptr(), self._keep.data_ptr(), self._small.data_ptr(), spare,
               _stream()]
         model_info[7] = N + n_new
-        h_new, s_new, counts, arena, scores, logits = fast.greedy_step(ti, model_info, h, int(cap_rows))
+        try:
+            h_new, s_new, counts, arena, scores, logits = fast.greedy_step(ti, model_info, h, int(cap_rows))
+        except RuntimeError:
+            # a C entry point refused its arguments before launching anything that changes the graph: rows [0, N) and the
+            # counters are as they were (the appended block sits beyond N and the grown index form in its own arena)
+            self._prefetch = pf
+            raise
         n_keep, _, n_det, a_next = counts.tolist()
         self.last_E = self.E + A * D                       # (edges of the graph the model call ran on)
         self._cur = 1 - self._cur
