@@ -88,6 +88,27 @@ __global__ __launch_bounds__(256) void k_wide_prep16(const float* __restrict__ W
     }
 }
 
+// Half-step image of the forward W_hh operand for k_wide_gru_fwd_pp: the 18-KB block one HALF of the block reads in one half
+// step of one item -- [piece 3][gate 3][64 hidden columns][16 k] -- is CONTIGUOUS, so its 18 one-KB request pieces are a
+// linear copy: imgpp[((((j * (H / 128) + c) * 2 + hx) * 9 + piece * 3 + gate) * 64 + col) * 16 + pos] = piece of
+// B[16 j + kk][gate H + 128 c + 64 hx + col], pos = ((kk >> 3) ^ ((col >> 4) & 1)) * 8 + (kk & 7) (the chunk swap of k_wide_prep16).
+__global__ __launch_bounds__(256) void k_wide_prep_pp(const float* __restrict__ W, int ldw, int H, uint16_t* __restrict__ img) {
+    const long total = (long)H * 3 * H;
+    const int nchunk = H >> 7;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int k = (int)(i / (3 * H)), n = (int)(i % (3 * H));
+        const float v = W[(size_t)n * ldw + k];                                          // B = W_hh^T
+        uint32_t p1, p2, p3;
+        w_split2(v, 0.f, p1, p2, p3);
+        const int j = k >> 4, kk = k & 15, gate = n / H, hcol = n % H, c = hcol >> 7, hx = (hcol >> 6) & 1, col = hcol & 63;
+        const size_t blk = ((size_t)(j * nchunk + c) * 2 + hx) * 9;
+        const size_t pos = (size_t)col * 16 + ((((kk >> 3) ^ ((col >> 4) & 1)) << 3) | (kk & 7));
+        img[(blk + gate) * 1024 + pos] = (uint16_t)p1;
+        img[(blk + 3 + gate) * 1024 + pos] = (uint16_t)p2;
+        img[(blk + 6 + gate) * 1024 + pos] = (uint16_t)p3;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // the tiled product
 // ------------------------------------------------------------------------------------------------------------
@@ -825,6 +846,412 @@ __global__ __launch_bounds__(512) void k_wide_gru_fwd_ring(WideArgs a, WideTiles
         ring_dma(a, c, 2, bx << 6, 2);
         ring_dma(a, c, 3, bx << 6, 3);
     }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// the tiled cell, third form (round 5): 128 x 384 items, the two halves of the block in OPPOSITE phases
+// ------------------------------------------------------------------------------------------------------------
+// What the ring form above left on the table (C5, per 4.41 M rows: 11.7 ms against 5.6-6.3 ms of MFMAs; PMC traffic 1.51 x):
+//   * its eight waves all run the same program between the same barriers -- request, read, split, 18 MFMAs -- so both waves
+//     of a SIMD want the matrix pipe at the same time and wait at the same time; per half step a wave issues four LDS-DMA
+//     pieces (~100 cycles of issue each) and ~50 vector instructions of A split for only 18 MFMAs (576 pipe cycles);
+//   * an item is 128 rows x 192 gate columns, so the A rows of a tile are fetched once per 64 hidden columns (4 x at H = 256);
+//   * the epilogue goes through a C tile that aliases the ring: two more barriers, and nothing can be in flight under it.
+// Here:
+//   * an item is 128 rows x (3 gates x 128 hidden columns): the A rows are fetched H / 128 times (2 x at H = 256);
+//   * wave (wr, hx) owns rows 32 wr .. + 31 and the hidden columns 64 hx .. + 63 of all three gates: six 32 x 32 accumulators,
+//     36 MFMAs per half step from ONE split of its A fragment (half the split work per MFMA) -- which only fits the register
+//     file because nothing is double buffered: a wave's operands are read into registers in one barrier interval (its LOAD
+//     segment) and consumed in the next (its MMA segment);
+//   * the halves hx = 0 (waves 0-3, "X") and hx = 1 (waves 4-7, "Y": one wave of each per SIMD) run in opposite phases: while
+//     X issues the 36 MFMAs of half step p, Y reads and splits its operands of step p and issues the requests of the
+//     interval; then they swap.  The matrix pipe of a SIMD always has exactly one wave feeding it, and everything else (DMA
+//     issue, LDS reads, the split, the waits) sits beside another wave's MFMAs by construction;
+//   * A travels through a ring of four 8-KB slots (raw fp32 rows, as above), the weights through TWO sub-slots per half
+//     (X reads only its 64 hidden columns of each gate, Y only its own: [piece][gate][64 columns][32 B] = 18 KB each), so a
+//     sub-slot is free one interval after its reader's LOAD segment and the next-but-one step's pieces go out a whole half
+//     step ahead.  The request stream is PERIODIC across items: the last steps of an item request the first steps of the
+//     next one (same slots), so every LOAD segment issues the same number of pieces and every wait is a constant counted vmcnt;
+//   * the tile's projected det rows (<= PP_NDMAX rows x 384 floats) are staged by one more piece per LOAD segment;
+//   * the epilogue runs straight from the accumulators: with the row operand first, a lane holds ONE column of all three
+//     gates for 16 rows per accumulator, so the gate arithmetic needs no C tile, no barrier and no LDS but the staged P
+//     rows; outputs leave as 128-byte row segments (4 B per lane), the gate planes nontemporal.
+// Same products in the same order as the forms above: bit-identical results.
+static constexpr int PP_NDMAX = 32;                                   // det rows of a tile staged in LDS
+static constexpr int PP_A = 128 * 64, PP_NA = 4;                      // A ring: four slots of 128 rows x 16 fp32
+static constexpr int PP_BH = 9 * 2048;                                // weight sub-slot of one half: [piece 3][gate 3][64 columns][32 B]
+static constexpr int PP_OFF_B = PP_NA * PP_A;                         // weight ring: [step parity 2][half 2]
+static constexpr int PP_OFF_P = PP_OFF_B + 4 * PP_BH;                 // staged P rows [PP_NDMAX][384]
+static constexpr int PP_OFF_D = PP_OFF_P + PP_NDMAX * 384 * 4;        // tile descriptors, double buffered: [row 128][loc 128][det 256]
+static constexpr int PP_DESC = (128 + 128 + 256) * 4;
+static constexpr int PP_OFF_X = PP_OFF_D + 2 * PP_DESC;               // 1 KB nobody reads: target of the filler piece
+static constexpr size_t W_PP_SHM = PP_OFF_X + 1024;
+
+struct PpOps { uint4 af[3]; uint4 bf[18]; };      // bf[(ct * 3 + gate) * 3 + piece], ct = 32-column group of the wave's 64 hidden columns
+
+// own requests down to the N youngest (the ones this segment issued), own LDS reads, then the barrier
+template <int N>
+__device__ __forceinline__ void pp_wait_barrier() {
+    if constexpr (N == 7) asm volatile("s_waitcnt vmcnt(7) lgkmcnt(0)" ::: "memory");
+    else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+__device__ __forceinline__ void pp_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
+// what a wave needs to issue its share of an interval's requests
+struct PpDma {
+    const char* img;             // contiguous-block weight image (k_wide_prep_pp)
+    int nchunk;                  // hidden chunks of 128 per half step of the image
+    int nb;                      // weight pieces of this wave per interval: 5 (waves 0, 1 of a half) or 4
+    uint32_t voff;               // wi * 1024 + 16 * lane: this lane's bytes of the wave's first piece
+    uint32_t lds;                // LDS byte address of the block's dynamic LDS
+    uint32_t lds_a;              // + 1024 * wave: this wave's piece of an A slot
+    int wi;                      // wave index within its half
+};
+
+// the weight pieces of half step j of hidden chunk c, for half hx_dst, into sub-slot (par, hx_dst): pieces wi, wi + 4, ...
+// of the 18 (a linear copy of a contiguous 18-KB block of the image)
+__device__ __forceinline__ void pp_dma_b(const PpDma& d, int j, int c, int hx_dst, int par) {
+    const char* src = d.img + (size_t)((j * d.nchunk + c) * 2 + hx_dst) * PP_BH;
+    const uint32_t dst = d.lds + PP_OFF_B + (uint32_t)(par * 2 + hx_dst) * PP_BH + 1024u * d.wi;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) glds16_so(src, d.voff + 4096u * k, dst + 4096u * k);
+    if (d.nb == 5) glds16_so(src, d.voff + 16384u, dst + 16384u);
+}
+
+__device__ __forceinline__ void pp_read(const char* lds, int aslot, int par, int hx, int a_off0, int a_off1, int b_off, float4& lo,
+                                        float4& hi, PpOps& o) {
+    const char* sa = lds + aslot * PP_A;
+    lo = *reinterpret_cast<const float4*>(sa + a_off0);
+    hi = *reinterpret_cast<const float4*>(sa + a_off1);
+    const char* sb = lds + PP_OFF_B + (par * 2 + hx) * PP_BH + b_off;
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+        for (int g = 0; g < 3; ++g)
+#pragma unroll
+            for (int pc = 0; pc < 3; ++pc)
+                o.bf[(ct * 3 + g) * 3 + pc] = *reinterpret_cast<const uint4*>(sb + (pc * 3 + g) * 2048 + ct * 1024);
+}
+__device__ __forceinline__ void pp_split(const float4& lo, const float4& hi, PpOps& o) {
+    w_split2(lo.x, lo.y, o.af[0].x, o.af[1].x, o.af[2].x);
+    w_split2(lo.z, lo.w, o.af[0].y, o.af[1].y, o.af[2].y);
+    w_split2(hi.x, hi.y, o.af[0].z, o.af[1].z, o.af[2].z);
+    w_split2(hi.z, hi.w, o.af[0].w, o.af[1].w, o.af[2].w);
+}
+__device__ __forceinline__ void pp_pin(PpOps& o) {      // (as ring_pin: the split stays in the LOAD segment that formed it)
+    asm volatile("" : "+v"(o.af[0].x), "+v"(o.af[0].y), "+v"(o.af[0].z), "+v"(o.af[0].w), "+v"(o.af[1].x), "+v"(o.af[1].y),
+                      "+v"(o.af[1].z), "+v"(o.af[1].w), "+v"(o.af[2].x), "+v"(o.af[2].y), "+v"(o.af[2].z), "+v"(o.af[2].w));
+}
+__device__ __forceinline__ void pp_mma(const PpOps& o, f32x16 (&acc)[6]) {
+#if defined(W3_NOMMA)
+    return;
+#endif
+#pragma unroll
+    for (int t = 0; t < 6; ++t) {
+        f32x16 c = acc[t];
+        c = w_mfma(o.af[2], o.bf[t * 3], c);        // smallest terms first (as wide_mma / ring_compute)
+        c = w_mfma(o.af[0], o.bf[t * 3 + 2], c);
+        c = w_mfma(o.af[1], o.bf[t * 3 + 1], c);
+        c = w_mfma(o.af[1], o.bf[t * 3], c);
+        c = w_mfma(o.af[0], o.bf[t * 3 + 1], c);
+        c = w_mfma(o.af[0], o.bf[t * 3], c);
+        acc[t] = c;
+    }
+}
+
+// one element of the cell (the expressions of gru_gate4, so that both forms round alike)
+__device__ __forceinline__ void gru_gate1(float ps_r, float pd_r, float ps_z, float pd_z, float ps_n, float pd_n, float ghr, float ghz,
+                                          float ghn, float bir, float biz, float bin_, float bhr, float bhz, float bhn, float hp,
+                                          float& o_h, float& o_r, float& o_z, float& o_n, float& o_hn) {
+    const float gir = ps_r - pd_r, giz = ps_z - pd_z, gin = ps_n - pd_n;
+    const float vr = ghr + bhr + bir, vz = ghz + bhz + biz, vhn = ghn + bhn;
+    const float orr = w_sigm(gir + vr);
+    const float ozz = w_sigm(giz + vz);
+    const float onn = w_tanh(gin + bin_ + orr * vhn);
+    o_h = (1.0f - ozz) * onn + ozz * hp;
+    o_r = orr; o_z = ozz; o_n = onn; o_hn = vhn;
+}
+
+// The epilogue of one wave, straight from its six accumulators: lane = hidden column (cl of the 32-column group ct), registers =
+// rows (w_acc_row), all three gates of an element in the same lane.  Outputs leave as 128-byte row segments (4 B per lane).
+template <int HX, bool STAGED, bool GATES>
+__device__ __forceinline__ void pp_epilogue(const WideArgs& a, const f32x16 (&acc)[6], const float* sP, const int* dsc, int hc0, int wr,
+                                            int hh, int lane) {
+    const int H = a.H;
+    const int cl = opaque(lane) & 31;
+    const int colw = hc0 + 64 * HX + cl;                           // + 32 ct
+    float bir[2], biz[2], bin_[2], bhr[2], bhz[2], bhn[2];
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+        const int c = colw + 32 * ct;
+        bir[ct] = a.b_ih[c]; biz[ct] = a.b_ih[H + c]; bin_[ct] = a.b_ih[2 * H + c];
+        bhr[ct] = a.b_hh[c]; bhz[ct] = a.b_hh[H + c]; bhn[ct] = a.b_hh[2 * H + c];
+    }
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) {
+        const int lr0 = 32 * wr + 8 * rg + 4 * hh;
+        const int4 rows4 = *reinterpret_cast<const int4*>(dsc + lr0);
+        const int4 locs4 = *reinterpret_cast<const int4*>(dsc + 128 + lr0);
+        const int rws[4] = {rows4.x, rows4.y, rows4.z, rows4.w}, lcs[4] = {locs4.x, locs4.y, locs4.z, locs4.w};
+        float hp[4][2];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct) hp[j][ct] = a.h[(size_t)rws[j] * a.ld_h + colw + 32 * ct];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int reg = 4 * rg + j;
+            const int ls = lcs[j] & 0xFFFF, ldd = lcs[j] >> 16;
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct) {
+                float s_r, s_z, s_n, d_r, d_z, d_n;
+                if constexpr (STAGED) {
+                    const float* ps = sP + ls * 384 + 64 * HX + 32 * ct + cl;
+                    const float* pd = sP + ldd * 384 + 64 * HX + 32 * ct + cl;
+                    s_r = ps[0]; s_z = ps[128]; s_n = ps[256];
+                    d_r = pd[0]; d_z = pd[128]; d_n = pd[256];
+                } else {
+                    const float* ps = a.P + (size_t)dsc[256 + ls] * a.ldp + colw + 32 * ct;
+                    const float* pd = a.P + (size_t)dsc[256 + ldd] * a.ldp + colw + 32 * ct;
+                    s_r = ps[0]; s_z = ps[H]; s_n = ps[2 * H];
+                    d_r = pd[0]; d_z = pd[H]; d_n = pd[2 * H];
+                }
+                float o_h, o_r, o_z, o_n, o_hn;
+                gru_gate1(s_r, d_r, s_z, d_z, s_n, d_n, acc[ct * 3][reg], acc[ct * 3 + 1][reg], acc[ct * 3 + 2][reg], bir[ct],
+                          biz[ct], bin_[ct], bhr[ct], bhz[ct], bhn[ct], hp[j][ct], o_h, o_r, o_z, o_n, o_hn);
+#if defined(W3_NOSTORE)
+                if (o_h + o_r + o_z + o_n + o_hn == 123.456f)
+#endif
+                {
+                    a.h_out[(size_t)rws[j] * a.ld_out + colw + 32 * ct] = o_h;
+                    if constexpr (GATES) {
+                        float* gp = a.gates + (size_t)rws[j] * H + colw + 32 * ct;
+                        __builtin_nontemporal_store(o_r, gp);
+                        __builtin_nontemporal_store(o_z, gp + a.gate_plane);
+                        __builtin_nontemporal_store(o_n, gp + 2 * a.gate_plane);
+                        __builtin_nontemporal_store(o_hn, gp + 3 * a.gate_plane);
+                    }
+                }
+            }
+        }
+    }
+}
+
+// The whole persistent loop of one half (HX = 0: X, waves 0-3; HX = 1: Y, waves 4-7).  Two instantiations instead of branches
+// on the half inside one loop: the operand registers of X live across an item boundary (loaded after X's epilogue, consumed
+// by the next item's first MMA segment), those of Y do not, and with both in one control-flow graph hipcc kept two copies
+// of the 84 operand registers alive (94 spilled registers, scratch reloads in front of the requests).
+template <int HX>
+__device__ __forceinline__ void pp_half(const WideArgs& a, const WideTiles& tl, char* const lds) {
+    const float* const sP = reinterpret_cast<const float*>(lds + PP_OFF_P);
+    const int H = a.H, nchunk = H >> 7, nsub = H >> 4;                     // hidden chunks of 128 per tile; half steps per item
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave & 3;                                               // row group of the wave
+    const int G = gridDim.x;
+    int t = blockIdx.x;
+    // ---- per-wave constants of the requests
+    PpDma d;
+    d.img = reinterpret_cast<const char*>(a.img);
+    d.nchunk = nchunk;
+    d.wi = wr;
+    d.nb = wr < 2 ? 5 : 4;
+    d.lds = lds_addr(lds);
+    d.lds_a = d.lds + 1024u * wave;
+    const uint32_t lane16 = 16u * lane;
+    d.voff = 1024u * wr + lane16;
+    // ---- fragment addresses
+    const int r = lane & 31, hh = lane >> 5;
+    const int arow = 32 * wr + r, fa = (arow >> 2) & 3;
+    const int a_off0 = arow * 64 + (((2 * hh) ^ fa) << 4), a_off1 = arow * 64 + (((2 * hh + 1) ^ fa) << 4);
+    const int b_off = r * 32 + ((hh ^ ((r >> 4) & 1)) << 4);
+    const int drow = tid >> 2, dchunk = (tid & 3) ^ ((drow >> 2) & 3);     // A piece: LDS chunk tid <- (row drow, chunk dchunk)
+    // ---- tile descriptors (padding slots -- the last tile only -- take slot 0's row and dets: they then compute and
+    //      store what slot 0 computes, byte for byte, and the epilogue needs no row guard)
+    auto desc_row = [&](int tile, int slot) {
+        const int rw = tl.t_row[(size_t)tile * 128 + slot];
+        return max(rw < 0 ? tl.t_row[(size_t)tile * 128] : rw, 0);
+    };
+    auto desc_loc = [&](int tile, int slot) {
+        const int rw = tl.t_row[(size_t)tile * 128 + slot];
+        return tl.t_loc[(size_t)tile * 128 + (rw < 0 ? 0 : slot)];
+    };
+    auto a_src = [&](int row) { return reinterpret_cast<const char*>(a.A + (size_t)row * a.lda + 4 * dchunk); };
+    int par_d = 0;                                                         // descriptor buffer of the current tile
+    int nd;
+    {
+        int* ds = reinterpret_cast<int*>(lds + PP_OFF_D);
+        const int dp0 = tl.t_dptr[t];
+        nd = tl.t_dptr[t + 1] - dp0;
+        if (tid < 128) { ds[tid] = desc_row(t, tid); ds[128 + tid] = desc_loc(t, tid); }
+        if (tid < 256) ds[256 + tid] = tid < nd ? tl.t_dets[dp0 + tid] : 0;
+    }
+    const char* pa = a_src(desc_row(t, drow));
+    // ---- the first item's head, as the tail of a previous item would have requested it
+    if (HX == 0) {
+        pp_dma_b(d, 0, 0, 1, 0);
+        pp_dma_b(d, 1, 0, 1, 1);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) glds16(pa + (size_t)j * 64, d.lds_a + (uint32_t)j * PP_A);
+    } else {
+        pp_dma_b(d, 0, 0, 0, 0);
+        pp_dma_b(d, 1, 0, 0, 1);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) glds16(pa + (size_t)j * 64, d.lds_a + (uint32_t)j * PP_A);
+    }
+    pp_wait_barrier<0>();
+    PpOps o;
+    float4 lo, hi;
+    if (HX == 0) {
+        pp_read(lds, 0, 0, 0, a_off0, a_off1, b_off, lo, hi, o);
+        pp_split(lo, hi, o);
+        pp_pin(o);
+    }
+    pp_barrier();
+    int bx = 0;
+    for (;;) {
+        const int hc0 = bx << 7;
+        const bool last_chunk = bx + 1 == nchunk;
+        const bool more_tiles = t + G < tl.T;
+        const bool more = !last_chunk || more_tiles;
+        // the item after this one (its first steps are requested by this item's last ones); none: this item again, unread
+        const int bx_n = more ? (last_chunk ? 0 : bx + 1) : bx;
+        const int* const dsc = reinterpret_cast<const int*>(lds + PP_OFF_D + par_d * PP_DESC);
+        const bool staged = nd <= PP_NDMAX;
+        const int np_need = staged ? (nd * 96 + 63) >> 6 : 0;             // 1-KB pieces of the tile's P rows (this chunk's columns)
+        int a_row_next = 0;
+        if (last_chunk && more_tiles) a_row_next = desc_row(t + G, drow);  // (needed by the last four steps' A requests)
+        const char* pa_n = pa;
+        f32x16 acc[6];
+#pragma unroll
+        for (int j = 0; j < 6; ++j)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[j][q] = 0.f;
+        // the staged-P piece of LOAD segment `seg` (0 .. 2 nsub - 1 in time order): piece 4 seg + wi, or the filler
+        auto dma_p = [&](int seg) {
+            const int piece = 4 * seg + d.wi;
+            if (piece < np_need && seg <= 2 * nsub - 3) {
+                const int idx = piece * 64 + (int)opaque(lane);
+                const int rw = min(idx / 96, nd - 1), cc = idx % 96;
+                glds16(a.P + (size_t)dsc[256 + rw] * a.ldp + (cc >> 5) * H + hc0 + 4 * (cc & 31), d.lds + PP_OFF_P + 1024u * piece);
+            } else {
+                glds16(d.img + lane16, d.lds + PP_OFF_X);
+            }
+        };
+        // One half step p.  X: MMA(p) | LOAD(p + 1): requests weights(p + 2) of half Y, A rows 0-63 of step p + 4, reads slot
+        // p + 1.  Y: LOAD(p): requests weights(p + 2) of half X, A rows 64-127 of step p + 3, reads slot p | MMA(p).
+        // U = p & 3 is a compile-time constant (slots).  Steps past the item's end are the next item's first ones.
+        // READ = false: X's last step of an item -- the requests of the interval, but the reads of the next item's step 0 wait
+        // until X's epilogue is through (its operand registers would otherwise be alive across the epilogue).
+#define PP_STEP(U, p, PA_, CH_, JB_, JA_, READ)                                                                    \
+        do {                                                                                                       \
+            if (HX == 0) {                                                                                         \
+                __builtin_amdgcn_sched_barrier(0);                                                                 \
+                pp_mma(o, acc);                                                                                    \
+                __builtin_amdgcn_sched_barrier(0);                                                                 \
+                pp_barrier();                                                                                      \
+                pp_dma_b(d, (JB_), (CH_), 1, (U) & 1);                                                             \
+                glds16((PA_) + (size_t)(JA_) * 64, d.lds_a + (uint32_t)((U) & 3) * PP_A);                          \
+                dma_p(2 * (p) + 1);                                                                                \
+                if (READ) {                                                                                        \
+                    pp_read(lds, ((U) + 1) & 3, ((U) + 1) & 1, 0, a_off0, a_off1, b_off, lo, hi, o);               \
+                    pp_split(lo, hi, o);                                                                           \
+                    pp_pin(o);                                                                                     \
+                }                                                                                                  \
+                if (d.nb == 5) pp_wait_barrier<7>(); else pp_wait_barrier<6>();                                    \
+            } else {                                                                                               \
+                pp_dma_b(d, (JB_), (CH_), 0, (U) & 1);                                                             \
+                glds16((PA_) + (size_t)(JA_) * 64, d.lds_a + (uint32_t)(((U) + 3) & 3) * PP_A);                    \
+                dma_p(2 * (p));                                                                                    \
+                pp_read(lds, (U) & 3, (U) & 1, 1, a_off0, a_off1, b_off, lo, hi, o);                               \
+                pp_split(lo, hi, o);                                                                               \
+                pp_pin(o);                                                                                         \
+                if (d.nb == 5) pp_wait_barrier<7>(); else pp_wait_barrier<6>();                                    \
+                __builtin_amdgcn_sched_barrier(0);                                                                 \
+                pp_mma(o, acc);                                                                                    \
+                __builtin_amdgcn_sched_barrier(0);                                                                 \
+                pp_barrier();                                                                                      \
+            }                                                                                                      \
+        } while (0)
+        constexpr int DA = HX == 0 ? 4 : 3;                               // X requests A rows of step p + 4, Y of step p + 3
+        int p = 0;
+        for (; p + 4 < nsub; p += 4) {
+            PP_STEP(0, p, pa, bx, p + 2, p + DA, true);
+            PP_STEP(1, p + 1, pa, bx, p + 3, p + 1 + DA, true);
+            PP_STEP(2, p + 2, pa, bx, p + 4, p + 2 + DA, true);
+            PP_STEP(3, p + 3, pa, bx, p + 5, p + 3 + DA, true);
+        }
+        // p = nsub - 4: the last four steps; requests past the item's end are the next item's
+        if (last_chunk && more_tiles) pa_n = a_src(a_row_next);
+        if (HX == 0) {
+            PP_STEP(0, p, pa_n, bx, p + 2, 0, true);
+            PP_STEP(1, p + 1, pa_n, bx, p + 3, 1, true);
+            PP_STEP(2, p + 2, pa_n, bx_n, 0, 2, true);
+            PP_STEP(3, p + 3, pa_n, bx_n, 1, 3, false);
+        } else {
+            PP_STEP(0, p, pa, bx, p + 2, p + 3, true);
+            PP_STEP(1, p + 1, pa_n, bx, p + 3, 0, true);
+            PP_STEP(2, p + 2, pa_n, bx_n, 0, 1, true);
+            PP_STEP(3, p + 3, pa_n, bx_n, 1, 2, true);
+        }
+#undef PP_STEP
+        // ---- the next tile's descriptor: requested here, written into the OTHER buffer behind the epilogue (nothing reads
+        //      that buffer before the barrier below)
+        int d_row = 0, d_loc = 0, d_det = 0, nd_next = nd;
+        if (last_chunk && more_tiles) {
+            const int tn = t + G;
+            const int dp0 = tl.t_dptr[tn];
+            nd_next = tl.t_dptr[tn + 1] - dp0;
+            if (tid < 128) { d_row = desc_row(tn, tid); d_loc = desc_loc(tn, tid); }
+            if (tid < 256 && tid < nd_next) d_det = tl.t_dets[dp0 + tid];
+        }
+        // ---- epilogue, from the accumulators (staged P rows or through the tile's det list; with / without the gate planes:
+        //      compile-time forms -- a pointer that may be LDS or global becomes a flat load, which waits for everything)
+#if !defined(W3_NOEPI)
+        if (staged) {
+            if (a.gates) pp_epilogue<HX, true, true>(a, acc, sP, dsc, hc0, wr, hh, lane);
+            else pp_epilogue<HX, true, false>(a, acc, sP, dsc, hc0, wr, hh, lane);
+        } else {
+            if (a.gates) pp_epilogue<HX, false, true>(a, acc, sP, dsc, hc0, wr, hh, lane);
+            else pp_epilogue<HX, false, false>(a, acc, sP, dsc, hc0, wr, hh, lane);
+        }
+#endif
+        if (!more) break;
+        if (last_chunk) {
+            int* ds = reinterpret_cast<int*>(lds + PP_OFF_D + (par_d ^ 1) * PP_DESC);
+            if (tid < 128) { ds[tid] = d_row; ds[128 + tid] = d_loc; }
+            if (tid < 256) ds[256 + tid] = d_det;
+        }
+        if (HX == 0) {                                                     // X: the next item's step 0 (slot 0, parity 0), beside Y's epilogue
+            pp_read(lds, 0, 0, 0, a_off0, a_off1, b_off, lo, hi, o);
+            pp_split(lo, hi, o);
+            pp_pin(o);
+        }
+        pp_barrier();                                                      // every wave is done with sP and the descriptor
+        if (last_chunk) {
+            t += G;
+            pa = pa_n;
+            par_d ^= 1;
+            nd = __builtin_amdgcn_readfirstlane(nd_next);
+            bx = 0;
+        } else {
+            ++bx;
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                       // (the unread re-requests of the last item must land before the LDS is handed on)
+}
+
+__global__ __launch_bounds__(512) void k_wide_gru_fwd_pp(WideArgs a, WideTiles tl) {
+    extern __shared__ __attribute__((aligned(16))) uint16_t w_dyn[];
+    if ((int)blockIdx.x >= tl.T) return;
+    if (__builtin_amdgcn_readfirstlane(threadIdx.x >> 8) == 0) pp_half<0>(a, tl, reinterpret_cast<char*>(w_dyn));
+    else pp_half<1>(a, tl, reinterpret_cast<char*>(w_dyn));
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -1781,7 +2208,8 @@ int tmpnn_wide_supported(int H, int IN) { return (H >= 128 && H <= 1024 && H % 1
 size_t tmpnn_wide_prep_bytes(int H, int IN) {
     if (H <= 0 || IN <= 0) return 0;
     // + the half-step images of the forward and backward-data W_hh operands (k_wide_gru_fwd_ring, k_wide_gemm_ring)
-    return sizeof(uint16_t) * 3 * ((size_t)H * 3 * H + (size_t)IN * 3 * H + (size_t)3 * H * IN + (size_t)3 * H * H + 2 * (size_t)H * 3 * H);
+    // + the contiguous-block image of the forward W_hh operand (k_wide_gru_fwd_pp)
+    return sizeof(uint16_t) * 3 * ((size_t)H * 3 * H + (size_t)IN * 3 * H + (size_t)3 * H * IN + (size_t)3 * H * H + 3 * (size_t)H * 3 * H);
 }
 
 int tmpnn_wide_prepare(const float* w_ih, const float* w_hh, int IN, int H, void* prep, tmpnn_stream stream) {
@@ -1800,6 +2228,7 @@ int tmpnn_wide_prepare(const float* w_ih, const float* w_hh, int IN, int H, void
     uint16_t* f_hh16 = b_hh + (size_t)3 * 3 * H * H;
     hipLaunchKernelGGL(k_wide_prep16, dim3(g1), dim3(256), 0, st, w_hh, H, H, 3 * H, 1, f_hh16);
     hipLaunchKernelGGL(k_wide_prep16, dim3(g1), dim3(256), 0, st, w_hh, H, 3 * H, H, 0, f_hh16 + (size_t)3 * H * 3 * H);
+    hipLaunchKernelGGL(k_wide_prep_pp, dim3(g1), dim3(256), 0, st, w_hh, H, H, f_hh16 + (size_t)2 * 3 * H * 3 * H);
     return check_launch("wide_prepare");
 }
 
@@ -1870,8 +2299,18 @@ int tmpnn_wide_gru_fwd_tiled(const void* prep, const int32_t* det_rows, int Dn, 
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     const int grid = tiles->T < cus ? tiles->T : cus;          // one persistent block per CU (LDS)
     a.img = f_hh + (size_t)3 * (3 * H * H + 3 * H * H + 3 * H * H + 3 * H * H);      // the half-step image (fifth of prep)
-    TM_SHM_ONCE(k_wide_gru_fwd_ring, W_RING_SHM);
-    hipLaunchKernelGGL(k_wide_gru_fwd_ring, dim3(grid), dim3(512), W_RING_SHM, st, a, tl);
+    const uint16_t* img_pp = a.img + (size_t)2 * 3 * H * 3 * H;                       // the contiguous-block image (seventh)
+    // default since round 5: the opposite-phase form on 128 x 384 items (k_wide_gru_fwd_pp); TMPNN_WIDE_FWD_RING=1 keeps the
+    // ring form of round 3 (same results bit for bit) for A/B runs
+    static const bool ring_form = [] { const char* e = getenv("TMPNN_WIDE_FWD_RING"); return e && e[0] == '1'; }();
+    if (ring_form) {
+        TM_SHM_ONCE(k_wide_gru_fwd_ring, W_RING_SHM);
+        hipLaunchKernelGGL(k_wide_gru_fwd_ring, dim3(grid), dim3(512), W_RING_SHM, st, a, tl);
+    } else {
+        a.img = img_pp;
+        TM_SHM_ONCE(k_wide_gru_fwd_pp, W_PP_SHM);
+        hipLaunchKernelGGL(k_wide_gru_fwd_pp, dim3(grid), dim3(512), W_PP_SHM, st, a, tl);
+    }
     return check_launch("wide_gru_fwd_tiled");
 }
 
