@@ -885,7 +885,21 @@ static constexpr int PP_OFF_P = PP_OFF_B + 4 * PP_BH;                 // staged 
 static constexpr int PP_OFF_D = PP_OFF_P + PP_NDMAX * 384 * 4;        // tile descriptors, double buffered: [row 128][loc 128][det 256]
 static constexpr int PP_DESC = (128 + 128 + 256) * 4;
 static constexpr int PP_OFF_X = PP_OFF_D + 2 * PP_DESC;               // 1 KB nobody reads: target of the filler piece
+#if defined(W3_TIMELINE)       // (profiling build: s_memtime stamps of block 0's second item, 32 per wave; tools/wide_pp_timeline.py)
+__device__ uint64_t g_pp_timeline[256];
+static constexpr int PP_OFF_T = PP_OFF_X + 1024;
+static constexpr size_t W_PP_SHM = PP_OFF_T + 2048;
+#define PP_STAMP(k) do { if (tl_on) { uint64_t t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory");   \
+                                      if (lane == 0 && (k) >= 0 && (k) < 32) reinterpret_cast<uint64_t*>(lds + PP_OFF_T)[wave * 32 + (k)] = t_; } } while (0)
+#else
 static constexpr size_t W_PP_SHM = PP_OFF_X + 1024;
+#define PP_STAMP(k) do { } while (0)
+#endif
+#if defined(W3_TIMELINE)
+#define PP_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+#else
+#define PP_LGKM0() do { } while (0)
+#endif
 
 struct PpOps { uint4 af[3]; uint4 bf[18]; };      // bf[(ct * 3 + gate) * 3 + piece], ct = 32-column group of the wave's 64 hidden columns
 
@@ -894,6 +908,10 @@ template <int N>
 __device__ __forceinline__ void pp_wait_barrier() {
     if constexpr (N == 7) asm volatile("s_waitcnt vmcnt(7) lgkmcnt(0)" ::: "memory");
     else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+    else if constexpr (N == 5) asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)" ::: "memory");
+    else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+    else if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");
+    else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
@@ -909,7 +927,7 @@ struct PpDma {
     const char* img;             // contiguous-block weight image (k_wide_prep_pp)
     int nchunk;                  // hidden chunks of 128 per half step of the image
     int nb;                      // weight pieces of this wave per interval: 5 (waves 0, 1 of a half) or 4
-    uint32_t voff;               // wi * 1024 + 16 * lane: this lane's bytes of the wave's first piece
+    uint32_t lane16;             // 16 * lane
     uint32_t lds;                // LDS byte address of the block's dynamic LDS
     uint32_t lds_a;              // + 1024 * wave: this wave's piece of an A slot
     int wi;                      // wave index within its half
@@ -917,12 +935,30 @@ struct PpDma {
 
 // the weight pieces of half step j of hidden chunk c, for half hx_dst, into sub-slot (par, hx_dst): pieces wi, wi + 4, ...
 // of the 18 (a linear copy of a contiguous 18-KB block of the image)
+// A wave's weight pieces are CONSECUTIVE 1-KB pieces of the sub-slot (waves 0 / 1 of a half: pieces 0-4 / 5-9, waves 2 / 3:
+// 10-13 / 14-17) and the image block is a linear copy of the sub-slot.  What a request costs is its INSTRUCTION, not its
+// bytes or its M0 write (measured with s_memtime stamps, seven requests per LOAD segment beside the partner's MFMAs: ~205
+// ticks each; the same with 4-byte pieces, with cache-hot sources, with one M0 write per group, and as plain 16-byte loads into
+// registers) -- so PP_NM of a wave's weight pieces are issued from its own MMA segment, one behind each of the first
+// accumulators' six MFMAs, where an issue costs a fraction of that.
+#ifndef PP_LOAD_PRIO
+#define PP_LOAD_PRIO 2     // s_setprio of a wave inside its LOAD segment (0 inside its MMA segment): its few requests / reads / split
+#endif                     // instructions then win the SIMD's issue arbitration against the partner's MFMA stream, which needs a slot every 32 cycles only
+__device__ __forceinline__ void pp_dma_b1(const PpDma& d, int j, int c, int hx_dst, int par, int k) {       // piece k of the wave's group
+#if defined(W3_NODMA)
+    return;
+#endif
+    const int q = (d.wi < 2 ? 5 * d.wi : 2 + 4 * d.wi) + k;
+    const void* src = uniform_ptr(d.img + (size_t)((j * d.nchunk + c) * 2 + hx_dst) * PP_BH + 1024u * q);
+    const uint32_t dst = __builtin_amdgcn_readfirstlane(d.lds + PP_OFF_B + (uint32_t)(par * 2 + hx_dst) * PP_BH + 1024u * q);
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(d.lane16), "s"(src), "s"(dst) : "memory", "m0");
+}
+// pieces [K0, 4) and the fifth where the wave has one (the part a LOAD segment issues); K0 = 0: the whole group
+template <int K0>
 __device__ __forceinline__ void pp_dma_b(const PpDma& d, int j, int c, int hx_dst, int par) {
-    const char* src = d.img + (size_t)((j * d.nchunk + c) * 2 + hx_dst) * PP_BH;
-    const uint32_t dst = d.lds + PP_OFF_B + (uint32_t)(par * 2 + hx_dst) * PP_BH + 1024u * d.wi;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) glds16_so(src, d.voff + 4096u * k, dst + 4096u * k);
-    if (d.nb == 5) glds16_so(src, d.voff + 16384u, dst + 16384u);
+    for (int k = K0; k < 4; ++k) pp_dma_b1(d, j, c, hx_dst, par, k);
+    if (d.nb == 5) pp_dma_b1(d, j, c, hx_dst, par, 4);
 }
 
 __device__ __forceinline__ void pp_read(const char* lds, int aslot, int par, int hx, int a_off0, int a_off1, int b_off, float4& lo,
@@ -939,22 +975,50 @@ __device__ __forceinline__ void pp_read(const char* lds, int aslot, int par, int
             for (int pc = 0; pc < 3; ++pc)
                 o.bf[(ct * 3 + g) * 3 + pc] = *reinterpret_cast<const uint4*>(sb + (pc * 3 + g) * 2048 + ct * 1024);
 }
+// w_split2 with its four subtractions as v_sub_f32 (inline asm): hipcc pairs them into v_pk_add_f32, and a PACKED fp32 add of the
+// LOAD wave does not run beside the partner's MFMAs (s_memtime: ~50 vector instructions of split took 700-940 ticks in the LOAD
+// segment; plain adds, converts and shifts do overlap -- profiles/r03_ubench_mfma_valu_overlap.md).  Same values bit for bit.
+__device__ __forceinline__ float pp_sub(float a, float b) {
+    float r;
+    asm("v_sub_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ void pp_split2(float x0, float x1, uint32_t& p1, uint32_t& p2, uint32_t& p3) {
+    p1 = w_pk(x0, x1);
+    float r0 = pp_sub(x0, __uint_as_float(p1 << 16)), r1 = pp_sub(x1, __uint_as_float(p1 & 0xFFFF0000u));
+    p2 = w_pk(r0, r1);
+    r0 = pp_sub(r0, __uint_as_float(p2 << 16));
+    r1 = pp_sub(r1, __uint_as_float(p2 & 0xFFFF0000u));
+    p3 = w_pk(r0, r1);
+}
 __device__ __forceinline__ void pp_split(const float4& lo, const float4& hi, PpOps& o) {
+#if defined(W3_NOSPLIT)
+    return;
+#endif
+#if defined(PP_PACKED_SPLIT)
     w_split2(lo.x, lo.y, o.af[0].x, o.af[1].x, o.af[2].x);
     w_split2(lo.z, lo.w, o.af[0].y, o.af[1].y, o.af[2].y);
     w_split2(hi.x, hi.y, o.af[0].z, o.af[1].z, o.af[2].z);
     w_split2(hi.z, hi.w, o.af[0].w, o.af[1].w, o.af[2].w);
+#else
+    pp_split2(lo.x, lo.y, o.af[0].x, o.af[1].x, o.af[2].x);
+    pp_split2(lo.z, lo.w, o.af[0].y, o.af[1].y, o.af[2].y);
+    pp_split2(hi.x, hi.y, o.af[0].z, o.af[1].z, o.af[2].z);
+    pp_split2(hi.z, hi.w, o.af[0].w, o.af[1].w, o.af[2].w);
+#endif
 }
 __device__ __forceinline__ void pp_pin(PpOps& o) {      // (as ring_pin: the split stays in the LOAD segment that formed it)
     asm volatile("" : "+v"(o.af[0].x), "+v"(o.af[0].y), "+v"(o.af[0].z), "+v"(o.af[0].w), "+v"(o.af[1].x), "+v"(o.af[1].y),
                       "+v"(o.af[1].z), "+v"(o.af[1].w), "+v"(o.af[2].x), "+v"(o.af[2].y), "+v"(o.af[2].z), "+v"(o.af[2].w));
 }
-__device__ __forceinline__ void pp_mma(const PpOps& o, f32x16 (&acc)[6]) {
-#if defined(W3_NOMMA)
-    return;
-#endif
+// The 36 MFMAs of a half step with the wave's requests of the interval woven in, one behind the six MFMAs of each
+// accumulator: its weight pieces of (half step jm, chunk cm) for half hxm (four, and the fifth where the wave has one), then
+// -- youngest, so that the counted wait of the next LOAD segment may leave it in flight -- its A piece (asrc -> adst).
+__device__ __forceinline__ void pp_mma(const PpOps& o, f32x16 (&acc)[6], const PpDma& d, int jm, int cm, int hxm, int parm, const char* asrc,
+                                       uint32_t adst) {
 #pragma unroll
     for (int t = 0; t < 6; ++t) {
+#if !defined(W3_NOMMA)
         f32x16 c = acc[t];
         c = w_mfma(o.af[2], o.bf[t * 3], c);        // smallest terms first (as wide_mma / ring_compute)
         c = w_mfma(o.af[0], o.bf[t * 3 + 2], c);
@@ -963,6 +1027,14 @@ __device__ __forceinline__ void pp_mma(const PpOps& o, f32x16 (&acc)[6]) {
         c = w_mfma(o.af[0], o.bf[t * 3 + 1], c);
         c = w_mfma(o.af[0], o.bf[t * 3], c);
         acc[t] = c;
+#endif
+        __builtin_amdgcn_sched_barrier(0);
+#if !defined(W3_NODMA)
+        if (t < 4) pp_dma_b1(d, jm, cm, hxm, parm, t);
+        else if (t == 4) { if (d.nb == 5) pp_dma_b1(d, jm, cm, hxm, parm, 4); }
+        else glds16(asrc, adst);
+#endif
+        __builtin_amdgcn_sched_barrier(0);
     }
 }
 
@@ -994,17 +1066,20 @@ __device__ __forceinline__ void pp_epilogue(const WideArgs& a, const f32x16 (&ac
         bir[ct] = a.b_ih[c]; biz[ct] = a.b_ih[H + c]; bin_[ct] = a.b_ih[2 * H + c];
         bhr[ct] = a.b_hh[c]; bhz[ct] = a.b_hh[H + c]; bhn[ct] = a.b_hh[2 * H + c];
     }
+    // Eight outputs (four rows x two column groups) per pass, STAGE BY STAGE: the element's chain (three differences, two
+    // sigmoids, a tanh, the merge: ~16 dependent vector / transcendental instructions) is latency-bound one element at a time
+    // with two waves per SIMD; eight independent chains side by side keep the issue port busy.
 #pragma unroll
     for (int rg = 0; rg < 4; ++rg) {
         const int lr0 = 32 * wr + 8 * rg + 4 * hh;
         const int4 rows4 = *reinterpret_cast<const int4*>(dsc + lr0);
         const int4 locs4 = *reinterpret_cast<const int4*>(dsc + 128 + lr0);
         const int rws[4] = {rows4.x, rows4.y, rows4.z, rows4.w}, lcs[4] = {locs4.x, locs4.y, locs4.z, locs4.w};
-        float hp[4][2];
+        float hp[8], xr[8], xz[8], xn[8], vhn[8];
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
-            for (int ct = 0; ct < 2; ++ct) hp[j][ct] = a.h[(size_t)rws[j] * a.ld_h + colw + 32 * ct];
+            for (int ct = 0; ct < 2; ++ct) hp[2 * j + ct] = a.h[(size_t)rws[j] * a.ld_h + colw + 32 * ct];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int reg = 4 * rg + j;
@@ -1023,24 +1098,44 @@ __device__ __forceinline__ void pp_epilogue(const WideArgs& a, const f32x16 (&ac
                     s_r = ps[0]; s_z = ps[H]; s_n = ps[2 * H];
                     d_r = pd[0]; d_z = pd[H]; d_n = pd[2 * H];
                 }
-                float o_h, o_r, o_z, o_n, o_hn;
-                gru_gate1(s_r, d_r, s_z, d_z, s_n, d_n, acc[ct * 3][reg], acc[ct * 3 + 1][reg], acc[ct * 3 + 2][reg], bir[ct],
-                          biz[ct], bin_[ct], bhr[ct], bhz[ct], bhn[ct], hp[j][ct], o_h, o_r, o_z, o_n, o_hn);
+                // (the expressions of gru_gate4, so that both forms round alike)
+                const int e = 2 * j + ct;
+                const float gir = s_r - d_r, giz = s_z - d_z, gin = s_n - d_n;
+                const float vr = acc[ct * 3][reg] + bhr[ct] + bir[ct], vz = acc[ct * 3 + 1][reg] + bhz[ct] + biz[ct];
+                vhn[e] = acc[ct * 3 + 2][reg] + bhn[ct];
+                xr[e] = gir + vr;
+                xz[e] = giz + vz;
+                xn[e] = gin + bin_[ct];
+            }
+        }
+        float orr[8], ozz[8], onn[8], oh[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) orr[e] = w_sigm(xr[e]);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) ozz[e] = w_sigm(xz[e]);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) onn[e] = w_tanh(xn[e] + orr[e] * vhn[e]);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) oh[e] = (1.0f - ozz[e]) * onn[e] + ozz[e] * hp[e];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct) {
+                const int e = 2 * j + ct;
 #if defined(W3_NOSTORE)
-                if (o_h + o_r + o_z + o_n + o_hn == 123.456f)
+                if (oh[e] + orr[e] + ozz[e] + onn[e] + vhn[e] == 123.456f)
 #endif
                 {
-                    a.h_out[(size_t)rws[j] * a.ld_out + colw + 32 * ct] = o_h;
+                    a.h_out[(size_t)rws[j] * a.ld_out + colw + 32 * ct] = oh[e];
                     if constexpr (GATES) {
                         float* gp = a.gates + (size_t)rws[j] * H + colw + 32 * ct;
-                        __builtin_nontemporal_store(o_r, gp);
-                        __builtin_nontemporal_store(o_z, gp + a.gate_plane);
-                        __builtin_nontemporal_store(o_n, gp + 2 * a.gate_plane);
-                        __builtin_nontemporal_store(o_hn, gp + 3 * a.gate_plane);
+                        __builtin_nontemporal_store(orr[e], gp);
+                        __builtin_nontemporal_store(ozz[e], gp + a.gate_plane);
+                        __builtin_nontemporal_store(onn[e], gp + 2 * a.gate_plane);
+                        __builtin_nontemporal_store(vhn[e], gp + 3 * a.gate_plane);
                     }
                 }
             }
-        }
     }
 }
 
@@ -1065,7 +1160,7 @@ __device__ __forceinline__ void pp_half(const WideArgs& a, const WideTiles& tl, 
     d.lds = lds_addr(lds);
     d.lds_a = d.lds + 1024u * wave;
     const uint32_t lane16 = 16u * lane;
-    d.voff = 1024u * wr + lane16;
+    d.lane16 = lane16;
     // ---- fragment addresses
     const int r = lane & 31, hh = lane >> 5;
     const int arow = 32 * wr + r, fa = (arow >> 2) & 3;
@@ -1093,18 +1188,16 @@ __device__ __forceinline__ void pp_half(const WideArgs& a, const WideTiles& tl, 
         if (tid < 256) ds[256 + tid] = tid < nd ? tl.t_dets[dp0 + tid] : 0;
     }
     const char* pa = a_src(desc_row(t, drow));
-    // ---- the first item's head, as the tail of a previous item would have requested it
+    // ---- the first item's head, as the tail of a previous item would have requested it: A steps 0-2, the weights of step 0
+    //      for both halves and of step 1 for X
     if (HX == 0) {
-        pp_dma_b(d, 0, 0, 1, 0);
-        pp_dma_b(d, 1, 0, 1, 1);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) glds16(pa + (size_t)j * 64, d.lds_a + (uint32_t)j * PP_A);
+        pp_dma_b<0>(d, 0, 0, 1, 0);
     } else {
-        pp_dma_b(d, 0, 0, 0, 0);
-        pp_dma_b(d, 1, 0, 0, 1);
-#pragma unroll
-        for (int j = 0; j < 3; ++j) glds16(pa + (size_t)j * 64, d.lds_a + (uint32_t)j * PP_A);
+        pp_dma_b<0>(d, 0, 0, 0, 0);
+        pp_dma_b<0>(d, 1, 0, 0, 1);
     }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) glds16(pa + (size_t)j * 64, d.lds_a + (uint32_t)j * PP_A);
     pp_wait_barrier<0>();
     PpOps o;
     float4 lo, hi;
@@ -1115,6 +1208,9 @@ __device__ __forceinline__ void pp_half(const WideArgs& a, const WideTiles& tl, 
     }
     pp_barrier();
     int bx = 0;
+#if defined(W3_TIMELINE)
+    int item_no = 0;
+#endif
     for (;;) {
         const int hc0 = bx << 7;
         const bool last_chunk = bx + 1 == nchunk;
@@ -1128,6 +1224,9 @@ __device__ __forceinline__ void pp_half(const WideArgs& a, const WideTiles& tl, 
         int a_row_next = 0;
         if (last_chunk && more_tiles) a_row_next = desc_row(t + G, drow);  // (needed by the last four steps' A requests)
         const char* pa_n = pa;
+#if defined(W3_TIMELINE)
+        const bool tl_on = blockIdx.x == 0 && item_no == 1;
+#endif
         f32x16 acc[6];
 #pragma unroll
         for (int j = 0; j < 6; ++j)
@@ -1149,51 +1248,77 @@ __device__ __forceinline__ void pp_half(const WideArgs& a, const WideTiles& tl, 
         // U = p & 3 is a compile-time constant (slots).  Steps past the item's end are the next item's first ones.
         // READ = false: X's last step of an item -- the requests of the interval, but the reads of the next item's step 0 wait
         // until X's epilogue is through (its operand registers would otherwise be alive across the epilogue).
+#if defined(W3_NODMA)
+#define PP_REQ(x) asm volatile("" ::: "memory")
+#else
+#define PP_REQ(x) x
+#endif
+        // A step's requests: the weight pieces and the A piece ride in the wave's MMA segment (pp_mma), the staged-P piece in
+        // its LOAD segment.  X, MMA(p): weights of step p + 1 for half Y (JB_, CH_), A rows 0-63 of step p + 3 (JA_);
+        // Y, MMA(p): weights of step p + 2 for half X, A rows 64-127 of step p + 3.  LOAD segments: the reads are requested
+        // FIRST (their latency runs under the request's issue), then the piece, then the split; the counted wait leaves the
+        // segment's piece and the preceding MMA segment's A piece in flight.
 #define PP_STEP(U, p, PA_, CH_, JB_, JA_, READ)                                                                    \
         do {                                                                                                       \
+            const int sk_ = ((p) - 4) * 6;                                                                         \
             if (HX == 0) {                                                                                         \
+                PP_STAMP(sk_);                                                                                     \
                 __builtin_amdgcn_sched_barrier(0);                                                                 \
-                pp_mma(o, acc);                                                                                    \
+                pp_mma(o, acc, d, (JB_), (CH_), 1, ((U) + 1) & 1, (PA_) + (size_t)(JA_) * 64,                      \
+                       d.lds_a + (uint32_t)(((U) + 3) & 3) * PP_A);                                                \
                 __builtin_amdgcn_sched_barrier(0);                                                                 \
+                PP_STAMP(sk_ + 1);                                                                                 \
                 pp_barrier();                                                                                      \
-                pp_dma_b(d, (JB_), (CH_), 1, (U) & 1);                                                             \
-                glds16((PA_) + (size_t)(JA_) * 64, d.lds_a + (uint32_t)((U) & 3) * PP_A);                          \
-                dma_p(2 * (p) + 1);                                                                                \
+                PP_STAMP(sk_ + 2);                                                                                 \
+                if (PP_LOAD_PRIO) __builtin_amdgcn_s_setprio(PP_LOAD_PRIO);                                        \
+                if (READ) pp_read(lds, ((U) + 1) & 3, ((U) + 1) & 1, 0, a_off0, a_off1, b_off, lo, hi, o);         \
+                PP_REQ(dma_p(2 * (p) + 1));                                                                        \
+                PP_STAMP(sk_ + 3);                                                                                 \
+                PP_LGKM0();                                                                                        \
+                PP_STAMP(sk_ + 4);                                                                                 \
                 if (READ) {                                                                                        \
-                    pp_read(lds, ((U) + 1) & 3, ((U) + 1) & 1, 0, a_off0, a_off1, b_off, lo, hi, o);               \
                     pp_split(lo, hi, o);                                                                           \
                     pp_pin(o);                                                                                     \
                 }                                                                                                  \
-                if (d.nb == 5) pp_wait_barrier<7>(); else pp_wait_barrier<6>();                                    \
+                PP_STAMP(sk_ + 5);                                                                                 \
+                if (PP_LOAD_PRIO) __builtin_amdgcn_s_setprio(0);                                                   \
+                pp_wait_barrier<2>();                                                                              \
             } else {                                                                                               \
-                pp_dma_b(d, (JB_), (CH_), 0, (U) & 1);                                                             \
-                glds16((PA_) + (size_t)(JA_) * 64, d.lds_a + (uint32_t)(((U) + 3) & 3) * PP_A);                    \
-                dma_p(2 * (p));                                                                                    \
+                PP_STAMP(sk_);                                                                                     \
+                if (PP_LOAD_PRIO) __builtin_amdgcn_s_setprio(PP_LOAD_PRIO);                                        \
                 pp_read(lds, (U) & 3, (U) & 1, 1, a_off0, a_off1, b_off, lo, hi, o);                               \
+                PP_REQ(dma_p(2 * (p)));                                                                            \
+                PP_STAMP(sk_ + 1);                                                                                 \
                 pp_split(lo, hi, o);                                                                               \
                 pp_pin(o);                                                                                         \
-                if (d.nb == 5) pp_wait_barrier<7>(); else pp_wait_barrier<6>();                                    \
+                PP_STAMP(sk_ + 2);                                                                                 \
+                if (PP_LOAD_PRIO) __builtin_amdgcn_s_setprio(0);                                                   \
+                pp_wait_barrier<2>();                                                                              \
+                PP_STAMP(sk_ + 3);                                                                                 \
                 __builtin_amdgcn_sched_barrier(0);                                                                 \
-                pp_mma(o, acc);                                                                                    \
+                pp_mma(o, acc, d, (JB_), (CH_), 0, (U) & 1, (PA_) + (size_t)(JA_) * 64,                            \
+                       d.lds_a + (uint32_t)(((U) + 3) & 3) * PP_A);                                                \
                 __builtin_amdgcn_sched_barrier(0);                                                                 \
+                PP_STAMP(sk_ + 4);                                                                                 \
                 pp_barrier();                                                                                      \
+                PP_STAMP(sk_ + 5);                                                                                 \
             }                                                                                                      \
         } while (0)
-        constexpr int DA = HX == 0 ? 4 : 3;                               // X requests A rows of step p + 4, Y of step p + 3
+        constexpr int DB = HX == 0 ? 1 : 2;                               // MMA(p) carries the weights of step p + DB (X: for Y's LOAD(p + 1); Y: for X's LOAD(p + 2))
         int p = 0;
         for (; p + 4 < nsub; p += 4) {
-            PP_STEP(0, p, pa, bx, p + 2, p + DA, true);
-            PP_STEP(1, p + 1, pa, bx, p + 3, p + 1 + DA, true);
-            PP_STEP(2, p + 2, pa, bx, p + 4, p + 2 + DA, true);
-            PP_STEP(3, p + 3, pa, bx, p + 5, p + 3 + DA, true);
+            PP_STEP(0, p, pa, bx, p + DB, p + 3, true);
+            PP_STEP(1, p + 1, pa, bx, p + 1 + DB, p + 4, true);
+            PP_STEP(2, p + 2, pa, bx, p + 2 + DB, p + 5, true);
+            PP_STEP(3, p + 3, pa, bx, p + 3 + DB, p + 6, true);
         }
         // p = nsub - 4: the last four steps; requests past the item's end are the next item's
         if (last_chunk && more_tiles) pa_n = a_src(a_row_next);
         if (HX == 0) {
-            PP_STEP(0, p, pa_n, bx, p + 2, 0, true);
-            PP_STEP(1, p + 1, pa_n, bx, p + 3, 1, true);
-            PP_STEP(2, p + 2, pa_n, bx_n, 0, 2, true);
-            PP_STEP(3, p + 3, pa_n, bx_n, 1, 3, false);
+            PP_STEP(0, p, pa, bx, p + 1, p + 3, true);
+            PP_STEP(1, p + 1, pa_n, bx, p + 2, 0, true);
+            PP_STEP(2, p + 2, pa_n, bx, p + 3, 1, true);
+            PP_STEP(3, p + 3, pa_n, bx_n, 0, 2, false);
         } else {
             PP_STEP(0, p, pa, bx, p + 2, p + 3, true);
             PP_STEP(1, p + 1, pa_n, bx, p + 3, 0, true);
@@ -1201,6 +1326,7 @@ __device__ __forceinline__ void pp_half(const WideArgs& a, const WideTiles& tl, 
             PP_STEP(3, p + 3, pa_n, bx_n, 1, 2, true);
         }
 #undef PP_STEP
+#undef PP_REQ
         // ---- the next tile's descriptor: requested here, written into the OTHER buffer behind the epilogue (nothing reads
         //      that buffer before the barrier below)
         int d_row = 0, d_loc = 0, d_det = 0, nd_next = nd;
@@ -1213,7 +1339,16 @@ __device__ __forceinline__ void pp_half(const WideArgs& a, const WideTiles& tl, 
         }
         // ---- epilogue, from the accumulators (staged P rows or through the tile's det list; with / without the gate planes:
         //      compile-time forms -- a pointer that may be LDS or global becomes a flat load, which waits for everything)
-#if !defined(W3_NOEPI)
+#if defined(W3_NOEPI)
+        {                                  // (timing build: the accumulators must stay alive or the MFMAs are removed with them)
+            float sm = 0.f;
+#pragma unroll
+            for (int j = 0; j < 6; ++j)
+#pragma unroll
+                for (int q = 0; q < 16; ++q) sm += acc[j][q];
+            a.h_out[(size_t)dsc[32 * wr] * a.ld_out + hc0 + (lane & 63)] = sm;
+        }
+#else
         if (staged) {
             if (a.gates) pp_epilogue<HX, true, true>(a, acc, sP, dsc, hc0, wr, hh, lane);
             else pp_epilogue<HX, true, false>(a, acc, sP, dsc, hc0, wr, hh, lane);
@@ -1221,6 +1356,14 @@ __device__ __forceinline__ void pp_half(const WideArgs& a, const WideTiles& tl, 
             if (a.gates) pp_epilogue<HX, false, true>(a, acc, sP, dsc, hc0, wr, hh, lane);
             else pp_epilogue<HX, false, false>(a, acc, sP, dsc, hc0, wr, hh, lane);
         }
+#endif
+#if defined(W3_TIMELINE)
+        PP_STAMP(30);
+        if (tl_on) {
+            __syncthreads();
+            if (tid < 256) g_pp_timeline[tid] = reinterpret_cast<const uint64_t*>(lds + PP_OFF_T)[tid];
+        }
+        ++item_no;
 #endif
         if (!more) break;
         if (last_chunk) {
@@ -2201,6 +2344,11 @@ using namespace tmpnn;
 
 extern "C" {
 
+#if defined(W3_TIMELINE)
+int tmpnn_debug_pp_timeline(uint64_t* host_out) {     // (profiling build only: synchronises)
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_pp_timeline), sizeof(uint64_t) * 256) == hipSuccess ? 0 : -1;
+}
+#endif
 int tmpnn_wide_supported(int H, int IN) { return (H >= 128 && H <= 1024 && H % 128 == 0 && IN == H) ? 1 : 0; }
 
 // bytes of the four weight images of one cell: forward hh (K = H, N = 3H), forward ih (K = IN, N = 3H),
