@@ -28,6 +28,7 @@ assert raw.tmpnn_debug_pp_timeline(buf) == 0
 t = np.array(buf, dtype=np.int64).reshape(8, 32)
 t0 = t[:, :31].min()
 names = {0: ['mma', 'bar', 'reads+req issued', 'lgkm wait', 'split'], 1: ['reads+req issued', 'split', 'wait+bar', 'mma', 'bar']}
+print('epilogue ticks per wave:', [int(t[w, 30] - t[w, 31]) for w in range(8)], ' epilogue start offsets:', [int(t[w, 31] - t[:, 31].min()) for w in range(8)])
 for w in range(8):
     hx = w >> 2
     print(f'wave {w} ({"XY"[hx]}): first stamp +{t[w, 0] - t0}')

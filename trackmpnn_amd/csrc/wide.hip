@@ -1339,6 +1339,7 @@ __device__ __forceinline__ void pp_half(const WideArgs& a, const WideTiles& tl, 
         }
         // ---- epilogue, from the accumulators (staged P rows or through the tile's det list; with / without the gate planes:
         //      compile-time forms -- a pointer that may be LDS or global becomes a flat load, which waits for everything)
+        PP_STAMP(31);
 #if defined(W3_NOEPI)
         {                                  // (timing build: the accumulators must stay alive or the MFMAs are removed with them)
             float sm = 0.f;
