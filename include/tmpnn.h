@@ -605,6 +605,14 @@ int tmpnn_track_load(int N, int ND, const int32_t* packed, const tmpnn_track_row
  * and the active set of timestep t -> active[], small[0]. */
 int tmpnn_track_select(const tmpnn_dgraph* g, const tmpnn_track_rows* rows, const float* score, int mode, int t,
                        int associate, int32_t* active, int32_t* small, tmpnn_stream stream);
+/* The same with a scratch for associate = 2: the associations by OPTIMAL ASSIGNMENT per timestep (reference hungarian(),
+ * utils/graph.py:33-93 -- scipy's linear_sum_assignment restated on the device, ties included; README.md:67,122 recommends
+ * --hungarian).  Inference graphs (mode 1) of <= TMPNN_DG_MAX_ROWS rows; a timestep's problem may have up to
+ * tmpnn_track_hungarian_max_dets() rows / columns; cost matrices beyond 4096 entries use `ws` (fp32 [rows x columns]).  A problem
+ * that fits neither sets bit 1 (value 2) of small[1] and is left unassociated: the caller then matches on the host instead. */
+int tmpnn_track_select_ws(const tmpnn_dgraph* g, const tmpnn_track_rows* rows, const float* score, int mode, int t,
+                          int associate, int32_t* active, int32_t* small, void* ws, size_t ws_bytes, tmpnn_stream stream);
+int tmpnn_track_hungarian_max_dets(void);
 /* update_graph, second half (:283-332): the block of timestep t appended behind row N (tmpnn_track_append), the features
  * of the new rows written (feats [A*D + D][ld_f]: zeros on edge rows, X[new_ids[j]][0:F] on det rows; NULL: not written)
  * and the index form of the grown graph derived into g_new (bound for N + A*D + D rows; ws / ws_ints as
@@ -612,8 +620,9 @@ int tmpnn_track_select(const tmpnn_dgraph* g, const tmpnn_track_rows* rows, cons
 int tmpnn_track_extend(int N, int A, int D, const int32_t* active, const int32_t* new_ids, int t, const int32_t* track,
                        const tmpnn_track_rows* rows, const float* X, int ld_x, int F, float* feats, int ld_f,
                        const tmpnn_dgraph* g_new, void* ws, size_t ws_ints, tmpnn_stream stream);
-/* decode_tracks (:431-520): associations from the scores (associate = 0: rows->assoc holds them, e.g. from the Hungarian
- * matching), track finalisation, row deletion into rows_out, the state rows and scores compacted (h_new [N][ld_hn],
+/* decode_tracks (:431-520): associations from the scores (associate = 1: the greedy rule; 2: optimal assignment per timestep as
+ * tmpnn_track_select_ws, graphs of <= TMPNN_DG_MAX_ROWS rows, its cost scratch = fin_ws / fin_ws_bytes, overflow in bit 1 of
+ * small[1]; 0: rows->assoc holds them already, e.g. from a matching on the host), track finalisation, row deletion into rows_out, the state rows and scores compacted (h_new [N][ld_hn],
  * s_new [N]; small[0] / small[2] = kept rows / kept det rows).  next_t >= 0: also the active set of timestep next_t on
  * the compacted rows by the inference rule (their associations carry over: deletion removes no future edge of a kept det)
  * -> active[], small[3]; the caller then reads small once per timestep instead of twice. */

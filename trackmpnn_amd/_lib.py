@@ -193,6 +193,8 @@ _SIGNATURES = {
     'tmpnn_track_load': (c_int, [c_int, c_int, c_void_p, _TRP, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, _DGP, c_void_p,
                                  c_size_t, c_void_p]),
     'tmpnn_track_select': (c_int, [_DGP, _TRP, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    'tmpnn_track_select_ws': (c_int, [_DGP, _TRP, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    'tmpnn_track_hungarian_max_dets': (c_int, []),
     'tmpnn_track_extend': (c_int, [c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, _TRP, c_void_p, c_int, c_int,
                                    c_void_p, c_int, _DGP, c_void_p, c_size_t, c_void_p]),
     'tmpnn_track_retire': (c_int, [_DGP, _TRP, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_size_t,

@@ -18,7 +18,7 @@
 //   tmpnn_track_finalize    :456-490                           y_out[:, 1]: the walk along the association links
 //
 // The index form (CSR etc.) is re-derived from the rows by tmpnn_graph_from_rows (csrc/graphconv.hip).  The Hungarian
-// matching stays on the host (tens of detections, scipy).  Integer work,
+// matching runs on the device too since round 5 (d_track_hungarian: scipy's algorithm restated).  Integer work,
 // HBM/latency bound, graphs of <= TMPNN_TRACK_MAX_ROWS rows: single-workgroup kernels with LDS scans.
 #include <algorithm>
 
@@ -108,6 +108,226 @@ __device__ __forceinline__ void d_track_associate(tmpnn_dgraph g, const int32_t*
 }
 __global__ __launch_bounds__(256) void k_track_associate(tmpnn_dgraph g, const int32_t* __restrict__ det_id, const uint8_t* __restrict__ labels, const float* __restrict__ score, int mode, int32_t* __restrict__ assoc, int32_t* __restrict__ status) {
     d_track_associate(g, det_id, labels, score, mode, assoc, status, (int)(blockIdx.x * 256 + threadIdx.x), (int)(gridDim.x * 256));
+}
+
+// ---- y_pred[:, 2] by optimal assignment (reference hungarian(), utils/graph.py:33-93; README: --hungarian) -----------------
+// Swept in ascending timestep t over the timesteps that edges lead into.  Rows of the problem: the dets with an edge into t
+// that are still unassociated (ascending graph row -- np.unique), columns: EVERY det of timestep t (ascending row), cost
+// 1 - score of the edge (fp32), 100 where there is none; an assignment is kept where its cost is <= 0.5.  The solver is scipy's
+// linear_sum_assignment (scipy/optimize/rectangular_lsap/rectangular_lsap.cpp: shortest augmenting paths in fp64, the matrix
+// transposed when it has more rows than columns) restated step for step, INCLUDING how it breaks ties, because which of several
+// optimal assignments comes out decides the tracks: the scan over the `remaining` columns keeps the first column of minimal
+// reduced cost unless a later one of equal cost is unassigned (then the last such), and `remaining` is filled in reverse and
+// compacted by moving its last entry into the hole.  One wave runs a problem: lane l owns columns l, l + 64, ... (reduced costs,
+// duals, path, position in `remaining` in registers), the row state lives in LDS; the scan's sequential rule is two wave
+// reductions over positions.  Problems of up to HG_MAX rows / columns; cost matrices of up to HG_LDS_COST entries in LDS, larger
+// ones in the caller's scratch.
+static constexpr int HG_MAX = 256, HG_K = HG_MAX / 64, HG_LDS_COST = 4096;
+struct HgShared {
+    double u[HG_MAX], spc[HG_MAX];
+    int col4row[HG_MAX], path[HG_MAX], rowlist[HG_MAX];
+    unsigned char SR[HG_MAX];
+    float cost[HG_LDS_COST];
+    unsigned char flag[4096];
+    short ridx[4096];
+    int wave[TK_THREADS / 64 + 1];
+    int d0, d1, tnext, nr;
+};
+__device__ __forceinline__ void hg_wave_sync() {          // LDS writes of this wave visible to its other lanes (one wave only)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+__device__ __forceinline__ double hg_wave_min(double x) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { const double y = __shfl_xor(x, off); x = y < x ? y : x; }
+    return x;
+}
+__device__ __forceinline__ int hg_wave_max(int x) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) x = max(x, __shfl_xor(x, off));
+    return x;
+}
+__device__ __forceinline__ int hg_wave_min_i(int x) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) x = min(x, __shfl_xor(x, off));
+    return x;
+}
+// rows i < nr <= nc columns; cost(i, j) = C[i * sr + j * sc]; result in S.col4row[0..nr)
+__device__ void hg_wave_solve(HgShared& S, const float* C, int sr, int sc, int nr, int nc, int lane) {
+    double v[HG_K];
+    int r4c[HG_K];
+#pragma unroll
+    for (int k = 0; k < HG_K; ++k) { v[k] = 0.0; r4c[k] = -1; }
+    for (int i = lane; i < nr; i += 64) { S.u[i] = 0.0; S.col4row[i] = -1; }
+    hg_wave_sync();
+    const int KU = (nc + 63) >> 6;                        // column groups in use
+    for (int cur = 0; cur < nr; ++cur) {
+        double spc[HG_K];
+        int path[HG_K], pos[HG_K];
+        bool alive[HG_K], scj[HG_K];
+#pragma unroll
+        for (int k = 0; k < HG_K; ++k) {
+            const int j = lane + 64 * k;
+            spc[k] = __builtin_huge_val(); path[k] = -1; pos[k] = nc - 1 - j; alive[k] = j < nc; scj[k] = false;
+        }
+        for (int i = lane; i < nr; i += 64) S.SR[i] = 0;
+        hg_wave_sync();
+        int i = cur, sink = -1, num_rem = nc;
+        double min_val = 0.0;
+        while (sink < 0 && num_rem > 0) {
+            if (lane == 0) S.SR[i] = 1;
+            const double ui = S.u[i];
+            double m = __builtin_huge_val();
+#pragma unroll
+            for (int k = 0; k < HG_K; ++k) {
+                if (k < KU && alive[k]) {
+                    const double c = (double)C[(size_t)i * sr + (size_t)(lane + 64 * k) * sc];
+                    const double r = min_val + c - ui - v[k];
+                    if (r < spc[k]) { path[k] = i; spc[k] = r; }
+                    m = spc[k] < m ? spc[k] : m;
+                }
+            }
+            m = hg_wave_min(m);
+            int best_u = -1, best_f = 0x7fffffff;
+#pragma unroll
+            for (int k = 0; k < HG_K; ++k)
+                if (k < KU && alive[k] && spc[k] == m) {
+                    if (r4c[k] == -1) best_u = max(best_u, pos[k]);
+                    best_f = min(best_f, pos[k]);
+                }
+            best_u = hg_wave_max(best_u);
+            best_f = hg_wave_min_i(best_f);
+            const int ipos = best_u >= 0 ? best_u : best_f;
+            int jsel = -1, r4sel = -2;
+#pragma unroll
+            for (int k = 0; k < HG_K; ++k)
+                if (k < KU && alive[k] && pos[k] == ipos) { jsel = lane + 64 * k; r4sel = r4c[k]; }
+            jsel = hg_wave_max(jsel);
+            r4sel = hg_wave_max(r4sel);
+            min_val = m;
+            if (r4sel == -1) sink = jsel; else i = r4sel;
+#pragma unroll
+            for (int k = 0; k < HG_K; ++k) {
+                if (lane + 64 * k == jsel) { scj[k] = true; alive[k] = false; }
+                else if (alive[k] && pos[k] == num_rem - 1) pos[k] = ipos;
+            }
+            --num_rem;
+        }
+        if (sink < 0) { if (lane == 0) S.nr = -1; return; }        // (cannot happen with nr <= nc and finite costs: never spin)
+        // dual variables (with col4row as it was BEFORE the augmentation), then the augmentation along `path`
+#pragma unroll
+        for (int k = 0; k < HG_K; ++k)
+            if (lane + 64 * k < nc) { S.spc[lane + 64 * k] = spc[k]; S.path[lane + 64 * k] = path[k]; }
+        hg_wave_sync();
+        for (int i2 = lane; i2 < nr; i2 += 64)
+            if (S.SR[i2]) S.u[i2] += (i2 == cur) ? min_val : (min_val - S.spc[S.col4row[i2]]);
+#pragma unroll
+        for (int k = 0; k < HG_K; ++k)
+            if (scj[k]) v[k] -= min_val - spc[k];
+        hg_wave_sync();
+        int j = sink;
+        for (;;) {
+            const int ip = S.path[j];
+#pragma unroll
+            for (int k = 0; k < HG_K; ++k)
+                if (lane + 64 * k == j) r4c[k] = ip;
+            const int old = S.col4row[ip];
+            hg_wave_sync();
+            if (lane == 0) S.col4row[ip] = j;
+            hg_wave_sync();
+            j = old;
+            if (ip == cur) break;
+        }
+    }
+}
+
+// the whole sweep, one block of TK_THREADS threads, graphs of <= FIN_LDS_DETS rows with <= HG_MAX dets; status bit 2: a problem
+// exceeded HG_MAX or the scratch (the associations are then incomplete: the host falls back to its own matching)
+__device__ void d_track_hungarian(tmpnn_dgraph g, const int32_t* __restrict__ ts, const int32_t* __restrict__ det_id,
+                                  const float* __restrict__ score, int32_t* __restrict__ assoc, int32_t* __restrict__ status,
+                                  float* __restrict__ cost_ws, int cost_ws_floats) {
+    __shared__ HgShared S;
+    const int tid = threadIdx.x, N = g.N, E = g.meta[0], Dn = g.meta[1];
+    for (int r = tid; r < N; r += TK_THREADS) assoc[r] = -1;
+    if (tid == 0) S.tnext = -1;
+    __syncthreads();
+    if (E == 0 || Dn == 0) return;
+    int t_done = -0x7fffffff;
+    for (;;) {
+        // the next timestep that edges lead into
+        if (tid == 0) S.tnext = 0x7fffffff;
+        __syncthreads();
+        {
+            int m = 0x7fffffff;
+            for (int e = tid; e < E; e += TK_THREADS) { const int tt = ts[g.dst[e]]; if (tt > t_done && tt < m) m = tt; }
+            m = hg_wave_min_i(m);
+            if ((tid & 63) == 0 && m != 0x7fffffff) atomicMin(&S.tnext, m);
+        }
+        __syncthreads();
+        const int t = S.tnext;
+        __syncthreads();
+        if (t == 0x7fffffff) break;
+        t_done = t;
+        // columns: the dets of timestep t (a contiguous run of the det list: rows are in time order)
+        if (tid == 0) { S.d0 = 0x7fffffff; S.d1 = -1; }
+        for (int d = tid; d < 4096; d += TK_THREADS) S.flag[d] = 0;
+        __syncthreads();
+        for (int d = tid; d < Dn; d += TK_THREADS)
+            if (ts[g.det_row[d]] == t) { atomicMin(&S.d0, d); atomicMax(&S.d1, d); }
+        // rows: unassociated src dets of the edges into t
+        for (int e = tid; e < E; e += TK_THREADS)
+            if (ts[g.dst[e]] == t && assoc[g.src[e]] == -1) S.flag[g.src_pos[e]] = 1;
+        __syncthreads();
+        const int d0 = S.d0, nc = S.d1 - S.d0 + 1;
+        int nr;
+        {
+            const int IT = (Dn + TK_THREADS - 1) / TK_THREADS;      // <= 4 (Dn <= FIN_LDS_DETS)
+            int run = 0;
+            for (int it = 0; it < IT; ++it) {
+                const int d = it * TK_THREADS + tid;
+                const int f = (d < Dn && S.flag[d]) ? 1 : 0;
+                int tot;
+                const int ex = tk_block_scan(f, S.wave, &tot);
+                if (f) { const int k = run + ex; S.ridx[d] = (short)min(k, 32767); if (k < HG_MAX) S.rowlist[k] = d; }
+                run += tot;
+            }
+            nr = run;
+        }
+        __syncthreads();
+        if (nr == 0) continue;
+        const bool lds_cost = (long)nr * nc <= HG_LDS_COST;
+        if (nr > HG_MAX || nc > HG_MAX || (!lds_cost && (cost_ws == nullptr || (long)nr * nc > cost_ws_floats))) {
+            if (tid == 0) atomicOr(status, 2);
+            continue;
+        }
+        float* C = lds_cost ? S.cost : cost_ws;
+        for (int x = tid; x < nr * nc; x += TK_THREADS) C[x] = 100.0f;
+        __syncthreads();
+        for (int e = tid; e < E; e += TK_THREADS) {
+            const int dr = g.dst[e];
+            if (ts[dr] == t && assoc[g.src[e]] == -1) C[(int)S.ridx[g.src_pos[e]] * nc + (g.dst_pos[e] - d0)] = 1.0f - score[g.edge_row[e]];
+        }
+        __threadfence_block();
+        __syncthreads();
+        const bool tr = nc < nr;                              // (scipy transposes a tall matrix)
+        if (tid == 0) S.nr = nr;
+        __syncthreads();
+        if (tid < 64) {
+            if (tr) hg_wave_solve(S, C, 1, nc, nc, nr, tid);
+            else hg_wave_solve(S, C, nc, 1, nr, nc, tid);
+        }
+        __syncthreads();
+        if (S.nr < 0) { if (tid == 0) atomicOr(status, 2); __syncthreads(); continue; }
+        const int na = tr ? nc : nr;
+        for (int i = tid; i < na; i += TK_THREADS) {
+            const int j = S.col4row[i];
+            const int pr = tr ? j : i, cu = tr ? i : j;          // (row of the problem = prev det, column = det of timestep t)
+            if (C[pr * nc + cu] <= 0.5f) assoc[g.det_row[S.rowlist[pr]]] = det_id[g.det_row[d0 + cu]];
+        }
+        __threadfence_block();
+        __syncthreads();
+    }
 }
 
 // ---- active set (utils/graph.py:270-278), ascending rows ----------------------------------------------------------
@@ -435,10 +655,15 @@ __global__ __launch_bounds__(TK_THREADS) void k_track_retire(tmpnn_dgraph g, tmp
                                                              const float* __restrict__ h, int ld_h, int W,
                                                              float* __restrict__ h_new, int ld_hn, float* __restrict__ s_new,
                                                              int next_t, int32_t* __restrict__ active,
-                                                             int32_t* __restrict__ fin_ws /* unused at this size; a kernel
-                                                             argument because a literal null in the LDS / global pointer
-                                                             select of the finalisation pass crashes hipcc */) {
-    if (associate) {
+                                                             int32_t* __restrict__ fin_ws /* unused by the finalisation at this
+                                                             size (a kernel argument because a literal null in its LDS /
+                                                             global pointer select crashes hipcc) */, int hung_floats) {
+    if (associate == 2) {                       // optimal assignment per timestep (--hungarian); its cost scratch rides in fin_ws
+        if (threadIdx.x == 0) small[1] = 0;
+        __syncthreads();
+        d_track_hungarian(g, r.ts, r.det_id, score, r.assoc, small + 1, reinterpret_cast<float*>(fin_ws), hung_floats);
+        __syncthreads();
+    } else if (associate) {
         d_track_associate(g, r.det_id, nullptr, score, 1, r.assoc, small + 1, (int)threadIdx.x, TK_THREADS);
         __syncthreads();
     }
@@ -457,8 +682,13 @@ __global__ __launch_bounds__(TK_THREADS) void k_track_retire(tmpnn_dgraph g, tmp
 // update_graph's first half in one launch (LDS-sized graphs): status word cleared, associations, active set
 __global__ __launch_bounds__(TK_THREADS) void k_track_select(tmpnn_dgraph g, tmpnn_track_rows r, const float* __restrict__ score,
                                                              int mode, int t, int associate, int32_t* __restrict__ active,
-                                                             int32_t* __restrict__ small) {
-    if (associate) {
+                                                             int32_t* __restrict__ small, float* __restrict__ hung_ws, int hung_floats) {
+    if (associate == 2) {
+        if (threadIdx.x == 0) small[1] = 0;
+        __syncthreads();
+        d_track_hungarian(g, r.ts, r.det_id, score, r.assoc, small + 1, hung_ws, hung_floats);
+        __syncthreads();
+    } else if (associate) {
         if (mode == 0 && threadIdx.x == 0) small[1] = 0;
         __syncthreads();
         d_track_associate(g, r.det_id, mode == 0 ? r.labels : nullptr, mode == 0 ? nullptr : score, mode, r.assoc, small + 1,
@@ -589,8 +819,15 @@ static int rows_ok(const tmpnn_track_rows* r) {
     return r && r->ts && r->det_id && r->assoc && r->is_edge && r->src && r->dst;
 }
 
+int tmpnn_track_hungarian_max_dets(void) { return HG_MAX; }
+
 int tmpnn_track_select(const tmpnn_dgraph* g, const tmpnn_track_rows* rows, const float* score, int mode, int t,
                        int associate, int32_t* active, int32_t* small, tmpnn_stream stream) {
+    return tmpnn_track_select_ws(g, rows, score, mode, t, associate, active, small, nullptr, 0, stream);
+}
+
+int tmpnn_track_select_ws(const tmpnn_dgraph* g, const tmpnn_track_rows* rows, const float* score, int mode, int t,
+                          int associate, int32_t* active, int32_t* small, void* ws, size_t ws_bytes, tmpnn_stream stream) {
     TM_REQUIRE(g && small, "track_select: null pointer");
     if (g->N == 0) {            // an emptied graph (cur_win_size = 1 and a timestep without detections): no active det, status 0;
         if (hipMemsetAsync(small, 0, 2 * sizeof(int32_t), as_stream(stream)) != hipSuccess)     // zero-size tensors have null data
@@ -600,10 +837,12 @@ int tmpnn_track_select(const tmpnn_dgraph* g, const tmpnn_track_rows* rows, cons
     TM_REQUIRE(rows_ok(rows) && active, "track_select: null pointer");
     TM_REQUIRE(mode == 0 ? rows->labels != nullptr : (mode == 1 && score != nullptr), "track_select: mode %d needs %s", mode,
                mode == 0 ? "labels" : "scores");
+    TM_REQUIRE(associate != 2 || (mode == 1 && g->N <= FIN_LDS_DETS),
+               "track_select: the optimal assignment (associate = 2) serves inference graphs of <= %d rows", FIN_LDS_DETS);
     int rc;
     if (g->N > 0 && g->N <= FIN_LDS_DETS) {
         hipLaunchKernelGGL(k_track_select, dim3(1), dim3(TK_THREADS), 0, as_stream(stream), *g, *rows, score, mode, t,
-                           associate ? 1 : 0, active, small);
+                           associate, active, small, reinterpret_cast<float*>(ws), (int)std::min<size_t>(ws_bytes / 4, 1u << 30));
         return check_launch("track_select");
     }
     if (associate) {
@@ -656,10 +895,12 @@ int tmpnn_track_retire(const tmpnn_dgraph* g, const tmpnn_track_rows* rows, cons
         TM_REQUIRE(y_track && pos_of_det && ND > 0, "track_retire: null pointer / empty sequence");
         TM_SHM_ONCE(k_track_retire, sizeof(int) * FIN_LDS_DETS);
         hipLaunchKernelGGL(k_track_retire, dim3(1), dim3(TK_THREADS), sizeof(int) * (size_t)N, as_stream(stream), *g, *rows, score,
-                           associate ? 1 : 0, t_upto, ret_win, y_track, ND, pos_of_det, keep, small, *rows_out, h, ld_h, W, h_new,
-                           ld_hn, s_new, next_t, active, reinterpret_cast<int32_t*>(fin_ws));
+                           associate, t_upto, ret_win, y_track, ND, pos_of_det, keep, small, *rows_out, h, ld_h, W, h_new,
+                           ld_hn, s_new, next_t, active, reinterpret_cast<int32_t*>(fin_ws),
+                           associate == 2 ? (int)std::min<size_t>(fin_ws_bytes / 4, 1u << 30) : 0);
         return check_launch("track_retire");
     }
+    TM_REQUIRE(associate != 2, "track_retire: the optimal assignment (associate = 2) serves graphs of <= %d rows", FIN_LDS_DETS);
     if (associate &&
         (rc = tmpnn_track_associate(g, rows->det_id, nullptr, score, 1, rows->assoc, small + 1, stream))) return rc;
     if ((rc = tmpnn_track_finalize(g, rows->ts, rows->det_id, rows->assoc, score, t_upto, y_track, ND, pos_of_det, fin_ws,

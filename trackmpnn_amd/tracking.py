@@ -20,6 +20,7 @@ state).  Host reads per timestep in greedy mode: ONE -- decode's (kept rows + th
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Optional, Tuple
 
 import numpy as np
@@ -53,6 +54,8 @@ class TrackGraph:
         self._cur = 0
         self._prefetch = None                            # (timestep, the score tensor decode() returned, active-set size)
         self._fast_addrs = None
+        self._hung_max = None
+        self._hung_ws = None
         self.E = 0
         self.Dn = 0
         self._active = torch.empty(cap, **i32)
@@ -232,6 +235,19 @@ class TrackGraph:
                 assoc[prev[rows_i[ok]]] = did[cur[cols_j[ok]]]
         r['assoc'][:N].copy_(torch.from_numpy(assoc))
 
+    def _hungarian_on_device(self) -> bool:
+        """The optimal assignment runs inside the select / retire launches (csrc/trackops.hip d_track_hungarian: scipy's
+        linear_sum_assignment restated, ties included) where the graph fits their one-launch form and no timestep's
+        problem can exceed the device solver (rows and columns are dets of the graph); else `_hungarian` on the host."""
+        if self._hung_max is None:
+            self._hung_max = int(_lib.load().tmpnn_track_hungarian_max_dets())
+        return 0 < self.N <= DG_MAX_ROWS and self.Dn <= self._hung_max and os.environ.get('TMPNN_HUNGARIAN_HOST', '0') != '1'
+
+    def _hung_scratch(self) -> torch.Tensor:
+        if self._hung_ws is None:
+            self._hung_ws = torch.empty((self._hung_max * self._hung_max,), dtype=torch.float32, device=self.device)
+        return self._hung_ws
+
     def update(self, score_pos: Optional[torch.Tensor], X: torch.Tensor, y: torch.Tensor, t: int, mode: str = 'test',
                use_hungarian: bool = False) -> torch.Tensor:
         """reference update_graph (utils/graph.py:189-334): re-derive the associations, pick the active dets, append
@@ -280,13 +296,21 @@ class TrackGraph:
             if not train:
                 sp = score_pos.detach().reshape(-1).float().contiguous()
             hung = not train and use_hungarian
-            if hung:
+            hung_dev = hung and self._hungarian_on_device()
+            if hung and not hung_dev:
                 self._hungarian(sp)
-            _lib.call('tmpnn_track_select', self.graph.cref(), C.byref(self._crows[self._cur]), _lib.ptr(sp),
-                      0 if train else 1, int(t), 0 if hung else 1, self._active.data_ptr(), self._small.data_ptr(), st)
-            if D == 0 and not train:
+            ws = self._hung_scratch() if hung_dev else None
+            _lib.call('tmpnn_track_select_ws', self.graph.cref(), C.byref(self._crows[self._cur]), _lib.ptr(sp),
+                      0 if train else 1, int(t), 2 if hung_dev else (0 if hung else 1), self._active.data_ptr(),
+                      self._small.data_ptr(), _lib.ptr(ws), 0 if ws is None else ws.numel() * 4, st)
+            if D == 0 and not train and not hung_dev:
                 return torch.zeros((0, Xd.shape[1]), dtype=Xd.dtype, device=self.device)
             A, status = self._small[:2].tolist()           # the ONE host read of an update: the size of the active set
+            if hung_dev and (status & 2):                  # a timestep's problem did not fit the device solver: match on the host
+                self._hungarian(sp)
+                _lib.call('tmpnn_track_select', self.graph.cref(), C.byref(self._crows[self._cur]), _lib.ptr(sp), 1, int(t), 0,
+                          self._active.data_ptr(), self._small.data_ptr(), st)
+                A, status = self._small[:2].tolist()
         if train and (status & 1):                         # (the label rule's assertion holds on empty timesteps too)
             raise AssertionError('More than one GT edge from same node!')
         if D == 0:
@@ -324,7 +348,8 @@ class TrackGraph:
                 self._prefetch = (int(next_t), sc0, 0, sc0._version)
             return h.detach()[:0].float(), sc0
         sp = score_pos.detach().reshape(-1).float().contiguous()
-        if use_hungarian:
+        hung_dev = use_hungarian and self._hungarian_on_device()
+        if use_hungarian and not hung_dev:
             self._hungarian(sp)
         ND = int(self.y_track.numel())
         wsb = int(_lib.load().tmpnn_track_finalize_ws(N))
@@ -338,9 +363,14 @@ class TrackGraph:
         nt = -1 if (next_t is None or use_hungarian) else int(next_t)
         # ---- device, one call: associations, finalisation walk, deletion as a stream compaction of rows, state and scores,
         # and (next_t) the active set of the next timestep on the compacted rows
+        if hung_dev:                                       # (N <= 4096: the finalisation needs no scratch; the slot carries the cost scratch)
+            hws = self._hung_scratch()
+            fin_ptr, fin_bytes = hws.data_ptr(), hws.numel() * 4
+        else:
+            fin_ptr, fin_bytes = (_lib.ptr(self._fin_ws) if wsb else None), wsb
         _lib.call('tmpnn_track_retire', self.graph.cref(), C.byref(self._crows[self._cur]), sp.data_ptr(),
-                  0 if use_hungarian else 1, int(t_upto), int(ret_win_size), self.y_track.data_ptr(), ND,
-                  self._pos_of_det.data_ptr(), _lib.ptr(self._fin_ws) if wsb else None, wsb, self._keep.data_ptr(),
+                  2 if hung_dev else (0 if use_hungarian else 1), int(t_upto), int(ret_win_size), self.y_track.data_ptr(), ND,
+                  self._pos_of_det.data_ptr(), fin_ptr, fin_bytes, self._keep.data_ptr(),
                   self._small.data_ptr(), C.byref(self._crows[1 - self._cur]), hd.data_ptr(), W, W, h_new.data_ptr(), W,
                   s_new.data_ptr(), nt, self._active.data_ptr(), _stream())
         if y_out is not None:
