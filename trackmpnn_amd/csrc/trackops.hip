@@ -130,6 +130,7 @@ struct HgShared {
     float cost[HG_LDS_COST];
     unsigned char flag[4096];
     short ridx[4096];
+    short ad[4096];                                       // per det index: det index of its association, -1 none
     int wave[TK_THREADS / 64 + 1];
     int d0, d1, tnext, nr;
 };
@@ -138,20 +139,50 @@ __device__ __forceinline__ void hg_wave_sync() {          // LDS writes of this 
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
-__device__ __forceinline__ double hg_wave_min(double x) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) { const double y = __shfl_xor(x, off); x = y < x ? y : x; }
-    return x;
+// Wave-wide minima without the LDS crossbar (__shfl_xor is a ds_bpermute: ~120 cycles a step, five reductions per scan made a
+// scan ~3600 cycles): four DPP exchange steps inside each row of 16 lanes (quad_perm xor 1, xor 2, row_half_mirror,
+// row_mirror), then the four rows through v_readlane and the scalar unit.  Keys are unsigned: a double goes through the usual
+// order-preserving map of its bits.
+template <int CTRL>
+__device__ __forceinline__ uint32_t hg_dpp(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xF, 0xF, false);
 }
-__device__ __forceinline__ int hg_wave_max(int x) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) x = max(x, __shfl_xor(x, off));
-    return x;
+template <int CTRL>
+__device__ __forceinline__ uint64_t hg_min_step64(uint64_t x) {
+    const uint64_t y = ((uint64_t)hg_dpp<CTRL>((uint32_t)(x >> 32)) << 32) | hg_dpp<CTRL>((uint32_t)x);
+    return y < x ? y : x;
 }
-__device__ __forceinline__ int hg_wave_min_i(int x) {
+__device__ __forceinline__ uint64_t hg_wave_min64(uint64_t x) {
+    x = hg_min_step64<0xB1>(x);          // quad_perm [1,0,3,2]
+    x = hg_min_step64<0x4E>(x);          // quad_perm [2,3,0,1]
+    x = hg_min_step64<0x141>(x);         // row_half_mirror
+    x = hg_min_step64<0x140>(x);         // row_mirror: every lane of a row of 16 holds the row's minimum
+    uint64_t m = ~0ull;
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) x = min(x, __shfl_xor(x, off));
-    return x;
+    for (int r = 0; r < 4; ++r) {
+        const uint64_t y = ((uint64_t)__builtin_amdgcn_readlane((uint32_t)(x >> 32), 16 * r) << 32) | (uint32_t)__builtin_amdgcn_readlane((uint32_t)x, 16 * r);
+        m = y < m ? y : m;
+    }
+    return m;
+}
+template <int CTRL>
+__device__ __forceinline__ uint32_t hg_min_step32(uint32_t x) { const uint32_t y = hg_dpp<CTRL>(x); return y < x ? y : x; }
+__device__ __forceinline__ uint32_t hg_wave_min32(uint32_t x) {
+    x = hg_min_step32<0xB1>(x);
+    x = hg_min_step32<0x4E>(x);
+    x = hg_min_step32<0x141>(x);
+    x = hg_min_step32<0x140>(x);
+    uint32_t m = ~0u;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { const uint32_t y = (uint32_t)__builtin_amdgcn_readlane(x, 16 * r); m = y < m ? y : m; }
+    return m;
+}
+__device__ __forceinline__ uint64_t hg_key(double x) {        // order-preserving: a < b  <=>  key(a) < key(b)   (no NaNs here)
+    const uint64_t b = (uint64_t)__double_as_longlong(x + 0.0);           // (-0.0 -> +0.0: scipy compares with ==)
+    return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+__device__ __forceinline__ int hg_wave_min_i(int x) {          // (block-level helper of the sweep: ints >= 0 or INT_MAX)
+    return (int)hg_wave_min32((uint32_t)x);
 }
 // rows i < nr <= nc columns; cost(i, j) = C[i * sr + j * sc]; result in S.col4row[0..nr)
 __device__ void hg_wave_solve(HgShared& S, const float* C, int sr, int sc, int nr, int nc, int lane) {
@@ -188,23 +219,31 @@ __device__ void hg_wave_solve(HgShared& S, const float* C, int sr, int sc, int n
                     m = spc[k] < m ? spc[k] : m;
                 }
             }
-            m = hg_wave_min(m);
-            int best_u = -1, best_f = 0x7fffffff;
+            // the minimum, then the scan's choice among the columns that attain it: an unassigned one if there is any (the one at
+            // the HIGHEST position of `remaining`), else the one at the lowest position -- one key: unassigned first
+            const uint64_t mk = hg_wave_min64(hg_key(m));
+            uint32_t sel = 0xFFFFFFFFu;
 #pragma unroll
             for (int k = 0; k < HG_K; ++k)
-                if (k < KU && alive[k] && spc[k] == m) {
-                    if (r4c[k] == -1) best_u = max(best_u, pos[k]);
-                    best_f = min(best_f, pos[k]);
+                if (k < KU && alive[k] && hg_key(spc[k]) == mk) {
+                    const uint32_t q = r4c[k] == -1 ? (uint32_t)(HG_MAX - 1 - pos[k]) : (uint32_t)(HG_MAX + pos[k]);
+                    sel = q < sel ? q : sel;
                 }
-            best_u = hg_wave_max(best_u);
-            best_f = hg_wave_min_i(best_f);
-            const int ipos = best_u >= 0 ? best_u : best_f;
+            sel = hg_wave_min32(sel);
+            const int ipos = sel < (uint32_t)HG_MAX ? HG_MAX - 1 - (int)sel : (int)sel - HG_MAX;
             int jsel = -1, r4sel = -2;
 #pragma unroll
-            for (int k = 0; k < HG_K; ++k)
-                if (k < KU && alive[k] && pos[k] == ipos) { jsel = lane + 64 * k; r4sel = r4c[k]; }
-            jsel = hg_wave_max(jsel);
-            r4sel = hg_wave_max(r4sel);
+            for (int k = 0; k < HG_K; ++k) {
+                const bool mine = k < KU && alive[k] && pos[k] == ipos;
+                const unsigned long long bal = __ballot(mine);
+                if (bal) {                                       // (exactly one column sits at a position)
+                    const int src = __ffsll((long long)bal) - 1;
+                    jsel = src + 64 * k;
+                    r4sel = __builtin_amdgcn_readlane(r4c[k], src);
+                    m = __longlong_as_double(((long long)__builtin_amdgcn_readlane((int)(__double_as_longlong(spc[k]) >> 32), src) << 32) |
+                                             (unsigned)__builtin_amdgcn_readlane((int)__double_as_longlong(spc[k]), src));
+                }
+            }
             min_val = m;
             if (r4sel == -1) sink = jsel; else i = r4sel;
 #pragma unroll
@@ -242,42 +281,108 @@ __device__ void hg_wave_solve(HgShared& S, const float* C, int sr, int sc, int n
     }
 }
 
-// the whole sweep, one block of TK_THREADS threads, graphs of <= FIN_LDS_DETS rows with <= HG_MAX dets; status bit 2: a problem
-// exceeded HG_MAX or the scratch (the associations are then incomplete: the host falls back to its own matching)
+// The same solver for problems of <= 64 columns (every KITTI / BDD frame): lane l is column l AND row l, all state in registers, the
+// only LDS traffic is the cost row of a scan; rows and columns are addressed with v_readlane / ballots instead of LDS arrays.
+__device__ __forceinline__ double hg_readlane_f64(double x, int l) {
+    const long long b = __double_as_longlong(x);
+    return __longlong_as_double(((long long)__builtin_amdgcn_readlane((int)(b >> 32), l) << 32) | (unsigned)__builtin_amdgcn_readlane((int)b, l));
+}
+__device__ void hg_wave_solve64(HgShared& S, const float* C, int sr, int sc, int nr, int nc, int lane) {
+    double v = 0.0, u = 0.0;
+    int r4c = -1, c4r = -1;
+    for (int cur = 0; cur < nr; ++cur) {
+        double spc = __builtin_huge_val();
+        int path = -1, pos = nc - 1 - lane;
+        bool alive = lane < nc, scj = false;
+        unsigned long long sr_mask = 0;
+        int i = cur, sink = -1, num_rem = nc;
+        double min_val = 0.0;
+        while (sink < 0 && num_rem > 0) {
+            i = __builtin_amdgcn_readfirstlane(i);
+            sr_mask |= 1ull << i;
+            const double ui = hg_readlane_f64(u, i);
+            if (alive) {
+                const double c = (double)C[(size_t)i * sr + (size_t)lane * sc];
+                const double r = min_val + c - ui - v;
+                if (r < spc) { path = i; spc = r; }
+            }
+            const uint64_t mk = hg_wave_min64(alive ? hg_key(spc) : ~0ull);
+            uint32_t sel = 0xFFFFFFFFu;
+            if (alive && hg_key(spc) == mk) sel = r4c == -1 ? (uint32_t)(HG_MAX - 1 - pos) : (uint32_t)(HG_MAX + pos);
+            sel = hg_wave_min32(sel);
+            const int ipos = sel < (uint32_t)HG_MAX ? HG_MAX - 1 - (int)sel : (int)sel - HG_MAX;
+            const unsigned long long bal = __ballot(alive && pos == ipos);
+            const int jsel = __ffsll((long long)bal) - 1;           // (exactly one column sits at a position)
+            const int r4sel = __builtin_amdgcn_readlane(r4c, jsel);
+            min_val = hg_readlane_f64(spc, jsel);
+            if (r4sel == -1) sink = jsel; else i = r4sel;
+            if (lane == jsel) { scj = true; alive = false; }
+            else if (alive && pos == num_rem - 1) pos = ipos;
+            --num_rem;
+        }
+        if (sink < 0) { if (lane == 0) S.nr = -1; return; }          // (cannot happen with nr <= nc and finite costs: never spin)
+        // dual variables (with the assignment as it was BEFORE the augmentation): row l needs the reduced cost of ITS column
+        const double spc_mine = __shfl(spc, c4r < 0 ? 0 : c4r);
+        if ((sr_mask >> lane) & 1ull) u += (lane == cur) ? min_val : (min_val - spc_mine);
+        if (scj) v -= min_val - spc;
+        int j = sink;
+        for (;;) {
+            const int ip = __builtin_amdgcn_readlane(path, j);
+            if (lane == j) r4c = ip;
+            const int old = __builtin_amdgcn_readlane(c4r, ip);
+            if (lane == ip) c4r = j;
+            j = old;
+            if (ip == cur) break;
+        }
+    }
+    if (lane < nr) S.col4row[lane] = c4r;
+}
+
+// the whole sweep, one block of TK_THREADS threads, graphs of <= FIN_LDS_DETS rows with <= HG_MAX dets per problem; status bit 2:
+// a problem exceeded HG_MAX or the scratch (the associations are then incomplete: the host falls back to its own matching).
+// What a timestep's passes need of an edge (the timestep it leads into, its endpoints' det indices, its cost) and of a det (its
+// timestep) is read ONCE into registers (four edges / dets per thread): a pass is then LDS and register work, not a chain of
+// dependent global loads per timestep; the result is kept per det index in LDS and written out once at the end.
 __device__ void d_track_hungarian(tmpnn_dgraph g, const int32_t* __restrict__ ts, const int32_t* __restrict__ det_id,
                                   const float* __restrict__ score, int32_t* __restrict__ assoc, int32_t* __restrict__ status,
                                   float* __restrict__ cost_ws, int cost_ws_floats) {
     __shared__ HgShared S;
+    constexpr int PER = 4096 / TK_THREADS;
     const int tid = threadIdx.x, N = g.N, E = g.meta[0], Dn = g.meta[1];
     for (int r = tid; r < N; r += TK_THREADS) assoc[r] = -1;
-    if (tid == 0) S.tnext = -1;
+    int e_t[PER], e_sp[PER], e_dp[PER], d_t[PER];
+    float e_c[PER];
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        const int e = tid + TK_THREADS * k, d = tid + TK_THREADS * k;
+        e_t[k] = 0x7fffffff; e_sp[k] = 0; e_dp[k] = 0; e_c[k] = 0.f; d_t[k] = -0x7fffffff;
+        if (e < E) { e_t[k] = ts[g.dst[e]]; e_sp[k] = g.src_pos[e]; e_dp[k] = g.dst_pos[e]; e_c[k] = 1.0f - score[g.edge_row[e]]; }
+        if (d < Dn) { d_t[k] = ts[g.det_row[d]]; S.ad[d] = -1; }
+    }
     __syncthreads();
     if (E == 0 || Dn == 0) return;
     int t_done = -0x7fffffff;
     for (;;) {
-        // the next timestep that edges lead into
-        if (tid == 0) S.tnext = 0x7fffffff;
+        // the next timestep that edges lead into; its dets are a contiguous run of the det list (rows are in time order)
+        if (tid == 0) { S.tnext = 0x7fffffff; S.d0 = 0x7fffffff; S.d1 = -1; }
+        for (int d = tid; d < Dn; d += TK_THREADS) S.flag[d] = 0;
         __syncthreads();
         {
             int m = 0x7fffffff;
-            for (int e = tid; e < E; e += TK_THREADS) { const int tt = ts[g.dst[e]]; if (tt > t_done && tt < m) m = tt; }
+#pragma unroll
+            for (int k = 0; k < PER; ++k) if (e_t[k] > t_done && e_t[k] < m) m = e_t[k];
             m = hg_wave_min_i(m);
             if ((tid & 63) == 0 && m != 0x7fffffff) atomicMin(&S.tnext, m);
         }
         __syncthreads();
         const int t = S.tnext;
-        __syncthreads();
         if (t == 0x7fffffff) break;
         t_done = t;
-        // columns: the dets of timestep t (a contiguous run of the det list: rows are in time order)
-        if (tid == 0) { S.d0 = 0x7fffffff; S.d1 = -1; }
-        for (int d = tid; d < 4096; d += TK_THREADS) S.flag[d] = 0;
-        __syncthreads();
-        for (int d = tid; d < Dn; d += TK_THREADS)
-            if (ts[g.det_row[d]] == t) { atomicMin(&S.d0, d); atomicMax(&S.d1, d); }
-        // rows: unassociated src dets of the edges into t
-        for (int e = tid; e < E; e += TK_THREADS)
-            if (ts[g.dst[e]] == t && assoc[g.src[e]] == -1) S.flag[g.src_pos[e]] = 1;
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            if (d_t[k] == t) { atomicMin(&S.d0, tid + TK_THREADS * k); atomicMax(&S.d1, tid + TK_THREADS * k); }
+            if (e_t[k] == t && S.ad[e_sp[k]] < 0) S.flag[e_sp[k]] = 1;     // rows: unassociated src dets of the edges into t
+        }
         __syncthreads();
         const int d0 = S.d0, nc = S.d1 - S.d0 + 1;
         int nr;
@@ -303,30 +408,38 @@ __device__ void d_track_hungarian(tmpnn_dgraph g, const int32_t* __restrict__ ts
         }
         float* C = lds_cost ? S.cost : cost_ws;
         for (int x = tid; x < nr * nc; x += TK_THREADS) C[x] = 100.0f;
+        if (tid == 0) S.nr = nr;
         __syncthreads();
-        for (int e = tid; e < E; e += TK_THREADS) {
-            const int dr = g.dst[e];
-            if (ts[dr] == t && assoc[g.src[e]] == -1) C[(int)S.ridx[g.src_pos[e]] * nc + (g.dst_pos[e] - d0)] = 1.0f - score[g.edge_row[e]];
-        }
+#pragma unroll
+        for (int k = 0; k < PER; ++k)
+            if (e_t[k] == t && S.ad[e_sp[k]] < 0) C[(int)S.ridx[e_sp[k]] * nc + (e_dp[k] - d0)] = e_c[k];
         __threadfence_block();
         __syncthreads();
         const bool tr = nc < nr;                              // (scipy transposes a tall matrix)
-        if (tid == 0) S.nr = nr;
-        __syncthreads();
         if (tid < 64) {
-            if (tr) hg_wave_solve(S, C, 1, nc, nc, nr, tid);
-            else hg_wave_solve(S, C, nc, 1, nr, nc, tid);
+            if (max(nr, nc) <= 64) {
+                if (tr) hg_wave_solve64(S, C, 1, nc, nc, nr, tid);
+                else hg_wave_solve64(S, C, nc, 1, nr, nc, tid);
+            } else {
+                if (tr) hg_wave_solve(S, C, 1, nc, nc, nr, tid);
+                else hg_wave_solve(S, C, nc, 1, nr, nc, tid);
+            }
         }
+        __threadfence_block();
         __syncthreads();
         if (S.nr < 0) { if (tid == 0) atomicOr(status, 2); __syncthreads(); continue; }
         const int na = tr ? nc : nr;
         for (int i = tid; i < na; i += TK_THREADS) {
             const int j = S.col4row[i];
             const int pr = tr ? j : i, cu = tr ? i : j;          // (row of the problem = prev det, column = det of timestep t)
-            if (C[pr * nc + cu] <= 0.5f) assoc[g.det_row[S.rowlist[pr]]] = det_id[g.det_row[d0 + cu]];
+            if (C[pr * nc + cu] <= 0.5f) S.ad[S.rowlist[pr]] = (short)(d0 + cu);
         }
-        __threadfence_block();
         __syncthreads();
+    }
+    // y_pred[:, 2] of the associated dets: the det id of the partner
+    for (int d = tid; d < Dn; d += TK_THREADS) {
+        const int pd = S.ad[d];
+        if (pd >= 0) assoc[g.det_row[d]] = det_id[g.det_row[pd]];
     }
 }
 
