@@ -19,8 +19,9 @@ from .graph import DeviceGraph, device_graph_from_adjacency
 
 class CapturedWindow:
     """calls: [(x, node_adj, edge_adj)] of one window in call order (what train.py:65-68,92-107 feeds the model).
-    Models on the fused batch-1 path (no attention heads, nhidden 32 / 64) are recorded through it; every other model
-    (attention heads, nhidden 128 / 256, padded widths) through the staged kernels on plans built before the capture.
+    Models on the fused batch-1 path (nhidden <= 64: 32 / 64 natively, other widths zero-padded when they have no attention
+    heads) are recorded through it; every other model (nhidden 128 ..., padded widths with heads) through the staged kernels
+    on plans built before the capture.
     loss_fn(outputs, h_last) -> scalar, with outputs = [(scores, logits)] per call.  `optimizer` (optional) must be
     capturable (e.g. torch.optim.Adam(..., capturable=True)); parameter gradients must already exist (GradBucket or
     zero_grad(set_to_none=False)), because their addresses are baked into the graph."""
@@ -38,7 +39,8 @@ class CapturedWindow:
             raise RuntimeError(f'CapturedWindow: at most {DG_BIG_ROWS} rows per call (this window: {nmax})')
         # models outside the fused batch-1 path (attention heads, nhidden 128 / 256, padded widths) are recorded through the
         # STAGED kernels on prebuilt plans: launch sizes are host values fixed at capture time, nothing reads back
-        self.staged = bool(getattr(model, '_padded', False)) or not small_eligible(model, nmax)
+        padded = bool(getattr(model, '_padded', False))
+        self.staged = not small_eligible(model, nmax) or (padded and model._small.att)
         self.static_x: List[torch.Tensor] = [x.detach().clone() for x, _, _ in calls]
         self.graphs: List[DeviceGraph] = [device_graph_from_adjacency(na, ea, dev) for _, na, ea in calls]
         for g in self.graphs:

@@ -61,10 +61,14 @@ class SmallPath:
     weights (rebuilt when a weight's version counter changes, i.e. once per optimizer step) and the layout of the
     flat per-call gradient buffer."""
 
-    def __init__(self, model):
+    def __init__(self, model, padded: bool = False):
         self.model = model
         spec = model.spec
         self.spec = spec
+        # padded: the state of a zero-padded width (nhidden not instantiated, padded to 32 / 64): the parameters it is
+        # handed are the padded COPIES (TrackMPNN._padded_params) and its BatchNorm buffers the padded ones (`pad_buffers`)
+        self.padded = padded
+        self.pad_buffers = None
         self.names: List[str] = spec.param_names()
         self.eligible = spec.H in (32, 64) and spec.K <= 8      # (more than 8 heads: the staged kernels run them in groups)
         # attention heads (K > 0): the same two launches per direction with the attention stage (tmpnn_att_fwd / _bwd) between
@@ -80,10 +84,14 @@ class SmallPath:
         self.f_fwd = self.f_bwd = None
         self._fast_addrs = None
         # layout of the flat gradient buffer (256-byte aligned slices), in param_names() order
-        sizes, offs = [], [0]
         named = dict(model.named_parameters())
-        for nm in self.names:
-            sizes.append(named[nm].numel())
+        self.set_grad_layout([named[nm] for nm in self.names])
+
+    def set_grad_layout(self, plist) -> None:
+        """Slices of the per-call flat gradient buffer for parameters of these shapes (the padded copies of a padded width)."""
+        sizes, offs = [], [0]
+        for p in plist:
+            sizes.append(p.numel())
             offs.append(offs[-1] + ((sizes[-1] + 63) // 64) * 64)
         self.grad_sizes, self.grad_offs, self.grad_total = sizes, offs[:-1], offs[-1]
 
@@ -122,7 +130,7 @@ class SmallPath:
             ptrs = dict(zip(self.names, key))
             st = _lib.CMpParams()
             self._fill(st, ptrs.__getitem__)
-            bufs = dict(self.model.named_buffers())
+            bufs = self.pad_buffers if self.padded else dict(self.model.named_buffers())
             for g in range(self.spec.G):
                 st.run_mean[g] = bufs[f'input_transforms.{g}.1.running_mean'].data_ptr()
                 st.run_var[g] = bufs[f'input_transforms.{g}.1.running_var'].data_ptr()

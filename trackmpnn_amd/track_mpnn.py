@@ -107,6 +107,7 @@ class TrackMPNN(nn.Module):
         # set by trackmpnn_amd.dist.GradBucket: parameter gradients are added straight into p.grad (functional.py)
         self.inplace_param_grads = False
         self._small = SmallPath(self)          # batch-1 path state (pointer structs, operand images)
+        self._small_pad = None                 # ... of a zero-padded width (its parameters are the padded copies)
         self._plist = None
         self._bufs = None
         self._anchor = None
@@ -121,7 +122,7 @@ class TrackMPNN(nn.Module):
     # per-call bookkeeping of the batch-1 path (plain Python values, reassigned on every forward call): kept out of
     # nn.Module.__setattr__'s parameter / buffer / sub-module checks (~2.5 us per assignment, twice per call)
     _PLAIN = frozenset(('_graph_cache', '_anchor', '_anch_key', '_anch_calls', '_gst', '_sink', '_sink_key', '_plist',
-                        '_bufs', '_pending_graphs', '_pad_cache'))
+                        '_bufs', '_pending_graphs', '_pad_cache', '_small_pad'))
 
     def __setattr__(self, name, value):
         if name in TrackMPNN._PLAIN:
@@ -136,6 +137,7 @@ class TrackMPNN(nn.Module):
             self.check_graphs()
         self._pad_cache = None
         self._small.invalidate()
+        self._small_pad = None
         self._plist = self._bufs = self._anchor = None
         self._sink = self._sink_key = None
         self._anch_key = None
@@ -151,6 +153,7 @@ class TrackMPNN(nn.Module):
         for k in TrackMPNN._PLAIN:
             state[k] = [] if k == '_pending_graphs' else (0 if k == '_anch_calls' else None)
         state['_small'] = None
+        state['_small_pad'] = None
         return state
 
     def __setstate__(self, state):
@@ -247,6 +250,8 @@ class TrackMPNN(nn.Module):
         out = self._pad_params(params)
         token = object()
         self._pad_cache = (key, out, token)
+        if self._small_pad is not None:
+            self._small_pad.invalidate()       # (fresh copies: new pointers AND new values behind version counters that start at 0)
         if torch.is_grad_enabled():
             live = [t for t in out if t.requires_grad]
             if live:
@@ -335,8 +340,10 @@ class TrackMPNN(nn.Module):
         if not x.is_cuda:
             raise RuntimeError(f'x is on {x.device}: trackmpnn_amd runs on the MI355X HIP kernels only '
                                '(no CPU or torch fallback exists)')
+        if self._padded and small_eligible(self, graph.N) and not self._small.att:
+            return self._forward_dgraph_padded(x, h_in, graph)
         if self._padded or not small_eligible(self, graph.N):
-            # models the fused iteration does not cover (attention heads, nhidden >= 128, padded widths): the staged kernels
+            # models the fused iteration does not cover (nhidden >= 128; padded widths with attention heads): the staged kernels
             # on the same device-resident graph (frame_graph() reads E and Dn back: their launch sizes are host values)
             return self.forward_graph(x, h_in, plan_single(graph.frame_graph(), int(x.shape[0])), dropout_keep=dropout_keep)
         if self._plist is None:
@@ -422,6 +429,95 @@ class TrackMPNN(nn.Module):
             return scores, logits, h_out, tuple([SparseAttention(fg, ak) for ak in a] for a in call['alphas'])
         return scores, logits, h_out, (None,) * self.spec.G
 
+    def _forward_dgraph_padded(self, x, h_in, graph: DeviceGraph):
+        """The fused iteration for a width the kernels are not instantiated for (nhidden padded to 32 / 64, no attention
+        heads): the same two launches per direction on the ZERO-PADDED parameter copies (built once per set of parameter
+        values; autograd hands the true parameters their gradients through the pads, summed over the calls of a window
+        first), padded BatchNorm buffers kept next to the true ones, and the carried state kept in its padded form behind
+        the [N, G * nhidden] tensor the caller sees (a view of it where there is one feature group)."""
+        if self._plist is None:
+            named = dict(self.named_parameters())
+            self._plist = [named[nm] for nm in self.spec.param_names()]
+            self._bufs = dict(self.named_buffers())
+        H, Hp, G = self.nhidden, self.hpad, self.spec.G
+        params = self._padded_params(self._plist)
+        sp = self._small_pad
+        if sp is None or sp.pad_buffers is None or next(iter(sp.pad_buffers.values())).device != x.device:
+            sp = SmallPath(self, padded=True)
+            sp.set_grad_layout(params)
+            pb = {}
+            for k, b in self._bufs.items():
+                if k.endswith('running_mean') or k.endswith('running_var'):
+                    pb[k] = torch.nn.functional.pad(b.detach().to(x.device), (0, Hp - H), value=1.0 if k.endswith('var') else 0.0).contiguous()
+                else:
+                    pb[k] = b.detach().to(x.device).clone()
+            sp.pad_buffers = pb
+            sp._buf_ver = {k: b._version for k, b in self._bufs.items()}
+            object.__setattr__(self, '_small_pad', sp)
+        else:
+            # the true buffers are the source of truth between calls (load_state_dict, manual edits): a padded copy is
+            # refreshed when its original's version counter has moved since this path last wrote it
+            for k, b in self._bufs.items():
+                if sp._buf_ver.get(k) != b._version or torch.cuda.is_current_stream_capturing():
+                    with torch.no_grad():
+                        if k.endswith('running_mean') or k.endswith('running_var'):
+                            sp.pad_buffers[k][:H].copy_(b)
+                        else:
+                            sp.pad_buffers[k].copy_(b)
+                    sp._buf_ver[k] = b._version
+        grad_on = torch.is_grad_enabled()
+        need_grad = grad_on and (any(p.requires_grad for p in params) or x.requires_grad
+                                 or (h_in is not None and h_in.requires_grad))
+        n = int(x.shape[0])
+        hp_in = None
+        if h_in is not None:
+            hp_in = getattr(h_in, '_tmpnn_padded_state', None)
+            if hp_in is None or hp_in.shape[0] != h_in.shape[0]:
+                hp_in = self._pad_state(h_in)
+        spare = max(256, graph.N)
+        append = (hp_in is not None and n > 0 and getattr(hp_in, '_tmpnn_spare_rows', 0) >= n
+                  and not getattr(hp_in, '_tmpnn_consumed', False))
+        if append:
+            hp_in._tmpnn_consumed = True
+        pgrad = grad_on and any(p.requires_grad for p in params)
+        fast = fast_module() if graph.cap == graph.N else None
+        if fast is not None and pgrad and all(p.requires_grad for p in params):
+            # the native node with a gradient SINK over the padded copies: each call returns one flat gradient buffer, autograd
+            # sums those per window and hands the slices to the copies once -- whose pad ops then reach the true parameters
+            tmpl, total, offs, shapes = sp.grad_template(params)
+            token = self._pad_cache[2] if self._pad_cache is not None else None
+            if self._sink is None or self._sink_key is not token or self._sink.device != x.device:
+                self._sink = _ParamSink.apply(total, offs, shapes, *params)
+                self._sink_key = token
+            info = sp.fast_info(params, graph, tmpl, self.training, need_grad, append, spare, sink_total=total)
+            scores, logits, h_pad = fast.small_iter(x, hp_in, self._sink, graph.arena, info, sp.keep())
+        elif fast is not None and not need_grad:
+            if self._anchor is None or self._anchor.device != x.device:
+                self._anchor = torch.zeros(1, device=x.device, requires_grad=True)
+            info = sp.fast_info(params, graph, sp.params(params), self.training, False, append, spare)
+            with torch.no_grad():
+                scores, logits, h_pad = fast.small_iter(x, hp_in, self._anchor, graph.arena, info, sp.keep())
+        else:
+            call = dict(small=sp, graph=graph, training=self.training, need_grad=need_grad, spare=spare, append=append,
+                        param_objs=params, anchored=False, check_pending=self.check_graphs, keep=None)
+            scores, logits, h_pad = _SmallIter.apply(call, x, hp_in, *params)
+        h_pad._tmpnn_spare_rows = spare
+        if self.training and n > 0:
+            with torch.no_grad():                                  # running statistics of the true units (one fused copy + the counters)
+                fl = [k for k in self._bufs if k.endswith('running_mean') or k.endswith('running_var')]
+                torch._foreach_copy_([self._bufs[k] for k in fl], [sp.pad_buffers[k][:H] for k in fl])
+                for k, b in self._bufs.items():
+                    if k not in fl:
+                        b.copy_(sp.pad_buffers[k])
+                    sp._buf_ver[k] = b._version
+        h_out = h_pad[:, :H] if G == 1 else self._unpad_state(h_pad)
+        h_out._tmpnn_padded_state = h_pad
+        if need_grad and self._pending_graphs:
+            for t in (scores, logits, h_pad):
+                if t.requires_grad:
+                    t.register_hook(self._check_graphs_hook)
+        return scores, logits, h_out, (None,) * G
+
     def _check_graphs_hook(self, grad):
         self.check_graphs()
         return None
@@ -439,7 +535,7 @@ class TrackMPNN(nn.Module):
             raise RuntimeError(f'x is on {x.device}: trackmpnn_amd runs on the MI355X HIP kernels only '
                                '(no CPU or torch fallback exists)')
         N = int(node_adj.shape[0])
-        small = SMALL_PATH and not self._padded and small_eligible(self, N)
+        small = SMALL_PATH and small_eligible(self, N) and not (self._padded and self._small.att)
         # the last call's graph is reused when the SAME adjacency objects come again unmodified (the static-window pattern:
         # several MP iterations on one graph).  Weak references: the cache pins neither a dense N x N adjacency nor its
         # device copy, and a recycled id() cannot alias (a dead reference never matches).
