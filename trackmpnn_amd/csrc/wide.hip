@@ -912,6 +912,7 @@ __device__ __forceinline__ void pp_wait_barrier() {
     else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
     else if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");
     else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
+    else if constexpr (N == 1) asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
@@ -1771,6 +1772,321 @@ __global__ __launch_bounds__(512) void k_wide_gemm_ring256(WideArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// C (+)= A B on 128 x 256 tiles with the block's halves in opposite phases (round 5; the structure of k_wide_gru_fwd_pp)
+// ------------------------------------------------------------------------------------------------------------
+// The backward product d_h += d_gh W_hh (C5: 4.41 M x 768 x 256) in the ring form above runs all eight waves through the same
+// request / read / split / MFMA phases between the same barriers (9.9 ms for 5.6 ms of matrix-pipe time).  Here, as in
+// k_wide_gru_fwd_pp: half X (waves 0-3) owns output columns 0-127, half Y columns 128-255; a wave's tile is 32 rows x 128
+// columns (four accumulators, 24 MFMAs per half step) with its operands read in one barrier interval (LOAD) and consumed in the
+// next (MMA); X and Y alternate, so each SIMD's matrix pipe always has exactly one wave feeding it; the requests of an
+// interval ride between the MMA wave's MFMAs (three weight pieces and the wave's A piece), the LOAD wave runs at raised
+// priority, the A split uses scalar subtractions.  A tile's K loop (3H / 16 half steps) runs into the next tile's without
+// draining (the request stream is periodic); the epilogue comes straight from the accumulators (lane = column): read-modify-
+// write of C and the fused row-F adjoint in 128-byte row segments.  Same products in the same order as the forms above.
+static constexpr int GP_A = 128 * 64, GP_NA = 4;                       // A ring: four slots of 128 rows x 16 fp32
+static constexpr int GP_BH = 3 * 128 * 32;                             // weight sub-slot of one half: [piece 3][128 columns][32 B]
+static constexpr int GP_OFF_B = GP_NA * GP_A;
+static constexpr int GP_OFF_S = GP_OFF_B + 4 * GP_BH;                 // the split A pieces X publishes for Y: [step parity 2][piece 3][128 rows][32 B]
+static constexpr int GP_S = 3 * 128 * 32;
+#if defined(W3_TIMELINE)
+static constexpr int GP_OFF_T = GP_OFF_S + 2 * GP_S;
+static constexpr size_t W_GEMM_PP_SHM = GP_OFF_T + 2048;
+#define GP_STAMP(k) do { if (tl_on) { uint64_t t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory");   \
+                                      if (lane == 0 && (k) >= 0 && (k) < 32) reinterpret_cast<uint64_t*>(lds + GP_OFF_T)[wave * 32 + (k)] = t_; } } while (0)
+#else
+static constexpr size_t W_GEMM_PP_SHM = GP_OFF_S + 2 * GP_S;          // 104 KB
+#define GP_STAMP(k) do { } while (0)
+#endif
+struct GpOps { uint4 af[3]; uint4 bf[12]; };                           // bf[ct * 3 + piece]
+
+// 4 x 4 transpose across the four lanes of a quad (DPP quad_perm): in, lane k holds column k of rows 0..3 in a0..a3; out,
+// lane k holds row k, columns 0..3.  Two exchange stages (lane bit 0 / register bit 0, then bit 1 / bit 1): 16 vector instructions.
+__device__ __forceinline__ float pp_dpp_x1(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+}
+__device__ __forceinline__ float pp_dpp_x2(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
+}
+__device__ __forceinline__ void pp_transpose4(float& a0, float& a1, float& a2, float& a3, bool b0, bool b1) {
+    float r;
+    r = pp_dpp_x1(b0 ? a0 : a1); if (b0) a0 = r; else a1 = r;
+    r = pp_dpp_x1(b0 ? a2 : a3); if (b0) a2 = r; else a3 = r;
+    r = pp_dpp_x2(b1 ? a0 : a2); if (b1) a0 = r; else a2 = r;
+    r = pp_dpp_x2(b1 ? a1 : a3); if (b1) a1 = r; else a3 = r;
+}
+
+// Half-step image of the backward W_hh operand for k_wide_gemm_pp256: the 12-KB block one half reads in one half step --
+// [piece 3][128 columns][16 k] -- is contiguous: imgpp[(((j * 2 + hx) * 3 + piece) * 128 + col) * 16 + pos] = piece of
+// B[16 j + kk][128 hx + col], pos as k_wide_prep16.  B[k][n] = W[k * ldw + n] (K = 3H gate rows, N = 256 hidden columns).
+__global__ __launch_bounds__(256) void k_wide_prep_gpp(const float* __restrict__ W, int ldw, int K, uint16_t* __restrict__ img) {
+    const long total = (long)K * 256;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int k = (int)(i >> 8), n = (int)(i & 255);
+        const float v = W[(size_t)k * ldw + n];
+        uint32_t p1, p2, p3;
+        w_split2(v, 0.f, p1, p2, p3);
+        const int j = k >> 4, kk = k & 15, hx = n >> 7, col = n & 127;
+        const size_t blk = ((size_t)j * 2 + hx) * 3;
+        const size_t pos = (size_t)col * 16 + ((((kk >> 3) ^ ((col >> 4) & 1)) << 3) | (kk & 7));
+        img[(blk + 0) * 2048 + pos] = (uint16_t)p1;
+        img[(blk + 1) * 2048 + pos] = (uint16_t)p2;
+        img[(blk + 2) * 2048 + pos] = (uint16_t)p3;
+    }
+}
+
+__device__ __forceinline__ void gp_read(const char* lds, int aslot, int par, int hx, int a_off0, int a_off1, int b_off, float4& lo,
+                                        float4& hi, GpOps& o) {
+    const char* sa = lds + aslot * GP_A;
+    lo = *reinterpret_cast<const float4*>(sa + a_off0);
+    hi = *reinterpret_cast<const float4*>(sa + a_off1);
+    const char* sb = lds + GP_OFF_B + (par * 2 + hx) * GP_BH + b_off;
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+        for (int pc = 0; pc < 3; ++pc) o.bf[ct * 3 + pc] = *reinterpret_cast<const uint4*>(sb + pc * 4096 + ct * 1024);
+}
+__device__ __forceinline__ void gp_split(const float4& lo, const float4& hi, GpOps& o) {
+    pp_split2(lo.x, lo.y, o.af[0].x, o.af[1].x, o.af[2].x);
+    pp_split2(lo.z, lo.w, o.af[0].y, o.af[1].y, o.af[2].y);
+    pp_split2(hi.x, hi.y, o.af[0].z, o.af[1].z, o.af[2].z);
+    pp_split2(hi.z, hi.w, o.af[0].w, o.af[1].w, o.af[2].w);
+    asm volatile("" : "+v"(o.af[0].x), "+v"(o.af[0].y), "+v"(o.af[0].z), "+v"(o.af[0].w), "+v"(o.af[1].x), "+v"(o.af[1].y),
+                      "+v"(o.af[1].z), "+v"(o.af[1].w), "+v"(o.af[2].x), "+v"(o.af[2].y), "+v"(o.af[2].z), "+v"(o.af[2].w));
+}
+// The A fragment of (row group, half step) is needed by the X wave and by the Y wave of that row group; X reads it first (its
+// LOAD segment comes an interval earlier), so X alone splits it and publishes the three bf16 pieces in LDS, and Y reads 48
+// bytes instead of 32 raw ones + ~50 vector instructions of split: with 24 MFMAs per segment the LOAD segments were the longer
+// ones (9.7 ms per C5 launch, no better than the ring form), and the split is the larger half of a LOAD segment.
+__device__ __forceinline__ void gp_publish(char* lds, int par, int s_off, const GpOps& o) {
+    char* sp = lds + GP_OFF_S + par * GP_S + s_off;
+    *reinterpret_cast<uint4*>(sp) = o.af[0];
+    *reinterpret_cast<uint4*>(sp + 4096) = o.af[1];
+    *reinterpret_cast<uint4*>(sp + 8192) = o.af[2];
+}
+__device__ __forceinline__ void gp_read_y(const char* lds, int par, int s_off, int b_off, GpOps& o) {
+    const char* sp = lds + GP_OFF_S + par * GP_S + s_off;
+    o.af[0] = *reinterpret_cast<const uint4*>(sp);
+    o.af[1] = *reinterpret_cast<const uint4*>(sp + 4096);
+    o.af[2] = *reinterpret_cast<const uint4*>(sp + 8192);
+    const char* sb = lds + GP_OFF_B + (par * 2 + 1) * GP_BH + b_off;
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+        for (int pc = 0; pc < 3; ++pc) o.bf[ct * 3 + pc] = *reinterpret_cast<const uint4*>(sb + pc * 4096 + ct * 1024);
+}
+// the wave's requests of an interval, woven behind the accumulators' MFMAs: its three weight pieces of (half step jb, half hxb)
+// into sub-slot (parb, hxb), then -- youngest -- its A piece
+__device__ __forceinline__ void gp_mma(const GpOps& o, f32x16 (&acc)[4], const char* img, int jb, int hxb, int parb, int wi, uint32_t lane16,
+                                       uint32_t lds0, const char* asrc, uint32_t adst) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        f32x16 c = acc[t];
+        c = w_mfma(o.af[2], o.bf[t * 3], c);        // smallest terms first (as gring_compute)
+        c = w_mfma(o.af[0], o.bf[t * 3 + 2], c);
+        c = w_mfma(o.af[1], o.bf[t * 3 + 1], c);
+        c = w_mfma(o.af[1], o.bf[t * 3], c);
+        c = w_mfma(o.af[0], o.bf[t * 3 + 1], c);
+        c = w_mfma(o.af[0], o.bf[t * 3], c);
+        acc[t] = c;
+        __builtin_amdgcn_sched_barrier(0);
+        if (t < 3) {                                 // pieces wi, wi + 4, wi + 8 of the twelve
+            const int q = wi + 4 * t;
+            glds16_so(img + (size_t)(jb * 2 + hxb) * GP_BH + 1024u * q, lane16, lds0 + GP_OFF_B + (uint32_t)(parb * 2 + hxb) * GP_BH + 1024u * q);
+        } else {
+            glds16(asrc, adst);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+template <int HX>
+__device__ __forceinline__ void gp_half(const WideArgs& a, char* const lds) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), wr = wave & 3;
+    const int nsub = a.K >> 4;                                             // half steps per tile (multiple of 8)
+    const int ntile = (a.R + 127) >> 7, G = gridDim.x;
+    int t = blockIdx.x;
+    const char* const img = reinterpret_cast<const char*>(a.img);
+    const uint32_t lds0 = lds_addr(lds), lds_a = lds0 + 1024u * wave, lane16 = 16u * lane;
+    const int r = lane & 31, hh = lane >> 5;
+    const int arow = 32 * wr + r, fa = (arow >> 2) & 3;
+    const int a_off0 = arow * 64 + (((2 * hh) ^ fa) << 4), a_off1 = arow * 64 + (((2 * hh + 1) ^ fa) << 4);
+    const int b_off = r * 32 + ((hh ^ ((r >> 4) & 1)) << 4);
+    const int s_off = arow * 32 + ((hh ^ ((arow >> 4) & 1)) << 4);       // this lane's 16 bytes of a published piece
+    const int drow = tid >> 2, dchunk = (tid & 3) ^ ((drow >> 2) & 3);
+    auto a_src = [&](int tile) {
+        const int rr = min(tile * 128 + drow, a.R - 1);                   // (rows past R repeat the last one: never stored)
+        const int row = a.a_rows ? a.a_rows[rr] : rr;
+        return reinterpret_cast<const char*>(a.A + (size_t)row * a.lda + 4 * dchunk);
+    };
+    auto kcol = [&](int j) { int kc = 16 * j; if (kc >= a.kskip_at) kc += a.kskip; return (size_t)kc * 4; };   // byte offset of half step j in an A row
+    auto dma_b = [&](int j, int hxb, int par) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int q = wr + 4 * k;
+            glds16_so(img + (size_t)(j * 2 + hxb) * GP_BH + 1024u * q, lane16, lds0 + GP_OFF_B + (uint32_t)(par * 2 + hxb) * GP_BH + 1024u * q);
+        }
+    };
+    const char* pa = a_src(t);
+    // ---- the first tile's head, as the tail of a previous tile would have requested it: A steps 0-2, the weights of step 0
+    //      for both halves and of step 1 for X
+    if (HX == 0) { dma_b(0, 1, 0); }
+    else { dma_b(0, 0, 0); dma_b(1, 0, 1); }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) glds16(pa + kcol(j), lds_a + (uint32_t)j * GP_A);
+    pp_wait_barrier<0>();
+    GpOps o;
+    float4 lo, hi;
+    if (HX == 0) {
+        gp_read(lds, 0, 0, 0, a_off0, a_off1, b_off, lo, hi, o);
+        gp_split(lo, hi, o);
+        gp_publish(lds, 0, s_off, o);
+    }
+    pp_barrier();
+#if defined(W3_TIMELINE)
+    int tile_no = 0;
+#endif
+    for (;;) {
+        const bool more = t + G < ntile;
+#if defined(W3_TIMELINE)
+        const bool tl_on = blockIdx.x == 0 && tile_no == 1;
+#endif
+        const char* pa_n = more ? a_src(t + G) : pa;                       // (the next tile's rows; none: this tile again, unread)
+        f32x16 acc[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[j][q] = 0.f;
+        GpOps oy;
+        // X, MMA(p): weights of step p + 1 for half Y, A rows 0-63 of step p + 3; Y, MMA(p): weights of step p + 2 for half X, A rows
+        // 64-127 of step p + 3 (steps past the tile's end: the next tile's first ones).  LOAD: reads, split, counted wait.
+#define GP_STEP(U, PA_, JB_, JA_, READ)                                                                            \
+        do {                                                                                                       \
+            const int sk_ = (p + (U) - 8) * 6;                                                                     \
+            if (HX == 0) {                                                                                         \
+                GP_STAMP(sk_);                                                                                     \
+                __builtin_amdgcn_sched_barrier(0);                                                                 \
+                gp_mma(o, acc, img, (JB_), 1, ((U) + 1) & 1, wr, lane16, lds0, (PA_) + kcol(JA_), lds_a + (uint32_t)(((U) + 3) & 3) * GP_A); \
+                __builtin_amdgcn_sched_barrier(0);                                                                 \
+                GP_STAMP(sk_ + 1);                                                                                 \
+                pp_barrier();                                                                                      \
+                GP_STAMP(sk_ + 2);                                                                                 \
+                __builtin_amdgcn_s_setprio(2);                                                                     \
+                if (READ) {                                                                                        \
+                    gp_read(lds, ((U) + 1) & 3, ((U) + 1) & 1, 0, a_off0, a_off1, b_off, lo, hi, o);               \
+                    gp_split(lo, hi, o);                                                                           \
+                    gp_publish(lds, ((U) + 1) & 1, s_off, o);                                                      \
+                }                                                                                                  \
+                __builtin_amdgcn_s_setprio(0);                                                                     \
+                GP_STAMP(sk_ + 3);                                                                                 \
+                pp_wait_barrier<1>();                                                                              \
+                GP_STAMP(sk_ + 4);                                                                                 \
+            } else {                                                                                               \
+                GP_STAMP(sk_);                                                                                     \
+                __builtin_amdgcn_s_setprio(2);                                                                     \
+                gp_read_y(lds, (U) & 1, s_off, b_off, oy);                                                         \
+                __builtin_amdgcn_s_setprio(0);                                                                     \
+                pp_wait_barrier<1>();                                                                              \
+                __builtin_amdgcn_sched_barrier(0);                                                                 \
+                gp_mma(oy, acc, img, (JB_), 0, (U) & 1, wr, lane16, lds0, (PA_) + kcol(JA_), lds_a + (uint32_t)(((U) + 3) & 3) * GP_A); \
+                __builtin_amdgcn_sched_barrier(0);                                                                 \
+                pp_barrier();                                                                                      \
+            }                                                                                                      \
+        } while (0)
+        constexpr int DB = HX == 0 ? 1 : 2;
+        int p = 0;
+        for (; p + 4 < nsub; p += 4) {
+            GP_STEP(0, pa, p + DB, p + 3, true);
+            GP_STEP(1, pa, p + 1 + DB, p + 4, true);
+            GP_STEP(2, pa, p + 2 + DB, p + 5, true);
+            GP_STEP(3, pa, p + 3 + DB, p + 6, true);
+        }
+        if (HX == 0) {
+            GP_STEP(0, pa, p + 1, p + 3, true);
+            GP_STEP(1, pa_n, p + 2, 0, true);
+            GP_STEP(2, pa_n, p + 3, 1, true);
+            GP_STEP(3, pa_n, 0, 2, false);
+        } else {
+            GP_STEP(0, pa, p + 2, p + 3, true);
+            GP_STEP(1, pa_n, p + 3, 0, true);
+            GP_STEP(2, pa_n, 0, 1, true);
+            GP_STEP(3, pa_n, 1, 2, true);
+        }
+#undef GP_STEP
+        GP_STAMP(30);
+        // ---- epilogue from the accumulators.  An accumulator holds one COLUMN of 16 rows per lane; as 4-byte accesses the tile's
+        //      read-modify-write of C and the two gathers of the fused row-F adjoint were ~300 vector-memory instructions per wave
+        //      (44 k ticks per tile, a quarter of the kernel -- what such an instruction costs is its issue).  The four registers of
+        //      a row group are transposed across each quad of lanes instead: a lane then holds FOUR consecutive columns of one row
+        //      and every access is 16 bytes (8 rows x 128 B per instruction).
+        {
+            const int lq = opaque(lane);
+            const int k4 = lq & 3, qd = (lq & 31) >> 2;
+            const bool b0 = (lq & 1) != 0, b1 = (lq & 2) != 0;
+            const int colq = 128 * HX + 4 * qd;                            // + 32 ct: this lane's four columns
+            const int r0 = t * 128;
+            int crow[4], asr[4], adr[4];
+            bool ok[4];
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                const int rr = r0 + 32 * wr + 8 * rg + 4 * hh + k4;       // this lane's row of the group
+                ok[rg] = rr < a.R;
+                const int rc = min(rr, a.R - 1);
+                crow[rg] = a.c_rows ? a.c_rows[rc] : rc;
+                asr[rg] = a.add_msg ? a.add_src[rc] : 0;
+                adr[rg] = a.add_msg ? a.add_dst[rc] : 0;
+            }
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                wf32x4 cp[4], ms[4], md[4];
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct) {
+                    if (a.accumulate) cp[ct] = *reinterpret_cast<const wf32x4*>(a.C + (size_t)crow[rg] * a.ldc + colq + 32 * ct);
+                    if (a.add_msg) {
+                        ms[ct] = *reinterpret_cast<const wf32x4*>(a.add_msg + (size_t)asr[rg] * a.ld_add + colq + 32 * ct);
+                        md[ct] = *reinterpret_cast<const wf32x4*>(a.add_msg + (size_t)adr[rg] * a.ld_add + colq + 32 * ct);
+                    }
+                }
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct) {
+                    float g0 = acc[ct][4 * rg], g1 = acc[ct][4 * rg + 1], g2 = acc[ct][4 * rg + 2], g3 = acc[ct][4 * rg + 3];
+                    pp_transpose4(g0, g1, g2, g3, b0, b1);
+                    wf32x4 v;
+                    v[0] = g0; v[1] = g1; v[2] = g2; v[3] = g3;
+                    if (a.accumulate) v += cp[ct];
+                    if (a.add_msg) v = (ms[ct] - md[ct]) + v;               // (the sum in the order of tmpnn_gather_diff_fwd(accumulate))
+                    if (ok[rg]) *reinterpret_cast<wf32x4*>(a.C + (size_t)crow[rg] * a.ldc + colq + 32 * ct) = v;
+                }
+            }
+        }
+#if defined(W3_TIMELINE)
+        GP_STAMP(31);
+        if (tl_on) {
+            __syncthreads();
+            if (tid < 256) g_pp_timeline[tid] = reinterpret_cast<const uint64_t*>(lds + GP_OFF_T)[tid];
+        }
+        ++tile_no;
+#endif
+        if (!more) break;
+        if (HX == 0) {                                                     // X: the next tile's step 0 (slot 0, parity 0)
+            gp_read(lds, 0, 0, 0, a_off0, a_off1, b_off, lo, hi, o);
+            gp_split(lo, hi, o);
+            gp_publish(lds, 0, s_off, o);
+        }
+        pp_barrier();
+        t += G;
+        pa = pa_n;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                       // (the unread re-requests of the last tile must land before the LDS is handed on)
+}
+
+__global__ __launch_bounds__(512) void k_wide_gemm_pp256(WideArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint16_t w_dyn[];
+    if ((int)blockIdx.x >= ((a.R + 127) >> 7)) return;
+    if (__builtin_amdgcn_readfirstlane(threadIdx.x >> 8) == 0) gp_half<0>(a, reinterpret_cast<char*>(w_dyn));
+    else gp_half<1>(a, reinterpret_cast<char*>(w_dyn));
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // backward, elementwise pass: d_gi = [dr | dz | dn], d_gh = [dr | dz | dn r] (compact rows), d_h[row] = dh z
 // ------------------------------------------------------------------------------------------------------------
 struct WideBwdArgs {
@@ -2316,10 +2632,19 @@ static int launch_dw(const WideDwArgs& q, int nslab, hipStream_t st) {
 }
 
 // the ring form needs whole 128-column blocks, K in whole groups of four half steps (>= 8) and 16-byte aligned rows
-static int launch_gemm_ring(const WideArgs& a, hipStream_t st) {
+static int launch_gemm_ring(const WideArgs& a, hipStream_t st, const uint16_t* img_gpp = nullptr) {
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     const int ntile = ceil_div(a.R, 128);
+    // default since round 5 where N = 256 (C5): the opposite-phase form; TMPNN_WIDE_GEMM_RING=1 keeps the ring form for A/B runs
+    static const bool ring_form = [] { const char* e = getenv("TMPNN_WIDE_GEMM_RING"); return e && e[0] == '1'; }();
+    if (!ring_form && a.N == 256 && a.K % 128 == 0 && img_gpp != nullptr) {
+        WideArgs b = a;
+        b.img = img_gpp;
+        TM_SHM_ONCE(k_wide_gemm_pp256, W_GEMM_PP_SHM);
+        hipLaunchKernelGGL(k_wide_gemm_pp256, dim3(ntile < cus ? ntile : cus), dim3(512), W_GEMM_PP_SHM, st, b);
+        return check_launch("wide_gemm_pp256");
+    }
 #ifndef WT_GEMM_RING128
     if (a.N % 256 == 0) {
         TM_SHM_ONCE(k_wide_gemm_ring256, W_GEMM_RING4_SHM);
@@ -2358,7 +2683,7 @@ size_t tmpnn_wide_prep_bytes(int H, int IN) {
     if (H <= 0 || IN <= 0) return 0;
     // + the half-step images of the forward and backward-data W_hh operands (k_wide_gru_fwd_ring, k_wide_gemm_ring)
     // + the contiguous-block image of the forward W_hh operand (k_wide_gru_fwd_pp)
-    return sizeof(uint16_t) * 3 * ((size_t)H * 3 * H + (size_t)IN * 3 * H + (size_t)3 * H * IN + (size_t)3 * H * H + 3 * (size_t)H * 3 * H);
+    return sizeof(uint16_t) * 3 * ((size_t)H * 3 * H + (size_t)IN * 3 * H + (size_t)3 * H * IN + (size_t)3 * H * H + 4 * (size_t)H * 3 * H);      // ... and of the backward W_hh operand (k_wide_gemm_pp256)
 }
 
 int tmpnn_wide_prepare(const float* w_ih, const float* w_hh, int IN, int H, void* prep, tmpnn_stream stream) {
@@ -2378,6 +2703,7 @@ int tmpnn_wide_prepare(const float* w_ih, const float* w_hh, int IN, int H, void
     hipLaunchKernelGGL(k_wide_prep16, dim3(g1), dim3(256), 0, st, w_hh, H, H, 3 * H, 1, f_hh16);
     hipLaunchKernelGGL(k_wide_prep16, dim3(g1), dim3(256), 0, st, w_hh, H, 3 * H, H, 0, f_hh16 + (size_t)3 * H * 3 * H);
     hipLaunchKernelGGL(k_wide_prep_pp, dim3(g1), dim3(256), 0, st, w_hh, H, H, f_hh16 + (size_t)2 * 3 * H * 3 * H);
+    if (H == 256) hipLaunchKernelGGL(k_wide_prep_gpp, dim3(g1), dim3(256), 0, st, w_hh, H, 3 * H, f_hh16 + (size_t)3 * 3 * H * 3 * H);
     return check_launch("wide_prepare");
 }
 
@@ -2668,7 +2994,7 @@ static int wide_gru_bwd_diff_impl(const void* prep, const tmpnn_graph* g, const 
     // (the E-row product of the backward: the ring form; its weight image is the sixth of prep)
     y.img = f_hh + (size_t)3 * (4 * 3 * H * H) + (size_t)3 * H * 3 * H;
     y.add_msg = add_msg; y.ld_add = ld_add; y.add_src = g->src; y.add_dst = g->dst;
-    if ((rc = launch_gemm_ring(y, st))) return done(rc);
+    if ((rc = launch_gemm_ring(y, st, H == 256 ? y.img + (size_t)2 * 3 * H * 3 * H : nullptr))) return done(rc);
 #else
     if (add_msg) return done(set_error(TMPNN_EINVAL, "wide_gru_bwd_diff: the store-GEMM build has no fused adjoint"));
     if ((rc = launch_store(y, st))) return done(rc);
