@@ -1899,22 +1899,72 @@ __device__ __forceinline__ void gp_mma(const GpOps& o, f32x16 (&acc)[4], const c
     }
 }
 
-template <int HX>
-__device__ __forceinline__ void gp_half(const WideArgs& a, char* const lds) {
+// S = 32-row sub-tiles per wave: S = 1 -> 128-row tiles (above), S = 2 -> 256 x 256 tiles (below).
+// Why 256 rows: what bounds these kernels is the CU's memory pipe, ~12-14 B per clock whatever the instruction mix (s_memtime:
+// an epilogue of 512 KB took 45 k ticks as 4-byte and as 16-byte accesses alike; a forward item moves 1.1 MB in ~80 k ticks; a
+// 128-row tile of this product 2.0 MB -- 0.38 of A, 1.15 of WEIGHTS re-streamed from L2, 0.5 of epilogue -- in ~150 k against
+// 79 k of MFMAs).  The weights are the same for every row tile: with 256 rows per tile they are streamed half as often (1.47 MB
+// per 128 rows).  A wave then owns 64 rows x 128 columns: eight accumulators (128 registers), 48 MFMAs per half step from one set
+// of twelve weight fragments; LDS: A ring 4 x 16 KB, weights 48 KB, published pieces 2 x 24 KB = 160 KB.
+template <int S> struct GqOps { uint4 af[S][3]; uint4 bf[12]; };
+template <int S> static constexpr int gq_a() { return S * GP_A; }                      // bytes of an A slot
+template <int S> static constexpr int gq_off_b() { return GP_NA * S * GP_A; }
+template <int S> static constexpr int gq_off_s() { return gq_off_b<S>() + 4 * GP_BH; }
+template <int S> static constexpr int gq_s() { return S * GP_S; }                     // bytes of a published-piece slot
+template <int S> static constexpr size_t gq_shm() { return (size_t)gq_off_s<S>() + 2 * gq_s<S>(); }
+
+template <int S>
+__device__ __forceinline__ void gq_mma(const GqOps<S>& o, f32x16 (&acc)[S][4], const char* img, int jb, int hxb, int parb, int wi,
+                                       uint32_t lane16, uint32_t lds0, const char* (&asrc)[S], size_t aoff, uint32_t adst) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+#pragma unroll
+        for (int sb = 0; sb < S; ++sb) {
+            f32x16 c = acc[sb][t];
+            c = w_mfma(o.af[sb][2], o.bf[t * 3], c);        // smallest terms first (as gring_compute)
+            c = w_mfma(o.af[sb][0], o.bf[t * 3 + 2], c);
+            c = w_mfma(o.af[sb][1], o.bf[t * 3 + 1], c);
+            c = w_mfma(o.af[sb][1], o.bf[t * 3], c);
+            c = w_mfma(o.af[sb][0], o.bf[t * 3 + 1], c);
+            c = w_mfma(o.af[sb][0], o.bf[t * 3], c);
+            acc[sb][t] = c;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (t < 3) {                                 // weight pieces wi, wi + 4, wi + 8 of the twelve
+            const int q = wi + 4 * t;
+            glds16_so(img + (size_t)(jb * 2 + hxb) * GP_BH + 1024u * q, lane16, lds0 + gq_off_b<S>() + (uint32_t)(parb * 2 + hxb) * GP_BH + 1024u * q);
+        } else {                                     // youngest: the wave's A pieces (rows 16 w .. of each 128-row half of the tile)
+#pragma unroll
+            for (int sb = 0; sb < S; ++sb) glds16(asrc[sb] + aoff, adst + (uint32_t)sb * GP_A);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+template <int HX, int S>
+__device__ __forceinline__ void gq_half(const WideArgs& a, char* const lds) {
+    constexpr int TR = 128 * S;                                            // rows of a tile
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), wr = wave & 3;
     const int nsub = a.K >> 4;                                             // half steps per tile (multiple of 8)
-    const int ntile = (a.R + 127) >> 7, G = gridDim.x;
+    const int ntile = (a.R + TR - 1) / TR, G = gridDim.x;
     int t = blockIdx.x;
     const char* const img = reinterpret_cast<const char*>(a.img);
     const uint32_t lds0 = lds_addr(lds), lds_a = lds0 + 1024u * wave, lane16 = 16u * lane;
     const int r = lane & 31, hh = lane >> 5;
-    const int arow = 32 * wr + r, fa = (arow >> 2) & 3;
-    const int a_off0 = arow * 64 + (((2 * hh) ^ fa) << 4), a_off1 = arow * 64 + (((2 * hh + 1) ^ fa) << 4);
+    // the wave's rows: 32 S wr + 32 sb + r.  An A slot is [S][128 rows][64 B] (sub-slot sb = rows 128 sb ..): row R of the tile
+    // sits in sub-slot R >> 7 at row R & 127
+    int a_off0[S], a_off1[S], s_off[S];
+#pragma unroll
+    for (int sb = 0; sb < S; ++sb) {
+        const int trow = 32 * S * wr + 32 * sb + r, sl = trow >> 7, ar = trow & 127, fa = (ar >> 2) & 3;
+        a_off0[sb] = sl * GP_A + ar * 64 + (((2 * hh) ^ fa) << 4);
+        a_off1[sb] = sl * GP_A + ar * 64 + (((2 * hh + 1) ^ fa) << 4);
+        s_off[sb] = sl * GP_S + ar * 32 + ((hh ^ ((ar >> 4) & 1)) << 4);
+    }
     const int b_off = r * 32 + ((hh ^ ((r >> 4) & 1)) << 4);
-    const int s_off = arow * 32 + ((hh ^ ((arow >> 4) & 1)) << 4);       // this lane's 16 bytes of a published piece
     const int drow = tid >> 2, dchunk = (tid & 3) ^ ((drow >> 2) & 3);
-    auto a_src = [&](int tile) {
-        const int rr = min(tile * 128 + drow, a.R - 1);                   // (rows past R repeat the last one: never stored)
+    auto a_src = [&](int tile, int sb) {
+        const int rr = min(tile * TR + 128 * sb + drow, a.R - 1);         // (rows past R repeat the last one: never stored)
         const int row = a.a_rows ? a.a_rows[rr] : rr;
         return reinterpret_cast<const char*>(a.A + (size_t)row * a.lda + 4 * dchunk);
     };
@@ -1923,71 +1973,93 @@ __device__ __forceinline__ void gp_half(const WideArgs& a, char* const lds) {
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
             const int q = wr + 4 * k;
-            glds16_so(img + (size_t)(j * 2 + hxb) * GP_BH + 1024u * q, lane16, lds0 + GP_OFF_B + (uint32_t)(par * 2 + hxb) * GP_BH + 1024u * q);
+            glds16_so(img + (size_t)(j * 2 + hxb) * GP_BH + 1024u * q, lane16, lds0 + gq_off_b<S>() + (uint32_t)(par * 2 + hxb) * GP_BH + 1024u * q);
         }
     };
-    const char* pa = a_src(t);
+    auto rd_b = [&](int par, int hx, GqOps<S>& o) {
+        const char* sbp = lds + gq_off_b<S>() + (par * 2 + hx) * GP_BH + b_off;
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+            for (int pc = 0; pc < 3; ++pc) o.bf[ct * 3 + pc] = *reinterpret_cast<const uint4*>(sbp + pc * 4096 + ct * 1024);
+    };
+    // X: raw A rows of (slot), split, publish for Y at (par), and this half's weights
+    auto load_x = [&](int aslot, int par, GqOps<S>& o) {
+        float4 lo[S], hi[S];
+        const char* sa = lds + aslot * gq_a<S>();
+#pragma unroll
+        for (int sb = 0; sb < S; ++sb) {
+            lo[sb] = *reinterpret_cast<const float4*>(sa + a_off0[sb]);
+            hi[sb] = *reinterpret_cast<const float4*>(sa + a_off1[sb]);
+        }
+        rd_b(par, 0, o);
+#pragma unroll
+        for (int sb = 0; sb < S; ++sb) {
+            pp_split2(lo[sb].x, lo[sb].y, o.af[sb][0].x, o.af[sb][1].x, o.af[sb][2].x);
+            pp_split2(lo[sb].z, lo[sb].w, o.af[sb][0].y, o.af[sb][1].y, o.af[sb][2].y);
+            pp_split2(hi[sb].x, hi[sb].y, o.af[sb][0].z, o.af[sb][1].z, o.af[sb][2].z);
+            pp_split2(hi[sb].z, hi[sb].w, o.af[sb][0].w, o.af[sb][1].w, o.af[sb][2].w);
+            char* sp = lds + gq_off_s<S>() + par * gq_s<S>() + s_off[sb];
+            *reinterpret_cast<uint4*>(sp) = o.af[sb][0];
+            *reinterpret_cast<uint4*>(sp + 4096) = o.af[sb][1];
+            *reinterpret_cast<uint4*>(sp + 8192) = o.af[sb][2];
+        }
+    };
+    auto load_y = [&](int par, GqOps<S>& o) {
+#pragma unroll
+        for (int sb = 0; sb < S; ++sb) {
+            const char* sp = lds + gq_off_s<S>() + par * gq_s<S>() + s_off[sb];
+            o.af[sb][0] = *reinterpret_cast<const uint4*>(sp);
+            o.af[sb][1] = *reinterpret_cast<const uint4*>(sp + 4096);
+            o.af[sb][2] = *reinterpret_cast<const uint4*>(sp + 8192);
+        }
+        rd_b(par, 1, o);
+    };
+    const char* pa[S];
+#pragma unroll
+    for (int sb = 0; sb < S; ++sb) pa[sb] = a_src(t, sb);
     // ---- the first tile's head, as the tail of a previous tile would have requested it: A steps 0-2, the weights of step 0
     //      for both halves and of step 1 for X
     if (HX == 0) { dma_b(0, 1, 0); }
     else { dma_b(0, 0, 0); dma_b(1, 0, 1); }
 #pragma unroll
-    for (int j = 0; j < 3; ++j) glds16(pa + kcol(j), lds_a + (uint32_t)j * GP_A);
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int sb = 0; sb < S; ++sb) glds16(pa[sb] + kcol(j), lds_a + (uint32_t)(j * gq_a<S>() + sb * GP_A));
     pp_wait_barrier<0>();
-    GpOps o;
-    float4 lo, hi;
-    if (HX == 0) {
-        gp_read(lds, 0, 0, 0, a_off0, a_off1, b_off, lo, hi, o);
-        gp_split(lo, hi, o);
-        gp_publish(lds, 0, s_off, o);
-    }
+    GqOps<S> o;
+    if (HX == 0) load_x(0, 0, o);
     pp_barrier();
-#if defined(W3_TIMELINE)
-    int tile_no = 0;
-#endif
     for (;;) {
         const bool more = t + G < ntile;
-#if defined(W3_TIMELINE)
-        const bool tl_on = blockIdx.x == 0 && tile_no == 1;
-#endif
-        const char* pa_n = more ? a_src(t + G) : pa;                       // (the next tile's rows; none: this tile again, unread)
-        f32x16 acc[4];
+        f32x16 acc[S][4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int sb = 0; sb < S; ++sb)
 #pragma unroll
-            for (int q = 0; q < 16; ++q) acc[j][q] = 0.f;
-        GpOps oy;
-        // X, MMA(p): weights of step p + 1 for half Y, A rows 0-63 of step p + 3; Y, MMA(p): weights of step p + 2 for half X, A rows
-        // 64-127 of step p + 3 (steps past the tile's end: the next tile's first ones).  LOAD: reads, split, counted wait.
-#define GP_STEP(U, PA_, JB_, JA_, READ)                                                                            \
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int q = 0; q < 16; ++q) acc[sb][j][q] = 0.f;
+        GqOps<S> oy;
+        // X, MMA(p): weights of step p + 1 for half Y, A rows of step p + 3 (this wave's pieces); Y, MMA(p): weights of step p + 2 for
+        // half X, its A pieces of step p + 3 (steps past the tile's end: the next tile's first ones).  LOAD: reads (X: split, publish).
+#define GQ_STEP(U, JB_, JA_, READ)                                                                                 \
         do {                                                                                                       \
-            const int sk_ = (p + (U) - 8) * 6;                                                                     \
             if (HX == 0) {                                                                                         \
-                GP_STAMP(sk_);                                                                                     \
                 __builtin_amdgcn_sched_barrier(0);                                                                 \
-                gp_mma(o, acc, img, (JB_), 1, ((U) + 1) & 1, wr, lane16, lds0, (PA_) + kcol(JA_), lds_a + (uint32_t)(((U) + 3) & 3) * GP_A); \
+                gq_mma<S>(o, acc, img, (JB_), 1, ((U) + 1) & 1, wr, lane16, lds0, pa, kcol(JA_), lds_a + (uint32_t)(((U) + 3) & 3) * gq_a<S>()); \
                 __builtin_amdgcn_sched_barrier(0);                                                                 \
-                GP_STAMP(sk_ + 1);                                                                                 \
                 pp_barrier();                                                                                      \
-                GP_STAMP(sk_ + 2);                                                                                 \
                 __builtin_amdgcn_s_setprio(2);                                                                     \
-                if (READ) {                                                                                        \
-                    gp_read(lds, ((U) + 1) & 3, ((U) + 1) & 1, 0, a_off0, a_off1, b_off, lo, hi, o);               \
-                    gp_split(lo, hi, o);                                                                           \
-                    gp_publish(lds, ((U) + 1) & 1, s_off, o);                                                      \
-                }                                                                                                  \
+                if (READ) load_x(((U) + 1) & 3, ((U) + 1) & 1, o);                                                 \
                 __builtin_amdgcn_s_setprio(0);                                                                     \
-                GP_STAMP(sk_ + 3);                                                                                 \
-                pp_wait_barrier<1>();                                                                              \
-                GP_STAMP(sk_ + 4);                                                                                 \
+                pp_wait_barrier<S>();                                                                              \
             } else {                                                                                               \
-                GP_STAMP(sk_);                                                                                     \
                 __builtin_amdgcn_s_setprio(2);                                                                     \
-                gp_read_y(lds, (U) & 1, s_off, b_off, oy);                                                         \
+                load_y((U) & 1, oy);                                                                               \
                 __builtin_amdgcn_s_setprio(0);                                                                     \
-                pp_wait_barrier<1>();                                                                              \
+                pp_wait_barrier<S>();                                                                              \
                 __builtin_amdgcn_sched_barrier(0);                                                                 \
-                gp_mma(oy, acc, img, (JB_), 0, (U) & 1, wr, lane16, lds0, (PA_) + kcol(JA_), lds_a + (uint32_t)(((U) + 3) & 3) * GP_A); \
+                gq_mma<S>(oy, acc, img, (JB_), 0, (U) & 1, wr, lane16, lds0, pa, kcol(JA_), lds_a + (uint32_t)(((U) + 3) & 3) * gq_a<S>()); \
                 __builtin_amdgcn_sched_barrier(0);                                                                 \
                 pp_barrier();                                                                                      \
             }                                                                                                      \
@@ -1995,95 +2067,82 @@ __device__ __forceinline__ void gp_half(const WideArgs& a, char* const lds) {
         constexpr int DB = HX == 0 ? 1 : 2;
         int p = 0;
         for (; p + 4 < nsub; p += 4) {
-            GP_STEP(0, pa, p + DB, p + 3, true);
-            GP_STEP(1, pa, p + 1 + DB, p + 4, true);
-            GP_STEP(2, pa, p + 2 + DB, p + 5, true);
-            GP_STEP(3, pa, p + 3 + DB, p + 6, true);
+            GQ_STEP(0, p + DB, p + 3, true);
+            GQ_STEP(1, p + 1 + DB, p + 4, true);
+            GQ_STEP(2, p + 2 + DB, p + 5, true);
+            GQ_STEP(3, p + 3 + DB, p + 6, true);
+        }
+        // the last four steps: after the first, every A request is the next tile's (none: this tile again, unread)
+        GQ_STEP(0, p + DB, p + 3, true);
+        if (more) {
+#pragma unroll
+            for (int sb = 0; sb < S; ++sb) pa[sb] = a_src(t + G, sb);
         }
         if (HX == 0) {
-            GP_STEP(0, pa, p + 1, p + 3, true);
-            GP_STEP(1, pa_n, p + 2, 0, true);
-            GP_STEP(2, pa_n, p + 3, 1, true);
-            GP_STEP(3, pa_n, 0, 2, false);
+            GQ_STEP(1, p + 2, 0, true);
+            GQ_STEP(2, p + 3, 1, true);
+            GQ_STEP(3, 0, 2, false);
         } else {
-            GP_STEP(0, pa, p + 2, p + 3, true);
-            GP_STEP(1, pa_n, p + 3, 0, true);
-            GP_STEP(2, pa_n, 0, 1, true);
-            GP_STEP(3, pa_n, 1, 2, true);
+            GQ_STEP(1, p + 3, 0, true);
+            GQ_STEP(2, 0, 1, true);
+            GQ_STEP(3, 1, 2, true);
         }
-#undef GP_STEP
-        GP_STAMP(30);
-        // ---- epilogue from the accumulators.  An accumulator holds one COLUMN of 16 rows per lane; as 4-byte accesses the tile's
-        //      read-modify-write of C and the two gathers of the fused row-F adjoint were ~300 vector-memory instructions per wave
-        //      (44 k ticks per tile, a quarter of the kernel -- what such an instruction costs is its issue).  The four registers of
-        //      a row group are transposed across each quad of lanes instead: a lane then holds FOUR consecutive columns of one row
-        //      and every access is 16 bytes (8 rows x 128 B per instruction).
+#undef GQ_STEP
+        // ---- epilogue from the accumulators: lane = column (cl of the 32-column group ct), registers = rows; 16 outputs per pass
         {
-            const int lq = opaque(lane);
-            const int k4 = lq & 3, qd = (lq & 31) >> 2;
-            const bool b0 = (lq & 1) != 0, b1 = (lq & 2) != 0;
-            const int colq = 128 * HX + 4 * qd;                            // + 32 ct: this lane's four columns
-            const int r0 = t * 128;
-            int crow[4], asr[4], adr[4];
-            bool ok[4];
+            const int cl = opaque(lane) & 31;
+            const int col0 = 128 * HX + cl;
+            const int r0 = t * TR;
 #pragma unroll
-            for (int rg = 0; rg < 4; ++rg) {
-                const int rr = r0 + 32 * wr + 8 * rg + 4 * hh + k4;       // this lane's row of the group
-                ok[rg] = rr < a.R;
-                const int rc = min(rr, a.R - 1);
-                crow[rg] = a.c_rows ? a.c_rows[rc] : rc;
-                asr[rg] = a.add_msg ? a.add_src[rc] : 0;
-                adr[rg] = a.add_msg ? a.add_dst[rc] : 0;
-            }
+            for (int sb = 0; sb < S; ++sb)
 #pragma unroll
-            for (int rg = 0; rg < 4; ++rg) {
-                wf32x4 cp[4], ms[4], md[4];
+                for (int rg = 0; rg < 4; ++rg) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    int crow[4], asr[4], adr[4];
+                    bool ok[4];
 #pragma unroll
-                for (int ct = 0; ct < 4; ++ct) {
-                    if (a.accumulate) cp[ct] = *reinterpret_cast<const wf32x4*>(a.C + (size_t)crow[rg] * a.ldc + colq + 32 * ct);
-                    if (a.add_msg) {
-                        ms[ct] = *reinterpret_cast<const wf32x4*>(a.add_msg + (size_t)asr[rg] * a.ld_add + colq + 32 * ct);
-                        md[ct] = *reinterpret_cast<const wf32x4*>(a.add_msg + (size_t)adr[rg] * a.ld_add + colq + 32 * ct);
+                    for (int j = 0; j < 4; ++j) {
+                        const int rr = r0 + 32 * S * wr + 32 * sb + 8 * rg + 4 * hh + j;
+                        ok[j] = rr < a.R;
+                        const int rc = min(rr, a.R - 1);
+                        crow[j] = a.c_rows ? a.c_rows[rc] : rc;
+                        asr[j] = a.add_msg ? a.add_src[rc] : 0;
+                        adr[j] = a.add_msg ? a.add_dst[rc] : 0;
                     }
-                }
+                    float cp[4][4], ms[4][4], md[4][4];
 #pragma unroll
-                for (int ct = 0; ct < 4; ++ct) {
-                    float g0 = acc[ct][4 * rg], g1 = acc[ct][4 * rg + 1], g2 = acc[ct][4 * rg + 2], g3 = acc[ct][4 * rg + 3];
-                    pp_transpose4(g0, g1, g2, g3, b0, b1);
-                    wf32x4 v;
-                    v[0] = g0; v[1] = g1; v[2] = g2; v[3] = g3;
-                    if (a.accumulate) v += cp[ct];
-                    if (a.add_msg) v = (ms[ct] - md[ct]) + v;               // (the sum in the order of tmpnn_gather_diff_fwd(accumulate))
-                    if (ok[rg]) *reinterpret_cast<wf32x4*>(a.C + (size_t)crow[rg] * a.ldc + colq + 32 * ct) = v;
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int ct = 0; ct < 4; ++ct) {
+                            cp[j][ct] = a.accumulate ? a.C[(size_t)crow[j] * a.ldc + col0 + 32 * ct] : 0.f;
+                            ms[j][ct] = a.add_msg ? a.add_msg[(size_t)asr[j] * a.ld_add + col0 + 32 * ct] : 0.f;
+                            md[j][ct] = a.add_msg ? a.add_msg[(size_t)adr[j] * a.ld_add + col0 + 32 * ct] : 0.f;
+                        }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int ct = 0; ct < 4; ++ct) {
+                            float v = acc[sb][ct][4 * rg + j];
+                            if (a.accumulate) v += cp[j][ct];
+                            if (a.add_msg) v = (ms[j][ct] - md[j][ct]) + v;       // (the sum in the order of tmpnn_gather_diff_fwd(accumulate))
+                            if (ok[j]) a.C[(size_t)crow[j] * a.ldc + col0 + 32 * ct] = v;
+                        }
                 }
-            }
         }
-#if defined(W3_TIMELINE)
-        GP_STAMP(31);
-        if (tl_on) {
-            __syncthreads();
-            if (tid < 256) g_pp_timeline[tid] = reinterpret_cast<const uint64_t*>(lds + GP_OFF_T)[tid];
-        }
-        ++tile_no;
-#endif
         if (!more) break;
-        if (HX == 0) {                                                     // X: the next tile's step 0 (slot 0, parity 0)
-            gp_read(lds, 0, 0, 0, a_off0, a_off1, b_off, lo, hi, o);
-            gp_split(lo, hi, o);
-            gp_publish(lds, 0, s_off, o);
-        }
+        if (HX == 0) load_x(0, 0, o);                                      // X: the next tile's step 0 (slot 0, parity 0)
         pp_barrier();
         t += G;
-        pa = pa_n;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                       // (the unread re-requests of the last tile must land before the LDS is handed on)
 }
 
+template <int S>
 __global__ __launch_bounds__(512) void k_wide_gemm_pp256(WideArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint16_t w_dyn[];
-    if ((int)blockIdx.x >= ((a.R + 127) >> 7)) return;
-    if (__builtin_amdgcn_readfirstlane(threadIdx.x >> 8) == 0) gp_half<0>(a, reinterpret_cast<char*>(w_dyn));
-    else gp_half<1>(a, reinterpret_cast<char*>(w_dyn));
+    if ((int)blockIdx.x >= (a.R + 128 * S - 1) / (128 * S)) return;
+    if (__builtin_amdgcn_readfirstlane(threadIdx.x >> 8) == 0) gq_half<0, S>(a, reinterpret_cast<char*>(w_dyn));
+    else gq_half<1, S>(a, reinterpret_cast<char*>(w_dyn));
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -2641,8 +2700,16 @@ static int launch_gemm_ring(const WideArgs& a, hipStream_t st, const uint16_t* i
     if (!ring_form && a.N == 256 && a.K % 128 == 0 && img_gpp != nullptr) {
         WideArgs b = a;
         b.img = img_gpp;
-        TM_SHM_ONCE(k_wide_gemm_pp256, W_GEMM_PP_SHM);
-        hipLaunchKernelGGL(k_wide_gemm_pp256, dim3(ntile < cus ? ntile : cus), dim3(512), W_GEMM_PP_SHM, st, b);
+        // 256-row tiles (the weights streamed half as often) unless TMPNN_WIDE_GEMM_ROWS=128
+        static const bool rows128 = [] { const char* e = getenv("TMPNN_WIDE_GEMM_ROWS"); return e && e[0] == '1' && e[1] == '2'; }();
+        if (rows128) {
+            TM_SHM_ONCE(k_wide_gemm_pp256<1>, gq_shm<1>());
+            hipLaunchKernelGGL(k_wide_gemm_pp256<1>, dim3(ntile < cus ? ntile : cus), dim3(512), gq_shm<1>(), st, b);
+        } else {
+            const int nt2 = ceil_div(a.R, 256);
+            TM_SHM_ONCE(k_wide_gemm_pp256<2>, gq_shm<2>());
+            hipLaunchKernelGGL(k_wide_gemm_pp256<2>, dim3(nt2 < cus ? nt2 : cus), dim3(512), gq_shm<2>(), st, b);
+        }
         return check_launch("wide_gemm_pp256");
     }
 #ifndef WT_GEMM_RING128
