@@ -272,7 +272,7 @@ def _pmc_kernel(stage):
                 'gru_bwd_data_edge_folded': 'k_gru_bwd_data_split<64, 3, true>',
                 'gru_bwd_weights_edge': 'k_gru_bwd_weights_split<1, 1>',
                 'gru_bwd_one_edge': ('k_gru_bwd_one<1, 3, true>' if os.environ.get('TMPNN_BWD_TWO', '1')[:1] == '0'
-                                     else 'k_gru_bwd_two<1, 3, true>')}.get(stage, '?')
+                                     else 'k_gru_bwd_two<1, 3, true')}.get(stage, '?')       # (prefix: the template list grew in round 4)
     return {'gru_fwd_edge': 'k_gru_fwd_lds<64, 64, 3,', 'gru_bwd_data_edge': 'k_gru_bwd_data_lds<64, 64, 1, false>',
             'gru_bwd_data_edge_folded': 'k_gru_bwd_data_lds<64, 64, 3, true>',
             'gru_bwd_weights_edge': 'k_gru_bwd_weights_lds<64, 1, 1>'}.get(stage, '?')
