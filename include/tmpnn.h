@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define TMPNN_ABI_VERSION 2 /* 2: struct tmpnn_graph gained seg_plan (round 4) */
+#define TMPNN_ABI_VERSION 3 /* 2: struct tmpnn_graph gained seg_plan (round 4); 3: win_plan (round 5) */
 
 #define TMPNN_OK 0
 #define TMPNN_EINVAL (-1)   /* bad shape / null pointer / unsupported width */
@@ -69,6 +69,26 @@ typedef struct tmpnn_seg_plan {
     size_t ws_floats;
 } tmpnn_seg_plan;
 
+/* Optional plan of a BATCH OF SMALL WINDOWS (block-diagonal: no edge crosses windows) for the edge -> det segment sum at H = 64
+ * (csrc/agg.hip, k_segsum_win): a workgroup owns a window at a time, walks its edge rows through the LDS in chunks, once, and every
+ * det consumes its run out of LDS -- each edge row is read from memory ONCE instead of once per endpoint; results equal the CSR
+ * kernel's bit for bit.  Built by
+ * the host once per graph (trackmpnn_amd.graph.win_plan) from the window label of every det; the caller owns the arrays. */
+typedef struct tmpnn_win_plan {
+    int32_t W;                /* windows */
+    int32_t nbig;             /* dets of the windows beyond the kernel's capacity (3072 edge rows / 256 dets): CSR kernel */
+    const int32_t* wrec;      /* [W][8] per window: first entry / count in erow, first visiting position (entry of det / drow /
+                                       rptr) / count of its dets, rptr[first visiting position], 0, 0, 0; 32-byte aligned */
+    const int32_t* erow;      /* [E]   edge rows, window by window, ascending within a window */
+    const int32_t* rptr;      /* [Dn+1] per visiting position: its run of incidences in `slot` */
+    const uint16_t* slot;     /* [2E]  per incidence, in the det's CSR order: place of its edge row in the window's part of
+                                       erow | 0x8000 where the det is the edge's later endpoint (the sign bit of tmpnn_graph.inc);
+                                       2E even-padded so that a window's part is read as whole 32-bit words */
+    const int32_t* det;       /* [Dn]  det index per visiting position (window-major) */
+    const int32_t* drow;      /* [Dn]  its graph row */
+    const int32_t* big_order; /* [nbig] det indices of the windows left to the CSR kernel */
+} tmpnn_win_plan;
+
 typedef struct tmpnn_graph {
     int32_t N;               /* rows of the state tensor (dets + edges) */
     int32_t E;               /* edge rows */
@@ -85,6 +105,8 @@ typedef struct tmpnn_graph {
                                 endpoint) are issued from the same CU close in time */
     const tmpnn_seg_plan* seg_plan; /* or NULL: dense graphs, H = 256 column blocks -- tmpnn_segsum_fwd and the wide cells'
                                        backward then read every edge row once (see tmpnn_seg_plan) */
+    const tmpnn_win_plan* win_plan; /* or NULL: batches of small windows, H = 64 -- the segment sums (tmpnn_segsum_fwd,
+                                       tmpnn_gather_diff_bwd) then read every edge row once (see tmpnn_win_plan) */
 } tmpnn_graph;
 
 /*

@@ -404,3 +404,89 @@ def _dense_segsum_case(g, g0):
             else:
                 scale = outs[1].abs().max().item()
                 assert (outs[0] - outs[1]).abs().max().item() <= 1e-5 * scale, (kind, c0, compact, acc)
+
+
+def _window_batch_graph(B, device):
+    """The last call's graph of B block-diagonal rolling windows (12 frames, ~8 dets a frame): ~1.4 k edges a window."""
+    from trackmpnn_amd import WindowBuilder, batch_windows, synth_window
+    distinct = min(B, 24)
+    wins = [WindowBuilder(synth_window(7000 + s, 12, 8.0, 25)).calls() for s in range(distinct)]
+    wins = (wins * ((B + distinct - 1) // distinct))[:B]
+    plans, _ = batch_windows(wins, device='cpu')
+    return plans[-1].graph.to(device)
+
+
+def test_window_plan_lists_every_incidence_once_in_run_order():
+    """build_win_plan on the CPU: every det's run is its CSR run, re-addressed as places in its window's edge list (ascending),
+    sign kept; windows beyond the kernel's capacity are listed for the CSR kernel; a crossing edge declines the plan."""
+    from trackmpnn_amd.graph import build_win_plan, WIN_CAP_DETS
+    g = _window_batch_graph(12, 'cpu')
+    dg = g.__dict__['_det_group']
+    wp = build_win_plan(g, dg)
+    assert wp is not None and wp.W == 12 and wp.nbig == 0
+    wrec, erow, rptr, slot, det, drow, _ = wp.t
+    seen = torch.zeros(2 * g.E, dtype=torch.int64)
+    rp, inc = g.rowptr.long(), g.inc.long()
+    for w in range(wp.W):
+        e0, ne, q0, nd, r0 = (int(v) for v in wrec[w, :5])
+        assert r0 == int(rptr[q0]) and r0 % 2 == 0
+        rows = erow[e0:e0 + ne].long()
+        assert bool((rows[1:] > rows[:-1]).all())
+        for q in range(q0, q0 + nd):
+            d = int(det[q])
+            assert int(drow[q]) == int(g.det_row[d])
+            run = slot[int(rptr[q]):int(rptr[q + 1])].long() & 0xffff
+            csr = inc[int(rp[d]):int(rp[d + 1])]
+            assert torch.equal(rows[run & 0x7fff], csr & 0x7fffffff) and torch.equal((run & 0x8000) != 0, csr < 0)
+            seen[int(rp[d]):int(rp[d + 1])] += 1
+    assert bool((seen == 1).all())
+    # four windows under one label: more dets than a lane group keeps sums for -> that window goes to the CSR kernel
+    merged = torch.where(dg < 4, torch.zeros_like(dg), dg)
+    wp2 = build_win_plan(g, merged)
+    assert wp2 is not None and wp2.W == 9 and wp2.nbig > WIN_CAP_DETS
+    assert sorted(wp2.t[6].tolist()) == torch.nonzero(merged == 0).flatten().tolist()
+    # labels that cut through a window: an edge would cross -> no plan
+    assert build_win_plan(g, torch.arange(g.Dn) % 2) is None
+
+
+@pytest.mark.gpu
+def test_window_segsum_reads_rows_once_and_equals_the_csr_kernel_bitwise():
+    """tmpnn_segsum_fwd with a tmpnn_win_plan on the graph (k_segsum_win: chunks of a window's edge rows staged in LDS once, the
+    dets' partial sums in registers) against the same entry point without one (k_segsum_pipe): BITWISE equal -- the same lane
+    groups take the same positions of a run in the same order.  Compact and scattered output, accumulate on and off, a column
+    block of a wider row, a window beyond the kernel's capacity (served by the CSR kernel through the plan's list)."""
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU')
+    import copy
+    from trackmpnn_amd import _lib
+    from trackmpnn_amd.graph import build_win_plan, win_plan
+    dev = torch.device('cuda:0')
+    g = _window_batch_graph(200, dev)
+    dg = g.__dict__['_det_group']
+    g0 = copy.copy(g)                                   # the same graph without a plan
+    g0.__dict__.pop('_win_plan', None)
+    g0.__dict__.pop('_det_group', None)
+    g0._c = None
+    assert win_plan(g) is not None and win_plan(g).nbig == 0 and g.cstruct().win_plan and not g0.cstruct().win_plan
+    g2 = copy.copy(g)                                   # windows 0..3 as one: beyond the capacity
+    g2._c = None
+    g2.__dict__['_win_plan'] = build_win_plan(g, torch.where(dg < 4, torch.zeros_like(dg), dg))
+    assert g2.__dict__['_win_plan'].nbig > 0
+    H, LD = 64, 192
+    st = _lib.raw_stream()
+    gen = torch.Generator().manual_seed(5)
+    x = torch.randn(g.N, LD, generator=gen).to(dev)
+    for c0, compact, acc in ((0, 1, 0), (64, 1, 1), (128, 0, 1), (0, 0, 0)):
+        rows = g.Dn if compact else g.N
+        base = torch.randn(rows, H, generator=gen).to(dev)
+        outs = []
+        for graph in (g0, g, g2, g):
+            o = base.clone()
+            _lib.call('tmpnn_segsum_fwd', graph.cref(), x.data_ptr() + 4 * c0, LD, o.data_ptr(), H, H, acc, compact, st)
+            outs.append(o)
+        torch.cuda.synchronize()
+        if not compact:                                 # (edge rows of a scattered output are not written)
+            keep = g.det_row.long()
+            outs = [o[keep] for o in outs]
+        for o in outs[1:]:
+            assert torch.equal(outs[0], o), (c0, compact, acc)

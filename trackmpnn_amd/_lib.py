@@ -17,7 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('TMPNN_LIB_PATH') or os.path.join(_HERE, 'lib', 'libtmpnn.so')
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), 'include', 'tmpnn.h')
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 c_int = C.c_int
 c_void_p = C.c_void_p
@@ -31,11 +31,18 @@ class CSegPlan(C.Structure):
                 ('rowptr2', c_void_p), ('inc2', c_void_p), ('ws', c_void_p), ('ws_floats', c_size_t)]
 
 
+class CWinPlan(C.Structure):
+    """struct tmpnn_win_plan (include/tmpnn.h): the single-read segment sum of a batch of small windows."""
+    _fields_ = [('W', C.c_int32), ('nbig', C.c_int32), ('wrec', c_void_p), ('erow', c_void_p),
+                ('rptr', c_void_p), ('slot', c_void_p), ('det', c_void_p), ('drow', c_void_p), ('big_order', c_void_p)]
+
+
 class CGraph(C.Structure):
     """struct tmpnn_graph (include/tmpnn.h)."""
     _fields_ = [('N', C.c_int32), ('E', C.c_int32), ('Dn', C.c_int32),
                 ('src', c_void_p), ('dst', c_void_p), ('edge_row', c_void_p), ('det_row', c_void_p),
-                ('rowptr', c_void_p), ('inc', c_void_p), ('det_order', c_void_p), ('seg_plan', c_void_p)]
+                ('rowptr', c_void_p), ('inc', c_void_p), ('det_order', c_void_p), ('seg_plan', c_void_p),
+                ('win_plan', c_void_p)]
 
 
 _GP = C.POINTER(CGraph)

@@ -541,6 +541,292 @@ static int segsum_dense(const tmpnn_graph* g, const tmpnn_seg_plan* pl, const fl
     return check_launch("segsum (dense form, second pass)");
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// segment sum of a BATCH OF SMALL WINDOWS with every edge row read once (round 5, struct tmpnn_win_plan)
+// ------------------------------------------------------------------------------------------------------------
+// k_segsum_pipe reads an edge row from either endpoint: 2 x 256 B per edge at H = 64, through a memory pipe that gives a CU
+// ~13 bytes per clock whatever the access pattern (the kernel's 0.42 ms per 6 M edges IS that rate).  A window of the rolling
+// graph is ~100 dets and 1-2 k edge rows that touch nothing outside it (373 KB of rows at H = 64: more than the LDS).  Here a
+// workgroup owns (window, column half) JOBS; it walks the window's edge rows in ascending order in CHUNKS of 512 rows, staged in
+// LDS once each (LDS-DMA, 128-byte row halves; the next chunk travels while this one is summed), and every det consumes the part
+// of its CSR run that lies in the chunk -- a run is ascending in edge row, so that part is a contiguous piece of it and the det's
+// lane groups simply carry on where they stopped.  The partial sums of a det stay in REGISTERS from the window's first chunk to its
+// last (8 dets per lane group: 256 dets per window), which is what makes the sums those of k_segsum_pipe BIT FOR BIT: the same
+// lane group takes the same strided positions of the run in the same order, and the groups are combined by the same xor tree at
+// the end -- only where a row comes from differs.  The window-major metadata (edge rows of a window, its dets' runs as 16-bit
+// places in that list, output rows) is built once per graph by the host (trackmpnn_amd.graph.win_plan); windows beyond the
+// capacities below are listed in the plan and take the CSR kernel.
+static constexpr int SW_CH = 512;                                     // edge rows of a chunk
+static constexpr int SW_MAXE = 3072, SW_MAXD = 256;                   // edge rows / dets of a window served here
+static constexpr int SW_NW = 16, SW_NPASS = SW_MAXD / (2 * SW_NW);    // waves; dets per lane group (two dets per wave and pass)
+static constexpr int SW_ROWS = SW_CH * 128;                           // bytes of a row buffer (128-byte row halves)
+// metadata of a job, each array rounded up to the 256-byte pieces it is staged in: rptr [nd + 1] | slot [2 ne] u16
+static constexpr int sw_pad(int bytes) { return (bytes + 255) & ~255; }
+static constexpr int SW_M_SLOT = sw_pad(4 * (SW_MAXD + 1)), SW_META_P = SW_M_SLOT + sw_pad(4 * SW_MAXE);
+static constexpr size_t SW_SHM = 2 * (size_t)SW_ROWS + 2 * SW_META_P;
+static_assert(SW_SHM <= 160 * 1024, "k_segsum_win: two chunks and two windows' metadata must fit the LDS");
+
+__device__ __forceinline__ uint32_t sw_lds_addr(const void* p) {
+    return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)(const char*)p;
+}
+// 16 bytes (DW = 4) or 4 bytes (DW = 1) per lane from a per-lane global address to (uniform LDS address) + DW * 4 * lane
+template <int DW>
+__device__ __forceinline__ void sw_glds(const void* gsrc, uint32_t lds_wave_base) {
+    unsigned keep;
+    lds_wave_base = __builtin_amdgcn_readfirstlane(lds_wave_base);
+    if constexpr (DW == 4)
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(gsrc), "s"(lds_wave_base) : "memory");
+    else
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(gsrc), "s"(lds_wave_base) : "memory");
+}
+
+#if (defined(SW_NOREDUCE) || defined(SW_NOSTAGE) || defined(SW_NOWRITE) || defined(SW_PASSES)) && !defined(TMPNN_ABLATE)
+#error "SW_NOREDUCE / SW_NOSTAGE are wrong-result timing ablations: build them with tools/build_variant.sh (-DTMPNN_ABLATE)"
+#endif
+struct SwJob { int j, hf, e0, ne, q0, nd, r0, nch, mb; };             // nch = 0: no further job
+
+// a window's record, by ONE scalar load: the compiler turns plain uniform loads of a kernel that also stores into vector loads
+// and waits for them with vmcnt -- which would wait for the chunk requests issued just before
+__device__ __forceinline__ void sw_window(const int32_t* wrec, int w, SwJob& jb) {
+    typedef int sw_v8 __attribute__((ext_vector_type(8)));
+    sw_v8 r;
+    const int32_t* p = wrec + 8 * (size_t)w;
+    asm volatile("s_load_dwordx8 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(r) : "s"(p) : "memory");
+    jb.e0 = r[0]; jb.ne = r[1]; jb.q0 = r[2]; jb.nd = r[3]; jb.r0 = r[4];
+}
+
+template <bool ACC>
+__global__ __launch_bounds__(1024) void k_segsum_win(tmpnn_win_plan pl, const float* __restrict__ in, int ld_in,
+                                                     float* __restrict__ out, int ld_out, int compact_out) {
+    extern __shared__ __attribute__((aligned(16))) char sw_lds[];
+    constexpr int NG = 4, U = 4, NW = SW_NW, NPASS = SW_NPASS, PPW = SW_CH / 8 / NW;
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int njob = 2 * pl.W, G = gridDim.x;
+    const int hl = lane >> 5, grp = (lane & 31) >> 3, c4 = (lane & 7) * 4;
+    auto m_rptr = [&](int b) { return reinterpret_cast<int*>(sw_lds + 2 * SW_ROWS + b * SW_META_P); };
+    auto m_slot = [&](int b) { return reinterpret_cast<uint16_t*>(sw_lds + 2 * SW_ROWS + b * SW_META_P + SW_M_SLOT); };
+    // the first job at or after j that this kernel serves (uniform scalar loads)
+    auto job_at = [&](int j, int mb) {
+        SwJob jb{j, 0, 0, 0, 0, 0, 0, 0, mb};
+        for (; jb.j < njob; jb.j += G) {
+            jb.hf = jb.j & 1;
+            sw_window(pl.wrec, jb.j >> 1, jb);
+            if (jb.ne <= SW_MAXE && jb.nd <= SW_MAXD && jb.nd > 0) {
+                jb.nch = jb.ne > 0 ? (jb.ne + SW_CH - 1) / SW_CH : 1;      // (a window without edges still writes its zeros)
+                break;
+            }
+        }
+        return jb;
+    };
+    auto advance = [&](SwJob& jb, int& c) {                               // the item after (jb, c)
+        if (c + 1 < jb.nch) ++c;
+        else { jb = job_at(jb.j + G, jb.mb ^ 1); c = 0; }
+    };
+    // the edge-row ids a lane needs for its pieces of a chunk (piece = 8 rows; lane -> row lane / 8): loaded an item ahead
+    auto load_ids = [&](const SwJob& jb, int c, int (&ids)[PPW]) {
+#pragma unroll
+        for (int k = 0; k < PPW; ++k) {
+            const int seg = c * SW_CH + 8 * (wv + NW * k) + (lane >> 3);
+            ids[k] = (jb.nch > 0 && c * SW_CH + 8 * (wv + NW * k) < jb.ne) ? pl.erow[jb.e0 + min(seg, jb.ne - 1)] : 0;
+        }
+    };
+    // requests of an item into row buffer b: its row halves, and with a job's first chunk the job's metadata
+    auto stage = [&](const SwJob& jb, int c, const int (&ids)[PPW], int b) {
+        if (jb.nch == 0) return;
+        const uint32_t rows_a = sw_lds_addr(sw_lds + b * SW_ROWS);
+#pragma unroll
+        for (int k = 0; k < PPW; ++k) {
+            const int piece = wv + NW * k;
+#ifdef SW_NOSTAGE
+            if (c * SW_CH + 8 * piece < jb.ne && c == 0 && jb.j < 2 * (int)gridDim.x)
+#else
+            if (c * SW_CH + 8 * piece < jb.ne)
+#endif
+                sw_glds<4>(in + (size_t)ids[k] * ld_in + 32 * jb.hf + c4, rows_a + 1024u * piece);
+        }
+        if (c != 0) return;
+        // rptr [nd + 1] and slot [2 ne] (as ne dwords): 256-byte pieces dealt round the waves
+        const int n_r = (jb.nd + 1 + 63) >> 6, n_s = (jb.ne + 63) >> 6;
+        for (int x = wv; x < n_r + n_s; x += NW) {
+            if (x < n_r)
+                sw_glds<1>(pl.rptr + jb.q0 + min(64 * x + lane, jb.nd), sw_lds_addr(m_rptr(jb.mb)) + 256u * x);
+            else
+                sw_glds<1>(reinterpret_cast<const int32_t*>(pl.slot + jb.r0) + min(64 * (x - n_r) + lane, jb.ne - 1),
+                           sw_lds_addr(m_slot(jb.mb)) + 256u * (x - n_r));
+        }
+    };
+    // the output rows of a job's dets, per pass of this lane (loaded an item ahead of the job's first chunk)
+    auto load_orow = [&](const SwJob& jb, int (&orow)[NPASS]) {
+#pragma unroll
+        for (int k = 0; k < NPASS; ++k) {
+            const int ql = 2 * NW * k + 2 * wv + hl;
+            orow[k] = (jb.nch > 0 && ql < jb.nd) ? (compact_out ? pl.det[jb.q0 + ql] : pl.drow[jb.q0 + ql]) : -1;
+        }
+    };
+    SwJob ja = job_at(blockIdx.x, 0);
+    if (ja.nch == 0) return;
+    int ca = 0, cb = 0, cc;
+    SwJob jb = ja;
+    advance(jb, cb);
+    int ids_b[PPW], ids_c[PPW], orow[NPASS], cur[NPASS];
+    float4 acc[NPASS], prev[NPASS / 4];                           // prev: lane group g keeps it for the passes k = g (mod 4)
+    load_ids(ja, 0, ids_c);
+    load_orow(ja, orow);
+    load_ids(jb, cb, ids_b);
+    stage(ja, 0, ids_c, 0);
+    int b = 0;
+    for (;;) {
+        // this item's rows (and metadata), the stores of the job before.  The builtin, not inline asm: the compiler's own
+        // wait-count bookkeeping then knows that every load of the last iteration has landed and adds no wait of its own behind
+        // the chunk requests below (it cannot see those: they are asm)
+        __builtin_amdgcn_s_waitcnt(0x0F70);                       // vmcnt(0)
+        asm volatile("" ::: "memory");
+        __syncthreads();
+        // the item after this one travels while this one is summed; the indices of the one after that are loaded behind it
+        stage(jb, cb, ids_b, b ^ 1);
+        SwJob jc = jb;
+        cc = cb;
+        if (jb.nch > 0) advance(jc, cc);
+        load_ids(jc, cc, ids_c);
+        const int r0 = ja.r0, c0 = ca * SW_CH, c1 = min(ja.ne, c0 + SW_CH);
+        const int* rp = m_rptr(ja.mb);
+        const uint16_t* sl = m_slot(ja.mb);
+        if (ca == 0) {
+#pragma unroll
+            for (int k = 0; k < NPASS; ++k) {
+                const int ql = 2 * NW * k + 2 * wv + hl;
+                cur[k] = (2 * NW * k < ja.nd && ql < ja.nd) ? rp[ql] - r0 + grp : 0;
+                acc[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            if (ACC) {                                            // what the sums are added to, fetched well ahead of the job's end
+#pragma unroll
+                for (int i = 0; i < NPASS / 4; ++i) {             // (ONE load per register quad: a second one would wait for the first)
+                    const int r = grp == 0 ? orow[4 * i] : grp == 1 ? orow[4 * i + 1] : grp == 2 ? orow[4 * i + 2] : orow[4 * i + 3];
+                    // (unconditional, row 0 for a det that is not there: a load under a branch is waited for at the join)
+                    prev[i] = *reinterpret_cast<const float4*>(out + (size_t)max(r, 0) * ld_out + 32 * ja.hf + c4);
+                }
+            }
+        }
+        const float* rows = reinterpret_cast<const float*>(sw_lds + b * SW_ROWS);
+#ifdef SW_NOREDUCE
+        if (ja.j < 0)
+#endif
+#pragma unroll
+        for (int k = 0; k < NPASS; ++k) {
+            if (2 * NW * k >= ja.nd) continue;                    // (uniform)
+#ifdef SW_PASSES
+            if (k >= SW_PASSES) continue;
+#endif
+            const int ql = 2 * NW * k + 2 * wv + hl;
+            const int p1 = ql < ja.nd ? rp[ql + 1] - r0 : 0;
+            int p = cur[k];
+            for (;;) {
+                unsigned s16[U];
+                bool live[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int pp = p + u * NG;
+                    s16[u] = pp < p1 ? sl[pp] : 0x7fffu;
+                    live[u] = (int)(s16[u] & 0x7fffu) < c1;        // (0x7fff: beyond any chunk)
+                }
+                if (__builtin_amdgcn_ballot_w64(live[0]) == 0) break;
+                float4 x[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+                    x[u] = *reinterpret_cast<const float4*>(rows + (live[u] ? (int)(s16[u] & 0x7fffu) - c0 : 0) * 32 + c4);
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const float w = (s16[u] & 0x8000u) ? -1.0f : 1.0f;
+                    if (live[u]) {
+                        x[u].x *= w; x[u].y *= w; x[u].z *= w; x[u].w *= w;
+                        acc[k].x += x[u].x; acc[k].y += x[u].y; acc[k].z += x[u].z; acc[k].w += x[u].w;
+                        p += NG;
+                    }
+                }
+                if (__builtin_amdgcn_ballot_w64(live[U - 1]) == 0) break;
+            }
+            cur[k] = p;
+        }
+#ifdef SW_NOWRITE
+        if (ca == ja.nch - 1 && ja.j < 0) {
+#else
+        if (ca == ja.nch - 1) {
+#endif
+            // the window's last chunk: combine the lane groups (k_segsum_pipe's tree) and write
+            if (ACC) {                                            // (one wait for the fetched rows here, none between the stores)
+#pragma unroll
+                for (int i = 0; i < NPASS / 4; ++i)
+                    asm volatile("" : "+v"(prev[i].x), "+v"(prev[i].y), "+v"(prev[i].z), "+v"(prev[i].w));
+            }
+#pragma unroll
+            for (int k = 0; k < NPASS; ++k) {
+                if (2 * NW * k >= ja.nd) continue;
+                float4 a = acc[k];
+#pragma unroll
+                for (int off = 8; off < 32; off <<= 1) {
+                    a.x += __shfl_xor(a.x, off);
+                    a.y += __shfl_xor(a.y, off);
+                    a.z += __shfl_xor(a.z, off);
+                    a.w += __shfl_xor(a.w, off);
+                }
+                if (ACC) {                                        // (group 0 takes it from the group that fetched it)
+                    const int from = lane + 8 * (k & 3);
+                    a.x += __shfl(prev[k >> 2].x, from);
+                    a.y += __shfl(prev[k >> 2].y, from);
+                    a.z += __shfl(prev[k >> 2].z, from);
+                    a.w += __shfl(prev[k >> 2].w, from);
+                }
+                if (orow[k] >= 0 && grp == 0) {
+                    *reinterpret_cast<float4*>(out + (size_t)orow[k] * ld_out + 32 * ja.hf + c4) = a;
+                }
+            }
+        }
+        if (jb.nch == 0) break;
+        if (cb == 0) load_orow(jb, orow);                         // (item b opens a job: its output rows, there by the next barrier)
+        ja = jb; ca = cb; jb = jc; cb = cc;
+#pragma unroll
+        for (int k = 0; k < PPW; ++k) ids_b[k] = ids_c[k];
+        b ^= 1;
+    }
+}
+
+static int cu_count() {
+    static const int v = [] {
+        int dev = 0, cus = 256;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        return cus > 0 ? cus : 256;
+    }();
+    return v;
+}
+
+static int segsum_win(const tmpnn_graph* g, const tmpnn_win_plan* pl, const float* in, int ld_in, float* out, int ld_out,
+                      int accumulate, int compact_out, hipStream_t st) {
+    TM_REQUIRE(pl->W > 0 && pl->wrec && pl->erow && pl->rptr && pl->slot && pl->det && pl->drow &&
+                   (pl->nbig == 0 || pl->big_order), "segsum: incomplete window plan");
+    const int njob = 2 * pl->W, cus = cu_count();
+    dim3 grid(njob < cus ? njob : cus), block(1024);
+    if (accumulate) {
+        TM_SHM_ONCE((k_segsum_win<true>), SW_SHM);
+        hipLaunchKernelGGL((k_segsum_win<true>), grid, block, SW_SHM, st, *pl, in, ld_in, out, ld_out, compact_out);
+    } else {
+        TM_SHM_ONCE((k_segsum_win<false>), SW_SHM);
+        hipLaunchKernelGGL((k_segsum_win<false>), grid, block, SW_SHM, st, *pl, in, ld_in, out, ld_out, compact_out);
+    }
+    int rc = check_launch("segsum (window-owned form)");
+    if (rc || pl->nbig == 0) return rc;
+    // the windows beyond the LDS capacity: the CSR kernel over their dets (its visiting order = the plan's list)
+    dim3 g2(grid_for(pl->nbig, 32));
+    if (accumulate)
+        hipLaunchKernelGGL((k_segsum_pipe<true, 4, 32>), g2, dim3(256), 0, st, pl->nbig, g->det_row, g->rowptr, g->inc, pl->big_order,
+                           in, ld_in, out, ld_out, 64, -1.0f, 0, compact_out);
+    else
+        hipLaunchKernelGGL((k_segsum_pipe<false, 4, 32>), g2, dim3(256), 0, st, pl->nbig, g->det_row, g->rowptr, g->inc, pl->big_order,
+                           in, ld_in, out, ld_out, 64, -1.0f, 0, compact_out);
+    return check_launch("segsum (windows beyond the LDS capacity)");
+}
+
 static int segsum(const tmpnn_graph* g, const float* in, int ld_in, float* out, int ld_out, int H, int accumulate,
                   float wneg, int cneg, int compact_out, tmpnn_stream stream) {
     int rc = check_graph(g);
@@ -551,6 +837,10 @@ static int segsum(const tmpnn_graph* g, const float* in, int ld_in, float* out, 
     hipStream_t st = as_stream(stream);
     if (g->seg_plan && H == 256 && wneg == -1.0f && cneg == 0)        // dense graph with a plan: every edge row read once
         return segsum_dense(g, g->seg_plan, in, ld_in, out, ld_out, accumulate, compact_out, st);
+    // a batch of small windows with a plan, enough of them to fill the chip: every edge row read once
+    if (g->win_plan && H == 64 && wneg == -1.0f && cneg == 0 && 2 * g->win_plan->W >= cu_count() &&
+        ld_in % 4 == 0 && ld_out % 4 == 0 && (((uintptr_t)in | (uintptr_t)out) & 15) == 0)
+        return segsum_win(g, g->win_plan, in, ld_in, out, ld_out, accumulate, compact_out, st);
     dim3 grid(grid_for(g->Dn, 64)), block(256);
 #define LS(K, A) hipLaunchKernelGGL((K<A>), grid, block, 0, st, g->Dn, g->det_row, g->rowptr, g->inc, g->det_order, in, ld_in, out, ld_out, H, wneg, cneg, compact_out)
 #define LSP(A, UU, CH)                                                                                       \

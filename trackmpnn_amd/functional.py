@@ -17,7 +17,7 @@ from typing import Dict, List, Optional, Sequence, Tuple
 import torch
 
 from . import _lib
-from .graph import CallPlan, dense_seg_plan, edge_tiles
+from .graph import CallPlan, dense_seg_plan, edge_tiles, win_plan
 
 ATT_DROPOUT_P = 0.5
 # OPT-IN fast path: accumulate parameter gradients straight into existing p.grad buffers (the kernels add into their
@@ -67,6 +67,9 @@ INPUT_TF = _variant('TMPNN_INPUT_TF', '1') != '0'
 # reads them.  Same gradients bit for bit; measured SLOWER (numbers in DESIGN), so off by default.
 RECOMPUTE_GATES = _variant('TMPNN_RECOMPUTE_GATES', '0') == '1'
 CONCAT_PROJ = _variant('TMPNN_CONCAT_PROJ', '1') != '0'
+# the window-owned segment sum (csrc/agg.hip k_segsum_win) on graphs with window labels: bit-equal to the CSR kernel, 0.70 ms
+# against its 0.43 ms per 6 M edges on MI355X -- kept opt-in
+WIN_SEGSUM = _variant('TMPNN_SEGSUM_WIN', '0') == '1'
 WIDE_FUSED_ADJOINT = _variant('TMPNN_WIDE_FUSED_ADJOINT', '1') != '0'
 _aux_streams: Dict[torch.device, 'torch.cuda.Stream'] = {}
 
@@ -366,6 +369,10 @@ def mp_forward(spec: ModelSpec, plan: CallPlan, x: torch.Tensor, h_in: Optional[
         # dense scenes: the plan of the single-read segment sum rides on the graph's C struct (tmpnn_segsum_fwd here and inside
         # the wide backward take it on 256-column blocks); None for ragged graphs
         dense_seg_plan(g)
+    if WIN_SEGSUM and H == 64 and E > 0:
+        # batches of small windows (batch_windows): the plan of the window-owned segment sum rides on the graph's C struct
+        # (None for graphs without window labels).  Opt-in: measured slower than the CSR kernel
+        win_plan(g)
     wide_preps = []
     # output head fused into the cells' epilogues where the LDS-resident kernel runs (else tmpnn_heads_fwd)
     cw = min(lib.tmpnn_gru_fwd_head_parts(H, H if use_proj_cat else spec.IN_e, 3 if (use_proj or use_proj_cat) else xmode),

@@ -52,19 +52,23 @@ class FrameGraph:
         if torch.device(device) == self.device:
             return self
         mv = lambda t: t.to(device)
-        return FrameGraph(self.N, self.E, self.Dn, mv(self.src), mv(self.dst), mv(self.edge_row), mv(self.det_row),
-                          mv(self.rowptr), mv(self.inc), mv(self.is_edge), mv(self.pos),
-                          None if self.src_pos is None else mv(self.src_pos),
-                          None if self.dst_pos is None else mv(self.dst_pos),
-                          None if self.det_order is None else mv(self.det_order))
+        g = FrameGraph(self.N, self.E, self.Dn, mv(self.src), mv(self.dst), mv(self.edge_row), mv(self.det_row),
+                       mv(self.rowptr), mv(self.inc), mv(self.is_edge), mv(self.pos),
+                       None if self.src_pos is None else mv(self.src_pos),
+                       None if self.dst_pos is None else mv(self.dst_pos),
+                       None if self.det_order is None else mv(self.det_order))
+        if '_det_group' in self.__dict__:                         # (the window labels: win_plan() is rebuilt over there)
+            g.__dict__['_det_group'] = mv(self.__dict__['_det_group'])
+        return g
 
     def cstruct(self) -> _lib.CGraph:
         if self._c is None:
-            plan = self.__dict__.get('_seg_plan')
+            plan, wplan = self.__dict__.get('_seg_plan'), self.__dict__.get('_win_plan')
             self._c = _lib.CGraph(self.N, self.E, self.Dn, self.src.data_ptr(), self.dst.data_ptr(),
                                   self.edge_row.data_ptr(), self.det_row.data_ptr(), self.rowptr.data_ptr(),
                                   self.inc.data_ptr(), _lib.ptr(self.det_order),
-                                  None if plan is None else C.addressof(plan.c))
+                                  None if plan is None else C.addressof(plan.c),
+                                  None if wplan is None else C.addressof(wplan.c))
         return self._c
 
     def cref(self):
@@ -306,8 +310,98 @@ def set_det_groups(graph: FrameGraph, det_group) -> FrameGraph:
     if dg.numel() != graph.Dn:
         raise ValueError('set_det_groups: one label per det expected')
     graph.det_order = torch.argsort(dg, stable=True).to(torch.int32).contiguous()
+    graph.__dict__['_det_group'] = dg
+    graph.__dict__.pop('_win_plan', None)
     graph._c = None
     return graph
+
+
+WIN_CAP_EDGES, WIN_CAP_DETS = 3072, 256     # csrc/agg.hip SW_MAXE / SW_MAXD: a window's edge rows / dets the kernel serves
+
+
+class WinPlan:
+    """struct tmpnn_win_plan (include/tmpnn.h) with the tensors it points at."""
+
+    def __init__(self, W, nbig, wrec, erow, rptr, slot, det, drow, big_order):
+        self.W, self.nbig = int(W), int(nbig)
+        self.t = (wrec, erow, rptr, slot, det, drow, big_order)
+        assert wrec.data_ptr() % 32 == 0
+        self.c = _lib.CWinPlan(self.W, self.nbig, wrec.data_ptr(), erow.data_ptr(), rptr.data_ptr(),
+                               slot.data_ptr(), det.data_ptr(), drow.data_ptr(), _lib.ptr(big_order))
+
+
+def build_win_plan(graph: FrameGraph, det_group: torch.Tensor) -> Optional[WinPlan]:
+    """The window-owned segment sum's plan (struct tmpnn_win_plan; csrc/agg.hip k_segsum_win) of a block-diagonal batch of small
+    windows -- the graphs batch_windows() builds out of the reference's rolling windows (reference/utils/graph.py:141-156: a
+    window's edges join dets of that window only).
+
+    Everything is listed window by window: the window's edge rows (ascending), its dets in det order (= the visiting order
+    set_det_groups gives), and per det its CSR run rewritten as 16-bit indices into the window's edge list, sign bit kept.
+    Returns None when an edge crosses windows or when too few edges sit in windows that fit the kernel's LDS.  Index plumbing
+    on the graph's device; two host reads."""
+    if graph.src_pos is None or graph.dst_pos is None or graph.E == 0 or graph.Dn == 0:
+        return None
+    dev, E, Dn = graph.device, graph.E, graph.Dn
+    i32 = lambda t: t.to(torch.int32).contiguous()
+    uw, wdet = torch.unique(det_group, return_inverse=True)
+    s, d = graph.src_pos.long(), graph.dst_pos.long()
+    wedge = wdet[s]
+    # (a run of the CSR ascends in edge row -- graph_from_edges keeps it so; the kernel consumes runs chunk by chunk on that)
+    rows_p = graph.inc.long() & 0x7fffffff
+    starts = torch.zeros(2 * E, dtype=torch.bool, device=dev)
+    starts[graph.rowptr.long()[:-1][graph.rowptr.long()[:-1] < 2 * E]] = True
+    unsorted_run = ((rows_p[1:] <= rows_p[:-1]) & ~starts[1:]).any()
+    W, bad = int(uw.numel()), bool((wedge != wdet[d]).any() | unsorted_run)   # (host read)
+    if bad:
+        return None
+    order = torch.argsort(wdet, stable=True)                               # visiting position -> det index
+    vis = torch.empty_like(order)
+    vis[order] = torch.arange(Dn, device=dev)
+    dptr = torch.zeros(W + 1, dtype=torch.long, device=dev)
+    dptr[1:] = torch.cumsum(torch.bincount(wdet, minlength=W), 0)
+    eorder = torch.argsort(wedge, stable=True)                             # edge indices window by window, rows ascending
+    eptr = torch.zeros(W + 1, dtype=torch.long, device=dev)
+    eptr[1:] = torch.cumsum(torch.bincount(wedge, minlength=W), 0)
+    local = torch.empty(E, dtype=torch.long, device=dev)                   # edge index -> its place in its window's list
+    local[eorder] = torch.arange(E, device=dev) - eptr[wedge[eorder]]
+    rowptr = graph.rowptr.long()
+    deg = rowptr[1:] - rowptr[:-1]
+    rptr = torch.zeros(Dn + 1, dtype=torch.long, device=dev)
+    rptr[1:] = torch.cumsum(deg[order], 0)
+    det_of_p = torch.repeat_interleave(torch.arange(Dn, device=dev), deg)  # CSR position -> det index
+    newpos = rptr[vis[det_of_p]] + torch.arange(2 * E, device=dev) - rowptr[det_of_p]
+    inc = graph.inc.long()
+    e_of_p = graph.pos.long()[inc & 0x7fffffff]
+    v = (local[e_of_p] & 0x7fff) | torch.where(inc < 0, 0x8000, 0)
+    slot = torch.empty(2 * E, dtype=torch.int16, device=dev)
+    slot[newpos] = torch.where(v >= 0x8000, v - 0x10000, v).to(torch.int16)
+    big_w = ((eptr[1:] - eptr[:-1]) > WIN_CAP_EDGES) | ((dptr[1:] - dptr[:-1]) > WIN_CAP_DETS)
+    big_order = order[big_w[wdet[order]]]
+    nbig, e_big = int(big_order.numel()), int((eptr[1:] - eptr[:-1])[big_w].sum())   # (host read)
+    if 2 * e_big > E:
+        return None
+    wrec = torch.zeros(W, 8, dtype=torch.long, device=dev)
+    wrec[:, 0], wrec[:, 1] = eptr[:-1], eptr[1:] - eptr[:-1]
+    wrec[:, 2], wrec[:, 3] = dptr[:-1], dptr[1:] - dptr[:-1]
+    wrec[:, 4] = rptr[dptr[:-1]]
+    return WinPlan(W, nbig, i32(wrec), i32(graph.edge_row.long()[eorder]), i32(rptr), slot, i32(order),
+                   i32(graph.det_row.long()[order]), i32(big_order) if nbig else None)
+
+
+def win_plan(graph: FrameGraph) -> Optional[WinPlan]:
+    """The graph's cached window plan (None without det groups or where build_win_plan declines), attached to the graph's C
+    struct: the segment sums at H = 32 / 64 then read every edge row once.  Not built inside a stream capture (host reads):
+    there the call returns None without caching and the CSR kernel serves the graph."""
+    d = graph.__dict__
+    if '_win_plan' not in d:
+        dg = d.get('_det_group')
+        if dg is None:
+            return None
+        if dg.is_cuda and torch.cuda.is_current_stream_capturing():
+            return None
+        d['_win_plan'] = build_win_plan(graph, dg)
+        graph._c = None                                           # (the C struct carries the plan's address)
+    return d['_win_plan']
 
 
 def graph_from_edges(N: int, is_edge: torch.Tensor, src: torch.Tensor, dst: torch.Tensor,
