@@ -70,20 +70,22 @@ typedef struct tmpnn_seg_plan {
 } tmpnn_seg_plan;
 
 /* Optional plan of a BATCH OF SMALL WINDOWS (block-diagonal: no edge crosses windows) for the edge -> det segment sum at H = 64
- * (csrc/agg.hip, k_segsum_win): a workgroup owns a window at a time, walks its edge rows through the LDS in chunks, once, and every
- * det consumes its run out of LDS -- each edge row is read from memory ONCE instead of once per endpoint; results equal the CSR
- * kernel's bit for bit.  Built by
- * the host once per graph (trackmpnn_amd.graph.win_plan) from the window label of every det; the caller owns the arrays. */
+ * (csrc/agg.hip, k_segsum_win): a workgroup owns a window at a time and walks its edge rows through the LDS in chunks of 160, once
+ * -- each edge row is read from memory ONCE instead of once per endpoint; results equal the CSR kernel's bit for bit.  Incidence i
+ * of a det's CSR run belongs to the stream (det, i % 4); stream s of a window's (window-local) dets is added to by lane group
+ * s % 128 of the workgroup.  Built by the host once per graph (trackmpnn_amd.graph.build_win_plan) from the window label of every
+ * det; the caller owns the arrays. */
 typedef struct tmpnn_win_plan {
     int32_t W;                /* windows */
-    int32_t nbig;             /* dets of the windows beyond the kernel's capacity (3072 edge rows / 256 dets): CSR kernel */
-    const int32_t* wrec;      /* [W][8] per window: first entry / count in erow, first visiting position (entry of det / drow /
-                                       rptr) / count of its dets, rptr[first visiting position], 0, 0, 0; 32-byte aligned */
-    const int32_t* erow;      /* [E]   edge rows, window by window, ascending within a window */
-    const int32_t* rptr;      /* [Dn+1] per visiting position: its run of incidences in `slot` */
-    const uint16_t* slot;     /* [2E]  per incidence, in the det's CSR order: place of its edge row in the window's part of
-                                       erow | 0x8000 where the det is the edge's later endpoint (the sign bit of tmpnn_graph.inc);
-                                       2E even-padded so that a window's part is read as whole 32-bit words */
+    int32_t nbig;             /* dets of the windows beyond the kernel's capacity (160 dets, 24 chunks, 15 steps a chunk): CSR kernel */
+    const int32_t* wrec;      /* [W][8] per window: first entry / count in erow, first visiting position (entry of det / drow) /
+                                       count of its dets (capacity + 1: left to the CSR kernel), first step in recs, and the steps of
+                                       its chunks, 4 bits each, in three words; 32-byte aligned */
+    const int32_t* erow;      /* edge rows, window by window, ascending within a window; a window's list starts at a multiple of 4 */
+    const uint16_t* recs;     /* [steps][128] per chunk and step, for each lane group: place of the edge row in the chunk | 0x100
+                                       where the det is the edge's later endpoint (the sign bit of tmpnn_graph.inc) | (stream / 128)
+                                       << 9 | 0x8000 for "nothing to do"; a lane group's records of one stream are in run order;
+                                       256-byte aligned */
     const int32_t* det;       /* [Dn]  det index per visiting position (window-major) */
     const int32_t* drow;      /* [Dn]  its graph row */
     const int32_t* big_order; /* [nbig] det indices of the windows left to the CSR kernel */

@@ -416,35 +416,65 @@ def _window_batch_graph(B, device):
     return plans[-1].graph.to(device)
 
 
-def test_window_plan_lists_every_incidence_once_in_run_order():
-    """build_win_plan on the CPU: every det's run is its CSR run, re-addressed as places in its window's edge list (ascending),
-    sign kept; windows beyond the kernel's capacity are listed for the CSR kernel; a crossing edge declines the plan."""
+def _emulate_window_kernel(g, wp, x):
+    """k_segsum_win (csrc/agg.hip) restated over the plan's records: per window and chunk, step by step, every lane group adds
+    the row its record names to the stream the record names; a det's four streams are combined as (s0 + s1) + (s2 + s3)."""
+    from trackmpnn_amd.graph import WIN_CH, WIN_NHG, WIN_CAP_DETS
+    wrec, erow, recs, det, _, _ = wp.t
+    recs = recs.long() & 0xffff
+    out = torch.full((g.Dn, x.shape[1]), float('nan'), dtype=x.dtype)
+    used = 0
+    for w in range(wp.W):
+        e0, ne, q0, nd, st = (int(v) for v in wrec[w, :5])
+        lm = [int(v) & 0xffffffff for v in wrec[w, 5:8]]
+        if nd > WIN_CAP_DETS:
+            continue
+        acc = torch.zeros(WIN_CAP_DETS * 4, x.shape[1], dtype=x.dtype)
+        for c in range((ne + WIN_CH - 1) // WIN_CH):
+            L = (lm[c // 8] >> (4 * (c % 8))) & 15
+            for s_ in range(L):
+                for hg in range(WIN_NHG):
+                    r = int(recs[(st + s_) * WIN_NHG + hg])
+                    if r & 0x8000:
+                        continue
+                    used += 1
+                    row = x[int(erow[e0 + c * WIN_CH + (r & 255)])]
+                    acc[((r >> 9) & 7) * WIN_NHG + hg] += -row if r & 0x100 else row
+            st += L
+        for q in range(nd):
+            a = acc[4 * q:4 * q + 4]
+            out[int(det[q0 + q])] = (a[0] + a[1]) + (a[2] + a[3])
+    return out, used
+
+
+def test_window_plan_adds_every_incidence_once_in_the_csr_kernels_order():
+    """build_win_plan on the CPU: the kernel's algorithm restated over the plan gives k_segsum_pipe's sums BIT FOR BIT (fp32, its
+    lane-group order: positions i, i + 4, ... of a run per group, then (g0 + g1) + (g2 + g3)) and uses every incidence once;
+    windows beyond the kernel's capacity are listed for the CSR kernel; a crossing edge declines the plan."""
     from trackmpnn_amd.graph import build_win_plan, WIN_CAP_DETS
     g = _window_batch_graph(12, 'cpu')
     dg = g.__dict__['_det_group']
+    x = torch.randn(g.N, 3, generator=torch.Generator().manual_seed(2))
+    rp, inc = g.rowptr.long(), g.inc.long()
+    ref = torch.zeros(g.Dn, 3)
+    for d in range(g.Dn):
+        a = torch.zeros(4, 3)
+        for i, p in enumerate(range(int(rp[d]), int(rp[d + 1]))):
+            v = int(inc[p])
+            a[i & 3] += -x[v & 0x7fffffff] if v < 0 else x[v & 0x7fffffff]
+        ref[d] = (a[0] + a[1]) + (a[2] + a[3])
     wp = build_win_plan(g, dg)
     assert wp is not None and wp.W == 12 and wp.nbig == 0
-    wrec, erow, rptr, slot, det, drow, _ = wp.t
-    seen = torch.zeros(2 * g.E, dtype=torch.int64)
-    rp, inc = g.rowptr.long(), g.inc.long()
-    for w in range(wp.W):
-        e0, ne, q0, nd, r0 = (int(v) for v in wrec[w, :5])
-        assert r0 == int(rptr[q0]) and r0 % 2 == 0
-        rows = erow[e0:e0 + ne].long()
-        assert bool((rows[1:] > rows[:-1]).all())
-        for q in range(q0, q0 + nd):
-            d = int(det[q])
-            assert int(drow[q]) == int(g.det_row[d])
-            run = slot[int(rptr[q]):int(rptr[q + 1])].long() & 0xffff
-            csr = inc[int(rp[d]):int(rp[d + 1])]
-            assert torch.equal(rows[run & 0x7fff], csr & 0x7fffffff) and torch.equal((run & 0x8000) != 0, csr < 0)
-            seen[int(rp[d]):int(rp[d + 1])] += 1
-    assert bool((seen == 1).all())
-    # four windows under one label: more dets than a lane group keeps sums for -> that window goes to the CSR kernel
+    out, used = _emulate_window_kernel(g, wp, x)
+    assert used == 2 * g.E and torch.equal(out, ref)
+    # four windows under one label: more dets than the kernel keeps streams for -> that window goes to the CSR kernel
     merged = torch.where(dg < 4, torch.zeros_like(dg), dg)
     wp2 = build_win_plan(g, merged)
     assert wp2 is not None and wp2.W == 9 and wp2.nbig > WIN_CAP_DETS
-    assert sorted(wp2.t[6].tolist()) == torch.nonzero(merged == 0).flatten().tolist()
+    assert sorted(wp2.t[5].tolist()) == torch.nonzero(merged == 0).flatten().tolist()
+    out2, _ = _emulate_window_kernel(g, wp2, x)
+    served = ~torch.isnan(out2[:, 0])
+    assert torch.equal(served, merged != 0) and torch.equal(out2[served], ref[served])
     # labels that cut through a window: an edge would cross -> no plan
     assert build_win_plan(g, torch.arange(g.Dn) % 2) is None
 
@@ -452,8 +482,8 @@ def test_window_plan_lists_every_incidence_once_in_run_order():
 @pytest.mark.gpu
 def test_window_segsum_reads_rows_once_and_equals_the_csr_kernel_bitwise():
     """tmpnn_segsum_fwd with a tmpnn_win_plan on the graph (k_segsum_win: chunks of a window's edge rows staged in LDS once, the
-    dets' partial sums in registers) against the same entry point without one (k_segsum_pipe): BITWISE equal -- the same lane
-    groups take the same positions of a run in the same order.  Compact and scattered output, accumulate on and off, a column
+    partial sums of a det's four streams in LDS) against the same entry point without one (k_segsum_pipe): BITWISE equal -- a
+    stream is k_segsum_pipe's lane group and is added to in the same order.  Compact and scattered output, accumulate on and off, a column
     block of a wider row, a window beyond the kernel's capacity (served by the CSR kernel through the plan's list)."""
     if not torch.cuda.is_available():
         pytest.skip('no GPU')

@@ -33,8 +33,8 @@ class CSegPlan(C.Structure):
 
 class CWinPlan(C.Structure):
     """struct tmpnn_win_plan (include/tmpnn.h): the single-read segment sum of a batch of small windows."""
-    _fields_ = [('W', C.c_int32), ('nbig', C.c_int32), ('wrec', c_void_p), ('erow', c_void_p),
-                ('rptr', c_void_p), ('slot', c_void_p), ('det', c_void_p), ('drow', c_void_p), ('big_order', c_void_p)]
+    _fields_ = [('W', C.c_int32), ('nbig', C.c_int32), ('wrec', c_void_p), ('erow', c_void_p), ('recs', c_void_p),
+                ('det', c_void_p), ('drow', c_void_p), ('big_order', c_void_p)]
 
 
 class CGraph(C.Structure):

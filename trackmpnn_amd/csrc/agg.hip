@@ -544,27 +544,34 @@ static int segsum_dense(const tmpnn_graph* g, const tmpnn_seg_plan* pl, const fl
 // ------------------------------------------------------------------------------------------------------------
 // segment sum of a BATCH OF SMALL WINDOWS with every edge row read once (round 5, struct tmpnn_win_plan)
 // ------------------------------------------------------------------------------------------------------------
-// k_segsum_pipe reads an edge row from either endpoint: 2 x 256 B per edge at H = 64, through a memory pipe that gives a CU
-// ~13 bytes per clock whatever the access pattern (the kernel's 0.42 ms per 6 M edges IS that rate).  A window of the rolling
-// graph is ~100 dets and 1-2 k edge rows that touch nothing outside it (373 KB of rows at H = 64: more than the LDS).  Here a
-// workgroup owns (window, column half) JOBS; it walks the window's edge rows in ascending order in CHUNKS of 512 rows, staged in
-// LDS once each (LDS-DMA, 128-byte row halves; the next chunk travels while this one is summed), and every det consumes the part
-// of its CSR run that lies in the chunk -- a run is ascending in edge row, so that part is a contiguous piece of it and the det's
-// lane groups simply carry on where they stopped.  The partial sums of a det stay in REGISTERS from the window's first chunk to its
-// last (8 dets per lane group: 256 dets per window), which is what makes the sums those of k_segsum_pipe BIT FOR BIT: the same
-// lane group takes the same strided positions of the run in the same order, and the groups are combined by the same xor tree at
-// the end -- only where a row comes from differs.  The window-major metadata (edge rows of a window, its dets' runs as 16-bit
-// places in that list, output rows) is built once per graph by the host (trackmpnn_amd.graph.win_plan); windows beyond the
-// capacities below are listed in the plan and take the CSR kernel.
-static constexpr int SW_CH = 512;                                     // edge rows of a chunk
-static constexpr int SW_MAXE = 3072, SW_MAXD = 256;                   // edge rows / dets of a window served here
-static constexpr int SW_NW = 16, SW_NPASS = SW_MAXD / (2 * SW_NW);    // waves; dets per lane group (two dets per wave and pass)
-static constexpr int SW_ROWS = SW_CH * 128;                           // bytes of a row buffer (128-byte row halves)
-// metadata of a job, each array rounded up to the 256-byte pieces it is staged in: rptr [nd + 1] | slot [2 ne] u16
-static constexpr int sw_pad(int bytes) { return (bytes + 255) & ~255; }
-static constexpr int SW_M_SLOT = sw_pad(4 * (SW_MAXD + 1)), SW_META_P = SW_M_SLOT + sw_pad(4 * SW_MAXE);
-static constexpr size_t SW_SHM = 2 * (size_t)SW_ROWS + 2 * SW_META_P;
-static_assert(SW_SHM <= 160 * 1024, "k_segsum_win: two chunks and two windows' metadata must fit the LDS");
+// k_segsum_pipe reads an edge row from either endpoint, 2 x 256 B per edge at H = 64, and it is bound by the number of memory
+// instructions a CU can retire (~80 clocks per 64-lane request whatever its width: 12.8 B / clock / CU with 16 bytes a lane -- its
+// 0.43 ms per 6 M edges ARE its 12 000 row requests per CU).  A window of the rolling graph is ~100 dets and 1-2 k edge rows that
+// touch nothing outside it.  Here a workgroup owns (window, column half) JOBS; it walks the window's edge rows in ascending order
+// in CHUNKS of 160 rows, staged in LDS once each (LDS-DMA, 128-byte row halves, three buffers: two chunks travel while one is
+// summed) -- half the row requests.  The sums are those of k_segsum_pipe BIT FOR BIT: incidence i of a det's run belongs to the
+// STREAM (det, i % 4), the lane group of k_segsum_pipe that adds it; a stream's partial sum lives in LDS for the length of the
+// job, is always added to by the same eight lanes, in run order (the host deals the streams round the 128 lane groups and lists,
+// per chunk and lane group, the incidences to add -- `recs`, trackmpnn_amd.graph.build_win_plan), and the four streams of a det
+// are combined as k_segsum_pipe's xor tree combines its lane groups.  Windows beyond the capacities below are listed in the plan
+// and take the CSR kernel.
+//
+// The request queue (vmcnt) retires in order and the compiler cannot see requests made by inline asm, so inside the loop NOTHING
+// is loaded into registers from memory: row ids, records and output rows travel by LDS-DMA as well, a window's record comes by a
+// scalar load, and what an accumulating launch adds to (the det rows of `out`) is staged as one more chunk of the job.  A wave
+// counts the requests (and stores) it issues per iteration; the wait at the top of an iteration lets exactly those of the
+// iteration before stay in flight.
+static constexpr int SW_CH = 160;                                     // edge rows of a chunk
+static constexpr int SW_MAXCH = 24, SW_MAXD = 160, SW_LCAP = 15;      // chunks / dets of a window, steps of a chunk served here
+static constexpr int SW_NW = 8, SW_NHG = 128;                         // waves; the plan's lane groups (8 lanes: a 128-byte row half),
+                                                                      // two per group of eight lanes here (g and g + 64)
+static constexpr int SW_ROWS = SW_CH * 128, SW_RECS = 4096, SW_ACCS = 4 * SW_MAXD * 128, SW_IDS = 768, SW_OROW = 768;
+static constexpr int SW_OFF_RECS = 3 * SW_ROWS, SW_OFF_ACCS = SW_OFF_RECS + 3 * SW_RECS, SW_OFF_IDS = SW_OFF_ACCS + SW_ACCS,
+                     SW_OFF_OROW = SW_OFF_IDS + 3 * SW_IDS;
+static constexpr size_t SW_SHM = SW_OFF_OROW + 2 * SW_OROW;
+static_assert(SW_SHM <= 160 * 1024, "k_segsum_win: three chunks and a window's streams must fit the LDS");
+static_assert(SW_MAXD <= SW_CH && SW_LCAP * 2 * SW_NHG <= SW_RECS && 4 * SW_CH <= SW_IDS && 4 * SW_MAXD <= SW_OROW &&
+                  4 * SW_MAXD <= 5 * SW_NHG && SW_CH / 8 <= 3 * SW_NW && SW_MAXD <= 3 * 8 * SW_NW, "k_segsum_win: capacities");
 
 __device__ __forceinline__ uint32_t sw_lds_addr(const void* p) {
     return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)(const char*)p;
@@ -572,6 +579,9 @@ __device__ __forceinline__ uint32_t sw_lds_addr(const void* p) {
 // 16 bytes (DW = 4) or 4 bytes (DW = 1) per lane from a per-lane global address to (uniform LDS address) + DW * 4 * lane
 template <int DW>
 __device__ __forceinline__ void sw_glds(const void* gsrc, uint32_t lds_wave_base) {
+#ifdef SW_NODMA
+    return;
+#endif
     unsigned keep;
     lds_wave_base = __builtin_amdgcn_readfirstlane(lds_wave_base);
     if constexpr (DW == 4)
@@ -581,215 +591,260 @@ __device__ __forceinline__ void sw_glds(const void* gsrc, uint32_t lds_wave_base
         asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
                      : "=&s"(keep) : "v"(gsrc), "s"(lds_wave_base) : "memory");
 }
+// everything but this wave's newest n requests / stores has landed (n wave-uniform; more than 8: everything)
+__device__ __forceinline__ void sw_wait(int n) {
+    if (n == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if (n == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+    else if (n == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else if (n == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    else if (n == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if (n == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+    else if (n == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else if (n == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+    else if (n == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
 
-#if (defined(SW_NOREDUCE) || defined(SW_NOSTAGE) || defined(SW_NOWRITE) || defined(SW_PASSES)) && !defined(TMPNN_ABLATE)
-#error "SW_NOREDUCE / SW_NOSTAGE are wrong-result timing ablations: build them with tools/build_variant.sh (-DTMPNN_ABLATE)"
+#if (defined(SW_NOREDUCE) || defined(SW_NOSTAGE) || defined(SW_NOWRITE) || defined(SW_NODMA) || defined(SW_NOSLOAD)) && !defined(TMPNN_ABLATE)
+#error "SW_NOREDUCE / SW_NOSTAGE / SW_NOWRITE are wrong-result timing ablations: build them with tools/build_variant.sh (-DTMPNN_ABLATE)"
 #endif
-struct SwJob { int j, hf, e0, ne, q0, nd, r0, nch, mb; };             // nch = 0: no further job
+// a job = (window, column half); its items: nch chunks of edge rows, then (accumulating launches) the det rows of `out` as one more
+// chunk; at least two items per job, so that two buffers of output rows are enough.  nit = 0: no further job
+struct SwJob {
+    int j, e0, ne, q0, nd, r0, lm2, mb, nit;
+    unsigned long long lm01;
+    __device__ __forceinline__ int hf() const { return j & 1; }
+    __device__ __forceinline__ int nch() const { return (ne + SW_CH - 1) / SW_CH; }
+};
+struct SwItem { SwJob jb; int c, L, roff; };                            // chunk, its steps, its first step in `recs`
+// (field by field: a 60-byte struct assignment is left as a memcpy between stack slots, i.e. scratch traffic inside the loop)
+__device__ __forceinline__ void sw_copy(SwItem& d, const SwItem& s) {
+    d.jb.j = s.jb.j; d.jb.e0 = s.jb.e0; d.jb.ne = s.jb.ne; d.jb.q0 = s.jb.q0; d.jb.nd = s.jb.nd; d.jb.r0 = s.jb.r0;
+    d.jb.lm01 = s.jb.lm01; d.jb.lm2 = s.jb.lm2; d.jb.mb = s.jb.mb; d.jb.nit = s.jb.nit;
+    d.c = s.c; d.L = s.L; d.roff = s.roff;
+}
 
 // a window's record, by ONE scalar load: the compiler turns plain uniform loads of a kernel that also stores into vector loads
-// and waits for them with vmcnt -- which would wait for the chunk requests issued just before
+// and waits for them with vmcnt -- which would wait for the chunk requests in flight
 __device__ __forceinline__ void sw_window(const int32_t* wrec, int w, SwJob& jb) {
     typedef int sw_v8 __attribute__((ext_vector_type(8)));
     sw_v8 r;
-    const int32_t* p = wrec + 8 * (size_t)w;
+    const int32_t* p = wrec + 8 * (size_t)__builtin_amdgcn_readfirstlane(w);
     asm volatile("s_load_dwordx8 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(r) : "s"(p) : "memory");
-    jb.e0 = r[0]; jb.ne = r[1]; jb.q0 = r[2]; jb.nd = r[3]; jb.r0 = r[4];
+    jb.e0 = r[0]; jb.ne = r[1]; jb.q0 = r[2]; jb.nd = r[3]; jb.r0 = r[4]; jb.lm2 = r[7];
+    jb.lm01 = ((unsigned long long)(unsigned)r[6] << 32) | (unsigned)r[5];
 }
 
 template <bool ACC>
-__global__ __launch_bounds__(1024) void k_segsum_win(tmpnn_win_plan pl, const float* __restrict__ in, int ld_in,
+__global__ __launch_bounds__(512) void k_segsum_win(tmpnn_win_plan pl, const float* __restrict__ in, int ld_in,
                                                      float* __restrict__ out, int ld_out, int compact_out) {
     extern __shared__ __attribute__((aligned(16))) char sw_lds[];
-    constexpr int NG = 4, U = 4, NW = SW_NW, NPASS = SW_NPASS, PPW = SW_CH / 8 / NW;
+    constexpr int NW = SW_NW;
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int njob = 2 * pl.W, G = gridDim.x;
-    const int hl = lane >> 5, grp = (lane & 31) >> 3, c4 = (lane & 7) * 4;
-    auto m_rptr = [&](int b) { return reinterpret_cast<int*>(sw_lds + 2 * SW_ROWS + b * SW_META_P); };
-    auto m_slot = [&](int b) { return reinterpret_cast<uint16_t*>(sw_lds + 2 * SW_ROWS + b * SW_META_P + SW_M_SLOT); };
-    // the first job at or after j that this kernel serves (uniform scalar loads)
-    auto job_at = [&](int j, int mb) {
-        SwJob jb{j, 0, 0, 0, 0, 0, 0, 0, mb};
+    const int hgl = tid >> 3, c4 = (lane & 7) * 4;                   // this lane's group of eight; its four columns of a row half
+    auto rows_of = [&](int b) { return reinterpret_cast<float*>(sw_lds + b * SW_ROWS); };
+    auto recs_of = [&](int b) { return reinterpret_cast<uint16_t*>(sw_lds + SW_OFF_RECS + b * SW_RECS); };
+    auto ids_of = [&](int b) { return reinterpret_cast<int*>(sw_lds + SW_OFF_IDS + b * SW_IDS); };
+    auto orow_of = [&](int b) { return reinterpret_cast<int*>(sw_lds + SW_OFF_OROW + b * SW_OROW); };
+    float* const accs = reinterpret_cast<float*>(sw_lds + SW_OFF_ACCS);
+    auto steps_of = [&](const SwJob& jb, int c) {
+        // (arithmetic on both sides of the select: a select between neighbouring FIELDS becomes an indexed load and the struct
+        //  goes to scratch)
+        const int lo = (int)(jb.lm01 >> (4 * (c & 15))) & 15, hi = (jb.lm2 >> (4 * (c & 7))) & 15;
+        return c < jb.nch() ? (c < 16 ? lo : hi) : 0;
+    };
+    // the first job at or after j that this kernel serves
+    auto job_at = [&](SwJob& jb, int j, int mb) {
+        jb.j = j; jb.mb = mb; jb.nit = 0;
         for (; jb.j < njob; jb.j += G) {
-            jb.hf = jb.j & 1;
+#ifdef SW_NOSLOAD
+            jb.e0 = 1460 * (jb.j >> 1); jb.ne = 1457; jb.q0 = 100 * (jb.j >> 1); jb.nd = 100; jb.r0 = 60 * (jb.j >> 1); jb.lm2 = 0;
+            jb.lm01 = 0x6666666666666666ull;
+#else
             sw_window(pl.wrec, jb.j >> 1, jb);
-            if (jb.ne <= SW_MAXE && jb.nd <= SW_MAXD && jb.nd > 0) {
-                jb.nch = jb.ne > 0 ? (jb.ne + SW_CH - 1) / SW_CH : 1;      // (a window without edges still writes its zeros)
+#endif
+            if (jb.nd > 0 && jb.nd <= SW_MAXD) {                      // (the plan marks the windows it leaves to the CSR kernel)
+                jb.nit = max(2, jb.nch() + (ACC ? 1 : 0));
                 break;
             }
         }
-        return jb;
     };
-    auto advance = [&](SwJob& jb, int& c) {                               // the item after (jb, c)
-        if (c + 1 < jb.nch) ++c;
-        else { jb = job_at(jb.j + G, jb.mb ^ 1); c = 0; }
+    auto next_item = [&](SwItem& it) {
+        if (it.jb.nit == 0) return;
+        if (it.c + 1 < it.jb.nit) { ++it.c; it.roff += it.L; }
+        else { job_at(it.jb, it.jb.j + G, it.jb.mb ^ 1); it.c = 0; it.roff = it.jb.r0; }
+        it.L = steps_of(it.jb, it.c);
     };
-    // the edge-row ids a lane needs for its pieces of a chunk (piece = 8 rows; lane -> row lane / 8): loaded an item ahead
-    auto load_ids = [&](const SwJob& jb, int c, int (&ids)[PPW]) {
-#pragma unroll
-        for (int k = 0; k < PPW; ++k) {
-            const int seg = c * SW_CH + 8 * (wv + NW * k) + (lane >> 3);
-            ids[k] = (jb.nch > 0 && c * SW_CH + 8 * (wv + NW * k) < jb.ne) ? pl.erow[jb.e0 + min(seg, jb.ne - 1)] : 0;
+    // what an item stages: rows of `in` by the window's edge list, or (the last item of an accumulating launch's job) the det
+    // rows of `out`; cnt = 0: nothing (a padding item, or the end of the stream)
+    auto item_cnt = [&](const SwItem& it, bool& prev) {
+        prev = false;
+        if (it.jb.nit == 0) return 0;
+        if (it.c < it.jb.nch()) return min(SW_CH, it.jb.ne - it.c * SW_CH);
+        if (ACC && it.c == it.jb.nit - 1) { prev = true; return it.jb.nd; }
+        return 0;
+    };
+    int fly = 0;                                                      // requests and stores of this wave in this iteration
+    // ids of an item into id buffer ib: the edge list is 16-byte aligned (one request of wave 8); the output rows are not
+    auto stage_ids = [&](const SwItem& it, int ib) {
+        bool prev;
+        const int cnt = item_cnt(it, prev);
+        if (cnt == 0) return;
+        if (!prev) {
+            if (wv == 4) {
+                const int n4 = (cnt + 3) >> 2;                        // (the list of a window is padded to a multiple of four)
+                if (lane < n4) sw_glds<4>(pl.erow + it.jb.e0 + it.c * SW_CH + 4 * lane, sw_lds_addr(ids_of(ib)));   // (<= 640 B)
+                ++fly;
+            }
+        } else if (wv >= 5 && wv < 8 && 64 * (wv - 5) < cnt) {   // (waves 5 .. 7)
+            const int32_t* src = (compact_out ? pl.det : pl.drow) + it.jb.q0;
+            sw_glds<1>(src + min(64 * (wv - 5) + lane, cnt - 1), sw_lds_addr(ids_of(ib)) + 256u * (wv - 5));
+            ++fly;
         }
     };
-    // requests of an item into row buffer b: its row halves, and with a job's first chunk the job's metadata
-    auto stage = [&](const SwJob& jb, int c, const int (&ids)[PPW], int b) {
-        if (jb.nch == 0) return;
-        const uint32_t rows_a = sw_lds_addr(sw_lds + b * SW_ROWS);
-#pragma unroll
-        for (int k = 0; k < PPW; ++k) {
-            const int piece = wv + NW * k;
+    auto stage_rows = [&](const SwItem& it, int rb) {
+        bool prev;
+        const int cnt = item_cnt(it, prev);
+        const SwJob& jb = it.jb;
+        if (jb.nit == 0) return;
+        if (it.c == 0 && wv >= 5 && 64 * (wv - 5) < jb.nd) {              // the job's output rows (for its sums' stores)
+            const int32_t* src = (compact_out ? pl.det : pl.drow) + jb.q0;
+            sw_glds<1>(src + min(64 * (wv - 5) + lane, jb.nd - 1), sw_lds_addr(orow_of(jb.mb)) + 256u * (wv - 5));
+            ++fly;
+        }
+        if (wv >= 4 && 4 * (7 - wv) < it.L) {                         // the chunk's records: 1 KB (four steps) a request
+            const int x = 7 - wv;
+            const int nl = min(64, 16 * (it.L - 4 * x));              // (16 lanes a step)
+            sw_glds<4>(pl.recs + ((size_t)it.roff + 4 * x) * SW_NHG + 8 * min(lane, nl - 1), sw_lds_addr(recs_of(rb)) + 1024u * x);
+            ++fly;
+        }
 #ifdef SW_NOSTAGE
-            if (c * SW_CH + 8 * piece < jb.ne && c == 0 && jb.j < 2 * (int)gridDim.x)
-#else
-            if (c * SW_CH + 8 * piece < jb.ne)
+        if (it.c != 0 || jb.j >= 2 * G) return;
 #endif
-                sw_glds<4>(in + (size_t)ids[k] * ld_in + 32 * jb.hf + c4, rows_a + 1024u * piece);
-        }
-        if (c != 0) return;
-        // rptr [nd + 1] and slot [2 ne] (as ne dwords): 256-byte pieces dealt round the waves
-        const int n_r = (jb.nd + 1 + 63) >> 6, n_s = (jb.ne + 63) >> 6;
-        for (int x = wv; x < n_r + n_s; x += NW) {
-            if (x < n_r)
-                sw_glds<1>(pl.rptr + jb.q0 + min(64 * x + lane, jb.nd), sw_lds_addr(m_rptr(jb.mb)) + 256u * x);
-            else
-                sw_glds<1>(reinterpret_cast<const int32_t*>(pl.slot + jb.r0) + min(64 * (x - n_r) + lane, jb.ne - 1),
-                           sw_lds_addr(m_slot(jb.mb)) + 256u * (x - n_r));
-        }
-    };
-    // the output rows of a job's dets, per pass of this lane (loaded an item ahead of the job's first chunk)
-    auto load_orow = [&](const SwJob& jb, int (&orow)[NPASS]) {
+        const float* base = prev ? out : in;
+        const int ld = prev ? ld_out : ld_in;
+        const int* idl = ids_of(rb);
 #pragma unroll
-        for (int k = 0; k < NPASS; ++k) {
-            const int ql = 2 * NW * k + 2 * wv + hl;
-            orow[k] = (jb.nch > 0 && ql < jb.nd) ? (compact_out ? pl.det[jb.q0 + ql] : pl.drow[jb.q0 + ql]) : -1;
+        for (int k = 0; k < 3; ++k) {
+            const int piece = wv + NW * k;
+            if (8 * piece < cnt) {
+                const int id = idl[min(8 * piece + (lane >> 3), cnt - 1)];
+                sw_glds<4>(base + (size_t)id * ld + 32 * jb.hf() + c4, sw_lds_addr(rows_of(rb)) + 1024u * piece);
+                ++fly;
+            }
         }
     };
-    SwJob ja = job_at(blockIdx.x, 0);
-    if (ja.nch == 0) return;
-    int ca = 0, cb = 0, cc;
-    SwJob jb = ja;
-    advance(jb, cb);
-    int ids_b[PPW], ids_c[PPW], orow[NPASS], cur[NPASS];
-    float4 acc[NPASS], prev[NPASS / 4];                           // prev: lane group g keeps it for the passes k = g (mod 4)
-    load_ids(ja, 0, ids_c);
-    load_orow(ja, orow);
-    load_ids(jb, cb, ids_b);
-    stage(ja, 0, ids_c, 0);
-    int b = 0;
+    SwItem A, B, Cn, D, En;
+    A.jb.e0 = A.jb.ne = A.jb.q0 = A.jb.nd = A.jb.r0 = A.jb.lm2 = 0;
+    A.jb.lm01 = 0;
+    job_at(A.jb, blockIdx.x, 0);
+    if (A.jb.nit == 0) return;
+    A.c = 0; A.L = steps_of(A.jb, 0); A.roff = A.jb.r0;
+    sw_copy(B, A);
+    next_item(B);
+    sw_copy(Cn, B);
+    next_item(Cn);
+    sw_copy(D, Cn);
+    next_item(D);
+    sw_copy(En, D);
+    next_item(En);
+    // every stream's sum starts at zero (and is put back to zero when its job's sums are written)
+    for (int x = tid; x < SW_ACCS / 16; x += 512) reinterpret_cast<float4*>(accs)[x] = make_float4(0.f, 0.f, 0.f, 0.f);
+    // prologue: ids of items 0 .. 3, then the rows of items 0 and 1 (item t's rows use id buffer t % 3, as its rows do)
+    stage_ids(A, 0);
+    stage_ids(B, 1);
+    stage_ids(Cn, 2);
+    sw_wait(0);
+    __syncthreads();
+    stage_rows(A, 0);
+    sw_wait(0);
+    __syncthreads();
+    fly = 0;
+    stage_rows(B, 1);
+    stage_ids(D, 0);
+    int fly_prev = fly;
+    int W_nd = 0, W_hf = 0, W_mb = 0;                                  // the job whose sums are written at the top of the next iteration
+    bool wr = false;
+    int rb = 0;                                                        // row / record / id buffer of item t: t % 3
     for (;;) {
-        // this item's rows (and metadata), the stores of the job before.  The builtin, not inline asm: the compiler's own
-        // wait-count bookkeeping then knows that every load of the last iteration has landed and adds no wait of its own behind
-        // the chunk requests below (it cannot see those: they are asm)
-        __builtin_amdgcn_s_waitcnt(0x0F70);                       // vmcnt(0)
-        asm volatile("" ::: "memory");
+        sw_wait(fly_prev);                                            // everything but what the iteration before this one issued
         __syncthreads();
-        // the item after this one travels while this one is summed; the indices of the one after that are loaded behind it
-        stage(jb, cb, ids_b, b ^ 1);
-        SwJob jc = jb;
-        cc = cb;
-        if (jb.nch > 0) advance(jc, cc);
-        load_ids(jc, cc, ids_c);
-        const int r0 = ja.r0, c0 = ca * SW_CH, c1 = min(ja.ne, c0 + SW_CH);
-        const int* rp = m_rptr(ja.mb);
-        const uint16_t* sl = m_slot(ja.mb);
-        if (ca == 0) {
-#pragma unroll
-            for (int k = 0; k < NPASS; ++k) {
-                const int ql = 2 * NW * k + 2 * wv + hl;
-                cur[k] = (2 * NW * k < ja.nd && ql < ja.nd) ? rp[ql] - r0 + grp : 0;
-                acc[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-            }
-            if (ACC) {                                            // what the sums are added to, fetched well ahead of the job's end
-#pragma unroll
-                for (int i = 0; i < NPASS / 4; ++i) {             // (ONE load per register quad: a second one would wait for the first)
-                    const int r = grp == 0 ? orow[4 * i] : grp == 1 ? orow[4 * i + 1] : grp == 2 ? orow[4 * i + 2] : orow[4 * i + 3];
-                    // (unconditional, row 0 for a det that is not there: a load under a branch is waited for at the join)
-                    prev[i] = *reinterpret_cast<const float4*>(out + (size_t)max(r, 0) * ld_out + 32 * ja.hf + c4);
-                }
-            }
-        }
-        const float* rows = reinterpret_cast<const float*>(sw_lds + b * SW_ROWS);
-#ifdef SW_NOREDUCE
-        if (ja.j < 0)
-#endif
-#pragma unroll
-        for (int k = 0; k < NPASS; ++k) {
-            if (2 * NW * k >= ja.nd) continue;                    // (uniform)
-#ifdef SW_PASSES
-            if (k >= SW_PASSES) continue;
-#endif
-            const int ql = 2 * NW * k + 2 * wv + hl;
-            const int p1 = ql < ja.nd ? rp[ql + 1] - r0 : 0;
-            int p = cur[k];
-            for (;;) {
-                unsigned s16[U];
-                bool live[U];
-#pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    const int pp = p + u * NG;
-                    s16[u] = pp < p1 ? sl[pp] : 0x7fffu;
-                    live[u] = (int)(s16[u] & 0x7fffu) < c1;        // (0x7fff: beyond any chunk)
-                }
-                if (__builtin_amdgcn_ballot_w64(live[0]) == 0) break;
-                float4 x[U];
-#pragma unroll
-                for (int u = 0; u < U; ++u)
-                    x[u] = *reinterpret_cast<const float4*>(rows + (live[u] ? (int)(s16[u] & 0x7fffu) - c0 : 0) * 32 + c4);
-#pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    const float w = (s16[u] & 0x8000u) ? -1.0f : 1.0f;
-                    if (live[u]) {
-                        x[u].x *= w; x[u].y *= w; x[u].z *= w; x[u].w *= w;
-                        acc[k].x += x[u].x; acc[k].y += x[u].y; acc[k].z += x[u].z; acc[k].w += x[u].w;
-                        p += NG;
-                    }
-                }
-                if (__builtin_amdgcn_ballot_w64(live[U - 1]) == 0) break;
-            }
-            cur[k] = p;
-        }
+        fly = 0;
+        if (wr) {
+            // the sums of the job that ended with item t - 1: a det's four streams combined as k_segsum_pipe's xor tree combines
+            // its lane groups, (+ the det row of `out`, staged as item t - 1), one store of 8 dets per wave; streams back to zero
+            const int* orow = orow_of(W_mb);
+            const float* prevr = rows_of(rb == 0 ? 2 : rb - 1);
 #ifdef SW_NOWRITE
-        if (ca == ja.nch - 1 && ja.j < 0) {
-#else
-        if (ca == ja.nch - 1) {
+            if (W_nd < 0)
 #endif
-            // the window's last chunk: combine the lane groups (k_segsum_pipe's tree) and write
-            if (ACC) {                                            // (one wait for the fetched rows here, none between the stores)
 #pragma unroll
-                for (int i = 0; i < NPASS / 4; ++i)
-                    asm volatile("" : "+v"(prev[i].x), "+v"(prev[i].y), "+v"(prev[i].z), "+v"(prev[i].w));
+            for (int p = 0; p < 3; ++p) {
+                if (64 * p + 8 * wv >= W_nd) continue;                // (uniform)
+                const int q = 64 * p + hgl, qc = min(q, W_nd - 1);
+                float* as = accs + qc * 4 * 32 + c4;
+                const float4 a0 = *reinterpret_cast<const float4*>(as), a1 = *reinterpret_cast<const float4*>(as + 32);
+                const float4 a2 = *reinterpret_cast<const float4*>(as + 64), a3 = *reinterpret_cast<const float4*>(as + 96);
+                const int orw = orow[qc];
+                float4 t;
+                t.x = (a0.x + a1.x) + (a2.x + a3.x);
+                t.y = (a0.y + a1.y) + (a2.y + a3.y);
+                t.z = (a0.z + a1.z) + (a2.z + a3.z);
+                t.w = (a0.w + a1.w) + (a2.w + a3.w);
+                if (ACC) {
+                    const float4 pv = *reinterpret_cast<const float4*>(prevr + qc * 32 + c4);
+                    t.x += pv.x; t.y += pv.y; t.z += pv.z; t.w += pv.w;
+                }
+                if (q < W_nd) {
+                    *reinterpret_cast<float4*>(out + (size_t)orw * ld_out + 32 * W_hf + c4) = t;
+                    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+                    *reinterpret_cast<float4*>(as) = z;
+                    *reinterpret_cast<float4*>(as + 32) = z;
+                    *reinterpret_cast<float4*>(as + 64) = z;
+                    *reinterpret_cast<float4*>(as + 96) = z;
+                }
+                ++fly;
             }
-#pragma unroll
-            for (int k = 0; k < NPASS; ++k) {
-                if (2 * NW * k >= ja.nd) continue;
-                float4 a = acc[k];
-#pragma unroll
-                for (int off = 8; off < 32; off <<= 1) {
-                    a.x += __shfl_xor(a.x, off);
-                    a.y += __shfl_xor(a.y, off);
-                    a.z += __shfl_xor(a.z, off);
-                    a.w += __shfl_xor(a.w, off);
-                }
-                if (ACC) {                                        // (group 0 takes it from the group that fetched it)
-                    const int from = lane + 8 * (k & 3);
-                    a.x += __shfl(prev[k >> 2].x, from);
-                    a.y += __shfl(prev[k >> 2].y, from);
-                    a.z += __shfl(prev[k >> 2].z, from);
-                    a.w += __shfl(prev[k >> 2].w, from);
-                }
-                if (orow[k] >= 0 && grp == 0) {
-                    *reinterpret_cast<float4*>(out + (size_t)orow[k] * ld_out + 32 * ja.hf + c4) = a;
-                }
+            __syncthreads();                                          // (item t + 2 is staged over item t - 1's buffer; streams are zero)
+            wr = false;
+        }
+        if (A.jb.nit == 0) break;
+        // rows and records two iterations ahead of their sums, ids two ahead of the rows that use them
+        stage_rows(Cn, rb == 0 ? 2 : rb - 1);
+        stage_ids(En, rb == 2 ? 0 : rb + 1);
+#ifdef SW_NOREDUCE
+        if (A.jb.j < 0)
+#endif
+        if (A.L > 0) {
+            // (eight lanes serve the plan's lane groups g and g + 64: two records a step, their streams never the same)
+            const uint16_t* rc = recs_of(rb) + hgl;
+            const float* rows = rows_of(rb) + c4;
+            float* ab = accs + hgl * 32 + c4;
+            unsigned r0 = rc[0], r1 = rc[64];
+            for (int s = 0; s < A.L; ++s) {
+                const int sn = min(s + 1, A.L - 1) * SW_NHG;
+                const unsigned n0 = rc[sn], n1 = rc[sn + 64];        // (the next records behind these ones' rows)
+                const float4 x0 = *reinterpret_cast<const float4*>(rows + (r0 & 255u) * 32);
+                const float4 x1 = *reinterpret_cast<const float4*>(rows + (r1 & 255u) * 32);
+                float* ap0 = ab + ((r0 >> 9) & 7u) * (SW_NHG * 32);
+                float* ap1 = ab + ((r1 >> 9) & 7u) * (SW_NHG * 32) + 64 * 32;
+                float4 a0 = *reinterpret_cast<const float4*>(ap0), a1 = *reinterpret_cast<const float4*>(ap1);
+                const float w0 = (r0 & 0x100u) ? -1.0f : 1.0f, w1 = (r1 & 0x100u) ? -1.0f : 1.0f;
+                a0.x += x0.x * w0; a0.y += x0.y * w0; a0.z += x0.z * w0; a0.w += x0.w * w0;
+                a1.x += x1.x * w1; a1.y += x1.y * w1; a1.z += x1.z * w1; a1.w += x1.w * w1;
+                if (!(r0 & 0x8000u)) *reinterpret_cast<float4*>(ap0) = a0;
+                if (!(r1 & 0x8000u)) *reinterpret_cast<float4*>(ap1) = a1;
+                r0 = n0; r1 = n1;
             }
         }
-        if (jb.nch == 0) break;
-        if (cb == 0) load_orow(jb, orow);                         // (item b opens a job: its output rows, there by the next barrier)
-        ja = jb; ca = cb; jb = jc; cb = cc;
-#pragma unroll
-        for (int k = 0; k < PPW; ++k) ids_b[k] = ids_c[k];
-        b ^= 1;
+        if (A.c == A.jb.nit - 1) { wr = true; W_nd = A.jb.nd; W_hf = A.jb.hf(); W_mb = A.jb.mb; }
+        sw_copy(A, B); sw_copy(B, Cn); sw_copy(Cn, D); sw_copy(D, En);
+        next_item(En);
+        rb = rb == 2 ? 0 : rb + 1;
+        fly_prev = fly;
     }
+    sw_wait(0);
 }
 
 static int cu_count() {
@@ -803,10 +858,10 @@ static int cu_count() {
 
 static int segsum_win(const tmpnn_graph* g, const tmpnn_win_plan* pl, const float* in, int ld_in, float* out, int ld_out,
                       int accumulate, int compact_out, hipStream_t st) {
-    TM_REQUIRE(pl->W > 0 && pl->wrec && pl->erow && pl->rptr && pl->slot && pl->det && pl->drow &&
+    TM_REQUIRE(pl->W > 0 && pl->wrec && pl->erow && pl->recs && pl->det && pl->drow &&
                    (pl->nbig == 0 || pl->big_order), "segsum: incomplete window plan");
     const int njob = 2 * pl->W, cus = cu_count();
-    dim3 grid(njob < cus ? njob : cus), block(1024);
+    dim3 grid(njob < cus ? njob : cus), block(512);
     if (accumulate) {
         TM_SHM_ONCE((k_segsum_win<true>), SW_SHM);
         hipLaunchKernelGGL((k_segsum_win<true>), grid, block, SW_SHM, st, *pl, in, ld_in, out, ld_out, compact_out);

@@ -67,7 +67,7 @@ INPUT_TF = _variant('TMPNN_INPUT_TF', '1') != '0'
 # reads them.  Same gradients bit for bit; measured SLOWER (numbers in DESIGN), so off by default.
 RECOMPUTE_GATES = _variant('TMPNN_RECOMPUTE_GATES', '0') == '1'
 CONCAT_PROJ = _variant('TMPNN_CONCAT_PROJ', '1') != '0'
-# the window-owned segment sum (csrc/agg.hip k_segsum_win) on graphs with window labels: bit-equal to the CSR kernel, 0.70 ms
+# the window-owned segment sum (csrc/agg.hip k_segsum_win) on graphs with window labels: bit-equal to the CSR kernel, 0.9 ms
 # against its 0.43 ms per 6 M edges on MI355X -- kept opt-in
 WIN_SEGSUM = _variant('TMPNN_SEGSUM_WIN', '0') == '1'
 WIDE_FUSED_ADJOINT = _variant('TMPNN_WIDE_FUSED_ADJOINT', '1') != '0'

@@ -316,18 +316,19 @@ def set_det_groups(graph: FrameGraph, det_group) -> FrameGraph:
     return graph
 
 
-WIN_CAP_EDGES, WIN_CAP_DETS = 3072, 256     # csrc/agg.hip SW_MAXE / SW_MAXD: a window's edge rows / dets the kernel serves
+# csrc/agg.hip k_segsum_win: edge rows of a chunk, chunks / dets of a window it serves, lane groups of a workgroup, steps of a chunk
+WIN_CH, WIN_MAXCH, WIN_CAP_DETS, WIN_NHG, WIN_LCAP = 160, 24, 160, 128, 15
 
 
 class WinPlan:
     """struct tmpnn_win_plan (include/tmpnn.h) with the tensors it points at."""
 
-    def __init__(self, W, nbig, wrec, erow, rptr, slot, det, drow, big_order):
+    def __init__(self, W, nbig, wrec, erow, recs, det, drow, big_order):
         self.W, self.nbig = int(W), int(nbig)
-        self.t = (wrec, erow, rptr, slot, det, drow, big_order)
-        assert wrec.data_ptr() % 32 == 0
-        self.c = _lib.CWinPlan(self.W, self.nbig, wrec.data_ptr(), erow.data_ptr(), rptr.data_ptr(),
-                               slot.data_ptr(), det.data_ptr(), drow.data_ptr(), _lib.ptr(big_order))
+        self.t = (wrec, erow, recs, det, drow, big_order)
+        assert not wrec.is_cuda or (wrec.data_ptr() % 32 == 0 and erow.data_ptr() % 16 == 0 and recs.data_ptr() % 256 == 0)
+        self.c = _lib.CWinPlan(self.W, self.nbig, wrec.data_ptr(), erow.data_ptr(), recs.data_ptr(), det.data_ptr(),
+                               drow.data_ptr(), _lib.ptr(big_order))
 
 
 def build_win_plan(graph: FrameGraph, det_group: torch.Tensor) -> Optional[WinPlan]:
@@ -335,57 +336,96 @@ def build_win_plan(graph: FrameGraph, det_group: torch.Tensor) -> Optional[WinPl
     windows -- the graphs batch_windows() builds out of the reference's rolling windows (reference/utils/graph.py:141-156: a
     window's edges join dets of that window only).
 
-    Everything is listed window by window: the window's edge rows (ascending), its dets in det order (= the visiting order
-    set_det_groups gives), and per det its CSR run rewritten as 16-bit indices into the window's edge list, sign bit kept.
-    Returns None when an edge crosses windows or when too few edges sit in windows that fit the kernel's LDS.  Index plumbing
-    on the graph's device; two host reads."""
+    A window's edge rows are listed in ascending order and cut into chunks of WIN_CH.  An incidence i of a det's CSR run belongs to
+    the STREAM (det, i % 4) -- the lane group of k_segsum_pipe that adds it -- and streams are dealt round the 128 lane groups of a
+    workgroup (stream % 128).  Per chunk, every lane group gets the list of its incidences whose edge row lies in the chunk, stream
+    by stream and in run order; the lists of a chunk are padded to the longest (`steps`) and stored step-major as 16-bit RECORDS
+    (place of the row in the chunk | sign << 8 | stream / 128 << 9 | nothing-to-do << 15).  Returns None when an edge crosses
+    windows, a run does not ascend in edge row, or too few edges sit in windows the kernel serves.  Index plumbing on the graph's
+    device; two host reads."""
     if graph.src_pos is None or graph.dst_pos is None or graph.E == 0 or graph.Dn == 0:
         return None
     dev, E, Dn = graph.device, graph.E, graph.Dn
+    CH, NHG = WIN_CH, WIN_NHG
     i32 = lambda t: t.to(torch.int32).contiguous()
+    ar = lambda n: torch.arange(n, device=dev)
     uw, wdet = torch.unique(det_group, return_inverse=True)
     s, d = graph.src_pos.long(), graph.dst_pos.long()
     wedge = wdet[s]
-    # (a run of the CSR ascends in edge row -- graph_from_edges keeps it so; the kernel consumes runs chunk by chunk on that)
-    rows_p = graph.inc.long() & 0x7fffffff
+    rowptr, inc = graph.rowptr.long(), graph.inc.long()
+    # (a run of the CSR ascends in edge row -- graph_from_edges keeps it so: a stream then meets the chunks in order)
+    rows_p = inc & 0x7fffffff
     starts = torch.zeros(2 * E, dtype=torch.bool, device=dev)
-    starts[graph.rowptr.long()[:-1][graph.rowptr.long()[:-1] < 2 * E]] = True
+    starts[rowptr[:-1][rowptr[:-1] < 2 * E]] = True
     unsorted_run = ((rows_p[1:] <= rows_p[:-1]) & ~starts[1:]).any()
     W, bad = int(uw.numel()), bool((wedge != wdet[d]).any() | unsorted_run)   # (host read)
     if bad:
         return None
     order = torch.argsort(wdet, stable=True)                               # visiting position -> det index
     vis = torch.empty_like(order)
-    vis[order] = torch.arange(Dn, device=dev)
+    vis[order] = ar(Dn)
+    nd = torch.bincount(wdet, minlength=W)
     dptr = torch.zeros(W + 1, dtype=torch.long, device=dev)
-    dptr[1:] = torch.cumsum(torch.bincount(wdet, minlength=W), 0)
+    dptr[1:] = torch.cumsum(nd, 0)
+    ne = torch.bincount(wedge, minlength=W)
+    eptr = torch.zeros(W + 1, dtype=torch.long, device=dev)               # a window's list starts at a multiple of 4 (16 bytes)
+    eptr[1:] = torch.cumsum((ne + 3) // 4 * 4, 0)
     eorder = torch.argsort(wedge, stable=True)                             # edge indices window by window, rows ascending
-    eptr = torch.zeros(W + 1, dtype=torch.long, device=dev)
-    eptr[1:] = torch.cumsum(torch.bincount(wedge, minlength=W), 0)
+    cum = torch.zeros(W + 1, dtype=torch.long, device=dev)
+    cum[1:] = torch.cumsum(ne, 0)
     local = torch.empty(E, dtype=torch.long, device=dev)                   # edge index -> its place in its window's list
-    local[eorder] = torch.arange(E, device=dev) - eptr[wedge[eorder]]
-    rowptr = graph.rowptr.long()
+    local[eorder] = ar(E) - cum[wedge[eorder]]
+    erow = torch.zeros(int(((ne + 3) // 4 * 4).sum()) + 4, dtype=torch.long, device=dev)
+    erow[eptr[wedge] + local] = graph.edge_row.long()
+    nch = (ne + CH - 1) // CH
+    cbase = torch.zeros(W + 1, dtype=torch.long, device=dev)
+    cbase[1:] = torch.cumsum(nch, 0)
+    # per incidence (CSR position p of det dd): stream, lane group, chunk
     deg = rowptr[1:] - rowptr[:-1]
-    rptr = torch.zeros(Dn + 1, dtype=torch.long, device=dev)
-    rptr[1:] = torch.cumsum(deg[order], 0)
-    det_of_p = torch.repeat_interleave(torch.arange(Dn, device=dev), deg)  # CSR position -> det index
-    newpos = rptr[vis[det_of_p]] + torch.arange(2 * E, device=dev) - rowptr[det_of_p]
-    inc = graph.inc.long()
-    e_of_p = graph.pos.long()[inc & 0x7fffffff]
-    v = (local[e_of_p] & 0x7fff) | torch.where(inc < 0, 0x8000, 0)
-    slot = torch.empty(2 * E, dtype=torch.int16, device=dev)
-    slot[newpos] = torch.where(v >= 0x8000, v - 0x10000, v).to(torch.int16)
-    big_w = ((eptr[1:] - eptr[:-1]) > WIN_CAP_EDGES) | ((dptr[1:] - dptr[:-1]) > WIN_CAP_DETS)
+    dd = torch.repeat_interleave(ar(Dn), deg)
+    i = ar(2 * E) - rowptr[dd]
+    wp_ = wdet[dd]
+    sid = (vis[dd] - dptr[wp_]) * 4 + (i & 3)
+    hg, j, seq = sid % NHG, sid // NHG, i >> 2
+    eloc = local[graph.pos.long()[rows_p]]
+    gc = cbase[wp_] + eloc // CH
+    ok = (nd[wp_] <= WIN_CAP_DETS) & (nch[wp_] <= WIN_MAXCH)                 # (the others: CSR kernel)
+    key = (((gc * NHG + hg) * 8 + j.clamp(max=7)) << 12) + seq.clamp(max=4095)
+    key = torch.where(ok, key, torch.full_like(key, 2 ** 62))
+    perm = torch.argsort(key, stable=True)
+    cell = (gc * NHG + hg)[perm]
+    ncell = int(cbase[-1]) * NHG                                           # (host read, with the two below)
+    cnt = torch.bincount(cell[ok[perm]], minlength=ncell)
+    cstart = torch.zeros(ncell + 1, dtype=torch.long, device=dev)
+    cstart[1:] = torch.cumsum(cnt, 0)
+    step = ar(2 * E) - cstart[cell.clamp(max=ncell - 1)]                   # (only the ok incidences, sorted first, are used)
+    steps = cnt.view(-1, NHG).max(1).values if ncell else torch.zeros(0, dtype=torch.long, device=dev)   # per chunk
+    # windows whose longest list is beyond what 4 bits / the LDS hold go to the CSR kernel as well
+    wofc = torch.repeat_interleave(ar(W), nch)
+    too_long = torch.zeros(W, dtype=torch.bool, device=dev)
+    too_long[wofc[steps > WIN_LCAP]] = True
+    big_w = (nd > WIN_CAP_DETS) | (nch > WIN_MAXCH) | too_long
+    steps = torch.where(big_w[wofc], torch.zeros_like(steps), steps)
     big_order = order[big_w[wdet[order]]]
-    nbig, e_big = int(big_order.numel()), int((eptr[1:] - eptr[:-1])[big_w].sum())   # (host read)
+    nbig, e_big = int(big_order.numel()), int(ne[big_w].sum())             # (host read)
     if 2 * e_big > E:
         return None
+    soff = torch.zeros(steps.numel() + 1, dtype=torch.long, device=dev)    # first step of a chunk in the record array
+    soff[1:] = torch.cumsum(steps, 0)
+    recs = torch.full(((int(soff[-1]) + 4) * NHG,), -2 ** 15, dtype=torch.int16, device=dev)      # 0x8000: nothing to do
+    use = ok[perm] & ~big_w[wp_[perm]]
+    pp = perm[use]
+    val = (eloc[pp] % CH) | torch.where(inc[pp] < 0, 0x100, 0) | (j[pp] << 9)
+    recs[(soff[gc[pp]] + step[use]) * NHG + hg[pp]] = val.to(torch.int16)
     wrec = torch.zeros(W, 8, dtype=torch.long, device=dev)
-    wrec[:, 0], wrec[:, 1] = eptr[:-1], eptr[1:] - eptr[:-1]
-    wrec[:, 2], wrec[:, 3] = dptr[:-1], dptr[1:] - dptr[:-1]
-    wrec[:, 4] = rptr[dptr[:-1]]
-    return WinPlan(W, nbig, i32(wrec), i32(graph.edge_row.long()[eorder]), i32(rptr), slot, i32(order),
-                   i32(graph.det_row.long()[order]), i32(big_order) if nbig else None)
+    wrec[:, 0], wrec[:, 1], wrec[:, 2], wrec[:, 3] = eptr[:-1], ne, dptr[:-1], nd
+    wrec[:, 4] = soff[cbase[:-1]]
+    cidx = ar(steps.numel()) - cbase[wofc]                                 # chunk index within its window
+    fits = cidx < WIN_MAXCH
+    wrec.view(-1).index_add_(0, (wofc * 8 + 5 + cidx // 8)[fits], (steps << (4 * (cidx % 8)))[fits])
+    wrec[big_w, 3] = WIN_CAP_DETS + 1 + 0 * wrec[big_w, 3]                 # (what the kernel reads as "not mine")
+    return WinPlan(W, nbig, i32(wrec), i32(erow), recs, i32(order), i32(graph.det_row.long()[order]),
+                   i32(big_order) if nbig else None)
 
 
 def win_plan(graph: FrameGraph) -> Optional[WinPlan]:
