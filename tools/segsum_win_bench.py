@@ -11,12 +11,14 @@ from trackmpnn_amd.graph import win_plan
 ap = argparse.ArgumentParser()
 ap.add_argument('--B', type=int, default=4096)
 ap.add_argument('--iters', type=int, default=20)
+ap.add_argument('--shape', default='c3', help='c3: 12 frames, Poisson(8) / 25 (tools/c3_sweep.py) ; c2: the bench step, 7 frames, Poisson(6) / 20')
 ap.add_argument('--one', action='store_true')
 a = ap.parse_args()
 dev = torch.device('cuda:0')
 H = 64
 st = torch.cuda.current_stream().cuda_stream
-plans, xs, _ = bench.build_batch(a.B, 12, 8.0, 25, 8, seed=3, device=dev)
+plans, xs, _ = (bench.build_batch(a.B, 12, 8.0, 25, 8, seed=3, device=dev) if a.shape == 'c3'
+                else bench.build_batch(a.B, 7, 6.0, 20, 8, seed=1, device=dev))
 g = plans[-1].graph
 wp = win_plan(g)
 assert wp is not None

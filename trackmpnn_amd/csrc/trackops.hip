@@ -757,20 +757,36 @@ __global__ __launch_bounds__(TK_THREADS) void k_track_finalize(tmpnn_dgraph g, c
 }
 
 
-// ---- decode_tracks in ONE launch for LDS-sized graphs: the five steps above as phases of one 1024-thread block ----------------
+// ---- decode_tracks for LDS-sized graphs: the decisions as phases of one 1024-thread block, the state rows behind it ----------
 // (a greedy timestep's GPU time is ~10 dependent launches of 2-8 us kernels; each launch saved is ~2 us of device gap and ~2 us
 //  of host time)
+#ifdef TK_TIMELINE            // (profiling build: s_memtime sums per phase of k_track_retire, thread 0; tools/track_timeline.py)
+__device__ unsigned long long g_tk_timeline[16];
+#define TK_STAMP(i)                                                                               \
+    do {                                                                                          \
+        __syncthreads();                                                                          \
+        if (threadIdx.x == 0) {                                                                   \
+            const unsigned long long now_ = __builtin_amdgcn_s_memtime();                         \
+            atomicAdd(&g_tk_timeline[(i)], now_ - tk_last);                                       \
+            tk_last = now_;                                                                       \
+        }                                                                                         \
+    } while (0)
+#else
+#define TK_STAMP(i) do { } while (0)
+#endif
 __global__ __launch_bounds__(TK_THREADS) void k_track_retire(tmpnn_dgraph g, tmpnn_track_rows r, const float* __restrict__ score,
                                                              int associate, int t_upto, int ret_win,
                                                              int32_t* __restrict__ y_track, int ND,
                                                              int32_t* __restrict__ pos_of_det, int32_t* __restrict__ keep,
                                                              int32_t* __restrict__ small, tmpnn_track_rows o,
-                                                             const float* __restrict__ h, int ld_h, int W,
-                                                             float* __restrict__ h_new, int ld_hn, float* __restrict__ s_new,
-                                                             int next_t, int32_t* __restrict__ active,
+                                                             float* __restrict__ s_new, int next_t, int32_t* __restrict__ active,
                                                              int32_t* __restrict__ fin_ws /* unused by the finalisation at this
                                                              size (a kernel argument because a literal null in its LDS /
                                                              global pointer select crashes hipcc) */, int hung_floats) {
+#ifdef TK_TIMELINE
+    unsigned long long tk_last = __builtin_amdgcn_s_memtime();
+    if (threadIdx.x == 0) atomicAdd(&g_tk_timeline[15], 1ull);
+#endif
     if (associate == 2) {                       // optimal assignment per timestep (--hungarian); its cost scratch rides in fin_ws
         if (threadIdx.x == 0) small[1] = 0;
         __syncthreads();
@@ -780,16 +796,23 @@ __global__ __launch_bounds__(TK_THREADS) void k_track_retire(tmpnn_dgraph g, tmp
         d_track_associate(g, r.det_id, nullptr, score, 1, r.assoc, small + 1, (int)threadIdx.x, TK_THREADS);
         __syncthreads();
     }
+    TK_STAMP(0);
     d_track_finalize(g, r.ts, r.det_id, r.assoc, score, t_upto, y_track, ND, pos_of_det, fin_ws);
     __syncthreads();
+    TK_STAMP(1);
     d_track_delete(g.N, r.ts, r.det_id, r.assoc, score, r.is_edge, r.src, r.dst, r.labels, t_upto, ret_win, keep, small, o.ts,
                    o.det_id, o.assoc, o.is_edge, o.src, o.dst, o.labels);
     __syncthreads();
-    d_track_gather2(h, ld_h, W, score, keep, small, h_new, ld_hn, s_new, (long)threadIdx.x, (long)TK_THREADS);
+    TK_STAMP(2);
+    // the kept rows' scores here (the next active set reads them); their state rows move in a launch of many blocks behind this
+    // one (tmpnn_track_retire): one block takes 14 us for a KITTI window's 96 KB and 84 us for a 12-frame window's
+    for (int q = threadIdx.x, nk = small[0]; q < nk; q += TK_THREADS) s_new[q] = score[keep[q]];
+    TK_STAMP(3);
     if (next_t >= 0) {
         __syncthreads();
         d_track_active(0, small, o.ts, o.assoc, s_new, 1, next_t, active, small + 3);
     }
+    TK_STAMP(4);
 }
 
 // update_graph's first half in one launch (LDS-sized graphs): status word cleared, associations, active set
@@ -843,6 +866,17 @@ __global__ __launch_bounds__(256) void k_track_load(int N, int ND, const int32_t
 using namespace tmpnn;
 
 extern "C" {
+#ifdef TK_TIMELINE
+int tmpnn_debug_tk_timeline(unsigned long long* host_out, int reset) {     // (profiling build only: synchronises)
+    if (hipMemcpyFromSymbol(host_out, HIP_SYMBOL(tmpnn::g_tk_timeline), sizeof(unsigned long long) * 16) != hipSuccess) return -1;
+    if (reset) {
+        unsigned long long z[16] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(tmpnn::g_tk_timeline), z, sizeof(z)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif
+
 
 int tmpnn_track_associate(const tmpnn_dgraph* g, const int32_t* det_id, const uint8_t* labels, const float* score,
                           int mode, int32_t* assoc, int32_t* status, tmpnn_stream stream) {
@@ -1008,10 +1042,15 @@ int tmpnn_track_retire(const tmpnn_dgraph* g, const tmpnn_track_rows* rows, cons
         TM_REQUIRE(y_track && pos_of_det && ND > 0, "track_retire: null pointer / empty sequence");
         TM_SHM_ONCE(k_track_retire, sizeof(int) * FIN_LDS_DETS);
         hipLaunchKernelGGL(k_track_retire, dim3(1), dim3(TK_THREADS), sizeof(int) * (size_t)N, as_stream(stream), *g, *rows, score,
-                           associate, t_upto, ret_win, y_track, ND, pos_of_det, keep, small, *rows_out, h, ld_h, W, h_new,
-                           ld_hn, s_new, next_t, active, reinterpret_cast<int32_t*>(fin_ws),
+                           associate, t_upto, ret_win, y_track, ND, pos_of_det, keep, small, *rows_out, s_new, next_t, active,
+                           reinterpret_cast<int32_t*>(fin_ws),
                            associate == 2 ? (int)std::min<size_t>(fin_ws_bytes / 4, 1u << 30) : 0);
-        return check_launch("track_retire");
+        if ((rc = check_launch("track_retire"))) return rc;
+        // the kept rows' state: sized for every row kept, the count read on the device (blocks beyond it leave at once)
+        long blocks = ((long)N * ((W + 3) / 4) + 255) / 256;
+        if (blocks > 1024) blocks = 1024;
+        hipLaunchKernelGGL(k_track_gather, dim3((int)blocks), dim3(256), 0, as_stream(stream), h, ld_h, W, keep, small, h_new, ld_hn);
+        return check_launch("track_retire (state rows)");
     }
     TM_REQUIRE(associate != 2, "track_retire: the optimal assignment (associate = 2) serves graphs of <= %d rows", FIN_LDS_DETS);
     if (associate &&
