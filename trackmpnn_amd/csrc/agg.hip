@@ -544,10 +544,9 @@ static int segsum_dense(const tmpnn_graph* g, const tmpnn_seg_plan* pl, const fl
 // ------------------------------------------------------------------------------------------------------------
 // segment sum of a BATCH OF SMALL WINDOWS with every edge row read once (round 5, struct tmpnn_win_plan)
 // ------------------------------------------------------------------------------------------------------------
-// k_segsum_pipe reads an edge row from either endpoint, 2 x 256 B per edge at H = 64, and it is bound by the number of memory
-// instructions a CU can retire (~80 clocks per 64-lane request whatever its width: 12.8 B / clock / CU with 16 bytes a lane -- its
-// 0.43 ms per 6 M edges ARE its 12 000 row requests per CU).  A window of the rolling graph is ~100 dets and 1-2 k edge rows that
-// touch nothing outside it.  Here a workgroup owns (window, column half) JOBS; it walks the window's edge rows in ascending order
+// k_segsum_pipe reads an edge row from either endpoint, 2 x 256 B per edge at H = 64, through a memory pipe that gives a CU ~12
+// bytes per clock (its 0.43 ms per 6 M edges ARE that rate).  A window of the rolling graph is ~40-100 dets and 0.4-2 k edge rows
+// that touch nothing outside it.  Here a workgroup owns (window, column half) JOBS; it walks the window's edge rows in ascending order
 // in CHUNKS of 160 rows, staged in LDS once each (LDS-DMA, 128-byte row halves, three buffers: two chunks travel while one is
 // summed) -- half the row requests.  The sums are those of k_segsum_pipe BIT FOR BIT: incidence i of a det's run belongs to the
 // STREAM (det, i % 4), the lane group of k_segsum_pipe that adds it; a stream's partial sum lives in LDS for the length of the
