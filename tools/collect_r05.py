@@ -160,4 +160,24 @@ The maxima of `k_track_retire` / `k_track_select` are the Hungarian sweeps of th
 problems solved one after another inside the launch); nothing waits or spins.  The round-4 outliers belong to the full bench run:
 see `profiles/r05_bench_kernel_stats.md` (MaxNs column of the same kernels in this round's trace of `bench.py`).
 ''')
+        ts = f'{ld}/c2_timestep.json'
+        if os.path.exists(ts):
+            d = json.load(open(ts))
+            f.write('''
+## Where a C2 timestep goes (`tools/greedy_trace.py`: the inference loop of the C2 sequence alone, 50 sequences back to back)
+
+Wall time per timestep (un-profiled run) against the GPU kernel time per timestep (`rocprofv3 --kernel-trace` of the same command):
+the greedy loop keeps the device busy for about three quarters of a timestep -- a dozen launches of 3-25 us whose lengths are the
+latency of their dependent memory round trips (every kernel starts on a cold L2), plus one device -> host copy of two counters; the
+Hungarian loop is bound by the two launches that run the assignment sweep (`tools/track_timeline.py` splits them: the solver itself,
+one wave, ~7 us per 6 x 6 problem, a dozen problems per timestep).
+
+''')
+            for m in ('greedy', 'hungarian'):
+                x = d[m]
+                f.write(f"**{m}**: wall {x['wall_ms_per_timestep'] * 1e3:.0f} us per timestep, GPU kernels {x['kernel_us_per_timestep']:.1f} us per timestep "
+                        f"({x['profiled_ms_per_timestep'] * 1e3:.0f} us per timestep under the profiler)\n\n| kernel | launches / timestep | us / timestep | avg us |\n|---|---|---|---|\n")
+                for k, v in x['kernels'].items():
+                    f.write(f"| `{k}` | {v['per_timestep']} | {v['us_per_timestep']} | {v['avg_us']} |\n")
+                f.write('\n')
     print('loops: written')

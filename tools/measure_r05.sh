@@ -82,6 +82,33 @@ with open(O + '/slowest.txt', 'w') as out:
 print(open(O + '/slowest.txt').read())
 PY
   rm -rf $O/tr
+  # the greedy / Hungarian loops of the C2 sequence alone: GPU kernel time per timestep against the wall time per timestep
+  for M in greedy hungarian; do
+    python3 $R/tools/greedy_trace.py C2 $M > $O/wall_$M.log 2>&1 || { tail -5 $O/wall_$M.log; exit 1; }
+    rocprofv3 --kernel-trace --output-format csv -d $O/tr_$M -o r -- python3 $R/tools/greedy_trace.py C2 $M > $O/trace_$M.log 2>&1 || { tail -5 $O/trace_$M.log; exit 1; }
+  done
+  python3 - <<'PY'
+import csv, glob, json, os, collections
+O = os.environ['GRAFT_REPO_ROOT'] + '/gpurun_out/r05_loops'
+out = {}
+for M in ('greedy', 'hungarian'):
+    f = glob.glob(f'{O}/tr_{M}/**/*kernel_trace.csv', recursive=True)[0]
+    rows = list(csv.DictReader(open(f)))
+    wall = json.loads([l for l in open(f'{O}/wall_{M}.log') if l.startswith('{')][-1])
+    prof = json.loads([l for l in open(f'{O}/trace_{M}.log') if l.startswith('{')][-1])
+    nts = prof['sequences'] * prof['frames']
+    by = collections.defaultdict(lambda: [0, 0])
+    for r in rows:
+        k = r['Kernel_Name'].split('(')[0].replace('void ', '').replace('tmpnn::', '')[:48]
+        by[k][0] += 1; by[k][1] += int(r['End_Timestamp']) - int(r['Start_Timestamp'])
+    out[M] = dict(wall_ms_per_timestep=wall['ms_per_timestep'], profiled_ms_per_timestep=prof['ms_per_timestep'],
+                  kernel_us_per_timestep=round(sum(v[1] for v in by.values()) / nts / 1e3, 2),
+                  kernels={k: dict(per_timestep=round(v[0] / nts, 2), us_per_timestep=round(v[1] / nts / 1e3, 2), avg_us=round(v[1] / v[0] / 1e3, 2))
+                           for k, v in sorted(by.items(), key=lambda kv: -kv[1][1])[:10]})
+json.dump(out, open(O + '/c2_timestep.json', 'w'), indent=1)
+print(json.dumps({m: {k: v for k, v in d.items() if k != 'kernels'} for m, d in out.items()}))
+PY
+  rm -rf $O/tr_greedy $O/tr_hungarian
   ;;
 *) echo "unknown part $part"; exit 2;;
 esac

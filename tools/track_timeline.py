@@ -1,5 +1,6 @@
 """s_memtime sums per phase of k_track_retire (variant build -DTK_TIMELINE, TMPNN_LIB_PATH) over the greedy / Hungarian inference
-loops of bench.py's C2 / C3 sequences: associate | finalize | delete | gather | active, us per launch (s_memtime: 100 MHz)."""
+loops of bench.py's C2 / C3 sequences: associate | finalize | delete | gather | active, us per launch (s_memtime ticks taken as 1 ns: the phase sums then add up to the kernel's duration in the trace);
+the hg: entries split the Hungarian sweep (both launches that run it: k_track_select and k_track_retire, per k_track_retire launch)."""
 import ctypes, json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -11,7 +12,7 @@ from trackmpnn_amd.loops import infer_sequence
 dev = torch.device('cuda:0')
 raw = ctypes.CDLL(os.environ['TMPNN_LIB_PATH'])
 buf = (ctypes.c_ulonglong * 16)()
-names = ['associate', 'finalize', 'delete', 'gather', 'active']
+names = ['associate', 'finalize', 'delete', 'gather', 'active', 'hg: build problem', 'hg: solve', 'hg: barrier after solve', 'hg: apply + loop top']
 for tag in ('C2', 'C3'):
     s = bench.LOOP_SHAPES[tag]
     torch.manual_seed(5)
@@ -30,4 +31,4 @@ for tag in ('C2', 'C3'):
         assert raw.tmpnn_debug_tk_timeline(buf, 1) == 0
         n = max(int(buf[15]), 1)
         print(json.dumps(dict(seq=tag, hungarian=hung, launches=n,
-                              us_per_launch={nm: round(buf[i] / n / 100.0, 2) for i, nm in enumerate(names)})), flush=True)
+                              us_per_launch={nm: round(buf[i] / n / 1000.0, 2) for i, nm in enumerate(names)})), flush=True)

@@ -343,6 +343,19 @@ __device__ void hg_wave_solve64(HgShared& S, const float* C, int sr, int sc, int
 // What a timestep's passes need of an edge (the timestep it leads into, its endpoints' det indices, its cost) and of a det (its
 // timestep) is read ONCE into registers (four edges / dets per thread): a pass is then LDS and register work, not a chain of
 // dependent global loads per timestep; the result is kept per det index in LDS and written out once at the end.
+#ifdef TK_TIMELINE
+__device__ unsigned long long g_tk_timeline[16];
+#define HG_STAMP(i)                                                                               \
+    do {                                                                                          \
+        if (threadIdx.x == 0) {                                                                   \
+            const unsigned long long now_ = __builtin_amdgcn_s_memtime();                         \
+            atomicAdd(&g_tk_timeline[(i)], now_ - hg_last);                                       \
+            hg_last = now_;                                                                       \
+        }                                                                                         \
+    } while (0)
+#else
+#define HG_STAMP(i) do { } while (0)
+#endif
 __device__ void d_track_hungarian(tmpnn_dgraph g, const int32_t* __restrict__ ts, const int32_t* __restrict__ det_id,
                                   const float* __restrict__ score, int32_t* __restrict__ assoc, int32_t* __restrict__ status,
                                   float* __restrict__ cost_ws, int cost_ws_floats) {
@@ -362,7 +375,11 @@ __device__ void d_track_hungarian(tmpnn_dgraph g, const int32_t* __restrict__ ts
     __syncthreads();
     if (E == 0 || Dn == 0) return;
     int t_done = -0x7fffffff;
+#ifdef TK_TIMELINE
+    unsigned long long hg_last = __builtin_amdgcn_s_memtime();
+#endif
     for (;;) {
+        HG_STAMP(8);
         // the next timestep that edges lead into; its dets are a contiguous run of the det list (rows are in time order)
         if (tid == 0) { S.tnext = 0x7fffffff; S.d0 = 0x7fffffff; S.d1 = -1; }
         for (int d = tid; d < Dn; d += TK_THREADS) S.flag[d] = 0;
@@ -416,6 +433,8 @@ __device__ void d_track_hungarian(tmpnn_dgraph g, const int32_t* __restrict__ ts
         __threadfence_block();
         __syncthreads();
         const bool tr = nc < nr;                              // (scipy transposes a tall matrix)
+        HG_STAMP(5);
+        if (tid == 0) { HG_STAMP(14); }
         if (tid < 64) {
             if (max(nr, nc) <= 64) {
                 if (tr) hg_wave_solve64(S, C, 1, nc, nc, nr, tid);
@@ -425,8 +444,10 @@ __device__ void d_track_hungarian(tmpnn_dgraph g, const int32_t* __restrict__ ts
                 else hg_wave_solve(S, C, nc, 1, nr, nc, tid);
             }
         }
+        HG_STAMP(6);
         __threadfence_block();
         __syncthreads();
+        HG_STAMP(7);
         if (S.nr < 0) { if (tid == 0) atomicOr(status, 2); __syncthreads(); continue; }
         const int na = tr ? nc : nr;
         for (int i = tid; i < na; i += TK_THREADS) {
@@ -761,7 +782,6 @@ __global__ __launch_bounds__(TK_THREADS) void k_track_finalize(tmpnn_dgraph g, c
 // (a greedy timestep's GPU time is ~10 dependent launches of 2-8 us kernels; each launch saved is ~2 us of device gap and ~2 us
 //  of host time)
 #ifdef TK_TIMELINE            // (profiling build: s_memtime sums per phase of k_track_retire, thread 0; tools/track_timeline.py)
-__device__ unsigned long long g_tk_timeline[16];
 #define TK_STAMP(i)                                                                               \
     do {                                                                                          \
         __syncthreads();                                                                          \
