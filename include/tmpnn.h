@@ -649,8 +649,10 @@ int tmpnn_track_extend(int N, int A, int D, const int32_t* active, const int32_t
  * tmpnn_track_select_ws, graphs of <= TMPNN_DG_MAX_ROWS rows, its cost scratch = fin_ws / fin_ws_bytes, overflow in bit 1 of
  * small[1]; 0: rows->assoc holds them already, e.g. from a matching on the host), track finalisation, row deletion into rows_out, the state rows and scores compacted (h_new [N][ld_hn],
  * s_new [N]; small[0] / small[2] = kept rows / kept det rows).  next_t >= 0: also the active set of timestep next_t on
- * the compacted rows by the inference rule (their associations carry over: deletion removes no future edge of a kept det)
- * -> active[], small[3]; the caller then reads small once per timestep instead of twice. */
+ * the compacted rows by the inference rule -> active[], small[3]; the caller then reads small once per timestep instead of twice.
+ * Greedy associations carry over (deletion removes no future edge of a kept det); with associate = 2 the next update_graph would
+ * re-derive them by its own assignment sweep over the compacted graph (a det that was assigned and deleted frees its column), so
+ * that sweep runs here, over the rows that stay, and rows_out->assoc holds ITS result (round 5). */
 int tmpnn_track_retire(const tmpnn_dgraph* g, const tmpnn_track_rows* rows, const float* score, int associate, int t_upto,
                        int ret_win, int32_t* y_track, int ND, int32_t* pos_of_det, void* fin_ws, size_t fin_ws_bytes,
                        int32_t* keep, int32_t* small, const tmpnn_track_rows* rows_out, const float* h, int ld_h, int W,

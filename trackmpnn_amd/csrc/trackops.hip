@@ -358,19 +358,30 @@ __device__ unsigned long long g_tk_timeline[16];
 #endif
 __device__ void d_track_hungarian(tmpnn_dgraph g, const int32_t* __restrict__ ts, const int32_t* __restrict__ det_id,
                                   const float* __restrict__ score, int32_t* __restrict__ assoc, int32_t* __restrict__ status,
-                                  float* __restrict__ cost_ws, int cost_ws_floats) {
+                                  float* __restrict__ cost_ws, int cost_ws_floats, const int* remap = nullptr, int n_out = 0) {
+    // remap (k_track_retire, after the deletion): new index of a row that stays, -1 for a deleted one -- the sweep then runs over
+    // the rows that stay, as the reference's NEXT update_graph runs it on the compacted graph (deleted dets and the edges that go
+    // with them take no part; det ids and the order of rows are what they will be), and writes assoc [n_out] in the new numbering
     __shared__ HgShared S;
     constexpr int PER = 4096 / TK_THREADS;
     const int tid = threadIdx.x, N = g.N, E = g.meta[0], Dn = g.meta[1];
-    for (int r = tid; r < N; r += TK_THREADS) assoc[r] = -1;
+    for (int r = tid; r < (remap ? n_out : N); r += TK_THREADS) assoc[r] = -1;
     int e_t[PER], e_sp[PER], e_dp[PER], d_t[PER];
     float e_c[PER];
 #pragma unroll
     for (int k = 0; k < PER; ++k) {
         const int e = tid + TK_THREADS * k, d = tid + TK_THREADS * k;
         e_t[k] = 0x7fffffff; e_sp[k] = 0; e_dp[k] = 0; e_c[k] = 0.f; d_t[k] = -0x7fffffff;
-        if (e < E) { e_t[k] = ts[g.dst[e]]; e_sp[k] = g.src_pos[e]; e_dp[k] = g.dst_pos[e]; e_c[k] = 1.0f - score[g.edge_row[e]]; }
-        if (d < Dn) { d_t[k] = ts[g.det_row[d]]; S.ad[d] = -1; }
+        if (e < E) {
+            const int er = g.edge_row[e];
+            e_t[k] = ts[g.dst[e]]; e_sp[k] = g.src_pos[e]; e_dp[k] = g.dst_pos[e]; e_c[k] = 1.0f - score[er];
+            if (remap && remap[er] < 0) e_t[k] = 0x7fffffff;
+        }
+        if (d < Dn) {
+            const int dr = g.det_row[d];
+            d_t[k] = ts[dr]; S.ad[d] = -1;
+            if (remap && remap[dr] < 0) d_t[k] = -0x7fffffff;
+        }
     }
     __syncthreads();
     if (E == 0 || Dn == 0) return;
@@ -460,7 +471,7 @@ __device__ void d_track_hungarian(tmpnn_dgraph g, const int32_t* __restrict__ ts
     // y_pred[:, 2] of the associated dets: the det id of the partner
     for (int d = tid; d < Dn; d += TK_THREADS) {
         const int pd = S.ad[d];
-        if (pd >= 0) assoc[g.det_row[d]] = det_id[g.det_row[pd]];
+        if (pd >= 0) { const int row = g.det_row[d]; assoc[remap ? remap[row] : row] = det_id[g.det_row[pd]]; }
     }
 }
 
@@ -830,6 +841,15 @@ __global__ __launch_bounds__(TK_THREADS) void k_track_retire(tmpnn_dgraph g, tmp
     TK_STAMP(3);
     if (next_t >= 0) {
         __syncthreads();
+        if (associate == 2) {
+            // --hungarian: the next update_graph re-derives the associations by its own sweep over the compacted graph (a det that
+            // was assigned and deleted frees its column there); that sweep here, over the rows that stay, into the new rows
+            extern __shared__ int tk_new_index[];             // (d_track_delete's: new index of a kept row, -1 deleted)
+            d_track_hungarian(g, r.ts, r.det_id, score, o.assoc, small + 1, reinterpret_cast<float*>(fin_ws), hung_floats,
+                              tk_new_index, small[0]);
+            __threadfence_block();
+            __syncthreads();
+        }
         d_track_active(0, small, o.ts, o.assoc, s_new, 1, next_t, active, small + 3);
     }
     TK_STAMP(4);

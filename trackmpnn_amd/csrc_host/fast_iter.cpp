@@ -228,11 +228,11 @@ std::vector<torch::Tensor> small_iter(torch::Tensor x, c10::optional<torch::Tens
 }
 
 // ------------------------------------------------------------------------------------------------------------------------
-// One greedy inference timestep of infer.py:70-87 without the interpreter between its launches: update_graph's block append
+// One inference timestep of infer.py:70-87 (greedy or, since round 5, --hungarian association) without the interpreter between its launches: update_graph's block append
 // (tmpnn_track_extend; the active set of this timestep was derived by the previous step's tmpnn_track_retire), the model call
 // in eval mode (tmpnn_mp_iter_fwd) and decode_tracks (tmpnn_track_retire, with the NEXT timestep's active set), then the one
 // host read of the timestep.  trackmpnn_amd/loops.py drives it for models on the fused path and graphs of LDS size; every other
-// case (Hungarian matching, attention heads, wide cells, re-initialisation, empty timesteps) takes TrackGraph.update / .decode.
+// case (Hungarian matching on the host, attention heads, wide cells, re-initialisation, empty timesteps) takes TrackGraph.update / .decode.
 // Same kernels, same arguments: the results are those of the Python path bit for bit.
 using extend_fn = int (*)(int, int, int, const int32_t*, const int32_t*, int, const int32_t*, const tmpnn_track_rows*, const float*,
                           int, int, float*, int, const tmpnn_dgraph*, void*, size_t, tmpnn_stream);
@@ -242,7 +242,7 @@ using retire_fn = int (*)(const tmpnn_dgraph*, const tmpnn_track_rows*, const fl
 using ints_fn = size_t (*)(int);
 
 std::vector<torch::Tensor> greedy_step(std::vector<int64_t> ti, std::vector<int64_t> info, torch::Tensor h, int64_t cap_rows) {
-    TORCH_CHECK(ti.size() == 24 && info.size() == 18, "greedy_step: bad descriptors");
+    TORCH_CHECK(ti.size() == 27 && info.size() == 18, "greedy_step: bad descriptors");
     const auto f_extend = reinterpret_cast<extend_fn>(ti[0]);
     const auto f_retire = reinterpret_cast<retire_fn>(ti[1]);
     const auto f_ints = reinterpret_cast<ints_fn>(ti[2]);
@@ -262,6 +262,12 @@ std::vector<torch::Tensor> greedy_step(std::vector<int64_t> ti, std::vector<int6
     auto* small = reinterpret_cast<int32_t*>(ti[21]);
     const int64_t spare_next = ti[22];
     const auto stream = reinterpret_cast<tmpnn_stream>(ti[23]);
+    // association rule of decode_tracks: 1 greedy, 2 optimal assignment on the device (--hungarian; its cost scratch, and the
+    // next timestep's active set then comes from the launch's second sweep over the rows that stay)
+    const int associate = (int)ti[24];
+    void* const hung_ws = reinterpret_cast<void*>(ti[25]);
+    const size_t hung_ws_bytes = (size_t)ti[26];
+    TORCH_CHECK(associate == 1 || (associate == 2 && hung_ws && hung_ws_bytes > 0), "greedy_step: association rule ", associate);
     const auto f_fwd = reinterpret_cast<fwd_fn>(info[0]);
     const auto f_err = reinterpret_cast<err_fn>(info[2]);
     const auto f_bind = reinterpret_cast<bind_fn>(info[6]);
@@ -298,7 +304,8 @@ std::vector<torch::Tensor> greedy_step(std::vector<int64_t> ti, std::vector<int6
     torch::Tensor hbuf = at::empty({(Nt + spare_next) * GH}, opts);
     torch::Tensor h_new = at::empty({0}, opts).set_(hbuf.storage(), 0, {Nt, GH}, {GH, 1});
     torch::Tensor s_new = at::empty({Nt, 1}, opts);
-    rc = f_retire(&dg, rows_cur, scores.data_ptr<float>(), 1, t_upto, ret_win, y_track, ND, pos_of_det, nullptr, 0, keep_rows,
+    rc = f_retire(&dg, rows_cur, scores.data_ptr<float>(), associate, t_upto, ret_win, y_track, ND, pos_of_det,
+                  associate == 2 ? hung_ws : nullptr, associate == 2 ? hung_ws_bytes : 0, keep_rows,
                   small, rows_out, h_out.data_ptr<float>(), (int)GH, (int)GH, h_new.data_ptr<float>(), (int)GH,
                   s_new.data_ptr<float>(), next_t, active, stream);
     TORCH_CHECK(rc == 0, "tmpnn_track_retire failed (code ", rc, "): ", f_err());

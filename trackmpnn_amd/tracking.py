@@ -287,9 +287,10 @@ class TrackGraph:
         lo, hi = self._t_range.get(int(t), (0, 0))
         D = hi - lo
         Xd = self._Xd
-        if (pf is not None and not train and not use_hungarian and pf[0] == int(t) and score_pos is pf[1]
+        if (pf is not None and not train and bool(use_hungarian) == pf[4] and pf[0] == int(t) and score_pos is pf[1]
                 and score_pos._version == pf[3]):
-            # decode() already derived this timestep's active set on the compacted rows (their associations carry over)
+            # decode() already derived this timestep's active set on the compacted rows (greedy associations carry over; the
+            # optimal assignment was re-derived over the rows that stayed, inside the same launch)
             A, status = pf[2], 0
         else:
             sp = None
@@ -344,8 +345,8 @@ class TrackGraph:
         self._prefetch = None
         if N == 0:              # an emptied window (cur_win_size = 1 and a timestep without detections): nothing to decode
             sc0 = score_pos.detach().reshape(-1)[:0].float()
-            if next_t is not None and not use_hungarian:
-                self._prefetch = (int(next_t), sc0, 0, sc0._version)
+            if next_t is not None:
+                self._prefetch = (int(next_t), sc0, 0, sc0._version, bool(use_hungarian))
             return h.detach()[:0].float(), sc0
         sp = score_pos.detach().reshape(-1).float().contiguous()
         hung_dev = use_hungarian and self._hungarian_on_device()
@@ -360,7 +361,7 @@ class TrackGraph:
         W = int(hd.shape[1])
         h_new = torch.empty((N, W), dtype=torch.float32, device=self.device)
         s_new = torch.empty((N, 1), dtype=torch.float32, device=self.device)
-        nt = -1 if (next_t is None or use_hungarian) else int(next_t)
+        nt = -1 if (next_t is None or (use_hungarian and not hung_dev)) else int(next_t)
         # ---- device, one call: associations, finalisation walk, deletion as a stream compaction of rows, state and scores,
         # and (next_t) the active set of the next timestep on the compacted rows
         if hung_dev:                                       # (N <= 4096: the finalisation needs no scratch; the slot carries the cost scratch)
@@ -381,12 +382,12 @@ class TrackGraph:
         self._graph = None                                 # (derived on first use: see `graph`)
         sc = s_new[:n_keep, 0]
         if nt >= 0:
-            self._prefetch = (nt, sc, a_next, sc._version)
+            self._prefetch = (nt, sc, a_next, sc._version, bool(use_hungarian))
         return h_new[:n_keep], sc
 
     # ---------------------------------------------------------------------------------------------------------------
     def greedy_step_fast(self, fast, model_info, h: torch.Tensor, cap_rows: int, t: int, t_upto: int, ret_win_size: int,
-                         next_t: Optional[int]):
+                         next_t: Optional[int], use_hungarian: bool = False):
         """One steady-state greedy timestep (update -> eval model call -> decode) through the native driver
         (csrc_host/fast_iter.cpp greedy_step): the same three tracker calls and the same model call as update() /
         TrackMPNN.forward_dgraph / decode(), issued without the interpreter between them, then the timestep's one host read.
@@ -396,13 +397,18 @@ class TrackGraph:
         pf = self._prefetch
         lo, hi = self._t_range.get(int(t), (0, 0))
         D = hi - lo
-        if pf is None or pf[0] != int(t) or D == 0:
+        if pf is None or pf[0] != int(t) or D == 0 or pf[4] != bool(use_hungarian):
             return None
         A = pf[2]
         N = self.N
         n_new = A * D + D
         if N == 0 or N + n_new > DG_MAX_ROWS or self._Xd.dtype != torch.float32:
             return None
+        if use_hungarian:           # the device solver must take every timestep's problem of the grown graph (rows, columns: dets)
+            if self._hung_max is None:
+                self._hung_max = int(_lib.load().tmpnn_track_hungarian_max_dets())
+            if self.Dn + D > self._hung_max or os.environ.get('TMPNN_HUNGARIAN_HOST', '0') == '1':
+                return None
         # what the native call would refuse with an exception is checked HERE, while nothing has been touched: the caller
         # then takes the Python path (update / forward_dgraph / decode) with the prefetched active set still in place
         GH = int(model_info[8]) * int(model_info[9])
@@ -422,6 +428,11 @@ class TrackGraph:
               C.addressof(self._crows[1 - self._cur]), self._Xf.data_ptr(), int(self._Xf.shape[1]), self.y_track.data_ptr(),
               int(self.y_track.numel()), self._pos_of_det.data_ptr(), self._keep.data_ptr(), self._small.data_ptr(), spare,
               _stream()]
+        if use_hungarian:
+            hws = self._hung_scratch()
+            ti += [2, hws.data_ptr(), hws.numel() * 4]
+        else:
+            ti += [1, 0, 0]
         model_info[7] = N + n_new
         try:
             h_new, s_new, counts, arena, scores, logits = fast.greedy_step(ti, model_info, h, int(cap_rows))
@@ -437,7 +448,7 @@ class TrackGraph:
         self._graph = None
         sc = s_new[:n_keep, 0]
         if nt >= 0:
-            self._prefetch = (nt, sc, a_next, sc._version)
+            self._prefetch = (nt, sc, a_next, sc._version, bool(use_hungarian))
         return h_new[:n_keep], sc, N + n_new + spare
 
     def kept_rows(self) -> torch.Tensor:
