@@ -116,6 +116,7 @@ def infer_sequence(model, X: torch.Tensor, y: torch.Tensor, cur_win_size: int = 
         sc = _pos_score(tg, scores, tp_classifier)
         st.stop('model_fwd')
         ncalls, edge_iters = 1, tg.E
+        step_info = None
         done = []                                              # TrackGraphs abandoned by a re-initialisation
         t_skip = t_st
         n_added = int(feats.shape[0])                          # rows the last update added (feats.shape[0] of infer.py:62)
@@ -135,8 +136,13 @@ def infer_sequence(model, X: torch.Tensor, y: torch.Tensor, cur_win_size: int = 
             else:
                 t_upto = t_end if t_cur == t_end - 1 else t_cur - cur_win_size + 2
                 if fast is not None and h is not None:
-                    # steady state: the whole timestep (append, model call, decode, the one host read) in the native driver
-                    r = tg.greedy_step_fast(fast, finfo(), h, h_cap, t_cur, t_upto, ret_win_size,
+                    # steady state: the whole timestep (append, model call, decode, the one host read) in the native driver.
+                    # Its model descriptor is built once per sequence (eval mode under no_grad: the parameters cannot change
+                    # inside this call; the per-step field, the row count, is overwritten by greedy_step_fast) -- building it
+                    # sits between the host read of one timestep and the first launch of the next, i.e. on the critical path
+                    if step_info is None:
+                        step_info = finfo()
+                    r = tg.greedy_step_fast(fast, step_info, h, h_cap, t_cur, t_upto, ret_win_size,
                                             t_cur + 1 if t_cur + 1 < t_end else None, use_hungarian)
                     if r is not None:
                         h, sc, h_cap = r
