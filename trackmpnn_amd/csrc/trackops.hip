@@ -132,7 +132,7 @@ struct HgShared {
     short ridx[4096];
     short ad[4096];                                       // per det index: det index of its association, -1 none
     int wave[TK_THREADS / 64 + 1];
-    int d0, d1, tnext, nr;
+    int d0, d1, tnext, nr, nrows;
 };
 __device__ __forceinline__ void hg_wave_sync() {          // LDS writes of this wave visible to its other lanes (one wave only)
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -389,12 +389,14 @@ __device__ void d_track_hungarian(tmpnn_dgraph g, const int32_t* __restrict__ ts
 #ifdef TK_TIMELINE
     unsigned long long hg_last = __builtin_amdgcn_s_memtime();
 #endif
+    // (an iteration starts with no timestep chosen, no det range and no row flags: set here, and again inside the loop once
+    //  everyone has read them -- one barrier less than doing it at the top)
+    if (tid == 0) { S.tnext = 0x7fffffff; S.d0 = 0x7fffffff; S.d1 = -1; }
+    for (int d = tid; d < Dn; d += TK_THREADS) S.flag[d] = 0;
+    __syncthreads();
     for (;;) {
         HG_STAMP(8);
         // the next timestep that edges lead into; its dets are a contiguous run of the det list (rows are in time order)
-        if (tid == 0) { S.tnext = 0x7fffffff; S.d0 = 0x7fffffff; S.d1 = -1; }
-        for (int d = tid; d < Dn; d += TK_THREADS) S.flag[d] = 0;
-        __syncthreads();
         {
             int m = 0x7fffffff;
 #pragma unroll
@@ -413,30 +415,34 @@ __device__ void d_track_hungarian(tmpnn_dgraph g, const int32_t* __restrict__ ts
         }
         __syncthreads();
         const int d0 = S.d0, nc = S.d1 - S.d0 + 1;
-        int nr;
-        {
-            const int IT = (Dn + TK_THREADS - 1) / TK_THREADS;      // <= 4 (Dn <= FIN_LDS_DETS)
+        // the rows in ascending det index: ONE wave ranks the flagged dets by ballots (a block-wide scan is three barriers a pass)
+        if (tid < 64) {
             int run = 0;
-            for (int it = 0; it < IT; ++it) {
-                const int d = it * TK_THREADS + tid;
-                const int f = (d < Dn && S.flag[d]) ? 1 : 0;
-                int tot;
-                const int ex = tk_block_scan(f, S.wave, &tot);
-                if (f) { const int k = run + ex; S.ridx[d] = (short)min(k, 32767); if (k < HG_MAX) S.rowlist[k] = d; }
-                run += tot;
+            for (int base = 0; base < Dn; base += 64) {
+                const int d = base + tid;
+                const bool f = d < Dn && S.flag[d];
+                const unsigned long long bal = __ballot(f);
+                if (f) {
+                    const int k = run + __popcll(bal & ((1ull << tid) - 1ull));
+                    S.ridx[d] = (short)min(k, 32767);
+                    if (k < HG_MAX) S.rowlist[k] = d;
+                }
+                run += __popcll(bal);
             }
-            nr = run;
+            if (tid == 0) S.nrows = run;
         }
         __syncthreads();
-        if (nr == 0) continue;
+        const int nr = S.nrows;
+        if (tid == 0) { S.tnext = 0x7fffffff; S.d0 = 0x7fffffff; S.d1 = -1; S.nr = nr; }
+        for (int d = tid; d < Dn; d += TK_THREADS) S.flag[d] = 0;
         const bool lds_cost = (long)nr * nc <= HG_LDS_COST;
-        if (nr > HG_MAX || nc > HG_MAX || (!lds_cost && (cost_ws == nullptr || (long)nr * nc > cost_ws_floats))) {
-            if (tid == 0) atomicOr(status, 2);
+        if (nr == 0 || nr > HG_MAX || nc > HG_MAX || (!lds_cost && (cost_ws == nullptr || (long)nr * nc > cost_ws_floats))) {
+            if (nr != 0 && tid == 0) atomicOr(status, 2);
+            __syncthreads();
             continue;
         }
         float* C = lds_cost ? S.cost : cost_ws;
         for (int x = tid; x < nr * nc; x += TK_THREADS) C[x] = 100.0f;
-        if (tid == 0) S.nr = nr;
         __syncthreads();
 #pragma unroll
         for (int k = 0; k < PER; ++k)
@@ -445,7 +451,6 @@ __device__ void d_track_hungarian(tmpnn_dgraph g, const int32_t* __restrict__ ts
         __syncthreads();
         const bool tr = nc < nr;                              // (scipy transposes a tall matrix)
         HG_STAMP(5);
-        if (tid == 0) { HG_STAMP(14); }
         if (tid < 64) {
             if (max(nr, nc) <= 64) {
                 if (tr) hg_wave_solve64(S, C, 1, nc, nc, nr, tid);
