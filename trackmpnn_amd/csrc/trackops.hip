@@ -152,6 +152,8 @@ __device__ __forceinline__ uint64_t hg_min_step64(uint64_t x) {
     const uint64_t y = ((uint64_t)hg_dpp<CTRL>((uint32_t)(x >> 32)) << 32) | hg_dpp<CTRL>((uint32_t)x);
     return y < x ? y : x;
 }
+// ROWS: rows of 16 lanes that can hold a live key (problems of <= 16 columns: the first row alone -- three pairs of v_readlane less)
+template <int ROWS = 4>
 __device__ __forceinline__ uint64_t hg_wave_min64(uint64_t x) {
     x = hg_min_step64<0xB1>(x);          // quad_perm [1,0,3,2]
     x = hg_min_step64<0x4E>(x);          // quad_perm [2,3,0,1]
@@ -159,7 +161,7 @@ __device__ __forceinline__ uint64_t hg_wave_min64(uint64_t x) {
     x = hg_min_step64<0x140>(x);         // row_mirror: every lane of a row of 16 holds the row's minimum
     uint64_t m = ~0ull;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
+    for (int r = 0; r < ROWS; ++r) {
         const uint64_t y = ((uint64_t)__builtin_amdgcn_readlane((uint32_t)(x >> 32), 16 * r) << 32) | (uint32_t)__builtin_amdgcn_readlane((uint32_t)x, 16 * r);
         m = y < m ? y : m;
     }
@@ -167,6 +169,7 @@ __device__ __forceinline__ uint64_t hg_wave_min64(uint64_t x) {
 }
 template <int CTRL>
 __device__ __forceinline__ uint32_t hg_min_step32(uint32_t x) { const uint32_t y = hg_dpp<CTRL>(x); return y < x ? y : x; }
+template <int ROWS = 4>
 __device__ __forceinline__ uint32_t hg_wave_min32(uint32_t x) {
     x = hg_min_step32<0xB1>(x);
     x = hg_min_step32<0x4E>(x);
@@ -174,7 +177,7 @@ __device__ __forceinline__ uint32_t hg_wave_min32(uint32_t x) {
     x = hg_min_step32<0x140>(x);
     uint32_t m = ~0u;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) { const uint32_t y = (uint32_t)__builtin_amdgcn_readlane(x, 16 * r); m = y < m ? y : m; }
+    for (int r = 0; r < ROWS; ++r) { const uint32_t y = (uint32_t)__builtin_amdgcn_readlane(x, 16 * r); m = y < m ? y : m; }
     return m;
 }
 __device__ __forceinline__ uint64_t hg_key(double x) {        // order-preserving: a < b  <=>  key(a) < key(b)   (no NaNs here)
@@ -287,6 +290,7 @@ __device__ __forceinline__ double hg_readlane_f64(double x, int l) {
     const long long b = __double_as_longlong(x);
     return __longlong_as_double(((long long)__builtin_amdgcn_readlane((int)(b >> 32), l) << 32) | (unsigned)__builtin_amdgcn_readlane((int)b, l));
 }
+template <int ROWS>
 __device__ void hg_wave_solve64(HgShared& S, const float* C, int sr, int sc, int nr, int nc, int lane) {
     double v = 0.0, u = 0.0;
     int r4c = -1, c4r = -1;
@@ -306,10 +310,10 @@ __device__ void hg_wave_solve64(HgShared& S, const float* C, int sr, int sc, int
                 const double r = min_val + c - ui - v;
                 if (r < spc) { path = i; spc = r; }
             }
-            const uint64_t mk = hg_wave_min64(alive ? hg_key(spc) : ~0ull);
+            const uint64_t mk = hg_wave_min64<ROWS>(alive ? hg_key(spc) : ~0ull);
             uint32_t sel = 0xFFFFFFFFu;
             if (alive && hg_key(spc) == mk) sel = r4c == -1 ? (uint32_t)(HG_MAX - 1 - pos) : (uint32_t)(HG_MAX + pos);
-            sel = hg_wave_min32(sel);
+            sel = hg_wave_min32<ROWS>(sel);
             const int ipos = sel < (uint32_t)HG_MAX ? HG_MAX - 1 - (int)sel : (int)sel - HG_MAX;
             const unsigned long long bal = __ballot(alive && pos == ipos);
             const int jsel = __ffsll((long long)bal) - 1;           // (exactly one column sits at a position)
@@ -453,8 +457,14 @@ __device__ void d_track_hungarian(tmpnn_dgraph g, const int32_t* __restrict__ ts
         HG_STAMP(5);
         if (tid < 64) {
             if (max(nr, nc) <= 64) {
-                if (tr) hg_wave_solve64(S, C, 1, nc, nc, nr, tid);
-                else hg_wave_solve64(S, C, nc, 1, nr, nc, tid);
+                // (the solver's columns: the longer side; lanes beyond them never hold a live key)
+                if (max(nr, nc) <= 16) {
+                    if (tr) hg_wave_solve64<1>(S, C, 1, nc, nc, nr, tid);
+                    else hg_wave_solve64<1>(S, C, nc, 1, nr, nc, tid);
+                } else {
+                    if (tr) hg_wave_solve64<4>(S, C, 1, nc, nc, nr, tid);
+                    else hg_wave_solve64<4>(S, C, nc, 1, nr, nc, tid);
+                }
             } else {
                 if (tr) hg_wave_solve(S, C, 1, nc, nc, nr, tid);
                 else hg_wave_solve(S, C, nc, 1, nr, nc, tid);
