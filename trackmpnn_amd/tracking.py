@@ -335,9 +335,12 @@ class TrackGraph:
                use_hungarian: bool = False, next_t: Optional[int] = None) -> Tuple[torch.Tensor, torch.Tensor]:
         """reference decode_tracks (utils/graph.py:392-539): re-derive the associations from the scores, finalise
         tracks up to t_upto and delete the decoded part of the graph -- all on the device, one call (tmpnn_track_retire:
-        associate, finalize, delete, gather); ONE host read: the number of kept rows.  `next_t` (greedy inference): the
+        associate, finalize, delete, gather); ONE host read: the number of kept rows.  `next_t` (inference): the
         timestep the loop will hand to update() next -- its active set is then derived here, on the compacted rows, and
-        read with the same host read, so that update(next_t) given the scores this call returns reads nothing.  The
+        read with the same host read, so that update(next_t) given the scores this call returns reads nothing.  Greedy
+        associations carry over to those rows; under `use_hungarian` (matching on the device) the launch runs the sweep
+        update_graph would run on the compacted graph and leaves ITS associations in the rows (what `y_pred()` shows between
+        this call and the next update is then the next update's column 2, not the decode's).  The
         finalised tracks live in `self.y_track` (fetch them with tracks() when the sequence is done); pass a host array
         `y_out` [ND, 2] only where it must be current after every call (tests): it costs a device -> host copy.
         Returns the compacted (h', score_pos')."""
@@ -388,9 +391,9 @@ class TrackGraph:
     # ---------------------------------------------------------------------------------------------------------------
     def greedy_step_fast(self, fast, model_info, h: torch.Tensor, cap_rows: int, t: int, t_upto: int, ret_win_size: int,
                          next_t: Optional[int], use_hungarian: bool = False):
-        """One steady-state greedy timestep (update -> eval model call -> decode) through the native driver
-        (csrc_host/fast_iter.cpp greedy_step): the same three tracker calls and the same model call as update() /
-        TrackMPNN.forward_dgraph / decode(), issued without the interpreter between them, then the timestep's one host read.
+        """One steady-state inference timestep (update -> eval model call -> decode; greedy or device-Hungarian association)
+        through the native driver (csrc_host/fast_iter.cpp greedy_step): the same three tracker calls and the same model call as
+        update() / TrackMPNN.forward_dgraph / decode(), issued without the interpreter between them, then the timestep's one host read.
         Preconditions (the caller checks them, else it takes the Python path): the previous decode / step prefetched this
         timestep's active set (`_prefetch`), D_t > 0, the grown graph fits the one-launch kernels (<= 4096 rows).
         Returns (h', score', capacity of h' in rows) or None when the preconditions do not hold."""
