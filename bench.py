@@ -192,6 +192,47 @@ def stage_profile(model, plan, H):
     return t, flops, nbytes
 
 
+def wide_stage_profile(g, H):
+    """C5 (H >= 128 cells, csrc/wide.hip): the dominant kernel of the step -- the wide edge cell's forward over 128-row edge
+    tiles, `tmpnn_wide_gru_fwd_tiled` (k_wide_prep / k_wide_gemm_store for the projected det rows + k_wide_gru_fwd_pp) -- timed
+    with HIP events on the launch stream and priced against both roofs: algorithmic bytes (24 H + 12) E + 28 H Dn over 8 TB/s,
+    and the executed bf16 products (6 per fp32 product of the 3H x H recurrent GEMM) over the 2.5 PFLOP/s dense bf16 peak."""
+    from trackmpnn_amd import _lib
+    from trackmpnn_amd.graph import edge_tiles
+    dev = g.device
+    N, E, Dn = g.N, g.E, g.Dn
+    st = torch.cuda.current_stream().cuda_stream
+    lib = _lib.load()
+    gen = torch.Generator(device=dev).manual_seed(0)
+    h = torch.randn(N, H, device=dev, generator=gen)
+    sc = 1.0 / H ** 0.5
+    wih, whh = sc * torch.randn(3 * H, H, device=dev, generator=gen), sc * torch.randn(3 * H, H, device=dev, generator=gen)
+    bih, bhh = torch.zeros(3 * H, device=dev), torch.zeros(3 * H, device=dev)
+    prep = torch.empty(int(lib.tmpnn_wide_prep_bytes(H, H)) // 4 + 4, device=dev)
+    _lib.call('tmpnn_wide_prepare', wih.data_ptr(), whh.data_ptr(), H, H, prep.data_ptr(), st)
+    P = torch.empty(Dn, 3 * H, device=dev)
+    out = torch.empty(N, H, device=dev)
+    gates = torch.empty(4, N, H, device=dev)
+    tiles = edge_tiles(g, 128)
+
+    def fwd():
+        _lib.call('tmpnn_wide_gru_fwd_tiled', prep.data_ptr(), g.det_row.data_ptr(), Dn, tiles.cref(), E, h.data_ptr(), H, H,
+                  bih.data_ptr(), bhh.data_ptr(), P.data_ptr(), out.data_ptr(), H, gates.data_ptr(), N * H, st)
+    ms = time_stage(fwd, iters=3)
+    nb = (24.0 * H + 12.0) * E + 28.0 * H * Dn
+    gbs = nb / (ms * 1e-3) / 1e9
+    bf16_tf = 6.0 * 2.0 * 3.0 * H * H * (E + Dn) / (ms * 1e-3) / 1e12
+    hbm_frac, pipe_frac = gbs / HBM_PEAK_GBS, bf16_tf / 2500.0
+    if hbm_frac >= pipe_frac:
+        roof = dict(bound='hbm', kernel='wide_gru_fwd_edge (k_wide_gru_fwd_pp)', achieved=gbs, peak=HBM_PEAK_GBS, unit='GB/s',
+                    frac=hbm_frac, traffic=None, ms=ms, algorithmic_bytes=nb, matrix_pipe_frac=pipe_frac)
+    else:
+        roof = dict(bound='mfma', kernel='wide_gru_fwd_edge (k_wide_gru_fwd_pp)', achieved=bf16_tf, peak=2500.0, unit='TFLOP/s',
+                    frac=pipe_frac, traffic=None, ms=ms, hbm_frac=hbm_frac, dtype='bf16 pieces of fp32 operands (bf16x6)')
+    return roof, {'wide_gru_fwd_edge': dict(ms=round(ms, 4), GBs=round(gbs, 1), hbm_frac=round(hbm_frac, 3),
+                                            bf16_tflops=round(bf16_tf, 1))}
+
+
 def att_bytes(E, Dn, H, K, train):
     """Algorithmic bytes of the attention stage per call (every array counted once; the det tables once).
     SURVEY 8(d) budgets, per head, a 4 E score, 8 E of alpha per incidence and ANOTHER 4 H E read of h[e]; this implementation
@@ -566,16 +607,173 @@ def loop_batch1(budget_s=1.5):
     return out
 
 
+# BASELINE.json configs as bench workloads.  c2 is the headline (configs[1]) and the default for every N;
+# c4 (configs[3]) and c5 (configs[4]) are the two configurations that are multi-GPU by definition: `--workload c4|c5` times
+# them as the main line, and with N > 1 the default c2 run appends both as `scaling_extras` behind the timed c2 region.
+WORKLOADS = {
+    'c2': dict(kind='rolling', frames=7, mean_dets=6.0, max_dets=20, ncat=3, H=64, windows=16384,
+               label='C2 KITTI Car/RRC-shaped rolling windows: 7 frames, D_t~clip(Poisson(6),1,20), F=8 (2d), H=64, K=0, diff; '
+                     '1 fwd per frame + 1 bwd per window'),
+    'c4': dict(kind='rolling', frames=7, mean_dets=12.0, max_dets=40, ncat=8, H=64, windows=4096,
+               label='C4 BDD100K All/libra-shaped rolling windows: 7 frames, D_t~clip(Poisson(12),1,40), F=13 (2d, 8 categories), '
+                     'H=64, K=0, diff; 1 fwd per frame + 1 bwd per window'),
+    'c5': dict(kind='static', frames=50, dets=300, ncat=3, H=256, iters=4, windows=1,
+               label='C5 dense stress: one static window of 50 frames x 300 dets per GPU, F=8, H=256, K=0, diff, 4 MP iterations '
+                     '+ 1 bwd'),
+}
+
+
+def static_step(model, plan0, planr, x, targets, iters, opt, bucket, world):
+    """The static window mode of SURVEY 8(d): first call with every row new, then iters - 1 empty-x calls on the same graph,
+    one backward of the BCE loss over every call's logits, (all-reduce), Adam."""
+    import torch.nn.functional as Fnn
+    h = None
+    loss = 0.0
+    for it in range(iters):
+        scores, logits, h, _ = model.forward_graph(x if it == 0 else x[:0], h, plan0 if it == 0 else planr)
+        loss = loss + Fnn.binary_cross_entropy_with_logits(logits, targets, reduction='sum')
+    opt.zero_grad(set_to_none=False)
+    loss.backward()
+    if world > 1:
+        from trackmpnn_amd.dist import allreduce_grads
+        allreduce_grads(model, bucket, world)
+    opt.step()
+    return loss
+
+
+def make_workload(name, rank, dev, windows=None, frames=None, dets=None):
+    """Everything a workload's step needs, resident on `dev`: returns dict(step=callable, edge_iters, model, bucket, plans,
+    H, F, config).  Rank r draws its own windows (seed r + 1) -- sequence-level data parallelism, no data-path collective."""
+    from trackmpnn_amd import TrackMPNN
+    from trackmpnn_amd.dist import GradBucket
+    w = dict(WORKLOADS[name])
+    H, F = w['H'], w['ncat'] + 5
+    torch.manual_seed(5)
+    model = TrackMPNN('2d', w['ncat'], H, 0, 'diff').to(dev).train()
+    opt = torch.optim.Adam(model.parameters(), lr=1e-4, weight_decay=5e-4)       # train.py:329
+    bucket = GradBucket(model)      # flat gradient storage for every N: p.grad aliases it, one all-reduce when N > 1
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    if w['kind'] == 'rolling':
+        B = int(windows or w['windows'])
+        fr = int(frames or w['frames'])
+        plans, xs, edge_iters = build_batch(B, fr, w['mean_dets'], w['max_dets'], F, seed=rank + 1, device=dev)
+        gen = torch.Generator().manual_seed(rank)
+        targets = [(torch.rand(p.graph.N, 1, generator=gen) < 0.3).float().to(dev) for p in plans]
+        cfg = dict(workload=f"{w['label']}; {B} windows/GPU batched block-diagonally (64 distinct seeds tiled)",
+                   windows_per_gpu=B, edge_iterations_per_gpu_step=edge_iters, rows_final=plans[-1].graph.N)
+        return dict(step=lambda: step(model, plans, xs, targets, opt, bucket, world), edge_iters=edge_iters, model=model,
+                    bucket=bucket, plans=plans, H=H, F=F, config=cfg, frames=fr, shape=w)
+    from trackmpnn_amd.graph import dense_static_graph, plan_single
+    fr, D = int(frames or w['frames']), int(dets or w['dets'])
+    g = dense_static_graph(fr, D, 'cpu').to(dev)
+    gen = torch.Generator().manual_seed(rank + 1)
+    x = torch.zeros(g.N, F, device=dev)
+    x[g.det_row.long()] = torch.randn(g.Dn, F, generator=gen).to(dev)
+    targets = (torch.rand(g.N, 1, generator=torch.Generator().manual_seed(rank)) < 0.3).float().to(dev)
+    plan0, planr = plan_single(g, g.N), plan_single(g, 0)
+    iters = w['iters']
+    cfg = dict(workload=f"{w['label']} ({fr} x {D}: Dn={g.Dn}, E={g.E})", windows_per_gpu=1,
+               edge_iterations_per_gpu_step=g.E * iters, rows_final=g.N)
+    return dict(step=lambda: static_step(model, plan0, planr, x, targets, iters, opt, bucket, world), edge_iters=g.E * iters,
+                model=model, bucket=bucket, plans=[plan0], H=H, F=F, config=cfg, frames=fr, shape=w)
+
+
+def timed_steps(fn, steps, warmup, world, dev, setup=0):
+    """`setup` + `warmup` untimed steps, then EXACTLY `steps` steps bracketed by barrier + device sync on both sides;
+    returns the MAX over ranks of the elapsed seconds."""
+    import torch.distributed as dist
+    for _ in range(setup):
+        fn()
+    torch.cuda.synchronize()
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = tmax.item()
+    return dt
+
+
+def total_over_ranks(v, world, dev):
+    if world == 1:
+        return float(v)
+    import torch.distributed as dist
+    tot = torch.tensor([float(v)], device=dev, dtype=torch.float64)
+    dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+    return tot.item()
+
+
+def allreduce_block(bucket, world, dev, backend):
+    """the step's one collective on its own (flat fp32 gradient bucket, SUM), outside the timed region:
+    median of 20 all-reduces bracketed by device syncs, max over ranks."""
+    import torch.distributed as dist
+    ts = []
+    for _ in range(22):
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        dist.all_reduce(bucket.flat, op=dist.ReduceOp.SUM)
+        torch.cuda.synchronize()
+        ts.append(time.perf_counter() - t1)
+    ar = torch.tensor([sorted(ts[2:])[10]], device=dev, dtype=torch.float64)
+    dist.all_reduce(ar, op=dist.ReduceOp.MAX)
+    return dict(us=round(ar.item() * 1e6, 1), bytes=int(bucket.flat.numel()) * 4, backend=backend,
+                note='one flat-bucket all_reduce(SUM) per optimizer step')
+
+
+def scaling_extras(args, rank, world, dev):
+    """BASELINE.json configs[3] (C4: BDD-shaped sequences data-parallel + gradient all-reduce) and configs[4] (C5: one dense
+    window per GPU, 1 -> 8 weak scaling) behind the timed C2 region of an N > 1 run: a short step block each (same bracketing:
+    barrier + sync, MAX over ranks, SUM of edges) and the workload's own all-reduce (221 KB / 3.4 MB bucket)."""
+    out = {}
+    for name, kw, steps in (('c4', dict(windows=args.extras_c4_windows), 3),
+                            ('c5', dict(frames=args.extras_c5_frames, dets=args.extras_c5_dets), 2)):
+        try:
+            wl = make_workload(name, rank, dev, **kw)
+            dt = timed_steps(wl['step'], steps, 1, world, dev, setup=1)
+            edges = total_over_ranks(wl['edge_iters'], world, dev)
+            out[name] = dict(value=edges * steps / dt, unit='graph-edges/s', ms_per_step=dt / steps * 1e3, steps=steps, warmup=1,
+                             n_gpus=world, scaling='weak', config=dict(wl['config'], parallelism=f'sequence-dp{world}'),
+                             allreduce=allreduce_block(wl['bucket'], world, dev, args.backend),
+                             mem_GB=round(torch.cuda.max_memory_allocated() / 2 ** 30, 2))
+        except Exception as e:                                # noqa: BLE001  (a reporting extra must not sink the bench line)
+            out[name] = dict(error=f'{type(e).__name__}: {e}'[:300])
+        wl = None
+        import gc
+        gc.collect()
+        torch.cuda.empty_cache()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=2)
-    ap.add_argument('--windows', type=int, default=16384, help='tracking windows per GPU per step')
+    ap.add_argument('--workload', choices=sorted(WORKLOADS), default='c2',
+                    help='BASELINE.json config timed as the main line: c2 = configs[1] (headline, default), c4 = configs[3], '
+                         'c5 = configs[4]')
+    ap.add_argument('--windows', type=int, default=None, help='tracking windows per GPU per step (rolling workloads; default '
+                    '16384 for c2, 4096 for c4)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-stage-profile', action='store_true')
     ap.add_argument('--no-latency', action='store_true', help='skip the batch-1 latency block')
     ap.add_argument('--no-loops', action='store_true', help='skip the loop_batch1 block (train chunk / inference loop)')
+    ap.add_argument('--no-scaling-extras', action='store_true', help='N > 1: skip the C4 / C5 blocks behind the C2 region')
+    ap.add_argument('--extras-c4-windows', type=int, default=4096, help='windows per GPU of the C4 extras block')
+    ap.add_argument('--extras-c5-frames', type=int, default=50, help='frames of the C5 window (extras block and --workload c5)')
+    ap.add_argument('--extras-c5-dets', type=int, default=300, help='dets per frame of the C5 window')
     ap.add_argument('--backend', default='nccl', help='torch.distributed backend (nccl = RCCL; gloo only to rehearse '
                     'the N > 1 code path with several ranks sharing one GPU)')
     ap.add_argument('--single-device', action='store_true', help='rehearsal: every rank uses cuda:0')
@@ -607,66 +805,28 @@ def main():
             __graft_entry__.build()
     if world > 1:
         dist.barrier()
-    from trackmpnn_amd import TrackMPNN
-    from trackmpnn_amd.dist import GradBucket
 
-    frames, mean_dets, max_dets, F, H = 7, 6.0, 20, 8, 64
-    torch.manual_seed(5)
-    model = TrackMPNN('2d', 3, H, 0, 'diff').to(dev).train()
-    opt = torch.optim.Adam(model.parameters(), lr=1e-4, weight_decay=5e-4)       # train.py:329
-    bucket = GradBucket(model)      # flat gradient storage for every N: p.grad aliases it, one all-reduce when N > 1
-    plans, xs, edge_iters = build_batch(args.windows, frames, mean_dets, max_dets, F, seed=rank + 1, device=dev)
-    gen = torch.Generator().manual_seed(rank)
-    targets = [(torch.rand(p.graph.N, 1, generator=gen) < 0.3).float().to(dev) for p in plans]
-
-    # setup, before the W warm-up steps of the contract: one pass over the batch builds the per-graph caches (edge tiles, index
-    # records) and brings a fresh box's clocks and allocator up (a first process on a cold box was seen at 36 ms per step
-    # with W = 2 where every later run gave 29)
-    for _ in range(2):
-        step(model, plans, xs, targets, opt, bucket, world)
-    torch.cuda.synchronize()
-    for _ in range(args.warmup):
-        step(model, plans, xs, targets, opt, bucket, world)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step(model, plans, xs, targets, opt, bucket, world)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = tmax.item()
-        tot = torch.tensor([float(edge_iters)], device=dev, dtype=torch.float64)
-        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
-        total_edges = tot.item()
-    else:
-        total_edges = float(edge_iters)
+    wl = make_workload(args.workload, rank, dev, windows=args.windows,
+                       frames=args.extras_c5_frames if args.workload == 'c5' else None,
+                       dets=args.extras_c5_dets if args.workload == 'c5' else None)
+    model, bucket, plans, H, F, edge_iters = wl['model'], wl['bucket'], wl['plans'], wl['H'], wl['F'], wl['edge_iters']
+    frames, mean_dets, max_dets = wl['frames'], wl['shape'].get('mean_dets'), wl['shape'].get('max_dets')
+    # SETUP_STEPS untimed steps BEFORE the W warm-up steps of the contract (reported as `setup_steps`): one pass over the batch
+    # builds the per-graph caches (edge tiles, index records) and brings a fresh box's clocks and allocator up (a first process
+    # on a cold box was seen at 36 ms per step with W = 2 where every later run gave 29)
+    SETUP_STEPS = 2
+    dt = timed_steps(wl['step'], args.steps, args.warmup, world, dev, setup=SETUP_STEPS)
+    cfg_main = wl['config']
+    total_edges = total_over_ranks(edge_iters, world, dev)
     value = total_edges * args.steps / dt
 
     roofline = None
     extra = {}
     if world > 1:
-        # the step's one collective on its own (flat fp32 gradient bucket, SUM), outside the timed region:
-        # median of 20 all-reduces bracketed by device syncs, max over ranks
-        ts = []
-        for _ in range(22):
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            dist.all_reduce(bucket.flat, op=dist.ReduceOp.SUM)
-            torch.cuda.synchronize()
-            ts.append(time.perf_counter() - t1)
-        ar = torch.tensor([sorted(ts[2:])[10]], device=dev, dtype=torch.float64)
-        dist.all_reduce(ar, op=dist.ReduceOp.MAX)
-        extra['allreduce'] = dict(us=round(ar.item() * 1e6, 1), bytes=int(bucket.flat.numel()) * 4,
-                                  backend=args.backend, note='one flat-bucket all_reduce(SUM) per optimizer step')
-    if rank == 0 and not args.no_stage_profile:
+        extra['allreduce'] = allreduce_block(bucket, world, dev, args.backend)
+    if rank == 0 and not args.no_stage_profile and wl['shape']['kind'] == 'static':
+        roofline, extra['stage_roofs'] = wide_stage_profile(plans[-1].graph, H)
+    elif rank == 0 and not args.no_stage_profile:
         t, flops, nbytes = stage_profile(model, plans[-1], H)
         # the dominant kernel AMONG THOSE THE STEP RUNS: with the one-pass backward (default) the two stand-alone
         # backward kernels are measured for comparison only
@@ -752,28 +912,33 @@ def main():
                 'MFMAs alone hold the pipe for ~45 % of the kernel), not by HBM -- DESIGN.md section 4')
         extra['stage_graph'] = dict(N=plans[-1].graph.N, E=plans[-1].graph.E, Dn=plans[-1].graph.Dn)
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and wl['shape']['kind'] == 'rolling':
         cpu = cpu_baseline(frames, mean_dets, max_dets, F, H, seed=1)
 
     lat = None
-    if rank == 0 and world == 1 and not args.no_latency:
+    if rank == 0 and world == 1 and not args.no_latency and args.workload == 'c2':
         lat = latency_batch1()
+
+    if world > 1 and args.workload == 'c2' and not args.no_scaling_extras:
+        # BASELINE.json configs[3] / configs[4] behind the timed C2 region (every rank takes part: barriers + all-reduces)
+        wl = model = bucket = None
+        plans = None
+        import gc
+        gc.collect()
+        torch.cuda.empty_cache()
+        extra['scaling_extras'] = scaling_extras(args, rank, world, dev)
 
     if rank == 0:
         out = dict(metric='graph_edges_per_sec_fwd_bwd', value=value, unit='graph-edges/s', n_gpus=world,
-                   steps=args.steps, warmup=args.warmup, ms_per_step=dt / args.steps * 1e3, higher_is_better=True,
-                   scaling='weak', vs_baseline=None, dtype='f32', data='synthetic',
+                   steps=args.steps, warmup=args.warmup, setup_steps=SETUP_STEPS, ms_per_step=dt / args.steps * 1e3,
+                   higher_is_better=True, scaling='weak', vs_baseline=None, dtype='f32', data='synthetic',
                    arithmetic=('fp32 in/out; GRU GEMMs as bf16x6 split products on the bf16 matrix pipe, fp32 accumulate, '
                                'error <= the f32 MFMA chain (tools/pilot_split.py)') if split_enabled() else 'fp32 MFMA',
-                   config=dict(workload='C2 KITTI Car/RRC-shaped rolling windows: 7 frames, D_t~clip(Poisson(6),1,20), '
-                                        'F=8 (2d), H=64, K=0, diff; 1 fwd per frame + 1 bwd per window; '
-                                        f'{args.windows} windows/GPU batched block-diagonally (64 distinct seeds tiled)',
-                               windows_per_gpu=args.windows, edge_iterations_per_gpu_step=edge_iters,
-                               rows_final=plans[-1].graph.N, parallelism=f'sequence-dp{world}'),
+                   config=dict(cfg_main, parallelism=f'sequence-dp{world}'),
                    roofline=roofline, cpu_baseline=cpu)
         out.update(extra)
         out['latency_batch1'] = lat
-        out['loop_batch1'] = loop_batch1() if (world == 1 and not args.no_loops) else None
+        out['loop_batch1'] = loop_batch1() if (world == 1 and not args.no_loops and args.workload == 'c2') else None
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -123,8 +123,11 @@ typedef struct tmpnn_graph {
 typedef struct tmpnn_edge_tiles {
     int32_t T;              /* tiles */
     int32_t rows_per_tile;  /* 128 (wide cells) or 32 (H <= 64 cells) */
-    const int32_t* t_row;   /* [T * rows_per_tile] graph row of each slot; -1 = padding (last tile only, BEHIND its valid slots:
-                               the wide forward lets a padding slot recompute and rewrite what the tile's slot 0 writes) */
+    const int32_t* t_row;   /* [T * rows_per_tile] graph row of each slot; -1 = padding.  PRECONDITION (device data, not validated by
+                               the entry points; trackmpnn_amd.graph.build_edge_tiles guarantees it and tests/test_graph.py checks
+                               it): padding occurs in the LAST tile only, BEHIND its valid slots, so slot 0 of every tile is a real
+                               row -- the wide forward (k_wide_gru_fwd_pp) has no row guard: a padding slot recomputes and rewrites
+                               what its tile's slot 0 writes, byte for byte */
     const int32_t* t_loc;   /* [T * rows_per_tile] (position of the slot's src det in the tile's det list) |
                                (position of its dst det) << 16 */
     const int32_t* t_dptr;  /* [T + 1] offsets into t_dets */

@@ -752,8 +752,10 @@ def run_all(report=print):
         god = go.to(DEV)
         for k, v in check_wide(128, go, god).items():
             rec(f'wide cell H=128, {T}x{D} window (E={go.E}) {k}', v, 0.0 if (k.endswith('untouched') or k.endswith('bits')) else 2e-4)
-    for H in (128, 256):
-        # a dense 3-block window (tiles staged in LDS), a larger ragged batch (both kinds) and the small batch (one tile)
+    for H in (128, 256, 384, 512):
+        # a dense 3-block window (tiles staged in LDS), a larger ragged batch (both kinds: det lists above and below the staged
+        # size, a partial last tile) and the small batch (one tile); H = 384 / 512: the periodic request stream of the pp
+        # forward beyond the two widths C5 and the H = 128 models use
         for tag, gt in (('dense 4x40', dense_static_graph(4, 40)), ('ragged batch', make_graph(B=40, frames=7, mean=7, seed=3)),
                         ('small batch', g)):
             r = check_wide_tiled(H, gt)

@@ -223,7 +223,7 @@ def test_bench_two_rank_branch_runs_end_to_end():
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
            '--master-port', str(_free_port()), os.path.join(root, 'bench.py'), '--gpus', '2', '--backend', 'gloo',
            '--single-device', '--windows', '256', '--steps', '2', '--warmup', '1', '--no-cpu-baseline', '--no-latency',
-           '--no-loops']
+           '--no-loops', '--extras-c4-windows', '64', '--extras-c5-frames', '6', '--extras-c5-dets', '40']
     r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
@@ -238,3 +238,17 @@ def test_bench_two_rank_branch_runs_end_to_end():
     total = out['value'] * out['ms_per_step'] * 1e-3
     assert 1.8 * per_rank < total < 2.2 * per_rank
     assert out['roofline'] is not None and out['cpu_baseline'] is None
+    # BASELINE.json configs[3] / configs[4] behind the C2 region (toy sizes here): C4 = BDD-shaped windows, F = 13, the 221 KB
+    # bucket; C5 = one dense static window per rank, H = 256, 4 iterations, the 3.4 MB bucket
+    ex = out['scaling_extras']
+    assert 'error' not in ex['c4'] and 'error' not in ex['c5'], ex
+    c4, c5 = ex['c4'], ex['c5']
+    assert c4['n_gpus'] == 2 and c4['allreduce']['bytes'] == 4 * 55234 and c4['allreduce']['us'] > 0
+    assert c4['config']['windows_per_gpu'] == 64 and 'F=13' in c4['config']['workload']
+    tot4 = c4['value'] * c4['ms_per_step'] * 1e-3
+    assert 1.6 * c4['config']['edge_iterations_per_gpu_step'] < tot4 < 2.4 * c4['config']['edge_iterations_per_gpu_step']
+    assert c5['n_gpus'] == 2 and c5['allreduce']['bytes'] == 4 * 858626 and c5['allreduce']['us'] > 0
+    per5 = c5['config']['edge_iterations_per_gpu_step']
+    assert per5 % 4 == 0 and per5 // 4 >= 5 * 40 * 40
+    tot5 = c5['value'] * c5['ms_per_step'] * 1e-3
+    assert abs(tot5 - 2 * per5) <= 1e-6 * tot5

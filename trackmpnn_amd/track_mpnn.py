@@ -472,7 +472,11 @@ class TrackMPNN(nn.Module):
         hp_in = None
         if h_in is not None:
             hp_in = getattr(h_in, '_tmpnn_padded_state', None)
-            if hp_in is None or hp_in.shape[0] != h_in.shape[0]:
+            # the padded tensor behind h_in is reused only while h_in is what this path returned: for several feature groups
+            # h_in is a COPY of it, so an in-place edit by the caller (masking / resetting rows) moves h_in's version counter
+            # and the state is padded afresh from h_in (one group: h_in is a view of the padded tensor, edits reach it)
+            if (hp_in is None or hp_in.shape[0] != h_in.shape[0]
+                    or (G > 1 and getattr(h_in, '_tmpnn_padded_ver', None) != (h_in.data_ptr(), h_in._version))):
                 hp_in = self._pad_state(h_in)
         spare = max(256, graph.N)
         append = (hp_in is not None and n > 0 and getattr(hp_in, '_tmpnn_spare_rows', 0) >= n
@@ -512,6 +516,7 @@ class TrackMPNN(nn.Module):
                     sp._buf_ver[k] = b._version
         h_out = h_pad[:, :H] if G == 1 else self._unpad_state(h_pad)
         h_out._tmpnn_padded_state = h_pad
+        h_out._tmpnn_padded_ver = (h_out.data_ptr(), h_out._version)
         if need_grad and self._pending_graphs:
             for t in (scores, logits, h_pad):
                 if t.requires_grad:

@@ -258,8 +258,8 @@ class TrackGraph:
         # silently ignored, so refuse it (the reference's loops pass the same sequence tensors every step)
         # Contract: X / y must hold what initialize() was given.  The same tensor objects pass when their
         # version counters have not moved; other tensors pass when they alias the same storage un-edited, or -- a loop that
-        # re-slices y or moves X per step -- when shape and contents agree (y: compared in full, it is a few hundred rows;
-        # X: shape, dtype and its first / last feature rows).
+        # re-slices y or moves X per step -- when shape, dtype and contents agree (both compared in full: y on the host, it is a
+        # few hundred rows; X on the device against the cached copy).
         if X is self._X_src and y is self._y_src:
             if (X._version, y._version) != self._src_versions:
                 raise ValueError('TrackGraph.update: X / y were modified in place after initialize(); their contents are '
@@ -274,8 +274,10 @@ class TrackGraph:
                 if same and nm == 'y':
                     same = bool(torch.equal(given.detach().cpu(), self._y_host))
                 elif same and given.numel():
-                    a, b = given.detach()[0], self._Xd
-                    same = bool(torch.equal(a[:1].to(b.device, b.dtype), b[:1]) and torch.equal(a[-1:].to(b.device, b.dtype), b[-1:]))
+                    # compared IN FULL against the device copy (one device compare + one host read; the verdict is cached by
+                    # taking `given` over as the identity to compare with, so a loop that keeps passing it pays this once)
+                    b = self._Xd
+                    same = bool(torch.equal(given.detach()[0].to(b.device, b.dtype), b))
                 if not same:
                     raise ValueError(f'TrackGraph.update: {nm} differs from what initialize() was given (its contents are '
                                      'cached on the device once per sequence); start a new TrackGraph for new data')
@@ -330,6 +332,16 @@ class TrackGraph:
         self._graph = g
         return feats if Xd.dtype == torch.float32 else feats.to(Xd.dtype)
 
+    @staticmethod
+    def _check_assoc_status(status: int, hung_dev: bool) -> None:
+        """Status word of a retire launch (include/tmpnn.h): bit 2 = a timestep's assignment problem did not fit the device
+        solver and was left unassociated.  The pre-checks (`_hungarian_on_device`, the Dn + D test of the native step) keep it
+        from firing; if it ever does, the tracks this launch finalised are incomplete -- fail loudly instead of carrying on."""
+        if hung_dev and (status & 2):
+            raise RuntimeError('TrackGraph: the device Hungarian solver reported an assignment problem it could not take '
+                               '(status bit 2) inside a decode launch: the finalised tracks of this step are incomplete. '
+                               'Set TMPNN_HUNGARIAN_HOST=1 to match on the host')
+
     # ---------------------------------------------------------------------------------------------------------------
     def decode(self, h: torch.Tensor, score_pos: torch.Tensor, y_out: Optional[np.ndarray], t_upto: int, ret_win_size: int,
                use_hungarian: bool = False, next_t: Optional[int] = None) -> Tuple[torch.Tensor, torch.Tensor]:
@@ -379,7 +391,8 @@ class TrackGraph:
                   s_new.data_ptr(), nt, self._active.data_ptr(), _stream())
         if y_out is not None:
             y_out[:, 1] = self.y_track[:y_out.shape[0]].cpu().numpy()
-        n_keep, _, n_det, a_next = self._small.tolist()    # the ONE host read of a decode: kept rows (how many are dets; next A)
+        n_keep, status, n_det, a_next = self._small.tolist()    # the ONE host read of a decode: kept rows (how many are dets; next A)
+        self._check_assoc_status(status, hung_dev)
         self._cur = 1 - self._cur
         self.N, self.E, self.Dn = n_keep, n_keep - n_det, n_det
         self._graph = None                                 # (derived on first use: see `graph`)
@@ -444,7 +457,8 @@ class TrackGraph:
             # counters are as they were (the appended block sits beyond N and the grown index form in its own arena)
             self._prefetch = pf
             raise
-        n_keep, _, n_det, a_next = counts.tolist()
+        n_keep, status, n_det, a_next = counts.tolist()
+        self._check_assoc_status(status, bool(use_hungarian))
         self.last_E = self.E + A * D                       # (edges of the graph the model call ran on)
         self._cur = 1 - self._cur
         self.N, self.E, self.Dn = n_keep, n_keep - n_det, n_det
