@@ -159,6 +159,11 @@ int tmpnn_gather_concat_bwd(const tmpnn_graph* g, const float* d_out, int ld_dou
 int tmpnn_segsum_fwd(const tmpnn_graph* g, const float* in, int ld_in, float* out, int ld_out,
                      int H, int accumulate, int compact_out /* out row = d instead of det_row[d] */,
                      tmpnn_stream stream);
+/* The same sum where the caller KNOWS that rows >= row_limit of `in` are all-zero -- a forward call's new edge rows, which
+ * enter the state as 0 (models/track_mpnn.py:61, utils/graph.py:148,291): those rows are not read (their +-0 changes no bit
+ * of a sum).  row_limit >= N reads every row.  Ignored by the dense / window plans (they take the plain form). */
+int tmpnn_segsum_fwd_live(const tmpnn_graph* g, const float* in, int ld_in, float* out, int ld_out,
+                          int H, int compact_out, int row_limit, tmpnn_stream stream);
 int tmpnn_segsum_bwd(const tmpnn_graph* g, const float* d_out, int ld_dout, float* d_in, int ld_din,
                      int H, int accumulate, tmpnn_stream stream);
 

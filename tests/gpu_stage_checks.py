@@ -70,6 +70,27 @@ def check_segsum(H, mode, acc, compact, g, gd):
     return (od.cpu() - exp).abs().max().item()
 
 
+def check_segsum_live(H, compact, g, gd, frac=0.6):
+    """tmpnn_segsum_fwd_live: rows >= row_limit are promised to be zero and must not change a bit of the sum -- the limited
+    launch on a state whose tail rows ARE zero equals the full read; and the tail is really left unread: poisoned with NaN
+    behind the limit, the result is still that of the zero tail."""
+    lim = int(g.N * frac)
+    x = torch.randn(g.N, H + 4)
+    x[lim:] = 0
+    xd = x.to(DEV)
+    rows_out = g.Dn if compact else g.N
+    outs = []
+    for name, src, extra in (('tmpnn_segsum_fwd', xd, (0, int(compact))), ('tmpnn_segsum_fwd_live', xd, (int(compact), lim)),
+                             ('tmpnn_segsum_fwd_live', None, (int(compact), lim)), ('tmpnn_segsum_fwd_live', xd, (int(compact), g.N))):
+        if src is None:
+            src = xd.clone()
+            src[lim:] = float('nan')
+        od = torch.full((rows_out, H + 8), 7.0, device=DEV)
+        _lib.call(name, gd.cref(), src.data_ptr(), x.shape[1], od.data_ptr(), od.shape[1], H, *extra, st())
+        outs.append(od.cpu())
+    return float(not (torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2]) and torch.equal(outs[0], outs[3])))
+
+
 def gru_ref(x, h, wih, whh, bih, bhh):
     gi = F.linear(x, wih, bih)
     gh = F.linear(h, whh, bhh)
@@ -730,6 +751,8 @@ def run_all(report=print):
             for acc in (False, True):
                 rec(f'segsum {mode} H={H} acc={acc}', check_segsum(H, mode, acc, False, g, gd), 2e-5)
         rec(f'segsum fwd compact H={H}', check_segsum(H, 'fwd', False, True, g, gd), 2e-5)
+        for compact in (False, True):
+            rec(f'segsum fwd live rows H={H} compact={compact} bit-equal', check_segsum_live(H, compact, g, gd), 0.0)
         for xmode, kind in ((1, 'edge'), (2, 'edge'), (0, 'det'), (0, 'edge')):
             r = check_gru(H, xmode, g, gd, kind)
             for k, v in r.items():

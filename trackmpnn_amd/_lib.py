@@ -96,6 +96,7 @@ _SIGNATURES = {
     'tmpnn_gather_diff_bwd': (c_int, [_GP, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p]),
     'tmpnn_gather_concat_bwd': (c_int, [_GP, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p]),
     'tmpnn_segsum_fwd': (c_int, [_GP, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    'tmpnn_segsum_fwd_live': (c_int, [_GP, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     'tmpnn_segsum_bwd': (c_int, [_GP, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p]),
     'tmpnn_att_fwd': (c_int, [_GP, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_float,
                               c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),

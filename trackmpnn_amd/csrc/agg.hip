@@ -229,7 +229,10 @@ __global__ __launch_bounds__(256) void k_gather_pipe(int E, const int32_t* __res
 
 // DUAL (the second pass of the dense form below): incidence entries >= nsplit address rows of `part` ([.][H], dense) instead of
 // rows of `in`
-template <bool ACC, int U = 4, int SEG_CHUNK = 32, bool DUAL = false>
+// LIM (tmpnn_segsum_fwd_live): rows >= row_limit are known to be all-zero -- the new edge rows of a call, which start at 0
+// (models/track_mpnn.py:61) -- and are NOT read (a lane group's load is masked off: no request at all).  Adding their +-0
+// changes no bit of a sum, so the result equals the full read's.
+template <bool ACC, int U = 4, int SEG_CHUNK = 32, bool DUAL = false, bool LIM = false>
 __global__ __launch_bounds__(256) void k_segsum_pipe(int Dn, const int32_t* __restrict__ det_row,
                                                      const int32_t* __restrict__ rowptr,
                                                      const int32_t* __restrict__ inc,
@@ -237,7 +240,8 @@ __global__ __launch_bounds__(256) void k_segsum_pipe(int Dn, const int32_t* __re
                                                      const float* __restrict__ in, int ld_in,
                                                      float* __restrict__ out, int ld_out, int H,
                                                      float wneg, int cneg, int compact_out,
-                                                     const float* __restrict__ part = nullptr, int nsplit = 0) {
+                                                     const float* __restrict__ part = nullptr, int nsplit = 0,
+                                                     int row_limit = 0x7fffffff) {
     const int lane = threadIdx.x & 63;
     const int lpr = H >> 2;
     const int ngrp = 64 / lpr;
@@ -289,7 +293,11 @@ __global__ __launch_bounds__(256) void k_segsum_pipe(int Dn, const int32_t* __re
             live[u] = vC[u] != 0x7fffffff;
             const int row = live[u] ? (vC[u] & 0x7fffffff) : 0;
             w[u] = vC[u] < 0 ? wneg : 1.0f;
-            if (DUAL && row >= nsplit)
+            if (LIM) {
+                live[u] = live[u] && row < row_limit;
+                x[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (live[u]) x[u] = *reinterpret_cast<const float4*>(in + (size_t)row * ld_in + (vC[u] < 0 ? cneg : 0) + c4);
+            } else if (DUAL && row >= nsplit)
                 x[u] = *reinterpret_cast<const float4*>(part + (size_t)(row - nsplit) * H + c4);
             else
                 x[u] = *reinterpret_cast<const float4*>(in + (size_t)row * ld_in + (vC[u] < 0 ? cneg : 0) + c4);
@@ -882,7 +890,7 @@ static int segsum_win(const tmpnn_graph* g, const tmpnn_win_plan* pl, const floa
 }
 
 static int segsum(const tmpnn_graph* g, const float* in, int ld_in, float* out, int ld_out, int H, int accumulate,
-                  float wneg, int cneg, int compact_out, tmpnn_stream stream) {
+                  float wneg, int cneg, int compact_out, tmpnn_stream stream, int row_limit = 0x7fffffff) {
     int rc = check_graph(g);
     if (rc) return rc;
     rc = check_rows(in, ld_in, out, ld_out, H, H + cneg, H);
@@ -908,6 +916,16 @@ static int segsum(const tmpnn_graph* g, const float* in, int ld_in, float* out, 
     // 8 TB/s on the C3 shape; on C2 4 is the faster one).  A property of the graph, not of a measurement.
     // A block walks 32-entry chunks of the visiting order (8 dets per wave; 64: 0.44 -> 0.42 ms per 6 M edges).
     const bool deep = (long)2 * g->E > (long)24 * g->Dn;
+    if (row_limit < g->N && !accumulate) {         // rows >= row_limit are zero and stay unread (k_segsum_pipe<.., LIM>)
+        grid = dim3(grid_for(g->Dn, deep ? 16 : 32));
+        if (deep)
+            hipLaunchKernelGGL((k_segsum_pipe<false, 8, 16, false, true>), grid, block, 0, st, g->Dn, g->det_row, g->rowptr, g->inc,
+                               g->det_order, in, ld_in, out, ld_out, H, wneg, cneg, compact_out, (const float*)nullptr, 0, row_limit);
+        else
+            hipLaunchKernelGGL((k_segsum_pipe<false, 4, 32, false, true>), grid, block, 0, st, g->Dn, g->det_row, g->rowptr, g->inc,
+                               g->det_order, in, ld_in, out, ld_out, H, wneg, cneg, compact_out, (const float*)nullptr, 0, row_limit);
+        return check_launch("segsum (live rows)");
+    }
     if (agg_variant()) {                 // (high-degree graphs: 16-entry chunks, 4 dets per wave: 0.47 -> 0.49 on the C3 shape)
         if (deep) { if (accumulate) LSP(true, 8, 16); else LSP(false, 8, 16); }
         else      { if (accumulate) LSP(true, 4, 32); else LSP(false, 4, 32); }
@@ -968,6 +986,12 @@ int tmpnn_segsum_fwd(const tmpnn_graph* g, const float* in, int ld_in, float* ou
                      int compact_out, tmpnn_stream stream) {
     TM_SLICED(H, segsum(g, in + c0, ld_in, out + c0, ld_out, w, accumulate, -1.0f, 0, compact_out, stream));
     return segsum(g, in, ld_in, out, ld_out, H, accumulate, -1.0f, 0, compact_out, stream);
+}
+int tmpnn_segsum_fwd_live(const tmpnn_graph* g, const float* in, int ld_in, float* out, int ld_out, int H, int compact_out,
+                          int row_limit, tmpnn_stream stream) {
+    TM_REQUIRE(row_limit >= 0, "segsum_fwd_live: row_limit %d", row_limit);
+    TM_SLICED(H, segsum(g, in + c0, ld_in, out + c0, ld_out, w, 0, -1.0f, 0, compact_out, stream, row_limit));
+    return segsum(g, in, ld_in, out, ld_out, H, 0, -1.0f, 0, compact_out, stream, row_limit);
 }
 int tmpnn_segsum_bwd(const tmpnn_graph* g, const float* d_out, int ld_dout, float* d_in, int ld_din, int H,
                      int accumulate, tmpnn_stream stream) {

@@ -458,7 +458,9 @@ def mp_forward(spec: ModelSpec, plan: CallPlan, x: torch.Tensor, h_in: Optional[
         es = es_all[gi]
         if K == 0:
             _seg_plan_guard(g, dev, aux_obj is not None)
-            _lib.call('tmpnn_segsum_fwd', g.cref(), hg, GH, es.data_ptr(), H, H, 0, 1, st_det)
+            # (the call's new edge rows are 0 and are not read: rows >= N_old -- h_cat[N_old:] was just zero-filled and only
+            #  its det rows written; without new rows every row is read)
+            _lib.call('tmpnn_segsum_fwd_live', g.cref(), hg, GH, es.data_ptr(), H, H, 1, N_old if n > 0 else N, st_det)
             alphas.append(None)
         else:
             # the kernels take up to ATT_KMAX heads per call (all of them from one read of h[e]); more heads run in groups whose
