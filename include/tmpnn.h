@@ -414,6 +414,15 @@ int tmpnn_focal_loss_fwd(const int32_t* rows, int R, const float* scores, const 
 int tmpnn_focal_loss_bwd(const int32_t* rows, int R, const float* scores, const uint8_t* targets, float gamma,
                          int use_alpha, float alpha0, float alpha1, const float* d_loss, float scale, float* d_scores,
                          tmpnn_stream stream);
+/* Binary cross-entropy with logits, SUMMED over n elements -- the loss SURVEY 8(d)'s metric is quoted with (BCE on every logit of
+ * a call against fixed {0,1} targets; `torch.nn.functional.binary_cross_entropy_with_logits(reduction='sum')`):
+ * loss_sum[0] = sum_i max(l_i, 0) - l_i t_i + log(1 + exp(-|l_i|)), fixed summation order (bitwise reproducible);
+ * backward d_logits[i] = d_loss[0] * (sigmoid(l_i) - t_i).  targets: float [n].  ws: tmpnn_bce_logits_ws(n) floats. */
+size_t tmpnn_bce_logits_ws(long n);
+int tmpnn_bce_logits_sum_fwd(const float* logits, const float* targets, long n, float* loss_sum, float* ws, size_t ws_floats,
+                             tmpnn_stream stream);
+int tmpnn_bce_logits_sum_bwd(const float* logits, const float* targets, long n, const float* d_loss, float* d_logits,
+                             tmpnn_stream stream);
 /* train.py:70-81 for one forward call of a batch-1 window in ONE launch each way: create_targets, the cross-entropy over the
  * logits and the two focal terms with gamma = 0 and no alpha (edge rows; det rows too with the TP classifier), bit for bit
  * the values tmpnn_targets / tmpnn_ce_loss_* / tmpnn_focal_loss_* produce (same expressions, sums in the same order).

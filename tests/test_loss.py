@@ -195,3 +195,31 @@ def test_train_losses_equals_the_separate_modules(tp):
     (c3 * 0.7 + f3 * 1.3).backward()
     assert c3.item() == loss_c.item() and f3.item() == loss_f.item()
     assert torch.equal(la.grad, lc.grad) and torch.equal(sa.grad, sc.grad)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('n', [0, 1, 5, 4095, 4096, 4097, 1_000_003])
+def test_bce_with_logits_sum_equals_torch(n):
+    """trackmpnn_amd.loss.bce_with_logits_sum (the loss bench.py's step uses; SURVEY 8(d): BCE on all logits vs fixed {0,1}
+    targets) against torch.nn.functional.binary_cross_entropy_with_logits(reduction='sum') evaluated in fp64: value within
+    1e-6 relative, gradient within 1e-6 absolute incl. an upstream factor; logits span +-40 (saturated sigmoids); bitwise
+    repeatable."""
+    import torch.nn.functional as Fnn
+    from trackmpnn_amd.loss import bce_with_logits_sum
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU')
+    gen = torch.Generator().manual_seed(n)
+    l = (torch.randn(n, 1, generator=gen) * 8.0).clamp(-40, 40)
+    t = (torch.rand(n, 1, generator=gen) < 0.3).float()
+    ld = l.to('cuda:0').requires_grad_(True)
+    loss = bce_with_logits_sum(ld, t.to('cuda:0'))
+    (loss * 1.7).backward()
+    l64 = l.double().requires_grad_(True)
+    ref = Fnn.binary_cross_entropy_with_logits(l64, t.double(), reduction='sum')
+    (ref * 1.7).backward()
+    assert loss.shape == () and abs(loss.item() - ref.item()) <= 1e-6 * max(1.0, abs(ref.item()))
+    if n:
+        assert ld.grad.shape == ld.shape
+        assert (ld.grad.cpu().double() - l64.grad).abs().max().item() <= 1e-6
+    loss2 = bce_with_logits_sum(ld.detach(), t.to('cuda:0'))
+    assert torch.equal(loss2, loss.detach())

@@ -836,6 +836,7 @@ def test_bench_own_windows_vs_oracle(weights):
     import torch.nn.functional as Fnn
     import bench
     from trackmpnn_amd import TrackMPNN
+    from trackmpnn_amd.loss import bce_with_logits_sum
     frames, mean_dets, max_dets, F, H = 7, 6.0, 20, 8, 64            # bench.main's workload constants
     plans, xs, edge_iters = bench.build_batch(64, frames, mean_dets, max_dets, F, seed=1, device='cpu')
     assert len(plans) == 6 and edge_iters > 60000
@@ -863,7 +864,7 @@ def test_bench_own_windows_vs_oracle(weights):
         assert (s.detach().cpu() - s_ref.detach()).abs().max().item() <= SCORE_TOL, c
         assert torch.allclose(l.detach().cpu(), l_ref.detach(), atol=LOGIT_ATOL, rtol=LOGIT_RTOL), c
         assert torch.allclose(h.detach().cpu(), h_ref.detach(), atol=LOGIT_ATOL, rtol=LOGIT_RTOL), c
-        loss = loss + Fnn.binary_cross_entropy_with_logits(l, t.to(DEV), reduction='sum')
+        loss = loss + bce_with_logits_sum(l, t.to(DEV))                  # (bench.step's loss; the oracle side: torch's)
         loss_ref = loss_ref + Fnn.binary_cross_entropy_with_logits(l_ref, t, reduction='sum')
     assert abs(loss.item() - loss_ref.item()) <= 2e-5 * abs(loss_ref.item())
     loss.backward()

@@ -172,6 +172,9 @@ _SIGNATURES = {
                                      c_void_p, c_size_t, c_void_p]),
     'tmpnn_focal_loss_bwd': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_float, c_int, c_float, c_float, c_void_p,
                                      c_float, c_void_p, c_void_p]),
+    'tmpnn_bce_logits_ws': (c_size_t, [C.c_long]),
+    'tmpnn_bce_logits_sum_fwd': (c_int, [c_void_p, c_void_p, C.c_long, c_void_p, c_void_p, c_size_t, c_void_p]),
+    'tmpnn_bce_logits_sum_bwd': (c_int, [c_void_p, c_void_p, C.c_long, c_void_p, c_void_p, c_void_p]),
     'tmpnn_train_losses_supported': (c_int, [c_int, c_int]),
     'tmpnn_train_losses_ws': (c_size_t, [c_int, c_int]),
     'tmpnn_train_losses_fwd': (c_int, [_GP, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p,

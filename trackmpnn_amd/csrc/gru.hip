@@ -960,6 +960,182 @@ __global__ __launch_bounds__(WPB * 64) void k_gru_fwd_split(GruFwdArgs a) {
     }
 }
 
+// XMODE 0 forward (the NODE cell, models/layers.py:114: x = the compact aggregate es[d], both GEMMs per row) on the bf16 pipe.
+// Both weight matrices as three bf16 pieces take 2 x 81 KB at H = 64 -- more than the LDS -- so a block owns ONE 32-column half
+// of the outputs: its slices [piece][3 gates x 32 columns][H + 8] of W_ih and W_hh are 2 x 40.5 KB, and the two blocks that
+// share a row range sit on the same XCD (block ids b and b + 8), so the second read of a row's operands is an L2 hit.
+// Items are 32-row tiles pulled from an LDS counter; per item a lane splits its half row of x, runs the x products
+// (r, z, n_in), splits its half row of h and runs the h products (r, z, n_h); the next item's operands are requested right
+// behind the split that consumed the registers.  Epilogue, staging stores and the fused head as in k_gru_fwd_split.
+template <int H, int WPB>
+__global__ __launch_bounds__(WPB * 64) void k_gru_fwd_split_node(GruFwdArgs a) {
+    extern __shared__ float lds[];
+    constexpr int KP = H + 8, NKB = H / 16, CW = H / 32, NQ4 = H / 8, NC = 96;
+    constexpr int H3 = 3 * H;
+    // blocks b and b + 8 (same XCD under the round-robin placement) take the two column halves of row group
+    // (b % 8) + 8 * (b / (8 * CW))
+    const int cwb = CW == 1 ? 0 : (blockIdx.x >> 3) % CW;
+    const int group = CW == 1 ? blockIdx.x : (blockIdx.x & 7) + 8 * (blockIdx.x / (8 * CW));
+    const int ngroups = CW == 1 ? gridDim.x : gridDim.x / CW;
+    const int cw0 = cwb * 32;
+    uint16_t* sWi = reinterpret_cast<uint16_t*>(lds);                 // [3][NC][KP]
+    uint16_t* sWh = sWi + 3 * NC * KP;
+    for (int i = threadIdx.x; i < H * NC / 4; i += WPB * 64) {
+        const int k = i / (NC / 4), j0 = (i % (NC / 4)) * 4;
+        const int col = (j0 / 32) * H + cw0 + (j0 % 32);
+        const float4 wi = *reinterpret_cast<const float4*>(a.wih_t + (size_t)k * H3 + col);
+        const float4 wh = *reinterpret_cast<const float4*>(a.whh_t + (size_t)k * H3 + col);
+        const float wiv[4] = {wi.x, wi.y, wi.z, wi.w}, whv[4] = {wh.x, wh.y, wh.z, wh.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            uint16_t q1, q2, q3;
+            split1(wiv[e], q1, q2, q3);
+            sWi[(0 * NC + j0 + e) * KP + k] = q1; sWi[(1 * NC + j0 + e) * KP + k] = q2; sWi[(2 * NC + j0 + e) * KP + k] = q3;
+            split1(whv[e], q1, q2, q3);
+            sWh[(0 * NC + j0 + e) * KP + k] = q1; sWh[(1 * NC + j0 + e) * KP + k] = q2; sWh[(2 * NC + j0 + e) * KP + k] = q3;
+        }
+    }
+    float* stg_base = reinterpret_cast<float*>(sWh + 3 * NC * KP);
+    int* next_item = reinterpret_cast<int*>(stg_base + WPB * (32 * STG_LD));
+    float* sBias = reinterpret_cast<float*>(next_item + 4);          // [b_ir+b_hr | b_iz+b_hz | b_in | b_hn | w_head] of this half
+    for (int i = threadIdx.x; i < 32; i += WPB * 64) {
+        const int f = cw0 + i;
+        sBias[i] = a.b_ih[f] + a.b_hh[f];
+        sBias[32 + i] = a.b_ih[H + f] + a.b_hh[H + f];
+        sBias[64 + i] = a.b_ih[2 * H + f];
+        sBias[96 + i] = a.b_hh[2 * H + f];
+        sBias[128 + i] = a.logit_part ? a.w_head[f] : 0.f;
+    }
+    if (threadIdx.x == 0) *next_item = 0;
+    __syncthreads();
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int c = lane & 31, half = lane >> 5;
+    if ((__builtin_amdgcn_readfirstlane(wave) >> 2) == 0) __builtin_amdgcn_s_setprio(2);   // SIMD partners out of lockstep
+    const int tiles_total = (a.R + 31) / 32;
+    const int per_group = (tiles_total + ngroups - 1) / ngroups;
+    const int item_lo = group * per_group;
+    const int item_hi = min(tiles_total, item_lo + per_group);
+
+    int item = 0;
+    if (lane == 0) item = atomicAdd(next_item, 1);
+    item = __builtin_amdgcn_readfirstlane(item) + item_lo;
+    if (item >= item_hi) return;
+    int r0 = item * 32;
+    int li = min(r0 + c, a.R - 1);
+    int row = a.rows[li];
+    float4 rawx[NQ4], rawh[NQ4];
+    {
+        const float4* xr = reinterpret_cast<const float4*>(a.msg + (size_t)(a.msg_compact ? li : row) * a.ld_msg + (H / 2) * half);
+        const float4* hr = reinterpret_cast<const float4*>(a.h + (size_t)row * a.ld_h + (H / 2) * half);
+#pragma unroll
+        for (int i = 0; i < NQ4; ++i) rawx[i] = xr[i];
+#pragma unroll
+        for (int i = 0; i < NQ4; ++i) rawh[i] = hr[i];
+    }
+    float* stg = stg_base + wave * (32 * STG_LD);
+    const uint16_t* wpi = sWi + c * KP + (H / 2) * half;
+    const uint16_t* wph = sWh + c * KP + (H / 2) * half;
+
+    for (;;) {
+        int nitem = 0;
+        if (lane == 0) nitem = atomicAdd(next_item, 1);
+        nitem = __builtin_amdgcn_readfirstlane(nitem) + item_lo;
+        const bool nvalid = nitem < item_hi;
+        const int nr0 = nvalid ? nitem * 32 : r0;
+        const int nli = min(nr0 + c, a.R - 1);
+        const int nrow = a.rows[nli];
+        f32x16 acc_r, acc_z, acc_hn, acc_in;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { acc_r[i] = 0.f; acc_z[i] = 0.f; acc_hn[i] = 0.f; acc_in[i] = 0.f; }
+        Split8 b[NKB];
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb) b[kb] = split8(rawx[2 * kb], rawx[2 * kb + 1]);
+        if (nvalid) {
+            const float4* xr = reinterpret_cast<const float4*>(a.msg + (size_t)(a.msg_compact ? nli : nrow) * a.ld_msg + (H / 2) * half);
+#pragma unroll
+            for (int i = 0; i < NQ4; ++i) rawx[i] = xr[i];
+        }
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb) {
+#pragma unroll
+            for (int g = 0; g < 3; ++g) {
+                const uint16_t* wp = wpi + (g * 32) * KP + 8 * kb;
+                const uint4 w1 = *reinterpret_cast<const uint4*>(wp);
+                const uint4 w2 = *reinterpret_cast<const uint4*>(wp + NC * KP);
+                const uint4 w3 = *reinterpret_cast<const uint4*>(wp + 2 * NC * KP);
+                if (g == 0) acc_r = mfma_x6(w1, w2, w3, b[kb], acc_r);
+                else if (g == 1) acc_z = mfma_x6(w1, w2, w3, b[kb], acc_z);
+                else acc_in = mfma_x6(w1, w2, w3, b[kb], acc_in);
+            }
+        }
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb) b[kb] = split8(rawh[2 * kb], rawh[2 * kb + 1]);
+        if (nvalid) {
+            const float4* hr = reinterpret_cast<const float4*>(a.h + (size_t)nrow * a.ld_h + (H / 2) * half);
+#pragma unroll
+            for (int i = 0; i < NQ4; ++i) rawh[i] = hr[i];
+        }
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb) {
+#pragma unroll
+            for (int g = 0; g < 3; ++g) {
+                const uint16_t* wp = wph + (g * 32) * KP + 8 * kb;
+                const uint4 w1 = *reinterpret_cast<const uint4*>(wp);
+                const uint4 w2 = *reinterpret_cast<const uint4*>(wp + NC * KP);
+                const uint4 w3 = *reinterpret_cast<const uint4*>(wp + 2 * NC * KP);
+                if (g == 0) acc_r = mfma_x6(w1, w2, w3, b[kb], acc_r);
+                else if (g == 1) acc_z = mfma_x6(w1, w2, w3, b[kb], acc_z);
+                else acc_hn = mfma_x6(w1, w2, w3, b[kb], acc_hn);
+            }
+        }
+        // epilogue: lane = its own row, accumulator register 4q + i <-> feature cw0 + 8q + 4 half + i
+        float4 hp4[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            hp4[q] = *reinterpret_cast<const float4*>(a.h + (size_t)row * a.ld_h + cw0 + 8 * q + 4 * half);
+        f32x16 outv;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 br = *reinterpret_cast<const float4*>(sBias + 8 * q + 4 * half);
+            const float4 bz = *reinterpret_cast<const float4*>(sBias + 32 + 8 * q + 4 * half);
+            const float4 bi = *reinterpret_cast<const float4*>(sBias + 64 + 8 * q + 4 * half);
+            const float4 bh = *reinterpret_cast<const float4*>(sBias + 96 + 8 * q + 4 * half);
+            const float brv[4] = {br.x, br.y, br.z, br.w}, bzv[4] = {bz.x, bz.y, bz.z, bz.w};
+            const float biv[4] = {bi.x, bi.y, bi.z, bi.w}, bhv[4] = {bh.x, bh.y, bh.z, bh.w};
+            const float hp[4] = {hp4[q].x, hp4[q].y, hp4[q].z, hp4[q].w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int reg = 4 * q + i;
+                const float ro = sigmoidf_(acc_r[reg] + brv[i]);
+                const float zo = sigmoidf_(acc_z[reg] + bzv[i]);
+                const float ho = acc_hn[reg] + bhv[i];
+                const float no = tanhf_(acc_in[reg] + biv[i] + ro * ho);
+                outv[reg] = (1.0f - zo) * no + zo * hp[i];
+                acc_r[reg] = ro; acc_z[reg] = zo; acc_hn[reg] = ho; acc_in[reg] = no;
+            }
+        }
+        if (a.logit_part) {
+            float p = 0.f;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 w = *reinterpret_cast<const float4*>(sBias + 128 + 8 * q + 4 * half);
+                p += outv[4 * q] * w.x + outv[4 * q + 1] * w.y + outv[4 * q + 2] * w.z + outv[4 * q + 3] * w.w;
+            }
+            p += __shfl_xor(p, 32);
+            if (half == 0 && r0 + c < a.R) a.logit_part[(size_t)cwb * a.part_stride + row] = p;
+        }
+        stage_store32(stg, c, half, lane, outv, a.h_out, a.ld_out, cw0, row, r0, a.R);
+        if (a.gates) {
+            stage_store32<true>(stg, c, half, lane, acc_r, a.gates, H, cw0, row, r0, a.R);
+            stage_store32<true>(stg, c, half, lane, acc_z, a.gates + a.gate_plane, H, cw0, row, r0, a.R);
+            stage_store32<true>(stg, c, half, lane, acc_in, a.gates + 2 * a.gate_plane, H, cw0, row, r0, a.R);
+            stage_store32<true>(stg, c, half, lane, acc_hn, a.gates + 3 * a.gate_plane, H, cw0, row, r0, a.R);
+        }
+        if (!nvalid) break;
+        r0 = nr0; li = nli; row = nrow;
+    }
+}
+
 // ---- the same forward over EDGE TILES (struct tmpnn_edge_tiles, rows_per_tile = 32) ----------------------------------
 // What holds k_gru_fwd_split is not bytes but a dependent chain inside a wave: after an item's 72 MFMAs the epilogue asks
 // for 24 scattered 16-byte pieces of P[src] / P[dst] per lane and waits for them (s_memtime, round 1: 15.5 k of an item's
@@ -3782,6 +3958,23 @@ int tmpnn_gru_fwd(const int32_t* rows, int R, int xmode, const int32_t* src, con
                 hipLaunchKernelGGL((k_gru_fwd_split<32, 8>), pgrid, dim3(512), shm2, st, a);
             }
             return check_launch("gru_fwd_split");
+        }
+        if (xmode == 0 && IN == H && split_enabled() && aligned16(msg) && aligned16(wih_t)) {
+            // the node cell on the bf16 pipe: one 32-column half of the outputs per block (k_gru_fwd_split_node)
+            const size_t shmn = (size_t)2 * 3 * 96 * (H + 8) * 2 + sizeof(float) * ((size_t)8 * 32 * STG_LD + 4 + 5 * 32);
+            const int cwn = H / 32;
+            const int want = ceil_div(ceil_div(R, 32), 8);                  // >= 8 row tiles per group of blocks
+            int groups = want < 256 / cwn ? want : 256 / cwn;
+            groups = (groups + 7) & ~7;                                      // whole sets of 8 (block pairs b, b + 8 on one XCD)
+            dim3 ngrid(groups * cwn);
+            if (H == 64) {
+                TM_SHM_ONCE((k_gru_fwd_split_node<64, 8>), shmn);
+                hipLaunchKernelGGL((k_gru_fwd_split_node<64, 8>), ngrid, dim3(512), shmn, st, a);
+            } else {
+                TM_SHM_ONCE((k_gru_fwd_split_node<32, 8>), shmn);
+                hipLaunchKernelGGL((k_gru_fwd_split_node<32, 8>), ngrid, dim3(512), shmn, st, a);
+            }
+            return check_launch("gru_fwd_split_node");
         }
         const size_t shm = sizeof(float) * ((size_t)((xmode == 3 ? 0 : IN) + H) * 3 * H + (size_t)wpb * 32 * STG_LD + 4);
         if (shm > 160 * 1024) goto generic;      // e.g. concat at H = 64: the weights alone take 144 KiB

@@ -292,6 +292,62 @@ __global__ __launch_bounds__(256) void k_train_losses_bwd(tmpnn_graph g, const i
     }
 }
 
+// ---- binary cross-entropy with logits, summed (the loss of SURVEY 8(d)'s metric: BCE on ALL logits of a call against fixed
+// {0,1} targets) in one pass each way instead of torch's six element-wise launches + reduction per call ----------------------
+// loss_i = max(l, 0) - l t + log(1 + exp(-|l|)) ; d loss_i / d l = sigmoid(l) - t.  Thread -> contiguous run of 16 elements,
+// block -> 4096 elements, fixed-order reductions (lane tree, waves in sequence, then the blocks' partials in sequence by one
+// wave): bitwise reproducible.
+static constexpr int BCE_PER_BLOCK = 4096;
+__global__ __launch_bounds__(256) void k_bce_fwd(const float* __restrict__ logits, const float* __restrict__ targets, long n,
+                                                 float* __restrict__ part) {
+    __shared__ float red[4];
+    const long base = (long)blockIdx.x * BCE_PER_BLOCK + threadIdx.x * 4;
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const long i = base + (long)j * 1024;
+        if (i + 3 < n) {
+            const float4 l = *reinterpret_cast<const float4*>(logits + i);
+            const float4 t = *reinterpret_cast<const float4*>(targets + i);
+            const float lv[4] = {l.x, l.y, l.z, l.w}, tv[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) s += fmaxf(lv[e], 0.f) - lv[e] * tv[e] + log1pf(__expf(-fabsf(lv[e])));
+        } else {
+            for (long k = i; k < n && k < i + 4; ++k) {
+                const float lv = logits[k], tv = targets[k];
+                s += fmaxf(lv, 0.f) - lv * tv + log1pf(__expf(-fabsf(lv)));
+            }
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = ((red[0] + red[1]) + red[2]) + red[3];
+}
+__global__ __launch_bounds__(64) void k_bce_finish(const float* __restrict__ part, int nb, float* __restrict__ loss) {
+    float s = 0.f;
+    for (int i = threadIdx.x; i < nb; i += 64) s += part[i];
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+    if (threadIdx.x == 0) loss[0] = s;
+}
+__global__ __launch_bounds__(256) void k_bce_bwd(const float* __restrict__ logits, const float* __restrict__ targets, long n,
+                                                 const float* __restrict__ d_loss, float* __restrict__ d_logits) {
+    const float g = d_loss[0];
+    const long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i + 3 < n) {
+        const float4 l = *reinterpret_cast<const float4*>(logits + i);
+        const float4 t = *reinterpret_cast<const float4*>(targets + i);
+        float4 d;
+        d.x = g * (__builtin_amdgcn_rcpf(1.0f + __expf(-l.x)) - t.x);
+        d.y = g * (__builtin_amdgcn_rcpf(1.0f + __expf(-l.y)) - t.y);
+        d.z = g * (__builtin_amdgcn_rcpf(1.0f + __expf(-l.z)) - t.z);
+        d.w = g * (__builtin_amdgcn_rcpf(1.0f + __expf(-l.w)) - t.w);
+        *reinterpret_cast<float4*>(d_logits + i) = d;
+    } else {
+        for (long k = i; k < n; ++k) d_logits[k] = g * (__builtin_amdgcn_rcpf(1.0f + __expf(-logits[k])) - targets[k]);
+    }
+}
+
 }  // namespace tmpnn
 
 using namespace tmpnn;
@@ -369,6 +425,36 @@ int tmpnn_focal_loss_bwd(const int32_t* rows, int R, const float* scores, const 
     hipLaunchKernelGGL(k_focal_bwd, dim3(ceil_div(R, 256)), dim3(256), 0, as_stream(stream), rows, R, scores, targets,
                        gamma, use_alpha, alpha0, alpha1, d_loss, scale, d_scores);
     return check_launch("focal_bwd");
+}
+
+size_t tmpnn_bce_logits_ws(long n) { return (size_t)((n > 0 ? n : 1) + BCE_PER_BLOCK - 1) / BCE_PER_BLOCK; }
+
+int tmpnn_bce_logits_sum_fwd(const float* logits, const float* targets, long n, float* loss_sum, float* ws, size_t ws_floats,
+                             tmpnn_stream stream) {
+    TM_REQUIRE(n >= 0 && loss_sum && (n == 0 || (logits && targets && ws)), "bce_logits_sum_fwd: null pointer");
+    hipStream_t st = as_stream(stream);
+    if (n == 0) {
+        hipError_t e = hipMemsetAsync(loss_sum, 0, sizeof(float), st);
+        return e == hipSuccess ? TMPNN_OK : set_error(TMPNN_ELAUNCH, "bce_logits_sum_fwd: memset");
+    }
+    TM_REQUIRE(aligned16(logits) && aligned16(targets), "bce_logits_sum_fwd: logits / targets must be 16-byte aligned");
+    const size_t nb = tmpnn_bce_logits_ws(n);
+    if (ws_floats < nb) return set_error(TMPNN_EWORKSPACE, "bce_logits_sum_fwd: workspace holds %zu floats, %zu needed", ws_floats, nb);
+    hipLaunchKernelGGL(k_bce_fwd, dim3((unsigned)nb), dim3(256), 0, st, logits, targets, n, ws);
+    int rc = check_launch("bce_fwd");
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_bce_finish, dim3(1), dim3(64), 0, st, ws, (int)nb, loss_sum);
+    return check_launch("bce_finish");
+}
+
+int tmpnn_bce_logits_sum_bwd(const float* logits, const float* targets, long n, const float* d_loss, float* d_logits,
+                             tmpnn_stream stream) {
+    TM_REQUIRE(n >= 0 && (n == 0 || (logits && targets && d_loss && d_logits)), "bce_logits_sum_bwd: null pointer");
+    if (n == 0) return TMPNN_OK;
+    TM_REQUIRE(aligned16(logits) && aligned16(targets) && aligned16(d_logits), "bce_logits_sum_bwd: 16-byte alignment");
+    hipLaunchKernelGGL(k_bce_bwd, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, as_stream(stream), logits, targets, n, d_loss,
+                       d_logits);
+    return check_launch("bce_bwd");
 }
 
 int tmpnn_train_losses_supported(int E, int Dn) { return (E >= 0 && Dn >= 0 && E <= TL_MAX_ROWS && Dn <= TL_MAX_ROWS) ? 1 : 0; }

@@ -171,6 +171,43 @@ class FocalLoss(nn.Module):
         return _Focal.apply(outputs, t8, self.gamma, ua, a0, a1, self.size_average, rows)
 
 
+class _BCELogitsSum(torch.autograd.Function):
+    """sum_i BCE-with-logits(l_i, t_i) in one launch (+ a one-wave finish); its backward in one (csrc/loss.hip k_bce_*)."""
+
+    @staticmethod
+    def forward(ctx, logits, targets):
+        l = logits.detach().reshape(-1)
+        l = l if (l.dtype == torch.float32 and l.is_contiguous()) else l.float().contiguous()
+        t = targets.detach().reshape(-1)
+        t = t if (t.dtype == torch.float32 and t.is_contiguous()) else t.float().contiguous()
+        if t.numel() != l.numel():
+            raise ValueError(f'bce_with_logits_sum: {l.numel()} logits, {t.numel()} targets')
+        n = l.numel()
+        loss = torch.empty((1,), dtype=torch.float32, device=l.device)
+        wsn = int(_lib.load().tmpnn_bce_logits_ws(n))
+        ws = torch.empty((wsn,), dtype=torch.float32, device=l.device)
+        _lib.call('tmpnn_bce_logits_sum_fwd', l.data_ptr(), t.data_ptr(), n, loss.data_ptr(), ws.data_ptr(), wsn, _stream())
+        ctx.l, ctx.t, ctx.shape = l, t, logits.shape
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, d_loss):
+        d = torch.empty_like(ctx.l)
+        dl = d_loss.reshape(1)
+        dl = dl if (dl.dtype == torch.float32 and dl.is_contiguous()) else dl.float().contiguous()
+        _lib.call('tmpnn_bce_logits_sum_bwd', ctx.l.data_ptr(), ctx.t.data_ptr(), ctx.l.numel(), dl.data_ptr(), d.data_ptr(),
+                  _stream())
+        return d.reshape(ctx.shape), None
+
+
+def bce_with_logits_sum(logits: torch.Tensor, targets: torch.Tensor) -> torch.Tensor:
+    """`torch.nn.functional.binary_cross_entropy_with_logits(logits, targets, reduction='sum')` -- the loss SURVEY 8(d)'s metric
+    is quoted with -- as one HIP launch per direction (torch: six element-wise launches and a reduction forward, five
+    backward, over a call's millions of logits).  Deterministic summation order; gradient only with respect to the logits."""
+    _need_cuda(logits, 'logits')
+    return _BCELogitsSum.apply(logits, targets)
+
+
 class _TrainLosses(torch.autograd.Function):
     """train.py:70-81 / :109-120 for one forward call as ONE autograd node: create_targets, CELoss over the logits and the
     two FocalLoss terms (gamma = 0, no alpha: what train.py constructs) over the scores of the edge rows and -- with the TP
