@@ -374,6 +374,9 @@ def mp_forward(spec: ModelSpec, plan: CallPlan, x: torch.Tensor, h_in: Optional[
         # (None for graphs without window labels).  Opt-in: measured slower than the CSR kernel
         win_plan(g)
     wide_preps = []
+    # the call's new EDGE rows enter the state as zeros (h_cat[N_old:] zero-filled above, only det rows written since): the
+    # edge cell's tiled forward skips the recurrent product of tiles made of such rows, the segment sum does not read them
+    zero_from = N_old if n > 0 else N
     # output head fused into the cells' epilogues where the LDS-resident kernel runs (else tmpnn_heads_fwd)
     cw = min(lib.tmpnn_gru_fwd_head_parts(H, H if use_proj_cat else spec.IN_e, 3 if (use_proj or use_proj_cat) else xmode),
              lib.tmpnn_gru_fwd_head_parts(H, H, 0))
@@ -427,9 +430,9 @@ def mp_forward(spec: ModelSpec, plan: CallPlan, x: torch.Tensor, h_in: Optional[
             w2n = _cached(('negt', e_wih_t.data_ptr(), H), (e_wih_t,), lambda: e_wih_t[H:].neg().contiguous())
             _lib.call('tmpnn_rows_linear', g.det_row.data_ptr(), Dn, hg, GH, H, w2n.data_ptr(), 3 * H,
                       proj.data_ptr() + 4 * Dn * 3 * H, 3 * H, st)
-            _lib.call('tmpnn_gru_fwd_tiles', edge_tiles(g, FWD_TILE_ROWS, dst_offset=Dn).cref(), E, proj.data_ptr(), 3 * H, hg, GH,
+            _lib.call('tmpnn_gru_fwd_tiles_z', edge_tiles(g, FWD_TILE_ROWS, dst_offset=Dn).cref(), E, proj.data_ptr(), 3 * H, hg, GH,
                       H, e_whh_t.data_ptr(), P[f + 'edge_gru.bias_ih'].data_ptr(), P[f + 'edge_gru.bias_hh'].data_ptr(),
-                      og, GH, gp, plane, we_g, part_g, N, st)
+                      og, GH, gp, plane, we_g, part_g, N, zero_from, st)
         elif use_proj:
             # (h[src]-h[dst]) W_ih^T = P[src] - P[dst] with P = h[dets] W_ih^T: the x-half of the edge cell's
             # forward GEMM runs over the Dn det rows instead of the E edge rows
@@ -438,9 +441,9 @@ def mp_forward(spec: ModelSpec, plan: CallPlan, x: torch.Tensor, h_in: Optional[
                       proj.data_ptr(), 3 * H, st)
             if FWD_TILED and E > 0:
                 recompute = RECOMPUTE_GATES and save
-                _lib.call('tmpnn_gru_fwd_tiles', edge_tiles(g, FWD_TILE_ROWS).cref(), E, proj.data_ptr(), 3 * H, hg, GH, H,
+                _lib.call('tmpnn_gru_fwd_tiles_z', edge_tiles(g, FWD_TILE_ROWS).cref(), E, proj.data_ptr(), 3 * H, hg, GH, H,
                           e_whh_t.data_ptr(), P[f + 'edge_gru.bias_ih'].data_ptr(), P[f + 'edge_gru.bias_hh'].data_ptr(),
-                          og, GH, None if recompute else gp, plane, we_g, part_g, N, st)
+                          og, GH, None if recompute else gp, plane, we_g, part_g, N, zero_from, st)
                 if recompute:
                     saved.setdefault('proj', {})[gi] = (proj, e_whh_t)
             else:
@@ -460,7 +463,7 @@ def mp_forward(spec: ModelSpec, plan: CallPlan, x: torch.Tensor, h_in: Optional[
             _seg_plan_guard(g, dev, aux_obj is not None)
             # (the call's new edge rows are 0 and are not read: rows >= N_old -- h_cat[N_old:] was just zero-filled and only
             #  its det rows written; without new rows every row is read)
-            _lib.call('tmpnn_segsum_fwd_live', g.cref(), hg, GH, es.data_ptr(), H, H, 1, N_old if n > 0 else N, st_det)
+            _lib.call('tmpnn_segsum_fwd_live', g.cref(), hg, GH, es.data_ptr(), H, H, 1, zero_from, st_det)
             alphas.append(None)
         else:
             # the kernels take up to ATT_KMAX heads per call (all of them from one read of h[e]); more heads run in groups whose
