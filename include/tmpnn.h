@@ -302,11 +302,6 @@ int tmpnn_gru_bwd_fused(const int32_t* rows, int R, int xmode, const int32_t* sr
 int tmpnn_gru_fwd_tiles(const tmpnn_edge_tiles* tiles, int R, const float* proj, int ld_proj, const float* h, int ld_h, int H,
                         const float* whh_t, const float* b_ih, const float* b_hh, float* h_out, int ld_out, float* gates,
                         size_t gate_plane, const float* w_head, float* logit_part, size_t part_stride, tmpnn_stream stream);
-/* The same launch where the caller KNOWS that state rows >= h_zero_from are all-zero (a call's new edge rows enter the state as 0,
- * models/track_mpnn.py:61): a tile made of such rows only skips its recurrent product (exactly +0).  Same results bit for bit. */
-int tmpnn_gru_fwd_tiles_z(const tmpnn_edge_tiles* tiles, int R, const float* proj, int ld_proj, const float* h, int ld_h, int H,
-                        const float* whh_t, const float* b_ih, const float* b_hh, float* h_out, int ld_out, float* gates,
-                        size_t gate_plane, const float* w_head, float* logit_part, size_t part_stride, int h_zero_from, tmpnn_stream stream);
 
 /* out[r, 0:NOUT] = in[rows[r], 0:H] @ wt[H][NOUT]  (compact output rows; H in {32, 64}, NOUT = 3H):
  * the det-row projection P of tmpnn_gru_fwd's xmode 3. */

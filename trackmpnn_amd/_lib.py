@@ -114,8 +114,6 @@ _SIGNATURES = {
     'tmpnn_gru_fwd_head_parts': (c_int, [c_int, c_int, c_int]),
     'tmpnn_gru_fwd_tiles': (c_int, [_TP, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p,
                                     c_void_p, c_int, c_void_p, c_size_t, c_void_p, c_void_p, c_size_t, c_void_p]),
-    'tmpnn_gru_fwd_tiles_z': (c_int, [_TP, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p,
-                                      c_void_p, c_int, c_void_p, c_size_t, c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
     'tmpnn_heads_finish': (c_int, [c_void_p, c_size_t, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     'tmpnn_gru_bwd_data': (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p,
                                    c_void_p, c_size_t, c_void_p, c_int, c_void_p, c_void_p,

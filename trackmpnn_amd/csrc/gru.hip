@@ -159,7 +159,6 @@ struct GruFwdArgs {
     float* gates; size_t gate_plane;
     // optional fused output head (track_mpnn.py:73): logit_part[cw][row] = w_head[cols of column wave cw] . h_out[row]
     const float* w_head; float* logit_part; size_t part_stride;
-    int h_zero_from = 0x7fffffff;   // tiled forward: state rows >= this are known to be all-zero (a call's new edge rows)
 };
 
 // 16 floats of x for list position li at feature offset f0 (multiple of 16)
@@ -1314,9 +1313,6 @@ __global__ __launch_bounds__(WPB * 64) void k_gru_fwd_split_tiled(GruFwdArgs a, 
         const int r0 = 32 * t;
         const int row = ix.row;
         const bool staged = ix.nd <= TCAP;
-        // a tile whose 32 state rows are all known zeros (new edge rows: h = 0, models/track_mpnn.py:61) skips the operand split
-        // and the 72 MFMAs -- their result is exactly the +0 the accumulators start from (wave-uniform branch)
-        const bool ztile = __builtin_amdgcn_ballot_w64(row < a.h_zero_from) == 0;
         Split8 b[NKB];
 #pragma unroll
         for (int kb = 0; kb < NKB; ++kb) b[kb] = split8(raw[2 * kb], raw[2 * kb + 1]);
@@ -1344,7 +1340,7 @@ __global__ __launch_bounds__(WPB * 64) void k_gru_fwd_split_tiled(GruFwdArgs a, 
         FT_MARK(0);                                             // item claim, operand wait + split, next item's requests
         __builtin_amdgcn_sched_barrier(0);
 #endif
-        if (!ztile) {
+        {
             const uint16_t* wp0 = sW + (cw0 + c) * KP + (H / 2) * half;
 #pragma unroll
             for (int kb = 0; kb < NKB; ++kb) {
@@ -4010,14 +4006,6 @@ generic:
 int tmpnn_gru_fwd_tiles(const tmpnn_edge_tiles* tiles, int R, const float* proj, int ld_proj, const float* h, int ld_h, int H,
                         const float* whh_t, const float* b_ih, const float* b_hh, float* h_out, int ld_out, float* gates,
                         size_t gate_plane, const float* w_head, float* logit_part, size_t part_stride, tmpnn_stream stream) {
-    return tmpnn_gru_fwd_tiles_z(tiles, R, proj, ld_proj, h, ld_h, H, whh_t, b_ih, b_hh, h_out, ld_out, gates, gate_plane, w_head,
-                                 logit_part, part_stride, 0x7fffffff, stream);
-}
-
-int tmpnn_gru_fwd_tiles_z(const tmpnn_edge_tiles* tiles, int R, const float* proj, int ld_proj, const float* h, int ld_h, int H,
-                          const float* whh_t, const float* b_ih, const float* b_hh, float* h_out, int ld_out, float* gates,
-                          size_t gate_plane, const float* w_head, float* logit_part, size_t part_stride, int h_zero_from,
-                          tmpnn_stream stream) {
     TM_REQUIRE(H == 32 || H == 64, "gru_fwd_tiles: H=%d (the tiled forward serves the LDS-resident cells, H in {32, 64})", H);
     TM_REQUIRE(R >= 0, "gru_fwd_tiles: R=%d", R);
     if (R == 0) return TMPNN_OK;
@@ -4036,7 +4024,6 @@ int tmpnn_gru_fwd_tiles_z(const tmpnn_edge_tiles* tiles, int R, const float* pro
     TM_REQUIRE(logit_part == nullptr || (w_head != nullptr && aligned16(w_head)), "gru_fwd_tiles: fused head needs a 16-byte aligned w_head");
     GruFwdArgs a{nullptr, R, nullptr, nullptr, proj, ld_proj, H, 0, h, ld_h, H, nullptr, whh_t, b_ih, b_hh, h_out, ld_out, gates,
                  gate_plane, w_head, logit_part, part_stride};
-    a.h_zero_from = h_zero_from < 0 ? 0 : h_zero_from;
     FwdTiles tl{tiles->t_row, tiles->t_loc, tiles->t_dptr, tiles->t_dets, tiles->T};
     hipStream_t st = as_stream(stream);
     const int ntiles = ceil_div(R, (H == 64) ? 192 : 256);

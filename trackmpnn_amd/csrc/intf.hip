@@ -23,15 +23,11 @@
 namespace tmpnn {
 
 static constexpr float IT_EPS = 1e-5f;
-static constexpr int IT_CH_BIG = 128;   // rows per chunk (whole segments): the 1024-thread form, one workgroup per CU
-static constexpr int IT_CH_SMALL = 32;  // ... the 256-thread form: three workgroups per CU, each its own chain of dependent phases
+static constexpr int IT_CH = 128;       // rows per chunk (whole segments)
 static constexpr int IT_SPB = 32;       // segments per group of a persistent workgroup (KITTI-shaped: ~190 det rows = two chunks)
 static constexpr int IT_FMAX = 128;     // widest input group (vis: 128 columns)
-static constexpr int IT_NT_BIG = 1024;  // threads per workgroup: the phases are chains of LDS round trips, hidden only by
-                                        // other waves (measured: 256 threads, one wave per SIMD AND one workgroup per CU, 316 us
-                                        // per backward launch)
-static constexpr int IT_NT_SMALL = 256; // round 6: segments of <= IT_CH_SMALL det rows -- several small workgroups per CU hide each
-                                        // other's round trips, and a barrier of 4 waves is cheaper than one of 16
+static constexpr int IT_NT = 1024;      // threads per workgroup: the phases are chains of LDS round trips, hidden only by
+                                        // other waves (measured: 256 threads, one wave per SIMD, 316 us per backward launch)
 
 struct ItFwdArgs {
     const float* x; int ld_x; int F; int nd;
@@ -44,14 +40,14 @@ struct ItFwdArgs {
 // the chunk [sa, sb) of whole segments starting at sa with at most IT_CH det rows (at least one segment), from the
 // workgroup's LDS copy of its seg_ptr entries (s_sp[j] = seg_ptr[s0 + j]: a walk over global memory costs a dependent
 // round trip per segment)
-__device__ __forceinline__ int it_chunk_end(const int* s_sp, int s0, int sa, int s1, int ch) {
+__device__ __forceinline__ int it_chunk_end(const int* s_sp, int s0, int sa, int s1) {
     const int base = s_sp[sa - s0];
     int sb = sa + 1;
-    while (sb < s1 && s_sp[sb + 1 - s0] - base <= ch) ++sb;
+    while (sb < s1 && s_sp[sb + 1 - s0] - base <= IT_CH) ++sb;
     return sb;
 }
 
-template <int H, int IT_NT, int IT_CH>
+template <int H>
 __global__ __launch_bounds__(IT_NT) void k_it_fwd(ItFwdArgs a) {
     constexpr int NSUB = IT_NT / H, LD = H + 4;
     extern __shared__ __attribute__((aligned(16))) float it_lds[];
@@ -92,7 +88,7 @@ __global__ __launch_bounds__(IT_NT) void k_it_fwd(ItFwdArgs a) {
     __syncthreads();
     for (int sa = s0; sa < s1;) {
         int sb, ra, rb;
-        if (a.training) { sb = it_chunk_end(s_sp, s0, sa, s1, IT_CH); ra = s_sp[sa - s0]; rb = s_sp[sb - s0]; }
+        if (a.training) { sb = it_chunk_end(s_sp, s0, sa, s1); ra = s_sp[sa - s0]; rb = s_sp[sb - s0]; }
         else { sb = s1; ra = sa * IT_CH; rb = min(a.nd, ra + IT_CH); }
         const int nr = rb - ra;
         // ---- Lin1 (narrow groups: the chunk's x rows go through LDS -- one coalesced pass instead of a dependent global
@@ -186,7 +182,7 @@ struct ItBwdArgs {
 
 // FPT: dW1 columns per thread (f = sub, sub + NSUB, ...): 1 covers the 2d / temp groups (F <= 16 <= NSUB), IT_FMAX / NSUB the
 // vis group
-template <int H, int FPT, int IT_NT, int IT_CH>
+template <int H, int FPT>
 __global__ __launch_bounds__(IT_NT) void k_it_bwd(ItBwdArgs a) {
     constexpr int NSUB = IT_NT / H, LD = H + 4, KPT = H / NSUB;       // KPT: dW2 columns per thread
     extern __shared__ __attribute__((aligned(16))) float it_lds[];
@@ -225,7 +221,7 @@ __global__ __launch_bounds__(IT_NT) void k_it_bwd(ItBwdArgs a) {
     __syncthreads();
     for (int sa = s0; sa < s1;) {
         int sb, ra, rb;
-        if (a.training) { sb = it_chunk_end(s_sp, s0, sa, s1, IT_CH); ra = s_sp[sa - s0]; rb = s_sp[sb - s0]; }
+        if (a.training) { sb = it_chunk_end(s_sp, s0, sa, s1); ra = s_sp[sa - s0]; rb = s_sp[sb - s0]; }
         else { sb = s1; ra = sa * IT_CH; rb = min(a.nd, ra + IT_CH); }
         const int nr = rb - ra;
         // ---- d_out (gathered), yhat and a (recomputed).  Every load of a thread's <= IT_CH / NSUB rows is requested
@@ -475,28 +471,21 @@ __global__ __launch_bounds__(64) void k_it_running(const float* __restrict__ mea
     }
 }
 
-static size_t it_fwd_shm(int H, int F, int CH) {
-    return sizeof(float) * ((size_t)H * (H + 4) + 2 * (size_t)CH * (H + 4) + 2 * (size_t)IT_SPB * H +
-                            (F > 16 ? (size_t)H * (F + 1) : (size_t)CH * 16));
+static size_t it_fwd_shm(int H, int F) {
+    return sizeof(float) * ((size_t)H * (H + 4) + 2 * (size_t)IT_CH * (H + 4) + 2 * (size_t)IT_SPB * H +
+                            (F > 16 ? (size_t)H * (F + 1) : (size_t)IT_CH * 16));
 }
-static size_t it_bwd_shm(int H, int NT, int CH) {
-    return sizeof(float) * ((size_t)H * (H + 4) + 3 * (size_t)CH * (H + 4) + (size_t)IT_SPB * H + 4 * (size_t)NT + (size_t)CH * 16 +
+static size_t it_bwd_shm(int H) {
+    return sizeof(float) * ((size_t)H * (H + 4) + 3 * (size_t)IT_CH * (H + 4) + (size_t)IT_SPB * H + 4 * IT_NT + (size_t)IT_CH * 16 +
                             (size_t)H * 17);
 }
-// the 256-thread form serves plans whose segments hold at most IT_CH_SMALL det rows and narrow inputs (the x chunk in LDS)
-static bool it_small(int F, int max_seg_rows) {
-    static const int off = [] { const char* e = getenv("TMPNN_IT_SMALL"); return (e && e[0] == '0') ? 1 : 0; }();
-    return !off && F <= 16 && max_seg_rows <= IT_CH_SMALL;
-}
-// persistent workgroups: as many as fit a CU at once (1024 threads: one, their LDS footprint admits no second; 256 threads:
-// three forward, two backward), fewer when there is less work
-static int it_blocks(int nd, int S, int training, int CH, int per_cu) {
-    const int groups = training ? ceil_div(S, IT_SPB) : ceil_div(nd, CH);
+// persistent workgroups: one per CU (their LDS footprint admits no second one), fewer when there is less work
+static int it_blocks(int nd, int S, int training) {
+    const int groups = training ? ceil_div(S, IT_SPB) : ceil_div(nd, IT_CH);
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    return groups < cus * per_cu ? groups : cus * per_cu;
+    return groups < cus ? groups : cus;
 }
-static constexpr int IT_PER_CU_FWD_SMALL = 3, IT_PER_CU_BWD_SMALL = 2;
 
 }  // namespace tmpnn
 
@@ -505,7 +494,7 @@ using namespace tmpnn;
 extern "C" {
 
 int tmpnn_input_tf_supported(int H, int F, int max_seg_rows) {
-    return ((H == 32 || H == 64) && F > 0 && F <= IT_FMAX && max_seg_rows >= 0 && max_seg_rows <= IT_CH_BIG) ? 1 : 0;
+    return ((H == 32 || H == 64) && F > 0 && F <= IT_FMAX && max_seg_rows >= 0 && max_seg_rows <= IT_CH) ? 1 : 0;
 }
 
 int tmpnn_input_tf_fwd(const float* xdet, int ld_x, int F, int nd, const int32_t* seg_ptr, const int32_t* seg_cnt,
@@ -514,7 +503,7 @@ int tmpnn_input_tf_fwd(const float* xdet, int ld_x, int F, int nd, const int32_t
                        const float* b2, float* y_save, float* mean, float* rstd, const int32_t* out_row, float* h_new,
                        int ld_h, tmpnn_stream stream) {
     TM_REQUIRE(tmpnn_input_tf_supported(H, F, max_seg_rows), "input_tf_fwd: H=%d F=%d max_seg_rows=%d (H in {32, 64}, F <= %d, "
-               "segments of at most %d det rows; use tmpnn_input_bn_fwd otherwise)", H, F, max_seg_rows, IT_FMAX, IT_CH_BIG);
+               "segments of at most %d det rows; use tmpnn_input_bn_fwd otherwise)", H, F, max_seg_rows, IT_FMAX, IT_CH);
     TM_REQUIRE(nd >= 0 && S >= 0, "input_tf_fwd: nd=%d S=%d", nd, S);
     TM_REQUIRE(w1 && b1 && gamma && beta && running_mean && running_var && w2 && b2 && mean && rstd, "input_tf_fwd: null parameter pointer");
     TM_REQUIRE(!training || (seg_ptr && seg_cnt && seg_of_det && S > 0), "input_tf_fwd: training needs segments");
@@ -523,17 +512,11 @@ int tmpnn_input_tf_fwd(const float* xdet, int ld_x, int F, int nd, const int32_t
     TM_REQUIRE(nd == 0 || (xdet && y_save && out_row && h_new && ld_x >= F && ld_h >= H), "input_tf_fwd: null/short buffers");
     ItFwdArgs a{xdet, ld_x, F, nd, seg_ptr, seg_cnt, seg_of_det, S, training, w1, b1, gamma, beta, running_mean, running_var,
                 w2, b2, y_save, mean, rstd, out_row, h_new, ld_h};
-    const bool small = it_small(F, max_seg_rows);
-    const int nb = small ? it_blocks(nd, S, training, IT_CH_SMALL, IT_PER_CU_FWD_SMALL) : it_blocks(nd, S, training, IT_CH_BIG, 1);
+    const int nb = it_blocks(nd, S, training);
+    const size_t shm = it_fwd_shm(H, F);
     if (nb > 0) {
-#define IT_FWD(HH, NT, CH, FSHM)                                                                                              \
-    do {                                                                                                                      \
-        TM_SHM_ONCE((k_it_fwd<HH, NT, CH>), it_fwd_shm(HH, FSHM, CH));                                                        \
-        hipLaunchKernelGGL((k_it_fwd<HH, NT, CH>), dim3(nb), dim3(NT), it_fwd_shm(HH, F, CH), st, a);                         \
-    } while (0)
-        if (small) { if (H == 64) IT_FWD(64, IT_NT_SMALL, IT_CH_SMALL, 16); else IT_FWD(32, IT_NT_SMALL, IT_CH_SMALL, 16); }
-        else { if (H == 64) IT_FWD(64, IT_NT_BIG, IT_CH_BIG, IT_FMAX); else IT_FWD(32, IT_NT_BIG, IT_CH_BIG, IT_FMAX); }
-#undef IT_FWD
+        if (H == 64) { TM_SHM_ONCE(k_it_fwd<64>, it_fwd_shm(64, IT_FMAX)); hipLaunchKernelGGL(k_it_fwd<64>, dim3(nb), dim3(IT_NT), shm, st, a); }
+        else { TM_SHM_ONCE(k_it_fwd<32>, it_fwd_shm(32, IT_FMAX)); hipLaunchKernelGGL(k_it_fwd<32>, dim3(nb), dim3(IT_NT), shm, st, a); }
         int rc = check_launch("it_fwd");
         if (rc) return rc;
     }
@@ -545,9 +528,7 @@ int tmpnn_input_tf_fwd(const float* xdet, int ld_x, int F, int nd, const int32_t
 }
 
 size_t tmpnn_input_tf_bwd_ws(int nd, int S, int H, int F, int training) {
-    // (sized for whichever form the launch picks: the 256-thread form runs more workgroups, each with its own slab)
-    const int nb1 = it_blocks(nd, S, training, IT_CH_BIG, 1), nb2 = it_blocks(nd, S, training, IT_CH_SMALL, IT_PER_CU_BWD_SMALL);
-    const int nb = nb1 > nb2 ? nb1 : nb2;
+    const int nb = it_blocks(nd, S, training);
     return sizeof(float) * (size_t)(nb > 0 ? nb : 1) * ((size_t)H * H + (size_t)H * F + 4 * H);
 }
 
@@ -570,20 +551,17 @@ int tmpnn_input_tf_bwd(const float* xdet, int ld_x, int F, int nd, const int32_t
     const size_t need = tmpnn_input_tf_bwd_ws(nd, S, H, F, training);
     if (ws_bytes < need) return set_error(TMPNN_EWORKSPACE, "input_tf_bwd: workspace %zu < %zu bytes", ws_bytes, need);
     if (!training && d_xzero && S > 0) (void)hipMemsetAsync(d_xzero, 0, sizeof(float) * (size_t)S * F, st);
-    const bool small = it_small(F, max_seg_rows);
-    const int nb = small ? it_blocks(nd, S, training, IT_CH_SMALL, IT_PER_CU_BWD_SMALL) : it_blocks(nd, S, training, IT_CH_BIG, 1);
+    const int nb = it_blocks(nd, S, training);
     const int slab_floats = H * H + H * F + 4 * H;
     ItBwdArgs a{xdet, ld_x, F, nd, seg_ptr, seg_cnt, seg_of_det, S, training, w1, b1, gamma, beta, w2, y_save, mean, rstd, out_row,
                 d_h, ld_dh, d_xdet, ld_dx, d_xzero, reinterpret_cast<float*>(ws), slab_floats};
-#define IT_BWD(HH, FF, NT, CH)                                                                                        \
-    do {                                                                                                              \
-        TM_SHM_ONCE((k_it_bwd<HH, FF, NT, CH>), it_bwd_shm(HH, NT, CH));                                              \
-        hipLaunchKernelGGL((k_it_bwd<HH, FF, NT, CH>), dim3(nb), dim3(NT), it_bwd_shm(HH, NT, CH), st, a);            \
+#define IT_BWD(HH, FF)                                                                                   \
+    do {                                                                                                 \
+        TM_SHM_ONCE((k_it_bwd<HH, FF>), it_bwd_shm(HH));                                                 \
+        hipLaunchKernelGGL((k_it_bwd<HH, FF>), dim3(nb), dim3(IT_NT), it_bwd_shm(HH), st, a);              \
     } while (0)
-    // FPT = dW1 columns per thread = ceil(F_max / NSUB): NSUB = NT / H row sub-groups
-    if (small) { if (H == 64) IT_BWD(64, 4, IT_NT_SMALL, IT_CH_SMALL); else IT_BWD(32, 2, IT_NT_SMALL, IT_CH_SMALL); }
-    else if (H == 64) { if (F <= 16) IT_BWD(64, 1, IT_NT_BIG, IT_CH_BIG); else IT_BWD(64, IT_FMAX / 16, IT_NT_BIG, IT_CH_BIG); }
-    else { if (F <= 16) IT_BWD(32, 1, IT_NT_BIG, IT_CH_BIG); else IT_BWD(32, IT_FMAX / 32, IT_NT_BIG, IT_CH_BIG); }
+    if (H == 64) { if (F <= 16) IT_BWD(64, 1); else IT_BWD(64, IT_FMAX / 16); }
+    else { if (F <= 16) IT_BWD(32, 1); else IT_BWD(32, IT_FMAX / 32); }
 #undef IT_BWD
     int rc = check_launch("it_bwd");
     if (rc) return rc;

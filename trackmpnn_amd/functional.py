@@ -375,7 +375,8 @@ def mp_forward(spec: ModelSpec, plan: CallPlan, x: torch.Tensor, h_in: Optional[
         win_plan(g)
     wide_preps = []
     # the call's new EDGE rows enter the state as zeros (h_cat[N_old:] zero-filled above, only det rows written since): the
-    # edge cell's tiled forward skips the recurrent product of tiles made of such rows, the segment sum does not read them
+    # segment sum does not read them.  (Measured and dropped in round 6: the tiled edge forward skipping the 72 MFMAs of tiles
+    # made of such rows -- bit-equal, 8.10 -> 8.09 ms per step: the matrix pipe is not what an item waits for.)
     zero_from = N_old if n > 0 else N
     # output head fused into the cells' epilogues where the LDS-resident kernel runs (else tmpnn_heads_fwd)
     cw = min(lib.tmpnn_gru_fwd_head_parts(H, H if use_proj_cat else spec.IN_e, 3 if (use_proj or use_proj_cat) else xmode),
@@ -430,9 +431,9 @@ def mp_forward(spec: ModelSpec, plan: CallPlan, x: torch.Tensor, h_in: Optional[
             w2n = _cached(('negt', e_wih_t.data_ptr(), H), (e_wih_t,), lambda: e_wih_t[H:].neg().contiguous())
             _lib.call('tmpnn_rows_linear', g.det_row.data_ptr(), Dn, hg, GH, H, w2n.data_ptr(), 3 * H,
                       proj.data_ptr() + 4 * Dn * 3 * H, 3 * H, st)
-            _lib.call('tmpnn_gru_fwd_tiles_z', edge_tiles(g, FWD_TILE_ROWS, dst_offset=Dn).cref(), E, proj.data_ptr(), 3 * H, hg, GH,
+            _lib.call('tmpnn_gru_fwd_tiles', edge_tiles(g, FWD_TILE_ROWS, dst_offset=Dn).cref(), E, proj.data_ptr(), 3 * H, hg, GH,
                       H, e_whh_t.data_ptr(), P[f + 'edge_gru.bias_ih'].data_ptr(), P[f + 'edge_gru.bias_hh'].data_ptr(),
-                      og, GH, gp, plane, we_g, part_g, N, zero_from, st)
+                      og, GH, gp, plane, we_g, part_g, N, st)
         elif use_proj:
             # (h[src]-h[dst]) W_ih^T = P[src] - P[dst] with P = h[dets] W_ih^T: the x-half of the edge cell's
             # forward GEMM runs over the Dn det rows instead of the E edge rows
@@ -441,9 +442,9 @@ def mp_forward(spec: ModelSpec, plan: CallPlan, x: torch.Tensor, h_in: Optional[
                       proj.data_ptr(), 3 * H, st)
             if FWD_TILED and E > 0:
                 recompute = RECOMPUTE_GATES and save
-                _lib.call('tmpnn_gru_fwd_tiles_z', edge_tiles(g, FWD_TILE_ROWS).cref(), E, proj.data_ptr(), 3 * H, hg, GH, H,
+                _lib.call('tmpnn_gru_fwd_tiles', edge_tiles(g, FWD_TILE_ROWS).cref(), E, proj.data_ptr(), 3 * H, hg, GH, H,
                           e_whh_t.data_ptr(), P[f + 'edge_gru.bias_ih'].data_ptr(), P[f + 'edge_gru.bias_hh'].data_ptr(),
-                          og, GH, None if recompute else gp, plane, we_g, part_g, N, zero_from, st)
+                          og, GH, None if recompute else gp, plane, we_g, part_g, N, st)
                 if recompute:
                     saved.setdefault('proj', {})[gi] = (proj, e_whh_t)
             else:
