@@ -51,13 +51,15 @@ def step(model, plans, xs, targets, opt, bucket, world):
     """fwd over every call of the window batch, one backward, (all-reduce), Adam.  Loss: BCE with logits over ALL logits of
     every call against fixed {0,1} targets, summed -- trackmpnn_amd.loss.bce_with_logits_sum, one launch per
     direction (equal to torch.nn.functional.binary_cross_entropy_with_logits(reduction='sum'), tests/test_loss.py)."""
+    from trackmpnn_amd.functional import weight_cache
     from trackmpnn_amd.loss import bce_with_logits_sum
     h = None
     loss = 0.0
-    for c, (plan, x, t) in enumerate(zip(plans, xs, targets)):
-        nxt = plans[c + 1].n_new if c + 1 < len(plans) else 0
-        scores, logits, h, _ = model.forward_graph(x, h, plan, reserve_rows=nxt)
-        loss = loss + bce_with_logits_sum(logits, t)
+    with weight_cache():        # the weights do not change between the forward calls of one step: their transposes are built once
+        for c, (plan, x, t) in enumerate(zip(plans, xs, targets)):
+            nxt = plans[c + 1].n_new if c + 1 < len(plans) else 0
+            scores, logits, h, _ = model.forward_graph(x, h, plan, reserve_rows=nxt)
+            loss = loss + bce_with_logits_sum(logits, t)
     opt.zero_grad(set_to_none=False)
     loss.backward()
     if world > 1:
@@ -629,11 +631,13 @@ def static_step(model, plan0, planr, x, targets, iters, opt, bucket, world):
     """The static window mode of SURVEY 8(d): first call with every row new, then iters - 1 empty-x calls on the same graph,
     one backward of the BCE loss over every call's logits, (all-reduce), Adam."""
     from trackmpnn_amd.loss import bce_with_logits_sum
+    from trackmpnn_amd.functional import weight_cache
     h = None
     loss = 0.0
-    for it in range(iters):
-        scores, logits, h, _ = model.forward_graph(x if it == 0 else x[:0], h, plan0 if it == 0 else planr)
-        loss = loss + bce_with_logits_sum(logits, targets)
+    with weight_cache():        # (one set of weight images for the iterations of a step)
+        for it in range(iters):
+            scores, logits, h, _ = model.forward_graph(x if it == 0 else x[:0], h, plan0 if it == 0 else planr)
+            loss = loss + bce_with_logits_sum(logits, targets)
     opt.zero_grad(set_to_none=False)
     loss.backward()
     if world > 1:

@@ -352,15 +352,17 @@ int tmpnn_input_bn_bwd(const float* xdet, int ld_x, int F, int nd, const int32_t
  * leave it.  Arguments and results as tmpnn_input_bn_fwd / _bwd (no activation workspace; the backward's workspace holds
  * one slab of parameter gradients per workgroup, added into dw1 .. db2 in a fixed order) plus max_seg_rows = the longest
  * segment's number of det rows, which the host knows from its plan.  tmpnn_input_tf_supported: H in {32, 64}, F <= 128,
- * max_seg_rows <= 128 -- callers use tmpnn_input_bn_* otherwise (one window of thousands of dets is ONE segment). */
+ * max_seg_rows <= 128 -- callers use tmpnn_input_bn_* otherwise (one window of thousands of dets is ONE segment).
+ * x_rows (int64 [nd], or NULL): det row i's features are row x_rows[i] of `xdet` -- the caller's x [n, F] with its new det
+ * rows listed (the gather of the det rows out of x rides in the kernel's own staging pass); NULL: row i. */
 int tmpnn_input_tf_supported(int H, int F, int max_seg_rows);
-int tmpnn_input_tf_fwd(const float* xdet, int ld_x, int F, int nd, const int32_t* seg_ptr, const int32_t* seg_cnt,
+int tmpnn_input_tf_fwd(const float* xdet, const int64_t* x_rows, int ld_x, int F, int nd, const int32_t* seg_ptr, const int32_t* seg_cnt,
                        const int32_t* seg_of_det, int S, int max_seg_rows, int H, int training, const float* w1, const float* b1,
                        const float* gamma, const float* beta, float* running_mean, float* running_var, const float* w2,
                        const float* b2, float* y_save, float* mean, float* rstd, const int32_t* out_row, float* h_new,
                        int ld_h, tmpnn_stream stream);
 size_t tmpnn_input_tf_bwd_ws(int nd, int S, int H, int F, int training);   /* bytes */
-int tmpnn_input_tf_bwd(const float* xdet, int ld_x, int F, int nd, const int32_t* seg_ptr, const int32_t* seg_cnt,
+int tmpnn_input_tf_bwd(const float* xdet, const int64_t* x_rows, int ld_x, int F, int nd, const int32_t* seg_ptr, const int32_t* seg_cnt,
                        const int32_t* seg_of_det, int S, int max_seg_rows, int H, int training, const float* w1, const float* b1,
                        const float* gamma, const float* beta, const float* w2, const float* y_save, const float* mean,
                        const float* rstd, const int32_t* out_row, const float* d_h, int ld_dh, float* d_xdet, int ld_dx,

@@ -367,8 +367,12 @@ def check_input_bn(H, F_, training, S=4, fused=False):
     out_row = torch.tensor(np.random.RandomState(0).permutation(Nrows)[:nd], dtype=torch.int32, device=DEV)
     h_new = torch.zeros(Nrows, ld, device=DEV)
     seg_of_det = torch.repeat_interleave(torch.arange(S, dtype=torch.int32), torch.tensor(nds)).to(DEV) if (H != 32 or fused) else None
+    # the one-launch form also takes x through a row list (the det rows of the caller's [n, F] x): a shuffled, larger copy
+    xr_idx = torch.tensor(np.random.RandomState(1).permutation(nd + 7)[:nd], dtype=torch.int64, device=DEV)
+    xS = torch.full((nd + 7, xD.shape[1]), float('nan'), device=DEV)
+    xS[xr_idx] = xD
     if fused:
-        _lib.call('tmpnn_input_tf_fwd', xD.data_ptr() + 4, Ft, F_, nd, seg_ptr.data_ptr(), seg_cnt.data_ptr(), _lib.ptr(seg_of_det), S,
+        _lib.call('tmpnn_input_tf_fwd', xS.data_ptr() + 4, xr_idx.data_ptr(), Ft, F_, nd, seg_ptr.data_ptr(), seg_cnt.data_ptr(), _lib.ptr(seg_of_det), S,
                   max(nds), H, int(training), P[t + '0.weight'].data_ptr(), P[t + '0.bias'].data_ptr(), P[t + '1.weight'].data_ptr(),
                   P[t + '1.bias'].data_ptr(), P[t + '1.running_mean'].data_ptr(), P[t + '1.running_var'].data_ptr(),
                   P[t + '3.weight'].data_ptr(), P[t + '3.bias'].data_ptr(), y_save.data_ptr(), mean.data_ptr(),
@@ -394,7 +398,7 @@ def check_input_bn(H, F_, training, S=4, fused=False):
     if fused:
         wsb = int(_lib.load().tmpnn_input_tf_bwd_ws(nd, S, H, F_, int(training)))
         ws = torch.empty(wsb // 4 + 1, device=DEV)
-        _lib.call('tmpnn_input_tf_bwd', xD.data_ptr() + 4, Ft, F_, nd, seg_ptr.data_ptr(), seg_cnt.data_ptr(), _lib.ptr(seg_of_det), S,
+        _lib.call('tmpnn_input_tf_bwd', xS.data_ptr() + 4, xr_idx.data_ptr(), Ft, F_, nd, seg_ptr.data_ptr(), seg_cnt.data_ptr(), _lib.ptr(seg_of_det), S,
                   max(nds), H, int(training), P[t + '0.weight'].data_ptr(), P[t + '0.bias'].data_ptr(), P[t + '1.weight'].data_ptr(),
                   P[t + '1.bias'].data_ptr(), P[t + '3.weight'].data_ptr(), y_save.data_ptr(), mean.data_ptr(),
                   rstd.data_ptr(), out_row.data_ptr(), d_hD.data_ptr() + 4 * H, ld, d_xdet.data_ptr() + 4, Ft,

@@ -147,11 +147,11 @@ _SIGNATURES = {
                                    c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                    c_void_p, c_size_t, c_void_p]),
     'tmpnn_input_tf_supported': (c_int, [c_int, c_int, c_int]),
-    'tmpnn_input_tf_fwd': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
+    'tmpnn_input_tf_fwd': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                    c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                    c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     'tmpnn_input_tf_bwd_ws': (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
-    'tmpnn_input_tf_bwd': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
+    'tmpnn_input_tf_bwd': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                    c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                    c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
                                    c_void_p, c_int, c_void_p,

@@ -30,7 +30,7 @@ static constexpr int IT_NT = 1024;      // threads per workgroup: the phases are
                                         // other waves (measured: 256 threads, one wave per SIMD, 316 us per backward launch)
 
 struct ItFwdArgs {
-    const float* x; int ld_x; int F; int nd;
+    const float* x; const int64_t* x_rows; int ld_x; int F; int nd;
     const int32_t* seg_ptr; const int32_t* seg_cnt; const int32_t* seg_of_det; int S; int training;
     const float* w1; const float* b1; const float* gamma; const float* beta;
     const float* run_mean; const float* run_var; const float* w2; const float* b2;
@@ -96,12 +96,13 @@ __global__ __launch_bounds__(IT_NT) void k_it_fwd(ItFwdArgs a) {
         if (F <= 16) {
             for (int t = tid; t < nr * 16; t += IT_NT) {
                 const int i = t >> 4, f = t & 15;
-                s_x[t] = f < F ? a.x[(size_t)(ra + i) * a.ld_x + f] : 0.f;
+                const size_t xrow = a.x_rows ? (size_t)a.x_rows[ra + i] : (size_t)(ra + i);
+                s_x[t] = f < F ? a.x[xrow * a.ld_x + f] : 0.f;
             }
             __syncthreads();
         }
         for (int i = sub; i < nr; i += NSUB) {
-            const float* xr = a.x + (size_t)(ra + i) * a.ld_x;
+            const float* xr = a.x + ((F > 16 && a.x_rows) ? (size_t)a.x_rows[ra + i] : (size_t)(ra + i)) * a.ld_x;
             float acc = b1;
             if (F <= 16) {
 #pragma unroll
@@ -172,7 +173,7 @@ __global__ __launch_bounds__(IT_NT) void k_it_fwd(ItFwdArgs a) {
 }
 
 struct ItBwdArgs {
-    const float* x; int ld_x; int F; int nd;
+    const float* x; const int64_t* x_rows; int ld_x; int F; int nd;
     const int32_t* seg_ptr; const int32_t* seg_cnt; const int32_t* seg_of_det; int S; int training;
     const float* w1; const float* b1; const float* gamma; const float* beta; const float* w2;
     const float* y_save; const float* mean; const float* rstd; const int32_t* out_row;
@@ -260,7 +261,8 @@ __global__ __launch_bounds__(IT_NT) void k_it_bwd(ItBwdArgs a) {
         if (F <= 16) {
             for (int t = tid; t < nr * 16; t += IT_NT) {
                 const int i = t >> 4, f = t & 15;
-                s_x[t] = f < F ? a.x[(size_t)(ra + i) * a.ld_x + f] : 0.f;
+                const size_t xrow = a.x_rows ? (size_t)a.x_rows[ra + i] : (size_t)(ra + i);
+                s_x[t] = f < F ? a.x[xrow * a.ld_x + f] : 0.f;
             }
         }
         __syncthreads();
@@ -357,7 +359,7 @@ __global__ __launch_bounds__(IT_NT) void k_it_bwd(ItBwdArgs a) {
         } else {
             for (int i = 0; i < nr; ++i) {
                 const float dy = s_a[i * LD + c];
-                const float* xr = a.x + (size_t)(ra + i) * a.ld_x;
+                const float* xr = a.x + (a.x_rows ? (size_t)a.x_rows[ra + i] : (size_t)(ra + i)) * a.ld_x;
 #pragma unroll
                 for (int j = 0; j < FPT; ++j) {
                     const int f = sub + j * NSUB;
@@ -497,7 +499,7 @@ int tmpnn_input_tf_supported(int H, int F, int max_seg_rows) {
     return ((H == 32 || H == 64) && F > 0 && F <= IT_FMAX && max_seg_rows >= 0 && max_seg_rows <= IT_CH) ? 1 : 0;
 }
 
-int tmpnn_input_tf_fwd(const float* xdet, int ld_x, int F, int nd, const int32_t* seg_ptr, const int32_t* seg_cnt,
+int tmpnn_input_tf_fwd(const float* xdet, const int64_t* x_rows, int ld_x, int F, int nd, const int32_t* seg_ptr, const int32_t* seg_cnt,
                        const int32_t* seg_of_det, int S, int max_seg_rows, int H, int training, const float* w1, const float* b1,
                        const float* gamma, const float* beta, float* running_mean, float* running_var, const float* w2,
                        const float* b2, float* y_save, float* mean, float* rstd, const int32_t* out_row, float* h_new,
@@ -510,7 +512,7 @@ int tmpnn_input_tf_fwd(const float* xdet, int ld_x, int F, int nd, const int32_t
     hipStream_t st = as_stream(stream);
     if (nd == 0 && !training) return TMPNN_OK;
     TM_REQUIRE(nd == 0 || (xdet && y_save && out_row && h_new && ld_x >= F && ld_h >= H), "input_tf_fwd: null/short buffers");
-    ItFwdArgs a{xdet, ld_x, F, nd, seg_ptr, seg_cnt, seg_of_det, S, training, w1, b1, gamma, beta, running_mean, running_var,
+    ItFwdArgs a{xdet, x_rows, ld_x, F, nd, seg_ptr, seg_cnt, seg_of_det, S, training, w1, b1, gamma, beta, running_mean, running_var,
                 w2, b2, y_save, mean, rstd, out_row, h_new, ld_h};
     const int nb = it_blocks(nd, S, training);
     const size_t shm = it_fwd_shm(H, F);
@@ -532,7 +534,7 @@ size_t tmpnn_input_tf_bwd_ws(int nd, int S, int H, int F, int training) {
     return sizeof(float) * (size_t)(nb > 0 ? nb : 1) * ((size_t)H * H + (size_t)H * F + 4 * H);
 }
 
-int tmpnn_input_tf_bwd(const float* xdet, int ld_x, int F, int nd, const int32_t* seg_ptr, const int32_t* seg_cnt,
+int tmpnn_input_tf_bwd(const float* xdet, const int64_t* x_rows, int ld_x, int F, int nd, const int32_t* seg_ptr, const int32_t* seg_cnt,
                        const int32_t* seg_of_det, int S, int max_seg_rows, int H, int training, const float* w1, const float* b1,
                        const float* gamma, const float* beta, const float* w2, const float* y_save, const float* mean,
                        const float* rstd, const int32_t* out_row, const float* d_h, int ld_dh, float* d_xdet, int ld_dx,
@@ -553,7 +555,7 @@ int tmpnn_input_tf_bwd(const float* xdet, int ld_x, int F, int nd, const int32_t
     if (!training && d_xzero && S > 0) (void)hipMemsetAsync(d_xzero, 0, sizeof(float) * (size_t)S * F, st);
     const int nb = it_blocks(nd, S, training);
     const int slab_floats = H * H + H * F + 4 * H;
-    ItBwdArgs a{xdet, ld_x, F, nd, seg_ptr, seg_cnt, seg_of_det, S, training, w1, b1, gamma, beta, w2, y_save, mean, rstd, out_row,
+    ItBwdArgs a{xdet, x_rows, ld_x, F, nd, seg_ptr, seg_cnt, seg_of_det, S, training, w1, b1, gamma, beta, w2, y_save, mean, rstd, out_row,
                 d_h, ld_dh, d_xdet, ld_dx, d_xzero, reinterpret_cast<float*>(ws), slab_floats};
 #define IT_BWD(HH, FF)                                                                                   \
     do {                                                                                                 \

@@ -308,7 +308,17 @@ def mp_forward(spec: ModelSpec, plan: CallPlan, x: torch.Tensor, h_in: Optional[
             # torch.nn.functional.batch_norm refuses a single row in training mode; so does the reference
             raise ValueError('Expected more than 1 value per channel when training, got input size '
                              f'[1, {H}]')
-        xdet = _f32c(x.detach().index_select(0, plan.new_det_local)) if nd > 0 else torch.empty((0, spec.F_total), **opts)
+        # the det rows of x: gathered here for the staged transform; the one-launch transform reads x through the row list
+        # (tmpnn_input_tf_*'s x_rows) -- no gather launch, no compact copy
+        tf_all = nd > 0 and all(_input_tf(plan, H, F) for _, F in spec.groups)
+        if tf_all:
+            xsrc, xrows = _f32c(x.detach()), plan.new_det_local
+            if xrows.dtype != torch.int64 or not xrows.is_contiguous():
+                xrows = xrows.long().contiguous()
+            xdet = None
+        else:
+            xdet = _f32c(x.detach().index_select(0, plan.new_det_local)) if nd > 0 else torch.empty((0, spec.F_total), **opts)
+            xsrc, xrows = xdet, None
         ws_a = torch.empty((max(nd, 1), H), **opts)
         y_saves, means, rstds = [], [], []
         f0 = 0
@@ -319,7 +329,7 @@ def mp_forward(spec: ModelSpec, plan: CallPlan, x: torch.Tensor, h_in: Optional[
             mean = torch.empty((SS, H), **opts)
             rstd = torch.empty((SS, H), **opts)
             if _input_tf(plan, H, F):
-                _lib.call('tmpnn_input_tf_fwd', xdet.data_ptr() + 4 * f0, spec.F_total, F, nd,
+                _lib.call('tmpnn_input_tf_fwd', xsrc.data_ptr() + 4 * f0, _lib.ptr(xrows), spec.F_total, F, nd,
                           plan.seg_ptr.data_ptr(), plan.seg_cnt.data_ptr(), _lib.ptr(plan.seg_of_det), S, plan.max_seg_nd, H,
                           int(training), P[t + '0.weight'].data_ptr(), P[t + '0.bias'].data_ptr(),
                           P[t + '1.weight'].data_ptr(), P[t + '1.bias'].data_ptr(),
@@ -343,7 +353,7 @@ def mp_forward(spec: ModelSpec, plan: CallPlan, x: torch.Tensor, h_in: Optional[
             rstds.append(rstd)
             f0 += F
         if save:
-            saved.update(xdet=xdet, y_save=y_saves, mean=means, rstd=rstds)
+            saved.update(xdet=xsrc, xrows=xrows, y_save=y_saves, mean=means, rstd=rstds)
 
     spare = max(int(reserve_rows), 0)
     if spare > 0:      # plain (non-view) tensor over a larger storage: the next call may extend it in place
@@ -753,7 +763,7 @@ def mp_backward(spec: ModelSpec, plan: CallPlan, saved: dict, P: Dict[str, torch
             if _input_tf(plan, H, F):
                 wsb = int(lib.tmpnn_input_tf_bwd_ws(nd, S, H, F, int(training)))
                 ws = torch.empty((wsb // 4 + 1,), **opts)
-                _lib.call('tmpnn_input_tf_bwd', xdet.data_ptr() + 4 * f0, Ft, F, nd,
+                _lib.call('tmpnn_input_tf_bwd', xdet.data_ptr() + 4 * f0, _lib.ptr(saved.get('xrows')), Ft, F, nd,
                           plan.seg_ptr.data_ptr(), plan.seg_cnt.data_ptr(), _lib.ptr(plan.seg_of_det), S, plan.max_seg_nd, H,
                           int(training), P[t + '0.weight'].data_ptr(), P[t + '0.bias'].data_ptr(),
                           P[t + '1.weight'].data_ptr(), P[t + '1.bias'].data_ptr(), P[t + '3.weight'].data_ptr(),
