@@ -315,7 +315,7 @@ def check_heads(C, g, gd):
     return res
 
 
-def check_input_bn(H, F_, training, S=4, fused=False):
+def check_input_bn(H, F_, training, S=4, fused=False, maxn=40, dx=True):
     """fused=False: the staged launches of tmpnn_input_bn_*; fused=True: tmpnn_input_tf_* (one launch per direction), with
     enough segments that several workgroups and several chunks per workgroup take part."""
     torch.manual_seed(H + F_)
@@ -325,7 +325,7 @@ def check_input_bn(H, F_, training, S=4, fused=False):
         cnts = [n + z for n, z in zip(nds, [6, 4, 0, 9])]
     else:
         rs = np.random.RandomState(S)
-        nds = [int(v) for v in rs.randint(1, 40, S)]
+        nds = [int(v) for v in rs.randint(1, maxn, S)]
         cnts = [n + int(z) for n, z in zip(nds, rs.randint(0, 30, S))]
         cnts = [max(c, 2) for c in cnts]
     nd = sum(nds)
@@ -401,8 +401,8 @@ def check_input_bn(H, F_, training, S=4, fused=False):
         _lib.call('tmpnn_input_tf_bwd', xS.data_ptr() + 4, xr_idx.data_ptr(), Ft, F_, nd, seg_ptr.data_ptr(), seg_cnt.data_ptr(), _lib.ptr(seg_of_det), S,
                   max(nds), H, int(training), P[t + '0.weight'].data_ptr(), P[t + '0.bias'].data_ptr(), P[t + '1.weight'].data_ptr(),
                   P[t + '1.bias'].data_ptr(), P[t + '3.weight'].data_ptr(), y_save.data_ptr(), mean.data_ptr(),
-                  rstd.data_ptr(), out_row.data_ptr(), d_hD.data_ptr() + 4 * H, ld, d_xdet.data_ptr() + 4, Ft,
-                  d_xzero.data_ptr(), grads['0.weight'].data_ptr(), grads['0.bias'].data_ptr(),
+                  rstd.data_ptr(), out_row.data_ptr(), d_hD.data_ptr() + 4 * H, ld, (d_xdet.data_ptr() + 4) if dx else None, Ft,
+                  d_xzero.data_ptr() if dx else None, grads['0.weight'].data_ptr(), grads['0.bias'].data_ptr(),
                   grads['1.weight'].data_ptr(), grads['1.bias'].data_ptr(), grads['3.weight'].data_ptr(),
                   grads['3.bias'].data_ptr(), ws.data_ptr(), wsb, st())
     else:
@@ -418,6 +418,8 @@ def check_input_bn(H, F_, training, S=4, fused=False):
     gs = max(1.0, max(pg[t + k].grad.abs().max().item() for k in grads))
     for k in grads:
         res['d' + k] = (grads[k].cpu() - pg[t + k].grad).abs().max().item() / gs
+    if not dx:               # (no gradient with respect to x asked for: the wave-owned form of the one-launch transform)
+        return res
     res['d_xdet'] = (d_xdet.cpu()[:, 1:1 + F_] - xfull.grad[is_det]).abs().max().item() / gs
     gz = xfull.grad[~is_det]
     segz = seg[~is_det]
@@ -815,6 +817,11 @@ def run_all(report=print):
         for training in (True, False):
             for k, v in check_input_bn(H, F_, training, S=S, fused=True).items():
                 rec(f'input_tf (one launch) H={H} F={F_} S={S} train={training} {k}', v, 2e-4)
+    # the wave-owned form (training, H = 64, F <= 16, segments of <= 32 det rows, no gradient with respect to x): many
+    # segments, tiles of one to a dozen segments, several groups per workgroup
+    for F_, S, maxn in ((8, 150, 33), (13, 700, 12), (8, 40, 2), (16, 9000, 8)):
+        for k, v in check_input_bn(64, F_, True, S=S, fused=True, maxn=maxn, dx=False).items():
+            rec(f'input_tf (wave-owned) H=64 F={F_} S={S} rows<{maxn} {k}', v, 2e-4)
     run_attention(rec, g)
     torch.cuda.synchronize()
     return results

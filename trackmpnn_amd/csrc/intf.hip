@@ -19,6 +19,7 @@
 // (the host knows the longest segment of its plan); callers fall back to the staged form for long segments (one window
 // of thousands of dets is ONE segment: BASELINE C5) or wide inputs.
 #include "common.h"
+#include <stdlib.h>
 
 namespace tmpnn {
 
@@ -422,6 +423,280 @@ __global__ __launch_bounds__(IT_NT) void k_it_bwd(ItBwdArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// Round 6: the same transform with TILES OWNED BY WAVES (training mode, H = 64, F <= 16, segments of <= ITW_R det rows).
+// The workgroup form above walks a group's chunks one after another, every phase between two block-wide barriers, and its
+// three 64 x 64 products run as scalar FMAs against LDS operands: 85-100 us forward and 150 us backward per call for ~100 k det
+// rows (1.5 ms of a 28-ms C2 step).  Here a wave owns a tile -- consecutive whole segments of at most ITW_R det rows -- from its
+// first load to its last store: lane = hidden column, so every per-column quantity of the transform (Lin1, the batch
+// statistics with their analytic zero-row terms, normalise + ReLU, dgamma / dbeta, the BatchNorm backward's two segment sums)
+// is lane-private, nothing waits at a barrier, and the eight waves of a workgroup are eight independent chains.  What crosses
+// lanes goes through a wave-private LDS tile read with broadcast ds_read_b128: Lin2 (the lane keeps row c of W2 in 64 registers),
+// and in the backward dW2^T (64 accumulators: the lane's column k of a against a broadcast row of d_out) fused with
+// da = d_out W2 (the lane keeps column k of W2) -- one pass over the d_out rows for both.  Results equal the workgroup form's to
+// rounding (same formulas; the products sum in another order).  Gradients with respect to x (d_xdet / d_xzero) are not formed
+// here: callers that ask for them take the workgroup form.
+static constexpr int ITW_R = 32;        // det rows of a tile
+static constexpr int ITW_NW = 8;        // waves of a workgroup
+static constexpr int ITW_FWD_WAVE_FLOATS = ITW_R * 64 + ITW_R * 16;              // a tile | x rows
+static constexpr int ITW_BWD_WAVE_FLOATS = 2 * ITW_R * 64 + ITW_R * 16;          // yhat | d_out -> d_yhat -> dy | x rows
+
+#define ITW_LDS_SYNC() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+// the tile [sa, sb) of whole segments starting at sa with at most ITW_R det rows (at least one segment)
+__device__ __forceinline__ int itw_chunk_end(const int* s_sp, int s0, int sa, int s1) {
+    const int base = s_sp[sa - s0];
+    int sb = sa + 1;
+    while (sb < s1 && s_sp[sb + 1 - s0] - base <= ITW_R) ++sb;
+    return sb;
+}
+
+// x rows [ra, ra + nr) of the tile -> s_x[i][16] (columns >= F zero)
+__device__ __forceinline__ void itw_stage_x(const float* __restrict__ x, const int64_t* __restrict__ x_rows, int ld_x, int F,
+                                            int ra, int nr, int lane, float* s_x) {
+    for (int t = lane; t < nr * 16; t += 64) {
+        const int i = t >> 4, f = t & 15;
+        const size_t xrow = x_rows ? (size_t)x_rows[ra + i] : (size_t)(ra + i);
+        s_x[t] = f < F ? x[xrow * ld_x + f] : 0.f;
+    }
+}
+
+__global__ __launch_bounds__(ITW_NW * 64) void k_itw_fwd(ItFwdArgs a) {
+    constexpr int H = 64;
+    extern __shared__ __attribute__((aligned(16))) float it_lds[];
+    __shared__ int s_sp[IT_SPB + 1];
+    const int tid = threadIdx.x, c = tid & 63, wave = tid >> 6;
+    float* s_a = it_lds + wave * ITW_FWD_WAVE_FLOATS;       // [ITW_R][64]: y, then a
+    float* s_x = s_a + ITW_R * 64;                          // [ITW_R][16]
+    const int F = a.F;
+    float w1r[16], w2r[64];
+#pragma unroll
+    for (int f = 0; f < 16; ++f) w1r[f] = f < F ? a.w1[c * F + f] : 0.f;
+#pragma unroll
+    for (int k4 = 0; k4 < 16; ++k4) {
+        const float4 w = *reinterpret_cast<const float4*>(a.w2 + c * H + 4 * k4);
+        w2r[4 * k4] = w.x; w2r[4 * k4 + 1] = w.y; w2r[4 * k4 + 2] = w.z; w2r[4 * k4 + 3] = w.w;
+    }
+    const float b1 = a.b1[c], gam = a.gamma[c], bet = a.beta[c], b2 = a.b2[c];
+    const int ngroups = (a.S + IT_SPB - 1) / IT_SPB;
+    for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+        const int s0 = grp * IT_SPB, s1 = min(a.S, s0 + IT_SPB);
+        __syncthreads();                                  // (the previous group's readers of s_sp are done)
+        if (tid <= s1 - s0) s_sp[tid] = a.seg_ptr[s0 + tid];
+        __syncthreads();
+        int j = 0;
+        for (int sa = s0; sa < s1; ++j) {
+            const int sb = itw_chunk_end(s_sp, s0, sa, s1);
+            if ((j & (ITW_NW - 1)) == wave) {
+                const int ra = s_sp[sa - s0], nr = s_sp[sb - s0] - ra;
+                int orow_l = 0, cnt_l = 1;
+                if (c < nr) orow_l = a.out_row[ra + c];              // (requested first, used last)
+                if (sa + c < sb) cnt_l = a.seg_cnt[sa + c];          // (a tile holds at most IT_SPB <= 64 segments: one per lane)
+                itw_stage_x(a.x, a.x_rows, a.ld_x, F, ra, nr, c, s_x);
+                ITW_LDS_SYNC();
+                // ---- Lin1 -> y (own column of the tile) + y_save
+                for (int i = 0; i < nr; ++i) {
+                    float acc = b1;
+#pragma unroll
+                    for (int f4 = 0; f4 < 4; ++f4) {
+                        const float4 xv = *reinterpret_cast<const float4*>(s_x + i * 16 + 4 * f4);
+                        acc = fmaf(xv.x, w1r[4 * f4], acc); acc = fmaf(xv.y, w1r[4 * f4 + 1], acc);
+                        acc = fmaf(xv.z, w1r[4 * f4 + 2], acc); acc = fmaf(xv.w, w1r[4 * f4 + 3], acc);
+                    }
+                    s_a[i * 64 + c] = acc;
+                    a.y_save[(size_t)(ra + i) * H + c] = acc;
+                }
+                // ---- per segment: batch statistics over ALL its new rows (the zero rows contribute Lin1(0) = b1), then
+                //      normalise + ReLU in place (lane-private column: no synchronisation)
+                for (int s = sa; s < sb; ++s) {
+                    const int p0 = s_sp[s - s0] - ra, p1 = s_sp[s + 1 - s0] - ra;
+                    const float cnt = (float)__shfl(cnt_l, s - sa, 64), nz = cnt - (float)(p1 - p0);
+                    float sum = nz * b1;
+                    for (int i = p0; i < p1; ++i) sum += s_a[i * 64 + c];
+                    const float m = sum / cnt;
+                    float sq = nz * (b1 - m) * (b1 - m);
+                    for (int i = p0; i < p1; ++i) { const float d = s_a[i * 64 + c] - m; sq += d * d; }
+                    const float r = rsqrtf(sq / cnt + IT_EPS);
+                    a.mean[(size_t)s * H + c] = m; a.rstd[(size_t)s * H + c] = r;
+                    for (int i = p0; i < p1; ++i) s_a[i * 64 + c] = fmaxf((s_a[i * 64 + c] - m) * r * gam + bet, 0.f);
+                }
+                ITW_LDS_SYNC();
+                // ---- Lin2: out[i][c] = b2[c] + sum_k a[i][k] W2[c][k]; two rows per pass (independent chains)
+                for (int i = 0; i < nr; i += 2) {
+                    const int i1 = min(i + 1, nr - 1);
+                    float acc0 = b2, acc1 = b2;
+#pragma unroll
+                    for (int k4 = 0; k4 < 16; ++k4) {
+                        const float4 a0 = *reinterpret_cast<const float4*>(s_a + i * 64 + 4 * k4);
+                        const float4 a1 = *reinterpret_cast<const float4*>(s_a + i1 * 64 + 4 * k4);
+                        acc0 = fmaf(a0.x, w2r[4 * k4], acc0); acc0 = fmaf(a0.y, w2r[4 * k4 + 1], acc0);
+                        acc0 = fmaf(a0.z, w2r[4 * k4 + 2], acc0); acc0 = fmaf(a0.w, w2r[4 * k4 + 3], acc0);
+                        acc1 = fmaf(a1.x, w2r[4 * k4], acc1); acc1 = fmaf(a1.y, w2r[4 * k4 + 1], acc1);
+                        acc1 = fmaf(a1.z, w2r[4 * k4 + 2], acc1); acc1 = fmaf(a1.w, w2r[4 * k4 + 3], acc1);
+                    }
+                    const int o0 = __shfl(orow_l, i, 64), o1 = __shfl(orow_l, i1, 64);
+                    a.h_new[(size_t)o0 * a.ld_h + c] = acc0;
+                    if (i + 1 < nr) a.h_new[(size_t)o1 * a.ld_h + c] = acc1;
+                }
+                ITW_LDS_SYNC();                                      // (the tile is free for the wave's next one)
+            }
+            sa = sb;
+        }
+    }
+}
+
+__global__ __launch_bounds__(ITW_NW * 64) void k_itw_bwd(ItBwdArgs a) {
+    constexpr int H = 64;
+    extern __shared__ __attribute__((aligned(16))) float it_lds[];
+    __shared__ int s_sp[IT_SPB + 1];
+    const int tid = threadIdx.x, c = tid & 63, wave = tid >> 6;       // c: the lane's hidden column (k of a / yhat / dy)
+    float* s_yh = it_lds + wave * ITW_BWD_WAVE_FLOATS;      // [ITW_R][64] yhat (lane-private columns)
+    float* s_d = s_yh + ITW_R * 64;                         // [ITW_R][64] d_out rows (broadcast reads), then d_yhat, then dy
+    float* s_x = s_d + ITW_R * 64;                          // [ITW_R][16]
+    const int F = a.F;
+    float w2c[64];                                          // column c of W2: w2c[j] = W2[j][c]
+#pragma unroll
+    for (int j = 0; j < 64; ++j) w2c[j] = a.w2[j * H + c];
+    const float b1 = a.b1[c], gam = a.gamma[c], bet = a.beta[c];
+    float acc_w2t[64];                                      // acc_w2t[j] = dW2[j][c]
+#pragma unroll
+    for (int j = 0; j < 64; ++j) acc_w2t[j] = 0.f;
+    float acc_w1[16];
+#pragma unroll
+    for (int f = 0; f < 16; ++f) acc_w1[f] = 0.f;
+    float v_dg = 0.f, v_dbt = 0.f, v_db1 = 0.f;
+    float v_db2 = 0.f;                                      // (lane c sums d_out[.][c])
+    const int ngroups = (a.S + IT_SPB - 1) / IT_SPB;
+    for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+        const int s0 = grp * IT_SPB, s1 = min(a.S, s0 + IT_SPB);
+        __syncthreads();
+        if (tid <= s1 - s0) s_sp[tid] = a.seg_ptr[s0 + tid];
+        __syncthreads();
+        int j = 0;
+        for (int sa = s0; sa < s1; ++j) {
+            const int sb = itw_chunk_end(s_sp, s0, sa, s1);
+            if ((j & (ITW_NW - 1)) == wave) {
+                const int ra = s_sp[sa - s0], nr = s_sp[sb - s0] - ra;
+                int orow_l = 0, cnt_l = 1;
+                if (c < nr) orow_l = a.out_row[ra + c];
+                if (sa + c < sb) cnt_l = a.seg_cnt[sa + c];
+                itw_stage_x(a.x, a.x_rows, a.ld_x, F, ra, nr, c, s_x);
+                // ---- d_out rows (gathered) -> s_d ; yhat (recomputed from y_save and the segment's statistics) -> s_yh
+                for (int s = sa; s < sb; ++s) {
+                    const int p0 = s_sp[s - s0] - ra, p1 = s_sp[s + 1 - s0] - ra;
+                    const float m = a.mean[(size_t)s * H + c], r = a.rstd[(size_t)s * H + c];
+                    for (int i = p0; i < p1; ++i) {
+                        const int orow = __shfl(orow_l, i, 64);
+                        const float d = a.d_h[(size_t)orow * a.ld_dh + c];
+                        const float yv = a.y_save[(size_t)(ra + i) * H + c];
+                        s_d[i * 64 + c] = d;
+                        s_yh[i * 64 + c] = (yv - m) * r;
+                        v_db2 += d;
+                    }
+                }
+                ITW_LDS_SYNC();
+                // ---- one pass over the d_out rows: dW2[j][c] += d_out[i][j] a[i][c] and da[i][c] = sum_j d_out[i][j] W2[j][c];
+                //      then the ReLU mask, dgamma / dbeta and d_yhat (into the lane's own column of s_d: row i of s_d has been
+                //      read by every lane of the wave when its iteration ends)
+                for (int i = 0; i < nr; ++i) {
+                    const float yh = s_yh[i * 64 + c];
+                    const float av = fmaxf(yh * gam + bet, 0.f);
+                    float da0 = 0.f, da1 = 0.f;
+#pragma unroll
+                    for (int j4 = 0; j4 < 16; ++j4) {
+                        const float4 dv = *reinterpret_cast<const float4*>(s_d + i * 64 + 4 * j4);
+                        acc_w2t[4 * j4] = fmaf(dv.x, av, acc_w2t[4 * j4]); acc_w2t[4 * j4 + 1] = fmaf(dv.y, av, acc_w2t[4 * j4 + 1]);
+                        acc_w2t[4 * j4 + 2] = fmaf(dv.z, av, acc_w2t[4 * j4 + 2]); acc_w2t[4 * j4 + 3] = fmaf(dv.w, av, acc_w2t[4 * j4 + 3]);
+                        da0 = fmaf(dv.x, w2c[4 * j4], da0); da1 = fmaf(dv.y, w2c[4 * j4 + 1], da1);
+                        da0 = fmaf(dv.z, w2c[4 * j4 + 2], da0); da1 = fmaf(dv.w, w2c[4 * j4 + 3], da1);
+                    }
+                    const float dz = av > 0.f ? da0 + da1 : 0.f;
+                    v_dg = fmaf(dz, yh, v_dg);
+                    v_dbt += dz;
+                    ITW_LDS_SYNC();                                  // (every lane's reads of row i are back)
+                    s_d[i * 64 + c] = dz * gam;
+                }
+                // ---- BatchNorm backward per segment: dy = rstd (d_yhat - q1 / n - yhat q2 / n) on the det rows; each of the
+                //      segment's zero rows (yhat0 = (b1 - mean) rstd, d_yhat0 = 0) receives dy0 = rstd (- q1 / n - yhat0 q2 / n)
+                for (int s = sa; s < sb; ++s) {
+                    const int p0 = s_sp[s - s0] - ra, p1 = s_sp[s + 1 - s0] - ra;
+                    const float cnt = (float)__shfl(cnt_l, s - sa, 64), nz = cnt - (float)(p1 - p0);
+                    const float m = a.mean[(size_t)s * H + c], r = a.rstd[(size_t)s * H + c];
+                    float q1 = 0.f, q2 = 0.f;
+                    for (int i = p0; i < p1; ++i) { const float g = s_d[i * 64 + c]; q1 += g; q2 = fmaf(g, s_yh[i * 64 + c], q2); }
+                    const float inv = 1.0f / cnt;
+                    for (int i = p0; i < p1; ++i) {
+                        const float dy = r * (s_d[i * 64 + c] - q1 * inv - s_yh[i * 64 + c] * q2 * inv);
+                        s_d[i * 64 + c] = dy;
+                        v_db1 += dy;
+                    }
+                    const float yh0 = (b1 - m) * r;
+                    const float dy0 = r * (-q1 * inv - yh0 * q2 * inv);
+                    v_db1 = fmaf(nz, dy0, v_db1);
+                }
+                // ---- dW1[c][f] += sum_i dy[i][c] x[i][f]   (columns >= F of s_x hold zeros)
+                for (int i = 0; i < nr; ++i) {
+                    const float dy = s_d[i * 64 + c];
+#pragma unroll
+                    for (int f4 = 0; f4 < 4; ++f4) {
+                        const float4 xv = *reinterpret_cast<const float4*>(s_x + i * 16 + 4 * f4);
+                        acc_w1[4 * f4] = fmaf(dy, xv.x, acc_w1[4 * f4]); acc_w1[4 * f4 + 1] = fmaf(dy, xv.y, acc_w1[4 * f4 + 1]);
+                        acc_w1[4 * f4 + 2] = fmaf(dy, xv.z, acc_w1[4 * f4 + 2]); acc_w1[4 * f4 + 3] = fmaf(dy, xv.w, acc_w1[4 * f4 + 3]);
+                    }
+                }
+                ITW_LDS_SYNC();
+            }
+            sa = sb;
+        }
+    }
+    // ---- this workgroup's slab: the eight waves' accumulators combined through LDS in wave order (deterministic)
+    __syncthreads();
+    float* s_all = it_lds;                                  // per wave an area of ITW_BWD_WAVE_FLOATS >= 64 * 64 floats
+    float* mine = s_all + wave * ITW_BWD_WAVE_FLOATS;
+#pragma unroll
+    for (int j = 0; j < 64; ++j) mine[j * 64 + c] = acc_w2t[j];
+    __syncthreads();
+    float* slab = a.slabs + (size_t)blockIdx.x * a.slab_floats;
+    for (int e = tid; e < H * H; e += ITW_NW * 64) {
+        float v = 0.f;
+#pragma unroll
+        for (int w = 0; w < ITW_NW; ++w) v += s_all[w * ITW_BWD_WAVE_FLOATS + e];
+        slab[e] = v;                                        // e = j * 64 + c = dW2[j][c]
+    }
+    __syncthreads();
+#pragma unroll
+    for (int f = 0; f < 16; ++f) mine[c * 16 + f] = acc_w1[f];
+    mine[1024 + c] = v_db2; mine[1088 + c] = v_dg; mine[1152 + c] = v_dbt; mine[1216 + c] = v_db1;
+    __syncthreads();
+    float* sl_w1 = slab + H * H;
+    for (int e = tid; e < H * F; e += ITW_NW * 64) {
+        const int k = e / F, f = e - k * F;
+        float v = 0.f;
+#pragma unroll
+        for (int w = 0; w < ITW_NW; ++w) v += s_all[w * ITW_BWD_WAVE_FLOATS + k * 16 + f];
+        sl_w1[e] = v;
+    }
+    float* sl_v = sl_w1 + H * F;
+    for (int e = tid; e < 4 * H; e += ITW_NW * 64) {
+        float v = 0.f;
+#pragma unroll
+        for (int w = 0; w < ITW_NW; ++w) v += s_all[w * ITW_BWD_WAVE_FLOATS + 1024 + e];
+        sl_v[e] = v;                                        // [db2 | dgamma | dbeta | db1]
+    }
+}
+
+// the wave-owned form serves training calls at H = 64 with narrow inputs and segments of at most ITW_R det rows
+// (TMPNN_IT_WAVE=0 keeps the workgroup form: A/B runs)
+static bool itw_serves(int H, int F, int max_seg_rows, int training) {
+    static const int off = [] { const char* e = getenv("TMPNN_IT_WAVE"); return (e && e[0] == '0') ? 1 : 0; }();
+    return !off && training && H == 64 && F <= 16 && max_seg_rows <= ITW_R;
+}
+static int itw_blocks(int S) {
+    const int groups = ceil_div(S, IT_SPB);
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    return groups < cus ? groups : cus;
+}
+
 // dst (+)= sum over slabs, fixed order: element e of [dW2 | dW1 | db2 | dgamma | dbeta | db1].  A block takes 32 elements
 // x 8 slices of the slab list; the slices are combined through LDS in slice order (deterministic).
 __global__ __launch_bounds__(256) void k_it_reduce(const float* __restrict__ slabs, int nslab, int slab_floats, int H, int F,
@@ -514,6 +789,15 @@ int tmpnn_input_tf_fwd(const float* xdet, const int64_t* x_rows, int ld_x, int F
     TM_REQUIRE(nd == 0 || (xdet && y_save && out_row && h_new && ld_x >= F && ld_h >= H), "input_tf_fwd: null/short buffers");
     ItFwdArgs a{xdet, x_rows, ld_x, F, nd, seg_ptr, seg_cnt, seg_of_det, S, training, w1, b1, gamma, beta, running_mean, running_var,
                 w2, b2, y_save, mean, rstd, out_row, h_new, ld_h};
+    if (nd > 0 && itw_serves(H, F, max_seg_rows, training)) {
+        const size_t shmw = sizeof(float) * (size_t)ITW_NW * ITW_FWD_WAVE_FLOATS;
+        TM_SHM_ONCE(k_itw_fwd, shmw);
+        hipLaunchKernelGGL(k_itw_fwd, dim3(itw_blocks(S)), dim3(ITW_NW * 64), shmw, st, a);
+        int rc = check_launch("itw_fwd");
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_it_running, dim3(H), dim3(64), 0, st, mean, rstd, seg_cnt, S, H, running_mean, running_var);
+        return check_launch("it_running");
+    }
     const int nb = it_blocks(nd, S, training);
     const size_t shm = it_fwd_shm(H, F);
     if (nb > 0) {
@@ -530,7 +814,8 @@ int tmpnn_input_tf_fwd(const float* xdet, const int64_t* x_rows, int ld_x, int F
 }
 
 size_t tmpnn_input_tf_bwd_ws(int nd, int S, int H, int F, int training) {
-    const int nb = it_blocks(nd, S, training);
+    int nb = it_blocks(nd, S, training);
+    if (training && itw_blocks(S) > nb) nb = itw_blocks(S);          // (whichever form the launch picks: one slab per workgroup)
     return sizeof(float) * (size_t)(nb > 0 ? nb : 1) * ((size_t)H * H + (size_t)H * F + 4 * H);
 }
 
@@ -553,10 +838,21 @@ int tmpnn_input_tf_bwd(const float* xdet, const int64_t* x_rows, int ld_x, int F
     const size_t need = tmpnn_input_tf_bwd_ws(nd, S, H, F, training);
     if (ws_bytes < need) return set_error(TMPNN_EWORKSPACE, "input_tf_bwd: workspace %zu < %zu bytes", ws_bytes, need);
     if (!training && d_xzero && S > 0) (void)hipMemsetAsync(d_xzero, 0, sizeof(float) * (size_t)S * F, st);
-    const int nb = it_blocks(nd, S, training);
+    const bool wave_form = itw_serves(H, F, max_seg_rows, training) && d_xdet == nullptr && d_xzero == nullptr;
+    const int nb = wave_form ? itw_blocks(S) : it_blocks(nd, S, training);
     const int slab_floats = H * H + H * F + 4 * H;
     ItBwdArgs a{xdet, x_rows, ld_x, F, nd, seg_ptr, seg_cnt, seg_of_det, S, training, w1, b1, gamma, beta, w2, y_save, mean, rstd, out_row,
                 d_h, ld_dh, d_xdet, ld_dx, d_xzero, reinterpret_cast<float*>(ws), slab_floats};
+    if (wave_form) {
+        const size_t shmw = sizeof(float) * (size_t)ITW_NW * ITW_BWD_WAVE_FLOATS;
+        TM_SHM_ONCE(k_itw_bwd, shmw);
+        hipLaunchKernelGGL(k_itw_bwd, dim3(nb), dim3(ITW_NW * 64), shmw, st, a);
+        int rc = check_launch("itw_bwd");
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_it_reduce, dim3(ceil_div(slab_floats, 32)), dim3(256), 0, st, reinterpret_cast<const float*>(ws), nb,
+                           slab_floats, H, F, dw2, dw1, db2, dgamma, dbeta, db1);
+        return check_launch("it_reduce");
+    }
 #define IT_BWD(HH, FF)                                                                                   \
     do {                                                                                                 \
         TM_SHM_ONCE((k_it_bwd<HH, FF>), it_bwd_shm(HH));                                                 \
