@@ -437,27 +437,56 @@ __global__ __launch_bounds__(IT_NT) void k_it_bwd(ItBwdArgs a) {
 // rounding (same formulas; the products sum in another order).  Gradients with respect to x (d_xdet / d_xzero) are not formed
 // here: callers that ask for them take the workgroup form.
 static constexpr int ITW_R = 32;        // det rows of a tile
+static constexpr int ITW_MS = 8;        // segments of a tile (their statistics ride in registers)
 static constexpr int ITW_NW = 8;        // waves of a workgroup
 static constexpr int ITW_FWD_WAVE_FLOATS = ITW_R * 64 + ITW_R * 16;              // a tile | x rows
 static constexpr int ITW_BWD_WAVE_FLOATS = 2 * ITW_R * 64 + ITW_R * 16;          // yhat | d_out -> d_yhat -> dy | x rows
 
 #define ITW_LDS_SYNC() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
-// the tile [sa, sb) of whole segments starting at sa with at most ITW_R det rows (at least one segment)
+// the tile [sa, sb) of whole segments starting at sa: at most ITW_R det rows and ITW_MS segments (at least one segment)
 __device__ __forceinline__ int itw_chunk_end(const int* s_sp, int s0, int sa, int s1) {
     const int base = s_sp[sa - s0];
     int sb = sa + 1;
-    while (sb < s1 && s_sp[sb + 1 - s0] - base <= ITW_R) ++sb;
+    while (sb < s1 && sb - sa < ITW_MS && s_sp[sb + 1 - s0] - base <= ITW_R) ++sb;
     return sb;
 }
 
-// x rows [ra, ra + nr) of the tile -> s_x[i][16] (columns >= F zero)
+// Every global round trip of a tile is taken ONCE, for all its rows together: a loop that loads, waits and stores row by row
+// pays the memory latency per row (the first form of these kernels: 80 / 110 us per call, most of it in such loops).
+// x rows [ra, ra + nr) of the tile -> s_x[i][16] (columns >= F zero): nr * 16 <= 512 elements = 8 per lane; the row ids
+// (x_rows) of all eight are requested, then the eight values, then the LDS writes
 __device__ __forceinline__ void itw_stage_x(const float* __restrict__ x, const int64_t* __restrict__ x_rows, int ld_x, int F,
                                             int ra, int nr, int lane, float* s_x) {
-    for (int t = lane; t < nr * 16; t += 64) {
-        const int i = t >> 4, f = t & 15;
-        const size_t xrow = x_rows ? (size_t)x_rows[ra + i] : (size_t)(ra + i);
-        s_x[t] = f < F ? x[xrow * ld_x + f] : 0.f;
+    size_t xrow[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int t = lane + 64 * q, i = min(t >> 4, nr - 1);
+        xrow[q] = x_rows ? (size_t)x_rows[ra + i] : (size_t)(ra + i);
     }
+    float v[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int f = lane & 15;
+        v[q] = x[xrow[q] * ld_x + min(f, F - 1)];
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int t = lane + 64 * q;
+        if (t < nr * 16) s_x[t] = (lane & 15) < F ? v[q] : 0.f;
+    }
+}
+
+// sum over rows [p0, p1) of the lane's column of a [.][64] tile, eight reads in flight
+__device__ __forceinline__ float itw_col_sum(const float* col, int p0, int p1) {
+    float sum = 0.f;
+    for (int b = p0; b < p1; b += 8) {
+        float v[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) v[t] = col[min(b + t, p1 - 1) * 64];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) sum += (b + t < p1) ? v[t] : 0.f;
+    }
+    return sum;
 }
 
 __global__ __launch_bounds__(ITW_NW * 64) void k_itw_fwd(ItFwdArgs a) {
@@ -467,6 +496,7 @@ __global__ __launch_bounds__(ITW_NW * 64) void k_itw_fwd(ItFwdArgs a) {
     const int tid = threadIdx.x, c = tid & 63, wave = tid >> 6;
     float* s_a = it_lds + wave * ITW_FWD_WAVE_FLOATS;       // [ITW_R][64]: y, then a
     float* s_x = s_a + ITW_R * 64;                          // [ITW_R][16]
+    float* col = s_a + c;                                   // the lane's column
     const int F = a.F;
     float w1r[16], w2r[64];
 #pragma unroll
@@ -490,37 +520,56 @@ __global__ __launch_bounds__(ITW_NW * 64) void k_itw_fwd(ItFwdArgs a) {
                 const int ra = s_sp[sa - s0], nr = s_sp[sb - s0] - ra;
                 int orow_l = 0, cnt_l = 1;
                 if (c < nr) orow_l = a.out_row[ra + c];              // (requested first, used last)
-                if (sa + c < sb) cnt_l = a.seg_cnt[sa + c];          // (a tile holds at most IT_SPB <= 64 segments: one per lane)
-                itw_stage_x(a.x, a.x_rows, a.ld_x, F, ra, nr, c, s_x);
-                ITW_LDS_SYNC();
-                // ---- Lin1 -> y (own column of the tile) + y_save
-                for (int i = 0; i < nr; ++i) {
-                    float acc = b1;
+                if (sa + c < sb) cnt_l = a.seg_cnt[sa + c];
+                if (nr > 0) {
+                    itw_stage_x(a.x, a.x_rows, a.ld_x, F, ra, nr, c, s_x);
+                    ITW_LDS_SYNC();
+                    // ---- Lin1 -> y (own column of the tile) + y_save, two rows per pass
+                    for (int i = 0; i < nr; i += 2) {
+                        const int i1 = min(i + 1, nr - 1);
+                        float acc0 = b1, acc1 = b1;
 #pragma unroll
-                    for (int f4 = 0; f4 < 4; ++f4) {
-                        const float4 xv = *reinterpret_cast<const float4*>(s_x + i * 16 + 4 * f4);
-                        acc = fmaf(xv.x, w1r[4 * f4], acc); acc = fmaf(xv.y, w1r[4 * f4 + 1], acc);
-                        acc = fmaf(xv.z, w1r[4 * f4 + 2], acc); acc = fmaf(xv.w, w1r[4 * f4 + 3], acc);
+                        for (int f4 = 0; f4 < 4; ++f4) {
+                            const float4 x0 = *reinterpret_cast<const float4*>(s_x + i * 16 + 4 * f4);
+                            const float4 x1 = *reinterpret_cast<const float4*>(s_x + i1 * 16 + 4 * f4);
+                            acc0 = fmaf(x0.x, w1r[4 * f4], acc0); acc0 = fmaf(x0.y, w1r[4 * f4 + 1], acc0);
+                            acc0 = fmaf(x0.z, w1r[4 * f4 + 2], acc0); acc0 = fmaf(x0.w, w1r[4 * f4 + 3], acc0);
+                            acc1 = fmaf(x1.x, w1r[4 * f4], acc1); acc1 = fmaf(x1.y, w1r[4 * f4 + 1], acc1);
+                            acc1 = fmaf(x1.z, w1r[4 * f4 + 2], acc1); acc1 = fmaf(x1.w, w1r[4 * f4 + 3], acc1);
+                        }
+                        col[i * 64] = acc0;
+                        a.y_save[(size_t)(ra + i) * H + c] = acc0;
+                        if (i + 1 < nr) { col[i1 * 64] = acc1; a.y_save[(size_t)(ra + i1) * H + c] = acc1; }
                     }
-                    s_a[i * 64 + c] = acc;
-                    a.y_save[(size_t)(ra + i) * H + c] = acc;
                 }
                 // ---- per segment: batch statistics over ALL its new rows (the zero rows contribute Lin1(0) = b1), then
                 //      normalise + ReLU in place (lane-private column: no synchronisation)
                 for (int s = sa; s < sb; ++s) {
                     const int p0 = s_sp[s - s0] - ra, p1 = s_sp[s + 1 - s0] - ra;
                     const float cnt = (float)__shfl(cnt_l, s - sa, 64), nz = cnt - (float)(p1 - p0);
-                    float sum = nz * b1;
-                    for (int i = p0; i < p1; ++i) sum += s_a[i * 64 + c];
-                    const float m = sum / cnt;
+                    const float m = (nz * b1 + itw_col_sum(col, p0, p1)) / cnt;
                     float sq = nz * (b1 - m) * (b1 - m);
-                    for (int i = p0; i < p1; ++i) { const float d = s_a[i * 64 + c] - m; sq += d * d; }
+                    for (int b = p0; b < p1; b += 8) {
+                        float v[8];
+#pragma unroll
+                        for (int t = 0; t < 8; ++t) v[t] = col[min(b + t, p1 - 1) * 64];
+#pragma unroll
+                        for (int t = 0; t < 8; ++t) { const float d = v[t] - m; sq += (b + t < p1) ? d * d : 0.f; }
+                    }
                     const float r = rsqrtf(sq / cnt + IT_EPS);
                     a.mean[(size_t)s * H + c] = m; a.rstd[(size_t)s * H + c] = r;
-                    for (int i = p0; i < p1; ++i) s_a[i * 64 + c] = fmaxf((s_a[i * 64 + c] - m) * r * gam + bet, 0.f);
+                    for (int b = p0; b < p1; b += 8) {
+                        float v[8];
+#pragma unroll
+                        for (int t = 0; t < 8; ++t) v[t] = col[min(b + t, p1 - 1) * 64];
+#pragma unroll
+                        for (int t = 0; t < 8; ++t)
+                            if (b + t < p1) col[(b + t) * 64] = fmaxf((v[t] - m) * r * gam + bet, 0.f);
+                    }
                 }
                 ITW_LDS_SYNC();
-                // ---- Lin2: out[i][c] = b2[c] + sum_k a[i][k] W2[c][k]; two rows per pass (independent chains)
+                // ---- Lin2: out[i][c] = b2[c] + sum_k a[i][k] W2[c][k]; two rows per pass (independent chains; four rows made
+                //      hipcc hoist 64 operand reads and spill)
                 for (int i = 0; i < nr; i += 2) {
                     const int i1 = min(i + 1, nr - 1);
                     float acc0 = b2, acc1 = b2;
@@ -552,6 +601,8 @@ __global__ __launch_bounds__(ITW_NW * 64) void k_itw_bwd(ItBwdArgs a) {
     float* s_yh = it_lds + wave * ITW_BWD_WAVE_FLOATS;      // [ITW_R][64] yhat (lane-private columns)
     float* s_d = s_yh + ITW_R * 64;                         // [ITW_R][64] d_out rows (broadcast reads), then d_yhat, then dy
     float* s_x = s_d + ITW_R * 64;                          // [ITW_R][16]
+    float* cyh = s_yh + c;
+    float* cd = s_d + c;
     const int F = a.F;
     float w2c[64];                                          // column c of W2: w2c[j] = W2[j][c]
 #pragma unroll
@@ -579,18 +630,43 @@ __global__ __launch_bounds__(ITW_NW * 64) void k_itw_bwd(ItBwdArgs a) {
                 int orow_l = 0, cnt_l = 1;
                 if (c < nr) orow_l = a.out_row[ra + c];
                 if (sa + c < sb) cnt_l = a.seg_cnt[sa + c];
-                itw_stage_x(a.x, a.x_rows, a.ld_x, F, ra, nr, c, s_x);
-                // ---- d_out rows (gathered) -> s_d ; yhat (recomputed from y_save and the segment's statistics) -> s_yh
-                for (int s = sa; s < sb; ++s) {
-                    const int p0 = s_sp[s - s0] - ra, p1 = s_sp[s + 1 - s0] - ra;
-                    const float m = a.mean[(size_t)s * H + c], r = a.rstd[(size_t)s * H + c];
-                    for (int i = p0; i < p1; ++i) {
+                // the statistics of the tile's (<= ITW_MS) segments: requested together, kept for both uses below
+                float mseg[ITW_MS], rseg[ITW_MS];
+#pragma unroll
+                for (int t = 0; t < ITW_MS; ++t) {
+                    const int s = min(sa + t, sb - 1);
+                    mseg[t] = a.mean[(size_t)s * H + c];
+                    rseg[t] = a.rstd[(size_t)s * H + c];
+                }
+                if (nr > 0) itw_stage_x(a.x, a.x_rows, a.ld_x, F, ra, nr, c, s_x);
+                // ---- d_out rows (gathered) -> s_d, y -> s_yh: eight rows' loads in flight per pass
+                for (int b = 0; b < nr; b += 8) {
+                    float dv[8], yv[8];
+#pragma unroll
+                    for (int t = 0; t < 8; ++t) {
+                        const int i = min(b + t, nr - 1);
                         const int orow = __shfl(orow_l, i, 64);
-                        const float d = a.d_h[(size_t)orow * a.ld_dh + c];
-                        const float yv = a.y_save[(size_t)(ra + i) * H + c];
-                        s_d[i * 64 + c] = d;
-                        s_yh[i * 64 + c] = (yv - m) * r;
-                        v_db2 += d;
+                        dv[t] = a.d_h[(size_t)orow * a.ld_dh + c];
+                        yv[t] = a.y_save[(size_t)(ra + i) * H + c];
+                    }
+#pragma unroll
+                    for (int t = 0; t < 8; ++t) {
+                        if (b + t < nr) { cd[(b + t) * 64] = dv[t]; cyh[(b + t) * 64] = yv[t]; v_db2 += dv[t]; }
+                    }
+                }
+                // ---- yhat = (y - mean) rstd of the row's segment, in place
+#pragma unroll
+                for (int t = 0; t < ITW_MS; ++t) {
+                    if (sa + t < sb) {
+                        const int p0 = s_sp[sa + t - s0] - ra, p1 = s_sp[sa + t + 1 - s0] - ra;
+                        for (int b = p0; b < p1; b += 8) {
+                            float v[8];
+#pragma unroll
+                            for (int u = 0; u < 8; ++u) v[u] = cyh[min(b + u, p1 - 1) * 64];
+#pragma unroll
+                            for (int u = 0; u < 8; ++u)
+                                if (b + u < p1) cyh[(b + u) * 64] = (v[u] - mseg[t]) * rseg[t];
+                        }
                     }
                 }
                 ITW_LDS_SYNC();
@@ -598,7 +674,7 @@ __global__ __launch_bounds__(ITW_NW * 64) void k_itw_bwd(ItBwdArgs a) {
                 //      then the ReLU mask, dgamma / dbeta and d_yhat (into the lane's own column of s_d: row i of s_d has been
                 //      read by every lane of the wave when its iteration ends)
                 for (int i = 0; i < nr; ++i) {
-                    const float yh = s_yh[i * 64 + c];
+                    const float yh = cyh[i * 64];
                     const float av = fmaxf(yh * gam + bet, 0.f);
                     float da0 = 0.f, da1 = 0.f;
 #pragma unroll
@@ -613,34 +689,56 @@ __global__ __launch_bounds__(ITW_NW * 64) void k_itw_bwd(ItBwdArgs a) {
                     v_dg = fmaf(dz, yh, v_dg);
                     v_dbt += dz;
                     ITW_LDS_SYNC();                                  // (every lane's reads of row i are back)
-                    s_d[i * 64 + c] = dz * gam;
+                    cd[i * 64] = dz * gam;
                 }
                 // ---- BatchNorm backward per segment: dy = rstd (d_yhat - q1 / n - yhat q2 / n) on the det rows; each of the
                 //      segment's zero rows (yhat0 = (b1 - mean) rstd, d_yhat0 = 0) receives dy0 = rstd (- q1 / n - yhat0 q2 / n)
-                for (int s = sa; s < sb; ++s) {
-                    const int p0 = s_sp[s - s0] - ra, p1 = s_sp[s + 1 - s0] - ra;
-                    const float cnt = (float)__shfl(cnt_l, s - sa, 64), nz = cnt - (float)(p1 - p0);
-                    const float m = a.mean[(size_t)s * H + c], r = a.rstd[(size_t)s * H + c];
-                    float q1 = 0.f, q2 = 0.f;
-                    for (int i = p0; i < p1; ++i) { const float g = s_d[i * 64 + c]; q1 += g; q2 = fmaf(g, s_yh[i * 64 + c], q2); }
-                    const float inv = 1.0f / cnt;
-                    for (int i = p0; i < p1; ++i) {
-                        const float dy = r * (s_d[i * 64 + c] - q1 * inv - s_yh[i * 64 + c] * q2 * inv);
-                        s_d[i * 64 + c] = dy;
-                        v_db1 += dy;
+#pragma unroll
+                for (int t = 0; t < ITW_MS; ++t) {
+                    if (sa + t < sb) {
+                        const int p0 = s_sp[sa + t - s0] - ra, p1 = s_sp[sa + t + 1 - s0] - ra;
+                        const float cnt = (float)__shfl(cnt_l, t, 64), nz = cnt - (float)(p1 - p0);
+                        const float m = mseg[t], r = rseg[t];
+                        float q1 = 0.f, q2 = 0.f;
+                        for (int b = p0; b < p1; b += 8) {
+                            float g[8], y[8];
+#pragma unroll
+                            for (int u = 0; u < 8; ++u) { const int i = min(b + u, p1 - 1); g[u] = cd[i * 64]; y[u] = cyh[i * 64]; }
+#pragma unroll
+                            for (int u = 0; u < 8; ++u)
+                                if (b + u < p1) { q1 += g[u]; q2 = fmaf(g[u], y[u], q2); }
+                        }
+                        const float inv = 1.0f / cnt;
+                        for (int b = p0; b < p1; b += 8) {
+                            float g[8], y[8];
+#pragma unroll
+                            for (int u = 0; u < 8; ++u) { const int i = min(b + u, p1 - 1); g[u] = cd[i * 64]; y[u] = cyh[i * 64]; }
+#pragma unroll
+                            for (int u = 0; u < 8; ++u) {
+                                if (b + u < p1) {
+                                    const float dy = r * (g[u] - q1 * inv - y[u] * q2 * inv);
+                                    cd[(b + u) * 64] = dy;
+                                    v_db1 += dy;
+                                }
+                            }
+                        }
+                        const float yh0 = (b1 - m) * r;
+                        const float dy0 = r * (-q1 * inv - yh0 * q2 * inv);
+                        v_db1 = fmaf(nz, dy0, v_db1);
                     }
-                    const float yh0 = (b1 - m) * r;
-                    const float dy0 = r * (-q1 * inv - yh0 * q2 * inv);
-                    v_db1 = fmaf(nz, dy0, v_db1);
                 }
-                // ---- dW1[c][f] += sum_i dy[i][c] x[i][f]   (columns >= F of s_x hold zeros)
-                for (int i = 0; i < nr; ++i) {
-                    const float dy = s_d[i * 64 + c];
+                // ---- dW1[c][f] += sum_i dy[i][c] x[i][f]   (columns >= F of s_x hold zeros), two rows per pass
+                for (int i = 0; i < nr; i += 2) {
+                    const int i1 = min(i + 1, nr - 1);
+                    const float dy0 = cd[i * 64], dy1 = (i + 1 < nr) ? cd[i1 * 64] : 0.f;
 #pragma unroll
                     for (int f4 = 0; f4 < 4; ++f4) {
-                        const float4 xv = *reinterpret_cast<const float4*>(s_x + i * 16 + 4 * f4);
-                        acc_w1[4 * f4] = fmaf(dy, xv.x, acc_w1[4 * f4]); acc_w1[4 * f4 + 1] = fmaf(dy, xv.y, acc_w1[4 * f4 + 1]);
-                        acc_w1[4 * f4 + 2] = fmaf(dy, xv.z, acc_w1[4 * f4 + 2]); acc_w1[4 * f4 + 3] = fmaf(dy, xv.w, acc_w1[4 * f4 + 3]);
+                        const float4 x0 = *reinterpret_cast<const float4*>(s_x + i * 16 + 4 * f4);
+                        const float4 x1 = *reinterpret_cast<const float4*>(s_x + i1 * 16 + 4 * f4);
+                        acc_w1[4 * f4] = fmaf(dy0, x0.x, acc_w1[4 * f4]); acc_w1[4 * f4 + 1] = fmaf(dy0, x0.y, acc_w1[4 * f4 + 1]);
+                        acc_w1[4 * f4 + 2] = fmaf(dy0, x0.z, acc_w1[4 * f4 + 2]); acc_w1[4 * f4 + 3] = fmaf(dy0, x0.w, acc_w1[4 * f4 + 3]);
+                        acc_w1[4 * f4] = fmaf(dy1, x1.x, acc_w1[4 * f4]); acc_w1[4 * f4 + 1] = fmaf(dy1, x1.y, acc_w1[4 * f4 + 1]);
+                        acc_w1[4 * f4 + 2] = fmaf(dy1, x1.z, acc_w1[4 * f4 + 2]); acc_w1[4 * f4 + 3] = fmaf(dy1, x1.w, acc_w1[4 * f4 + 3]);
                     }
                 }
                 ITW_LDS_SYNC();
