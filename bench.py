@@ -153,13 +153,6 @@ def stage_profile(model, plan, H):
                   g.dst.data_ptr(), dmsg.data_ptr(), H, gW[0].data_ptr(), gW[1].data_ptr(), gW[2].data_ptr(),
                   gW[3].data_ptr(), fws.data_ptr(), fwsb, st)
 
-    def gru_bwd_w_variant(v):
-        def run():
-            _lib.call('tmpnn_gru_bwd_weights_variant', g.edge_row.data_ptr(), E, 1, g.src.data_ptr(), g.dst.data_ptr(),
-                      None, 0, 0, H, h.data_ptr(), H, H, gates.data_ptr(), N * H, dout.data_ptr(), H, None, None,
-                      gW[0].data_ptr(), gW[1].data_ptr(), gW[2].data_ptr(), gW[3].data_ptr(), ws.data_ptr(), wsb, v, st)
-        return run
-
     def gather():
         _lib.call('tmpnn_gather_diff_fwd', g.cref(), h.data_ptr(), H, out.data_ptr(), H, H, 0, st)
 
@@ -170,14 +163,11 @@ def stage_profile(model, plan, H):
     t = {name: time_stage(fn) for name, fn in (('gru_fwd_edge', gru_fwd), ('gru_bwd_data_edge', gru_bwd_data),
                                                ('gru_bwd_data_edge_folded', gru_bwd_data_folded),
                                                ('gru_bwd_weights_edge', gru_bwd_w),
-                                               ('gru_bwd_weights_edge_f32mfma', gru_bwd_w_variant(0)),
-                                               ('gru_bwd_weights_edge_bf16x6', gru_bwd_w_variant(1)),
                                                ('gather_diff', gather),
                                                ('segsum', segsum)) + ((('gru_bwd_one_edge', gru_bwd_one),) if fwsb else ())}
     flops = {'gru_fwd_edge': 12.0 * H * H * E, 'gru_bwd_data_edge': 12.0 * H * H * E,
              'gru_bwd_data_edge_folded': 12.0 * H * H * E,
-             'gru_bwd_weights_edge': 12.0 * H * H * E, 'gru_bwd_weights_edge_f32mfma': 12.0 * H * H * E,
-             'gru_bwd_weights_edge_bf16x6': 12.0 * H * H * E, 'gru_bwd_one_edge': 24.0 * H * H * E}
+             'gru_bwd_weights_edge': 12.0 * H * H * E, 'gru_bwd_one_edge': 24.0 * H * H * E}
     # SURVEY 8(d) algorithmic bytes per launch (every array counted once; det-row gathers count the det table once)
     b_gather = 4.0 * H * E + 4.0 * H * Dn + 8.0 * E
     b_segsum = 4.0 * H * E + 4.0 * H * Dn + 4.0 * (2 * E + Dn + 1) + 2.0 * E
@@ -192,7 +182,6 @@ def stage_profile(model, plan, H):
               'gru_bwd_weights_edge': (24.0 * H + 12.0) * E + 4.0 * H * Dn}
     # one pass: dh 4H + gates 16H + h 4H in, d_msg 4H + d_h 4H out, dy and three ids; h and d_es det tables once
     nbytes['gru_bwd_one_edge'] = (32.0 * H + 16.0) * E + 8.0 * H * Dn
-    nbytes['gru_bwd_weights_edge_f32mfma'] = nbytes['gru_bwd_weights_edge_bf16x6'] = nbytes['gru_bwd_weights_edge']
     return t, flops, nbytes
 
 
@@ -904,8 +893,6 @@ def main():
                                                          nbytes['gru_bwd_data_edge_folded'] + nbytes['gru_bwd_weights_edge'])
                                + 2 * nbytes['segsum']) / gE, 1),
             survey_aggregation_model=16 * H + 36)
-        from trackmpnn_amd import _lib as _l
-        extra['weights_kernel'] = {1: 'bf16x6', 0: 'f32-mfma'}[_l.load().tmpnn_gru_bwd_weights_choice()]
         extra['backward'] = 'one-pass (tmpnn_gru_bwd_fused)' if one_pass else 'data + weights kernels'
         if one_pass:
             two = t['gru_bwd_data_edge_folded'] + t['gru_bwd_weights_edge']

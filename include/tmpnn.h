@@ -35,7 +35,9 @@
 extern "C" {
 #endif
 
-#define TMPNN_ABI_VERSION 3 /* 2: struct tmpnn_graph gained seg_plan (round 4); 3: win_plan (round 5) */
+#define TMPNN_ABI_VERSION 4 /* 2: struct tmpnn_graph gained seg_plan (round 4); 3: win_plan (round 5); 4 (round 6, frozen): the
+                               exported set is what a default run can reach (80 entry points: 15 superseded or internal ones
+                               left it), tmpnn_input_tf_* take x_rows, + tmpnn_segsum_fwd_live, tmpnn_bce_logits_* */
 
 #define TMPNN_OK 0
 #define TMPNN_EINVAL (-1)   /* bad shape / null pointer / unsupported width */
@@ -262,7 +264,6 @@ int tmpnn_gru_bwd_data(const int32_t* rows, int R, int IN, const float* h, int l
  * loaded): nothing is measured or decided inside a call, so every run and every rank takes the same kernel and
  * gradients are bitwise reproducible across processes.  tmpnn_gru_bwd_weights_variant takes the form explicitly
  * (variant 0 / 1; -1 = the process default) -- used by bench.py to time both forms. */
-int tmpnn_gru_bwd_weights_choice(void);
 size_t tmpnn_gru_bwd_weights_ws(int R, int IN, int H);
 int tmpnn_gru_bwd_weights(const int32_t* rows, int R, int xmode, const int32_t* src, const int32_t* dst,
                           const float* msg, int ld_msg, int msg_compact, int IN,
@@ -271,13 +272,6 @@ int tmpnn_gru_bwd_weights(const int32_t* rows, int R, int xmode, const int32_t* 
                           const float* dy, const float* w_head,
                           float* dW_ih, float* dW_hh, float* db_ih, float* db_hh,
                           void* ws, size_t ws_bytes, tmpnn_stream stream);
-int tmpnn_gru_bwd_weights_variant(const int32_t* rows, int R, int xmode, const int32_t* src, const int32_t* dst,
-                                  const float* msg, int ld_msg, int msg_compact, int IN,
-                                  const float* h, int ld_h, int H,
-                                  const float* gates, size_t gate_plane, const float* d_hout, int ld_dhout,
-                                  const float* dy, const float* w_head,
-                                  float* dW_ih, float* dW_hh, float* db_ih, float* db_hh,
-                                  void* ws, size_t ws_bytes, int variant, tmpnn_stream stream);
 
 /* Fused backward of one cell: tmpnn_gru_bwd_data + tmpnn_gru_bwd_weights in ONE pass over the gates
  * (arguments as in those two; available when tmpnn_gru_bwd_fused_available(H, IN, xmode) != 0, i.e. H = 64,
@@ -503,15 +497,12 @@ int tmpnn_graph_from_coo_arena(int N, const int64_t* node_idx, const float* node
 /* The same conversion for graphs of up to TMPNN_DG_BIG_ROWS rows (dense scenes): above TMPNN_DG_MAX_ROWS the work
  * arrays do not fit the LDS and live in `ws` (tmpnn_graph_from_coo_ws_ints(N) ints, 0 for small N: then this is
  * tmpnn_graph_from_coo_arena). */
-size_t tmpnn_graph_from_coo_ws_ints(int N);
 int tmpnn_graph_from_coo_arena_ws(int N, const int64_t* node_idx, const float* node_val, int64_t nnz_node,
                                   const int64_t* edge_idx, const float* edge_val, int64_t nnz_edge, void* arena, int cap,
                                   void* ws, size_t ws_ints, tmpnn_stream stream);
 
 /* The same index form from the ROW form of a graph (type mask + the two endpoint rows of every edge row): what the
  * tracker-side operations below edit.  Same validation, same status bits. */
-int tmpnn_graph_from_rows(int N, const uint8_t* is_edge, const int32_t* row_src, const int32_t* row_dst,
-                          const tmpnn_dgraph* g, tmpnn_stream stream);
 /* ... for graphs of up to TMPNN_DG_BIG_ROWS rows (`ws`: tmpnn_graph_from_coo_ws_ints(N) ints, as for tmpnn_graph_from_coo_arena_ws). */
 int tmpnn_graph_from_rows_ws(int N, const uint8_t* is_edge, const int32_t* row_src, const int32_t* row_dst,
                              const tmpnn_dgraph* g, void* ws, size_t ws_ints, tmpnn_stream stream);
@@ -595,29 +586,15 @@ int tmpnn_mp_iter_bwd_parts(const tmpnn_mp_params* P, const float* prep, const t
  * positives point at themselves; status bit 0 is set if a det has more than one positive future edge.
  * mode 1 (inference, greedy: :251-268 and :437-454): best-scoring future edge (>= 0.5, to a det >= 0.5) of the nearest
  * timestep. */
-int tmpnn_track_associate(const tmpnn_dgraph* g, const int32_t* det_id, const uint8_t* labels, const float* score,
-                          int mode, int32_t* assoc, int32_t* status, tmpnn_stream stream);
 /* Active set at time t (utils/graph.py:270-278): rows in ascending order into active[], their number into count[0]. */
-int tmpnn_track_active(int N, const int32_t* ts, const int32_t* assoc, const float* score, int mode, int t,
-                       int32_t* active, int32_t* count, tmpnn_stream stream);
 /* Append the block of timestep t behind row N (utils/graph.py:283-325): A x D edge rows (src-major) then D det rows
  * with ids new_ids[D]; labels from track[det id] (int32 [ND] track of every detection, -1 = false positive; NULL at
  * inference).  The row arrays must have room for N + A*D + D entries. */
-int tmpnn_track_append(int N, int A, int D, const int32_t* active, const int32_t* new_ids, int t, const int32_t* track,
-                       int32_t* ts, int32_t* det_id, int32_t* assoc, uint8_t* is_edge, int32_t* row_src,
-                       int32_t* row_dst, uint8_t* labels, tmpnn_stream stream);
 /* The rows decode_tracks deletes (utils/graph.py:492-512) as a stream compaction: keep[] = kept rows (ascending),
  * count[0] = their number, count[2] = how many of them are det rows (count: >= 3 ints), o_* = the compacted row form with
  * renumbered endpoints. */
-int tmpnn_track_delete(int N, const int32_t* ts, const int32_t* det_id, const int32_t* assoc, const float* score,
-                       const uint8_t* is_edge, const int32_t* row_src, const int32_t* row_dst, const uint8_t* labels,
-                       int t_upto, int ret_win, int32_t* keep, int32_t* count, int32_t* o_ts, int32_t* o_det_id,
-                       int32_t* o_assoc, uint8_t* o_is_edge, int32_t* o_src, int32_t* o_dst, uint8_t* o_labels,
-                       tmpnn_stream stream);
 /* out[q][0:W] = in[keep[q]][0:W] for q < count[0] (count read on the device; the launch covers max_rows): the hidden
  * state and the scores follow the deletion without leaving HBM (utils/graph.py:514,519). */
-int tmpnn_track_gather(const float* in, int ld_in, int W, int max_rows, const int32_t* keep, const int32_t* count,
-                       float* out, int ld_out, tmpnn_stream stream);
 /* decode_tracks' track finalisation (utils/graph.py:456-490) on the device: y_track [ND] = y_out[:, 1] of the sequence
  * (int32, -1 = no track yet; it stays in device memory between calls), updated for the window's dets from the
  * association links assoc[] (det ids, the output of tmpnn_track_associate or of the Hungarian matching), the scores and
@@ -625,9 +602,6 @@ int tmpnn_track_gather(const float* in, int ld_in, int W, int max_rows, const in
  * the graph's dets; entries of dets outside the graph are never read).  ws: tmpnn_track_finalize_ws(N) bytes, only
  * needed when the graph may hold more than 4096 dets (0 otherwise). */
 size_t tmpnn_track_finalize_ws(int max_dets);
-int tmpnn_track_finalize(const tmpnn_dgraph* g, const int32_t* ts, const int32_t* det_id, const int32_t* assoc,
-                         const float* score, int t_upto, int32_t* y_track, int ND, int32_t* pos_of_det, void* ws,
-                         size_t ws_bytes, tmpnn_stream stream);
 
 /* One call per phase of a timestep, as the reference's loops call update_graph / decode_tracks (train.py:102-104,
  * infer.py:70-87): the kernels above enqueued back to back.  At batch 1 a timestep is bound by the number of calls and
@@ -702,19 +676,10 @@ int tmpnn_wide_gru_fwd_tiled(const void* prep, const int32_t* det_rows, int Dn, 
                              float* h_out, int ld_out, float* gates, size_t gate_plane, tmpnn_stream stream);
 /* Data gradient (as tmpnn_gru_bwd_data with IN = H, no fused adjoint): d_msg[rows[r]][0:H] = d_gi W_ih,
  * d_h[rows[r]] = dh z + d_gh W_hh.  ws: tmpnn_wide_gru_bwd_data_ws(R, H) bytes (the materialised d_gi, d_gh). */
-size_t tmpnn_wide_gru_bwd_data_ws(int R, int H);
-int tmpnn_wide_gru_bwd_data(const void* prep, const int32_t* rows, int R, const float* h, int ld_h, int H,
-                            const float* gates, size_t gate_plane, const float* d_hout, int ld_dhout, const float* dy,
-                            const float* w_head, float* d_msg, int ld_dmsg, float* d_h, int ld_dh, void* ws,
-                            size_t ws_bytes, tmpnn_stream stream);
 
 /* Weight gradient of the same cell from the gate gradients tmpnn_wide_gru_bwd_data left in ITS workspace (`dg_ws`, read
  * only): dW_ih += d_gi^T (h[src] - h[dst]), dW_hh += d_gh^T h[rows], db_ih / db_hh += column sums (replaces
  * tmpnn_gru_bwd_weights for the wide cells: layers.py:84-116 backward).  ws: tmpnn_wide_gru_bwd_weights_ws(R, H) bytes. */
-size_t tmpnn_wide_gru_bwd_weights_ws(int R, int H);
-int tmpnn_wide_gru_bwd_weights(const void* dg_ws, const int32_t* rows, int R, const int32_t* src, const int32_t* dst,
-                               const float* h, int ld_h, int H, float* dW_ih, float* dW_hh, float* db_ih, float* db_hh,
-                               void* ws, size_t ws_bytes, tmpnn_stream stream);
 
 /* The whole backward of a wide EDGE cell under the diff message x[e] = h[src e] - h[dst e] (models/layers.py:90-95, 107),
  * with both W_ih products taken on the det side by linearity -- the backward twin of the forward's projected det rows:
@@ -736,11 +701,6 @@ int tmpnn_wide_gru_bwd_diff(const void* prep, const tmpnn_graph* g, const float*
  * aux_stream must differ from stream; do not use while `stream` is being captured into a graph.  ev_fork / ev_join: two
  * events of the caller (hipEventDisableTiming is enough) that the call records and waits on -- the library creates, destroys
  * and synchronises nothing; on return (also with an error code) `stream` waits for everything enqueued on aux_stream. */
-int tmpnn_wide_gru_bwd_diff_aux(const void* prep, const tmpnn_graph* g, const float* h, int ld_h, int H, const float* gates,
-                            size_t gate_plane, const float* d_hout, int ld_dhout, const float* dy, const float* w_head,
-                            float* d_h, int ld_dh, float* dW_ih, float* dW_hh, float* db_ih, float* db_hh, void* ws,
-                            size_t ws_bytes, tmpnn_stream stream,
-                                tmpnn_stream aux_stream, tmpnn_event ev_fork, tmpnn_event ev_join);
 /* ... and with the adjoint of row F (models/layers.py:103: d_h[e] += add_msg[src[e]] - add_msg[dst[e]], what
  * tmpnn_gather_diff_fwd(g, add_msg, ld_add, d_h, ld_dh, H, accumulate = 1) would add afterwards) taken in the epilogue of the
  * E-row product: one read-modify-write pass over d_h's edge rows less.  add_msg: the table whose det rows hold d_es (>= H
@@ -750,6 +710,38 @@ int tmpnn_wide_gru_bwd_diff_fused(const void* prep, const tmpnn_graph* g, const 
                                   float* d_h, int ld_dh, float* dW_ih, float* dW_hh, float* db_ih, float* db_hh, void* ws,
                                   size_t ws_bytes, const float* add_msg, int ld_add, tmpnn_stream stream,
                                   tmpnn_stream aux_stream, tmpnn_event ev_fork, tmpnn_event ev_join);
+
+/* ---- comparison builds only (-DTMPNN_KEEP_VARIANTS; tools/build_variant.sh) ------------------------------------------------
+ * Superseded forms kept for A/B runs: the two-kernel backward of the wide cells (the shipped path takes both W_ih products on
+ * the det side, tmpnn_wide_gru_bwd_diff*), its two-stream form, the explicit choice of the H = 64 weight-gradient kernel, the
+ * block append without features.  The shipped libtmpnn.so does NOT export them. */
+#ifdef TMPNN_KEEP_VARIANTS
+int tmpnn_track_append(int N, int A, int D, const int32_t* active, const int32_t* new_ids, int t, const int32_t* track,
+                       int32_t* ts, int32_t* det_id, int32_t* assoc, uint8_t* is_edge, int32_t* row_src,
+                       int32_t* row_dst, uint8_t* labels, tmpnn_stream stream);
+int tmpnn_gru_bwd_weights_variant(const int32_t* rows, int R, int xmode, const int32_t* src, const int32_t* dst,
+                                  const float* msg, int ld_msg, int msg_compact, int IN,
+                                  const float* h, int ld_h, int H,
+                                  const float* gates, size_t gate_plane, const float* d_hout, int ld_dhout,
+                                  const float* dy, const float* w_head,
+                                  float* dW_ih, float* dW_hh, float* db_ih, float* db_hh,
+                                  void* ws, size_t ws_bytes, int variant, tmpnn_stream stream);
+int tmpnn_gru_bwd_weights_choice(void);
+int tmpnn_wide_gru_bwd_diff_aux(const void* prep, const tmpnn_graph* g, const float* h, int ld_h, int H, const float* gates,
+                            size_t gate_plane, const float* d_hout, int ld_dhout, const float* dy, const float* w_head,
+                            float* d_h, int ld_dh, float* dW_ih, float* dW_hh, float* db_ih, float* db_hh, void* ws,
+                            size_t ws_bytes, tmpnn_stream stream,
+                                tmpnn_stream aux_stream, tmpnn_event ev_fork, tmpnn_event ev_join);
+size_t tmpnn_wide_gru_bwd_data_ws(int R, int H);
+int tmpnn_wide_gru_bwd_data(const void* prep, const int32_t* rows, int R, const float* h, int ld_h, int H,
+                            const float* gates, size_t gate_plane, const float* d_hout, int ld_dhout, const float* dy,
+                            const float* w_head, float* d_msg, int ld_dmsg, float* d_h, int ld_dh, void* ws,
+                            size_t ws_bytes, tmpnn_stream stream);
+size_t tmpnn_wide_gru_bwd_weights_ws(int R, int H);
+int tmpnn_wide_gru_bwd_weights(const void* dg_ws, const int32_t* rows, int R, const int32_t* src, const int32_t* dst,
+                               const float* h, int ld_h, int H, float* dW_ih, float* dW_hh, float* db_ih, float* db_hh,
+                               void* ws, size_t ws_bytes, tmpnn_stream stream);
+#endif
 
 #ifdef __cplusplus
 }

@@ -590,7 +590,11 @@ def check_wide(H, g, gd):
     for e in evs:
         e.record()
     evf, evj = evs[0].cuda_event, evs[1].cuda_event
-    for tag, use_aux, fused in (('aux stream', True, False), ('fused adjoint', False, True), ('fused adjoint + aux', True, True)):
+    has_variants = hasattr(lib, 'tmpnn_wide_gru_bwd_data')      # (a -DTMPNN_KEEP_VARIANTS build: the superseded forms too)
+    forms = (('fused adjoint', False, True), ('fused adjoint + aux', True, True))
+    if has_variants:
+        forms = (('aux stream', True, False),) + forms
+    for tag, use_aux, fused in forms:
         dh2, gr2 = fresh()
         args = (prep.data_ptr(), gd.cref(), hD.data_ptr() + 4 * H, ld, H, gates.data_ptr(), g.N * H,
                 doutD.data_ptr() + 4 * H, ld, None, None, dh2.data_ptr() + 4 * H, ld, gr2[0].data_ptr(), gr2[1].data_ptr(),
@@ -604,7 +608,9 @@ def check_wide(H, g, gd):
         torch.cuda.synchronize()
         same = torch.equal(dh2, dh) and all(torch.equal(a, b) for a, b in zip(gr2, gr))
         res[f'det-side, {tag}: bits'] = 0.0 if same else 1.0
-    # per-edge form
+    # per-edge form (comparison builds only: the shipped library takes both W_ih products on the det side)
+    if not has_variants:
+        return res
     dh, gr = fresh()
     wsb = int(lib.tmpnn_wide_gru_bwd_data_ws(R, H))
     ws = torch.empty(wsb // 4 + 1, device=DEV)

@@ -24,6 +24,26 @@ def test_header_symbols_exported(lib):
 
 def test_bindings_cover_header(lib):
     assert sorted(_lib._SIGNATURES) == _lib.header_symbols()
+    # the comparison-build section of the header (#ifdef TMPNN_KEEP_VARIANTS) and its optional bindings agree too
+    assert sorted(_lib._VARIANT_SIGNATURES) == sorted(set(_lib.header_symbols(variants=True)) - set(_lib.header_symbols()))
+
+
+def test_shipped_library_exports_exactly_the_header(lib):
+    """The boundary is frozen at ABI v4: libtmpnn.so exports the entry points include/tmpnn.h declares for the shipped
+    library and nothing else (superseded forms live behind -DTMPNN_KEEP_VARIANTS; helpers other entry points call are
+    hidden), and the count INTEGRATION.md / DESIGN.md quote is that number."""
+    import re
+    import subprocess
+    if os.environ.get('TMPNN_LIB_PATH'):
+        pytest.skip('a comparison build is loaded')
+    out = subprocess.run(['nm', '-D', '--defined-only', _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = sorted(m.group(1) for m in re.finditer(r' T (tmpnn_[a-z0-9_]+)$', out, flags=re.M))
+    names = _lib.header_symbols()
+    assert exported == names
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for doc in ('INTEGRATION.md', 'DESIGN.md'):
+        txt = open(os.path.join(root, doc)).read()
+        assert f'{len(names)} entry points' in txt, f'{doc} does not quote the current count ({len(names)} entry points)'
 
 
 def test_abi_version_and_error_string(lib):

@@ -17,7 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('TMPNN_LIB_PATH') or os.path.join(_HERE, 'lib', 'libtmpnn.so')
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), 'include', 'tmpnn.h')
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 c_int = C.c_int
 c_void_p = C.c_void_p
@@ -123,9 +123,6 @@ _SIGNATURES = {
     'tmpnn_gru_bwd_weights': (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                                       c_void_p, c_int, c_int, c_void_p, c_size_t, c_void_p, c_int, c_void_p, c_void_p,
                                       c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
-    'tmpnn_gru_bwd_weights_variant': (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
-                                              c_void_p, c_int, c_int, c_void_p, c_size_t, c_void_p, c_int, c_void_p, c_void_p,
-                                              c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
     'tmpnn_gru_bwd_fused_available': (c_int, [c_int, c_int, c_int]),
     'tmpnn_gru_bwd_fused_ws': (c_size_t, [c_int, c_int, c_int]),
     'tmpnn_gru_bwd_fused': (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
@@ -133,7 +130,6 @@ _SIGNATURES = {
                                     c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int,
                                     c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                     c_void_p, c_size_t, c_void_p]),
-    'tmpnn_gru_bwd_weights_choice': (c_int, []),
     'tmpnn_rows_linear': (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p]),
     'tmpnn_transpose': (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
     'tmpnn_input_bn_fwd': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
@@ -185,22 +181,10 @@ _SIGNATURES = {
     'tmpnn_dgraph_bind': (c_int, [c_void_p, c_int, c_int, _DGP]),
     'tmpnn_graph_from_coo': (c_int, [c_int, c_void_p, c_void_p, C.c_int64, c_void_p, c_void_p, C.c_int64, _DGP, c_void_p]),
     'tmpnn_graph_from_coo_arena': (c_int, [c_int, c_void_p, c_void_p, C.c_int64, c_void_p, c_void_p, C.c_int64, c_void_p, c_int, c_void_p]),
-    'tmpnn_graph_from_coo_ws_ints': (c_size_t, [c_int]),
     'tmpnn_graph_from_coo_arena_ws': (c_int, [c_int, c_void_p, c_void_p, C.c_int64, c_void_p, c_void_p, C.c_int64, c_void_p, c_int,
                                               c_void_p, c_size_t, c_void_p]),
-    'tmpnn_graph_from_rows': (c_int, [c_int, c_void_p, c_void_p, c_void_p, _DGP, c_void_p]),
     'tmpnn_graph_from_rows_ws': (c_int, [c_int, c_void_p, c_void_p, c_void_p, _DGP, c_void_p, c_size_t, c_void_p]),
-    'tmpnn_track_associate': (c_int, [_DGP, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
-    'tmpnn_track_active': (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
-    'tmpnn_track_append': (c_int, [c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
-                                   c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
-    'tmpnn_track_delete': (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-                                   c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-                                   c_void_p, c_void_p, c_void_p]),
-    'tmpnn_track_gather': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     'tmpnn_track_finalize_ws': (c_size_t, [c_int]),
-    'tmpnn_track_finalize': (c_int, [_DGP, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p,
-                                     c_size_t, c_void_p]),
     'tmpnn_track_load': (c_int, [c_int, c_int, c_void_p, _TRP, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, _DGP, c_void_p,
                                  c_size_t, c_void_p]),
     'tmpnn_track_select': (c_int, [_DGP, _TRP, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
@@ -218,19 +202,10 @@ _SIGNATURES = {
                                    c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
     'tmpnn_wide_gru_fwd_tiled': (c_int, [c_void_p, c_void_p, c_int, _TP, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p,
                                          c_void_p, c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
-    'tmpnn_wide_gru_bwd_data_ws': (c_size_t, [c_int, c_int]),
-    'tmpnn_wide_gru_bwd_data': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_size_t, c_void_p, c_int,
-                                        c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
-    'tmpnn_wide_gru_bwd_weights_ws': (c_size_t, [c_int, c_int]),
-    'tmpnn_wide_gru_bwd_weights': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p,
-                                           c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     'tmpnn_wide_gru_bwd_diff_ws': (c_size_t, [c_int, c_int, c_int, c_int]),
     'tmpnn_wide_gru_bwd_diff': (c_int, [c_void_p, _GP, c_void_p, c_int, c_int, c_void_p, c_size_t, c_void_p, c_int,
                                         c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                         c_void_p, c_size_t, c_void_p]),
-    'tmpnn_wide_gru_bwd_diff_aux': (c_int, [c_void_p, _GP, c_void_p, c_int, c_int, c_void_p, c_size_t, c_void_p, c_int,
-                                            c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
-                                            c_void_p, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p]),
     'tmpnn_wide_gru_bwd_diff_fused': (c_int, [c_void_p, _GP, c_void_p, c_int, c_int, c_void_p, c_size_t, c_void_p, c_int,
                                               c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                               c_void_p, c_size_t, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
@@ -254,10 +229,34 @@ _SIGNATURES = {
 _lib: Optional[C.CDLL] = None
 
 
-def header_symbols() -> List[str]:
-    """Every function name include/tmpnn.h declares."""
+# entry points only a comparison build (-DTMPNN_KEEP_VARIANTS, tools/build_variant.sh) exports: bound when the loaded library
+# has them (TMPNN_LIB_PATH pointing at such a build), absent from the shipped one
+_VARIANT_SIGNATURES = {
+    'tmpnn_track_append': (c_int, [c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                                   c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    'tmpnn_gru_bwd_weights_variant': (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
+                                              c_void_p, c_int, c_int, c_void_p, c_size_t, c_void_p, c_int, c_void_p, c_void_p,
+                                              c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
+    'tmpnn_gru_bwd_weights_choice': (c_int, []),
+    'tmpnn_wide_gru_bwd_diff_aux': (c_int, [c_void_p, _GP, c_void_p, c_int, c_int, c_void_p, c_size_t, c_void_p, c_int,
+                                            c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                                            c_void_p, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p]),
+    'tmpnn_wide_gru_bwd_data_ws': (c_size_t, [c_int, c_int]),
+    'tmpnn_wide_gru_bwd_data': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_size_t, c_void_p, c_int,
+                                        c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
+    'tmpnn_wide_gru_bwd_weights_ws': (c_size_t, [c_int, c_int]),
+    'tmpnn_wide_gru_bwd_weights': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p,
+                                           c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+}
+
+
+def header_symbols(variants: bool = False) -> List[str]:
+    """Every function name include/tmpnn.h declares for the shipped library (variants=True: also the comparison-build
+    entry points of its `#ifdef TMPNN_KEEP_VARIANTS` section)."""
     with open(HEADER_PATH) as f:
         txt = f.read()
+    if not variants:
+        txt = re.sub(r'#ifdef TMPNN_KEEP_VARIANTS.*?#endif', '', txt, flags=re.S)
     txt = re.sub(r'/\*.*?\*/', '', txt, flags=re.S)
     return sorted(set(re.findall(r'\b(tmpnn_[a-z0-9_]+)\s*\(', txt)))
 
@@ -279,6 +278,11 @@ def load() -> C.CDLL:
             raise RuntimeError(f'libtmpnn.so does not export {name}; rebuild it') from e
         fn.restype = res
         fn.argtypes = args
+    for name, (res, args) in _VARIANT_SIGNATURES.items():
+        fn = getattr(lib, name, None)
+        if fn is not None:
+            fn.restype = res
+            fn.argtypes = args
     v = lib.tmpnn_abi_version()
     if v != ABI_VERSION:
         raise RuntimeError(f'libtmpnn.so ABI version {v} != expected {ABI_VERSION}; rebuild it')

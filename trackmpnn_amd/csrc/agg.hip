@@ -549,6 +549,7 @@ static int segsum_dense(const tmpnn_graph* g, const tmpnn_seg_plan* pl, const fl
     return check_launch("segsum (dense form, second pass)");
 }
 
+#ifdef TMPNN_KEEP_VARIANTS      // measured 2 x slower than the CSR kernel (DESIGN_HISTORY 13.6): comparison builds only
 // ------------------------------------------------------------------------------------------------------------
 // segment sum of a BATCH OF SMALL WINDOWS with every edge row read once (round 5, struct tmpnn_win_plan)
 // ------------------------------------------------------------------------------------------------------------
@@ -889,6 +890,8 @@ static int segsum_win(const tmpnn_graph* g, const tmpnn_win_plan* pl, const floa
     return check_launch("segsum (windows beyond the LDS capacity)");
 }
 
+#endif  // TMPNN_KEEP_VARIANTS
+
 static int segsum(const tmpnn_graph* g, const float* in, int ld_in, float* out, int ld_out, int H, int accumulate,
                   float wneg, int cneg, int compact_out, tmpnn_stream stream, int row_limit = 0x7fffffff) {
     int rc = check_graph(g);
@@ -899,10 +902,12 @@ static int segsum(const tmpnn_graph* g, const float* in, int ld_in, float* out, 
     hipStream_t st = as_stream(stream);
     if (g->seg_plan && H == 256 && wneg == -1.0f && cneg == 0)        // dense graph with a plan: every edge row read once
         return segsum_dense(g, g->seg_plan, in, ld_in, out, ld_out, accumulate, compact_out, st);
+#ifdef TMPNN_KEEP_VARIANTS
     // a batch of small windows with a plan, enough of them to fill the chip: every edge row read once
     if (g->win_plan && H == 64 && wneg == -1.0f && cneg == 0 && 2 * g->win_plan->W >= cu_count() &&
         ld_in % 4 == 0 && ld_out % 4 == 0 && (((uintptr_t)in | (uintptr_t)out) & 15) == 0)
         return segsum_win(g, g->win_plan, in, ld_in, out, ld_out, accumulate, compact_out, st);
+#endif
     dim3 grid(grid_for(g->Dn, 64)), block(256);
 #define LS(K, A) hipLaunchKernelGGL((K<A>), grid, block, 0, st, g->Dn, g->det_row, g->rowptr, g->inc, g->det_order, in, ld_in, out, ld_out, H, wneg, cneg, compact_out)
 #define LSP(A, UU, CH)                                                                                       \

@@ -36,6 +36,37 @@
     } while (0)
 
 
+// ---- entry-point-shaped helpers that other entry points call (single stages of tmpnn_track_select / _retire, the conversions'
+//      small-graph forms): C linkage, NOT exported by the shared library
+#define TMPNN_INTERNAL __attribute__((visibility("hidden")))
+extern "C" {
+#ifndef TMPNN_KEEP_VARIANTS
+// (the implementation behind tmpnn_gru_bwd_weights; an entry point of its own only in comparison builds)
+TMPNN_INTERNAL int tmpnn_gru_bwd_weights_variant(const int32_t* rows, int R, int xmode, const int32_t* src, const int32_t* dst,
+                                  const float* msg, int ld_msg, int msg_compact, int IN, const float* h, int ld_h, int H,
+                                  const float* gates, size_t gate_plane, const float* d_hout, int ld_dhout, const float* dy,
+                                  const float* w_head, float* dW_ih, float* dW_hh, float* db_ih, float* db_hh, void* ws,
+                                  size_t ws_bytes, int variant, tmpnn_stream stream);
+#endif
+TMPNN_INTERNAL size_t tmpnn_graph_from_coo_ws_ints(int N);
+TMPNN_INTERNAL int tmpnn_graph_from_rows(int N, const uint8_t* is_edge, const int32_t* row_src, const int32_t* row_dst,
+                          const tmpnn_dgraph* g, tmpnn_stream stream);
+TMPNN_INTERNAL int tmpnn_track_active(int N, const int32_t* ts, const int32_t* assoc, const float* score, int mode, int t,
+                       int32_t* active, int32_t* count, tmpnn_stream stream);
+TMPNN_INTERNAL int tmpnn_track_associate(const tmpnn_dgraph* g, const int32_t* det_id, const uint8_t* labels, const float* score,
+                          int mode, int32_t* assoc, int32_t* status, tmpnn_stream stream);
+TMPNN_INTERNAL int tmpnn_track_delete(int N, const int32_t* ts, const int32_t* det_id, const int32_t* assoc, const float* score,
+                       const uint8_t* is_edge, const int32_t* row_src, const int32_t* row_dst, const uint8_t* labels,
+                       int t_upto, int ret_win, int32_t* keep, int32_t* count, int32_t* o_ts, int32_t* o_det_id,
+                       int32_t* o_assoc, uint8_t* o_is_edge, int32_t* o_src, int32_t* o_dst, uint8_t* o_labels,
+                       tmpnn_stream stream);
+TMPNN_INTERNAL int tmpnn_track_finalize(const tmpnn_dgraph* g, const int32_t* ts, const int32_t* det_id, const int32_t* assoc,
+                         const float* score, int t_upto, int32_t* y_track, int ND, int32_t* pos_of_det, void* ws,
+                         size_t ws_bytes, tmpnn_stream stream);
+TMPNN_INTERNAL int tmpnn_track_gather(const float* in, int ld_in, int W, int max_rows, const int32_t* keep, const int32_t* count,
+                       float* out, int ld_out, tmpnn_stream stream);
+}
+
 namespace tmpnn {
 
 int set_error(int code, const char* fmt, ...);

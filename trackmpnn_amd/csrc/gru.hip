@@ -4342,7 +4342,9 @@ int tmpnn_gru_bwd_fused(const int32_t* rows, int R, int xmode, const int32_t* sr
     return check_launch("gru_reduce_w");
 }
 
+#ifdef TMPNN_KEEP_VARIANTS
 int tmpnn_gru_bwd_weights_choice(void) { return weights_variant_default(); }
+#endif  // TMPNN_KEEP_VARIANTS
 
 size_t tmpnn_gru_bwd_weights_ws(int R, int IN, int H) {
     if (R <= 0) return 0;

@@ -953,6 +953,7 @@ int tmpnn_track_active(int N, const int32_t* ts, const int32_t* assoc, const flo
     return check_launch("track_active");
 }
 
+#ifdef TMPNN_KEEP_VARIANTS
 int tmpnn_track_append(int N, int A, int D, const int32_t* active, const int32_t* new_ids, int t, const int32_t* track,
                        int32_t* ts, int32_t* det_id, int32_t* assoc, uint8_t* is_edge, int32_t* row_src,
                        int32_t* row_dst, uint8_t* labels, tmpnn_stream stream) {
@@ -967,6 +968,7 @@ int tmpnn_track_append(int N, int A, int D, const int32_t* active, const int32_t
                        (float*)nullptr, 0);
     return check_launch("track_append");
 }
+#endif  // TMPNN_KEEP_VARIANTS
 
 int tmpnn_track_delete(int N, const int32_t* ts, const int32_t* det_id, const int32_t* assoc, const float* score,
                        const uint8_t* is_edge, const int32_t* row_src, const int32_t* row_dst, const uint8_t* labels,

@@ -601,6 +601,7 @@ __device__ __forceinline__ void ring_compute(const RingOps& o, f32x16 (&acc)[3])
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                         \
         }                                                                                              \
     } while (0)
+#ifdef TMPNN_KEEP_VARIANTS      // superseded by the opposite-phase form (round 5): comparison builds only
 __global__ __launch_bounds__(512) void k_wide_gru_fwd_ring(WideArgs a, WideTiles tl) {
     extern __shared__ __attribute__((aligned(16))) uint16_t w_dyn[];
     char* const ring = reinterpret_cast<char*>(w_dyn);
@@ -847,6 +848,7 @@ __global__ __launch_bounds__(512) void k_wide_gru_fwd_ring(WideArgs a, WideTiles
         ring_dma(a, c, 3, bx << 6, 3);
     }
 }
+#endif  // TMPNN_KEEP_VARIANTS
 
 // ------------------------------------------------------------------------------------------------------------
 // the tiled cell, third form (round 5): 128 x 384 items, the two halves of the block in OPPOSITE phases
@@ -2696,12 +2698,16 @@ static int launch_gemm_ring(const WideArgs& a, hipStream_t st, const uint16_t* i
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     const int ntile = ceil_div(a.R, 128);
     // default since round 5 where N = 256 (C5): the opposite-phase form; TMPNN_WIDE_GEMM_RING=1 keeps the ring form for A/B runs
+#ifdef TMPNN_KEEP_VARIANTS
     static const bool ring_form = [] { const char* e = getenv("TMPNN_WIDE_GEMM_RING"); return e && e[0] == '1'; }();
+    // 256-row tiles (the weights streamed half as often) unless TMPNN_WIDE_GEMM_ROWS=128
+    static const bool rows128 = [] { const char* e = getenv("TMPNN_WIDE_GEMM_ROWS"); return e && e[0] == '1' && e[1] == '2'; }();
+#else
+    constexpr bool ring_form = false, rows128 = false;
+#endif
     if (!ring_form && a.N == 256 && a.K % 128 == 0 && img_gpp != nullptr) {
         WideArgs b = a;
         b.img = img_gpp;
-        // 256-row tiles (the weights streamed half as often) unless TMPNN_WIDE_GEMM_ROWS=128
-        static const bool rows128 = [] { const char* e = getenv("TMPNN_WIDE_GEMM_ROWS"); return e && e[0] == '1' && e[1] == '2'; }();
         if (rows128) {
             TM_SHM_ONCE(k_wide_gemm_pp256<1>, gq_shm<1>());
             hipLaunchKernelGGL(k_wide_gemm_pp256<1>, dim3(ntile < cus ? ntile : cus), dim3(512), gq_shm<1>(), st, b);
@@ -2844,22 +2850,27 @@ int tmpnn_wide_gru_fwd_tiled(const void* prep, const int32_t* det_rows, int Dn, 
     const uint16_t* img_pp = a.img + (size_t)2 * 3 * H * 3 * H;                       // the contiguous-block image (seventh)
     // default since round 5: the opposite-phase form on 128 x 384 items (k_wide_gru_fwd_pp); TMPNN_WIDE_FWD_RING=1 keeps the
     // ring form of round 3 (same results bit for bit) for A/B runs
+#ifdef TMPNN_KEEP_VARIANTS
     static const bool ring_form = [] { const char* e = getenv("TMPNN_WIDE_FWD_RING"); return e && e[0] == '1'; }();
     if (ring_form) {
         TM_SHM_ONCE(k_wide_gru_fwd_ring, W_RING_SHM);
         hipLaunchKernelGGL(k_wide_gru_fwd_ring, dim3(grid), dim3(512), W_RING_SHM, st, a, tl);
-    } else {
-        a.img = img_pp;
-        TM_SHM_ONCE(k_wide_gru_fwd_pp, W_PP_SHM);
-        hipLaunchKernelGGL(k_wide_gru_fwd_pp, dim3(grid), dim3(512), W_PP_SHM, st, a, tl);
+        return check_launch("wide_gru_fwd_tiled (ring form)");
     }
+#endif
+    a.img = img_pp;
+    TM_SHM_ONCE(k_wide_gru_fwd_pp, W_PP_SHM);
+    hipLaunchKernelGGL(k_wide_gru_fwd_pp, dim3(grid), dim3(512), W_PP_SHM, st, a, tl);
     return check_launch("wide_gru_fwd_tiled");
 }
 
+#ifdef TMPNN_KEEP_VARIANTS
 size_t tmpnn_wide_gru_bwd_data_ws(int R, int H) { return R > 0 ? sizeof(float) * 2 * (size_t)R * 3 * H : 0; }
+#endif  // TMPNN_KEEP_VARIANTS
 
 /* Data gradient of the cell (arguments as tmpnn_gru_bwd_data, IN = H): d_msg[rows[r]][0:H] = d_gi W_ih,
  * d_h[rows[r]] = dh z + d_gh W_hh.  ws: tmpnn_wide_gru_bwd_data_ws bytes. */
+#ifdef TMPNN_KEEP_VARIANTS
 int tmpnn_wide_gru_bwd_data(const void* prep, const int32_t* rows, int R, const float* h, int ld_h, int H,
                             const float* gates, size_t gate_plane, const float* d_hout, int ld_dhout, const float* dy,
                             const float* w_head, float* d_msg, int ld_dmsg, float* d_h, int ld_dh, void* ws,
@@ -2896,6 +2907,7 @@ int tmpnn_wide_gru_bwd_data(const void* prep, const int32_t* rows, int R, const 
     y.A = dgh; y.img = b_hh; y.C = d_h; y.ldc = ld_dh; y.accumulate = 1;
     return launch_store(y, st);
 }
+#endif  // TMPNN_KEEP_VARIANTS
 
 static int dw_slabs(int R, int H) {
     const int tiles = (3 * H / DW_TILE_M) * (H / 128);
@@ -2905,15 +2917,18 @@ static int dw_slabs(int R, int H) {
     return s < 1 ? 1 : s;
 }
 
+#ifdef TMPNN_KEEP_VARIANTS
 size_t tmpnn_wide_gru_bwd_weights_ws(int R, int H) {
     if (R <= 0) return 0;
     const int n = dw_slabs(R, H);
     const size_t per = (size_t)3 * H * H + (size_t)3 * H;
     return sizeof(float) * ((size_t)n * per + reduce_slabs_ws_floats(n, (size_t)3 * H * H));
 }
+#endif  // TMPNN_KEEP_VARIANTS
 
 /* Weight gradient of the cell from the gate gradients tmpnn_wide_gru_bwd_data left in ITS workspace (`dg_ws`: d_gi then
  * d_gh, [R][3H] each): dW_ih += d_gi^T (h[src] - h[dst]), dW_hh += d_gh^T h[rows], db_* += column sums.  */
+#ifdef TMPNN_KEEP_VARIANTS
 int tmpnn_wide_gru_bwd_weights(const void* dg_ws, const int32_t* rows, int R, const int32_t* src, const int32_t* dst,
                                const float* h, int ld_h, int H, float* dW_ih, float* dW_hh, float* db_ih, float* db_hh,
                                void* ws, size_t ws_bytes, tmpnn_stream stream) {
@@ -2947,6 +2962,7 @@ int tmpnn_wide_gru_bwd_weights(const void* dg_ws, const int32_t* rows, int R, co
     }
     return TMPNN_OK;
 }
+#endif  // TMPNN_KEEP_VARIANTS
 
 // ---- det-side form of the W_ih products -------------------------------------------------------------------
 static int gates4_blocks(int R, int H) {
@@ -3106,6 +3122,7 @@ int tmpnn_wide_gru_bwd_diff(const void* prep, const tmpnn_graph* g, const float*
                                   db_ih, db_hh, ws, ws_bytes, stream, nullptr, nullptr, nullptr, nullptr, 0);
 }
 
+#ifdef TMPNN_KEEP_VARIANTS
 int tmpnn_wide_gru_bwd_diff_aux(const void* prep, const tmpnn_graph* g, const float* h, int ld_h, int H, const float* gates,
                                 size_t gate_plane, const float* d_hout, int ld_dhout, const float* dy, const float* w_head,
                                 float* d_h, int ld_dh, float* dW_ih, float* dW_hh, float* db_ih, float* db_hh, void* ws,
@@ -3114,6 +3131,7 @@ int tmpnn_wide_gru_bwd_diff_aux(const void* prep, const tmpnn_graph* g, const fl
     return wide_gru_bwd_diff_impl(prep, g, h, ld_h, H, gates, gate_plane, d_hout, ld_dhout, dy, w_head, d_h, ld_dh, dW_ih, dW_hh,
                                   db_ih, db_hh, ws, ws_bytes, stream, aux_stream, ev_fork, ev_join, nullptr, 0);
 }
+#endif  // TMPNN_KEEP_VARIANTS
 
 int tmpnn_wide_gru_bwd_diff_fused(const void* prep, const tmpnn_graph* g, const float* h, int ld_h, int H, const float* gates,
                                   size_t gate_plane, const float* d_hout, int ld_dhout, const float* dy, const float* w_head,

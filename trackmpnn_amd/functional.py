@@ -32,7 +32,7 @@ FUSED_BWD = os.environ.get('TMPNN_FUSED_BWD', '1') == '1'     # one-pass cell ba
 # (det-side branches of the wide cells on a second stream: worth 1.5-6 ms of a 195-ms C5 step until round 4's single-read segment sum
 #  took most of what it hid -- since then the two forms are within the run-to-run spread (4 alternating pairs: 186.8 vs 188.5 ms, a
 #  later pair 184.7 vs 183.4); off by default: the simpler form)
-WIDE_OVERLAP = os.environ.get('TMPNN_WIDE_OVERLAP', '0') == '1'
+WIDE_OVERLAP = os.environ.get('TMPNN_WIDE_OVERLAP', '0') == '1' and os.environ.get('TMPNN_KEEP_VARIANTS', '0') == '1'   # (tmpnn_wide_gru_bwd_diff_aux: comparison builds)
 ATT_KMAX = 8                 # heads per tmpnn_att_fwd / _bwd call (include/tmpnn.h)
 _SPLIT = os.environ.get('TMPNN_SPLIT', '1')[:1] != '0'        # TMPNN_SPLIT=0: every GEMM on the f32-input MFMA (tested)
 

@@ -58,6 +58,38 @@ class SparseAttention:
         out[det_of_pos, (g.inc & 0x7FFFFFFF).long()] = self.alpha
         return out
 
+    # ---- the reference's consumers of forward()'s 4th output treat a head's attention as a dense [N, N] tensor
+    #      (attention_weights.py:62: `att.cpu().detach().numpy()`, :84-93: `.shape`, `a[row][col]`): those uses work on this
+    #      object unchanged -- the dense matrix is built on first use and kept
+    def _dense(self) -> torch.Tensor:
+        d = self.__dict__.get('_dense_cache')
+        if d is None:
+            d = self.__dict__['_dense_cache'] = self.to_reference_dense()
+        return d
+
+    @property
+    def shape(self):
+        return torch.Size((self.graph.N, self.graph.N))
+
+    def size(self, dim=None):
+        return self.shape if dim is None else self.shape[dim]
+
+    def cpu(self) -> torch.Tensor:
+        return self._dense().cpu()
+
+    def detach(self) -> torch.Tensor:
+        return self._dense().detach()
+
+    def numpy(self):
+        return self._dense().detach().cpu().numpy()
+
+    def __array__(self, dtype=None):
+        a = self.numpy()
+        return a if dtype is None else a.astype(dtype)
+
+    def __getitem__(self, idx):
+        return self._dense()[idx]
+
     def per_edge(self) -> torch.Tensor:
         """[E, 2]: weight the src det / the dst det gives each edge (oracle layout)."""
         g = self.graph
