@@ -153,6 +153,15 @@ def stage_profile(model, plan, H):
                   g.dst.data_ptr(), dmsg.data_ptr(), H, gW[0].data_ptr(), gW[1].data_ptr(), gW[2].data_ptr(),
                   gW[3].data_ptr(), fws.data_ptr(), fwsb, st)
 
+    nwih_t = P[f + 'node_gru.weight_ih'].detach().t().contiguous()
+    nwhh_t = P[f + 'node_gru.weight_hh'].detach().t().contiguous()
+    nbih, nbhh = P[f + 'node_gru.bias_ih'].detach(), P[f + 'node_gru.bias_hh'].detach()
+
+    def gru_fwd_node():             # as the training step runs it: x = the compact aggregate es[d], both products per det row
+        _lib.call('tmpnn_gru_fwd', g.det_row.data_ptr(), Dn, 0, None, None, es.data_ptr(), H, 1, H, h.data_ptr(), H, H,
+                  nwih_t.data_ptr(), nwhh_t.data_ptr(), nbih.data_ptr(), nbhh.data_ptr(), out.data_ptr(), H, gates.data_ptr(),
+                  N * H, None, None, 0, st)
+
     def gather():
         _lib.call('tmpnn_gather_diff_fwd', g.cref(), h.data_ptr(), H, out.data_ptr(), H, H, 0, st)
 
@@ -164,14 +173,16 @@ def stage_profile(model, plan, H):
                                                ('gru_bwd_data_edge_folded', gru_bwd_data_folded),
                                                ('gru_bwd_weights_edge', gru_bwd_w),
                                                ('gather_diff', gather),
-                                               ('segsum', segsum)) + ((('gru_bwd_one_edge', gru_bwd_one),) if fwsb else ())}
-    flops = {'gru_fwd_edge': 12.0 * H * H * E, 'gru_bwd_data_edge': 12.0 * H * H * E,
+                                               ('segsum', segsum), ('gru_fwd_node', gru_fwd_node)) + ((('gru_bwd_one_edge', gru_bwd_one),) if fwsb else ())}
+    flops = {'gru_fwd_node': 12.0 * H * H * Dn, 'gru_fwd_edge': 12.0 * H * H * E, 'gru_bwd_data_edge': 12.0 * H * H * E,
              'gru_bwd_data_edge_folded': 12.0 * H * H * E,
              'gru_bwd_weights_edge': 12.0 * H * H * E, 'gru_bwd_one_edge': 24.0 * H * H * E}
     # SURVEY 8(d) algorithmic bytes per launch (every array counted once; det-row gathers count the det table once)
     b_gather = 4.0 * H * E + 4.0 * H * Dn + 8.0 * E
     b_segsum = 4.0 * H * E + 4.0 * H * Dn + 4.0 * (2 * E + Dn + 1) + 2.0 * E
     nbytes = {'gather_diff': b_gather, 'segsum': b_segsum,
+              # per det row: es 4H + h 4H in, h_out 4H + gates 16H out, the row id
+              'gru_fwd_node': (28.0 * H + 4.0) * Dn,
               # det rows -> P (4H in, 12H out per det), then per edge: h 4H in, h_out 4H + gates 16H out, 3 ids; P read once
               'gru_fwd_edge': (24.0 * H + 12.0) * E + 28.0 * H * Dn,
               # per edge: dh 4H + gates 16H + h 4H in, d_msg 4H + d_h 4H out, row id
@@ -305,6 +316,8 @@ def _pmc_kernel(stage):
         return {'gru_fwd_edge': 'k_gru_fwd_split_tiled<64, 8>' if _fn.FWD_TILED else 'k_gru_fwd_split<64, 8>', 'gru_bwd_data_edge': 'k_gru_bwd_data_split<64, 1, false>',
                 'gru_bwd_data_edge_folded': 'k_gru_bwd_data_split<64, 3, true>',
                 'gru_bwd_weights_edge': 'k_gru_bwd_weights_split<1, 1>',
+                'segsum': 'k_segsum_pipe<false, 4, 32, false', 'gather_diff': 'k_gather_pipe<false, false',
+                'gru_fwd_node': 'k_gru_fwd_split_node<64',
                 'gru_bwd_one_edge': ('k_gru_bwd_one<1, 3, true>' if os.environ.get('TMPNN_BWD_TWO', '1')[:1] == '0'
                                      else 'k_gru_bwd_two<1, 3, true')}.get(stage, '?')       # (prefix: the template list grew in round 4)
     return {'gru_fwd_edge': 'k_gru_fwd_lds<64, 64, 3,', 'gru_bwd_data_edge': 'k_gru_bwd_data_lds<64, 64, 1, false>',
@@ -312,7 +325,7 @@ def _pmc_kernel(stage):
             'gru_bwd_weights_edge': 'k_gru_bwd_weights_lds<64, 1, 1>'}.get(stage, '?')
 
 
-def kernel_source_digest(files=('gru.hip', 'common.h')):
+def kernel_source_digest(files=('gru.hip', 'agg.hip', 'common.h')):
     """sha256 (first 16 hex digits) of the kernel sources a committed PMC pass belongs to: tools/collect_r05.py records it
     next to the counters, `pmc_traffic` compares it with the tree that is running."""
     import hashlib
@@ -332,7 +345,7 @@ def pmc_traffic(stage, E):
     kernel); `source` says where the number comes from (file, the date and HEAD of the pass, the digest of the kernel
     sources it was taken on).  bytes is None when no profile was taken on a graph of exactly this size, or when the
     profile records a source digest and the kernel sources have changed since (`source.stale`)."""
-    for tag in ('r05', 'r04', 'r03', 'r02', 'r01'):
+    for tag in ('r06', 'r05', 'r04', 'r03', 'r02', 'r01'):
         name_ = f'{tag}_pmc_traffic_stage_kernels.json'
         try:
             prof = json.load(open(os.path.join(ROOT, 'profiles', name_)))
@@ -867,9 +880,14 @@ def main():
                                 for k in t}
         agg_b = nbytes['gather_diff'] + nbytes['segsum']
         agg_t = (t['gather_diff'] + t['segsum']) * 1e-3
+        tr_s, _ = pmc_traffic('segsum', plans[-1].graph.E)
+        tr_g, _ = pmc_traffic('gather_diff', plans[-1].graph.E)
         extra['roofline_aggregation'] = dict(
             bound='hbm', kernel='gather_diff+segsum', achieved=agg_b / agg_t / 1e9, peak=HBM_PEAK_GBS, unit='GB/s',
-            frac=agg_b / agg_t / 1e9 / HBM_PEAK_GBS, traffic=None,
+            frac=agg_b / agg_t / 1e9 / HBM_PEAK_GBS,
+            traffic=(tr_s + tr_g) if (tr_s is not None and tr_g is not None) else None,
+            traffic_segsum=tr_s, traffic_ratio_segsum=(round(tr_s / nbytes['segsum'], 3) if tr_s is not None else None),
+            traffic_gather=tr_g, traffic_ratio_gather=(round(tr_g / nbytes['gather_diff'], 3) if tr_g is not None else None),
             gather_GBs=nbytes['gather_diff'] / (t['gather_diff'] * 1e-3) / 1e9,
             segsum_GBs=nbytes['segsum'] / (t['segsum'] * 1e-3) / 1e9)
         extra['stage_ms'] = {k: round(v, 4) for k, v in t.items()}

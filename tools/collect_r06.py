@@ -1,4 +1,4 @@
-"""Round-5 summaries under profiles/ from the outputs of tools/measure_r06.sh (gpurun_out/r06_*):
+"""Round-6 summaries under profiles/ from the outputs of tools/measure_r06.sh (gpurun_out/r06_*):
   r06_bench_kernel_stats.{csv,md}  r06_bench_line.json  r06_bench_line_unprofiled.json  r06_pmc_traffic_stage_kernels.json (with the
   date, HEAD and kernel-source digest of the pass: bench.py refuses the file once the kernel sources change)  -- the shared
   parts of tools/collect_r03.py, run with the r06 tag --  r06_c2_step_kernels.md  r06_c5_dense_stress.md  r06_loops.md"""
@@ -56,7 +56,7 @@ c5 = f'gpurun_out/{tag}_c5'
 if os.path.exists(f'{c5}/kernel_stats.csv') and os.path.exists(f'{c5}/pp_plain.log'):
     import shutil
     shutil.copy(f'{c5}/kernel_stats.csv', f'profiles/{tag}_c5_kernel_stats.csv')
-    pp, ring = _jl(f'{c5}/pp_plain.log'), _jl(f'{c5}/ring_plain.log')
+    pp = _jl(f'{c5}/pp_plain.log')
     pm = json.load(open(f'{c5}/pmc.json')) if os.path.exists(f'{c5}/pmc.json') else {}
     E, N, H, Dn = pp['E'], pp['N'], 256, pp.get('Dn', 15000)
     sp = pp.get('seg_plan') or dict(T=0, I=0)
@@ -85,8 +85,8 @@ if os.path.exists(f'{c5}/kernel_stats.csv') and os.path.exists(f'{c5}/pp_plain.l
 | round 2 (LDS-tiled bf16x6 GEMMs, det-side W_ih products) | 257 | 68.6 M | 161.9 |
 | round 3 (edge tiles + ring kernels) | 192-195 | 91 M | 211 |
 | round 4 (single-read segment sum) | 183-189 | 95.5 M | 225 |
-| round 5, the ring forms of the two E-row products on THIS box (`TMPNN_WIDE_FWD_RING=1 TMPNN_WIDE_GEMM_RING=1`) | {ring['ms_per_step']:.1f} | {ring['edges_per_s'] / 1e6:.1f} M | {ring['tflops']:.1f} |
-| round 5 (default): `k_wide_gru_fwd_pp` + `k_wide_gemm_pp256<2>`, the block's halves in opposite phases | **{pp['ms_per_step']:.1f}** | **{pp['edges_per_s'] / 1e6:.1f} M** | **{pp['tflops']:.1f}** |
+| round 5: `k_wide_gru_fwd_pp` + `k_wide_gemm_pp256<2>`, the block's halves in opposite phases | 180.3 | 97.9 M | 230.9 |
+| round 6 (same kernels; this box, loss = sum of logits as in the rounds above) | **{pp['ms_per_step']:.1f}** | **{pp['edges_per_s'] / 1e6:.1f} M** | **{pp['tflops']:.1f}** |
 
 ## Per kernel (one stream; every duration un-shared)
 
@@ -115,12 +115,22 @@ fraction (6 bf16 products per fp32 product x 2 flops / duration against the dens
             f.write(f"| `{short}` | {calls / 3:.1f} | {avg_ms:.3f} | {pct:.1f} | {a['bytes'] / 1e9:.2f} | {gbs:.0f} | {gbs / HBM:.2f} | "
                     f"{'%.0f' % tf if tf else ''} | {'%.2f' % (tf / MFMA_PEAK) if tf else ''} | {'%.2f' % tr if tr else ''} | "
                     f"{'%.2f' % (tr / (a['bytes'] / 1e9)) if tr else ''} |\n")
+        cal = 'gpurun_out/fetch_calib.txt'
         f.write("""
-Round 4's table of the same launches: `k_wide_gru_fwd_ring` 11.73 ms (PMC traffic 1.51 x), `k_wide_gemm_ring256` 9.86 ms (1.09 x),
-`k_wide_dw2` 4.63 ms, `k_wide_gates_bwd4` 8.88 ms (`profiles/r04_c5_dense_stress.md`).  What the round measured inside the two
-new kernels (s_memtime stamps, build-time ablations): DESIGN.md section 13.1.
+## Is the 2 x FETCH_SIZE correction right for these kernels' access widths?  (round 6: `tools/ubench/fetch_calib.hip`)
+
+Round 5 suspected that the forward's 1.51 x came from the correction overstating its 4-byte-per-lane previous-state reads (the guide
+calibrates 16 B per lane only).  Measured on a 2 GiB buffer read exactly once per kernel (8 x the Infinity Cache):
+
+```
+""" + (open(cal).read() if os.path.exists(cal) else '(no calibration run in gpurun_out/)\n') + """```
+
+FETCH_SIZE is half the bytes for EVERY width these kernels use -- 16 B and 4 B per lane, contiguous or split in two 128-byte runs,
+into registers or by LDS-DMA: the factor 2 applies unchanged and the forward's traffic ratio is real, not a counter artefact.  What it
+is made of (per 128-row item: A rows requested once per 128-column block = twice at H = 256, the previous-state rows again in the
+epilogue, the staged P rows): DESIGN.md section 4 (wide cells).
 """)
-    print('c5:', pp['ms_per_step'], ring['ms_per_step'])
+    print('c5:', pp['ms_per_step'])
 
 # ---------------------------------------------------------------------------------------------- loops
 ld = f'gpurun_out/{tag}_loops'

@@ -27,7 +27,6 @@ bench)
 c5)
   O=$R/gpurun_out/${T}_c5; rm -rf $O; mkdir -p $O
   python3 $R/tools/c5_bench.py --steps 4 > $O/pp_plain.log 2>&1 || { tail -5 $O/pp_plain.log; exit 1; }
-  TMPNN_WIDE_FWD_RING=1 TMPNN_WIDE_GEMM_RING=1 python3 $R/tools/c5_bench.py --steps 4 > $O/ring_plain.log 2>&1 || { tail -5 $O/ring_plain.log; exit 1; }
   rocprofv3 --kernel-trace --stats --output-format csv -d $O/st -o r -- python3 $R/tools/c5_bench.py --steps 2 > $O/stats.log 2>&1 || { tail -5 $O/stats.log; exit 1; }
   cp $(ls $O/st/*kernel_stats.csv $O/st/*/*kernel_stats.csv 2>/dev/null | head -1) $O/kernel_stats.csv; rm -rf $O/st
   for C in FETCH_SIZE WRITE_SIZE; do
@@ -48,7 +47,7 @@ for C in ('FETCH_SIZE', 'WRITE_SIZE'):
 json.dump(res, open(O + '/pmc.json', 'w'), indent=1)
 PY
   rm -rf $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE
-  tail -1 $O/pp_plain.log | cut -c1-200; tail -1 $O/ring_plain.log | cut -c1-200
+  tail -1 $O/pp_plain.log | cut -c1-200
   ;;
 loops)
   O=$R/gpurun_out/${T}_loops; rm -rf $O; mkdir -p $O

@@ -1935,16 +1935,31 @@ __global__ __launch_bounds__(512) void k_rows_gemm_split(const int32_t* __restri
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int c = lane & 31, half = lane >> 5;
     float* stg = reinterpret_cast<float*>(sW + 3 * NOUT * KP) + wave * (32 * STG_LD);
+    // the wave's rows of the NEXT tile are requested before this tile's matrix phase (round 6: the loop used to load, wait,
+    // compute and store tile by tile)
+    constexpr int NQ4 = H / 8;
+    float4 raw[NQ4];
+    int row_n = 0, orow_n = 0;
+    auto request = [&](int tile) {
+        const int r0 = (tile * 8 + wave) * 32;
+        if (tile < ntiles && r0 < R) {
+            const int li = min(r0 + c, R - 1);
+            row_n = rows ? rows[li] : li;
+            orow_n = out_rows ? out_rows[li] : li;
+            const float4* xr = reinterpret_cast<const float4*>(in + (size_t)row_n * ld_in + (H / 2) * half);
+#pragma unroll
+            for (int i = 0; i < NQ4; ++i) raw[i] = xr[i];
+        }
+    };
+    request(blockIdx.x);
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int r0 = (tile * 8 + wave) * 32;
-        if (r0 >= R) continue;
-        const int li = min(r0 + c, R - 1);
-        const int row = rows ? rows[li] : li;
-        const int orow = out_rows ? out_rows[li] : li;
-        const float4* xr = reinterpret_cast<const float4*>(in + (size_t)row * ld_in + (H / 2) * half);
+        if (r0 >= R) continue;                     // (only the last tile: nothing was requested for it, nothing follows)
+        const int orow = orow_n;
         Split8 b[NKB];
 #pragma unroll
-        for (int kb = 0; kb < NKB; ++kb) b[kb] = split8(xr[2 * kb], xr[2 * kb + 1]);
+        for (int kb = 0; kb < NKB; ++kb) b[kb] = split8(raw[2 * kb], raw[2 * kb + 1]);
+        request(tile + gridDim.x);
         f32x16 acc[NT];
 #pragma unroll
         for (int t = 0; t < NT; ++t)
