@@ -15,7 +15,8 @@
 #if defined(WT_NOSTORE) || defined(WT_NOSPLIT) || defined(WT_NOREAD) || defined(WT_NOMMA) || defined(WT_NOEPI) ||          \
     defined(WT_NODMA) || defined(WT_NOBAR) || defined(WT_DW_NOSTAGE) || defined(WT_DW_NOMMA) || defined(WT_DW_NOLOAD) ||   \
     defined(FT_EXP_NOSTORE) || defined(FT_EXP_NOLOGITSTORE) || defined(FT_EXP_NODMA) || defined(W3_NOEPI) ||               \
-    defined(W3_NOMMA) || defined(W3_NOSTORE) || defined(W3_NODMA) || defined(W3_NOSPLIT) || (defined(TWO_EXP) && TWO_EXP != 0)
+    defined(W3_NOMMA) || defined(W3_NOSTORE) || defined(W3_NODMA) || defined(W3_NOSPLIT) || (defined(TWO_EXP) && TWO_EXP != 0) || \
+    defined(ITW_ABL_NOPROD)
 #error "wrong-result timing ablation requested without -DTMPNN_ABLATE"
 #endif
 #endif
