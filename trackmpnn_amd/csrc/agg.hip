@@ -587,9 +587,6 @@ __device__ __forceinline__ uint32_t sw_lds_addr(const void* p) {
 // 16 bytes (DW = 4) or 4 bytes (DW = 1) per lane from a per-lane global address to (uniform LDS address) + DW * 4 * lane
 template <int DW>
 __device__ __forceinline__ void sw_glds(const void* gsrc, uint32_t lds_wave_base) {
-#ifdef SW_NODMA
-    return;
-#endif
     unsigned keep;
     lds_wave_base = __builtin_amdgcn_readfirstlane(lds_wave_base);
     if constexpr (DW == 4)
@@ -613,9 +610,6 @@ __device__ __forceinline__ void sw_wait(int n) {
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-#if (defined(SW_NOREDUCE) || defined(SW_NOSTAGE) || defined(SW_NOWRITE) || defined(SW_NODMA) || defined(SW_NOSLOAD)) && !defined(TMPNN_ABLATE)
-#error "SW_NOREDUCE / SW_NOSTAGE / SW_NOWRITE are wrong-result timing ablations: build them with tools/build_variant.sh (-DTMPNN_ABLATE)"
-#endif
 // a job = (window, column half); its items: nch chunks of edge rows, then (accumulating launches) the det rows of `out` as one more
 // chunk; at least two items per job, so that two buffers of output rows are enough.  nit = 0: no further job
 struct SwJob {
@@ -666,12 +660,7 @@ __global__ __launch_bounds__(512) void k_segsum_win(tmpnn_win_plan pl, const flo
     auto job_at = [&](SwJob& jb, int j, int mb) {
         jb.j = j; jb.mb = mb; jb.nit = 0;
         for (; jb.j < njob; jb.j += G) {
-#ifdef SW_NOSLOAD
-            jb.e0 = 1460 * (jb.j >> 1); jb.ne = 1457; jb.q0 = 100 * (jb.j >> 1); jb.nd = 100; jb.r0 = 60 * (jb.j >> 1); jb.lm2 = 0;
-            jb.lm01 = 0x6666666666666666ull;
-#else
             sw_window(pl.wrec, jb.j >> 1, jb);
-#endif
             if (jb.nd > 0 && jb.nd <= SW_MAXD) {                      // (the plan marks the windows it leaves to the CSR kernel)
                 jb.nit = max(2, jb.nch() + (ACC ? 1 : 0));
                 break;
@@ -727,9 +716,6 @@ __global__ __launch_bounds__(512) void k_segsum_win(tmpnn_win_plan pl, const flo
             sw_glds<4>(pl.recs + ((size_t)it.roff + 4 * x) * SW_NHG + 8 * min(lane, nl - 1), sw_lds_addr(recs_of(rb)) + 1024u * x);
             ++fly;
         }
-#ifdef SW_NOSTAGE
-        if (it.c != 0 || jb.j >= 2 * G) return;
-#endif
         const float* base = prev ? out : in;
         const int ld = prev ? ld_out : ld_in;
         const int* idl = ids_of(rb);
@@ -784,9 +770,6 @@ __global__ __launch_bounds__(512) void k_segsum_win(tmpnn_win_plan pl, const flo
             // its lane groups, (+ the det row of `out`, staged as item t - 1), one store of 8 dets per wave; streams back to zero
             const int* orow = orow_of(W_mb);
             const float* prevr = rows_of(rb == 0 ? 2 : rb - 1);
-#ifdef SW_NOWRITE
-            if (W_nd < 0)
-#endif
 #pragma unroll
             for (int p = 0; p < 3; ++p) {
                 if (64 * p + 8 * wv >= W_nd) continue;                // (uniform)
@@ -821,9 +804,6 @@ __global__ __launch_bounds__(512) void k_segsum_win(tmpnn_win_plan pl, const flo
         // rows and records two iterations ahead of their sums, ids two ahead of the rows that use them
         stage_rows(Cn, rb == 0 ? 2 : rb - 1);
         stage_ids(En, rb == 2 ? 0 : rb + 1);
-#ifdef SW_NOREDUCE
-        if (A.jb.j < 0)
-#endif
         if (A.L > 0) {
             // (eight lanes serve the plan's lane groups g and g + 64: two records a step, their streams never the same)
             const uint16_t* rc = recs_of(rb) + hgl;

@@ -475,11 +475,7 @@ template <int KT>
 __global__ __launch_bounds__(256) void k_att_bwd_dha(AttArgs A, const float* __restrict__ dpre, float* __restrict__ d_ha) {
     ATT_DET_ROUNDS();
     const int H = A.H, KH = KT * H;
-#ifdef ATT_UD
-    constexpr int U = ATT_UD;
-#else
     constexpr int U = KT <= 1 ? 4 : (KT <= 4 ? 2 : 1);
-#endif
     float4 av[KT];
 #pragma unroll
     for (int k = 0; k < KT; ++k) av[k] = ld4(A.a + (size_t)k * H + c4);

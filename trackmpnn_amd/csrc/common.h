@@ -8,19 +8,6 @@
 
 #include "tmpnn.h"
 
-// Timing ablations (-DWT_NO*, -DWT_DW_NO*, -DFT_EXP_*, -DTWO_EXP=n: parts of a kernel removed at compile time to price them;
-// the numbers are in DESIGN.md) produce WRONG RESULTS.  They compile only together with -DTMPNN_ABLATE
-// (tools/build_variant.sh passes it), so a stray -D can never yield a silently wrong libtmpnn.so.
-#if !defined(TMPNN_ABLATE)
-#if defined(WT_NOSTORE) || defined(WT_NOSPLIT) || defined(WT_NOREAD) || defined(WT_NOMMA) || defined(WT_NOEPI) ||          \
-    defined(WT_NODMA) || defined(WT_NOBAR) || defined(WT_DW_NOSTAGE) || defined(WT_DW_NOMMA) || defined(WT_DW_NOLOAD) ||   \
-    defined(FT_EXP_NOSTORE) || defined(FT_EXP_NOLOGITSTORE) || defined(FT_EXP_NODMA) || defined(W3_NOEPI) ||               \
-    defined(W3_NOMMA) || defined(W3_NOSTORE) || defined(W3_NODMA) || defined(W3_NOSPLIT) || (defined(TWO_EXP) && TWO_EXP != 0) || \
-    defined(ITW_ABL_NOPROD)
-#error "wrong-result timing ablation requested without -DTMPNN_ABLATE"
-#endif
-#endif
-
 // The LDS-resident kernels need more than the default 64 KiB of dynamic LDS: raise the limit ONCE per (kernel
 // instantiation, device) instead of before every launch (idempotent function-attribute setup, not data state).
 #define TM_SHM_ONCE(kernel, bytes)                                                                           \

@@ -516,12 +516,7 @@ __device__ __forceinline__ void stage_store32(float* stg, int c, int half, int l
         const int rr = idx >> 3, ch = idx & 7;
         const float4 x = *reinterpret_cast<const float4*>(stg + rr * STG_LD + ch * 4);
         const int orow = __shfl(row, rr, 64);               // lane rr (< 32) owns row r0 + rr
-#ifdef FT_EXP_NOSTORE
-        asm volatile("" :: "v"(x.x), "v"(x.y), "v"(x.z), "v"(x.w), "v"(orow));
-        if (false) {
-#else
         if (r0 + rr < R) {
-#endif
             float* p = dst + (size_t)orow * ld + col0 + ch * 4;
             if (NT) {      // streamed once, read back only by the backward pass: keep it out of the way of L2
                 __builtin_nontemporal_store(x.x, p); __builtin_nontemporal_store(x.y, p + 1);
@@ -1147,16 +1142,7 @@ __global__ __launch_bounds__(WPB * 64) void k_gru_fwd_split_node(GruFwdArgs a) {
 // Rows of 3 gates x 32 columns sit 400 bytes apart (16 consecutive det positions -> 16 different 16-byte slots of the bank
 // row).  A tile with more than TCAP distinct dets takes the gathers of k_gru_fwd_split.  Same products, same order, same
 // epilogue arithmetic: bit-identical results.
-#ifdef FT_TIMELINE            // build-time instrument (tools/isa_timeline.py --fwd-tiles): per-phase s_memtime sums of every wave
-__device__ unsigned long long g_ft_timeline[16];
-#define FT_MARK(i)                                                            \
-    do {                                                                      \
-        const unsigned long long now_ = __builtin_amdgcn_s_memtime();         \
-        ft_acc[(i)] += now_ - ft_last; ft_last = now_;                        \
-    } while (0)
-#else
 #define FT_MARK(i) do { } while (0)
-#endif
 struct FwdTiles { const int32_t* t_row; const int32_t* t_loc; const int32_t* t_dptr; const int32_t* t_dets; int T; };
 static constexpr int TCAP = 24, TP_LD = 100;                   // dets staged per item; floats per staged row
 static constexpr int TP_AREA = TCAP * TP_LD;                   // floats per wave (>= 32 * STG_LD: the output staging tile)
@@ -1193,9 +1179,6 @@ __device__ __forceinline__ void tiled_stage_p(const GruFwdArgs& a, const TiledId
     for (int i0 = 0; i0 < nchunk; i0 += 64) {
         const int idx = i0 + lane;
         const int j = idx / 25, rem = idx - 25 * j;
-#ifdef FT_DMA_SHFL
-        const int det = __shfl(x.det, j, 64);
-#else
         // the 64 chunks of a pass belong to four det rows at most: their ids by v_readlane (a cross-lane read through the
         // LDS pipe here is a round trip per pass, 2.9 k of an item's 21 k cycles in the s_memtime profile)
         const int j0 = i0 / 25;
@@ -1203,13 +1186,7 @@ __device__ __forceinline__ void tiled_stage_p(const GruFwdArgs& a, const TiledId
         const int d2 = __builtin_amdgcn_readlane(x.det, j0 + 2), d3 = __builtin_amdgcn_readlane(x.det, min(j0 + 3, 63));
         const int dj = j - j0;
         const int det = dj == 0 ? d0 : dj == 1 ? d1 : dj == 2 ? d2 : d3;
-#endif
-#ifdef FT_EXP_NODMA
-        asm volatile("" :: "v"(det));
-        if (false)
-#else
         if (idx < nchunk && rem < 24)
-#endif
             glds16_g(a.msg + (size_t)det * a.ld_msg + (rem >> 3) * H + cw0 + 4 * (rem & 7), area + 16u * i0);
     }
 }
@@ -1233,11 +1210,7 @@ __device__ __forceinline__ void tiled_stage_p2(const GruFwdArgs& a, const TiledI
     }
 }
 
-#ifdef FT_DMA_OLD            // comparison builds: the general request loop
-#define FT_STAGE_P tiled_stage_p
-#else
 #define FT_STAGE_P tiled_stage_p2
-#endif
 template <int H, int WPB>
 __global__ __launch_bounds__(WPB * 64) void k_gru_fwd_split_tiled(GruFwdArgs a, FwdTiles tl) {
     extern __shared__ float lds[];
@@ -1298,11 +1271,6 @@ __global__ __launch_bounds__(WPB * 64) void k_gru_fwd_split_tiled(GruFwdArgs a, 
         for (int i = 0; i < NQ4; ++i) raw[i] = xr[i];
     }
 
-#ifdef FT_TIMELINE
-    unsigned long long ft_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    unsigned long long ft_last = __builtin_amdgcn_s_memtime();
-    unsigned long long ft_items = 0;
-#endif
     for (;;) {
         int nitem = 0;
         if (lane == 0) nitem = atomicAdd(next_item, 1);
@@ -1322,24 +1290,9 @@ __global__ __launch_bounds__(WPB * 64) void k_gru_fwd_split_tiled(GruFwdArgs a, 
 #pragma unroll
             for (int i = 0; i < NQ4; ++i) raw[i] = xr[i];
         }
-#ifdef FT_HP_EARLY
-        // (measured, same box: requesting the merge term's previous state before the matrix phase instead of after it
-        //  changes nothing -- 2.66 vs 2.60 ms per 6.03 M rows; kept behind this switch)
-        float4 hp4[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-            hp4[q] = *reinterpret_cast<const float4*>(a.h + (size_t)row * a.ld_h + cw0 + 8 * q + 4 * half);
-        __builtin_amdgcn_sched_barrier(0);                     // (left alone hipcc sinks these loads to the end of the MFMAs)
-#endif
         f32x16 acc_r, acc_z, acc_hn, acc_in;
 #pragma unroll
         for (int i = 0; i < 16; ++i) { acc_r[i] = 0.f; acc_z[i] = 0.f; acc_hn[i] = 0.f; }
-#ifdef FT_TIMELINE
-        asm volatile("" : "+v"(b[0].p1.x), "+v"(b[NKB - 1].p3.w));
-        __builtin_amdgcn_sched_barrier(0);
-        FT_MARK(0);                                             // item claim, operand wait + split, next item's requests
-        __builtin_amdgcn_sched_barrier(0);
-#endif
         {
             const uint16_t* wp0 = sW + (cw0 + c) * KP + (H / 2) * half;
 #pragma unroll
@@ -1356,12 +1309,6 @@ __global__ __launch_bounds__(WPB * 64) void k_gru_fwd_split_tiled(GruFwdArgs a, 
                 }
             }
         }
-#ifdef FT_TIMELINE
-        asm volatile("" : "+v"(acc_r[0]), "+v"(acc_z[0]), "+v"(acc_hn[0]));
-        __builtin_amdgcn_sched_barrier(0);
-        FT_MARK(1);                                             // matrix phase (until the last MFMA's result is readable)
-        __builtin_amdgcn_sched_barrier(0);
-#endif
         // the staged P rows were requested an item ago; only the loads issued since (the next item's operand and index
         // loads, at least NQ4 of them) may still be in flight
         if (staged) {
@@ -1372,17 +1319,10 @@ __global__ __launch_bounds__(WPB * 64) void k_gru_fwd_split_tiled(GruFwdArgs a, 
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
         }
-#ifdef FT_TIMELINE
-        __builtin_amdgcn_sched_barrier(0);
-        FT_MARK(2);                                             // wait for the staged P rows
-        __builtin_amdgcn_sched_barrier(0);
-#endif
-#ifndef FT_HP_EARLY
         float4 hp4[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q)
             hp4[q] = *reinterpret_cast<const float4*>(a.h + (size_t)row * a.ld_h + cw0 + 8 * q + 4 * half);
-#endif
         f32x16 outv;
         {
             float4 gs[4], gd[4], hs[4], hd[4];
@@ -1469,12 +1409,6 @@ __global__ __launch_bounds__(WPB * 64) void k_gru_fwd_split_tiled(GruFwdArgs a, 
                 }
             }
         }
-#ifdef FT_TIMELINE
-        asm volatile("" : "+v"(outv[0]), "+v"(outv[15]), "+v"(acc_in[15]));
-        __builtin_amdgcn_sched_barrier(0);
-        FT_MARK(3);                                             // P reads from LDS, previous state from HBM, gate arithmetic
-        __builtin_amdgcn_sched_barrier(0);
-#endif
         if (a.logit_part) {
             float p = 0.f;
 #pragma unroll
@@ -1483,63 +1417,22 @@ __global__ __launch_bounds__(WPB * 64) void k_gru_fwd_split_tiled(GruFwdArgs a, 
                 p += outv[4 * q] * w.x + outv[4 * q + 1] * w.y + outv[4 * q + 2] * w.z + outv[4 * q + 3] * w.w;
             }
             p += __shfl_xor(p, 32);
-#ifdef FT_EXP_NOLOGITSTORE
-            asm volatile("" :: "v"(p));
-#else
             if (half == 0 && r0 + c < a.R) a.logit_part[(size_t)(cw0 / 32) * a.part_stride + row] = p;
-#endif
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // every read of the staged P rows is back: the area is free
-#ifdef FT_TIMELINE
-        __builtin_amdgcn_sched_barrier(0);
-        FT_MARK(4);                                             // output-head partial
-        __builtin_amdgcn_sched_barrier(0);
-#endif
         stage_store32(stg, c, half, lane, outv, a.h_out, a.ld_out, cw0, row, r0, a.R);
-#ifdef FT_TIMELINE
-        __builtin_amdgcn_sched_barrier(0);
-        FT_MARK(5);                                             // h_out through the staging tile
-        __builtin_amdgcn_sched_barrier(0);
-#endif
         if (a.gates) {
             stage_store32<true>(stg, c, half, lane, acc_r, a.gates, H, cw0, row, r0, a.R);
             stage_store32<true>(stg, c, half, lane, acc_z, a.gates + a.gate_plane, H, cw0, row, r0, a.R);
             stage_store32<true>(stg, c, half, lane, acc_in, a.gates + 2 * a.gate_plane, H, cw0, row, r0, a.R);
             stage_store32<true>(stg, c, half, lane, acc_hn, a.gates + 3 * a.gate_plane, H, cw0, row, r0, a.R);
         }
-#ifdef FT_TIMELINE
-        __builtin_amdgcn_sched_barrier(0);
-        FT_MARK(6);                                             // the four gate planes
-        __builtin_amdgcn_sched_barrier(0);
-        ++ft_items;
-#endif
         if (!nvalid) break;
         cw0 = ncw0; t = nt; ix = nix;
         if (ix.nd <= TCAP) FT_STAGE_P<H>(a, ix, cw0, lane, area);      // (the staging tile's last reads are back: stage_store32)
-#ifdef FT_TIMELINE
-        __builtin_amdgcn_sched_barrier(0);
-        FT_MARK(7);                                             // DMA requests of the next item's P rows
-        __builtin_amdgcn_sched_barrier(0);
-#endif
     }
-#ifdef FT_TIMELINE
-    if (lane == 0) {
-        for (int i = 0; i < 8; ++i) atomicAdd(&g_ft_timeline[i], ft_acc[i]);
-        atomicAdd(&g_ft_timeline[8], ft_items);
-    }
-#endif
 }
 
-#ifdef FT_TIMELINE
-extern "C" int tmpnn_debug_ft_timeline(unsigned long long* out16, int reset) {
-    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_ft_timeline), sizeof(unsigned long long) * 16) != hipSuccess) return -1;
-    if (reset) {
-        unsigned long long z[16] = {};
-        if (hipMemcpyToSymbol(HIP_SYMBOL(g_ft_timeline), z, sizeof(z)) != hipSuccess) return -1;
-    }
-    return 0;
-}
-#endif
 
 // ---- the tiled forward at FOUR waves per SIMD (edge tiles of 16 rows) ------------------------------------------------------
 // The s_memtime profile of k_gru_fwd_split_tiled (tools/fwd_timeline.py) shows what holds it: an item is one dependent
@@ -1593,11 +1486,7 @@ __device__ __forceinline__ int t16_det(const FwdTiles& tl, const T16Idx& x, int 
     return tl.t_dets[x.dp0 + min(lane, max(x.nd - 1, 0))];
 }
 __device__ __forceinline__ void nt_store4(float* p, const f32x4& v) {
-#ifdef T16_PLAIN_STORES
-    *reinterpret_cast<f32x4*>(p) = v;
-#else
     __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(p));
-#endif
 }
 
 template <int H, int WPB>
@@ -3391,18 +3280,7 @@ __device__ __forceinline__ f32x16 mfma32_c(const uint4 (&a)[3], const uint4 (&b)
     return mfma_bf16(a[0], b[0], acc);
 }
 
-#ifdef TWO_TIMELINE           // build-time instrument (tools/bwd_timeline.py): per-phase s_memtime sums, by role (W_ih / W_hh side)
-__device__ unsigned long long g_two_timeline[2][8];
-#define TWO_MARK(i)                                                           \
-    do {                                                                      \
-        __builtin_amdgcn_sched_barrier(0);                                    \
-        const unsigned long long now_ = __builtin_amdgcn_s_memtime();         \
-        tw_acc[(i)] += now_ - tw_last; tw_last = now_;                        \
-        __builtin_amdgcn_sched_barrier(0);                                    \
-    } while (0)
-#else
 #define TWO_MARK(i) do { } while (0)
-#endif
 struct TwoRaw { float4 dh, r, z, n, hn, hp, xa, xb, ea, eb; float dy; };
 // (the gate planes are read exactly once; requesting them nontemporal was measured to change nothing: 3.87-3.88 vs 3.87-3.90 ms
 //  per 6.03 M rows, the L1's pending-request queue is full either way -- switch removed in round 4)
@@ -3619,10 +3497,6 @@ __global__ __launch_bounds__(512) void k_gru_bwd_two(GruBwdFusedArgs a, int ntil
         }                                                                                                    \
         if (TWO_SCHED == 0) __builtin_amdgcn_sched_barrier(0);                                               \
     } while (0)
-#ifdef TWO_TIMELINE
-    unsigned long long tw_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    unsigned long long tw_last = __builtin_amdgcn_s_memtime();
-#endif
     for (int it = 0; it < nmine; ++it) {
         const int tile = blockIdx.x + it * G;
         uint16_t* const cur = lds16 + (it & 1) * BUF;
@@ -3683,9 +3557,6 @@ __global__ __launch_bounds__(512) void k_gru_bwd_two(GruBwdFusedArgs a, int ntil
                 }
             }
             if (TWO_SCHED == 0) __builtin_amdgcn_sched_barrier(0);
-#ifdef TWO_TIMELINE
-            asm volatile("" : "+v"(acc[j][0]));
-#endif
             TWO_MARK(2);                                        // six 32 x 32 x 16 MFMAs of dW + the bias dot products
 #pragma unroll
             for (int pc = 0; pc < 3; ++pc) bd[pc] = *reinterpret_cast<const uint4*>(pd + pc * PA);
@@ -3706,9 +3577,6 @@ __global__ __launch_bounds__(512) void k_gru_bwd_two(GruBwdFusedArgs a, int ntil
             // ---- staging slice s6 of the next tile; what it freed is requested for the tile after that
             if (TWO_SCHED == 0) TWO_STAGE(0);
             __builtin_amdgcn_sched_barrier(0);
-#ifdef TWO_TIMELINE
-            asm volatile("" : "+v"(accd[0][0]), "+v"(accd[1][0]));
-#endif
             TWO_MARK(3);                                        // row operand reads + twelve 16 x 16 x 32 MFMAs of the data product
         }
         // the staged tile's successor becomes the tile being staged; its successor's row id is fetched
@@ -3745,12 +3613,6 @@ __global__ __launch_bounds__(512) void k_gru_bwd_two(GruBwdFusedArgs a, int ntil
         __syncthreads();
         TWO_MARK(5);                                            // barrier
     }
-#ifdef TWO_TIMELINE
-    if (lane == 0) {
-        for (int i = 0; i < 6; ++i) atomicAdd(&g_two_timeline[role][i], tw_acc[i]);
-        atomicAdd(&g_two_timeline[role][6], (unsigned long long)nmine);
-    }
-#endif
 #undef TWO_STAGE
 #undef TWO_GATHER_IDS
 #undef TWO_ISSUE_GATHER
@@ -3785,16 +3647,6 @@ __global__ __launch_bounds__(512) void k_gru_bwd_two(GruBwdFusedArgs a, int ntil
     }
 }
 
-#ifdef TWO_TIMELINE
-extern "C" int tmpnn_debug_two_timeline(unsigned long long* out16, int reset) {
-    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_two_timeline), sizeof(unsigned long long) * 16) != hipSuccess) return -1;
-    if (reset) {
-        unsigned long long z[16] = {};
-        if (hipMemcpyToSymbol(HIP_SYMBOL(g_two_timeline), z, sizeof(z)) != hipSuccess) return -1;
-    }
-    return 0;
-}
-#endif
 
 // dW_ih[j][k] += sum_rs slab[rs][j][k], k < IN ; dW_hh[j][k-IN] += ... ; biases likewise
 __global__ void k_gru_reduce_w(const float* __restrict__ slab_w, const float* __restrict__ slab_b, int n_rs,

@@ -573,10 +573,6 @@ __global__ __launch_bounds__(ITW_NW * 64) void k_itw_fwd(ItFwdArgs a) {
                 for (int i = 0; i < nr; i += 2) {
                     const int i1 = min(i + 1, nr - 1);
                     float acc0 = b2, acc1 = b2;
-#ifdef ITW_ABL_NOPROD       // (timing ablation, wrong results: -DTMPNN_ABLATE builds only)
-                    acc0 += s_a[i * 64 + c]; acc1 += s_a[i1 * 64 + c];
-                    if (false)
-#endif
 #pragma unroll
                     for (int k4 = 0; k4 < 16; ++k4) {
                         const float4 a0 = *reinterpret_cast<const float4*>(s_a + i * 64 + 4 * k4);
@@ -681,10 +677,6 @@ __global__ __launch_bounds__(ITW_NW * 64) void k_itw_bwd(ItBwdArgs a) {
                     const float yh = cyh[i * 64];
                     const float av = fmaxf(yh * gam + bet, 0.f);
                     float da0 = 0.f, da1 = 0.f;
-#ifdef ITW_ABL_NOPROD
-                    da0 = s_d[i * 64 + c];
-                    if (false)
-#endif
 #pragma unroll
                     for (int j4 = 0; j4 < 16; ++j4) {
                         const float4 dv = *reinterpret_cast<const float4*>(s_d + i * 64 + 4 * j4);

@@ -347,19 +347,7 @@ __device__ void hg_wave_solve64(HgShared& S, const float* C, int sr, int sc, int
 // What a timestep's passes need of an edge (the timestep it leads into, its endpoints' det indices, its cost) and of a det (its
 // timestep) is read ONCE into registers (four edges / dets per thread): a pass is then LDS and register work, not a chain of
 // dependent global loads per timestep; the result is kept per det index in LDS and written out once at the end.
-#ifdef TK_TIMELINE
-__device__ unsigned long long g_tk_timeline[16];
-#define HG_STAMP(i)                                                                               \
-    do {                                                                                          \
-        if (threadIdx.x == 0) {                                                                   \
-            const unsigned long long now_ = __builtin_amdgcn_s_memtime();                         \
-            atomicAdd(&g_tk_timeline[(i)], now_ - hg_last);                                       \
-            hg_last = now_;                                                                       \
-        }                                                                                         \
-    } while (0)
-#else
 #define HG_STAMP(i) do { } while (0)
-#endif
 __device__ void d_track_hungarian(tmpnn_dgraph g, const int32_t* __restrict__ ts, const int32_t* __restrict__ det_id,
                                   const float* __restrict__ score, int32_t* __restrict__ assoc, int32_t* __restrict__ status,
                                   float* __restrict__ cost_ws, int cost_ws_floats, const int* remap = nullptr, int n_out = 0) {
@@ -390,9 +378,6 @@ __device__ void d_track_hungarian(tmpnn_dgraph g, const int32_t* __restrict__ ts
     __syncthreads();
     if (E == 0 || Dn == 0) return;
     int t_done = -0x7fffffff;
-#ifdef TK_TIMELINE
-    unsigned long long hg_last = __builtin_amdgcn_s_memtime();
-#endif
     // (an iteration starts with no timestep chosen, no det range and no row flags: set here, and again inside the loop once
     //  everyone has read them -- one barrier less than doing it at the top)
     if (tid == 0) { S.tnext = 0x7fffffff; S.d0 = 0x7fffffff; S.d1 = -1; }
@@ -807,19 +792,7 @@ __global__ __launch_bounds__(TK_THREADS) void k_track_finalize(tmpnn_dgraph g, c
 // ---- decode_tracks for LDS-sized graphs: the decisions as phases of one 1024-thread block, the state rows behind it ----------
 // (a greedy timestep's GPU time is ~10 dependent launches of 2-8 us kernels; each launch saved is ~2 us of device gap and ~2 us
 //  of host time)
-#ifdef TK_TIMELINE            // (profiling build: s_memtime sums per phase of k_track_retire, thread 0; tools/track_timeline.py)
-#define TK_STAMP(i)                                                                               \
-    do {                                                                                          \
-        __syncthreads();                                                                          \
-        if (threadIdx.x == 0) {                                                                   \
-            const unsigned long long now_ = __builtin_amdgcn_s_memtime();                         \
-            atomicAdd(&g_tk_timeline[(i)], now_ - tk_last);                                       \
-            tk_last = now_;                                                                       \
-        }                                                                                         \
-    } while (0)
-#else
 #define TK_STAMP(i) do { } while (0)
-#endif
 __global__ __launch_bounds__(TK_THREADS) void k_track_retire(tmpnn_dgraph g, tmpnn_track_rows r, const float* __restrict__ score,
                                                              int associate, int t_upto, int ret_win,
                                                              int32_t* __restrict__ y_track, int ND,
@@ -829,10 +802,6 @@ __global__ __launch_bounds__(TK_THREADS) void k_track_retire(tmpnn_dgraph g, tmp
                                                              int32_t* __restrict__ fin_ws /* unused by the finalisation at this
                                                              size (a kernel argument because a literal null in its LDS /
                                                              global pointer select crashes hipcc) */, int hung_floats) {
-#ifdef TK_TIMELINE
-    unsigned long long tk_last = __builtin_amdgcn_s_memtime();
-    if (threadIdx.x == 0) atomicAdd(&g_tk_timeline[15], 1ull);
-#endif
     if (associate == 2) {                       // optimal assignment per timestep (--hungarian); its cost scratch rides in fin_ws
         if (threadIdx.x == 0) small[1] = 0;
         __syncthreads();
@@ -921,16 +890,6 @@ __global__ __launch_bounds__(256) void k_track_load(int N, int ND, const int32_t
 using namespace tmpnn;
 
 extern "C" {
-#ifdef TK_TIMELINE
-int tmpnn_debug_tk_timeline(unsigned long long* host_out, int reset) {     // (profiling build only: synchronises)
-    if (hipMemcpyFromSymbol(host_out, HIP_SYMBOL(tmpnn::g_tk_timeline), sizeof(unsigned long long) * 16) != hipSuccess) return -1;
-    if (reset) {
-        unsigned long long z[16] = {0};
-        if (hipMemcpyToSymbol(HIP_SYMBOL(tmpnn::g_tk_timeline), z, sizeof(z)) != hipSuccess) return -1;
-    }
-    return 0;
-}
-#endif
 
 
 int tmpnn_track_associate(const tmpnn_dgraph* g, const int32_t* det_id, const uint8_t* labels, const float* score,

@@ -511,9 +511,7 @@ __device__ __forceinline__ void ring_wait_barrier() {       // own DMAs down to 
     else if constexpr (N >= 8) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
     else if constexpr (N >= 4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-#ifndef WT_NOBAR
     __builtin_amdgcn_s_barrier();
-#endif
     asm volatile("" ::: "memory");
 }
 
@@ -541,9 +539,6 @@ __device__ __forceinline__ void ring_dma(const WideArgs& a, const RingCtx& c, in
 //   ring_compute: 18 MFMAs on operands that are all in registers
 struct RingOps { float4 lo, hi; uint4 af[3]; uint4 bf[9]; };
 __device__ __forceinline__ void ring_read(const char* slot_base, int a_off0, int a_off1, int b_off, RingOps& o) {
-#ifdef WT_NOREAD
-    return;
-#endif
     o.lo = *reinterpret_cast<const float4*>(slot_base + a_off0);
     o.hi = *reinterpret_cast<const float4*>(slot_base + a_off1);
     const char* sb = slot_base + RG_A + b_off;
@@ -553,9 +548,6 @@ __device__ __forceinline__ void ring_read(const char* slot_base, int a_off0, int
         for (int p = 0; p < 3; ++p) o.bf[ct * 3 + p] = *reinterpret_cast<const uint4*>(sb + ct * 64 * 32 + p * 192 * 32);
 }
 __device__ __forceinline__ void ring_split(RingOps& o) {
-#ifdef WT_NOSPLIT
-    return;
-#endif
     w_split2(o.lo.x, o.lo.y, o.af[0].x, o.af[1].x, o.af[2].x);
     w_split2(o.lo.z, o.lo.w, o.af[0].y, o.af[1].y, o.af[2].y);
     w_split2(o.hi.x, o.hi.y, o.af[0].z, o.af[1].z, o.af[2].z);
@@ -581,16 +573,8 @@ __device__ __forceinline__ void ring_compute(const RingOps& o, f32x16 (&acc)[3])
     }
 }
 
-#if defined(WT_NOMMA)
-#define RING_MMA(...) asm volatile("" ::: "memory")
-#else
 #define RING_MMA(...) ring_compute(__VA_ARGS__)
-#endif
-#if defined(WT_NODMA)
-#define RING_DMA(...) asm volatile("" ::: "memory")
-#else
 #define RING_DMA(...) ring_dma(__VA_ARGS__)
-#endif
 // the next step's A split (about 50 vector-ALU instructions) woven between this step's 18 MFMAs: three MFMAs cover the
 // LDS round trip of the raw fragment, then three vector instructions per MFMA
 #define RING_WEAVE()                                                                                   \
@@ -756,13 +740,11 @@ __global__ __launch_bounds__(512) void k_wide_gru_fwd_ring(WideArgs a, WideTiles
         //  use of the row id it loaded an item ago, and anywhere else that wait would drain the DMAs in flight)
         if (last_chunk && more_tiles) pa_next = reinterpret_cast<const char*>(a.A + (size_t)max(a_row_next, 0) * a.lda + 4 * dchunk);
         ring_wait_barrier<0>();                               // every wave has its last operands: sC may overwrite the ring
-#ifndef WT_NO_HP_PIN
         // (hipcc must see the state rows as landed HERE: with them still pending in its books -- and a branch-dependent
         //  number of stores behind them -- it waits vmcnt(0) before each epilogue row, i.e. for the previous row's stores:
         //  12.21 -> 11.95 ms per C5 iteration)
 #pragma unroll
         for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(hp[i]));
-#endif
         RING_MMA(R[1], acc);
         const int nbx = last_chunk ? 0 : bx + 1;
         const bool more = !last_chunk || more_tiles;
@@ -775,9 +757,6 @@ __global__ __launch_bounds__(512) void k_wide_gru_fwd_ring(WideArgs a, WideTiles
                     sC[(32 * wr + w_acc_row(reg, half)) * 192 + 64 * gate + 32 * wc + cl] = acc[gate][reg];
         }
         __syncthreads();
-#if defined(WT_NOEPI)
-        if (a.gates == reinterpret_cast<float*>(8)) sC[tid] = hp[0][0] + hp[1][1] + hp[2][2] + hp[3][3];
-#else
         {
             const int te = opaque(tid), q = te & 15;
 #pragma unroll
@@ -809,31 +788,17 @@ __global__ __launch_bounds__(512) void k_wide_gru_fwd_ring(WideArgs a, WideTiles
                 float4 o_h, o_r, o_z, o_n, o_hn;
                 gru_gate4(s_r, d_r, s_z, d_z, s_n, d_n, ghr, ghz, ghn, sBias, q, make_float4(hp[i][0], hp[i][1], hp[i][2], hp[i][3]), o_h, o_r, o_z, o_n, o_hn);
                 const int col = hc0 + 4 * q;
-#if defined(WT_NOSTORE)
-                if (o_h.x + o_r.y + o_z.z + o_n.w + o_hn.x == 123.456f)
-#endif
                 *reinterpret_cast<float4*>(a.h_out + (size_t)grow * a.ld_out + col) = o_h;
-#if defined(WT_NOSTORE)
-                if (o_h.x + o_r.y + o_z.z + o_n.w + o_hn.x == 123.456f)
-#endif
                 if (a.gates) {
                     float* gp = a.gates + (size_t)grow * H + col;
-#ifndef WT_PLAIN_GATE_STORES     // (C5: 12.40 -> 12.03 ms) the planes are next read by the backward pass: streamed past L2, where this block's A rows wait for reuse
                     auto nt4 = [](float* p, const float4& v) {
                         wf32x4 x; x[0] = v.x; x[1] = v.y; x[2] = v.z; x[3] = v.w;
                         __builtin_nontemporal_store(x, reinterpret_cast<wf32x4*>(p));
                     };
                     nt4(gp, o_r); nt4(gp + a.gate_plane, o_z); nt4(gp + 2 * a.gate_plane, o_n); nt4(gp + 3 * a.gate_plane, o_hn);
-#else
-                    *reinterpret_cast<float4*>(gp) = o_r;
-                    *reinterpret_cast<float4*>(gp + a.gate_plane) = o_z;
-                    *reinterpret_cast<float4*>(gp + 2 * a.gate_plane) = o_n;
-                    *reinterpret_cast<float4*>(gp + 3 * a.gate_plane) = o_hn;
-#endif
                 }
             }
         }
-#endif
         __syncthreads();
         if (!more) break;
         if (last_chunk) {
@@ -887,21 +852,9 @@ static constexpr int PP_OFF_P = PP_OFF_B + 4 * PP_BH;                 // staged 
 static constexpr int PP_OFF_D = PP_OFF_P + PP_NDMAX * 384 * 4;        // tile descriptors, double buffered: [row 128][loc 128][det 256]
 static constexpr int PP_DESC = (128 + 128 + 256) * 4;
 static constexpr int PP_OFF_X = PP_OFF_D + 2 * PP_DESC;               // 1 KB nobody reads: target of the filler piece
-#if defined(W3_TIMELINE)       // (profiling build: s_memtime stamps of block 0's second item, 32 per wave; tools/wide_pp_timeline.py)
-__device__ uint64_t g_pp_timeline[256];
-static constexpr int PP_OFF_T = PP_OFF_X + 1024;
-static constexpr size_t W_PP_SHM = PP_OFF_T + 2048;
-#define PP_STAMP(k) do { if (tl_on) { uint64_t t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory");   \
-                                      if (lane == 0 && (k) >= 0 && (k) < 32) reinterpret_cast<uint64_t*>(lds + PP_OFF_T)[wave * 32 + (k)] = t_; } } while (0)
-#else
 static constexpr size_t W_PP_SHM = PP_OFF_X + 1024;
 #define PP_STAMP(k) do { } while (0)
-#endif
-#if defined(W3_TIMELINE)
-#define PP_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
-#else
 #define PP_LGKM0() do { } while (0)
-#endif
 
 struct PpOps { uint4 af[3]; uint4 bf[18]; };      // bf[(ct * 3 + gate) * 3 + piece], ct = 32-column group of the wave's 64 hidden columns
 
@@ -948,9 +901,6 @@ struct PpDma {
 #define PP_LOAD_PRIO 2     // s_setprio of a wave inside its LOAD segment (0 inside its MMA segment): its few requests / reads / split
 #endif                     // instructions then win the SIMD's issue arbitration against the partner's MFMA stream, which needs a slot every 32 cycles only
 __device__ __forceinline__ void pp_dma_b1(const PpDma& d, int j, int c, int hx_dst, int par, int k) {       // piece k of the wave's group
-#if defined(W3_NODMA)
-    return;
-#endif
     const int q = (d.wi < 2 ? 5 * d.wi : 2 + 4 * d.wi) + k;
     const void* src = uniform_ptr(d.img + (size_t)((j * d.nchunk + c) * 2 + hx_dst) * PP_BH + 1024u * q);
     const uint32_t dst = __builtin_amdgcn_readfirstlane(d.lds + PP_OFF_B + (uint32_t)(par * 2 + hx_dst) * PP_BH + 1024u * q);
@@ -995,20 +945,10 @@ __device__ __forceinline__ void pp_split2(float x0, float x1, uint32_t& p1, uint
     p3 = w_pk(r0, r1);
 }
 __device__ __forceinline__ void pp_split(const float4& lo, const float4& hi, PpOps& o) {
-#if defined(W3_NOSPLIT)
-    return;
-#endif
-#if defined(PP_PACKED_SPLIT)
-    w_split2(lo.x, lo.y, o.af[0].x, o.af[1].x, o.af[2].x);
-    w_split2(lo.z, lo.w, o.af[0].y, o.af[1].y, o.af[2].y);
-    w_split2(hi.x, hi.y, o.af[0].z, o.af[1].z, o.af[2].z);
-    w_split2(hi.z, hi.w, o.af[0].w, o.af[1].w, o.af[2].w);
-#else
     pp_split2(lo.x, lo.y, o.af[0].x, o.af[1].x, o.af[2].x);
     pp_split2(lo.z, lo.w, o.af[0].y, o.af[1].y, o.af[2].y);
     pp_split2(hi.x, hi.y, o.af[0].z, o.af[1].z, o.af[2].z);
     pp_split2(hi.z, hi.w, o.af[0].w, o.af[1].w, o.af[2].w);
-#endif
 }
 __device__ __forceinline__ void pp_pin(PpOps& o) {      // (as ring_pin: the split stays in the LOAD segment that formed it)
     asm volatile("" : "+v"(o.af[0].x), "+v"(o.af[0].y), "+v"(o.af[0].z), "+v"(o.af[0].w), "+v"(o.af[1].x), "+v"(o.af[1].y),
@@ -1021,7 +961,6 @@ __device__ __forceinline__ void pp_mma(const PpOps& o, f32x16 (&acc)[6], const P
                                        uint32_t adst) {
 #pragma unroll
     for (int t = 0; t < 6; ++t) {
-#if !defined(W3_NOMMA)
         f32x16 c = acc[t];
         c = w_mfma(o.af[2], o.bf[t * 3], c);        // smallest terms first (as wide_mma / ring_compute)
         c = w_mfma(o.af[0], o.bf[t * 3 + 2], c);
@@ -1030,13 +969,10 @@ __device__ __forceinline__ void pp_mma(const PpOps& o, f32x16 (&acc)[6], const P
         c = w_mfma(o.af[0], o.bf[t * 3 + 1], c);
         c = w_mfma(o.af[0], o.bf[t * 3], c);
         acc[t] = c;
-#endif
         __builtin_amdgcn_sched_barrier(0);
-#if !defined(W3_NODMA)
         if (t < 4) pp_dma_b1(d, jm, cm, hxm, parm, t);
         else if (t == 4) { if (d.nb == 5) pp_dma_b1(d, jm, cm, hxm, parm, 4); }
         else glds16(asrc, adst);
-#endif
         __builtin_amdgcn_sched_barrier(0);
     }
 }
@@ -1125,9 +1061,6 @@ __device__ __forceinline__ void pp_epilogue(const WideArgs& a, const f32x16 (&ac
 #pragma unroll
             for (int ct = 0; ct < 2; ++ct) {
                 const int e = 2 * j + ct;
-#if defined(W3_NOSTORE)
-                if (oh[e] + orr[e] + ozz[e] + onn[e] + vhn[e] == 123.456f)
-#endif
                 {
                     a.h_out[(size_t)rws[j] * a.ld_out + colw + 32 * ct] = oh[e];
                     if constexpr (GATES) {
@@ -1211,9 +1144,6 @@ __device__ __forceinline__ void pp_half(const WideArgs& a, const WideTiles& tl, 
     }
     pp_barrier();
     int bx = 0;
-#if defined(W3_TIMELINE)
-    int item_no = 0;
-#endif
     for (;;) {
         const int hc0 = bx << 7;
         const bool last_chunk = bx + 1 == nchunk;
@@ -1227,9 +1157,6 @@ __device__ __forceinline__ void pp_half(const WideArgs& a, const WideTiles& tl, 
         int a_row_next = 0;
         if (last_chunk && more_tiles) a_row_next = desc_row(t + G, drow);  // (needed by the last four steps' A requests)
         const char* pa_n = pa;
-#if defined(W3_TIMELINE)
-        const bool tl_on = blockIdx.x == 0 && item_no == 1;
-#endif
         f32x16 acc[6];
 #pragma unroll
         for (int j = 0; j < 6; ++j)
@@ -1251,11 +1178,7 @@ __device__ __forceinline__ void pp_half(const WideArgs& a, const WideTiles& tl, 
         // U = p & 3 is a compile-time constant (slots).  Steps past the item's end are the next item's first ones.
         // READ = false: X's last step of an item -- the requests of the interval, but the reads of the next item's step 0 wait
         // until X's epilogue is through (its operand registers would otherwise be alive across the epilogue).
-#if defined(W3_NODMA)
-#define PP_REQ(x) asm volatile("" ::: "memory")
-#else
 #define PP_REQ(x) x
-#endif
         // A step's requests: the weight pieces and the A piece ride in the wave's MMA segment (pp_mma), the staged-P piece in
         // its LOAD segment.  X, MMA(p): weights of step p + 1 for half Y (JB_, CH_), A rows 0-63 of step p + 3 (JA_);
         // Y, MMA(p): weights of step p + 2 for half X, A rows 64-127 of step p + 3.  LOAD segments: the reads are requested
@@ -1343,16 +1266,6 @@ __device__ __forceinline__ void pp_half(const WideArgs& a, const WideTiles& tl, 
         // ---- epilogue, from the accumulators (staged P rows or through the tile's det list; with / without the gate planes:
         //      compile-time forms -- a pointer that may be LDS or global becomes a flat load, which waits for everything)
         PP_STAMP(31);
-#if defined(W3_NOEPI)
-        {                                  // (timing build: the accumulators must stay alive or the MFMAs are removed with them)
-            float sm = 0.f;
-#pragma unroll
-            for (int j = 0; j < 6; ++j)
-#pragma unroll
-                for (int q = 0; q < 16; ++q) sm += acc[j][q];
-            a.h_out[(size_t)dsc[32 * wr] * a.ld_out + hc0 + (lane & 63)] = sm;
-        }
-#else
         if (staged) {
             if (a.gates) pp_epilogue<HX, true, true>(a, acc, sP, dsc, hc0, wr, hh, lane);
             else pp_epilogue<HX, true, false>(a, acc, sP, dsc, hc0, wr, hh, lane);
@@ -1360,15 +1273,6 @@ __device__ __forceinline__ void pp_half(const WideArgs& a, const WideTiles& tl, 
             if (a.gates) pp_epilogue<HX, false, true>(a, acc, sP, dsc, hc0, wr, hh, lane);
             else pp_epilogue<HX, false, false>(a, acc, sP, dsc, hc0, wr, hh, lane);
         }
-#endif
-#if defined(W3_TIMELINE)
-        PP_STAMP(30);
-        if (tl_on) {
-            __syncthreads();
-            if (tid < 256) g_pp_timeline[tid] = reinterpret_cast<const uint64_t*>(lds + PP_OFF_T)[tid];
-        }
-        ++item_no;
-#endif
         if (!more) break;
         if (last_chunk) {
             int* ds = reinterpret_cast<int*>(lds + PP_OFF_D + (par_d ^ 1) * PP_DESC);
@@ -1790,15 +1694,8 @@ static constexpr int GP_BH = 3 * 128 * 32;                             // weight
 static constexpr int GP_OFF_B = GP_NA * GP_A;
 static constexpr int GP_OFF_S = GP_OFF_B + 4 * GP_BH;                 // the split A pieces X publishes for Y: [step parity 2][piece 3][128 rows][32 B]
 static constexpr int GP_S = 3 * 128 * 32;
-#if defined(W3_TIMELINE)
-static constexpr int GP_OFF_T = GP_OFF_S + 2 * GP_S;
-static constexpr size_t W_GEMM_PP_SHM = GP_OFF_T + 2048;
-#define GP_STAMP(k) do { if (tl_on) { uint64_t t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory");   \
-                                      if (lane == 0 && (k) >= 0 && (k) < 32) reinterpret_cast<uint64_t*>(lds + GP_OFF_T)[wave * 32 + (k)] = t_; } } while (0)
-#else
 static constexpr size_t W_GEMM_PP_SHM = GP_OFF_S + 2 * GP_S;          // 104 KB
 #define GP_STAMP(k) do { } while (0)
-#endif
 struct GpOps { uint4 af[3]; uint4 bf[12]; };                           // bf[ct * 3 + piece]
 
 // 4 x 4 transpose across the four lanes of a quad (DPP quad_perm): in, lane k holds column k of rows 0..3 in a0..a3; out,
@@ -2501,13 +2398,11 @@ __global__ __launch_bounds__(512) void k_wide_dw2(WideDwArgs q, int mt_count, in
     // slots of ONE XCD, so the second reader of a row finds it in that XCD's L2 (same partition and sums: only the
     // placement of the blocks changes; -DWT_DW_PLAIN_ORDER keeps tile = blockIdx.x, slab = blockIdx.y).
     int tile = blockIdx.x, slab = blockIdx.y;
-#ifndef WT_DW_PLAIN_ORDER
     if ((gridDim.y & 7) == 0) {
         const int id = blockIdx.x + gridDim.x * blockIdx.y, slot = id >> 3;
         tile = slot % (int)gridDim.x;
         slab = (id & 7) + 8 * (slot / (int)gridDim.x);
     }
-#endif
     const int mt = tile / nt_count, nt = tile % nt_count;
     const int H = q.H;
     const int srow = tid >> 5, c32 = tid & 31;                       // staging: 16 rows x 32 threads
@@ -2606,11 +2501,6 @@ __global__ __launch_bounds__(512) void k_wide_dw2(WideDwArgs q, int mt_count, in
 #pragma unroll
             for (int b = 0; b < 2; ++b) {
                 f32x16 v = acc[j][b];
-#ifdef WT_DW_NOMMA                                          // (timing ablations, wrong results: -DWT_DW_NOMMA / NOSTAGE / NOLOAD)
-                v[0] += __uint_as_float(aq[0].x ^ aq[1].y ^ aq[2].z ^ bq[b][0].x ^ bq[b][1].y ^ bq[b][2].z);
-                acc[j][b] = v;
-                continue;
-#endif
                 v = w_mfma(aq[2], bq[b][0], v);
                 v = w_mfma(aq[0], bq[b][2], v);
                 v = w_mfma(aq[1], bq[b][1], v);
@@ -2631,13 +2521,9 @@ __global__ __launch_bounds__(512) void k_wide_dw2(WideDwArgs q, int mt_count, in
         __builtin_amdgcn_sched_barrier(0);
         asm volatile("" : "+v"(raw.a[0]), "+v"(raw.a[1]), "+v"(raw.a[2]), "+v"(raw.b0), "+v"(raw.b1) : : "memory");
         uint16_t* nA = base + ((ch & 1) ^ 1) * (DW2_A + DW2_B);
-#ifndef WT_DW_NOSTAGE
         stage(raw, nA, nA + DW2_A);                      // chunk ch + 1
-#endif
-#ifndef WT_DW_NOLOAD
         dw2_rows<XB>(q, ca, cb, raw);                    // chunk ch + 3 (its indices: requested two chunks ago)
         dw2_index<XB>(q, r_lo + (ch + 5) * 16 + srow, r_end, raw);
-#endif
         __syncthreads();
     };
     for (int ch = 0; ch < nchunk; ch += 2) {
@@ -2669,18 +2555,10 @@ __global__ __launch_bounds__(512) void k_wide_dw2(WideDwArgs q, int mt_count, in
     }
 }
 
-#ifdef WT_DW_OLD
-static constexpr int DW_TILE_M = 192, DW_CHUNK = 32;
-#else
 static constexpr int DW_TILE_M = 384, DW_CHUNK = 16;
-#endif
 // one launch of the weight-gradient kernel over q.R rows in nslab slabs of q.rows_per_slab rows
 static int launch_dw(const WideDwArgs& q, int nslab, hipStream_t st) {
     const int mt = 3 * q.H / DW_TILE_M, nt = q.H / 128;
-#ifdef WT_DW_OLD
-    TM_SHM_ONCE(k_wide_dw, DW_SHM);
-    hipLaunchKernelGGL(k_wide_dw, dim3(mt * nt, nslab), dim3(512), DW_SHM, st, q, mt, nt);
-#else
     if (q.xb) {
         TM_SHM_ONCE(k_wide_dw2<true>, DW2_SHM);
         hipLaunchKernelGGL(k_wide_dw2<true>, dim3(mt * nt, nslab), dim3(512), DW2_SHM, st, q, mt, nt);
@@ -2688,7 +2566,6 @@ static int launch_dw(const WideDwArgs& q, int nslab, hipStream_t st) {
         TM_SHM_ONCE(k_wide_dw2<false>, DW2_SHM);
         hipLaunchKernelGGL(k_wide_dw2<false>, dim3(mt * nt, nslab), dim3(512), DW2_SHM, st, q, mt, nt);
     }
-#endif
     return check_launch("wide_dw");
 }
 
@@ -2718,13 +2595,11 @@ static int launch_gemm_ring(const WideArgs& a, hipStream_t st, const uint16_t* i
         }
         return check_launch("wide_gemm_pp256");
     }
-#ifndef WT_GEMM_RING128
     if (a.N % 256 == 0) {
         TM_SHM_ONCE(k_wide_gemm_ring256, W_GEMM_RING4_SHM);
         hipLaunchKernelGGL(k_wide_gemm_ring256, dim3(ntile < cus ? ntile : cus), dim3(512), W_GEMM_RING4_SHM, st, a);
         return check_launch("wide_gemm_ring256");
     }
-#endif
     TM_SHM_ONCE(k_wide_gemm_ring, W_GEMM_RING_SHM);
     hipLaunchKernelGGL(k_wide_gemm_ring, dim3(ntile < cus ? ntile : cus), dim3(512), W_GEMM_RING_SHM, st, a);
     return check_launch("wide_gemm_ring");
@@ -2743,11 +2618,6 @@ using namespace tmpnn;
 
 extern "C" {
 
-#if defined(W3_TIMELINE)
-int tmpnn_debug_pp_timeline(uint64_t* host_out) {     // (profiling build only: synchronises)
-    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_pp_timeline), sizeof(uint64_t) * 256) == hipSuccess ? 0 : -1;
-}
-#endif
 int tmpnn_wide_supported(int H, int IN) { return (H >= 128 && H <= 1024 && H % 128 == 0 && IN == H) ? 1 : 0; }
 
 // bytes of the four weight images of one cell: forward hh (K = H, N = 3H), forward ih (K = IN, N = 3H),
@@ -3073,15 +2943,10 @@ static int wide_gru_bwd_diff_impl(const void* prep, const tmpnn_graph* g, const 
     WideArgs y{};
     y.A = dg4; y.lda = 4 * H; y.a_rows = g->edge_row; y.R = R; y.K = 3 * H; y.kskip_at = 2 * H; y.kskip = H;
     y.img = b_hh; y.N = H; y.C = d_h; y.ldc = ld_dh; y.c_rows = g->edge_row; y.accumulate = 1;
-#ifndef WT_GEMM_STORE
     // (the E-row product of the backward: the ring form; its weight image is the sixth of prep)
     y.img = f_hh + (size_t)3 * (4 * 3 * H * H) + (size_t)3 * H * 3 * H;
     y.add_msg = add_msg; y.ld_add = ld_add; y.add_src = g->src; y.add_dst = g->dst;
     if ((rc = launch_gemm_ring(y, st, H == 256 ? y.img + (size_t)2 * 3 * H * 3 * H : nullptr))) return done(rc);
-#else
-    if (add_msg) return done(set_error(TMPNN_EINVAL, "wide_gru_bwd_diff: the store-GEMM build has no fused adjoint"));
-    if ((rc = launch_store(y, st))) return done(rc);
-#endif
     // 3. S[d] = signed segment sum of d_gi (image columns 0..3H) over the det's incident edges, compact rows
     for (int k = 0; k < 3; ++k)
         if ((rc = tmpnn_segsum_fwd(g, dg4 + (size_t)k * H, 4 * H, S + (size_t)k * H, 3 * H, H, 0, 1,
