@@ -306,7 +306,7 @@ def att_stage_profile(g, H, K, train, iters=5):
 
 def split_enabled():
     """The library default: GRU GEMMs on the bf16 matrix pipe as fp32-accurate 3 x 3 split products (bf16x6,
-    csrc/gru.hip); TMPNN_SPLIT=0 keeps them on the f32-input MFMA."""
+    csrc/gru_common.h); TMPNN_SPLIT=0 keeps them on the f32-input MFMA."""
     return os.environ.get('TMPNN_SPLIT', '1')[:1] != '0'
 
 
@@ -325,7 +325,7 @@ def _pmc_kernel(stage):
             'gru_bwd_weights_edge': 'k_gru_bwd_weights_lds<64, 1, 1>'}.get(stage, '?')
 
 
-def kernel_source_digest(files=('gru.hip', 'agg.hip', 'common.h')):
+def kernel_source_digest(files=('gru_common.h', 'gru_fwd.hip', 'gru_bwd.hip', 'agg.hip', 'common.h')):
     """sha256 (first 16 hex digits) of the kernel sources a committed PMC pass belongs to: tools/collect_r05.py records it
     next to the counters, `pmc_traffic` compares it with the tree that is running."""
     import hashlib

@@ -19,7 +19,7 @@ if glob.glob(f'gpurun_out/{tag}_stats/**/*_kernel_stats.csv', recursive=True):
         d['collected'] = datetime.date.today().isoformat()
         d['head'] = subprocess.run(['git', 'rev-parse', '--short=12', 'HEAD'], capture_output=True, text=True).stdout.strip()
         d['kernel_source_digest'] = bench.kernel_source_digest()
-        d['digest_of'] = 'sha256[:16] of trackmpnn_amd/csrc/gru.hip + common.h (bench.kernel_source_digest)'
+        d['digest_of'] = 'sha256[:16] of trackmpnn_amd/csrc/{gru_common.h, gru_fwd.hip, gru_bwd.hip, agg.hip, common.h} (bench.kernel_source_digest)'
         json.dump(d, open(p, 'w'), indent=1)
         print('pmc traffic json: provenance added', d['head'], d['kernel_source_digest'])
 

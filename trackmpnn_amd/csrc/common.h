@@ -101,7 +101,7 @@ int launch_gemm(const GemmArgs& g, hipStream_t st);
 // split-K variant for K >> M,N (weight gradients): partial products go to `ws`, then reduced into C (+=).
 size_t gemm_splitk_ws_floats(int M, int N, int K);
 int launch_gemm_splitk(const GemmArgs& g, float* ws, size_t ws_floats, hipStream_t st);
-// MFMA row products of the small dense stages (csrc/gru.hip, bf16x6 = fp32-accurate, see there):
+// MFMA row products of the small dense stages (csrc/gru_fwd.hip, bf16x6 = fp32-accurate, see there):
 //   out[orow(r)][0:NOUT] (=|+=) in[irow(r)][0:KD] @ W,  W[k][n] = wt[k ld_wt + n] or (wt_trans) wt[n ld_wt + k];
 //   KD in {32, 64, 128}; NOUT / 32 in {1, 2, 4, 6} (KD 64), {1, 2, 3} (KD 32) or {1, 2} (KD 128): rows_gemm_supported(); rows / out_rows: optional row lists (NULL = r).
 bool rows_gemm_supported(int KD, int NOUT);

@@ -1,9 +1,9 @@
 // Wide GRU cells (H = 128 / 256; BASELINE.json C5: H = 256, 4.4 M edge rows per iteration) on the bf16 matrix pipe.
 //
-// At H <= 64 the cell's weight matrices fit the LDS and the kernels of gru.hip keep them resident.  At H = 256 they
+// At H <= 64 the cell's weight matrices fit the LDS and the kernels of gru_fwd.hip / gru_bwd.hip keep them resident.  At H = 256 they
 // are 0.8 MB each, so round 1 streamed them from L2 into f32-input MFMAs (64 / 45 TFLOP/s forward / backward-data).
 // Here the products are LDS-tiled GEMMs on bf16x6 split products (three bf16 pieces per fp32 operand, six
-// v_mfma_f32_32x32x16_bf16 per fp32 product, fp32 accumulate: as accurate as the f32 MFMA chain, see gru.hip), 2.7x
+// v_mfma_f32_32x32x16_bf16 per fp32 product, fp32 accumulate: as accurate as the f32 MFMA chain, see gru_common.h), 2.7x
 // the f32-MFMA ceiling:
 //
 //   block tile 128 rows x 128 (or 3 x 64) columns, K step 32; 8 waves, each a 32 x 64 (or 32 x 3 x 32) sub-tile;
