@@ -1030,9 +1030,10 @@ def test_node_cell_forward_ragged_sizes(R, H):
     cw = H // 32
     parts = torch.full((cw, N), 7.0, device=DEV)
     st = torch.cuda.current_stream().cuda_stream
+    wih_t, whh_t, bihD, bhhD, whD = d(wih.t()), d(whh.t()), d(bih), d(bhh), d(w_head)       # (kept alive over the launch)
     _lib.call('tmpnn_gru_fwd', rowsD.data_ptr(), R, 0, None, None, msgD.data_ptr(), H, 1, H, hD.data_ptr(), H + 4, H,
-              d(wih.t()).data_ptr(), d(whh.t()).data_ptr(), d(bih).data_ptr(), d(bhh).data_ptr(), out.data_ptr(), H,
-              gates.data_ptr(), N * H, d(w_head).data_ptr(), parts.data_ptr(), N, st)
+              wih_t.data_ptr(), whh_t.data_ptr(), bihD.data_ptr(), bhhD.data_ptr(), out.data_ptr(), H,
+              gates.data_ptr(), N * H, whD.data_ptr(), parts.data_ptr(), N, st)
     torch.cuda.synchronize()
     x64, h64 = msg.double(), h[rows, :H].double()
     gi = x64 @ wih.double().t() + bih.double()
