@@ -748,7 +748,17 @@ def scaling_extras(args, rank, world, dev):
     for name, kw, steps in (('c4', dict(windows=args.extras_c4_windows), 3),
                             ('c5', dict(frames=args.extras_c5_frames, dets=args.extras_c5_dets), 2)):
         try:
-            wl = make_workload(name, rank, dev, **kw)
+            wl, err = None, None
+            try:
+                wl = make_workload(name, rank, dev, **kw)          # (no collective inside: a rank may fail here alone, e.g. out of memory)
+            except Exception as e:                                 # noqa: BLE001
+                err = e
+            # every rank learns whether ALL ranks built the workload before the first collective of its steps is issued
+            import torch.distributed as dist
+            ok = torch.tensor([0.0 if wl is None else 1.0], device=dev)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if ok.item() < 1.0:
+                raise err if err is not None else RuntimeError('another rank could not build the workload')
             dt = timed_steps(wl['step'], steps, 1, world, dev, setup=1)
             edges = total_over_ranks(wl['edge_iters'], world, dev)
             out[name] = dict(value=edges * steps / dt, unit='graph-edges/s', ms_per_step=dt / steps * 1e3, steps=steps, warmup=1,
