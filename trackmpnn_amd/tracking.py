@@ -174,8 +174,10 @@ class TrackGraph:
             tg._Xd = X[0].to(tg.device)
             tg._Xf = tg._Xd if (tg._Xd.dtype == torch.float32 and tg._Xd.is_contiguous()) else tg._Xd.float().contiguous()
         tg._sequence(yy, order)
-        tg._yy = yy                                        # (train mode: the active-set SIZE follows from the labels alone, see update)
-        tg._added_ts = [t0, t1]
+        tg._order_host, tg._trk_host = order, trk          # (train mode: the active-set SIZE follows from the labels alone, see update)
+        tg._tr = dict(last={}, dup=False, t_prev=t0, n_prev=0)
+        tg._train_state_add(t0, trk[ids0].tolist())
+        tg._train_state_add(t1, trk[ids1].tolist())
         tg._X_src, tg._y_src = X, y
         tg._src_versions = (X._version, y._version)        # (an in-place edit after initialize() must not pass the identity check)
         tg._y_host = y.detach().cpu() if y.is_cuda else y.detach().clone()
@@ -249,37 +251,30 @@ class TrackGraph:
             self._hung_max = int(_lib.load().tmpnn_track_hungarian_max_dets())
         return 0 < self.N <= DG_MAX_ROWS and self.Dn <= self._hung_max and os.environ.get('TMPNN_HUNGARIAN_HOST', '0') != '1'
 
-    def _train_active_count(self, t: int):
-        """Size of update_graph(mode='train')'s active set at time t, and whether its label rule would assert, from the
-        labels alone (utils/graph.py:228-245, 271-274): active = the dets of the previous non-empty timestep + every
-        true-positive det that is still unassociated.  A TP det's first later same-track det always finds it active (nothing
-        associated it before), so the edge between them exists and is its positive one: a TP det is unassociated iff the
-        graph holds no later det of its track; it would own two positive edges ("More than one GT edge from same node!") iff
-        the first later timestep with dets of its track holds two of them.  Training never deletes rows, so the graph's dets
-        are those of the timesteps added so far.  The device derives the same set (tmpnn_track_select: its order is what the
-        append needs); this spares the host read of its size.  TMPNN_TRACK_VERIFY=1 reads the device count and compares."""
-        yy = self._yy
-        ts_all, trk_all = yy[:, 0], yy[:, 1]
-        m = np.isin(ts_all, np.asarray(self._added_ts, dtype=np.int64))
-        ts, trk = ts_all[m], trk_all[m]
-        t_prev = ts.max()
-        tp = trk >= 0
-        last_of_track = {}
-        if tp.any():
-            order = np.argsort(ts[tp], kind='stable')
-            for k, tt in zip(trk[tp][order], ts[tp][order]):
-                last_of_track[int(k)] = int(tt)             # ascending time: the last write is the track's latest timestep
-        last_ts = np.array([last_of_track.get(int(k), -1) for k in trk], dtype=np.int64)
-        A = int((ts == t_prev).sum() + (tp & (ts == last_ts) & (ts < t_prev)).sum())
-        # the label rule's assertion: a (track, timestep) with two dets behind an earlier det of the same track
-        dup = False
-        if tp.any():
-            key = np.stack([trk[tp], ts[tp]], 1)
-            uniq, cnt = np.unique(key, axis=0, return_counts=True)
-            for (k, td) in uniq[cnt > 1]:
-                if ((trk == k) & (ts < td)).any():
-                    dup = True
-        return A, dup
+    # ---- update_graph(mode='train') without a host read: the active set's SIZE follows from the labels alone -----------------
+    # (utils/graph.py:228-245, 271-274)  active = the dets of the previous non-empty timestep + every true-positive det that is
+    # still unassociated.  A TP det's first later same-track det always finds it active (nothing associated it before), so the
+    # edge between them exists and is its positive one: a TP det is unassociated iff the graph holds no later det of its track,
+    # and it owns two positive edges ("More than one GT edge from same node!", raised by the reference at the NEXT update) iff
+    # that first later timestep holds two dets of its track.  Training never deletes rows.  The state below is a few Python ints
+    # per track, advanced once per appended timestep; the device derives the same set (tmpnn_track_select: the append needs its
+    # order), TMPNN_TRACK_VERIFY=1 reads the device's count as well and compares.
+    def _train_state_add(self, t: int, tracks) -> None:
+        st = self._tr
+        seen = {}
+        for k in tracks:
+            if k >= 0:
+                seen[k] = seen.get(k, 0) + 1
+        for k, m in seen.items():
+            if m > 1 and k in st['last']:
+                st['dup'] = True                           # (an earlier det of track k now has two positive edges)
+            st['last'][k] = (t, m)
+        st['t_prev'], st['n_prev'] = t, len(tracks)
+
+    def _train_active_count(self):
+        st = self._tr
+        tp = st['t_prev']
+        return st['n_prev'] + sum(m for (ts, m) in st['last'].values() if ts < tp), st['dup']
 
     def _hung_scratch(self) -> torch.Tensor:
         if self._hung_ws is None:
@@ -348,7 +343,7 @@ class TrackGraph:
                 return torch.zeros((0, Xd.shape[1]), dtype=Xd.dtype, device=self.device)
             if train and _TRAIN_HOST_COUNTS:
                 # training: the active set's size and the label rule's assertion follow from the labels (no host read)
-                A, dup = self._train_active_count(int(t))
+                A, dup = self._train_active_count()
                 status = 1 if dup else 0
                 if _TRACK_VERIFY:
                     A_dev, st_dev = self._small[:2].tolist()
@@ -375,7 +370,7 @@ class TrackGraph:
                   _lib.ptr(ws), 0 if ws is None else ws.numel(), st)
         self.N, self.E, self.Dn = N + n_new, self.E + A * D, self.Dn + D
         if train:
-            self._added_ts.append(int(t))
+            self._train_state_add(int(t), self._trk_host[self._order_host[lo:hi]].tolist())
         g._meta = (self.E, self.Dn, 0)
         self._graph = g
         return feats if Xd.dtype == torch.float32 else feats.to(Xd.dtype)
