@@ -47,6 +47,16 @@ def build_batch(B, frames, mean_dets, max_dets, F, seed, device):
     return plans, xs, edge_iters
 
 
+def make_adam(model):
+    """optim.Adam(model.parameters(), lr, weight_decay) as train.py:329 constructs it; the single-launch (fused) form of torch's
+    Adam where this torch build offers it for the device (same update rule; the default form is ~20 small launches per step)."""
+    kw = dict(lr=1e-4, weight_decay=5e-4)
+    try:
+        return torch.optim.Adam(model.parameters(), fused=True, **kw)
+    except (RuntimeError, TypeError, ValueError):
+        return torch.optim.Adam(model.parameters(), **kw)
+
+
 def step(model, plans, xs, targets, opt, bucket, world):
     """fwd over every call of the window batch, one backward, (all-reduce), Adam.  Loss: BCE with logits over ALL logits of
     every call against fixed {0,1} targets, summed -- trackmpnn_amd.loss.bce_with_logits_sum, one launch per
@@ -579,7 +589,7 @@ def loop_batch1(budget_s=1.5):
         X, y = sequence(1001, s['frames'], s['mean'], s['mx'], s['ncat'])
         Xi, yi = sequence(2001, LOOP_INFER_FRAMES, s['mean'], s['mx'], s['ncat'])
         model.train()
-        opt = torch.optim.Adam(model.parameters(), lr=1e-4, weight_decay=5e-4)
+        opt = make_adam(model)
 
         def chunk(stages=None):
             opt.zero_grad(set_to_none=True)
@@ -658,7 +668,7 @@ def make_workload(name, rank, dev, windows=None, frames=None, dets=None):
     H, F = w['H'], w['ncat'] + 5
     torch.manual_seed(5)
     model = TrackMPNN('2d', w['ncat'], H, 0, 'diff').to(dev).train()
-    opt = torch.optim.Adam(model.parameters(), lr=1e-4, weight_decay=5e-4)       # train.py:329
+    opt = make_adam(model)                                                        # train.py:329
     bucket = GradBucket(model)      # flat gradient storage for every N: p.grad aliases it, one all-reduce when N > 1
     world = int(os.environ.get('WORLD_SIZE', '1'))
     if w['kind'] == 'rolling':
