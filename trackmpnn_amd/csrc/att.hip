@@ -86,17 +86,15 @@ __global__ __launch_bounds__(256) void k_att_score(AttArgs A) {
     float4 av[KT];
 #pragma unroll
     for (int k = 0; k < KT; ++k) av[k] = ld4(A.a + (size_t)k * H + c4);
-    // a lane group takes U CONSECUTIVE edge rows (round 6; before: rows rpb apart): edges are src-major, so a run of
-    // consecutive rows mostly shares its src det and the group loads that row of ha once per run instead of once per edge
     const long chunk = (long)rpb * U;
-    long e0 = (long)blockIdx.x * chunk + (long)slot * U;
+    long e0 = (long)blockIdx.x * chunk + slot;
     const long step = (long)gridDim.x * chunk;
     const int lane = threadIdx.x & 63, lg = threadIdx.x % lpr, gbase = lane - lg;
     int4 idn[U];                         // (src det, dst det, src position, dst position), held by lane 0 of the group
     auto load_ids = [&](long base) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const long e = base + u;
+            const long e = base + (long)u * rpb;
             const long ec = e < A.E ? e : (A.E - 1);
             idn[u] = *reinterpret_cast<const int4*>(A.erec + 8 * ec);
         }
@@ -108,24 +106,15 @@ __global__ __launch_bounds__(256) void k_att_score(AttArgs A) {
         float4 x[U][KT], y[U][KT];
         int2 pq[U];
         bool ok[U];
-        int sdet_prev = -1;
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            ok[u] = e0 + u < A.E;
+            ok[u] = e0 + (long)u * rpb < A.E;
             const int sdet = __shfl(idn[u].x, gbase), ddet = __shfl(idn[u].y, gbase);
             pq[u] = make_int2(__shfl(idn[u].z, gbase), __shfl(idn[u].w, gbase));
+            const float* ps = A.ha + (size_t)sdet * KH + c4;
             const float* pd = A.ha + (size_t)ddet * KH + c4;
-            if (u > 0 && sdet == sdet_prev) {
 #pragma unroll
-                for (int k = 0; k < KT; ++k) x[u][k] = x[u - 1][k];
-            } else {
-                const float* ps = A.ha + (size_t)sdet * KH + c4;
-#pragma unroll
-                for (int k = 0; k < KT; ++k) x[u][k] = ld4(ps + k * H);
-            }
-#pragma unroll
-            for (int k = 0; k < KT; ++k) y[u][k] = ld4(pd + k * H);
-            sdet_prev = sdet;
+            for (int k = 0; k < KT; ++k) { x[u][k] = ld4(ps + k * H); y[u][k] = ld4(pd + k * H); }
         }
         if (e0 + step < A.E) load_ids(e0 + step);
 #pragma unroll
