@@ -490,6 +490,9 @@ def test_window_segsum_reads_rows_once_and_equals_the_csr_kernel_bitwise():
     import copy
     from trackmpnn_amd import _lib
     from trackmpnn_amd.graph import build_win_plan, win_plan
+    if not hasattr(_lib.load(), 'tmpnn_wide_gru_bwd_data'):
+        pytest.skip('k_segsum_win compiles only with -DTMPNN_KEEP_VARIANTS (tools/build_variants_all.sh; load it with '
+                    'TMPNN_LIB_PATH): the shipped library ignores tmpnn_graph.win_plan')
     dev = torch.device('cuda:0')
     g = _window_batch_graph(200, dev)
     dg = g.__dict__['_det_group']
