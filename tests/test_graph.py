@@ -523,3 +523,39 @@ def test_window_segsum_reads_rows_once_and_equals_the_csr_kernel_bitwise():
             outs = [o[keep] for o in outs]
         for o in outs[1:]:
             assert torch.equal(outs[0], o), (c0, compact, acc)
+
+
+def test_train_mode_active_set_rule_on_the_host_equals_the_replayed_reference_rule():
+    """TrackGraph.update(mode='train') sizes its append from the labels (tracking.TrackGraph._train_active_count: the dets of the
+    previous non-empty timestep + every true-positive det whose track has no later detection yet) instead of reading the
+    device's count back.  WindowBuilder replays the reference's rule literally (utils/graph.py:228-245, 271-274: associations
+    through existing edges); on chunks of every shape -- false positives, missed detections, pauses, empty timesteps -- the
+    two must give the same active-set size at every timestep."""
+    from trackmpnn_amd import WindowBuilder, synth_window
+    from trackmpnn_amd.tracking import TrackGraph
+
+    class Host:                                         # the two host methods on a bare state (no device)
+        _train_state_add = TrackGraph._train_state_add
+        _train_active_count = TrackGraph._train_active_count
+
+    checked = 0
+    for seed in range(80):
+        yy = synth_window(900 + seed, 5 + seed % 8, 3.0 + seed % 7, 30, survival=0.6 + 0.05 * (seed % 8), fp_rate=0.05 * (seed % 6),
+                          dropout=0.1 * (seed % 5))
+        if seed % 4 == 0:
+            yy = yy[yy[:, 0] != 2]                      # an empty timestep
+        times = np.unique(yy[:, 0])
+        calls = WindowBuilder(yy).calls()
+        if len(calls) < 2:
+            continue
+        h = Host()
+        h._tr = dict(last={}, dup=False, t_prev=int(times[0]), n_prev=0)
+        for tt in times[:2]:
+            h._train_state_add(int(tt), yy[yy[:, 0] == tt, 1].tolist())
+        for c, tt in zip(calls[1:], times[2:]):
+            nt = int((yy[:, 0] == tt).sum())
+            A, dup = h._train_active_count()
+            assert not dup and A * nt + nt == c.n_new, (seed, int(tt), A, c.n_new)
+            h._train_state_add(int(tt), yy[yy[:, 0] == tt, 1].tolist())
+            checked += 1
+    assert checked > 300
