@@ -439,6 +439,7 @@ __global__ __launch_bounds__(IT_NT) void k_it_bwd(ItBwdArgs a) {
 static constexpr int ITW_R = 32;        // det rows of a tile
 static constexpr int ITW_MS = 8;        // segments of a tile (their statistics ride in registers)
 static constexpr int ITW_NW = 8;        // waves of a workgroup
+static constexpr int ITW_SPB = 64;      // segments of a workgroup's group: one tile boundary search per lane
 static constexpr int ITW_FWD_WAVE_FLOATS = ITW_R * 64 + ITW_R * 16;              // a tile | x rows
 static constexpr int ITW_BWD_WAVE_FLOATS = 2 * ITW_R * 64 + ITW_R * 16;          // yhat | d_out -> d_yhat -> dy | x rows
 
@@ -492,7 +493,7 @@ __device__ __forceinline__ float itw_col_sum(const float* col, int p0, int p1) {
 __global__ __launch_bounds__(ITW_NW * 64) void k_itw_fwd(ItFwdArgs a) {
     constexpr int H = 64;
     extern __shared__ __attribute__((aligned(16))) float it_lds[];
-    __shared__ int s_sp[IT_SPB + 1];
+    __shared__ int s_sp[ITW_SPB + 1];
     const int tid = threadIdx.x, c = tid & 63, wave = tid >> 6;
     float* s_a = it_lds + wave * ITW_FWD_WAVE_FLOATS;       // [ITW_R][64]: y, then a
     float* s_x = s_a + ITW_R * 64;                          // [ITW_R][16]
@@ -507,15 +508,18 @@ __global__ __launch_bounds__(ITW_NW * 64) void k_itw_fwd(ItFwdArgs a) {
         w2r[4 * k4] = w.x; w2r[4 * k4 + 1] = w.y; w2r[4 * k4 + 2] = w.z; w2r[4 * k4 + 3] = w.w;
     }
     const float b1 = a.b1[c], gam = a.gamma[c], bet = a.beta[c], b2 = a.b2[c];
-    const int ngroups = (a.S + IT_SPB - 1) / IT_SPB;
+    const int ngroups = (a.S + ITW_SPB - 1) / ITW_SPB;
     for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
-        const int s0 = grp * IT_SPB, s1 = min(a.S, s0 + IT_SPB);
+        const int s0 = grp * ITW_SPB, s1 = min(a.S, s0 + ITW_SPB);
         __syncthreads();                                  // (the previous group's readers of s_sp are done)
         if (tid <= s1 - s0) s_sp[tid] = a.seg_ptr[s0 + tid];
         __syncthreads();
+        // lane l: where a tile that starts at segment s0 + l ends; the wave then follows the chain from segment s0 (the tiles
+        // are dealt to the waves round robin: every wave finds the same chain)
+        const int nxt_l = (s0 + c < s1) ? itw_chunk_end(s_sp, s0, s0 + c, s1) : s1;
         int j = 0;
         for (int sa = s0; sa < s1; ++j) {
-            const int sb = itw_chunk_end(s_sp, s0, sa, s1);
+            const int sb = __shfl(nxt_l, sa - s0, 64);
             if ((j & (ITW_NW - 1)) == wave) {
                 const int ra = s_sp[sa - s0], nr = s_sp[sb - s0] - ra;
                 int orow_l = 0, cnt_l = 1;
@@ -596,7 +600,7 @@ __global__ __launch_bounds__(ITW_NW * 64) void k_itw_fwd(ItFwdArgs a) {
 __global__ __launch_bounds__(ITW_NW * 64) void k_itw_bwd(ItBwdArgs a) {
     constexpr int H = 64;
     extern __shared__ __attribute__((aligned(16))) float it_lds[];
-    __shared__ int s_sp[IT_SPB + 1];
+    __shared__ int s_sp[ITW_SPB + 1];
     const int tid = threadIdx.x, c = tid & 63, wave = tid >> 6;       // c: the lane's hidden column (k of a / yhat / dy)
     float* s_yh = it_lds + wave * ITW_BWD_WAVE_FLOATS;      // [ITW_R][64] yhat (lane-private columns)
     float* s_d = s_yh + ITW_R * 64;                         // [ITW_R][64] d_out rows (broadcast reads), then d_yhat, then dy
@@ -616,15 +620,16 @@ __global__ __launch_bounds__(ITW_NW * 64) void k_itw_bwd(ItBwdArgs a) {
     for (int f = 0; f < 16; ++f) acc_w1[f] = 0.f;
     float v_dg = 0.f, v_dbt = 0.f, v_db1 = 0.f;
     float v_db2 = 0.f;                                      // (lane c sums d_out[.][c])
-    const int ngroups = (a.S + IT_SPB - 1) / IT_SPB;
+    const int ngroups = (a.S + ITW_SPB - 1) / ITW_SPB;
     for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
-        const int s0 = grp * IT_SPB, s1 = min(a.S, s0 + IT_SPB);
+        const int s0 = grp * ITW_SPB, s1 = min(a.S, s0 + ITW_SPB);
         __syncthreads();
         if (tid <= s1 - s0) s_sp[tid] = a.seg_ptr[s0 + tid];
         __syncthreads();
+        const int nxt_l = (s0 + c < s1) ? itw_chunk_end(s_sp, s0, s0 + c, s1) : s1;      // (see k_itw_fwd)
         int j = 0;
         for (int sa = s0; sa < s1; ++j) {
-            const int sb = itw_chunk_end(s_sp, s0, sa, s1);
+            const int sb = __shfl(nxt_l, sa - s0, 64);
             if ((j & (ITW_NW - 1)) == wave) {
                 const int ra = s_sp[sa - s0], nr = s_sp[sb - s0] - ra;
                 int orow_l = 0, cnt_l = 1;
@@ -789,7 +794,7 @@ static bool itw_serves(int H, int F, int max_seg_rows, int training) {
     return !off && training && H == 64 && F <= 16 && max_seg_rows <= ITW_R;
 }
 static int itw_blocks(int S) {
-    const int groups = ceil_div(S, IT_SPB);
+    const int groups = ceil_div(S, ITW_SPB);
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     return groups < cus ? groups : cus;
