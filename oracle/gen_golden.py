@@ -475,6 +475,9 @@ def main():
     if args.only == 'unsorted':
         run_unsorted_fixtures(args.out)
         return
+    if args.only == 'wide':
+        run_wide_fixtures(args.out)
+        return
     seed = 0
     for feats, ncat in (('2d', 3), ('2d+temp+vis', 3)):
         for msg in ('diff', 'concat'):
@@ -522,6 +525,14 @@ def main():
     run_infer_fixture('infer_greedy_w3_r0_reinit', args.out, 503, T=14, dmean=4, cur_win=3, ret_win=0, hungarian=False,
                       gap=(5, 10))
     run_unsorted_fixtures(args.out)
+    run_wide_fixtures(args.out)
+
+
+def run_wide_fixtures(out_dir):
+    """round 6: hidden widths served by the wide-cell kernels (csrc/wide.hip: H >= 128), pinned to the real reference like the
+    H <= 64 paths (so far they were compared with the oracle only).  Perturbation 0.15: the same per-layer gain as 0.3 at H = 32."""
+    run_fixture('roll_2d_diff_k0_train_h128', out_dir, '2d', 3, 128, 0, 'diff', 'train', 900, T=5, dmean=4, pscale=0.15)
+    run_fixture('roll_2d_concat_k0_eval_h128', out_dir, '2d', 3, 128, 0, 'concat', 'eval', 901, T=4, dmean=3, pscale=0.15)
 
 
 def run_unsorted_fixtures(out_dir):
