@@ -692,3 +692,48 @@ def test_fused_iteration_with_attention_heads_matches_the_reference(name):
             tol = 2e-3 * gscale      # exactly-zero true gradient (BatchNorm removes the mean): cancellation noise
         err = (p.grad.cpu() - grads[k]).abs().max().item()
         assert err <= tol, f'grad {k}: {err} > {tol}'
+
+
+@pytest.mark.parametrize('features', ['2d', '2d+temp'])
+def test_padded_width_state_honours_in_place_edits_between_calls(features):
+    """A zero-padded width on the fused path keeps the carried state in padded form behind the [N, G nhidden] tensor the caller
+    sees (one feature group: a view of it; several: a copy).  An in-place edit of that tensor between two calls -- resetting
+    rows, as a loop that masks tracks does -- must reach the next call either way (round-5 advisor finding: the copy's edit
+    was dropped): the continuation equals the one from a fresh clone of the edited state."""
+    from trackmpnn_amd import TrackMPNN, WindowBuilder, synth_window
+    from trackmpnn_amd.graph import device_graph_from_adjacency
+    from oracle import trackmpnn_oracle as orc
+    torch.manual_seed(9)
+    model = TrackMPNN(features, 3, 48, 0, 'diff').to(DEV).eval()
+    F = 8 + (2 if 'temp' in features else 0)
+    y = synth_window(3, 4, 4, 8)
+    calls = WindowBuilder(y).calls()
+    gen = torch.Generator().manual_seed(1)
+
+    def adj(c_upto):
+        N = sum(c.n_new for c in calls[:c_upto + 1])
+        is_edge = np.concatenate([c.is_edge for c in calls[:c_upto + 1]])
+        src = np.concatenate([c.src for c in calls[:c_upto + 1]]); dst = np.concatenate([c.dst for c in calls[:c_upto + 1]])
+        er = np.nonzero(is_edge)[0]
+        na = torch.zeros(N, N); ea = torch.zeros(N, N)
+        na[er, src] = 1.0; na[er, dst] = -1.0
+        dr = np.nonzero(~is_edge)[0]
+        na[dr, dr] = 1.0
+        ea[src, er] = 1.0; ea[dst, er] = -1.0
+        ea[er, er] = 1.0
+        return na.to(DEV), ea.to(DEV)
+
+    xs = []
+    for c in calls:
+        x = torch.zeros(c.n_new, F)
+        x[~torch.from_numpy(c.is_edge)] = torch.randn(int((~c.is_edge).sum()), F, generator=gen)
+        xs.append(x.to(DEV))
+    with torch.no_grad():
+        na, ea = adj(0)
+        _, _, h, _ = model(xs[0], None, na, ea)
+        assert getattr(h, '_tmpnn_padded_state', None) is not None, 'expected the padded fused path'
+        h[1::2] = 0.0                                        # the caller's in-place edit
+        na, ea = adj(1)
+        s_a, _, h_a, _ = model(xs[1], h, na, ea)
+        s_b, _, h_b, _ = model(xs[1], h.clone(), na, ea)     # (a clone carries no padded state: padded afresh from its values)
+    assert torch.equal(s_a, s_b) and torch.equal(h_a, h_b)
