@@ -712,8 +712,9 @@ def test_padded_width_state_honours_in_place_edits_between_calls(features):
 
     def adj(c_upto):
         N = sum(c.n_new for c in calls[:c_upto + 1])
-        is_edge = np.concatenate([c.is_edge for c in calls[:c_upto + 1]])
-        src = np.concatenate([c.src for c in calls[:c_upto + 1]]); dst = np.concatenate([c.dst for c in calls[:c_upto + 1]])
+        is_edge = np.concatenate([c.new_is_edge for c in calls[:c_upto + 1]])
+        src = np.concatenate([c.new_src for c in calls[:c_upto + 1]])
+        dst = np.concatenate([c.new_dst for c in calls[:c_upto + 1]])
         er = np.nonzero(is_edge)[0]
         na = torch.zeros(N, N); ea = torch.zeros(N, N)
         na[er, src] = 1.0; na[er, dst] = -1.0
@@ -726,7 +727,7 @@ def test_padded_width_state_honours_in_place_edits_between_calls(features):
     xs = []
     for c in calls:
         x = torch.zeros(c.n_new, F)
-        x[~torch.from_numpy(c.is_edge)] = torch.randn(int((~c.is_edge).sum()), F, generator=gen)
+        x[~torch.from_numpy(c.new_is_edge)] = torch.randn(int((~c.new_is_edge).sum()), F, generator=gen)
         xs.append(x.to(DEV))
     with torch.no_grad():
         na, ea = adj(0)
