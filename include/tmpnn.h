@@ -638,6 +638,17 @@ int tmpnn_track_hungarian_max_dets(void);
 int tmpnn_track_extend(int N, int A, int D, const int32_t* active, const int32_t* new_ids, int t, const int32_t* track,
                        const tmpnn_track_rows* rows, const float* X, int ld_x, int F, float* feats, int ld_f,
                        const tmpnn_dgraph* g_new, void* ws, size_t ws_ints, tmpnn_stream stream);
+/* update_graph's second half AND the input transform of the model call that follows it, in ONE launch (round 6; inference,
+ * graphs of N + A*D + D <= TMPNN_DG_MAX_ROWS rows, the fused batch-1 path's H in {32, 64}): block 0 appends the block and
+ * derives the grown graph's index form into g_new as tmpnn_track_extend does; G further blocks run the transform of the D new
+ * dets in eval mode (running statistics) straight from X[new_ids[j]][0:F_total] into h[N + A*D + j][0:G*H] and write zeros to the
+ * A*D new edge rows of h -- what the first launch of tmpnn_mp_iter_fwd(training = 0) does with the features tmpnn_track_extend
+ * would have written (same code, same arithmetic order: bit-identical).  The caller follows with
+ * tmpnn_mp_iter_fwd_parts(parts = 1, x = NULL).  h [N + A*D + D][G*H]: rows [0, N) hold the carried state.  save / save_floats:
+ * as tmpnn_mp_iter_fwd for (N + A*D + D, A*D + D) -- the transform's Lin1 outputs and statistics land where that call puts them. */
+int tmpnn_track_extend_tf(int N, int A, int D, const int32_t* active, const int32_t* new_ids, int t, const int32_t* track,
+                          const tmpnn_track_rows* rows, const float* X, int ld_x, const tmpnn_mp_params* P, float* h,
+                          float* save, size_t save_floats, const tmpnn_dgraph* g_new, tmpnn_stream stream);
 /* decode_tracks (:431-520): associations from the scores (associate = 1: the greedy rule; 2: optimal assignment per timestep as
  * tmpnn_track_select_ws, graphs of <= TMPNN_DG_MAX_ROWS rows, its cost scratch = fin_ws / fin_ws_bytes, overflow in bit 1 of
  * small[1]; 0: rows->assoc holds them already, e.g. from a matching on the host), track finalisation, row deletion into rows_out, the state rows and scores compacted (h_new [N][ld_hn],
@@ -645,11 +656,17 @@ int tmpnn_track_extend(int N, int A, int D, const int32_t* active, const int32_t
  * the compacted rows by the inference rule -> active[], small[3]; the caller then reads small once per timestep instead of twice.
  * Greedy associations carry over (deletion removes no future edge of a kept det); with associate = 2 the next update_graph would
  * re-derive them by its own assignment sweep over the compacted graph (a det that was assigned and deleted frees its column), so
- * that sweep runs here, over the rows that stay, and rows_out->assoc holds ITS result (round 5). */
+ * that sweep runs here, over the rows that stay, and rows_out->assoc holds ITS result (round 5).
+ * notify (or NULL; round 6): int32 [8] in PINNED HOST memory that the runtime maps into the device's address space at the same
+ * address (hipHostMalloc; checked).  The caller clears notify[4]; the launch that produces the counters stores small[0..3] into
+ * notify[0..3] and then 1 into notify[4] (release order, system scope).  The host may then poll notify[4] (acquire) instead of
+ * copying `small` back behind the call: it has the counts while the kept rows' state is still moving, and no copy is enqueued.
+ * The device never waits for the host; a caller that does not see the flag may still synchronise and read `small`. */
 int tmpnn_track_retire(const tmpnn_dgraph* g, const tmpnn_track_rows* rows, const float* score, int associate, int t_upto,
                        int ret_win, int32_t* y_track, int ND, int32_t* pos_of_det, void* fin_ws, size_t fin_ws_bytes,
                        int32_t* keep, int32_t* small, const tmpnn_track_rows* rows_out, const float* h, int ld_h, int W,
-                       float* h_new, int ld_hn, float* s_new, int next_t, int32_t* active, tmpnn_stream stream);
+                       float* h_new, int ld_hn, float* s_new, int next_t, int32_t* active, int32_t* notify,
+                       tmpnn_stream stream);
 
 
 /* ======================================================================================================

@@ -22,13 +22,12 @@
 // Sizes (E, Dn) are read from the graph's device-side meta (tmpnn_dgraph): grids are sized from N alone and
 // surplus blocks exit, so the host never synchronises.  fp32 throughout; every reduction has a fixed order.
 #include "common.h"
+#include "small_bn_dev.h"
 
 namespace tmpnn {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-static constexpr float BN_EPS_S = 1e-5f;
-static constexpr float BN_MOM_S = 0.1f;
 static constexpr int TR = 16;            // rows per tile
 static constexpr int SMALL_BWD_BLOCKS = 96;
 
@@ -89,149 +88,14 @@ __host__ __device__ inline PrepLayout prep_layout(int H, int IN_e) {
     return L;
 }
 
-// ------------------------------------------------------------------------------------------------------------
-// saved-for-backward layout (floats)
-// ------------------------------------------------------------------------------------------------------------
-struct SaveLayout { size_t gates, es, ysave, mean, rstd, total; };
-__host__ __device__ inline SaveLayout save_layout(int N, int n, int G, int H) {
-    SaveLayout L;
-    L.gates = 0;                                   // [G][4][N][H]   r, z, n, W_hn h + b_hn   (row-indexed)
-    L.es = L.gates + (size_t)G * 4 * N * H;         // [G][N][H]      edge -> node sums, by det INDEX
-    L.ysave = L.es + (size_t)G * N * H;             // [G][n][H]      Lin1 output of the new det rows (by new-det index)
-    L.mean = L.ysave + (size_t)G * (n > 0 ? n : 1) * H;   // [G][H]
-    L.rstd = L.mean + (size_t)G * H;                // [G][H]
-    L.total = L.rstd + (size_t)G * H;
-    return L;
-}
+// (saved-for-backward layout: small_bn_dev.h)
 
 // ------------------------------------------------------------------------------------------------------------
-// input transform, forward: one block per feature group
+// input transform, forward: one block per feature group (the transform itself: small_bn_dev.h)
 // ------------------------------------------------------------------------------------------------------------
-struct BnFwdArgs {
-    tmpnn_mp_params P;
-    tmpnn_dgraph g;
-    int n_new, training;
-    const float* x; int ld_x;
-    float* h;                  // [N][G*H]
-    float* ysave; float* mean; float* rstd;     // may be scratch when nothing is saved
-    int* newdet;               // [n_new + 1] scratch: local indices of the new det rows, count at [n_new]
-};
-
 template <int H>
 __global__ __launch_bounds__(256) void k_small_bn_fwd(BnFwdArgs a) {
-    const int gi = blockIdx.x;
-    const int G = a.P.G, GH = G * H;
-    const int N = a.g.N, n = a.n_new, N_old = N - n;
-    const int F = a.P.F[gi];
-    int f0 = 0;
-    for (int q = 0; q < gi; ++q) f0 += a.P.F[q];
-    const int tid = threadIdx.x;
-    __shared__ int s_wsum[5];
-    __shared__ float s_mean[H], s_rstd[H], s_w2t[H * (H + 1)];
-    extern __shared__ float s_a[];                 // [CH][H + 1] activation chunk
-    int* newdet = a.newdet + (size_t)gi * (n + 1);
-
-    // ---- compact list of the new det rows (ascending); every group's block builds its own copy
-    {
-        const int IT = (n + 255) / 256;
-        const int i0 = tid * IT, i1 = min(n, i0 + IT);
-        int cnt = 0;
-        for (int i = i0; i < i1; ++i) cnt += a.g.is_edge[N_old + i] ? 0 : 1;
-        const int lane = tid & 63, wave = tid >> 6;
-        int inc = cnt;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) { const int t = __shfl_up(inc, off); if (lane >= off) inc += t; }
-        if (lane == 63) s_wsum[wave] = inc;
-        __syncthreads();
-        if (tid == 0) { int run = 0; for (int w = 0; w < 4; ++w) { const int t = s_wsum[w]; s_wsum[w] = run; run += t; } s_wsum[4] = run; }
-        __syncthreads();
-        int p = s_wsum[wave] + inc - cnt;
-        for (int i = i0; i < i1; ++i)
-            if (!a.g.is_edge[N_old + i]) newdet[p++] = i;
-    }
-    const int nd = s_wsum[4];
-    if (tid == 0) newdet[n] = nd;
-    // The new EDGE rows of x must be all-zero (utils/graph.py:148-149, 291-292 always builds them so): only det rows are
-    // read here, while the reference would run whatever an edge row holds through Lin1 and into the batch statistics.
-    // A non-zero edge row therefore marks the call invalid (status bit 64: NaN outputs, ValueError at the next check)
-    // instead of diverging silently.
-    {
-        bool bad = false;
-        for (int idx = tid; idx < n * F; idx += 256) {
-            const int i = idx / F, f = idx - i * F;
-            if (a.g.is_edge[N_old + i] && a.x[(size_t)i * a.ld_x + f0 + f] != 0.f) bad = true;
-        }
-        if (bad) atomicOr(&a.g.meta[2], 64);
-    }
-    // new edge rows start at zero (track_mpnn.py:61); new det rows are written below
-    for (int idx = tid; idx < n * (H / 4); idx += 256) {
-        const int i = idx / (H / 4), c4 = idx % (H / 4);
-        if (a.g.is_edge[N_old + i])
-            *reinterpret_cast<float4*>(a.h + (size_t)(N_old + i) * GH + gi * H + 4 * c4) = make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-    __syncthreads();
-    const float* W1 = a.P.w1[gi];
-    const float* b1 = a.P.b1[gi];
-    float* ysave = a.ysave + (size_t)gi * (n > 0 ? n : 1) * H;
-    const int c = tid % H, sub = tid / H;
-    constexpr int NSUB = 256 / H;
-    // ---- Lin1 on the det rows: y1[i][c] = b1[c] + sum_f x[i][f] W1[c][f]
-    for (int i = sub; i < nd; i += NSUB) {
-        const float* xr = a.x + (size_t)newdet[i] * a.ld_x + f0;
-        float acc = b1[c];
-        for (int f = 0; f < F; ++f) acc = fmaf(xr[f], W1[c * F + f], acc);
-        ysave[(size_t)i * H + c] = acc;
-    }
-    __syncthreads();
-    // ---- statistics over ALL n new rows: the n - nd zero rows contribute Lin1(0) = b1 (models/track_mpnn.py:59)
-    if (a.training) {
-        const float cnt = (float)n, nz = (float)(n - nd);
-        if (tid < H) {
-            const float b = b1[tid];
-            float sum = nz * b;
-            for (int i = 0; i < nd; ++i) sum += ysave[(size_t)i * H + tid];
-            const float m = sum / cnt;
-            float sq = nz * (b - m) * (b - m);
-            for (int i = 0; i < nd; ++i) { const float d = ysave[(size_t)i * H + tid] - m; sq += d * d; }
-            const float var = sq / cnt;
-            s_mean[tid] = m;
-            s_rstd[tid] = rsqrtf(var + BN_EPS_S);
-            float* rm = a.P.run_mean[gi];
-            float* rv = a.P.run_var[gi];
-            rm[tid] = (1.0f - BN_MOM_S) * rm[tid] + BN_MOM_S * m;
-            rv[tid] = (1.0f - BN_MOM_S) * rv[tid] + BN_MOM_S * (var * (cnt / (cnt - 1.0f)));
-            if (tid == 0 && a.P.num_batches_tracked[gi]) a.P.num_batches_tracked[gi][0] += 1;
-        }
-    } else if (tid < H) {
-        s_mean[tid] = a.P.run_mean[gi][tid];
-        s_rstd[tid] = rsqrtf(a.P.run_var[gi][tid] + BN_EPS_S);
-    }
-    // W2 transposed into LDS: s_w2t[k][c] = W2[c][k]
-    const float* W2 = a.P.w2[gi];
-    for (int idx = tid; idx < H * H; idx += 256) { const int cc = idx / H, k = idx % H; s_w2t[k * (H + 1) + cc] = W2[idx]; }
-    __syncthreads();
-    if (tid < H) {
-        a.mean[(size_t)gi * H + tid] = s_mean[tid];
-        a.rstd[(size_t)gi * H + tid] = s_rstd[tid];
-    }
-    // ---- a = relu(gamma yhat + beta) ; out = a W2^T + b2 -> h[new det rows], in chunks of CH rows
-    constexpr int CH = 64;
-    const float gam = a.P.gamma[gi][c], bet = a.P.beta[gi][c], b2 = a.P.b2[gi][c];
-    for (int i0 = 0; i0 < nd; i0 += CH) {
-        const int rows = min(CH, nd - i0);
-        for (int i = sub; i < rows; i += NSUB) {
-            const float yh = (ysave[(size_t)(i0 + i) * H + c] - s_mean[c]) * s_rstd[c];
-            s_a[i * (H + 1) + c] = fmaxf(yh * gam + bet, 0.f);
-        }
-        __syncthreads();
-        for (int i = sub; i < rows; i += NSUB) {
-            float acc = b2;
-#pragma unroll 8
-            for (int k = 0; k < H; ++k) acc = fmaf(s_a[i * (H + 1) + k], s_w2t[k * (H + 1) + c], acc);
-            a.h[(size_t)(N_old + newdet[i0 + i]) * GH + gi * H + c] = acc;
-        }
-        __syncthreads();
-    }
+    d_small_bn_fwd<H>(a, (int)blockIdx.x, BnSrcGraph{a.g.is_edge, a.g.N - a.n_new, a.x, a.ld_x});
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -1143,7 +1007,8 @@ int tmpnn_mp_iter_fwd_parts(const tmpnn_mp_params* P, const float* prep, const t
     if (N == 0) return TMPNN_OK;
     TM_REQUIRE(prep && h && h_out && logits && scores, "mp_iter_fwd: null buffer");
     TM_REQUIRE(aligned16(prep) && aligned16(h) && aligned16(h_out), "mp_iter_fwd: h / h_out / prep must be 16-byte aligned");
-    TM_REQUIRE(n_new == 0 || (x != nullptr && ld_x >= P->F_total), "mp_iter_fwd: x [%d][ld %d] for F_total=%d", n_new, ld_x, P->F_total);
+    TM_REQUIRE(n_new == 0 || (parts & 1) || (x != nullptr && ld_x >= P->F_total), "mp_iter_fwd: x [%d][ld %d] for F_total=%d", n_new, ld_x,
+               P->F_total);
     TM_REQUIRE(!(training && n_new == 1), "Expected more than 1 value per channel when training, got input size [1, %d]", H);
     const SaveLayout SL = save_layout(N, n_new, G, H);
     float* sv = save;

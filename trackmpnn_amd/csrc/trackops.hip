@@ -23,6 +23,8 @@
 #include <algorithm>
 
 #include "common.h"
+#include "graphconv_dev.h"
+#include "small_bn_dev.h"
 
 namespace tmpnn {
 
@@ -48,66 +50,6 @@ __device__ __forceinline__ int tk_block_scan(int v, int* s_wave, int* total) {
     *total = s_wave[TK_THREADS / 64];
     __syncthreads();
     return res;
-}
-
-// ---- y_pred[:, 2] ------------------------------------------------------------------------------------------
-// mode 0 (train, utils/graph.py:229-245): a true-positive det is associated through its ONE label-positive future
-//   edge (more than one: status bit 1); a false positive is "associated" with itself so that it stays inactive.
-// mode 1 (inference, greedy, :251-268 / :437-454): a det scored >= 0.5 looks at its future edges scored >= 0.5 that
-//   lead to a det scored >= 0.5, keeps those of the NEAREST timestep (rows before the first det row after the first
-//   such edge) and takes the highest score (first of equals).
-__device__ __forceinline__ void d_track_associate(tmpnn_dgraph g, const int32_t* __restrict__ det_id,
-                                                         const uint8_t* __restrict__ labels,
-                                                         const float* __restrict__ score, int mode,
-                                                         int32_t* __restrict__ assoc, int32_t* __restrict__ status, int i0, int stride) {
-    const int N = g.N, Dn = g.meta[1];
-    for (int r = i0; r < N; r += stride)
-        if (g.is_edge[r]) assoc[r] = -1;
-    for (int d = i0; d < Dn; d += stride) {
-        const int row = g.det_row[d];
-        const int p0 = g.rowptr[d], p1 = g.rowptr[d + 1];
-        int out = -1;
-        if (mode == 0) {
-            if (labels[row]) {
-                int cnt = 0;
-                for (int p = p0; p < p1; ++p) {
-                    const int key = g.inc[p];
-                    if (key < 0) continue;                        // past edge (this det is its later endpoint)
-                    if (labels[key]) { ++cnt; out = det_id[g.dst[g.pos[key]]]; }
-                }
-                if (cnt > 1) { atomicOr(status, 1); }
-                if (cnt != 1) out = cnt == 0 ? -1 : out;
-            } else {
-                out = det_id[row];
-            }
-        } else if (score[row] >= 0.5f) {
-            int first = -1;
-            for (int p = p0; p < p1 && first < 0; ++p) {
-                const int key = g.inc[p];
-                if (key < 0) continue;
-                if (score[key] >= 0.5f && score[g.dst[g.pos[key]]] >= 0.5f) first = key;
-            }
-            if (first >= 0) {
-                // first det row after `first`: det_row is ascending -> binary search
-                int lo = 0, hi = Dn;
-                while (lo < hi) { const int mid = (lo + hi) >> 1; if (g.det_row[mid] > first) hi = mid; else lo = mid + 1; }
-                const int limit = lo < Dn ? g.det_row[lo] : N;
-                float best = -1.f;
-                int best_e = -1;
-                for (int p = p0; p < p1; ++p) {
-                    const int key = g.inc[p];
-                    if (key < 0 || key < first || key >= limit) continue;
-                    const float s = score[key];
-                    if (s >= 0.5f && score[g.dst[g.pos[key]]] >= 0.5f && s > best) { best = s; best_e = key; }
-                }
-                if (best_e >= 0) out = det_id[g.dst[g.pos[best_e]]];
-            }
-        }
-        assoc[row] = out;
-    }
-}
-__global__ __launch_bounds__(256) void k_track_associate(tmpnn_dgraph g, const int32_t* __restrict__ det_id, const uint8_t* __restrict__ labels, const float* __restrict__ score, int mode, int32_t* __restrict__ assoc, int32_t* __restrict__ status) {
-    d_track_associate(g, det_id, labels, score, mode, assoc, status, (int)(blockIdx.x * 256 + threadIdx.x), (int)(gridDim.x * 256));
 }
 
 // ---- y_pred[:, 2] by optimal assignment (reference hungarian(), utils/graph.py:33-93; README: --hungarian) -----------------
@@ -187,6 +129,94 @@ __device__ __forceinline__ uint64_t hg_key(double x) {        // order-preservin
 __device__ __forceinline__ int hg_wave_min_i(int x) {          // (block-level helper of the sweep: ints >= 0 or INT_MAX)
     return (int)hg_wave_min32((uint32_t)x);
 }
+// ---- y_pred[:, 2] ------------------------------------------------------------------------------------------
+// mode 0 (train, utils/graph.py:229-245): a true-positive det is associated through its ONE label-positive future
+//   edge (more than one: status bit 1); a false positive is "associated" with itself so that it stays inactive.
+// mode 1 (inference, greedy, :251-268 / :437-454): a det scored >= 0.5 looks at its future edges scored >= 0.5 that
+//   lead to a det scored >= 0.5, keeps those of the NEAREST timestep (rows before the first det row after the first
+//   such edge) and takes the highest score (first of equals).
+// mode 1 runs one WAVE per det, a lane per incident edge (round 6): a thread per det walked its incidences through a chain of
+// four dependent loads each (inc -> pos -> dst -> score: ~50 L2 round trips for a det of a KITTI window, and only Dn threads at
+// work); a wave issues every incidence's chain side by side and picks the first / the best edge by two wave reductions.
+// (i0, stride): a wave-aligned thread index and thread count (a block's threadIdx.x / size, or a 256-thread grid's global index).
+__device__ __forceinline__ void d_track_associate(tmpnn_dgraph g, const int32_t* __restrict__ det_id,
+                                                         const uint8_t* __restrict__ labels,
+                                                         const float* __restrict__ score, int mode,
+                                                         int32_t* __restrict__ assoc, int32_t* __restrict__ status, int i0, int stride) {
+    const int N = g.N, Dn = g.meta[1];
+    for (int r = i0; r < N; r += stride)
+        if (g.is_edge[r]) assoc[r] = -1;
+    if (mode != 0) {
+        const int lane = i0 & 63, wave = i0 >> 6, nw = stride >> 6;
+        for (int d = wave; d < Dn; d += nw) {                          // (wave-uniform control flow throughout)
+            const int row = g.det_row[d];
+            int out = -1;
+            if (score[row] >= 0.5f) {
+                const int p0 = g.rowptr[d], p1 = g.rowptr[d + 1];
+                // the first qualifying future edge: incidences are in ascending edge-row order, so it is the smallest row of
+                // the first chunk of 64 that holds one
+                int first = 0x7fffffff;
+                for (int base = p0; base < p1 && first == 0x7fffffff; base += 64) {
+                    const int p = base + lane;
+                    int cand = 0x7fffffff;
+                    if (p < p1) {
+                        const int key = g.inc[p];
+                        if (key >= 0 && score[key] >= 0.5f && score[g.dst[g.pos[key]]] >= 0.5f) cand = key;
+                    }
+                    first = hg_wave_min_i(cand);
+                }
+                if (first != 0x7fffffff) {
+                    // first det row after `first`: det_row is ascending -> binary search (every lane the same search)
+                    int lo = 0, hi = Dn;
+                    while (lo < hi) { const int mid = (lo + hi) >> 1; if (g.det_row[mid] > first) hi = mid; else lo = mid + 1; }
+                    const int limit = lo < Dn ? g.det_row[lo] : N;
+                    // highest score among the qualifying edges in [first, limit), the first of equals: the maximum of
+                    // (score bits, ~row) -- scores here are >= 0.5, their bit patterns order like the values
+                    uint64_t bestk = 0;
+                    for (int base = p0; base < p1; base += 64) {
+                        const int p = base + lane;
+                        uint64_t k = 0;
+                        if (p < p1) {
+                            const int key = g.inc[p];
+                            if (key >= first && key < limit) {
+                                const float s = score[key];
+                                if (s >= 0.5f && score[g.dst[g.pos[key]]] >= 0.5f)
+                                    k = ((uint64_t)__float_as_uint(s) << 32) | (uint32_t)(0x7fffffff - key);
+                            }
+                        }
+                        k = ~hg_wave_min64(~k);
+                        bestk = k > bestk ? k : bestk;
+                    }
+                    if (bestk) out = det_id[g.dst[g.pos[0x7fffffff - (int)(uint32_t)bestk]]];
+                }
+            }
+            if (lane == 0) assoc[row] = out;
+        }
+        return;
+    }
+    for (int d = i0; d < Dn; d += stride) {
+        const int row = g.det_row[d];
+        const int p0 = g.rowptr[d], p1 = g.rowptr[d + 1];
+        int out = -1;
+        if (labels[row]) {
+            int cnt = 0;
+            for (int p = p0; p < p1; ++p) {
+                const int key = g.inc[p];
+                if (key < 0) continue;                        // past edge (this det is its later endpoint)
+                if (labels[key]) { ++cnt; out = det_id[g.dst[g.pos[key]]]; }
+            }
+            if (cnt > 1) { atomicOr(status, 1); }
+            if (cnt != 1) out = cnt == 0 ? -1 : out;
+        } else {
+            out = det_id[row];
+        }
+        assoc[row] = out;
+    }
+}
+__global__ __launch_bounds__(256) void k_track_associate(tmpnn_dgraph g, const int32_t* __restrict__ det_id, const uint8_t* __restrict__ labels, const float* __restrict__ score, int mode, int32_t* __restrict__ assoc, int32_t* __restrict__ status) {
+    d_track_associate(g, det_id, labels, score, mode, assoc, status, (int)(blockIdx.x * 256 + threadIdx.x), (int)(gridDim.x * 256));
+}
+
 // rows i < nr <= nc columns; cost(i, j) = C[i * sr + j * sc]; result in S.col4row[0..nr)
 __device__ void hg_wave_solve(HgShared& S, const float* C, int sr, int sc, int nr, int nc, int lane) {
     double v[HG_K];
@@ -519,24 +549,25 @@ __global__ __launch_bounds__(TK_THREADS) void k_track_active(int N, const int32_
 // ---- append the block of timestep t (utils/graph.py:283-325) ------------------------------------------------------
 // rows [N, N + A*D): edge (a, j) at N + a*D + j with src = active[a], dst = N + A*D + j ; rows [N + A*D, N + A*D + D): dets.
 // labels (training): det j is positive iff its track id >= 0; edge (a, j) iff both belong to the same track.
-__global__ __launch_bounds__(256) void k_track_append(int N, int A, int D, const int32_t* __restrict__ active,
-                                                      const int32_t* __restrict__ new_ids, int t,
-                                                      const int32_t* __restrict__ track /* [ND] or NULL */,
-                                                      int32_t* __restrict__ ts, int32_t* __restrict__ det_id,
-                                                      int32_t* __restrict__ assoc, uint8_t* __restrict__ is_edge,
-                                                      int32_t* __restrict__ row_src, int32_t* __restrict__ row_dst,
-                                                      uint8_t* __restrict__ labels,
-                                                      const float* __restrict__ X /* [ND][ld_x] or NULL */, int ld_x, int F,
-                                                      float* __restrict__ feats /* [n][ld_f]: zeros on edge rows */, int ld_f) {
+__device__ __forceinline__ void d_track_append(int N, int A, int D, const int32_t* __restrict__ active,
+                                               const int32_t* __restrict__ new_ids, int t,
+                                               const int32_t* __restrict__ track /* [ND] or NULL */,
+                                               int32_t* __restrict__ ts, int32_t* __restrict__ det_id,
+                                               int32_t* __restrict__ assoc, uint8_t* __restrict__ is_edge,
+                                               int32_t* __restrict__ row_src, int32_t* __restrict__ row_dst,
+                                               uint8_t* __restrict__ labels,
+                                               const float* __restrict__ X /* [ND][ld_x] or NULL */, int ld_x, int F,
+                                               float* __restrict__ feats /* [n][ld_f]: zeros on edge rows */, int ld_f,
+                                               const long i0, const long stride) {
     const int n = A * D + D;
     if (feats) {          // the new rows' features (utils/graph.py:291-293, 318): zeros on the edge rows, X[id] on the det rows
         const long total = (long)n * F;
-        for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        for (long i = i0; i < total; i += stride) {
             const int r = (int)(i / F), c = (int)(i % F);
             feats[(size_t)r * ld_f + c] = r < A * D ? 0.f : X[(size_t)new_ids[r - A * D] * ld_x + c];
         }
     }
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    for (int i = (int)i0; i < n; i += (int)stride) {
         const int r = N + i;
         assoc[r] = -1;
         if (i < A * D) {
@@ -554,6 +585,35 @@ __global__ __launch_bounds__(256) void k_track_append(int N, int A, int D, const
             row_src[r] = -1; row_dst[r] = -1;
             if (labels) labels[r] = (track && track[new_ids[j]] >= 0) ? 1 : 0;
         }
+    }
+}
+__global__ __launch_bounds__(256) void k_track_append(int N, int A, int D, const int32_t* __restrict__ active, const int32_t* __restrict__ new_ids, int t, const int32_t* __restrict__ track, int32_t* __restrict__ ts, int32_t* __restrict__ det_id, int32_t* __restrict__ assoc, uint8_t* __restrict__ is_edge, int32_t* __restrict__ row_src, int32_t* __restrict__ row_dst, uint8_t* __restrict__ labels, const float* __restrict__ X, int ld_x, int F, float* __restrict__ feats, int ld_f) {
+    d_track_append(N, A, D, active, new_ids, t, track, ts, det_id, assoc, is_edge, row_src, row_dst, labels, X, ld_x, F, feats, ld_f,
+                   (long)blockIdx.x * 256 + threadIdx.x, (long)gridDim.x * 256);
+}
+
+// ---- update_graph's second half AND the model call's input transform in ONE launch (inference, LDS-sized graphs) ----------------
+// block 0: the block of timestep t appended behind row N, then the grown graph's index form (graphconv_dev.h), as
+// tmpnn_track_extend does in two launches; blocks 1 .. G: the input transform of the D new dets (small_bn_dev.h; eval mode:
+// running statistics) straight from X[new_ids[j]] into h[N + A*D + j], zeros on the A*D new edge rows -- what the first launch
+// of tmpnn_mp_iter_fwd would do behind the append.  Neither half reads what the other writes: they run side by side, and a greedy
+// timestep has two launches (~6 us of launch gaps) and the transform's ~14 us less on its critical path.
+struct ExtendArgs {
+    int N, A, D, t;
+    const int32_t* active; const int32_t* new_ids; const int32_t* track;
+    tmpnn_track_rows r;
+};
+template <int H>
+__global__ __launch_bounds__(GC_THREADS) void k_track_extend_tf(ExtendArgs e, tmpnn_dgraph g, BnFwdArgs b, BnSrcBlock src) {
+    if (blockIdx.x == 0) {
+        d_track_append(e.N, e.A, e.D, e.active, e.new_ids, e.t, e.track, e.r.ts, e.r.det_id, e.r.assoc, e.r.is_edge, e.r.src,
+                       e.r.dst, e.r.labels, nullptr, 0, 0, nullptr, 0, (long)threadIdx.x, (long)GC_THREADS);
+        __threadfence_block();
+        __syncthreads();
+        d_graph_from_coo<true, false>(g.N, nullptr, nullptr, 0L, nullptr, nullptr, 0L, e.r.is_edge, e.r.src, e.r.dst, g, nullptr);
+    } else {
+        if (threadIdx.x >= 256) return;       // (the transform is written for 256 threads; ended waves leave the block's barriers)
+        d_small_bn_fwd<H>(b, (int)blockIdx.x - 1, src);
     }
 }
 
@@ -598,8 +658,10 @@ __device__ __forceinline__ void d_track_delete(int N, const int32_t* __restrict_
     const int IT = (N + TK_THREADS - 1) / TK_THREADS;
     const int r0 = tid * IT, r1 = min(N, r0 + IT);
     int mine = 0, mine_dets = 0;
-    for (int r = r0; r < r1; ++r) {
+    uint32_t kmask = 0;                                     // the verdicts of this thread's rows (IT <= 32 at TMPNN_TRACK_MAX_ROWS):
+    for (int r = r0; r < r1; ++r) {                         // evaluated once -- each is a chain of dependent loads
         const bool k = kept(r);
+        kmask |= (k ? 1u : 0u) << (r - r0);
         mine += k ? 1 : 0;
         mine_dets += (k && !is_edge[r]) ? 1 : 0;
     }
@@ -607,7 +669,7 @@ __device__ __forceinline__ void d_track_delete(int N, const int32_t* __restrict_
     int total;
     int p = tk_block_scan(mine, s_wave, &total);
     for (int r = r0; r < r1; ++r) {
-        if (kept(r)) { s_new[r] = p; keep[p] = r; ++p; }
+        if ((kmask >> (r - r0)) & 1u) { s_new[r] = p; keep[p] = r; ++p; }
         else s_new[r] = -1;
     }
     __syncthreads();
@@ -789,6 +851,25 @@ __global__ __launch_bounds__(TK_THREADS) void k_track_finalize(tmpnn_dgraph g, c
 }
 
 
+// ---- the counters of a retire call mirrored into host memory the device can write (notify: int32 [8], pinned + mapped) --------
+// [0..3] = small[0..3], then [4] = 1 with release order at system scope: the host polls [4] instead of enqueueing a device -> host
+// copy behind the launch (a blit kernel of ~4 us plus the copy's own synchronisation, per timestep of the batch-1 loops), and
+// has the counts while the state rows of the same call are still moving.  The device never waits for the host.
+__device__ __forceinline__ void d_track_publish(const int32_t* __restrict__ small, int32_t* __restrict__ notify) {
+    const int c0 = __hip_atomic_load(small + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int c1 = __hip_atomic_load(small + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int c2 = __hip_atomic_load(small + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int c3 = __hip_atomic_load(small + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(notify + 0, c0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(notify + 1, c1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(notify + 2, c2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(notify + 3, c3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(notify + 4, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__global__ void k_track_publish(const int32_t* __restrict__ small, int32_t* __restrict__ notify) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) d_track_publish(small, notify);
+}
+
 // ---- decode_tracks for LDS-sized graphs: the decisions as phases of one 1024-thread block, the state rows behind it ----------
 // (a greedy timestep's GPU time is ~10 dependent launches of 2-8 us kernels; each launch saved is ~2 us of device gap and ~2 us
 //  of host time)
@@ -801,7 +882,8 @@ __global__ __launch_bounds__(TK_THREADS) void k_track_retire(tmpnn_dgraph g, tmp
                                                              float* __restrict__ s_new, int next_t, int32_t* __restrict__ active,
                                                              int32_t* __restrict__ fin_ws /* unused by the finalisation at this
                                                              size (a kernel argument because a literal null in its LDS /
-                                                             global pointer select crashes hipcc) */, int hung_floats) {
+                                                             global pointer select crashes hipcc) */, int hung_floats,
+                                                             int32_t* __restrict__ notify) {
     if (associate == 2) {                       // optimal assignment per timestep (--hungarian); its cost scratch rides in fin_ws
         if (threadIdx.x == 0) small[1] = 0;
         __syncthreads();
@@ -812,9 +894,8 @@ __global__ __launch_bounds__(TK_THREADS) void k_track_retire(tmpnn_dgraph g, tmp
         __syncthreads();
     }
     TK_STAMP(0);
-    d_track_finalize(g, r.ts, r.det_id, r.assoc, score, t_upto, y_track, ND, pos_of_det, fin_ws);
-    __syncthreads();
-    TK_STAMP(1);
+    // (the finalisation walk runs LAST: nothing below reads what it writes -- y_track, pos_of_det -- and it reads the rows as the
+    //  association left them; the counters the host waits for are then published before it, see `notify`)
     d_track_delete(g.N, r.ts, r.det_id, r.assoc, score, r.is_edge, r.src, r.dst, r.labels, t_upto, ret_win, keep, small, o.ts,
                    o.det_id, o.assoc, o.is_edge, o.src, o.dst, o.labels);
     __syncthreads();
@@ -837,6 +918,11 @@ __global__ __launch_bounds__(TK_THREADS) void k_track_retire(tmpnn_dgraph g, tmp
         d_track_active(0, small, o.ts, o.assoc, s_new, 1, next_t, active, small + 3);
     }
     TK_STAMP(4);
+    __syncthreads();
+    // the host may go on (it sizes the next timestep's launches from these) while the walk below and the state rows' launch run
+    if (notify && threadIdx.x == 0) d_track_publish(small, notify);
+    d_track_finalize(g, r.ts, r.det_id, r.assoc, score, t_upto, y_track, ND, pos_of_det, fin_ws);
+    TK_STAMP(1);
 }
 
 // update_graph's first half in one launch (LDS-sized graphs): status word cleared, associations, active set
@@ -888,6 +974,19 @@ __global__ __launch_bounds__(256) void k_track_load(int N, int ND, const int32_t
 }  // namespace tmpnn
 
 using namespace tmpnn;
+
+// a notify buffer is written by a kernel through the pointer the host reads it by: it must be host memory the runtime mapped into
+// the device's address space at that very address.  Asked of the runtime once per buffer (the loops reuse one per sequence).
+static bool notify_ok(const int32_t* notify) {
+    if (!notify) return true;
+    static thread_local const int32_t* verified = nullptr;
+    if (notify == verified) return true;
+    hipPointerAttribute_t at;
+    if (hipPointerGetAttributes(&at, notify) != hipSuccess) { (void)hipGetLastError(); return false; }
+    if (at.type != hipMemoryTypeHost || at.devicePointer != (void*)notify) return false;
+    verified = notify;
+    return true;
+}
 
 extern "C" {
 
@@ -1037,14 +1136,56 @@ int tmpnn_track_extend(int N, int A, int D, const int32_t* active, const int32_t
     return tmpnn_graph_from_rows_ws(N + n, rows->is_edge, rows->src, rows->dst, g_new, ws, ws_ints, stream);
 }
 
+int tmpnn_track_extend_tf(int N, int A, int D, const int32_t* active, const int32_t* new_ids, int t, const int32_t* track,
+                          const tmpnn_track_rows* rows, const float* X, int ld_x, const tmpnn_mp_params* P, float* h,
+                          float* save, size_t save_floats, const tmpnn_dgraph* g_new, tmpnn_stream stream) {
+    TM_REQUIRE(N >= 0 && A >= 0 && D > 0 && (long)N + (long)A * D + D <= TMPNN_DG_MAX_ROWS,
+               "track_extend_tf: N=%d A=%d D=%d exceeds the one-launch form's %d rows", N, A, D, TMPNN_DG_MAX_ROWS);
+    TM_REQUIRE(rows_ok(rows) && (A == 0 || active) && new_ids && g_new && P && X && h && save, "track_extend_tf: null pointer");
+    const int n = A * D + D, Nt = N + n, G = P->G, H = P->H;
+    TM_REQUIRE((H == 32 || H == 64) && G >= 1 && G <= 3, "track_extend_tf: H=%d G=%d (the fused batch-1 path)", H, G);
+    TM_REQUIRE(ld_x >= P->F_total, "track_extend_tf: X [ND][ld %d] for F_total=%d", ld_x, P->F_total);
+    for (int q = 0; q < G; ++q)
+        TM_REQUIRE(P->F[q] > 0 && P->w1[q] && P->b1[q] && P->gamma[q] && P->beta[q] && P->w2[q] && P->b2[q] && P->run_mean[q] &&
+                       P->run_var[q], "track_extend_tf: null input-transform pointer in group %d", q);
+    TM_REQUIRE(g_new->meta && g_new->is_edge && g_new->pos && g_new->src && g_new->dst && g_new->src_pos && g_new->dst_pos &&
+                   g_new->edge_row && g_new->det_row && g_new->rowptr && g_new->inc && g_new->N == Nt && Nt <= g_new->cap,
+               "track_extend_tf: g_new must be bound for N + A*D + D = %d rows", Nt);
+    TM_REQUIRE(aligned16(h) && aligned16(save), "track_extend_tf: h / save must be 16-byte aligned");
+    if (save_floats < tmpnn_mp_iter_save_floats(Nt, n, G, H))
+        return set_error(TMPNN_EWORKSPACE, "track_extend_tf: save buffer %zu < %zu floats", save_floats,
+                         tmpnn_mp_iter_save_floats(Nt, n, G, H));
+    const SaveLayout SL = save_layout(Nt, n, G, H);
+    ExtendArgs e{N, A, D, t, active, new_ids, track, *rows};
+    BnFwdArgs b{*P, *g_new, n, 0, nullptr, 0, h, save + SL.ysave, save + SL.mean, save + SL.rstd,
+                reinterpret_cast<int*>(save + SL.total)};
+    BnSrcBlock src{A * D, new_ids, X, ld_x};
+    const size_t shm = std::max(sizeof(int) * ((size_t)8 * Nt + 1), sizeof(float) * 64 * (size_t)(H + 1));
+    if (H == 64) {
+        TM_SHM_ONCE(k_track_extend_tf<64>, sizeof(int) * (8 * TMPNN_DG_MAX_ROWS + 1));
+        hipLaunchKernelGGL(k_track_extend_tf<64>, dim3(1 + G), dim3(GC_THREADS), shm, as_stream(stream), e, *g_new, b, src);
+    } else {
+        TM_SHM_ONCE(k_track_extend_tf<32>, sizeof(int) * (8 * TMPNN_DG_MAX_ROWS + 1));
+        hipLaunchKernelGGL(k_track_extend_tf<32>, dim3(1 + G), dim3(GC_THREADS), shm, as_stream(stream), e, *g_new, b, src);
+    }
+    return check_launch("track_extend_tf");
+}
+
 int tmpnn_track_retire(const tmpnn_dgraph* g, const tmpnn_track_rows* rows, const float* score, int associate, int t_upto,
                        int ret_win, int32_t* y_track, int ND, int32_t* pos_of_det, void* fin_ws, size_t fin_ws_bytes,
                        int32_t* keep, int32_t* small, const tmpnn_track_rows* rows_out, const float* h, int ld_h, int W,
-                       float* h_new, int ld_hn, float* s_new, int next_t, int32_t* active, tmpnn_stream stream) {
+                       float* h_new, int ld_hn, float* s_new, int next_t, int32_t* active, int32_t* notify,
+                       tmpnn_stream stream) {
     TM_REQUIRE(g && small, "track_retire: null pointer");
+    TM_REQUIRE(notify_ok(notify), "track_retire: notify must be pinned host memory mapped into the device's address space at the "
+               "same address (hipHostMalloc), 32 bytes");
     if (g->N == 0) {            // nothing to decode (the old per-phase entry points returned early too): kept rows = kept dets =
         if (hipMemsetAsync(small, 0, 4 * sizeof(int32_t), as_stream(stream)) != hipSuccess)     // next active set = 0
             return set_error(TMPNN_ELAUNCH, "track_retire: clearing the counters failed");
+        if (notify) {
+            hipLaunchKernelGGL(k_track_publish, dim3(1), dim3(64), 0, as_stream(stream), small, notify);
+            return check_launch("track_retire (publish)");
+        }
         return TMPNN_OK;
     }
     TM_REQUIRE(rows_ok(rows) && rows_ok(rows_out) && score && keep && h && h_new && s_new, "track_retire: null pointer");
@@ -1060,7 +1201,7 @@ int tmpnn_track_retire(const tmpnn_dgraph* g, const tmpnn_track_rows* rows, cons
         hipLaunchKernelGGL(k_track_retire, dim3(1), dim3(TK_THREADS), sizeof(int) * (size_t)N, as_stream(stream), *g, *rows, score,
                            associate, t_upto, ret_win, y_track, ND, pos_of_det, keep, small, *rows_out, s_new, next_t, active,
                            reinterpret_cast<int32_t*>(fin_ws),
-                           associate == 2 ? (int)std::min<size_t>(fin_ws_bytes / 4, 1u << 30) : 0);
+                           associate == 2 ? (int)std::min<size_t>(fin_ws_bytes / 4, 1u << 30) : 0, notify);
         if ((rc = check_launch("track_retire"))) return rc;
         // the kept rows' state: sized for every row kept, the count read on the device (blocks beyond it leave at once)
         long blocks = ((long)N * ((W + 3) / 4) + 255) / 256;
@@ -1089,6 +1230,10 @@ int tmpnn_track_retire(const tmpnn_dgraph* g, const tmpnn_track_rows* rows, cons
                            (const int32_t*)rows_out->ts, (const int32_t*)rows_out->assoc, (const float*)s_new, 1, next_t, active,
                            small + 3);
         if ((rc = check_launch("track_retire (next active set)"))) return rc;
+    }
+    if (notify) {
+        hipLaunchKernelGGL(k_track_publish, dim3(1), dim3(64), 0, as_stream(stream), small, notify);
+        return check_launch("track_retire (publish)");
     }
     return TMPNN_OK;
 }

@@ -13,6 +13,7 @@
 #include <torch/extension.h>
 
 #include <cstdint>
+#include <chrono>
 #include <cstring>
 
 #include "tmpnn.h"
@@ -238,11 +239,15 @@ using extend_fn = int (*)(int, int, int, const int32_t*, const int32_t*, int, co
                           int, int, float*, int, const tmpnn_dgraph*, void*, size_t, tmpnn_stream);
 using retire_fn = int (*)(const tmpnn_dgraph*, const tmpnn_track_rows*, const float*, int, int, int, int32_t*, int, int32_t*, void*,
                           size_t, int32_t*, int32_t*, const tmpnn_track_rows*, const float*, int, int, float*, int, float*, int,
-                          int32_t*, tmpnn_stream);
+                          int32_t*, int32_t*, tmpnn_stream);
 using ints_fn = size_t (*)(int);
+using extend_tf_fn = int (*)(int, int, int, const int32_t*, const int32_t*, int, const int32_t*, const tmpnn_track_rows*, const float*,
+                             int, const tmpnn_mp_params*, float*, float*, size_t, const tmpnn_dgraph*, tmpnn_stream);
+using fwd_parts_fn = int (*)(const tmpnn_mp_params*, const float*, const tmpnn_dgraph*, int, const float*, int, float*, int, float*,
+                             float*, float*, float*, size_t, int, tmpnn_stream);
 
 std::vector<torch::Tensor> greedy_step(std::vector<int64_t> ti, std::vector<int64_t> info, torch::Tensor h, int64_t cap_rows) {
-    TORCH_CHECK(ti.size() == 27 && info.size() == 18, "greedy_step: bad descriptors");
+    TORCH_CHECK(ti.size() == 30 && info.size() == 18, "greedy_step: bad descriptors");
     const auto f_extend = reinterpret_cast<extend_fn>(ti[0]);
     const auto f_retire = reinterpret_cast<retire_fn>(ti[1]);
     const auto f_ints = reinterpret_cast<ints_fn>(ti[2]);
@@ -267,6 +272,13 @@ std::vector<torch::Tensor> greedy_step(std::vector<int64_t> ti, std::vector<int6
     const int associate = (int)ti[24];
     void* const hung_ws = reinterpret_cast<void*>(ti[25]);
     const size_t hung_ws_bytes = (size_t)ti[26];
+    // the counters' mirror in pinned, device-mapped host memory (tmpnn_track_retire `notify`; 0: read `small` back by a copy)
+    int32_t* const notify = reinterpret_cast<int32_t*>(ti[27]);
+    // the block append and the model call's input transform in one launch (tmpnn_track_extend_tf) + the iteration alone
+    // (tmpnn_mp_iter_fwd_parts, parts = 1); 0: the two calls as the Python path makes them (tmpnn_track_extend, tmpnn_mp_iter_fwd)
+    const auto f_extend_tf = reinterpret_cast<extend_tf_fn>(ti[28]);
+    const auto f_fwd_parts = reinterpret_cast<fwd_parts_fn>(ti[29]);
+    const bool one_launch = f_extend_tf != nullptr && f_fwd_parts != nullptr;
     TORCH_CHECK(associate == 1 || (associate == 2 && hung_ws && hung_ws_bytes > 0), "greedy_step: association rule ", associate);
     const auto f_fwd = reinterpret_cast<fwd_fn>(info[0]);
     const auto f_err = reinterpret_cast<err_fn>(info[2]);
@@ -282,9 +294,6 @@ std::vector<torch::Tensor> greedy_step(std::vector<int64_t> ti, std::vector<int6
     torch::Tensor arena = at::empty({(int64_t)f_ints(Nt)}, iopts);
     tmpnn_dgraph dg;
     TORCH_CHECK(f_bind(arena.data_ptr(), Nt, Nt, &dg) == 0, "tmpnn_dgraph_bind failed");
-    torch::Tensor feats = at::empty({n_new, F}, opts);
-    int rc = f_extend(N, A, D, active, new_ids, t, track, rows_cur, X, F, F, feats.data_ptr<float>(), F, &dg, nullptr, 0, stream);
-    TORCH_CHECK(rc == 0, "tmpnn_track_extend failed (code ", rc, "): ", f_err());
     // the model call (eval mode): the carried state extended in place where its storage has the room
     torch::Tensor h_cat;
     if (cap_rows >= Nt && (int64_t)h.storage().nbytes() >= (int64_t)((h.storage_offset() + (int64_t)Nt * GH) * sizeof(float))) {
@@ -296,10 +305,24 @@ std::vector<torch::Tensor> greedy_step(std::vector<int64_t> ti, std::vector<int6
     torch::Tensor h_out = at::empty({Nt, GH}, opts), logits = at::empty({Nt, 1}, opts), scores = at::empty({Nt, 1}, opts);
     const size_t nsave = save_floats(Nt, n_new, G, H);
     torch::Tensor save = at::empty({(int64_t)nsave}, opts);
-    rc = f_fwd(reinterpret_cast<const tmpnn_mp_params*>(info[3]), reinterpret_cast<const float*>(info[5]), &dg, n_new,
-               feats.data_ptr<float>(), F, h_cat.data_ptr<float>(), 0, h_out.data_ptr<float>(), logits.data_ptr<float>(),
-               scores.data_ptr<float>(), save.data_ptr<float>(), nsave, stream);
-    TORCH_CHECK(rc == 0, "tmpnn_mp_iter_fwd failed (code ", rc, "): ", f_err());
+    int rc;
+    if (one_launch) {
+        rc = f_extend_tf(N, A, D, active, new_ids, t, track, rows_cur, X, F, reinterpret_cast<const tmpnn_mp_params*>(info[3]),
+                         h_cat.data_ptr<float>(), save.data_ptr<float>(), nsave, &dg, stream);
+        TORCH_CHECK(rc == 0, "tmpnn_track_extend_tf failed (code ", rc, "): ", f_err());
+        rc = f_fwd_parts(reinterpret_cast<const tmpnn_mp_params*>(info[3]), reinterpret_cast<const float*>(info[5]), &dg, n_new,
+                         nullptr, 0, h_cat.data_ptr<float>(), 0, h_out.data_ptr<float>(), logits.data_ptr<float>(),
+                         scores.data_ptr<float>(), nullptr, 0, 1, stream);
+        TORCH_CHECK(rc == 0, "tmpnn_mp_iter_fwd_parts failed (code ", rc, "): ", f_err());
+    } else {
+        torch::Tensor feats = at::empty({n_new, F}, opts);
+        rc = f_extend(N, A, D, active, new_ids, t, track, rows_cur, X, F, F, feats.data_ptr<float>(), F, &dg, nullptr, 0, stream);
+        TORCH_CHECK(rc == 0, "tmpnn_track_extend failed (code ", rc, "): ", f_err());
+        rc = f_fwd(reinterpret_cast<const tmpnn_mp_params*>(info[3]), reinterpret_cast<const float*>(info[5]), &dg, n_new,
+                   feats.data_ptr<float>(), F, h_cat.data_ptr<float>(), 0, h_out.data_ptr<float>(), logits.data_ptr<float>(),
+                   scores.data_ptr<float>(), save.data_ptr<float>(), nsave, stream);
+        TORCH_CHECK(rc == 0, "tmpnn_mp_iter_fwd failed (code ", rc, "): ", f_err());
+    }
     // decode_tracks + the next timestep's active set; the compacted state lands in a buffer with room for the next block
     torch::Tensor hbuf = at::empty({(Nt + spare_next) * GH}, opts);
     torch::Tensor h_new = at::empty({0}, opts).set_(hbuf.storage(), 0, {Nt, GH}, {GH, 1});
@@ -307,10 +330,26 @@ std::vector<torch::Tensor> greedy_step(std::vector<int64_t> ti, std::vector<int6
     rc = f_retire(&dg, rows_cur, scores.data_ptr<float>(), associate, t_upto, ret_win, y_track, ND, pos_of_det,
                   associate == 2 ? hung_ws : nullptr, associate == 2 ? hung_ws_bytes : 0, keep_rows,
                   small, rows_out, h_out.data_ptr<float>(), (int)GH, (int)GH, h_new.data_ptr<float>(), (int)GH,
-                  s_new.data_ptr<float>(), next_t, active, stream);
+                  s_new.data_ptr<float>(), next_t, active, notify, stream);
     TORCH_CHECK(rc == 0, "tmpnn_track_retire failed (code ", rc, "): ", f_err());
-    // the one host read of the timestep: kept rows, kept det rows, the next active-set size
-    torch::Tensor counts = at::from_blob(small, {4}, iopts).cpu();
+    // the one host read of the timestep: kept rows, status, kept det rows, the next active-set size.  With a mirror: poll its
+    // flag (the launch stores the counters there, then the flag) -- no copy is enqueued and the counts are here while the kept
+    // rows' state is still moving; a flag that stays down for 20 ms (a long Hungarian sweep is < 1 ms) falls back to the copy.
+    torch::Tensor counts;
+    if (notify != nullptr) {
+        const auto t0 = std::chrono::steady_clock::now();
+        bool seen = false;
+        for (unsigned spins = 1;; ++spins) {
+            if (__atomic_load_n(notify + 4, __ATOMIC_ACQUIRE) != 0) { seen = true; break; }
+            if ((spins & 0xfff) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(20)) break;
+            __builtin_ia32_pause();
+        }
+        if (seen) {
+            counts = at::empty({4}, at::TensorOptions().dtype(torch::kInt32));
+            std::memcpy(counts.data_ptr(), notify, 4 * sizeof(int32_t));
+        }
+    }
+    if (!counts.defined()) counts = at::from_blob(small, {4}, iopts).cpu();
     return {h_new, s_new, counts, arena, scores, logits};
 }
 

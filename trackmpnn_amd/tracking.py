@@ -21,6 +21,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import time
 from typing import Optional, Tuple
 
 import numpy as np
@@ -34,6 +35,12 @@ TRACK_MAX_ROWS = 32768       # TMPNN_TRACK_MAX_ROWS
 # (TMPNN_TRACK_HOST_COUNTS=0 keeps the read); TMPNN_TRACK_VERIFY=1 reads the device's count as well and compares (tests)
 _TRAIN_HOST_COUNTS = os.environ.get('TMPNN_TRACK_HOST_COUNTS', '1') != '0'
 _TRACK_VERIFY = os.environ.get('TMPNN_TRACK_VERIFY', '0') == '1'
+# decode / the native timestep: the launch mirrors its counters into pinned host memory and the host polls the mirror's flag
+# instead of copying `small` back (include/tmpnn.h tmpnn_track_retire `notify`); TMPNN_TRACK_NOTIFY=0 keeps the copy
+_TRACK_NOTIFY = os.environ.get('TMPNN_TRACK_NOTIFY', '1') != '0'
+# the native timestep: block append + the model call's input transform in one launch (tmpnn_track_extend_tf);
+# TMPNN_TRACK_EXTEND_TF=0 keeps tmpnn_track_extend + the two launches of tmpnn_mp_iter_fwd
+_TRACK_EXTEND_TF = os.environ.get('TMPNN_TRACK_EXTEND_TF', '1') != '0'
 
 
 def _stream() -> int:
@@ -65,6 +72,9 @@ class TrackGraph:
         self._active = torch.empty(cap, **i32)
         self._keep = torch.empty(cap, **i32)
         self._small = torch.zeros(4, **i32)              # [0] count, [1] status, [2] kept dets, [3] next active-set size
+        # the mirror of `small` a retire launch writes for the host: [0..3] the counters, [4] the flag (pinned, device-mapped)
+        self._notify = torch.zeros(8, dtype=torch.int32).pin_memory() if (_TRACK_NOTIFY and self.device.type == 'cuda') else None
+        self._notify_np = None if self._notify is None else self._notify.numpy()
         self.track: Optional[torch.Tensor] = None        # int32 [ND] track id of every detection (training labels)
         self._graph: Optional[DeviceGraph] = None        # index form of the rows; None: stale (re-derived on first use)
         # per sequence, set by initialize(): the finalised tracks y_out[:, 1] (device, -1 = none yet), the detections of
@@ -431,10 +441,11 @@ class TrackGraph:
                   2 if hung_dev else (0 if use_hungarian else 1), int(t_upto), int(ret_win_size), self.y_track.data_ptr(), ND,
                   self._pos_of_det.data_ptr(), fin_ptr, fin_bytes, self._keep.data_ptr(),
                   self._small.data_ptr(), C.byref(self._crows[1 - self._cur]), hd.data_ptr(), W, W, h_new.data_ptr(), W,
-                  s_new.data_ptr(), nt, self._active.data_ptr(), _stream())
+                  s_new.data_ptr(), nt, self._active.data_ptr(), self._notify_arm(), _stream())
         if y_out is not None:
             y_out[:, 1] = self.y_track[:y_out.shape[0]].cpu().numpy()
-        n_keep, status, n_det, a_next = self._small.tolist()    # the ONE host read of a decode: kept rows (how many are dets; next A)
+        # the ONE host read of a decode: kept rows (how many are dets; next A)
+        n_keep, status, n_det, a_next = self._notify_wait() or self._small.tolist()
         self._check_assoc_status(status, hung_dev)
         self._cur = 1 - self._cur
         self.N, self.E, self.Dn = n_keep, n_keep - n_det, n_det
@@ -478,7 +489,8 @@ class TrackGraph:
         if self._fast_addrs is None:
             lib = _lib.load()
             addr = lambda f: C.cast(f, C.c_void_p).value
-            self._fast_addrs = (addr(lib.tmpnn_track_extend), addr(lib.tmpnn_track_retire), addr(lib.tmpnn_dgraph_ints))
+            self._fast_addrs = (addr(lib.tmpnn_track_extend), addr(lib.tmpnn_track_retire), addr(lib.tmpnn_dgraph_ints),
+                                addr(lib.tmpnn_track_extend_tf) if _TRACK_EXTEND_TF else 0, addr(lib.tmpnn_mp_iter_fwd_parts))
         fa = self._fast_addrs
         nt = -1 if next_t is None else int(next_t)
         spare = 2 * n_new + 256                  # room behind the compacted state for the next block (else: one copy)
@@ -492,6 +504,8 @@ class TrackGraph:
             ti += [2, hws.data_ptr(), hws.numel() * 4]
         else:
             ti += [1, 0, 0]
+        ti.append(self._notify_arm() or 0)
+        ti += [fa[3], fa[4]]
         model_info[7] = N + n_new
         try:
             h_new, s_new, counts, arena, scores, logits = fast.greedy_step(ti, model_info, h, int(cap_rows))
@@ -510,6 +524,31 @@ class TrackGraph:
         if nt >= 0:
             self._prefetch = (nt, sc, a_next, sc._version, bool(use_hungarian))
         return h_new[:n_keep], sc, N + n_new + spare
+
+    def _notify_arm(self):
+        """Clear the mirror's flag; its address for the launch (None: no mirror, the caller copies `small` back)."""
+        if self._notify is None:
+            return None
+        self._notify_np[4] = 0
+        return self._notify.data_ptr()
+
+    def _notify_wait(self, limit_s: float = 0.02):
+        """The counters once the launch has published them (polling the flag: no copy, no stream synchronisation); None when
+        there is no mirror or the flag stays down for `limit_s` -- the caller then reads `small` (which synchronises)."""
+        m = self._notify_np
+        if m is None:
+            return None
+        spins = 0
+        t0 = None
+        while m[4] == 0:
+            spins += 1
+            if (spins & 0x3ff) == 0:
+                now = time.perf_counter()
+                if t0 is None:
+                    t0 = now
+                elif now - t0 > limit_s:
+                    return None
+        return [int(m[0]), int(m[1]), int(m[2]), int(m[3])]
 
     def kept_rows(self) -> torch.Tensor:
         """Rows of the previous graph that the last decode() kept (ascending)."""
