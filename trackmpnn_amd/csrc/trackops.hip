@@ -76,6 +76,17 @@ struct HgShared {
     int wave[TK_THREADS / 64 + 1];
     int d0, d1, tnext, nr, nrows;
 };
+// A retire launch runs the sweep twice (decode_tracks on the grown graph, then the next update_graph's over the rows that stay).
+// The second sweep's problem of a timestep is the first sweep's whenever its rows are the same dets (its columns -- every det of
+// a timestep at or after t_upto -- and its costs -- the scores -- are; an edge that goes away starts at a deleted det, which was a
+// row of the first problem or took no part in it): the first sweep leaves rows and outcome of each problem here and the second
+// takes the outcome over instead of solving again (round 6; in steady state only the oldest timestep's problem differs).
+static constexpr int HG_MEMO_T = 16, HG_MEMO_R = 64;
+struct HgMemo {
+    int n;
+    int t[HG_MEMO_T], nr[HG_MEMO_T], nc[HG_MEMO_T], d0[HG_MEMO_T];
+    short rows[HG_MEMO_T][HG_MEMO_R], assign[HG_MEMO_T][HG_MEMO_R];    // det index of a row; det index it was associated with, -1 none
+};
 __device__ __forceinline__ void hg_wave_sync() {          // LDS writes of this wave visible to its other lanes (one wave only)
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_wave_barrier();
@@ -380,7 +391,8 @@ __device__ void hg_wave_solve64(HgShared& S, const float* C, int sr, int sc, int
 #define HG_STAMP(i) do { } while (0)
 __device__ void d_track_hungarian(tmpnn_dgraph g, const int32_t* __restrict__ ts, const int32_t* __restrict__ det_id,
                                   const float* __restrict__ score, int32_t* __restrict__ assoc, int32_t* __restrict__ status,
-                                  float* __restrict__ cost_ws, int cost_ws_floats, const int* remap = nullptr, int n_out = 0) {
+                                  float* __restrict__ cost_ws, int cost_ws_floats, const int* remap = nullptr, int n_out = 0,
+                                  HgMemo* memo = nullptr, int memo_mode = 0 /* 1: record, 2: look up */) {
     // remap (k_track_retire, after the deletion): new index of a row that stays, -1 for a deleted one -- the sweep then runs over
     // the rows that stay, as the reference's NEXT update_graph runs it on the compacted graph (deleted dets and the edges that go
     // with them take no part; det ids and the order of rows are what they will be), and writes assoc [n_out] in the new numbering
@@ -410,7 +422,7 @@ __device__ void d_track_hungarian(tmpnn_dgraph g, const int32_t* __restrict__ ts
     int t_done = -0x7fffffff;
     // (an iteration starts with no timestep chosen, no det range and no row flags: set here, and again inside the loop once
     //  everyone has read them -- one barrier less than doing it at the top)
-    if (tid == 0) { S.tnext = 0x7fffffff; S.d0 = 0x7fffffff; S.d1 = -1; }
+    if (tid == 0) { S.tnext = 0x7fffffff; S.d0 = 0x7fffffff; S.d1 = -1; if (memo_mode == 1) memo->n = 0; }
     for (int d = tid; d < Dn; d += TK_THREADS) S.flag[d] = 0;
     __syncthreads();
     for (;;) {
@@ -460,6 +472,25 @@ __device__ void d_track_hungarian(tmpnn_dgraph g, const int32_t* __restrict__ ts
             __syncthreads();
             continue;
         }
+        if (memo_mode == 2) {                                 // (block-uniform throughout)
+            int hit = -1;
+            for (int q = 0; q < memo->n; ++q) if (memo->t[q] == t) { hit = q; break; }
+            if (hit >= 0 && memo->nr[hit] == nr && memo->nc[hit] == nc && memo->d0[hit] == d0) {
+                int diff = 0;
+                for (int i = tid; i < nr; i += TK_THREADS) diff |= memo->rows[hit][i] != (short)S.rowlist[i];
+                if (!__syncthreads_or(diff)) {
+                    for (int i = tid; i < nr; i += TK_THREADS) {
+                        const int a = memo->assign[hit][i];
+                        if (a >= 0) S.ad[S.rowlist[i]] = (short)a;
+                    }
+                    __syncthreads();
+                    continue;
+                }
+            }
+        }
+        const int rec = (memo_mode == 1 && memo->n < HG_MEMO_T && nr <= HG_MEMO_R) ? memo->n : -1;
+        if (rec >= 0)
+            for (int i = tid; i < nr; i += TK_THREADS) { memo->rows[rec][i] = (short)S.rowlist[i]; memo->assign[rec][i] = -1; }
         float* C = lds_cost ? S.cost : cost_ws;
         for (int x = tid; x < nr * nc; x += TK_THREADS) C[x] = 100.0f;
         __syncthreads();
@@ -494,8 +525,12 @@ __device__ void d_track_hungarian(tmpnn_dgraph g, const int32_t* __restrict__ ts
         for (int i = tid; i < na; i += TK_THREADS) {
             const int j = S.col4row[i];
             const int pr = tr ? j : i, cu = tr ? i : j;          // (row of the problem = prev det, column = det of timestep t)
-            if (C[pr * nc + cu] <= 0.5f) S.ad[S.rowlist[pr]] = (short)(d0 + cu);
+            if (C[pr * nc + cu] <= 0.5f) {
+                S.ad[S.rowlist[pr]] = (short)(d0 + cu);
+                if (rec >= 0) memo->assign[rec][pr] = (short)(d0 + cu);
+            }
         }
+        if (rec >= 0 && tid == 0) { memo->t[rec] = t; memo->nr[rec] = nr; memo->nc[rec] = nc; memo->d0[rec] = d0; memo->n = rec + 1; }
         __syncthreads();
     }
     // y_pred[:, 2] of the associated dets: the det id of the partner
@@ -884,10 +919,12 @@ __global__ __launch_bounds__(TK_THREADS) void k_track_retire(tmpnn_dgraph g, tmp
                                                              size (a kernel argument because a literal null in its LDS /
                                                              global pointer select crashes hipcc) */, int hung_floats,
                                                              int32_t* __restrict__ notify) {
+    __shared__ HgMemo memo;                     // (associate = 2: what the first sweep leaves for the second, see HgMemo)
     if (associate == 2) {                       // optimal assignment per timestep (--hungarian); its cost scratch rides in fin_ws
         if (threadIdx.x == 0) small[1] = 0;
         __syncthreads();
-        d_track_hungarian(g, r.ts, r.det_id, score, r.assoc, small + 1, reinterpret_cast<float*>(fin_ws), hung_floats);
+        d_track_hungarian(g, r.ts, r.det_id, score, r.assoc, small + 1, reinterpret_cast<float*>(fin_ws), hung_floats, nullptr, 0,
+                          &memo, next_t >= 0 ? 1 : 0);
         __syncthreads();
     } else if (associate) {
         d_track_associate(g, r.det_id, nullptr, score, 1, r.assoc, small + 1, (int)threadIdx.x, TK_THREADS);
@@ -911,7 +948,7 @@ __global__ __launch_bounds__(TK_THREADS) void k_track_retire(tmpnn_dgraph g, tmp
             // was assigned and deleted frees its column there); that sweep here, over the rows that stay, into the new rows
             extern __shared__ int tk_new_index[];             // (d_track_delete's: new index of a kept row, -1 deleted)
             d_track_hungarian(g, r.ts, r.det_id, score, o.assoc, small + 1, reinterpret_cast<float*>(fin_ws), hung_floats,
-                              tk_new_index, small[0]);
+                              tk_new_index, small[0], &memo, 2);
             __threadfence_block();
             __syncthreads();
         }
