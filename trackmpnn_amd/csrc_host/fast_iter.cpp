@@ -302,20 +302,24 @@ std::vector<torch::Tensor> greedy_step(std::vector<int64_t> ti, std::vector<int6
         h_cat = at::empty({Nt, GH}, opts);
         if (N > 0) h_cat.narrow(0, 0, N).copy_(h);
     }
-    torch::Tensor h_out = at::empty({Nt, GH}, opts), logits = at::empty({Nt, 1}, opts), scores = at::empty({Nt, 1}, opts);
     const size_t nsave = save_floats(Nt, n_new, G, H);
     torch::Tensor save = at::empty({(int64_t)nsave}, opts);
+    torch::Tensor h_out, logits, scores;
     int rc;
     if (one_launch) {
+        // (the device has been idle since the previous timestep's last launch: this one goes out before anything it does not need
+        //  is allocated)
         rc = f_extend_tf(N, A, D, active, new_ids, t, track, rows_cur, X, F, reinterpret_cast<const tmpnn_mp_params*>(info[3]),
                          h_cat.data_ptr<float>(), save.data_ptr<float>(), nsave, &dg, stream);
         TORCH_CHECK(rc == 0, "tmpnn_track_extend_tf failed (code ", rc, "): ", f_err());
+        h_out = at::empty({Nt, GH}, opts); logits = at::empty({Nt, 1}, opts); scores = at::empty({Nt, 1}, opts);
         rc = f_fwd_parts(reinterpret_cast<const tmpnn_mp_params*>(info[3]), reinterpret_cast<const float*>(info[5]), &dg, n_new,
                          nullptr, 0, h_cat.data_ptr<float>(), 0, h_out.data_ptr<float>(), logits.data_ptr<float>(),
                          scores.data_ptr<float>(), nullptr, 0, 1, stream);
         TORCH_CHECK(rc == 0, "tmpnn_mp_iter_fwd_parts failed (code ", rc, "): ", f_err());
     } else {
         torch::Tensor feats = at::empty({n_new, F}, opts);
+        h_out = at::empty({Nt, GH}, opts); logits = at::empty({Nt, 1}, opts); scores = at::empty({Nt, 1}, opts);
         rc = f_extend(N, A, D, active, new_ids, t, track, rows_cur, X, F, F, feats.data_ptr<float>(), F, &dg, nullptr, 0, stream);
         TORCH_CHECK(rc == 0, "tmpnn_track_extend failed (code ", rc, "): ", f_err());
         rc = f_fwd(reinterpret_cast<const tmpnn_mp_params*>(info[3]), reinterpret_cast<const float*>(info[5]), &dg, n_new,
@@ -350,7 +354,9 @@ std::vector<torch::Tensor> greedy_step(std::vector<int64_t> ti, std::vector<int6
         }
     }
     if (!counts.defined()) counts = at::from_blob(small, {4}, iopts).cpu();
-    return {h_new, s_new, counts, arena, scores, logits};
+    // (the kept rows: views cut here -- a slice made by the interpreter costs ~2 us of the gap in front of the next launch)
+    const int64_t n_keep = std::min<int64_t>(std::max<int64_t>(counts.data_ptr<int32_t>()[0], 0), Nt);
+    return {h_new.narrow(0, 0, n_keep), s_new.select(1, 0).narrow(0, 0, n_keep), counts};
 }
 
 // ------------------------------------------------------------------------------------------------------------------------

@@ -65,6 +65,7 @@ class TrackGraph:
         self._cur = 0
         self._prefetch = None                            # (timestep, the score tensor decode() returned, active-set size)
         self._fast_addrs = None
+        self._fast_tpl = None
         self._hung_max = None
         self._hung_ws = None
         self.E = 0
@@ -486,29 +487,38 @@ class TrackGraph:
                 and int(self._Xf.shape[1]) == int(model_info[11])):
             return None
         self._prefetch = None
-        if self._fast_addrs is None:
+        tpl = self._fast_tpl
+        if tpl is None or tpl[30] != bool(use_hungarian):
+            # everything of the call descriptor that does not change within a sequence, built once: a dozen data_ptr() calls per
+            # timestep sat between the host read of one timestep and the first launch of the next
             lib = _lib.load()
             addr = lambda f: C.cast(f, C.c_void_p).value
-            self._fast_addrs = (addr(lib.tmpnn_track_extend), addr(lib.tmpnn_track_retire), addr(lib.tmpnn_dgraph_ints),
-                                addr(lib.tmpnn_track_extend_tf) if _TRACK_EXTEND_TF else 0, addr(lib.tmpnn_mp_iter_fwd_parts))
-        fa = self._fast_addrs
+            tpl = [addr(lib.tmpnn_track_extend), addr(lib.tmpnn_track_retire), addr(lib.tmpnn_dgraph_ints), 0, 0, 0, 0, 0, 0, 0,
+                   self._active.data_ptr(), self._ids_sorted.data_ptr(), self.track.data_ptr(), C.addressof(self._crows[0]),
+                   C.addressof(self._crows[1]), self._Xf.data_ptr(), int(self._Xf.shape[1]), self.y_track.data_ptr(),
+                   int(self.y_track.numel()), self._pos_of_det.data_ptr(), self._keep.data_ptr(), self._small.data_ptr(), 0, 0]
+            if use_hungarian:
+                hws = self._hung_scratch()
+                tpl += [2, hws.data_ptr(), hws.numel() * 4]
+            else:
+                tpl += [1, 0, 0]
+            tpl += [0 if self._notify is None else self._notify.data_ptr(),
+                    addr(lib.tmpnn_track_extend_tf) if _TRACK_EXTEND_TF else 0, addr(lib.tmpnn_mp_iter_fwd_parts), bool(use_hungarian)]
+            self._fast_tpl = tpl
         nt = -1 if next_t is None else int(next_t)
         spare = 2 * n_new + 256                  # room behind the compacted state for the next block (else: one copy)
-        ti = [fa[0], fa[1], fa[2], N, A, D, int(t), int(t_upto), int(ret_win_size), nt, self._active.data_ptr(),
-              self._ids_sorted.data_ptr() + 4 * lo, self.track.data_ptr(), C.addressof(self._crows[self._cur]),
-              C.addressof(self._crows[1 - self._cur]), self._Xf.data_ptr(), int(self._Xf.shape[1]), self.y_track.data_ptr(),
-              int(self.y_track.numel()), self._pos_of_det.data_ptr(), self._keep.data_ptr(), self._small.data_ptr(), spare,
-              _stream()]
-        if use_hungarian:
-            hws = self._hung_scratch()
-            ti += [2, hws.data_ptr(), hws.numel() * 4]
-        else:
-            ti += [1, 0, 0]
-        ti.append(self._notify_arm() or 0)
-        ti += [fa[3], fa[4]]
+        ti = tpl[:30]
+        ti[3:10] = (N, A, D, int(t), int(t_upto), int(ret_win_size), nt)
+        ti[11] += 4 * lo
+        if self._cur:
+            ti[13], ti[14] = ti[14], ti[13]
+        ti[22] = spare
+        ti[23] = _stream()
+        if self._notify is not None:
+            self._notify_np[4] = 0
         model_info[7] = N + n_new
         try:
-            h_new, s_new, counts, arena, scores, logits = fast.greedy_step(ti, model_info, h, int(cap_rows))
+            h_keep, sc, counts = fast.greedy_step(ti, model_info, h, int(cap_rows))
         except RuntimeError:
             # a C entry point refused its arguments before launching anything that changes the graph: rows [0, N) and the
             # counters are as they were (the appended block sits beyond N and the grown index form in its own arena)
@@ -520,10 +530,9 @@ class TrackGraph:
         self._cur = 1 - self._cur
         self.N, self.E, self.Dn = n_keep, n_keep - n_det, n_det
         self._graph = None
-        sc = s_new[:n_keep, 0]
         if nt >= 0:
             self._prefetch = (nt, sc, a_next, sc._version, bool(use_hungarian))
-        return h_new[:n_keep], sc, N + n_new + spare
+        return h_keep, sc, N + n_new + spare
 
     def _notify_arm(self):
         """Clear the mirror's flag; its address for the launch (None: no mirror, the caller copies `small` back)."""
