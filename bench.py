@@ -617,6 +617,12 @@ def loop_batch1(budget_s=1.5):
                 ms_per_sequence=round(ms, 3), frames=LOOP_INFER_FRAMES, ms_per_timestep=round(ms / LOOP_INFER_FRAMES, 4),
                 calls=ncalls, edge_iterations=edges, tracks=int(y_out[:, 1].max()) + 1,
                 stages_ms={k: round(v * 1e3, 3) for k, v in st.items()})
+        # the loop as the reference README runs it (README.md:52-67, 113-122): --hungarian with a model trained by
+        # --no-tp-classifier -- every detection counts as a true positive (infer.py:77-80), so active sets and graphs are larger
+        ms, (y_out, ncalls, edges) = timed(lambda: infer_sequence(model, Xi, yi, s['win'], 0, True, dev, False))
+        out['infer'][f'{tag}/hungarian_no_tp_classifier'] = dict(
+            ms_per_sequence=round(ms, 3), frames=LOOP_INFER_FRAMES, ms_per_timestep=round(ms / LOOP_INFER_FRAMES, 4), calls=ncalls,
+            edge_iterations=edges, tracks=int(y_out[:, 1].max()) + 1)
     out['note'] = ('batch 1, fp32, one process; ms_* = un-instrumented wall time incl. every host read; stages_ms = a second, '
                    'instrumented pass (device sync around each stage: its sum exceeds the wall time).  The real reference on '
                    'the same sequences: BASELINE.md section 5 (build-container CPU; it cannot travel to this box)')

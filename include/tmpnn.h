@@ -541,7 +541,9 @@ int tmpnn_mp_iter_fwd(const tmpnn_mp_params* P, const float* prep, const tmpnn_d
  * bit 1 = skip the iteration launch, bit 2 = the aggregate es [G][N][H] (by det INDEX, the layout of the save buffer at
  * tmpnn_mp_iter_save_es_offset floats) has been written by the caller -- tmpnn_att_fwd(out = save + offset + g N H,
  * ld_out = H) on the state `h` that the input transform launch completed -- and the det tiles read it instead of forming
- * the signed sum.  Sequence: parts = 2, tmpnn_att_fwd per feature group, parts = 1 | 4.  parts = 0 is tmpnn_mp_iter_fwd. */
+ * the signed sum.  Sequence: parts = 2, tmpnn_att_fwd per feature group, parts = 1 | 4.  parts = 0 is tmpnn_mp_iter_fwd.
+ * bit 3 (round 6; inference only): scores[det rows] = 1 -- a model trained without the TP classifier (the reference README's
+ * commands, README.md:52-67), whose detections all count as true positives in the loop (infer.py:53-56, 77-80); logits unchanged. */
 size_t tmpnn_mp_iter_save_es_offset(int N, int n_new, int G, int H);
 int tmpnn_mp_iter_fwd_parts(const tmpnn_mp_params* P, const float* prep, const tmpnn_dgraph* g, int n_new,
                             const float* x, int ld_x, float* h, int training,

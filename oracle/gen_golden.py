@@ -297,13 +297,15 @@ def node_adj_diag_zero(na):
 
 
 def run_infer_fixture(name, out_dir, seed, T, dmean, cur_win, ret_win, hungarian, H=32, K=0, msg='diff', light=False,
-                      gap=None, shuffle=False):
+                      gap=None, shuffle=False, no_tp=False):
     """The inference loop of infer.py:48-87 on the real reference: eval-mode model, update_graph(mode='test'),
     decode_tracks(cuda=False) with its row deletion between calls.  Every forward call is stored with ITS inputs
     (x, the row-deleted carried state, the adjacency pair as produced) and outputs; every decode step with the rows
     it kept (read off a marker array passed as `labels`), y_pred before / after and the finalised tracks y_out.
     light=True (dense scenes, thousands of rows): only what drives and checks the graph maintenance is kept -- the
-    scores of every call, y_pred, kept rows, y_out -- no states, adjacency or parameters."""
+    scores of every call, y_pred, kept rows, y_out -- no states, adjacency or parameters.
+    no_tp=True: a model trained with --no-tp-classifier (the reference README's commands, README.md:52-67): every detection counts
+    as a true positive -- its row of `scores` is overwritten with (0, 1) after every model call (infer.py:53-56, 77-80)."""
     from models.track_mpnn import TrackMPNN
     from utils.graph import decode_tracks, initialize_graph, update_graph
 
@@ -371,6 +373,10 @@ def run_infer_fixture(name, out_dir, seed, T, dmean, cur_win, ret_win, hungarian
         c = 0
         record_call(c, feats, None, node_adj, edge_adj, scores, logits, states, y_pred)
         scores = torch.cat((1 - scores, scores), dim=1)
+        if no_tp:
+            idx_node = torch.nonzero((y_pred[:, 0] != -1))[:, 0]
+            scores[idx_node, 0] = 0
+            scores[idx_node, 1] = 1
         nsteps = 0
         t_skip = t_st
         for t_cur in range(t_st, t_end):
@@ -390,6 +396,10 @@ def run_infer_fixture(name, out_dir, seed, T, dmean, cur_win, ret_win, hungarian
             c += 1
             record_call(c, feats, h_in, node_adj, edge_adj, scores, logits, states, y_pred)
             scores = torch.cat((1 - scores, scores), dim=1)
+            if no_tp:
+                idx_node = torch.nonzero((y_pred[:, 0] != -1))[:, 0]
+                scores[idx_node, 0] = 0
+                scores[idx_node, 1] = 1
             t_upto = t_end if t_cur == t_end - 1 else t_cur - cur_win + 2
             N = states.shape[0]
             marker = torch.arange(N, dtype=torch.int64)
@@ -418,6 +428,8 @@ def run_infer_fixture(name, out_dir, seed, T, dmean, cur_win, ret_win, hungarian
                 ncalls=ncalls, seed=seed, T=T, cur_win_size=cur_win, ret_win_size=ret_win, hungarian=bool(hungarian),
                 rows_deleted=n_del, reinitialisations=n_reinit, torch=torch.__version__,
                 reference='arangesh/TrackMPNN infer.py:48-87 loop')
+    if no_tp:
+        meta['tp_classifier'] = False
     if shuffle:
         meta['detections'] = 'listed in shuffled order'
     out['meta'] = np.array(json.dumps(meta))
@@ -478,6 +490,9 @@ def main():
     if args.only == 'wide':
         run_wide_fixtures(args.out)
         return
+    if args.only == 'notp':
+        run_notp_fixtures(args.out)
+        return
     seed = 0
     for feats, ncat in (('2d', 3), ('2d+temp+vis', 3)):
         for msg in ('diff', 'concat'):
@@ -526,6 +541,7 @@ def main():
                       gap=(5, 10))
     run_unsorted_fixtures(args.out)
     run_wide_fixtures(args.out)
+    run_notp_fixtures(args.out)
 
 
 def run_wide_fixtures(out_dir):
@@ -542,6 +558,15 @@ def run_unsorted_fixtures(out_dir):
                       shuffle=True)
     run_infer_fixture('infer_hungarian_w4_r1_unsorted', out_dir, 505, T=9, dmean=4, cur_win=4, ret_win=1, hungarian=True,
                       shuffle=True)
+
+
+def run_notp_fixtures(out_dir):
+    """round 6: the inference loop as the reference README runs it (README.md:52-67, 113-122): a model trained with
+    --no-tp-classifier, --hungarian association (and the greedy rule), cur_win_size 5, ret_win_size 0, H = 64."""
+    run_infer_fixture('infer_hungarian_w5_r0_notp', out_dir, 506, T=9, dmean=4, cur_win=5, ret_win=0, hungarian=True, H=64,
+                      no_tp=True)
+    run_infer_fixture('infer_greedy_w5_r0_notp', out_dir, 507, T=8, dmean=3, cur_win=5, ret_win=0, hungarian=False, H=64,
+                      no_tp=True)
 
 
 def run_c1(out_dir):

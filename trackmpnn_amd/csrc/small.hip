@@ -112,6 +112,7 @@ struct IterFwdArgs {
     float* es;                 // [G][N][H]   or NULL (nothing saved)
     int es_given;              // != 0: es already holds the edge -> node aggregate of every det (the attention stage wrote it:
                                // tmpnn_att_fwd between the two launches of tmpnn_mp_iter_fwd_parts); det tiles read it
+    int det_score_one;         // != 0: scores[det rows] = 1 (a model without TP classifier at inference, infer.py:53-56, 77-80)
 };
 
 // gi/gh MFMA loop of one column slice: acc[gate] += A(tile rows, K = W) x image.  The weight operands (3 gates x W/16
@@ -297,7 +298,7 @@ __global__ __launch_bounds__(256) void k_small_iter_fwd(IterFwdArgs a) {
         const float y = ((sLog[0][tid] + sLog[1][tid]) + (sLog[2][tid] + sLog[3][tid])) + bias;
         const int grow = sRow[tid];
         a.logits[grow] = y;
-        a.scores[grow] = sigm(y);
+        a.scores[grow] = (!is_e && a.det_score_one) ? 1.0f : sigm(y);
     }
 }
 
@@ -1019,8 +1020,9 @@ int tmpnn_mp_iter_fwd_parts(const tmpnn_mp_params* P, const float* prep, const t
         TM_REQUIRE(aligned16(save), "mp_iter_fwd: save must be 16-byte aligned");
     }
     hipStream_t st = as_stream(stream);
-    TM_REQUIRE((parts & ~7) == 0 && (!(parts & 4) || sv != nullptr), "mp_iter_fwd_parts: parts=%d (an aggregate given by the "
+    TM_REQUIRE((parts & ~15) == 0 && (!(parts & 4) || sv != nullptr), "mp_iter_fwd_parts: parts=%d (an aggregate given by the "
                "caller lives in the save buffer)", parts);
+    TM_REQUIRE(!(parts & 8) || !training, "mp_iter_fwd_parts: parts bit 3 (det scores = 1) is an inference rule");
     if (n_new > 0 && !(parts & 1)) {
         TM_REQUIRE(sv != nullptr, "mp_iter_fwd: a call with new rows needs the save buffer (the input transform keeps its "
                                   "Lin1 outputs and statistics there), also in inference");
@@ -1033,7 +1035,7 @@ int tmpnn_mp_iter_fwd_parts(const tmpnn_mp_params* P, const float* prep, const t
     }
     if (parts & 2) return TMPNN_OK;
     IterFwdArgs a{*P, *g, prep, h, h_out, logits, scores, sv ? sv + SL.gates : nullptr, sv ? sv + SL.es : nullptr,
-                  (parts & 4) ? 1 : 0};
+                  (parts & 4) ? 1 : 0, (parts & 8) ? 1 : 0};
     const int grid = (N + TR - 1) / TR + 2;
     if (H == 64 && P->IN_e == 64) hipLaunchKernelGGL((k_small_iter_fwd<64, 64>), dim3(grid), dim3(256), 0, st, a);
     else if (H == 64) hipLaunchKernelGGL((k_small_iter_fwd<64, 128>), dim3(grid), dim3(256), 0, st, a);

@@ -247,7 +247,7 @@ using fwd_parts_fn = int (*)(const tmpnn_mp_params*, const float*, const tmpnn_d
                              float*, float*, float*, size_t, int, tmpnn_stream);
 
 std::vector<torch::Tensor> greedy_step(std::vector<int64_t> ti, std::vector<int64_t> info, torch::Tensor h, int64_t cap_rows) {
-    TORCH_CHECK(ti.size() == 30 && info.size() == 18, "greedy_step: bad descriptors");
+    TORCH_CHECK(ti.size() == 31 && info.size() == 18, "greedy_step: bad descriptors");
     const auto f_extend = reinterpret_cast<extend_fn>(ti[0]);
     const auto f_retire = reinterpret_cast<retire_fn>(ti[1]);
     const auto f_ints = reinterpret_cast<ints_fn>(ti[2]);
@@ -279,6 +279,9 @@ std::vector<torch::Tensor> greedy_step(std::vector<int64_t> ti, std::vector<int6
     const auto f_extend_tf = reinterpret_cast<extend_tf_fn>(ti[28]);
     const auto f_fwd_parts = reinterpret_cast<fwd_parts_fn>(ti[29]);
     const bool one_launch = f_extend_tf != nullptr && f_fwd_parts != nullptr;
+    // 8: the model has no TP classifier -- every detection's score is 1 (tmpnn_mp_iter_fwd_parts bit 3; infer.py:77-80)
+    const int score_rule = (int)ti[30];
+    TORCH_CHECK((score_rule & ~8) == 0 && (score_rule == 0 || f_fwd_parts != nullptr), "greedy_step: score rule ", score_rule);
     TORCH_CHECK(associate == 1 || (associate == 2 && hung_ws && hung_ws_bytes > 0), "greedy_step: association rule ", associate);
     const auto f_fwd = reinterpret_cast<fwd_fn>(info[0]);
     const auto f_err = reinterpret_cast<err_fn>(info[2]);
@@ -315,16 +318,21 @@ std::vector<torch::Tensor> greedy_step(std::vector<int64_t> ti, std::vector<int6
         h_out = at::empty({Nt, GH}, opts); logits = at::empty({Nt, 1}, opts); scores = at::empty({Nt, 1}, opts);
         rc = f_fwd_parts(reinterpret_cast<const tmpnn_mp_params*>(info[3]), reinterpret_cast<const float*>(info[5]), &dg, n_new,
                          nullptr, 0, h_cat.data_ptr<float>(), 0, h_out.data_ptr<float>(), logits.data_ptr<float>(),
-                         scores.data_ptr<float>(), nullptr, 0, 1, stream);
+                         scores.data_ptr<float>(), nullptr, 0, 1 | score_rule, stream);
         TORCH_CHECK(rc == 0, "tmpnn_mp_iter_fwd_parts failed (code ", rc, "): ", f_err());
     } else {
         torch::Tensor feats = at::empty({n_new, F}, opts);
         h_out = at::empty({Nt, GH}, opts); logits = at::empty({Nt, 1}, opts); scores = at::empty({Nt, 1}, opts);
         rc = f_extend(N, A, D, active, new_ids, t, track, rows_cur, X, F, F, feats.data_ptr<float>(), F, &dg, nullptr, 0, stream);
         TORCH_CHECK(rc == 0, "tmpnn_track_extend failed (code ", rc, "): ", f_err());
-        rc = f_fwd(reinterpret_cast<const tmpnn_mp_params*>(info[3]), reinterpret_cast<const float*>(info[5]), &dg, n_new,
-                   feats.data_ptr<float>(), F, h_cat.data_ptr<float>(), 0, h_out.data_ptr<float>(), logits.data_ptr<float>(),
-                   scores.data_ptr<float>(), save.data_ptr<float>(), nsave, stream);
+        if (f_fwd_parts != nullptr)
+            rc = f_fwd_parts(reinterpret_cast<const tmpnn_mp_params*>(info[3]), reinterpret_cast<const float*>(info[5]), &dg, n_new,
+                             feats.data_ptr<float>(), F, h_cat.data_ptr<float>(), 0, h_out.data_ptr<float>(), logits.data_ptr<float>(),
+                             scores.data_ptr<float>(), save.data_ptr<float>(), nsave, score_rule, stream);
+        else
+            rc = f_fwd(reinterpret_cast<const tmpnn_mp_params*>(info[3]), reinterpret_cast<const float*>(info[5]), &dg, n_new,
+                       feats.data_ptr<float>(), F, h_cat.data_ptr<float>(), 0, h_out.data_ptr<float>(), logits.data_ptr<float>(),
+                       scores.data_ptr<float>(), save.data_ptr<float>(), nsave, stream);
         TORCH_CHECK(rc == 0, "tmpnn_mp_iter_fwd failed (code ", rc, "): ", f_err());
     }
     // decode_tracks + the next timestep's active set; the compacted state lands in a buffer with room for the next block

@@ -143,7 +143,7 @@ def infer_sequence(model, X: torch.Tensor, y: torch.Tensor, cur_win_size: int = 
                     if step_info is None:
                         step_info = finfo()
                     r = tg.greedy_step_fast(fast, step_info, h, h_cap, t_cur, t_upto, ret_win_size,
-                                            t_cur + 1 if t_cur + 1 < t_end else None, use_hungarian)
+                                            t_cur + 1 if t_cur + 1 < t_end else None, use_hungarian, tp_classifier)
                     if r is not None:
                         h, sc, h_cap = r
                         n_added = 1                            # (a native step only runs with D_t > 0 new detections)
@@ -171,10 +171,11 @@ def infer_sequence(model, X: torch.Tensor, y: torch.Tensor, cur_win_size: int = 
 def _fast_greedy(model, use_hungarian: bool, tp_classifier: bool, stages):
     """(native module, call-descriptor factory, 0) where a steady-state greedy timestep can run in csrc_host/fast_iter.cpp's
     greedy_step: models on the fused batch-1 path without attention heads, eval mode, greedy or (where the device solver takes
-    the sequence's problems: TrackGraph.greedy_step_fast checks per timestep) Hungarian association with the TP classifier, no
-    per-stage instrumentation; (None, None, 0) otherwise."""
+    the sequence's problems: TrackGraph.greedy_step_fast checks per timestep) Hungarian association, with or without the TP
+    classifier (without: the iteration writes 1 as every detection's score, infer.py:77-80), no per-stage instrumentation;
+    (None, None, 0) otherwise."""
     from .small import fast_module, small_eligible
-    if not tp_classifier or stages is not None or model.training or getattr(model, '_padded', False):
+    if stages is not None or model.training or getattr(model, '_padded', False):
         return None, None, 0
     sp = getattr(model, '_small', None)
     if sp is None or not sp.eligible or sp.att or not small_eligible(model, 1):

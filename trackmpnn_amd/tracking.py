@@ -458,7 +458,7 @@ class TrackGraph:
 
     # ---------------------------------------------------------------------------------------------------------------
     def greedy_step_fast(self, fast, model_info, h: torch.Tensor, cap_rows: int, t: int, t_upto: int, ret_win_size: int,
-                         next_t: Optional[int], use_hungarian: bool = False):
+                         next_t: Optional[int], use_hungarian: bool = False, tp_classifier: bool = True):
         """One steady-state inference timestep (update -> eval model call -> decode; greedy or device-Hungarian association)
         through the native driver (csrc_host/fast_iter.cpp greedy_step): the same three tracker calls and the same model call as
         update() / TrackMPNN.forward_dgraph / decode(), issued without the interpreter between them, then the timestep's one host read.
@@ -514,6 +514,7 @@ class TrackGraph:
             ti[13], ti[14] = ti[14], ti[13]
         ti[22] = spare
         ti[23] = _stream()
+        ti.append(0 if tp_classifier else 8)     # (no TP classifier: every detection's score is 1, infer.py:77-80)
         if self._notify is not None:
             self._notify_np[4] = 0
         model_info[7] = N + n_new
