@@ -145,12 +145,20 @@ since round 5 (`csrc/trackops.hip d_track_hungarian`: scipy's linear_sum_assignm
 bit-equal to the host matching incl. ties) against the host matching (`TMPNN_HUNGARIAN_HOST=1`: scipy, two more device <-> host copies
 per sweep), same box, same sequences:
 
-| sequence | greedy | Hungarian on the device | Hungarian on the host (round 4's form) |
-|---|---|---|---|
+| sequence | greedy | Hungarian on the device | Hungarian, model without TP classifier (the README's commands) | Hungarian on the host (round 4's form) |
+|---|---|---|---|---|
 ''')
         for c in ('C2', 'C3', 'C4'):
             f.write(f"| {c} | {dev['infer'][c + '/greedy']['ms_per_timestep']:.3f} | **{dev['infer'][c + '/hungarian']['ms_per_timestep']:.3f}** | "
+                    f"{dev['infer'].get(c + '/hungarian_no_tp_classifier', {}).get('ms_per_timestep', float('nan')):.3f} | "
                     f"{host['infer'][c + '/hungarian']['ms_per_timestep']:.3f} |\n")
+        f.write('''
+Round 5 on the same sequences: greedy 0.097 / 0.110 / 0.121, Hungarian on the device 0.150 / 0.308 / 0.242.  What changed (DESIGN.md
+section 7, item 4): the retire launch mirrors its counters into pinned host memory and the host polls a flag there (no copy-back);
+block append + index form + the model call's input transform in one launch (`k_track_extend_tf`); greedy association a wave per det;
+the counters published before the finalisation walk; the second Hungarian sweep of a launch reuses the first's outcome per unchanged
+problem; models without TP classifier (README.md:52-67) ride the native timestep.
+''')
         f.write('\nTrain chunk (`train.py:54-135`), ms per chunk: ' + ', '.join(f"{c} {dev['train'][c]['ms_per_chunk']:.2f}" for c in ('C2', 'C3', 'C4')) + '\n')
         if os.path.exists(f'{ld}/slowest.txt'):
             f.write('''
@@ -177,10 +185,11 @@ see `profiles/r06_bench_kernel_stats.md` (MaxNs column of the same kernels in th
 ## Where a C2 timestep goes (`tools/greedy_trace.py`: the inference loop of the C2 sequence alone, 50 sequences back to back)
 
 Wall time per timestep (un-profiled run) against the GPU kernel time per timestep (`rocprofv3 --kernel-trace` of the same command):
-the greedy loop keeps the device busy for about three quarters of a timestep -- a dozen launches of 3-25 us whose lengths are the
-latency of their dependent memory round trips (every kernel starts on a cold L2), plus one device -> host copy of two counters; the
-Hungarian loop is bound by the two launches that run the assignment sweep (`tools/track_timeline.py` splits them: the solver itself,
-one wave, ~7 us per 6 x 6 problem, a dozen problems per timestep).
+four launches per steady-state timestep (`k_track_extend_tf`, `k_small_iter_fwd`, `k_track_retire`, `k_track_gather`) whose lengths
+are the latency of their dependent memory round trips (every kernel starts on a cold L2); the host's part -- polling the counters'
+flag, sizing and issuing the next timestep's first launch -- is the rest.  The Hungarian loop is bound by the retire launch's two
+assignment sweeps (the solver itself, one wave, ~6 us per problem, a timestep's problems one after another: the rows of problem t
+are the dets still unassociated after the problems before it).
 
 ''')
             for m in ('greedy', 'hungarian'):

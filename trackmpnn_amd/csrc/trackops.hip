@@ -133,6 +133,19 @@ __device__ __forceinline__ uint32_t hg_wave_min32(uint32_t x) {
     for (int r = 0; r < ROWS; ++r) { const uint32_t y = (uint32_t)__builtin_amdgcn_readlane(x, 16 * r); m = y < m ? y : m; }
     return m;
 }
+// minima over a ROW of 16 lanes (the four DPP steps alone: every lane of the row ends up with its row's minimum)
+__device__ __forceinline__ uint32_t hg_row_min32(uint32_t x) {
+    x = hg_min_step32<0xB1>(x);
+    x = hg_min_step32<0x4E>(x);
+    x = hg_min_step32<0x141>(x);
+    return hg_min_step32<0x140>(x);
+}
+__device__ __forceinline__ uint64_t hg_row_min64(uint64_t x) {
+    x = hg_min_step64<0xB1>(x);
+    x = hg_min_step64<0x4E>(x);
+    x = hg_min_step64<0x141>(x);
+    return hg_min_step64<0x140>(x);
+}
 __device__ __forceinline__ uint64_t hg_key(double x) {        // order-preserving: a < b  <=>  key(a) < key(b)   (no NaNs here)
     const uint64_t b = (uint64_t)__double_as_longlong(x + 0.0);           // (-0.0 -> +0.0: scipy compares with ==)
     return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
@@ -146,10 +159,10 @@ __device__ __forceinline__ int hg_wave_min_i(int x) {          // (block-level h
 // mode 1 (inference, greedy, :251-268 / :437-454): a det scored >= 0.5 looks at its future edges scored >= 0.5 that
 //   lead to a det scored >= 0.5, keeps those of the NEAREST timestep (rows before the first det row after the first
 //   such edge) and takes the highest score (first of equals).
-// mode 1 runs one WAVE per det, a lane per incident edge (round 6): a thread per det walked its incidences through a chain of
-// four dependent loads each (inc -> pos -> dst -> score: ~50 L2 round trips for a det of a KITTI window, and only Dn threads at
-// work); a wave issues every incidence's chain side by side and picks the first / the best edge by two wave reductions.
-// (i0, stride): a wave-aligned thread index and thread count (a block's threadIdx.x / size, or a 256-thread grid's global index).
+// mode 1 runs a group of 16 LANES per det, a lane per incident edge (round 6): a thread per det walked its incidences through a
+// chain of four dependent loads each (inc -> pos -> dst -> score: ~50 L2 round trips for a det of a KITTI window, and only Dn
+// threads at work); a group issues every incidence's chain side by side and picks the first / the best edge by DPP row reductions.
+// (i0, stride): a 16-aligned thread index and thread count (a block's threadIdx.x / size, or a 256-thread grid's global index).
 __device__ __forceinline__ void d_track_associate(tmpnn_dgraph g, const int32_t* __restrict__ det_id,
                                                          const uint8_t* __restrict__ labels,
                                                          const float* __restrict__ score, int mode,
@@ -158,44 +171,50 @@ __device__ __forceinline__ void d_track_associate(tmpnn_dgraph g, const int32_t*
     for (int r = i0; r < N; r += stride)
         if (g.is_edge[r]) assoc[r] = -1;
     if (mode != 0) {
-        const int lane = i0 & 63, wave = i0 >> 6, nw = stride >> 6;
-        for (int d = wave; d < Dn; d += nw) {                          // (wave-uniform control flow throughout)
+        // a group of 16 lanes (one DPP row) per det: a KITTI / BDD det has ~6-20 incidences, and all dets of a window go in one round
+        const int lane = i0 & 15, grp = i0 >> 4, ng = stride >> 4;
+        for (int d = grp; d < Dn; d += ng) {                           // (group-uniform control flow throughout)
             const int row = g.det_row[d];
             int out = -1;
             if (score[row] >= 0.5f) {
                 const int p0 = g.rowptr[d], p1 = g.rowptr[d + 1];
                 // the first qualifying future edge: incidences are in ascending edge-row order, so it is the smallest row of
-                // the first chunk of 64 that holds one
-                int first = 0x7fffffff;
-                for (int base = p0; base < p1 && first == 0x7fffffff; base += 64) {
+                // the first chunk of 16 that holds one
+                int first = 0x7fffffff, first_pos = 0;
+                for (int base = p0; base < p1 && first == 0x7fffffff; base += 16) {
                     const int p = base + lane;
-                    int cand = 0x7fffffff;
+                    int cand = 0x7fffffff, cpos = 0;
                     if (p < p1) {
                         const int key = g.inc[p];
-                        if (key >= 0 && score[key] >= 0.5f && score[g.dst[g.pos[key]]] >= 0.5f) cand = key;
+                        if (key >= 0) {
+                            cpos = g.pos[key];
+                            if (score[key] >= 0.5f && score[g.dst[cpos]] >= 0.5f) cand = key;
+                        }
                     }
-                    first = hg_wave_min_i(cand);
+                    first = (int)hg_row_min32((uint32_t)cand);
+                    // (its index among the edge rows rides along: the lane that holds `first` hands it to the group)
+                    first_pos = (int)hg_row_min32(cand == first ? (uint32_t)cpos : 0xFFFFFFFFu);
                 }
                 if (first != 0x7fffffff) {
-                    // first det row after `first`: det_row is ascending -> binary search (every lane the same search)
-                    int lo = 0, hi = Dn;
-                    while (lo < hi) { const int mid = (lo + hi) >> 1; if (g.det_row[mid] > first) hi = mid; else lo = mid + 1; }
+                    // first det row after `first`: `first` has first - pos[first] det rows in front of it (pos = its index among
+                    // the edge rows), and det_row is ascending
+                    const int lo = first - first_pos;
                     const int limit = lo < Dn ? g.det_row[lo] : N;
                     // highest score among the qualifying edges in [first, limit), the first of equals: the maximum of
                     // (score bits, ~row) -- scores here are >= 0.5, their bit patterns order like the values
                     uint64_t bestk = 0;
-                    for (int base = p0; base < p1; base += 64) {
+                    for (int base = p0; base < p1; base += 16) {
                         const int p = base + lane;
                         uint64_t k = 0;
                         if (p < p1) {
                             const int key = g.inc[p];
                             if (key >= first && key < limit) {
-                                const float s = score[key];
-                                if (s >= 0.5f && score[g.dst[g.pos[key]]] >= 0.5f)
-                                    k = ((uint64_t)__float_as_uint(s) << 32) | (uint32_t)(0x7fffffff - key);
+                                const float sc = score[key];
+                                if (sc >= 0.5f && score[g.dst[g.pos[key]]] >= 0.5f)
+                                    k = ((uint64_t)__float_as_uint(sc) << 32) | (uint32_t)(0x7fffffff - key);
                             }
                         }
-                        k = ~hg_wave_min64(~k);
+                        k = ~hg_row_min64(~k);
                         bestk = k > bestk ? k : bestk;
                     }
                     if (bestk) out = det_id[g.dst[g.pos[0x7fffffff - (int)(uint32_t)bestk]]];
