@@ -875,7 +875,76 @@ __device__ __forceinline__ void d_track_finalize(tmpnn_dgraph g, const int32_t* 
             if (flag[k] & 4) y_track[det_id[g.det_row[k]]] = oldv[k];
         return;
     }
-    if (tid == 0) {
+    if (Dn <= FIN_LDS_DETS) {
+        // The same pass WITHOUT its serial loop (round 6: one thread over LDS arrays took 0.15 us per det -- 5 of the 8 us of this
+        // function for a KITTI window, 9 of 12 for a BDD one).  A det's link leads to a later det, so the pass is three closures
+        // along the links, each by pointer doubling in ONE wave (lanes over the dets in chunks of 64, no workgroup barrier; a
+        // round's reads may or may not see what the same round wrote -- every mark is monotone, so both are right):
+        //   on a path  = eligible, or linked from a det on a path          (bit 2 of the flag, value 4)
+        //   reached    = linked from a det on a path (bit 1)  ->  a START is an eligible det that is not reached
+        //   label      = that of the LATEST start (largest position) whose walk comes through: max along the links
+        // and the new ids are handed out in the order of the starts: a count over the positions before.
+        if (tid < 64) {
+            const int lane = tid;
+            int* const jump = s_order;                                  // (free here: the det-id order is the other branch's)
+            for (int k = lane; k < Dn; k += 64) {
+                const int nk = s_next[k];
+                jump[k] = nk > k ? nk : -1;
+                if (s_flag[k] & 1) s_flag[k] |= 4;
+            }
+            hg_wave_sync();
+            for (;;) {
+                int more = 0;
+                for (int k = lane; k < Dn; k += 64) {
+                    const int j = jump[k];
+                    if (j >= 0) {
+                        if (s_flag[k] & 4) s_flag[j] |= 4;
+                        const int jj = jump[j];
+                        jump[k] = jj;
+                        more |= jj >= 0 ? 1 : 0;
+                    }
+                }
+                hg_wave_sync();
+                if (__ballot(more != 0) == 0) break;
+            }
+            for (int k = lane; k < Dn; k += 64) {
+                const int nk = s_next[k];
+                if (nk > k && (s_flag[k] & 4)) s_flag[nk] |= 2;
+            }
+            hg_wave_sync();
+            int run = s_max + 1;                                        // next free track id
+            for (int base = 0; base < Dn; base += 64) {
+                const int k = base + lane;
+                const unsigned char f = k < Dn ? s_flag[k] : (unsigned char)0;
+                const bool start = (f & 1) && !(f & 2);
+                const bool fresh = start && s_old[k] == -1;
+                const unsigned long long bal = __ballot(fresh);
+                if (k < Dn) {
+                    s_best[k] = start ? k : -1;
+                    if (start) s_tid[k] = fresh ? run + __popcll(bal & ((1ull << lane) - 1ull)) : s_old[k];
+                    const int nk = s_next[k];
+                    jump[k] = nk > k ? nk : -1;
+                }
+                run += __popcll(bal);
+            }
+            hg_wave_sync();
+            for (;;) {
+                int more = 0;
+                for (int k = lane; k < Dn; k += 64) {
+                    const int j = jump[k];
+                    if (j >= 0) {
+                        const int b = s_best[k];
+                        if (b >= 0) atomicMax(&s_best[j], b);
+                        const int jj = jump[j];
+                        jump[k] = jj;
+                        more |= jj >= 0 ? 1 : 0;
+                    }
+                }
+                hg_wave_sync();
+                if (__ballot(more != 0) == 0) break;
+            }
+        }
+    } else if (tid == 0) {
         int next_id = s_max + 1;
         for (int k = 0; k < Dn; ++k) {
             unsigned char f = flag[k];
