@@ -582,18 +582,21 @@ __device__ __forceinline__ void d_track_active(int N, const int32_t* __restrict_
     const int tprev = s_tprev;
     const int IT = (N + TK_THREADS - 1) / TK_THREADS;
     const int r0 = tid * IT, r1 = min(N, r0 + IT);
-    auto is_active = [&](int r) {
-        const int v = ts[r];
-        if (v == -1) return false;
-        if (mode == 0) return assoc[r] == -1 || v == tprev;
-        return assoc[r] == -1 && score[r] >= 0.5f;
-    };
+    // (a row's three operands are requested together: behind short-circuit tests they were a chain of dependent loads; the
+    //  verdicts are kept in a mask -- IT <= 32 at TMPNN_TRACK_MAX_ROWS -- instead of being derived twice)
     int mine = 0;
-    for (int r = r0; r < r1; ++r) mine += is_active(r) ? 1 : 0;
+    uint32_t amask = 0;
+    for (int r = r0; r < r1; ++r) {
+        const int v = ts[r], a = assoc[r];
+        const float sc = (mode == 0) ? 1.0f : score[r];
+        const bool on = v != -1 && (mode == 0 ? (a == -1 || v == tprev) : (a == -1 && sc >= 0.5f));
+        amask |= (on ? 1u : 0u) << (r - r0);
+        mine += on ? 1 : 0;
+    }
     int total;
     int p = tk_block_scan(mine, s_wave, &total);
     for (int r = r0; r < r1; ++r)
-        if (is_active(r)) active[p++] = r;
+        if ((amask >> (r - r0)) & 1u) active[p++] = r;
     if (tid == 0) count[0] = total;
 }
 __global__ __launch_bounds__(TK_THREADS) void k_track_active(int N, const int32_t* __restrict__ n_dev, const int32_t* __restrict__ ts, const int32_t* __restrict__ assoc, const float* __restrict__ score, int mode, int t, int32_t* __restrict__ active, int32_t* __restrict__ count) {
@@ -700,24 +703,28 @@ __device__ __forceinline__ void d_track_delete(int N, const int32_t* __restrict_
     atomicMax(&s_max, m);
     __syncthreads();
     const int max_id = s_max;
-    auto retained = [&](int r) {       // det row < max_id that survives
-        return assoc[r] == -1 && score[r] >= 0.5f && ts[r] >= t_upto - ret_win;
-    };
-    auto kept = [&](int r) {
-        if (r < max_id) return !is_edge[r] && retained(r);
-        if (!is_edge[r]) return true;
-        const int s = row_src[r];                           // an edge at or after max_id: dropped with its start det
-        return !(s < max_id && !retained(s));
-    };
+    // kept: below max_id the RETAINED dets only (unassociated, scored >= 0.5, not older than t_upto - ret_win); at or after it every
+    // det, and every edge whose start det is not a dropped one
     const int IT = (N + TK_THREADS - 1) / TK_THREADS;
     const int r0 = tid * IT, r1 = min(N, r0 + IT);
     int mine = 0, mine_dets = 0;
     uint32_t kmask = 0;                                     // the verdicts of this thread's rows (IT <= 32 at TMPNN_TRACK_MAX_ROWS):
-    for (int r = r0; r < r1; ++r) {                         // evaluated once -- each is a chain of dependent loads
-        const bool k = kept(r);
+    for (int r = r0; r < r1; ++r) {                         // evaluated once, a row's operands requested together: behind the
+        const bool e = is_edge[r] != 0;                     // short-circuit tests of kept() they were a chain of dependent loads
+        const int a = assoc[r], t = ts[r], sr = row_src[r];
+        const float sc = score[r];
+        bool k;
+        if (r < max_id) k = !e && a == -1 && sc >= 0.5f && t >= t_upto - ret_win;
+        else if (!e) k = true;
+        else if (sr >= max_id) k = true;
+        else {                                              // an edge at or after max_id: dropped with its start det
+            const int a2 = assoc[sr], t2 = ts[sr];
+            const float s2 = score[sr];
+            k = a2 == -1 && s2 >= 0.5f && t2 >= t_upto - ret_win;
+        }
         kmask |= (k ? 1u : 0u) << (r - r0);
         mine += k ? 1 : 0;
-        mine_dets += (k && !is_edge[r]) ? 1 : 0;
+        mine_dets += (k && !e) ? 1 : 0;
     }
     if (mine_dets) atomicAdd(&s_dets, mine_dets);
     int total;
