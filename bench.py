@@ -569,15 +569,21 @@ def loop_batch1(budget_s=1.5):
                 if k.startswith('output_transform') and k.endswith('bias'):
                     prm.copy_(0.5 * torch.randn(prm.shape, generator=gp))
 
-    def timed(fn):
+    worst = {}
+
+    def timed(fn, tag=None):
         for _ in range(3):
             r = fn()
         torch.cuda.synchronize()
-        n, t0 = 0, time.perf_counter()
+        n, t0, mx = 0, time.perf_counter(), 0.0
         while time.perf_counter() - t0 < budget_s or n < 3:
+            t1 = time.perf_counter()
             r = fn()
+            mx = max(mx, time.perf_counter() - t1)       # (host time of one call: the loops read the device every timestep)
             n += 1
         torch.cuda.synchronize()
+        if tag is not None:
+            worst[tag] = (round(mx * 1e3, 3), n)
         return (time.perf_counter() - t0) / n * 1e3, r
 
     out = dict(train={}, infer={})
@@ -610,11 +616,13 @@ def loop_batch1(budget_s=1.5):
                                  stages_ms={k: round(v * 1e3, 3) for k, v in st.items()})
         model.eval()
         for hung in (False, True):
-            ms, (y_out, ncalls, edges) = timed(lambda: infer_sequence(model, Xi, yi, s['win'], 0, hung, dev))
+            key = f"{tag}/{'hungarian' if hung else 'greedy'}"
+            ms, (y_out, ncalls, edges) = timed(lambda: infer_sequence(model, Xi, yi, s['win'], 0, hung, dev), key)
             st = {}
             infer_sequence(model, Xi, yi, s['win'], 0, hung, dev, stages=st)
-            out['infer'][f"{tag}/{'hungarian' if hung else 'greedy'}"] = dict(
-                ms_per_sequence=round(ms, 3), frames=LOOP_INFER_FRAMES, ms_per_timestep=round(ms / LOOP_INFER_FRAMES, 4),
+            out['infer'][key] = dict(
+                ms_per_sequence=round(ms, 3), slowest_sequence_ms=worst[key][0], sequences_timed=worst[key][1],
+                frames=LOOP_INFER_FRAMES, ms_per_timestep=round(ms / LOOP_INFER_FRAMES, 4),
                 calls=ncalls, edge_iterations=edges, tracks=int(y_out[:, 1].max()) + 1,
                 stages_ms={k: round(v * 1e3, 3) for k, v in st.items()})
         # the loop as the reference README runs it (README.md:52-67, 113-122): --hungarian with a model trained by

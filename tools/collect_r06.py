@@ -175,8 +175,29 @@ inference loops of the three sequence shapes: ~0.5 M dispatches) there is no suc
             f.write('''```
 
 The maxima of `k_track_retire` / `k_track_select` are the Hungarian sweeps of the C3 sequences (12-frame windows: ten timesteps'
-problems solved one after another inside the launch); nothing waits or spins.  The round-4 outliers belong to the full bench run:
-see `profiles/r06_bench_kernel_stats.md` (MaxNs column of the same kernels in this round's trace of `bench.py`).
+problems solved one after another inside the launch); nothing waits or spins.
+
+The outliers of the full bench run (`profiles/r06_bench_kernel_stats.md`: MaxNs of `k_track_retire` 20-31 ms) are an artefact of
+tracing that run, not of the kernel: `tools/outliers.py` over a `rocprofv3 --kernel-trace` of `bench.py` finds ONE or TWO such
+dispatches among ~770 000 (20.6 ms in one trace, 31.2 ms + 1.1 ms in another), each in the middle of a Hungarian inference loop
+between neighbours of ordinary length, on the same queue:
+
+```
+      + 23928.723 ms .. + 23928.947 ms      223.7 us  k_track_retire
+      + 23928.947 ms .. + 23928.951 ms        4.2 us  k_track_gather
+      + 23928.964 ms .. + 23928.979 ms       14.4 us  k_track_extend_tf<64>
+      + 23928.979 ms .. + 23929.001 ms       22.1 us  k_small_iter_fwd<64, 64>
+   >> + 23929.001 ms .. + 23960.169 ms    31168.4 us  k_track_retire
+      + 23960.169 ms .. + 23960.176 ms        7.3 us  k_track_gather
+      + 23960.176 ms .. + 23960.181 ms        4.1 us  __amd_rocclr_copyBuffer      (the host's poll gave up after 20 ms and copied)
+      + 23960.231 ms .. + 23960.251 ms       19.6 us  k_track_extend_tf<64>
+```
+
+The same command WITHOUT the profiler has no such call: `bench.py` now reports the slowest single sequence of every timed loop
+(`loop_batch1.infer.*.slowest_sequence_ms`, host time of one 40-frame sequence) -- C2 / C3 / C4 Hungarian 4.79 / 9.40 / 7.71 ms against
+means of 4.66 / 9.33 / 7.64 ms over 322 / 161 / 197 sequences (a 20-ms stall would be two to four sequences long).  The kernel has no
+wait in it (the device never waits for the host; its loops are bounded by the problem sizes); round 4's 29.2 ms / 20.9 ms maxima were
+found in traces of the full bench run as well and never in a trace of the loops alone.
 ''')
         ts = f'{ld}/c2_timestep.json'
         if os.path.exists(ts):

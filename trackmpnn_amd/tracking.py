@@ -38,6 +38,7 @@ _TRACK_VERIFY = os.environ.get('TMPNN_TRACK_VERIFY', '0') == '1'
 # decode / the native timestep: the launch mirrors its counters into pinned host memory and the host polls the mirror's flag
 # instead of copying `small` back (include/tmpnn.h tmpnn_track_retire `notify`); TMPNN_TRACK_NOTIFY=0 keeps the copy
 _TRACK_NOTIFY = os.environ.get('TMPNN_TRACK_NOTIFY', '1') != '0'
+_NOTIFY_POOL: list = []      # pinned int32 [8] mirrors not in use (list.pop / append are atomic under the GIL)
 # the native timestep: block append + the model call's input transform in one launch (tmpnn_track_extend_tf);
 # TMPNN_TRACK_EXTEND_TF=0 keeps tmpnn_track_extend + the two launches of tmpnn_mp_iter_fwd
 _TRACK_EXTEND_TF = os.environ.get('TMPNN_TRACK_EXTEND_TF', '1') != '0'
@@ -74,7 +75,10 @@ class TrackGraph:
         self._keep = torch.empty(cap, **i32)
         self._small = torch.zeros(4, **i32)              # [0] count, [1] status, [2] kept dets, [3] next active-set size
         # the mirror of `small` a retire launch writes for the host: [0..3] the counters, [4] the flag (pinned, device-mapped)
-        self._notify = torch.zeros(8, dtype=torch.int32).pin_memory() if (_TRACK_NOTIFY and self.device.type == 'cuda') else None
+        # (taken from a process-wide free list and handed back when this graph goes away: the loops make one TrackGraph per
+        #  sequence, and pinning fresh host memory means a page-table update on the device under whatever kernel is running)
+        self._notify = (_NOTIFY_POOL.pop() if _NOTIFY_POOL else torch.zeros(8, dtype=torch.int32).pin_memory()) \
+            if (_TRACK_NOTIFY and self.device.type == 'cuda') else None
         self._notify_np = None if self._notify is None else self._notify.numpy()
         self.track: Optional[torch.Tensor] = None        # int32 [ND] track id of every detection (training labels)
         self._graph: Optional[DeviceGraph] = None        # index form of the rows; None: stale (re-derived on first use)
@@ -86,6 +90,12 @@ class TrackGraph:
         self._t_range: dict = {}
         self._Xd: Optional[torch.Tensor] = None
         self._fin_ws: Optional[torch.Tensor] = None
+
+    def __del__(self):
+        # every launch that writes the mirror has been waited for by the call that issued it: the buffer is free to reuse
+        n = getattr(self, '_notify', None)
+        if n is not None and len(_NOTIFY_POOL) < 64:
+            _NOTIFY_POOL.append(n)
 
     @property
     def rows(self):
