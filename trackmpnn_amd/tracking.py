@@ -93,9 +93,12 @@ class TrackGraph:
 
     def __del__(self):
         # every launch that writes the mirror has been waited for by the call that issued it: the buffer is free to reuse
-        n = getattr(self, '_notify', None)
-        if n is not None and len(_NOTIFY_POOL) < 64:
-            _NOTIFY_POOL.append(n)
+        try:
+            n = getattr(self, '_notify', None)
+            if n is not None and len(_NOTIFY_POOL) < 64:
+                _NOTIFY_POOL.append(n)
+        except Exception:       # (interpreter shutdown: the module's globals may be gone)
+            pass
 
     @property
     def rows(self):
