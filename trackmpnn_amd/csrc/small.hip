@@ -113,6 +113,7 @@ struct IterFwdArgs {
     int es_given;              // != 0: es already holds the edge -> node aggregate of every det (the attention stage wrote it:
                                // tmpnn_att_fwd between the two launches of tmpnn_mp_iter_fwd_parts); det tiles read it
     int det_score_one;         // != 0: scores[det rows] = 1 (a model without TP classifier at inference, infer.py:53-56, 77-80)
+    int det_tile;              // dets per det tile (<= TR): see k_small_iter_fwd
 };
 
 // gi/gh MFMA loop of one column slice: acc[gate] += A(tile rows, K = W) x image.  The weight operands (3 gates x W/16
@@ -158,13 +159,19 @@ __global__ __launch_bounds__(256) void k_small_iter_fwd(IterFwdArgs a) {
         for (int i = blockIdx.x * 256 + threadIdx.x; i < a.g.N; i += gridDim.x * 256) { a.logits[i] = qnan; a.scores[i] = qnan; }
         return;
     }
+    // A det tile's staging sums the det's incident edge rows (~50 per det in a KITTI-sized window): with TR dets per tile that is
+    // ~800 row loads from ONE CU, bound by its L1's outstanding misses (10 us of the launch's 16 at the C2 shape, 18 of 23 at the
+    // BDD shape, while the edge tiles are done after 2) -- and a window has only 2-5 such tiles.  Small graphs therefore take
+    // det_tile = 4 dets per tile (four times the CUs on the aggregation; the matrix phase computes TR rows either way, rows
+    // beyond the tile's dets are never stored): same arithmetic per row, bit-identical results (round 6).
     const int E = a.g.meta[0], Dn = a.g.meta[1];
-    const int nEt = (E + TR - 1) / TR, nDt = (Dn + TR - 1) / TR;
+    const int TD = a.det_tile;
+    const int nEt = (E + TR - 1) / TR, nDt = (Dn + TD - 1) / TD;
     const int b = blockIdx.x;
     if (b >= nEt + nDt) return;
     const bool is_e = b < nEt;
-    const int r0 = (is_e ? b : b - nEt) * TR;
-    const int R = is_e ? E : Dn;
+    const int r0 = (is_e ? b : b - nEt) * (is_e ? TR : TD);
+    const int R = is_e ? E : min(Dn, r0 + TD);       // (rows of the tile at or beyond R are not part of it)
     const int G = a.P.G, GH = G * H, N = a.g.N;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     constexpr int LDX = IN_E + 4, LDH = H + 4;
@@ -173,6 +180,11 @@ __global__ __launch_bounds__(256) void k_small_iter_fwd(IterFwdArgs a) {
     __shared__ float sHp[TR * (H + 1)];        // h_prev of the tile, natural order (merge term of the epilogue)
     __shared__ float sLog[4][TR];
     __shared__ int sRow[TR], sS[TR], sD[TR];
+    // det tiles: the CSR runs of the tile's dets are one contiguous stretch of inc[] -- staged in LDS in one coalesced pass, so that
+    // the aggregation below is straight-line row loads, sixteen in flight per thread, instead of a dependent (incidence -> row)
+    // pair of round trips per four rows: ~26 of them in a row for a det of a KITTI-sized window
+    constexpr int SINC = 1024;
+    __shared__ int sPtr[TR + 1], sInc[SINC];
     if (tid < TR) {
         const int q = r0 + tid;
         const bool ok = q < R;
@@ -180,12 +192,23 @@ __global__ __launch_bounds__(256) void k_small_iter_fwd(IterFwdArgs a) {
         sRow[tid] = is_e ? a.g.edge_row[qc] : a.g.det_row[qc];
         sS[tid] = is_e ? a.g.src[qc] : 0;
         sD[tid] = is_e ? a.g.dst[qc] : 0;
+    } else if (tid < 2 * TR + 1 && !is_e) {
+        sPtr[tid - TR] = a.g.rowptr[min(r0 + tid - TR, R)];
     }
     float lsum[4] = {0.f, 0.f, 0.f, 0.f};
     const PrepLayout PL = prep_layout(H, IN_E);
     const int IN = is_e ? IN_E : H;
     const float* w_head = is_e ? a.P.w_edge : a.P.w_node;
     __syncthreads();
+    bool inc_lds = false;
+    if (!is_e && !a.es_given) {                                            // (block-uniform)
+        const int pb = sPtr[0], cnt = sPtr[TR] - pb;
+        inc_lds = cnt <= SINC;
+        if (inc_lds) {
+            for (int i = tid; i < cnt; i += 256) sInc[i] = a.g.inc[pb + i];
+            __syncthreads();
+        }
+    }
     for (int gi = 0; gi < G; ++gi) {
         const float* hg = a.h + gi * H;
         const float* img = a.prep + (size_t)gi * PL.per_group;
@@ -226,7 +249,26 @@ __global__ __launch_bounds__(256) void k_small_iter_fwd(IterFwdArgs a) {
                     // edge -> node aggregation (models/layers.py:103): signed sum over the det's incident edge rows,
                     // CSR order (ascending edge row), four rows in flight
                     const int d = r0 + row;
-                    const int p0 = a.g.rowptr[d], p1 = a.g.rowptr[d + 1];
+                    const int p0 = sPtr[row], p1 = sPtr[row + 1];
+                    if (inc_lds) {
+                        constexpr int UA = 16;
+                        const int* keys = sInc - sPtr[0];
+                        for (int p = p0; p < p1; p += UA) {
+                            int key[UA];
+                            float4 v[UA];
+#pragma unroll
+                            for (int u = 0; u < UA; ++u) key[u] = p + u < p1 ? keys[p + u] : 0;
+#pragma unroll
+                            for (int u = 0; u < UA; ++u)
+                                v[u] = *reinterpret_cast<const float4*>(hg + (size_t)(key[u] & 0x7fffffff) * GH + 4 * c4);
+#pragma unroll
+                            for (int u = 0; u < UA; ++u)
+                                if (p + u < p1) {
+                                    const float sgn = key[u] < 0 ? -1.0f : 1.0f;
+                                    x0.x += sgn * v[u].x; x0.y += sgn * v[u].y; x0.z += sgn * v[u].z; x0.w += sgn * v[u].w;
+                                }
+                        }
+                    } else
                     for (int p = p0; p < p1; p += 4) {
                         float4 v[4];
                         float sg[4];
@@ -1035,8 +1077,9 @@ int tmpnn_mp_iter_fwd_parts(const tmpnn_mp_params* P, const float* prep, const t
     }
     if (parts & 2) return TMPNN_OK;
     IterFwdArgs a{*P, *g, prep, h, h_out, logits, scores, sv ? sv + SL.gates : nullptr, sv ? sv + SL.es : nullptr,
-                  (parts & 4) ? 1 : 0, (parts & 8) ? 1 : 0};
-    const int grid = (N + TR - 1) / TR + 2;
+                  (parts & 4) ? 1 : 0, (parts & 8) ? 1 : 0, N <= TMPNN_DG_MAX_ROWS ? 4 : TR};
+    // (sized from N alone: E / Dn live on the device.  ceil(E / TR) + ceil(Dn / det_tile) <= N / det_tile + 2; surplus blocks exit)
+    const int grid = a.det_tile < TR ? (N + a.det_tile - 1) / a.det_tile + 2 : (N + TR - 1) / TR + 2;
     if (H == 64 && P->IN_e == 64) hipLaunchKernelGGL((k_small_iter_fwd<64, 64>), dim3(grid), dim3(256), 0, st, a);
     else if (H == 64) hipLaunchKernelGGL((k_small_iter_fwd<64, 128>), dim3(grid), dim3(256), 0, st, a);
     else if (P->IN_e == 32) hipLaunchKernelGGL((k_small_iter_fwd<32, 32>), dim3(grid), dim3(256), 0, st, a);
