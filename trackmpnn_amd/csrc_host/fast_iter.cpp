@@ -15,6 +15,7 @@
 #include <cstdint>
 #include <chrono>
 #include <cstring>
+#include <tuple>
 
 #include "tmpnn.h"
 
@@ -367,6 +368,55 @@ std::vector<torch::Tensor> greedy_step(std::vector<int64_t> ti, std::vector<int6
     return {h_new.narrow(0, 0, n_keep), s_new.select(1, 0).narrow(0, 0, n_keep), counts};
 }
 
+// Several steady-state timesteps in a row without the interpreter between them (round 6: what the interpreter did between two
+// timesteps -- unpacking the counts, the bookkeeping, building the next descriptor -- sat between the host read of one timestep and
+// the first launch of the next, while the device waited).  steps: five integers per timestep (t, t_upto, next_t or -1, address of
+// its det ids, D); state: N, A, E, Dn as the previous decode left them; limits: the one-launch kernels' row limit and the device
+// solver's det limit (0: greedy).  Stops BEFORE a timestep the native step does not take (no detections, the grown graph too large,
+// a problem the device solver may not take) and AFTER one whose status word is not clean or that ends the sequence; the caller
+// goes on from there.  Returns {h', scores', counts of the last step} and {steps done, sum of E over their model calls, N, E, Dn,
+// A, row-set flips, capacity of h' in rows}.
+std::tuple<std::vector<torch::Tensor>, std::vector<int64_t>> greedy_run(std::vector<int64_t> ti, std::vector<int64_t> info, torch::Tensor h,
+                                                                         int64_t cap_rows, std::vector<int64_t> steps,
+                                                                         std::vector<int64_t> state, std::vector<int64_t> limits) {
+    TORCH_CHECK(ti.size() == 31 && info.size() == 18 && steps.size() % 5 == 0 && state.size() == 4 && limits.size() == 2,
+                "greedy_run: bad descriptors");
+    int64_t N = state[0], A = state[1], E = state[2], Dn = state[3];
+    const int64_t max_rows = limits[0], hung_max = limits[1];
+    int64_t done = 0, edges = 0, flips = 0;
+    torch::Tensor sc, counts;
+    for (size_t k = 0; k + 5 <= steps.size(); k += 5) {
+        const int64_t D = steps[k + 4];
+        if (D <= 0 || N == 0) break;
+        const int64_t n_new = A * D + D;
+        if (N + n_new > max_rows || (hung_max > 0 && Dn + D > hung_max)) break;
+        ti[3] = N; ti[4] = A; ti[5] = D; ti[6] = steps[k]; ti[7] = steps[k + 1]; ti[9] = steps[k + 2]; ti[11] = steps[k + 3];
+        ti[22] = 2 * n_new + 256;
+        info[7] = N + n_new;
+        if (ti[27] != 0) __atomic_store_n(reinterpret_cast<int32_t*>(ti[27]) + 4, 0, __ATOMIC_RELAXED);   // (the mirror's flag: armed per launch)
+        std::vector<torch::Tensor> r;
+        try {
+            r = greedy_step(ti, info, h, cap_rows);
+        } catch (const c10::Error&) {
+            if (done == 0) throw;                  // (nothing changed yet: the caller sees the refusal itself)
+            break;                                  // the caller's next call meets it as its first step
+        }
+        const int32_t* c = r[2].data_ptr<int32_t>();
+        edges += E + A * D;
+        std::swap(ti[13], ti[14]);
+        ++flips;
+        cap_rows = N + n_new + ti[22];
+        h = r[0]; sc = r[1]; counts = r[2];
+        N = c[0]; Dn = c[2]; E = N - Dn; A = c[3];
+        ++done;
+        if (hung_max > 0 && (c[1] & 2)) break;     // (a status the caller raises on)
+        if (steps[k + 2] < 0) break;
+    }
+    std::vector<torch::Tensor> out;
+    if (done > 0) out = {h, sc, counts};
+    return {out, {done, edges, N, E, Dn, A, flips, cap_rows}};
+}
+
 // ------------------------------------------------------------------------------------------------------------------------
 // train.py:70-81 for one forward call as a native autograd node: tmpnn_train_losses_fwd / _bwd (one launch each way) without
 // the interpreter's Function.apply / backward bookkeeping (~50 us per call of a batch-1 train chunk).  trackmpnn_amd/loss.py
@@ -456,4 +506,5 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     m.def("train_losses", &train_losses, "create_targets + CELoss + the focal terms of one forward call as one native autograd node");
     m.def("small_iter", &small_iter, "fused TrackMPNN iteration on one small graph (in-place or sink gradient mode)");
     m.def("greedy_step", &greedy_step, "one greedy inference timestep: block append, model call (eval), decode_tracks, one host read");
+    m.def("greedy_run", &greedy_run, "steady-state inference timesteps back to back (greedy_step in a loop, no interpreter between them)");
 }

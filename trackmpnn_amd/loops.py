@@ -138,17 +138,21 @@ def infer_sequence(model, X: torch.Tensor, y: torch.Tensor, cur_win_size: int = 
                 if fast is not None and h is not None:
                     # steady state: the whole timestep (append, model call, decode, the one host read) in the native driver.
                     # Its model descriptor is built once per sequence (eval mode under no_grad: the parameters cannot change
-                    # inside this call; the per-step field, the row count, is overwritten by greedy_step_fast) -- building it
+                    # inside this call; the per-step field, the row count, is overwritten by the driver) -- building it
                     # sits between the host read of one timestep and the first launch of the next, i.e. on the critical path
                     if step_info is None:
                         step_info = finfo()
-                    r = tg.greedy_step_fast(fast, step_info, h, h_cap, t_cur, t_upto, ret_win_size,
-                                            t_cur + 1 if t_cur + 1 < t_end else None, use_hungarian, tp_classifier)
+                    # every remaining timestep is offered: the driver runs them back to back and stops in front of the first
+                    # one it does not take (no detections, a graph beyond the one-launch kernels, ...)
+                    steps = [(t, t_end if t == t_end - 1 else t - cur_win_size + 2, t + 1 if t + 1 < t_end else -1)
+                             for t in range(t_cur, t_end)]
+                    r = tg.greedy_run_fast(fast, step_info, h, h_cap, steps, ret_win_size, use_hungarian, tp_classifier)
                     if r is not None:
-                        h, sc, h_cap = r
+                        h, sc, h_cap, n_done, edges = r
                         n_added = 1                            # (a native step only runs with D_t > 0 new detections)
-                        ncalls += 1
-                        edge_iters += tg.last_E
+                        ncalls += n_done
+                        edge_iters += edges
+                        t_skip = t_cur + n_done                # (the loop variable moves past the timesteps that ran)
                         continue
                 feats = tg.update(sc, X, y, t_cur, mode='test', use_hungarian=use_hungarian)
                 n_added = int(feats.shape[0])
@@ -171,7 +175,7 @@ def infer_sequence(model, X: torch.Tensor, y: torch.Tensor, cur_win_size: int = 
 def _fast_greedy(model, use_hungarian: bool, tp_classifier: bool, stages):
     """(native module, call-descriptor factory, 0) where a steady-state greedy timestep can run in csrc_host/fast_iter.cpp's
     greedy_step: models on the fused batch-1 path without attention heads, eval mode, greedy or (where the device solver takes
-    the sequence's problems: TrackGraph.greedy_step_fast checks per timestep) Hungarian association, with or without the TP
+    the sequence's problems: the driver checks per timestep) Hungarian association, with or without the TP
     classifier (without: the iteration writes 1 as every detection's score, infer.py:77-80), no per-stage instrumentation;
     (None, None, 0) otherwise."""
     from .small import fast_module, small_eligible
@@ -181,7 +185,7 @@ def _fast_greedy(model, use_hungarian: bool, tp_classifier: bool, stages):
     if sp is None or not sp.eligible or sp.att or not small_eligible(model, 1):
         return None, None, 0
     fast = fast_module()
-    if fast is None or not hasattr(fast, 'greedy_step'):
+    if fast is None or not hasattr(fast, 'greedy_run'):
         return None, None, 0
     if model._plist is None:
         named = dict(model.named_parameters())

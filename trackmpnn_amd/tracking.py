@@ -472,27 +472,41 @@ class TrackGraph:
     # ---------------------------------------------------------------------------------------------------------------
     def greedy_step_fast(self, fast, model_info, h: torch.Tensor, cap_rows: int, t: int, t_upto: int, ret_win_size: int,
                          next_t: Optional[int], use_hungarian: bool = False, tp_classifier: bool = True):
-        """One steady-state inference timestep (update -> eval model call -> decode; greedy or device-Hungarian association)
-        through the native driver (csrc_host/fast_iter.cpp greedy_step): the same three tracker calls and the same model call as
-        update() / TrackMPNN.forward_dgraph / decode(), issued without the interpreter between them, then the timestep's one host read.
-        Preconditions (the caller checks them, else it takes the Python path): the previous decode / step prefetched this
-        timestep's active set (`_prefetch`), D_t > 0, the grown graph fits the one-launch kernels (<= 4096 rows).
-        Returns (h', score', capacity of h' in rows) or None when the preconditions do not hold."""
+        """One steady-state inference timestep through the native driver: greedy_run_fast with a single step.  Returns
+        (h', score', capacity of h' in rows) or None when the preconditions do not hold."""
+        r = self.greedy_run_fast(fast, model_info, h, cap_rows, [(int(t), int(t_upto), -1 if next_t is None else int(next_t))],
+                                 ret_win_size, use_hungarian, tp_classifier)
+        return None if r is None else r[:3]
+
+    def greedy_run_fast(self, fast, model_info, h: torch.Tensor, cap_rows: int, steps, ret_win_size: int,
+                        use_hungarian: bool = False, tp_classifier: bool = True):
+        """Steady-state inference timesteps (update -> eval model call -> decode; greedy or device-Hungarian association) through
+        the native driver (csrc_host/fast_iter.cpp greedy_run / greedy_step): per timestep the same three tracker calls and the
+        same model call as update() / TrackMPNN.forward_dgraph / decode(), issued without the interpreter between them or between
+        the timesteps, and the timestep's one host read.  steps: [(t, t_upto, next_t or -1), ...] in loop order; as many of them
+        as the native step takes are run (it stops in front of a timestep without detections, a grown graph beyond the
+        one-launch kernels' 4096 rows, a problem the device solver may not take).
+        Preconditions for the first step (else None and the caller takes the Python path): the previous decode / step prefetched
+        its active set (`_prefetch`), D_t > 0, the grown graph fits.
+        Returns (h', score', capacity of h' in rows, steps done, sum of E over their model calls) or None."""
         pf = self._prefetch
-        lo, hi = self._t_range.get(int(t), (0, 0))
+        t = int(steps[0][0])
+        lo, hi = self._t_range.get(t, (0, 0))
         D = hi - lo
-        if pf is None or pf[0] != int(t) or D == 0 or pf[4] != bool(use_hungarian):
+        if pf is None or pf[0] != t or D == 0 or pf[4] != bool(use_hungarian):
             return None
         A = pf[2]
         N = self.N
         n_new = A * D + D
         if N == 0 or N + n_new > DG_MAX_ROWS or self._Xd.dtype != torch.float32:
             return None
+        hung_max = 0
         if use_hungarian:           # the device solver must take every timestep's problem of the grown graph (rows, columns: dets)
             if self._hung_max is None:
                 self._hung_max = int(_lib.load().tmpnn_track_hungarian_max_dets())
             if self.Dn + D > self._hung_max or os.environ.get('TMPNN_HUNGARIAN_HOST', '0') == '1':
                 return None
+            hung_max = self._hung_max
         # what the native call would refuse with an exception is checked HERE, while nothing has been touched: the caller
         # then takes the Python path (update / forward_dgraph / decode) with the prefetched active set still in place
         GH = int(model_info[8]) * int(model_info[9])
@@ -518,35 +532,40 @@ class TrackGraph:
             tpl += [0 if self._notify is None else self._notify.data_ptr(),
                     addr(lib.tmpnn_track_extend_tf) if _TRACK_EXTEND_TF else 0, addr(lib.tmpnn_mp_iter_fwd_parts), bool(use_hungarian)]
             self._fast_tpl = tpl
-        nt = -1 if next_t is None else int(next_t)
-        spare = 2 * n_new + 256                  # room behind the compacted state for the next block (else: one copy)
         ti = tpl[:30]
-        ti[3:10] = (N, A, D, int(t), int(t_upto), int(ret_win_size), nt)
-        ti[11] += 4 * lo
+        ti[8] = int(ret_win_size)
         if self._cur:
             ti[13], ti[14] = ti[14], ti[13]
-        ti[22] = spare
         ti[23] = _stream()
         ti.append(0 if tp_classifier else 8)     # (no TP classifier: every detection's score is 1, infer.py:77-80)
-        if self._notify is not None:
-            self._notify_np[4] = 0
-        model_info[7] = N + n_new
+        ids0 = tpl[11]
+        flat = []
+        tr = self._t_range
+        for (ts_, tu_, nt_) in steps:
+            l_, h_ = tr.get(int(ts_), (0, 0))
+            flat += (int(ts_), int(tu_), int(nt_), ids0 + 4 * l_, h_ - l_)
         try:
-            h_keep, sc, counts = fast.greedy_step(ti, model_info, h, int(cap_rows))
+            out, st = fast.greedy_run(ti, model_info, h, int(cap_rows), flat, [N, A, self.E, self.Dn], [DG_MAX_ROWS, hung_max])
         except RuntimeError:
             # a C entry point refused its arguments before launching anything that changes the graph: rows [0, N) and the
             # counters are as they were (the appended block sits beyond N and the grown index form in its own arena)
             self._prefetch = pf
             raise
-        n_keep, status, n_det, a_next = counts.tolist()
-        self._check_assoc_status(status, bool(use_hungarian))
-        self.last_E = self.E + A * D                       # (edges of the graph the model call ran on)
-        self._cur = 1 - self._cur
-        self.N, self.E, self.Dn = n_keep, n_keep - n_det, n_det
+        done, edges, n_keep, e_keep, dn_keep, a_next, flips, cap = st
+        if done == 0:               # (cannot happen after the checks above; nothing was touched)
+            self._prefetch = pf
+            return None
+        h_keep, sc, counts = out
+        self.last_E = edges                                # (sum of the edges of the graphs the model calls ran on)
+        if flips & 1:
+            self._cur = 1 - self._cur
+        self.N, self.E, self.Dn = n_keep, e_keep, dn_keep
         self._graph = None
+        self._check_assoc_status(int(counts[1]), bool(use_hungarian))
+        nt = int(steps[done - 1][2])
         if nt >= 0:
             self._prefetch = (nt, sc, a_next, sc._version, bool(use_hungarian))
-        return h_keep, sc, N + n_new + spare
+        return h_keep, sc, cap, done, edges
 
     def _notify_arm(self):
         """Clear the mirror's flag; its address for the launch (None: no mirror, the caller copies `small` back)."""
