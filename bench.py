@@ -569,6 +569,11 @@ def loop_batch1(budget_s=1.5):
                 if k.startswith('output_transform') and k.endswith('bias'):
                     prm.copy_(0.5 * torch.randn(prm.shape, generator=gp))
 
+    # objects alive here (the C2 batch's plans, the models) go to the permanent generation: a full collection of the interpreter's
+    # garbage collector in the middle of a timed sequence otherwise shows up as a multi-millisecond `slowest_sequence_ms`
+    import gc
+    gc.collect()
+    gc.freeze()
     worst = {}
 
     def timed(fn, tag=None):

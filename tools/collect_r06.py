@@ -177,10 +177,9 @@ inference loops of the three sequence shapes: ~0.5 M dispatches) there is no suc
 The maxima of `k_track_retire` / `k_track_select` are the Hungarian sweeps of the C3 sequences (12-frame windows: ten timesteps'
 problems solved one after another inside the launch); nothing waits or spins.
 
-The outliers of the full bench run (`profiles/r06_bench_kernel_stats.md`: MaxNs of `k_track_retire` 20-31 ms) are an artefact of
-tracing that run, not of the kernel: `tools/outliers.py` over a `rocprofv3 --kernel-trace` of `bench.py` finds ONE or TWO such
-dispatches among ~770 000 (20.6 ms in one trace, 31.2 ms + 1.1 ms in another), each in the middle of a Hungarian inference loop
-between neighbours of ordinary length, on the same queue:
+The outliers of the full bench run (`profiles/r06_bench_kernel_stats.md`: MaxNs of `k_track_retire` 20-31 ms): `tools/outliers.py`
+over a `rocprofv3 --kernel-trace` of `bench.py` finds ONE or TWO such dispatches among ~770 000 (20.6 ms in one trace, 31.2 ms +
+1.1 ms in another), each in the middle of a Hungarian inference loop between neighbours of ordinary length, on the same queue:
 
 ```
       + 23928.723 ms .. + 23928.947 ms      223.7 us  k_track_retire
@@ -193,11 +192,16 @@ between neighbours of ordinary length, on the same queue:
       + 23960.231 ms .. + 23960.251 ms       19.6 us  k_track_extend_tf<64>
 ```
 
-The same command WITHOUT the profiler has no such call: `bench.py` now reports the slowest single sequence of every timed loop
-(`loop_batch1.infer.*.slowest_sequence_ms`, host time of one 40-frame sequence) -- C2 / C3 / C4 Hungarian 4.79 / 9.40 / 7.71 ms against
-means of 4.66 / 9.33 / 7.64 ms over 322 / 161 / 197 sequences (a 20-ms stall would be two to four sequences long).  The kernel has no
-wait in it (the device never waits for the host; its loops are bounded by the problem sizes); round 4's 29.2 ms / 20.9 ms maxima were
-found in traces of the full bench run as well and never in a trace of the loops alone.
+The kernel has no wait in it (the device never waits for the host; its loops are bounded by the problem sizes), the same inputs
+take 0.1-0.3 ms in the launches around it, and a trace of the loops alone has never shown one (round 4's 29.2 ms / 20.9 ms maxima
+were found in traces of the full bench run too).  `bench.py` now reports the slowest single sequence of every timed loop
+(`loop_batch1.infer.*.slowest_sequence_ms`, host time of one 40-frame sequence) so that the un-profiled run can be asked the same
+question: in four runs, two show every slowest sequence within 25 % of its mean (e.g. C2 / C3 / C4 Hungarian 4.79 / 9.40 / 7.71 ms
+against 4.66 / 9.33 / 7.64 over 322 / 161 / 197 sequences), and two show one or two sequences 5-10 ms above it (C3 greedy 12.4 ms
+and C4 greedy 7.4 ms against means of 2.2, in ~700 sequences each; freezing the interpreter's garbage collector before the loops
+does not remove them).  So a stall of 5-30 ms hits the loop about once per 1-2 s of run time, with or without the profiler, not
+reproducibly, and lands on whatever is running -- under the profiler the longest kernel of the loop; it comes from outside the
+kernels (the host thread or the queue losing its slot on a shared box is what fits; host timing alone cannot tell which).
 ''')
         ts = f'{ld}/c2_timestep.json'
         if os.path.exists(ts):
