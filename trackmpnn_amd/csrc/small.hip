@@ -672,21 +672,24 @@ __device__ __forceinline__ float4 adjoint_at(const FinishArgs& a, int row, int g
         }
     } else {
         // adjoint of row E: d h[d] += sum_{e: src=d} d_x[e][0:H] -/+ sum_{e: dst=d} d_x[e][0:H | H:2H]; CSR order
+        // (sixteen incidences, then their sixteen rows, each batch as straight-line loads: four at a time with the incidence
+        //  behind a select was a dependent pair of round trips per four rows, ~26 in a row for a det of a KITTI-sized window)
         const int p0 = a.g.rowptr[p], p1 = a.g.rowptr[p + 1];
-        for (int q = p0; q < p1; q += 4) {
-            float4 v[4];
-            float w[4];
+        constexpr int UA = 16;
+        for (int q = p0; q < p1; q += UA) {
+            int key[UA];
+            float4 v[UA];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const bool live = q + u < p1;
-                const int key = live ? a.g.inc[q + u] : 0;
-                const bool neg = key < 0;
-                w[u] = live ? ((neg && IN_E == H) ? -1.0f : 1.0f) : 0.f;
-                v[u] = *reinterpret_cast<const float4*>(dm + (size_t)(key & 0x7fffffff) * ldm + ((neg && IN_E == 2 * H) ? H : 0));
-            }
+            for (int u = 0; u < UA; ++u) key[u] = a.g.inc[min(q + u, p1 - 1)];
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
-                if (w[u] != 0.f) { acc.x += w[u] * v[u].x; acc.y += w[u] * v[u].y; acc.z += w[u] * v[u].z; acc.w += w[u] * v[u].w; }
+            for (int u = 0; u < UA; ++u)
+                v[u] = *reinterpret_cast<const float4*>(dm + (size_t)(key[u] & 0x7fffffff) * ldm + ((key[u] < 0 && IN_E == 2 * H) ? H : 0));
+#pragma unroll
+            for (int u = 0; u < UA; ++u)
+                if (q + u < p1) {
+                    const float w = (key[u] < 0 && IN_E == H) ? -1.0f : 1.0f;
+                    acc.x += w * v[u].x; acc.y += w * v[u].y; acc.z += w * v[u].z; acc.w += w * v[u].w;
+                }
         }
     }
     const float4 t = *reinterpret_cast<const float4*>(a.d_h + (size_t)row * (G * H) + gi * H + 4 * c4);
