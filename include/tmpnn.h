@@ -647,10 +647,14 @@ int tmpnn_track_extend(int N, int A, int D, const int32_t* active, const int32_t
  * A*D new edge rows of h -- what the first launch of tmpnn_mp_iter_fwd(training = 0) does with the features tmpnn_track_extend
  * would have written (same code, same arithmetic order: bit-identical).  The caller follows with
  * tmpnn_mp_iter_fwd_parts(parts = 1, x = NULL).  h [N + A*D + D][G*H]: rows [0, N) hold the carried state.  save / save_floats:
- * as tmpnn_mp_iter_fwd for (N + A*D + D, A*D + D) -- the transform's Lin1 outputs and statistics land where that call puts them. */
+ * as tmpnn_mp_iter_fwd for (N + A*D + D, A*D + D) -- the transform's Lin1 outputs and statistics land where that call puts them.
+ * counts (or NULL): the `small` words of the tmpnn_track_retire call in front of this one on the stream.  The launch then takes
+ * N = counts[0] and A = counts[3] ON THE DEVICE and the arguments N / A (and g_new's binding, h, save) are upper bounds the buffers
+ * were sized with: the caller enqueues the timestep's first launch without waiting for the previous decode's counters, reads them
+ * while it runs, and re-binds g_new's arena (same capacity) with the exact row count for the calls that follow. */
 int tmpnn_track_extend_tf(int N, int A, int D, const int32_t* active, const int32_t* new_ids, int t, const int32_t* track,
                           const tmpnn_track_rows* rows, const float* X, int ld_x, const tmpnn_mp_params* P, float* h,
-                          float* save, size_t save_floats, const tmpnn_dgraph* g_new, tmpnn_stream stream);
+                          float* save, size_t save_floats, const tmpnn_dgraph* g_new, const int32_t* counts, tmpnn_stream stream);
 /* decode_tracks (:431-520): associations from the scores (associate = 1: the greedy rule; 2: optimal assignment per timestep as
  * tmpnn_track_select_ws, graphs of <= TMPNN_DG_MAX_ROWS rows, its cost scratch = fin_ws / fin_ws_bytes, overflow in bit 1 of
  * small[1]; 0: rows->assoc holds them already, e.g. from a matching on the host), track finalisation, row deletion into rows_out, the state rows and scores compacted (h_new [N][ld_hn],

@@ -55,10 +55,14 @@ struct BnSrcBlock {
 };
 
 // one workgroup (its first 256 threads) per feature group gi; dynamic LDS: 64 * (H + 1) floats
+// (rows_total / rows_new >= 0: the graph's row count and the number of new rows where they are known on the device only -- the
+//  struct's fields are then what the host sized the buffers with; the struct itself is never written: a kernel argument that is
+//  modified is copied to scratch memory, and every pointer of it is then read from there)
 template <int H, class SRC>
-__device__ __forceinline__ void d_small_bn_fwd(const BnFwdArgs& a, const int gi, const SRC src) {
+__device__ __forceinline__ void d_small_bn_fwd(const BnFwdArgs& a, const int gi, const SRC src, const int rows_total = -1,
+                                               const int rows_new = -1) {
     const int G = a.P.G, GH = G * H;
-    const int N = a.g.N, n = a.n_new, N_old = N - n;
+    const int N = rows_total >= 0 ? rows_total : a.g.N, n = rows_new >= 0 ? rows_new : a.n_new, N_old = N - n;
     const int F = a.P.F[gi];
     int f0 = 0;
     for (int q = 0; q < gi; ++q) f0 += a.P.F[q];

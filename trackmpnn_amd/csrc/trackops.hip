@@ -660,17 +660,23 @@ struct ExtendArgs {
     const int32_t* active; const int32_t* new_ids; const int32_t* track;
     tmpnn_track_rows r;
 };
+// counts (or NULL): the `small` words of the decode launch in front of this one on the stream -- N = counts[0] (the rows it kept)
+// and A = counts[3] (the active set it derived) are then read HERE, and e.N / e.A / the graph's N / the transform's row counts
+// are only what the host sized the buffers with (upper bounds): the host enqueues this launch without waiting for that decode.
 template <int H>
-__global__ __launch_bounds__(GC_THREADS) void k_track_extend_tf(ExtendArgs e, tmpnn_dgraph g, BnFwdArgs b, BnSrcBlock src) {
+__global__ __launch_bounds__(GC_THREADS) void k_track_extend_tf(ExtendArgs e, tmpnn_dgraph g, BnFwdArgs b, BnSrcBlock src,
+                                                                const int32_t* __restrict__ counts) {
+    const int N = counts ? counts[0] : e.N, A = counts ? counts[3] : e.A;
+    const int n = A * e.D + e.D, Nt = N + n;
     if (blockIdx.x == 0) {
-        d_track_append(e.N, e.A, e.D, e.active, e.new_ids, e.t, e.track, e.r.ts, e.r.det_id, e.r.assoc, e.r.is_edge, e.r.src,
+        d_track_append(N, A, e.D, e.active, e.new_ids, e.t, e.track, e.r.ts, e.r.det_id, e.r.assoc, e.r.is_edge, e.r.src,
                        e.r.dst, e.r.labels, nullptr, 0, 0, nullptr, 0, (long)threadIdx.x, (long)GC_THREADS);
         __threadfence_block();
         __syncthreads();
-        d_graph_from_coo<true, false>(g.N, nullptr, nullptr, 0L, nullptr, nullptr, 0L, e.r.is_edge, e.r.src, e.r.dst, g, nullptr);
+        d_graph_from_coo<true, false>(Nt, nullptr, nullptr, 0L, nullptr, nullptr, 0L, e.r.is_edge, e.r.src, e.r.dst, g, nullptr);
     } else {
         if (threadIdx.x >= 256) return;       // (the transform is written for 256 threads; ended waves leave the block's barriers)
-        d_small_bn_fwd<H>(b, (int)blockIdx.x - 1, src);
+        d_small_bn_fwd<H>(b, (int)blockIdx.x - 1, BnSrcBlock{A * e.D, src.ids, src.X, src.ld_x}, Nt, n);
     }
 }
 
@@ -1270,7 +1276,8 @@ int tmpnn_track_extend(int N, int A, int D, const int32_t* active, const int32_t
 
 int tmpnn_track_extend_tf(int N, int A, int D, const int32_t* active, const int32_t* new_ids, int t, const int32_t* track,
                           const tmpnn_track_rows* rows, const float* X, int ld_x, const tmpnn_mp_params* P, float* h,
-                          float* save, size_t save_floats, const tmpnn_dgraph* g_new, tmpnn_stream stream) {
+                          float* save, size_t save_floats, const tmpnn_dgraph* g_new, const int32_t* counts,
+                          tmpnn_stream stream) {
     TM_REQUIRE(N >= 0 && A >= 0 && D > 0 && (long)N + (long)A * D + D <= TMPNN_DG_MAX_ROWS,
                "track_extend_tf: N=%d A=%d D=%d exceeds the one-launch form's %d rows", N, A, D, TMPNN_DG_MAX_ROWS);
     TM_REQUIRE(rows_ok(rows) && (A == 0 || active) && new_ids && g_new && P && X && h && save, "track_extend_tf: null pointer");
@@ -1281,7 +1288,8 @@ int tmpnn_track_extend_tf(int N, int A, int D, const int32_t* active, const int3
         TM_REQUIRE(P->F[q] > 0 && P->w1[q] && P->b1[q] && P->gamma[q] && P->beta[q] && P->w2[q] && P->b2[q] && P->run_mean[q] &&
                        P->run_var[q], "track_extend_tf: null input-transform pointer in group %d", q);
     TM_REQUIRE(g_new->meta && g_new->is_edge && g_new->pos && g_new->src && g_new->dst && g_new->src_pos && g_new->dst_pos &&
-                   g_new->edge_row && g_new->det_row && g_new->rowptr && g_new->inc && g_new->N == Nt && Nt <= g_new->cap,
+                   g_new->edge_row && g_new->det_row && g_new->rowptr && g_new->inc && (counts ? g_new->N <= Nt : g_new->N == Nt) &&
+                   Nt <= g_new->cap,
                "track_extend_tf: g_new must be bound for N + A*D + D = %d rows", Nt);
     TM_REQUIRE(aligned16(h) && aligned16(save), "track_extend_tf: h / save must be 16-byte aligned");
     if (save_floats < tmpnn_mp_iter_save_floats(Nt, n, G, H))
@@ -1295,10 +1303,10 @@ int tmpnn_track_extend_tf(int N, int A, int D, const int32_t* active, const int3
     const size_t shm = std::max(sizeof(int) * ((size_t)8 * Nt + 1), sizeof(float) * 64 * (size_t)(H + 1));
     if (H == 64) {
         TM_SHM_ONCE(k_track_extend_tf<64>, sizeof(int) * (8 * TMPNN_DG_MAX_ROWS + 1));
-        hipLaunchKernelGGL(k_track_extend_tf<64>, dim3(1 + G), dim3(GC_THREADS), shm, as_stream(stream), e, *g_new, b, src);
+        hipLaunchKernelGGL(k_track_extend_tf<64>, dim3(1 + G), dim3(GC_THREADS), shm, as_stream(stream), e, *g_new, b, src, counts);
     } else {
         TM_SHM_ONCE(k_track_extend_tf<32>, sizeof(int) * (8 * TMPNN_DG_MAX_ROWS + 1));
-        hipLaunchKernelGGL(k_track_extend_tf<32>, dim3(1 + G), dim3(GC_THREADS), shm, as_stream(stream), e, *g_new, b, src);
+        hipLaunchKernelGGL(k_track_extend_tf<32>, dim3(1 + G), dim3(GC_THREADS), shm, as_stream(stream), e, *g_new, b, src, counts);
     }
     return check_launch("track_extend_tf");
 }

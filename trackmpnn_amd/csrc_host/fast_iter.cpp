@@ -243,174 +243,245 @@ using retire_fn = int (*)(const tmpnn_dgraph*, const tmpnn_track_rows*, const fl
                           int32_t*, int32_t*, tmpnn_stream);
 using ints_fn = size_t (*)(int);
 using extend_tf_fn = int (*)(int, int, int, const int32_t*, const int32_t*, int, const int32_t*, const tmpnn_track_rows*, const float*,
-                             int, const tmpnn_mp_params*, float*, float*, size_t, const tmpnn_dgraph*, tmpnn_stream);
+                             int, const tmpnn_mp_params*, float*, float*, size_t, const tmpnn_dgraph*, const int32_t*, tmpnn_stream);
 using fwd_parts_fn = int (*)(const tmpnn_mp_params*, const float*, const tmpnn_dgraph*, int, const float*, int, float*, int, float*,
                              float*, float*, float*, size_t, int, tmpnn_stream);
 
-std::vector<torch::Tensor> greedy_step(std::vector<int64_t> ti, std::vector<int64_t> info, torch::Tensor h, int64_t cap_rows) {
-    TORCH_CHECK(ti.size() == 31 && info.size() == 18, "greedy_step: bad descriptors");
-    const auto f_extend = reinterpret_cast<extend_fn>(ti[0]);
-    const auto f_retire = reinterpret_cast<retire_fn>(ti[1]);
-    const auto f_ints = reinterpret_cast<ints_fn>(ti[2]);
-    const int N = (int)ti[3], A = (int)ti[4], D = (int)ti[5], t = (int)ti[6], t_upto = (int)ti[7], ret_win = (int)ti[8];
-    const int next_t = (int)ti[9];
-    auto* active = reinterpret_cast<int32_t*>(ti[10]);
-    const auto* new_ids = reinterpret_cast<const int32_t*>(ti[11]);
-    const auto* track = reinterpret_cast<const int32_t*>(ti[12]);
-    const auto* rows_cur = reinterpret_cast<const tmpnn_track_rows*>(ti[13]);
-    const auto* rows_out = reinterpret_cast<const tmpnn_track_rows*>(ti[14]);
-    const auto* X = reinterpret_cast<const float*>(ti[15]);
-    const int F = (int)ti[16];
-    auto* y_track = reinterpret_cast<int32_t*>(ti[17]);
-    const int ND = (int)ti[18];
-    auto* pos_of_det = reinterpret_cast<int32_t*>(ti[19]);
-    auto* keep_rows = reinterpret_cast<int32_t*>(ti[20]);
-    auto* small = reinterpret_cast<int32_t*>(ti[21]);
-    const int64_t spare_next = ti[22];
-    const auto stream = reinterpret_cast<tmpnn_stream>(ti[23]);
+// The driver's state and the two halves of a timestep.  FRONT: the block append + index form + input transform
+// (tmpnn_track_extend_tf; or tmpnn_track_extend when the one-launch form is switched off).  BACK: the iteration
+// (tmpnn_mp_iter_fwd_parts) and decode_tracks (tmpnn_track_retire, with the NEXT timestep's active set).
+namespace {
+struct Driver {
+    extend_fn f_extend; retire_fn f_retire; ints_fn f_ints; extend_tf_fn f_extend_tf; fwd_parts_fn f_fwd_parts; fwd_fn f_fwd;
+    err_fn f_err; bind_fn f_bind;
+    int32_t* active; const int32_t* track; const float* X; int F; int32_t* y_track; int ND; int32_t* pos_of_det; int32_t* keep_rows;
+    int32_t* small; tmpnn_stream stream; int associate; void* hung_ws; size_t hung_ws_bytes; int32_t* notify; int score_rule;
+    int ret_win; bool one_launch;
+    const tmpnn_mp_params* P; const float* prep; int64_t G, H, GH;
+    at::TensorOptions opts, iopts;
+};
+struct Front {                // what the first launch of a timestep produced / was given
+    bool valid = false;
+    int64_t cap = 0;          // rows the index form's arena is laid out for (>= the timestep's rows)
+    torch::Tensor arena, h_cat, save, feats;
+};
+}  // namespace
+
+static Driver make_driver(const std::vector<int64_t>& ti, const std::vector<int64_t>& info, const torch::Tensor& h) {
+    TORCH_CHECK(ti.size() == 31 && info.size() == 18, "greedy_run: bad descriptors");
+    Driver d;
+    d.f_extend = reinterpret_cast<extend_fn>(ti[0]);
+    d.f_retire = reinterpret_cast<retire_fn>(ti[1]);
+    d.f_ints = reinterpret_cast<ints_fn>(ti[2]);
+    d.ret_win = (int)ti[8];
+    d.active = reinterpret_cast<int32_t*>(ti[10]);
+    d.track = reinterpret_cast<const int32_t*>(ti[12]);
+    d.X = reinterpret_cast<const float*>(ti[15]);
+    d.F = (int)ti[16];
+    d.y_track = reinterpret_cast<int32_t*>(ti[17]);
+    d.ND = (int)ti[18];
+    d.pos_of_det = reinterpret_cast<int32_t*>(ti[19]);
+    d.keep_rows = reinterpret_cast<int32_t*>(ti[20]);
+    d.small = reinterpret_cast<int32_t*>(ti[21]);
+    d.stream = reinterpret_cast<tmpnn_stream>(ti[23]);
     // association rule of decode_tracks: 1 greedy, 2 optimal assignment on the device (--hungarian; its cost scratch, and the
     // next timestep's active set then comes from the launch's second sweep over the rows that stay)
-    const int associate = (int)ti[24];
-    void* const hung_ws = reinterpret_cast<void*>(ti[25]);
-    const size_t hung_ws_bytes = (size_t)ti[26];
+    d.associate = (int)ti[24];
+    d.hung_ws = reinterpret_cast<void*>(ti[25]);
+    d.hung_ws_bytes = (size_t)ti[26];
     // the counters' mirror in pinned, device-mapped host memory (tmpnn_track_retire `notify`; 0: read `small` back by a copy)
-    int32_t* const notify = reinterpret_cast<int32_t*>(ti[27]);
+    d.notify = reinterpret_cast<int32_t*>(ti[27]);
     // the block append and the model call's input transform in one launch (tmpnn_track_extend_tf) + the iteration alone
     // (tmpnn_mp_iter_fwd_parts, parts = 1); 0: the two calls as the Python path makes them (tmpnn_track_extend, tmpnn_mp_iter_fwd)
-    const auto f_extend_tf = reinterpret_cast<extend_tf_fn>(ti[28]);
-    const auto f_fwd_parts = reinterpret_cast<fwd_parts_fn>(ti[29]);
-    const bool one_launch = f_extend_tf != nullptr && f_fwd_parts != nullptr;
+    d.f_extend_tf = reinterpret_cast<extend_tf_fn>(ti[28]);
+    d.f_fwd_parts = reinterpret_cast<fwd_parts_fn>(ti[29]);
+    d.one_launch = d.f_extend_tf != nullptr && d.f_fwd_parts != nullptr;
     // 8: the model has no TP classifier -- every detection's score is 1 (tmpnn_mp_iter_fwd_parts bit 3; infer.py:77-80)
-    const int score_rule = (int)ti[30];
-    TORCH_CHECK((score_rule & ~8) == 0 && (score_rule == 0 || f_fwd_parts != nullptr), "greedy_step: score rule ", score_rule);
-    TORCH_CHECK(associate == 1 || (associate == 2 && hung_ws && hung_ws_bytes > 0), "greedy_step: association rule ", associate);
-    const auto f_fwd = reinterpret_cast<fwd_fn>(info[0]);
-    const auto f_err = reinterpret_cast<err_fn>(info[2]);
-    const auto f_bind = reinterpret_cast<bind_fn>(info[6]);
-    const int64_t G = info[8], H = info[9], GH = G * H;
-    TORCH_CHECK(h.defined() && h.dim() == 2 && h.size(0) == N && h.size(1) == GH && h.is_contiguous() &&
-                    h.scalar_type() == torch::kFloat32, "greedy_step: h must be a contiguous fp32 [", N, ", ", GH, "] tensor");
-    TORCH_CHECK(D > 0 && F == info[11], "greedy_step: D = ", D, ", F = ", F);
-    const int n_new = A * D + D, Nt = N + n_new;
-    auto opts = h.options().requires_grad(false);
-    auto iopts = opts.dtype(torch::kInt32);
-    // update_graph: the block of timestep t, its features, the grown graph's index form
-    torch::Tensor arena = at::empty({(int64_t)f_ints(Nt)}, iopts);
+    d.score_rule = (int)ti[30];
+    TORCH_CHECK((d.score_rule & ~8) == 0 && (d.score_rule == 0 || d.f_fwd_parts != nullptr), "greedy_run: score rule ", d.score_rule);
+    TORCH_CHECK(d.associate == 1 || (d.associate == 2 && d.hung_ws && d.hung_ws_bytes > 0), "greedy_run: association rule ", d.associate);
+    d.f_fwd = reinterpret_cast<fwd_fn>(info[0]);
+    d.f_err = reinterpret_cast<err_fn>(info[2]);
+    d.f_bind = reinterpret_cast<bind_fn>(info[6]);
+    d.P = reinterpret_cast<const tmpnn_mp_params*>(info[3]);
+    d.prep = reinterpret_cast<const float*>(info[5]);
+    d.G = info[8]; d.H = info[9]; d.GH = d.G * d.H;
+    TORCH_CHECK(d.F == info[11], "greedy_run: F = ", d.F);
+    d.opts = h.options().requires_grad(false);
+    d.iopts = d.opts.dtype(torch::kInt32);
+    return d;
+}
+
+// FRONT of a timestep.  counts == nullptr: N / A are exact and h [N][GH] is the carried state (extended in place where its
+// storage has the room, else copied).  counts != nullptr (the launch is enqueued BEHIND the previous timestep's decode, before its
+// counters are known): N / A are upper bounds, the launch reads the exact values on the device, and hbuf is the buffer the
+// previous decode compacts the state into (sized by the caller for N + A*D + D rows).
+static Front launch_front(const Driver& d, int64_t N, int64_t A, int64_t D, int t, const int32_t* new_ids,
+                          const tmpnn_track_rows* rows, const torch::Tensor& h, int64_t cap_rows, const int32_t* counts) {
+    Front f;
+    const int64_t n_new = A * D + D, Nt = N + n_new;
+    f.cap = Nt;
+    f.arena = at::empty({(int64_t)d.f_ints((int)Nt)}, d.iopts);
     tmpnn_dgraph dg;
-    TORCH_CHECK(f_bind(arena.data_ptr(), Nt, Nt, &dg) == 0, "tmpnn_dgraph_bind failed");
-    // the model call (eval mode): the carried state extended in place where its storage has the room
-    torch::Tensor h_cat;
-    if (cap_rows >= Nt && (int64_t)h.storage().nbytes() >= (int64_t)((h.storage_offset() + (int64_t)Nt * GH) * sizeof(float))) {
-        h_cat = at::empty({0}, opts).set_(h.storage(), h.storage_offset(), {Nt, GH}, {GH, 1});
+    TORCH_CHECK(d.f_bind(f.arena.data_ptr(), (int)Nt, (int)Nt, &dg) == 0, "tmpnn_dgraph_bind failed");
+    if (counts != nullptr || (cap_rows >= Nt && (int64_t)h.storage().nbytes() >=
+                                                    (int64_t)((h.storage_offset() + Nt * d.GH) * sizeof(float)))) {
+        TORCH_CHECK((int64_t)h.storage().nbytes() >= (int64_t)((h.storage_offset() + Nt * d.GH) * sizeof(float)),
+                    "greedy_run: the state buffer is too small for the enqueued timestep");
+        f.h_cat = at::empty({0}, d.opts).set_(h.storage(), h.storage_offset(), {Nt, d.GH}, {d.GH, 1});
     } else {
-        h_cat = at::empty({Nt, GH}, opts);
-        if (N > 0) h_cat.narrow(0, 0, N).copy_(h);
+        f.h_cat = at::empty({Nt, d.GH}, d.opts);
+        if (N > 0) f.h_cat.narrow(0, 0, N).copy_(h);
     }
-    const size_t nsave = save_floats(Nt, n_new, G, H);
-    torch::Tensor save = at::empty({(int64_t)nsave}, opts);
-    torch::Tensor h_out, logits, scores;
+    const size_t nsave = save_floats(Nt, n_new, d.G, d.H);
+    f.save = at::empty({(int64_t)nsave}, d.opts);
     int rc;
-    if (one_launch) {
-        // (the device has been idle since the previous timestep's last launch: this one goes out before anything it does not need
-        //  is allocated)
-        rc = f_extend_tf(N, A, D, active, new_ids, t, track, rows_cur, X, F, reinterpret_cast<const tmpnn_mp_params*>(info[3]),
-                         h_cat.data_ptr<float>(), save.data_ptr<float>(), nsave, &dg, stream);
-        TORCH_CHECK(rc == 0, "tmpnn_track_extend_tf failed (code ", rc, "): ", f_err());
-        h_out = at::empty({Nt, GH}, opts); logits = at::empty({Nt, 1}, opts); scores = at::empty({Nt, 1}, opts);
-        rc = f_fwd_parts(reinterpret_cast<const tmpnn_mp_params*>(info[3]), reinterpret_cast<const float*>(info[5]), &dg, n_new,
-                         nullptr, 0, h_cat.data_ptr<float>(), 0, h_out.data_ptr<float>(), logits.data_ptr<float>(),
-                         scores.data_ptr<float>(), nullptr, 0, 1 | score_rule, stream);
-        TORCH_CHECK(rc == 0, "tmpnn_mp_iter_fwd_parts failed (code ", rc, "): ", f_err());
+    if (d.one_launch) {
+        rc = d.f_extend_tf((int)N, (int)A, (int)D, d.active, new_ids, t, d.track, rows, d.X, d.F, d.P, f.h_cat.data_ptr<float>(),
+                           f.save.data_ptr<float>(), nsave, &dg, counts, d.stream);
+        TORCH_CHECK(rc == 0, "tmpnn_track_extend_tf failed (code ", rc, "): ", d.f_err());
     } else {
-        torch::Tensor feats = at::empty({n_new, F}, opts);
-        h_out = at::empty({Nt, GH}, opts); logits = at::empty({Nt, 1}, opts); scores = at::empty({Nt, 1}, opts);
-        rc = f_extend(N, A, D, active, new_ids, t, track, rows_cur, X, F, F, feats.data_ptr<float>(), F, &dg, nullptr, 0, stream);
-        TORCH_CHECK(rc == 0, "tmpnn_track_extend failed (code ", rc, "): ", f_err());
-        if (f_fwd_parts != nullptr)
-            rc = f_fwd_parts(reinterpret_cast<const tmpnn_mp_params*>(info[3]), reinterpret_cast<const float*>(info[5]), &dg, n_new,
-                             feats.data_ptr<float>(), F, h_cat.data_ptr<float>(), 0, h_out.data_ptr<float>(), logits.data_ptr<float>(),
-                             scores.data_ptr<float>(), save.data_ptr<float>(), nsave, score_rule, stream);
-        else
-            rc = f_fwd(reinterpret_cast<const tmpnn_mp_params*>(info[3]), reinterpret_cast<const float*>(info[5]), &dg, n_new,
-                       feats.data_ptr<float>(), F, h_cat.data_ptr<float>(), 0, h_out.data_ptr<float>(), logits.data_ptr<float>(),
-                       scores.data_ptr<float>(), save.data_ptr<float>(), nsave, stream);
-        TORCH_CHECK(rc == 0, "tmpnn_mp_iter_fwd failed (code ", rc, "): ", f_err());
+        TORCH_CHECK(counts == nullptr, "greedy_run: an early front needs the one-launch form");
+        f.feats = at::empty({n_new, d.F}, d.opts);
+        rc = d.f_extend((int)N, (int)A, (int)D, d.active, new_ids, t, d.track, rows, d.X, d.F, d.F, f.feats.data_ptr<float>(), d.F, &dg,
+                        nullptr, 0, d.stream);
+        TORCH_CHECK(rc == 0, "tmpnn_track_extend failed (code ", rc, "): ", d.f_err());
     }
-    // decode_tracks + the next timestep's active set; the compacted state lands in a buffer with room for the next block
-    torch::Tensor hbuf = at::empty({(Nt + spare_next) * GH}, opts);
-    torch::Tensor h_new = at::empty({0}, opts).set_(hbuf.storage(), 0, {Nt, GH}, {GH, 1});
-    torch::Tensor s_new = at::empty({Nt, 1}, opts);
-    rc = f_retire(&dg, rows_cur, scores.data_ptr<float>(), associate, t_upto, ret_win, y_track, ND, pos_of_det,
-                  associate == 2 ? hung_ws : nullptr, associate == 2 ? hung_ws_bytes : 0, keep_rows,
-                  small, rows_out, h_out.data_ptr<float>(), (int)GH, (int)GH, h_new.data_ptr<float>(), (int)GH,
-                  s_new.data_ptr<float>(), next_t, active, notify, stream);
-    TORCH_CHECK(rc == 0, "tmpnn_track_retire failed (code ", rc, "): ", f_err());
-    // the one host read of the timestep: kept rows, status, kept det rows, the next active-set size.  With a mirror: poll its
-    // flag (the launch stores the counters there, then the flag) -- no copy is enqueued and the counts are here while the kept
-    // rows' state is still moving; a flag that stays down for 20 ms (a long Hungarian sweep is < 1 ms) falls back to the copy.
+    f.valid = true;
+    return f;
+}
+
+// BACK of a timestep on the exact row counts: the iteration, then decode_tracks + the next timestep's active set; the compacted
+// state lands in `hbuf` ((Nt + spare) rows: room for the next block, whose front may already be enqueued behind this).
+struct Back { torch::Tensor hbuf, h_new, s_new, h_out, logits, scores; };
+static Back launch_back(const Driver& d, Front& f, int64_t N, int64_t A, int64_t D, int t_upto, int next_t,
+                        const tmpnn_track_rows* rows_cur, const tmpnn_track_rows* rows_out, int64_t spare) {
+    Back b;
+    const int64_t n_new = A * D + D, Nt = N + n_new;
+    tmpnn_dgraph dg;
+    TORCH_CHECK(Nt <= f.cap && d.f_bind(f.arena.data_ptr(), (int)f.cap, (int)Nt, &dg) == 0, "tmpnn_dgraph_bind failed");
+    torch::Tensor h_cat = f.h_cat.size(0) == Nt ? f.h_cat
+                                                 : at::empty({0}, d.opts).set_(f.h_cat.storage(), f.h_cat.storage_offset(), {Nt, d.GH}, {d.GH, 1});
+    b.h_out = at::empty({Nt, d.GH}, d.opts); b.logits = at::empty({Nt, 1}, d.opts); b.scores = at::empty({Nt, 1}, d.opts);
+    int rc;
+    if (d.one_launch)
+        rc = d.f_fwd_parts(d.P, d.prep, &dg, (int)n_new, nullptr, 0, h_cat.data_ptr<float>(), 0, b.h_out.data_ptr<float>(),
+                           b.logits.data_ptr<float>(), b.scores.data_ptr<float>(), nullptr, 0, 1 | d.score_rule, d.stream);
+    else if (d.f_fwd_parts != nullptr)
+        rc = d.f_fwd_parts(d.P, d.prep, &dg, (int)n_new, f.feats.data_ptr<float>(), d.F, h_cat.data_ptr<float>(), 0,
+                           b.h_out.data_ptr<float>(), b.logits.data_ptr<float>(), b.scores.data_ptr<float>(), f.save.data_ptr<float>(),
+                           (size_t)f.save.numel(), d.score_rule, d.stream);
+    else
+        rc = d.f_fwd(d.P, d.prep, &dg, (int)n_new, f.feats.data_ptr<float>(), d.F, h_cat.data_ptr<float>(), 0, b.h_out.data_ptr<float>(),
+                     b.logits.data_ptr<float>(), b.scores.data_ptr<float>(), f.save.data_ptr<float>(), (size_t)f.save.numel(), d.stream);
+    TORCH_CHECK(rc == 0, "tmpnn_mp_iter_fwd failed (code ", rc, "): ", d.f_err());
+    b.hbuf = at::empty({(Nt + spare) * d.GH}, d.opts);
+    b.h_new = at::empty({0}, d.opts).set_(b.hbuf.storage(), 0, {Nt, d.GH}, {d.GH, 1});
+    b.s_new = at::empty({Nt, 1}, d.opts);
+    if (d.notify != nullptr) __atomic_store_n(d.notify + 4, 0, __ATOMIC_RELAXED);      // (the mirror's flag: armed per launch)
+    rc = d.f_retire(&dg, rows_cur, b.scores.data_ptr<float>(), d.associate, t_upto, d.ret_win, d.y_track, d.ND, d.pos_of_det,
+                    d.associate == 2 ? d.hung_ws : nullptr, d.associate == 2 ? d.hung_ws_bytes : 0, d.keep_rows, d.small, rows_out,
+                    b.h_out.data_ptr<float>(), (int)d.GH, (int)d.GH, b.h_new.data_ptr<float>(), (int)d.GH, b.s_new.data_ptr<float>(),
+                    next_t, d.active, d.notify, d.stream);
+    TORCH_CHECK(rc == 0, "tmpnn_track_retire failed (code ", rc, "): ", d.f_err());
+    return b;
+}
+
+// the one host read of a timestep: kept rows, status, kept det rows, the next active-set size.  With a mirror: poll its flag (the
+// launch stores the counters there, then the flag) -- no copy is enqueued and the counts are here while the kept rows' state is
+// still moving; a flag that stays down for 20 ms (a long Hungarian sweep is < 1 ms) falls back to the copy.
+static torch::Tensor read_counts(const Driver& d) {
     torch::Tensor counts;
-    if (notify != nullptr) {
+    if (d.notify != nullptr) {
         const auto t0 = std::chrono::steady_clock::now();
         bool seen = false;
         for (unsigned spins = 1;; ++spins) {
-            if (__atomic_load_n(notify + 4, __ATOMIC_ACQUIRE) != 0) { seen = true; break; }
+            if (__atomic_load_n(d.notify + 4, __ATOMIC_ACQUIRE) != 0) { seen = true; break; }
             if ((spins & 0xfff) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(20)) break;
             __builtin_ia32_pause();
         }
         if (seen) {
             counts = at::empty({4}, at::TensorOptions().dtype(torch::kInt32));
-            std::memcpy(counts.data_ptr(), notify, 4 * sizeof(int32_t));
+            std::memcpy(counts.data_ptr(), d.notify, 4 * sizeof(int32_t));
         }
     }
-    if (!counts.defined()) counts = at::from_blob(small, {4}, iopts).cpu();
-    // (the kept rows: views cut here -- a slice made by the interpreter costs ~2 us of the gap in front of the next launch)
-    const int64_t n_keep = std::min<int64_t>(std::max<int64_t>(counts.data_ptr<int32_t>()[0], 0), Nt);
-    return {h_new.narrow(0, 0, n_keep), s_new.select(1, 0).narrow(0, 0, n_keep), counts};
+    if (!counts.defined()) counts = at::from_blob(d.small, {4}, d.iopts).cpu();
+    return counts;
 }
 
-// Several steady-state timesteps in a row without the interpreter between them (round 6: what the interpreter did between two
-// timesteps -- unpacking the counts, the bookkeeping, building the next descriptor -- sat between the host read of one timestep and
-// the first launch of the next, while the device waited).  steps: five integers per timestep (t, t_upto, next_t or -1, address of
-// its det ids, D); state: N, A, E, Dn as the previous decode left them; limits: the one-launch kernels' row limit and the device
-// solver's det limit (0: greedy).  Stops BEFORE a timestep the native step does not take (no detections, the grown graph too large,
-// a problem the device solver may not take) and AFTER one whose status word is not clean or that ends the sequence; the caller
-// goes on from there.  Returns {h', scores', counts of the last step} and {steps done, sum of E over their model calls, N, E, Dn,
-// A, row-set flips, capacity of h' in rows}.
+// Steady-state timesteps back to back (round 6: what the interpreter did between two timesteps -- unpacking the counts, the
+// bookkeeping, building the next descriptor -- sat between the host read of one timestep and the first launch of the next, while
+// the device waited).  steps: five integers per timestep (t, t_upto, next_t or -1, address of its det ids, D); state: N, A, E, Dn as
+// the previous decode left them; limits: the one-launch kernels' row limit, the device solver's det limit (0: greedy) and whether
+// the next timestep's FRONT may be enqueued before this timestep's counters are read (it then reads N and A on the device, the
+// buffers sized by upper bounds: N <= the rows before the deletion, A <= the dets before it).  Stops BEFORE a timestep the native
+// step does not take (no detections, the grown graph too large, a problem the device solver may not take: an early front of
+// such a timestep is simply left behind -- it wrote beyond the rows in use, the caller's own update writes the same block again)
+// and AFTER one whose status word is not clean or that ends the sequence; the caller goes on from there.  Returns {h', scores',
+// counts of the last step} and {steps done, sum of E over their model calls, N, E, Dn, A, row-set flips, capacity of h' in rows}.
 std::tuple<std::vector<torch::Tensor>, std::vector<int64_t>> greedy_run(std::vector<int64_t> ti, std::vector<int64_t> info, torch::Tensor h,
                                                                          int64_t cap_rows, std::vector<int64_t> steps,
                                                                          std::vector<int64_t> state, std::vector<int64_t> limits) {
-    TORCH_CHECK(ti.size() == 31 && info.size() == 18 && steps.size() % 5 == 0 && state.size() == 4 && limits.size() == 2,
-                "greedy_run: bad descriptors");
+    TORCH_CHECK(steps.size() % 5 == 0 && state.size() == 4 && limits.size() == 3, "greedy_run: bad descriptors");
+    const Driver d = make_driver(ti, info, h);
     int64_t N = state[0], A = state[1], E = state[2], Dn = state[3];
     const int64_t max_rows = limits[0], hung_max = limits[1];
+    const bool early = limits[2] != 0 && d.one_launch;
+    TORCH_CHECK(h.defined() && h.dim() == 2 && h.size(0) == N && h.size(1) == d.GH && h.is_contiguous() &&
+                    h.scalar_type() == torch::kFloat32, "greedy_run: h must be a contiguous fp32 [", N, ", ", d.GH, "] tensor");
+    const tmpnn_track_rows* rows_cur = reinterpret_cast<const tmpnn_track_rows*>(ti[13]);
+    const tmpnn_track_rows* rows_out = reinterpret_cast<const tmpnn_track_rows*>(ti[14]);
     int64_t done = 0, edges = 0, flips = 0;
     torch::Tensor sc, counts;
-    for (size_t k = 0; k + 5 <= steps.size(); k += 5) {
-        const int64_t D = steps[k + 4];
+    Front front;
+    const size_t K = steps.size() / 5;
+    for (size_t k = 0; k < K; ++k) {
+        const int64_t D = steps[5 * k + 4];
         if (D <= 0 || N == 0) break;
-        const int64_t n_new = A * D + D;
-        if (N + n_new > max_rows || (hung_max > 0 && Dn + D > hung_max)) break;
-        ti[3] = N; ti[4] = A; ti[5] = D; ti[6] = steps[k]; ti[7] = steps[k + 1]; ti[9] = steps[k + 2]; ti[11] = steps[k + 3];
-        ti[22] = 2 * n_new + 256;
-        info[7] = N + n_new;
-        if (ti[27] != 0) __atomic_store_n(reinterpret_cast<int32_t*>(ti[27]) + 4, 0, __ATOMIC_RELAXED);   // (the mirror's flag: armed per launch)
-        std::vector<torch::Tensor> r;
+        const int64_t n_new = A * D + D, Nt = N + n_new;
+        if (Nt > max_rows || (hung_max > 0 && Dn + D > hung_max)) break;
+        const int t = (int)steps[5 * k], t_upto = (int)steps[5 * k + 1], next_t = (int)steps[5 * k + 2];
+        // the next timestep's front, if it may go out before this one's counters are read: its bounds and the room it needs
+        int64_t D2 = 0, N_ub = 0, A_ub = 0, n_ub = 0;
+        bool early_next = false;
+        if (early && next_t >= 0 && k + 1 < K) {
+            D2 = steps[5 * (k + 1) + 4];
+            N_ub = Nt; A_ub = Dn + D; n_ub = A_ub * D2 + D2;
+            early_next = D2 > 0 && N_ub + n_ub <= max_rows && (hung_max == 0 || Dn + D + D2 <= hung_max);
+        }
+        const int64_t spare = std::max<int64_t>(2 * n_new + 256, early_next ? n_ub : 0);
+        Back back;
         try {
-            r = greedy_step(ti, info, h, cap_rows);
+            if (!front.valid)
+                front = launch_front(d, N, A, D, t, reinterpret_cast<const int32_t*>(steps[5 * k + 3]), rows_cur, h, cap_rows, nullptr);
+            back = launch_back(d, front, N, A, D, t_upto, next_t, rows_cur, rows_out, spare);
         } catch (const c10::Error&) {
             if (done == 0) throw;                  // (nothing changed yet: the caller sees the refusal itself)
             break;                                  // the caller's next call meets it as its first step
         }
-        const int32_t* c = r[2].data_ptr<int32_t>();
+        Front next_front;
+        if (early_next) {
+            try {
+                next_front = launch_front(d, N_ub, A_ub, D2, (int)steps[5 * (k + 1)], reinterpret_cast<const int32_t*>(steps[5 * (k + 1) + 3]),
+                                          rows_out, back.h_new, Nt + spare, d.small);
+            } catch (const c10::Error&) {
+                next_front = Front();               // (refused before anything was launched: that timestep takes the ordinary way)
+            }
+        }
+        counts = read_counts(d);
+        const int32_t* c = counts.data_ptr<int32_t>();
         edges += E + A * D;
-        std::swap(ti[13], ti[14]);
+        std::swap(rows_cur, rows_out);
         ++flips;
-        cap_rows = N + n_new + ti[22];
-        h = r[0]; sc = r[1]; counts = r[2];
-        N = c[0]; Dn = c[2]; E = N - Dn; A = c[3];
+        cap_rows = Nt + spare;
+        const int64_t n_keep = std::min<int64_t>(std::max<int64_t>(c[0], 0), Nt);
+        h = back.h_new.narrow(0, 0, n_keep);
+        sc = back.s_new.select(1, 0).narrow(0, 0, n_keep);
+        N = n_keep; Dn = c[2]; E = N - Dn; A = c[3];
+        front = next_front;
         ++done;
         if (hung_max > 0 && (c[1] & 2)) break;     // (a status the caller raises on)
-        if (steps[k + 2] < 0) break;
+        if (next_t < 0) break;
     }
     std::vector<torch::Tensor> out;
     if (done > 0) out = {h, sc, counts};
@@ -505,6 +576,5 @@ std::vector<torch::Tensor> train_losses(torch::Tensor logits, torch::Tensor scor
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     m.def("train_losses", &train_losses, "create_targets + CELoss + the focal terms of one forward call as one native autograd node");
     m.def("small_iter", &small_iter, "fused TrackMPNN iteration on one small graph (in-place or sink gradient mode)");
-    m.def("greedy_step", &greedy_step, "one greedy inference timestep: block append, model call (eval), decode_tracks, one host read");
     m.def("greedy_run", &greedy_run, "steady-state inference timesteps back to back (greedy_step in a loop, no interpreter between them)");
 }

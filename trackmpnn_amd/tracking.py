@@ -42,6 +42,9 @@ _NOTIFY_POOL: list = []      # pinned int32 [8] mirrors not in use (list.pop / a
 # the native timestep: block append + the model call's input transform in one launch (tmpnn_track_extend_tf);
 # TMPNN_TRACK_EXTEND_TF=0 keeps tmpnn_track_extend + the two launches of tmpnn_mp_iter_fwd
 _TRACK_EXTEND_TF = os.environ.get('TMPNN_TRACK_EXTEND_TF', '1') != '0'
+# the native driver enqueues a timestep's first launch behind the previous decode BEFORE reading that decode's counters (the launch
+# reads N and A on the device; buffers sized by upper bounds); TMPNN_TRACK_EARLY_FRONT=0: after the read, as every other launch
+_TRACK_EARLY_FRONT = os.environ.get('TMPNN_TRACK_EARLY_FRONT', '1') != '0'
 
 
 def _stream() -> int:
@@ -545,7 +548,8 @@ class TrackGraph:
             l_, h_ = tr.get(int(ts_), (0, 0))
             flat += (int(ts_), int(tu_), int(nt_), ids0 + 4 * l_, h_ - l_)
         try:
-            out, st = fast.greedy_run(ti, model_info, h, int(cap_rows), flat, [N, A, self.E, self.Dn], [DG_MAX_ROWS, hung_max])
+            out, st = fast.greedy_run(ti, model_info, h, int(cap_rows), flat, [N, A, self.E, self.Dn],
+                                      [DG_MAX_ROWS, hung_max, 1 if _TRACK_EARLY_FRONT else 0])
         except RuntimeError:
             # a C entry point refused its arguments before launching anything that changes the graph: rows [0, N) and the
             # counters are as they were (the appended block sits beyond N and the grown index form in its own arena)
