@@ -186,11 +186,20 @@ __device__ __forceinline__ void d_graph_from_coo(int N, const int64_t* __restric
                 __builtin_amdgcn_wave_barrier();
                 continue;
             }
+            // (the run's keys four per 16-byte read where the run allows it: every lane reads the same words, and one read per key
+            //  made this placement -- L reads for each of L lanes -- the longest phase of the conversion for BDD-sized dets)
+            const int* const run = s_inc + base;
+            const int head = min(L, (int)((16u - ((unsigned)(size_t)run & 15u)) & 15u) >> 2);
             for (int i = lane; i < L; i += 64) {
-                const int key = s_inc[base + i];
+                const int key = run[i];
                 const int row = key & 0x7fffffff;
-                int rank = 0;
-                for (int j = 0; j < L; ++j) rank += ((s_inc[base + j] & 0x7fffffff) < row) ? 1 : 0;
+                int rank = 0, j = 0;
+                for (; j < head; ++j) rank += ((run[j] & 0x7fffffff) < row) ? 1 : 0;
+                for (; j + 4 <= L; j += 4) {
+                    const int4 k4 = *reinterpret_cast<const int4*>(run + j);
+                    rank += ((k4.x & 0x7fffffff) < row) + ((k4.y & 0x7fffffff) < row) + ((k4.z & 0x7fffffff) < row) + ((k4.w & 0x7fffffff) < row);
+                }
+                for (; j < L; ++j) rank += ((run[j] & 0x7fffffff) < row) ? 1 : 0;
                 g.inc[base + rank] = key;
             }
         }

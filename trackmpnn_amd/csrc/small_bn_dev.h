@@ -44,12 +44,15 @@ struct BnFwdArgs {
 struct BnSrcGraph {
     const uint8_t* is_edge; int N_old; const float* x; int ld_x;
     static constexpr bool kCheckEdgeRows = true;
+    static constexpr bool kBlockLayout = false;
     __device__ __forceinline__ bool edge(int i) const { return is_edge[N_old + i] != 0; }
     __device__ __forceinline__ const float* row(int i) const { return x + (size_t)i * ld_x; }
 };
 struct BnSrcBlock {
     int ne; const int32_t* ids; const float* X; int ld_x;
     static constexpr bool kCheckEdgeRows = false;
+    static constexpr bool kBlockLayout = true;      // edge rows first, then the dets: no scan for the det list, and the caller zeroes
+                                                    // the edge rows of h itself (k_track_extend_tf: its otherwise idle threads)
     __device__ __forceinline__ bool edge(int i) const { return i < ne; }
     __device__ __forceinline__ const float* row(int i) const { return X + (size_t)ids[i - ne] * ld_x; }
 };
@@ -73,7 +76,12 @@ __device__ __forceinline__ void d_small_bn_fwd(const BnFwdArgs& a, const int gi,
     int* newdet = a.newdet + (size_t)gi * (n + 1);
 
     // ---- compact list of the new det rows (ascending); every group's block builds its own copy
-    {
+    if constexpr (SRC::kBlockLayout) {
+        const int nd_ = n - src.ne;
+        for (int i = tid; i < nd_; i += 256) newdet[i] = src.ne + i;
+        if (tid == 0) s_wsum[4] = nd_;
+        __syncthreads();
+    } else {
         const int IT = (n + 255) / 256;
         const int i0 = tid * IT, i1 = min(n, i0 + IT);
         int cnt = 0;
@@ -105,7 +113,7 @@ __device__ __forceinline__ void d_small_bn_fwd(const BnFwdArgs& a, const int gi,
         if (bad) atomicOr(&a.g.meta[2], 64);
     }
     // new edge rows start at zero (track_mpnn.py:61); new det rows are written below
-    for (int idx = tid; idx < n * (H / 4); idx += 256) {
+    for (int idx = tid; !SRC::kBlockLayout && idx < n * (H / 4); idx += 256) {
         const int i = idx / (H / 4), c4 = idx % (H / 4);
         if (src.edge(i))
             *reinterpret_cast<float4*>(a.h + (size_t)(N_old + i) * GH + gi * H + 4 * c4) = make_float4(0.f, 0.f, 0.f, 0.f);

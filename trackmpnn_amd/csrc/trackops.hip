@@ -675,8 +675,18 @@ __global__ __launch_bounds__(GC_THREADS) void k_track_extend_tf(ExtendArgs e, tm
         __syncthreads();
         d_graph_from_coo<true, false>(Nt, nullptr, nullptr, 0L, nullptr, nullptr, 0L, e.r.is_edge, e.r.src, e.r.dst, g, nullptr);
     } else {
-        if (threadIdx.x >= 256) return;       // (the transform is written for 256 threads; ended waves leave the block's barriers)
-        d_small_bn_fwd<H>(b, (int)blockIdx.x - 1, BnSrcBlock{A * e.D, src.ids, src.X, src.ld_x}, Nt, n);
+        const int gi = (int)blockIdx.x - 1;
+        if (threadIdx.x >= 256) {
+            // the transform is written for 256 threads; the other 768 write the zeros of the A*D new edge rows of this group's
+            // columns (track_mpnn.py:61; ~50 stores per thread of the transform at a BDD-sized block) and leave: ended waves drop
+            // out of the block's barriers
+            const int GH = b.P.G * H, lpr = H / 4;
+            const long total = (long)A * e.D * lpr;
+            for (long i = threadIdx.x - 256; i < total; i += GC_THREADS - 256)
+                *reinterpret_cast<float4*>(b.h + (size_t)(N + i / lpr) * GH + gi * H + 4 * (i % lpr)) = make_float4(0.f, 0.f, 0.f, 0.f);
+            return;
+        }
+        d_small_bn_fwd<H>(b, gi, BnSrcBlock{A * e.D, src.ids, src.X, src.ld_x}, Nt, n);
     }
 }
 
