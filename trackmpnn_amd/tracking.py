@@ -80,8 +80,12 @@ class TrackGraph:
         # the mirror of `small` a retire launch writes for the host: [0..3] the counters, [4] the flag (pinned, device-mapped)
         # (taken from a process-wide free list and handed back when this graph goes away: the loops make one TrackGraph per
         #  sequence, and pinning fresh host memory means a page-table update on the device under whatever kernel is running)
-        self._notify = (_NOTIFY_POOL.pop() if _NOTIFY_POOL else torch.zeros(8, dtype=torch.int32).pin_memory()) \
-            if (_TRACK_NOTIFY and self.device.type == 'cuda') else None
+        self._notify = None
+        if _TRACK_NOTIFY and self.device.type == 'cuda':
+            try:
+                self._notify = _NOTIFY_POOL.pop() if _NOTIFY_POOL else torch.zeros(8, dtype=torch.int32).pin_memory()
+            except (RuntimeError, IndexError):      # (no pinned memory to be had: the counters are copied back instead)
+                self._notify = None
         self._notify_np = None if self._notify is None else self._notify.numpy()
         self.track: Optional[torch.Tensor] = None        # int32 [ND] track id of every detection (training labels)
         self._graph: Optional[DeviceGraph] = None        # index form of the rows; None: stale (re-derived on first use)
