@@ -651,14 +651,19 @@ int tmpnn_track_extend(int N, int A, int D, const int32_t* active, const int32_t
  * counts (or NULL): the `small` words of the tmpnn_track_retire call in front of this one on the stream.  The launch then takes
  * N = counts[0] and A = counts[3] ON THE DEVICE and the arguments N / A (and g_new's binding, h, save) are upper bounds the buffers
  * were sized with: the caller enqueues the timestep's first launch without waiting for the previous decode's counters, reads them
- * while it runs, and re-binds g_new's arena (same capacity) with the exact row count for the calls that follow. */
+ * while it runs, and re-binds g_new's arena (same capacity) with the exact row count for the calls that follow.
+ * gather_src / ld_gather / gather_keep (with counts; or NULL): that decode was called with h_new = NULL, i.e. it left the kept
+ * rows' state where it was; further blocks of this launch move it -- h[q][0:G*H] = gather_src[gather_keep[q]][0:G*H] for
+ * q < counts[0] -- beside the append and the transform (which touch rows >= N only). */
 int tmpnn_track_extend_tf(int N, int A, int D, const int32_t* active, const int32_t* new_ids, int t, const int32_t* track,
                           const tmpnn_track_rows* rows, const float* X, int ld_x, const tmpnn_mp_params* P, float* h,
-                          float* save, size_t save_floats, const tmpnn_dgraph* g_new, const int32_t* counts, tmpnn_stream stream);
+                          float* save, size_t save_floats, const tmpnn_dgraph* g_new, const int32_t* counts,
+                          const float* gather_src, int ld_gather, const int32_t* gather_keep, tmpnn_stream stream);
 /* decode_tracks (:431-520): associations from the scores (associate = 1: the greedy rule; 2: optimal assignment per timestep as
  * tmpnn_track_select_ws, graphs of <= TMPNN_DG_MAX_ROWS rows, its cost scratch = fin_ws / fin_ws_bytes, overflow in bit 1 of
  * small[1]; 0: rows->assoc holds them already, e.g. from a matching on the host), track finalisation, row deletion into rows_out, the state rows and scores compacted (h_new [N][ld_hn],
- * s_new [N]; small[0] / small[2] = kept rows / kept det rows).  next_t >= 0: also the active set of timestep next_t on
+ * s_new [N]; small[0] / small[2] = kept rows / kept det rows; h_new = NULL on graphs of <= TMPNN_DG_MAX_ROWS rows: the kept rows'
+ * state is NOT moved -- `keep` lists the rows, the caller moves them, e.g. tmpnn_track_extend_tf's gather_* arguments).  next_t >= 0: also the active set of timestep next_t on
  * the compacted rows by the inference rule -> active[], small[3]; the caller then reads small once per timestep instead of twice.
  * Greedy associations carry over (deletion removes no future edge of a kept det); with associate = 2 the next update_graph would
  * re-derive them by its own assignment sweep over the compacted graph (a det that was assigned and deleted frees its column), so

@@ -193,7 +193,7 @@ _SIGNATURES = {
     'tmpnn_track_extend': (c_int, [c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, _TRP, c_void_p, c_int, c_int,
                                    c_void_p, c_int, _DGP, c_void_p, c_size_t, c_void_p]),
     'tmpnn_track_extend_tf': (c_int, [c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, _TRP, c_void_p, c_int, c_void_p,
-                                      c_void_p, c_void_p, c_size_t, _DGP, c_void_p, c_void_p]),
+                                      c_void_p, c_void_p, c_size_t, _DGP, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
     'tmpnn_track_retire': (c_int, [_DGP, _TRP, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_size_t,
                                    c_void_p, c_void_p, _TRP, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_int,
                                    c_void_p, c_void_p, c_void_p]),

@@ -663,11 +663,25 @@ struct ExtendArgs {
 // counts (or NULL): the `small` words of the decode launch in front of this one on the stream -- N = counts[0] (the rows it kept)
 // and A = counts[3] (the active set it derived) are then read HERE, and e.N / e.A / the graph's N / the transform's row counts
 // are only what the host sized the buffers with (upper bounds): the host enqueues this launch without waiting for that decode.
+// gat_* (with counts): the state rows the previous decode kept have NOT been moved yet (tmpnn_track_retire with h_new = NULL): the
+// blocks behind the transform's do it here -- h[q][0:G*H] = gat_src[gat_keep[q]][0:G*H] for q < counts[0] -- beside the append and
+// the transform, neither of which reads or writes those rows (one launch and its ~5 us less per timestep).
 template <int H>
 __global__ __launch_bounds__(GC_THREADS) void k_track_extend_tf(ExtendArgs e, tmpnn_dgraph g, BnFwdArgs b, BnSrcBlock src,
-                                                                const int32_t* __restrict__ counts) {
+                                                                const int32_t* __restrict__ counts,
+                                                                const float* __restrict__ gat_src, int gat_ld,
+                                                                const int32_t* __restrict__ gat_keep) {
     const int N = counts ? counts[0] : e.N, A = counts ? counts[3] : e.A;
     const int n = A * e.D + e.D, Nt = N + n;
+    if ((int)blockIdx.x > b.P.G) {
+        const int GHc = b.P.G * H, lpr = GHc / 4;
+        const long total = (long)N * lpr, stride = (long)(gridDim.x - 1 - b.P.G) * GC_THREADS;
+        for (long i = (long)(blockIdx.x - 1 - b.P.G) * GC_THREADS + threadIdx.x; i < total; i += stride) {
+            const int q = (int)(i / lpr), c = (int)(i % lpr) * 4;
+            *reinterpret_cast<float4*>(b.h + (size_t)q * GHc + c) = *reinterpret_cast<const float4*>(gat_src + (size_t)gat_keep[q] * gat_ld + c);
+        }
+        return;
+    }
     if (blockIdx.x == 0) {
         d_track_append(N, A, e.D, e.active, e.new_ids, e.t, e.track, e.r.ts, e.r.det_id, e.r.assoc, e.r.is_edge, e.r.src,
                        e.r.dst, e.r.labels, nullptr, 0, 0, nullptr, 0, (long)threadIdx.x, (long)GC_THREADS);
@@ -1287,7 +1301,10 @@ int tmpnn_track_extend(int N, int A, int D, const int32_t* active, const int32_t
 int tmpnn_track_extend_tf(int N, int A, int D, const int32_t* active, const int32_t* new_ids, int t, const int32_t* track,
                           const tmpnn_track_rows* rows, const float* X, int ld_x, const tmpnn_mp_params* P, float* h,
                           float* save, size_t save_floats, const tmpnn_dgraph* g_new, const int32_t* counts,
-                          tmpnn_stream stream) {
+                          const float* gather_src, int ld_gather, const int32_t* gather_keep, tmpnn_stream stream) {
+    TM_REQUIRE(gather_src == nullptr || (counts != nullptr && gather_keep != nullptr && P != nullptr && ld_gather >= P->G * P->H &&
+                                         aligned16(gather_src) && (ld_gather & 3) == 0),
+               "track_extend_tf: the deferred state gather needs counts, the kept-row list and an aligned source of >= G*H columns");
     TM_REQUIRE(N >= 0 && A >= 0 && D > 0 && (long)N + (long)A * D + D <= TMPNN_DG_MAX_ROWS,
                "track_extend_tf: N=%d A=%d D=%d exceeds the one-launch form's %d rows", N, A, D, TMPNN_DG_MAX_ROWS);
     TM_REQUIRE(rows_ok(rows) && (A == 0 || active) && new_ids && g_new && P && X && h && save, "track_extend_tf: null pointer");
@@ -1311,12 +1328,16 @@ int tmpnn_track_extend_tf(int N, int A, int D, const int32_t* active, const int3
                 reinterpret_cast<int*>(save + SL.total)};
     BnSrcBlock src{A * D, new_ids, X, ld_x};
     const size_t shm = std::max(sizeof(int) * ((size_t)8 * Nt + 1), sizeof(float) * 64 * (size_t)(H + 1));
+    // (gather blocks: one per 1024 float4 of the rows there may be, at most 32)
+    const int gb = gather_src ? std::min(32, std::max(1, ceil_div((long)N * (G * H / 4), GC_THREADS))) : 0;
     if (H == 64) {
         TM_SHM_ONCE(k_track_extend_tf<64>, sizeof(int) * (8 * TMPNN_DG_MAX_ROWS + 1));
-        hipLaunchKernelGGL(k_track_extend_tf<64>, dim3(1 + G), dim3(GC_THREADS), shm, as_stream(stream), e, *g_new, b, src, counts);
+        hipLaunchKernelGGL(k_track_extend_tf<64>, dim3(1 + G + gb), dim3(GC_THREADS), shm, as_stream(stream), e, *g_new, b, src, counts,
+                           gather_src, ld_gather, gather_keep);
     } else {
         TM_SHM_ONCE(k_track_extend_tf<32>, sizeof(int) * (8 * TMPNN_DG_MAX_ROWS + 1));
-        hipLaunchKernelGGL(k_track_extend_tf<32>, dim3(1 + G), dim3(GC_THREADS), shm, as_stream(stream), e, *g_new, b, src, counts);
+        hipLaunchKernelGGL(k_track_extend_tf<32>, dim3(1 + G + gb), dim3(GC_THREADS), shm, as_stream(stream), e, *g_new, b, src, counts,
+                           gather_src, ld_gather, gather_keep);
     }
     return check_launch("track_extend_tf");
 }
@@ -1338,9 +1359,11 @@ int tmpnn_track_retire(const tmpnn_dgraph* g, const tmpnn_track_rows* rows, cons
         }
         return TMPNN_OK;
     }
-    TM_REQUIRE(rows_ok(rows) && rows_ok(rows_out) && score && keep && h && h_new && s_new, "track_retire: null pointer");
-    TM_REQUIRE(W > 0 && ld_h >= W && ld_hn >= W && aligned16(h) && aligned16(h_new), "track_retire: W=%d ld_h=%d ld_hn=%d", W,
-               ld_h, ld_hn);
+    TM_REQUIRE(rows_ok(rows) && rows_ok(rows_out) && score && keep && s_new && (h_new == nullptr || h), "track_retire: null pointer");
+    TM_REQUIRE(h_new == nullptr || (W > 0 && ld_h >= W && ld_hn >= W && aligned16(h) && aligned16(h_new)),
+               "track_retire: W=%d ld_h=%d ld_hn=%d", W, ld_h, ld_hn);
+    TM_REQUIRE(h_new != nullptr || (g->N > 0 && g->N <= FIN_LDS_DETS), "track_retire: the state gather can be left to the caller "
+               "(h_new = NULL) on graphs of <= %d rows only", FIN_LDS_DETS);
     TM_REQUIRE(next_t < 0 || active, "track_retire: the next timestep's active set needs its buffer");
     const int N = g->N;
     int rc;
@@ -1353,6 +1376,7 @@ int tmpnn_track_retire(const tmpnn_dgraph* g, const tmpnn_track_rows* rows, cons
                            reinterpret_cast<int32_t*>(fin_ws),
                            associate == 2 ? (int)std::min<size_t>(fin_ws_bytes / 4, 1u << 30) : 0, notify);
         if ((rc = check_launch("track_retire"))) return rc;
+        if (h_new == nullptr) return TMPNN_OK;      // (the caller moves the kept rows' state itself: tmpnn_track_extend_tf)
         // the kept rows' state: sized for every row kept, the count read on the device (blocks beyond it leave at once)
         long blocks = ((long)N * ((W + 3) / 4) + 255) / 256;
         if (blocks > 1024) blocks = 1024;

@@ -243,7 +243,8 @@ using retire_fn = int (*)(const tmpnn_dgraph*, const tmpnn_track_rows*, const fl
                           int32_t*, int32_t*, tmpnn_stream);
 using ints_fn = size_t (*)(int);
 using extend_tf_fn = int (*)(int, int, int, const int32_t*, const int32_t*, int, const int32_t*, const tmpnn_track_rows*, const float*,
-                             int, const tmpnn_mp_params*, float*, float*, size_t, const tmpnn_dgraph*, const int32_t*, tmpnn_stream);
+                             int, const tmpnn_mp_params*, float*, float*, size_t, const tmpnn_dgraph*, const int32_t*, const float*, int,
+                             const int32_t*, tmpnn_stream);
 using fwd_parts_fn = int (*)(const tmpnn_mp_params*, const float*, const tmpnn_dgraph*, int, const float*, int, float*, int, float*,
                              float*, float*, float*, size_t, int, tmpnn_stream);
 
@@ -316,8 +317,10 @@ static Driver make_driver(const std::vector<int64_t>& ti, const std::vector<int6
 // storage has the room, else copied).  counts != nullptr (the launch is enqueued BEHIND the previous timestep's decode, before its
 // counters are known): N / A are upper bounds, the launch reads the exact values on the device, and hbuf is the buffer the
 // previous decode compacts the state into (sized by the caller for N + A*D + D rows).
+// gather_src (early fronts only): the decode in front left the kept rows' state in place (h_out of its timestep); this launch moves it.
 static Front launch_front(const Driver& d, int64_t N, int64_t A, int64_t D, int t, const int32_t* new_ids,
-                          const tmpnn_track_rows* rows, const torch::Tensor& h, int64_t cap_rows, const int32_t* counts) {
+                          const tmpnn_track_rows* rows, const torch::Tensor& h, int64_t cap_rows, const int32_t* counts,
+                          const float* gather_src = nullptr) {
     Front f;
     const int64_t n_new = A * D + D, Nt = N + n_new;
     f.cap = Nt;
@@ -338,7 +341,8 @@ static Front launch_front(const Driver& d, int64_t N, int64_t A, int64_t D, int 
     int rc;
     if (d.one_launch) {
         rc = d.f_extend_tf((int)N, (int)A, (int)D, d.active, new_ids, t, d.track, rows, d.X, d.F, d.P, f.h_cat.data_ptr<float>(),
-                           f.save.data_ptr<float>(), nsave, &dg, counts, d.stream);
+                           f.save.data_ptr<float>(), nsave, &dg, counts, gather_src, (int)d.GH, gather_src ? d.keep_rows : nullptr,
+                           d.stream);
         TORCH_CHECK(rc == 0, "tmpnn_track_extend_tf failed (code ", rc, "): ", d.f_err());
     } else {
         TORCH_CHECK(counts == nullptr, "greedy_run: an early front needs the one-launch form");
@@ -354,8 +358,9 @@ static Front launch_front(const Driver& d, int64_t N, int64_t A, int64_t D, int 
 // BACK of a timestep on the exact row counts: the iteration, then decode_tracks + the next timestep's active set; the compacted
 // state lands in `hbuf` ((Nt + spare) rows: room for the next block, whose front may already be enqueued behind this).
 struct Back { torch::Tensor hbuf, h_new, s_new, h_out, logits, scores; };
+// defer_gather: the kept rows' state stays in h_out; the NEXT timestep's (early) front moves it into h_new.
 static Back launch_back(const Driver& d, Front& f, int64_t N, int64_t A, int64_t D, int t_upto, int next_t,
-                        const tmpnn_track_rows* rows_cur, const tmpnn_track_rows* rows_out, int64_t spare) {
+                        const tmpnn_track_rows* rows_cur, const tmpnn_track_rows* rows_out, int64_t spare, bool defer_gather) {
     Back b;
     const int64_t n_new = A * D + D, Nt = N + n_new;
     tmpnn_dgraph dg;
@@ -381,8 +386,8 @@ static Back launch_back(const Driver& d, Front& f, int64_t N, int64_t A, int64_t
     if (d.notify != nullptr) __atomic_store_n(d.notify + 4, 0, __ATOMIC_RELAXED);      // (the mirror's flag: armed per launch)
     rc = d.f_retire(&dg, rows_cur, b.scores.data_ptr<float>(), d.associate, t_upto, d.ret_win, d.y_track, d.ND, d.pos_of_det,
                     d.associate == 2 ? d.hung_ws : nullptr, d.associate == 2 ? d.hung_ws_bytes : 0, d.keep_rows, d.small, rows_out,
-                    b.h_out.data_ptr<float>(), (int)d.GH, (int)d.GH, b.h_new.data_ptr<float>(), (int)d.GH, b.s_new.data_ptr<float>(),
-                    next_t, d.active, d.notify, d.stream);
+                    b.h_out.data_ptr<float>(), (int)d.GH, (int)d.GH, defer_gather ? nullptr : b.h_new.data_ptr<float>(), (int)d.GH,
+                    b.s_new.data_ptr<float>(), next_t, d.active, d.notify, d.stream);
     TORCH_CHECK(rc == 0, "tmpnn_track_retire failed (code ", rc, "): ", d.f_err());
     return b;
 }
@@ -454,20 +459,17 @@ std::tuple<std::vector<torch::Tensor>, std::vector<int64_t>> greedy_run(std::vec
         try {
             if (!front.valid)
                 front = launch_front(d, N, A, D, t, reinterpret_cast<const int32_t*>(steps[5 * k + 3]), rows_cur, h, cap_rows, nullptr);
-            back = launch_back(d, front, N, A, D, t_upto, next_t, rows_cur, rows_out, spare);
+            back = launch_back(d, front, N, A, D, t_upto, next_t, rows_cur, rows_out, spare, early_next);
         } catch (const c10::Error&) {
             if (done == 0) throw;                  // (nothing changed yet: the caller sees the refusal itself)
             break;                                  // the caller's next call meets it as its first step
         }
         Front next_front;
-        if (early_next) {
-            try {
-                next_front = launch_front(d, N_ub, A_ub, D2, (int)steps[5 * (k + 1)], reinterpret_cast<const int32_t*>(steps[5 * (k + 1) + 3]),
-                                          rows_out, back.h_new, Nt + spare, d.small);
-            } catch (const c10::Error&) {
-                next_front = Front();               // (refused before anything was launched: that timestep takes the ordinary way)
-            }
-        }
+        if (early_next)
+            // (it also moves this timestep's kept state rows, which the decode above left in place: a refusal here -- its arguments
+            //  are those of every other front -- leaves the state incomplete and is an error, not a fallback)
+            next_front = launch_front(d, N_ub, A_ub, D2, (int)steps[5 * (k + 1)], reinterpret_cast<const int32_t*>(steps[5 * (k + 1) + 3]),
+                                      rows_out, back.h_new, Nt + spare, d.small, back.h_out.data_ptr<float>());
         counts = read_counts(d);
         const int32_t* c = counts.data_ptr<int32_t>();
         edges += E + A * D;
