@@ -155,9 +155,11 @@ per sweep), same box, same sequences:
         f.write('''
 Round 5 on the same sequences: greedy 0.097 / 0.110 / 0.121, Hungarian on the device 0.150 / 0.308 / 0.242.  What changed (DESIGN.md
 section 7, item 4): the retire launch mirrors its counters into pinned host memory and the host polls a flag there (no copy-back);
-block append + index form + the model call's input transform in one launch (`k_track_extend_tf`); greedy association a wave per det;
-the counters published before the finalisation walk; the second Hungarian sweep of a launch reuses the first's outcome per unchanged
-problem; models without TP classifier (README.md:52-67) ride the native timestep.
+block append + index form + the model call's input transform in one launch (`k_track_extend_tf`), enqueued before the previous decode's
+counters are read and moving that decode's kept state rows as well; greedy association a DPP row per det; the finalisation walk by
+pointer doubling; the counters published before that walk; the fused iteration's det tiles summing their incident rows as
+straight-line loads; steady-state timesteps back to back inside the native driver; the second Hungarian sweep of a launch reuses the
+first's outcome per unchanged problem; models without TP classifier (README.md:52-67) ride the native timestep.
 ''')
         f.write('\nTrain chunk (`train.py:54-135`), ms per chunk: ' + ', '.join(f"{c} {dev['train'][c]['ms_per_chunk']:.2f}" for c in ('C2', 'C3', 'C4')) + '\n')
         if os.path.exists(f'{ld}/slowest.txt'):
@@ -210,9 +212,10 @@ kernels (the host thread or the queue losing its slot on a shared box is what fi
 ## Where a C2 timestep goes (`tools/greedy_trace.py`: the inference loop of the C2 sequence alone, 50 sequences back to back)
 
 Wall time per timestep (un-profiled run) against the GPU kernel time per timestep (`rocprofv3 --kernel-trace` of the same command):
-four launches per steady-state timestep (`k_track_extend_tf`, `k_small_iter_fwd`, `k_track_retire`, `k_track_gather`) whose lengths
-are the latency of their dependent memory round trips (every kernel starts on a cold L2); the host's part -- polling the counters'
-flag, sizing and issuing the next timestep's first launch -- is the rest.  The Hungarian loop is bound by the retire launch's two
+three launches per steady-state timestep (`k_track_extend_tf` -- enqueued behind the previous decode before its counters are read, it
+also moves that decode's kept state rows --, `k_small_iter_fwd`, `k_track_retire`) whose lengths are the latency of their dependent
+memory round trips (every kernel starts on a cold L2); the rest is dispatch gaps and the host's part (polling the counters' flag,
+sizing and issuing the iteration and the decode).  The Hungarian loop is bound by the retire launch's two
 assignment sweeps (the solver itself, one wave, ~6 us per problem, a timestep's problems one after another: the rows of problem t
 are the dets still unassociated after the problems before it).
 
