@@ -728,6 +728,44 @@ __device__ __forceinline__ void d_track_delete(int N, const int32_t* __restrict_
     const int tid = threadIdx.x;
     if (tid == 0) { s_max = 0; s_dets = 0; }
     __syncthreads();
+    if (N <= TK_THREADS) {
+        // a row per thread (the windows of the reference's loops): everything the phase reads of its row is requested up front and
+        // kept -- the general form below reads the rows three times (max_id, the verdicts, the copy), a round trip each (round 6)
+        const int r = tid;
+        const bool in = r < N;
+        const int rc = in ? r : 0;
+        const int t = ts[rc], di = det_id[rc], a = assoc[rc], sr = row_src[rc], dr = row_dst[rc];
+        const float sc = score[rc];
+        const bool e = is_edge[rc] != 0;
+        const uint8_t lb = labels ? labels[rc] : (uint8_t)0;
+        atomicMax(&s_max, (in && t != -1 && t < t_upto) ? r + 1 : 0);
+        __syncthreads();
+        const int max_id = s_max;
+        bool k = false;
+        if (in) {
+            if (r < max_id) k = !e && a == -1 && sc >= 0.5f && t >= t_upto - ret_win;
+            else if (!e || sr >= max_id) k = true;
+            else {                                              // an edge at or after max_id: dropped with its start det
+                const int a2 = assoc[sr], t2 = ts[sr];
+                const float s2 = score[sr];
+                k = a2 == -1 && s2 >= 0.5f && t2 >= t_upto - ret_win;
+            }
+        }
+        if (k && !e) atomicAdd(&s_dets, 1);
+        int total;
+        const int p = tk_block_scan(k ? 1 : 0, s_wave, &total);
+        if (in) s_new[r] = k ? p : -1;
+        if (k) keep[p] = r;
+        __syncthreads();
+        if (k) {
+            o_ts[p] = t; o_det_id[p] = di; o_assoc[p] = a; o_is_edge[p] = e ? 1 : 0;
+            if (o_labels) o_labels[p] = lb;
+            o_src[p] = e ? s_new[sr] : -1;
+            o_dst[p] = e ? s_new[dr] : -1;
+        }
+        if (tid == 0) { count[0] = total; count[2] = s_dets; }
+        return;
+    }
     int m = 0;
     for (int r = tid; r < N; r += TK_THREADS) { const int v = ts[r]; if (v != -1 && v < t_upto) m = max(m, r + 1); }
     atomicMax(&s_max, m);
